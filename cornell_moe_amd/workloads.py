@@ -1,0 +1,71 @@
+"""Synthetic GP / acquisition workloads: the named BASELINE.json configurations.
+
+All FP64.  One ``numpy.random.default_rng(seed)`` per configuration; X ~ U[0,1]^d, y = sum_k sin(3 x_k) + 0.1 U[0,1]
+(plus the analytic partials 3 cos(3 x_k) for observed derivative dims), Matern-5/2 with alpha = 1, l_k = 0.7,
+noise 0.01, domain [0,1]^d, inner GD parameters = examples/main.py:123-130 of the reference.
+"""
+import numpy as np
+
+INNER_GD = (1, 6, 1, 3, 0.0, 1.0, 0.1, 1.0e-10)  # examples/main.py:123-130
+
+CONFIGS = {
+    # name: (seed, n, d, q, M, P, derivs)
+    "C1": dict(seed=1001, n=200, d=2, q=1, M=0, P=0, derivs=()),
+    "C2": dict(seed=1002, n=500, d=4, q=2, M=1000, P=10, derivs=()),
+    "C3": dict(seed=1003, n=1000, d=8, q=4, M=10000, P=10, derivs=()),
+    "C4": dict(seed=1004, n=1000, d=8, q=4, M=10000, P=10, derivs=()),
+    "C5": dict(seed=1005, n=2000, d=12, q=8, M=20000, P=50, derivs=(0, 1, 2)),
+}
+
+
+class Workload(object):
+    pass
+
+
+def make_workload(name=None, seed=None, n=None, d=None, q=None, M=None, P=None, derivs=None, num_restarts=1, p=0):
+    """Build a synthetic workload; keyword arguments override the named configuration's entries."""
+    cfg = dict(CONFIGS[name]) if name else dict(seed=0, n=0, d=0, q=1, M=0, P=0, derivs=())
+    for k, v in (("seed", seed), ("n", n), ("d", d), ("q", q), ("M", M), ("P", P), ("derivs", derivs)):
+        if v is not None:
+            cfg[k] = v
+    rng = np.random.default_rng(cfg["seed"])
+    n, d, q, M, P = cfg["n"], cfg["d"], cfg["q"], cfg["M"], cfg["P"]
+    derivs = tuple(int(v) for v in cfg["derivs"])
+    g = len(derivs)
+    w = Workload()
+    w.name, w.n, w.d, w.q, w.p, w.M, w.P, w.derivs, w.g = name, n, d, q, p, M, P, derivs, g
+    w.X = rng.uniform(0.0, 1.0, size=(n, d))
+    y = np.sin(3.0 * w.X).sum(axis=1) + 0.1 * rng.uniform(0.0, 1.0, size=n)
+    w.y = np.zeros((n, 1 + g))
+    w.y[:, 0] = y
+    for a, dd in enumerate(derivs):
+        w.y[:, 1 + a] = 3.0 * np.cos(3.0 * w.X[:, dd])
+    w.alpha = 1.0
+    w.lengths = np.full(d, 0.7)
+    w.hyperparameters = np.concatenate([[w.alpha], w.lengths])
+    w.noise = np.full(1 + g, 0.01)
+    w.bounds = np.tile(np.array([0.0, 1.0]), d)
+    w.Xq = rng.uniform(0.0, 1.0, size=(q, d))
+    w.Xp = rng.uniform(0.0, 1.0, size=(p, d))
+    w.discrete = rng.uniform(0.0, 1.0, size=(P, d))
+    w.query = rng.uniform(0.0, 1.0, size=(100, d))
+    m = (q + p) * (1 + g)
+    w.m = m
+    # KG: antithetic table Z[ceil(M/2)][m]; EI: table Z[M][q+p] (drawn after, so KG tables do not depend on it)
+    w.kg_normals = rng.standard_normal(size=((M + 1) // 2, m))
+    w.ei_normals = rng.standard_normal(size=(M, q + p))
+    # extra restarts (C4): independent points_to_sample sets
+    w.Xq_restarts = rng.uniform(0.0, 1.0, size=(num_restarts, q, d))
+    w.Xq_restarts[0] = w.Xq
+    w.inner_gd = INNER_GD
+    return w
+
+
+def kg_normals_full(w):
+    """Expand the antithetic table to the [M][m] array the device consumes: row 2j = Z[j], row 2j+1 = -Z[j]
+    (gpp_knowledge_gradient_optimization.cpp:171-180)."""
+    Z = w.kg_normals
+    full = np.empty((2 * Z.shape[0], Z.shape[1]))
+    full[0::2] = Z
+    full[1::2] = -Z
+    return full[: w.M]

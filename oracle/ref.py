@@ -1,0 +1,267 @@
+"""ctypes binding of oracle/_ref/libmoe_ref.so -- TEST INFRASTRUCTURE ONLY.
+
+The library is the unmodified reference C++ core (compiled in place by oracle/Makefile) behind oracle/ref_harness.cpp.
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_PATH = os.path.join(_HERE, "_ref", "libmoe_ref.so")
+
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int)
+
+
+def available():
+    return os.path.exists(_PATH)
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not available():
+            raise RuntimeError("oracle/_ref/libmoe_ref.so not built (run `make -C oracle ref` where /root/reference exists)")
+        _lib = C.CDLL(_PATH)
+        _lib.ref_last_error.restype = C.c_char_p
+        _lib.ref_gp_create.restype = C.c_void_p
+        _lib.ref_gp_create.argtypes = [C.c_int, C.c_double, _dp, _dp, _dp, _dp, _ip, C.c_int, C.c_int, C.c_int]
+        _lib.ref_gp_destroy.argtypes = [C.c_void_p]
+        _lib.ref_gp_num_sampled.argtypes = [C.c_void_p]
+        _lib.ref_gp_add_points.argtypes = [C.c_void_p, _dp, _dp, C.c_int]
+        _lib.ref_gp_dump.argtypes = [C.c_void_p, _dp, _dp, _dp]
+        _lib.ref_gp_mix_cov.argtypes = [C.c_void_p, _dp, C.c_int, _ip, C.c_int, _dp]
+        _lib.ref_gp_mean.argtypes = [C.c_void_p, _dp, C.c_int, _dp]
+        _lib.ref_gp_additional_mean.argtypes = [C.c_void_p, _dp, C.c_int, _ip, C.c_int, _dp]
+        _lib.ref_gp_grad_mean.argtypes = [C.c_void_p, _dp, C.c_int, _dp]
+        _lib.ref_gp_var.argtypes = [C.c_void_p, _dp, C.c_int, _dp]
+        _lib.ref_gp_chol_var.argtypes = [C.c_void_p, _dp, C.c_int, _dp]
+        _lib.ref_gp_grad_var.argtypes = [C.c_void_p, _dp, C.c_int, C.c_int, _dp]
+        _lib.ref_gp_grad_chol_var.argtypes = [C.c_void_p, _dp, C.c_int, C.c_int, _dp]
+        _lib.ref_posterior_mean.argtypes = [C.c_void_p, C.c_int, _dp, _dp, _dp]
+        _lib.ref_covariance.argtypes = [C.c_int, C.c_int, C.c_double, _dp, _dp, _ip, C.c_int, _dp, _ip, C.c_int, _dp, _dp]
+        _lib.ref_cholesky.argtypes = [C.c_int, _dp]
+        _lib.ref_chol_solve.argtypes = [_dp, C.c_int, _dp]
+        _lib.ref_tri_solve.argtypes = [_dp, C.c_char, C.c_int, _dp]
+        _lib.ref_ei.argtypes = [C.c_void_p, _dp, _dp, C.c_int, C.c_int, C.c_int, C.c_double, _dp, _dp, _dp, _dp]
+        _lib.ref_kg.argtypes = [C.c_void_p, C.c_int, _dp, _dp, _dp, C.c_int, _dp, _dp, C.c_int, C.c_int, C.c_int,
+                                C.c_double, _dp, C.c_long, C.c_int, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp]
+        _lib.ref_kg_grad_batch.argtypes = [C.c_void_p, C.c_int, _dp, _dp, _dp, C.c_int, _dp, C.c_int, C.c_int, C.c_int,
+                                           C.c_double, _dp, C.c_long, C.c_int, _dp, _dp, _dp]
+    return _lib
+
+
+def _d(a):
+    """contiguous float64 array + its pointer (None -> NULL)."""
+    if a is None:
+        return None, None
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    return a, a.ctypes.data_as(_dp)
+
+
+def _i(a):
+    if a is None or len(a) == 0:
+        return None, None
+    a = np.ascontiguousarray(a, dtype=np.int32)
+    return a, a.ctypes.data_as(_ip)
+
+
+class RefError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("reference error %d: %s" % (code, msg))
+        self.code = code
+
+
+def _check(rc):
+    if rc != 0:
+        raise RefError(rc, lib().ref_last_error().decode("utf-8", "replace"))
+
+
+def covariance(cov_type, alpha, lengths, p1, d1, p2, d2):
+    """(cov[(1+g1),(1+g2)] col-major flat, grad_cov[d,(1+g1),(1+g2)] flat) from the reference covariance classes."""
+    L = lib()
+    dim = len(p1)
+    g1, g2 = len(d1), len(d2)
+    cov = np.zeros((1 + g1) * (1 + g2))
+    gcov = np.zeros(dim * (1 + g1) * (1 + g2))
+    l_, lp = _d(lengths)
+    a1, p1p = _d(p1)
+    a2, p2p = _d(p2)
+    i1, d1p = _i(d1)
+    i2, d2p = _i(d2)
+    _check(L.ref_covariance(cov_type, dim, alpha, lp, p1p, d1p, g1, p2p, d2p, g2, cov.ctypes.data_as(_dp),
+                            gcov.ctypes.data_as(_dp)))
+    return cov, gcov
+
+
+def cholesky(a):
+    a = np.array(a, dtype=np.float64, order="F")
+    n = a.shape[0]
+    flat = np.ascontiguousarray(a.T).ravel().copy()  # col-major flat
+    rc = lib().ref_cholesky(n, flat.ctypes.data_as(_dp))
+    return rc, flat.reshape(n, n).T.copy()
+
+
+class RefGP(object):
+    """The reference GaussianProcess (gpp_math.hpp:275-868) behind the harness."""
+
+    def __init__(self, cov_type, alpha, lengths, X, y, noise, derivs):
+        L = lib()
+        X = np.ascontiguousarray(X, dtype=np.float64)
+        self.n, self.d = X.shape
+        self.derivs = [int(v) for v in derivs]
+        self.g = len(self.derivs)
+        self.N = self.n * (1 + self.g)
+        self.keep = [X, _d(y)[0], _d(noise)[0], _d(lengths)[0], _i(self.derivs)[0]]
+        dp = self.keep[4].ctypes.data_as(_ip) if self.keep[4] is not None else None
+        self.h = L.ref_gp_create(cov_type, alpha, self.keep[3].ctypes.data_as(_dp), X.ctypes.data_as(_dp),
+                                 self.keep[1].ctypes.data_as(_dp), self.keep[2].ctypes.data_as(_dp), dp, self.g, self.d,
+                                 self.n)
+        if not self.h:
+            raise RefError(4, L.ref_last_error().decode("utf-8", "replace"))
+
+    def __del__(self):
+        try:
+            if getattr(self, "h", None):
+                lib().ref_gp_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    def dump(self):
+        K = np.zeros(self.N * self.N)
+        kiy = np.zeros(self.N)
+        mean = C.c_double(0.0)
+        lib().ref_gp_dump(self.h, K.ctypes.data_as(_dp), kiy.ctypes.data_as(_dp), C.byref(mean))
+        return K.reshape(self.N, self.N).T.copy(), kiy, mean.value  # K_chol as [row, col]
+
+    def add_points(self, pts, vals):
+        pts, pp = _d(pts)
+        vals, vp = _d(vals)
+        k = pts.reshape(-1, self.d).shape[0]
+        _check(lib().ref_gp_add_points(self.h, pp, vp, k))
+        self.n += k
+        self.N = self.n * (1 + self.g)
+
+    def mix_cov(self, pts, derivs2=()):
+        pts, pp = _d(pts)
+        k = pts.reshape(-1, self.d).shape[0]
+        i2, d2p = _i(list(derivs2))
+        g2 = len(derivs2)
+        out = np.zeros(self.N * k * (1 + g2))
+        lib().ref_gp_mix_cov(self.h, pp, k, d2p, g2, out.ctypes.data_as(_dp))
+        return out.reshape(k * (1 + g2), self.N).T.copy()  # [row=N, col]
+
+    def _q(self, fn, pts, size, *extra):
+        pts, pp = _d(pts)
+        k = pts.reshape(-1, self.d).shape[0]
+        out = np.zeros(size(k))
+        _check(fn(self.h, pp, k, *extra, out.ctypes.data_as(_dp)))
+        return out
+
+    def mean(self, pts):
+        return self._q(lib().ref_gp_mean, pts, lambda k: k)
+
+    def additional_mean(self, pts, derivs2=()):
+        i2, d2p = _i(list(derivs2))
+        g2 = len(derivs2)
+        return self._q(lib().ref_gp_additional_mean, pts, lambda k: k * (1 + g2), d2p, g2)
+
+    def grad_mean(self, pts):
+        return self._q(lib().ref_gp_grad_mean, pts, lambda k: self.d * k * (1 + self.g))
+
+    def var(self, pts):
+        return self._q(lib().ref_gp_var, pts, lambda k: (k * (1 + self.g)) ** 2)
+
+    def chol_var(self, pts):
+        return self._q(lib().ref_gp_chol_var, pts, lambda k: (k * (1 + self.g)) ** 2)
+
+    def grad_var(self, pts, nd):
+        return self._q(lib().ref_gp_grad_var, pts, lambda k: self.d * (k * (1 + self.g)) ** 2 * nd, nd)
+
+    def grad_chol_var(self, pts, nd):
+        return self._q(lib().ref_gp_grad_chol_var, pts, lambda k: self.d * (k * (1 + self.g)) ** 2 * nd, nd)
+
+    def posterior_mean(self, pt, num_fidelity=0):
+        pt, pp = _d(pt)
+        val = C.c_double(0.0)
+        grad = np.zeros(self.d - num_fidelity)
+        _check(lib().ref_posterior_mean(self.h, num_fidelity, pp, C.byref(val), grad.ctypes.data_as(_dp)))
+        return val.value, grad
+
+    def ei(self, Xq, Xp, M, best_so_far, normals, want_grad=True):
+        Xq, qp = _d(Xq)
+        q = Xq.reshape(-1, self.d).shape[0]
+        if Xp is None or len(Xp) == 0:
+            p, Xp_, pp = 0, None, None
+        else:
+            Xp_, pp = _d(Xp)
+            p = Xp_.reshape(-1, self.d).shape[0]
+        normals, npp = _d(normals)
+        assert normals.size >= M * (q + p)
+        ei = C.c_double(0.0)
+        sec = C.c_double(0.0)
+        grad = np.zeros(q * self.d) if want_grad else None
+        _check(lib().ref_ei(self.h, qp, pp, q, p, M, best_so_far, npp, C.byref(ei),
+                            grad.ctypes.data_as(_dp) if want_grad else None, C.byref(sec)))
+        return ei.value, (grad.reshape(q, self.d) if want_grad else None), sec.value
+
+    def kg(self, gd, bounds, discrete, Xq, Xp, M, best_so_far, normals, want_grad=True, num_fidelity=0, details=False):
+        """Returns dict(kg, grad[q,d], best_point[M,d], seconds=(state, eval), ...)."""
+        gd, gdp = _d(gd)
+        bounds, bp = _d(bounds)
+        discrete, dp = _d(discrete)
+        P = discrete.reshape(-1, self.d - num_fidelity).shape[0]
+        Xq, qp = _d(Xq)
+        q = Xq.reshape(-1, self.d).shape[0]
+        if Xp is None or len(Xp) == 0:
+            p, Xp_, pp = 0, None, None
+        else:
+            Xp_, pp = _d(Xp)
+            p = Xp_.reshape(-1, self.d).shape[0]
+        m = (q + p) * (1 + self.g)
+        normals, npp = _d(normals)
+        assert normals.size >= ((M + 1) // 2) * m, "normal table too small"
+        kg = C.c_double(0.0)
+        grad = np.zeros(q * self.d)
+        best_point = np.zeros(M * self.d)
+        tsm = np.zeros(m)
+        chol = np.zeros(m * m)
+        gchol = np.zeros(self.d * m * m * q)
+        cic = np.zeros(m * M)
+        sec = np.zeros(2)
+        P_ = lambda a: a.ctypes.data_as(_dp)  # noqa: E731
+        _check(lib().ref_kg(self.h, num_fidelity, gdp, bp, dp, P, qp, pp, q, p, M, best_so_far, npp, normals.size,
+                            1 if want_grad else 0, C.byref(kg), P_(grad), P_(best_point), P_(tsm), P_(chol), P_(gchol),
+                            P_(cic), P_(sec)))
+        out = dict(kg=kg.value, grad=grad.reshape(q, self.d) if want_grad else None,
+                   best_point=best_point.reshape(M, self.d), seconds=(sec[0], sec[1]))
+        if details:
+            out.update(to_sample_mean=tsm, chol_var=chol.reshape(m, m).T.copy(), grad_chol=gchol,
+                       chol_inverse_cov=cic.reshape(M, m))
+        return out
+
+    def kg_grad_batch(self, gd, bounds, discrete, Xq_all, M, best_so_far, normals, num_threads, num_fidelity=0):
+        gd, gdp = _d(gd)
+        bounds, bp = _d(bounds)
+        discrete, dp = _d(discrete)
+        P = discrete.reshape(-1, self.d - num_fidelity).shape[0]
+        Xq_all = np.ascontiguousarray(Xq_all, dtype=np.float64)
+        R, q, _ = Xq_all.shape
+        normals, npp = _d(normals)
+        kg = np.zeros(R)
+        grad = np.zeros(R * q * self.d)
+        wall = C.c_double(0.0)
+        _check(lib().ref_kg_grad_batch(self.h, num_fidelity, gdp, bp, dp, P, Xq_all.ctypes.data_as(_dp), R, q, M,
+                                       best_so_far, npp, normals.size, num_threads, kg.ctypes.data_as(_dp),
+                                       grad.ctypes.data_as(_dp), C.byref(wall)))
+        return kg, grad.reshape(R, q, self.d), wall.value
+
+
+def num_procs():
+    return lib().ref_num_procs()
