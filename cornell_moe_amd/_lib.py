@@ -1,0 +1,90 @@
+"""ctypes binding of libmoe_hip.so (include/moe_hip.h).  There is NO fallback: a missing library or a missing GPU raises."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libmoe_hip.so")
+
+dp = C.POINTER(C.c_double)
+ip = C.POINTER(C.c_int)
+
+MOE_OK, MOE_ERR_RUNTIME, MOE_ERR_BOUNDS, MOE_ERR_INVALID_VALUE, MOE_ERR_SINGULAR = 0, 1, 2, 3, 4
+COV_SQUARE_EXPONENTIAL, COV_MATERN_NU_2P5 = 0, 1
+
+
+class MoeError(C.Structure):
+    _fields_ = [("code", C.c_int), ("message", C.c_char * 480), ("payload", C.c_double * 3)]
+
+
+class GdParams(C.Structure):
+    _fields_ = [("num_multistarts", C.c_int), ("max_num_steps", C.c_int), ("max_num_restarts", C.c_int),
+                ("num_steps_averaged", C.c_int), ("gamma", C.c_double), ("pre_mult", C.c_double),
+                ("max_relative_change", C.c_double), ("tolerance", C.c_double)]
+
+
+class KgStats(C.Structure):
+    _fields_ = [("posterior_mean_evals", C.c_longlong), ("posterior_grad_evals", C.c_longlong), ("ms_state", C.c_double),
+                ("ms_mc", C.c_double), ("ms_tail", C.c_double)]
+
+
+# every symbol include/moe_hip.h declares: (restype, argtypes)
+_EP = C.POINTER(MoeError)
+_GP = C.c_void_p
+SIGNATURES = {
+    "moe_version": (C.c_char_p, []),
+    "moe_device_count": (C.c_int, [ip]),
+    "moe_device_arch": (C.c_int, [C.c_int, C.c_char_p, C.c_int]),
+    "moe_gp_create": (C.c_int, [dp, C.c_int, dp, dp, dp, ip, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(_GP), _EP]),
+    "moe_gp_destroy": (C.c_int, [_GP]),
+    "moe_gp_dim": (C.c_int, [_GP]),
+    "moe_gp_num_sampled": (C.c_int, [_GP]),
+    "moe_gp_num_derivatives": (C.c_int, [_GP]),
+    "moe_gp_add_points": (C.c_int, [_GP, dp, dp, C.c_int, _EP]),
+    "moe_gp_get_factor": (C.c_int, [_GP, dp, dp, dp, _EP]),
+    "moe_gp_mean": (C.c_int, [_GP, dp, C.c_int, dp, _EP]),
+    "moe_gp_additional_mean": (C.c_int, [_GP, dp, C.c_int, dp, _EP]),
+    "moe_gp_grad_mean": (C.c_int, [_GP, dp, C.c_int, dp, _EP]),
+    "moe_gp_variance": (C.c_int, [_GP, dp, C.c_int, dp, _EP]),
+    "moe_gp_cholesky_variance": (C.c_int, [_GP, dp, C.c_int, dp, _EP]),
+    "moe_gp_grad_variance": (C.c_int, [_GP, dp, C.c_int, C.c_int, dp, _EP]),
+    "moe_gp_grad_cholesky_variance": (C.c_int, [_GP, dp, C.c_int, C.c_int, dp, _EP]),
+    "moe_posterior_mean": (C.c_int, [_GP, C.c_int, dp, dp, dp, _EP]),
+    "moe_normal_draws": (C.c_int, [C.c_uint, C.c_longlong, dp]),
+    "moe_ei": (C.c_int, [_GP, dp, dp, C.c_int, C.c_int, C.c_int, C.c_double, dp, dp, dp, _EP]),
+    "moe_kg": (C.c_int, [_GP, C.c_int, C.POINTER(GdParams), dp, dp, C.c_int, dp, dp, C.c_int, C.c_int, C.c_int, C.c_double,
+                         dp, C.c_int, C.c_int, C.c_int, dp, dp, dp, C.POINTER(KgStats), _EP]),
+    "moe_kg_batch": (C.c_int, [_GP, C.c_int, C.POINTER(GdParams), dp, dp, C.c_int, dp, C.c_int, dp, C.c_int, C.c_int,
+                               C.c_int, C.c_double, dp, C.c_int, C.c_int, C.c_int, dp, dp, C.POINTER(KgStats), _EP]),
+    "moe_gp_mix_covariance": (C.c_int, [_GP, dp, C.c_int, ip, C.c_int, dp, _EP]),
+    "moe_cov_build_probe": (C.c_int, [_GP, dp, C.c_int, C.c_int, dp, dp, _EP]),
+    "moe_last_kernel_ms": (C.c_int, [_GP, dp]),
+}
+
+_lib = None
+
+
+def load():
+    """Load libmoe_hip.so (building it is __graft_entry__.build()'s / `python -m cornell_moe_amd.build`'s job)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError("%s is missing: run `python -m cornell_moe_amd.build` (needs hipcc); there is no CPU fallback"
+                              % LIB_PATH)
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def device_count():
+    n = C.c_int(0)
+    load().moe_device_count(C.byref(n))
+    return n.value
+
+
+def require_gpu():
+    if device_count() <= 0:
+        raise RuntimeError("libmoe_hip: no HIP device visible and there is no CPU fallback")

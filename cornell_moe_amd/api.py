@@ -1,0 +1,289 @@
+"""numpy-level wrappers over the C ABI (include/moe_hip.h).  Thin: argument marshalling + error mapping only.
+
+Exceptions mirror the reference's Python-visible classes (gpp_python.cpp:71-124, 285-379):
+OptimalLearningException, BoundsException(value, min, max), InvalidValueException(value, truth, tolerance),
+SingularMatrixException(num_rows, leading_minor_index).
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import dp, ip
+
+
+class OptimalLearningException(Exception):
+    pass
+
+
+class BoundsException(OptimalLearningException):
+    def __init__(self, message, value=0.0, min=0.0, max=0.0):  # noqa: A002  (names follow gpp_python.cpp:315-317)
+        super(BoundsException, self).__init__(message)
+        self.value, self.min, self.max = value, min, max
+
+
+class InvalidValueException(OptimalLearningException):
+    def __init__(self, message, value=0.0, truth=0.0, tolerance=0.0):
+        super(InvalidValueException, self).__init__(message)
+        self.value, self.truth, self.tolerance = value, truth, tolerance
+
+
+class SingularMatrixException(OptimalLearningException):
+    def __init__(self, message, num_rows=0, leading_minor_index=0):
+        super(SingularMatrixException, self).__init__(message)
+        self.num_rows, self.leading_minor_index = int(num_rows), int(leading_minor_index)
+
+
+def _raise(err):
+    msg = err.message.decode("utf-8", "replace")
+    p = list(err.payload)
+    if err.code == _lib.MOE_ERR_BOUNDS:
+        raise BoundsException(msg, p[0], p[1], p[2])
+    if err.code == _lib.MOE_ERR_INVALID_VALUE:
+        raise InvalidValueException(msg, p[0], p[1], p[2])
+    if err.code == _lib.MOE_ERR_SINGULAR:
+        raise SingularMatrixException(msg, p[0], p[1])
+    raise OptimalLearningException(msg)
+
+
+def _check(rc, err):
+    if rc != 0:
+        _raise(err)
+
+
+def _d(a):
+    if a is None:
+        return None, None
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    return a, a.ctypes.data_as(dp)
+
+
+def normal_draws(seed, count):
+    out = np.empty(int(count), dtype=np.float64)
+    _lib.load().moe_normal_draws(C.c_uint(int(seed) & 0xFFFFFFFF), int(count), out.ctypes.data_as(dp))
+    return out
+
+
+class DeviceGP(object):
+    """Device-resident GP: handle around moe_gp_t (replaces the reference's C_GP.GaussianProcess object)."""
+
+    def __init__(self, hyperparameters, X, y, noise_variance, derivatives=(), cov_type=_lib.COV_MATERN_NU_2P5, device=0):
+        L = _lib.load()
+        X = np.ascontiguousarray(X, dtype=np.float64)
+        if X.ndim != 2:
+            raise BoundsException("points_sampled must be 2-D [num_sampled][dim]")
+        self.n, self.d = X.shape
+        self.derivatives = [int(v) for v in derivatives]
+        self.g = len(self.derivatives)
+        y = np.ascontiguousarray(y, dtype=np.float64).reshape(self.n, 1 + self.g)
+        hyper, hp = _d(hyperparameters)
+        noise, npn = _d(noise_variance)
+        if hyper.size != 1 + self.d:
+            raise InvalidValueException("hyperparameters must be [alpha, lengths...]", hyper.size, 1 + self.d, 0)
+        if noise.size != 1 + self.g:
+            raise InvalidValueException("noise_variance must have 1 + num_derivatives entries", noise.size, 1 + self.g, 0)
+        dv = np.ascontiguousarray(self.derivatives, dtype=np.int32)
+        self._h = C.c_void_p(None)
+        err = _lib.MoeError()
+        rc = L.moe_gp_create(hp, int(cov_type), X.ctypes.data_as(dp), y.ctypes.data_as(dp), npn,
+                             dv.ctypes.data_as(ip) if self.g else None, self.g, self.d, self.n, int(device),
+                             C.byref(self._h), C.byref(err))
+        _check(rc, err)
+        self.device = device
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            _lib.load().moe_gp_destroy(self._h)
+            self._h = C.c_void_p(None)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- bookkeeping ----
+    @property
+    def N(self):
+        return self.n * (1 + self.g)
+
+    def add_points(self, pts, vals):
+        pts, pp = _d(pts)
+        vals, vp = _d(vals)
+        k = pts.reshape(-1, self.d).shape[0]
+        err = _lib.MoeError()
+        _check(_lib.load().moe_gp_add_points(self._h, pp, vp, k, C.byref(err)), err)
+        self.n += k
+
+    def get_factor(self):
+        N = self.N
+        K = np.zeros(N * N)
+        kiy = np.zeros(N)
+        mean = C.c_double(0.0)
+        err = _lib.MoeError()
+        _check(_lib.load().moe_gp_get_factor(self._h, K.ctypes.data_as(dp), kiy.ctypes.data_as(dp), C.byref(mean),
+                                             C.byref(err)), err)
+        return K.reshape(N, N).T.copy(), kiy, mean.value
+
+    # ---- posterior queries (raw column-major outputs, flat) ----
+    def _q(self, fn, pts, size, *extra):
+        pts, pp = _d(pts)
+        k = pts.reshape(-1, self.d).shape[0]
+        out = np.zeros(size(k))
+        err = _lib.MoeError()
+        _check(fn(self._h, pp, k, *extra, out.ctypes.data_as(dp), C.byref(err)), err)
+        return out
+
+    def mean(self, pts):
+        return self._q(_lib.load().moe_gp_mean, pts, lambda k: k)
+
+    def additional_mean(self, pts):
+        return self._q(_lib.load().moe_gp_additional_mean, pts, lambda k: k)
+
+    def grad_mean(self, pts):
+        return self._q(_lib.load().moe_gp_grad_mean, pts, lambda k: self.d * k * (1 + self.g))
+
+    def variance(self, pts):
+        return self._q(_lib.load().moe_gp_variance, pts, lambda k: (k * (1 + self.g)) ** 2)
+
+    def cholesky_variance(self, pts):
+        return self._q(_lib.load().moe_gp_cholesky_variance, pts, lambda k: (k * (1 + self.g)) ** 2)
+
+    def grad_variance(self, pts, num_derivs):
+        return self._q(_lib.load().moe_gp_grad_variance, pts, lambda k: self.d * (k * (1 + self.g)) ** 2 * num_derivs,
+                       int(num_derivs))
+
+    def grad_cholesky_variance(self, pts, num_derivs):
+        return self._q(_lib.load().moe_gp_grad_cholesky_variance, pts,
+                       lambda k: self.d * (k * (1 + self.g)) ** 2 * num_derivs, int(num_derivs))
+
+    def mix_covariance(self, pts, derivs2=()):
+        pts, pp = _d(pts)
+        k = pts.reshape(-1, self.d).shape[0]
+        g2 = len(derivs2)
+        dv = np.ascontiguousarray(list(derivs2), dtype=np.int32)
+        out = np.zeros(self.N * k * (1 + g2))
+        err = _lib.MoeError()
+        _check(_lib.load().moe_gp_mix_covariance(self._h, pp, k, dv.ctypes.data_as(ip) if g2 else None, g2,
+                                                 out.ctypes.data_as(dp), C.byref(err)), err)
+        return out.reshape(k * (1 + g2), self.N).T.copy()
+
+    def cov_build_probe(self, pts, repeat=10):
+        pts, pp = _d(pts)
+        k = pts.reshape(-1, self.d).shape[0]
+        ms, nbytes = C.c_double(0.0), C.c_double(0.0)
+        err = _lib.MoeError()
+        _check(_lib.load().moe_cov_build_probe(self._h, pp, k, int(repeat), C.byref(ms), C.byref(nbytes), C.byref(err)), err)
+        return ms.value, nbytes.value
+
+    def posterior_mean(self, point, num_fidelity=0, want_grad=True):
+        point, pp = _d(point)
+        val = C.c_double(0.0)
+        grad = np.zeros(self.d - num_fidelity)
+        err = _lib.MoeError()
+        _check(_lib.load().moe_posterior_mean(self._h, int(num_fidelity), pp, C.byref(val),
+                                              grad.ctypes.data_as(dp) if want_grad else None, C.byref(err)), err)
+        return val.value, (grad if want_grad else None)
+
+    # ---- acquisition functions ----
+    def ei(self, Xq, Xp, num_mc, best_so_far, normals, want_grad=True, want_value=True):
+        Xq, qp = _d(Xq)
+        q = Xq.reshape(-1, self.d).shape[0]
+        if Xp is None or np.size(Xp) == 0:
+            p, ppp = 0, None
+        else:
+            Xp, ppp = _d(Xp)
+            p = Xp.reshape(-1, self.d).shape[0]
+        normals, npn = _d(normals)
+        if normals.size < num_mc * (q + p):
+            raise InvalidValueException("normal table too small", normals.size, num_mc * (q + p), 0)
+        ei = C.c_double(0.0)
+        grad = np.zeros(q * self.d)
+        err = _lib.MoeError()
+        _check(_lib.load().moe_ei(self._h, qp, ppp, q, p, int(num_mc), float(best_so_far), npn,
+                                  C.byref(ei) if want_value else None, grad.ctypes.data_as(dp) if want_grad else None,
+                                  C.byref(err)), err)
+        return (ei.value if want_value else None), (grad.reshape(q, self.d) if want_grad else None)
+
+    @staticmethod
+    def _gd(params):
+        if isinstance(params, _lib.GdParams):
+            return params
+        g = _lib.GdParams()
+        (g.num_multistarts, g.max_num_steps, g.max_num_restarts, g.num_steps_averaged) = [int(v) for v in params[:4]]
+        (g.gamma, g.pre_mult, g.max_relative_change, g.tolerance) = [float(v) for v in params[4:8]]
+        return g
+
+    def kg(self, inner_params, bounds, discrete, Xq, Xp, num_mc, best_so_far, normals, want_grad=True, num_fidelity=0,
+           first_sample=0, num_local=None, want_best_points=False):
+        """One KG evaluation (or an even-aligned MC shard of it).  Returns dict(kg_sum, grad_sum, kg, grad, stats, ...);
+        `kg`/`grad` are the normalised values assuming this call covered all num_mc samples."""
+        L = _lib.load()
+        gd = self._gd(inner_params)
+        bounds, bp = _d(bounds)
+        discrete, dpp = _d(discrete)
+        P = discrete.reshape(-1, self.d - num_fidelity).shape[0]
+        Xq, qp = _d(Xq)
+        q = Xq.reshape(-1, self.d).shape[0]
+        if Xp is None or np.size(Xp) == 0:
+            p, ppp = 0, None
+        else:
+            Xp, ppp = _d(Xp)
+            p = Xp.reshape(-1, self.d).shape[0]
+        m = (q + p) * (1 + self.g)
+        normals, npn = _d(normals)
+        if normals.size < ((num_mc + 1) // 2) * m:
+            raise InvalidValueException("normal table too small", normals.size, ((num_mc + 1) // 2) * m, 0)
+        if num_local is None:
+            num_local = num_mc - first_sample
+        kg_sum = C.c_double(0.0)
+        grad = np.zeros(q * self.d)
+        best = np.zeros(num_local * self.d) if want_best_points else None
+        stats = _lib.KgStats()
+        err = _lib.MoeError()
+        rc = L.moe_kg(self._h, int(num_fidelity), C.byref(gd), bp, dpp, P, qp, ppp, q, p, int(num_mc), float(best_so_far),
+                      npn, int(first_sample), int(num_local), 1 if want_grad else 0, C.byref(kg_sum),
+                      grad.ctypes.data_as(dp), best.ctypes.data_as(dp) if want_best_points else None, C.byref(stats),
+                      C.byref(err))
+        _check(rc, err)
+        out = dict(kg_sum=kg_sum.value, grad_sum=grad.reshape(q, self.d) if want_grad else None,
+                   kg=kg_sum.value / num_mc, grad=(grad.reshape(q, self.d) / num_mc) if want_grad else None,
+                   mean_evals=stats.posterior_mean_evals, grad_evals=stats.posterior_grad_evals,
+                   ms_state=stats.ms_state, ms_mc=stats.ms_mc, ms_tail=stats.ms_tail)
+        if want_best_points:
+            out["best_point"] = best.reshape(num_local, self.d)
+        return out
+
+    def kg_batch(self, inner_params, bounds, discrete, Xq_all, Xp, num_mc, best_so_far, normals, want_grad=True,
+                 num_fidelity=0, first_sample=0, num_local=None):
+        L = _lib.load()
+        gd = self._gd(inner_params)
+        bounds, bp = _d(bounds)
+        discrete, dpp = _d(discrete)
+        P = discrete.reshape(-1, self.d - num_fidelity).shape[0]
+        Xq_all = np.ascontiguousarray(Xq_all, dtype=np.float64)
+        R, q, _ = Xq_all.shape
+        if Xp is None or np.size(Xp) == 0:
+            p, ppp = 0, None
+        else:
+            Xp, ppp = _d(Xp)
+            p = Xp.reshape(-1, self.d).shape[0]
+        normals, npn = _d(normals)
+        if num_local is None:
+            num_local = num_mc - first_sample
+        kg_sum = np.zeros(R)
+        grad = np.zeros(R * q * self.d)
+        stats = _lib.KgStats()
+        err = _lib.MoeError()
+        rc = L.moe_kg_batch(self._h, int(num_fidelity), C.byref(gd), bp, dpp, P, Xq_all.ctypes.data_as(dp), R, ppp, q, p,
+                            int(num_mc), float(best_so_far), npn, int(first_sample), int(num_local),
+                            1 if want_grad else 0, kg_sum.ctypes.data_as(dp), grad.ctypes.data_as(dp), C.byref(stats),
+                            C.byref(err))
+        _check(rc, err)
+        return dict(kg_sum=kg_sum, grad_sum=grad.reshape(R, q, self.d), mean_evals=stats.posterior_mean_evals,
+                    grad_evals=stats.posterior_grad_evals, ms_state=stats.ms_state, ms_mc=stats.ms_mc, ms_tail=stats.ms_tail)
+
+    def last_kernel_ms(self):
+        out = np.zeros(5)
+        _lib.load().moe_last_kernel_ms(self._h, out.ctypes.data_as(dp))
+        return dict(mc=out[0], cov_build=out[1], tail=out[2], state=out[3], total=out[4])

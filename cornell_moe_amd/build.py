@@ -1,0 +1,64 @@
+"""Build libmoe_hip.so (hand-written HIP kernels + C ABI) for gfx950 with hipcc, in tree.
+
+    python -m cornell_moe_amd.build            # incremental
+    python -m cornell_moe_amd.build --force
+
+hipcc cross-compiles without a GPU.  The .so is git-ignored but travels with gpurun snapshots.
+"""
+import concurrent.futures
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(HERE, "build")
+LIB = os.path.join(HERE, "lib", "libmoe_hip.so")
+SOURCES = ["kernels_cov.hip", "kernels_linalg.hip", "host_math.hip", "gp.hip", "kg.hip", "ei.hip", "api.hip"]
+HEADERS = ["common.hpp", "kernels.hpp", "device_cov.hpp", "host_math.hpp", "gp.hpp", "kg.hpp",
+           os.path.join("..", "..", "include", "moe_hip.h")]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function"]
+
+
+def _hipcc():
+    for cand in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
+        if cand and (os.path.isabs(cand) and os.path.exists(cand) or not os.path.isabs(cand)):
+            return cand
+    return "hipcc"
+
+
+def _newest_header():
+    return max(os.path.getmtime(os.path.join(CSRC, h)) for h in HEADERS)
+
+
+def _compile(src, force):
+    obj = os.path.join(OBJ, src.replace(".hip", ".o"))
+    srcp = os.path.join(CSRC, src)
+    if not force and os.path.exists(obj) and os.path.getmtime(obj) >= max(os.path.getmtime(srcp), _newest_header()):
+        return obj, False
+    cmd = [_hipcc()] + FLAGS + ["-c", srcp, "-o", obj]
+    res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, universal_newlines=True)
+    if res.returncode != 0:
+        raise RuntimeError("hipcc failed for %s:\n%s" % (src, res.stdout))
+    return obj, True
+
+
+def build(force=False, verbose=False):
+    os.makedirs(OBJ, exist_ok=True)
+    os.makedirs(os.path.dirname(LIB), exist_ok=True)
+    with concurrent.futures.ThreadPoolExecutor(max_workers=min(8, len(SOURCES))) as ex:
+        results = list(ex.map(lambda s: _compile(s, force), SOURCES))
+    objs = [r[0] for r in results]
+    rebuilt = any(r[1] for r in results)
+    if rebuilt or not os.path.exists(LIB):
+        cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+        res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, universal_newlines=True)
+        if res.returncode != 0:
+            raise RuntimeError("link failed:\n%s" % res.stdout)
+    if verbose:
+        print("libmoe_hip.so:", LIB, "(rebuilt)" if rebuilt else "(up to date)")
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv, verbose=True)

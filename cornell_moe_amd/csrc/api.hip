@@ -1,0 +1,314 @@
+// cornell_moe_amd/csrc/api.hip -- the C ABI of libmoe_hip.so (include/moe_hip.h).  Host code only.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <random>
+
+#include "gp.hpp"
+#include "kg.hpp"
+
+struct moe_gp {
+  moe::GpDev dev;
+  moe_gp(const double* hyper, int cov_type, const double* X, const double* y, const double* noise, const int* derivs, int g,
+         int d, int n, int device)
+      : dev(hyper, cov_type, X, y, noise, derivs, g, d, n, device) {}
+};
+
+namespace {
+
+void set_err(moe_error_t* err, int code, const char* msg, const double* payload) {
+  if (!err) return;
+  err->code = code;
+  std::strncpy(err->message, msg ? msg : "", sizeof(err->message) - 1);
+  err->message[sizeof(err->message) - 1] = '\0';
+  for (int i = 0; i < 3; ++i) err->payload[i] = payload ? payload[i] : 0.0;
+}
+
+template <typename F>
+int guarded(moe_error_t* err, F&& f) {
+  try {
+    if (err) set_err(err, MOE_OK, "", nullptr);
+    f();
+    return MOE_OK;
+  } catch (const moe::Error& e) {
+    set_err(err, e.code, e.what(), e.payload);
+    return e.code;
+  } catch (const std::exception& e) {
+    set_err(err, MOE_ERR_RUNTIME, e.what(), nullptr);
+    return MOE_ERR_RUNTIME;
+  }
+}
+
+void require(bool cond, const char* what) {
+  if (!cond) throw moe::Error(MOE_ERR_RUNTIME, what);
+}
+
+moe::DerivList no_derivs() {
+  moe::DerivList d;
+  d.g = 0;
+  for (int i = 0; i < moe::kMaxDerivs; ++i) d.idx[i] = 0;
+  return d;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* moe_version(void) { return "cornell_moe_amd 0.1 (gfx950)"; }
+
+int moe_device_count(int* count) {
+  int c = 0;
+  if (hipGetDeviceCount(&c) != hipSuccess) c = 0;
+  if (count) *count = c;
+  return MOE_OK;
+}
+
+int moe_device_arch(int device, char* name, int name_len) {
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device) != hipSuccess) return MOE_ERR_RUNTIME;
+  std::strncpy(name, prop.gcnArchName, name_len - 1);
+  name[name_len - 1] = '\0';
+  return MOE_OK;
+}
+
+int moe_gp_create(const double* hyperparameters, int cov_type, const double* points_sampled,
+                  const double* points_sampled_value, const double* noise_variance, const int* derivatives,
+                  int num_derivatives, int dim, int num_sampled, int device, moe_gp_t** gp_out, moe_error_t* err) {
+  return guarded(err, [&] {
+    require(gp_out != nullptr, "gp_out is NULL");
+    *gp_out = nullptr;
+    *gp_out = new moe_gp(hyperparameters, cov_type, points_sampled, points_sampled_value, noise_variance, derivatives,
+                         num_derivatives, dim, num_sampled, device);
+  });
+}
+
+int moe_gp_destroy(moe_gp_t* gp) {
+  delete gp;
+  return MOE_OK;
+}
+
+int moe_gp_dim(const moe_gp_t* gp) { return gp->dev.d; }
+int moe_gp_num_sampled(const moe_gp_t* gp) { return gp->dev.n; }
+int moe_gp_num_derivatives(const moe_gp_t* gp) { return gp->dev.g; }
+
+int moe_gp_add_points(moe_gp_t* gp, const double* new_points, const double* new_values, int num_new, moe_error_t* err) {
+  return guarded(err, [&] { gp->dev.add_points(new_points, new_values, num_new); });
+}
+
+int moe_gp_get_factor(const moe_gp_t* gp_c, double* K_chol, double* K_inv_y, double* mean, moe_error_t* err) {
+  return guarded(err, [&] {
+    moe::GpDev& gp = const_cast<moe_gp_t*>(gp_c)->dev;
+    gp.use_device();
+    if (K_chol) gp.dL.download(K_chol, (size_t)gp.N * gp.N, gp.stream);
+    if (K_inv_y) gp.dKinvY.download(K_inv_y, gp.N, gp.stream);
+    MOE_HIP_CHECK(hipStreamSynchronize(gp.stream));
+    if (mean) *mean = gp.mean;
+  });
+}
+
+int moe_gp_mean(const moe_gp_t* gp_c, const double* pts, int num_pts, double* out, moe_error_t* err) {
+  return guarded(err, [&] {
+    moe::GpDev& gp = const_cast<moe_gp_t*>(gp_c)->dev;
+    moe::StateHost h;
+    moe::compute_state(gp, pts, num_pts, no_derivs(), 0, nullptr, 0, false, nullptr, &h);
+    moe::host_mean(h, out);
+  });
+}
+
+int moe_gp_additional_mean(const moe_gp_t* gp, const double* pts, int num_pts, double* out, moe_error_t* err) {
+  return moe_gp_mean(gp, pts, num_pts, out, err);  // same quantity; the reference differs only in its temporaries
+}
+
+int moe_gp_grad_mean(const moe_gp_t* gp_c, const double* pts, int num_pts, double* out, moe_error_t* err) {
+  return guarded(err, [&] {
+    moe::GpDev& gp = const_cast<moe_gp_t*>(gp_c)->dev;
+    moe::StateHost h;
+    moe::compute_state(gp, pts, num_pts, gp.derivs, num_pts, nullptr, 0, false, nullptr, &h);
+    moe::host_grad_mean(h, out);
+  });
+}
+
+int moe_gp_variance(const moe_gp_t* gp_c, const double* pts, int num_pts, double* out, moe_error_t* err) {
+  return guarded(err, [&] {
+    moe::GpDev& gp = const_cast<moe_gp_t*>(gp_c)->dev;
+    moe::StateHost h;
+    moe::compute_state(gp, pts, num_pts, gp.derivs, 0, nullptr, 0, false, nullptr, &h);
+    moe::host_variance(h, out);
+  });
+}
+
+int moe_gp_cholesky_variance(const moe_gp_t* gp_c, const double* pts, int num_pts, double* out, moe_error_t* err) {
+  return guarded(err, [&] {
+    moe::GpDev& gp = const_cast<moe_gp_t*>(gp_c)->dev;
+    moe::StateHost h;
+    moe::compute_state(gp, pts, num_pts, gp.derivs, 0, nullptr, 0, false, nullptr, &h);
+    moe::host_variance(h, out);
+    const int m = h.lay.m;
+    const int lm = moe::host_cholesky(m, out);
+    if (lm != 0)
+      throw moe::Error(MOE_ERR_SINGULAR,
+                       "GP-Variance matrix singular. Check for duplicate points_to_sample or points_to_sample "
+                       "duplicating points_sampled with 0 noise.",
+                       m, lm);
+  });
+}
+
+int moe_gp_grad_variance(const moe_gp_t* gp_c, const double* pts, int num_pts, int num_derivs, double* out,
+                         moe_error_t* err) {
+  return guarded(err, [&] {
+    moe::GpDev& gp = const_cast<moe_gp_t*>(gp_c)->dev;
+    require(num_derivs >= 0 && num_derivs <= num_pts, "num_derivs must be in [0, num_pts]");
+    moe::StateHost h;
+    moe::compute_state(gp, pts, num_pts, gp.derivs, num_derivs, nullptr, 0, false, nullptr, &h);
+    const size_t blk = (size_t)gp.d * h.lay.m * h.lay.m;
+    for (int p = 0; p < num_derivs; ++p) moe::host_grad_variance_per_point(h, p, out + blk * p);
+  });
+}
+
+int moe_gp_grad_cholesky_variance(const moe_gp_t* gp_c, const double* pts, int num_pts, int num_derivs, double* out,
+                                  moe_error_t* err) {
+  return guarded(err, [&] {
+    moe::GpDev& gp = const_cast<moe_gp_t*>(gp_c)->dev;
+    require(num_derivs >= 0 && num_derivs <= num_pts, "num_derivs must be in [0, num_pts]");
+    moe::StateHost h;
+    moe::compute_state(gp, pts, num_pts, gp.derivs, num_derivs, nullptr, 0, false, nullptr, &h);
+    const int m = h.lay.m;
+    std::vector<double> chol((size_t)m * m);
+    moe::host_variance(h, chol.data());
+    const int lm = moe::host_cholesky(m, chol.data());
+    if (lm != 0)
+      throw moe::Error(MOE_ERR_SINGULAR,
+                       "GP-Variance matrix singular. Check for duplicate points_to_sample or points_to_sample "
+                       "duplicating points_sampled with 0 noise.",
+                       m, lm);
+    const size_t blk = (size_t)gp.d * m * m;
+    for (int p = 0; p < num_derivs; ++p) moe::host_grad_cholesky_per_point(h, p, chol.data(), out + blk * p);
+  });
+}
+
+int moe_posterior_mean(const moe_gp_t* gp_c, int num_fidelity, const double* point, double* value, double* grad,
+                       moe_error_t* err) {
+  return guarded(err, [&] {
+    moe::GpDev& gp = const_cast<moe_gp_t*>(gp_c)->dev;
+    require(num_fidelity >= 0 && num_fidelity < gp.d, "num_fidelity out of range");
+    std::vector<double> pt(gp.d, 1.0);  // fidelity coordinates pinned to 1 (gpp_knowledge_gradient_optimization.cpp:353-357)
+    for (int i = 0; i < gp.d - num_fidelity; ++i) pt[i] = point[i];
+    moe::StateHost h;
+    moe::compute_state(gp, pt.data(), 1, no_derivs(), grad ? 1 : 0, nullptr, 0, false, nullptr, &h);
+    if (value) {
+      double mu;
+      moe::host_mean(h, &mu);
+      *value = -mu;
+    }
+    if (grad) {
+      std::vector<double> g(gp.d);
+      moe::host_grad_mean(h, g.data());
+      for (int i = 0; i < gp.d - num_fidelity; ++i) grad[i] = -g[i];
+    }
+  });
+}
+
+int moe_normal_draws(unsigned int seed, long long count, double* out) {
+  // mt19937 + Box-Muller (polar-free form): u1,u2 in (0,1]; z0 = sqrt(-2 ln u1) cos(2 pi u2), z1 = ... sin(...).
+  std::mt19937 eng(seed);
+  const double two_pi = 6.283185307179586476925286766559;
+  long long i = 0;
+  while (i < count) {
+    const double u1 = (static_cast<double>(eng()) + 1.0) / 4294967296.0;
+    const double u2 = (static_cast<double>(eng()) + 1.0) / 4294967296.0;
+    const double r = std::sqrt(-2.0 * std::log(u1));
+    out[i++] = r * std::cos(two_pi * u2);
+    if (i < count) out[i++] = r * std::sin(two_pi * u2);
+  }
+  return MOE_OK;
+}
+
+int moe_gp_mix_covariance(const moe_gp_t* gp_c, const double* pts, int num_pts, const int* derivs2, int g2, double* out,
+                          moe_error_t* err) {
+  return guarded(err, [&] {
+    moe::GpDev& gp = const_cast<moe_gp_t*>(gp_c)->dev;
+    gp.use_device();
+    moe::DerivList d2 = no_derivs();
+    require(g2 >= 0 && g2 <= moe::kMaxDerivs, "g2 out of range");
+    d2.g = g2;
+    for (int i = 0; i < g2; ++i) d2.idx[i] = derivs2[i];
+    const std::vector<double> P = gp.padded(pts, num_pts);
+    gp.dPts.upload(P.data(), P.size(), gp.stream);
+    const size_t total = (size_t)gp.N * num_pts * (1 + g2);
+    gp.dE.reserve(total);
+    moe::launch_cov_build(gp.cp, gp.dX.p, gp.n, gp.derivs, gp.dPts.p, num_pts, d2, nullptr, gp.dE.p, gp.N, 0, gp.stream);
+    gp.dE.download(out, total, gp.stream);
+    MOE_HIP_CHECK(hipStreamSynchronize(gp.stream));
+  });
+}
+
+int moe_cov_build_probe(const moe_gp_t* gp_c, const double* pts, int num_pts, int repeat, double* avg_ms,
+                        double* bytes_per_launch, moe_error_t* err) {
+  return guarded(err, [&] {
+    moe::GpDev& gp = const_cast<moe_gp_t*>(gp_c)->dev;
+    gp.use_device();
+    const std::vector<double> P = gp.padded(pts, num_pts);
+    moe::DevBuf<double> dP, dOut;
+    dP.upload(P.data(), P.size(), gp.stream);
+    dOut.reserve((size_t)gp.N * num_pts);
+    hipEvent_t e0, e1;
+    MOE_HIP_CHECK(hipEventCreate(&e0));
+    MOE_HIP_CHECK(hipEventCreate(&e1));
+    moe::launch_cov_build(gp.cp, gp.dX.p, gp.n, gp.derivs, dP.p, num_pts, no_derivs(), nullptr, dOut.p, gp.N, 0, gp.stream);
+    MOE_HIP_CHECK(hipEventRecord(e0, gp.stream));
+    for (int r = 0; r < repeat; ++r)
+      moe::launch_cov_build(gp.cp, gp.dX.p, gp.n, gp.derivs, dP.p, num_pts, no_derivs(), nullptr, dOut.p, gp.N, 0, gp.stream);
+    MOE_HIP_CHECK(hipEventRecord(e1, gp.stream));
+    MOE_HIP_CHECK(hipEventSynchronize(e1));
+    float ms = 0.f;
+    MOE_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    if (avg_ms) *avg_ms = ms / std::max(repeat, 1);
+    if (bytes_per_launch)
+      *bytes_per_launch = 8.0 * ((double)gp.n * gp.d + (double)num_pts * gp.d + (double)gp.N * num_pts);
+  });
+}
+
+int moe_last_kernel_ms(const moe_gp_t* gp, double* out5) {
+  for (int i = 0; i < 5; ++i) out5[i] = gp->dev.last_ms[i];
+  return MOE_OK;
+}
+
+int moe_ei(const moe_gp_t* gp_c, const double* points_to_sample, const double* points_being_sampled, int num_to_sample,
+           int num_being_sampled, int num_mc, double best_so_far, const double* normals, double* ei, double* grad_ei,
+           moe_error_t* err) {
+  return guarded(err, [&] {
+    moe::GpDev& gp = const_cast<moe_gp_t*>(gp_c)->dev;
+    moe::ei_evaluate(gp, points_to_sample, points_being_sampled, num_to_sample, num_being_sampled, num_mc, best_so_far,
+                     normals, ei, grad_ei);
+  });
+}
+
+int moe_kg_batch(const moe_gp_t* gp_c, int num_fidelity, const moe_gd_params_t* inner_params, const double* domain_bounds,
+                 const double* discrete_pts, int num_pts, const double* points_to_sample_all, int num_evals,
+                 const double* points_being_sampled, int num_to_sample, int num_being_sampled, int num_mc,
+                 double best_so_far, const double* normals, int first_sample, int num_local, int want_grad,
+                 double* kg_sum, double* grad_sum, moe_kg_stats_t* stats, moe_error_t* err) {
+  return guarded(err, [&] {
+    moe::GpDev& gp = const_cast<moe_gp_t*>(gp_c)->dev;
+    moe::kg_evaluate_batch(gp, num_fidelity, *inner_params, domain_bounds, discrete_pts, num_pts, points_to_sample_all,
+                           num_evals, points_being_sampled, num_to_sample, num_being_sampled, num_mc, best_so_far, normals,
+                           first_sample, num_local, want_grad != 0, kg_sum, grad_sum, nullptr, stats);
+  });
+}
+
+int moe_kg(const moe_gp_t* gp_c, int num_fidelity, const moe_gd_params_t* inner_params, const double* domain_bounds,
+           const double* discrete_pts, int num_pts, const double* points_to_sample, const double* points_being_sampled,
+           int num_to_sample, int num_being_sampled, int num_mc, double best_so_far, const double* normals,
+           int first_sample, int num_local, int want_grad, double* kg_sum, double* grad_sum, double* best_points,
+           moe_kg_stats_t* stats, moe_error_t* err) {
+  return guarded(err, [&] {
+    moe::GpDev& gp = const_cast<moe_gp_t*>(gp_c)->dev;
+    moe::kg_evaluate_batch(gp, num_fidelity, *inner_params, domain_bounds, discrete_pts, num_pts, points_to_sample, 1,
+                           points_being_sampled, num_to_sample, num_being_sampled, num_mc, best_so_far, normals,
+                           first_sample, num_local, want_grad != 0, kg_sum, grad_sum, best_points, stats);
+  });
+}
+
+}  // extern "C"

@@ -1,0 +1,183 @@
+// cornell_moe_amd/csrc/ei.hip -- q,p-EI by Monte Carlo (value + gradient) on gfx950.
+//
+// ExpectedImprovementEvaluator::ComputeExpectedImprovement / ComputeGradExpectedImprovement (gpp_math.cpp:1991-2126):
+//   V = Var(Xu) + 1e-6 I,  L = chol(V),  per sample: y = mu + L z,  I = max(0, max_j (best_so_far - y_j)),  w = argmax;
+//   EI = sum I / M;   grad EI[k,:] = (1/M) sum_{I>0} ( -[w == k] grad mu_k  -  sum_j dL[w][j]/dXs_k z_j ).
+// One lane per MC sample (the per-sample work is O(u^2), u <= 16); sums are block-reduced in a fixed order and finished
+// by a single workgroup, so results are bitwise reproducible.
+#include <cmath>
+
+#include "kg.hpp"
+
+namespace moe {
+
+namespace {
+
+constexpr int kMaxUnionEi = 16;
+
+struct EiParams {
+  int u, q, d, num_mc;
+  double best_so_far;
+  const double* mu;       // [u]
+  const double* L;        // [u x u] col-major lower
+  const double* grad_mu;  // [q][d]
+  const double* gchol;    // [q][u][u][d]: gchol[k*d*u*u + dd + c*d + r*d*u] = dL[r][c]/dXs_{k,dd}, r >= c
+  const double* normals;  // [num_mc][u]
+  double* partial;        // [gridDim.x][1 + q*d]
+  int want_grad;
+};
+
+__device__ __forceinline__ double wave_sum_ei(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+__global__ __launch_bounds__(256) void ei_mc_kernel(EiParams P) {
+  constexpr int MU = kMaxUnionEi;
+  __shared__ double red[4];
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool active = i < P.num_mc;
+  const int u = P.u, d = P.d;
+  const int ncomp = 1 + (P.want_grad ? P.q * d : 0);
+  double z[MU];
+  double imp = 0.0;
+  int winner = u + 1;
+  if (active) {
+#pragma unroll
+    for (int j = 0; j < MU; ++j) z[j] = (j < u) ? P.normals[(long)i * u + j] : 0.0;
+#pragma unroll
+    for (int r = 0; r < MU; ++r) {
+      if (r < u) {
+        double y = P.mu[r];
+#pragma unroll
+        for (int c = 0; c < MU; ++c)
+          if (c <= r) y = fma(P.L[r + c * u], z[c], y);
+        const double t = P.best_so_far - y;
+        if (t > imp) {
+          imp = t;
+          winner = r;
+        }
+      }
+    }
+  }
+  for (int comp = 0; comp < ncomp; ++comp) {
+    double contrib = 0.0;
+    if (active && imp > 0.0) {
+      if (comp == 0) {
+        contrib = imp;
+      } else {
+        const int k = (comp - 1) / d, dd = (comp - 1) % d;
+        double v = 0.0;
+        if (winner == k) v = -P.grad_mu[k * d + dd];
+        const double* g = P.gchol + (long)k * d * u * u + dd + (long)winner * d * u;
+#pragma unroll
+        for (int j = 0; j < MU; ++j)
+          if (j <= winner && j < u) v = fma(-g[j * d], z[j], v);
+        contrib = v;
+      }
+    }
+    const double w = wave_sum_ei(contrib);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = w;
+    __syncthreads();
+    if (threadIdx.x == 0) P.partial[(long)blockIdx.x * ncomp + comp] = (red[0] + red[1]) + (red[2] + red[3]);
+    __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(256) void sum_partials_kernel(const double* __restrict__ partial, int num_blocks, int ncomp,
+                                                          double* __restrict__ out) {
+  __shared__ double red[256];
+  for (int comp = 0; comp < ncomp; ++comp) {
+    double acc = 0.0;
+    for (int b = threadIdx.x; b < num_blocks; b += 256) acc += partial[(long)b * ncomp + comp];
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+      if (threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) out[comp] = red[0];
+    __syncthreads();
+  }
+}
+
+}  // namespace
+
+void ei_evaluate(GpDev& gp, const double* Xq, const double* Xp, int q, int p, int num_mc, double best_so_far,
+                 const double* normals, double* ei, double* grad_ei) {
+  gp.use_device();
+  hipStream_t s = gp.stream;
+  const int d = gp.d, u = q + p;
+  if (q <= 0) throw Error(MOE_ERR_BOUNDS, "num_to_sample must be positive", q, 1, 1e9);
+  if (p < 0) throw Error(MOE_ERR_BOUNDS, "num_being_sampled must be non-negative", p, 0, 1e9);
+  if (u > kMaxUnionEi) throw Error(MOE_ERR_BOUNDS, "q + p > 16 is not supported by the device kernels", u, 1, kMaxUnionEi);
+  if (num_mc <= 0) throw Error(MOE_ERR_BOUNDS, "num_mc must be positive", num_mc, 1, 1e12);
+  const bool want_grad = grad_ei != nullptr;
+  std::vector<double> U((size_t)u * d);
+  std::copy(Xq, Xq + (size_t)q * d, U.begin());
+  if (p > 0) std::copy(Xp, Xp + (size_t)p * d, U.begin() + (size_t)q * d);
+  DerivList none;
+  none.g = 0;
+  for (int i = 0; i < kMaxDerivs; ++i) none.idx[i] = 0;
+  // EI points carry no derivative observations even when the GP does (ExpectedImprovementState, gpp_math.cpp:2149-2150)
+  StateHost sh;
+  compute_state(gp, U.data(), u, none, want_grad ? q : 0, nullptr, 0, false, nullptr, &sh);
+  std::vector<double> mu(u), chol((size_t)u * u);
+  host_mean(sh, mu.data());
+  host_variance(sh, chol.data());
+  for (int i = 0; i < u; ++i) chol[i + (size_t)i * u] += 1.0e-6;  // gpp_math.cpp:2000-2002
+  const int lm = host_cholesky(u, chol.data());
+  if (lm != 0)
+    throw Error(MOE_ERR_SINGULAR,
+                "GP-Variance matrix singular. Check for duplicate points_to_sample/being_sampled or "
+                "points_to_sample/being_sampled duplicating points_sampled with 0 noise.",
+                u, lm);
+  std::vector<double> blob;
+  auto push = [&](const double* ptr, size_t cnt) {
+    const size_t off = blob.size();
+    blob.insert(blob.end(), ptr, ptr + cnt);
+    return off;
+  };
+  const size_t o_mu = push(mu.data(), u);
+  const size_t o_L = push(chol.data(), (size_t)u * u);
+  size_t o_gmu = 0, o_gc = 0;
+  if (want_grad) {
+    std::vector<double> grad_mu((size_t)q * d), gchol((size_t)q * d * u * u);
+    host_grad_mean(sh, grad_mu.data());
+    for (int k = 0; k < q; ++k) host_grad_cholesky_per_point(sh, k, chol.data(), &gchol[(size_t)k * d * u * u]);
+    o_gmu = push(grad_mu.data(), grad_mu.size());
+    o_gc = push(gchol.data(), gchol.size());
+  }
+  const int ncomp = 1 + (want_grad ? q * d : 0);
+  const int blocks = (num_mc + 255) / 256;
+  DevBuf<double> dBlob, dNormals, dPartial, dOut;
+  dBlob.upload(blob.data(), blob.size(), s);
+  dNormals.upload(normals, (size_t)num_mc * u, s);
+  dPartial.reserve((size_t)blocks * ncomp);
+  dOut.reserve(ncomp);
+  EiParams P;
+  P.u = u;
+  P.q = q;
+  P.d = d;
+  P.num_mc = num_mc;
+  P.best_so_far = best_so_far;
+  P.mu = dBlob.p + o_mu;
+  P.L = dBlob.p + o_L;
+  P.grad_mu = dBlob.p + o_gmu;
+  P.gchol = dBlob.p + o_gc;
+  P.normals = dNormals.p;
+  P.partial = dPartial.p;
+  P.want_grad = want_grad ? 1 : 0;
+  hipLaunchKernelGGL(ei_mc_kernel, dim3(blocks), dim3(256), 0, s, P);
+  hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, s, dPartial.p, blocks, ncomp, dOut.p);
+  MOE_HIP_CHECK(hipGetLastError());
+  std::vector<double> out(ncomp);
+  dOut.download(out.data(), ncomp, s);
+  MOE_HIP_CHECK(hipStreamSynchronize(s));
+  if (ei) *ei = out[0] / (double)num_mc;
+  if (want_grad)
+    for (int c = 0; c < q * d; ++c) grad_ei[c] = out[1 + c] / (double)num_mc;
+}
+
+}  // namespace moe

@@ -1,0 +1,166 @@
+// cornell_moe_amd/csrc/gp.hip -- see gp.hpp.
+#include "gp.hpp"
+
+#include <cmath>
+
+namespace moe {
+
+GpDev::GpDev(const double* hyper, int cov_type, const double* X_in, const double* y_in, const double* noise_in,
+             const int* derivs_in, int g_in, int d_in, int n_in, int device_in)
+    : device(device_in), d(d_in), n(n_in), g(g_in) {
+  if (d <= 0 || d > kMaxDimPadded) throw Error(MOE_ERR_BOUNDS, "dim out of range", d, 1, kMaxDimPadded);
+  if (g < 0 || g > kMaxDerivs) throw Error(MOE_ERR_BOUNDS, "num_derivatives out of range", g, 0, kMaxDerivs);
+  if (n <= 0) throw Error(MOE_ERR_BOUNDS, "num_sampled must be positive", n, 1, 1e9);
+  if (cov_type != MOE_COV_SQUARE_EXPONENTIAL && cov_type != MOE_COV_MATERN_NU_2P5)
+    throw Error(MOE_ERR_INVALID_VALUE, "unknown covariance type", cov_type, 0, 1);
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count <= 0)
+    throw Error(MOE_ERR_RUNTIME, "no HIP device visible: libmoe_hip has no CPU fallback");
+  if (device < 0 || device >= count) throw Error(MOE_ERR_BOUNDS, "device index out of range", device, 0, count - 1);
+  dp = round_up(d, 4);
+  N = n * (1 + g);
+  cp.type = cov_type;
+  cp.dim = d;
+  cp.dp = dp;
+  cp.alpha = hyper[0];
+  if (!(cp.alpha > 0.0)) throw Error(MOE_ERR_BOUNDS, "alpha must be positive", cp.alpha, 0.0, INFINITY);
+  for (int k = 0; k < kMaxDimPadded; ++k) {
+    cp.inv_l2[k] = 0.0;
+    cp.inv_l[k] = 0.0;
+  }
+  for (int k = 0; k < d; ++k) {
+    const double l = hyper[1 + k];
+    if (!(l > 0.0)) throw Error(MOE_ERR_BOUNDS, "length scale must be positive", l, 0.0, INFINITY);  // gpp_covariance.cpp:85-92
+    cp.inv_l2[k] = 1.0 / (l * l);
+    cp.inv_l[k] = 1.0 / l;
+  }
+  derivs.g = g;
+  for (int i = 0; i < kMaxDerivs; ++i) derivs.idx[i] = 0;
+  for (int i = 0; i < g; ++i) {
+    if (derivs_in[i] < 0 || derivs_in[i] >= d) throw Error(MOE_ERR_BOUNDS, "derivative index out of range", derivs_in[i], 0, d - 1);
+    derivs.idx[i] = derivs_in[i];
+  }
+  X.assign(X_in, X_in + (size_t)n * d);
+  y.assign(y_in, y_in + (size_t)N);
+  noise.assign(noise_in, noise_in + (1 + g));
+  use_device();
+  MOE_HIP_CHECK(hipStreamCreate(&stream));
+  rebuild();
+}
+
+GpDev::~GpDev() {
+  if (stream) {
+    (void)hipSetDevice(device);
+    (void)hipStreamDestroy(stream);
+  }
+}
+
+void GpDev::use_device() const { MOE_HIP_CHECK(hipSetDevice(device)); }
+
+std::vector<double> GpDev::padded(const double* pts, int k) const {
+  std::vector<double> out((size_t)k * dp, 0.0);
+  for (int i = 0; i < k; ++i)
+    for (int j = 0; j < d; ++j) out[(size_t)i * dp + j] = pts[(size_t)i * d + j];
+  return out;
+}
+
+void GpDev::rebuild() {
+  use_device();
+  N = n * (1 + g);
+  const std::vector<double> Xp = padded(X.data(), n);
+  dX.upload(Xp.data(), Xp.size(), stream);
+  dNoise.upload(noise.data(), noise.size(), stream);
+  dL.reserve((size_t)N * N);
+  dLinv.reserve((size_t)N * N);
+  dInfo.reserve(1);
+  dKinvY.reserve(N);
+  dTmp.reserve((size_t)2 * N);
+  launch_cov_build(cp, dX.p, n, derivs, dX.p, n, derivs, dNoise.p, dL.p, N, 0, stream);
+  launch_cholesky_and_inverse(N, dL.p, N, dLinv.p, N, nullptr, dInfo.p, stream);
+  int info = 0;
+  dInfo.download(&info, 1, stream);
+  // mean_ = average of the function-value column only (gpp_math.cpp:498-504)
+  mean = 0.0;
+  for (int i = 0; i < n; ++i) mean += y[(size_t)i * (1 + g)];
+  mean /= n;
+  std::vector<double> ymm(y);
+  for (int i = 0; i < n; ++i) ymm[(size_t)i * (1 + g)] -= mean;
+  MOE_HIP_CHECK(hipMemcpyAsync(dTmp.p, ymm.data(), sizeof(double) * N, hipMemcpyHostToDevice, stream));
+  MOE_HIP_CHECK(hipStreamSynchronize(stream));
+  if (info != 0)
+    throw Error(MOE_ERR_SINGULAR,
+                "Covariance matrix (K) singular. Check for duplicate points_sampled (with 0 noise) and/or extreme "
+                "hyperparameter values.",
+                N, info);
+  launch_tri_gemm('N', N, 1, dLinv.p, N, dTmp.p, N, dTmp.p + N, N, stream);
+  launch_tri_gemm('T', N, 1, dLinv.p, N, dTmp.p + N, N, dKinvY.p, N, stream);
+  MOE_HIP_CHECK(hipStreamSynchronize(stream));
+}
+
+void GpDev::add_points(const double* pts, const double* vals, int k) {
+  X.insert(X.end(), pts, pts + (size_t)k * d);
+  y.insert(y.end(), vals, vals + (size_t)k * (1 + g));
+  n += k;
+  rebuild();
+}
+
+void compute_state(GpDev& gp, const double* U, int u, const DerivList& dt, int nd, const double* extra, int A, bool need_W,
+                   StateDev* dev, StateHost* host) {
+  gp.use_device();
+  hipStream_t s = gp.stream;
+  StateLayout lay;
+  lay.d = gp.d;
+  lay.u = u;
+  lay.gt = dt.g;
+  lay.m = u * (1 + dt.g);
+  lay.nd = nd;
+  lay.A = A;
+  const int c = lay.c();
+  const int ngrad = nd * (1 + dt.g) * gp.d;
+  const int N = gp.N;
+  const std::vector<double> Up = gp.padded(U, u);
+  gp.dPts.upload(Up.data(), Up.size(), s);
+  if (A > 0) {
+    const std::vector<double> Ep = gp.padded(extra, A);
+    gp.dExtra.upload(Ep.data(), Ep.size(), s);
+  }
+  gp.dE.reserve((size_t)N * c);
+  gp.dVE.reserve((size_t)N * c);
+  gp.dGram.reserve((size_t)c * c);
+  gp.dEK.reserve(c);
+  launch_cov_build(gp.cp, gp.dX.p, gp.n, gp.derivs, gp.dPts.p, u, dt, nullptr, gp.dE.p, N, 0, s);
+  if (nd > 0) launch_grad_kstar(gp.cp, gp.dX.p, gp.n, gp.derivs, gp.dPts.p, nd, dt, gp.dE.p, N, lay.m, s);
+  if (A > 0) {
+    DerivList none;
+    none.g = 0;
+    for (int i = 0; i < kMaxDerivs; ++i) none.idx[i] = 0;
+    launch_cov_build(gp.cp, gp.dX.p, gp.n, gp.derivs, gp.dExtra.p, A, none, nullptr, gp.dE.p, N, lay.m + ngrad, s);
+  }
+  launch_tri_gemm('N', N, c, gp.dLinv.p, N, gp.dE.p, N, gp.dVE.p, N, s);
+  if (need_W) {
+    gp.dWE.reserve((size_t)N * (lay.m + ngrad));
+    launch_tri_gemm('T', N, lay.m + ngrad, gp.dLinv.p, N, gp.dVE.p, N, gp.dWE.p, N, s);
+  }
+  launch_gemm_tn(c, c, N, gp.dVE.p, N, gp.dVE.p, N, gp.dGram.p, c, s);
+  launch_gemm_tn(c, 1, N, gp.dE.p, N, gp.dKinvY.p, N, gp.dEK.p, c, s);
+  host->lay = lay;
+  host->cp = gp.cp;
+  host->dt = dt;
+  host->U.assign(U, U + (size_t)u * gp.d);
+  if (A > 0)
+    host->extra.assign(extra, extra + (size_t)A * gp.d);
+  else
+    host->extra.clear();
+  host->gram.resize((size_t)c * c);
+  host->ek.resize(c);
+  host->mean = gp.mean;
+  gp.dGram.download(host->gram.data(), (size_t)c * c, s);
+  gp.dEK.download(host->ek.data(), c, s);
+  MOE_HIP_CHECK(hipStreamSynchronize(s));
+  if (dev) {
+    dev->lay = lay;
+    dev->have_W = need_W;
+  }
+}
+
+}  // namespace moe

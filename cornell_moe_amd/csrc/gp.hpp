@@ -1,0 +1,56 @@
+// cornell_moe_amd/csrc/gp.hpp -- device-resident Gaussian process (the object behind moe_gp_t) and the per-call
+// "points state" set-up shared by the posterior queries, q-EI and q-KG.
+#pragma once
+#include <memory>
+#include <vector>
+
+#include "common.hpp"
+#include "host_math.hpp"
+#include "kernels.hpp"
+
+namespace moe {
+
+// HBM-resident state of one GP (replaces GaussianProcess' K_chol_/K_inv_y_ members, gpp_math.hpp:840-868):
+//   dX     [n][DP]   padded training points
+//   dL     [N][N]    Cholesky factor of K + noise (lower; strict upper zero)
+//   dLinv  [N][N]    its explicit inverse (lower)
+//   dKinvY [N]       K^-1 (y - mean)
+struct GpDev {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  int d = 0, dp = 0, n = 0, g = 0, N = 0;
+  CovParams cp;
+  DerivList derivs;
+  std::vector<double> X, y, noise;  // host copies (reference keeps them too, gpp_math.hpp:846-856)
+  double mean = 0.0;
+  DevBuf<double> dX, dL, dLinv, dKinvY, dNoise, dTmp;
+  DevBuf<int> dInfo;
+  // reusable workspaces for states
+  DevBuf<double> dPts, dExtra, dE, dVE, dWE, dGram, dEK;
+  // timing of the last KG call (ms): mc, cov-build, tail contraction, state, total
+  double last_ms[5] = {0, 0, 0, 0, 0};
+
+  GpDev(const double* hyper, int cov_type, const double* X_in, const double* y_in, const double* noise_in,
+        const int* derivs_in, int g_in, int d_in, int n_in, int device_in);
+  ~GpDev();
+  GpDev(const GpDev&) = delete;
+  GpDev& operator=(const GpDev&) = delete;
+
+  void use_device() const;
+  void rebuild();  // K assembly + Cholesky + inverse + K^-1 (y - mean)  (RecomputeDerivedVariables, gpp_math.cpp:481-511)
+  void add_points(const double* pts, const double* vals, int k);
+  std::vector<double> padded(const double* pts, int k) const;  // [k][d] -> [k][DP]
+};
+
+// Device-side product of a state set-up.  Columns of E (ld = N): see StateLayout.
+struct StateDev {
+  StateLayout lay;
+  bool have_W = false;  // dWE = K^-1 E was computed (needed by the KG kernels)
+};
+
+// Builds E = [K*(X,U) | dK*/dU (first nd points) | K(X, extra)], VE = L^-1 E, optionally WE = L^-T VE, then
+// gram = VE^T VE and ek = E^T K^-1(y-mean); downloads gram/ek into `host` (synchronises the GP's stream).
+void compute_state(GpDev& gp, const double* U, int u, const DerivList& dt, int nd, const double* extra, int A, bool need_W,
+                   StateDev* dev, StateHost* host);
+
+}  // namespace moe

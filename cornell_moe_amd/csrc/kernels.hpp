@@ -1,0 +1,57 @@
+// cornell_moe_amd/csrc/kernels.hpp -- launch wrappers of the hand-written gfx950 kernels (definitions in kernels_*.hip).
+//
+// Device data layout (everything FP64):
+//   points      : row-major [point][DP], DP = dim rounded up to a multiple of 4, zero padded
+//                 (a zero pad contributes exactly +0.0 to every squared distance);
+//   matrices    : column-major, leading dimension given explicitly (rows are what consecutive lanes walk, so every
+//                 global store/load of a matrix column is a coalesced 512 B per wavefront);
+//   CovParams   : kernel type, alpha, 1/l^2 per (padded) dimension, passed by value.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "common.hpp"
+
+namespace moe {
+
+constexpr int kMaxDimPadded = 16;  // dims up to 16 (C5 has 12)
+constexpr int kMaxDerivs = 16;
+
+struct CovParams {
+  int type;  // MOE_COV_*
+  int dim;   // true dim
+  int dp;    // padded dim (multiple of 4)
+  double alpha;
+  double inv_l2[kMaxDimPadded];  // 1 / length^2, 0 in padded slots
+  double inv_l[kMaxDimPadded];   // 1 / length, 0 in padded slots
+};
+
+struct DerivList {
+  int g;
+  int idx[kMaxDerivs];
+};
+
+// out[(i*(1+gA)+a) + (col0 + j*(1+gB)+b) * ld] = cov(A_i, B_j)[a, b]   (BuildMixCovarianceMatrix, gpp_math.cpp:309-335)
+// If diag_noise != nullptr (A == B, gA == gB): adds diag_noise[a] where row == col (gpp_math.cpp:426-455).
+void launch_cov_build(const CovParams& cp, const double* A, int nA, const DerivList& dA, const double* B, int nB,
+                      const DerivList& dB, const double* diag_noise, double* out, long ld, long col0, hipStream_t s);
+
+// E[(j*(1+g)+n) + (col0 + (i*(1+gt)+m)*dim + dd) * ld] = d cov(P_i, X_j)[m, n] / d P_{i,dd}
+// (grad_K_star fill, gpp_math.cpp:616-637)
+void launch_grad_kstar(const CovParams& cp, const double* X, int n, const DerivList& dX, const double* P, int nP,
+                       const DerivList& dP, double* out, long ld, long col0, hipStream_t s);
+
+// C[N x c] (ldc) = op(T) * B[N x c] (ldb); T lower-triangular N x N (ldt), op = 'N' or 'T'.
+void launch_tri_gemm(char op, int N, int c, const double* T, long ldt, const double* B, long ldb, double* C, long ldc,
+                     hipStream_t s);
+
+// C[m x n] (ldc) = A^T B, A is K x m (lda), B is K x n (ldb); reduction over the K rows.
+void launch_gemm_tn(int m, int n, int K, const double* A, long lda, const double* B, long ldb, double* C, long ldc,
+                    hipStream_t s);
+
+// In-place blocked Cholesky of the lower triangle of A (N x N, lda) + explicit inverse of the factor into Linv
+// (N x N, ldl, lower; strict upper zeroed).  info (device int): 0 or failing pivot index + 1 (pivot <= 1e-16).
+void launch_cholesky_and_inverse(int N, double* A, long lda, double* Linv, long ldl, double* work, int* info,
+                                 hipStream_t s);
+size_t cholesky_work_doubles(int N);
+
+}  // namespace moe

@@ -1,0 +1,156 @@
+// cornell_moe_amd/csrc/kernels_cov.hip -- covariance-matrix assembly kernels for gfx950 (CDNA4, wave64).
+//
+// cov_build_kernel: K(A, B) with optional derivative-observation blocks (BuildMixCovarianceMatrix,
+// gpp_math.cpp:309-335; BuildCovarianceMatrixWithNoiseVariance :426-455).  Output-write bound: one thread owns one
+// OUTPUT ROW (so a wavefront's 64 stores of one column are 512 contiguous bytes), the B points of the tile are staged
+// once in LDS and read as wave-uniform broadcasts, the A point stays in registers for the whole tile.
+// Algorithmic bytes per launch: 8 * [nA*d + nB*d + nA(1+gA) * nB(1+gB)].
+#include "device_cov.hpp"
+
+namespace moe {
+
+namespace {
+
+constexpr int kCovRows = 256;  // output rows per workgroup (4 wavefronts)
+constexpr int kCovCols = 16;   // B points per workgroup
+
+template <int DP, bool DERIVS>
+__global__ __launch_bounds__(kCovRows) void cov_build_kernel(CovParams cp, const double* __restrict__ A, int nA,
+                                                            DerivList dA, const double* __restrict__ B, int nB,
+                                                            DerivList dB, const double* __restrict__ diag_noise,
+                                                            double* __restrict__ out, long ld, long col0) {
+  __shared__ double Bs[kCovCols][DP];
+  const int gA = DERIVS ? dA.g : 0, gB = DERIVS ? dB.g : 0;
+  const int rows = nA * (1 + gA);
+  const int j0 = blockIdx.y * kCovCols;
+  const int nj = min(kCovCols, nB - j0);
+  for (int t = threadIdx.x; t < nj * DP; t += blockDim.x) Bs[t / DP][t % DP] = B[(long)(j0 + t / DP) * DP + (t % DP)];
+  __syncthreads();
+  const int r = blockIdx.x * kCovRows + threadIdx.x;
+  if (r >= rows) return;
+  const int i = DERIVS ? r / (1 + gA) : r;
+  const int a = DERIVS ? r % (1 + gA) : 0;
+  double xi[DP];
+#pragma unroll
+  for (int k = 0; k < DP; ++k) xi[k] = A[(long)i * DP + k];
+  for (int jj = 0; jj < nj; ++jj) {
+    double diff[DP];
+    double r2 = 0.0;
+#pragma unroll
+    for (int k = 0; k < DP; ++k) {
+      diff[k] = xi[k] - Bs[jj][k];
+      r2 = fma(diff[k] * diff[k], cp.inv_l2[k], r2);
+    }
+    const Radial rd = radial_scalars(cp.type, cp.alpha, r2);
+    if (!DERIVS) {
+      double v = rd.base;
+      const long col = col0 + j0 + jj;
+      if (diag_noise != nullptr && (long)r == col - col0) v += diag_noise[0];
+      out[(long)r + col * ld] = v;
+    } else {
+      for (int b = 0; b < 1 + gB; ++b) {
+        double v = cov_entry<DP>(cp, rd, diff, a, b, dA, dB);
+        const long colrel = (long)(j0 + jj) * (1 + gB) + b;
+        if (diag_noise != nullptr && (long)r == colrel) v += diag_noise[a];
+        out[(long)r + (col0 + colrel) * ld] = v;
+      }
+    }
+  }
+}
+
+// d cov(P_i, X_j)[m, n] / d P_{i,dd}: one thread per training row (j, n); P staged in LDS.
+template <int DP, bool DERIVS>
+__global__ __launch_bounds__(256) void grad_kstar_kernel(CovParams cp, const double* __restrict__ X, int n, DerivList dX,
+                                                        const double* __restrict__ P, int nP, DerivList dP,
+                                                        double* __restrict__ out, long ld, long col0) {
+  extern __shared__ double Ps[];  // [nP][DP]
+  for (int t = threadIdx.x; t < nP * DP; t += blockDim.x) Ps[t] = P[t];
+  __syncthreads();
+  const int g = DERIVS ? dX.g : 0, gt = DERIVS ? dP.g : 0;
+  const int rows = n * (1 + g);
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= rows) return;
+  const int j = DERIVS ? r / (1 + g) : r;
+  const int nb = DERIVS ? r % (1 + g) : 0;
+  double xj[DP];
+#pragma unroll
+  for (int k = 0; k < DP; ++k) xj[k] = X[(long)j * DP + k];
+  for (int i = 0; i < nP; ++i) {
+    double diff[DP];  // p1 - p2 = P_i - X_j
+    double r2 = 0.0;
+#pragma unroll
+    for (int k = 0; k < DP; ++k) {
+      diff[k] = Ps[i * DP + k] - xj[k];
+      r2 = fma(diff[k] * diff[k], cp.inv_l2[k], r2);
+    }
+    const Radial rd = radial_scalars(cp.type, cp.alpha, r2);
+    if (!DERIVS) {
+#pragma unroll
+      for (int dd = 0; dd < DP; ++dd) {
+        if (dd < cp.dim) out[(long)r + (col0 + (long)i * cp.dim + dd) * ld] = (-diff[dd] * cp.inv_l2[dd]) * rd.first;
+      }
+    } else {
+      for (int m = 0; m < 1 + gt; ++m)
+        for (int dd = 0; dd < cp.dim; ++dd)
+          out[(long)r + (col0 + ((long)i * (1 + gt) + m) * cp.dim + dd) * ld] =
+              grad_cov_entry<DP>(cp, rd, diff, m, nb, dd, dP, dX);
+    }
+  }
+}
+
+template <int DP>
+void cov_build_dp(const CovParams& cp, const double* A, int nA, const DerivList& dA, const double* B, int nB,
+                  const DerivList& dB, const double* diag_noise, double* out, long ld, long col0, hipStream_t s) {
+  const bool derivs = dA.g > 0 || dB.g > 0;
+  const int rows = nA * (1 + dA.g);
+  dim3 grid((rows + kCovRows - 1) / kCovRows, (nB + kCovCols - 1) / kCovCols);
+  if (grid.x == 0 || grid.y == 0) return;
+  if (derivs)
+    hipLaunchKernelGGL((cov_build_kernel<DP, true>), grid, dim3(kCovRows), 0, s, cp, A, nA, dA, B, nB, dB, diag_noise, out, ld,
+                       col0);
+  else
+    hipLaunchKernelGGL((cov_build_kernel<DP, false>), grid, dim3(kCovRows), 0, s, cp, A, nA, dA, B, nB, dB, diag_noise, out,
+                       ld, col0);
+}
+
+template <int DP>
+void grad_kstar_dp(const CovParams& cp, const double* X, int n, const DerivList& dX, const double* P, int nP,
+                   const DerivList& dP, double* out, long ld, long col0, hipStream_t s) {
+  const bool derivs = dX.g > 0 || dP.g > 0;
+  const int rows = n * (1 + dX.g);
+  if (rows == 0 || nP == 0) return;
+  dim3 grid((rows + 255) / 256);
+  const size_t shm = sizeof(double) * (size_t)nP * DP;
+  if (derivs)
+    hipLaunchKernelGGL((grad_kstar_kernel<DP, true>), grid, dim3(256), shm, s, cp, X, n, dX, P, nP, dP, out, ld, col0);
+  else
+    hipLaunchKernelGGL((grad_kstar_kernel<DP, false>), grid, dim3(256), shm, s, cp, X, n, dX, P, nP, dP, out, ld, col0);
+}
+
+}  // namespace
+
+void launch_cov_build(const CovParams& cp, const double* A, int nA, const DerivList& dA, const double* B, int nB,
+                      const DerivList& dB, const double* diag_noise, double* out, long ld, long col0, hipStream_t s) {
+  switch (cp.dp) {
+    case 4: cov_build_dp<4>(cp, A, nA, dA, B, nB, dB, diag_noise, out, ld, col0, s); break;
+    case 8: cov_build_dp<8>(cp, A, nA, dA, B, nB, dB, diag_noise, out, ld, col0, s); break;
+    case 12: cov_build_dp<12>(cp, A, nA, dA, B, nB, dB, diag_noise, out, ld, col0, s); break;
+    case 16: cov_build_dp<16>(cp, A, nA, dA, B, nB, dB, diag_noise, out, ld, col0, s); break;
+    default: throw Error(MOE_ERR_RUNTIME, "unsupported padded dimension");
+  }
+  MOE_HIP_CHECK(hipGetLastError());
+}
+
+void launch_grad_kstar(const CovParams& cp, const double* X, int n, const DerivList& dX, const double* P, int nP,
+                       const DerivList& dP, double* out, long ld, long col0, hipStream_t s) {
+  switch (cp.dp) {
+    case 4: grad_kstar_dp<4>(cp, X, n, dX, P, nP, dP, out, ld, col0, s); break;
+    case 8: grad_kstar_dp<8>(cp, X, n, dX, P, nP, dP, out, ld, col0, s); break;
+    case 12: grad_kstar_dp<12>(cp, X, n, dX, P, nP, dP, out, ld, col0, s); break;
+    case 16: grad_kstar_dp<16>(cp, X, n, dX, P, nP, dP, out, ld, col0, s); break;
+    default: throw Error(MOE_ERR_RUNTIME, "unsupported padded dimension");
+  }
+  MOE_HIP_CHECK(hipGetLastError());
+}
+
+}  // namespace moe

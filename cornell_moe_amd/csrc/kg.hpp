@@ -1,0 +1,19 @@
+// cornell_moe_amd/csrc/kg.hpp -- Monte-Carlo acquisition evaluators (q-EI, q-KG) on the device GP.
+#pragma once
+#include "gp.hpp"
+
+namespace moe {
+
+// ExpectedImprovementEvaluator::Compute[Grad]ExpectedImprovement (gpp_math.cpp:1991-2126).  normals[num_mc][q+p].
+void ei_evaluate(GpDev& gp, const double* Xq, const double* Xp, int q, int p, int num_mc, double best_so_far,
+                 const double* normals, double* ei, double* grad_ei);
+
+// KnowledgeGradientEvaluator::Compute[Grad]KnowledgeGradient (gpp_knowledge_gradient_optimization.cpp:69-227) for
+// `num_evals` independent points_to_sample sets; see include/moe_hip.h (moe_kg / moe_kg_batch) for argument meaning.
+// best_points (may be NULL) is only filled for num_evals == 1.
+void kg_evaluate_batch(GpDev& gp, int num_fidelity, const moe_gd_params_t& gd, const double* bounds, const double* discrete,
+                       int P, const double* Xq_all, int num_evals, const double* Xp, int q, int p, int num_mc,
+                       double best_so_far, const double* normals, int first_sample, int num_local, bool want_grad,
+                       double* kg_sum, double* grad_sum, double* best_points, moe_kg_stats_t* stats);
+
+}  // namespace moe

@@ -1,0 +1,173 @@
+/* include/moe_hip.h -- public C ABI of libmoe_hip.so (MI355X / gfx950).
+ *
+ * A drop-in for the one hot path of wujian16/Cornell-MOE: GP posterior + Monte-Carlo acquisition (q-EI, q-KG, d-KG).
+ * Each entry point states the reference interface it replaces (file:line under moe/optimal_learning/cpp/ of the
+ * reference).  The reference crosses this boundary through a boost::python module (`moe.build.GPP`,
+ * gpp_python.cpp:453-600); INTEGRATION.md shows the ctypes/pybind stub a maintainer would add to bind these symbols
+ * instead.
+ *
+ * Conventions (identical to the reference's Python boundary, gpp_python_common.cpp:52-129):
+ *   - all floating point is FP64; points are row-major [point][dim]; sizes are explicit ints;
+ *   - all pointers are HOST pointers owned by the caller unless the name ends in `_dev`;
+ *   - every function returns a status code (0 = ok) and, on failure, fills *err (may be NULL);
+ *     codes map one-to-one onto the reference's exception classes (gpp_exception.hpp:144-509).
+ *   - matrices returned to the caller are column-major exactly as the reference C++ fills them
+ *     (the Python shim applies the same symmetrisation / transposition as gpp_python_gaussian_process.cpp:136-185).
+ * There is NO CPU fallback: every compute entry point requires a visible gfx950 device and fails with
+ * MOE_ERR_RUNTIME otherwise.
+ */
+#ifndef MOE_HIP_H_
+#define MOE_HIP_H_
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MOE_OK 0
+#define MOE_ERR_RUNTIME 1        /* OptimalLearningException (gpp_exception.hpp:144) - also HIP runtime failures */
+#define MOE_ERR_BOUNDS 2         /* BoundsException<T>(value, min, max)        (gpp_exception.hpp:260) */
+#define MOE_ERR_INVALID_VALUE 3  /* InvalidValueException<T>(value, truth, tol) (gpp_exception.hpp:350) */
+#define MOE_ERR_SINGULAR 4       /* SingularMatrixException(num_rows, leading_minor_index) (gpp_exception.hpp:440) */
+
+#define MOE_COV_SQUARE_EXPONENTIAL 0 /* gpp_covariance.hpp:195 */
+#define MOE_COV_MATERN_NU_2P5 1      /* gpp_covariance.hpp:313 (what the Python boundary always builds, gpp_python_gaussian_process.cpp:53) */
+
+typedef struct moe_error {
+  int code;
+  char message[480];
+  double payload[3]; /* Bounds: value,min,max; InvalidValue: value,truth,tolerance; Singular: num_rows,leading_minor_index,0 */
+} moe_error_t;
+
+/* GradientDescentParameters (gpp_optimizer_parameters.hpp:81-133) */
+typedef struct moe_gd_params {
+  int num_multistarts;
+  int max_num_steps;
+  int max_num_restarts;
+  int num_steps_averaged;
+  double gamma;
+  double pre_mult;
+  double max_relative_change;
+  double tolerance;
+} moe_gd_params_t;
+
+/* Counters the device fills during one KG evaluation (S and G must be counted on device). */
+typedef struct moe_kg_stats {
+  long long posterior_mean_evals; /* value passes over the training set (incl. the discretised-set scan, per point) */
+  long long posterior_grad_evals; /* value+gradient passes */
+  double ms_state;                /* wall ms: state set-up (K*, solves, Var, chol, grad chol) */
+  double ms_mc;                   /* wall ms: MC inner-optimisation kernel */
+  double ms_tail;                 /* wall ms: gradient tail (N x M covariance build + contraction) */
+} moe_kg_stats_t;
+
+typedef struct moe_gp moe_gp_t; /* opaque; replaces the heap GaussianProcess owned by the Python object
+                                   (gpp_python_gaussian_process.cpp:55-61) */
+
+/* ---- runtime ---- */
+int moe_device_count(int* count);
+/* "gfx950" etc. of device `device`; name_len >= 64. */
+int moe_device_arch(int device, char* name, int name_len);
+const char* moe_version(void);
+
+/* ---- Gaussian process: GaussianProcess ctor (gpp_math.cpp:553-573, RecomputeDerivedVariables :481-511) ----
+ * hyperparameters = [alpha, length_0 .. length_{d-1}] (gpp_python_common.cpp:100-105). K assembly, Cholesky,
+ * triangular inverse and K^-1 (y - mean) run on device `device` and stay resident there.
+ * Fails with MOE_ERR_SINGULAR (payload: N, leading minor index) when a pivot <= 1e-16 (gpp_linear_algebra.cpp:118). */
+int moe_gp_create(const double* hyperparameters, int cov_type, const double* points_sampled,
+                  const double* points_sampled_value, const double* noise_variance, const int* derivatives,
+                  int num_derivatives, int dim, int num_sampled, int device, moe_gp_t** gp_out, moe_error_t* err);
+int moe_gp_destroy(moe_gp_t* gp);
+int moe_gp_dim(const moe_gp_t* gp);
+int moe_gp_num_sampled(const moe_gp_t* gp);
+int moe_gp_num_derivatives(const moe_gp_t* gp);
+/* AddPointsToGP (gpp_math.cpp:1699-1718): appends points and re-derives everything (mean included). */
+int moe_gp_add_points(moe_gp_t* gp, const double* new_points, const double* new_values, int num_new, moe_error_t* err);
+/* Debug/parity accessors: K_chol [N*N col-major, lower triangle valid], K_inv_y [N], mean (any may be NULL). */
+int moe_gp_get_factor(const moe_gp_t* gp, double* K_chol, double* K_inv_y, double* mean, moe_error_t* err);
+
+/* ---- posterior queries; semantics of the Python-visible methods (gpp_python_gaussian_process.cpp:64-236) ----
+ * m = num_pts * (1 + num_derivatives of the GP). */
+/* compute_mean_of_points -> ComputeMeanOfPoints (gpp_math.cpp:662-678); out[num_pts] (function values only) */
+int moe_gp_mean(const moe_gp_t* gp, const double* pts, int num_pts, double* out, moe_error_t* err);
+/* compute_mean_of_additional_points -> ComputeMeanOfAdditionalPoints (gpp_math.cpp:688-710); out[num_pts] */
+int moe_gp_additional_mean(const moe_gp_t* gp, const double* pts, int num_pts, double* out, moe_error_t* err);
+/* compute_grad_mean_of_points -> ComputeGradMeanOfPoints (gpp_math.cpp:721-726); out[dim * m] */
+int moe_gp_grad_mean(const moe_gp_t* gp, const double* pts, int num_pts, double* out, moe_error_t* err);
+/* compute_variance_of_points -> ComputeVarianceOfPoints (gpp_math.cpp:924-970); out[m*m] col-major */
+int moe_gp_variance(const moe_gp_t* gp, const double* pts, int num_pts, double* out, moe_error_t* err);
+/* compute_cholesky_variance_of_points: chol of the above (lower; strict upper holds the variance leftovers exactly like
+ * ComputeCholeskyFactorL leaves them); MOE_ERR_SINGULAR on failure */
+int moe_gp_cholesky_variance(const moe_gp_t* gp, const double* pts, int num_pts, double* out, moe_error_t* err);
+/* compute_grad_variance_of_points -> ComputeGradVarianceOfPoints (gpp_math.cpp:1359-1373); out[num_derivs][m][m][dim] */
+int moe_gp_grad_variance(const moe_gp_t* gp, const double* pts, int num_pts, int num_derivs, double* out, moe_error_t* err);
+/* compute_grad_cholesky_variance_of_points -> ComputeGradCholeskyVarianceOfPoints (gpp_math.cpp:1454-1474) */
+int moe_gp_grad_cholesky_variance(const moe_gp_t* gp, const double* pts, int num_pts, int num_derivs, double* out,
+                                  moe_error_t* err);
+
+/* compute_posterior_mean / compute_grad_posterior_mean (gpp_python_knowledge_gradient.cpp:44-72 ->
+ * PosteriorMeanEvaluator, gpp_knowledge_gradient_optimization.cpp:322-351). point[dim - num_fidelity];
+ * value = -mu(point, fidelity coords = 1); grad[dim - num_fidelity] = -grad mu. Either output may be NULL. */
+int moe_posterior_mean(const moe_gp_t* gp, int num_fidelity, const double* point, double* value, double* grad,
+                       moe_error_t* err);
+
+/* ---- normal draws ----
+ * Fills out[count] with N(0,1) draws from mt19937(seed) + Box-Muller, the host-side stand-in for NormalRNG
+ * (gpp_random.hpp:204-303).  boost::normal_distribution's draw algorithm is Boost-version dependent and the reference
+ * pins no draws, so draw-for-draw parity with a given Boost is NOT claimed; parity runs pass explicit tables. */
+int moe_normal_draws(unsigned int seed, long long count, double* out);
+
+/* ---- q,p-EI by Monte Carlo: compute_expected_improvement / compute_grad_expected_improvement
+ * (gpp_python_expected_improvement.cpp:44-109 -> ExpectedImprovementEvaluator, gpp_math.cpp:1991-2126).
+ * normals[num_mc][q+p] is the explicit N(0,1) table (row i feeds sample i, the role NormalRNGSimulator plays in the
+ * reference's tests, gpp_random.hpp:314-340).  ei and/or grad_ei[q*dim] may be NULL. */
+int moe_ei(const moe_gp_t* gp, const double* points_to_sample, const double* points_being_sampled, int num_to_sample,
+           int num_being_sampled, int num_mc, double best_so_far, const double* normals, double* ei, double* grad_ei,
+           moe_error_t* err);
+
+/* ---- q-KG / d-KG by Monte Carlo: compute_knowledge_gradient / compute_grad_knowledge_gradient
+ * (gpp_python_knowledge_gradient.cpp:74-154 -> KnowledgeGradientEvaluator<TensorProductDomain>,
+ * gpp_knowledge_gradient_optimization.cpp:69-227, state :246-317, inner optimisation :420-472,
+ * gpp_optimization.hpp:708-828/1242-1283, gpp_domain.cpp:64-105).
+ *   domain_bounds[2*(dim-num_fidelity)] = [min0,max0,...]; discrete_pts[num_pts][dim-num_fidelity];
+ *   normals[ceil(num_mc/2)][m], m = (q+p)(1+g): even sample 2j uses row j, odd sample 2j+1 uses -row j
+ *   (antithetic pairs, .cpp:171-180);
+ *   first_sample/num_local select the contiguous, even-aligned slice [first_sample, first_sample+num_local) of the MC
+ *   samples this call evaluates (multi-GPU sharding); pass 0,num_mc for the whole evaluation.
+ * Outputs: kg_sum = SUM over the local samples of (best_posterior + best_function_value) (divide by num_mc after the
+ * cross-rank sum); grad_sum[q*dim] likewise un-normalised, the winner term M*grad_mu (.cpp:157-161) being added only
+ * by the call with first_sample == 0; best_points[num_local][dim] (may be NULL); stats (may be NULL).
+ * want_grad = 0 reproduces ComputeKnowledgeGradient (value only). */
+int moe_kg(const moe_gp_t* gp, int num_fidelity, const moe_gd_params_t* inner_params, const double* domain_bounds,
+           const double* discrete_pts, int num_pts, const double* points_to_sample, const double* points_being_sampled,
+           int num_to_sample, int num_being_sampled, int num_mc, double best_so_far, const double* normals,
+           int first_sample, int num_local, int want_grad, double* kg_sum, double* grad_sum, double* best_points,
+           moe_kg_stats_t* stats, moe_error_t* err);
+
+/* Batched form: `num_evals` independent evaluations (different points_to_sample[e][q][dim], same GP / discrete set /
+ * normals) in one pass -- the multistart axis of ComputeKGOptimalPointsToSampleViaMultistartGradientDescent
+ * (gpp_knowledge_gradient_optimization.hpp:860-935) and EvaluateKGAtPointList (:1090-1141).
+ * kg_sum[num_evals], grad_sum[num_evals][q*dim]. */
+int moe_kg_batch(const moe_gp_t* gp, int num_fidelity, const moe_gd_params_t* inner_params, const double* domain_bounds,
+                 const double* discrete_pts, int num_pts, const double* points_to_sample_all, int num_evals,
+                 const double* points_being_sampled, int num_to_sample, int num_being_sampled, int num_mc,
+                 double best_so_far, const double* normals, int first_sample, int num_local, int want_grad,
+                 double* kg_sum, double* grad_sum, moe_kg_stats_t* stats, moe_error_t* err);
+
+/* ---- covariance assembly (exposed for parity tests and the HBM-roofline measurement) ----
+ * BuildMixCovarianceMatrix (gpp_math.cpp:309-335, 469-479): out[N x num_pts*(1+g2)] col-major = K(X, pts) with
+ * derivative blocks; derivs2[g2] are the derivative observations carried by `pts`. */
+int moe_gp_mix_covariance(const moe_gp_t* gp, const double* pts, int num_pts, const int* derivs2, int g2, double* out,
+                          moe_error_t* err);
+/* Timing probe: builds K(X, pts) [N x num_pts] on device `repeat` times without copying it back; returns the average
+ * kernel milliseconds (HIP events) and the algorithmic bytes per launch. */
+int moe_cov_build_probe(const moe_gp_t* gp, const double* pts, int num_pts, int repeat, double* avg_ms,
+                        double* bytes_per_launch, moe_error_t* err);
+
+/* Timing of the last moe_kg / moe_kg_batch call's dominant kernels, measured with HIP events on the library's stream:
+ * out[0] = MC inner-optimisation kernel ms, out[1] = N x M covariance-build ms, out[2] = tail contraction ms,
+ * out[3] = state set-up ms, out[4] = total device ms. */
+int moe_last_kernel_ms(const moe_gp_t* gp, double* out5);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MOE_HIP_H_ */
