@@ -64,6 +64,20 @@ def normal_draws(seed, count):
     return out
 
 
+def debug_cholesky(a, device=0):
+    """Device Cholesky + inverse factor of an SPD matrix (parity probe); returns (L, Linv) as [row, col] arrays."""
+    a = np.array(a, dtype=np.float64)
+    n = a.shape[0]
+    flat = np.ascontiguousarray(a.T).ravel()
+    chol = np.zeros(n * n)
+    inv = np.zeros(n * n)
+    info = C.c_int(0)
+    err = _lib.MoeError()
+    _check(_lib.load().moe_debug_cholesky(n, flat.ctypes.data_as(dp), int(device), chol.ctypes.data_as(dp),
+                                          inv.ctypes.data_as(dp), C.byref(info), C.byref(err)), err)
+    return chol.reshape(n, n).T.copy(), inv.reshape(n, n).T.copy()
+
+
 class DeviceGP(object):
     """Device-resident GP: handle around moe_gp_t (replaces the reference's C_GP.GaussianProcess object)."""
 

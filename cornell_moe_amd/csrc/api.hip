@@ -270,6 +270,30 @@ int moe_cov_build_probe(const moe_gp_t* gp_c, const double* pts, int num_pts, in
   });
 }
 
+int moe_debug_cholesky(int n, const double* a, int device, double* chol, double* chol_inv, int* info, moe_error_t* err) {
+  return guarded(err, [&] {
+    require(n > 0, "n must be positive");
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0)
+      throw moe::Error(MOE_ERR_RUNTIME, "no HIP device visible: libmoe_hip has no CPU fallback");
+    MOE_HIP_CHECK(hipSetDevice(device));
+    moe::DevBuf<double> dA, dLinv;
+    moe::DevBuf<int> dInfo;
+    hipStream_t s = nullptr;
+    dA.upload(a, (size_t)n * n, s);
+    dLinv.reserve((size_t)n * n);
+    dInfo.reserve(1);
+    moe::launch_cholesky_and_inverse(n, dA.p, n, dLinv.p, n, nullptr, dInfo.p, s);
+    int inf = 0;
+    dInfo.download(&inf, 1, s);
+    if (chol) dA.download(chol, (size_t)n * n, s);
+    if (chol_inv) dLinv.download(chol_inv, (size_t)n * n, s);
+    MOE_HIP_CHECK(hipStreamSynchronize(s));
+    if (info) *info = inf;
+    if (inf != 0) throw moe::Error(MOE_ERR_SINGULAR, "matrix singular in device Cholesky", n, inf);
+  });
+}
+
 int moe_last_kernel_ms(const moe_gp_t* gp, double* out5) {
   for (int i = 0; i < 5; ++i) out5[i] = gp->dev.last_ms[i];
   return MOE_OK;

@@ -249,7 +249,7 @@ __global__ __launch_bounds__(kWaves * 64) void kg_mc_kernel(KgMcParams P) {
     xq[k] = x[k] * P.cp.inv_l[k];
   }
 
-  unsigned long long n_val = P.A, n_grad = 0;  // the scan counts as A posterior-mean evaluations
+  unsigned long long n_val = 0, n_grad = 0;  // passes over the N+m points (the A-point scan is O(A m), not counted)
   const double step_tolerance = P.tolerance / (double)P.max_num_steps;
   double fcur = 0.0;
 

@@ -52,7 +52,7 @@ typedef struct moe_gd_params {
 
 /* Counters the device fills during one KG evaluation (S and G must be counted on device). */
 typedef struct moe_kg_stats {
-  long long posterior_mean_evals; /* value passes over the training set (incl. the discretised-set scan, per point) */
+  long long posterior_mean_evals; /* value-only passes over the N+m points made by the line search (all samples) */
   long long posterior_grad_evals; /* value+gradient passes */
   double ms_state;                /* wall ms: state set-up (K*, solves, Var, chol, grad chol) */
   double ms_mc;                   /* wall ms: MC inner-optimisation kernel */
@@ -161,6 +161,12 @@ int moe_gp_mix_covariance(const moe_gp_t* gp, const double* pts, int num_pts, co
  * kernel milliseconds (HIP events) and the algorithmic bytes per launch. */
 int moe_cov_build_probe(const moe_gp_t* gp, const double* pts, int num_pts, int repeat, double* avg_ms,
                         double* bytes_per_launch, moe_error_t* err);
+
+/* Parity probe of the device factorisation used by moe_gp_create: factors the SPD matrix a[n*n] (column-major, lower
+ * triangle read) with the blocked device Cholesky that replaces ComputeCholeskyFactorL (gpp_linear_algebra.cpp:109-148);
+ * writes the factor to chol[n*n] (strict upper = 0) and its explicit inverse to chol_inv[n*n]; *info = 0 or the failing
+ * leading-minor index (pivot <= 1e-16), in which case MOE_ERR_SINGULAR is returned. */
+int moe_debug_cholesky(int n, const double* a, int device, double* chol, double* chol_inv, int* info, moe_error_t* err);
 
 /* Timing of the last moe_kg / moe_kg_batch call's dominant kernels, measured with HIP events on the library's stream:
  * out[0] = MC inner-optimisation kernel ms, out[1] = N x M covariance-build ms, out[2] = tail contraction ms,

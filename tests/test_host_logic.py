@@ -1,0 +1,84 @@
+"""CPU tests (-m "not gpu"): host-side logic -- workloads, MC/restart sharding, and the N>1 collectives on gloo
+(world_size 2, multi-process) with a closed-form per-sample contribution standing in for the device evaluation of a shard."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+from cornell_moe_amd import dist as mdist
+from cornell_moe_amd.workloads import kg_normals_full, make_workload
+
+
+def test_workload_shapes_and_antithetic_table():
+    w = make_workload("C3", M=101)
+    assert w.X.shape == (1000, 8) and w.Xq.shape == (4, 8) and w.discrete.shape == (10, 8)
+    assert w.kg_normals.shape == (51, 4)
+    full = kg_normals_full(w)
+    assert full.shape == (101, 4)
+    assert np.array_equal(full[0::2], w.kg_normals) and np.array_equal(full[1::2], -w.kg_normals[:50])
+    w5 = make_workload("C5", n=20, M=8)
+    assert w5.y.shape == (20, 4) and w5.m == 8 * 4 and w5.derivs == (0, 1, 2)
+
+
+@pytest.mark.parametrize("num_mc,world", [(10000, 8), (10000, 3), (7, 2), (1, 4), (2, 8), (101, 5)])
+def test_shard_samples_partition(num_mc, world):
+    cover = []
+    for r in range(world):
+        first, count = mdist.shard_samples(num_mc, r, world)
+        assert first % 2 == 0 and count >= 0
+        if count:
+            assert first + count <= num_mc
+            assert count % 2 == 0 or first + count == num_mc  # only the globally last slice may end on an odd count
+        cover.extend(range(first, first + count))
+    assert cover == list(range(num_mc))
+
+
+def test_shard_restarts_partition():
+    allr = sorted(sum((mdist.shard_restarts(64, r, 8) for r in range(8)), []))
+    assert allr == list(range(64))
+    assert mdist.shard_restarts(3, 2, 8) == [2] and mdist.shard_restarts(3, 5, 8) == []
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, num_mc, q, d, ret):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        # per-sample contributions known in closed form: sample i contributes (i + 1) to KG and i * ones to grad
+        def eval_shard(first, count):
+            idx = np.arange(first, first + count, dtype=np.float64)
+            return float(np.sum(idx + 1.0)), np.sum(idx) * np.ones((q, d))
+        kg, grad = mdist.kg_grad_mc_sharded(eval_shard, num_mc, rank, world)
+        mine = mdist.shard_restarts(5, rank, world)
+        lkg = [10.0 + i for i in mine]
+        lgrad = np.array([np.full((q, d), float(i)) for i in mine]).reshape(len(mine), q, d)
+        akg, agrad = mdist.gather_restarts(mine, lkg, lgrad, 5)
+        ret[rank] = (kg, grad, akg, agrad)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_gloo_world2_allreduce_and_gather():
+    import torch.multiprocessing as mp
+    world, num_mc, q, d = 2, 1001, 2, 3
+    port = _free_port()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(world, port, num_mc, q, d, ret), nprocs=world, join=True)
+    total = num_mc * (num_mc + 1) / 2.0
+    for r in range(world):
+        kg, grad, akg, agrad = ret[r]
+        assert kg == pytest.approx(total / num_mc, rel=1e-15)
+        assert np.allclose(grad, (num_mc * (num_mc - 1) / 2.0) / num_mc, rtol=1e-15)
+        assert np.array_equal(akg, 10.0 + np.arange(5))
+        assert all(np.all(agrad[i] == i) for i in range(5))

@@ -1,0 +1,110 @@
+"""CPU tests (-m "not gpu"): the plain-C restatement (oracle/moe_oracle.c) against
+ (1) the reference's own known-answer vectors (gpp_linear_algebra_test.cpp:237-262),
+ (2) the committed golden fixtures generated from the unmodified reference (tools/make_golden.py),
+ (3) the unmodified reference itself (oracle/_ref) when it is built (it is wherever /root/reference exists)."""
+import numpy as np
+import pytest
+
+from helpers import TOL, kg_tolerances, rel
+from oracle import orc, ref
+
+
+def _gp(c):
+    i = c.inp
+    return orc.OrcGP(int(i["cov_type"]), float(i["alpha"]), i["lengths"], i["X"], i["y"], i["noise"], list(i["derivs"]))
+
+
+def test_known_answer_cholesky(golden):
+    _, la = golden
+    for name in ("la_A", "la_B"):
+        rc, L = orc.cholesky(la[name])
+        assert rc == 0
+        assert np.array_equal(np.tril(L), la[name + "_chol"])  # exact: small-integer inputs (reference checks with tol 0)
+    # pivot failure reporting (gpp_linear_algebra.cpp:118, 141-142): leading minor index = k + 1
+    bad = np.array([[4.0, 2.0], [2.0, 1.0]])
+    rc, _ = orc.cholesky(bad)
+    assert rc == 2
+    x = orc.chol_solve(la["la_A_chol"], la["la_A"] @ np.array([1.0, -2.0, 3.0, 0.5]))
+    assert np.allclose(x, [1.0, -2.0, 3.0, 0.5], rtol=1e-13)
+
+
+def test_golden_gp_and_posterior(golden):
+    cases, _ = golden
+    for c in cases:
+        gp = _gp(c)
+        K, kiy, mean = gp.dump()
+        assert rel(np.tril(K), c.out["K_chol"]) < TOL["K_chol"]
+        assert rel(kiy, c.out["K_inv_y"]) < TOL["K_inv_y"]
+        assert abs(mean - float(c.out["mean"])) < 1e-13
+        pts = c.inp["query"]
+        m4 = 4 * (1 + gp.g)
+        assert rel(gp.mean(pts), c.out["q_mean"]) < TOL["q_mean"]
+        assert rel(gp.grad_mean(pts), c.out["q_grad_mean"]) < TOL["q_grad_mean"]
+        assert rel(gp.var(pts), c.out["q_var"]) < TOL["q_var"]
+        assert rel(np.tril(gp.chol_var(pts).reshape(m4, m4).T), c.out["q_chol_var"]) < TOL["q_chol_var"]
+        assert rel(gp.grad_var(pts, 2), c.out["q_grad_var"]) < TOL["q_grad_var"]
+        assert rel(gp.grad_chol_var(pts, 2), c.out["q_grad_chol_var"]) < TOL["q_grad_chol_var"]
+        assert rel(gp.mix_cov(pts, list(c.inp["derivs"])), c.out["q_mix_cov"]) < TOL["q_mix_cov"]
+
+
+def test_golden_ei_kg(golden):
+    cases, _ = golden
+    for c in cases:
+        gp = _gp(c)
+        i = c.inp
+        Xp = i["Xp"] if int(i["p"]) > 0 else None
+        ei, gei = gp.ei(i["Xq"], Xp, int(i["M"]), float(i["ei_best"]), i["ei_normals"])
+        assert abs(ei - float(c.out["ei"])) <= TOL["ei"] * max(abs(float(c.out["ei"])), 1e-3)
+        assert rel(gei, c.out["grad_ei"]) < TOL["grad_ei"]
+        r = gp.kg(i["inner_gd"], i["bounds"], i["discrete"], i["Xq"], Xp, int(i["M"]), float(i["best_so_far"]), i["kg_normals"])
+        assert abs(r["kg"] - float(c.out["kg"])) <= TOL["kg"] * abs(float(c.out["kg"]))
+        gtol, ptol = kg_tolerances(c)
+        assert np.abs(r["grad"] - c.out["grad_kg"]).max() <= gtol
+        assert np.abs(r["best_point"] - c.out["kg_best_point"]).max() <= ptol
+        rv = gp.kg(i["inner_gd"], i["bounds"], i["discrete"], i["Xq"], Xp, int(i["M"]), float(i["best_so_far"]), i["kg_normals"],
+                   want_grad=False)
+        assert abs(rv["kg"] - float(c.out["kg_value_only"])) <= TOL["kg"] * abs(float(c.out["kg_value_only"]))
+
+
+def test_singular_detection():
+    X = np.array([[0.1, 0.2], [0.1, 0.2], [0.5, 0.5]])
+    with pytest.raises(orc.SingularMatrix):
+        orc.OrcGP(1, 1.0, [1.0, 1.0], X, np.zeros((3, 1)), [0.0], ())
+
+
+@pytest.mark.skipif(not ref.available(), reason="oracle/_ref not built (reference tree absent)")
+def test_restatement_vs_live_reference():
+    """Fresh random cases straight against the unmodified reference (not just the stored fixtures)."""
+    rng = np.random.default_rng(99)
+    for cov_type in (0, 1):
+        for derivs in ((), (0, 2)):
+            n, d, q, p, P, M = 25, 3, 2, 1, 4, 24
+            g = len(derivs)
+            X = rng.uniform(size=(n, d))
+            y = rng.uniform(-1, 1, size=(n, 1 + g))
+            lengths = rng.uniform(0.4, 1.2, size=d)
+            noise = np.full(1 + g, 0.05)
+            R = ref.RefGP(cov_type, 1.4, lengths, X, y, noise, derivs)
+            O = orc.OrcGP(cov_type, 1.4, lengths, X, y, noise, derivs)
+            pts = rng.uniform(size=(3, d))
+            for name, args in (("mean", ()), ("grad_mean", ()), ("var", ()), ("grad_var", (2,)), ("grad_chol_var", (2,))):
+                assert rel(getattr(O, name)(pts, *args), getattr(R, name)(pts, *args)) < 1e-10, name
+            for a in range(3):  # covariance blocks incl. coincident points
+                p1, p2 = pts[a], (pts[a] if a == 2 else pts[(a + 1) % 3])
+                cr, gr = ref.covariance(cov_type, 1.4, lengths, p1, derivs, p2, derivs)
+                co, go = orc.covariance(cov_type, 1.4, lengths, p1, derivs, p2, derivs)
+                assert np.allclose(co, cr, rtol=1e-14, atol=1e-300) and np.allclose(go, gr, rtol=1e-14, atol=1e-300)
+            Xq, Xp, disc = rng.uniform(size=(q, d)), rng.uniform(size=(p, d)), rng.uniform(size=(P, d))
+            m = (q + p) * (1 + g)
+            nm = rng.standard_normal(((M + 1) // 2, m))
+            gd = (1, 6, 1, 3, 0.0, 1.0, 0.1, 1e-10)
+            bounds = np.tile([0.0, 1.0], d)
+            best = float(R.additional_mean(disc).min())
+            kr = R.kg(gd, bounds, disc, Xq, Xp, M, best, nm)
+            ko = O.kg(gd, bounds, disc, Xq, Xp, M, best, nm)
+            assert abs(kr["kg"] - ko["kg"]) < 1e-10 * abs(kr["kg"])
+            assert rel(ko["grad"], kr["grad"]) < 1e-9
+            en = rng.standard_normal((M, q + p))
+            er, gr_, _ = R.ei(Xq, Xp, M, float(np.median(y[:, 0])), en)
+            eo, go_ = O.ei(Xq, Xp, M, float(np.median(y[:, 0])), en)
+            assert abs(er - eo) < 1e-12 and rel(go_, gr_) < 1e-10

@@ -1,0 +1,122 @@
+"""Generate tests/golden/ref_fixtures.npz from the UNMODIFIED reference (oracle/_ref, built from /root/reference).
+
+Run where /root/reference exists:   python tools/make_golden.py
+The fixtures pin oracle/moe_oracle.c and the device path on boxes where the reference is absent.  Cases follow the shapes
+of the reference's own ping-test fixtures (gpp_knowledge_gradient_optimization_test.cpp:384-441, gpp_math_test.cpp:1446-1702):
+dim=3, num_sampled=7, q in {1,2,3}, p in {0,2}, num_pts=5, derivatives {0,1,2} or none, 16 MC iterations, alpha=2.80723,
+lengths ~ U(0.5,2.5), data ~ U(-5,5), noise 0.1, best_so_far=7.0 -- plus a few larger synthetic cases.
+"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import ref  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden", "ref_fixtures.npz")
+
+
+def make_case(seed, n, d, q, p, P, derivs, M, cov_type, alpha, noise, best_so_far, box, inner_gd, data_scale=5.0,
+              length_range=(0.5, 2.5)):
+    rng = np.random.default_rng(seed)
+    g = len(derivs)
+    c = dict(seed=seed, n=n, d=d, q=q, p=p, P=P, derivs=np.array(derivs, dtype=np.int32), M=M, cov_type=cov_type,
+             alpha=alpha, best_so_far=best_so_far, inner_gd=np.array(inner_gd, dtype=np.float64))
+    c["lengths"] = rng.uniform(length_range[0], length_range[1], size=d)
+    c["X"] = rng.uniform(box[0], box[1], size=(n, d))
+    c["y"] = rng.uniform(-data_scale, data_scale, size=(n, 1 + g))
+    c["noise"] = np.full(1 + g, noise)
+    c["bounds"] = np.tile(np.array(box, dtype=np.float64), d)
+    c["Xq"] = rng.uniform(box[0], box[1], size=(q, d))
+    c["Xp"] = rng.uniform(box[0], box[1], size=(p, d))
+    c["discrete"] = rng.uniform(box[0], box[1], size=(P, d))
+    c["query"] = rng.uniform(box[0], box[1], size=(4, d))
+    m = (q + p) * (1 + g)
+    c["kg_normals"] = rng.standard_normal(size=((M + 1) // 2, m))
+    c["ei_normals"] = rng.standard_normal(size=(M, q + p))
+    return c
+
+
+def run_case(c):
+    gp = ref.RefGP(int(c["cov_type"]), float(c["alpha"]), c["lengths"], c["X"], c["y"], c["noise"], list(c["derivs"]))
+    out = {}
+    K, kiy, mean = gp.dump()
+    out["K_chol"] = np.tril(K)
+    out["K_inv_y"] = kiy
+    out["mean"] = np.array(mean)
+    pts = c["query"]
+    g = len(c["derivs"])
+    m4 = 4 * (1 + g)
+    out["q_mean"] = gp.mean(pts)
+    out["q_grad_mean"] = gp.grad_mean(pts)
+    out["q_var"] = gp.var(pts)
+    out["q_chol_var"] = np.tril(gp.chol_var(pts).reshape(m4, m4).T)
+    out["q_grad_var"] = gp.grad_var(pts, 2)
+    out["q_grad_chol_var"] = gp.grad_chol_var(pts, 2)
+    out["q_mix_cov"] = gp.mix_cov(pts, list(c["derivs"]))
+    pm, pg = gp.posterior_mean(pts[0])
+    out["post_mean"] = np.array(pm)
+    out["post_grad"] = pg
+    Xp = c["Xp"] if c["p"] > 0 else None
+    ei, gei, _ = gp.ei(c["Xq"], Xp, int(c["M"]), float(c["ei_best"]), c["ei_normals"])
+    out["ei"] = np.array(ei)
+    out["grad_ei"] = gei
+    r = gp.kg(c["inner_gd"], c["bounds"], c["discrete"], c["Xq"], Xp, int(c["M"]), float(c["best_so_far"]), c["kg_normals"],
+              want_grad=True, details=True)
+    out["kg"] = np.array(r["kg"])
+    out["grad_kg"] = r["grad"]
+    out["kg_best_point"] = r["best_point"]
+    out["kg_to_sample_mean"] = r["to_sample_mean"]
+    out["kg_chol_var"] = r["chol_var"]
+    rv = gp.kg(c["inner_gd"], c["bounds"], c["discrete"], c["Xq"], Xp, int(c["M"]), float(c["best_so_far"]), c["kg_normals"],
+               want_grad=False)
+    out["kg_value_only"] = np.array(rv["kg"])
+    return out
+
+
+def main():
+    cases = []
+    inner_test = (1, 100, 10, 3, 0.0, 1.0, 0.1, 1e-10)   # inner GD of the reference's KG ping test (100 steps, 10 restarts)
+    inner_prod = (1, 6, 1, 3, 0.0, 1.0, 0.1, 1e-10)      # examples/main.py:123-130
+    k = 0
+    for (q, p) in [(1, 0), (2, 0), (1, 2), (3, 2)]:
+        for derivs in [(), (0, 1, 2)]:
+            cases.append(make_case(3141 + k, 7, 3, q, p, 5, derivs, 16, 0, 2.80723, 0.1, 7.0, (-5.0, 5.0), inner_test))
+            k += 1
+    for derivs in [(), (1,)]:
+        cases.append(make_case(2718 + k, 7, 3, 2, 1, 5, derivs, 16, 1, 2.80723, 0.1, 7.0, (-5.0, 5.0), inner_prod))
+        k += 1
+    # larger synthetic cases in the unit box (SURVEY 8d style)
+    cases.append(make_case(1001, 60, 4, 2, 0, 10, (), 64, 1, 1.0, 0.01, 0.0, (0.0, 1.0), inner_prod, data_scale=1.0,
+                           length_range=(0.6, 0.8)))
+    cases.append(make_case(1002, 80, 5, 3, 1, 10, (), 64, 0, 1.3, 0.05, 0.2, (0.0, 1.0), inner_prod, data_scale=1.0,
+                           length_range=(0.5, 0.9)))
+    cases.append(make_case(1003, 40, 3, 2, 1, 6, (0, 2), 32, 1, 1.0, 0.1, 0.3, (0.0, 1.0), inner_prod, data_scale=1.0,
+                           length_range=(0.5, 0.9)))
+    blob = {"num_cases": np.array(len(cases))}
+    for i, c in enumerate(cases):
+        c["ei_best"] = float(np.median(c["y"][:, 0]))
+        out = run_case(c)
+        for key, val in c.items():
+            blob["c%d_in_%s" % (i, key)] = np.asarray(val)
+        for key, val in out.items():
+            blob["c%d_out_%s" % (i, key)] = np.asarray(val)
+        print("case %d: n=%d d=%d q=%d p=%d g=%d cov=%d  KG=%.12g  EI=%.12g" % (
+            i, c["n"], c["d"], c["q"], c["p"], len(c["derivs"]), c["cov_type"], float(out["kg"]), float(out["ei"])))
+    # the reference's own known-answer vectors (gpp_linear_algebra_test.cpp:237-262), restated as data
+    blob["la_A"] = np.array([[81.0, 27.0, 0.0, 90.0], [27.0, 13.0, 8.0, 44.0], [0.0, 8.0, 52.0, 40.0], [90.0, 44.0, 40.0, 217.0]])
+    blob["la_A_chol"] = np.array([[9.0, 0, 0, 0], [3.0, 2.0, 0, 0], [0.0, 4.0, 6.0, 0], [10.0, 7.0, 2.0, 8.0]])
+    blob["la_B"] = np.array([[25.0, 15.0, -5.0], [15.0, 18.0, 0.0], [-5.0, 0.0, 11.0]])
+    blob["la_B_chol"] = np.array([[5.0, 0, 0], [3.0, 3.0, 0], [-1.0, 1.0, 3.0]])
+    for name in ("la_A", "la_B"):
+        rc, Lr = ref.cholesky(blob[name])
+        assert rc == 0 and np.array_equal(np.tril(Lr), blob[name + "_chol"]), "reference disagrees with its own golden vector"
+    os.makedirs(os.path.dirname(OUT), exist_ok=True)
+    np.savez_compressed(OUT, **blob)
+    print("wrote", OUT, os.path.getsize(OUT), "bytes")
+
+
+if __name__ == "__main__":
+    main()
