@@ -63,7 +63,7 @@ def main():
     ap.add_argument("--restarts", type=int, default=8, help="independent KG evaluations per GPU per step")
     ap.add_argument("--shard", choices=["restarts", "mc"], default="restarts")
     ap.add_argument("--config", default="C3")
-    ap.add_argument("--cpu-sample-mc", type=int, default=1000)
+    ap.add_argument("--cpu-sample-mc", type=int, default=400)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 

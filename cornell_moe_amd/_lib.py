@@ -58,6 +58,7 @@ SIGNATURES = {
     "moe_gp_mix_covariance": (C.c_int, [_GP, dp, C.c_int, ip, C.c_int, dp, _EP]),
     "moe_cov_build_probe": (C.c_int, [_GP, dp, C.c_int, C.c_int, dp, dp, _EP]),
     "moe_debug_cholesky": (C.c_int, [C.c_int, dp, C.c_int, dp, dp, ip, _EP]),
+    "moe_debug_math": (C.c_int, [C.c_int, dp, C.c_int, dp, dp, _EP]),
     "moe_last_kernel_ms": (C.c_int, [_GP, dp]),
 }
 

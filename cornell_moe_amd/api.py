@@ -78,6 +78,16 @@ def debug_cholesky(a, device=0):
     return chol.reshape(n, n).T.copy(), inv.reshape(n, n).T.copy()
 
 
+def debug_math(x, device=0):
+    """(exp(-x), sqrt(x)) evaluated by the device fast-math routines, x >= 0."""
+    x, xp = _d(x)
+    e = np.zeros(x.size)
+    r = np.zeros(x.size)
+    err = _lib.MoeError()
+    _check(_lib.load().moe_debug_math(x.size, xp, int(device), e.ctypes.data_as(dp), r.ctypes.data_as(dp), C.byref(err)), err)
+    return e, r
+
+
 class DeviceGP(object):
     """Device-resident GP: handle around moe_gp_t (replaces the reference's C_GP.GaussianProcess object)."""
 

@@ -294,6 +294,23 @@ int moe_debug_cholesky(int n, const double* a, int device, double* chol, double*
   });
 }
 
+int moe_debug_math(int n, const double* x, int device, double* exp_neg, double* sqrt_out, moe_error_t* err) {
+  return guarded(err, [&] {
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0)
+      throw moe::Error(MOE_ERR_RUNTIME, "no HIP device visible: libmoe_hip has no CPU fallback");
+    MOE_HIP_CHECK(hipSetDevice(device));
+    moe::DevBuf<double> dx, de, dr;
+    dx.upload(x, n, nullptr);
+    de.reserve(n);
+    dr.reserve(n);
+    moe::launch_debug_math(dx.p, n, de.p, dr.p, nullptr);
+    de.download(exp_neg, n, nullptr);
+    dr.download(sqrt_out, n, nullptr);
+    MOE_HIP_CHECK(hipStreamSynchronize(nullptr));
+  });
+}
+
 int moe_last_kernel_ms(const moe_gp_t* gp, double* out5) {
   for (int i = 0; i < 5; ++i) out5[i] = gp->dev.last_ms[i];
   return MOE_OK;

@@ -10,6 +10,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include "fastmath.hpp"
 #include "kernels.hpp"
 
 namespace moe {
@@ -20,21 +21,30 @@ struct Radial {
 
 __host__ __device__ __forceinline__ Radial radial_scalars(int type, double alpha, double r2) {
   Radial r;
+#if defined(__HIP_DEVICE_COMPILE__)
+#define MOE_EXP_NONPOS(x) exp_nonpos(x)
+#define MOE_SQRT_NONNEG(x) sqrt_nonneg(x)
+#else  // host side of the same formulas (host_math.hip)
+#define MOE_EXP_NONPOS(x) exp(x)
+#define MOE_SQRT_NONNEG(x) sqrt(x)
+#endif
   if (type == MOE_COV_SQUARE_EXPONENTIAL) {
-    const double k = alpha * exp(-0.5 * r2);
+    const double k = alpha * MOE_EXP_NONPOS(-0.5 * r2);
     r.base = k;
     r.first = k;
     r.second = k;
     r.third = k;
   } else {
-    const double s = sqrt(r2);
+    const double s = MOE_SQRT_NONNEG(r2);
     const double a = 2.236067977499789696409173668731276235 * s;
-    const double e = exp(-a);
+    const double e = MOE_EXP_NONPOS(-a);
     r.base = alpha * e * (1.0 + a + (5.0 / 3.0) * r2);
     r.first = (5.0 / 3.0) * alpha * e * (a + 1.0);
     r.second = (25.0 / 3.0) * alpha * e;
     r.third = (r2 > 0.0) ? r.second * 2.236067977499789696409173668731276235 / s : 0.0;
   }
+#undef MOE_EXP_NONPOS
+#undef MOE_SQRT_NONNEG
   return r;
 }
 

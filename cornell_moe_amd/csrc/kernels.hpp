@@ -40,6 +40,9 @@ void launch_cov_build(const CovParams& cp, const double* A, int nA, const DerivL
 void launch_grad_kstar(const CovParams& cp, const double* X, int n, const DerivList& dX, const double* P, int nP,
                        const DerivList& dP, double* out, long ld, long col0, hipStream_t s);
 
+// e[i] = exp_nonpos(-x[i]), r[i] = sqrt_nonneg(x[i])  (accuracy probe of fastmath.hpp)
+void launch_debug_math(const double* x, int n, double* e, double* r, hipStream_t s);
+
 // C[N x c] (ldc) = op(T) * B[N x c] (ldb); T lower-triangular N x N (ldt), op = 'N' or 'T'.
 void launch_tri_gemm(char op, int N, int c, const double* T, long ldt, const double* B, long ldb, double* C, long ldc,
                      hipStream_t s);

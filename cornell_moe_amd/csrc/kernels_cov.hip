@@ -127,7 +127,19 @@ void grad_kstar_dp(const CovParams& cp, const double* X, int n, const DerivList&
     hipLaunchKernelGGL((grad_kstar_kernel<DP, false>), grid, dim3(256), shm, s, cp, X, n, dX, P, nP, dP, out, ld, col0);
 }
 
+__global__ void debug_math_kernel(const double* __restrict__ x, int n, double* __restrict__ e, double* __restrict__ r) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  e[i] = exp_nonpos(-x[i]);
+  r[i] = sqrt_nonneg(x[i]);
+}
+
 }  // namespace
+
+void launch_debug_math(const double* x, int n, double* e, double* r, hipStream_t s) {
+  hipLaunchKernelGGL(debug_math_kernel, dim3((n + 255) / 256), dim3(256), 0, s, x, n, e, r);
+  MOE_HIP_CHECK(hipGetLastError());
+}
 
 void launch_cov_build(const CovParams& cp, const double* A, int nA, const DerivList& dA, const double* B, int nB,
                       const DerivList& dB, const double* diag_noise, double* out, long ld, long col0, hipStream_t s) {

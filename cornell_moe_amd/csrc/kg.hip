@@ -24,6 +24,7 @@
 #include <cmath>
 
 #include "device_cov.hpp"
+#include "fastmath.hpp"
 
 namespace moe {
 
@@ -71,17 +72,18 @@ __device__ __forceinline__ double uniform(double v) {
   return __hiloint2double(hi, lo);
 }
 
-// base = cov[0,0], first = coefficient of the gradient (see device_cov.hpp) -- the two scalars the inner loop needs.
+// base = cov[0,0] / alpha, first = (gradient coefficient) / alpha (see device_cov.hpp) -- the two scalars the inner loop
+// needs; alpha is folded into the per-sample weights.  want_first is wave-uniform.
 template <int COV>
-__device__ __forceinline__ void radial2(double alpha, double r2, double& base, double& first) {
+__device__ __forceinline__ void radial2(double r2, bool want_first, double& base, double& first) {
   if (COV == MOE_COV_SQUARE_EXPONENTIAL) {
-    base = alpha * exp(-0.5 * r2);
+    base = exp_nonpos(-0.5 * r2);
     first = base;
   } else {
-    const double a = 2.236067977499789696409173668731276235 * sqrt(r2);
-    const double ae = alpha * exp(-a);
-    base = ae * (1.0 + a + (5.0 / 3.0) * r2);
-    first = (5.0 / 3.0) * ae * (a + 1.0);
+    const double a = 2.236067977499789696409173668731276235 * sqrt_nonneg(r2);
+    const double e = exp_nonpos(-a);
+    base = e * fma(a, fma(a, 1.0 / 3.0, 1.0), 1.0);  // e^-a (1 + a + a^2/3)   [5 r2 / 3 == a^2 / 3]
+    first = want_first ? (5.0 / 3.0) * (e * (a + 1.0)) : 0.0;
   }
 }
 
@@ -105,9 +107,9 @@ __device__ __forceinline__ double eval_point(const double* __restrict__ xs, cons
       diff[k] = xs[k * ldx + j] - xq[k];
       r2 = fma(diff[k], diff[k], r2);
     }
-    const double aj = aw[j];
+    const double aj = aw[j];  // alpha * a_i[j]
     double base, first;
-    radial2<COV>(P.cp.alpha, r2, base, first);
+    radial2<COV>(r2, want_grad, base, first);
     accf = fma(aj, base, accf);
     if (want_grad) {
       const double coef = aj * first;
@@ -213,7 +215,7 @@ __global__ __launch_bounds__(kWaves * 64) void kg_mc_kernel(KgMcParams P) {
       for (int c = 0; c < MU; ++c)
         if (j - P.n == c) v = beta[c];
     }
-    aw[j] = v;
+    aw[j] = P.cp.alpha * v;
   }
   // (each lane only ever reads back the aw[] entries it wrote itself: j = lane mod 64 -- no cross-lane hazard)
 

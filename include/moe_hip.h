@@ -168,6 +168,10 @@ int moe_cov_build_probe(const moe_gp_t* gp, const double* pts, int num_pts, int 
  * leading-minor index (pivot <= 1e-16), in which case MOE_ERR_SINGULAR is returned. */
 int moe_debug_cholesky(int n, const double* a, int device, double* chol, double* chol_inv, int* info, moe_error_t* err);
 
+/* Accuracy probe of the device exp / sqrt used inside the covariance loops (csrc/fastmath.hpp):
+ * exp_neg[i] = exp(-x[i]), sqrt_out[i] = sqrt(x[i]) for x[i] >= 0. */
+int moe_debug_math(int n, const double* x, int device, double* exp_neg, double* sqrt_out, moe_error_t* err);
+
 /* Timing of the last moe_kg / moe_kg_batch call's dominant kernels, measured with HIP events on the library's stream:
  * out[0] = MC inner-optimisation kernel ms, out[1] = N x M covariance-build ms, out[2] = tail contraction ms,
  * out[3] = state set-up ms, out[4] = total device ms. */

@@ -214,3 +214,20 @@ def test_add_points_matches_fresh_build(api):
     b = api.DeviceGP([1.2, 0.5, 0.6, 0.7], X, y, [0.02])
     q = rng.uniform(size=(7, 3))
     assert np.array_equal(a.mean(q), b.mean(q)) and np.array_equal(a.variance(q), b.variance(q))
+
+
+def test_fastmath(api):
+    """Device exp(-x) / sqrt(x) (csrc/fastmath.hpp) vs numpy: <= 2 ulp over the ranges the covariance loops produce."""
+    rng = np.random.default_rng(5)
+    x = np.concatenate([[0.0, 1e-300, 1e-200, 1e-30, 1e-16, 0.5, 1.0, 2.0, 700.0, 745.0, 800.0],
+                        rng.uniform(0, 40, 200000), 10.0 ** rng.uniform(-12, 2.5, 200000)])
+    e, r = api.debug_math(x)
+    ref_e, ref_r = np.exp(-x), np.sqrt(x)
+    big = ref_e > 1e-300
+    ulp_e = np.abs(e[big] - ref_e[big]) / np.spacing(ref_e[big])
+    assert ulp_e.max() <= 2.0, ulp_e.max()
+    assert np.all(e[~big] <= 1e-299)
+    pos = x >= 1e-290
+    ulp_r = np.abs(r[pos] - ref_r[pos]) / np.spacing(ref_r[pos])
+    assert ulp_r.max() <= 1.0, ulp_r.max()
+    assert r[0] == 1e-150 and e[0] == 1.0

@@ -8,5 +8,5 @@ timeout 120 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -3 | 
 timeout 600 python bench.py --steps 10 --warmup 2 2> gpurun_out/bench.err | tee gpurun_out/bench.json
 tail -5 gpurun_out/bench.err
 export TMPDIR=/tmp
-cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d "$GRAFT_REPO_ROOT/gpurun_out/prof" -o kg -- python "$GRAFT_REPO_ROOT/bench.py" --steps 5 --warmup 1 --no-cpu-baseline > "$GRAFT_REPO_ROOT/gpurun_out/prof_bench.json" 2> "$GRAFT_REPO_ROOT/gpurun_out/prof.err"
+cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$GRAFT_REPO_ROOT/gpurun_out/prof" -o kg -- python "$GRAFT_REPO_ROOT/bench.py" --steps 5 --warmup 1 --no-cpu-baseline > "$GRAFT_REPO_ROOT/gpurun_out/prof_bench.json" 2> "$GRAFT_REPO_ROOT/gpurun_out/prof.err"
 cd "$GRAFT_REPO_ROOT"; find gpurun_out/prof -name "*stats*" | head; 
