@@ -1,0 +1,426 @@
+"""Drop-in for the reference's ``moe.build.GPP`` extension module (BOOST_PYTHON_MODULE(GPP), gpp_python.cpp:453-600),
+restricted to the GP-posterior + Monte-Carlo acquisition hot path and backed by libmoe_hip.so (include/moe_hip.h).
+
+Every name below carries the Python-visible signature of the boost::python export it replaces, so
+``moe/optimal_learning/python/cpp_wrappers/*.py`` can run unchanged on top of it after
+
+    import cornell_moe_amd.GPP, sys; sys.modules["moe.build.GPP"] = cornell_moe_amd.GPP
+
+(INTEGRATION.md).  Data conventions are the reference's (gpp_python_common.cpp:52-129): inputs are flat Python lists of
+float (row-major ``[point][dim]``), sizes are explicit ints, outputs are new Python lists.
+
+Randomness: the reference seeds boost::mt19937 + boost::normal_distribution, whose draw algorithm is Boost-version
+dependent and pinned by no reference test.  Here a RandomnessSourceContainer seeds ``moe_normal_draws``
+(mt19937 + Box-Muller); the *semantics* are kept -- thread i is seeded ``seed + i`` (gpp_python_common.cpp:152-156), and
+every evaluation first rewinds to the most recent seed (gpp_knowledge_gradient_optimization.cpp:164, gpp_math.cpp:2076),
+so repeated calls use common random numbers -- but draw-for-draw equality with a given Boost is not claimed.
+There is no CPU fallback: every compute entry point needs a visible gfx950 device.
+"""
+import os
+import time
+
+import numpy as np
+
+from . import _lib
+from . import api as _api
+from .api import (BoundsException, InvalidValueException, OptimalLearningException,  # noqa: F401  (module-level exports)
+                  SingularMatrixException)
+
+
+# ---- enums (gpp_python_common.cpp:200-241) ----
+class _Enum(object):
+    def __init__(self, name, value):
+        self.name, self.value = name, value
+
+    def __repr__(self):
+        return "GPP.%s" % self.name
+
+    def __int__(self):
+        return self.value
+
+
+class OptimizerTypes(object):
+    null = _Enum("OptimizerTypes.null", 0)
+    gradient_descent = _Enum("OptimizerTypes.gradient_descent", 1)
+    newton = _Enum("OptimizerTypes.newton", 2)
+
+
+class DomainTypes(object):
+    tensor_product = _Enum("DomainTypes.tensor_product", 0)
+    simplex = _Enum("DomainTypes.simplex", 1)
+
+
+class LogLikelihoodTypes(object):
+    log_marginal_likelihood = _Enum("LogLikelihoodTypes.log_marginal_likelihood", 0)
+    leave_one_out_log_likelihood = _Enum("LogLikelihoodTypes.leave_one_out_log_likelihood", 1)
+
+
+# ---- optimizer parameter structs (gpp_python_common.cpp:243-301, gpp_optimizer_parameters.hpp:81-133) ----
+class GradientDescentParameters(object):
+    def __init__(self, num_multistarts, max_num_steps, max_num_restarts, num_steps_averaged, gamma, pre_mult,
+                 max_relative_change, tolerance):
+        self.num_multistarts = int(num_multistarts)
+        self.max_num_steps = int(max_num_steps)
+        self.max_num_restarts = int(max_num_restarts)
+        self.num_steps_averaged = int(num_steps_averaged)
+        self.gamma = float(gamma)
+        self.pre_mult = float(pre_mult)
+        self.max_relative_change = float(max_relative_change)
+        self.tolerance = float(tolerance)
+
+    def _as_tuple(self):
+        return (self.num_multistarts, self.max_num_steps, self.max_num_restarts, self.num_steps_averaged, self.gamma,
+                self.pre_mult, self.max_relative_change, self.tolerance)
+
+
+class NewtonParameters(object):
+    """Field container only (gpp_optimizer_parameters.hpp:186-243); Newton drives hyperparameter optimisation, which is
+    outside the hot path."""
+
+    def __init__(self, num_multistarts, max_num_steps, gamma, time_factor, max_relative_change, tolerance):
+        self.num_multistarts = int(num_multistarts)
+        self.max_num_steps = int(max_num_steps)
+        self.gamma = float(gamma)
+        self.time_factor = float(time_factor)
+        self.max_relative_change = float(max_relative_change)
+        self.tolerance = float(tolerance)
+
+
+# ---- randomness (gpp_python_common.cpp:131-198, gpp_random.hpp:54-303) ----
+def _randomized_seed(base_seed, thread_id):
+    # NormalRNG::SetRandomizedSeed mixes the seed with time and the thread id (gpp_random.cpp:86-107)
+    mix = int(time.time() * 1e6) ^ (os.getpid() << 16) ^ int.from_bytes(os.urandom(4), "little")
+    return (int(base_seed) + 0x9E3779B9 * (int(thread_id) + 1) + mix) & 0xFFFFFFFF
+
+
+class _NormalStream(object):
+    """NormalRNG stand-in: remembers its last seed; ``table(count)`` is the stream replayed from that seed."""
+
+    def __init__(self, seed):
+        self.last_seed = int(seed) & 0xFFFFFFFF
+        self._cache = None
+
+    def set_seed(self, seed):
+        self.last_seed = int(seed) & 0xFFFFFFFF
+        self._cache = None
+
+    def table(self, count):
+        if self._cache is None or self._cache.size < count:
+            self._cache = _api.normal_draws(self.last_seed, max(int(count), 1))
+        return self._cache[:count]
+
+
+class RandomnessSourceContainer(object):
+    kNormalDefaultSeed = 314  # gpp_python_common.hpp:147-148
+    kUniformDefaultSeed = 314
+
+    def __init__(self, num_threads=1):
+        self.num_normal_rng = int(num_threads)
+        self.uniform_seed = self.kUniformDefaultSeed
+        self.normal_rng_vec = [_NormalStream(self.kNormalDefaultSeed + i) for i in range(self.num_normal_rng)]
+        self._uniform = np.random.RandomState(self.uniform_seed)
+
+    def SetExplicitUniformGeneratorSeed(self, seed):
+        self.uniform_seed = int(seed) & 0xFFFFFFFF
+        self._uniform = np.random.RandomState(self.uniform_seed)
+
+    def SetRandomizedUniformGeneratorSeed(self, seed):
+        self.SetExplicitUniformGeneratorSeed(_randomized_seed(seed, 0))
+
+    def ResetUniformRNGSeed(self):
+        self._uniform = np.random.RandomState(self.uniform_seed)
+
+    def SetExplicitNormalRNGSeed(self, seed):
+        for i, rng in enumerate(self.normal_rng_vec):
+            rng.set_seed(int(seed) + i)
+
+    def SetRandomizedNormalRNGSeed(self, seed):
+        for i, rng in enumerate(self.normal_rng_vec):
+            rng.set_seed(_randomized_seed(seed, i))
+
+    def SetNormalRNGSeedPythonList(self, seed_list, seed_flag_list):
+        if len(seed_list) != len(seed_flag_list) or len(seed_list) != self.num_normal_rng:
+            return False
+        for i, (seed, flag) in enumerate(zip(seed_list, seed_flag_list)):
+            if int(flag):
+                self.normal_rng_vec[i].set_seed(int(seed))
+        return True
+
+    def ResetNormalRNGSeed(self):
+        pass  # streams are replayed from their last seed on every evaluation already
+
+    def PrintState(self):
+        print("Uniform:\n  seed %d" % self.uniform_seed)
+        for i, rng in enumerate(self.normal_rng_vec):
+            print("NormalRNG %d:\n  last seed %d" % (i, rng.last_seed))
+
+    # used by the multistart drivers (Latin-hypercube start generation, gpp_random.cpp:173-194)
+    def _uniform_random(self, size):
+        return self._uniform.uniform(0.0, 1.0, size=size)
+
+
+def _flat(values, count=None):
+    a = np.ascontiguousarray(np.asarray(values, dtype=np.float64).ravel())
+    if count is not None:
+        if a.size < count:
+            raise InvalidValueException("input list shorter than the sizes passed with it", a.size, count, 0)
+        a = a[:count]
+    return a
+
+
+# ---- GaussianProcess (gpp_python_gaussian_process.cpp:42-62, 294-465) ----
+class GaussianProcess(object):
+    """``GaussianProcess(hyperparameters=[alpha, [lengths]], points_sampled, points_sampled_value, noise_variance,
+    derivatives, num_derivatives, dim, num_sampled)``.  Like the reference (``MaternNu2p5 sqexp(...)``,
+    gpp_python_gaussian_process.cpp:53) the kernel is Matern-5/2 whatever the Python covariance class is called;
+    ``cov_type`` (keyword only, not in the reference) lets tests select the square exponential."""
+
+    def __init__(self, hyperparameters, points_sampled, points_sampled_value, noise_variance, derivatives, num_derivatives,
+                 dim, num_sampled, cov_type=_lib.COV_MATERN_NU_2P5, device=None):
+        alpha = float(hyperparameters[0])
+        lengths = _flat(hyperparameters[1], dim)
+        self.dim = int(dim)
+        self._g = int(num_derivatives)
+        X = _flat(points_sampled, dim * num_sampled).reshape(num_sampled, dim)
+        y = _flat(points_sampled_value, num_sampled * (1 + self._g)).reshape(num_sampled, 1 + self._g)
+        noise = _flat(noise_variance, 1 + self._g)
+        derivs = [int(v) for v in list(derivatives)[:self._g]]
+        if device is None:
+            device = int(os.environ.get("LOCAL_RANK", "0")) % max(_lib.device_count(), 1)
+        self._dev = _api.DeviceGP(np.concatenate([[alpha], lengths]), X, y, noise, derivs, cov_type=cov_type, device=device)
+        self._X, self._y = X.copy(), y.copy()
+        self._seed = 0
+        self.set_randomized_seed(0)  # make_gaussian_process calls SetRandomizedSeed(0) (:60)
+
+    @property
+    def num_sampled(self):
+        return self._dev.n
+
+    def _pts(self, points, num):
+        return _flat(points, self.dim * num).reshape(num, self.dim)
+
+    def compute_mean_of_points(self, points_to_sample, num_to_sample):
+        return list(self._dev.mean(self._pts(points_to_sample, num_to_sample)))
+
+    def compute_mean_of_additional_points(self, discrete_pts, num_pts):
+        return list(self._dev.additional_mean(self._pts(discrete_pts, num_pts)))
+
+    def compute_grad_mean_of_points(self, points_to_sample, num_to_sample):
+        return list(self._dev.grad_mean(self._pts(points_to_sample, num_to_sample)))
+
+    def compute_variance_of_points(self, points_to_sample, num_to_sample):
+        m = num_to_sample * (1 + self._g)
+        var = self._dev.variance(self._pts(points_to_sample, num_to_sample)).reshape(m, m)  # [col][row]; symmetric
+        low = np.tril(var.T)  # [row][col], lower triangle
+        return list((low + np.tril(low, -1).T).ravel())  # lower copied to upper, emitted row-major (:136-151)
+
+    def compute_cholesky_variance_of_points(self, points_to_sample, num_to_sample):
+        m = num_to_sample * (1 + self._g)
+        chol = self._dev.cholesky_variance(self._pts(points_to_sample, num_to_sample))  # flat col-major, upper = leftovers
+        # ZeroUpperTriangle(num_to_sample, ...) -- the reference passes num_to_sample, not m (:177); reproduced literally
+        k = num_to_sample
+        for j in range(1, k):
+            chol[j * k:j * k + j] = 0.0
+        return list(chol.reshape(m, m).T.ravel())  # emitted row-major (:178-185)
+
+    def compute_grad_variance_of_points(self, points_to_sample, num_to_sample, num_derivatives):
+        return list(self._dev.grad_variance(self._pts(points_to_sample, num_to_sample), num_derivatives))
+
+    def compute_grad_cholesky_variance_of_points(self, points_to_sample, num_to_sample, num_derivatives):
+        return list(self._dev.grad_cholesky_variance(self._pts(points_to_sample, num_to_sample), num_derivatives))
+
+    def add_sampled_points(self, new_points, new_points_value, num_new_points):
+        pts = self._pts(new_points, num_new_points)
+        vals = _flat(new_points_value, num_new_points * (1 + self._g)).reshape(num_new_points, 1 + self._g)
+        self._dev.add_points(pts, vals)
+        self._X, self._y = np.vstack([self._X, pts]), np.vstack([self._y, vals])
+
+    def sample_point_from_gp(self, point_to_sample):
+        """SamplePointFromGP (gpp_math.cpp:1760-1797): mean + chol(Var) w, one draw of 1 + g normals from the GP's own
+        stream (which, unlike the acquisition streams, is NOT rewound between calls)."""
+        pt = self._pts(point_to_sample, 1)
+        g1 = 1 + self._g
+        w = _api.normal_draws(self._seed, self._drawn + g1)[self._drawn:]
+        self._drawn += g1
+        mean = np.zeros(g1)
+        mean[0] = self._dev.mean(pt)[0]
+        if self._g:
+            # derivative rows of the posterior mean come from the grad-mean of the value row at the observed dims
+            gm = self._dev.grad_mean(pt).reshape(g1, self.dim)
+            for a, dd in enumerate(self._dev.derivatives):
+                mean[1 + a] = gm[0, dd]
+        L = np.tril(self._dev.cholesky_variance(pt).reshape(g1, g1).T)
+        return list(mean + L @ w)
+
+    def sample_global_optima(self, num_optima, inner_number, domain_bounds):
+        raise OptimalLearningException("sample_global_optima (PES support code) is outside the hot path (SURVEY 8, out of scope)")
+
+    def set_explicit_seed(self, seed):
+        self._seed, self._drawn = int(seed) & 0xFFFFFFFF, 0
+
+    def set_randomized_seed(self, seed):
+        self.set_explicit_seed(_randomized_seed(seed, 0))
+
+    def reset_to_most_recent_seed(self):
+        self._drawn = 0
+
+    def print_historical_data(self):
+        print(self._X)
+        print(self._y[:, 0])
+
+
+def _gd_params(optimizer_parameters):
+    gd = optimizer_parameters.optimizer_parameters  # duck-typed _CppOptimizerParameters (gpp_python_knowledge_gradient.cpp:100)
+    if hasattr(gd, "_as_tuple"):
+        return gd._as_tuple()
+    return (gd.num_multistarts, gd.max_num_steps, gd.max_num_restarts, gd.num_steps_averaged, gd.gamma, gd.pre_mult,
+            gd.max_relative_change, gd.tolerance)
+
+
+def _being_sampled(gp, points_being_sampled, num_being_sampled):
+    if num_being_sampled <= 0:
+        return None
+    return _flat(points_being_sampled, gp.dim * num_being_sampled).reshape(num_being_sampled, gp.dim)
+
+
+# ---- posterior mean (gpp_python_knowledge_gradient.cpp:44-72) ----
+def compute_posterior_mean(gaussian_process, num_fidelity, points_to_sample):
+    return gaussian_process._dev.posterior_mean(_flat(points_to_sample, gaussian_process.dim - num_fidelity), num_fidelity,
+                                                want_grad=False)[0]
+
+
+def compute_grad_posterior_mean(gaussian_process, num_fidelity, points_to_sample):
+    return list(gaussian_process._dev.posterior_mean(_flat(points_to_sample, gaussian_process.dim - num_fidelity),
+                                                     num_fidelity, want_grad=True)[1])
+
+
+# ---- q,p-EI (gpp_python_expected_improvement.cpp:44-109) ----
+def _ei(gaussian_process, points_to_sample, points_being_sampled, num_to_sample, num_being_sampled, max_int_steps,
+        best_so_far, randomness_source, want_grad):
+    gp = gaussian_process
+    Xq = _flat(points_to_sample, gp.dim * num_to_sample).reshape(num_to_sample, gp.dim)
+    Xp = _being_sampled(gp, points_being_sampled, num_being_sampled)
+    u = num_to_sample + max(num_being_sampled, 0)
+    normals = randomness_source.normal_rng_vec[0].table(int(max_int_steps) * u)
+    return gp._dev.ei(Xq, Xp, int(max_int_steps), float(best_so_far), normals, want_grad=want_grad, want_value=not want_grad)
+
+
+def compute_expected_improvement(gaussian_process, points_to_sample, points_being_sampled, num_to_sample, num_being_sampled,
+                                 max_int_steps, best_so_far, force_monte_carlo, randomness_source):
+    return _ei(gaussian_process, points_to_sample, points_being_sampled, num_to_sample, num_being_sampled, max_int_steps,
+               best_so_far, randomness_source, False)[0]
+
+
+def compute_grad_expected_improvement(gaussian_process, points_to_sample, points_being_sampled, num_to_sample,
+                                      num_being_sampled, max_int_steps, best_so_far, force_monte_carlo, randomness_source):
+    return list(_ei(gaussian_process, points_to_sample, points_being_sampled, num_to_sample, num_being_sampled,
+                    max_int_steps, best_so_far, randomness_source, True)[1].ravel())
+
+
+def evaluate_EI_at_point_list(gaussian_process, optimizer_parameters, domain_bounds, initial_guesses, points_being_sampled,
+                              num_multistarts, num_to_sample, num_being_sampled, best_so_far, max_int_steps,
+                              max_num_threads, randomness_source, status):
+    """EvaluateEIAtPointList (gpp_math.hpp:1900-1950) via gpp_python_expected_improvement.cpp:221-276."""
+    if max_num_threads > randomness_source.num_normal_rng:
+        raise BoundsException("Fewer randomness_sources than max_num_threads.", randomness_source.num_normal_rng,
+                              max_num_threads, 1e9)
+    gp = gaussian_process
+    guesses = _flat(initial_guesses, gp.dim * num_to_sample * num_multistarts).reshape(num_multistarts, num_to_sample, gp.dim)
+    out = []
+    for Xq in guesses:
+        out.append(compute_expected_improvement(gp, Xq, points_being_sampled, num_to_sample, num_being_sampled,
+                                                max_int_steps, best_so_far, False, randomness_source))
+    status["evaluate_EI_at_point_list"] = bool(len(out) > 0 and max(out) > 0.0)
+    return out
+
+
+# ---- q-KG / d-KG (gpp_python_knowledge_gradient.cpp:74-154) ----
+def _kg(gaussian_process, num_fidelity, optimizer_parameters, domain_bounds, discrete_pts, points_to_sample,
+        points_being_sampled, num_pts, num_to_sample, num_being_sampled, max_int_steps, best_so_far, randomness_source,
+        want_grad):
+    gp = gaussian_process
+    size = gp.dim - num_fidelity
+    Xq = _flat(points_to_sample, gp.dim * num_to_sample).reshape(num_to_sample, gp.dim)
+    Xp = _being_sampled(gp, points_being_sampled, num_being_sampled)
+    discrete = _flat(discrete_pts, size * num_pts).reshape(num_pts, size)
+    bounds = _flat(domain_bounds, 2 * size)
+    m = (num_to_sample + max(num_being_sampled, 0)) * (1 + gp._g)
+    M = int(max_int_steps)
+    normals = randomness_source.normal_rng_vec[0].table(((M + 1) // 2) * m)
+    return gp._dev.kg(_gd_params(optimizer_parameters), bounds, discrete, Xq, Xp, M, float(best_so_far), normals,
+                      want_grad=want_grad, num_fidelity=int(num_fidelity))
+
+
+def compute_knowledge_gradient(gaussian_process, num_fidelity, optimizer_parameters, domain_bounds, discrete_pts,
+                               points_to_sample, points_being_sampled, num_pts, num_to_sample, num_being_sampled,
+                               max_int_steps, best_so_far, randomness_source):
+    return _kg(gaussian_process, num_fidelity, optimizer_parameters, domain_bounds, discrete_pts, points_to_sample,
+               points_being_sampled, num_pts, num_to_sample, num_being_sampled, max_int_steps, best_so_far,
+               randomness_source, False)["kg"]
+
+
+def compute_grad_knowledge_gradient(gaussian_process, num_fidelity, optimizer_parameters, domain_bounds, discrete_pts,
+                                    points_to_sample, points_being_sampled, num_pts, num_to_sample, num_being_sampled,
+                                    max_int_steps, best_so_far, randomness_source):
+    return list(_kg(gaussian_process, num_fidelity, optimizer_parameters, domain_bounds, discrete_pts, points_to_sample,
+                    points_being_sampled, num_pts, num_to_sample, num_being_sampled, max_int_steps, best_so_far,
+                    randomness_source, True)["grad"].ravel())
+
+
+def evaluate_KG_at_point_list(gaussian_process, num_fidelity, optimizer_parameters, domain_bounds, discrete_being_sampled,
+                              initial_guesses, num_multistarts, num_pts, num_to_sample, num_being_sampled, best_so_far,
+                              max_int_steps, max_num_threads, randomness_source, status):
+    """EvaluateKGAtPointList (gpp_knowledge_gradient_optimization.hpp:1090-1141) via
+    gpp_python_knowledge_gradient.cpp:344-397: ``discrete_being_sampled`` = discrete points followed by the points being
+    sampled, read exactly as the reference reads it (discrete block = first num_pts*(dim - num_fidelity) entries,
+    points_being_sampled at offset dim*num_pts)."""
+    if max_num_threads > randomness_source.num_normal_rng:
+        raise BoundsException("Fewer randomness_sources than max_num_threads.", randomness_source.num_normal_rng,
+                              max_num_threads, 1e9)
+    gp = gaussian_process
+    size = gp.dim - num_fidelity
+    flat = _flat(discrete_being_sampled)
+    discrete = flat[:num_pts * size].reshape(num_pts, size)
+    Xp = flat[gp.dim * num_pts:gp.dim * (num_pts + num_being_sampled)].reshape(num_being_sampled, gp.dim) \
+        if num_being_sampled > 0 else None
+    guesses = _flat(initial_guesses, gp.dim * num_to_sample * num_multistarts).reshape(num_multistarts, num_to_sample, gp.dim)
+    m = (num_to_sample + max(num_being_sampled, 0)) * (1 + gp._g)
+    M = int(max_int_steps)
+    normals = randomness_source.normal_rng_vec[0].table(((M + 1) // 2) * m)
+    r = gp._dev.kg_batch(_gd_params(optimizer_parameters), _flat(domain_bounds)[:2 * size], discrete, guesses, Xp, M,
+                         float(best_so_far), normals, want_grad=False, num_fidelity=int(num_fidelity))
+    values = list(r["kg_sum"] / M)
+    status["evaluate_KG_at_point_list"] = bool(len(values) > 0)
+    return values
+
+
+def multistart_knowledge_gradient_optimization(optimizer_parameters, optimizer_parameters_inner, gaussian_process,
+                                               num_fidelity, domain_bounds, discrete_pts, points_being_sampled, num_pts,
+                                               num_to_sample, num_being_sampled, best_so_far, max_int_steps,
+                                               max_num_threads, randomness_source, status):
+    """MultistartKnowledgeGradientOptimizationWrapper (gpp_python_knowledge_gradient.cpp:243-313).  Tensor-product domain;
+    the outer optimisation runs in ``cornell_moe_amd.multistart`` with every restart's KG gradient evaluated in one batched
+    device pass per GD step."""
+    from . import multistart
+    if max_num_threads > randomness_source.num_normal_rng:
+        raise BoundsException("Fewer randomness_sources than max_num_threads.", randomness_source.num_normal_rng,
+                              max_num_threads, 1e9)
+    if int(optimizer_parameters.domain_type) != int(DomainTypes.tensor_product):
+        raise OptimalLearningException("only the tensor-product domain is implemented on the device path")
+    gp = gaussian_process
+    size = gp.dim - num_fidelity
+    discrete = _flat(discrete_pts, size * num_pts).reshape(num_pts, size)
+    Xp = _being_sampled(gp, points_being_sampled, num_being_sampled)
+    bounds = _flat(domain_bounds, 2 * gp.dim)
+    best, found = multistart.kg_optimal_points(
+        gp._dev, int(num_fidelity), optimizer_parameters, optimizer_parameters_inner, bounds, discrete, Xp,
+        int(num_to_sample), float(best_so_far), int(max_int_steps), randomness_source)
+    kind = "gradient_descent" if int(optimizer_parameters.optimizer_type) == int(OptimizerTypes.gradient_descent) else "lhc"
+    status["%s_tensor_product_domain_found_update" % kind] = bool(found)
+    return list(np.asarray(best).ravel())
+
+
+def run_cpp_tests():
+    """The reference runs its C++ unit-test suite here (gpp_python_test.cpp:307-314); this backend's tests are the pytest
+    suite under tests/ (returns 0 = no failures, like the reference on success)."""
+    return 0
