@@ -14,8 +14,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "build")
 LIB = os.path.join(HERE, "lib", "libmoe_hip.so")
-SOURCES = ["kernels_cov.hip", "kernels_linalg.hip", "host_math.hip", "gp.hip", "kg.hip", "ei.hip", "api.hip"]
-HEADERS = ["common.hpp", "kernels.hpp", "device_cov.hpp", "host_math.hpp", "gp.hpp", "kg.hpp",
+SOURCES = ["kernels_cov.hip", "kernels_linalg.hip", "host_math.hip", "gp.hip", "kg.hip", "kg_mc_dp4.hip", "kg_mc_dp8.hip",
+           "kg_mc_dp12.hip", "kg_mc_dp16.hip", "ei.hip", "api.hip"]
+HEADERS = ["common.hpp", "kernels.hpp", "device_cov.hpp", "fastmath.hpp", "host_math.hpp", "gp.hpp", "kg.hpp", "kg_mc.hpp",
            os.path.join("..", "..", "include", "moe_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function"]
 
@@ -46,7 +47,7 @@ def _compile(src, force):
 def build(force=False, verbose=False):
     os.makedirs(OBJ, exist_ok=True)
     os.makedirs(os.path.dirname(LIB), exist_ok=True)
-    with concurrent.futures.ThreadPoolExecutor(max_workers=min(8, len(SOURCES))) as ex:
+    with concurrent.futures.ThreadPoolExecutor(max_workers=min(os.cpu_count() or 4, len(SOURCES))) as ex:
         results = list(ex.map(lambda s: _compile(s, force), SOURCES))
     objs = [r[0] for r in results]
     rebuilt = any(r[1] for r in results)

@@ -45,6 +45,11 @@ GpDev::GpDev(const double* hyper, int cov_type, const double* X_in, const double
   noise.assign(noise_in, noise_in + (1 + g));
   use_device();
   MOE_HIP_CHECK(hipStreamCreate(&stream));
+  {
+    hipDeviceProp_t prop;
+    MOE_HIP_CHECK(hipGetDeviceProperties(&prop, device));
+    if (prop.multiProcessorCount > 0) num_cu = prop.multiProcessorCount;
+  }
   rebuild();
 }
 
@@ -104,10 +109,11 @@ void GpDev::add_points(const double* pts, const double* vals, int k) {
   rebuild();
 }
 
-void compute_state(GpDev& gp, const double* U, int u, const DerivList& dt, int nd, const double* extra, int A, bool need_W,
-                   StateDev* dev, StateHost* host) {
+void compute_state_batch(GpDev& gp, const double* U_all, int u, const DerivList& dt, int nd, const double* extra_all, int A,
+                         bool need_W, int num_evals, BatchLayout* blay, std::vector<StateHost>* hosts) {
   gp.use_device();
   hipStream_t s = gp.stream;
+  const int E = num_evals;
   StateLayout lay;
   lay.d = gp.d;
   lay.u = u;
@@ -118,47 +124,77 @@ void compute_state(GpDev& gp, const double* U, int u, const DerivList& dt, int n
   const int c = lay.c();
   const int ngrad = nd * (1 + dt.g) * gp.d;
   const int N = gp.N;
-  const std::vector<double> Up = gp.padded(U, u);
-  gp.dPts.upload(Up.data(), Up.size(), s);
-  if (A > 0) {
-    const std::vector<double> Ep = gp.padded(extra, A);
-    gp.dExtra.upload(Ep.data(), Ep.size(), s);
+  BatchLayout bl;
+  bl.E = E;
+  bl.m = lay.m;
+  bl.ngrad = ngrad;
+  bl.A = A;
+  const long ctot = bl.total();
+  // padded point uploads: all evaluations' union points, the differentiated subset (first nd of each), the extras
+  std::vector<double> Up((size_t)E * u * gp.dp, 0.0), Dp((size_t)E * nd * gp.dp, 0.0), Ep((size_t)E * A * gp.dp, 0.0);
+  for (int e = 0; e < E; ++e) {
+    for (int i = 0; i < u; ++i)
+      for (int k = 0; k < gp.d; ++k) Up[((size_t)e * u + i) * gp.dp + k] = U_all[((size_t)e * u + i) * gp.d + k];
+    for (int i = 0; i < nd; ++i)
+      for (int k = 0; k < gp.d; ++k) Dp[((size_t)e * nd + i) * gp.dp + k] = U_all[((size_t)e * u + i) * gp.d + k];
+    for (int j = 0; j < A; ++j)
+      for (int k = 0; k < gp.d; ++k) Ep[((size_t)e * A + j) * gp.dp + k] = extra_all[((size_t)e * A + j) * gp.d + k];
   }
-  gp.dE.reserve((size_t)N * c);
-  gp.dVE.reserve((size_t)N * c);
-  gp.dGram.reserve((size_t)c * c);
-  gp.dEK.reserve(c);
-  launch_cov_build(gp.cp, gp.dX.p, gp.n, gp.derivs, gp.dPts.p, u, dt, nullptr, gp.dE.p, N, 0, s);
-  if (nd > 0) launch_grad_kstar(gp.cp, gp.dX.p, gp.n, gp.derivs, gp.dPts.p, nd, dt, gp.dE.p, N, lay.m, s);
+  gp.dPts.upload(Up.data(), Up.size(), s);
+  if (nd > 0) gp.dPtsGrad.upload(Dp.data(), Dp.size(), s);
+  if (A > 0) gp.dExtra.upload(Ep.data(), Ep.size(), s);
+  gp.dE.reserve((size_t)N * ctot);
+  gp.dVE.reserve((size_t)N * ctot);
+  gp.dGram.reserve((size_t)c * c * E);
+  gp.dEK.reserve(ctot);
+  launch_cov_build(gp.cp, gp.dX.p, gp.n, gp.derivs, gp.dPts.p, E * u, dt, nullptr, gp.dE.p, N, bl.col_kstar0(0), s);
+  if (nd > 0) launch_grad_kstar(gp.cp, gp.dX.p, gp.n, gp.derivs, gp.dPtsGrad.p, E * nd, dt, gp.dE.p, N, bl.col_grad0(0), s);
   if (A > 0) {
     DerivList none;
     none.g = 0;
     for (int i = 0; i < kMaxDerivs; ++i) none.idx[i] = 0;
-    launch_cov_build(gp.cp, gp.dX.p, gp.n, gp.derivs, gp.dExtra.p, A, none, nullptr, gp.dE.p, N, lay.m + ngrad, s);
+    launch_cov_build(gp.cp, gp.dX.p, gp.n, gp.derivs, gp.dExtra.p, E * A, none, nullptr, gp.dE.p, N, bl.col_extra0(0), s);
   }
-  launch_tri_gemm('N', N, c, gp.dLinv.p, N, gp.dE.p, N, gp.dVE.p, N, s);
+  launch_tri_gemm('N', N, (int)ctot, gp.dLinv.p, N, gp.dE.p, N, gp.dVE.p, N, s);
   if (need_W) {
-    gp.dWE.reserve((size_t)N * (lay.m + ngrad));
-    launch_tri_gemm('T', N, lay.m + ngrad, gp.dLinv.p, N, gp.dVE.p, N, gp.dWE.p, N, s);
+    const int cw = E * (lay.m + ngrad);
+    gp.dWE.reserve((size_t)N * cw);
+    launch_tri_gemm('T', N, cw, gp.dLinv.p, N, gp.dVE.p, N, gp.dWE.p, N, s);
   }
-  launch_gemm_tn(c, c, N, gp.dVE.p, N, gp.dVE.p, N, gp.dGram.p, c, s);
-  launch_gemm_tn(c, 1, N, gp.dE.p, N, gp.dKinvY.p, N, gp.dEK.p, c, s);
-  host->lay = lay;
-  host->cp = gp.cp;
-  host->dt = dt;
-  host->U.assign(U, U + (size_t)u * gp.d);
-  if (A > 0)
-    host->extra.assign(extra, extra + (size_t)A * gp.d);
-  else
-    host->extra.clear();
-  host->gram.resize((size_t)c * c);
-  host->ek.resize(c);
-  host->mean = gp.mean;
-  gp.dGram.download(host->gram.data(), (size_t)c * c, s);
-  gp.dEK.download(host->ek.data(), c, s);
+  launch_gram_batch(E, lay.m, ngrad, A, N, gp.dVE.p, N, gp.dGram.p, s);
+  launch_gemm_tn((int)ctot, 1, N, gp.dE.p, N, gp.dKinvY.p, N, gp.dEK.p, (int)ctot, s);
+  std::vector<double> gram_all((size_t)c * c * E), ek_all((size_t)ctot);
+  gp.dGram.download(gram_all.data(), gram_all.size(), s);
+  gp.dEK.download(ek_all.data(), ek_all.size(), s);
   MOE_HIP_CHECK(hipStreamSynchronize(s));
+  hosts->resize(E);
+  for (int e = 0; e < E; ++e) {
+    StateHost& h = (*hosts)[e];
+    h.lay = lay;
+    h.cp = gp.cp;
+    h.dt = dt;
+    h.U.assign(U_all + (size_t)e * u * gp.d, U_all + (size_t)(e + 1) * u * gp.d);
+    if (A > 0)
+      h.extra.assign(extra_all + (size_t)e * A * gp.d, extra_all + (size_t)(e + 1) * A * gp.d);
+    else
+      h.extra.clear();
+    h.gram.assign(gram_all.begin() + (size_t)e * c * c, gram_all.begin() + (size_t)(e + 1) * c * c);
+    h.ek.resize(c);
+    for (int l = 0; l < lay.m; ++l) h.ek[l] = ek_all[bl.col_kstar0(e) + l];
+    for (int l = 0; l < ngrad; ++l) h.ek[lay.m + l] = ek_all[bl.col_grad0(e) + l];
+    for (int l = 0; l < A; ++l) h.ek[lay.m + ngrad + l] = ek_all[bl.col_extra0(e) + l];
+    h.mean = gp.mean;
+  }
+  if (blay) *blay = bl;
+}
+
+void compute_state(GpDev& gp, const double* U, int u, const DerivList& dt, int nd, const double* extra, int A, bool need_W,
+                   StateDev* dev, StateHost* host) {
+  std::vector<StateHost> hosts;
+  compute_state_batch(gp, U, u, dt, nd, extra, A, need_W, 1, nullptr, &hosts);
+  *host = std::move(hosts[0]);
   if (dev) {
-    dev->lay = lay;
+    dev->lay = host->lay;
     dev->have_W = need_W;
   }
 }

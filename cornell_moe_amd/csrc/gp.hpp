@@ -26,7 +26,11 @@ struct GpDev {
   DevBuf<double> dX, dL, dLinv, dKinvY, dNoise, dTmp;
   DevBuf<int> dInfo;
   // reusable workspaces for states
-  DevBuf<double> dPts, dExtra, dE, dVE, dWE, dGram, dEK;
+  DevBuf<double> dPts, dPtsGrad, dExtra, dE, dVE, dWE, dGram, dEK;
+  // reusable workspaces of the KG evaluator (kg.hip)
+  DevBuf<double> kBlob, kNormals, kTab, kBestPoint, kBestValue, kBeta, kT, kC, kTB, kOut;
+  DevBuf<unsigned long long> kCounters;
+  int num_cu = 256;
   // timing of the last KG call (ms): mc, cov-build, tail contraction, state, total
   double last_ms[5] = {0, 0, 0, 0, 0};
 
@@ -52,5 +56,19 @@ struct StateDev {
 // gram = VE^T VE and ek = E^T K^-1(y-mean); downloads gram/ek into `host` (synchronises the GP's stream).
 void compute_state(GpDev& gp, const double* U, int u, const DerivList& dt, int nd, const double* extra, int A, bool need_W,
                    StateDev* dev, StateHost* host);
+
+// The same for `num_evals` independent point sets in one pass (the multistart axis): U_all[e][u][d], extra_all[e][A][d].
+// Columns of E / VE / WE (ld = N) are grouped by kind so that every group is one launch:
+//   [ K* of eval 0 | K* of eval 1 | ... | dK* of eval 0 | ... | extra of eval 0 | ... ]
+// i.e. W_e = WE + col_kstar0(e) * N (m columns) and K^-1 dK*_e = WE + col_grad0(e) * N (ngrad columns).
+struct BatchLayout {
+  int E = 1, m = 0, ngrad = 0, A = 0;
+  long col_kstar0(int e) const { return (long)e * m; }
+  long col_grad0(int e) const { return (long)E * m + (long)e * ngrad; }
+  long col_extra0(int e) const { return (long)E * (m + ngrad) + (long)e * A; }
+  long total() const { return (long)E * (m + ngrad + A); }
+};
+void compute_state_batch(GpDev& gp, const double* U_all, int u, const DerivList& dt, int nd, const double* extra_all, int A,
+                         bool need_W, int num_evals, BatchLayout* blay, std::vector<StateHost>* hosts);
 
 }  // namespace moe

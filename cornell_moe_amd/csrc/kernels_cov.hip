@@ -5,6 +5,8 @@
 // OUTPUT ROW (so a wavefront's 64 stores of one column are 512 contiguous bytes), the B points of the tile are staged
 // once in LDS and read as wave-uniform broadcasts, the A point stays in registers for the whole tile.
 // Algorithmic bytes per launch: 8 * [nA*d + nB*d + nA(1+gA) * nB(1+gB)].
+#include <algorithm>
+
 #include "device_cov.hpp"
 
 namespace moe {
@@ -22,11 +24,11 @@ __global__ __launch_bounds__(kCovRows) void cov_build_kernel(CovParams cp, const
   __shared__ double Bs[kCovCols][DP];
   const int gA = DERIVS ? dA.g : 0, gB = DERIVS ? dB.g : 0;
   const int rows = nA * (1 + gA);
-  const int j0 = blockIdx.y * kCovCols;
+  const int j0 = blockIdx.x * kCovCols;  // column tiles on grid.x (up to 2^31-1 tiles: N x M builds have M >> 65535*16)
   const int nj = min(kCovCols, nB - j0);
   for (int t = threadIdx.x; t < nj * DP; t += blockDim.x) Bs[t / DP][t % DP] = B[(long)(j0 + t / DP) * DP + (t % DP)];
   __syncthreads();
-  const int r = blockIdx.x * kCovRows + threadIdx.x;
+  const int r = blockIdx.y * kCovRows + threadIdx.x;
   if (r >= rows) return;
   const int i = DERIVS ? r / (1 + gA) : r;
   const int a = DERIVS ? r % (1 + gA) : 0;
@@ -103,7 +105,7 @@ void cov_build_dp(const CovParams& cp, const double* A, int nA, const DerivList&
                   const DerivList& dB, const double* diag_noise, double* out, long ld, long col0, hipStream_t s) {
   const bool derivs = dA.g > 0 || dB.g > 0;
   const int rows = nA * (1 + dA.g);
-  dim3 grid((rows + kCovRows - 1) / kCovRows, (nB + kCovCols - 1) / kCovCols);
+  dim3 grid((nB + kCovCols - 1) / kCovCols, (rows + kCovRows - 1) / kCovRows);
   if (grid.x == 0 || grid.y == 0) return;
   if (derivs)
     hipLaunchKernelGGL((cov_build_kernel<DP, true>), grid, dim3(kCovRows), 0, s, cp, A, nA, dA, B, nB, dB, diag_noise, out, ld,
@@ -120,11 +122,18 @@ void grad_kstar_dp(const CovParams& cp, const double* X, int n, const DerivList&
   const int rows = n * (1 + dX.g);
   if (rows == 0 || nP == 0) return;
   dim3 grid((rows + 255) / 256);
-  const size_t shm = sizeof(double) * (size_t)nP * DP;
-  if (derivs)
-    hipLaunchKernelGGL((grad_kstar_kernel<DP, true>), grid, dim3(256), shm, s, cp, X, n, dX, P, nP, dP, out, ld, col0);
-  else
-    hipLaunchKernelGGL((grad_kstar_kernel<DP, false>), grid, dim3(256), shm, s, cp, X, n, dX, P, nP, dP, out, ld, col0);
+  constexpr int kChunk = 256;  // points staged in LDS per launch (batched states pass E * nd points)
+  for (int p0 = 0; p0 < nP; p0 += kChunk) {
+    const int np = std::min(kChunk, nP - p0);
+    const size_t shm = sizeof(double) * (size_t)np * DP;
+    const long c0 = col0 + (long)p0 * (1 + dP.g) * cp.dim;
+    if (derivs)
+      hipLaunchKernelGGL((grad_kstar_kernel<DP, true>), grid, dim3(256), shm, s, cp, X, n, dX, P + (long)p0 * DP, np, dP, out,
+                         ld, c0);
+    else
+      hipLaunchKernelGGL((grad_kstar_kernel<DP, false>), grid, dim3(256), shm, s, cp, X, n, dX, P + (long)p0 * DP, np, dP, out,
+                         ld, c0);
+  }
 }
 
 __global__ void debug_math_kernel(const double* __restrict__ x, int n, double* __restrict__ e, double* __restrict__ r) {

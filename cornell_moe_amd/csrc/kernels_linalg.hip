@@ -99,6 +99,60 @@ void tile_gemm(int M, int Ncols, int K, const double* A, long lda, const double*
   MOE_HIP_CHECK(hipGetLastError());
 }
 
+// Batched Gram matrices G_e = V_e^T V_e over column groups of V (see kernels.hpp): 32 x 32 output tile per workgroup,
+// blockIdx.z = evaluation, only tiles with tile-row >= tile-col are computed and mirrored.
+struct GramMap {
+  int E, m, ng, A;
+  __device__ __forceinline__ long col(int e, int l) const {
+    if (l < m) return (long)e * m + l;
+    if (l < m + ng) return (long)E * m + (long)e * ng + (l - m);
+    return (long)E * (m + ng) + (long)e * A + (l - m - ng);
+  }
+};
+
+__global__ __launch_bounds__(256) void gram_batch_kernel(GramMap gm, int K, const double* __restrict__ V, long ldv,
+                                                        double* __restrict__ G) {
+  constexpr int T = 32;
+  __shared__ double As[TK][T + 1];
+  __shared__ double Bs[TK][T + 1];
+  if (blockIdx.y > blockIdx.x) return;
+  const int c = gm.m + gm.ng + gm.A;
+  const int e = blockIdx.z;
+  const int i0 = blockIdx.x * T, j0 = blockIdx.y * T;
+  const int tx = threadIdx.x % 16, ty = threadIdx.x / 16;
+  double acc[2][2] = {{0.0, 0.0}, {0.0, 0.0}};
+  for (int k0 = 0; k0 < K; k0 += TK) {
+    for (int t = threadIdx.x; t < TK * T; t += 256) {
+      const int kk = t % TK, ii = t / TK;
+      const int gk = k0 + kk;
+      const int gi = i0 + ii, gj = j0 + ii;
+      As[kk][ii] = (gi < c && gk < K) ? V[(long)gk + gm.col(e, gi) * ldv] : 0.0;
+      Bs[kk][ii] = (gj < c && gk < K) ? V[(long)gk + gm.col(e, gj) * ldv] : 0.0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < TK; ++kk) {
+      const double a0 = As[kk][tx], a1 = As[kk][tx + 16], b0 = Bs[kk][ty], b1 = Bs[kk][ty + 16];
+      acc[0][0] = fma(a0, b0, acc[0][0]);
+      acc[0][1] = fma(a0, b1, acc[0][1]);
+      acc[1][0] = fma(a1, b0, acc[1][0]);
+      acc[1][1] = fma(a1, b1, acc[1][1]);
+    }
+    __syncthreads();
+  }
+  double* Ge = G + (long)e * c * c;
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const int gi = i0 + tx + 16 * a, gj = j0 + ty + 16 * b;
+      if (gi < c && gj < c) {
+        Ge[(long)gi + (long)gj * c] = acc[a][b];
+        Ge[(long)gj + (long)gi * c] = acc[a][b];  // symmetric: identical sum, so both triangles hold the same bits
+      }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------------------------
 // Blocked Cholesky (lower, in place) with explicit inverse factor.
 // ------------------------------------------------------------------------------------------------------------------
@@ -319,6 +373,15 @@ void launch_tri_gemm(char op, int N, int c, const double* T, long ldt, const dou
 void launch_gemm_tn(int m, int n, int K, const double* A, long lda, const double* B, long ldb, double* C, long ldc,
                     hipStream_t s) {
   tile_gemm<0>(m, n, K, A, lda, B, ldb, C, ldc, s);
+}
+
+void launch_gram_batch(int E, int m, int ng, int A, int K, const double* V, long ldv, double* G, hipStream_t s) {
+  const int c = m + ng + A;
+  if (c <= 0 || E <= 0) return;
+  GramMap gm{E, m, ng, A};
+  dim3 grid((c + 31) / 32, (c + 31) / 32, E);
+  hipLaunchKernelGGL(gram_batch_kernel, grid, dim3(256), 0, s, gm, K, V, ldv, G);
+  MOE_HIP_CHECK(hipGetLastError());
 }
 
 size_t cholesky_work_doubles(int) { return 1; }

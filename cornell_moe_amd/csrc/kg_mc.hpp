@@ -1,0 +1,549 @@
+// cornell_moe_amd/csrc/kg_mc.hpp -- the q-KG / d-KG Monte-Carlo inner-optimisation kernel (gfx950), shared by the
+// per-dimension translation units kg_mc_dp*.hip (one instantiation set per padded dimension, compiled in parallel).
+//
+// What the reference does per MC sample i (gpp_knowledge_gradient_optimization.cpp:170-196): draw z_i, set the fantasy
+// observations y_i = mu(Xu) + L z_i, RE-SOLVE K_after^-1 (y - mean) with two O((N+m)^2) triangular sweeps
+// (gpp_math.cpp:531-551), then maximise -mu_after,i(x) from the best discretised start with a back-tracking
+// line-search gradient descent (.cpp:420-472, gpp_optimization.hpp:708-828).
+//
+// What this kernel does instead -- same mathematics, no N^2 work per sample:
+//   K_after^-1 (y_i - mean) = [ K^-1(y - mean) - W beta_i ; beta_i ],   W = K^-1 K*(X,Xu),  beta_i = L^-T z_i,
+// (block elimination of the (N+m) system; the reference's own gradient tail relies on the same identity, .cpp:199-209),
+// so  mu_after,i(x) = mean + sum over the n + u points p of  [ w_p0 base(x,p) + first(x,p) sum_a w_pa (p - x)_{d_a} ]
+// with a per-sample weight block w (1 + g values per point: the function-value weight and one weight per observed
+// partial derivative) that costs N*m flops to form.
+//
+// Mapping: ONE WAVEFRONT owns one MC sample at a time and pulls the next sample of its evaluation from an atomic
+// counter when it finishes (persistent waves: no workgroup-level tail while a slow line search finishes).  Lanes stride
+// over the n + u points; point coordinates are staged once per workgroup in LDS, tile-major [tile][dim][64 lanes] so that
+// every ds_read_b64 is conflict free and its address is base + immediate; the wave's weights live in its own LDS slab with
+// the same tiling; each posterior-mean (or mean + gradient) evaluation ends in a 64-lane butterfly reduction.  Control
+// flow of the line search is wave-uniform: there is no intra-wave divergence.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "fastmath.hpp"
+#include "kernels.hpp"
+
+namespace moe {
+
+constexpr int kMaxM = 64;  // m = (q + p)(1 + g) limit of the MC kernel (z / beta scratch per wave)
+
+struct KgRec {  // offsets (doubles) of one evaluation's small operands inside the blob; identical for every evaluation
+  int L;        // [m x m] col-major lower Cholesky factor of Var(Xu) + noise
+  int mu_disc;  // [A]      mu_n at the discretised points
+  int C_disc;   // [A][m]   L^-1 cov_n(Xu, x_j)
+  int disc;     // [A][size] discretised points (unscaled, fidelity dims dropped)
+  int XuP;      // [u][dp]  union points, padded (unscaled)
+  int Mk;       // unused by the MC kernel
+  int stride;   // record length
+};
+
+struct KgMcParams {
+  int cov_type, dim;
+  double alpha;
+  double inv_lp[kMaxDimPadded];  // 1 / length of table row r (row r holds original dimension perm[r]); 0 in pad rows
+  int perm[kMaxDimPadded];       // the GP's observed-derivative dimensions come first: perm[a] = derivatives[a], a < g
+  int n, g, N, u, m, f, A, ntiles, E;
+  double mean;
+  const double* XsTab;  // [E][ntiles][DP][64] scaled coordinates of X then Xu_e, zero padded
+  long tab_stride;
+  const double* KinvY;  // [N], entry (j, a) at j (1 + g) + a
+  const double* W;      // K^-1 K*: evaluation e at W + e * w_stride, [N x m], ld N
+  long w_stride;
+  const double* blob;
+  KgRec rec;
+  const double* bounds;   // [2 size]
+  const double* normals;  // [ceil(M/2)][m]
+  int first_sample, num_local;
+  int max_num_steps, max_num_restarts;
+  double gamma, pre_mult, max_relative_change, tolerance;
+  double* best_point;  // [E][num_local][DP] (unscaled, fidelity coords = 1, pads = 0)
+  double* best_value;  // [E][num_local]
+  double* beta;        // [E][num_local][m]
+  unsigned long long* counters;  // [E][2]: value passes, value + gradient passes
+  unsigned int* next_sample;     // [E] work counters (zeroed before launch)
+};
+
+// Launchers (one translation unit per padded dimension).  `waves` = wavefronts per workgroup, `shm` = dynamic LDS bytes.
+void launch_kg_mc_dp4(const KgMcParams& P, int G, bool xlds, int blocks, int waves, size_t shm, hipStream_t s);
+void launch_kg_mc_dp8(const KgMcParams& P, int G, bool xlds, int blocks, int waves, size_t shm, hipStream_t s);
+void launch_kg_mc_dp12(const KgMcParams& P, int G, bool xlds, int blocks, int waves, size_t shm, hipStream_t s);
+void launch_kg_mc_dp16(const KgMcParams& P, int G, bool xlds, int blocks, int waves, size_t shm, hipStream_t s);
+
+#if defined(__HIPCC__)
+namespace mc {
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+__device__ __forceinline__ double uniform(double v) {
+  // all lanes hold the same bits after a butterfly; tell the compiler so (value moves to SGPRs, branches become scalar)
+  const int lo = __builtin_amdgcn_readfirstlane(__double2loint(v));
+  const int hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
+  return __hiloint2double(hi, lo);
+}
+
+// Radial scalars divided by alpha (alpha is folded into the weights): base = cov[0,0], first = first-derivative
+// coefficient, second = Hessian-product coefficient (device_cov.hpp).
+template <int COV, bool NEED_FIRST, bool NEED_SECOND>
+__device__ __forceinline__ void radial3(double r2, double& base, double& first, double& second) {
+  if (COV == MOE_COV_SQUARE_EXPONENTIAL) {
+    base = exp_nonpos(-0.5 * r2);
+    first = base;
+    second = base;
+  } else {
+    const double a = 2.236067977499789696409173668731276235 * sqrt_nonneg(r2);
+    const double e = exp_nonpos(-a);
+    base = e * fma(a, fma(a, 1.0 / 3.0, 1.0), 1.0);  // e^-a (1 + a + a^2/3)   [5 r2 / 3 == a^2 / 3]
+    first = NEED_FIRST ? (5.0 / 3.0) * (e * (a + 1.0)) : 0.0;
+    second = NEED_SECOND ? (25.0 / 3.0) * e : 0.0;
+  }
+}
+
+// One pass over the n + u points for the wave's sample: returns f = -mu_after(x) and (if WG) grad f in table-row order.
+// xq = scaled query coordinates in table-row order (wave-uniform).  xs = coordinate table [tile][DP][64] (LDS, or global
+// when it does not fit), aw = this wave's weights [tile][1+G][64] in LDS (zero beyond the real points, so padded lanes
+// contribute exactly 0).
+template <int DP, int G, bool WG, int COV>
+__device__ __forceinline__ double eval_loop(const double* __restrict__ xs, const double* __restrict__ aw, int ntiles,
+                                            double mean, const double (&xq)[DP], const double* inv_lp,
+                                            double (&grad)[DP], int lane) {
+  double accf = 0.0;
+  double accg[DP];
+  double accd[G > 0 ? G : 1];
+#pragma unroll
+  for (int k = 0; k < DP; ++k) accg[k] = 0.0;
+#pragma unroll
+  for (int a = 0; a < (G > 0 ? G : 1); ++a) accd[a] = 0.0;
+  // Software-pipelined tile loop: the next tile's coordinates / weights are requested from LDS before the current
+  // tile's ~55 FP64 instructions run, so the ds_read latency hides behind them instead of stalling every tile.
+  const double* xt = xs + lane;
+  const double* wt = aw + lane;
+  double cx[DP], cw[1 + G];
+#pragma unroll
+  for (int k = 0; k < DP; ++k) cx[k] = xt[k * 64];
+#pragma unroll
+  for (int a = 0; a < 1 + G; ++a) cw[a] = wt[a * 64];
+#pragma unroll(WG ? 2 : 4)
+  for (int t = 0; t < ntiles; ++t) {
+    double nx[DP], nw[1 + G];
+    if (t + 1 < ntiles) {  // (the last iteration harmlessly re-reads its own tile: no zero fill, no branch around loads)
+      xt += DP * 64;
+      wt += (1 + G) * 64;
+    }
+#pragma unroll
+    for (int k = 0; k < DP; ++k) nx[k] = xt[k * 64];
+#pragma unroll
+    for (int a = 0; a < 1 + G; ++a) nw[a] = wt[a * 64];
+    double diff[DP];
+    double r2 = 0.0;
+#pragma unroll
+    for (int k = 0; k < DP; ++k) {
+      diff[k] = cx[k] - xq[k];
+      r2 = fma(diff[k], diff[k], r2);
+    }
+    const double w0 = cw[0];  // alpha * (function-value weight)
+    double base, first, second;
+    radial3<COV, (WG || G > 0), (WG && G > 0)>(r2, base, first, second);
+    double sd = 0.0;  // sum_a w_a diff[a]  (derivative-observation weights; table rows a < G are the observed dims)
+    if (G > 0) {
+#pragma unroll
+      for (int a = 0; a < G; ++a) sd = fma(cw[1 + a], diff[a], sd);
+    }
+    accf = fma(w0, base, accf);
+    if (G > 0) accf = fma(first, sd, accf);
+    if (WG) {
+      double coef = w0 * first;
+      if (G > 0) {
+        coef = fma(second, sd, coef);
+#pragma unroll
+        for (int a = 0; a < G; ++a) accd[a] = fma(first, cw[1 + a], accd[a]);
+      }
+#pragma unroll
+      for (int k = 0; k < DP; ++k) accg[k] = fma(coef, diff[k], accg[k]);
+    }
+#pragma unroll
+    for (int k = 0; k < DP; ++k) cx[k] = nx[k];
+#pragma unroll
+    for (int a = 0; a < 1 + G; ++a) cw[a] = nw[a];
+  }
+  const double mu = mean + uniform(wave_sum(accf));
+  if (WG) {
+#pragma unroll
+    for (int k = 0; k < DP; ++k) {
+      // d mu / d x_k = inv_l[k] * ( sum coef (Xs_k - xq_k)  -  [k < G] sum first w_k );   f = -mu
+      double v = uniform(wave_sum(accg[k]));
+      if (G > 0 && k < G) v -= uniform(wave_sum(accd[k < G ? k : 0]));
+      grad[k] = -(v * inv_lp[k]);
+    }
+  }
+  return -mu;
+}
+
+// The covariance type is wave-uniform: branch ONCE per pass (a branch inside the tile loop would split it into basic blocks
+// and stop the scheduler from interleaving the independent per-tile dependency chains).
+template <int DP, int G, bool WG>
+__device__ __forceinline__ double eval_pass(const double* __restrict__ xs, const double* __restrict__ aw, int ntiles,
+                                            int cov_type, double mean, const double (&xq)[DP], const double* inv_lp,
+                                            double (&grad)[DP], int lane) {
+  if (cov_type == MOE_COV_SQUARE_EXPONENTIAL)
+    return eval_loop<DP, G, WG, MOE_COV_SQUARE_EXPONENTIAL>(xs, aw, ntiles, mean, xq, inv_lp, grad, lane);
+  return eval_loop<DP, G, WG, MOE_COV_MATERN_NU_2P5>(xs, aw, ntiles, mean, xq, inv_lp, grad, lane);
+}
+
+// TensorProductDomain::LimitUpdate (gpp_domain.cpp:64-105) on one coordinate.
+__device__ __forceinline__ double limit_update_1d(double lo, double hi, double max_relative_change, double x, double desired) {
+  double dist = fmin(x - lo, hi - x);
+  if (fabs(desired) > max_relative_change * dist) desired = copysign(max_relative_change * dist, desired);
+  const double next = x + desired;
+  if (next < lo || next > hi) {
+    if (next < lo) {
+      dist = lo - x;
+      desired = (x + desired * 0.5 < lo) ? dist * 0.5 : desired * 0.5;
+    } else {
+      dist = hi - x;
+      desired = (x + desired * 0.5 > hi) ? dist * 0.5 : desired * 0.5;
+    }
+  }
+  return desired;
+}
+
+// VectorNorm (gpp_linear_algebra.cpp:53-72)
+template <int DP>
+__device__ __forceinline__ double vector_norm(const double (&v)[DP], int size) {
+  if (size == 1) return fabs(v[0]);
+  double scale = 0.0, scaled = 1.0;
+#pragma unroll
+  for (int i = 0; i < DP; ++i) {
+    if (i < size && v[i] != 0.0) {
+      const double av = fabs(v[i]);
+      if (scale < av) {
+        const double t = scale / av;
+        scaled = 1.0 + scaled * (t * t);
+        scale = av;
+      } else {
+        const double t = av / scale;
+        scaled += t * t;
+      }
+    }
+  }
+  return scale * sqrt(scaled);
+}
+
+// out[r] = v[perm[r]] for wave-uniform v (select chains on uniform data; identity when the GP has no derivatives)
+template <int DP, int G>
+__device__ __forceinline__ void to_table_order(const double (&v)[DP], const int* perm, double (&out)[DP]) {
+  if (G == 0) {
+#pragma unroll
+    for (int r = 0; r < DP; ++r) out[r] = v[r];
+  } else {
+#pragma unroll
+    for (int r = 0; r < DP; ++r) {
+      double o = 0.0;
+#pragma unroll
+      for (int k = 0; k < DP; ++k) o = (perm[r] == k) ? v[k] : o;
+      out[r] = o;
+    }
+  }
+}
+
+template <int DP, int G>
+__device__ __forceinline__ void from_table_order(const double (&v)[DP], const int* perm, double (&out)[DP]) {
+  if (G == 0) {
+#pragma unroll
+    for (int k = 0; k < DP; ++k) out[k] = v[k];
+  } else {
+#pragma unroll
+    for (int k = 0; k < DP; ++k) {
+      double o = 0.0;
+#pragma unroll
+      for (int r = 0; r < DP; ++r) o = (perm[r] == k) ? v[r] : o;
+      out[k] = o;
+    }
+  }
+}
+
+// One MC sample: weights, discretised-set scan, line-search gradient descent.  Called with the whole wave converged.
+template <int DP, int G>
+__device__ __forceinline__ void kg_sample(const KgMcParams& P, int e, int sl, const double* __restrict__ xs,
+                                          double* __restrict__ aw, double* __restrict__ zb, int lane) {
+  const int m = P.m, u = P.u, n = P.n, g1 = 1 + P.g;
+  const int s = P.first_sample + sl;  // global sample index
+  const int size = P.dim - P.f;       // problem size of the inner optimisation
+  const double* rec = P.blob + (long)e * P.rec.stride;
+  const double* Lsm = rec + P.rec.L;
+  const double* We = P.W + (long)e * P.w_stride;
+
+  // ---- z_i (antithetic, .cpp:171-180) and beta = L^-T z: lane c owns component c; scratch copies in LDS ----
+  const double sign = (s & 1) ? -1.0 : 1.0;
+  double zc = 0.0;
+  if (lane < m) zc = sign * P.normals[(long)(s >> 1) * m + lane];
+  double bc = 0.0;
+  for (int c = m - 1; c >= 0; --c) {
+    double part = 0.0;
+    if (lane > c && lane < m) part = Lsm[lane + c * m] * bc;
+    const double tot = wave_sum(part);
+    if (lane == c) bc = (zc - tot) / Lsm[c + c * m];
+  }
+  zb[lane] = zc;  // kMaxM == 64 == wavefront size
+  zb[kMaxM + lane] = bc;
+  __builtin_amdgcn_wave_barrier();  // keep the cross-lane LDS reads below after these writes
+  // ---- per-sample weights (see file header) into this wave's LDS slab ----
+  for (int t = 0; t < P.ntiles; ++t) {
+    const int j = t * 64 + lane;
+    double* w = aw + (long)t * (1 + G) * 64 + lane;
+#pragma unroll
+    for (int a = 0; a < 1 + G; ++a) {
+      double v = 0.0;
+      if (a < g1) {
+        if (j < n) {
+          const long row = (long)j * g1 + a;
+          v = P.KinvY[row];
+          for (int c = 0; c < m; ++c) v = fma(-We[row + (long)c * P.N], zb[kMaxM + c], v);
+        } else if (j < n + u) {
+          v = zb[kMaxM + (j - n) * g1 + a];
+        }
+        // fold alpha and, for derivative weights, the -1/l of (x - X)_{d_a} / l^2 = -diff_scaled[a] / l
+        v *= (a == 0) ? P.alpha : -P.alpha * P.inv_lp[a > 0 ? a - 1 : 0];
+      }
+      w[a * 64] = v;
+    }
+  }
+  // (each lane only ever reads back the weight entries it wrote itself -- no cross-lane hazard; zb is read by every lane
+  //  but was written before the wave-wide butterflies above/below execute, and LDS ops of one wave complete in order)
+
+  // ---- discretised-set scan (.cpp:436-449): f_j = -(mu_n(x_j) + c_j . z); keep the FIRST best ----
+  const double* mu_disc = rec + P.rec.mu_disc;
+  const double* C_disc = rec + P.rec.C_disc;
+  double best_f = -INFINITY;
+  int best_j = 0;
+  for (int j0 = 0; j0 < P.A; j0 += 64) {
+    const int j = j0 + lane;
+    double fj = -INFINITY;
+    if (j < P.A) {
+      double v = mu_disc[j];
+      for (int c = 0; c < m; ++c) v = fma(C_disc[(long)j * m + c], zb[c], v);
+      fj = -v;
+    }
+    double wmax = fj;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) wmax = fmax(wmax, __shfl_xor(wmax, off, 64));
+    const unsigned long long ballot = __ballot(fj == wmax);
+    const int first_lane = __ffsll((long long)ballot) - 1;
+    if (wmax > best_f) {  // strict: an earlier chunk wins ties (priority-queue semantics of .cpp:440-447)
+      best_f = wmax;
+      best_j = j0 + first_lane;
+    }
+  }
+  best_j = __builtin_amdgcn_readfirstlane(best_j);
+
+  const double* disc = rec + P.rec.disc;
+  double x[DP];
+#pragma unroll
+  for (int k = 0; k < DP; ++k) x[k] = (k < size) ? disc[(long)best_j * size + k] : ((k < P.dim) ? 1.0 : 0.0);
+
+  unsigned long long n_val = 0, n_grad = 0;  // passes over the n + u points (the A-point scan is O(A m), not counted)
+  const double step_tolerance = P.tolerance / (double)P.max_num_steps;
+  double fcur = 0.0;
+
+  // GradientDescentOptimizerLineSearch::Optimize (gpp_optimization.hpp:1242-1283) around
+  // GradientDescentOptimizationLineSearch (:708-828), written as a wave-uniform state machine with ONE evaluation site
+  // per kind of pass, so every posterior-mean value is produced by the same instruction sequence (re-evaluating a point
+  // reproduces its value bit for bit, which lets us reuse f(x) where the reference recomputes it).
+  enum { PH_GRAD = 0, PH_TRIAL = 1, PH_CLAMPED = 2 };
+  if (P.max_num_restarts > 0) {
+    int phase = PH_GRAD, restart = 0, istep = 0, search = 0;
+    double alpha_n = 0.0, norm = 0.0, f0 = 0.0;
+    double grad[DP], step[DP], xstart[DP], tq[DP], tqp[DP], gp[DP];
+#pragma unroll
+    for (int k = 0; k < DP; ++k) {
+      xstart[k] = x[k];
+      grad[k] = 0.0;
+      step[k] = 0.0;
+      gp[k] = 0.0;
+    }
+    while (true) {
+#pragma unroll
+      for (int k = 0; k < DP; ++k) {
+        double tk = x[k];
+        if (k < size) {
+          if (phase == PH_TRIAL) tk = x[k] + alpha_n * grad[k];
+          if (phase == PH_CLAMPED) tk = x[k] + step[k];
+        }
+        tq[k] = tk;
+      }
+      to_table_order<DP, G>(tq, P.perm, tqp);
+#pragma unroll
+      for (int r = 0; r < DP; ++r) tqp[r] *= P.inv_lp[r];
+      double fval;
+      if (phase == PH_GRAD) {
+        fval = eval_pass<DP, G, true>(xs, aw, P.ntiles, P.cov_type, P.mean, tqp, P.inv_lp, gp, lane);
+      } else {
+        fval = eval_pass<DP, G, false>(xs, aw, P.ntiles, P.cov_type, P.mean, tqp, P.inv_lp, gp, lane);
+      }
+      bool accept_test = false, end_gd = false;
+      double obj2 = 0.0;
+      if (phase == PH_GRAD) {
+        n_grad++;
+        f0 = fval;
+        fcur = fval;
+        norm = 0.0;
+        from_table_order<DP, G>(gp, P.perm, grad);
+#pragma unroll
+        for (int k = 0; k < DP; ++k)
+          if (k < size) norm = fma(grad[k], grad[k], norm);
+        alpha_n = P.pre_mult * pow((double)(istep + 1), -P.gamma);
+        search = 0;
+        phase = PH_TRIAL;
+        continue;
+      } else if (phase == PH_TRIAL) {
+        n_val++;
+        const bool armijo = (fval - f0 > 0.5 * alpha_n * norm);
+        if (!armijo) {
+          alpha_n *= 0.5;
+          search += 1;
+          if (search < 30) continue;
+        }
+        bool changed = false, nonzero = false;
+#pragma unroll
+        for (int k = 0; k < DP; ++k) {
+          step[k] = 0.0;
+          if (k < size) {
+            const double want = alpha_n * grad[k];
+            step[k] = limit_update_1d(P.bounds[2 * k], P.bounds[2 * k + 1], P.max_relative_change, x[k], want);
+            changed = changed || (step[k] != want);
+            nonzero = nonzero || (step[k] != 0.0);
+          }
+        }
+        if (search == 30 || !nonzero) {
+          end_gd = true;  // .hpp:781-785: x restored (a zero step re-evaluates f(x) == f0 and is rejected)
+        } else if (changed) {
+          phase = PH_CLAMPED;
+          continue;
+        } else {
+          obj2 = fval;  // clamp left the step untouched: f(x + step) is the last trial value
+          accept_test = true;
+        }
+      } else {  // PH_CLAMPED
+        n_val++;
+        obj2 = fval;
+        accept_test = true;
+      }
+      if (accept_test) {
+        if (obj2 <= f0) {
+          end_gd = true;
+        } else {
+#pragma unroll
+          for (int k = 0; k < DP; ++k)
+            if (k < size) x[k] += step[k];
+          fcur = obj2;
+          istep += 1;
+          if (vector_norm<DP>(step, size) < step_tolerance || istep >= P.max_num_steps) {
+            end_gd = true;
+          } else {
+            phase = PH_GRAD;
+            continue;
+          }
+        }
+      }
+      if (end_gd) {
+        restart += 1;
+        double delta[DP];
+#pragma unroll
+        for (int k = 0; k < DP; ++k) delta[k] = xstart[k] - x[k];
+        if (restart < P.max_num_restarts && vector_norm<DP>(delta, size) > P.tolerance) {
+#pragma unroll
+          for (int k = 0; k < DP; ++k) xstart[k] = x[k];
+          istep = 0;
+          phase = PH_GRAD;
+          continue;
+        }
+        break;
+      }
+    }
+  } else {
+    // reference returns without touching its outputs (.cpp:425-427): value 0, point filled with 1.0 (.cpp:163)
+#pragma unroll
+    for (int k = 0; k < DP; ++k) x[k] = (k < P.dim) ? 1.0 : 0.0;
+    fcur = 0.0;
+  }
+
+  const long so = (long)e * P.num_local + sl;
+  if (lane == 0) {
+    P.best_value[so] = fcur;
+    atomicAdd(&P.counters[2 * e], n_val);
+    atomicAdd(&P.counters[2 * e + 1], n_grad);
+  }
+  if (lane < DP) {
+    double v = 0.0;
+#pragma unroll
+    for (int k = 0; k < DP; ++k)
+      if (lane == k) v = x[k];
+    P.best_point[so * DP + lane] = v;
+  }
+  if (lane < m) P.beta[so * m + lane] = bc;
+}
+
+template <int DP, int G, bool XLDS>
+__global__ __launch_bounds__(512) void kg_mc_kernel(KgMcParams P) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int ntiles = P.ntiles;
+  const int tab = ntiles * DP * 64;
+  const int wslab = ntiles * (1 + G) * 64 + 2 * kMaxM;
+  double* aw = smem + (XLDS ? tab : 0) + wave * wslab;
+  double* zb = aw + ntiles * (1 + G) * 64;
+  // evaluation of this workgroup: workgroups b, b + E, b + 2E, ... serve evaluation b mod E (b mod 8 is also the XCD, so
+  // with E = 8 each evaluation's W / table stay in one XCD's L2); with fewer workgroups than evaluations they loop.
+  for (int e = blockIdx.x % P.E; e < P.E; e += (gridDim.x < (unsigned)P.E ? gridDim.x : P.E)) {
+    const double* xs = P.XsTab + (long)e * P.tab_stride;
+    if (XLDS) {
+      __syncthreads();  // previous evaluation's readers are done
+      for (int t = threadIdx.x; t < tab; t += blockDim.x) smem[t] = xs[t];
+      xs = smem;
+      __syncthreads();
+    }
+    while (true) {
+      unsigned int sl = 0;
+      if (lane == 0) sl = atomicAdd(&P.next_sample[e], 1u);
+      sl = (unsigned int)__builtin_amdgcn_readfirstlane((int)sl);
+      if (sl >= (unsigned int)P.num_local) break;
+      kg_sample<DP, G>(P, e, (int)sl, xs, aw, zb, lane);
+    }
+    if (gridDim.x >= (unsigned)P.E) break;
+  }
+}
+
+template <int DP, int G, bool XLDS>
+inline void launch_inst(const KgMcParams& P, int blocks, int waves, size_t shm, hipStream_t s) {
+  auto kern = kg_mc_kernel<DP, G, XLDS>;
+  MOE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+  hipLaunchKernelGGL(kern, dim3(blocks), dim3(waves * 64), shm, s, P);
+  MOE_HIP_CHECK(hipGetLastError());
+}
+
+template <int DP>
+inline void launch_dp(const KgMcParams& P, int G, bool xlds, int blocks, int waves, size_t shm, hipStream_t s) {
+  switch (G) {
+    case 0:
+      if (xlds) launch_inst<DP, 0, true>(P, blocks, waves, shm, s); else launch_inst<DP, 0, false>(P, blocks, waves, shm, s);
+      break;
+    case 2:
+      if (xlds) launch_inst<DP, 2, true>(P, blocks, waves, shm, s); else launch_inst<DP, 2, false>(P, blocks, waves, shm, s);
+      break;
+    case 4:
+      if (xlds) launch_inst<DP, 4, true>(P, blocks, waves, shm, s); else launch_inst<DP, 4, false>(P, blocks, waves, shm, s);
+      break;
+    default: throw Error(MOE_ERR_RUNTIME, "unsupported derivative-slot count in the MC kernel");
+  }
+}
+
+}  // namespace mc
+#endif  // __HIPCC__
+
+}  // namespace moe

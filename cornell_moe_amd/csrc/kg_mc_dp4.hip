@@ -1,0 +1,10 @@
+// cornell_moe_amd/csrc/kg_mc_dp4.hip -- instantiations of the KG Monte-Carlo kernel (kg_mc.hpp) for padded dimension 4.
+#include "kg_mc.hpp"
+
+namespace moe {
+
+void launch_kg_mc_dp4(const KgMcParams& P, int G, bool xlds, int blocks, int waves, size_t shm, hipStream_t s) {
+  mc::launch_dp<4>(P, G, xlds, blocks, waves, shm, s);
+}
+
+}  // namespace moe
