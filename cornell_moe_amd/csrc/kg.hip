@@ -110,7 +110,8 @@ __global__ __launch_bounds__(256) void kg_sw_kernel(KgTailParams P) {
   double acc[MU];
 #pragma unroll
   for (int c = 0; c < MU; ++c) acc[c] = 0.0;
-  for (int row = lane; row < P.N; row += 64) {
+#pragma unroll 4
+  for (int row = lane; row < P.N; row += 64) {  // unrolled: the T / W loads of four row groups are in flight together
     const double t = Tc[row];
 #pragma unroll
     for (int c = 0; c < MU; ++c)
@@ -382,7 +383,7 @@ void kg_evaluate_batch(GpDev& gp, int num_fidelity, const moe_gd_params_t& gd, c
   // ---- MC launch geometry: workgroup = `waves` wavefronts sharing one LDS coordinate table ----
   const size_t tab_bytes = sizeof(double) * (size_t)ntiles * dp * 64;
   const size_t slab_bytes = sizeof(double) * ((size_t)ntiles * (1 + G) * 64 + 2 * kMaxM);
-  const size_t lds_max = 160 * 1024;
+  const size_t lds_max = 160 * 1024 - sizeof(double) * kExpTabLen;  // the exp table sits in front of everything
   bool xlds = true;
   int waves = 0;
   if (tab_bytes + slab_bytes <= lds_max) waves = (int)std::min<size_t>(8, (lds_max - tab_bytes) / slab_bytes);
@@ -395,9 +396,9 @@ void kg_evaluate_batch(GpDev& gp, int num_fidelity, const moe_gd_params_t& gd, c
   }
   if (waves < 1) throw Error(MOE_ERR_RUNTIME, "training set too large for the MC kernel (one sample's weights exceed LDS)");
   waves = std::max(1, std::min(waves, env_int("MOE_KG_WAVES", waves)));
-  const size_t shm = (xlds ? tab_bytes : 0) + (size_t)waves * slab_bytes;
+  const size_t shm = sizeof(double) * kExpTabLen + (xlds ? tab_bytes : 0) + (size_t)waves * slab_bytes;
   const int num_cu = gp.num_cu;
-  const int wg_per_cu = std::max(1, std::min((int)(lds_max / shm), 8 / waves));
+  const int wg_per_cu = std::max(1, std::min((int)((size_t)160 * 1024 / shm), 8 / waves));
   int blocks = num_cu * wg_per_cu;
   if (blocks >= E) blocks = (blocks / E) * E;  // the same number of workgroups for every evaluation
   blocks = env_int("MOE_KG_BLOCKS", blocks);

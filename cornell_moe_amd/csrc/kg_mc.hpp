@@ -28,6 +28,7 @@
 namespace moe {
 
 constexpr int kMaxM = 64;  // m = (q + p)(1 + g) limit of the MC kernel (z / beta scratch per wave)
+constexpr int kExpTabLen = 32;  // 2^(j/32) table at the start of the MC kernel's LDS (fastmath.hpp exp_nonpos_tab)
 
 struct KgRec {  // offsets (doubles) of one evaluation's small operands inside the blob; identical for every evaluation
   int L;        // [m x m] col-major lower Cholesky factor of Var(Xu) + noise
@@ -80,6 +81,33 @@ __device__ __forceinline__ double wave_sum(double v) {
   return v;
 }
 
+// One DPP data movement of a double (two 32-bit v_mov_b32 dpp).  FULL = every lane has a valid source (the in-row
+// permutations): the destination's previous contents are irrelevant, so the source itself is passed as `old` and no
+// zero-fill is emitted.  Otherwise lanes masked off by ROW_MASK read 0.
+template <int CTRL, int ROW_MASK, bool FULL>
+__device__ __forceinline__ double dpp_move(double v) {
+  const int slo = __double2loint(v), shi = __double2hiint(v);
+  const int lo = __builtin_amdgcn_update_dpp(FULL ? slo : 0, slo, CTRL, ROW_MASK, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(FULL ? shi : 0, shi, CTRL, ROW_MASK, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+
+// Sum over the 64 lanes, returned wave-uniform (in SGPRs).  All-VALU: four in-row DPP steps (quad xor 1, quad xor 2,
+// half-row mirror, row mirror), row_bcast15 into rows 1 and 3, row_bcast31 into rows 2 and 3, then v_readlane of lane 63.
+// ~20 instructions with ALU latencies, instead of six dependent ds_bpermute round trips (~100 cycles each) per sum.
+// The summation tree is fixed, so results are deterministic.  Requires all 64 lanes active.
+__device__ __forceinline__ double wave_sum_uniform(double v) {
+  v += dpp_move<0xB1, 0xf, true>(v);    // quad_perm [1,0,3,2]
+  v += dpp_move<0x4E, 0xf, true>(v);    // quad_perm [2,3,0,1]
+  v += dpp_move<0x141, 0xf, true>(v);   // row_half_mirror
+  v += dpp_move<0x140, 0xf, true>(v);   // row_mirror
+  v += dpp_move<0x142, 0xa, false>(v);  // row_bcast15 -> rows 1, 3
+  v += dpp_move<0x143, 0xc, false>(v);  // row_bcast31 -> rows 2, 3
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), 63);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
+  return __hiloint2double(hi, lo);
+}
+
 __device__ __forceinline__ double uniform(double v) {
   // all lanes hold the same bits after a butterfly; tell the compiler so (value moves to SGPRs, branches become scalar)
   const int lo = __builtin_amdgcn_readfirstlane(__double2loint(v));
@@ -90,14 +118,16 @@ __device__ __forceinline__ double uniform(double v) {
 // Radial scalars divided by alpha (alpha is folded into the weights): base = cov[0,0], first = first-derivative
 // coefficient, second = Hessian-product coefficient (device_cov.hpp).
 template <int COV, bool NEED_FIRST, bool NEED_SECOND>
-__device__ __forceinline__ void radial3(double r2, double& base, double& first, double& second) {
+__device__ __forceinline__ void radial3(double r2, const double* __restrict__ etab, double& base, double& first,
+                                        double& second) {
+  // r2 >= 1e-300 by construction (the distance accumulation starts from 1e-300, see eval_loop)
   if (COV == MOE_COV_SQUARE_EXPONENTIAL) {
-    base = exp_nonpos(-0.5 * r2);
+    base = exp_nonpos_tab(-0.5 * r2, etab);
     first = base;
     second = base;
   } else {
-    const double a = 2.236067977499789696409173668731276235 * sqrt_nonneg(r2);
-    const double e = exp_nonpos(-a);
+    const double a = 2.236067977499789696409173668731276235 * sqrt_pos(r2);
+    const double e = exp_nonpos_tab(-a, etab);
     base = e * fma(a, fma(a, 1.0 / 3.0, 1.0), 1.0);  // e^-a (1 + a + a^2/3)   [5 r2 / 3 == a^2 / 3]
     first = NEED_FIRST ? (5.0 / 3.0) * (e * (a + 1.0)) : 0.0;
     second = NEED_SECOND ? (25.0 / 3.0) * e : 0.0;
@@ -109,9 +139,9 @@ __device__ __forceinline__ void radial3(double r2, double& base, double& first, 
 // when it does not fit), aw = this wave's weights [tile][1+G][64] in LDS (zero beyond the real points, so padded lanes
 // contribute exactly 0).
 template <int DP, int G, bool WG, int COV>
-__device__ __forceinline__ double eval_loop(const double* __restrict__ xs, const double* __restrict__ aw, int ntiles,
-                                            double mean, const double (&xq)[DP], const double* inv_lp,
-                                            double (&grad)[DP], int lane) {
+__device__ __forceinline__ double eval_loop(const double* __restrict__ xs, const double* __restrict__ aw,
+                                            const double* __restrict__ etab, int ntiles, double mean,
+                                            const double (&xq)[DP], const double* inv_lp, double (&grad)[DP], int lane) {
   double accf = 0.0;
   double accg[DP];
   double accd[G > 0 ? G : 1];
@@ -140,7 +170,7 @@ __device__ __forceinline__ double eval_loop(const double* __restrict__ xs, const
 #pragma unroll
     for (int a = 0; a < 1 + G; ++a) nw[a] = wt[a * 64];
     double diff[DP];
-    double r2 = 0.0;
+    double r2 = 1.0e-300;  // keeps r2 > 0 for the rsq-based sqrt at no cost (invisible next to any r2 >= 1e-284)
 #pragma unroll
     for (int k = 0; k < DP; ++k) {
       diff[k] = cx[k] - xq[k];
@@ -148,7 +178,7 @@ __device__ __forceinline__ double eval_loop(const double* __restrict__ xs, const
     }
     const double w0 = cw[0];  // alpha * (function-value weight)
     double base, first, second;
-    radial3<COV, (WG || G > 0), (WG && G > 0)>(r2, base, first, second);
+    radial3<COV, (WG || G > 0), (WG && G > 0)>(r2, etab, base, first, second);
     double sd = 0.0;  // sum_a w_a diff[a]  (derivative-observation weights; table rows a < G are the observed dims)
     if (G > 0) {
 #pragma unroll
@@ -171,13 +201,13 @@ __device__ __forceinline__ double eval_loop(const double* __restrict__ xs, const
 #pragma unroll
     for (int a = 0; a < 1 + G; ++a) cw[a] = nw[a];
   }
-  const double mu = mean + uniform(wave_sum(accf));
+  const double mu = mean + wave_sum_uniform(accf);
   if (WG) {
 #pragma unroll
     for (int k = 0; k < DP; ++k) {
       // d mu / d x_k = inv_l[k] * ( sum coef (Xs_k - xq_k)  -  [k < G] sum first w_k );   f = -mu
-      double v = uniform(wave_sum(accg[k]));
-      if (G > 0 && k < G) v -= uniform(wave_sum(accd[k < G ? k : 0]));
+      double v = wave_sum_uniform(accg[k]);
+      if (G > 0 && k < G) v -= wave_sum_uniform(accd[k < G ? k : 0]);
       grad[k] = -(v * inv_lp[k]);
     }
   }
@@ -187,12 +217,12 @@ __device__ __forceinline__ double eval_loop(const double* __restrict__ xs, const
 // The covariance type is wave-uniform: branch ONCE per pass (a branch inside the tile loop would split it into basic blocks
 // and stop the scheduler from interleaving the independent per-tile dependency chains).
 template <int DP, int G, bool WG>
-__device__ __forceinline__ double eval_pass(const double* __restrict__ xs, const double* __restrict__ aw, int ntiles,
-                                            int cov_type, double mean, const double (&xq)[DP], const double* inv_lp,
-                                            double (&grad)[DP], int lane) {
+__device__ __forceinline__ double eval_pass(const double* __restrict__ xs, const double* __restrict__ aw,
+                                            const double* __restrict__ etab, int ntiles, int cov_type, double mean,
+                                            const double (&xq)[DP], const double* inv_lp, double (&grad)[DP], int lane) {
   if (cov_type == MOE_COV_SQUARE_EXPONENTIAL)
-    return eval_loop<DP, G, WG, MOE_COV_SQUARE_EXPONENTIAL>(xs, aw, ntiles, mean, xq, inv_lp, grad, lane);
-  return eval_loop<DP, G, WG, MOE_COV_MATERN_NU_2P5>(xs, aw, ntiles, mean, xq, inv_lp, grad, lane);
+    return eval_loop<DP, G, WG, MOE_COV_SQUARE_EXPONENTIAL>(xs, aw, etab, ntiles, mean, xq, inv_lp, grad, lane);
+  return eval_loop<DP, G, WG, MOE_COV_MATERN_NU_2P5>(xs, aw, etab, ntiles, mean, xq, inv_lp, grad, lane);
 }
 
 // TensorProductDomain::LimitUpdate (gpp_domain.cpp:64-105) on one coordinate.
@@ -270,7 +300,8 @@ __device__ __forceinline__ void from_table_order(const double (&v)[DP], const in
 // One MC sample: weights, discretised-set scan, line-search gradient descent.  Called with the whole wave converged.
 template <int DP, int G>
 __device__ __forceinline__ void kg_sample(const KgMcParams& P, int e, int sl, const double* __restrict__ xs,
-                                          double* __restrict__ aw, double* __restrict__ zb, int lane) {
+                                          double* __restrict__ aw, double* __restrict__ zb,
+                                          const double* __restrict__ etab, int lane) {
   const int m = P.m, u = P.u, n = P.n, g1 = 1 + P.g;
   const int s = P.first_sample + sl;  // global sample index
   const int size = P.dim - P.f;       // problem size of the inner optimisation
@@ -293,6 +324,10 @@ __device__ __forceinline__ void kg_sample(const KgMcParams& P, int e, int sl, co
   zb[kMaxM + lane] = bc;
   __builtin_amdgcn_wave_barrier();  // keep the cross-lane LDS reads below after these writes
   // ---- per-sample weights (see file header) into this wave's LDS slab ----
+  // v(j,a) = KinvY[(j,a)] - sum_c W[(j,a), c] beta_c.  The W loads are issued four columns at a time (column index clamped
+  // to m - 1; beta is 0 beyond m) and two tiles per iteration, so ~10 independent L2 loads are in flight per wait
+  // instead of one dependent load per fma.
+#pragma unroll 2
   for (int t = 0; t < P.ntiles; ++t) {
     const int j = t * 64 + lane;
     double* w = aw + (long)t * (1 + G) * 64 + lane;
@@ -303,7 +338,16 @@ __device__ __forceinline__ void kg_sample(const KgMcParams& P, int e, int sl, co
         if (j < n) {
           const long row = (long)j * g1 + a;
           v = P.KinvY[row];
-          for (int c = 0; c < m; ++c) v = fma(-We[row + (long)c * P.N], zb[kMaxM + c], v);
+          for (int c0 = 0; c0 < m; c0 += 4) {
+            const double l0 = We[row + (long)c0 * P.N];
+            const double l1 = We[row + (long)min(c0 + 1, m - 1) * P.N];
+            const double l2 = We[row + (long)min(c0 + 2, m - 1) * P.N];
+            const double l3 = We[row + (long)min(c0 + 3, m - 1) * P.N];
+            v = fma(-l0, zb[kMaxM + c0], v);
+            v = fma(-l1, zb[kMaxM + min(c0 + 1, kMaxM - 1)], v);
+            v = fma(-l2, zb[kMaxM + min(c0 + 2, kMaxM - 1)], v);
+            v = fma(-l3, zb[kMaxM + min(c0 + 3, kMaxM - 1)], v);
+          }
         } else if (j < n + u) {
           v = zb[kMaxM + (j - n) * g1 + a];
         }
@@ -365,25 +409,17 @@ __device__ __forceinline__ void kg_sample(const KgMcParams& P, int e, int sl, co
       grad[k] = 0.0;
       step[k] = 0.0;
       gp[k] = 0.0;
+      tq[k] = x[k];  // tq = the point the next pass evaluates; every transition below sets it (no per-pass selects)
     }
     while (true) {
-#pragma unroll
-      for (int k = 0; k < DP; ++k) {
-        double tk = x[k];
-        if (k < size) {
-          if (phase == PH_TRIAL) tk = x[k] + alpha_n * grad[k];
-          if (phase == PH_CLAMPED) tk = x[k] + step[k];
-        }
-        tq[k] = tk;
-      }
       to_table_order<DP, G>(tq, P.perm, tqp);
 #pragma unroll
       for (int r = 0; r < DP; ++r) tqp[r] *= P.inv_lp[r];
       double fval;
       if (phase == PH_GRAD) {
-        fval = eval_pass<DP, G, true>(xs, aw, P.ntiles, P.cov_type, P.mean, tqp, P.inv_lp, gp, lane);
+        fval = eval_pass<DP, G, true>(xs, aw, etab, P.ntiles, P.cov_type, P.mean, tqp, P.inv_lp, gp, lane);
       } else {
-        fval = eval_pass<DP, G, false>(xs, aw, P.ntiles, P.cov_type, P.mean, tqp, P.inv_lp, gp, lane);
+        fval = eval_pass<DP, G, false>(xs, aw, etab, P.ntiles, P.cov_type, P.mean, tqp, P.inv_lp, gp, lane);
       }
       bool accept_test = false, end_gd = false;
       double obj2 = 0.0;
@@ -394,11 +430,16 @@ __device__ __forceinline__ void kg_sample(const KgMcParams& P, int e, int sl, co
         norm = 0.0;
         from_table_order<DP, G>(gp, P.perm, grad);
 #pragma unroll
-        for (int k = 0; k < DP; ++k)
-          if (k < size) norm = fma(grad[k], grad[k], norm);
-        alpha_n = P.pre_mult * pow((double)(istep + 1), -P.gamma);
+        for (int k = 0; k < DP; ++k) {
+          if (k >= size) grad[k] = 0.0;  // fidelity / pad coordinates stay pinned
+          norm = fma(grad[k], grad[k], norm);
+        }
+        // pre_mult * (i+1)^-gamma (gpp_optimization.hpp:741); x^-0 == 1 exactly, so gamma == 0 needs no pow()
+        alpha_n = (P.gamma == 0.0) ? P.pre_mult : P.pre_mult * pow((double)(istep + 1), -P.gamma);
         search = 0;
         phase = PH_TRIAL;
+#pragma unroll
+        for (int k = 0; k < DP; ++k) tq[k] = fma(alpha_n, grad[k], x[k]);
         continue;
       } else if (phase == PH_TRIAL) {
         n_val++;
@@ -406,7 +447,11 @@ __device__ __forceinline__ void kg_sample(const KgMcParams& P, int e, int sl, co
         if (!armijo) {
           alpha_n *= 0.5;
           search += 1;
-          if (search < 30) continue;
+          if (search < 30) {
+#pragma unroll
+            for (int k = 0; k < DP; ++k) tq[k] = fma(alpha_n, grad[k], x[k]);
+            continue;
+          }
         }
         bool changed = false, nonzero = false;
 #pragma unroll
@@ -423,6 +468,8 @@ __device__ __forceinline__ void kg_sample(const KgMcParams& P, int e, int sl, co
           end_gd = true;  // .hpp:781-785: x restored (a zero step re-evaluates f(x) == f0 and is rejected)
         } else if (changed) {
           phase = PH_CLAMPED;
+#pragma unroll
+          for (int k = 0; k < DP; ++k) tq[k] = x[k] + step[k];
           continue;
         } else {
           obj2 = fval;  // clamp left the step untouched: f(x + step) is the last trial value
@@ -438,14 +485,15 @@ __device__ __forceinline__ void kg_sample(const KgMcParams& P, int e, int sl, co
           end_gd = true;
         } else {
 #pragma unroll
-          for (int k = 0; k < DP; ++k)
-            if (k < size) x[k] += step[k];
+          for (int k = 0; k < DP; ++k) x[k] += step[k];
           fcur = obj2;
           istep += 1;
           if (vector_norm<DP>(step, size) < step_tolerance || istep >= P.max_num_steps) {
             end_gd = true;
           } else {
             phase = PH_GRAD;
+#pragma unroll
+            for (int k = 0; k < DP; ++k) tq[k] = x[k];
             continue;
           }
         }
@@ -457,7 +505,10 @@ __device__ __forceinline__ void kg_sample(const KgMcParams& P, int e, int sl, co
         for (int k = 0; k < DP; ++k) delta[k] = xstart[k] - x[k];
         if (restart < P.max_num_restarts && vector_norm<DP>(delta, size) > P.tolerance) {
 #pragma unroll
-          for (int k = 0; k < DP; ++k) xstart[k] = x[k];
+          for (int k = 0; k < DP; ++k) {
+            xstart[k] = x[k];
+            tq[k] = x[k];
+          }
           istep = 0;
           phase = PH_GRAD;
           continue;
@@ -496,16 +547,20 @@ __global__ __launch_bounds__(512) void kg_mc_kernel(KgMcParams P) {
   const int ntiles = P.ntiles;
   const int tab = ntiles * DP * 64;
   const int wslab = ntiles * (1 + G) * 64 + 2 * kMaxM;
-  double* aw = smem + (XLDS ? tab : 0) + wave * wslab;
+  // LDS: [32] exp table | [tab] coordinates (if XLDS) | per-wave slabs
+  double* coords = smem + kExpTabLen;
+  double* aw = coords + (XLDS ? tab : 0) + wave * wslab;
   double* zb = aw + ntiles * (1 + G) * 64;
+  if (threadIdx.x < kExpTabLen) smem[threadIdx.x] = kExp2Tab32[threadIdx.x];
+  if (!XLDS) __syncthreads();
   // evaluation of this workgroup: workgroups b, b + E, b + 2E, ... serve evaluation b mod E (b mod 8 is also the XCD, so
   // with E = 8 each evaluation's W / table stay in one XCD's L2); with fewer workgroups than evaluations they loop.
   for (int e = blockIdx.x % P.E; e < P.E; e += (gridDim.x < (unsigned)P.E ? gridDim.x : P.E)) {
     const double* xs = P.XsTab + (long)e * P.tab_stride;
     if (XLDS) {
       __syncthreads();  // previous evaluation's readers are done
-      for (int t = threadIdx.x; t < tab; t += blockDim.x) smem[t] = xs[t];
-      xs = smem;
+      for (int t = threadIdx.x; t < tab; t += blockDim.x) coords[t] = xs[t];
+      xs = coords;
       __syncthreads();
     }
     while (true) {
@@ -513,7 +568,7 @@ __global__ __launch_bounds__(512) void kg_mc_kernel(KgMcParams P) {
       if (lane == 0) sl = atomicAdd(&P.next_sample[e], 1u);
       sl = (unsigned int)__builtin_amdgcn_readfirstlane((int)sl);
       if (sl >= (unsigned int)P.num_local) break;
-      kg_sample<DP, G>(P, e, (int)sl, xs, aw, zb, lane);
+      kg_sample<DP, G>(P, e, (int)sl, xs, aw, zb, smem, lane);
     }
     if (gridDim.x >= (unsigned)P.E) break;
   }

@@ -1,0 +1,85 @@
+// tools/mathcheck.hip -- accuracy (ulp vs long-double host references) of candidate FP64 exp / sqrt sequences for the
+// covariance inner loops.  Build: hipcc --offload-arch=gfx950 -O3 tools/mathcheck.hip -o tools/bin/mathcheck
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <random>
+#include <vector>
+
+#include "../cornell_moe_amd/csrc/fastmath.hpp"
+
+using namespace moe;
+
+__device__ double sqrt_one_heron(double s) {
+  const double y = __builtin_amdgcn_rsq(s);
+  double g = s * y;
+  double h = 0.5 * y;
+  const double e = fma(-h, g, 0.5);
+  g = fma(g, e, g);
+  h = fma(h, e, h);
+  const double d = fma(-g, g, s);
+  g = fma(d, h, g);
+  return g;
+}
+
+__global__ void k(const double* x, int n, const double* tab, double* e_poly, double* e_tab, double* s_two, double* s_one) {
+  __shared__ double T[32];
+  if (threadIdx.x < 32) T[threadIdx.x] = tab[threadIdx.x];
+  __syncthreads();
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  e_poly[i] = exp_nonpos(-x[i]);
+  e_tab[i] = exp_nonpos_tab(-x[i], T);
+  s_two[i] = sqrt_nonneg(x[i]);
+  s_one[i] = sqrt_one_heron(fmax(x[i], 1e-300));
+}
+
+static double ulp_of(double ref) {
+  if (ref == 0) return 4.9e-324;
+  int ex;
+  std::frexp(ref, &ex);
+  return std::ldexp(1.0, ex - 53);
+}
+
+int main() {
+  std::mt19937_64 rng(7);
+  std::vector<double> x;
+  for (double v : {0.0, 1e-300, 1e-30, 1e-16, 1e-8, 0.5, 1.0, 2.0, 10.0, 100.0, 700.0, 744.0, 745.2, 760.0, 800.0}) x.push_back(v);
+  std::uniform_real_distribution<double> u(0.0, 40.0), lg(-12.0, 2.8);
+  for (int i = 0; i < 2000000; ++i) x.push_back(u(rng));
+  for (int i = 0; i < 2000000; ++i) x.push_back(std::pow(10.0, lg(rng)));
+  const int n = (int)x.size();
+  std::vector<double> tab(32);
+  for (int j = 0; j < 32; ++j) tab[j] = (double)std::exp2((long double)j / 32.0L);
+  double *dx, *dt, *d[4];
+  hipMalloc(&dx, 8 * n);
+  hipMalloc(&dt, 8 * 32);
+  for (auto& p : d) hipMalloc(&p, 8 * n);
+  hipMemcpy(dx, x.data(), 8 * n, hipMemcpyHostToDevice);
+  hipMemcpy(dt, tab.data(), 8 * 32, hipMemcpyHostToDevice);
+  hipLaunchKernelGGL(k, dim3((n + 255) / 256), dim3(256), 0, 0, dx, n, dt, d[0], d[1], d[2], d[3]);
+  std::vector<double> h[4];
+  for (int a = 0; a < 4; ++a) {
+    h[a].resize(n);
+    hipMemcpy(h[a].data(), d[a], 8 * n, hipMemcpyDeviceToHost);
+  }
+  const char* names[4] = {"exp poly-11", "exp table-32", "sqrt 2 heron", "sqrt 1 heron"};
+  for (int a = 0; a < 4; ++a) {
+    double worst = 0, wx = 0;
+    for (int i = 0; i < n; ++i) {
+      long double ref = (a < 2) ? expl(-(long double)x[i]) : sqrtl((long double)x[i]);
+      if (a < 2 && ref < 1e-300L) continue;
+      if (a >= 2 && x[i] < 1e-290) continue;
+      const double err = (double)fabsl((long double)h[a][i] - ref) / ulp_of((double)ref);
+      if (err > worst) {
+        worst = err;
+        wx = x[i];
+      }
+    }
+    std::printf("%-14s max error %.3f ulp at x = %.17g\n", names[a], worst, wx);
+  }
+  std::printf("exp(-0) poly %.17g tab %.17g ; exp(-745.2) poly %g tab %g ; exp(-800) poly %g tab %g\n", h[0][0], h[1][0], h[0][12],
+              h[1][12], h[0][14], h[1][14]);
+  return 0;
+}
