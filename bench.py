@@ -55,6 +55,18 @@ def cpu_baseline(w, best, sample_mc, log):
             "sample": "one orc_kg value+gradient at %d of %d MC samples, wall %.2f s, scaled linearly in M" % (sample_mc, w.M, wall)}
 
 
+def measured_traffic(kernel):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (tools/gpu_round.sh -> tools/hbm_traffic.py:
+    FETCH_SIZE and WRITE_SIZE collected in separate --pmc runs, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for
+    gfx950).  bench.py cannot run the profiler on itself, so it reports the latest committed measurement or null."""
+    path = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+    try:
+        with open(path) as fh:
+            return float(json.load(fh)[kernel]["hbm_bytes_per_launch"])
+    except Exception:
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -175,14 +187,18 @@ def main():
                                                                                                  w.P, R),
                        "shard": args.shard, "evals_per_step": evals_per_step},
             "roofline": {"bound": "mfma", "achieved": ach_tflops, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": ach_tflops / FP64_PEAK_TFLOPS, "traffic": None, "kernel": "kg_mc_kernel",
-                         "avg_launch_ms": mc_ms, "value_passes_per_sample": S, "grad_passes_per_sample": Gp,
-                         "note": "dominant kernel is FP64 vector-ALU bound (exp/sqrt per covariance entry); it does not use "
+                         "frac": ach_tflops / FP64_PEAK_TFLOPS, "traffic": measured_traffic("kg_mc_kernel"),
+                         "kernel": "kg_mc_kernel", "avg_launch_ms": mc_ms * R, "avg_ms_per_eval": mc_ms,
+                         "evals_per_launch": R, "value_passes_per_sample": S, "grad_passes_per_sample": Gp,
+                         "note": "dominant kernel is FP64 vector-ALU bound (sqrt + exp per covariance entry); it does not use "
                                  "MFMA -- on gfx950 the dense FP64 MFMA peak equals the FP64 vector peak (78.6 TFLOP/s), "
-                                 "which is the peak used here; HBM traffic of this kernel is ~1 MB per launch"},
+                                 "which is the peak used here; achieved = SURVEY 8(d) algorithmic flops with the device-counted "
+                                 "passes / HIP-event kernel time; one launch covers all evaluations of a step; traffic = "
+                                 "measured HBM bytes per launch (bytes, PMC), tiny next to the compute time"},
             "roofline_cov_build": {"bound": "hbm", "achieved": cov_tbs * 1e3, "peak": HBM_PEAK_TBS * 1e3, "unit": "GB/s",
-                                   "frac": cov_tbs / HBM_PEAK_TBS, "traffic": None, "kernel": "cov_build_kernel (N x M)",
-                                   "avg_launch_ms": cov_ms, "bytes_per_launch": cov_bytes},
+                                   "frac": cov_tbs / HBM_PEAK_TBS, "traffic": measured_traffic("cov_build_kernel"),
+                                   "kernel": "cov_build_kernel (N x M per evaluation, one launch per step)",
+                                   "avg_launch_ms": cov_ms * R, "avg_ms_per_eval": cov_ms, "bytes_per_eval": cov_bytes},
             "kernel_ms_per_eval": {"mc": mc_ms, "cov_build": cov_ms, "tail": ms_tail / args.steps,
                                    "state_host": ms_state / args.steps},
         }

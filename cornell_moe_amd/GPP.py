@@ -420,6 +420,17 @@ def multistart_knowledge_gradient_optimization(optimizer_parameters, optimizer_p
     return list(np.asarray(best).ravel())
 
 
+def posterior_mean_optimization(gaussian_process, num_fidelity, optimizer_parameters, domain_bounds, initial_guess, status):
+    """ComputeOptimalPosteriorMeanWrapper (gpp_python_knowledge_gradient.cpp:315-342): line-search descent on the posterior
+    mean from one initial guess; returns the best point (dim - num_fidelity coordinates)."""
+    from . import multistart
+    if int(optimizer_parameters.domain_type) != int(DomainTypes.tensor_product):
+        raise OptimalLearningException("only the tensor-product domain is implemented on the device path")
+    best, _ = multistart.posterior_mean_optimization(gaussian_process._dev, int(num_fidelity), optimizer_parameters,
+                                                     _flat(domain_bounds), _flat(initial_guess))
+    return list(best)
+
+
 def run_cpp_tests():
     """The reference runs its C++ unit-test suite here (gpp_python_test.cpp:307-314); this backend's tests are the pytest
     suite under tests/ (returns 0 = no failures, like the reference on success)."""

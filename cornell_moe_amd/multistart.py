@@ -1,0 +1,179 @@
+"""Outer multistart optimisation of q-KG: the callers of the hot path, host-driven, with every restart's
+KG value / gradient evaluated in ONE batched device pass per step (moe_kg_batch) instead of one OpenMP thread per restart.
+
+Follows ComputeKGOptimalPointsToSample (gpp_knowledge_gradient_optimization.cpp:490-551):
+  * Latin-hypercube starts in the repeated domain (gpp_random.cpp:173-194, gpp_domain.hpp:490-504);
+  * KG value at every start, the best 20 kept (gpp_knowledge_gradient_optimization.hpp:895-921; the reference pops an
+    under-filled queue when there are fewer than 20 starts -- here all starts are kept in that case);
+  * restarted gradient ASCENT on each kept start: x += LimitUpdate(pre_mult (i+1)^-gamma grad KG), no function evaluations,
+    stop when |step| < tolerance / max_num_steps (gpp_optimization.hpp:619-705, 1144-1185);
+  * KG value at every end point, the best one returned if it beats -inf (MultistartOptimizer, gpp_optimization.hpp:1472-1546);
+  * Latin-hypercube value search as the fall-back / null-optimiser path (.cpp:514-541).
+Every evaluation replays the same normal table (the reference rewinds its RNG before each evaluation), so the descent
+sees common random numbers.  Also: posterior_mean_optimization (ComputeOptimalPosteriorMean from one initial guess,
+gpp_knowledge_gradient_optimization.cpp:420-472 / gpp_python_knowledge_gradient.cpp:315-342).
+"""
+import numpy as np
+
+TOP_K = 20  # gpp_knowledge_gradient_optimization.hpp:901
+
+
+def latin_hypercube(bounds, num_samples, uniform):
+    """ComputeLatinHypercubePointsInDomain: bounds [dim][2]; uniform(size) -> U[0,1) draws; returns [num_samples][dim]."""
+    bounds = np.asarray(bounds, dtype=np.float64).reshape(-1, 2)
+    dim = bounds.shape[0]
+    pts = np.empty((num_samples, dim))
+    for i in range(dim):
+        edge = (bounds[i, 1] - bounds[i, 0]) / float(num_samples)
+        order = np.argsort(uniform(num_samples), kind="stable")  # a uniform random ordering of the slices
+        pts[:, i] = bounds[i, 0] + edge * order + edge * uniform(num_samples)
+    return pts
+
+
+def repeated_domain_starts(bounds, num_points, num_repeats, uniform):
+    """RepeatedDomain::GenerateUniformPointsInDomain: [num_points][num_repeats][dim], one hypercube per repeat."""
+    dim = np.asarray(bounds).size // 2
+    out = np.empty((num_points, num_repeats, dim))
+    for r in range(num_repeats):
+        out[:, r, :] = latin_hypercube(bounds, num_points, uniform)
+    return out
+
+
+def limit_update(bounds, max_relative_change, x, step):
+    """TensorProductDomain::LimitUpdate (gpp_domain.cpp:64-105), vectorised over leading axes; x, step [..., dim]."""
+    b = np.asarray(bounds, dtype=np.float64).reshape(-1, 2)
+    lo, hi = b[:, 0], b[:, 1]
+    step = np.array(step, dtype=np.float64, copy=True)
+    dist = np.minimum(x - lo, hi - x)
+    big = np.abs(step) > max_relative_change * dist
+    step = np.where(big, np.copysign(max_relative_change * dist, step), step)
+    nxt = x + step
+    below, above = nxt < lo, nxt > hi
+    half = 0.5 * step
+    step = np.where(below, np.where(x + half < lo, 0.5 * (lo - x), half), step)
+    step = np.where(above, np.where(x + half > hi, 0.5 * (hi - x), half), step)
+    return step
+
+
+def _gd(params):
+    p = params.optimizer_parameters
+    return (int(p.num_multistarts), int(p.max_num_steps), int(p.max_num_restarts), int(p.num_steps_averaged), float(p.gamma),
+            float(p.pre_mult), float(p.max_relative_change), float(p.tolerance))
+
+
+def kg_values(dev_gp, num_fidelity, inner_gd, inner_bounds, discrete, Xq_all, Xp, num_mc, best_so_far, normals):
+    r = dev_gp.kg_batch(inner_gd, inner_bounds, discrete, Xq_all, Xp, num_mc, best_so_far, normals, want_grad=False,
+                        num_fidelity=num_fidelity)
+    return r["kg_sum"] / num_mc
+
+
+def kg_gradient_ascent(dev_gp, num_fidelity, gd, inner_gd, bounds, inner_bounds, discrete, starts, Xp, num_mc, best_so_far,
+                       normals, on_step=None):
+    """GradientDescentOptimizer::Optimize for every start at once.  starts [S][q][dim] -> end points [S][q][dim]."""
+    _, max_steps, max_restarts, _, gamma, pre_mult, max_rel, tol = gd
+    x = np.array(starts, dtype=np.float64, copy=True)
+    S = x.shape[0]
+    if max_restarts <= 0:
+        return x
+    step_tol = tol / float(max_steps)
+    alive = np.ones(S, dtype=bool)          # restart loop still running
+    for _ in range(max_restarts):
+        if not alive.any():
+            break
+        x_begin = x.copy()
+        running = alive.copy()              # inner GD loop still running
+        for i in range(max_steps):
+            idx = np.flatnonzero(running)
+            if idx.size == 0:
+                break
+            alpha = pre_mult * float(i + 1) ** (-gamma)
+            r = dev_gp.kg_batch(inner_gd, inner_bounds, discrete, x[idx], Xp, num_mc, best_so_far, normals, want_grad=True,
+                                num_fidelity=num_fidelity)
+            grad = r["grad_sum"] / num_mc
+            step = limit_update(bounds, max_rel, x[idx], alpha * grad)
+            x[idx] += step
+            norm = np.sqrt((step.reshape(idx.size, -1) ** 2).sum(axis=1))
+            running[idx[norm < step_tol]] = False
+            if on_step is not None:
+                on_step(i, idx, r)
+        delta = np.sqrt(((x_begin - x).reshape(S, -1) ** 2).sum(axis=1))
+        alive &= delta > tol
+    return x
+
+
+def kg_optimal_points(dev_gp, num_fidelity, optimizer_parameters, optimizer_parameters_inner, bounds, discrete, Xp,
+                      num_to_sample, best_so_far, num_mc, randomness, starts=None):
+    """ComputeKGOptimalPointsToSample.  Returns (best_points [q][dim], found_flag)."""
+    d = dev_gp.d
+    q = int(num_to_sample)
+    size = d - num_fidelity
+    bounds = np.asarray(bounds, dtype=np.float64).reshape(-1)[:2 * d]
+    inner_bounds = bounds[:2 * size]
+    inner_gd = _gd(optimizer_parameters_inner)
+    p = 0 if Xp is None else np.asarray(Xp).reshape(-1, d).shape[0]
+    m = (q + p) * (1 + dev_gp.g)
+    normals = randomness.normal_rng_vec[0].table(((num_mc + 1) // 2) * m)
+    from . import GPP
+    use_gd = int(optimizer_parameters.optimizer_type) == int(GPP.OptimizerTypes.gradient_descent)
+    best_point, best_value, found = np.zeros((q, d)), -np.inf, False
+
+    def consider(points, values):
+        nonlocal best_point, best_value, found
+        j = int(np.argmax(values))
+        if values[j] > best_value:      # strict, like MultistartOptimizer's per-thread compare
+            best_value, best_point, found = float(values[j]), np.array(points[j], copy=True), True
+
+    if use_gd:
+        gd = _gd(optimizer_parameters)
+        if starts is None:
+            starts = repeated_domain_starts(bounds, gd[0], q, randomness._uniform_random)
+        starts = np.asarray(starts, dtype=np.float64).reshape(-1, q, d)
+        vals = kg_values(dev_gp, num_fidelity, inner_gd, inner_bounds, discrete, starts, Xp, num_mc, best_so_far, normals)
+        keep = np.argsort(-vals, kind="stable")[:TOP_K]
+        ends = kg_gradient_ascent(dev_gp, num_fidelity, gd, inner_gd, bounds, inner_bounds, discrete, starts[keep], Xp, num_mc,
+                                  best_so_far, normals)
+        end_vals = kg_values(dev_gp, num_fidelity, inner_gd, inner_bounds, discrete, ends, Xp, num_mc, best_so_far, normals)
+        consider(ends, end_vals)
+    if not found:
+        n_lhc = int(optimizer_parameters.num_random_samples or 0)
+        if n_lhc > 0:
+            pts = repeated_domain_starts(bounds, n_lhc, q, randomness._uniform_random)
+            vals = kg_values(dev_gp, num_fidelity, inner_gd, inner_bounds, discrete, pts, Xp, num_mc, best_so_far, normals)
+            consider(pts, vals)
+    return best_point, found
+
+
+def posterior_mean_optimization(dev_gp, num_fidelity, optimizer_parameters, bounds, initial_guess):
+    """ComputeOptimalPosteriorMean from ONE start: back-tracking line-search ascent on f = -mu (fidelity coordinates = 1),
+    gpp_optimization.hpp:708-828 / 1242-1283.  Returns (best_point [dim - num_fidelity], found_flag)."""
+    _, max_steps, max_restarts, _, gamma, pre_mult, max_rel, tol = _gd(optimizer_parameters)
+    size = dev_gp.d - num_fidelity
+    b = np.asarray(bounds, dtype=np.float64).reshape(-1)[:2 * size]
+    x = np.array(initial_guess, dtype=np.float64).reshape(-1)[:size].copy()
+
+    def f(pt, grad=False):
+        v, g = dev_gp.posterior_mean(pt, num_fidelity, want_grad=grad)
+        return (v, g) if grad else v
+
+    step_tol = tol / float(max_steps)
+    for _ in range(max(max_restarts, 0)):
+        x_begin = x.copy()
+        for i in range(max_steps):
+            f0, g = f(x, True)
+            alpha = pre_mult * float(i + 1) ** (-gamma)
+            norm2 = float(np.dot(g, g))
+            search = 0
+            while search < 30:
+                if f(x + alpha * g) - f0 > 0.5 * alpha * norm2:
+                    break
+                alpha *= 0.5
+                search += 1
+            step = limit_update(b, max_rel, x, alpha * g)
+            if search == 30 or f(x + step) <= f0:
+                break
+            x = x + step
+            if np.sqrt(float(np.dot(step, step))) < step_tol:
+                break
+        if np.sqrt(float(np.dot(x_begin - x, x_begin - x))) <= tol:
+            break
+    return x, True

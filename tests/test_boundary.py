@@ -19,6 +19,7 @@ HOT_PATH_EXPORTS = [
     ("compute_grad_knowledge_gradient", 13),            # :115-123
     ("multistart_knowledge_gradient_optimization", 15),  # :243-252
     ("evaluate_KG_at_point_list", 15),                  # :344-354
+    ("posterior_mean_optimization", 6),                 # :315-320
     ("compute_expected_improvement", 9),                # gpp_python_expected_improvement.cpp:44-50
     ("compute_grad_expected_improvement", 9),           # :77-83
     ("evaluate_EI_at_point_list", 13),                  # :221-231
@@ -61,8 +62,7 @@ def test_every_hot_path_binding_of_the_reference_wrappers_exists():
     from cornell_moe_amd import GPP
     in_scope = ["knowledge_gradient.py", "expected_improvement.py", "gaussian_process.py", "domain.py", "optimization.py",
                 "covariance.py"]
-    out_of_scope = {"multistart_expected_improvement_optimization",  # EI outer optimiser: SURVEY 8f (next, after KG's)
-                    "posterior_mean_optimization"}                   # provided by cornell_moe_amd.multistart (8f rank 1)
+    out_of_scope = {"multistart_expected_improvement_optimization"}  # EI outer optimiser: SURVEY 8f (next, after KG's)
     missing = []
     for fn in in_scope:
         src = open(os.path.join(REF_WRAPPERS, fn)).read()
@@ -114,3 +114,38 @@ def test_wrapper_mirror_containers():
     assert int(opt.optimizer_parameters.domain_type) == 0 and int(opt.optimizer_parameters.optimizer_type) == 1
     cov = cw.SquareExponential([1.0, 0.5, 0.6])
     assert cw.cppify_hyperparameters(cov.hyperparameters) == [1.0, [0.5, 0.6]]
+
+
+def test_multistart_host_pieces():
+    """LimitUpdate (gpp_domain.cpp:64-105) vectorised == a scalar restatement; Latin hypercube has one point per slice."""
+    from cornell_moe_amd import multistart as ms
+    rng = np.random.default_rng(3)
+    bounds = np.array([[0.0, 1.0], [-2.0, 3.0], [5.0, 5.5]])
+
+    def scalar(lo, hi, mrc, x, s):
+        dist = min(x - lo, hi - x)
+        if abs(s) > mrc * dist:
+            s = np.copysign(mrc * dist, s)
+        nxt = x + s
+        if nxt < lo:
+            s = 0.5 * (lo - x) if x + 0.5 * s < lo else 0.5 * s
+        elif nxt > hi:
+            s = 0.5 * (hi - x) if x + 0.5 * s > hi else 0.5 * s
+        return s
+
+    x = bounds[:, 0] + rng.uniform(size=(50, 2, 3)) * (bounds[:, 1] - bounds[:, 0])
+    x[0, 0] = bounds[:, 0]  # on the walls
+    x[1, 1] = bounds[:, 1]
+    step = rng.normal(scale=2.0, size=x.shape)
+    got = ms.limit_update(bounds, 0.7, x, step)
+    for idx in np.ndindex(x.shape):
+        lo, hi = bounds[idx[-1]]
+        assert got[idx] == scalar(lo, hi, 0.7, x[idx], step[idx])
+    assert np.all(x + got >= bounds[:, 0] - 1e-15) and np.all(x + got <= bounds[:, 1] + 1e-15)
+    u = np.random.RandomState(1)
+    pts = ms.repeated_domain_starts(bounds.ravel(), 16, 3, lambda n: u.uniform(size=n))
+    assert pts.shape == (16, 3, 3)
+    for r in range(3):
+        for k in range(3):
+            cells = np.floor((pts[:, r, k] - bounds[k, 0]) / ((bounds[k, 1] - bounds[k, 0]) / 16)).astype(int)
+            assert sorted(cells) == list(range(16))

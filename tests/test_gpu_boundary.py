@@ -110,3 +110,45 @@ def test_exceptions_cross_the_boundary_as_reference_classes():
         GPP.GaussianProcess([1.0, [0.5, 0.5]], list(X.ravel()), list(np.zeros(10)), [0.0], [], 0, 2, 10)
     with pytest.raises(GPP.OptimalLearningException):
         GPP.GaussianProcess([1.0, [0.5, -0.5]], list(X.ravel()), list(np.zeros(10)), [0.1], [], 0, 2, 10)
+
+
+def test_multistart_knowledge_gradient_optimization():
+    """The outer optimiser: restarted gradient ascent over Latin-hypercube starts returns a point inside
+    the domain whose KG is at least the best starting KG; deterministic for fixed seeds; status dict filled like the reference."""
+    from cornell_moe_amd import GPP
+    cw, w, gp = _setup(seed=41, n=60, d=2, q=2, p=0, P=6, M=200)
+    ps = cw.PosteriorMean(gp, 0)
+    dom = cw.TensorProductDomain([[0.0, 1.0]] * 2)
+    inner = cw.GradientDescentOptimizer(dom, ps, cw.GradientDescentParameters(1, 6, 1, 3, 0.0, 1.0, 0.1, 1e-10))
+
+    def run():
+        rnd = GPP.RandomnessSourceContainer(1)
+        rnd.SetExplicitNormalRNGSeed(7)
+        rnd.SetExplicitUniformGeneratorSeed(11)
+        kg = cw.KnowledgeGradient(gp, 0, inner, w.discrete, num_mc_iterations=w.M, randomness=rnd)
+        outer = cw.GradientDescentOptimizer(dom, kg, cw.GradientDescentParameters(12, 8, 2, 4, 0.7, 0.3, 0.2, 1e-7), 10)
+        status = {}
+        best = cw.multistart_knowledge_gradient_optimization(outer, inner, 12, w.discrete, 2, w.discrete.shape[0],
+                                                             randomness=rnd, max_num_threads=1, status=status)
+        return kg, rnd, best, status
+
+    kg, rnd, best, status = run()
+    assert best.shape == (2, 2) and best.min() >= 0.0 and best.max() <= 1.0
+    assert status == {"gradient_descent_tensor_product_domain_found_update": True}
+    kg.set_current_point(best)
+    v_best = kg.compute_knowledge_gradient()
+    # the same starts the optimiser drew (same uniform seed) cannot beat its answer
+    from cornell_moe_amd import multistart as ms
+    rnd2 = GPP.RandomnessSourceContainer(1)
+    rnd2.SetExplicitUniformGeneratorSeed(11)
+    starts = ms.repeated_domain_starts(np.array([0.0, 1.0, 0.0, 1.0]), 12, 2, rnd2._uniform_random)
+    vals = kg.evaluate_at_point_list(starts, max_num_threads=1)
+    assert v_best >= vals.max() - 1e-12 * abs(vals.max())
+    _, _, best2, _ = run()
+    assert np.array_equal(best, best2)
+    # recommendation step of the BO loop: posterior-mean optimisation from the best discrete point
+    x0 = w.discrete[int(np.argmin(gp.compute_mean_of_additional_points(w.discrete)))]
+    xs = np.array(GPP.posterior_mean_optimization(gp._gaussian_process, 0, inner.optimizer_parameters, [0.0, 1.0, 0.0, 1.0],
+                                                  list(x0), {}))
+    assert xs.shape == (2,) and xs.min() >= 0.0 and xs.max() <= 1.0
+    assert gp.compute_mean_of_points(xs[None, :])[0] <= gp.compute_mean_of_points(x0[None, :])[0] + 1e-12

@@ -1,0 +1,30 @@
+"""Reduce the FETCH_SIZE / WRITE_SIZE rocprofv3 passes (tools/gpu_round.sh) to HBM bytes per launch for the KG kernels.
+
+FETCH_SIZE / WRITE_SIZE are in KiB-like units of 1 KB (rocprofv3 derived counters); on gfx950 FETCH_SIZE reports 1/2 of
+the bytes of a wide coalesced streaming read (MI355X_MICROARCH.md section HBM), so the read side is doubled -- an upper
+estimate for kernels whose reads are not wide streams."""
+import csv
+import glob
+import json
+import os
+import sys
+from collections import defaultdict
+
+root = sys.argv[1]
+acc = defaultdict(lambda: defaultdict(list))
+for f in glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recursive=True):
+    with open(f) as fh:
+        for row in csv.DictReader(fh):
+            name = row["Kernel_Name"]
+            key = "kg_mc_kernel" if "kg_mc_kernel" in name else ("cov_build_kernel" if "cov_build_kernel" in name else None)
+            if key == "cov_build_kernel" and int(row["Grid_Size"]) < 1_000_000:
+                continue  # only the N x (E M) gradient-tail build, not the small state builds
+            if key:
+                acc[key][row["Counter_Name"]].append(float(row["Counter_Value"]))
+out = {}
+for k, c in acc.items():
+    fetch = sum(c.get("FETCH_SIZE", [0])) / max(len(c.get("FETCH_SIZE", [1])), 1)
+    write = sum(c.get("WRITE_SIZE", [0])) / max(len(c.get("WRITE_SIZE", [1])), 1)
+    out[k] = {"fetch_size_raw_kb": fetch, "write_size_raw_kb": write,
+              "hbm_bytes_per_launch": (2.0 * fetch + write) * 1024.0, "launches": len(c.get("FETCH_SIZE", []))}
+print(json.dumps(out))
