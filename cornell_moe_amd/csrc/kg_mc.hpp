@@ -87,8 +87,14 @@ __device__ __forceinline__ double wave_sum(double v) {
 template <int CTRL, int ROW_MASK, bool FULL>
 __device__ __forceinline__ double dpp_move(double v) {
   const int slo = __double2loint(v), shi = __double2hiint(v);
-  const int lo = __builtin_amdgcn_update_dpp(FULL ? slo : 0, slo, CTRL, ROW_MASK, 0xf, false);
-  const int hi = __builtin_amdgcn_update_dpp(FULL ? shi : 0, shi, CTRL, ROW_MASK, 0xf, false);
+  int lo, hi;
+  if (FULL) {  // every destination lane is written: no `old` operand, hence no copy to set it up
+    lo = __builtin_amdgcn_mov_dpp(slo, CTRL, ROW_MASK, 0xf, false);
+    hi = __builtin_amdgcn_mov_dpp(shi, CTRL, ROW_MASK, 0xf, false);
+  } else {
+    lo = __builtin_amdgcn_update_dpp(0, slo, CTRL, ROW_MASK, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(0, shi, CTRL, ROW_MASK, 0xf, false);
+  }
   return __hiloint2double(hi, lo);
 }
 
@@ -242,26 +248,17 @@ __device__ __forceinline__ double limit_update_1d(double lo, double hi, double m
   return desired;
 }
 
-// VectorNorm (gpp_linear_algebra.cpp:53-72)
+// 2-norm of the first `size` entries.  The reference's VectorNorm (gpp_linear_algebra.cpp:53-72) uses the scaled
+// (overflow-safe) recurrence with one FP64 division per entry; here the value only feeds the two threshold tests of the
+// line search (|step| < tolerance / max_steps, |x - x_start| > tolerance) on O(1)-magnitude vectors, where sqrt(sum v^2)
+// agrees with it to 2 ulp, so the plain form (an order of magnitude fewer instructions) is used.
 template <int DP>
 __device__ __forceinline__ double vector_norm(const double (&v)[DP], int size) {
-  if (size == 1) return fabs(v[0]);
-  double scale = 0.0, scaled = 1.0;
+  double ss = 0.0;
 #pragma unroll
-  for (int i = 0; i < DP; ++i) {
-    if (i < size && v[i] != 0.0) {
-      const double av = fabs(v[i]);
-      if (scale < av) {
-        const double t = scale / av;
-        scaled = 1.0 + scaled * (t * t);
-        scale = av;
-      } else {
-        const double t = av / scale;
-        scaled += t * t;
-      }
-    }
-  }
-  return scale * sqrt(scaled);
+  for (int i = 0; i < DP; ++i)
+    if (i < size) ss = fma(v[i], v[i], ss);
+  return sqrt(ss);
 }
 
 // out[r] = v[perm[r]] for wave-uniform v (select chains on uniform data; identity when the GP has no derivatives)
@@ -395,64 +392,52 @@ __device__ __forceinline__ void kg_sample(const KgMcParams& P, int e, int sl, co
   double fcur = 0.0;
 
   // GradientDescentOptimizerLineSearch::Optimize (gpp_optimization.hpp:1242-1283) around
-  // GradientDescentOptimizationLineSearch (:708-828), written as a wave-uniform state machine with ONE evaluation site
-  // per kind of pass, so every posterior-mean value is produced by the same instruction sequence (re-evaluating a point
-  // reproduces its value bit for bit, which lets us reuse f(x) where the reference recomputes it).
-  enum { PH_GRAD = 0, PH_TRIAL = 1, PH_CLAMPED = 2 };
+  // GradientDescentOptimizationLineSearch (:708-828), as plain nested wave-uniform loops.  The Armijo back-tracking loop --
+  // where 5 of every 6 passes are spent -- carries only (alpha, search) through its back edge; x and grad are loop
+  // invariant there, so the compiler has no array phis to shuffle (a single-evaluation-site state machine cost ~250
+  // v_mov_b64 / lane-spill instructions per pass).  Every posterior-mean value comes from the same dataflow (eval_loop,
+  // explicit fma only), so re-evaluating a point reproduces its value bit for bit at any call site, which lets us reuse
+  // f(x) where the reference recomputes it.
   if (P.max_num_restarts > 0) {
-    int phase = PH_GRAD, restart = 0, istep = 0, search = 0;
-    double alpha_n = 0.0, norm = 0.0, f0 = 0.0;
     double grad[DP], step[DP], xstart[DP], tq[DP], tqp[DP], gp[DP];
 #pragma unroll
-    for (int k = 0; k < DP; ++k) {
-      xstart[k] = x[k];
-      grad[k] = 0.0;
-      step[k] = 0.0;
-      gp[k] = 0.0;
-      tq[k] = x[k];  // tq = the point the next pass evaluates; every transition below sets it (no per-pass selects)
-    }
-    while (true) {
-      to_table_order<DP, G>(tq, P.perm, tqp);
+    for (int k = 0; k < DP; ++k) gp[k] = 0.0;
+    for (int restart = 0; restart < P.max_num_restarts; ++restart) {
 #pragma unroll
-      for (int r = 0; r < DP; ++r) tqp[r] *= P.inv_lp[r];
-      double fval;
-      if (phase == PH_GRAD) {
-        fval = eval_pass<DP, G, true>(xs, aw, etab, P.ntiles, P.cov_type, P.mean, tqp, P.inv_lp, gp, lane);
-      } else {
-        fval = eval_pass<DP, G, false>(xs, aw, etab, P.ntiles, P.cov_type, P.mean, tqp, P.inv_lp, gp, lane);
-      }
-      bool accept_test = false, end_gd = false;
-      double obj2 = 0.0;
-      if (phase == PH_GRAD) {
+      for (int k = 0; k < DP; ++k) xstart[k] = x[k];
+      for (int istep = 0; istep < P.max_num_steps;) {
+        // ---- f(x), grad f(x) ----
+        to_table_order<DP, G>(x, P.perm, tqp);
+#pragma unroll
+        for (int r = 0; r < DP; ++r) tqp[r] *= P.inv_lp[r];
+        const double f0 = eval_pass<DP, G, true>(xs, aw, etab, P.ntiles, P.cov_type, P.mean, tqp, P.inv_lp, gp, lane);
         n_grad++;
-        f0 = fval;
-        fcur = fval;
-        norm = 0.0;
+        fcur = f0;
         from_table_order<DP, G>(gp, P.perm, grad);
+        double norm = 0.0;
 #pragma unroll
         for (int k = 0; k < DP; ++k) {
           if (k >= size) grad[k] = 0.0;  // fidelity / pad coordinates stay pinned
           norm = fma(grad[k], grad[k], norm);
         }
         // pre_mult * (i+1)^-gamma (gpp_optimization.hpp:741); x^-0 == 1 exactly, so gamma == 0 needs no pow()
-        alpha_n = (P.gamma == 0.0) ? P.pre_mult : P.pre_mult * pow((double)(istep + 1), -P.gamma);
-        search = 0;
-        phase = PH_TRIAL;
+        double alpha_n = (P.gamma == 0.0) ? P.pre_mult : P.pre_mult * pow((double)(istep + 1), -P.gamma);
+        // ---- Armijo back-tracking (.hpp:745-760): unclamped trial points ----
+        int search = 0;
+        double ftrial;
+        while (true) {
 #pragma unroll
-        for (int k = 0; k < DP; ++k) tq[k] = fma(alpha_n, grad[k], x[k]);
-        continue;
-      } else if (phase == PH_TRIAL) {
-        n_val++;
-        const bool armijo = (fval - f0 > 0.5 * alpha_n * norm);
-        if (!armijo) {
+          for (int k = 0; k < DP; ++k) tq[k] = fma(alpha_n, grad[k], x[k]);
+          to_table_order<DP, G>(tq, P.perm, tqp);
+#pragma unroll
+          for (int r = 0; r < DP; ++r) tqp[r] *= P.inv_lp[r];
+          ftrial = eval_pass<DP, G, false>(xs, aw, etab, P.ntiles, P.cov_type, P.mean, tqp, P.inv_lp, gp, lane);
+          n_val++;
+          if (ftrial - f0 > 0.5 * alpha_n * norm) break;
           alpha_n *= 0.5;
-          search += 1;
-          if (search < 30) {
-#pragma unroll
-            for (int k = 0; k < DP; ++k) tq[k] = fma(alpha_n, grad[k], x[k]);
-            continue;
-          }
+          if (++search >= 30) break;
         }
+        // ---- LimitUpdate, then accept only if f improves (.hpp:762-795) ----
         bool changed = false, nonzero = false;
 #pragma unroll
         for (int k = 0; k < DP; ++k) {
@@ -464,57 +449,28 @@ __device__ __forceinline__ void kg_sample(const KgMcParams& P, int e, int sl, co
             nonzero = nonzero || (step[k] != 0.0);
           }
         }
-        if (search == 30 || !nonzero) {
-          end_gd = true;  // .hpp:781-785: x restored (a zero step re-evaluates f(x) == f0 and is rejected)
-        } else if (changed) {
-          phase = PH_CLAMPED;
+        if (search == 30 || !nonzero) break;  // .hpp:781-785: x restored (a zero step re-evaluates f(x) == f0: rejected)
+        double obj2 = ftrial;  // clamp left the step untouched: f(x + step) is the last trial value
+        if (changed) {
 #pragma unroll
           for (int k = 0; k < DP; ++k) tq[k] = x[k] + step[k];
-          continue;
-        } else {
-          obj2 = fval;  // clamp left the step untouched: f(x + step) is the last trial value
-          accept_test = true;
+          to_table_order<DP, G>(tq, P.perm, tqp);
+#pragma unroll
+          for (int r = 0; r < DP; ++r) tqp[r] *= P.inv_lp[r];
+          obj2 = eval_pass<DP, G, false>(xs, aw, etab, P.ntiles, P.cov_type, P.mean, tqp, P.inv_lp, gp, lane);
+          n_val++;
         }
-      } else {  // PH_CLAMPED
-        n_val++;
-        obj2 = fval;
-        accept_test = true;
+        if (obj2 <= f0) break;
+#pragma unroll
+        for (int k = 0; k < DP; ++k) x[k] += step[k];
+        fcur = obj2;
+        istep += 1;
+        if (vector_norm<DP>(step, size) < step_tolerance) break;
       }
-      if (accept_test) {
-        if (obj2 <= f0) {
-          end_gd = true;
-        } else {
+      double delta[DP];
 #pragma unroll
-          for (int k = 0; k < DP; ++k) x[k] += step[k];
-          fcur = obj2;
-          istep += 1;
-          if (vector_norm<DP>(step, size) < step_tolerance || istep >= P.max_num_steps) {
-            end_gd = true;
-          } else {
-            phase = PH_GRAD;
-#pragma unroll
-            for (int k = 0; k < DP; ++k) tq[k] = x[k];
-            continue;
-          }
-        }
-      }
-      if (end_gd) {
-        restart += 1;
-        double delta[DP];
-#pragma unroll
-        for (int k = 0; k < DP; ++k) delta[k] = xstart[k] - x[k];
-        if (restart < P.max_num_restarts && vector_norm<DP>(delta, size) > P.tolerance) {
-#pragma unroll
-          for (int k = 0; k < DP; ++k) {
-            xstart[k] = x[k];
-            tq[k] = x[k];
-          }
-          istep = 0;
-          phase = PH_GRAD;
-          continue;
-        }
-        break;
-      }
+      for (int k = 0; k < DP; ++k) delta[k] = xstart[k] - x[k];
+      if (!(vector_norm<DP>(delta, size) > P.tolerance)) break;
     }
   } else {
     // reference returns without touching its outputs (.cpp:425-427): value 0, point filled with 1.0 (.cpp:163)

@@ -12,7 +12,13 @@ from cornell_moe_amd.workloads import make_workload  # noqa: E402
 cfg = sys.argv[1] if len(sys.argv) > 1 else "C3"
 R = int(sys.argv[2]) if len(sys.argv) > 2 else 8
 reps = int(sys.argv[3]) if len(sys.argv) > 3 else 3
-w = make_workload(cfg, num_restarts=R)
+over = {}
+if ":" in cfg:  # e.g. C3:n=60,M=2000  -- override fields of a named configuration
+    cfg, tail = cfg.split(":", 1)
+    for kv in tail.split(","):
+        k, v = kv.split("=")
+        over[k] = int(v)
+w = make_workload(cfg, num_restarts=R, **over)
 G = DeviceGP(w.hyperparameters, w.X, w.y, w.noise, w.derivs)
 best = float(G.additional_mean(w.discrete).min())
 for i in range(reps):
