@@ -28,7 +28,7 @@ struct GpDev {
   // reusable workspaces for states
   DevBuf<double> dPts, dPtsGrad, dExtra, dE, dVE, dWE, dGram, dEK;
   // reusable workspaces of the KG evaluator (kg.hip)
-  DevBuf<double> kBlob, kNormals, kTab, kBestPoint, kBestValue, kBeta, kT, kC, kTB, kOut;
+  DevBuf<double> kBlob, kNormals, kTab, kBestPoint, kBestValue, kBeta, kT, kC, kTB, kOut, kSW;
   DevBuf<unsigned long long> kCounters;
   int num_cu = 256;
   // timing of the last KG call (ms): mc, cov-build, tail contraction, state, total

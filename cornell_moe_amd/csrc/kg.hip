@@ -77,6 +77,7 @@ struct KgTailParams {
   DerivList derivs;  // the GP's derivative observations (carried by the union points too)
   int u, q, m, g, N, E, num_local, first_sample, ngrad, chunks;
   const double* T;           // [N x E*num_local], ld N
+  const double* SW;          // optional precomputed W^T T, [m x E*num_local] col-major (large m: tile GEMM); else null
   const double* W;           // evaluation e at W + e * w_stride, [N x m], ld N
   long w_stride;
   const double* Gm;          // K^-1 dK*/dXq: evaluation e at Gm + e * g_stride, [N x ngrad], ld N
@@ -107,21 +108,24 @@ __global__ __launch_bounds__(256) void kg_sw_kernel(KgTailParams P) {
   const int m = P.m, g1 = 1 + P.g;
   const double* Tc = P.T + w * P.N;
   const double* We = P.W + (long)e * P.w_stride;
-  double acc[MU];
-#pragma unroll
-  for (int c = 0; c < MU; ++c) acc[c] = 0.0;
-#pragma unroll 4
-  for (int row = lane; row < P.N; row += 64) {  // unrolled: the T / W loads of four row groups are in flight together
-    const double t = Tc[row];
-#pragma unroll
-    for (int c = 0; c < MU; ++c)
-      if (c < m) acc[c] = fma(We[row + (long)c * P.N], t, acc[c]);
-  }
   double mine = 0.0;
+  if (P.SW != nullptr) {
+    if (lane < m) mine = P.SW[w * m + lane];
+  } else {
+    double acc[MU];
 #pragma unroll
-  for (int c = 0; c < MU; ++c) {
-    const double v = wave_sum64(acc[c]);
-    if (lane == c) mine = v;
+    for (int c = 0; c < MU; ++c) acc[c] = 0.0;
+    for (int row = lane; row < P.N; row += 64) {
+      const double t = Tc[row];
+#pragma unroll
+      for (int c = 0; c < MU; ++c)
+        if (c < m) acc[c] = fma(We[row + (long)c * P.N], t, acc[c]);
+    }
+#pragma unroll
+    for (int c = 0; c < MU; ++c) {
+      const double v = wave_sum64(acc[c]);
+      if (lane == c) mine = v;
+    }
   }
   const double* rec = P.blob + (long)e * P.rec.stride;
   const double* Lsm = rec + P.rec.L;
@@ -352,6 +356,16 @@ void launch_mc(const KgMcParams& P, int dp, int G, bool xlds, int blocks, int wa
   }
 }
 
+void launch_mc_block(const KgMcParams& P, int dp, int G, int tpw, int blocks, int waves, hipStream_t s) {
+  switch (dp) {
+    case 4: launch_kg_mc_block_dp4(P, G, tpw, blocks, waves, s); break;
+    case 8: launch_kg_mc_block_dp8(P, G, tpw, blocks, waves, s); break;
+    case 12: launch_kg_mc_block_dp12(P, G, tpw, blocks, waves, s); break;
+    case 16: launch_kg_mc_block_dp16(P, G, tpw, blocks, waves, s); break;
+    default: throw Error(MOE_ERR_RUNTIME, "unsupported padded dimension");
+  }
+}
+
 }  // namespace
 
 void kg_evaluate_batch(GpDev& gp, int num_fidelity, const moe_gd_params_t& gd, const double* bounds, const double* discrete,
@@ -394,11 +408,25 @@ void kg_evaluate_batch(GpDev& gp, int num_fidelity, const moe_gd_params_t& gd, c
       xlds = false;
     }
   }
-  if (waves < 1) throw Error(MOE_ERR_RUNTIME, "training set too large for the MC kernel (one sample's weights exceed LDS)");
-  waves = std::max(1, std::min(waves, env_int("MOE_KG_WAVES", waves)));
-  const size_t shm = sizeof(double) * kExpTabLen + (xlds ? tab_bytes : 0) + (size_t)waves * slab_bytes;
+  // Variant selection: the wave-per-sample kernel needs the coordinate table AND >= 4 weight slabs in LDS; bigger point
+  // sets (up to 32 tiles = 2048 points) go to the workgroup-per-sample kernel (coordinates in registers, 4 waves);
+  // beyond that the wave-per-sample kernel streams coordinates from L2 (slow, but correct).
+  int variant = (xlds && waves >= 4) ? 0 : (ntiles <= 32 ? 1 : 0);
+  variant = env_int("MOE_KG_VARIANT", variant);
+  const int tpw = (ntiles > 16 && env_int("MOE_KG_TPW", 8) == 8) ? 8 : 4;  // tiles of 64 points per wavefront
+  if (variant == 1 && ntiles > 32) throw Error(MOE_ERR_RUNTIME, "workgroup-per-sample MC kernel holds at most 2048 points");
+  if (variant == 0 && waves < 1)
+    throw Error(MOE_ERR_RUNTIME, "training set too large for the MC kernel (one sample's weights exceed LDS)");
   const int num_cu = gp.num_cu;
-  const int wg_per_cu = std::max(1, std::min((int)((size_t)160 * 1024 / shm), 8 / waves));
+  size_t shm = 0;
+  int wg_per_cu = 1;
+  if (variant == 0) {
+    waves = std::max(1, std::min(waves, env_int("MOE_KG_WAVES", waves)));
+    shm = sizeof(double) * kExpTabLen + (xlds ? tab_bytes : 0) + (size_t)waves * slab_bytes;
+    wg_per_cu = std::max(1, std::min((int)((size_t)160 * 1024 / shm), 8 / waves));
+  } else {
+    waves = (ntiles + tpw - 1) / tpw;  // <= 8 (tpw 4) or <= 4 (tpw 8)
+  }
   int blocks = num_cu * wg_per_cu;
   if (blocks >= E) blocks = (blocks / E) * E;  // the same number of workgroups for every evaluation
   blocks = env_int("MOE_KG_BLOCKS", blocks);
@@ -608,7 +636,10 @@ void kg_evaluate_batch(GpDev& gp, int num_fidelity, const moe_gd_params_t& gd, c
   mp.next_sample = reinterpret_cast<unsigned int*>(dCounters.p + 2 * E);
   EventTimer t_mc, t_cov, t_tail;
   t_mc.start(s);
-  launch_mc(mp, dp, G, xlds, blocks, waves, shm, s);
+  if (variant == 0)
+    launch_mc(mp, dp, G, xlds, blocks, waves, shm, s);
+  else
+    launch_mc_block(mp, dp, G, tpw, blocks, waves, s);
   t_mc.stop(s);
 
   // ---- 3. gradient tail ----
@@ -626,6 +657,7 @@ void kg_evaluate_batch(GpDev& gp, int num_fidelity, const moe_gd_params_t& gd, c
   tl.ngrad = ngrad;
   tl.chunks = chunks;
   tl.T = dT.p;
+  tl.SW = nullptr;
   tl.W = mp.W;
   tl.w_stride = mp.w_stride;
   tl.Gm = gp.dWE.p + bl.col_grad0(0) * N;
@@ -646,6 +678,15 @@ void kg_evaluate_batch(GpDev& gp, int num_fidelity, const moe_gd_params_t& gd, c
     launch_cov_build(gp.cp, gp.dX.p, n, gp.derivs, dBestPoint.p, E * num_local, none, nullptr, dT.p, N, 0, s);
     t_cov.stop(s);
     t_tail.start(s);
+    if (m > 8) {
+      // S_W = W_e^T T_e per evaluation as a tile GEMM (the one-wave-per-sample loop re-reads W from L2 for every sample,
+      // N m 8 bytes each -- fine for q-KG's m = q + p, prohibitive for d-KG's m = (q + p)(1 + g))
+      gp.kSW.reserve((size_t)m * E * num_local);
+      for (int e = 0; e < E; ++e)
+        launch_gemm_tn(m, num_local, N, tl.W + (long)e * tl.w_stride, N, dT.p + (size_t)e * num_local * N, N,
+                       gp.kSW.p + (size_t)e * num_local * m, m, s);
+      tl.SW = gp.kSW.p;
+    }
     launch_tail(tl, s);
     hipLaunchKernelGGL(kg_zc_kernel, dim3(m, E), dim3(256), 0, s, tl);
     t_tail.stop(s);

@@ -72,6 +72,12 @@ void launch_kg_mc_dp8(const KgMcParams& P, int G, bool xlds, int blocks, int wav
 void launch_kg_mc_dp12(const KgMcParams& P, int G, bool xlds, int blocks, int waves, size_t shm, hipStream_t s);
 void launch_kg_mc_dp16(const KgMcParams& P, int G, bool xlds, int blocks, int waves, size_t shm, hipStream_t s);
 
+// Workgroup-per-sample variant (coordinates and weights in registers): `tpw` tiles of 64 points per wavefront (4 or 8).
+void launch_kg_mc_block_dp4(const KgMcParams& P, int G, int tpw, int blocks, int waves, hipStream_t s);
+void launch_kg_mc_block_dp8(const KgMcParams& P, int G, int tpw, int blocks, int waves, hipStream_t s);
+void launch_kg_mc_block_dp12(const KgMcParams& P, int G, int tpw, int blocks, int waves, hipStream_t s);
+void launch_kg_mc_block_dp16(const KgMcParams& P, int G, int tpw, int blocks, int waves, hipStream_t s);
+
 #if defined(__HIPCC__)
 namespace mc {
 
@@ -294,6 +300,281 @@ __device__ __forceinline__ void from_table_order(const double (&v)[DP], const in
   }
 }
 
+// Evaluator of the wave-per-sample kernel: one pass = eval_pass over the LDS tables.
+template <int DP, int G>
+struct WaveEval {
+  const double* __restrict__ xs;
+  const double* __restrict__ aw;
+  const double* __restrict__ etab;
+  int ntiles, cov_type;
+  double mean;
+  const double* inv_lp;
+  int lane;
+  template <bool WG>
+  __device__ __forceinline__ double eval(const double (&xq)[DP], double (&grad)[DP]) {
+    return eval_pass<DP, G, WG>(xs, aw, etab, ntiles, cov_type, mean, xq, inv_lp, grad, lane);
+  }
+};
+
+// The inner optimisation of one MC sample from the start point x (in/out, original dimension order): returns the final
+// objective value f = -mu_after(x).  `ev.eval<WG>(xq, grad)` evaluates f (and, if WG, grad f in table-row order) at the scaled
+// query xq; it must return wave-uniform values.
+template <int DP, int G, class EV>
+__device__ __forceinline__ double line_search(const KgMcParams& P, EV& ev, double (&x)[DP], unsigned long long& n_val,
+                                              unsigned long long& n_grad) {
+  const int size = P.dim - P.f;  // problem size of the inner optimisation
+  const double step_tolerance = P.tolerance / (double)P.max_num_steps;
+  double fcur = 0.0;
+
+  // GradientDescentOptimizerLineSearch::Optimize (gpp_optimization.hpp:1242-1283) around
+  // GradientDescentOptimizationLineSearch (:708-828), as plain nested wave-uniform loops.  The Armijo back-tracking loop --
+  // where 5 of every 6 passes are spent -- carries only (alpha, search) through its back edge; x and grad are loop
+  // invariant there, so the compiler has no array phis to shuffle (a single-evaluation-site state machine cost ~250
+  // v_mov_b64 / lane-spill instructions per pass).  Every posterior-mean value comes from the same dataflow (eval_loop,
+  // explicit fma only), so re-evaluating a point reproduces its value bit for bit at any call site, which lets us reuse
+  // f(x) where the reference recomputes it.
+  if (P.max_num_restarts > 0) {
+    double grad[DP], step[DP], xstart[DP], tq[DP], tqp[DP], gp[DP];
+#pragma unroll
+    for (int k = 0; k < DP; ++k) gp[k] = 0.0;
+    for (int restart = 0; restart < P.max_num_restarts; ++restart) {
+#pragma unroll
+      for (int k = 0; k < DP; ++k) xstart[k] = x[k];
+      for (int istep = 0; istep < P.max_num_steps;) {
+        // ---- f(x), grad f(x) ----
+        to_table_order<DP, G>(x, P.perm, tqp);
+#pragma unroll
+        for (int r = 0; r < DP; ++r) tqp[r] *= P.inv_lp[r];
+        const double f0 = ev.template eval<true>(tqp, gp);
+        n_grad++;
+        fcur = f0;
+        from_table_order<DP, G>(gp, P.perm, grad);
+        double norm = 0.0;
+#pragma unroll
+        for (int k = 0; k < DP; ++k) {
+          if (k >= size) grad[k] = 0.0;  // fidelity / pad coordinates stay pinned
+          norm = fma(grad[k], grad[k], norm);
+        }
+        // pre_mult * (i+1)^-gamma (gpp_optimization.hpp:741); x^-0 == 1 exactly, so gamma == 0 needs no pow()
+        double alpha_n = (P.gamma == 0.0) ? P.pre_mult : P.pre_mult * pow((double)(istep + 1), -P.gamma);
+        // ---- Armijo back-tracking (.hpp:745-760): unclamped trial points ----
+        int search = 0;
+        double ftrial;
+        while (true) {
+#pragma unroll
+          for (int k = 0; k < DP; ++k) tq[k] = fma(alpha_n, grad[k], x[k]);
+          to_table_order<DP, G>(tq, P.perm, tqp);
+#pragma unroll
+          for (int r = 0; r < DP; ++r) tqp[r] *= P.inv_lp[r];
+          ftrial = ev.template eval<false>(tqp, gp);
+          n_val++;
+          if (ftrial - f0 > 0.5 * alpha_n * norm) break;
+          alpha_n *= 0.5;
+          if (++search >= 30) break;
+        }
+        // ---- LimitUpdate, then accept only if f improves (.hpp:762-795) ----
+        bool changed = false, nonzero = false;
+#pragma unroll
+        for (int k = 0; k < DP; ++k) {
+          step[k] = 0.0;
+          if (k < size) {
+            const double want = alpha_n * grad[k];
+            step[k] = limit_update_1d(P.bounds[2 * k], P.bounds[2 * k + 1], P.max_relative_change, x[k], want);
+            changed = changed || (step[k] != want);
+            nonzero = nonzero || (step[k] != 0.0);
+          }
+        }
+        if (search == 30 || !nonzero) break;  // .hpp:781-785: x restored (a zero step re-evaluates f(x) == f0: rejected)
+        double obj2 = ftrial;  // clamp left the step untouched: f(x + step) is the last trial value
+        if (changed) {
+#pragma unroll
+          for (int k = 0; k < DP; ++k) tq[k] = x[k] + step[k];
+          to_table_order<DP, G>(tq, P.perm, tqp);
+#pragma unroll
+          for (int r = 0; r < DP; ++r) tqp[r] *= P.inv_lp[r];
+          obj2 = ev.template eval<false>(tqp, gp);
+          n_val++;
+        }
+        if (obj2 <= f0) break;
+#pragma unroll
+        for (int k = 0; k < DP; ++k) x[k] += step[k];
+        fcur = obj2;
+        istep += 1;
+        if (vector_norm<DP>(step, size) < step_tolerance) break;
+      }
+      double delta[DP];
+#pragma unroll
+      for (int k = 0; k < DP; ++k) delta[k] = xstart[k] - x[k];
+      if (!(vector_norm<DP>(delta, size) > P.tolerance)) break;
+    }
+  } else {
+    // reference returns without touching its outputs (.cpp:425-427): value 0, point filled with 1.0 (.cpp:163)
+#pragma unroll
+    for (int k = 0; k < DP; ++k) x[k] = (k < P.dim) ? 1.0 : 0.0;
+    fcur = 0.0;
+  }
+  return fcur;
+}
+
+// The same line search with its wave-uniform vectors (x, grad, step, x at restart start) parked in an LDS scratch `st`
+// (4 x kMaxDimPadded doubles, private to the wave) between evaluations, for kernels whose registers are better spent on
+// point data (workgroup-per-sample variant: the evaluator's __syncthreads is an LDS fence, so nothing is cached across
+// passes).  Identical arithmetic to line_search; uniform LDS reads are broadcasts that do not occupy the VALU.
+template <int DP, int G, class EV>
+__device__ __forceinline__ double line_search_lds(const KgMcParams& P, EV& ev, double* __restrict__ st, double (&x)[DP],
+                                                  unsigned long long& n_val, unsigned long long& n_grad) {
+  const int size = P.dim - P.f;
+  const double step_tolerance = P.tolerance / (double)P.max_num_steps;
+  double* sX = st;
+  double* sG = st + kMaxDimPadded;
+  double* sS = st + 2 * kMaxDimPadded;
+  double* sX0 = st + 3 * kMaxDimPadded;
+  double fcur = 0.0;
+  if (P.max_num_restarts <= 0) {
+#pragma unroll
+    for (int k = 0; k < DP; ++k) x[k] = (k < P.dim) ? 1.0 : 0.0;
+    return 0.0;
+  }
+#pragma unroll
+  for (int k = 0; k < DP; ++k) sX[k] = x[k];
+  double tq[DP], tqp[DP], gp[DP];
+#pragma unroll
+  for (int k = 0; k < DP; ++k) gp[k] = 0.0;
+  for (int restart = 0; restart < P.max_num_restarts; ++restart) {
+#pragma unroll
+    for (int k = 0; k < DP; ++k) sX0[k] = sX[k];
+    for (int istep = 0; istep < P.max_num_steps;) {
+#pragma unroll
+      for (int k = 0; k < DP; ++k) tq[k] = sX[k];
+      to_table_order<DP, G>(tq, P.perm, tqp);
+#pragma unroll
+      for (int r = 0; r < DP; ++r) tqp[r] *= P.inv_lp[r];
+      const double f0 = ev.template eval<true>(tqp, gp);
+      n_grad++;
+      fcur = f0;
+      double norm = 0.0;
+      {
+        double g[DP];
+        from_table_order<DP, G>(gp, P.perm, g);
+#pragma unroll
+        for (int k = 0; k < DP; ++k) {
+          const double gk = (k < size) ? g[k] : 0.0;
+          sG[k] = gk;
+          norm = fma(gk, gk, norm);
+        }
+      }
+      double alpha_n = (P.gamma == 0.0) ? P.pre_mult : P.pre_mult * pow((double)(istep + 1), -P.gamma);
+      int search = 0;
+      double ftrial;
+      while (true) {
+#pragma unroll
+        for (int k = 0; k < DP; ++k) tq[k] = fma(alpha_n, sG[k], sX[k]);
+        to_table_order<DP, G>(tq, P.perm, tqp);
+#pragma unroll
+        for (int r = 0; r < DP; ++r) tqp[r] *= P.inv_lp[r];
+        ftrial = ev.template eval<false>(tqp, gp);
+        n_val++;
+        if (ftrial - f0 > 0.5 * alpha_n * norm) break;
+        alpha_n *= 0.5;
+        if (++search >= 30) break;
+      }
+      bool changed = false, nonzero = false;
+#pragma unroll
+      for (int k = 0; k < DP; ++k) {
+        double sk = 0.0;
+        if (k < size) {
+          const double want = alpha_n * sG[k];
+          sk = limit_update_1d(P.bounds[2 * k], P.bounds[2 * k + 1], P.max_relative_change, sX[k], want);
+          changed = changed || (sk != want);
+          nonzero = nonzero || (sk != 0.0);
+        }
+        sS[k] = sk;
+      }
+      if (search == 30 || !nonzero) break;
+      double obj2 = ftrial;
+      if (changed) {
+#pragma unroll
+        for (int k = 0; k < DP; ++k) tq[k] = sX[k] + sS[k];
+        to_table_order<DP, G>(tq, P.perm, tqp);
+#pragma unroll
+        for (int r = 0; r < DP; ++r) tqp[r] *= P.inv_lp[r];
+        obj2 = ev.template eval<false>(tqp, gp);
+        n_val++;
+      }
+      if (obj2 <= f0) break;
+      double ss = 0.0;
+#pragma unroll
+      for (int k = 0; k < DP; ++k) {
+        const double sk = sS[k];
+        sX[k] = sX[k] + sk;
+        if (k < size) ss = fma(sk, sk, ss);
+      }
+      fcur = obj2;
+      istep += 1;
+      if (sqrt(ss) < step_tolerance) break;
+    }
+    double ds = 0.0;
+#pragma unroll
+    for (int k = 0; k < DP; ++k) {
+      const double dk = sX0[k] - sX[k];
+      if (k < size) ds = fma(dk, dk, ds);
+    }
+    if (!(sqrt(ds) > P.tolerance)) break;
+  }
+#pragma unroll
+  for (int k = 0; k < DP; ++k) x[k] = sX[k];
+  return fcur;
+}
+
+// z_i (antithetic pairs, .cpp:171-180) and beta = L^-T z for global sample index s: lane c owns component c; copies go to
+// the LDS scratch zb ([0, kMaxM) = z, [kMaxM, 2 kMaxM) = beta) for the uniform reads of the weight loop and the scan.
+__device__ __forceinline__ void draw_z_beta(const KgMcParams& P, const double* __restrict__ Lsm, int s, int lane,
+                                            double* __restrict__ zb, double& zc, double& bc) {
+  const int m = P.m;
+  const double sign = (s & 1) ? -1.0 : 1.0;
+  zc = 0.0;
+  if (lane < m) zc = sign * P.normals[(long)(s >> 1) * m + lane];
+  bc = 0.0;
+  for (int c = m - 1; c >= 0; --c) {
+    double part = 0.0;
+    if (lane > c && lane < m) part = Lsm[lane + c * m] * bc;
+    const double tot = wave_sum(part);
+    if (lane == c) bc = (zc - tot) / Lsm[c + c * m];
+  }
+  zb[lane] = zc;  // kMaxM == 64 == wavefront size
+  zb[kMaxM + lane] = bc;
+  __builtin_amdgcn_wave_barrier();  // keep later cross-lane LDS reads after these writes
+}
+
+// Discretised-set scan (.cpp:436-449): f_j = -(mu_n(x_j) + c_j . z); returns the index of the FIRST best point.
+__device__ __forceinline__ int discrete_scan(const KgMcParams& P, const double* __restrict__ rec, const double* __restrict__ zb,
+                                             int lane) {
+  const int m = P.m;
+  const double* mu_disc = rec + P.rec.mu_disc;
+  const double* C_disc = rec + P.rec.C_disc;
+  double best_f = -INFINITY;
+  int best_j = 0;
+  for (int j0 = 0; j0 < P.A; j0 += 64) {
+    const int j = j0 + lane;
+    double fj = -INFINITY;
+    if (j < P.A) {
+      double v = mu_disc[j];
+      for (int c = 0; c < m; ++c) v = fma(C_disc[(long)j * m + c], zb[c], v);
+      fj = -v;
+    }
+    double wmax = fj;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) wmax = fmax(wmax, __shfl_xor(wmax, off, 64));
+    const unsigned long long ballot = __ballot(fj == wmax);
+    const int first_lane = __ffsll((long long)ballot) - 1;
+    if (wmax > best_f) {  // strict: an earlier chunk wins ties (priority-queue semantics of .cpp:440-447)
+      best_f = wmax;
+      best_j = j0 + first_lane;
+    }
+  }
+  return __builtin_amdgcn_readfirstlane(best_j);
+}
+
 // One MC sample: weights, discretised-set scan, line-search gradient descent.  Called with the whole wave converged.
 template <int DP, int G>
 __device__ __forceinline__ void kg_sample(const KgMcParams& P, int e, int sl, const double* __restrict__ xs,
@@ -306,20 +587,8 @@ __device__ __forceinline__ void kg_sample(const KgMcParams& P, int e, int sl, co
   const double* Lsm = rec + P.rec.L;
   const double* We = P.W + (long)e * P.w_stride;
 
-  // ---- z_i (antithetic, .cpp:171-180) and beta = L^-T z: lane c owns component c; scratch copies in LDS ----
-  const double sign = (s & 1) ? -1.0 : 1.0;
-  double zc = 0.0;
-  if (lane < m) zc = sign * P.normals[(long)(s >> 1) * m + lane];
-  double bc = 0.0;
-  for (int c = m - 1; c >= 0; --c) {
-    double part = 0.0;
-    if (lane > c && lane < m) part = Lsm[lane + c * m] * bc;
-    const double tot = wave_sum(part);
-    if (lane == c) bc = (zc - tot) / Lsm[c + c * m];
-  }
-  zb[lane] = zc;  // kMaxM == 64 == wavefront size
-  zb[kMaxM + lane] = bc;
-  __builtin_amdgcn_wave_barrier();  // keep the cross-lane LDS reads below after these writes
+  double zc, bc;
+  draw_z_beta(P, Lsm, s, lane, zb, zc, bc);
   // ---- per-sample weights (see file header) into this wave's LDS slab ----
   // v(j,a) = KinvY[(j,a)] - sum_c W[(j,a), c] beta_c.  The W loads are issued four columns at a time (column index clamped
   // to m - 1; beta is 0 beyond m) and two tiles per iteration, so ~10 independent L2 loads are in flight per wait
@@ -357,30 +626,7 @@ __device__ __forceinline__ void kg_sample(const KgMcParams& P, int e, int sl, co
   // (each lane only ever reads back the weight entries it wrote itself -- no cross-lane hazard; zb is read by every lane
   //  but was written before the wave-wide butterflies above/below execute, and LDS ops of one wave complete in order)
 
-  // ---- discretised-set scan (.cpp:436-449): f_j = -(mu_n(x_j) + c_j . z); keep the FIRST best ----
-  const double* mu_disc = rec + P.rec.mu_disc;
-  const double* C_disc = rec + P.rec.C_disc;
-  double best_f = -INFINITY;
-  int best_j = 0;
-  for (int j0 = 0; j0 < P.A; j0 += 64) {
-    const int j = j0 + lane;
-    double fj = -INFINITY;
-    if (j < P.A) {
-      double v = mu_disc[j];
-      for (int c = 0; c < m; ++c) v = fma(C_disc[(long)j * m + c], zb[c], v);
-      fj = -v;
-    }
-    double wmax = fj;
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) wmax = fmax(wmax, __shfl_xor(wmax, off, 64));
-    const unsigned long long ballot = __ballot(fj == wmax);
-    const int first_lane = __ffsll((long long)ballot) - 1;
-    if (wmax > best_f) {  // strict: an earlier chunk wins ties (priority-queue semantics of .cpp:440-447)
-      best_f = wmax;
-      best_j = j0 + first_lane;
-    }
-  }
-  best_j = __builtin_amdgcn_readfirstlane(best_j);
+  const int best_j = discrete_scan(P, rec, zb, lane);
 
   const double* disc = rec + P.rec.disc;
   double x[DP];
@@ -388,96 +634,8 @@ __device__ __forceinline__ void kg_sample(const KgMcParams& P, int e, int sl, co
   for (int k = 0; k < DP; ++k) x[k] = (k < size) ? disc[(long)best_j * size + k] : ((k < P.dim) ? 1.0 : 0.0);
 
   unsigned long long n_val = 0, n_grad = 0;  // passes over the n + u points (the A-point scan is O(A m), not counted)
-  const double step_tolerance = P.tolerance / (double)P.max_num_steps;
-  double fcur = 0.0;
-
-  // GradientDescentOptimizerLineSearch::Optimize (gpp_optimization.hpp:1242-1283) around
-  // GradientDescentOptimizationLineSearch (:708-828), as plain nested wave-uniform loops.  The Armijo back-tracking loop --
-  // where 5 of every 6 passes are spent -- carries only (alpha, search) through its back edge; x and grad are loop
-  // invariant there, so the compiler has no array phis to shuffle (a single-evaluation-site state machine cost ~250
-  // v_mov_b64 / lane-spill instructions per pass).  Every posterior-mean value comes from the same dataflow (eval_loop,
-  // explicit fma only), so re-evaluating a point reproduces its value bit for bit at any call site, which lets us reuse
-  // f(x) where the reference recomputes it.
-  if (P.max_num_restarts > 0) {
-    double grad[DP], step[DP], xstart[DP], tq[DP], tqp[DP], gp[DP];
-#pragma unroll
-    for (int k = 0; k < DP; ++k) gp[k] = 0.0;
-    for (int restart = 0; restart < P.max_num_restarts; ++restart) {
-#pragma unroll
-      for (int k = 0; k < DP; ++k) xstart[k] = x[k];
-      for (int istep = 0; istep < P.max_num_steps;) {
-        // ---- f(x), grad f(x) ----
-        to_table_order<DP, G>(x, P.perm, tqp);
-#pragma unroll
-        for (int r = 0; r < DP; ++r) tqp[r] *= P.inv_lp[r];
-        const double f0 = eval_pass<DP, G, true>(xs, aw, etab, P.ntiles, P.cov_type, P.mean, tqp, P.inv_lp, gp, lane);
-        n_grad++;
-        fcur = f0;
-        from_table_order<DP, G>(gp, P.perm, grad);
-        double norm = 0.0;
-#pragma unroll
-        for (int k = 0; k < DP; ++k) {
-          if (k >= size) grad[k] = 0.0;  // fidelity / pad coordinates stay pinned
-          norm = fma(grad[k], grad[k], norm);
-        }
-        // pre_mult * (i+1)^-gamma (gpp_optimization.hpp:741); x^-0 == 1 exactly, so gamma == 0 needs no pow()
-        double alpha_n = (P.gamma == 0.0) ? P.pre_mult : P.pre_mult * pow((double)(istep + 1), -P.gamma);
-        // ---- Armijo back-tracking (.hpp:745-760): unclamped trial points ----
-        int search = 0;
-        double ftrial;
-        while (true) {
-#pragma unroll
-          for (int k = 0; k < DP; ++k) tq[k] = fma(alpha_n, grad[k], x[k]);
-          to_table_order<DP, G>(tq, P.perm, tqp);
-#pragma unroll
-          for (int r = 0; r < DP; ++r) tqp[r] *= P.inv_lp[r];
-          ftrial = eval_pass<DP, G, false>(xs, aw, etab, P.ntiles, P.cov_type, P.mean, tqp, P.inv_lp, gp, lane);
-          n_val++;
-          if (ftrial - f0 > 0.5 * alpha_n * norm) break;
-          alpha_n *= 0.5;
-          if (++search >= 30) break;
-        }
-        // ---- LimitUpdate, then accept only if f improves (.hpp:762-795) ----
-        bool changed = false, nonzero = false;
-#pragma unroll
-        for (int k = 0; k < DP; ++k) {
-          step[k] = 0.0;
-          if (k < size) {
-            const double want = alpha_n * grad[k];
-            step[k] = limit_update_1d(P.bounds[2 * k], P.bounds[2 * k + 1], P.max_relative_change, x[k], want);
-            changed = changed || (step[k] != want);
-            nonzero = nonzero || (step[k] != 0.0);
-          }
-        }
-        if (search == 30 || !nonzero) break;  // .hpp:781-785: x restored (a zero step re-evaluates f(x) == f0: rejected)
-        double obj2 = ftrial;  // clamp left the step untouched: f(x + step) is the last trial value
-        if (changed) {
-#pragma unroll
-          for (int k = 0; k < DP; ++k) tq[k] = x[k] + step[k];
-          to_table_order<DP, G>(tq, P.perm, tqp);
-#pragma unroll
-          for (int r = 0; r < DP; ++r) tqp[r] *= P.inv_lp[r];
-          obj2 = eval_pass<DP, G, false>(xs, aw, etab, P.ntiles, P.cov_type, P.mean, tqp, P.inv_lp, gp, lane);
-          n_val++;
-        }
-        if (obj2 <= f0) break;
-#pragma unroll
-        for (int k = 0; k < DP; ++k) x[k] += step[k];
-        fcur = obj2;
-        istep += 1;
-        if (vector_norm<DP>(step, size) < step_tolerance) break;
-      }
-      double delta[DP];
-#pragma unroll
-      for (int k = 0; k < DP; ++k) delta[k] = xstart[k] - x[k];
-      if (!(vector_norm<DP>(delta, size) > P.tolerance)) break;
-    }
-  } else {
-    // reference returns without touching its outputs (.cpp:425-427): value 0, point filled with 1.0 (.cpp:163)
-#pragma unroll
-    for (int k = 0; k < DP; ++k) x[k] = (k < P.dim) ? 1.0 : 0.0;
-    fcur = 0.0;
-  }
+  WaveEval<DP, G> ev{xs, aw, etab, P.ntiles, P.cov_type, P.mean, P.inv_lp, lane};
+  const double fcur = line_search<DP, G>(P, ev, x, n_val, n_grad);
 
   const long so = (long)e * P.num_local + sl;
   if (lane == 0) {
@@ -527,6 +685,255 @@ __global__ __launch_bounds__(512) void kg_mc_kernel(KgMcParams P) {
       kg_sample<DP, G>(P, e, (int)sl, xs, aw, zb, smem, lane);
     }
     if (gridDim.x >= (unsigned)P.E) break;
+  }
+}
+
+// =====================================================================================================================
+// Workgroup-per-sample variant for training sets whose coordinate table + per-wave weight slabs no longer fit the 160 KB of
+// LDS (e.g. d-KG at n = 2000, d = 12, g = 3: 196 KB of coordinates, 80 KB of weights per sample).  The points are split
+// statically over the NW wavefronts of a workgroup, TPW tiles of 64 per wave, and BOTH their coordinates (loaded once per
+// workgroup) and the current sample's weights live in REGISTERS -- the inner loop touches no memory at all.  All waves
+// run the same line search in lockstep: each pass ends with one wavefront sum per wave, one LDS slot per wave, ONE
+// __syncthreads, and a fixed-order sum of the NW partials, so every wave takes bit-identical decisions.
+// =====================================================================================================================
+constexpr int kPartLen = 24;       // doubles per partial slot: f | DP gradient sums | G derivative sums (<= 1 + 16 + 4)
+constexpr int kMaxBlockWaves = 8;
+
+template <int DP, int G, int TPW>
+struct BlockEval {
+  double cx[TPW][DP];  // scaled coordinates of this lane's TPW points (table-row order), resident for the kernel's life
+  const double* __restrict__ wl;  // this lane's weights for the current sample: LDS [TPW][1+G][64] slab of this wave (+lane)
+  const double* __restrict__ etab;
+  double* __restrict__ part;  // LDS [2][kMaxBlockWaves][kPartLen]
+  const double* inv_lp;
+  double mean;
+  int nw, wave, lane, cov_type, par;
+
+  template <bool WG, int COV>
+  __device__ __forceinline__ void accumulate(const double (&xq)[DP], double& accf, double (&accg)[DP],
+                                             double (&accd)[G > 0 ? G : 1]) {
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) {
+      double cw[1 + G];
+#pragma unroll
+      for (int a = 0; a < 1 + G; ++a) cw[a] = wl[(t * (1 + G) + a) * 64];
+      double diff[DP];
+      double r2 = 1.0e-300;
+#pragma unroll
+      for (int k = 0; k < DP; ++k) {
+        diff[k] = cx[t][k] - xq[k];
+        r2 = fma(diff[k], diff[k], r2);
+      }
+      double base, first, second;
+      radial3<COV, (WG || G > 0), (WG && G > 0)>(r2, etab, base, first, second);
+      double sd = 0.0;
+      if (G > 0) {
+#pragma unroll
+        for (int a = 0; a < G; ++a) sd = fma(cw[1 + a], diff[a], sd);
+      }
+      accf = fma(cw[0], base, accf);
+      if (G > 0) accf = fma(first, sd, accf);
+      if (WG) {
+        double coef = cw[0] * first;
+        if (G > 0) {
+          coef = fma(second, sd, coef);
+#pragma unroll
+          for (int a = 0; a < G; ++a) accd[a] = fma(first, cw[1 + a], accd[a]);
+        }
+#pragma unroll
+        for (int k = 0; k < DP; ++k) accg[k] = fma(coef, diff[k], accg[k]);
+      }
+      // two tiles are scheduled together (ILP for the single resident wave), more would only raise register pressure
+      if ((t & 1) == 1) __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+
+  template <bool WG>
+  __device__ __forceinline__ double eval(const double (&xq)[DP], double (&grad)[DP]) {
+    double accf = 0.0, accg[DP], accd[G > 0 ? G : 1];
+#pragma unroll
+    for (int k = 0; k < DP; ++k) accg[k] = 0.0;
+#pragma unroll
+    for (int a = 0; a < (G > 0 ? G : 1); ++a) accd[a] = 0.0;
+    if (cov_type == MOE_COV_SQUARE_EXPONENTIAL)
+      accumulate<WG, MOE_COV_SQUARE_EXPONENTIAL>(xq, accf, accg, accd);
+    else
+      accumulate<WG, MOE_COV_MATERN_NU_2P5>(xq, accf, accg, accd);
+    double* slot = part + (par * kMaxBlockWaves + wave) * kPartLen;
+    const double sf = wave_sum_uniform(accf);
+    if (lane == 0) slot[0] = sf;
+    if (WG) {
+#pragma unroll
+      for (int k = 0; k < DP; ++k) {
+        const double v = wave_sum_uniform(accg[k]);
+        if (lane == 0) slot[1 + k] = v;
+      }
+      if (G > 0) {
+#pragma unroll
+        for (int a = 0; a < G; ++a) {
+          const double v = wave_sum_uniform(accd[a]);
+          if (lane == 0) slot[1 + DP + a] = v;
+        }
+      }
+    }
+    __syncthreads();
+    const double* all = part + par * kMaxBlockWaves * kPartLen;
+    par ^= 1;
+    double f = 0.0;
+    for (int w = 0; w < nw; ++w) f += all[w * kPartLen];
+    if (WG) {
+#pragma unroll
+      for (int k = 0; k < DP; ++k) {
+        double v = 0.0;
+        for (int w = 0; w < nw; ++w) v += all[w * kPartLen + 1 + k];
+        if (G > 0 && k < G) {
+          double dsum = 0.0;
+          for (int w = 0; w < nw; ++w) dsum += all[w * kPartLen + 1 + DP + (k < G ? k : 0)];
+          v -= dsum;
+        }
+        grad[k] = -(uniform(v) * inv_lp[k]);
+      }
+    }
+    return -(mean + uniform(f));
+  }
+};
+
+template <int DP, int G, int TPW>
+__global__ __launch_bounds__(TPW <= 4 ? 512 : 256) void kg_mc_block_kernel(KgMcParams P) {  // TPW 4: up to 8 waves (256 regs); TPW 8: 4 waves (512 regs)
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  // LDS: [32] exp table | z, beta scratch (2 kMaxM) | partial slots [2][8][kPartLen] | control words (2 doubles) |
+  //      line-search state [nw][4 kMaxDimPadded] | weights of the current sample [nw][TPW][1+G][64]
+  double* etab = smem;
+  double* zb = smem + kExpTabLen;
+  double* part = zb + 2 * kMaxM;
+  int* ctl = reinterpret_cast<int*>(part + 2 * kMaxBlockWaves * kPartLen);  // [0] sample index, [1] best discretised point
+  double* stw = part + 2 * kMaxBlockWaves * kPartLen + 2 + (threadIdx.x >> 6) * (4 * kMaxDimPadded);
+  double* wslab = part + 2 * kMaxBlockWaves * kPartLen + 2 + kMaxBlockWaves * 4 * kMaxDimPadded +
+                  (threadIdx.x >> 6) * (TPW * (1 + G) * 64) + (threadIdx.x & 63);
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int nw = blockDim.x >> 6;
+  const int n = P.n, u = P.u, m = P.m, g1 = 1 + P.g;
+  const int size = P.dim - P.f;
+  if (threadIdx.x < kExpTabLen) etab[threadIdx.x] = kExp2Tab32[threadIdx.x];
+  BlockEval<DP, G, TPW> ev;
+  ev.etab = etab;
+  ev.wl = wslab;
+  ev.part = part;
+  ev.inv_lp = P.inv_lp;
+  ev.mean = P.mean;
+  ev.nw = nw;
+  ev.wave = wave;
+  ev.lane = lane;
+  ev.cov_type = P.cov_type;
+  ev.par = 0;
+  for (int e = blockIdx.x % P.E; e < P.E; e += (gridDim.x < (unsigned)P.E ? gridDim.x : P.E)) {
+    const double* tab = P.XsTab + (long)e * P.tab_stride;
+    const double* rec = P.blob + (long)e * P.rec.stride;
+    const double* Lsm = rec + P.rec.L;
+    const double* We = P.W + (long)e * P.w_stride;
+    // this lane's points: tiles wave*TPW .. wave*TPW + TPW - 1 (tiles beyond the table hold no points: zero coordinates)
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) {
+      const int tile = wave * TPW + t;
+#pragma unroll
+      for (int k = 0; k < DP; ++k) ev.cx[t][k] = (tile < P.ntiles) ? tab[((long)tile * DP + k) * 64 + lane] : 0.0;
+    }
+    while (true) {
+      if (threadIdx.x == 0) ctl[0] = (int)atomicAdd(&P.next_sample[e], 1u);
+      __syncthreads();
+      const int sl = ctl[0];
+      if (sl >= P.num_local) break;
+      const int s = P.first_sample + sl;
+      double zc = 0.0, bc = 0.0;
+      if (wave == 0) {
+        draw_z_beta(P, Lsm, s, lane, zb, zc, bc);
+        const int bj = discrete_scan(P, rec, zb, lane);
+        if (lane == 0) ctl[1] = bj;
+      }
+      __syncthreads();
+      // ---- weights of this lane's points for this sample, into this wave's LDS slab (rolled loop: no register arrays) ----
+#pragma unroll 1
+      for (int t = 0; t < TPW; ++t) {
+        const int j = (wave * TPW + t) * 64 + lane;
+#pragma unroll
+        for (int a = 0; a < 1 + G; ++a) {
+          double v = 0.0;
+          if (a < g1) {
+            if (j < n) {
+              const long row = (long)j * g1 + a;
+              v = P.KinvY[row];
+              for (int c0 = 0; c0 < m; c0 += 4) {
+                const double l0 = We[row + (long)c0 * P.N];
+                const double l1 = We[row + (long)min(c0 + 1, m - 1) * P.N];
+                const double l2 = We[row + (long)min(c0 + 2, m - 1) * P.N];
+                const double l3 = We[row + (long)min(c0 + 3, m - 1) * P.N];
+                v = fma(-l0, zb[kMaxM + c0], v);
+                v = fma(-l1, zb[kMaxM + min(c0 + 1, kMaxM - 1)], v);
+                v = fma(-l2, zb[kMaxM + min(c0 + 2, kMaxM - 1)], v);
+                v = fma(-l3, zb[kMaxM + min(c0 + 3, kMaxM - 1)], v);
+              }
+            } else if (j < n + u) {
+              v = zb[kMaxM + (j - n) * g1 + a];
+            }
+            v *= (a == 0) ? P.alpha : -P.alpha * P.inv_lp[a > 0 ? a - 1 : 0];
+          }
+          wslab[(t * (1 + G) + a) * 64] = v;  // read back only by this lane
+        }
+      }
+      const int best_j = ctl[1];
+      const double* disc = rec + P.rec.disc;
+      double x[DP];
+#pragma unroll
+      for (int k = 0; k < DP; ++k) x[k] = (k < size) ? disc[(long)best_j * size + k] : ((k < P.dim) ? 1.0 : 0.0);
+      unsigned long long n_val = 0, n_grad = 0;
+      const double fcur = line_search_lds<DP, G>(P, ev, stw, x, n_val, n_grad);
+      if (wave == 0) {
+        const long so = (long)e * P.num_local + sl;
+        if (lane == 0) {
+          P.best_value[so] = fcur;
+          atomicAdd(&P.counters[2 * e], n_val);
+          atomicAdd(&P.counters[2 * e + 1], n_grad);
+        }
+        if (lane < DP) {
+          double v = 0.0;
+#pragma unroll
+          for (int k = 0; k < DP; ++k)
+            if (lane == k) v = x[k];
+          P.best_point[so * DP + lane] = v;
+        }
+        if (lane < m) P.beta[so * m + lane] = bc;
+      }
+    }
+    if (gridDim.x >= (unsigned)P.E) break;
+    __syncthreads();
+  }
+}
+
+template <int DP, int G, int TPW>
+inline void launch_block_inst(const KgMcParams& P, int blocks, int waves, hipStream_t s) {
+  const size_t shm = sizeof(double) * (kExpTabLen + 2 * kMaxM + 2 * kMaxBlockWaves * kPartLen + 2 +
+                                       kMaxBlockWaves * 4 * kMaxDimPadded + (size_t)waves * TPW * (1 + G) * 64);
+  auto kern = kg_mc_block_kernel<DP, G, TPW>;
+  MOE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+  hipLaunchKernelGGL((kg_mc_block_kernel<DP, G, TPW>), dim3(blocks), dim3(waves * 64), shm, s, P);
+  MOE_HIP_CHECK(hipGetLastError());
+}
+
+template <int DP>
+inline void launch_block_dp(const KgMcParams& P, int G, int tpw, int blocks, int waves, hipStream_t s) {
+  if (tpw != 4 && tpw != 8) throw Error(MOE_ERR_RUNTIME, "unsupported tiles-per-wave in the workgroup-per-sample MC kernel");
+  switch (G) {
+    case 0:
+      if (tpw == 4) launch_block_inst<DP, 0, 4>(P, blocks, waves, s); else launch_block_inst<DP, 0, 8>(P, blocks, waves, s);
+      break;
+    case 2:
+      if (tpw == 4) launch_block_inst<DP, 2, 4>(P, blocks, waves, s); else launch_block_inst<DP, 2, 8>(P, blocks, waves, s);
+      break;
+    case 4:
+      if (tpw == 4) launch_block_inst<DP, 4, 4>(P, blocks, waves, s); else launch_block_inst<DP, 4, 8>(P, blocks, waves, s);
+      break;
+    default: throw Error(MOE_ERR_RUNTIME, "unsupported derivative-slot count in the MC kernel");
   }
 }
 

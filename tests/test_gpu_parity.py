@@ -176,6 +176,37 @@ def test_headline_shape_properties(api):
     assert whole["grad_evals"] <= 6 * w.M and whole["grad_evals"] >= w.M and whole["mean_evals"] >= w.M
 
 
+def test_workgroup_per_sample_kernel_matches_wave_per_sample(api, monkeypatch):
+    """The two MC kernel variants (csrc/kg_mc.hpp: wave-per-sample with LDS tables, workgroup-per-sample with register
+    tiles) implement the same algorithm with different summation trees: q-KG and d-KG results agree to rounding, and both
+    match the oracle where it is affordable."""
+    from cornell_moe_amd.workloads import make_workload
+    from oracle import orc
+    for kw, cov in ((dict(seed=61, n=700, d=5, q=3, M=400, P=8, derivs=(), p=1), 1),
+                    (dict(seed=62, n=300, d=6, q=2, M=300, P=6, derivs=(1, 4), p=0), 1),
+                    (dict(seed=63, n=150, d=3, q=2, M=200, P=5, derivs=(0, 1, 2), p=1), 0)):
+        w = make_workload(**kw)
+        G = api.DeviceGP(w.hyperparameters, w.X, w.y, w.noise, w.derivs, cov_type=cov)
+        best = float(G.additional_mean(w.discrete).min())
+        args = (w.inner_gd, w.bounds, w.discrete, w.Xq, w.Xp if w.p else None, w.M, best, w.kg_normals)
+        monkeypatch.setenv("MOE_KG_VARIANT", "0")
+        a = G.kg(*args, want_best_points=True)
+        monkeypatch.setenv("MOE_KG_VARIANT", "1")
+        b = G.kg(*args, want_best_points=True)
+        monkeypatch.delenv("MOE_KG_VARIANT")
+        scale = max(np.abs(a["grad"]).max(), abs(a["kg"]))
+        assert abs(a["kg"] - b["kg"]) <= 1e-10 * abs(a["kg"])
+        assert np.abs(a["grad"] - b["grad"]).max() <= 1e-10 * scale
+        assert (np.abs(a["best_point"] - b["best_point"]).max(axis=1) > 1e-9).mean() <= 0.005
+        assert a["grad_evals"] == b["grad_evals"]
+        if w.n <= 300:
+            O = orc.OrcGP(cov, w.alpha, w.lengths, w.X, w.y, w.noise, w.derivs)
+            ro = O.kg(w.inner_gd, w.bounds, w.discrete, w.Xq, w.Xp if w.p else None, w.M, best, w.kg_normals)
+            so = max(np.abs(ro["grad"]).max(), abs(ro["kg"]))
+            assert abs(b["kg"] - ro["kg"]) <= TOL["kg"] * abs(ro["kg"])
+            assert np.abs(b["grad"] - ro["grad"]).max() <= TOL["grad_kg"] * so
+
+
 def test_error_mapping(api):
     rng = np.random.default_rng(1)
     X = rng.uniform(size=(12, 2))
