@@ -97,63 +97,75 @@ struct KgTailParams {
 
 constexpr int kTbChunk = 128;  // samples per workgroup of kg_tb_kernel
 
-// One wavefront per (evaluation, sample): S_W = W^T T_i by lanes striding the N rows, then
-// c_i = L^-1 ( K(Xu, x*_i)[:, 0] - S_W ) with lane r owning component r.
+// c_i = L^-1 ( K(Xu, x*_i)[:, 0] - W^T T_i ) for every sample; one wavefront per sample at a time, lane r owns component r.
+// S_W = W^T T_i comes either precomputed (P.SW: tile GEMM, large m) or is formed here by lanes striding the N rows with
+// W_e staged ONCE per workgroup in LDS ([c][row], conflict-free) and reused for the kSwChunk samples of the workgroup --
+// re-reading W from L2 for every sample (N m 8 bytes each) made this the slowest kernel of the tail.
+constexpr int kSwChunk = 64;  // samples per workgroup (16 per wavefront)
+
 template <int DP, int MU>
 __global__ __launch_bounds__(256) void kg_sw_kernel(KgTailParams P) {
-  const int lane = threadIdx.x & 63;
-  const long w = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (w >= (long)P.E * P.num_local) return;
-  const int e = (int)(w / P.num_local);
-  const int m = P.m, g1 = 1 + P.g;
-  const double* Tc = P.T + w * P.N;
-  const double* We = P.W + (long)e * P.w_stride;
-  double mine = 0.0;
-  if (P.SW != nullptr) {
-    if (lane < m) mine = P.SW[w * m + lane];
-  } else {
-    double acc[MU];
-#pragma unroll
-    for (int c = 0; c < MU; ++c) acc[c] = 0.0;
-    for (int row = lane; row < P.N; row += 64) {
-      const double t = Tc[row];
-#pragma unroll
-      for (int c = 0; c < MU; ++c)
-        if (c < m) acc[c] = fma(We[row + (long)c * P.N], t, acc[c]);
-    }
-#pragma unroll
-    for (int c = 0; c < MU; ++c) {
-      const double v = wave_sum64(acc[c]);
-      if (lane == c) mine = v;
-    }
-  }
+  extern __shared__ __attribute__((aligned(16))) double Ws[];  // [m][N] when P.SW == nullptr
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int e = blockIdx.y;
+  const int m = P.m, g1 = 1 + P.g, N = P.N;
   const double* rec = P.blob + (long)e * P.rec.stride;
   const double* Lsm = rec + P.rec.L;
-  double R = 0.0;
-  if (lane < m) {
-    const int r = lane / g1, b = lane - r * g1;
-    const double* Xu = rec + P.rec.XuP + (long)r * DP;
-    const double* xs = P.best_point + w * DP;
-    double diff[DP];
-    double r2 = 0.0;
+  if (P.SW == nullptr) {
+    const double* We = P.W + (long)e * P.w_stride;
+    for (int t = threadIdx.x; t < N * m; t += 256) Ws[t] = We[t];  // W_e is [N x m] col-major == [c][row]
+    __syncthreads();
+  }
+  const int i1 = min(P.num_local, (int)(blockIdx.x + 1) * kSwChunk);
+  for (int i = blockIdx.x * kSwChunk + wave; i < i1; i += 4) {
+    const long w = (long)e * P.num_local + i;
+    double mine = 0.0;
+    if (P.SW != nullptr) {
+      if (lane < m) mine = P.SW[w * m + lane];
+    } else {
+      const double* Tc = P.T + w * N;
+      double acc[MU];
 #pragma unroll
-    for (int k = 0; k < DP; ++k) {
-      diff[k] = Xu[k] - xs[k];
-      r2 = fma(diff[k] * diff[k], P.cp.inv_l2[k], r2);
+      for (int c = 0; c < MU; ++c) acc[c] = 0.0;
+#pragma unroll 4
+      for (int row = lane; row < N; row += 64) {
+        const double t = Tc[row];
+#pragma unroll
+        for (int c = 0; c < MU; ++c)
+          if (c < m) acc[c] = fma(Ws[c * N + row], t, acc[c]);
+      }
+#pragma unroll
+      for (int c = 0; c < MU; ++c) {
+        const double v = wave_sum64(acc[c]);
+        if (lane == c) mine = v;
+      }
     }
-    const Radial rd = radial_scalars(P.cp.type, P.cp.alpha, r2);
-    DerivList none;
-    none.g = 0;
-    R = cov_entry<DP>(P.cp, rd, diff, b, 0, P.derivs, none) - mine;
+    double R = 0.0;
+    if (lane < m) {
+      const int r = lane / g1, b = lane - r * g1;
+      const double* Xu = rec + P.rec.XuP + (long)r * DP;
+      const double* xs = P.best_point + w * DP;
+      double diff[DP];
+      double r2 = 0.0;
+#pragma unroll
+      for (int k = 0; k < DP; ++k) {
+        diff[k] = Xu[k] - xs[k];
+        r2 = fma(diff[k] * diff[k], P.cp.inv_l2[k], r2);
+      }
+      const Radial rd = radial_scalars(P.cp.type, P.cp.alpha, r2);
+      DerivList none;
+      none.g = 0;
+      R = cov_entry<DP>(P.cp, rd, diff, b, 0, P.derivs, none) - mine;
+    }
+    double cv = 0.0;
+    for (int r = 0; r < m; ++r) {
+      double part = 0.0;
+      if (lane < r) part = Lsm[r + lane * m] * cv;
+      const double tot = wave_sum64(part);
+      if (lane == r) cv = (R - tot) / Lsm[r + r * m];
+    }
+    if (lane < m) P.C[w * m + lane] = cv;
   }
-  double cv = 0.0;
-  for (int r = 0; r < m; ++r) {
-    double part = 0.0;
-    if (lane < r) part = Lsm[r + lane * m] * cv;
-    const double tot = wave_sum64(part);
-    if (lane == r) cv = (R - tot) / Lsm[r + r * m];
-  }
-  if (lane < m) P.C[w * m + lane] = cv;
 }
 
 // TBpart[e][chunk][c][row] = sum over the chunk's samples of T[row, i] beta_i[c]   (thread = row; T read coalesced, the
@@ -270,20 +282,28 @@ __global__ __launch_bounds__(256) void kg_dir_kernel(KgTailParams P) {
   }
 }
 
+template <int DP, int MU>
+void launch_sw_inst(const KgTailParams& P, hipStream_t s) {
+  dim3 grid((P.num_local + kSwChunk - 1) / kSwChunk, P.E);
+  const size_t shm = (P.SW == nullptr) ? sizeof(double) * (size_t)P.N * P.m : 0;
+  auto kern = kg_sw_kernel<DP, MU>;
+  if (shm > 48 * 1024)
+    MOE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+  hipLaunchKernelGGL(kern, grid, dim3(256), shm, s, P);
+}
+
 template <int DP>
 void launch_sw_dp(const KgTailParams& P, hipStream_t s) {
-  const long waves = (long)P.E * P.num_local;
-  dim3 grid((unsigned)((waves + 3) / 4));
   if (P.m <= 4)
-    hipLaunchKernelGGL((kg_sw_kernel<DP, 4>), grid, dim3(256), 0, s, P);
+    launch_sw_inst<DP, 4>(P, s);
   else if (P.m <= 8)
-    hipLaunchKernelGGL((kg_sw_kernel<DP, 8>), grid, dim3(256), 0, s, P);
+    launch_sw_inst<DP, 8>(P, s);
   else if (P.m <= 16)
-    hipLaunchKernelGGL((kg_sw_kernel<DP, 16>), grid, dim3(256), 0, s, P);
+    launch_sw_inst<DP, 16>(P, s);
   else if (P.m <= 32)
-    hipLaunchKernelGGL((kg_sw_kernel<DP, 32>), grid, dim3(256), 0, s, P);
+    launch_sw_inst<DP, 32>(P, s);
   else
-    hipLaunchKernelGGL((kg_sw_kernel<DP, 64>), grid, dim3(256), 0, s, P);
+    launch_sw_inst<DP, 64>(P, s);
   hipLaunchKernelGGL((kg_dir_kernel<DP>), dim3(P.q, P.E), dim3(256), 0, s, P);
 }
 
@@ -678,7 +698,7 @@ void kg_evaluate_batch(GpDev& gp, int num_fidelity, const moe_gd_params_t& gd, c
     launch_cov_build(gp.cp, gp.dX.p, n, gp.derivs, dBestPoint.p, E * num_local, none, nullptr, dT.p, N, 0, s);
     t_cov.stop(s);
     t_tail.start(s);
-    if (m > 8) {
+    if (m > 8 || (size_t)N * m * sizeof(double) > 96 * 1024) {
       // S_W = W_e^T T_e per evaluation as a tile GEMM (the one-wave-per-sample loop re-reads W from L2 for every sample,
       // N m 8 bytes each -- fine for q-KG's m = q + p, prohibitive for d-KG's m = (q + p)(1 + g))
       gp.kSW.reserve((size_t)m * E * num_local);

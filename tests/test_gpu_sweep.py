@@ -1,0 +1,100 @@
+"""GPU parity sweep: seeded random configurations at the edges of the kernels' parameter space, each checked against the
+plain-C oracle on the same normal table -- fidelity dimensions, points being sampled, tile-boundary point counts, odd MC
+counts, both kernels, derivative observations on arbitrary dimensions, both MC kernel variants, many evaluations per
+batch, gamma != 0, several restarts of the inner optimiser, MC shards."""
+import numpy as np
+import pytest
+
+from helpers import TOL
+
+pytestmark = pytest.mark.gpu
+
+CASES = [
+    # seed, n, d, q, p, P, M, derivs, cov, num_fidelity, inner_gd
+    (101, 60, 2, 1, 0, 3, 51, (), 1, 0, (1, 6, 1, 3, 0.0, 1.0, 0.1, 1e-10)),      # one tile, odd M
+    (102, 64, 3, 2, 0, 4, 40, (), 0, 0, (1, 6, 1, 3, 0.0, 1.0, 0.1, 1e-10)),      # n + u = 66: spills into a 2nd tile
+    (103, 62, 3, 2, 0, 4, 40, (), 1, 0, (1, 6, 1, 3, 0.0, 1.0, 0.1, 1e-10)),      # n + u = 64 exactly
+    (104, 130, 4, 2, 1, 6, 64, (), 1, 1, (1, 6, 1, 3, 0.0, 1.0, 0.1, 1e-10)),     # one fidelity dimension, p = 1
+    (105, 90, 5, 3, 2, 5, 32, (), 0, 2, (1, 4, 2, 3, 0.5, 0.8, 0.3, 1e-8)),       # two fidelity dims, gamma != 0, 2 restarts
+    (106, 80, 4, 2, 0, 5, 48, (2,), 1, 0, (1, 6, 1, 3, 0.0, 1.0, 0.1, 1e-10)),    # d-KG, one derivative on dim 2
+    (107, 70, 4, 2, 1, 5, 36, (3, 0), 0, 0, (1, 6, 1, 3, 0.0, 1.0, 0.1, 1e-10)),  # d-KG, derivatives listed out of order
+    (108, 50, 5, 1, 1, 4, 24, (0, 1, 2, 4), 1, 0, (1, 5, 1, 3, 0.0, 1.0, 0.2, 1e-9)),  # four derivatives (all slots used)
+    (109, 200, 8, 4, 0, 10, 100, (), 1, 0, (1, 6, 1, 3, 0.0, 1.0, 0.1, 1e-10)),   # headline shape, small
+    (110, 40, 12, 2, 0, 6, 30, (0, 5, 11), 1, 0, (1, 6, 1, 3, 0.0, 1.0, 0.1, 1e-10)),  # d = 12 (C5's dimension), g = 3
+    (111, 33, 16, 1, 0, 3, 20, (), 0, 0, (1, 6, 1, 3, 0.0, 1.0, 0.1, 1e-10)),     # largest supported dimension
+]
+
+
+def _mk(case):
+    from cornell_moe_amd.workloads import make_workload
+    seed, n, d, q, p, P, M, derivs, cov, f, gd = case
+    w = make_workload(seed=seed, n=n, d=d, q=q, M=M, P=P, derivs=derivs, p=p)
+    w.discrete = w.discrete[:, :d - f]
+    w.bounds_inner = w.bounds[:2 * (d - f)]
+    return w, cov, f, gd
+
+
+@pytest.mark.parametrize("case", CASES, ids=[str(c[0]) for c in CASES])
+def test_kg_against_oracle(case, monkeypatch):
+    from cornell_moe_amd import api
+    from oracle import orc
+    w, cov, f, gd = _mk(case)
+    O = orc.OrcGP(cov, w.alpha, w.lengths, w.X, w.y, w.noise, w.derivs)
+    G = api.DeviceGP(w.hyperparameters, w.X, w.y, w.noise, w.derivs, cov_type=cov)
+    full = np.hstack([w.discrete, np.ones((w.discrete.shape[0], f))])
+    best = float(O.additional_mean(full).min())
+    Xp = w.Xp if w.p else None
+    ro = O.kg(gd, w.bounds_inner, w.discrete, w.Xq, Xp, w.M, best, w.kg_normals, num_fidelity=f)
+    scale = max(float(np.abs(ro["grad"]).max()), abs(ro["kg"]))
+    ptol = 1e-8 if gd[1] * gd[2] <= 8 else 1e-6
+    for variant in ("0", "1"):
+        monkeypatch.setenv("MOE_KG_VARIANT", variant)
+        rg = G.kg(gd, w.bounds_inner, w.discrete, w.Xq, Xp, w.M, best, w.kg_normals, num_fidelity=f, want_best_points=True)
+        assert abs(rg["kg"] - ro["kg"]) <= TOL["kg"] * max(abs(ro["kg"]), 1e-6), (variant, rg["kg"], ro["kg"])
+        assert np.abs(rg["grad"] - ro["grad"]).max() <= TOL["grad_kg"] * max(scale, 1e-6), variant
+        mism = np.abs(rg["best_point"] - ro["best_point"]).max(axis=1) > ptol
+        assert mism.mean() <= 0.02, (variant, mism.mean())
+        assert rg["grad_evals"] == ro["grad_evals"] and rg["mean_evals"] <= ro["mean_evals"]
+        rv = G.kg(gd, w.bounds_inner, w.discrete, w.Xq, Xp, w.M, best, w.kg_normals, num_fidelity=f, want_grad=False)
+        assert rv["kg_sum"] == rg["kg_sum"]
+        # two even-aligned MC shards add up to the whole
+        h = 2 * ((w.M // 2 + 1) // 2)
+        if 0 < h < w.M:
+            a = G.kg(gd, w.bounds_inner, w.discrete, w.Xq, Xp, w.M, best, w.kg_normals, num_fidelity=f, first_sample=0, num_local=h)
+            b = G.kg(gd, w.bounds_inner, w.discrete, w.Xq, Xp, w.M, best, w.kg_normals, num_fidelity=f, first_sample=h,
+                     num_local=w.M - h)
+            assert abs(a["kg_sum"] + b["kg_sum"] - rg["kg_sum"]) <= 1e-11 * abs(rg["kg_sum"])
+            gscale = max(np.abs(rg["grad_sum"]).max(), abs(rg["kg_sum"]))
+            assert np.abs(a["grad_sum"] + b["grad_sum"] - rg["grad_sum"]).max() <= 1e-10 * gscale
+
+
+def test_many_evaluations_per_batch(monkeypatch):
+    """More evaluations than workgroups-per-evaluation slots: 300 point sets in one batch == 300 single calls (first few
+    checked bitwise), for both MC kernel variants."""
+    from cornell_moe_amd import api
+    from cornell_moe_amd.workloads import make_workload
+    w = make_workload(seed=120, n=50, d=2, q=2, M=16, P=4, derivs=(), num_restarts=300)
+    G = api.DeviceGP(w.hyperparameters, w.X, w.y, w.noise, ())
+    best = float(G.additional_mean(w.discrete).min())
+    for variant in ("0", "1"):
+        monkeypatch.setenv("MOE_KG_VARIANT", variant)
+        b = G.kg_batch(w.inner_gd, w.bounds, w.discrete, w.Xq_restarts, None, w.M, best, w.kg_normals)
+        assert np.all(np.isfinite(b["kg_sum"])) and np.all(np.isfinite(b["grad_sum"]))
+        for e in (0, 1, 255, 256, 299):
+            one = G.kg(w.inner_gd, w.bounds, w.discrete, w.Xq_restarts[e], None, w.M, best, w.kg_normals)
+            assert one["kg_sum"] == b["kg_sum"][e] and np.array_equal(one["grad_sum"], b["grad_sum"][e])
+
+
+def test_ei_against_oracle_sweep():
+    from cornell_moe_amd import api
+    from oracle import orc
+    for case in CASES[:6]:
+        w, cov, f, gd = _mk(case)
+        O = orc.OrcGP(cov, w.alpha, w.lengths, w.X, w.y, w.noise, w.derivs)
+        G = api.DeviceGP(w.hyperparameters, w.X, w.y, w.noise, w.derivs, cov_type=cov)
+        Xp = w.Xp if w.p else None
+        eb = float(np.median(w.y[:, 0]))
+        eo, go = O.ei(w.Xq, Xp, w.M, eb, w.ei_normals)
+        eg, gg = G.ei(w.Xq, Xp, w.M, eb, w.ei_normals)
+        assert abs(eo - eg) <= TOL["ei"] * max(abs(eo), 1e-3)
+        assert np.abs(gg - go).max() <= TOL["grad_ei"] * max(np.abs(go).max(), 1e-3)
