@@ -202,7 +202,7 @@ def main():
             "kernel_ms_per_eval": {"mc": mc_ms, "cov_build": cov_ms, "tail": ms_tail / args.steps,
                                    "state_host": ms_state / args.steps},
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # reported baseline: rank 0 at N = 1 only
             out["cpu_baseline"] = cpu_baseline(w, best, args.cpu_sample_mc, log)
             out["speedup_vs_cpu_all_cores"] = value / out["cpu_baseline"]["value"]
         print(json.dumps(out), flush=True)

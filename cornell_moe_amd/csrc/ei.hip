@@ -6,6 +6,7 @@
 // One lane per MC sample (the per-sample work is O(u^2), u <= 16); sums are block-reduced in a fixed order and finished
 // by a single workgroup, so results are bitwise reproducible.
 #include <cmath>
+#include <cstring>
 
 #include "kg.hpp"
 
@@ -151,9 +152,14 @@ void ei_evaluate(GpDev& gp, const double* Xq, const double* Xp, int q, int p, in
   }
   const int ncomp = 1 + (want_grad ? q * d : 0);
   const int blocks = (num_mc + 255) / 256;
-  DevBuf<double> dBlob, dNormals, dPartial, dOut;
-  dBlob.upload(blob.data(), blob.size(), s);
-  dNormals.upload(normals, (size_t)num_mc * u, s);
+  // persistent workspaces (hipMalloc / hipFree per call cost more than the whole evaluation)
+  DevBuf<double>&dBlob = gp.kBlob, &dNormals = gp.kNormals, &dPartial = gp.kTB, &dOut = gp.kOut;
+  const size_t n_norm = (size_t)num_mc * u;
+  gp.hKgIn.reserve(blob.size() + n_norm);
+  std::memcpy(gp.hKgIn.p, blob.data(), sizeof(double) * blob.size());
+  std::memcpy(gp.hKgIn.p + blob.size(), normals, sizeof(double) * n_norm);
+  dBlob.upload(gp.hKgIn.p, blob.size(), s);
+  dNormals.upload(gp.hKgIn.p + blob.size(), n_norm, s);
   dPartial.reserve((size_t)blocks * ncomp);
   dOut.reserve(ncomp);
   EiParams P;
@@ -172,8 +178,9 @@ void ei_evaluate(GpDev& gp, const double* Xq, const double* Xp, int q, int p, in
   hipLaunchKernelGGL(ei_mc_kernel, dim3(blocks), dim3(256), 0, s, P);
   hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, s, dPartial.p, blocks, ncomp, dOut.p);
   MOE_HIP_CHECK(hipGetLastError());
-  std::vector<double> out(ncomp);
-  dOut.download(out.data(), ncomp, s);
+  gp.hKgOut.reserve(ncomp);
+  double* out = gp.hKgOut.p;
+  dOut.download(out, ncomp, s);
   MOE_HIP_CHECK(hipStreamSynchronize(s));
   if (ei) *ei = out[0] / (double)num_mc;
   if (want_grad)

@@ -2,6 +2,7 @@
 #include "gp.hpp"
 
 #include <cmath>
+#include <cstring>
 
 namespace moe {
 
@@ -130,8 +131,14 @@ void compute_state_batch(GpDev& gp, const double* U_all, int u, const DerivList&
   bl.ngrad = ngrad;
   bl.A = A;
   const long ctot = bl.total();
-  // padded point uploads: all evaluations' union points, the differentiated subset (first nd of each), the extras
-  std::vector<double> Up((size_t)E * u * gp.dp, 0.0), Dp((size_t)E * nd * gp.dp, 0.0), Ep((size_t)E * A * gp.dp, 0.0);
+  // padded point upload: all evaluations' union points | the differentiated subset (first nd of each) | the extras,
+  // packed into ONE pinned staging buffer and ONE copy
+  const size_t nU = (size_t)E * u * gp.dp, nD = (size_t)E * nd * gp.dp, nX = (size_t)E * A * gp.dp;
+  gp.hStateIn.reserve(nU + nD + nX);
+  std::memset(gp.hStateIn.p, 0, sizeof(double) * (nU + nD + nX));
+  double* Up = gp.hStateIn.p;
+  double* Dp = Up + nU;
+  double* Ep = Dp + nD;
   for (int e = 0; e < E; ++e) {
     for (int i = 0; i < u; ++i)
       for (int k = 0; k < gp.d; ++k) Up[((size_t)e * u + i) * gp.dp + k] = U_all[((size_t)e * u + i) * gp.d + k];
@@ -140,20 +147,24 @@ void compute_state_batch(GpDev& gp, const double* U_all, int u, const DerivList&
     for (int j = 0; j < A; ++j)
       for (int k = 0; k < gp.d; ++k) Ep[((size_t)e * A + j) * gp.dp + k] = extra_all[((size_t)e * A + j) * gp.d + k];
   }
-  gp.dPts.upload(Up.data(), Up.size(), s);
-  if (nd > 0) gp.dPtsGrad.upload(Dp.data(), Dp.size(), s);
-  if (A > 0) gp.dExtra.upload(Ep.data(), Ep.size(), s);
+  gp.dStateIn.upload(gp.hStateIn.p, nU + nD + nX, s);
+  double* dUp = gp.dStateIn.p;
+  double* dDp = dUp + nU;
+  double* dEp = dDp + nD;
+  // (kg.hip reads the union points back through gp.dPts)
+  gp.dPts.reserve(nU);
+  MOE_HIP_CHECK(hipMemcpyAsync(gp.dPts.p, dUp, sizeof(double) * nU, hipMemcpyDeviceToDevice, s));
   gp.dE.reserve((size_t)N * ctot);
   gp.dVE.reserve((size_t)N * ctot);
-  gp.dGram.reserve((size_t)c * c * E);
-  gp.dEK.reserve(ctot);
-  launch_cov_build(gp.cp, gp.dX.p, gp.n, gp.derivs, gp.dPts.p, E * u, dt, nullptr, gp.dE.p, N, bl.col_kstar0(0), s);
-  if (nd > 0) launch_grad_kstar(gp.cp, gp.dX.p, gp.n, gp.derivs, gp.dPtsGrad.p, E * nd, dt, gp.dE.p, N, bl.col_grad0(0), s);
+  const size_t nG = (size_t)c * c * E;
+  gp.dGram.reserve(nG + ctot);  // gram matrices followed by ek: one download
+  launch_cov_build(gp.cp, gp.dX.p, gp.n, gp.derivs, dUp, E * u, dt, nullptr, gp.dE.p, N, bl.col_kstar0(0), s);
+  if (nd > 0) launch_grad_kstar(gp.cp, gp.dX.p, gp.n, gp.derivs, dDp, E * nd, dt, gp.dE.p, N, bl.col_grad0(0), s);
   if (A > 0) {
     DerivList none;
     none.g = 0;
     for (int i = 0; i < kMaxDerivs; ++i) none.idx[i] = 0;
-    launch_cov_build(gp.cp, gp.dX.p, gp.n, gp.derivs, gp.dExtra.p, E * A, none, nullptr, gp.dE.p, N, bl.col_extra0(0), s);
+    launch_cov_build(gp.cp, gp.dX.p, gp.n, gp.derivs, dEp, E * A, none, nullptr, gp.dE.p, N, bl.col_extra0(0), s);
   }
   launch_tri_gemm('N', N, (int)ctot, gp.dLinv.p, N, gp.dE.p, N, gp.dVE.p, N, s);
   if (need_W) {
@@ -162,11 +173,12 @@ void compute_state_batch(GpDev& gp, const double* U_all, int u, const DerivList&
     launch_tri_gemm('T', N, cw, gp.dLinv.p, N, gp.dVE.p, N, gp.dWE.p, N, s);
   }
   launch_gram_batch(E, lay.m, ngrad, A, N, gp.dVE.p, N, gp.dGram.p, s);
-  launch_gemm_tn((int)ctot, 1, N, gp.dE.p, N, gp.dKinvY.p, N, gp.dEK.p, (int)ctot, s);
-  std::vector<double> gram_all((size_t)c * c * E), ek_all((size_t)ctot);
-  gp.dGram.download(gram_all.data(), gram_all.size(), s);
-  gp.dEK.download(ek_all.data(), ek_all.size(), s);
+  launch_gemm_tn((int)ctot, 1, N, gp.dE.p, N, gp.dKinvY.p, N, gp.dGram.p + nG, (int)ctot, s);
+  gp.hStateOut.reserve(nG + ctot);
+  gp.dGram.download(gp.hStateOut.p, nG + ctot, s);
   MOE_HIP_CHECK(hipStreamSynchronize(s));
+  const double* gram_all = gp.hStateOut.p;
+  const double* ek_all = gp.hStateOut.p + nG;
   hosts->resize(E);
   for (int e = 0; e < E; ++e) {
     StateHost& h = (*hosts)[e];
@@ -178,7 +190,7 @@ void compute_state_batch(GpDev& gp, const double* U_all, int u, const DerivList&
       h.extra.assign(extra_all + (size_t)e * A * gp.d, extra_all + (size_t)(e + 1) * A * gp.d);
     else
       h.extra.clear();
-    h.gram.assign(gram_all.begin() + (size_t)e * c * c, gram_all.begin() + (size_t)(e + 1) * c * c);
+    h.gram.assign(gram_all + (size_t)e * c * c, gram_all + (size_t)(e + 1) * c * c);
     h.ek.resize(c);
     for (int l = 0; l < lay.m; ++l) h.ek[l] = ek_all[bl.col_kstar0(e) + l];
     for (int l = 0; l < ngrad; ++l) h.ek[lay.m + l] = ek_all[bl.col_grad0(e) + l];

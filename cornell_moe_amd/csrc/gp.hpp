@@ -26,7 +26,8 @@ struct GpDev {
   DevBuf<double> dX, dL, dLinv, dKinvY, dNoise, dTmp;
   DevBuf<int> dInfo;
   // reusable workspaces for states
-  DevBuf<double> dPts, dPtsGrad, dExtra, dE, dVE, dWE, dGram, dEK;
+  DevBuf<double> dPts, dPtsGrad, dExtra, dE, dVE, dWE, dGram, dEK, dStateIn;
+  PinnedBuf<double> hStateIn, hStateOut, hKgIn, hKgOut;  // pinned staging for the per-call operands / results
   // reusable workspaces of the KG evaluator (kg.hip)
   DevBuf<double> kBlob, kNormals, kTab, kBestPoint, kBestValue, kBeta, kT, kC, kTB, kOut, kSW;
   DevBuf<unsigned long long> kCounters;

@@ -19,11 +19,14 @@ constexpr int TK = 16;
 // MODE 0: C = A^T B, A is K x m (element (k,i) at k + i*lda): full k range.
 // MODE 1: C = T B,   T lower (element (i,k) at i + k*lda), k < i0 + TM.
 // MODE 2: C = T^T B, T lower (element (k,i) at k + i*lda), k >= i0.
-template <int TM, int TN, int MODE>
+// KT = depth of one LDS stage: skinny outputs (few workgroups, latency-bound K loop) use deep stages so the loop has 4x
+// fewer global-load / barrier round trips; big outputs keep 16 for occupancy.
+template <int TM, int TN, int MODE, int KT>
 __global__ __launch_bounds__(256) void tile_gemm_kernel(int M, int Ncols, int K, const double* __restrict__ A, long lda,
                                                        const double* __restrict__ B, long ldb, double* __restrict__ C,
                                                        long ldc) {
   constexpr int RM = TM / 16, RN = TN / 16;
+  constexpr int TK = KT;
   __shared__ double As[TK][TM + 1];
   __shared__ double Bs[TK][TN + 1];
   const int tx = threadIdx.x % 16, ty = threadIdx.x / 16;
@@ -91,10 +94,10 @@ void tile_gemm(int M, int Ncols, int K, const double* A, long lda, const double*
   const long blocks64 = (long)((M + 63) / 64) * ((Ncols + 63) / 64);
   if (blocks64 >= 512) {
     dim3 grid((M + 63) / 64, (Ncols + 63) / 64);
-    hipLaunchKernelGGL((tile_gemm_kernel<64, 64, MODE>), grid, dim3(256), 0, s, M, Ncols, K, A, lda, B, ldb, C, ldc);
+    hipLaunchKernelGGL((tile_gemm_kernel<64, 64, MODE, 16>), grid, dim3(256), 0, s, M, Ncols, K, A, lda, B, ldb, C, ldc);
   } else {
     dim3 grid((M + 31) / 32, (Ncols + 15) / 16);
-    hipLaunchKernelGGL((tile_gemm_kernel<32, 16, MODE>), grid, dim3(256), 0, s, M, Ncols, K, A, lda, B, ldb, C, ldc);
+    hipLaunchKernelGGL((tile_gemm_kernel<32, 16, MODE, 64>), grid, dim3(256), 0, s, M, Ncols, K, A, lda, B, ldb, C, ldc);
   }
   MOE_HIP_CHECK(hipGetLastError());
 }
@@ -113,6 +116,7 @@ struct GramMap {
 __global__ __launch_bounds__(256) void gram_batch_kernel(GramMap gm, int K, const double* __restrict__ V, long ldv,
                                                         double* __restrict__ G) {
   constexpr int T = 32;
+  constexpr int TK = 64;  // deep stages: the grid is tiny (c <= a few hundred), the K loop is latency-bound
   __shared__ double As[TK][T + 1];
   __shared__ double Bs[TK][T + 1];
   if (blockIdx.y > blockIdx.x) return;

@@ -567,9 +567,12 @@ void kg_evaluate_batch(GpDev& gp, int num_fidelity, const moe_gd_params_t& gd, c
   DevBuf<double>&dBlob = gp.kBlob, &dNormals = gp.kNormals, &dTab = gp.kTab, &dBestPoint = gp.kBestPoint,
   &dBestValue = gp.kBestValue, &dBeta = gp.kBeta, &dT = gp.kT, &dC = gp.kC, &dTB = gp.kTB, &dOut = gp.kOut;
   DevBuf<unsigned long long>& dCounters = gp.kCounters;
-  dBlob.upload(blob.data(), blob.size(), s);
+  gp.hKgIn.reserve(blob.size() + (size_t)((num_mc + 1) / 2) * m);
+  std::memcpy(gp.hKgIn.p, blob.data(), sizeof(double) * blob.size());
+  dBlob.upload(gp.hKgIn.p, blob.size(), s);
   const long num_norm = (long)((num_mc + 1) / 2) * m;
-  dNormals.upload(normals, num_norm, s);
+  std::memcpy(gp.hKgIn.p + blob.size(), normals, sizeof(double) * num_norm);
+  dNormals.upload(gp.hKgIn.p + blob.size(), num_norm, s);
   const long tab_stride = (long)ntiles * dp * 64;
   dTab.reserve((size_t)tab_stride * E);
   dBestPoint.reserve((size_t)E * num_local * dp);
@@ -714,10 +717,13 @@ void kg_evaluate_batch(GpDev& gp, int num_fidelity, const moe_gd_params_t& gd, c
     hipLaunchKernelGGL(kg_sum_kernel, dim3(E), dim3(256), 0, s, tl);
   }
   MOE_HIP_CHECK(hipGetLastError());
-  std::vector<double> out((size_t)out_stride * E);
-  dOut.download(out.data(), out.size(), s);
-  std::vector<unsigned long long> counters((size_t)2 * E);
-  dCounters.download(counters.data(), counters.size(), s);
+  // results through pinned memory: [out_stride * E doubles | 2 E counters]
+  const size_t n_out = (size_t)out_stride * E;
+  gp.hKgOut.reserve(n_out + 2 * (size_t)E);
+  double* out = gp.hKgOut.p;
+  dOut.download(out, n_out, s);
+  unsigned long long* counters = reinterpret_cast<unsigned long long*>(gp.hKgOut.p + n_out);
+  dCounters.download(counters, (size_t)2 * E, s);
   std::vector<double> bp;
   if (best_points && E == 1) {
     bp.resize((size_t)num_local * dp);

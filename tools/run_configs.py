@@ -1,0 +1,105 @@
+"""Measure every BASELINE.json configuration that fits one GPU, with the reference CPU path beside it where that is
+affordable: prints one JSON object (kept under profiles/ as rNN_configs.json).
+
+  C1  GP posterior mean/var, n=200 d=2 (plumbing)            GPU vs reference, 100 query points
+  C2  q-EI value+grad, n=500 d=4 q=2, 1k MC                   GPU evals/s vs reference (1 core)
+  C3  q-KG value+grad, n=1000 d=8 q=4, 10k MC (headline)      see bench.py; here: single evaluation and batch of 8
+  C4  64 multistarts x C3 on ONE GPU                          one moe_kg_batch of 64 evaluations
+  C5  d-KG, n=2000 d=12 q=8 g=3, 20k MC                       GPU only (the reference needs ~hours: see note)
+Also: covariance-build HBM roofline at sizes >> cache through moe_cov_build_probe."""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from cornell_moe_amd.api import DeviceGP  # noqa: E402
+from cornell_moe_amd.workloads import make_workload  # noqa: E402
+
+try:
+    from oracle import ref
+    HAVE_REF = ref.available()
+except Exception:  # pragma: no cover
+    HAVE_REF = False
+
+
+def timeit(fn, reps=5):
+    fn()
+    ts = []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        fn()
+        ts.append(time.perf_counter() - t0)
+    return float(np.median(ts))
+
+
+out = {}
+
+# ---- C1 ----
+w = make_workload("C1")
+t0 = time.perf_counter()
+G = DeviceGP(w.hyperparameters, w.X, w.y, w.noise, ())
+t_build = time.perf_counter() - t0
+t_mean = timeit(lambda: G.mean(w.query))
+t_var = timeit(lambda: G.variance(w.query[:20]))
+c1 = {"gpu_build_s": t_build, "gpu_mean_100pts_s": t_mean, "gpu_var_20pts_s": t_var}
+if HAVE_REF:
+    t0 = time.perf_counter()
+    R = ref.RefGP(1, w.alpha, w.lengths, w.X, w.y, w.noise, ())
+    c1["ref_build_s"] = time.perf_counter() - t0
+    c1["ref_mean_100pts_s"] = timeit(lambda: R.mean(w.query))
+    c1["ref_var_20pts_s"] = timeit(lambda: R.var(w.query[:20]))
+    c1["max_rel_err_mean"] = float(np.abs(G.mean(w.query) - R.mean(w.query)).max() / np.abs(R.mean(w.query)).max())
+out["C1"] = c1
+
+# ---- C2 ----
+w = make_workload("C2")
+G = DeviceGP(w.hyperparameters, w.X, w.y, w.noise, ())
+best = float(np.min(w.y[:, 0])) + 0.5
+t = timeit(lambda: G.ei(w.Xq, None, w.M, best, w.ei_normals), reps=20)
+c2 = {"gpu_ei_grad_evals_per_s": 1.0 / t, "gpu_ms_per_eval": 1e3 * t}
+if HAVE_REF:
+    R = ref.RefGP(1, w.alpha, w.lengths, w.X, w.y, w.noise, ())
+    tr = timeit(lambda: R.ei(w.Xq, None, w.M, best, w.ei_normals), reps=5)
+    c2["ref_1core_evals_per_s"] = 1.0 / tr
+    eo, go = R.ei(w.Xq, None, w.M, best, w.ei_normals)[:2]
+    eg, gg = G.ei(w.Xq, None, w.M, best, w.ei_normals)
+    c2["rel_err_ei"] = abs(eo - eg) / max(abs(eo), 1e-300)
+    c2["max_abs_err_grad"] = float(np.abs(go - gg).max())
+out["C2"] = c2
+
+# ---- C3 / C4 ----
+w = make_workload("C3", num_restarts=64)
+G = DeviceGP(w.hyperparameters, w.X, w.y, w.noise, ())
+best = float(G.additional_mean(w.discrete).min())
+c3 = {}
+for R_ in (1, 8, 64):
+    t = timeit(lambda: G.kg_batch(w.inner_gd, w.bounds, w.discrete, w.Xq_restarts[:R_], None, w.M, best, w.kg_normals), reps=3)
+    c3["batch_%d_evals_per_s" % R_] = R_ / t
+    c3["batch_%d_ms_per_eval" % R_] = 1e3 * t / R_
+out["C3"] = {k: v for k, v in c3.items() if not k.startswith("batch_64")}
+out["C4_one_gpu"] = {"wall_s_64_multistarts": 64.0 / c3["batch_64_evals_per_s"], "evals_per_s": c3["batch_64_evals_per_s"]}
+# covariance build N x M roofline at the C3 tail shape, M = 80000 columns (640 MB >> caches)
+ms, nbytes = G.cov_build_probe(np.random.default_rng(0).uniform(size=(80000, 8)), repeat=10)
+out["cov_build_N1000xM80000"] = {"ms": ms, "GB_per_s": nbytes / ms / 1e6, "frac_of_8TBs": nbytes / ms / 1e6 / 8000.0}
+
+# ---- C5 ----
+w = make_workload("C5")
+t0 = time.perf_counter()
+G = DeviceGP(w.hyperparameters, w.X, w.y, w.noise, w.derivs)
+c5 = {"gpu_build_s_N8000": time.perf_counter() - t0}
+best = float(G.additional_mean(w.discrete).min())
+t = timeit(lambda: G.kg(w.inner_gd, w.bounds, w.discrete, w.Xq, None, w.M, best, w.kg_normals), reps=2)
+c5["gpu_dkg_grad_evals_per_s"] = 1.0 / t
+c5["gpu_ms_per_eval"] = 1e3 * t
+km = G.last_kernel_ms()
+c5["kernel_ms"] = {k: float(v) for k, v in km.items()}
+c5["note"] = ("reference CPU path not timed at this size: one evaluation re-factorises the (N+m)^2 = 8032^2 fantasy matrix "
+              "(1.7e11 flop at ~2 GFLOP/s) and re-solves it for each of the 20000 samples (2.6e12 flop): hours")
+ms, nbytes = G.cov_build_probe(np.random.default_rng(1).uniform(size=(20000, 12)), repeat=5)
+out["cov_build_N8000xM20000_derivative_rows"] = {"ms": ms, "GB_per_s": nbytes / ms / 1e6, "frac_of_8TBs": nbytes / ms / 1e6 / 8000.0}
+out["C5"] = c5
+print(json.dumps(out, indent=1))
