@@ -158,6 +158,11 @@ class RandomnessSourceContainer(object):
     def _uniform_random(self, size):
         return self._uniform.uniform(0.0, 1.0, size=size)
 
+    def _next_uniform_seed(self):
+        """A fresh mt19937 seed per Latin-hypercube draw, itself a deterministic function of the uniform generator's
+        seed and the number of draws so far (the reference advances ONE engine across draws)."""
+        return int(self._uniform.randint(0, 2 ** 31 - 1))
+
 
 def _flat(values, count=None):
     a = np.ascontiguousarray(np.asarray(values, dtype=np.float64).ravel())

@@ -55,6 +55,10 @@ SIGNATURES = {
                          dp, C.c_int, C.c_int, C.c_int, dp, dp, dp, C.POINTER(KgStats), _EP]),
     "moe_kg_batch": (C.c_int, [_GP, C.c_int, C.POINTER(GdParams), dp, dp, C.c_int, dp, C.c_int, dp, C.c_int, C.c_int,
                                C.c_int, C.c_double, dp, C.c_int, C.c_int, C.c_int, dp, dp, C.POINTER(KgStats), _EP]),
+    "moe_kg_multistart": (C.c_int, [_GP, C.c_int, C.POINTER(GdParams), C.POINTER(GdParams), dp, dp, C.c_int, dp, C.c_int, dp,
+                                    C.c_int, C.c_int, C.c_int, C.c_double, dp, C.c_int, dp, dp, ip, _EP]),
+    "moe_posterior_mean_optimize": (C.c_int, [_GP, C.c_int, C.POINTER(GdParams), dp, dp, dp, dp, _EP]),
+    "moe_latin_hypercube": (C.c_int, [C.c_uint, dp, C.c_int, C.c_int, dp]),
     "moe_gp_mix_covariance": (C.c_int, [_GP, dp, C.c_int, ip, C.c_int, dp, _EP]),
     "moe_cov_build_probe": (C.c_int, [_GP, dp, C.c_int, C.c_int, dp, dp, _EP]),
     "moe_debug_cholesky": (C.c_int, [C.c_int, dp, C.c_int, dp, dp, ip, _EP]),

@@ -64,6 +64,15 @@ def normal_draws(seed, count):
     return out
 
 
+def latin_hypercube(seed, bounds, num_points):
+    """moe_latin_hypercube: [num_points][dim] points, one per slice of every edge (gpp_random.cpp:173-194)."""
+    bounds, bp = _d(bounds)
+    dim = bounds.size // 2
+    out = np.zeros((int(num_points), dim))
+    _lib.load().moe_latin_hypercube(C.c_uint(int(seed) & 0xFFFFFFFF), bp, dim, int(num_points), out.ctypes.data_as(dp))
+    return out
+
+
 def debug_cholesky(a, device=0):
     """Device Cholesky + inverse factor of an SPD matrix (parity probe); returns (L, Linv) as [row, col] arrays."""
     a = np.array(a, dtype=np.float64)
@@ -306,6 +315,42 @@ class DeviceGP(object):
         _check(rc, err)
         return dict(kg_sum=kg_sum, grad_sum=grad.reshape(R, q, self.d), mean_evals=stats.posterior_mean_evals,
                     grad_evals=stats.posterior_grad_evals, ms_state=stats.ms_state, ms_mc=stats.ms_mc, ms_tail=stats.ms_tail)
+
+    def kg_multistart(self, outer_params, inner_params, bounds, discrete, starts, Xp, num_mc, best_so_far, normals,
+                      gradient_ascent=True, num_fidelity=0):
+        """moe_kg_multistart: starts [S][q][dim] -> (best_points [q][dim], best_kg, found)."""
+        L = _lib.load()
+        go, gi = self._gd(outer_params), self._gd(inner_params)
+        bounds, bp = _d(bounds)
+        discrete, dpp = _d(discrete)
+        P = discrete.reshape(-1, self.d - num_fidelity).shape[0]
+        starts = np.ascontiguousarray(starts, dtype=np.float64)
+        S, q, _ = starts.shape
+        if Xp is None or np.size(Xp) == 0:
+            p, ppp = 0, None
+        else:
+            Xp, ppp = _d(Xp)
+            p = Xp.reshape(-1, self.d).shape[0]
+        normals, npn = _d(normals)
+        best = np.zeros(q * self.d)
+        best_kg = C.c_double(0.0)
+        found = C.c_int(0)
+        err = _lib.MoeError()
+        _check(L.moe_kg_multistart(self._h, int(num_fidelity), C.byref(go), C.byref(gi), bp, dpp, P, starts.ctypes.data_as(dp), S,
+                                   ppp, q, p, int(num_mc), float(best_so_far), npn, 1 if gradient_ascent else 0,
+                                   best.ctypes.data_as(dp), C.byref(best_kg), C.byref(found), C.byref(err)), err)
+        return best.reshape(q, self.d), best_kg.value, bool(found.value)
+
+    def posterior_mean_optimize(self, params, bounds, initial_guess, num_fidelity=0):
+        g = self._gd(params)
+        bounds, bp = _d(bounds)
+        x0, xp = _d(initial_guess)
+        out = np.zeros(self.d - num_fidelity)
+        val = C.c_double(0.0)
+        err = _lib.MoeError()
+        _check(_lib.load().moe_posterior_mean_optimize(self._h, int(num_fidelity), C.byref(g), bp, xp, out.ctypes.data_as(dp),
+                                                       C.byref(val), C.byref(err)), err)
+        return out, val.value
 
     def last_kernel_ms(self):
         out = np.zeros(5)

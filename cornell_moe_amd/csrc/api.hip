@@ -339,6 +339,36 @@ int moe_kg_batch(const moe_gp_t* gp_c, int num_fidelity, const moe_gd_params_t* 
   });
 }
 
+int moe_kg_multistart(const moe_gp_t* gp_c, int num_fidelity, const moe_gd_params_t* outer_params,
+                      const moe_gd_params_t* inner_params, const double* domain_bounds, const double* discrete_pts, int num_pts,
+                      const double* start_points, int num_starts, const double* points_being_sampled, int num_to_sample,
+                      int num_being_sampled, int num_mc, double best_so_far, const double* normals, int do_gradient_ascent,
+                      double* best_points, double* best_kg, int* found, moe_error_t* err) {
+  return guarded(err, [&] {
+    moe::GpDev& gp = const_cast<moe_gp_t*>(gp_c)->dev;
+    require(outer_params && inner_params && best_points && best_kg && found, "NULL argument");
+    moe::kg_multistart(gp, num_fidelity, *outer_params, *inner_params, domain_bounds, discrete_pts, num_pts, start_points,
+                       num_starts, points_being_sampled, num_to_sample, num_being_sampled, num_mc, best_so_far, normals,
+                       do_gradient_ascent, best_points, best_kg, found);
+  });
+}
+
+int moe_posterior_mean_optimize(const moe_gp_t* gp_c, int num_fidelity, const moe_gd_params_t* params,
+                                const double* domain_bounds, const double* initial_guess, double* best_point,
+                                double* best_value, moe_error_t* err) {
+  return guarded(err, [&] {
+    moe::GpDev& gp = const_cast<moe_gp_t*>(gp_c)->dev;
+    require(params && best_point, "NULL argument");
+    moe::posterior_mean_optimize(gp, num_fidelity, *params, domain_bounds, initial_guess, best_point, best_value);
+  });
+}
+
+int moe_latin_hypercube(unsigned int seed, const double* domain_bounds, int dim, int num_points, double* out) {
+  if (dim <= 0 || num_points <= 0 || !domain_bounds || !out) return MOE_ERR_BOUNDS;
+  moe::latin_hypercube(seed, domain_bounds, dim, num_points, out);
+  return MOE_OK;
+}
+
 int moe_kg(const moe_gp_t* gp_c, int num_fidelity, const moe_gd_params_t* inner_params, const double* domain_bounds,
            const double* discrete_pts, int num_pts, const double* points_to_sample, const double* points_being_sampled,
            int num_to_sample, int num_being_sampled, int num_mc, double best_so_far, const double* normals,

@@ -75,7 +75,7 @@ __global__ void build_xs_tab_kernel(const double* __restrict__ X, int n, const d
 struct KgTailParams {
   CovParams cp;
   DerivList derivs;  // the GP's derivative observations (carried by the union points too)
-  int u, q, m, g, N, E, num_local, first_sample, ngrad, chunks;
+  int u, q, m, g, N, E, num_local, first_sample, ngrad, chunks, sw_chunk;
   const double* T;           // [N x E*num_local], ld N
   const double* SW;          // optional precomputed W^T T, [m x E*num_local] col-major (large m: tile GEMM); else null
   const double* W;           // evaluation e at W + e * w_stride, [N x m], ld N
@@ -101,7 +101,7 @@ constexpr int kTbChunk = 128;  // samples per workgroup of kg_tb_kernel
 // S_W = W^T T_i comes either precomputed (P.SW: tile GEMM, large m) or is formed here by lanes striding the N rows with
 // W_e staged ONCE per workgroup in LDS ([c][row], conflict-free) and reused for the kSwChunk samples of the workgroup --
 // re-reading W from L2 for every sample (N m 8 bytes each) made this the slowest kernel of the tail.
-constexpr int kSwChunk = 64;  // samples per workgroup (16 per wavefront)
+constexpr int kSwChunk = 64;  // samples per workgroup (16 per wavefront); 16 when the batch is too small to fill the chip
 
 template <int DP, int MU>
 __global__ __launch_bounds__(256) void kg_sw_kernel(KgTailParams P) {
@@ -116,8 +116,8 @@ __global__ __launch_bounds__(256) void kg_sw_kernel(KgTailParams P) {
     for (int t = threadIdx.x; t < N * m; t += 256) Ws[t] = We[t];  // W_e is [N x m] col-major == [c][row]
     __syncthreads();
   }
-  const int i1 = min(P.num_local, (int)(blockIdx.x + 1) * kSwChunk);
-  for (int i = blockIdx.x * kSwChunk + wave; i < i1; i += 4) {
+  const int i1 = min(P.num_local, (int)(blockIdx.x + 1) * P.sw_chunk);
+  for (int i = blockIdx.x * P.sw_chunk + wave; i < i1; i += 4) {
     const long w = (long)e * P.num_local + i;
     double mine = 0.0;
     if (P.SW != nullptr) {
@@ -284,7 +284,7 @@ __global__ __launch_bounds__(256) void kg_dir_kernel(KgTailParams P) {
 
 template <int DP, int MU>
 void launch_sw_inst(const KgTailParams& P, hipStream_t s) {
-  dim3 grid((P.num_local + kSwChunk - 1) / kSwChunk, P.E);
+  dim3 grid((P.num_local + P.sw_chunk - 1) / P.sw_chunk, P.E);
   const size_t shm = (P.SW == nullptr) ? sizeof(double) * (size_t)P.N * P.m : 0;
   auto kern = kg_sw_kernel<DP, MU>;
   if (shm > 48 * 1024)
@@ -477,6 +477,7 @@ void kg_evaluate_batch(GpDev& gp, int num_fidelity, const moe_gd_params_t& gd, c
   BatchLayout bl;
   std::vector<StateHost> hosts;
   compute_state_batch(gp, U_all.data(), u, gp.derivs, want_grad ? q : 0, extra_all.data(), A, true, E, &bl, &hosts);
+  const double ms_dev_state = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wall0).count();
 
   // ---- host m x m algebra per evaluation -> one blob ----
   KgRec rec;
@@ -615,6 +616,9 @@ void kg_evaluate_batch(GpDev& gp, int num_fidelity, const moe_gd_params_t& gd, c
     MOE_HIP_CHECK(hipGetLastError());
   }
   const double ms_state = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wall0).count();
+  if (env_int("MOE_TRACE", 0))
+    std::fprintf(stderr, "[moe] state: device part + sync %.3f ms, host algebra + uploads %.3f ms (E = %d)\n", ms_dev_state,
+                 ms_state - ms_dev_state, E);
 
   // ---- 2. MC kernel ----
   KgMcParams mp;
@@ -679,6 +683,7 @@ void kg_evaluate_batch(GpDev& gp, int num_fidelity, const moe_gd_params_t& gd, c
   tl.first_sample = first_sample;
   tl.ngrad = ngrad;
   tl.chunks = chunks;
+  tl.sw_chunk = ((long)E * num_local / kSwChunk >= 1024) ? kSwChunk : 16;
   tl.T = dT.p;
   tl.SW = nullptr;
   tl.W = mp.W;

@@ -16,4 +16,17 @@ void kg_evaluate_batch(GpDev& gp, int num_fidelity, const moe_gd_params_t& gd, c
                        double best_so_far, const double* normals, int first_sample, int num_local, bool want_grad,
                        double* kg_sum, double* grad_sum, double* best_points, moe_kg_stats_t* stats);
 
+// ---- callers of the hot path (multistart.hip) ----
+// ComputeLatinHypercubePointsInDomain (gpp_random.cpp:173-194): out[num_points][dim], mt19937(seed).
+void latin_hypercube(unsigned int seed, const double* bounds, int dim, int num_points, double* out);
+// ComputeKGOptimalPointsToSampleViaMultistartGradientDescent / ...ViaLatinHypercubeSearch
+// (gpp_knowledge_gradient_optimization.hpp:860-1141) from caller-supplied starts [num_starts][q][d].
+void kg_multistart(GpDev& gp, int num_fidelity, const moe_gd_params_t& outer, const moe_gd_params_t& inner, const double* bounds,
+                   const double* discrete, int P, const double* starts, int num_starts, const double* Xp, int q, int p,
+                   int num_mc, double best_so_far, const double* normals, int do_gradient_ascent, double* best_points,
+                   double* best_kg, int* found);
+// ComputeOptimalPosteriorMean from one initial guess (gpp_knowledge_gradient_optimization.cpp:420-472).
+void posterior_mean_optimize(GpDev& gp, int num_fidelity, const moe_gd_params_t& gd, const double* bounds, const double* x0,
+                             double* best_point, double* best_value);
+
 }  // namespace moe

@@ -1,0 +1,215 @@
+// cornell_moe_amd/csrc/multistart.hip -- the callers of the hot path, host C++ above the evaluators:
+//   * ComputeKGOptimalPointsToSampleViaMultistartGradientDescent (gpp_knowledge_gradient_optimization.hpp:860-935):
+//     KG value at every start, the best 20 kept (:895-921), restarted gradient ASCENT on each
+//     (GradientDescentOptimizer, gpp_optimization.hpp:619-705, 1144-1185), KG value at every end point, best one returned
+//     (MultistartOptimizer, gpp_optimization.hpp:1472-1546);
+//   * ComputeKGOptimalPointsToSampleViaLatinHypercubeSearch / EvaluateKGAtPointList (:1090-1141): value search;
+//   * ComputeOptimalPosteriorMean from one initial guess (gpp_knowledge_gradient_optimization.cpp:420-472);
+//   * ComputeLatinHypercubePointsInDomain (gpp_random.cpp:173-194) for the start sets.
+// Where the reference runs one OpenMP thread per restart, every step here evaluates ALL live restarts in one batched
+// device pass (kg_evaluate_batch).  Every evaluation replays the same normal table (the reference rewinds its RNG before
+// each evaluation), so the ascent sees common random numbers.
+#include <algorithm>
+#include <cmath>
+#include <numeric>
+#include <random>
+
+#include "gp.hpp"
+#include "kg.hpp"
+
+namespace moe {
+
+namespace {
+
+constexpr int kTopK = 20;  // gpp_knowledge_gradient_optimization.hpp:901
+
+// TensorProductDomain::LimitUpdate (gpp_domain.cpp:64-105) on one coordinate.
+double limit_update_1d(double lo, double hi, double max_relative_change, double x, double desired) {
+  double dist = std::fmin(x - lo, hi - x);
+  if (std::fabs(desired) > max_relative_change * dist) desired = std::copysign(max_relative_change * dist, desired);
+  const double next = x + desired;
+  if (next < lo) {
+    desired = (x + desired * 0.5 < lo) ? (lo - x) * 0.5 : desired * 0.5;
+  } else if (next > hi) {
+    desired = (x + desired * 0.5 > hi) ? (hi - x) * 0.5 : desired * 0.5;
+  }
+  return desired;
+}
+
+double norm2(const double* v, int n) {
+  double s = 0.0;
+  for (int i = 0; i < n; ++i) s += v[i] * v[i];
+  return std::sqrt(s);
+}
+
+}  // namespace
+
+void latin_hypercube(unsigned int seed, const double* bounds, int dim, int num_points, double* out) {
+  std::mt19937 eng(seed);
+  std::vector<int> index(num_points);
+  for (int i = 0; i < dim; ++i) {
+    const double lo = bounds[2 * i], edge = (bounds[2 * i + 1] - bounds[2 * i]) / (double)num_points;
+    std::iota(index.begin(), index.end(), 0);
+    std::shuffle(index.begin(), index.end(), eng);
+    std::uniform_real_distribution<double> uni(0.0, edge);
+    for (int j = 0; j < num_points; ++j) out[(size_t)j * dim + i] = lo + edge * index[j] + uni(eng);
+  }
+}
+
+void kg_values(GpDev& gp, int num_fidelity, const moe_gd_params_t& inner, const double* inner_bounds, const double* discrete,
+               int P, const double* Xq_all, int num_evals, const double* Xp, int q, int p, int num_mc, double best_so_far,
+               const double* normals, double* values) {
+  if (num_evals <= 0) return;
+  std::vector<double> sums(num_evals);
+  kg_evaluate_batch(gp, num_fidelity, inner, inner_bounds, discrete, P, Xq_all, num_evals, Xp, q, p, num_mc, best_so_far,
+                    normals, 0, num_mc, false, sums.data(), nullptr, nullptr, nullptr);
+  for (int e = 0; e < num_evals; ++e) values[e] = sums[e] / (double)num_mc;
+}
+
+// GradientDescentOptimizer::Optimize for every start at once; x [S][q][d] in place.
+void kg_gradient_ascent(GpDev& gp, int num_fidelity, const moe_gd_params_t& outer, const moe_gd_params_t& inner,
+                        const double* bounds, const double* discrete, int P, double* x, int S, const double* Xp, int q, int p,
+                        int num_mc, double best_so_far, const double* normals) {
+  const int d = gp.d, qd = q * d;
+  if (outer.max_num_restarts <= 0 || S <= 0) return;
+  const double step_tol = outer.tolerance / (double)outer.max_num_steps;
+  std::vector<char> alive(S, 1), running(S);
+  std::vector<double> x_begin((size_t)S * qd), xs((size_t)S * qd), ksum(S), gsum((size_t)S * qd);
+  std::vector<int> idx;
+  for (int r = 0; r < outer.max_num_restarts; ++r) {
+    if (std::none_of(alive.begin(), alive.end(), [](char c) { return c != 0; })) break;
+    std::copy(x, x + (size_t)S * qd, x_begin.begin());
+    running = alive;
+    for (int i = 0; i < outer.max_num_steps; ++i) {
+      idx.clear();
+      for (int s = 0; s < S; ++s)
+        if (running[s]) idx.push_back(s);
+      if (idx.empty()) break;
+      const double alpha = outer.pre_mult * std::pow((double)(i + 1), -outer.gamma);
+      for (size_t k = 0; k < idx.size(); ++k) std::copy(x + (size_t)idx[k] * qd, x + (size_t)(idx[k] + 1) * qd, &xs[k * qd]);
+      kg_evaluate_batch(gp, num_fidelity, inner, bounds, discrete, P, xs.data(), (int)idx.size(), Xp, q, p, num_mc, best_so_far,
+                        normals, 0, num_mc, true, ksum.data(), gsum.data(), nullptr, nullptr);
+      for (size_t k = 0; k < idx.size(); ++k) {
+        double* xk = x + (size_t)idx[k] * qd;
+        double step[1024];
+        for (int j = 0; j < qd; ++j) {
+          const int dd = j % d;
+          const double want = alpha * gsum[k * qd + j] / (double)num_mc;
+          step[j] = limit_update_1d(bounds[2 * dd], bounds[2 * dd + 1], outer.max_relative_change, xk[j], want);
+          xk[j] += step[j];
+        }
+        if (norm2(step, qd) < step_tol) running[idx[k]] = 0;
+      }
+    }
+    for (int s = 0; s < S; ++s) {
+      if (!alive[s]) continue;
+      double delta[1024];
+      for (int j = 0; j < qd; ++j) delta[j] = x_begin[(size_t)s * qd + j] - x[(size_t)s * qd + j];
+      if (!(norm2(delta, qd) > outer.tolerance)) alive[s] = 0;
+    }
+  }
+}
+
+void kg_multistart(GpDev& gp, int num_fidelity, const moe_gd_params_t& outer, const moe_gd_params_t& inner, const double* bounds,
+                   const double* discrete, int P, const double* starts, int num_starts, const double* Xp, int q, int p,
+                   int num_mc, double best_so_far, const double* normals, int do_gradient_ascent, double* best_points,
+                   double* best_kg, int* found) {
+  const int d = gp.d, qd = q * d;
+  if (num_starts <= 0) throw Error(MOE_ERR_BOUNDS, "num_multistarts must be > 1", num_starts, 1, 1e9);  // hpp:881-883
+  if (qd > 1024) throw Error(MOE_ERR_BOUNDS, "num_to_sample * dim > 1024", qd, 1, 1024);
+  *found = 0;
+  *best_kg = -INFINITY;
+  std::vector<double> vals(num_starts);
+  kg_values(gp, num_fidelity, inner, bounds, discrete, P, starts, num_starts, Xp, q, p, num_mc, best_so_far, normals, vals.data());
+  std::vector<double> ends;
+  std::vector<double> end_vals;
+  int S = num_starts;
+  if (do_gradient_ascent) {
+    std::vector<int> order(num_starts);
+    std::iota(order.begin(), order.end(), 0);
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return vals[a] > vals[b]; });
+    S = std::min(num_starts, kTopK);
+    ends.resize((size_t)S * qd);
+    for (int s = 0; s < S; ++s) std::copy(starts + (size_t)order[s] * qd, starts + (size_t)(order[s] + 1) * qd, &ends[(size_t)s * qd]);
+    kg_gradient_ascent(gp, num_fidelity, outer, inner, bounds, discrete, P, ends.data(), S, Xp, q, p, num_mc, best_so_far, normals);
+    end_vals.resize(S);
+    kg_values(gp, num_fidelity, inner, bounds, discrete, P, ends.data(), S, Xp, q, p, num_mc, best_so_far, normals,
+              end_vals.data());
+  } else {
+    ends.assign(starts, starts + (size_t)num_starts * qd);
+    end_vals = vals;
+  }
+  for (int s = 0; s < S; ++s) {
+    if (end_vals[s] > *best_kg) {  // strict, like MultistartOptimizer's compare (gpp_optimization.hpp:1512)
+      *best_kg = end_vals[s];
+      std::copy(&ends[(size_t)s * qd], &ends[(size_t)(s + 1) * qd], best_points);
+      *found = 1;
+    }
+  }
+}
+
+// ComputeOptimalPosteriorMean from ONE start (gpp_knowledge_gradient_optimization.cpp:420-472): back-tracking line-search
+// ascent on f = -mu (fidelity coordinates pinned to 1), gpp_optimization.hpp:708-828 / 1242-1283.
+void posterior_mean_optimize(GpDev& gp, int num_fidelity, const moe_gd_params_t& gd, const double* bounds, const double* x0,
+                             double* best_point, double* best_value) {
+  const int d = gp.d, size = d - num_fidelity;
+  if (num_fidelity < 0 || num_fidelity >= d) throw Error(MOE_ERR_BOUNDS, "num_fidelity out of range", num_fidelity, 0, d - 1);
+  DerivList none;
+  none.g = 0;
+  for (int i = 0; i < kMaxDerivs; ++i) none.idx[i] = 0;
+  std::vector<double> x(x0, x0 + size), pt(d, 1.0), g(size), trial(size), step(size), x_begin(size), gm(d);
+  auto f = [&](const double* p, double* grad) {
+    std::copy(p, p + size, pt.begin());
+    StateHost h;
+    compute_state(gp, pt.data(), 1, none, grad ? 1 : 0, nullptr, 0, false, nullptr, &h);
+    double mu;
+    host_mean(h, &mu);
+    if (grad) {
+      host_grad_mean(h, gm.data());
+      for (int k = 0; k < size; ++k) grad[k] = -gm[k];
+    }
+    return -mu;
+  };
+  double fcur = f(x.data(), nullptr);
+  const double step_tol = gd.tolerance / (double)std::max(gd.max_num_steps, 1);
+  for (int r = 0; r < gd.max_num_restarts; ++r) {
+    x_begin = x;
+    for (int i = 0; i < gd.max_num_steps; ++i) {
+      const double f0 = f(x.data(), g.data());
+      fcur = f0;
+      double alpha = gd.pre_mult * std::pow((double)(i + 1), -gd.gamma);
+      const double n2 = std::inner_product(g.begin(), g.end(), g.begin(), 0.0);
+      int search = 0;
+      double ftrial = f0;
+      for (; search < 30; ++search) {
+        for (int k = 0; k < size; ++k) trial[k] = x[k] + alpha * g[k];
+        ftrial = f(trial.data(), nullptr);
+        if (ftrial - f0 > 0.5 * alpha * n2) break;
+        alpha *= 0.5;
+      }
+      bool changed = false, nonzero = false;
+      for (int k = 0; k < size; ++k) {
+        const double want = alpha * g[k];
+        step[k] = limit_update_1d(bounds[2 * k], bounds[2 * k + 1], gd.max_relative_change, x[k], want);
+        changed = changed || step[k] != want;
+        nonzero = nonzero || step[k] != 0.0;
+      }
+      if (search == 30 || !nonzero) break;
+      double obj2 = ftrial;
+      if (changed) {
+        for (int k = 0; k < size; ++k) trial[k] = x[k] + step[k];
+        obj2 = f(trial.data(), nullptr);
+      }
+      if (obj2 <= f0) break;
+      for (int k = 0; k < size; ++k) x[k] += step[k];
+      fcur = obj2;
+      if (norm2(step.data(), size) < step_tol) break;
+    }
+    for (int k = 0; k < size; ++k) step[k] = x_begin[k] - x[k];
+    if (!(norm2(step.data(), size) > gd.tolerance)) break;
+  }
+  std::copy(x.begin(), x.end(), best_point);
+  if (best_value) *best_value = fcur;
+}
+
+}  // namespace moe

@@ -1,5 +1,8 @@
-"""Outer multistart optimisation of q-KG: the callers of the hot path, host-driven, with every restart's
-KG value / gradient evaluated in ONE batched device pass per step (moe_kg_batch) instead of one OpenMP thread per restart.
+"""Outer multistart optimisation of q-KG: thin drivers over the C ABI (moe_kg_multistart,
+moe_posterior_mean_optimize, moe_latin_hypercube -- csrc/multistart.hip), where every restart's KG value / gradient is
+evaluated in ONE batched device pass per step instead of one OpenMP thread per restart.  The numpy functions below
+(latin_hypercube, limit_update, kg_gradient_ascent) restate the same logic on top of moe_kg_batch; tests use them as the
+independent check of the C++ drivers.
 
 Follows ComputeKGOptimalPointsToSample (gpp_knowledge_gradient_optimization.cpp:490-551):
   * Latin-hypercube starts in the repeated domain (gpp_random.cpp:173-194, gpp_domain.hpp:490-504);
@@ -103,77 +106,45 @@ def kg_gradient_ascent(dev_gp, num_fidelity, gd, inner_gd, bounds, inner_bounds,
 
 def kg_optimal_points(dev_gp, num_fidelity, optimizer_parameters, optimizer_parameters_inner, bounds, discrete, Xp,
                       num_to_sample, best_so_far, num_mc, randomness, starts=None):
-    """ComputeKGOptimalPointsToSample.  Returns (best_points [q][dim], found_flag)."""
+    """ComputeKGOptimalPointsToSample (gpp_knowledge_gradient_optimization.cpp:490-551): multistart gradient ascent from
+    Latin-hypercube starts, Latin-hypercube value search as the fall-back / null-optimiser path.
+    Returns (best_points [q][dim], found_flag)."""
+    from . import GPP, api
     d = dev_gp.d
     q = int(num_to_sample)
-    size = d - num_fidelity
     bounds = np.asarray(bounds, dtype=np.float64).reshape(-1)[:2 * d]
-    inner_bounds = bounds[:2 * size]
     inner_gd = _gd(optimizer_parameters_inner)
     p = 0 if Xp is None else np.asarray(Xp).reshape(-1, d).shape[0]
     m = (q + p) * (1 + dev_gp.g)
     normals = randomness.normal_rng_vec[0].table(((num_mc + 1) // 2) * m)
-    from . import GPP
+
+    def lhc(count):  # RepeatedDomain::GenerateUniformPointsInDomain: one hypercube per repeat (gpp_domain.hpp:490-504)
+        out = np.empty((count, q, d))
+        for r in range(q):
+            out[:, r, :] = api.latin_hypercube(randomness._next_uniform_seed(), bounds, count)
+        return out
+
     use_gd = int(optimizer_parameters.optimizer_type) == int(GPP.OptimizerTypes.gradient_descent)
-    best_point, best_value, found = np.zeros((q, d)), -np.inf, False
-
-    def consider(points, values):
-        nonlocal best_point, best_value, found
-        j = int(np.argmax(values))
-        if values[j] > best_value:      # strict, like MultistartOptimizer's per-thread compare
-            best_value, best_point, found = float(values[j]), np.array(points[j], copy=True), True
-
+    best, found = np.zeros((q, d)), False
     if use_gd:
         gd = _gd(optimizer_parameters)
         if starts is None:
-            starts = repeated_domain_starts(bounds, gd[0], q, randomness._uniform_random)
+            starts = lhc(gd[0])
         starts = np.asarray(starts, dtype=np.float64).reshape(-1, q, d)
-        vals = kg_values(dev_gp, num_fidelity, inner_gd, inner_bounds, discrete, starts, Xp, num_mc, best_so_far, normals)
-        keep = np.argsort(-vals, kind="stable")[:TOP_K]
-        ends = kg_gradient_ascent(dev_gp, num_fidelity, gd, inner_gd, bounds, inner_bounds, discrete, starts[keep], Xp, num_mc,
-                                  best_so_far, normals)
-        end_vals = kg_values(dev_gp, num_fidelity, inner_gd, inner_bounds, discrete, ends, Xp, num_mc, best_so_far, normals)
-        consider(ends, end_vals)
+        best, _, found = dev_gp.kg_multistart(gd, inner_gd, bounds, discrete, starts, Xp, num_mc, best_so_far, normals,
+                                              gradient_ascent=True, num_fidelity=num_fidelity)
     if not found:
         n_lhc = int(optimizer_parameters.num_random_samples or 0)
         if n_lhc > 0:
-            pts = repeated_domain_starts(bounds, n_lhc, q, randomness._uniform_random)
-            vals = kg_values(dev_gp, num_fidelity, inner_gd, inner_bounds, discrete, pts, Xp, num_mc, best_so_far, normals)
-            consider(pts, vals)
-    return best_point, found
+            best, _, found = dev_gp.kg_multistart(_gd(optimizer_parameters_inner), inner_gd, bounds, discrete, lhc(n_lhc), Xp,
+                                                  num_mc, best_so_far, normals, gradient_ascent=False,
+                                                  num_fidelity=num_fidelity)
+    return best, found
 
 
 def posterior_mean_optimization(dev_gp, num_fidelity, optimizer_parameters, bounds, initial_guess):
-    """ComputeOptimalPosteriorMean from ONE start: back-tracking line-search ascent on f = -mu (fidelity coordinates = 1),
-    gpp_optimization.hpp:708-828 / 1242-1283.  Returns (best_point [dim - num_fidelity], found_flag)."""
-    _, max_steps, max_restarts, _, gamma, pre_mult, max_rel, tol = _gd(optimizer_parameters)
+    """ComputeOptimalPosteriorMean from ONE start (moe_posterior_mean_optimize).  Returns (best_point, found_flag)."""
     size = dev_gp.d - num_fidelity
-    b = np.asarray(bounds, dtype=np.float64).reshape(-1)[:2 * size]
-    x = np.array(initial_guess, dtype=np.float64).reshape(-1)[:size].copy()
-
-    def f(pt, grad=False):
-        v, g = dev_gp.posterior_mean(pt, num_fidelity, want_grad=grad)
-        return (v, g) if grad else v
-
-    step_tol = tol / float(max_steps)
-    for _ in range(max(max_restarts, 0)):
-        x_begin = x.copy()
-        for i in range(max_steps):
-            f0, g = f(x, True)
-            alpha = pre_mult * float(i + 1) ** (-gamma)
-            norm2 = float(np.dot(g, g))
-            search = 0
-            while search < 30:
-                if f(x + alpha * g) - f0 > 0.5 * alpha * norm2:
-                    break
-                alpha *= 0.5
-                search += 1
-            step = limit_update(b, max_rel, x, alpha * g)
-            if search == 30 or f(x + step) <= f0:
-                break
-            x = x + step
-            if np.sqrt(float(np.dot(step, step))) < step_tol:
-                break
-        if np.sqrt(float(np.dot(x_begin - x, x_begin - x))) <= tol:
-            break
-    return x, True
+    best, _ = dev_gp.posterior_mean_optimize(_gd(optimizer_parameters), np.asarray(bounds, dtype=np.float64).reshape(-1)[:2 * size],
+                                             np.asarray(initial_guess, dtype=np.float64).reshape(-1)[:size], num_fidelity)
+    return best, True

@@ -152,6 +152,26 @@ int moe_kg_batch(const moe_gp_t* gp, int num_fidelity, const moe_gd_params_t* in
                  double best_so_far, const double* normals, int first_sample, int num_local, int want_grad,
                  double* kg_sum, double* grad_sum, moe_kg_stats_t* stats, moe_error_t* err);
 
+/* ---- callers of the hot path: the outer optimisation over points_to_sample ----
+ * multistart_knowledge_gradient_optimization (gpp_python_knowledge_gradient.cpp:243-313) ->
+ * ComputeKGOptimalPointsToSampleViaMultistartGradientDescent (gpp_knowledge_gradient_optimization.hpp:860-935) when
+ * do_gradient_ascent != 0: KG at every start, best 20 kept, restarted gradient ascent with `outer_params`
+ * (gpp_optimization.hpp:619-705, 1144-1185), best end point returned; with do_gradient_ascent == 0 the value search of
+ * ...ViaLatinHypercubeSearch / EvaluateKGAtPointList (:1090-1141).  start_points[num_starts][q][dim] are supplied by
+ * the caller (moe_latin_hypercube reproduces the reference's generator, gpp_random.cpp:173-194); domain_bounds[2*dim].
+ * Every step evaluates all live restarts in ONE batched device pass.  *found = 1 iff a point with KG > -inf was found. */
+int moe_kg_multistart(const moe_gp_t* gp, int num_fidelity, const moe_gd_params_t* outer_params,
+                      const moe_gd_params_t* inner_params, const double* domain_bounds, const double* discrete_pts, int num_pts,
+                      const double* start_points, int num_starts, const double* points_being_sampled, int num_to_sample,
+                      int num_being_sampled, int num_mc, double best_so_far, const double* normals, int do_gradient_ascent,
+                      double* best_points, double* best_kg, int* found, moe_error_t* err);
+/* posterior_mean_optimization (gpp_python_knowledge_gradient.cpp:315-342) -> ComputeOptimalPosteriorMean from ONE initial
+ * guess: line-search ascent on -mu with fidelity coordinates pinned to 1.  best_point[dim - num_fidelity]. */
+int moe_posterior_mean_optimize(const moe_gp_t* gp, int num_fidelity, const moe_gd_params_t* params, const double* domain_bounds,
+                                const double* initial_guess, double* best_point, double* best_value, moe_error_t* err);
+/* ComputeLatinHypercubePointsInDomain (gpp_random.cpp:173-194) with mt19937(seed): out[num_points][dim]. */
+int moe_latin_hypercube(unsigned int seed, const double* domain_bounds, int dim, int num_points, double* out);
+
 /* ---- covariance assembly (exposed for parity tests and the HBM-roofline measurement) ----
  * BuildMixCovarianceMatrix (gpp_math.cpp:309-335, 469-479): out[N x num_pts*(1+g2)] col-major = K(X, pts) with
  * derivative blocks; derivs2[g2] are the derivative observations carried by `pts`. */
