@@ -376,12 +376,12 @@ void launch_mc(const KgMcParams& P, int dp, int G, bool xlds, int blocks, int wa
   }
 }
 
-void launch_mc_block(const KgMcParams& P, int dp, int G, int tpw, int blocks, int waves, hipStream_t s) {
+void launch_mc_block(const KgMcParams& P, int dp, int G, int tr, int num_lds_tiles, int blocks, int waves, hipStream_t s) {
   switch (dp) {
-    case 4: launch_kg_mc_block_dp4(P, G, tpw, blocks, waves, s); break;
-    case 8: launch_kg_mc_block_dp8(P, G, tpw, blocks, waves, s); break;
-    case 12: launch_kg_mc_block_dp12(P, G, tpw, blocks, waves, s); break;
-    case 16: launch_kg_mc_block_dp16(P, G, tpw, blocks, waves, s); break;
+    case 4: launch_kg_mc_block_dp4(P, G, tr, num_lds_tiles, blocks, waves, s); break;
+    case 8: launch_kg_mc_block_dp8(P, G, tr, num_lds_tiles, blocks, waves, s); break;
+    case 12: launch_kg_mc_block_dp12(P, G, tr, num_lds_tiles, blocks, waves, s); break;
+    case 16: launch_kg_mc_block_dp16(P, G, tr, num_lds_tiles, blocks, waves, s); break;
     default: throw Error(MOE_ERR_RUNTIME, "unsupported padded dimension");
   }
 }
@@ -431,10 +431,23 @@ void kg_evaluate_batch(GpDev& gp, int num_fidelity, const moe_gd_params_t& gd, c
   // Variant selection: the wave-per-sample kernel needs the coordinate table AND >= 4 weight slabs in LDS; bigger point
   // sets (up to 32 tiles = 2048 points) go to the workgroup-per-sample kernel (coordinates in registers, 4 waves);
   // beyond that the wave-per-sample kernel streams coordinates from L2 (slow, but correct).
-  int variant = (xlds && waves >= 4) ? 0 : (ntiles <= 32 ? 1 : 0);
+  // workgroup-per-sample geometry: 8 wavefronts; TR register tiles per wave, the remaining tiles in LDS
+  const int bwaves = 8;
+  int tr = -1, num_lds_tiles = 0;
+  for (int cand : {0, 2, 4}) {
+    const int tl = std::max(0, ntiles - bwaves * cand);
+    if (kg_mc_block_lds_bytes(dp, G, tl) <= (size_t)160 * 1024) {
+      tr = cand;
+      num_lds_tiles = tl;
+      break;
+    }
+  }
+  tr = env_int("MOE_KG_TR", tr);
+  if (tr >= 0) num_lds_tiles = std::max(0, ntiles - bwaves * tr);
+  int variant = (xlds && waves >= 4) ? 0 : (tr >= 0 ? 1 : 0);
   variant = env_int("MOE_KG_VARIANT", variant);
-  const int tpw = (ntiles > 16 && env_int("MOE_KG_TPW", 8) == 8) ? 8 : 4;  // tiles of 64 points per wavefront
-  if (variant == 1 && ntiles > 32) throw Error(MOE_ERR_RUNTIME, "workgroup-per-sample MC kernel holds at most 2048 points");
+  if (variant == 1 && (tr < 0 || kg_mc_block_lds_bytes(dp, G, num_lds_tiles) > (size_t)160 * 1024))
+    throw Error(MOE_ERR_RUNTIME, "point set too large for the workgroup-per-sample MC kernel");
   if (variant == 0 && waves < 1)
     throw Error(MOE_ERR_RUNTIME, "training set too large for the MC kernel (one sample's weights exceed LDS)");
   const int num_cu = gp.num_cu;
@@ -445,7 +458,7 @@ void kg_evaluate_batch(GpDev& gp, int num_fidelity, const moe_gd_params_t& gd, c
     shm = sizeof(double) * kExpTabLen + (xlds ? tab_bytes : 0) + (size_t)waves * slab_bytes;
     wg_per_cu = std::max(1, std::min((int)((size_t)160 * 1024 / shm), 8 / waves));
   } else {
-    waves = (ntiles + tpw - 1) / tpw;  // <= 8 (tpw 4) or <= 4 (tpw 8)
+    waves = bwaves;
   }
   int blocks = num_cu * wg_per_cu;
   if (blocks >= E) blocks = (blocks / E) * E;  // the same number of workgroups for every evaluation
@@ -479,6 +492,26 @@ void kg_evaluate_batch(GpDev& gp, int num_fidelity, const moe_gd_params_t& gd, c
   compute_state_batch(gp, U_all.data(), u, gp.derivs, want_grad ? q : 0, extra_all.data(), A, true, E, &bl, &hosts);
   const double ms_dev_state = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wall0).count();
 
+  // ---- table-row order of the dimensions ----
+  TabParams tp;
+  {
+    // table-row order: the GP's observed-derivative dimensions first (so derivative weight a multiplies row a), then
+    // the remaining dimensions in ascending order; padded rows map to themselves (their lengths are 0)
+    std::vector<int> order;
+    std::vector<bool> used(kMaxDimPadded, false);
+    for (int a = 0; a < g; ++a) {
+      if (used[gp.derivs.idx[a]]) throw Error(MOE_ERR_INVALID_VALUE, "duplicate derivative index", gp.derivs.idx[a], 0, 0);
+      order.push_back(gp.derivs.idx[a]);
+      used[gp.derivs.idx[a]] = true;
+    }
+    for (int k = 0; k < kMaxDimPadded; ++k)  // derivative dims are < d <= dp, so rows [0, dp) are a permutation of [0, dp)
+      if (!used[k]) order.push_back(k);
+    if (dp < G) throw Error(MOE_ERR_RUNTIME, "padded dimension smaller than the derivative-slot count");
+    for (int r = 0; r < kMaxDimPadded; ++r) {
+      tp.perm[r] = order[r];
+      tp.inv_lp[r] = gp.cp.inv_l[order[r]];
+    }
+  }
   // ---- host m x m algebra per evaluation -> one blob ----
   KgRec rec;
   int off = 0;
@@ -495,9 +528,17 @@ void kg_evaluate_batch(GpDev& gp, int num_fidelity, const moe_gd_params_t& gd, c
   const int rec_bp = take(1);
   rec.Mk = 0;
   rec.stride = off;
-  std::vector<double> blob((size_t)rec.stride * E + 2 * size + 2, 0.0);
+  std::vector<double> blob((size_t)rec.stride * E + 2 * kMaxDimPadded, 0.0);
   const size_t o_bounds = (size_t)rec.stride * E;
-  std::copy(bounds, bounds + 2 * size, blob.begin() + o_bounds);
+  unsigned int free_mask = 0;  // table-row order: bounds of row r = bounds of original dimension perm[r]
+  for (int r = 0; r < kMaxDimPadded; ++r) {
+    const int k = tp.perm[r];
+    if (k < size) {
+      blob[o_bounds + 2 * r] = bounds[2 * k];
+      blob[o_bounds + 2 * r + 1] = bounds[2 * k + 1];
+      free_mask |= 1u << r;
+    }
+  }
   std::vector<int> winner(E, -1);
   std::vector<double> best_posterior(E, best_so_far);
   std::vector<std::vector<double>> grad_mu(E), Mk(E);
@@ -591,25 +632,6 @@ void kg_evaluate_batch(GpDev& gp, int num_fidelity, const moe_gd_params_t& gd, c
   MOE_HIP_CHECK(hipMemsetAsync(dCounters.p, 0, sizeof(unsigned long long) * 3 * E, s));
 
   // ---- coordinate tables ----
-  TabParams tp;
-  {
-    // table-row order: the GP's observed-derivative dimensions first (so derivative weight a multiplies row a), then
-    // the remaining dimensions in ascending order; padded rows map to themselves (their lengths are 0)
-    std::vector<int> order;
-    std::vector<bool> used(kMaxDimPadded, false);
-    for (int a = 0; a < g; ++a) {
-      if (used[gp.derivs.idx[a]]) throw Error(MOE_ERR_INVALID_VALUE, "duplicate derivative index", gp.derivs.idx[a], 0, 0);
-      order.push_back(gp.derivs.idx[a]);
-      used[gp.derivs.idx[a]] = true;
-    }
-    for (int k = 0; k < kMaxDimPadded; ++k)  // derivative dims are < d <= dp, so rows [0, dp) are a permutation of [0, dp)
-      if (!used[k]) order.push_back(k);
-    if (dp < G) throw Error(MOE_ERR_RUNTIME, "padded dimension smaller than the derivative-slot count");
-    for (int r = 0; r < kMaxDimPadded; ++r) {
-      tp.perm[r] = order[r];
-      tp.inv_lp[r] = gp.cp.inv_l[order[r]];
-    }
-  }
   {
     dim3 grid((unsigned)((tab_stride + 255) / 256), E);
     hipLaunchKernelGGL(build_xs_tab_kernel, grid, dim3(256), 0, s, gp.dX.p, n, gp.dPts.p, u, dp, ntiles, tp, dTab.p, tab_stride);
@@ -647,6 +669,7 @@ void kg_evaluate_batch(GpDev& gp, int num_fidelity, const moe_gd_params_t& gd, c
   mp.blob = dBlob.p;
   mp.rec = rec;
   mp.bounds = dBlob.p + o_bounds;
+  mp.free_mask = free_mask;
   mp.normals = dNormals.p;
   mp.first_sample = first_sample;
   mp.num_local = num_local;
@@ -666,7 +689,7 @@ void kg_evaluate_batch(GpDev& gp, int num_fidelity, const moe_gd_params_t& gd, c
   if (variant == 0)
     launch_mc(mp, dp, G, xlds, blocks, waves, shm, s);
   else
-    launch_mc_block(mp, dp, G, tpw, blocks, waves, s);
+    launch_mc_block(mp, dp, G, tr, num_lds_tiles, blocks, waves, s);
   t_mc.stop(s);
 
   // ---- 3. gradient tail ----

@@ -54,7 +54,8 @@ struct KgMcParams {
   long w_stride;
   const double* blob;
   KgRec rec;
-  const double* bounds;   // [2 size]
+  const double* bounds;   // [2 kMaxDimPadded] domain bounds in TABLE-ROW order (row r = original dimension perm[r])
+  unsigned int free_mask; // bit r set: table row r is an optimised coordinate (a real, non-fidelity dimension)
   const double* normals;  // [ceil(M/2)][m]
   int first_sample, num_local;
   int max_num_steps, max_num_restarts;
@@ -72,11 +73,13 @@ void launch_kg_mc_dp8(const KgMcParams& P, int G, bool xlds, int blocks, int wav
 void launch_kg_mc_dp12(const KgMcParams& P, int G, bool xlds, int blocks, int waves, size_t shm, hipStream_t s);
 void launch_kg_mc_dp16(const KgMcParams& P, int G, bool xlds, int blocks, int waves, size_t shm, hipStream_t s);
 
-// Workgroup-per-sample variant (coordinates and weights in registers): `tpw` tiles of 64 points per wavefront (4 or 8).
-void launch_kg_mc_block_dp4(const KgMcParams& P, int G, int tpw, int blocks, int waves, hipStream_t s);
-void launch_kg_mc_block_dp8(const KgMcParams& P, int G, int tpw, int blocks, int waves, hipStream_t s);
-void launch_kg_mc_block_dp12(const KgMcParams& P, int G, int tpw, int blocks, int waves, hipStream_t s);
-void launch_kg_mc_block_dp16(const KgMcParams& P, int G, int tpw, int blocks, int waves, hipStream_t s);
+// Workgroup-per-sample variant: the first `num_lds_tiles` tiles of 64 points in LDS, `tr` (0, 2 or 4) register tiles per
+// wavefront for the rest; bytes of dynamic LDS = kg_mc_block_lds_bytes(...).
+void launch_kg_mc_block_dp4(const KgMcParams& P, int G, int tr, int num_lds_tiles, int blocks, int waves, hipStream_t s);
+void launch_kg_mc_block_dp8(const KgMcParams& P, int G, int tr, int num_lds_tiles, int blocks, int waves, hipStream_t s);
+void launch_kg_mc_block_dp12(const KgMcParams& P, int G, int tr, int num_lds_tiles, int blocks, int waves, hipStream_t s);
+void launch_kg_mc_block_dp16(const KgMcParams& P, int G, int tr, int num_lds_tiles, int blocks, int waves, hipStream_t s);
+size_t kg_mc_block_lds_bytes(int dp, int G, int num_lds_tiles);
 
 #if defined(__HIPCC__)
 namespace mc {
@@ -322,7 +325,14 @@ struct WaveEval {
 template <int DP, int G, class EV>
 __device__ __forceinline__ double line_search(const KgMcParams& P, EV& ev, double (&x)[DP], unsigned long long& n_val,
                                               unsigned long long& n_grad) {
-  const int size = P.dim - P.f;  // problem size of the inner optimisation
+  // Everything below is in TABLE-ROW order (x, grad, step, bounds): the evaluator works in that order, so no permutation
+  // happens per pass; the caller's x is permuted on entry and exit only.  (free_mask marks the optimised coordinates.)
+  {
+    double xp[DP];
+    to_table_order<DP, G>(x, P.perm, xp);
+#pragma unroll
+    for (int r = 0; r < DP; ++r) x[r] = xp[r];
+  }
   const double step_tolerance = P.tolerance / (double)P.max_num_steps;
   double fcur = 0.0;
 
@@ -342,17 +352,15 @@ __device__ __forceinline__ double line_search(const KgMcParams& P, EV& ev, doubl
       for (int k = 0; k < DP; ++k) xstart[k] = x[k];
       for (int istep = 0; istep < P.max_num_steps;) {
         // ---- f(x), grad f(x) ----
-        to_table_order<DP, G>(x, P.perm, tqp);
-#pragma unroll
-        for (int r = 0; r < DP; ++r) tqp[r] *= P.inv_lp[r];
+        #pragma unroll
+        for (int r = 0; r < DP; ++r) tqp[r] = x[r] * P.inv_lp[r];
         const double f0 = ev.template eval<true>(tqp, gp);
         n_grad++;
         fcur = f0;
-        from_table_order<DP, G>(gp, P.perm, grad);
         double norm = 0.0;
 #pragma unroll
         for (int k = 0; k < DP; ++k) {
-          if (k >= size) grad[k] = 0.0;  // fidelity / pad coordinates stay pinned
+          grad[k] = ((P.free_mask >> k) & 1u) ? gp[k] : 0.0;  // fidelity / pad coordinates stay pinned
           norm = fma(grad[k], grad[k], norm);
         }
         // pre_mult * (i+1)^-gamma (gpp_optimization.hpp:741); x^-0 == 1 exactly, so gamma == 0 needs no pow()
@@ -363,9 +371,8 @@ __device__ __forceinline__ double line_search(const KgMcParams& P, EV& ev, doubl
         while (true) {
 #pragma unroll
           for (int k = 0; k < DP; ++k) tq[k] = fma(alpha_n, grad[k], x[k]);
-          to_table_order<DP, G>(tq, P.perm, tqp);
 #pragma unroll
-          for (int r = 0; r < DP; ++r) tqp[r] *= P.inv_lp[r];
+          for (int r = 0; r < DP; ++r) tqp[r] = tq[r] * P.inv_lp[r];
           ftrial = ev.template eval<false>(tqp, gp);
           n_val++;
           if (ftrial - f0 > 0.5 * alpha_n * norm) break;
@@ -377,7 +384,7 @@ __device__ __forceinline__ double line_search(const KgMcParams& P, EV& ev, doubl
 #pragma unroll
         for (int k = 0; k < DP; ++k) {
           step[k] = 0.0;
-          if (k < size) {
+          if ((P.free_mask >> k) & 1u) {
             const double want = alpha_n * grad[k];
             step[k] = limit_update_1d(P.bounds[2 * k], P.bounds[2 * k + 1], P.max_relative_change, x[k], want);
             changed = changed || (step[k] != want);
@@ -389,9 +396,8 @@ __device__ __forceinline__ double line_search(const KgMcParams& P, EV& ev, doubl
         if (changed) {
 #pragma unroll
           for (int k = 0; k < DP; ++k) tq[k] = x[k] + step[k];
-          to_table_order<DP, G>(tq, P.perm, tqp);
 #pragma unroll
-          for (int r = 0; r < DP; ++r) tqp[r] *= P.inv_lp[r];
+          for (int r = 0; r < DP; ++r) tqp[r] = tq[r] * P.inv_lp[r];
           obj2 = ev.template eval<false>(tqp, gp);
           n_val++;
         }
@@ -400,18 +406,24 @@ __device__ __forceinline__ double line_search(const KgMcParams& P, EV& ev, doubl
         for (int k = 0; k < DP; ++k) x[k] += step[k];
         fcur = obj2;
         istep += 1;
-        if (vector_norm<DP>(step, size) < step_tolerance) break;
+        if (vector_norm<DP>(step, DP) < step_tolerance) break;  // step is 0 on pinned coordinates
       }
       double delta[DP];
 #pragma unroll
       for (int k = 0; k < DP; ++k) delta[k] = xstart[k] - x[k];
-      if (!(vector_norm<DP>(delta, size) > P.tolerance)) break;
+      if (!(vector_norm<DP>(delta, DP) > P.tolerance)) break;
     }
   } else {
     // reference returns without touching its outputs (.cpp:425-427): value 0, point filled with 1.0 (.cpp:163)
 #pragma unroll
-    for (int k = 0; k < DP; ++k) x[k] = (k < P.dim) ? 1.0 : 0.0;
+    for (int k = 0; k < DP; ++k) x[k] = (P.perm[k] < P.dim) ? 1.0 : 0.0;
     fcur = 0.0;
+  }
+  {
+    double xo[DP];
+    from_table_order<DP, G>(x, P.perm, xo);
+#pragma unroll
+    for (int k = 0; k < DP; ++k) x[k] = xo[k];
   }
   return fcur;
 }
@@ -423,7 +435,6 @@ __device__ __forceinline__ double line_search(const KgMcParams& P, EV& ev, doubl
 template <int DP, int G, class EV>
 __device__ __forceinline__ double line_search_lds(const KgMcParams& P, EV& ev, double* __restrict__ st, double (&x)[DP],
                                                   unsigned long long& n_val, unsigned long long& n_grad) {
-  const int size = P.dim - P.f;
   const double step_tolerance = P.tolerance / (double)P.max_num_steps;
   double* sX = st;
   double* sG = st + kMaxDimPadded;
@@ -435,9 +446,10 @@ __device__ __forceinline__ double line_search_lds(const KgMcParams& P, EV& ev, d
     for (int k = 0; k < DP; ++k) x[k] = (k < P.dim) ? 1.0 : 0.0;
     return 0.0;
   }
-#pragma unroll
-  for (int k = 0; k < DP; ++k) sX[k] = x[k];
   double tq[DP], tqp[DP], gp[DP];
+  to_table_order<DP, G>(x, P.perm, tq);  // table-row order from here on (see line_search)
+#pragma unroll
+  for (int k = 0; k < DP; ++k) sX[k] = tq[k];
 #pragma unroll
   for (int k = 0; k < DP; ++k) gp[k] = 0.0;
   for (int restart = 0; restart < P.max_num_restarts; ++restart) {
@@ -445,33 +457,23 @@ __device__ __forceinline__ double line_search_lds(const KgMcParams& P, EV& ev, d
     for (int k = 0; k < DP; ++k) sX0[k] = sX[k];
     for (int istep = 0; istep < P.max_num_steps;) {
 #pragma unroll
-      for (int k = 0; k < DP; ++k) tq[k] = sX[k];
-      to_table_order<DP, G>(tq, P.perm, tqp);
-#pragma unroll
-      for (int r = 0; r < DP; ++r) tqp[r] *= P.inv_lp[r];
+      for (int r = 0; r < DP; ++r) tqp[r] = sX[r] * P.inv_lp[r];
       const double f0 = ev.template eval<true>(tqp, gp);
       n_grad++;
       fcur = f0;
       double norm = 0.0;
-      {
-        double g[DP];
-        from_table_order<DP, G>(gp, P.perm, g);
 #pragma unroll
-        for (int k = 0; k < DP; ++k) {
-          const double gk = (k < size) ? g[k] : 0.0;
-          sG[k] = gk;
-          norm = fma(gk, gk, norm);
-        }
+      for (int k = 0; k < DP; ++k) {
+        const double gk = ((P.free_mask >> k) & 1u) ? gp[k] : 0.0;
+        sG[k] = gk;
+        norm = fma(gk, gk, norm);
       }
       double alpha_n = (P.gamma == 0.0) ? P.pre_mult : P.pre_mult * pow((double)(istep + 1), -P.gamma);
       int search = 0;
       double ftrial;
       while (true) {
 #pragma unroll
-        for (int k = 0; k < DP; ++k) tq[k] = fma(alpha_n, sG[k], sX[k]);
-        to_table_order<DP, G>(tq, P.perm, tqp);
-#pragma unroll
-        for (int r = 0; r < DP; ++r) tqp[r] *= P.inv_lp[r];
+        for (int r = 0; r < DP; ++r) tqp[r] = fma(alpha_n, sG[r], sX[r]) * P.inv_lp[r];
         ftrial = ev.template eval<false>(tqp, gp);
         n_val++;
         if (ftrial - f0 > 0.5 * alpha_n * norm) break;
@@ -482,7 +484,7 @@ __device__ __forceinline__ double line_search_lds(const KgMcParams& P, EV& ev, d
 #pragma unroll
       for (int k = 0; k < DP; ++k) {
         double sk = 0.0;
-        if (k < size) {
+        if ((P.free_mask >> k) & 1u) {
           const double want = alpha_n * sG[k];
           sk = limit_update_1d(P.bounds[2 * k], P.bounds[2 * k + 1], P.max_relative_change, sX[k], want);
           changed = changed || (sk != want);
@@ -494,10 +496,7 @@ __device__ __forceinline__ double line_search_lds(const KgMcParams& P, EV& ev, d
       double obj2 = ftrial;
       if (changed) {
 #pragma unroll
-        for (int k = 0; k < DP; ++k) tq[k] = sX[k] + sS[k];
-        to_table_order<DP, G>(tq, P.perm, tqp);
-#pragma unroll
-        for (int r = 0; r < DP; ++r) tqp[r] *= P.inv_lp[r];
+        for (int r = 0; r < DP; ++r) tqp[r] = (sX[r] + sS[r]) * P.inv_lp[r];
         obj2 = ev.template eval<false>(tqp, gp);
         n_val++;
       }
@@ -507,7 +506,7 @@ __device__ __forceinline__ double line_search_lds(const KgMcParams& P, EV& ev, d
       for (int k = 0; k < DP; ++k) {
         const double sk = sS[k];
         sX[k] = sX[k] + sk;
-        if (k < size) ss = fma(sk, sk, ss);
+        ss = fma(sk, sk, ss);
       }
       fcur = obj2;
       istep += 1;
@@ -517,12 +516,13 @@ __device__ __forceinline__ double line_search_lds(const KgMcParams& P, EV& ev, d
 #pragma unroll
     for (int k = 0; k < DP; ++k) {
       const double dk = sX0[k] - sX[k];
-      if (k < size) ds = fma(dk, dk, ds);
+      ds = fma(dk, dk, ds);
     }
     if (!(sqrt(ds) > P.tolerance)) break;
   }
 #pragma unroll
-  for (int k = 0; k < DP; ++k) x[k] = sX[k];
+  for (int k = 0; k < DP; ++k) tq[k] = sX[k];
+  from_table_order<DP, G>(tq, P.perm, x);
   return fcur;
 }
 
@@ -690,19 +690,59 @@ __global__ __launch_bounds__(512) void kg_mc_kernel(KgMcParams P) {
 
 // =====================================================================================================================
 // Workgroup-per-sample variant for training sets whose coordinate table + per-wave weight slabs no longer fit the 160 KB of
-// LDS (e.g. d-KG at n = 2000, d = 12, g = 3: 196 KB of coordinates, 80 KB of weights per sample).  The points are split
-// statically over the NW wavefronts of a workgroup, TPW tiles of 64 per wave, and BOTH their coordinates (loaded once per
-// workgroup) and the current sample's weights live in REGISTERS -- the inner loop touches no memory at all.  All waves
-// run the same line search in lockstep: each pass ends with one wavefront sum per wave, one LDS slot per wave, ONE
-// __syncthreads, and a fixed-order sum of the NW partials, so every wave takes bit-identical decisions.
+// LDS (e.g. d-KG at n = 2000, d = 12, g = 3: 196 KB of coordinates, 80 KB of weights per sample).  ONE sample at a time
+// per workgroup of 8 wavefronts; the point tiles are split statically over the waves and over the two on-chip stores:
+//   * the first T_L tiles live in LDS (coordinates, loaded once per workgroup, and the current sample's weights), each wave
+//     sweeping its share with the same software-pipelined loop as the wave-per-sample kernel;
+//   * the last 8 * TR tiles live in REGISTERS: TR tiles per wave, coordinates for the kernel's lifetime and weights per
+//     sample (the register file, 512 KB per CU, is the largest on-chip store; at TR = 2, d = 12, g = 3 that is 68 VGPRs).
+// The host picks the smallest TR in {0, 2, 4} for which the LDS part fits.  All waves run the same line search in lockstep:
+// each pass ends with one wavefront sum per wave, one LDS slot per wave, ONE __syncthreads, and a fixed-order sum of the
+// per-wave partials, so every wave takes bit-identical decisions.
 // =====================================================================================================================
 constexpr int kPartLen = 24;       // doubles per partial slot: f | DP gradient sums | G derivative sums (<= 1 + 16 + 4)
 constexpr int kMaxBlockWaves = 8;
 
-template <int DP, int G, int TPW>
+// One point's contribution to the accumulators (shared by the LDS-tile loop and the register tiles).
+template <int DP, int G, bool WG, int COV>
+__device__ __forceinline__ void point_terms(const double (&cx)[DP], const double (&cw)[1 + G], const double (&xq)[DP],
+                                            const double* __restrict__ etab, double& accf, double (&accg)[DP],
+                                            double (&accd)[G > 0 ? G : 1]) {
+  double diff[DP];
+  double r2 = 1.0e-300;
+#pragma unroll
+  for (int k = 0; k < DP; ++k) {
+    diff[k] = cx[k] - xq[k];
+    r2 = fma(diff[k], diff[k], r2);
+  }
+  double base, first, second;
+  radial3<COV, (WG || G > 0), (WG && G > 0)>(r2, etab, base, first, second);
+  double sd = 0.0;
+  if (G > 0) {
+#pragma unroll
+    for (int a = 0; a < G; ++a) sd = fma(cw[1 + a], diff[a], sd);
+  }
+  accf = fma(cw[0], base, accf);
+  if (G > 0) accf = fma(first, sd, accf);
+  if (WG) {
+    double coef = cw[0] * first;
+    if (G > 0) {
+      coef = fma(second, sd, coef);
+#pragma unroll
+      for (int a = 0; a < G; ++a) accd[a] = fma(first, cw[1 + a], accd[a]);
+    }
+#pragma unroll
+    for (int k = 0; k < DP; ++k) accg[k] = fma(coef, diff[k], accg[k]);
+  }
+}
+
+template <int DP, int G, int TR>
 struct BlockEval {
-  double cx[TPW][DP];  // scaled coordinates of this lane's TPW points (table-row order), resident for the kernel's life
-  const double* __restrict__ wl;  // this lane's weights for the current sample: LDS [TPW][1+G][64] slab of this wave (+lane)
+  double cx[TR > 0 ? TR : 1][DP];     // register tiles: scaled coordinates (resident for the kernel's life)
+  double cw[TR > 0 ? TR : 1][1 + G];  // register tiles: weights of the current sample
+  const double* __restrict__ xl;      // this wave's LDS tiles: coordinates [ntl][DP][64] (+lane)
+  const double* __restrict__ wl;      // this wave's LDS tiles: weights of the current sample [ntl][1+G][64] (+lane)
+  int ntl;                            // number of LDS tiles of this wave
   const double* __restrict__ etab;
   double* __restrict__ part;  // LDS [2][kMaxBlockWaves][kPartLen]
   const double* inv_lp;
@@ -712,40 +752,36 @@ struct BlockEval {
   template <bool WG, int COV>
   __device__ __forceinline__ void accumulate(const double (&xq)[DP], double& accf, double (&accg)[DP],
                                              double (&accd)[G > 0 ? G : 1]) {
+    // ---- LDS tiles: software-pipelined (next tile requested before the current one is consumed) ----
+    if (ntl > 0) {
+      const double* xt = xl;
+      const double* wt = wl;
+      double c0[DP], w0[1 + G];
 #pragma unroll
-    for (int t = 0; t < TPW; ++t) {
-      double cw[1 + G];
+      for (int k = 0; k < DP; ++k) c0[k] = xt[k * 64];
 #pragma unroll
-      for (int a = 0; a < 1 + G; ++a) cw[a] = wl[(t * (1 + G) + a) * 64];
-      double diff[DP];
-      double r2 = 1.0e-300;
-#pragma unroll
-      for (int k = 0; k < DP; ++k) {
-        diff[k] = cx[t][k] - xq[k];
-        r2 = fma(diff[k], diff[k], r2);
-      }
-      double base, first, second;
-      radial3<COV, (WG || G > 0), (WG && G > 0)>(r2, etab, base, first, second);
-      double sd = 0.0;
-      if (G > 0) {
-#pragma unroll
-        for (int a = 0; a < G; ++a) sd = fma(cw[1 + a], diff[a], sd);
-      }
-      accf = fma(cw[0], base, accf);
-      if (G > 0) accf = fma(first, sd, accf);
-      if (WG) {
-        double coef = cw[0] * first;
-        if (G > 0) {
-          coef = fma(second, sd, coef);
-#pragma unroll
-          for (int a = 0; a < G; ++a) accd[a] = fma(first, cw[1 + a], accd[a]);
+      for (int a = 0; a < 1 + G; ++a) w0[a] = wt[a * 64];
+#pragma unroll 2
+      for (int t = 0; t < ntl; ++t) {
+        double c1[DP], w1[1 + G];
+        if (t + 1 < ntl) {
+          xt += DP * 64;
+          wt += (1 + G) * 64;
         }
 #pragma unroll
-        for (int k = 0; k < DP; ++k) accg[k] = fma(coef, diff[k], accg[k]);
+        for (int k = 0; k < DP; ++k) c1[k] = xt[k * 64];
+#pragma unroll
+        for (int a = 0; a < 1 + G; ++a) w1[a] = wt[a * 64];
+        point_terms<DP, G, WG, COV>(c0, w0, xq, etab, accf, accg, accd);
+#pragma unroll
+        for (int k = 0; k < DP; ++k) c0[k] = c1[k];
+#pragma unroll
+        for (int a = 0; a < 1 + G; ++a) w0[a] = w1[a];
       }
-      // two tiles are scheduled together (ILP for the single resident wave), more would only raise register pressure
-      if ((t & 1) == 1) __builtin_amdgcn_sched_barrier(0);
     }
+    // ---- register tiles ----
+#pragma unroll
+    for (int t = 0; t < TR; ++t) point_terms<DP, G, WG, COV>(cx[t], cw[t], xq, etab, accf, accg, accd);
   }
 
   template <bool WG>
@@ -798,27 +834,67 @@ struct BlockEval {
   }
 };
 
-template <int DP, int G, int TPW>
-__global__ __launch_bounds__(TPW <= 4 ? 512 : 256) void kg_mc_block_kernel(KgMcParams P) {  // TPW 4: up to 8 waves (256 regs); TPW 8: 4 waves (512 regs)
+// v(j, a) of the weight block for point j (see file header), alpha and the derivative scaling folded in.
+template <int G>
+__device__ __forceinline__ void point_weights(const KgMcParams& P, const double* __restrict__ We, const double* __restrict__ zb,
+                                              int j, double (&w)[1 + G]) {
+  const int n = P.n, u = P.u, m = P.m, g1 = 1 + P.g;
+#pragma unroll
+  for (int a = 0; a < 1 + G; ++a) {
+    double v = 0.0;
+    if (a < g1) {
+      if (j < n) {
+        const long row = (long)j * g1 + a;
+        v = P.KinvY[row];
+        for (int c0 = 0; c0 < m; c0 += 4) {
+          const double l0 = We[row + (long)c0 * P.N];
+          const double l1 = We[row + (long)min(c0 + 1, m - 1) * P.N];
+          const double l2 = We[row + (long)min(c0 + 2, m - 1) * P.N];
+          const double l3 = We[row + (long)min(c0 + 3, m - 1) * P.N];
+          v = fma(-l0, zb[kMaxM + c0], v);
+          v = fma(-l1, zb[kMaxM + min(c0 + 1, kMaxM - 1)], v);
+          v = fma(-l2, zb[kMaxM + min(c0 + 2, kMaxM - 1)], v);
+          v = fma(-l3, zb[kMaxM + min(c0 + 3, kMaxM - 1)], v);
+        }
+      } else if (j < n + u) {
+        v = zb[kMaxM + (j - n) * g1 + a];
+      }
+      v *= (a == 0) ? P.alpha : -P.alpha * P.inv_lp[a > 0 ? a - 1 : 0];
+    }
+    w[a] = v;
+  }
+}
+
+// Fixed LDS words of the workgroup-per-sample kernel (doubles), before the tile data.
+constexpr int kBlockFixed = kExpTabLen + 2 * kMaxM + 2 * kMaxBlockWaves * kPartLen + 2 + kMaxBlockWaves * 4 * kMaxDimPadded;
+
+template <int DP, int G, int TR>
+__global__ __launch_bounds__(512) void kg_mc_block_kernel(KgMcParams P, int num_lds_tiles) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   // LDS: [32] exp table | z, beta scratch (2 kMaxM) | partial slots [2][8][kPartLen] | control words (2 doubles) |
-  //      line-search state [nw][4 kMaxDimPadded] | weights of the current sample [nw][TPW][1+G][64]
+  //      line-search state [8][4 kMaxDimPadded] | coordinates of the LDS tiles [T_L][DP][64] | their weights [T_L][1+G][64]
   double* etab = smem;
   double* zb = smem + kExpTabLen;
   double* part = zb + 2 * kMaxM;
   int* ctl = reinterpret_cast<int*>(part + 2 * kMaxBlockWaves * kPartLen);  // [0] sample index, [1] best discretised point
   double* stw = part + 2 * kMaxBlockWaves * kPartLen + 2 + (threadIdx.x >> 6) * (4 * kMaxDimPadded);
-  double* wslab = part + 2 * kMaxBlockWaves * kPartLen + 2 + kMaxBlockWaves * 4 * kMaxDimPadded +
-                  (threadIdx.x >> 6) * (TPW * (1 + G) * 64) + (threadIdx.x & 63);
+  double* ldsx = smem + kBlockFixed;
+  double* ldsw = ldsx + (long)num_lds_tiles * DP * 64;
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   const int nw = blockDim.x >> 6;
-  const int n = P.n, u = P.u, m = P.m, g1 = 1 + P.g;
+  const int m = P.m;
   const int size = P.dim - P.f;
+  // LDS tiles [0, T_L) are dealt to the waves in contiguous runs; register tiles are T_L + wave * TR + t
+  const int TL = num_lds_tiles;
+  const int per = (TL + nw - 1) / nw;
+  const int tl0 = min(wave * per, TL), tl1 = min(tl0 + per, TL);
   if (threadIdx.x < kExpTabLen) etab[threadIdx.x] = kExp2Tab32[threadIdx.x];
-  BlockEval<DP, G, TPW> ev;
+  BlockEval<DP, G, TR> ev;
+  ev.xl = ldsx + (long)tl0 * DP * 64 + lane;
+  ev.wl = ldsw + (long)tl0 * (1 + G) * 64 + lane;
+  ev.ntl = tl1 - tl0;
   ev.etab = etab;
-  ev.wl = wslab;
   ev.part = part;
   ev.inv_lp = P.inv_lp;
   ev.mean = P.mean;
@@ -832,10 +908,11 @@ __global__ __launch_bounds__(TPW <= 4 ? 512 : 256) void kg_mc_block_kernel(KgMcP
     const double* rec = P.blob + (long)e * P.rec.stride;
     const double* Lsm = rec + P.rec.L;
     const double* We = P.W + (long)e * P.w_stride;
-    // this lane's points: tiles wave*TPW .. wave*TPW + TPW - 1 (tiles beyond the table hold no points: zero coordinates)
+    __syncthreads();  // previous evaluation's readers of the LDS coordinates are done
+    for (int t = threadIdx.x; t < TL * DP * 64; t += blockDim.x) ldsx[t] = tab[t];
 #pragma unroll
-    for (int t = 0; t < TPW; ++t) {
-      const int tile = wave * TPW + t;
+    for (int t = 0; t < TR; ++t) {
+      const int tile = TL + wave * TR + t;
 #pragma unroll
       for (int k = 0; k < DP; ++k) ev.cx[t][k] = (tile < P.ntiles) ? tab[((long)tile * DP + k) * 64 + lane] : 0.0;
     }
@@ -852,34 +929,19 @@ __global__ __launch_bounds__(TPW <= 4 ? 512 : 256) void kg_mc_block_kernel(KgMcP
         if (lane == 0) ctl[1] = bj;
       }
       __syncthreads();
-      // ---- weights of this lane's points for this sample, into this wave's LDS slab (rolled loop: no register arrays) ----
+      // ---- weights of this wave's points for this sample: LDS tiles into the LDS slab, register tiles into registers ----
+      {
+        double* wdst = ldsw + (long)tl0 * (1 + G) * 64 + lane;
 #pragma unroll 1
-      for (int t = 0; t < TPW; ++t) {
-        const int j = (wave * TPW + t) * 64 + lane;
+        for (int t = tl0; t < tl1; ++t) {
+          double w[1 + G];
+          point_weights<G>(P, We, zb, t * 64 + lane, w);
 #pragma unroll
-        for (int a = 0; a < 1 + G; ++a) {
-          double v = 0.0;
-          if (a < g1) {
-            if (j < n) {
-              const long row = (long)j * g1 + a;
-              v = P.KinvY[row];
-              for (int c0 = 0; c0 < m; c0 += 4) {
-                const double l0 = We[row + (long)c0 * P.N];
-                const double l1 = We[row + (long)min(c0 + 1, m - 1) * P.N];
-                const double l2 = We[row + (long)min(c0 + 2, m - 1) * P.N];
-                const double l3 = We[row + (long)min(c0 + 3, m - 1) * P.N];
-                v = fma(-l0, zb[kMaxM + c0], v);
-                v = fma(-l1, zb[kMaxM + min(c0 + 1, kMaxM - 1)], v);
-                v = fma(-l2, zb[kMaxM + min(c0 + 2, kMaxM - 1)], v);
-                v = fma(-l3, zb[kMaxM + min(c0 + 3, kMaxM - 1)], v);
-              }
-            } else if (j < n + u) {
-              v = zb[kMaxM + (j - n) * g1 + a];
-            }
-            v *= (a == 0) ? P.alpha : -P.alpha * P.inv_lp[a > 0 ? a - 1 : 0];
-          }
-          wslab[(t * (1 + G) + a) * 64] = v;  // read back only by this lane
+          for (int a = 0; a < 1 + G; ++a) wdst[a * 64] = w[a];  // read back only by this lane
+          wdst += (1 + G) * 64;
         }
+#pragma unroll
+        for (int t = 0; t < TR; ++t) point_weights<G>(P, We, zb, (TL + wave * TR + t) * 64 + lane, ev.cw[t]);
       }
       const int best_j = ctl[1];
       const double* disc = rec + P.rec.disc;
@@ -906,33 +968,34 @@ __global__ __launch_bounds__(TPW <= 4 ? 512 : 256) void kg_mc_block_kernel(KgMcP
       }
     }
     if (gridDim.x >= (unsigned)P.E) break;
-    __syncthreads();
   }
 }
 
-template <int DP, int G, int TPW>
-inline void launch_block_inst(const KgMcParams& P, int blocks, int waves, hipStream_t s) {
-  const size_t shm = sizeof(double) * (kExpTabLen + 2 * kMaxM + 2 * kMaxBlockWaves * kPartLen + 2 +
-                                       kMaxBlockWaves * 4 * kMaxDimPadded + (size_t)waves * TPW * (1 + G) * 64);
-  auto kern = kg_mc_block_kernel<DP, G, TPW>;
+template <int DP, int G, int TR>
+inline void launch_block_inst(const KgMcParams& P, int num_lds_tiles, int blocks, int waves, hipStream_t s) {
+  const size_t shm = sizeof(double) * (kBlockFixed + (size_t)num_lds_tiles * (DP + 1 + G) * 64);
+  auto kern = kg_mc_block_kernel<DP, G, TR>;
   MOE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
-  hipLaunchKernelGGL((kg_mc_block_kernel<DP, G, TPW>), dim3(blocks), dim3(waves * 64), shm, s, P);
+  hipLaunchKernelGGL(kern, dim3(blocks), dim3(waves * 64), shm, s, P, num_lds_tiles);
   MOE_HIP_CHECK(hipGetLastError());
 }
 
+template <int DP, int G>
+inline void launch_block_g(const KgMcParams& P, int tr, int num_lds_tiles, int blocks, int waves, hipStream_t s) {
+  switch (tr) {
+    case 0: launch_block_inst<DP, G, 0>(P, num_lds_tiles, blocks, waves, s); break;
+    case 2: launch_block_inst<DP, G, 2>(P, num_lds_tiles, blocks, waves, s); break;
+    case 4: launch_block_inst<DP, G, 4>(P, num_lds_tiles, blocks, waves, s); break;
+    default: throw Error(MOE_ERR_RUNTIME, "unsupported register-tile count in the workgroup-per-sample MC kernel");
+  }
+}
+
 template <int DP>
-inline void launch_block_dp(const KgMcParams& P, int G, int tpw, int blocks, int waves, hipStream_t s) {
-  if (tpw != 4 && tpw != 8) throw Error(MOE_ERR_RUNTIME, "unsupported tiles-per-wave in the workgroup-per-sample MC kernel");
+inline void launch_block_dp(const KgMcParams& P, int G, int tr, int num_lds_tiles, int blocks, int waves, hipStream_t s) {
   switch (G) {
-    case 0:
-      if (tpw == 4) launch_block_inst<DP, 0, 4>(P, blocks, waves, s); else launch_block_inst<DP, 0, 8>(P, blocks, waves, s);
-      break;
-    case 2:
-      if (tpw == 4) launch_block_inst<DP, 2, 4>(P, blocks, waves, s); else launch_block_inst<DP, 2, 8>(P, blocks, waves, s);
-      break;
-    case 4:
-      if (tpw == 4) launch_block_inst<DP, 4, 4>(P, blocks, waves, s); else launch_block_inst<DP, 4, 8>(P, blocks, waves, s);
-      break;
+    case 0: launch_block_g<DP, 0>(P, tr, num_lds_tiles, blocks, waves, s); break;
+    case 2: launch_block_g<DP, 2>(P, tr, num_lds_tiles, blocks, waves, s); break;
+    case 4: launch_block_g<DP, 4>(P, tr, num_lds_tiles, blocks, waves, s); break;
     default: throw Error(MOE_ERR_RUNTIME, "unsupported derivative-slot count in the MC kernel");
   }
 }

@@ -7,8 +7,12 @@ void launch_kg_mc_dp4(const KgMcParams& P, int G, bool xlds, int blocks, int wav
   mc::launch_dp<4>(P, G, xlds, blocks, waves, shm, s);
 }
 
-void launch_kg_mc_block_dp4(const KgMcParams& P, int G, int tpw, int blocks, int waves, hipStream_t s) {
-  mc::launch_block_dp<4>(P, G, tpw, blocks, waves, s);
+void launch_kg_mc_block_dp4(const KgMcParams& P, int G, int tr, int num_lds_tiles, int blocks, int waves, hipStream_t s) {
+  mc::launch_block_dp<4>(P, G, tr, num_lds_tiles, blocks, waves, s);
+}
+
+size_t kg_mc_block_lds_bytes(int dp, int G, int num_lds_tiles) {
+  return sizeof(double) * (mc::kBlockFixed + (size_t)num_lds_tiles * (dp + 1 + G) * 64);
 }
 
 }  // namespace moe

@@ -7,8 +7,8 @@ void launch_kg_mc_dp8(const KgMcParams& P, int G, bool xlds, int blocks, int wav
   mc::launch_dp<8>(P, G, xlds, blocks, waves, shm, s);
 }
 
-void launch_kg_mc_block_dp8(const KgMcParams& P, int G, int tpw, int blocks, int waves, hipStream_t s) {
-  mc::launch_block_dp<8>(P, G, tpw, blocks, waves, s);
+void launch_kg_mc_block_dp8(const KgMcParams& P, int G, int tr, int num_lds_tiles, int blocks, int waves, hipStream_t s) {
+  mc::launch_block_dp<8>(P, G, tr, num_lds_tiles, blocks, waves, s);
 }
 
 }  // namespace moe
