@@ -331,10 +331,10 @@ def evaluate_EI_at_point_list(gaussian_process, optimizer_parameters, domain_bou
                               max_num_threads, 1e9)
     gp = gaussian_process
     guesses = _flat(initial_guesses, gp.dim * num_to_sample * num_multistarts).reshape(num_multistarts, num_to_sample, gp.dim)
-    out = []
-    for Xq in guesses:
-        out.append(compute_expected_improvement(gp, Xq, points_being_sampled, num_to_sample, num_being_sampled,
-                                                max_int_steps, best_so_far, False, randomness_source))
+    Xp = _being_sampled(gp, points_being_sampled, num_being_sampled)
+    u = num_to_sample + max(num_being_sampled, 0)
+    normals = randomness_source.normal_rng_vec[0].table(int(max_int_steps) * u)
+    out = list(gp._dev.ei_batch(guesses, Xp, int(max_int_steps), float(best_so_far), normals, want_grad=False)[0])
     status["evaluate_EI_at_point_list"] = bool(len(out) > 0 and max(out) > 0.0)
     return out
 

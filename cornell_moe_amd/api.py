@@ -238,6 +238,26 @@ class DeviceGP(object):
                                   C.byref(err)), err)
         return (ei.value if want_value else None), (grad.reshape(q, self.d) if want_grad else None)
 
+    def ei_batch(self, Xq_all, Xp, num_mc, best_so_far, normals, want_grad=True):
+        """moe_ei_batch: Xq_all [E][q][dim] -> (ei [E], grad [E][q][dim] or None)."""
+        Xq_all = np.ascontiguousarray(Xq_all, dtype=np.float64)
+        E, q, _ = Xq_all.shape
+        if Xp is None or np.size(Xp) == 0:
+            p, ppp = 0, None
+        else:
+            Xp, ppp = _d(Xp)
+            p = Xp.reshape(-1, self.d).shape[0]
+        normals, npn = _d(normals)
+        if normals.size < num_mc * (q + p):
+            raise InvalidValueException("normal table too small", normals.size, num_mc * (q + p), 0)
+        ei = np.zeros(E)
+        grad = np.zeros(E * q * self.d)
+        err = _lib.MoeError()
+        _check(_lib.load().moe_ei_batch(self._h, Xq_all.ctypes.data_as(dp), E, ppp, q, p, int(num_mc), float(best_so_far), npn,
+                                        ei.ctypes.data_as(dp), grad.ctypes.data_as(dp) if want_grad else None, C.byref(err)),
+               err)
+        return ei, (grad.reshape(E, q, self.d) if want_grad else None)
+
     @staticmethod
     def _gd(params):
         if isinstance(params, _lib.GdParams):

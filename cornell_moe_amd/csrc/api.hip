@@ -326,6 +326,16 @@ int moe_ei(const moe_gp_t* gp_c, const double* points_to_sample, const double* p
   });
 }
 
+int moe_ei_batch(const moe_gp_t* gp_c, const double* points_to_sample_all, int num_evals, const double* points_being_sampled,
+                 int num_to_sample, int num_being_sampled, int num_mc, double best_so_far, const double* normals,
+                 double* ei, double* grad_ei, moe_error_t* err) {
+  return guarded(err, [&] {
+    moe::GpDev& gp = const_cast<moe_gp_t*>(gp_c)->dev;
+    moe::ei_evaluate_batch(gp, points_to_sample_all, num_evals, points_being_sampled, num_to_sample, num_being_sampled, num_mc,
+                           best_so_far, normals, ei, grad_ei);
+  });
+}
+
 int moe_kg_batch(const moe_gp_t* gp_c, int num_fidelity, const moe_gd_params_t* inner_params, const double* domain_bounds,
                  const double* discrete_pts, int num_pts, const double* points_to_sample_all, int num_evals,
                  const double* points_being_sampled, int num_to_sample, int num_being_sampled, int num_mc,

@@ -23,9 +23,10 @@ struct EiParams {
   const double* L;        // [u x u] col-major lower
   const double* grad_mu;  // [q][d]
   const double* gchol;    // [q][u][u][d]: gchol[k*d*u*u + dd + c*d + r*d*u] = dL[r][c]/dXs_{k,dd}, r >= c
-  const double* normals;  // [num_mc][u]
-  double* partial;        // [gridDim.x][1 + q*d]
+  const double* normals;  // [num_mc][u]  (shared by all evaluations: common random numbers)
+  double* partial;        // [E][gridDim.x][1 + q*d]
   int want_grad;
+  long blob_stride;       // doubles between consecutive evaluations' (mu, L, grad_mu, gchol) records
 };
 
 __device__ __forceinline__ double wave_sum_ei(double v) {
@@ -37,6 +38,11 @@ __device__ __forceinline__ double wave_sum_ei(double v) {
 __global__ __launch_bounds__(256) void ei_mc_kernel(EiParams P) {
   constexpr int MU = kMaxUnionEi;
   __shared__ double red[4];
+  const long eoff = (long)blockIdx.y * P.blob_stride;  // this evaluation's record
+  P.mu += eoff;
+  P.L += eoff;
+  P.grad_mu += eoff;
+  P.gchol += eoff;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const bool active = i < P.num_mc;
   const int u = P.u, d = P.d;
@@ -81,7 +87,8 @@ __global__ __launch_bounds__(256) void ei_mc_kernel(EiParams P) {
     const double w = wave_sum_ei(contrib);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = w;
     __syncthreads();
-    if (threadIdx.x == 0) P.partial[(long)blockIdx.x * ncomp + comp] = (red[0] + red[1]) + (red[2] + red[3]);
+    if (threadIdx.x == 0)
+      P.partial[((long)blockIdx.y * gridDim.x + blockIdx.x) * ncomp + comp] = (red[0] + red[1]) + (red[2] + red[3]);
     __syncthreads();
   }
 }
@@ -89,6 +96,8 @@ __global__ __launch_bounds__(256) void ei_mc_kernel(EiParams P) {
 __global__ __launch_bounds__(256) void sum_partials_kernel(const double* __restrict__ partial, int num_blocks, int ncomp,
                                                           double* __restrict__ out) {
   __shared__ double red[256];
+  partial += (long)blockIdx.x * num_blocks * ncomp;  // one workgroup per evaluation
+  out += (long)blockIdx.x * ncomp;
   for (int comp = 0; comp < ncomp; ++comp) {
     double acc = 0.0;
     for (int b = threadIdx.x; b < num_blocks; b += 256) acc += partial[(long)b * ncomp + comp];
@@ -105,63 +114,60 @@ __global__ __launch_bounds__(256) void sum_partials_kernel(const double* __restr
 
 }  // namespace
 
-void ei_evaluate(GpDev& gp, const double* Xq, const double* Xp, int q, int p, int num_mc, double best_so_far,
-                 const double* normals, double* ei, double* grad_ei) {
+void ei_evaluate_batch(GpDev& gp, const double* Xq_all, int num_evals, const double* Xp, int q, int p, int num_mc,
+                       double best_so_far, const double* normals, double* ei, double* grad_ei) {
   gp.use_device();
   hipStream_t s = gp.stream;
-  const int d = gp.d, u = q + p;
+  const int d = gp.d, u = q + p, E = num_evals;
   if (q <= 0) throw Error(MOE_ERR_BOUNDS, "num_to_sample must be positive", q, 1, 1e9);
   if (p < 0) throw Error(MOE_ERR_BOUNDS, "num_being_sampled must be non-negative", p, 0, 1e9);
+  if (E <= 0) throw Error(MOE_ERR_BOUNDS, "num_evals must be positive", E, 1, 1e9);
   if (u > kMaxUnionEi) throw Error(MOE_ERR_BOUNDS, "q + p > 16 is not supported by the device kernels", u, 1, kMaxUnionEi);
   if (num_mc <= 0) throw Error(MOE_ERR_BOUNDS, "num_mc must be positive", num_mc, 1, 1e12);
   const bool want_grad = grad_ei != nullptr;
-  std::vector<double> U((size_t)u * d);
-  std::copy(Xq, Xq + (size_t)q * d, U.begin());
-  if (p > 0) std::copy(Xp, Xp + (size_t)p * d, U.begin() + (size_t)q * d);
+  std::vector<double> U_all((size_t)E * u * d);
+  for (int e = 0; e < E; ++e) {
+    std::copy(Xq_all + (size_t)e * q * d, Xq_all + (size_t)(e + 1) * q * d, &U_all[(size_t)e * u * d]);
+    if (p > 0) std::copy(Xp, Xp + (size_t)p * d, &U_all[(size_t)e * u * d + (size_t)q * d]);
+  }
   DerivList none;
   none.g = 0;
   for (int i = 0; i < kMaxDerivs; ++i) none.idx[i] = 0;
   // EI points carry no derivative observations even when the GP does (ExpectedImprovementState, gpp_math.cpp:2149-2150)
-  StateHost sh;
-  compute_state(gp, U.data(), u, none, want_grad ? q : 0, nullptr, 0, false, nullptr, &sh);
-  std::vector<double> mu(u), chol((size_t)u * u);
-  host_mean(sh, mu.data());
-  host_variance(sh, chol.data());
-  for (int i = 0; i < u; ++i) chol[i + (size_t)i * u] += 1.0e-6;  // gpp_math.cpp:2000-2002
-  const int lm = host_cholesky(u, chol.data());
-  if (lm != 0)
-    throw Error(MOE_ERR_SINGULAR,
-                "GP-Variance matrix singular. Check for duplicate points_to_sample/being_sampled or "
-                "points_to_sample/being_sampled duplicating points_sampled with 0 noise.",
-                u, lm);
-  std::vector<double> blob;
-  auto push = [&](const double* ptr, size_t cnt) {
-    const size_t off = blob.size();
-    blob.insert(blob.end(), ptr, ptr + cnt);
-    return off;
-  };
-  const size_t o_mu = push(mu.data(), u);
-  const size_t o_L = push(chol.data(), (size_t)u * u);
-  size_t o_gmu = 0, o_gc = 0;
-  if (want_grad) {
-    std::vector<double> grad_mu((size_t)q * d), gchol((size_t)q * d * u * u);
-    host_grad_mean(sh, grad_mu.data());
-    for (int k = 0; k < q; ++k) host_grad_cholesky_per_point(sh, k, chol.data(), &gchol[(size_t)k * d * u * u]);
-    o_gmu = push(grad_mu.data(), grad_mu.size());
-    o_gc = push(gchol.data(), gchol.size());
+  std::vector<StateHost> hosts;
+  compute_state_batch(gp, U_all.data(), u, none, want_grad ? q : 0, nullptr, 0, false, E, nullptr, &hosts);
+  // per-evaluation record: mu [u] | L [u*u] | grad_mu [q*d] | gchol [q*d*u*u]
+  const size_t o_mu = 0, o_L = u, o_gmu = o_L + (size_t)u * u, o_gc = o_gmu + (size_t)q * d;
+  const size_t rec = o_gc + (want_grad ? (size_t)q * d * u * u : 0);
+  const size_t n_norm = (size_t)num_mc * u;
+  gp.hKgIn.reserve(rec * E + n_norm);
+  double* blob = gp.hKgIn.p;
+  for (int e = 0; e < E; ++e) {
+    const StateHost& sh = hosts[e];
+    double* r = blob + rec * e;
+    double* chol = r + o_L;
+    host_mean(sh, r + o_mu);
+    host_variance(sh, chol);
+    for (int i = 0; i < u; ++i) chol[i + (size_t)i * u] += 1.0e-6;  // gpp_math.cpp:2000-2002
+    const int lm = host_cholesky(u, chol);
+    if (lm != 0)
+      throw Error(MOE_ERR_SINGULAR,
+                  "GP-Variance matrix singular. Check for duplicate points_to_sample/being_sampled or "
+                  "points_to_sample/being_sampled duplicating points_sampled with 0 noise.",
+                  u, lm);
+    if (want_grad) {
+      host_grad_mean(sh, r + o_gmu);
+      for (int k = 0; k < q; ++k) host_grad_cholesky_per_point(sh, k, chol, r + o_gc + (size_t)k * d * u * u);
+    }
   }
+  std::memcpy(blob + rec * E, normals, sizeof(double) * n_norm);
   const int ncomp = 1 + (want_grad ? q * d : 0);
   const int blocks = (num_mc + 255) / 256;
   // persistent workspaces (hipMalloc / hipFree per call cost more than the whole evaluation)
-  DevBuf<double>&dBlob = gp.kBlob, &dNormals = gp.kNormals, &dPartial = gp.kTB, &dOut = gp.kOut;
-  const size_t n_norm = (size_t)num_mc * u;
-  gp.hKgIn.reserve(blob.size() + n_norm);
-  std::memcpy(gp.hKgIn.p, blob.data(), sizeof(double) * blob.size());
-  std::memcpy(gp.hKgIn.p + blob.size(), normals, sizeof(double) * n_norm);
-  dBlob.upload(gp.hKgIn.p, blob.size(), s);
-  dNormals.upload(gp.hKgIn.p + blob.size(), n_norm, s);
-  dPartial.reserve((size_t)blocks * ncomp);
-  dOut.reserve(ncomp);
+  DevBuf<double>&dBlob = gp.kBlob, &dPartial = gp.kTB, &dOut = gp.kOut;
+  dBlob.upload(blob, rec * E + n_norm, s);
+  dPartial.reserve((size_t)E * blocks * ncomp);
+  dOut.reserve((size_t)E * ncomp);
   EiParams P;
   P.u = u;
   P.q = q;
@@ -172,19 +178,27 @@ void ei_evaluate(GpDev& gp, const double* Xq, const double* Xp, int q, int p, in
   P.L = dBlob.p + o_L;
   P.grad_mu = dBlob.p + o_gmu;
   P.gchol = dBlob.p + o_gc;
-  P.normals = dNormals.p;
+  P.normals = dBlob.p + rec * E;
   P.partial = dPartial.p;
   P.want_grad = want_grad ? 1 : 0;
-  hipLaunchKernelGGL(ei_mc_kernel, dim3(blocks), dim3(256), 0, s, P);
-  hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, s, dPartial.p, blocks, ncomp, dOut.p);
+  P.blob_stride = (long)rec;
+  hipLaunchKernelGGL(ei_mc_kernel, dim3(blocks, E), dim3(256), 0, s, P);
+  hipLaunchKernelGGL(sum_partials_kernel, dim3(E), dim3(256), 0, s, dPartial.p, blocks, ncomp, dOut.p);
   MOE_HIP_CHECK(hipGetLastError());
-  gp.hKgOut.reserve(ncomp);
+  gp.hKgOut.reserve((size_t)E * ncomp);
   double* out = gp.hKgOut.p;
-  dOut.download(out, ncomp, s);
+  dOut.download(out, (size_t)E * ncomp, s);
   MOE_HIP_CHECK(hipStreamSynchronize(s));
-  if (ei) *ei = out[0] / (double)num_mc;
-  if (want_grad)
-    for (int c = 0; c < q * d; ++c) grad_ei[c] = out[1 + c] / (double)num_mc;
+  for (int e = 0; e < E; ++e) {
+    if (ei) ei[e] = out[(size_t)e * ncomp] / (double)num_mc;
+    if (want_grad)
+      for (int c = 0; c < q * d; ++c) grad_ei[(size_t)e * q * d + c] = out[(size_t)e * ncomp + 1 + c] / (double)num_mc;
+  }
+}
+
+void ei_evaluate(GpDev& gp, const double* Xq, const double* Xp, int q, int p, int num_mc, double best_so_far,
+                 const double* normals, double* ei, double* grad_ei) {
+  ei_evaluate_batch(gp, Xq, 1, Xp, q, p, num_mc, best_so_far, normals, ei, grad_ei);
 }
 
 }  // namespace moe

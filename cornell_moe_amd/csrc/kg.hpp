@@ -8,6 +8,11 @@ namespace moe {
 void ei_evaluate(GpDev& gp, const double* Xq, const double* Xp, int q, int p, int num_mc, double best_so_far,
                  const double* normals, double* ei, double* grad_ei);
 
+// The same for `num_evals` independent points_to_sample sets (EvaluateEIAtPointList, gpp_math.hpp:1900-1950, and the
+// multistart axis): ei[num_evals], grad_ei[num_evals][q*dim] (either may be NULL).
+void ei_evaluate_batch(GpDev& gp, const double* Xq_all, int num_evals, const double* Xp, int q, int p, int num_mc,
+                       double best_so_far, const double* normals, double* ei, double* grad_ei);
+
 // KnowledgeGradientEvaluator::Compute[Grad]KnowledgeGradient (gpp_knowledge_gradient_optimization.cpp:69-227) for
 // `num_evals` independent points_to_sample sets; see include/moe_hip.h (moe_kg / moe_kg_batch) for argument meaning.
 // best_points (may be NULL) is only filled for num_evals == 1.

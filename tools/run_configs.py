@@ -61,6 +61,9 @@ G = DeviceGP(w.hyperparameters, w.X, w.y, w.noise, ())
 best = float(np.min(w.y[:, 0])) + 0.5
 t = timeit(lambda: G.ei(w.Xq, None, w.M, best, w.ei_normals), reps=20)
 c2 = {"gpu_ei_grad_evals_per_s": 1.0 / t, "gpu_ms_per_eval": 1e3 * t}
+Xq64 = np.random.default_rng(2).uniform(0.05, 0.95, size=(64,) + w.Xq.shape)
+tb = timeit(lambda: G.ei_batch(Xq64, None, w.M, best, w.ei_normals), reps=10)
+c2["gpu_batch_64_evals_per_s"] = 64.0 / tb
 if HAVE_REF:
     R = ref.RefGP(1, w.alpha, w.lengths, w.X, w.y, w.noise, ())
     tr = timeit(lambda: R.ei(w.Xq, None, w.M, best, w.ei_normals), reps=5)
