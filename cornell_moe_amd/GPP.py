@@ -334,9 +334,35 @@ def evaluate_EI_at_point_list(gaussian_process, optimizer_parameters, domain_bou
     Xp = _being_sampled(gp, points_being_sampled, num_being_sampled)
     u = num_to_sample + max(num_being_sampled, 0)
     normals = randomness_source.normal_rng_vec[0].table(int(max_int_steps) * u)
-    out = list(gp._dev.ei_batch(guesses, Xp, int(max_int_steps), float(best_so_far), normals, want_grad=False)[0])
+    if num_to_sample == 1 and num_being_sampled <= 0:  # analytic evaluator (gpp_math.cpp:2317-2335)
+        out = list(gp._dev.ei_analytic_batch(guesses.reshape(num_multistarts, gp.dim), float(best_so_far), want_grad=False)[0])
+    else:
+        out = list(gp._dev.ei_batch(guesses, Xp, int(max_int_steps), float(best_so_far), normals, want_grad=False)[0])
     status["evaluate_EI_at_point_list"] = bool(len(out) > 0 and max(out) > 0.0)
     return out
+
+
+def multistart_expected_improvement_optimization(optimizer_parameters, gaussian_process, domain_bounds, points_being_sampled,
+                                                 num_to_sample, num_being_sampled, best_so_far, max_int_steps,
+                                                 max_num_threads, use_gpu, which_gpu, randomness_source, status):
+    """MultistartExpectedImprovementOptimizationWrapper (gpp_python_expected_improvement.cpp:221-276).  Tensor-product
+    domain; every live restart's EI gradient is evaluated in one batched device pass per step.  ``use_gpu`` / ``which_gpu``
+    are accepted for signature compatibility (this backend always runs on its GP's device)."""
+    from . import multistart
+    if max_num_threads > randomness_source.num_normal_rng:
+        raise BoundsException("Fewer randomness_sources than max_num_threads.", randomness_source.num_normal_rng,
+                              max_num_threads, 1e9)
+    if int(optimizer_parameters.domain_type) != int(DomainTypes.tensor_product):
+        raise OptimalLearningException("only the tensor-product domain is implemented on the device path")
+    if int(optimizer_parameters.optimizer_type) not in (int(OptimizerTypes.null), int(OptimizerTypes.gradient_descent)):
+        raise OptimalLearningException("ERROR: invalid optimizer choice. Setting all coordinates to 0.0.")
+    gp = gaussian_process
+    Xp = _being_sampled(gp, points_being_sampled, num_being_sampled)
+    best, found = multistart.ei_optimal_points(gp._dev, optimizer_parameters, _flat(domain_bounds, 2 * gp.dim), Xp,
+                                               int(num_to_sample), float(best_so_far), int(max_int_steps), randomness_source)
+    kind = "gradient_descent" if int(optimizer_parameters.optimizer_type) == int(OptimizerTypes.gradient_descent) else "lhc"
+    status["%s_tensor_product_domain_found_update" % kind] = bool(found)
+    return list(np.asarray(best).ravel())
 
 
 # ---- q-KG / d-KG (gpp_python_knowledge_gradient.cpp:74-154) ----

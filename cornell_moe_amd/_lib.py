@@ -52,6 +52,9 @@ SIGNATURES = {
     "moe_normal_draws": (C.c_int, [C.c_uint, C.c_longlong, dp]),
     "moe_ei": (C.c_int, [_GP, dp, dp, C.c_int, C.c_int, C.c_int, C.c_double, dp, dp, dp, _EP]),
     "moe_ei_batch": (C.c_int, [_GP, dp, C.c_int, dp, C.c_int, C.c_int, C.c_int, C.c_double, dp, dp, dp, _EP]),
+    "moe_ei_analytic_batch": (C.c_int, [_GP, dp, C.c_int, C.c_double, dp, dp, _EP]),
+    "moe_ei_multistart": (C.c_int, [_GP, C.POINTER(GdParams), dp, dp, C.c_int, dp, C.c_int, C.c_int, C.c_int, C.c_double, dp,
+                                    C.c_int, dp, dp, ip, _EP]),
     "moe_kg": (C.c_int, [_GP, C.c_int, C.POINTER(GdParams), dp, dp, C.c_int, dp, dp, C.c_int, C.c_int, C.c_int, C.c_double,
                          dp, C.c_int, C.c_int, C.c_int, dp, dp, dp, C.POINTER(KgStats), _EP]),
     "moe_kg_batch": (C.c_int, [_GP, C.c_int, C.POINTER(GdParams), dp, dp, C.c_int, dp, C.c_int, dp, C.c_int, C.c_int,

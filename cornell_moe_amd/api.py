@@ -258,6 +258,43 @@ class DeviceGP(object):
                err)
         return ei, (grad.reshape(E, q, self.d) if want_grad else None)
 
+    def ei_analytic_batch(self, points, best_so_far, want_grad=True):
+        """moe_ei_analytic_batch: points [E][dim] -> (ei [E], grad [E][dim] or None)."""
+        points = np.ascontiguousarray(points, dtype=np.float64).reshape(-1, self.d)
+        E = points.shape[0]
+        ei = np.zeros(E)
+        grad = np.zeros((E, self.d))
+        err = _lib.MoeError()
+        _check(_lib.load().moe_ei_analytic_batch(self._h, points.ctypes.data_as(dp), E, float(best_so_far),
+                                                 ei.ctypes.data_as(dp), grad.ctypes.data_as(dp) if want_grad else None,
+                                                 C.byref(err)), err)
+        return ei, (grad if want_grad else None)
+
+    def ei_multistart(self, outer_params, bounds, starts, Xp, num_mc, best_so_far, normals, gradient_ascent=True):
+        """moe_ei_multistart: starts [S][q][dim] -> (best_points [q][dim], best_ei, found)."""
+        go = self._gd(outer_params)
+        bounds, bp = _d(bounds)
+        starts = np.ascontiguousarray(starts, dtype=np.float64)
+        S, q, _ = starts.shape
+        if Xp is None or np.size(Xp) == 0:
+            p, ppp = 0, None
+        else:
+            Xp, ppp = _d(Xp)
+            p = Xp.reshape(-1, self.d).shape[0]
+        npn = None
+        if normals is not None:
+            normals, npn = _d(normals)
+            if normals.size < num_mc * (q + p):
+                raise InvalidValueException("normal table too small", normals.size, num_mc * (q + p), 0)
+        best = np.zeros(q * self.d)
+        best_ei = C.c_double(0.0)
+        found = C.c_int(0)
+        err = _lib.MoeError()
+        _check(_lib.load().moe_ei_multistart(self._h, C.byref(go), bp, starts.ctypes.data_as(dp), S, ppp, q, p, int(num_mc),
+                                             float(best_so_far), npn, 1 if gradient_ascent else 0, best.ctypes.data_as(dp),
+                                             C.byref(best_ei), C.byref(found), C.byref(err)), err)
+        return best.reshape(q, self.d), best_ei.value, bool(found.value)
+
     @staticmethod
     def _gd(params):
         if isinstance(params, _lib.GdParams):

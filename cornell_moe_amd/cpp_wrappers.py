@@ -254,6 +254,20 @@ def _default_randomness(randomness, num_threads=1):
     return r
 
 
+def multistart_expected_improvement_optimization(ei_optimizer, num_multistarts, num_to_sample, use_gpu=False, which_gpu=0,
+                                                 randomness=None, max_num_threads=DEFAULT_MAX_NUM_THREADS, status=None):
+    """cpp_wrappers/expected_improvement.py:22-105 (num_multistarts is unused there too: the count lives in
+    ei_optimizer.optimizer_parameters)."""
+    randomness = _default_randomness(randomness, max_num_threads)
+    status = {} if status is None else status
+    ei = ei_optimizer.objective_function
+    best = C_GP.multistart_expected_improvement_optimization(
+        ei_optimizer.optimizer_parameters, ei._gaussian_process._gaussian_process,
+        [float(x) for x in cppify(ei_optimizer.domain.domain_bounds)], cppify(ei._points_being_sampled), num_to_sample,
+        ei.num_being_sampled, ei._best_so_far, ei._num_mc_iterations, max_num_threads, use_gpu, which_gpu, randomness, status)
+    return uncppify(best, (num_to_sample, ei.dim))
+
+
 class ExpectedImprovement(object):
     """cpp_wrappers/expected_improvement.py:109-367 (q,p-EI by Monte Carlo)."""
 

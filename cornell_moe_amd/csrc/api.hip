@@ -336,6 +336,27 @@ int moe_ei_batch(const moe_gp_t* gp_c, const double* points_to_sample_all, int n
   });
 }
 
+int moe_ei_analytic_batch(const moe_gp_t* gp_c, const double* points, int num_evals, double best_so_far, double* ei,
+                          double* grad_ei, moe_error_t* err) {
+  return guarded(err, [&] {
+    moe::GpDev& gp = const_cast<moe_gp_t*>(gp_c)->dev;
+    require(points != nullptr, "NULL argument");
+    moe::ei_analytic_batch(gp, points, num_evals, best_so_far, ei, grad_ei);
+  });
+}
+
+int moe_ei_multistart(const moe_gp_t* gp_c, const moe_gd_params_t* outer_params, const double* domain_bounds,
+                      const double* start_points, int num_starts, const double* points_being_sampled, int num_to_sample,
+                      int num_being_sampled, int num_mc, double best_so_far, const double* normals, int do_gradient_ascent,
+                      double* best_points, double* best_ei, int* found, moe_error_t* err) {
+  return guarded(err, [&] {
+    moe::GpDev& gp = const_cast<moe_gp_t*>(gp_c)->dev;
+    require(outer_params && domain_bounds && start_points && best_points && best_ei && found, "NULL argument");
+    moe::ei_multistart(gp, *outer_params, domain_bounds, start_points, num_starts, points_being_sampled, num_to_sample,
+                       num_being_sampled, num_mc, best_so_far, normals, do_gradient_ascent, best_points, best_ei, found);
+  });
+}
+
 int moe_kg_batch(const moe_gp_t* gp_c, int num_fidelity, const moe_gd_params_t* inner_params, const double* domain_bounds,
                  const double* discrete_pts, int num_pts, const double* points_to_sample_all, int num_evals,
                  const double* points_being_sampled, int num_to_sample, int num_being_sampled, int num_mc,

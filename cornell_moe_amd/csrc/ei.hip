@@ -201,4 +201,48 @@ void ei_evaluate(GpDev& gp, const double* Xq, const double* Xp, int q, int p, in
   ei_evaluate_batch(gp, Xq, 1, Xp, q, p, num_mc, best_so_far, normals, ei, grad_ei);
 }
 
+// OnePotentialSampleExpectedImprovementEvaluator (gpp_math.cpp:2195-2259) for `num_evals` single points: the posterior at
+// one point is a scalar Gaussian, so EI = (best - mu) Phi(c) + sigma phi(c), c = (best - mu) / sigma.  The N-sized work
+// (K*, K^-1 K*, grad K*) for ALL points runs in one batched device pass; what is left per point is scalar.
+void ei_analytic_batch(GpDev& gp, const double* pts, int num_evals, double best_so_far, double* ei, double* grad_ei) {
+  gp.use_device();
+  const int d = gp.d, E = num_evals;
+  if (E <= 0) throw Error(MOE_ERR_BOUNDS, "num_evals must be positive", E, 1, 1e9);
+  const bool want_grad = grad_ei != nullptr;
+  DerivList none;
+  none.g = 0;
+  for (int i = 0; i < kMaxDerivs; ++i) none.idx[i] = 0;
+  std::vector<StateHost> hosts;
+  compute_state_batch(gp, pts, 1, none, want_grad ? 1 : 0, nullptr, 0, false, E, nullptr, &hosts);
+  constexpr double kMinVarEI = 2.2250738585072014e-308;                                    // gpp_math.hpp:1316
+  constexpr double kMinVarGradEI = 150.0 * 2.220446049250313e-16 * 2.220446049250313e-16;  // gpp_math.hpp:1323
+  auto pdf = [](double z) { return std::exp(-0.5 * z * z) / 2.5066282746310002; };
+  auto cdf = [](double z) { return 0.5 * std::erfc(-z * 0.70710678118654752440); };
+  std::vector<double> gmu(d), gchol(d);
+  for (int e = 0; e < E; ++e) {
+    const StateHost& sh = hosts[e];
+    double mu, var;
+    host_mean(sh, &mu);
+    host_variance(sh, &var);
+    const double t = best_so_far - mu;
+    if (ei) {
+      const double sigma = std::sqrt(std::fmax(kMinVarEI, var));
+      ei[e] = std::fmax(0.0, t * cdf(t / sigma) + sigma * pdf(t / sigma));
+    }
+    if (want_grad) {
+      const double v = std::fmax(kMinVarGradEI, var);
+      double sigma = std::sqrt(v);
+      host_grad_mean(sh, gmu.data());
+      host_grad_cholesky_per_point(sh, 0, &sigma, gchol.data());
+      const double c = t / sigma, pdf_c = pdf(c), cdf_c = cdf(c);
+      for (int i = 0; i < d; ++i) {
+        const double d_c = (-sigma * gmu[i] - gchol[i] * t) / v;
+        const double d_a = -gmu[i] * cdf_c + t * pdf_c * d_c;
+        const double d_b = gchol[i] * pdf_c + sigma * (-c) * pdf_c * d_c;
+        grad_ei[(size_t)e * d + i] = d_a + d_b;
+      }
+    }
+  }
+}
+
 }  // namespace moe

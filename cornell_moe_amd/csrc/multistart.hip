@@ -11,6 +11,7 @@
 // each evaluation), so the ascent sees common random numbers.
 #include <algorithm>
 #include <cmath>
+#include <functional>
 #include <numeric>
 #include <random>
 
@@ -66,15 +67,22 @@ void kg_values(GpDev& gp, int num_fidelity, const moe_gd_params_t& inner, const 
   for (int e = 0; e < num_evals; ++e) values[e] = sums[e] / (double)num_mc;
 }
 
-// GradientDescentOptimizer::Optimize for every start at once; x [S][q][d] in place.
-void kg_gradient_ascent(GpDev& gp, int num_fidelity, const moe_gd_params_t& outer, const moe_gd_params_t& inner,
-                        const double* bounds, const double* discrete, int P, double* x, int S, const double* Xp, int q, int p,
-                        int num_mc, double best_so_far, const double* normals) {
-  const int d = gp.d, qd = q * d;
+namespace {
+
+// A maximisation objective evaluated at a BATCH of points [n][qd]: values [n], grads [n][qd].
+struct BatchObjective {
+  std::function<void(const double* x_all, int n, double* values)> values;
+  std::function<void(const double* x_all, int n, double* grads)> grads;
+};
+
+// GradientDescentOptimizer::Optimize (gpp_optimization.hpp:619-705, 1144-1185) for every start at once; x [S][qd] in place.
+// bounds are per coordinate of ONE point (RepeatedDomain applies them to each of the q points, gpp_domain.hpp:509-520).
+void gradient_ascent(const BatchObjective& f, const moe_gd_params_t& outer, const double* bounds, int d, int qd, double* x,
+                     int S) {
   if (outer.max_num_restarts <= 0 || S <= 0) return;
   const double step_tol = outer.tolerance / (double)outer.max_num_steps;
   std::vector<char> alive(S, 1), running(S);
-  std::vector<double> x_begin((size_t)S * qd), xs((size_t)S * qd), ksum(S), gsum((size_t)S * qd);
+  std::vector<double> x_begin((size_t)S * qd), xs((size_t)S * qd), grad((size_t)S * qd), step(qd);
   std::vector<int> idx;
   for (int r = 0; r < outer.max_num_restarts; ++r) {
     if (std::none_of(alive.begin(), alive.end(), [](char c) { return c != 0; })) break;
@@ -87,42 +95,37 @@ void kg_gradient_ascent(GpDev& gp, int num_fidelity, const moe_gd_params_t& oute
       if (idx.empty()) break;
       const double alpha = outer.pre_mult * std::pow((double)(i + 1), -outer.gamma);
       for (size_t k = 0; k < idx.size(); ++k) std::copy(x + (size_t)idx[k] * qd, x + (size_t)(idx[k] + 1) * qd, &xs[k * qd]);
-      kg_evaluate_batch(gp, num_fidelity, inner, bounds, discrete, P, xs.data(), (int)idx.size(), Xp, q, p, num_mc, best_so_far,
-                        normals, 0, num_mc, true, ksum.data(), gsum.data(), nullptr, nullptr);
+      f.grads(xs.data(), (int)idx.size(), grad.data());
       for (size_t k = 0; k < idx.size(); ++k) {
         double* xk = x + (size_t)idx[k] * qd;
-        double step[1024];
         for (int j = 0; j < qd; ++j) {
           const int dd = j % d;
-          const double want = alpha * gsum[k * qd + j] / (double)num_mc;
-          step[j] = limit_update_1d(bounds[2 * dd], bounds[2 * dd + 1], outer.max_relative_change, xk[j], want);
+          step[j] = limit_update_1d(bounds[2 * dd], bounds[2 * dd + 1], outer.max_relative_change, xk[j], alpha * grad[k * qd + j]);
           xk[j] += step[j];
         }
-        if (norm2(step, qd) < step_tol) running[idx[k]] = 0;
+        if (norm2(step.data(), qd) < step_tol) running[idx[k]] = 0;
       }
     }
     for (int s = 0; s < S; ++s) {
       if (!alive[s]) continue;
-      double delta[1024];
-      for (int j = 0; j < qd; ++j) delta[j] = x_begin[(size_t)s * qd + j] - x[(size_t)s * qd + j];
-      if (!(norm2(delta, qd) > outer.tolerance)) alive[s] = 0;
+      for (int j = 0; j < qd; ++j) step[j] = x_begin[(size_t)s * qd + j] - x[(size_t)s * qd + j];
+      if (!(norm2(step.data(), qd) > outer.tolerance)) alive[s] = 0;
     }
   }
 }
 
-void kg_multistart(GpDev& gp, int num_fidelity, const moe_gd_params_t& outer, const moe_gd_params_t& inner, const double* bounds,
-                   const double* discrete, int P, const double* starts, int num_starts, const double* Xp, int q, int p,
-                   int num_mc, double best_so_far, const double* normals, int do_gradient_ascent, double* best_points,
-                   double* best_kg, int* found) {
-  const int d = gp.d, qd = q * d;
-  if (num_starts <= 0) throw Error(MOE_ERR_BOUNDS, "num_multistarts must be > 1", num_starts, 1, 1e9);  // hpp:881-883
-  if (qd > 1024) throw Error(MOE_ERR_BOUNDS, "num_to_sample * dim > 1024", qd, 1, 1024);
+// Value at every start, the best 20 kept, restarted ascent on each, value at every end point, best one returned if it
+// beats `floor_value` (MultistartOptimizer, gpp_optimization.hpp:1472-1546; the reference seeds its IO container with
+// -inf for KG, gpp_knowledge_gradient_optimization.hpp:924, and -1.0 for EI, gpp_math.hpp:1728).
+void multistart(const BatchObjective& f, const moe_gd_params_t& outer, const double* bounds, int d, int qd, const double* starts,
+                int num_starts, int do_gradient_ascent, double floor_value, double* best_points, double* best_value,
+                int* found) {
+  if (num_starts <= 0) throw Error(MOE_ERR_BOUNDS, "num_multistarts must be > 1", num_starts, 1, 1e9);
   *found = 0;
-  *best_kg = -INFINITY;
+  *best_value = floor_value;
   std::vector<double> vals(num_starts);
-  kg_values(gp, num_fidelity, inner, bounds, discrete, P, starts, num_starts, Xp, q, p, num_mc, best_so_far, normals, vals.data());
-  std::vector<double> ends;
-  std::vector<double> end_vals;
+  f.values(starts, num_starts, vals.data());
+  std::vector<double> ends, end_vals;
   int S = num_starts;
   if (do_gradient_ascent) {
     std::vector<int> order(num_starts);
@@ -131,21 +134,60 @@ void kg_multistart(GpDev& gp, int num_fidelity, const moe_gd_params_t& outer, co
     S = std::min(num_starts, kTopK);
     ends.resize((size_t)S * qd);
     for (int s = 0; s < S; ++s) std::copy(starts + (size_t)order[s] * qd, starts + (size_t)(order[s] + 1) * qd, &ends[(size_t)s * qd]);
-    kg_gradient_ascent(gp, num_fidelity, outer, inner, bounds, discrete, P, ends.data(), S, Xp, q, p, num_mc, best_so_far, normals);
+    gradient_ascent(f, outer, bounds, d, qd, ends.data(), S);
     end_vals.resize(S);
-    kg_values(gp, num_fidelity, inner, bounds, discrete, P, ends.data(), S, Xp, q, p, num_mc, best_so_far, normals,
-              end_vals.data());
+    f.values(ends.data(), S, end_vals.data());
   } else {
     ends.assign(starts, starts + (size_t)num_starts * qd);
     end_vals = vals;
   }
   for (int s = 0; s < S; ++s) {
-    if (end_vals[s] > *best_kg) {  // strict, like MultistartOptimizer's compare (gpp_optimization.hpp:1512)
-      *best_kg = end_vals[s];
+    if (end_vals[s] > *best_value) {  // strict, like MultistartOptimizer's compare (gpp_optimization.hpp:1512)
+      *best_value = end_vals[s];
       std::copy(&ends[(size_t)s * qd], &ends[(size_t)(s + 1) * qd], best_points);
       *found = 1;
     }
   }
+}
+
+}  // namespace
+
+void kg_multistart(GpDev& gp, int num_fidelity, const moe_gd_params_t& outer, const moe_gd_params_t& inner, const double* bounds,
+                   const double* discrete, int P, const double* starts, int num_starts, const double* Xp, int q, int p,
+                   int num_mc, double best_so_far, const double* normals, int do_gradient_ascent, double* best_points,
+                   double* best_kg, int* found) {
+  const int d = gp.d, qd = q * d;
+  BatchObjective f;
+  f.values = [&](const double* x_all, int n, double* values) {
+    kg_values(gp, num_fidelity, inner, bounds, discrete, P, x_all, n, Xp, q, p, num_mc, best_so_far, normals, values);
+  };
+  f.grads = [&](const double* x_all, int n, double* grads) {
+    std::vector<double> ksum(n);
+    kg_evaluate_batch(gp, num_fidelity, inner, bounds, discrete, P, x_all, n, Xp, q, p, num_mc, best_so_far, normals, 0, num_mc,
+                      true, ksum.data(), grads, nullptr, nullptr);
+    for (size_t j = 0; j < (size_t)n * qd; ++j) grads[j] /= (double)num_mc;
+  };
+  multistart(f, outer, bounds, d, qd, starts, num_starts, do_gradient_ascent, -INFINITY, best_points, best_kg, found);
+}
+
+void ei_multistart(GpDev& gp, const moe_gd_params_t& outer, const double* bounds, const double* starts, int num_starts,
+                   const double* Xp, int q, int p, int num_mc, double best_so_far, const double* normals,
+                   int do_gradient_ascent, double* best_points, double* best_ei, int* found) {
+  const int d = gp.d, qd = q * d;
+  BatchObjective f;
+  if (q == 1 && p == 0) {  // special analytic case (gpp_math.hpp:1703, gpp_math.cpp:2317)
+    f.values = [&](const double* x_all, int n, double* values) { ei_analytic_batch(gp, x_all, n, best_so_far, values, nullptr); };
+    f.grads = [&](const double* x_all, int n, double* grads) { ei_analytic_batch(gp, x_all, n, best_so_far, nullptr, grads); };
+  } else {
+    if (normals == nullptr) throw Error(MOE_ERR_RUNTIME, "q,p-EI by Monte Carlo needs a normal table");
+    f.values = [&](const double* x_all, int n, double* values) {
+      ei_evaluate_batch(gp, x_all, n, Xp, q, p, num_mc, best_so_far, normals, values, nullptr);
+    };
+    f.grads = [&](const double* x_all, int n, double* grads) {
+      ei_evaluate_batch(gp, x_all, n, Xp, q, p, num_mc, best_so_far, normals, nullptr, grads);
+    };
+  }
+  multistart(f, outer, bounds, d, qd, starts, num_starts, do_gradient_ascent, -1.0, best_points, best_ei, found);
 }
 
 // ComputeOptimalPosteriorMean from ONE start (gpp_knowledge_gradient_optimization.cpp:420-472): back-tracking line-search

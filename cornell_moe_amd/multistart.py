@@ -70,10 +70,11 @@ def kg_values(dev_gp, num_fidelity, inner_gd, inner_bounds, discrete, Xq_all, Xp
     return r["kg_sum"] / num_mc
 
 
-def kg_gradient_ascent(dev_gp, num_fidelity, gd, inner_gd, bounds, inner_bounds, discrete, starts, Xp, num_mc, best_so_far,
-                       normals, on_step=None):
-    """GradientDescentOptimizer::Optimize for every start at once.  starts [S][q][dim] -> end points [S][q][dim]."""
+def gradient_ascent(grad_fn, gd, bounds, starts, on_step=None):
+    """GradientDescentOptimizer::Optimize (gpp_optimization.hpp:619-705, 1144-1185) for every start at once.
+    grad_fn(x [k][q][dim]) -> gradient [k][q][dim] of the objective being MAXIMISED.  starts [S][q][dim] -> end points."""
     _, max_steps, max_restarts, _, gamma, pre_mult, max_rel, tol = gd
+    max_steps, max_restarts = int(max_steps), int(max_restarts)
     x = np.array(starts, dtype=np.float64, copy=True)
     S = x.shape[0]
     if max_restarts <= 0:
@@ -90,18 +91,45 @@ def kg_gradient_ascent(dev_gp, num_fidelity, gd, inner_gd, bounds, inner_bounds,
             if idx.size == 0:
                 break
             alpha = pre_mult * float(i + 1) ** (-gamma)
-            r = dev_gp.kg_batch(inner_gd, inner_bounds, discrete, x[idx], Xp, num_mc, best_so_far, normals, want_grad=True,
-                                num_fidelity=num_fidelity)
-            grad = r["grad_sum"] / num_mc
+            grad = grad_fn(x[idx])
             step = limit_update(bounds, max_rel, x[idx], alpha * grad)
             x[idx] += step
             norm = np.sqrt((step.reshape(idx.size, -1) ** 2).sum(axis=1))
             running[idx[norm < step_tol]] = False
             if on_step is not None:
-                on_step(i, idx, r)
+                on_step(i, idx)
         delta = np.sqrt(((x_begin - x).reshape(S, -1) ** 2).sum(axis=1))
         alive &= delta > tol
     return x
+
+
+def multistart_best(value_fn, grad_fn, gd, bounds, starts, floor_value=-np.inf, do_gradient_ascent=True):
+    """Value at every start, the best TOP_K kept, restarted ascent on each, best end point by value (strict compare against
+    floor_value): MultistartOptimizer (gpp_optimization.hpp:1472-1546) as driven by gpp_math.hpp:1683-1800 /
+    gpp_knowledge_gradient_optimization.hpp:860-935.  Returns (best_point, best_value, found)."""
+    starts = np.asarray(starts, dtype=np.float64)
+    vals = np.asarray(value_fn(starts))
+    if do_gradient_ascent:
+        order = np.argsort(-vals, kind="stable")[:TOP_K]
+        ends = gradient_ascent(grad_fn, gd, bounds, starts[order])
+        end_vals = np.asarray(value_fn(ends))
+    else:
+        ends, end_vals = starts, vals
+    best, best_val, found = np.zeros_like(starts[0]), floor_value, False
+    for s in range(ends.shape[0]):
+        if end_vals[s] > best_val:
+            best, best_val, found = ends[s].copy(), float(end_vals[s]), True
+    return best, best_val, found
+
+
+def kg_gradient_ascent(dev_gp, num_fidelity, gd, inner_gd, bounds, inner_bounds, discrete, starts, Xp, num_mc, best_so_far,
+                       normals, on_step=None):
+    """gradient_ascent on q-KG: every live restart's gradient comes from ONE moe_kg_batch call per step."""
+    def grad_fn(x):
+        r = dev_gp.kg_batch(inner_gd, inner_bounds, discrete, x, Xp, num_mc, best_so_far, normals, want_grad=True,
+                            num_fidelity=num_fidelity)
+        return r["grad_sum"] / num_mc
+    return gradient_ascent(grad_fn, gd, bounds, starts, on_step)
 
 
 def kg_optimal_points(dev_gp, num_fidelity, optimizer_parameters, optimizer_parameters_inner, bounds, discrete, Xp,
@@ -139,6 +167,37 @@ def kg_optimal_points(dev_gp, num_fidelity, optimizer_parameters, optimizer_para
             best, _, found = dev_gp.kg_multistart(_gd(optimizer_parameters_inner), inner_gd, bounds, discrete, lhc(n_lhc), Xp,
                                                   num_mc, best_so_far, normals, gradient_ascent=False,
                                                   num_fidelity=num_fidelity)
+    return best, found
+
+
+def ei_optimal_points(dev_gp, optimizer_parameters, bounds, Xp, num_to_sample, best_so_far, num_mc, randomness):
+    """ComputeOptimalPointsToSample (gpp_math.cpp:2369-2425): multistart gradient ascent on q,p-EI from Latin-hypercube
+    starts (ComputeOptimalPointsToSampleWithRandomStarts, gpp_math.hpp:1836-1866), Latin-hypercube value search as the
+    fall-back / null-optimiser path (gpp_python_expected_improvement.cpp:148-206).  Returns (best_points [q][dim], found)."""
+    from . import GPP, api
+    d = dev_gp.d
+    q = int(num_to_sample)
+    bounds = np.asarray(bounds, dtype=np.float64).reshape(-1)[:2 * d]
+    p = 0 if Xp is None else np.asarray(Xp).reshape(-1, d).shape[0]
+    normals = None if (q == 1 and p == 0) else randomness.normal_rng_vec[0].table(int(num_mc) * (q + p))
+
+    def lhc(count):
+        out = np.empty((count, q, d))
+        for r in range(q):
+            out[:, r, :] = api.latin_hypercube(randomness._next_uniform_seed(), bounds, count)
+        return out
+
+    use_gd = int(optimizer_parameters.optimizer_type) == int(GPP.OptimizerTypes.gradient_descent)
+    best, found = np.zeros((q, d)), False
+    if use_gd:
+        gd = _gd(optimizer_parameters)
+        best, _, found = dev_gp.ei_multistart(gd, bounds, lhc(gd[0]), Xp, num_mc, best_so_far, normals, gradient_ascent=True)
+    if not found:
+        n_lhc = int(optimizer_parameters.num_random_samples or 0)
+        if n_lhc > 0:
+            null_gd = (1, 1, 0, 0, 1.0, 1.0, 1.0, 0.0)
+            best, _, found = dev_gp.ei_multistart(null_gd, bounds, lhc(n_lhc), Xp, num_mc, best_so_far, normals,
+                                                  gradient_ascent=False)
     return best, found
 
 

@@ -130,6 +130,25 @@ int moe_ei_batch(const moe_gp_t* gp, const double* points_to_sample_all, int num
                  int num_to_sample, int num_being_sampled, int num_mc, double best_so_far, const double* normals,
                  double* ei, double* grad_ei, moe_error_t* err);
 
+/* Analytic 1,0-EI and its gradient at `num_evals` single points (points[num_evals][dim]) --
+ * OnePotentialSampleExpectedImprovementEvaluator::Compute[Grad]ExpectedImprovement (gpp_math.cpp:2195-2259), the evaluator
+ * the reference's multistart / point-list drivers take when num_to_sample == 1 and num_being_sampled == 0
+ * (gpp_math.hpp:1703, gpp_math.cpp:2317).  ei[num_evals] and/or grad_ei[num_evals][dim] may be NULL. */
+int moe_ei_analytic_batch(const moe_gp_t* gp, const double* points, int num_evals, double best_so_far, double* ei,
+                          double* grad_ei, moe_error_t* err);
+
+/* q,p-EI optimisation from caller-supplied starts (start_points[num_starts][q][dim]) --
+ * ComputeOptimalPointsToSampleViaMultistartGradientDescent (gpp_math.hpp:1683-1800: EI at every start, best 20 kept,
+ * restarted gradient ascent on each, best end point returned) when do_gradient_ascent != 0, EvaluateEIAtPointList
+ * (gpp_math.cpp:2305-2356: best start by value) otherwise; behind multistart_expected_improvement_optimization
+ * (gpp_python_expected_improvement.cpp:221-276).  q == 1 && p == 0 uses the analytic evaluator (normals may be NULL);
+ * otherwise normals[num_mc][q+p] is replayed by every evaluation.  Tensor-product domain: domain_bounds[2*dim] applies to
+ * each of the q points.  *found = 1 when some end point beats -1.0, the reference's starting best (gpp_math.hpp:1728). */
+int moe_ei_multistart(const moe_gp_t* gp, const moe_gd_params_t* outer_params, const double* domain_bounds,
+                      const double* start_points, int num_starts, const double* points_being_sampled, int num_to_sample,
+                      int num_being_sampled, int num_mc, double best_so_far, const double* normals, int do_gradient_ascent,
+                      double* best_points, double* best_ei, int* found, moe_error_t* err);
+
 /* ---- q-KG / d-KG by Monte Carlo: compute_knowledge_gradient / compute_grad_knowledge_gradient
  * (gpp_python_knowledge_gradient.cpp:74-154 -> KnowledgeGradientEvaluator<TensorProductDomain>,
  * gpp_knowledge_gradient_optimization.cpp:69-227, state :246-317, inner optimisation :420-472,

@@ -739,6 +739,58 @@ int orc_ei(const orc_gp* gp, const double* Xq, const double* Xp, int q, int p, i
 }
 
 /* ------------------------------------------------------------------------------------------------------------------
+ * analytic 1,0-EI (OnePotentialSampleExpectedImprovementEvaluator, gpp_math.cpp:2195-2259): the posterior at one point is a
+ * scalar Gaussian, EI = (best - mu) Phi(c) + sigma phi(c), c = (best - mu) / sigma.  Phi via erfc, like the shimmed
+ * boost::math::cdf the reference build under oracle/_ref uses.
+ * ---------------------------------------------------------------------------------------------------------------- */
+static double std_normal_pdf(double z) { return exp(-0.5 * z * z) / 2.5066282746310002; }
+static double std_normal_cdf(double z) { return 0.5 * erfc(-z * 0.70710678118654752440); }
+
+int orc_ei_analytic(const orc_gp* gp, const double* pt, double best_so_far, double* ei_out, double* grad) {
+  const int dim = gp->dim;
+  const double kMinVarEI = 2.2250738585072014e-308;                                   /* gpp_math.hpp:1316 */
+  const double kMinVarGradEI = 150.0 * 2.220446049250313e-16 * 2.220446049250313e-16; /* gpp_math.hpp:1323 */
+  if (ei_out) { /* state without gradients (:2271-2281) */
+    pts_state s;
+    double mu, var;
+    pts_state_fill(gp, &s, pt, 1, NULL, 0, 0, 0, 0);
+    mean_of_points(gp, &s, &mu);
+    variance_of_points(gp, &s, NULL, 0, &var);
+    const double sigma = sqrt(fmax(kMinVarEI, var));
+    const double t = best_so_far - mu;
+    const double ei = t * std_normal_cdf(t / sigma) + sigma * std_normal_pdf(t / sigma);
+    *ei_out = fmax(0.0, ei);
+    pts_state_free(&s);
+  }
+  if (grad) {
+    pts_state s;
+    double mu, var;
+    double* grad_mu = dalloc(dim);
+    double* gchol = dalloc(dim);
+    pts_state_fill(gp, &s, pt, 1, NULL, 0, 1, 1, 0);
+    mean_of_points(gp, &s, &mu);
+    grad_mean_of_points(gp, &s, grad_mu);
+    variance_of_points(gp, &s, NULL, 0, &var);
+    var = fmax(kMinVarGradEI, var);
+    double sigma = sqrt(var);
+    grad_cholesky_per_point(gp, &s, 0, &sigma, gchol);
+    const double mu_diff = best_so_far - mu;
+    const double c = mu_diff / sigma;
+    const double pdf_c = std_normal_pdf(c), cdf_c = std_normal_cdf(c);
+    for (int i = 0; i < dim; ++i) {
+      const double d_c = (-sigma * grad_mu[i] - gchol[i] * mu_diff) / var;
+      const double d_a = -grad_mu[i] * cdf_c + mu_diff * pdf_c * d_c;
+      const double d_b = gchol[i] * pdf_c + sigma * (-c) * pdf_c * d_c;
+      grad[i] = d_a + d_b;
+    }
+    free(grad_mu);
+    free(gchol);
+    pts_state_free(&s);
+  }
+  return 0;
+}
+
+/* ------------------------------------------------------------------------------------------------------------------
  * q-KG / d-KG by Monte Carlo (gpp_knowledge_gradient_optimization.cpp)
  * ---------------------------------------------------------------------------------------------------------------- */
 

@@ -72,6 +72,9 @@ int orc_gp_grad_chol_var(const orc_gp* gp, const double* pts, int k, int nd, dou
 int orc_ei(const orc_gp* gp, const double* Xq, const double* Xp, int q, int p, int M, double best_so_far,
            const double* normals, double* ei, double* grad);
 
+/* analytic 1,0-EI and its gradient [dim] (gpp_math.cpp:2195-2259); either output may be NULL. */
+int orc_ei_analytic(const orc_gp* gp, const double* pt, double best_so_far, double* ei, double* grad);
+
 /* gpp_knowledge_gradient_optimization.cpp:69-227 (+ :420-472, gpp_optimization.hpp:708-828, 1242-1283, gpp_domain.cpp:64-105).
  * gd[8] = {num_multistarts, max_num_steps, max_num_restarts, num_steps_averaged, gamma, pre_mult, max_relative_change,
  * tolerance}; bounds[2*(d-f)]; discrete[P][d-f]; normals[ceil(M/2)][m] (antithetic pairs); grad / best_point may be NULL.

@@ -54,6 +54,7 @@ def lib():
         L.orc_chol_solve.argtypes = [_dp, C.c_int, _dp]
         L.orc_tri_solve.argtypes = [_dp, C.c_char, C.c_int, C.c_int, _dp]
         L.orc_ei.argtypes = [C.c_void_p, _dp, _dp, C.c_int, C.c_int, C.c_int, C.c_double, _dp, _dp, _dp]
+        L.orc_ei_analytic.argtypes = [C.c_void_p, _dp, C.c_double, _dp, _dp]
         L.orc_kg.argtypes = [C.c_void_p, C.c_int, _dp, _dp, _dp, C.c_int, _dp, _dp, C.c_int, C.c_int, C.c_int, C.c_double,
                              _dp, C.c_int, _dp, _dp, _dp, _lp]
         _lib = L
@@ -217,6 +218,13 @@ class OrcGP(object):
         if rc:
             raise SingularMatrix("variance singular at minor %d" % rc)
         return ei.value, (grad.reshape(q, self.d) if want_grad else None)
+
+    def ei_analytic(self, pt, best_so_far, want_grad=True):
+        pt, pp = _d(pt)
+        ei = C.c_double(0.0)
+        grad = np.zeros(self.d)
+        lib().orc_ei_analytic(self.h, pp, best_so_far, C.byref(ei), grad.ctypes.data_as(_dp) if want_grad else None)
+        return ei.value, (grad if want_grad else None)
 
     def kg(self, gd, bounds, discrete, Xq, Xp, M, best_so_far, normals, want_grad=True, num_fidelity=0):
         gd, gdp = _d(gd)

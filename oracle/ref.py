@@ -49,6 +49,8 @@ def lib():
         _lib.ref_chol_solve.argtypes = [_dp, C.c_int, _dp]
         _lib.ref_tri_solve.argtypes = [_dp, C.c_char, C.c_int, _dp]
         _lib.ref_ei.argtypes = [C.c_void_p, _dp, _dp, C.c_int, C.c_int, C.c_int, C.c_double, _dp, _dp, _dp, _dp]
+        _lib.ref_ei_analytic.argtypes = [C.c_void_p, _dp, C.c_double, _dp, _dp]
+        _lib.ref_ei_multistart_analytic.argtypes = [C.c_void_p, _dp, _dp, _dp, C.c_int, C.c_double, C.POINTER(C.c_int), _dp]
         _lib.ref_kg.argtypes = [C.c_void_p, C.c_int, _dp, _dp, _dp, C.c_int, _dp, _dp, C.c_int, C.c_int, C.c_int,
                                 C.c_double, _dp, C.c_long, C.c_int, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp]
         _lib.ref_kg_grad_batch.argtypes = [C.c_void_p, C.c_int, _dp, _dp, _dp, C.c_int, _dp, C.c_int, C.c_int, C.c_int,
@@ -210,6 +212,27 @@ class RefGP(object):
         _check(lib().ref_ei(self.h, qp, pp, q, p, M, best_so_far, npp, C.byref(ei),
                             grad.ctypes.data_as(_dp) if want_grad else None, C.byref(sec)))
         return ei.value, (grad.reshape(q, self.d) if want_grad else None), sec.value
+
+    def ei_analytic(self, pt, best_so_far):
+        """OnePotentialSampleExpectedImprovementEvaluator: (EI, grad [d])."""
+        pt, pp = _d(pt)
+        ei = C.c_double(0.0)
+        grad = np.zeros(self.d)
+        _check(lib().ref_ei_analytic(self.h, pp, best_so_far, C.byref(ei), grad.ctypes.data_as(_dp)))
+        return ei.value, grad
+
+    def ei_multistart_analytic(self, gd, bounds, starts, best_so_far):
+        """ComputeOptimalPointsToSampleViaMultistartGradientDescent at q = 1, p = 0: (best_point [d], found)."""
+        gd, gdp = _d(gd)
+        bounds, bp = _d(bounds)
+        starts, sp = _d(starts)
+        S = starts.reshape(-1, self.d).shape[0]
+        assert S >= 20, "the reference pops its top-20 queue unconditionally"
+        found = C.c_int(0)
+        best = np.zeros(self.d)
+        _check(lib().ref_ei_multistart_analytic(self.h, gdp, bp, sp, S, best_so_far, C.byref(found),
+                                                best.ctypes.data_as(_dp)))
+        return best, bool(found.value)
 
     def kg(self, gd, bounds, discrete, Xq, Xp, M, best_so_far, normals, want_grad=True, num_fidelity=0, details=False):
         """Returns dict(kg, grad[q,d], best_point[M,d], seconds=(state, eval), ...)."""

@@ -33,6 +33,7 @@
 #include "gpp_geometry.hpp"
 #include "gpp_knowledge_gradient_optimization.hpp"
 #include "gpp_linear_algebra.hpp"
+#include "gpp_optimization.hpp"
 #include "gpp_optimizer_parameters.hpp"
 #include "gpp_random.hpp"
 
@@ -243,6 +244,40 @@ int ref_ei(void* hv, const double* Xq, const double* Xp, int q, int p, int M, do
     if (grad) ev.ComputeGradExpectedImprovement(&st, grad);
     auto t1 = std::chrono::steady_clock::now();
     if (seconds) *seconds = std::chrono::duration<double>(t1 - t0).count();
+  });
+}
+
+// ---- analytic 1,0-EI (OnePotentialSampleExpectedImprovementEvaluator, gpp_math.cpp:2195-2259) ----
+int ref_ei_analytic(void* hv, const double* pt, double best_so_far, double* ei, double* grad) {
+  return guarded([&] {
+    GaussianProcess* gp = static_cast<RefGP*>(hv)->gp;
+    OnePotentialSampleExpectedImprovementEvaluator ev(*gp, best_so_far);
+    OnePotentialSampleExpectedImprovementEvaluator::StateType st(ev, pt, grad != nullptr);
+    if (ei) *ei = ev.ComputeExpectedImprovement(&st);
+    if (grad) ev.ComputeGradExpectedImprovement(&st, grad);
+  });
+}
+
+// ---- 1,0-EI multistart gradient descent from a given start set (ComputeOptimalPointsToSampleViaMultistartGradientDescent,
+// gpp_math.hpp:1683-1742).  q = 1, p = 0 takes the analytic evaluator, so no random source is involved and the result is a
+// deterministic function of the inputs.  num_starts must be >= 20 (the reference pops its top-20 queue unconditionally). ----
+int ref_ei_multistart_analytic(void* hv, const double* gd, const double* bounds, const double* starts, int num_starts,
+                               double best_so_far, int* found, double* best_point) {
+  return guarded([&] {
+    GaussianProcess* gp = static_cast<RefGP*>(hv)->gp;
+    const int d = gp->dim();
+    std::vector<ClosedInterval> iv(d);
+    for (int i = 0; i < d; ++i) iv[i] = ClosedInterval(bounds[2 * i], bounds[2 * i + 1]);
+    TensorProductDomain dom(iv.data(), d);
+    GradientDescentParameters gdp(static_cast<int>(gd[0]), static_cast<int>(gd[1]), static_cast<int>(gd[2]),
+                                  static_cast<int>(gd[3]), gd[4], gd[5], gd[6], gd[7]);
+    ThreadSchedule sched(1, omp_sched_static);
+    NormalRNG rng(1);
+    double dummy = 0.0;
+    bool found_flag = false;
+    ComputeOptimalPointsToSampleViaMultistartGradientDescent(*gp, gdp, dom, sched, starts, &dummy, num_starts, 1, 0,
+                                                             best_so_far, 1, &rng, &found_flag, best_point);
+    *found = found_flag ? 1 : 0;
   });
 }
 

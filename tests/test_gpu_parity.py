@@ -81,6 +81,36 @@ def test_golden_ei(api, golden):
         assert ei2 == ei
 
 
+def test_golden_analytic_ei_and_ei_multistart(api, golden):
+    """a20 + its caller: analytic 1,0-EI (moe_ei_analytic_batch) and the EI multistart driver (moe_ei_multistart) against the
+    reference's OnePotentialSampleExpectedImprovementEvaluator / ComputeOptimalPointsToSampleViaMultistartGradientDescent."""
+    cases, _ = golden
+    seen = 0
+    for c in cases:
+        i = c.inp
+        G = _dev_gp(api, i)
+        best = float(i["ei_best"])
+        ei, grad = G.ei_analytic_batch(i["query"], best)
+        ref_ei, ref_grad = c.out["ei_analytic"], c.out["grad_ei_analytic"]
+        assert np.abs(ei - ref_ei).max() <= 1e-11 * max(np.abs(ref_ei).max(), 1e-6)
+        assert np.abs(grad - ref_grad).max() <= 1e-9 * max(np.abs(ref_grad).max(), 1e-6)
+        if "ms_starts" not in i:
+            continue
+        seen += 1
+        d = int(i["d"])
+        pt, val, found = G.ei_multistart(tuple(i["ms_gd"]), i["bounds"], i["ms_starts"].reshape(-1, 1, d), None, 1, best, None)
+        assert found == bool(c.out["ms_found"])
+        assert np.abs(pt.ravel() - c.out["ms_best_point"]).max() <= 1e-8
+        assert abs(val - float(c.out["ms_best_ei"])) <= 1e-10 * abs(float(c.out["ms_best_ei"]))
+        # value-only search (EvaluateEIAtPointList): the best start by analytic EI
+        pt0, val0, found0 = G.ei_multistart(tuple(i["ms_gd"]), i["bounds"], i["ms_starts"].reshape(-1, 1, d), None, 1, best, None,
+                                            gradient_ascent=False)
+        all_ei = G.ei_analytic_batch(i["ms_starts"], best, want_grad=False)[0]
+        assert found0 and val0 == all_ei.max() and np.array_equal(pt0.ravel(), i["ms_starts"][int(np.argmax(all_ei))])
+        assert val >= val0
+    assert seen == 3
+
+
 def test_golden_kg(api, golden):
     cases, _ = golden
     ran = 0

@@ -66,6 +66,35 @@ def test_golden_ei_kg(golden):
         assert abs(rv["kg"] - float(c.out["kg_value_only"])) <= TOL["kg"] * abs(float(c.out["kg_value_only"]))
 
 
+def test_golden_analytic_ei_and_multistart(golden):
+    """a20: analytic 1,0-EI (gpp_math.cpp:2195-2259) against the reference's values, and the numpy restatement of the
+    multistart driver (cornell_moe_amd.multistart.multistart_best, the independent check of the C++ driver in the GPU
+    tests) against the reference's ComputeOptimalPointsToSampleViaMultistartGradientDescent on the same start set."""
+    from cornell_moe_amd import multistart as ms
+    cases, _ = golden
+    seen = 0
+    for c in cases:
+        gp = _gp(c)
+        i = c.inp
+        best = float(i["ei_best"])
+        for k, pt in enumerate(i["query"]):
+            v, g = gp.ei_analytic(pt, best)
+            assert abs(v - c.out["ei_analytic"][k]) <= 1e-12 * max(abs(c.out["ei_analytic"][k]), 1e-6)
+            assert np.abs(g - c.out["grad_ei_analytic"][k]).max() <= 1e-10 * max(np.abs(c.out["grad_ei_analytic"][k]).max(), 1e-6)
+        if "ms_starts" not in i:
+            continue
+        seen += 1
+        d = int(i["d"])
+        value_fn = lambda x: np.array([gp.ei_analytic(p.ravel(), best, want_grad=False)[0] for p in x])  # noqa: E731
+        grad_fn = lambda x: np.array([gp.ei_analytic(p.ravel(), best)[1] for p in x]).reshape(x.shape)  # noqa: E731
+        pt, val, found = ms.multistart_best(value_fn, grad_fn, tuple(i["ms_gd"]), i["bounds"], i["ms_starts"].reshape(-1, 1, d),
+                                            floor_value=-1.0)
+        assert found == bool(c.out["ms_found"])
+        assert np.abs(pt.ravel() - c.out["ms_best_point"]).max() <= 1e-8
+        assert abs(val - float(c.out["ms_best_ei"])) <= 1e-10 * abs(float(c.out["ms_best_ei"]))
+    assert seen == 3
+
+
 def test_singular_detection():
     X = np.array([[0.1, 0.2], [0.1, 0.2], [0.5, 0.5]])
     with pytest.raises(orc.SingularMatrix):

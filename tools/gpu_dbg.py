@@ -1,20 +1,18 @@
-import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import sys
 import numpy as np
+sys.path.insert(0, '/root/repo')
+from cornell_moe_amd import api
 from cornell_moe_amd.workloads import make_workload
-from cornell_moe_amd.api import DeviceGP
-from oracle import ref
-def rel(a, b):
-    a = np.asarray(a, dtype=float); b = np.asarray(b, dtype=float)
-    return float(np.max(np.abs(a - b)) / max(np.max(np.abs(b)), 1e-300))
-for (n, d, q, M, noise, bs) in [(40, 3, 2, 64, 0.1, None), (40, 4, 2, 64, 0.1, None), (200, 3, 2, 64, 0.01, None), (40, 3, 2, 512, 0.1, None), (40, 3, 2, 64, 0.1, -100.0), (500, 4, 2, 1000, 0.01, 10.0)]:
-    w = make_workload(seed=5, n=n, d=d, q=q, M=M, P=5, derivs=(), p=0)
-    w.noise[:] = noise
-    R = ref.RefGP(1, w.alpha, w.lengths, w.X, w.y, w.noise, w.derivs)
-    G = DeviceGP(w.hyperparameters, w.X, w.y, w.noise, w.derivs)
-    bestkg = float(R.additional_mean(w.discrete).min()) if bs is None else bs
-    kr = R.kg(w.inner_gd, w.bounds, w.discrete, w.Xq, None, M, bestkg, w.kg_normals, details=True)
-    kg = G.kg(w.inner_gd, w.bounds, w.discrete, w.Xq, None, M, bestkg, w.kg_normals)
-    print(n, d, q, M, noise, bs, "kg", kr["kg"], kg["kg"], "grad rel", rel(kg["grad"], kr["grad"]))
-    print("  mu(Xq)", kr["to_sample_mean"], "best", bestkg)
-    print("  ref", kr["grad"].ravel()); print("  dev", kg["grad"].ravel())
+from oracle import orc
+w = make_workload(seed=33, n=80, d=3, q=2, M=400, P=7, derivs=(), p=1)
+O = orc.OrcGP(0, w.alpha, w.lengths, w.X, w.y, w.noise, ())
+G = api.DeviceGP(w.hyperparameters, w.X, w.y, w.noise, (), cov_type=0)
+best = float(np.median(w.y[:, 0]))
+pts = np.random.default_rng(1).uniform(size=(30, 3))
+want = np.array([O.ei_analytic(p, best, want_grad=False)[0] for p in pts])
+for E in (1, 2, 5, 30):
+    a = G.ei_analytic_batch(pts[:E], best, want_grad=False)[0]
+    b, g = G.ei_analytic_batch(pts[:E], best, want_grad=True)
+    print(E, np.abs(a - want[:E]).max(), np.abs(b - want[:E]).max())
+mu = G.mean(pts[:3]); var = [G.variance(pts[k:k+1]) for k in range(3)]
+print(mu, O.mean(pts[:3]), var, [O.var(pts[k:k+1]) for k in range(3)])

@@ -63,6 +63,15 @@ def run_case(c):
     ei, gei, _ = gp.ei(c["Xq"], Xp, int(c["M"]), float(c["ei_best"]), c["ei_normals"])
     out["ei"] = np.array(ei)
     out["grad_ei"] = gei
+    # analytic 1,0-EI at each query point (OnePotentialSampleExpectedImprovementEvaluator, gpp_math.cpp:2195-2259)
+    a = [gp.ei_analytic(pt, float(c["ei_best"])) for pt in pts]
+    out["ei_analytic"] = np.array([v for v, _ in a])
+    out["grad_ei_analytic"] = np.array([gr for _, gr in a])
+    if "ms_starts" in c:  # 1,0-EI multistart gradient descent from a fixed start set (gpp_math.hpp:1683-1742)
+        best, found = gp.ei_multistart_analytic(c["ms_gd"], c["bounds"], c["ms_starts"], float(c["ei_best"]))
+        out["ms_best_point"] = best
+        out["ms_found"] = np.array(int(found))
+        out["ms_best_ei"] = np.array(gp.ei_analytic(best, float(c["ei_best"]))[0])
     r = gp.kg(c["inner_gd"], c["bounds"], c["discrete"], c["Xq"], Xp, int(c["M"]), float(c["best_so_far"]), c["kg_normals"],
               want_grad=True, details=True)
     out["kg"] = np.array(r["kg"])
@@ -98,6 +107,10 @@ def main():
     blob = {"num_cases": np.array(len(cases))}
     for i, c in enumerate(cases):
         c["ei_best"] = float(np.median(c["y"][:, 0]))
+        if c["seed"] in (1001, 1002, 1003):  # EI multistart: 24 starts (>= 20: the reference pops a 20-deep queue), own rng
+            rs = np.random.default_rng(int(c["seed"]) + 77)
+            c["ms_starts"] = rs.uniform(0.0, 1.0, size=(24, c["d"]))
+            c["ms_gd"] = np.array((24, 20, 2, 4, 0.7, 0.05, 0.2, 1e-8))  # contractive steps: FP64 round-off stays ~1e-13
         out = run_case(c)
         for key, val in c.items():
             blob["c%d_in_%s" % (i, key)] = np.asarray(val)
