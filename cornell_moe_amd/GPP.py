@@ -322,10 +322,10 @@ def compute_grad_expected_improvement(gaussian_process, points_to_sample, points
                     max_int_steps, best_so_far, randomness_source, True)[1].ravel())
 
 
-def evaluate_EI_at_point_list(gaussian_process, optimizer_parameters, domain_bounds, initial_guesses, points_being_sampled,
-                              num_multistarts, num_to_sample, num_being_sampled, best_so_far, max_int_steps,
-                              max_num_threads, randomness_source, status):
-    """EvaluateEIAtPointList (gpp_math.hpp:1900-1950) via gpp_python_expected_improvement.cpp:221-276."""
+def evaluate_EI_at_point_list(gaussian_process, initial_guesses, points_being_sampled, num_multistarts, num_to_sample,
+                              num_being_sampled, best_so_far, max_int_steps, max_num_threads, randomness_source, status):
+    """EvaluateEIAtPointListWrapper (gpp_python_expected_improvement.cpp:401-440) -> EvaluateEIAtPointList
+    (gpp_math.cpp:2305-2356)."""
     if max_num_threads > randomness_source.num_normal_rng:
         raise BoundsException("Fewer randomness_sources than max_num_threads.", randomness_source.num_normal_rng,
                               max_num_threads, 1e9)

@@ -320,8 +320,7 @@ class ExpectedImprovement(object):
         status = {} if status is None else status
         num_to_evaluate, num_to_sample, _ = points_to_evaluate.shape
         return numpy.array(C_GP.evaluate_EI_at_point_list(
-            self._gaussian_process._gaussian_process, None, None, cppify(points_to_evaluate),
-            cppify(self._points_being_sampled), num_to_evaluate, num_to_sample, self.num_being_sampled, self._best_so_far,
+            self._gaussian_process._gaussian_process, cppify(points_to_evaluate), cppify(self._points_being_sampled), num_to_evaluate, num_to_sample, self.num_being_sampled, self._best_so_far,
             self._num_mc_iterations, max_num_threads, randomness, status))
 
 

@@ -124,7 +124,7 @@ int moe_ei(const moe_gp_t* gp, const double* points_to_sample, const double* poi
            moe_error_t* err);
 
 /* Batched form: `num_evals` independent points_to_sample sets (points_to_sample_all[e][q][dim]) against the same
- * points_being_sampled and normal table -- evaluate_EI_at_point_list (gpp_python_expected_improvement.cpp:221-276 ->
+ * points_being_sampled and normal table -- evaluate_EI_at_point_list (gpp_python_expected_improvement.cpp:401-440 ->
  * EvaluateEIAtPointList, gpp_math.hpp:1900-1950).  ei[num_evals] and/or grad_ei[num_evals][q*dim] may be NULL. */
 int moe_ei_batch(const moe_gp_t* gp, const double* points_to_sample_all, int num_evals, const double* points_being_sampled,
                  int num_to_sample, int num_being_sampled, int num_mc, double best_so_far, const double* normals,

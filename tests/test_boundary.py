@@ -22,8 +22,8 @@ HOT_PATH_EXPORTS = [
     ("posterior_mean_optimization", 6),                 # :315-320
     ("compute_expected_improvement", 9),                # gpp_python_expected_improvement.cpp:44-50
     ("compute_grad_expected_improvement", 9),           # :77-83
-    ("evaluate_EI_at_point_list", 13),                  # :221-231 (EvaluateEIAtPointListWrapper)
-    ("multistart_expected_improvement_optimization", 13),  # MultistartExpectedImprovementOptimizationWrapper
+    ("evaluate_EI_at_point_list", 11),                  # :401-408 (EvaluateEIAtPointListWrapper)
+    ("multistart_expected_improvement_optimization", 13),  # :221-229 (MultistartExpectedImprovementOptimizationWrapper)
 ]
 GP_METHODS = [  # gpp_python_gaussian_process.cpp:294-465 (self + listed arguments)
     ("compute_mean_of_points", 2), ("compute_mean_of_additional_points", 2), ("compute_grad_mean_of_points", 2),
@@ -71,6 +71,30 @@ def test_every_hot_path_binding_of_the_reference_wrappers_exists():
             if name not in out_of_scope and not hasattr(GPP, name):
                 missing.append((fn, name))
     assert not missing, missing
+
+
+@pytest.mark.skipif(not os.path.isdir(REF_WRAPPERS), reason="reference tree not present (GPU box)")
+def test_call_sites_of_the_reference_wrappers_fit_our_signatures():
+    """Every ``C_GP.<name>(...)`` call in the reference's hot-path wrapper files passes an argument count our function of that
+    name accepts (ast scan of the reference sources; nothing is imported from them)."""
+    import ast
+    from cornell_moe_amd import GPP
+    checked = 0
+    for fn in ("knowledge_gradient.py", "expected_improvement.py", "gaussian_process.py"):
+        tree = ast.parse(open(os.path.join(REF_WRAPPERS, fn)).read())
+        for node in ast.walk(tree):
+            if not (isinstance(node, ast.Call) and isinstance(node.func, ast.Attribute)
+                    and isinstance(node.func.value, ast.Name) and node.func.value.id == "C_GP"):
+                continue
+            obj = getattr(GPP, node.func.attr)
+            params = list(inspect.signature(obj.__init__ if inspect.isclass(obj) else obj).parameters.values())
+            if inspect.isclass(obj):
+                params = params[1:]
+            required = [p for p in params if p.default is inspect.Parameter.empty]
+            n = len(node.args) + len(node.keywords)
+            assert len(required) <= n <= len(params), (fn, node.func.attr, n, len(required), len(params))
+            checked += 1
+    assert checked >= 15
 
 
 def test_randomness_source_semantics():
