@@ -462,6 +462,173 @@ def posterior_mean_optimization(gaussian_process, num_fidelity, optimizer_parame
     return list(best)
 
 
+# ---- MCMC-averaged evaluators (gpp_python_knowledge_gradient_mcmc.cpp, gpp_python_expected_improvement_mcmc.cpp) ----
+class GaussianProcessMCMC(object):
+    """C_GP.GaussianProcessMCMC (make_gaussian_process_mcmc, gpp_python_knowledge_gradient_mcmc.cpp:45-75): num_mcmc
+    Matern-5/2 GPs over the same data; hyperparameters_list flat [num_mcmc][1 + dim] = (alpha, lengths...),
+    noise_variance_list flat [num_mcmc][1 + num_derivatives]."""
+
+    def __init__(self, hyperparameters_list, noise_variance_list, points_sampled, points_sampled_value, derivatives, num_mcmc,
+                 num_derivatives, dim, num_sampled, device=0):
+        self.dim = int(dim)
+        self.num_mcmc = int(num_mcmc)
+        self._g = int(num_derivatives)
+        X = _flat(points_sampled, dim * num_sampled).reshape(num_sampled, dim)
+        y = _flat(points_sampled_value, num_sampled * (1 + self._g)).reshape(num_sampled, 1 + self._g)
+        hyp = _flat(hyperparameters_list, self.num_mcmc * (dim + 1)).reshape(self.num_mcmc, dim + 1)
+        noise = _flat(noise_variance_list, self.num_mcmc * (1 + self._g)).reshape(self.num_mcmc, 1 + self._g)
+        derivs = [int(v) for v in list(derivatives)[:self._g]]
+        self._dev = _api.DeviceGPMCMC(hyp, noise, X, y, derivs, device=device)
+
+    num_sampled = property(lambda self: self._dev.n)
+
+
+def _kg_mcmc(gp_mcmc, num_fidelity, optimizer_parameters, domain_bounds, discrete_pts, points_to_sample, points_being_sampled,
+             num_pts, num_to_sample, num_being_sampled, max_int_steps, best_so_far, randomness_source, want_grad):
+    gp = gp_mcmc
+    size = gp.dim - num_fidelity
+    Xq = _flat(points_to_sample, gp.dim * num_to_sample).reshape(1, num_to_sample, gp.dim)
+    Xp = _being_sampled(gp, points_being_sampled, num_being_sampled)
+    discrete = _flat(discrete_pts, gp.num_mcmc * num_pts * size).reshape(gp.num_mcmc, num_pts, size)
+    bounds = _flat(domain_bounds, 2 * size)
+    best = _flat(best_so_far, gp.num_mcmc)
+    M = int(max_int_steps)
+    normals = randomness_source.normal_rng_vec[0].table(((M + 1) // 2) * (num_to_sample + max(num_being_sampled, 0)) * (1 + gp._g))
+    kg, grad = gp._dev.kg_batch(_gd_params(optimizer_parameters), bounds, discrete, Xq, Xp, M, best, normals, want_grad=want_grad,
+                                num_fidelity=int(num_fidelity))
+    return float(kg[0]), (grad[0] if want_grad else None)
+
+
+def compute_knowledge_gradient_mcmc(gaussian_process_mcmc, num_fidelity, optimizer_parameters, domain_bounds, discrete_pts,
+                                    points_to_sample, points_being_sampled, num_pts, num_to_sample, num_being_sampled,
+                                    max_int_steps, best_so_far, randomness_source):
+    """ComputeKnowledgeGradientMCMCWrapper (gpp_python_knowledge_gradient_mcmc.cpp:77-118)."""
+    return _kg_mcmc(gaussian_process_mcmc, num_fidelity, optimizer_parameters, domain_bounds, discrete_pts, points_to_sample,
+                    points_being_sampled, num_pts, num_to_sample, num_being_sampled, max_int_steps, best_so_far,
+                    randomness_source, False)[0]
+
+
+def compute_grad_knowledge_gradient_mcmc(gaussian_process_mcmc, num_fidelity, optimizer_parameters, domain_bounds, discrete_pts,
+                                         points_to_sample, points_being_sampled, num_pts, num_to_sample, num_being_sampled,
+                                         max_int_steps, best_so_far, randomness_source):
+    """ComputeGradKnowledgeGradientMCMCWrapper (gpp_python_knowledge_gradient_mcmc.cpp:120-165)."""
+    return list(_kg_mcmc(gaussian_process_mcmc, num_fidelity, optimizer_parameters, domain_bounds, discrete_pts, points_to_sample,
+                         points_being_sampled, num_pts, num_to_sample, num_being_sampled, max_int_steps, best_so_far,
+                         randomness_source, True)[1].ravel())
+
+
+def multistart_knowledge_gradient_mcmc_optimization(optimizer_parameters, optimizer_parameters_inner, gaussian_process_mcmc,
+                                                    num_fidelity, domain_bounds, discrete_pts, points_being_sampled, num_pts,
+                                                    num_to_sample, num_being_sampled, best_so_far, max_int_steps,
+                                                    max_num_threads, randomness_source, status):
+    """MultistartKnowledgeGradientMCMCOptimizationWrapper (gpp_python_knowledge_gradient_mcmc.cpp:256-324)."""
+    from . import multistart
+    if max_num_threads > randomness_source.num_normal_rng:
+        raise BoundsException("Fewer randomness_sources than max_num_threads.", randomness_source.num_normal_rng,
+                              max_num_threads, 1e9)
+    if int(optimizer_parameters.domain_type) != int(DomainTypes.tensor_product):
+        raise OptimalLearningException("only the tensor-product domain is implemented on the device path")
+    gp = gaussian_process_mcmc
+    size = gp.dim - num_fidelity
+    discrete = _flat(discrete_pts, gp.num_mcmc * num_pts * size).reshape(gp.num_mcmc, num_pts, size)
+    Xp = _being_sampled(gp, points_being_sampled, num_being_sampled)
+    best, found = multistart.kg_mcmc_optimal_points(
+        gp._dev, int(num_fidelity), optimizer_parameters, optimizer_parameters_inner, _flat(domain_bounds, 2 * gp.dim), discrete,
+        Xp, int(num_to_sample), _flat(best_so_far, gp.num_mcmc), int(max_int_steps), randomness_source)
+    kind = "gradient_descent" if int(optimizer_parameters.optimizer_type) == int(OptimizerTypes.gradient_descent) else "lhc"
+    status["%s_tensor_product_domain_found_update" % kind] = bool(found)
+    return list(np.asarray(best).ravel())
+
+
+def evaluate_KG_mcmc_at_point_list(gaussian_process_mcmc, num_fidelity, optimizer_parameters, domain_bounds, initial_guesses,
+                                   discrete_being_sampled, num_multistarts, num_pts, num_to_sample, num_being_sampled,
+                                   best_so_far, max_int_steps, max_num_threads, randomness_source, status):
+    """EvaluateKGMCMCAtPointListWrapper (gpp_python_knowledge_gradient_mcmc.cpp:326-383).  Argument order is the C++
+    wrapper's (initial_guesses BEFORE discrete_being_sampled; the reference's own Python caller,
+    cpp_wrappers/knowledge_gradient_mcmc.py:292-308, passes the two the other way round).  discrete_being_sampled =
+    all GPs' discrete points [num_mcmc][num_pts][dim - num_fidelity] followed by points_being_sampled [p][dim]."""
+    if max_num_threads > randomness_source.num_normal_rng:
+        raise BoundsException("Fewer randomness_sources than max_num_threads.", randomness_source.num_normal_rng,
+                              max_num_threads, 1e9)
+    gp = gaussian_process_mcmc
+    size = gp.dim - num_fidelity
+    n_disc = gp.num_mcmc * num_pts * size
+    packed = _flat(discrete_being_sampled, n_disc + max(num_being_sampled, 0) * gp.dim)
+    discrete = packed[:n_disc].reshape(gp.num_mcmc, num_pts, size)
+    Xp = packed[n_disc:].reshape(num_being_sampled, gp.dim) if num_being_sampled > 0 else None
+    guesses = _flat(initial_guesses, gp.dim * num_to_sample * num_multistarts).reshape(num_multistarts, num_to_sample, gp.dim)
+    M = int(max_int_steps)
+    normals = randomness_source.normal_rng_vec[0].table(((M + 1) // 2) * (num_to_sample + max(num_being_sampled, 0)) * (1 + gp._g))
+    kg, _ = gp._dev.kg_batch(_gd_params(optimizer_parameters), _flat(domain_bounds, 2 * size), discrete, guesses, Xp, M,
+                             _flat(best_so_far, gp.num_mcmc), normals, want_grad=False, num_fidelity=int(num_fidelity))
+    status["evaluate_KG_at_point_list"] = bool(len(kg) > 0 and np.max(kg) > -np.inf)
+    return list(kg)
+
+
+def _ei_mcmc(gp_mcmc, points_to_sample, points_being_sampled, num_to_sample, num_being_sampled, max_int_steps, best_so_far,
+             randomness_source, want_grad):
+    gp = gp_mcmc
+    Xq = _flat(points_to_sample, gp.dim * num_to_sample).reshape(1, num_to_sample, gp.dim)
+    Xp = _being_sampled(gp, points_being_sampled, num_being_sampled)
+    u = num_to_sample + max(num_being_sampled, 0)
+    normals = randomness_source.normal_rng_vec[0].table(int(max_int_steps) * u)
+    ei, grad = gp._dev.ei_batch(Xq, Xp, int(max_int_steps), _flat(best_so_far, gp.num_mcmc), normals, want_grad=want_grad)
+    return float(ei[0]), (grad[0] if want_grad else None)
+
+
+def compute_expected_improvement_mcmc(gaussian_process_mcmc, points_to_sample, points_being_sampled, num_to_sample,
+                                      num_being_sampled, max_int_steps, best_so_far, randomness_source):
+    """ComputeExpectedImprovementMCMCWrapper (gpp_python_expected_improvement_mcmc.cpp:42-72): always Monte Carlo."""
+    return _ei_mcmc(gaussian_process_mcmc, points_to_sample, points_being_sampled, num_to_sample, num_being_sampled,
+                    max_int_steps, best_so_far, randomness_source, False)[0]
+
+
+def compute_grad_expected_improvement_mcmc(gaussian_process_mcmc, points_to_sample, points_being_sampled, num_to_sample,
+                                           num_being_sampled, max_int_steps, best_so_far, randomness_source):
+    """ComputeGradExpectedImprovementMCMCWrapper (gpp_python_expected_improvement_mcmc.cpp:74-108)."""
+    return list(_ei_mcmc(gaussian_process_mcmc, points_to_sample, points_being_sampled, num_to_sample, num_being_sampled,
+                         max_int_steps, best_so_far, randomness_source, True)[1].ravel())
+
+
+def multistart_expected_improvement_mcmc_optimization(optimizer_parameters, gaussian_process_mcmc, domain_bounds,
+                                                      points_being_sampled, num_to_sample, num_being_sampled, best_so_far,
+                                                      max_int_steps, max_num_threads, randomness_source, status):
+    """MultistartExpectedImprovementMCMCOptimizationWrapper (gpp_python_expected_improvement_mcmc.cpp)."""
+    from . import multistart
+    if max_num_threads > randomness_source.num_normal_rng:
+        raise BoundsException("Fewer randomness_sources than max_num_threads.", randomness_source.num_normal_rng,
+                              max_num_threads, 1e9)
+    if int(optimizer_parameters.domain_type) != int(DomainTypes.tensor_product):
+        raise OptimalLearningException("only the tensor-product domain is implemented on the device path")
+    gp = gaussian_process_mcmc
+    Xp = _being_sampled(gp, points_being_sampled, num_being_sampled)
+    best, found = multistart.ei_mcmc_optimal_points(gp._dev, optimizer_parameters, _flat(domain_bounds, 2 * gp.dim), Xp,
+                                                    int(num_to_sample), _flat(best_so_far, gp.num_mcmc), int(max_int_steps),
+                                                    randomness_source)
+    kind = "gradient_descent" if int(optimizer_parameters.optimizer_type) == int(OptimizerTypes.gradient_descent) else "lhc"
+    status["%s_tensor_product_domain_found_update" % kind] = bool(found)
+    return list(np.asarray(best).ravel())
+
+
+def evaluate_EI_mcmc_at_point_list(gaussian_process_mcmc, initial_guesses, points_being_sampled, num_multistarts, num_to_sample,
+                                   num_being_sampled, best_so_far, max_int_steps, max_num_threads, randomness_source, status):
+    """EvaluateEIMCMCAtPointListWrapper -> EvaluateEIMCMCAtPointList (gpp_expected_improvement_mcmc_optimization.cpp:239-298):
+    the analytic evaluator at num_to_sample == 1, num_being_sampled == 0."""
+    if max_num_threads > randomness_source.num_normal_rng:
+        raise BoundsException("Fewer randomness_sources than max_num_threads.", randomness_source.num_normal_rng,
+                              max_num_threads, 1e9)
+    gp = gaussian_process_mcmc
+    guesses = _flat(initial_guesses, gp.dim * num_to_sample * num_multistarts).reshape(num_multistarts, num_to_sample, gp.dim)
+    Xp = _being_sampled(gp, points_being_sampled, num_being_sampled)
+    analytic = num_to_sample == 1 and num_being_sampled <= 0
+    u = num_to_sample + max(num_being_sampled, 0)
+    normals = None if analytic else randomness_source.normal_rng_vec[0].table(int(max_int_steps) * u)
+    ei, _ = gp._dev.ei_batch(guesses, Xp, int(max_int_steps), _flat(best_so_far, gp.num_mcmc), normals, want_grad=False,
+                             analytic=analytic)
+    status["evaluate_EI_at_point_list"] = bool(len(ei) > 0 and np.max(ei) > 0.0)
+    return list(ei)
+
+
 def run_cpp_tests():
     """The reference runs its C++ unit-test suite here (gpp_python_test.cpp:307-314); this backend's tests are the pytest
     suite under tests/ (returns 0 = no failures, like the reference on success)."""

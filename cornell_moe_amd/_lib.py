@@ -30,6 +30,7 @@ class KgStats(C.Structure):
 # every symbol include/moe_hip.h declares: (restype, argtypes)
 _EP = C.POINTER(MoeError)
 _GP = C.c_void_p
+_GPA = C.POINTER(C.c_void_p)  # const moe_gp_t* const*: the handles of an MCMC ensemble
 SIGNATURES = {
     "moe_version": (C.c_char_p, []),
     "moe_device_count": (C.c_int, [ip]),
@@ -61,6 +62,14 @@ SIGNATURES = {
                                C.c_int, C.c_double, dp, C.c_int, C.c_int, C.c_int, dp, dp, C.POINTER(KgStats), _EP]),
     "moe_kg_multistart": (C.c_int, [_GP, C.c_int, C.POINTER(GdParams), C.POINTER(GdParams), dp, dp, C.c_int, dp, C.c_int, dp,
                                     C.c_int, C.c_int, C.c_int, C.c_double, dp, C.c_int, dp, dp, ip, _EP]),
+    "moe_kg_mcmc_batch": (C.c_int, [_GPA, C.c_int, C.c_int, C.POINTER(GdParams), dp, dp, C.c_int, dp, C.c_int, dp, C.c_int,
+                                    C.c_int, C.c_int, dp, dp, C.c_int, C.c_int, dp, dp, _EP]),
+    "moe_kg_mcmc_finalize": (C.c_int, [dp, dp, dp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "moe_ei_mcmc_batch": (C.c_int, [_GPA, C.c_int, dp, C.c_int, dp, C.c_int, C.c_int, C.c_int, dp, dp, C.c_int, dp, dp, _EP]),
+    "moe_kg_mcmc_multistart": (C.c_int, [_GPA, C.c_int, C.c_int, C.POINTER(GdParams), C.POINTER(GdParams), dp, dp, C.c_int, dp,
+                                         C.c_int, dp, C.c_int, C.c_int, C.c_int, dp, dp, C.c_int, dp, dp, ip, _EP]),
+    "moe_ei_mcmc_multistart": (C.c_int, [_GPA, C.c_int, C.POINTER(GdParams), dp, dp, C.c_int, dp, C.c_int, C.c_int, C.c_int, dp,
+                                         dp, C.c_int, dp, dp, ip, _EP]),
     "moe_posterior_mean_optimize": (C.c_int, [_GP, C.c_int, C.POINTER(GdParams), dp, dp, dp, dp, _EP]),
     "moe_latin_hypercube": (C.c_int, [C.c_uint, dp, C.c_int, C.c_int, dp]),
     "moe_gp_mix_covariance": (C.c_int, [_GP, dp, C.c_int, ip, C.c_int, dp, _EP]),

@@ -413,3 +413,130 @@ class DeviceGP(object):
         out = np.zeros(5)
         _lib.load().moe_last_kernel_ms(self._h, out.ctypes.data_as(dp))
         return dict(mc=out[0], cov_build=out[1], tail=out[2], state=out[3], total=out[4])
+
+
+class DeviceGPMCMC(object):
+    """num_mcmc device GPs over the same data, one per hyper-parameter sample (replaces C_GP.GaussianProcessMCMC,
+    gpp_knowledge_gradient_mcmc_optimization.cpp:24-49: Matern-5/2, hypers [num_mcmc][1 + dim] = (alpha, lengths),
+    noises [num_mcmc][1 + num_derivatives]).  `members` restricts construction to a subset of the GP indices (the GP-index
+    shard of a multi-GPU run); the MCMC-averaged evaluators below then return that subset's share."""
+
+    def __init__(self, hypers, noises, X, y, derivatives=(), device=0, members=None):
+        X = np.ascontiguousarray(X, dtype=np.float64)
+        self.n, self.d = X.shape
+        self.derivatives = [int(v) for v in derivatives]
+        self.g = len(self.derivatives)
+        hypers = np.ascontiguousarray(hypers, dtype=np.float64).reshape(-1, self.d + 1)
+        noises = np.ascontiguousarray(noises, dtype=np.float64).reshape(-1, 1 + self.g)
+        self.total_num_mcmc = hypers.shape[0]
+        self.members = list(range(self.total_num_mcmc)) if members is None else [int(i) for i in members]
+        self.gps = [DeviceGP(hypers[i], X, y, noises[i], self.derivatives, cov_type=_lib.COV_MATERN_NU_2P5, device=device)
+                    for i in self.members]
+        self._arr = (C.c_void_p * max(len(self.gps), 1))(*[gp._h.value for gp in self.gps])
+
+    num_mcmc = property(lambda self: len(self.gps))
+
+    def _common(self, Xq_all, Xp):
+        Xq_all = np.ascontiguousarray(Xq_all, dtype=np.float64)
+        E, q, _ = Xq_all.shape
+        if Xp is None or np.size(Xp) == 0:
+            p, ppp = 0, None
+        else:
+            Xp, ppp = _d(Xp)
+            p = Xp.reshape(-1, self.d).shape[0]
+        return Xq_all, E, q, Xp, p, ppp
+
+    def _local(self, per_gp):
+        """Rows of a per-GP array [total_num_mcmc][...] that belong to this object's members."""
+        a = np.asarray(per_gp, dtype=np.float64).reshape(self.total_num_mcmc, -1)
+        return np.ascontiguousarray(a[self.members])
+
+    def kg_batch(self, inner_params, bounds, discrete_all, Xq_all, Xp, num_mc, best_so_far, normals, want_grad=True,
+                 num_fidelity=0, finalize=True):
+        """moe_kg_mcmc_batch: Xq_all [E][q][dim], discrete_all [total_num_mcmc][P][dim - f], best_so_far [total_num_mcmc]
+        -> (kg [E], grad [E][q][dim] or None).  finalize=False returns this object's members' plain sums."""
+        Xq_all, E, q, Xp, p, ppp = self._common(Xq_all, Xp)
+        g = DeviceGP._gd(inner_params)
+        bounds, bp = _d(bounds)
+        disc = self._local(discrete_all)
+        P = disc.shape[1] // (self.d - num_fidelity)
+        best = self._local(best_so_far).ravel()
+        normals, npn = _d(normals)
+        m = (q + p) * (1 + self.g)
+        if normals.size < ((num_mc + 1) // 2) * m:
+            raise InvalidValueException("normal table too small", normals.size, ((num_mc + 1) // 2) * m, 0)
+        kg = np.zeros(E)
+        grad = np.zeros((E, q, self.d))
+        err = _lib.MoeError()
+        _check(_lib.load().moe_kg_mcmc_batch(self._arr, len(self.gps), int(num_fidelity), C.byref(g), bp, disc.ctypes.data_as(dp),
+                                             P, Xq_all.ctypes.data_as(dp), E, ppp, q, p, int(num_mc), best.ctypes.data_as(dp),
+                                             npn, 1 if finalize else 0, self.total_num_mcmc, kg.ctypes.data_as(dp),
+                                             grad.ctypes.data_as(dp) if want_grad else None, C.byref(err)), err)
+        return kg, (grad if want_grad else None)
+
+    def kg_finalize(self, kg_sum, grad_sum, Xq_all, num_fidelity=0):
+        """moe_kg_mcmc_finalize on all-reduced sums: mean over total_num_mcmc, fidelity cost and its gradient term."""
+        Xq_all = np.ascontiguousarray(Xq_all, dtype=np.float64)
+        E, q, _ = Xq_all.shape
+        kg = np.array(kg_sum, dtype=np.float64, copy=True).reshape(E)
+        grad = None if grad_sum is None else np.array(grad_sum, dtype=np.float64, copy=True).reshape(E, q, self.d)
+        rc = _lib.load().moe_kg_mcmc_finalize(kg.ctypes.data_as(dp), grad.ctypes.data_as(dp) if grad is not None else None,
+                                              Xq_all.ctypes.data_as(dp), E, q, self.d, int(num_fidelity), self.total_num_mcmc)
+        if rc:
+            raise BoundsException("moe_kg_mcmc_finalize: bad argument", rc, 0, 0)
+        return kg, grad
+
+    def ei_batch(self, Xq_all, Xp, num_mc, best_so_far, normals, want_grad=True, analytic=False):
+        """moe_ei_mcmc_batch: (ei [E], grad [E][q][dim] or None), averaged over this object's members."""
+        Xq_all, E, q, Xp, p, ppp = self._common(Xq_all, Xp)
+        best = self._local(best_so_far).ravel()
+        npn = None
+        if not analytic:
+            normals, npn = _d(normals)
+            if normals.size < num_mc * (q + p):
+                raise InvalidValueException("normal table too small", normals.size, num_mc * (q + p), 0)
+        ei = np.zeros(E)
+        grad = np.zeros((E, q, self.d))
+        err = _lib.MoeError()
+        _check(_lib.load().moe_ei_mcmc_batch(self._arr, len(self.gps), Xq_all.ctypes.data_as(dp), E, ppp, q, p, int(num_mc),
+                                             best.ctypes.data_as(dp), npn, 1 if analytic else 0, ei.ctypes.data_as(dp),
+                                             grad.ctypes.data_as(dp) if want_grad else None, C.byref(err)), err)
+        return ei, (grad if want_grad else None)
+
+    def kg_multistart(self, outer_params, inner_params, bounds, discrete_all, starts, Xp, num_mc, best_so_far, normals,
+                      gradient_ascent=True, num_fidelity=0):
+        """moe_kg_mcmc_multistart: starts [S][q][dim] -> (best_points [q][dim], best_kg, found)."""
+        starts, S, q, Xp, p, ppp = self._common(starts, Xp)
+        go, gi = DeviceGP._gd(outer_params), DeviceGP._gd(inner_params)
+        bounds, bp = _d(bounds)
+        disc = self._local(discrete_all)
+        P = disc.shape[1] // (self.d - num_fidelity)
+        best = self._local(best_so_far).ravel()
+        normals, npn = _d(normals)
+        out = np.zeros(q * self.d)
+        val = C.c_double(0.0)
+        found = C.c_int(0)
+        err = _lib.MoeError()
+        _check(_lib.load().moe_kg_mcmc_multistart(self._arr, len(self.gps), int(num_fidelity), C.byref(go), C.byref(gi), bp,
+                                                  disc.ctypes.data_as(dp), P, starts.ctypes.data_as(dp), S, ppp, q, p, int(num_mc),
+                                                  best.ctypes.data_as(dp), npn, 1 if gradient_ascent else 0,
+                                                  out.ctypes.data_as(dp), C.byref(val), C.byref(found), C.byref(err)), err)
+        return out.reshape(q, self.d), val.value, bool(found.value)
+
+    def ei_multistart(self, outer_params, bounds, starts, Xp, num_mc, best_so_far, normals, gradient_ascent=True):
+        """moe_ei_mcmc_multistart: starts [S][q][dim] -> (best_points [q][dim], best_ei, found)."""
+        starts, S, q, Xp, p, ppp = self._common(starts, Xp)
+        go = DeviceGP._gd(outer_params)
+        bounds, bp = _d(bounds)
+        best = self._local(best_so_far).ravel()
+        npn = None
+        if normals is not None:
+            normals, npn = _d(normals)
+        out = np.zeros(q * self.d)
+        val = C.c_double(0.0)
+        found = C.c_int(0)
+        err = _lib.MoeError()
+        _check(_lib.load().moe_ei_mcmc_multistart(self._arr, len(self.gps), C.byref(go), bp, starts.ctypes.data_as(dp), S, ppp, q, p,
+                                                  int(num_mc), best.ctypes.data_as(dp), npn, 1 if gradient_ascent else 0,
+                                                  out.ctypes.data_as(dp), C.byref(val), C.byref(found), C.byref(err)), err)
+        return out.reshape(q, self.d), val.value, bool(found.value)

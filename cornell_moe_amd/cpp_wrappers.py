@@ -441,3 +441,227 @@ def multistart_knowledge_gradient_optimization(kg_optimizer, inner_optimizer, nu
         cppify(kg._points_being_sampled), num_pts, num_to_sample, kg.num_being_sampled, kg._best_so_far,
         kg._num_mc_iterations, max_num_threads, randomness, status)
     return uncppify(best, (num_to_sample, kg.dim))
+
+
+# ---- MCMC-averaged wrappers (cpp_wrappers/knowledge_gradient_mcmc.py, expected_improvement_mcmc.py) ----
+class GaussianProcessMCMC(object):
+    """cpp_wrappers/knowledge_gradient_mcmc.py:163-240: one GP per hyper-parameter sample over the same historical data.
+    hyperparameters_list [num_mcmc][1 + dim], noise_variance_list [num_mcmc][1 + num_derivatives]."""
+
+    def __init__(self, hyperparameters_list, noise_variance_list, historical_data, derivatives):
+        self._hyperparameters_list = copy.deepcopy(numpy.asarray(hyperparameters_list, dtype=numpy.float64))
+        self._num_mcmc = self._hyperparameters_list.shape[0]
+        self._historical_data = copy.deepcopy(historical_data)
+        self._noise_variance_list = copy.deepcopy(numpy.asarray(noise_variance_list, dtype=numpy.float64))
+        self._derivatives = copy.deepcopy(derivatives)
+        self._num_derivatives = len(cppify(self._derivatives))
+        self._gaussian_process_mcmc = C_GP.GaussianProcessMCMC(
+            cppify(self._hyperparameters_list), cppify(self._noise_variance_list), cppify(self._historical_data.points_sampled),
+            cppify(self._historical_data.points_sampled_value), cppify(self._derivatives), self._num_mcmc, self._num_derivatives,
+            self._historical_data.dim, self._historical_data.num_sampled)
+
+    dim = property(lambda self: self._historical_data.dim)
+    num_sampled = property(lambda self: self._historical_data.num_sampled)
+    num_derivatives = property(lambda self: self._num_derivatives)
+    derivatives = property(lambda self: numpy.copy(self._derivatives))
+    noise_variance_list = property(lambda self: numpy.copy(self._noise_variance_list))
+
+    def get_historical_data_copy(self):
+        return copy.deepcopy(self._historical_data)
+
+    def member_models(self):
+        """The per-sample GaussianProcess wrappers the reference keeps beside the MCMC object
+        (log_likelihood_mcmc.py:238-262: `models`), built the same way: Matern-5/2 with each sample's hyper-parameters."""
+        return [GaussianProcess(SquareExponential(self._hyperparameters_list[i]), self._noise_variance_list[i],
+                                self._historical_data, list(self._derivatives)) for i in range(self._num_mcmc)]
+
+
+class PosteriorMeanMCMC(object):
+    """cpp_wrappers/knowledge_gradient_mcmc.py:19-160: the posterior mean averaged over the per-sample GPs."""
+
+    def __init__(self, gaussian_process_list, num_fidelity, points_to_sample=None, randomness=None):
+        self._gaussian_process_list = gaussian_process_list
+        self._num_fidelity = num_fidelity
+        self._points_to_sample = numpy.zeros((1, gaussian_process_list[0].dim)) if points_to_sample is None else points_to_sample
+        self._randomness = _default_randomness(randomness)
+        self.objective_type = None
+
+    dim = property(lambda self: self._gaussian_process_list[0].dim)
+    problem_size = property(lambda self: self.dim - self._num_fidelity)
+
+    def get_current_point(self):
+        return numpy.copy(self._points_to_sample)
+
+    def set_current_point(self, points_to_sample):
+        self._points_to_sample = numpy.copy(numpy.atleast_2d(points_to_sample))
+
+    current_point = property(get_current_point, set_current_point)
+
+    def compute_posterior_mean_mcmc(self, force_monte_carlo=False):
+        total = 0.0
+        for gp in self._gaussian_process_list:
+            total += C_GP.compute_posterior_mean(gp._gaussian_process, self._num_fidelity, cppify(self._points_to_sample))
+        return total / len(self._gaussian_process_list)
+
+    compute_objective_function = compute_posterior_mean_mcmc
+
+    def compute_grad_posterior_mean_mcmc(self, force_monte_carlo=False):
+        grad = numpy.zeros((1, self.dim - self._num_fidelity))
+        for gp in self._gaussian_process_list:
+            grad += uncppify(C_GP.compute_grad_posterior_mean(gp._gaussian_process, self._num_fidelity,
+                                                              cppify(self._points_to_sample)), (1, self.dim - self._num_fidelity))
+        return grad / len(self._gaussian_process_list)
+
+    compute_grad_objective_function = compute_grad_posterior_mean_mcmc
+
+
+class KnowledgeGradientMCMC(object):
+    """cpp_wrappers/knowledge_gradient_mcmc.py:243-420."""
+
+    def __init__(self, gaussian_process_mcmc, gaussian_process_list, num_fidelity, inner_optimizer, discrete_pts_list,
+                 num_to_sample, points_to_sample=None, points_being_sampled=None,
+                 num_mc_iterations=DEFAULT_EXPECTED_IMPROVEMENT_MC_ITERATIONS, randomness=None):
+        self._num_mc_iterations = num_mc_iterations
+        self._gaussian_process_mcmc = gaussian_process_mcmc
+        self._gaussian_process_list = gaussian_process_list
+        self._num_fidelity = num_fidelity
+        self._inner_optimizer = inner_optimizer
+        self._discrete_pts_list, self._best_so_far_list = [], []
+        for discrete_pts, gp in zip(discrete_pts_list, gaussian_process_list):
+            self._discrete_pts_list.append(numpy.copy(discrete_pts))
+            full = numpy.ones((discrete_pts.shape[0], gp.dim))
+            full[:, :discrete_pts.shape[1]] = discrete_pts
+            self._best_so_far_list.append(numpy.amin(gp.compute_mean_of_additional_points(full)))  # :268-274
+        self._points_being_sampled = numpy.array([]) if points_being_sampled is None else numpy.copy(points_being_sampled)
+        self._points_to_sample = (numpy.zeros((num_to_sample, gaussian_process_mcmc.dim)) if points_to_sample is None
+                                  else points_to_sample)
+        self._randomness = _default_randomness(randomness)
+        self.objective_type = None
+
+    dim = property(lambda self: self._gaussian_process_mcmc.dim)
+    num_to_sample = property(lambda self: self._points_to_sample.shape[0])
+    num_being_sampled = property(lambda self: self._points_being_sampled.shape[0])
+    discrete = property(lambda self: self._discrete_pts_list[0].shape[0])
+    problem_size = property(lambda self: self.num_to_sample * self.dim)
+
+    def get_current_point(self):
+        return numpy.copy(self._points_to_sample)
+
+    def set_current_point(self, points_to_sample):
+        self._points_to_sample = numpy.copy(numpy.atleast_2d(points_to_sample))
+
+    current_point = property(get_current_point, set_current_point)
+
+    def _args(self):
+        return (self._gaussian_process_mcmc._gaussian_process_mcmc, self._num_fidelity, self._inner_optimizer.optimizer_parameters,
+                [float(x) for x in cppify(self._inner_optimizer.domain.domain_bounds)], cppify(numpy.array(self._discrete_pts_list)),
+                cppify(self._points_to_sample), cppify(self._points_being_sampled), self.discrete, self.num_to_sample,
+                self.num_being_sampled, self._num_mc_iterations, cppify(numpy.array(self._best_so_far_list)), self._randomness)
+
+    def compute_knowledge_gradient_mcmc(self, force_monte_carlo=False):
+        return C_GP.compute_knowledge_gradient_mcmc(*self._args())
+
+    compute_objective_function = compute_knowledge_gradient_mcmc
+
+    def compute_grad_knowledge_gradient_mcmc(self, force_monte_carlo=False):
+        return uncppify(C_GP.compute_grad_knowledge_gradient_mcmc(*self._args()), (self.num_to_sample, self.dim))
+
+    compute_grad_objective_function = compute_grad_knowledge_gradient_mcmc
+
+    def evaluate_at_point_list(self, points_to_evaluate, randomness=None, max_num_threads=DEFAULT_MAX_NUM_THREADS, status=None):
+        """:292-310, with the two list arguments in the order the C++ wrapper declares them (the reference's Python passes
+        them swapped; see GPP.evaluate_KG_mcmc_at_point_list)."""
+        randomness = self._randomness if (randomness is None and max_num_threads == 1) else _default_randomness(
+            randomness, max_num_threads)
+        status = {} if status is None else status
+        num_to_evaluate, num_to_sample, _ = points_to_evaluate.shape
+        packed = numpy.concatenate((numpy.ravel(self._discrete_pts_list), numpy.ravel(self._points_being_sampled)))
+        bounds = [float(x) for x in cppify(self._inner_optimizer.domain.domain_bounds)]
+        return numpy.array(C_GP.evaluate_KG_mcmc_at_point_list(
+            self._gaussian_process_mcmc._gaussian_process_mcmc, self._num_fidelity, self._inner_optimizer.optimizer_parameters,
+            bounds, cppify(points_to_evaluate), cppify(packed), num_to_evaluate, self.discrete, num_to_sample,
+            self.num_being_sampled, cppify(numpy.array(self._best_so_far_list)), self._num_mc_iterations, max_num_threads,
+            randomness, status))
+
+
+def multistart_knowledge_gradient_mcmc_optimization(kg_optimizer, inner_optimizer, num_multistarts, discrete_pts, num_to_sample,
+                                                    num_pts, randomness=None, max_num_threads=DEFAULT_MAX_NUM_THREADS,
+                                                    status=None):
+    """cpp_wrappers/knowledge_gradient_mcmc.py:200-240."""
+    randomness = _default_randomness(randomness, max_num_threads)
+    status = {} if status is None else status
+    kg = kg_optimizer.objective_function
+    best = C_GP.multistart_knowledge_gradient_mcmc_optimization(
+        kg_optimizer.optimizer_parameters, inner_optimizer.optimizer_parameters, kg._gaussian_process_mcmc._gaussian_process_mcmc,
+        kg._num_fidelity, [float(x) for x in cppify(kg_optimizer.domain.domain_bounds)], cppify(numpy.array(discrete_pts)),
+        cppify(kg._points_being_sampled), num_pts, num_to_sample, kg.num_being_sampled,
+        cppify(numpy.array(kg._best_so_far_list)), kg._num_mc_iterations, max_num_threads, randomness, status)
+    return uncppify(best, (num_to_sample, kg.dim))
+
+
+class ExpectedImprovementMCMC(object):
+    """cpp_wrappers/expected_improvement_mcmc.py:60-260."""
+
+    def __init__(self, gaussian_process_mcmc, num_to_sample, points_to_sample=None, points_being_sampled=None,
+                 num_mc_iterations=DEFAULT_EXPECTED_IMPROVEMENT_MC_ITERATIONS, randomness=None):
+        self._num_mc_iterations = num_mc_iterations
+        self._gaussian_process_mcmc = gaussian_process_mcmc
+        values = gaussian_process_mcmc._historical_data.points_sampled_value
+        best = numpy.amin(values[:, 0]) if values.size > 0 else numpy.finfo(numpy.float64).max
+        self._best_so_far_list = gaussian_process_mcmc._num_mcmc * [best]
+        self._points_being_sampled = numpy.array([]) if points_being_sampled is None else numpy.copy(points_being_sampled)
+        self._points_to_sample = (numpy.zeros((num_to_sample, gaussian_process_mcmc.dim)) if points_to_sample is None
+                                  else numpy.copy(numpy.atleast_2d(points_to_sample)))
+        self._randomness = _default_randomness(randomness)
+        self.objective_type = None
+
+    dim = property(lambda self: self._gaussian_process_mcmc.dim)
+    num_to_sample = property(lambda self: self._points_to_sample.shape[0])
+    num_being_sampled = property(lambda self: self._points_being_sampled.shape[0])
+    problem_size = property(lambda self: self.num_to_sample * self.dim)
+
+    def get_current_point(self):
+        return numpy.copy(self._points_to_sample)
+
+    def set_current_point(self, points_to_sample):
+        self._points_to_sample = numpy.copy(numpy.atleast_2d(points_to_sample))
+
+    current_point = property(get_current_point, set_current_point)
+
+    def _args(self):
+        return (self._gaussian_process_mcmc._gaussian_process_mcmc, cppify(self._points_to_sample),
+                cppify(self._points_being_sampled), self.num_to_sample, self.num_being_sampled, self._num_mc_iterations,
+                cppify(numpy.array(self._best_so_far_list)), self._randomness)
+
+    def compute_expected_improvement(self, force_monte_carlo=False):
+        return C_GP.compute_expected_improvement_mcmc(*self._args())
+
+    compute_objective_function = compute_expected_improvement
+
+    def compute_grad_expected_improvement(self, force_monte_carlo=False):
+        return uncppify(C_GP.compute_grad_expected_improvement_mcmc(*self._args()), (self.num_to_sample, self.dim))
+
+    compute_grad_objective_function = compute_grad_expected_improvement
+
+    def evaluate_at_point_list(self, points_to_evaluate, randomness=None, max_num_threads=DEFAULT_MAX_NUM_THREADS, status=None):
+        randomness = self._randomness if (randomness is None and max_num_threads == 1) else _default_randomness(
+            randomness, max_num_threads)
+        status = {} if status is None else status
+        num_to_evaluate, num_to_sample, _ = points_to_evaluate.shape
+        return numpy.array(C_GP.evaluate_EI_mcmc_at_point_list(
+            self._gaussian_process_mcmc._gaussian_process_mcmc, cppify(points_to_evaluate), cppify(self._points_being_sampled),
+            num_to_evaluate, num_to_sample, self.num_being_sampled, cppify(numpy.array(self._best_so_far_list)),
+            self._num_mc_iterations, max_num_threads, randomness, status))
+
+
+def multistart_expected_improvement_mcmc_optimization(ei_optimizer, num_multistarts, num_to_sample, randomness=None,
+                                                      max_num_threads=DEFAULT_MAX_NUM_THREADS, status=None):
+    """cpp_wrappers/expected_improvement_mcmc.py:22-57."""
+    randomness = _default_randomness(randomness, max_num_threads)
+    status = {} if status is None else status
+    ei = ei_optimizer.objective_function
+    best = C_GP.multistart_expected_improvement_mcmc_optimization(
+        ei_optimizer.optimizer_parameters, ei._gaussian_process_mcmc._gaussian_process_mcmc,
+        [float(x) for x in cppify(ei_optimizer.domain.domain_bounds)], cppify(ei._points_being_sampled), num_to_sample,
+        ei.num_being_sampled, cppify(numpy.array(ei._best_so_far_list)), ei._num_mc_iterations, max_num_threads, randomness, status)
+    return uncppify(best, (num_to_sample, ei.dim))

@@ -384,6 +384,89 @@ int moe_kg_multistart(const moe_gp_t* gp_c, int num_fidelity, const moe_gd_param
   });
 }
 
+namespace {
+std::vector<moe::GpDev*> ensemble(const moe_gp_t* const* gps, int num_mcmc) {
+  require(gps != nullptr && num_mcmc > 0, "empty MCMC ensemble");
+  std::vector<moe::GpDev*> v(num_mcmc);
+  for (int i = 0; i < num_mcmc; ++i) {
+    require(gps[i] != nullptr, "NULL GP handle in the MCMC ensemble");
+    v[i] = &const_cast<moe_gp_t*>(gps[i])->dev;
+  }
+  return v;
+}
+}  // namespace
+
+int moe_kg_mcmc_batch(const moe_gp_t* const* gps, int num_mcmc, int num_fidelity, const moe_gd_params_t* inner_params,
+                      const double* domain_bounds, const double* discrete_pts_all, int num_pts,
+                      const double* points_to_sample_all, int num_evals, const double* points_being_sampled, int num_to_sample,
+                      int num_being_sampled, int num_mc, const double* best_so_far, const double* normals, int finalize,
+                      int total_num_mcmc, double* kg, double* grad_kg, moe_error_t* err) {
+  return guarded(err, [&] {
+    require(inner_params && domain_bounds && discrete_pts_all && points_to_sample_all && best_so_far && normals && kg,
+            "NULL argument");
+    require(num_evals > 0, "num_evals must be positive");
+    const std::vector<moe::GpDev*> v = ensemble(gps, num_mcmc);
+    moe::kg_mcmc_sums(v, num_fidelity, *inner_params, domain_bounds, discrete_pts_all, num_pts, points_to_sample_all, num_evals,
+                      points_being_sampled, num_to_sample, num_being_sampled, num_mc, best_so_far, normals, grad_kg != nullptr,
+                      kg, grad_kg);
+    if (finalize)
+      moe::kg_mcmc_finalize(kg, grad_kg, points_to_sample_all, num_evals, num_to_sample, v[0]->d, num_fidelity,
+                            total_num_mcmc > 0 ? total_num_mcmc : num_mcmc);
+  });
+}
+
+int moe_kg_mcmc_finalize(double* kg, double* grad_kg, const double* points_to_sample_all, int num_evals, int num_to_sample,
+                         int dim, int num_fidelity, int total_num_mcmc) {
+  if (!kg || !points_to_sample_all || num_evals <= 0 || num_to_sample <= 0 || dim <= 0 || num_fidelity < 0 ||
+      num_fidelity >= dim || total_num_mcmc <= 0)
+    return MOE_ERR_BOUNDS;
+  moe::kg_mcmc_finalize(kg, grad_kg, points_to_sample_all, num_evals, num_to_sample, dim, num_fidelity, total_num_mcmc);
+  return MOE_OK;
+}
+
+int moe_ei_mcmc_batch(const moe_gp_t* const* gps, int num_mcmc, const double* points_to_sample_all, int num_evals,
+                      const double* points_being_sampled, int num_to_sample, int num_being_sampled, int num_mc,
+                      const double* best_so_far, const double* normals, int analytic, double* ei, double* grad_ei,
+                      moe_error_t* err) {
+  return guarded(err, [&] {
+    require(points_to_sample_all && best_so_far && (analytic || normals), "NULL argument");
+    require(num_evals > 0, "num_evals must be positive");
+    const std::vector<moe::GpDev*> v = ensemble(gps, num_mcmc);
+    moe::ei_mcmc_batch(v, points_to_sample_all, num_evals, points_being_sampled, num_to_sample, num_being_sampled, num_mc,
+                       best_so_far, normals, analytic != 0, ei, grad_ei);
+  });
+}
+
+int moe_kg_mcmc_multistart(const moe_gp_t* const* gps, int num_mcmc, int num_fidelity, const moe_gd_params_t* outer_params,
+                           const moe_gd_params_t* inner_params, const double* domain_bounds, const double* discrete_pts_all,
+                           int num_pts, const double* start_points, int num_starts, const double* points_being_sampled,
+                           int num_to_sample, int num_being_sampled, int num_mc, const double* best_so_far,
+                           const double* normals, int do_gradient_ascent, double* best_points, double* best_kg, int* found,
+                           moe_error_t* err) {
+  return guarded(err, [&] {
+    require(outer_params && inner_params && domain_bounds && discrete_pts_all && start_points && best_so_far && normals &&
+                best_points && best_kg && found,
+            "NULL argument");
+    const std::vector<moe::GpDev*> v = ensemble(gps, num_mcmc);
+    moe::kg_mcmc_multistart(v, num_fidelity, *outer_params, *inner_params, domain_bounds, discrete_pts_all, num_pts, start_points,
+                            num_starts, points_being_sampled, num_to_sample, num_being_sampled, num_mc, best_so_far, normals,
+                            do_gradient_ascent, best_points, best_kg, found);
+  });
+}
+
+int moe_ei_mcmc_multistart(const moe_gp_t* const* gps, int num_mcmc, const moe_gd_params_t* outer_params,
+                           const double* domain_bounds, const double* start_points, int num_starts,
+                           const double* points_being_sampled, int num_to_sample, int num_being_sampled, int num_mc,
+                           const double* best_so_far, const double* normals, int do_gradient_ascent, double* best_points,
+                           double* best_ei, int* found, moe_error_t* err) {
+  return guarded(err, [&] {
+    require(outer_params && domain_bounds && start_points && best_so_far && best_points && best_ei && found, "NULL argument");
+    const std::vector<moe::GpDev*> v = ensemble(gps, num_mcmc);
+    moe::ei_mcmc_multistart(v, *outer_params, domain_bounds, start_points, num_starts, points_being_sampled, num_to_sample,
+                            num_being_sampled, num_mc, best_so_far, normals, do_gradient_ascent, best_points, best_ei, found);
+  });
+}
+
 int moe_posterior_mean_optimize(const moe_gp_t* gp_c, int num_fidelity, const moe_gd_params_t* params,
                                 const double* domain_bounds, const double* initial_guess, double* best_point,
                                 double* best_value, moe_error_t* err) {

@@ -1,5 +1,8 @@
 // cornell_moe_amd/csrc/kg.hpp -- Monte-Carlo acquisition evaluators (q-EI, q-KG) on the device GP.
 #pragma once
+#include <functional>
+#include <vector>
+
 #include "gp.hpp"
 
 namespace moe {
@@ -26,6 +29,15 @@ void kg_evaluate_batch(GpDev& gp, int num_fidelity, const moe_gd_params_t& gd, c
                        double* kg_sum, double* grad_sum, double* best_points, moe_kg_stats_t* stats);
 
 // ---- callers of the hot path (multistart.hip) ----
+// A maximisation objective evaluated at a BATCH of points [n][qd]: values [n], grads [n][qd].
+struct BatchObjective {
+  std::function<void(const double* x_all, int n, double* values)> values;
+  std::function<void(const double* x_all, int n, double* grads)> grads;
+};
+// MultistartOptimizer over a batched objective: see multistart.hip.  bounds[2*d] apply to each of the qd/d points.
+void multistart(const BatchObjective& f, const moe_gd_params_t& outer, const double* bounds, int d, int qd, const double* starts,
+                int num_starts, int do_gradient_ascent, double floor_value, double* best_points, double* best_value,
+                int* found);
 // ComputeLatinHypercubePointsInDomain (gpp_random.cpp:173-194): out[num_points][dim], mt19937(seed).
 void latin_hypercube(unsigned int seed, const double* bounds, int dim, int num_points, double* out);
 // ComputeKGOptimalPointsToSampleViaMultistartGradientDescent / ...ViaLatinHypercubeSearch
@@ -42,5 +54,25 @@ void ei_multistart(GpDev& gp, const moe_gd_params_t& outer, const double* bounds
 // ComputeOptimalPosteriorMean from one initial guess (gpp_knowledge_gradient_optimization.cpp:420-472).
 void posterior_mean_optimize(GpDev& gp, int num_fidelity, const moe_gd_params_t& gd, const double* bounds, const double* x0,
                              double* best_point, double* best_value);
+
+// ---- MCMC-averaged evaluators (mcmc.hip): `gps` are num_mcmc device GPs over the same data, one per
+// hyper-parameter sample (GaussianProcessMCMC, gpp_knowledge_gradient_mcmc_optimization.cpp:24-49) ----
+// Sums over the given GPs of the per-GP KG / grad KG (each already divided by num_mc): kg_sum[E], grad_sum[E][q*d].
+void kg_mcmc_sums(const std::vector<GpDev*>& gps, int num_fidelity, const moe_gd_params_t& inner, const double* bounds,
+                  const double* discrete_all, int P, const double* Xq_all, int num_evals, const double* Xp, int q, int p,
+                  int num_mc, const double* best_so_far, const double* normals, bool want_grad, double* kg_sum, double* grad_sum);
+// KnowledgeGradientMCMCEvaluator::Compute[Grad]KnowledgeGradient's last step (.cpp:84-180): divide by num_mcmc and by the
+// fidelity cost (and add the cost-gradient term).  In place; grad may be NULL.
+void kg_mcmc_finalize(double* kg, double* grad, const double* Xq_all, int num_evals, int q, int d, int num_fidelity, int num_mcmc);
+void ei_mcmc_batch(const std::vector<GpDev*>& gps, const double* Xq_all, int num_evals, const double* Xp, int q, int p, int num_mc,
+                   const double* best_so_far, const double* normals, bool analytic, double* ei, double* grad_ei);
+void kg_mcmc_multistart(const std::vector<GpDev*>& gps, int num_fidelity, const moe_gd_params_t& outer,
+                        const moe_gd_params_t& inner, const double* bounds, const double* discrete_all, int P,
+                        const double* starts, int num_starts, const double* Xp, int q, int p, int num_mc,
+                        const double* best_so_far, const double* normals, int do_gradient_ascent, double* best_points,
+                        double* best_kg, int* found);
+void ei_mcmc_multistart(const std::vector<GpDev*>& gps, const moe_gd_params_t& outer, const double* bounds, const double* starts,
+                        int num_starts, const double* Xp, int q, int p, int num_mc, const double* best_so_far,
+                        const double* normals, int do_gradient_ascent, double* best_points, double* best_ei, int* found);
 
 }  // namespace moe

@@ -69,12 +69,6 @@ void kg_values(GpDev& gp, int num_fidelity, const moe_gd_params_t& inner, const 
 
 namespace {
 
-// A maximisation objective evaluated at a BATCH of points [n][qd]: values [n], grads [n][qd].
-struct BatchObjective {
-  std::function<void(const double* x_all, int n, double* values)> values;
-  std::function<void(const double* x_all, int n, double* grads)> grads;
-};
-
 // GradientDescentOptimizer::Optimize (gpp_optimization.hpp:619-705, 1144-1185) for every start at once; x [S][qd] in place.
 // bounds are per coordinate of ONE point (RepeatedDomain applies them to each of the q points, gpp_domain.hpp:509-520).
 void gradient_ascent(const BatchObjective& f, const moe_gd_params_t& outer, const double* bounds, int d, int qd, double* x,
@@ -114,6 +108,8 @@ void gradient_ascent(const BatchObjective& f, const moe_gd_params_t& outer, cons
   }
 }
 
+}  // namespace
+
 // Value at every start, the best 20 kept, restarted ascent on each, value at every end point, best one returned if it
 // beats `floor_value` (MultistartOptimizer, gpp_optimization.hpp:1472-1546; the reference seeds its IO container with
 // -inf for KG, gpp_knowledge_gradient_optimization.hpp:924, and -1.0 for EI, gpp_math.hpp:1728).
@@ -134,12 +130,16 @@ void multistart(const BatchObjective& f, const moe_gd_params_t& outer, const dou
     S = std::min(num_starts, kTopK);
     ends.resize((size_t)S * qd);
     for (int s = 0; s < S; ++s) std::copy(starts + (size_t)order[s] * qd, starts + (size_t)(order[s] + 1) * qd, &ends[(size_t)s * qd]);
+    // what the reference returns when nothing beats floor_value: the point its IO container was seeded with, i.e. the first
+    // entry popped from its top-20 queue = the lowest-valued kept start (gpp_math.hpp:1717-1728)
+    std::copy(&ends[(size_t)(S - 1) * qd], &ends[(size_t)S * qd], best_points);
     gradient_ascent(f, outer, bounds, d, qd, ends.data(), S);
     end_vals.resize(S);
     f.values(ends.data(), S, end_vals.data());
   } else {
     ends.assign(starts, starts + (size_t)num_starts * qd);
     end_vals = vals;
+    std::copy(starts, starts + qd, best_points);  // seeded with the first point of the list (gpp_math.cpp:2326)
   }
   for (int s = 0; s < S; ++s) {
     if (end_vals[s] > *best_value) {  // strict, like MultistartOptimizer's compare (gpp_optimization.hpp:1512)
@@ -149,8 +149,6 @@ void multistart(const BatchObjective& f, const moe_gd_params_t& outer, const dou
     }
   }
 }
-
-}  // namespace
 
 void kg_multistart(GpDev& gp, int num_fidelity, const moe_gd_params_t& outer, const moe_gd_params_t& inner, const double* bounds,
                    const double* discrete, int P, const double* starts, int num_starts, const double* Xp, int q, int p,

@@ -8,6 +8,9 @@ The path shards on two independent axes:
   * MC samples of one evaluation: contiguous EVEN-ALIGNED slices (antithetic pairs 2j/2j+1 stay together,
     gpp_knowledge_gradient_optimization.cpp:171-180); ONE all_reduce(SUM) of 1 + q*d doubles (264 B at the headline
     shape) -- latency-bound, so it is a single fused collective per evaluation.
+  * GP index of an MCMC-averaged evaluation (num_mcmc GPs over the same data): rank r builds and
+    evaluates members r, r+W, ...; ONE all_reduce(SUM) of E x (1 + q*d) doubles of plain per-GP sums, then the mean /
+    fidelity-cost step (moe_kg_mcmc_finalize) on every rank.
 torch is used for the process group and the collective only; compute goes through the C ABI.
 """
 import numpy as np
@@ -85,3 +88,24 @@ def gather_restarts(local_idx, local_kg, local_grad, num_restarts, group=None, d
                 kg[gi] = row[1]
                 grad[gi] = row[2:].reshape(grad.shape[1:])
     return kg, grad
+
+
+def shard_members(num_mcmc, rank, world):
+    """GP indices of an MCMC ensemble that `rank` builds and evaluates (round-robin)."""
+    return list(range(rank, num_mcmc, world))
+
+
+def kg_mcmc_sharded(local_sums, finalize, group=None, device=None):
+    """One batch of MCMC-averaged KG evaluations with the GP index sharded over the ranks.
+
+    local_sums() -> (kg_sum [E], grad_sum [E][q][d]): DeviceGPMCMC(members=shard_members(...)).kg_batch(..., finalize=False)
+    (zeros when this rank owns no member); finalize(kg_sum, grad_sum) -> (kg [E], grad [E][q][d]) is
+    DeviceGPMCMC.kg_finalize (mean over ALL members, fidelity cost and its gradient term)."""
+    import torch.distributed as dist
+    kg_sum, grad_sum = local_sums()
+    kg_sum = np.asarray(kg_sum, dtype=np.float64)
+    grad_sum = np.asarray(grad_sum, dtype=np.float64)
+    t = _tensor(np.concatenate([kg_sum.ravel(), grad_sum.ravel()]), device)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    out = t.cpu().numpy()
+    return finalize(out[:kg_sum.size].reshape(kg_sum.shape), out[kg_sum.size:].reshape(grad_sum.shape))

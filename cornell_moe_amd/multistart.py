@@ -201,6 +201,63 @@ def ei_optimal_points(dev_gp, optimizer_parameters, bounds, Xp, num_to_sample, b
     return best, found
 
 
+def _lhc_starts(randomness, bounds, count, q, d):
+    """RepeatedDomain::GenerateUniformPointsInDomain: one Latin hypercube per repeat (gpp_domain.hpp:490-504)."""
+    from . import api
+    out = np.empty((count, q, d))
+    for r in range(q):
+        out[:, r, :] = api.latin_hypercube(randomness._next_uniform_seed(), bounds, count)
+    return out
+
+
+def kg_mcmc_optimal_points(dev_mcmc, num_fidelity, optimizer_parameters, optimizer_parameters_inner, bounds, discrete_all, Xp,
+                           num_to_sample, best_so_far, num_mc, randomness):
+    """ComputeKGMCMCOptimalPointsToSample (gpp_knowledge_gradient_mcmc_optimization.cpp:236-296): kg_optimal_points on the
+    MCMC-averaged, cost-scaled objective.  Returns (best_points [q][dim], found)."""
+    from . import GPP
+    d, q = dev_mcmc.d, int(num_to_sample)
+    bounds = np.asarray(bounds, dtype=np.float64).reshape(-1)[:2 * d]
+    inner_gd = _gd(optimizer_parameters_inner)
+    p = 0 if Xp is None else np.asarray(Xp).reshape(-1, d).shape[0]
+    normals = randomness.normal_rng_vec[0].table(((num_mc + 1) // 2) * (q + p) * (1 + dev_mcmc.g))
+    use_gd = int(optimizer_parameters.optimizer_type) == int(GPP.OptimizerTypes.gradient_descent)
+    best, found = np.zeros((q, d)), False
+    if use_gd:
+        gd = _gd(optimizer_parameters)
+        best, _, found = dev_mcmc.kg_multistart(gd, inner_gd, bounds, discrete_all, _lhc_starts(randomness, bounds, gd[0], q, d), Xp,
+                                                num_mc, best_so_far, normals, gradient_ascent=True, num_fidelity=num_fidelity)
+    if not found:
+        n_lhc = int(optimizer_parameters.num_random_samples or 0)
+        if n_lhc > 0:
+            best, _, found = dev_mcmc.kg_multistart(inner_gd, inner_gd, bounds, discrete_all,
+                                                    _lhc_starts(randomness, bounds, n_lhc, q, d), Xp, num_mc, best_so_far, normals,
+                                                    gradient_ascent=False, num_fidelity=num_fidelity)
+    return best, found
+
+
+def ei_mcmc_optimal_points(dev_mcmc, optimizer_parameters, bounds, Xp, num_to_sample, best_so_far, num_mc, randomness):
+    """ComputeMCMCOptimalPointsToSample (gpp_expected_improvement_mcmc_optimization.cpp:300-388): ei_optimal_points on the
+    MCMC-averaged EI.  Returns (best_points [q][dim], found)."""
+    from . import GPP
+    d, q = dev_mcmc.d, int(num_to_sample)
+    bounds = np.asarray(bounds, dtype=np.float64).reshape(-1)[:2 * d]
+    p = 0 if Xp is None else np.asarray(Xp).reshape(-1, d).shape[0]
+    normals = None if (q == 1 and p == 0) else randomness.normal_rng_vec[0].table(int(num_mc) * (q + p))
+    use_gd = int(optimizer_parameters.optimizer_type) == int(GPP.OptimizerTypes.gradient_descent)
+    best, found = np.zeros((q, d)), False
+    if use_gd:
+        gd = _gd(optimizer_parameters)
+        best, _, found = dev_mcmc.ei_multistart(gd, bounds, _lhc_starts(randomness, bounds, gd[0], q, d), Xp, num_mc, best_so_far,
+                                                normals, gradient_ascent=True)
+    if not found:
+        n_lhc = int(optimizer_parameters.num_random_samples or 0)
+        if n_lhc > 0:
+            best, _, found = dev_mcmc.ei_multistart((1, 1, 0, 0, 1.0, 1.0, 1.0, 0.0), bounds,
+                                                    _lhc_starts(randomness, bounds, n_lhc, q, d), Xp, num_mc, best_so_far, normals,
+                                                    gradient_ascent=False)
+    return best, found
+
+
 def posterior_mean_optimization(dev_gp, num_fidelity, optimizer_parameters, bounds, initial_guess):
     """ComputeOptimalPosteriorMean from ONE start (moe_posterior_mean_optimize).  Returns (best_point, found_flag)."""
     size = dev_gp.d - num_fidelity

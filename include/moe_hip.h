@@ -198,6 +198,49 @@ int moe_posterior_mean_optimize(const moe_gp_t* gp, int num_fidelity, const moe_
 /* ComputeLatinHypercubePointsInDomain (gpp_random.cpp:173-194) with mt19937(seed): out[num_points][dim]. */
 int moe_latin_hypercube(unsigned int seed, const double* domain_bounds, int dim, int num_points, double* out);
 
+/* ---- MCMC-averaged evaluators: the acquisition averaged over `num_mcmc` GPs built on the same data, one
+ * per hyper-parameter sample -- GaussianProcessMCMC (gpp_knowledge_gradient_mcmc_optimization.cpp:24-49; Python ctor
+ * gpp_python_knowledge_gradient_mcmc.cpp:45-75).  `gps` is an array of num_mcmc handles from moe_gp_create (the caller owns
+ * them; they must share dim and the observed-derivative list).  best_so_far[num_mcmc] is per GP; every GP replays the same
+ * normal table. ----
+ * compute_knowledge_gradient_mcmc / compute_grad_knowledge_gradient_mcmc / evaluate_KG_mcmc_at_point_list
+ * (gpp_python_knowledge_gradient_mcmc.cpp:77-190, 400-470 -> KnowledgeGradientMCMCEvaluator, .cpp:51-180) for `num_evals`
+ * point sets points_to_sample_all[num_evals][q][dim]; discrete_pts_all[num_mcmc][num_pts][dim - num_fidelity].
+ * finalize != 0: kg[e] = mean_i KG_i / cost, grad likewise with the cost-gradient term (cost = largest product of the
+ * fidelity coordinates over the q points, 1 when num_fidelity == 0; .cpp:84-127), normalised by total_num_mcmc.
+ * finalize == 0: plain sums over the GPs given -- the GP-index shard of a multi-GPU evaluation, to be all-reduced and then
+ * passed through moe_kg_mcmc_finalize.  grad_kg may be NULL (value only). */
+int moe_kg_mcmc_batch(const moe_gp_t* const* gps, int num_mcmc, int num_fidelity, const moe_gd_params_t* inner_params,
+                      const double* domain_bounds, const double* discrete_pts_all, int num_pts,
+                      const double* points_to_sample_all, int num_evals, const double* points_being_sampled, int num_to_sample,
+                      int num_being_sampled, int num_mc, const double* best_so_far, const double* normals, int finalize,
+                      int total_num_mcmc, double* kg, double* grad_kg, moe_error_t* err);
+int moe_kg_mcmc_finalize(double* kg, double* grad_kg, const double* points_to_sample_all, int num_evals, int num_to_sample,
+                         int dim, int num_fidelity, int total_num_mcmc);
+/* compute_expected_improvement_mcmc / compute_grad_expected_improvement_mcmc / evaluate_EI_mcmc_at_point_list
+ * (gpp_python_expected_improvement_mcmc.cpp:42-108 -> ExpectedImprovementMCMCEvaluator,
+ * gpp_expected_improvement_mcmc_optimization.cpp:48-88); analytic != 0 takes the 1,0-EI evaluator (:136-176; needs
+ * num_to_sample == 1, num_being_sampled == 0; normals may be NULL).  ei and/or grad_ei may be NULL. */
+int moe_ei_mcmc_batch(const moe_gp_t* const* gps, int num_mcmc, const double* points_to_sample_all, int num_evals,
+                      const double* points_being_sampled, int num_to_sample, int num_being_sampled, int num_mc,
+                      const double* best_so_far, const double* normals, int analytic, double* ei, double* grad_ei,
+                      moe_error_t* err);
+/* multistart_knowledge_gradient_mcmc_optimization / multistart_expected_improvement_mcmc_optimization from caller-supplied
+ * starts (gpp_knowledge_gradient_mcmc_optimization.hpp:665-862, gpp_expected_improvement_mcmc_optimization.hpp:840-990):
+ * same driver as moe_kg_multistart / moe_ei_multistart on the MCMC-averaged objective.  The EI driver reports found = 0
+ * unless some end point has EI > 0 (the reference seeds it with 0.0, not -1.0). */
+int moe_kg_mcmc_multistart(const moe_gp_t* const* gps, int num_mcmc, int num_fidelity, const moe_gd_params_t* outer_params,
+                           const moe_gd_params_t* inner_params, const double* domain_bounds, const double* discrete_pts_all,
+                           int num_pts, const double* start_points, int num_starts, const double* points_being_sampled,
+                           int num_to_sample, int num_being_sampled, int num_mc, const double* best_so_far,
+                           const double* normals, int do_gradient_ascent, double* best_points, double* best_kg, int* found,
+                           moe_error_t* err);
+int moe_ei_mcmc_multistart(const moe_gp_t* const* gps, int num_mcmc, const moe_gd_params_t* outer_params,
+                           const double* domain_bounds, const double* start_points, int num_starts,
+                           const double* points_being_sampled, int num_to_sample, int num_being_sampled, int num_mc,
+                           const double* best_so_far, const double* normals, int do_gradient_ascent, double* best_points,
+                           double* best_ei, int* found, moe_error_t* err);
+
 /* ---- covariance assembly (exposed for parity tests and the HBM-roofline measurement) ----
  * BuildMixCovarianceMatrix (gpp_math.cpp:309-335, 469-479): out[N x num_pts*(1+g2)] col-major = K(X, pts) with
  * derivative blocks; derivs2[g2] are the derivative observations carried by `pts`. */

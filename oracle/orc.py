@@ -249,3 +249,73 @@ class OrcGP(object):
             raise SingularMatrix("singular at minor %d" % rc)
         return dict(kg=kg.value, grad=grad.reshape(q, self.d) if want_grad else None,
                     best_point=best_point.reshape(M, self.d), mean_evals=counters[0], grad_evals=counters[1])
+
+
+class OrcGPMCMC(object):
+    """Restatement of the MCMC-averaged evaluators on top of OrcGP (numpy level): GaussianProcessMCMC builds one Matern-5/2 GP
+    per hyper-parameter sample (gpp_knowledge_gradient_mcmc_optimization.cpp:24-49); the evaluators average the per-GP
+    results and, for KG, divide by the fidelity cost (:84-180; gpp_expected_improvement_mcmc_optimization.cpp:48-88)."""
+
+    def __init__(self, hypers, noises, X, y, derivs):
+        X = np.ascontiguousarray(X, dtype=np.float64)
+        self.n, self.d = X.shape
+        self.derivs = [int(v) for v in derivs]
+        self.g = len(self.derivs)
+        hypers = np.asarray(hypers, dtype=np.float64).reshape(-1, self.d + 1)
+        noises = np.asarray(noises, dtype=np.float64).reshape(-1, 1 + self.g)
+        self.num_mcmc = hypers.shape[0]
+        self.gps = [OrcGP(1, float(hypers[i, 0]), hypers[i, 1:], X, y, noises[i], self.derivs) for i in range(self.num_mcmc)]
+
+    @staticmethod
+    def cost(Xq, num_fidelity):
+        """ComputeCost / ComputeGradCost (:84-127): the largest product of the fidelity coordinates over the q points."""
+        Xq = np.asarray(Xq, dtype=np.float64)
+        q, d = Xq.shape
+        grad = np.zeros((q, d))
+        if num_fidelity == 0:
+            return 1.0, grad
+        cost, index = 0.0, -1
+        for i in range(q):
+            pc = float(np.prod(Xq[i, d - num_fidelity:]))
+            if cost < pc:
+                cost, index = pc, i
+        for j in range(d - num_fidelity, d):
+            grad[index, j] = cost / Xq[index, j]
+        return cost, grad
+
+    def kg(self, gd, bounds, discrete_all, Xq, Xp, M, best_so_far, normals, want_grad=True, num_fidelity=0):
+        Xq = np.asarray(Xq, dtype=np.float64).reshape(-1, self.d)
+        discrete_all = np.asarray(discrete_all, dtype=np.float64).reshape(self.num_mcmc, -1, self.d - num_fidelity)
+        kg, grad = 0.0, np.zeros_like(Xq)
+        for i, gp in enumerate(self.gps):
+            r = gp.kg(gd, bounds, discrete_all[i], Xq, Xp, M, float(best_so_far[i]), normals, want_grad=want_grad,
+                      num_fidelity=num_fidelity)
+            kg += r["kg"]
+            if want_grad:
+                grad += r["grad"]
+        cost, gcost = self.cost(Xq, num_fidelity)
+        kg_mean = kg / self.num_mcmc
+        if not want_grad:
+            return kg_mean / cost, None
+        grad = (grad / self.num_mcmc * cost - kg_mean * gcost) / (cost * cost)
+        return kg_mean / cost, grad
+
+    def ei(self, Xq, Xp, M, best_so_far, normals, want_grad=True):
+        Xq = np.asarray(Xq, dtype=np.float64).reshape(-1, self.d)
+        ei, grad = 0.0, np.zeros_like(Xq)
+        for i, gp in enumerate(self.gps):
+            v, g = gp.ei(Xq, Xp, M, float(best_so_far[i]), normals, want_grad=want_grad)
+            ei += v
+            if want_grad:
+                grad += g
+        return ei / self.num_mcmc, (grad / self.num_mcmc if want_grad else None)
+
+    def ei_analytic(self, pt, best_so_far, want_grad=True):
+        """OnePotentialSampleExpectedImprovementMCMCEvaluator (gpp_expected_improvement_mcmc_optimization.cpp:136-176)."""
+        ei, grad = 0.0, np.zeros(self.d)
+        for i, gp in enumerate(self.gps):
+            v, g = gp.ei_analytic(pt, float(best_so_far[i]), want_grad=want_grad)
+            ei += v
+            if want_grad:
+                grad += g
+        return ei / self.num_mcmc, (grad / self.num_mcmc if want_grad else None)

@@ -51,6 +51,13 @@ def lib():
         _lib.ref_ei.argtypes = [C.c_void_p, _dp, _dp, C.c_int, C.c_int, C.c_int, C.c_double, _dp, _dp, _dp, _dp]
         _lib.ref_ei_analytic.argtypes = [C.c_void_p, _dp, C.c_double, _dp, _dp]
         _lib.ref_ei_multistart_analytic.argtypes = [C.c_void_p, _dp, _dp, _dp, C.c_int, C.c_double, C.POINTER(C.c_int), _dp]
+        _lib.ref_gpmcmc_create.restype = C.c_void_p
+        _lib.ref_gpmcmc_create.argtypes = [_dp, _dp, C.c_int, _dp, _dp, _ip, C.c_int, C.c_int, C.c_int]
+        _lib.ref_gpmcmc_destroy.argtypes = [C.c_void_p]
+        _lib.ref_kg_mcmc.argtypes = [C.c_void_p, C.c_int, _dp, _dp, _dp, C.c_int, _dp, _dp, C.c_int, C.c_int, C.c_int, _dp, _dp,
+                                     C.c_long, C.c_int, _dp, _dp]
+        _lib.ref_ei_mcmc.argtypes = [C.c_void_p, _dp, _dp, C.c_int, C.c_int, C.c_int, _dp, _dp, _dp, _dp]
+        _lib.ref_ei_mcmc_multistart_analytic.argtypes = [C.c_void_p, _dp, _dp, _dp, C.c_int, _dp, C.POINTER(C.c_int), _dp]
         _lib.ref_kg.argtypes = [C.c_void_p, C.c_int, _dp, _dp, _dp, C.c_int, _dp, _dp, C.c_int, C.c_int, C.c_int,
                                 C.c_double, _dp, C.c_long, C.c_int, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp]
         _lib.ref_kg_grad_batch.argtypes = [C.c_void_p, C.c_int, _dp, _dp, _dp, C.c_int, _dp, C.c_int, C.c_int, C.c_int,
@@ -288,3 +295,80 @@ class RefGP(object):
 
 def num_procs():
     return lib().ref_num_procs()
+
+
+class RefGPMCMC(object):
+    """The reference GaussianProcessMCMC (gpp_knowledge_gradient_mcmc_optimization.hpp:140-198): one Matern-5/2 GP per
+    hyper-parameter sample over the same data.  hypers [num_mcmc][1 + d] = (alpha, lengths), noises [num_mcmc][1 + g]."""
+
+    def __init__(self, hypers, noises, X, y, derivs):
+        X = np.ascontiguousarray(X, dtype=np.float64)
+        self.n, self.d = X.shape
+        self.derivs = [int(v) for v in derivs]
+        self.g = len(self.derivs)
+        hypers, hp = _d(hypers)
+        noises, nop = _d(noises)
+        self.num_mcmc = hypers.reshape(-1, self.d + 1).shape[0]
+        ya, yp = _d(y)
+        da, dp = _i(self.derivs)
+        self.h = lib().ref_gpmcmc_create(hp, nop, self.num_mcmc, X.ctypes.data_as(_dp), yp, dp, self.g, self.d, self.n)
+        if not self.h:
+            raise RefError(4, lib().ref_last_error().decode("utf-8", "replace"))
+
+    def __del__(self):
+        try:
+            if getattr(self, "h", None):
+                lib().ref_gpmcmc_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    def kg(self, gd, bounds, discrete_all, Xq, Xp, M, best_so_far, normals, want_grad=True, num_fidelity=0):
+        """KnowledgeGradientMCMCEvaluator: (KG, grad [q][d] or None).  discrete_all [num_mcmc][P][d-f]; best_so_far [num_mcmc]."""
+        gd, gdp = _d(gd)
+        bounds, bp = _d(bounds)
+        discrete_all, dp = _d(discrete_all)
+        P = discrete_all.reshape(self.num_mcmc, -1, self.d - num_fidelity).shape[1]
+        Xq, qp = _d(Xq)
+        q = Xq.reshape(-1, self.d).shape[0]
+        if Xp is None or len(Xp) == 0:
+            p, pp = 0, None
+        else:
+            Xp, pp = _d(Xp)
+            p = Xp.reshape(-1, self.d).shape[0]
+        best, bsp = _d(best_so_far)
+        normals, npp = _d(normals)
+        kg = C.c_double(0.0)
+        grad = np.zeros(q * self.d)
+        _check(lib().ref_kg_mcmc(self.h, num_fidelity, gdp, bp, dp, P, qp, pp, q, p, M, bsp, npp, normals.size,
+                                 1 if want_grad else 0, C.byref(kg), grad.ctypes.data_as(_dp)))
+        return kg.value, (grad.reshape(q, self.d) if want_grad else None)
+
+    def ei(self, Xq, Xp, M, best_so_far, normals, want_grad=True):
+        Xq, qp = _d(Xq)
+        q = Xq.reshape(-1, self.d).shape[0]
+        if Xp is None or len(Xp) == 0:
+            p, pp = 0, None
+        else:
+            Xp, pp = _d(Xp)
+            p = Xp.reshape(-1, self.d).shape[0]
+        best, bsp = _d(best_so_far)
+        normals, npp = _d(normals)
+        assert normals.size >= M * (q + p)
+        ei = C.c_double(0.0)
+        grad = np.zeros(q * self.d)
+        _check(lib().ref_ei_mcmc(self.h, qp, pp, q, p, M, bsp, npp, C.byref(ei), grad.ctypes.data_as(_dp) if want_grad else None))
+        return ei.value, (grad.reshape(q, self.d) if want_grad else None)
+
+    def ei_multistart_analytic(self, gd, bounds, starts, best_so_far):
+        """ComputeEIMCMCOptimalPointsToSampleViaMultistartGradientDescent at q = 1, p = 0: (best_point [d], found)."""
+        gd, gdp = _d(gd)
+        bounds, bp = _d(bounds)
+        starts, sp = _d(starts)
+        S = starts.reshape(-1, self.d).shape[0]
+        assert S >= 20, "the reference pops its top-20 queue unconditionally"
+        best_so_far, bsp = _d(best_so_far)
+        found = C.c_int(0)
+        best = np.zeros(self.d)
+        _check(lib().ref_ei_mcmc_multistart_analytic(self.h, gdp, bp, sp, S, bsp, C.byref(found), best.ctypes.data_as(_dp)))
+        return best, bool(found.value)

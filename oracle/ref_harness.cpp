@@ -31,6 +31,8 @@
 #include "gpp_domain.hpp"
 #include "gpp_exception.hpp"
 #include "gpp_geometry.hpp"
+#include "gpp_expected_improvement_mcmc_optimization.hpp"
+#include "gpp_knowledge_gradient_mcmc_optimization.hpp"
 #include "gpp_knowledge_gradient_optimization.hpp"
 #include "gpp_linear_algebra.hpp"
 #include "gpp_optimization.hpp"
@@ -326,6 +328,92 @@ int ref_kg(void* hv, int num_fidelity, const double* gd, const double* bounds, c
       seconds[0] = std::chrono::duration<double>(t1 - t0).count();
       seconds[1] = std::chrono::duration<double>(t2 - t1).count();
     }
+  });
+}
+
+// ---- MCMC-averaged evaluators: GaussianProcessMCMC (gpp_knowledge_gradient_mcmc_optimization.cpp:24-49),
+// KnowledgeGradientMCMCEvaluator (:51-180), ExpectedImprovementMCMCEvaluator (gpp_expected_improvement_mcmc_optimization.cpp) ----
+void* ref_gpmcmc_create(const double* hypers, const double* noises, int num_mcmc, const double* X, const double* y,
+                        const int* derivs, int g, int d, int n) {
+  GaussianProcessMCMC* h = nullptr;
+  const int rc = guarded([&] { h = new GaussianProcessMCMC(hypers, noises, num_mcmc, X, y, nn(derivs), g, d, n); });
+  return rc == 0 ? h : nullptr;
+}
+
+void ref_gpmcmc_destroy(void* hv) { delete static_cast<GaussianProcessMCMC*>(hv); }
+
+// discrete_all[num_mcmc][P][d - num_fidelity]; best_so_far[num_mcmc]; normals as for ref_kg (every GP replays the same
+// stream: each per-GP evaluator rewinds the shared RNG, gpp_knowledge_gradient_optimization.cpp:78, 139).
+int ref_kg_mcmc(void* hv, int num_fidelity, const double* gd, const double* bounds, const double* discrete_all, int P,
+                const double* Xq, const double* Xp, int q, int p, int M, const double* best_so_far, const double* normals,
+                long num_normals, int want_grad, double* kg, double* grad) {
+  return guarded([&] {
+    GaussianProcessMCMC* gpm = static_cast<GaussianProcessMCMC*>(hv);
+    const int d = gpm->dim();
+    std::vector<ClosedInterval> iv(d - num_fidelity);
+    for (int i = 0; i < d - num_fidelity; ++i) iv[i] = ClosedInterval(bounds[2 * i], bounds[2 * i + 1]);
+    TensorProductDomain dom(iv.data(), d - num_fidelity);
+    GradientDescentParameters gdp(static_cast<int>(gd[0]), static_cast<int>(gd[1]), static_cast<int>(gd[2]),
+                                  static_cast<int>(gd[3]), gd[4], gd[5], gd[6], gd[7]);
+    std::vector<double> table(normals, normals + num_normals);
+    NormalRNGSimulator rng(table);
+    double dummy = 0.0;
+    std::vector<KnowledgeGradientState<TensorProductDomain>::EvaluatorType> evaluators;
+    KnowledgeGradientMCMCEvaluator<TensorProductDomain> ev(*gpm, num_fidelity, discrete_all, P, M, dom, gdp, best_so_far,
+                                                           &evaluators);
+    std::vector<KnowledgeGradientEvaluator<TensorProductDomain>::StateType> states;
+    KnowledgeGradientMCMCEvaluator<TensorProductDomain>::StateType st(ev, Xq, p > 0 ? Xp : &dummy, q, p, P,
+                                                                      nn(gpm->derivatives().data()), gpm->num_derivatives(),
+                                                                      want_grad != 0, &rng, &states);
+    if (kg) *kg = ev.ComputeKnowledgeGradient(&st);
+    if (want_grad && grad) {
+      std::fill(grad, grad + static_cast<size_t>(q) * d, 0.0);  // the evaluator accumulates into its output (.cpp:163-166)
+      ev.ComputeGradKnowledgeGradient(&st, grad);
+    }
+  });
+}
+
+int ref_ei_mcmc(void* hv, const double* Xq, const double* Xp, int q, int p, int M, const double* best_so_far,
+                const double* normals, double* ei, double* grad) {
+  return guarded([&] {
+    GaussianProcessMCMC* gpm = static_cast<GaussianProcessMCMC*>(hv);
+    const int d = gpm->dim();
+    std::vector<double> table(normals, normals + static_cast<size_t>(M) * (q + p));
+    NormalRNGSimulator rng(table);
+    double dummy = 0.0;
+    std::vector<ExpectedImprovementState::EvaluatorType> evaluators;
+    ExpectedImprovementMCMCEvaluator ev(*gpm, M, best_so_far, &evaluators);
+    std::vector<ExpectedImprovementEvaluator::StateType> states;
+    ExpectedImprovementMCMCEvaluator::StateType st(ev, Xq, p > 0 ? Xp : &dummy, q, p, nn(gpm->derivatives().data()),
+                                                   gpm->num_derivatives(), grad != nullptr, &rng, &states);
+    if (ei) *ei = ev.ComputeExpectedImprovement(&st);
+    if (grad) {
+      std::fill(grad, grad + static_cast<size_t>(q) * d, 0.0);
+      ev.ComputeGradExpectedImprovement(&st, grad);
+    }
+  });
+}
+
+// 1,0-EI multistart gradient descent on the MCMC-averaged analytic EI from a given start set
+// (ComputeEIMCMCOptimalPointsToSampleViaMultistartGradientDescent, gpp_expected_improvement_mcmc_optimization.hpp:850-925):
+// deterministic (no random source involved).  num_starts must be >= 20.
+int ref_ei_mcmc_multistart_analytic(void* hv, const double* gd, const double* bounds, const double* starts, int num_starts,
+                                    const double* best_so_far, int* found, double* best_point) {
+  return guarded([&] {
+    GaussianProcessMCMC* gpm = static_cast<GaussianProcessMCMC*>(hv);
+    const int d = gpm->dim();
+    std::vector<ClosedInterval> iv(d);
+    for (int i = 0; i < d; ++i) iv[i] = ClosedInterval(bounds[2 * i], bounds[2 * i + 1]);
+    TensorProductDomain dom(iv.data(), d);
+    GradientDescentParameters gdp(static_cast<int>(gd[0]), static_cast<int>(gd[1]), static_cast<int>(gd[2]),
+                                  static_cast<int>(gd[3]), gd[4], gd[5], gd[6], gd[7]);
+    ThreadSchedule sched(1, omp_sched_static);
+    NormalRNG rng(1);
+    double dummy = 0.0;
+    bool found_flag = false;
+    ComputeEIMCMCOptimalPointsToSampleViaMultistartGradientDescent(*gpm, gdp, dom, sched, starts, &dummy, num_starts, 1, 0,
+                                                                   best_so_far, 1, &rng, &found_flag, best_point);
+    *found = found_flag ? 1 : 0;
   });
 }
 

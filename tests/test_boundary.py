@@ -24,6 +24,11 @@ HOT_PATH_EXPORTS = [
     ("compute_grad_expected_improvement", 9),           # :77-83
     ("evaluate_EI_at_point_list", 11),                  # :401-408 (EvaluateEIAtPointListWrapper)
     ("multistart_expected_improvement_optimization", 13),  # :221-229 (MultistartExpectedImprovementOptimizationWrapper)
+    # MCMC-averaged evaluators: gpp_python_knowledge_gradient_mcmc.cpp, gpp_python_expected_improvement_mcmc.cpp
+    ("compute_knowledge_gradient_mcmc", 13), ("compute_grad_knowledge_gradient_mcmc", 13),
+    ("multistart_knowledge_gradient_mcmc_optimization", 15), ("evaluate_KG_mcmc_at_point_list", 15),
+    ("compute_expected_improvement_mcmc", 8), ("compute_grad_expected_improvement_mcmc", 8),
+    ("multistart_expected_improvement_mcmc_optimization", 11), ("evaluate_EI_mcmc_at_point_list", 11),
 ]
 GP_METHODS = [  # gpp_python_gaussian_process.cpp:294-465 (self + listed arguments)
     ("compute_mean_of_points", 2), ("compute_mean_of_additional_points", 2), ("compute_grad_mean_of_points", 2),
@@ -45,6 +50,7 @@ def test_gpp_exports_and_arity():
     for name, nargs in GP_METHODS:
         assert len(_positional(getattr(GPP.GaussianProcess, name))) == nargs + 1, name
     assert len(_positional(GPP.GaussianProcess.__init__)) == 1 + 8  # make_gaussian_process, :42-47
+    assert len(_positional(GPP.GaussianProcessMCMC.__init__)) == 1 + 9  # make_gaussian_process_mcmc (..._mcmc.cpp:45-50)
     for cls in ("OptimalLearningException", "BoundsException", "InvalidValueException", "SingularMatrixException"):
         assert issubclass(getattr(GPP, cls), Exception)
     assert issubclass(GPP.SingularMatrixException, GPP.OptimalLearningException)
@@ -62,7 +68,7 @@ def test_every_hot_path_binding_of_the_reference_wrappers_exists():
     """Static scan of the reference's own wrapper files: each C_GP.<name> they use on the hot path resolves in our module."""
     from cornell_moe_amd import GPP
     in_scope = ["knowledge_gradient.py", "expected_improvement.py", "gaussian_process.py", "domain.py", "optimization.py",
-                "covariance.py"]
+                "covariance.py", "knowledge_gradient_mcmc.py", "expected_improvement_mcmc.py"]
     out_of_scope = set()
     missing = []
     for fn in in_scope:
@@ -80,7 +86,8 @@ def test_call_sites_of_the_reference_wrappers_fit_our_signatures():
     import ast
     from cornell_moe_amd import GPP
     checked = 0
-    for fn in ("knowledge_gradient.py", "expected_improvement.py", "gaussian_process.py"):
+    for fn in ("knowledge_gradient.py", "expected_improvement.py", "gaussian_process.py", "knowledge_gradient_mcmc.py",
+               "expected_improvement_mcmc.py"):
         tree = ast.parse(open(os.path.join(REF_WRAPPERS, fn)).read())
         for node in ast.walk(tree):
             if not (isinstance(node, ast.Call) and isinstance(node.func, ast.Attribute)
@@ -94,7 +101,7 @@ def test_call_sites_of_the_reference_wrappers_fit_our_signatures():
             n = len(node.args) + len(node.keywords)
             assert len(required) <= n <= len(params), (fn, node.func.attr, n, len(required), len(params))
             checked += 1
-    assert checked >= 15
+    assert checked >= 30
 
 
 def test_randomness_source_semantics():

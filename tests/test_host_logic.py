@@ -82,3 +82,63 @@ def test_gloo_world2_allreduce_and_gather():
         assert np.allclose(grad, (num_mc * (num_mc - 1) / 2.0) / num_mc, rtol=1e-15)
         assert np.array_equal(akg, 10.0 + np.arange(5))
         assert all(np.all(agrad[i] == i) for i in range(5))
+
+
+def _mcmc_worker(rank, world, port, ret):
+    """GP-index shard of an MCMC-averaged KG evaluation: per-GP values from the oracle (test infrastructure standing in for
+    the device evaluation, which needs a GPU), the sum over ranks by all_reduce, the mean / cost step by the C ABI's
+    host-side moe_kg_mcmc_finalize."""
+    import ctypes as C
+
+    import torch.distributed as dist
+    from cornell_moe_amd import _lib
+    from helpers import load_golden_mcmc
+    from oracle import orc
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        c = load_golden_mcmc()[1]
+        i = c.inp
+        d, f, q = int(i["d"]), int(i["num_fidelity"]), int(i["q"])
+        nm = int(i["num_mcmc"])
+        mine = mdist.shard_members(nm, rank, world)
+
+        def local_sums():
+            kg, grad = np.zeros(1), np.zeros((1, q, d))
+            for k in mine:
+                gp = orc.OrcGP(1, float(i["hypers"][k, 0]), i["hypers"][k, 1:], i["X"], i["y"], i["noises"][k], list(i["derivs"]))
+                r = gp.kg(i["inner_gd"], i["bounds"][:2 * (d - f)], i["discrete"][k], i["Xq"], i["Xp"], int(i["M"]),
+                          float(i["kg_best"][k]), i["kg_normals"], num_fidelity=f)
+                kg[0] += r["kg"]
+                grad[0] += r["grad"]
+            return kg, grad
+
+        def finalize(kg_sum, grad_sum):
+            dp = C.POINTER(C.c_double)
+            kg = np.array(kg_sum, dtype=np.float64, copy=True)
+            grad = np.array(grad_sum, dtype=np.float64, copy=True)
+            xq = np.ascontiguousarray(i["Xq"], dtype=np.float64)
+            rc = _lib.load().moe_kg_mcmc_finalize(kg.ctypes.data_as(dp), grad.ctypes.data_as(dp), xq.ctypes.data_as(dp), 1, q, d, f, nm)
+            assert rc == 0
+            return kg, grad
+
+        kg, grad = mdist.kg_mcmc_sharded(local_sums, finalize)
+        ret[rank] = (mine, float(kg[0]), grad[0], float(c.out["kg"]), c.out["grad_kg"])
+    finally:
+        dist.destroy_process_group()
+
+
+def test_gloo_world2_mcmc_member_shards():
+    import torch.multiprocessing as mp
+    world = 2
+    port = _free_port()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_mcmc_worker, args=(world, port, ret), nprocs=world, join=True)
+    assert sorted(ret[0][0] + ret[1][0]) == [0, 1, 2]
+    for r in range(world):
+        _, kg, grad, ref_kg, ref_grad = ret[r]
+        assert abs(kg - ref_kg) <= 1e-8 * abs(ref_kg)
+        assert np.abs(grad - ref_grad).max() <= 1e-8 * max(np.abs(ref_grad).max(), abs(ref_kg))
+    assert ret[0][1] == ret[1][1] and np.array_equal(ret[0][2], ret[1][2])  # every rank holds the same reduced result

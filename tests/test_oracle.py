@@ -95,6 +95,39 @@ def test_golden_analytic_ei_and_multistart(golden):
     assert seen == 3
 
 
+def test_golden_mcmc_averaged_evaluators():
+    """the numpy-level restatement of the MCMC-averaged evaluators (oracle/orc.py: OrcGPMCMC -- per-GP oracle
+    results averaged, KG divided by the fidelity cost with its gradient term) against the reference's GaussianProcessMCMC +
+    KnowledgeGradientMCMCEvaluator / ExpectedImprovementMCMCEvaluator, and the multistart restatement on the averaged analytic
+    EI against ComputeEIMCMCOptimalPointsToSampleViaMultistartGradientDescent."""
+    from cornell_moe_amd import multistart as ms
+    from helpers import load_golden_mcmc
+    cases = load_golden_mcmc()
+    assert len(cases) == 3
+    for c in cases:
+        i = c.inp
+        d, f = int(i["d"]), int(i["num_fidelity"])
+        O = orc.OrcGPMCMC(i["hypers"], i["noises"], i["X"], i["y"], list(i["derivs"]))
+        kg, gkg = O.kg(i["inner_gd"], i["bounds"][:2 * (d - f)], i["discrete"], i["Xq"], i["Xp"], int(i["M"]), i["kg_best"],
+                       i["kg_normals"], num_fidelity=f)
+        assert abs(kg - float(c.out["kg"])) <= TOL["kg"] * abs(float(c.out["kg"]))
+        assert np.abs(gkg - c.out["grad_kg"]).max() <= TOL["grad_kg"] * max(np.abs(c.out["grad_kg"]).max(), abs(kg))
+        kv, _ = O.kg(i["inner_gd"], i["bounds"][:2 * (d - f)], i["discrete"], i["Xq"], i["Xp"], int(i["M"]), i["kg_best"],
+                     i["kg_normals"], want_grad=False, num_fidelity=f)
+        assert abs(kv - float(c.out["kg_value_only"])) <= TOL["kg"] * abs(kv)
+        ei, gei = O.ei(i["Xq"], i["Xp"], int(i["M"]), i["ei_best"], i["ei_normals"])
+        assert abs(ei - float(c.out["ei"])) <= TOL["ei"] * abs(ei)
+        assert rel(gei, c.out["grad_ei"]) < TOL["grad_ei"]
+        best = i["ei_best"]
+        value_fn = lambda x: np.array([O.ei_analytic(p.ravel(), best, want_grad=False)[0] for p in x])  # noqa: E731
+        grad_fn = lambda x: np.array([O.ei_analytic(p.ravel(), best)[1] for p in x]).reshape(x.shape)  # noqa: E731
+        pt, val, found = ms.multistart_best(value_fn, grad_fn, tuple(i["ms_gd"]), i["bounds"], i["ms_starts"].reshape(-1, 1, d),
+                                            floor_value=0.0)
+        assert found == bool(c.out["ms_found"])
+        assert np.abs(pt.ravel() - c.out["ms_best_point"]).max() <= 1e-8
+        assert abs(val - float(c.out["ms_best_ei"])) <= 1e-10 * abs(val)
+
+
 def test_singular_detection():
     X = np.array([[0.1, 0.2], [0.1, 0.2], [0.5, 0.5]])
     with pytest.raises(orc.SingularMatrix):

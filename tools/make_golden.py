@@ -85,6 +85,49 @@ def run_case(c):
     return out
 
 
+def mcmc_cases():
+    """MCMC-averaged evaluators: small ensembles, with and without derivative observations / fidelity
+    dimensions, from the reference's GaussianProcessMCMC + KnowledgeGradientMCMCEvaluator / ExpectedImprovementMCMCEvaluator."""
+    from oracle import orc
+    out = []
+    rng = np.random.default_rng(4242)
+    n, d, q, p, P, M, nm = 30, 4, 2, 1, 5, 24, 3
+    for derivs, f in (((), 0), ((1,), 1), ((0, 2), 2)):
+        g = len(derivs)
+        c = dict(n=n, d=d, q=q, p=p, P=P, M=M, num_mcmc=nm, derivs=np.array(derivs, dtype=np.int32), num_fidelity=f)
+        c["X"] = rng.uniform(0.05, 1.0, size=(n, d))
+        c["y"] = rng.uniform(-1.0, 1.0, size=(n, 1 + g))
+        c["hypers"] = np.c_[rng.uniform(0.8, 1.5, nm), rng.uniform(0.4, 0.9, size=(nm, d))]
+        c["noises"] = rng.uniform(0.01, 0.1, size=(nm, 1 + g))
+        c["Xq"] = rng.uniform(0.2, 0.9, size=(q, d))
+        c["Xp"] = rng.uniform(0.2, 0.9, size=(p, d))
+        c["discrete"] = rng.uniform(0.0, 1.0, size=(nm, P, d - f))
+        c["kg_best"] = rng.uniform(-0.5, 0.5, nm)
+        c["ei_best"] = np.full(nm, float(np.median(c["y"][:, 0])))
+        c["kg_normals"] = rng.standard_normal(((M + 1) // 2, (q + p) * (1 + g)))
+        c["ei_normals"] = rng.standard_normal((M, q + p))
+        c["inner_gd"] = np.array((1, 6, 1, 3, 0.0, 1.0, 0.1, 1e-10))
+        c["bounds"] = np.tile([0.0, 1.0], d)
+        c["ms_starts"] = rng.uniform(0.0, 1.0, size=(24, d))
+        c["ms_gd"] = np.array((24, 20, 2, 4, 0.7, 0.05, 0.2, 1e-8))
+        R = ref.RefGPMCMC(c["hypers"], c["noises"], c["X"], c["y"], derivs)
+        o = {}
+        kg, gkg = R.kg(c["inner_gd"], c["bounds"][:2 * (d - f)], c["discrete"], c["Xq"], c["Xp"], M, c["kg_best"], c["kg_normals"],
+                       num_fidelity=f)
+        o["kg"], o["grad_kg"] = np.array(kg), gkg
+        o["kg_value_only"] = np.array(R.kg(c["inner_gd"], c["bounds"][:2 * (d - f)], c["discrete"], c["Xq"], c["Xp"], M, c["kg_best"],
+                                           c["kg_normals"], want_grad=False, num_fidelity=f)[0])
+        ei, gei = R.ei(c["Xq"], c["Xp"], M, c["ei_best"], c["ei_normals"])
+        o["ei"], o["grad_ei"] = np.array(ei), gei
+        best, found = R.ei_multistart_analytic(c["ms_gd"], c["bounds"], c["ms_starts"], c["ei_best"])
+        o["ms_best_point"], o["ms_found"] = best, np.array(int(found))
+        O = orc.OrcGPMCMC(c["hypers"], c["noises"], c["X"], c["y"], derivs)
+        o["ms_best_ei"] = np.array(O.ei_analytic(best, c["ei_best"], want_grad=False)[0])
+        print("mcmc case: g=%d f=%d  KG=%.12g  EI=%.12g  ms_best_ei=%.6g found=%d" % (g, f, kg, ei, float(o["ms_best_ei"]), found))
+        out.append((c, o))
+    return out
+
+
 def main():
     cases = []
     inner_test = (1, 100, 10, 3, 0.0, 1.0, 0.1, 1e-10)   # inner GD of the reference's KG ping test (100 steps, 10 restarts)
@@ -118,6 +161,13 @@ def main():
             blob["c%d_out_%s" % (i, key)] = np.asarray(val)
         print("case %d: n=%d d=%d q=%d p=%d g=%d cov=%d  KG=%.12g  EI=%.12g" % (
             i, c["n"], c["d"], c["q"], c["p"], len(c["derivs"]), c["cov_type"], float(out["kg"]), float(out["ei"])))
+    mc = mcmc_cases()
+    blob["num_mcmc_cases"] = np.array(len(mc))
+    for i, (c, o) in enumerate(mc):
+        for key, val in c.items():
+            blob["m%d_in_%s" % (i, key)] = np.asarray(val)
+        for key, val in o.items():
+            blob["m%d_out_%s" % (i, key)] = np.asarray(val)
     # the reference's own known-answer vectors (gpp_linear_algebra_test.cpp:237-262), restated as data
     blob["la_A"] = np.array([[81.0, 27.0, 0.0, 90.0], [27.0, 13.0, 8.0, 44.0], [0.0, 8.0, 52.0, 40.0], [90.0, 44.0, 40.0, 217.0]])
     blob["la_A_chol"] = np.array([[9.0, 0, 0, 0], [3.0, 2.0, 0, 0], [0.0, 4.0, 6.0, 0], [10.0, 7.0, 2.0, 8.0]])

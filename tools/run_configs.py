@@ -89,6 +89,26 @@ out["C4_one_gpu"] = {"wall_s_64_multistarts": 64.0 / c3["batch_64_evals_per_s"],
 ms, nbytes = G.cov_build_probe(np.random.default_rng(0).uniform(size=(80000, 8)), repeat=10)
 out["cov_build_N1000xM80000"] = {"ms": ms, "GB_per_s": nbytes / ms / 1e6, "frac_of_8TBs": nbytes / ms / 1e6 / 8000.0}
 
+# ---- MCMC-averaged q-KG: what examples/main.py runs -- 16 hyper-parameter samples x the C3 shape ----
+from cornell_moe_amd.api import DeviceGPMCMC  # noqa: E402
+w = make_workload("C3", num_restarts=8)
+rng = np.random.default_rng(16)
+nm = 16
+hyp = np.c_[rng.uniform(0.8, 1.2, nm), rng.uniform(0.6, 0.8, size=(nm, w.d))]
+noi = np.full((nm, 1), 0.01)
+t0 = time.perf_counter()
+GM = DeviceGPMCMC(hyp, noi, w.X, w.y, ())
+t_build = time.perf_counter() - t0
+disc_all = np.stack([w.discrete] * nm)
+best_all = np.array([float(g.additional_mean(w.discrete).min()) for g in GM.gps])
+mc = {"num_mcmc": nm, "gpu_build_16_gps_s": t_build}
+for R_ in (1, 8):
+    t = timeit(lambda: GM.kg_batch(w.inner_gd, w.bounds, disc_all, w.Xq_restarts[:R_], None, w.M, best_all, w.kg_normals), reps=2)
+    mc["batch_%d_mcmc_evals_per_s" % R_] = R_ / t
+    mc["batch_%d_per_gp_evals_per_s" % R_] = R_ * nm / t
+out["C3_x16_mcmc"] = mc
+del GM
+
 # ---- C5 ----
 w = make_workload("C5")
 t0 = time.perf_counter()
