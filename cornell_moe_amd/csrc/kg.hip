@@ -19,6 +19,8 @@
 #include "kg.hpp"
 
 #include <algorithm>
+#include <array>
+#include <memory>
 #include <chrono>
 #include <cmath>
 #include <cstdlib>
@@ -388,10 +390,12 @@ void launch_mc_block(const KgMcParams& P, int dp, int G, int tr, int num_lds_til
 
 }  // namespace
 
-void kg_evaluate_batch(GpDev& gp, int num_fidelity, const moe_gd_params_t& gd, const double* bounds, const double* discrete,
-                       int P, const double* Xq_all, int num_evals, const double* Xp, int q, int p, int num_mc,
-                       double best_so_far, const double* normals, int first_sample, int num_local, bool want_grad,
-                       double* kg_sum, double* grad_sum, double* best_points, moe_kg_stats_t* stats) {
+// Everything up to and including the asynchronous launches on gp.stream; the returned object's collect() waits for the
+// stream and assembles the results.  Launching on several GPs (MCMC ensemble members, each with its own stream and
+// workspaces) before collecting any of them overlaps one member's host algebra with the others' kernels.
+KgPending kg_launch(GpDev& gp, int num_fidelity, const moe_gd_params_t& gd, const double* bounds, const double* discrete, int P,
+                    const double* Xq_all, int num_evals, const double* Xp, int q, int p, int num_mc, double best_so_far,
+                    const double* normals, int first_sample, int num_local, bool want_grad, bool want_best_points) {
   gp.use_device();
   hipStream_t s = gp.stream;
   const int d = gp.d, dp = gp.dp, f = num_fidelity, u = q + p, n = gp.n, g = gp.g, g1 = 1 + gp.g, N = gp.N;
@@ -464,7 +468,6 @@ void kg_evaluate_batch(GpDev& gp, int num_fidelity, const moe_gd_params_t& gd, c
   if (blocks >= E) blocks = (blocks / E) * E;  // the same number of workgroups for every evaluation
   blocks = env_int("MOE_KG_BLOCKS", blocks);
 
-  if (stats) std::memset(stats, 0, sizeof(*stats));
   const auto wall0 = std::chrono::steady_clock::now();
 
   // ---- 1. state set-up for the whole batch ----
@@ -541,7 +544,9 @@ void kg_evaluate_batch(GpDev& gp, int num_fidelity, const moe_gd_params_t& gd, c
   }
   std::vector<int> winner(E, -1);
   std::vector<double> best_posterior(E, best_so_far);
-  std::vector<std::vector<double>> grad_mu(E), Mk(E);
+  auto grad_mu_p = std::make_shared<std::vector<std::vector<double>>>(E);
+  auto Mk_p = std::make_shared<std::vector<std::vector<double>>>(E);
+  std::vector<std::vector<double>>&grad_mu = *grad_mu_p, &Mk = *Mk_p;
   for (int e = 0; e < E; ++e) {
     const StateHost& sh = hosts[e];
     const double* U = &U_all[(size_t)e * u * d];
@@ -684,7 +689,8 @@ void kg_evaluate_batch(GpDev& gp, int num_fidelity, const moe_gd_params_t& gd, c
   mp.beta = dBeta.p;
   mp.counters = dCounters.p;
   mp.next_sample = reinterpret_cast<unsigned int*>(dCounters.p + 2 * E);
-  EventTimer t_mc, t_cov, t_tail;
+  auto timers = std::make_shared<std::array<EventTimer, 3>>();
+  EventTimer &t_mc = (*timers)[0], &t_cov = (*timers)[1], &t_tail = (*timers)[2];
   t_mc.start(s);
   if (variant == 0)
     launch_mc(mp, dp, G, xlds, blocks, waves, shm, s);
@@ -752,56 +758,76 @@ void kg_evaluate_batch(GpDev& gp, int num_fidelity, const moe_gd_params_t& gd, c
   dOut.download(out, n_out, s);
   unsigned long long* counters = reinterpret_cast<unsigned long long*>(gp.hKgOut.p + n_out);
   dCounters.download(counters, (size_t)2 * E, s);
-  std::vector<double> bp;
-  if (best_points && E == 1) {
-    bp.resize((size_t)num_local * dp);
-    dBestPoint.download(bp.data(), bp.size(), s);
+  const bool fetch_bp = want_best_points && E == 1;
+  auto bp_p = std::make_shared<std::vector<double>>();
+  if (fetch_bp) {
+    bp_p->resize((size_t)num_local * dp);
+    dBestPoint.download(bp_p->data(), bp_p->size(), s);
   }
-  MOE_HIP_CHECK(hipStreamSynchronize(s));
-  if (best_points && E == 1)
-    for (int i = 0; i < num_local; ++i)
-      for (int k = 0; k < d; ++k) best_points[(size_t)i * d + k] = bp[(size_t)i * dp + k];
+  GpDev* gpp = &gp;
+  KgPending pending;
+  pending.collect = [=](double* kg_sum, double* grad_sum, double* best_points, moe_kg_stats_t* stats) {
+    GpDev& gp = *gpp;
+    gp.use_device();
+    if (stats) std::memset(stats, 0, sizeof(*stats));
+    MOE_HIP_CHECK(hipStreamSynchronize(s));
+    const std::vector<std::vector<double>>&grad_mu = *grad_mu_p, &Mk = *Mk_p;
+    if (best_points && fetch_bp)
+      for (int i = 0; i < num_local; ++i)
+        for (int k = 0; k < d; ++k) best_points[(size_t)i * d + k] = (*bp_p)[(size_t)i * dp + k];
 
-  // ---- host assembly of the gradient ----
-  for (int e = 0; e < E; ++e) {
-    const double* o = &out[(size_t)out_stride * e];
-    kg_sum[e] = o[0];
-    if (want_grad) {
-      const double* ZC = o + 1;
-      const double* DIR = o + 1 + m * m;
-      const double* GTB = DIR + ngrad;
-      for (int k = 0; k < q; ++k)
-        for (int dd = 0; dd < d; ++dd) {
-          double direct = 0.0;
-          for (int b = 0; b < g1; ++b) direct += DIR[(k * g1 + b) * d + dd] - GTB[(k * g1 + b) * d + dd];
-          const double* M = &Mk[e][((size_t)k * d + dd) * m * m];
-          double zmc = 0.0;
-          for (int j = 0; j < m; ++j)
-            for (int r = j; r < m; ++r) zmc = std::fma(M[r + (size_t)j * m], ZC[r + (size_t)j * m], zmc);
-          grad_sum[(size_t)e * q * d + (size_t)k * d + dd] = -(direct - zmc);  // aggregate -= gic . z   (.cpp:214-221)
-        }
-      // winner term: + M * grad_mu[winner]  (.cpp:157-161); added once, by the shard that owns sample 0
-      if (winner[e] >= 0 && winner[e] < q && first_sample == 0)
-        for (int k = 0; k < d; ++k)
-          grad_sum[(size_t)e * q * d + (size_t)winner[e] * d + k] += (double)num_mc * grad_mu[e][(size_t)winner[e] * d + k];
+    // ---- host assembly of the gradient ----
+    for (int e = 0; e < E; ++e) {
+      const double* o = &out[(size_t)out_stride * e];
+      kg_sum[e] = o[0];
+      if (want_grad) {
+        const double* ZC = o + 1;
+        const double* DIR = o + 1 + m * m;
+        const double* GTB = DIR + ngrad;
+        for (int k = 0; k < q; ++k)
+          for (int dd = 0; dd < d; ++dd) {
+            double direct = 0.0;
+            for (int b = 0; b < g1; ++b) direct += DIR[(k * g1 + b) * d + dd] - GTB[(k * g1 + b) * d + dd];
+            const double* M = &Mk[e][((size_t)k * d + dd) * m * m];
+            double zmc = 0.0;
+            for (int j = 0; j < m; ++j)
+              for (int r = j; r < m; ++r) zmc = std::fma(M[r + (size_t)j * m], ZC[r + (size_t)j * m], zmc);
+            grad_sum[(size_t)e * q * d + (size_t)k * d + dd] = -(direct - zmc);  // aggregate -= gic . z   (.cpp:214-221)
+          }
+        // winner term: + M * grad_mu[winner]  (.cpp:157-161); added once, by the shard that owns sample 0
+        if (winner[e] >= 0 && winner[e] < q && first_sample == 0)
+          for (int k = 0; k < d; ++k)
+            grad_sum[(size_t)e * q * d + (size_t)winner[e] * d + k] += (double)num_mc * grad_mu[e][(size_t)winner[e] * d + k];
+      }
+      if (stats) {
+        stats->posterior_mean_evals += (long long)counters[2 * e];
+        stats->posterior_grad_evals += (long long)counters[2 * e + 1];
+      }
     }
+    const double wall = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wall0).count();
+    const double ms_mc = (*timers)[0].ms(), ms_cov = want_grad ? (*timers)[1].ms() : 0.0,
+                 ms_tail = want_grad ? (*timers)[2].ms() : 0.0;
+    gp.last_ms[0] = ms_mc / E;
+    gp.last_ms[1] = ms_cov / E;
+    gp.last_ms[2] = ms_tail / E;
+    gp.last_ms[3] = ms_state / E;
+    gp.last_ms[4] = wall / E;
     if (stats) {
-      stats->posterior_mean_evals += (long long)counters[2 * e];
-      stats->posterior_grad_evals += (long long)counters[2 * e + 1];
+      stats->ms_state = ms_state;
+      stats->ms_mc = ms_mc;
+      stats->ms_tail = ms_cov + ms_tail;
     }
-  }
-  const double wall = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wall0).count();
-  const double ms_mc = t_mc.ms(), ms_cov = want_grad ? t_cov.ms() : 0.0, ms_tail = want_grad ? t_tail.ms() : 0.0;
-  gp.last_ms[0] = ms_mc / E;
-  gp.last_ms[1] = ms_cov / E;
-  gp.last_ms[2] = ms_tail / E;
-  gp.last_ms[3] = ms_state / E;
-  gp.last_ms[4] = wall / E;
-  if (stats) {
-    stats->ms_state = ms_state;
-    stats->ms_mc = ms_mc;
-    stats->ms_tail = ms_cov + ms_tail;
-  }
+  };
+  return pending;
+}
+
+void kg_evaluate_batch(GpDev& gp, int num_fidelity, const moe_gd_params_t& gd, const double* bounds, const double* discrete,
+                       int P, const double* Xq_all, int num_evals, const double* Xp, int q, int p, int num_mc,
+                       double best_so_far, const double* normals, int first_sample, int num_local, bool want_grad,
+                       double* kg_sum, double* grad_sum, double* best_points, moe_kg_stats_t* stats) {
+  KgPending pending = kg_launch(gp, num_fidelity, gd, bounds, discrete, P, Xq_all, num_evals, Xp, q, p, num_mc, best_so_far,
+                                normals, first_sample, num_local, want_grad, best_points != nullptr);
+  pending.collect(kg_sum, grad_sum, best_points, stats);
 }
 
 }  // namespace moe

@@ -28,6 +28,15 @@ void kg_evaluate_batch(GpDev& gp, int num_fidelity, const moe_gd_params_t& gd, c
                        double best_so_far, const double* normals, int first_sample, int num_local, bool want_grad,
                        double* kg_sum, double* grad_sum, double* best_points, moe_kg_stats_t* stats);
 
+// kg_evaluate_batch split at its only wait: kg_launch does the state set-up, the host m x m algebra and every
+// asynchronous launch on gp.stream; collect() waits for the stream and assembles kg_sum / grad_sum (same meaning as above).
+struct KgPending {
+  std::function<void(double* kg_sum, double* grad_sum, double* best_points, moe_kg_stats_t* stats)> collect;
+};
+KgPending kg_launch(GpDev& gp, int num_fidelity, const moe_gd_params_t& gd, const double* bounds, const double* discrete, int P,
+                    const double* Xq_all, int num_evals, const double* Xp, int q, int p, int num_mc, double best_so_far,
+                    const double* normals, int first_sample, int num_local, bool want_grad, bool want_best_points);
+
 // ---- callers of the hot path (multistart.hip) ----
 // A maximisation objective evaluated at a BATCH of points [n][qd]: values [n], grads [n][qd].
 struct BatchObjective {

@@ -41,9 +41,15 @@ void kg_mcmc_sums(const std::vector<GpDev*>& gps, int num_fidelity, const moe_gd
   if (want_grad) std::fill(grad_sum, grad_sum + (size_t)E * qd, 0.0);
   std::vector<double> ks(E), gs(want_grad ? (size_t)E * qd : 0);
   const size_t disc_stride = (size_t)P * (d - num_fidelity);
+  // launch every member (own stream, own workspaces), then collect: member i's kernels run while member i+1's state set-up
+  // and host algebra are being prepared
+  std::vector<KgPending> pending;
+  pending.reserve(gps.size());
+  for (size_t i = 0; i < gps.size(); ++i)
+    pending.push_back(kg_launch(*gps[i], num_fidelity, inner, bounds, discrete_all + i * disc_stride, P, Xq_all, E, Xp, q, p,
+                                num_mc, best_so_far[i], normals, 0, num_mc, want_grad, false));
   for (size_t i = 0; i < gps.size(); ++i) {
-    kg_evaluate_batch(*gps[i], num_fidelity, inner, bounds, discrete_all + i * disc_stride, P, Xq_all, E, Xp, q, p, num_mc,
-                      best_so_far[i], normals, 0, num_mc, want_grad, ks.data(), want_grad ? gs.data() : nullptr, nullptr, nullptr);
+    pending[i].collect(ks.data(), want_grad ? gs.data() : nullptr, nullptr, nullptr);
     for (int e = 0; e < E; ++e) kg_sum[e] += ks[e] / (double)num_mc;
     if (want_grad)
       for (size_t j = 0; j < (size_t)E * qd; ++j) grad_sum[j] += gs[j] / (double)num_mc;
