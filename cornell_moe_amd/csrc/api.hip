@@ -277,13 +277,14 @@ int moe_debug_cholesky(int n, const double* a, int device, double* chol, double*
     if (hipGetDeviceCount(&count) != hipSuccess || count <= 0)
       throw moe::Error(MOE_ERR_RUNTIME, "no HIP device visible: libmoe_hip has no CPU fallback");
     MOE_HIP_CHECK(hipSetDevice(device));
-    moe::DevBuf<double> dA, dLinv;
+    moe::DevBuf<double> dA, dLinv, dWork;
     moe::DevBuf<int> dInfo;
     hipStream_t s = nullptr;
     dA.upload(a, (size_t)n * n, s);
     dLinv.reserve((size_t)n * n);
+    dWork.reserve(moe::cholesky_work_doubles(n));
     dInfo.reserve(1);
-    moe::launch_cholesky_and_inverse(n, dA.p, n, dLinv.p, n, nullptr, dInfo.p, s);
+    moe::launch_cholesky_and_inverse(n, dA.p, n, dLinv.p, n, dWork.p, dInfo.p, s);
     int inf = 0;
     dInfo.download(&inf, 1, s);
     if (chol) dA.download(chol, (size_t)n * n, s);

@@ -82,7 +82,8 @@ void GpDev::rebuild() {
   dKinvY.reserve(N);
   dTmp.reserve((size_t)2 * N);
   launch_cov_build(cp, dX.p, n, derivs, dX.p, n, derivs, dNoise.p, dL.p, N, 0, stream);
-  launch_cholesky_and_inverse(N, dL.p, N, dLinv.p, N, nullptr, dInfo.p, stream);
+  dWE.reserve(cholesky_work_doubles(N));  // the state workspace doubles as scratch of the recursive inversion
+  launch_cholesky_and_inverse(N, dL.p, N, dLinv.p, N, dWE.p, dInfo.p, stream);
   int info = 0;
   dInfo.download(&info, 1, stream);
   // mean_ = average of the function-value column only (gpp_math.cpp:498-504)

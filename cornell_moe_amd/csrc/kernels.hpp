@@ -57,6 +57,7 @@ void launch_gram_batch(int E, int m, int ng, int A, int K, const double* V, long
 
 // In-place blocked Cholesky of the lower triangle of A (N x N, lda) + explicit inverse of the factor into Linv
 // (N x N, ldl, lower; strict upper zeroed).  info (device int): 0 or failing pivot index + 1 (pivot <= 1e-16).
+// work: cholesky_work_doubles(N) doubles of device scratch for the recursive inversion.
 void launch_cholesky_and_inverse(int N, double* A, long lda, double* Linv, long ldl, double* work, int* info,
                                  hipStream_t s);
 size_t cholesky_work_doubles(int N);

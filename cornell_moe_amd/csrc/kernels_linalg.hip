@@ -19,9 +19,11 @@ constexpr int TK = 16;
 // MODE 0: C = A^T B, A is K x m (element (k,i) at k + i*lda): full k range.
 // MODE 1: C = T B,   T lower (element (i,k) at i + k*lda), k < i0 + TM.
 // MODE 2: C = T^T B, T lower (element (k,i) at k + i*lda), k >= i0.
+// MODE 3: C = A B,   A general M x K (element (i,k) at i + k*lda), B K x Ncols LOWER triangular: k >= j0.
+// NEG: store -C (the off-diagonal blocks of a triangular inverse).
 // KT = depth of one LDS stage: skinny outputs (few workgroups, latency-bound K loop) use deep stages so the loop has 4x
 // fewer global-load / barrier round trips; big outputs keep 16 for occupancy.
-template <int TM, int TN, int MODE, int KT>
+template <int TM, int TN, int MODE, int KT, bool NEG = false>
 __global__ __launch_bounds__(256) void tile_gemm_kernel(int M, int Ncols, int K, const double* __restrict__ A, long lda,
                                                        const double* __restrict__ B, long ldb, double* __restrict__ C,
                                                        long ldc) {
@@ -34,6 +36,7 @@ __global__ __launch_bounds__(256) void tile_gemm_kernel(int M, int Ncols, int K,
   int k_lo = 0, k_hi = K;
   if (MODE == 1) k_hi = min(K, i0 + TM);
   if (MODE == 2) k_lo = (i0 / TK) * TK;
+  if (MODE == 3) k_lo = (j0 / TK) * TK;
   double acc[RM][RN];
 #pragma unroll
   for (int a = 0; a < RM; ++a)
@@ -42,11 +45,11 @@ __global__ __launch_bounds__(256) void tile_gemm_kernel(int M, int Ncols, int K,
 
   for (int k0 = k_lo; k0 < k_hi; k0 += TK) {
     // stage A tile: As[kk][ii] = Aop(i0+ii, k0+kk)
-    if (MODE == 1) {
+    if (MODE == 1 || MODE == 3) {
       for (int t = threadIdx.x; t < TK * TM; t += 256) {
         const int ii = t % TM, kk = t / TM;
         const int gi = i0 + ii, gk = k0 + kk;
-        As[kk][ii] = (gi < M && gk < K && gk <= gi) ? A[(long)gi + (long)gk * lda] : 0.0;
+        As[kk][ii] = (gi < M && gk < K && (MODE == 3 || gk <= gi)) ? A[(long)gi + (long)gk * lda] : 0.0;
       }
     } else {
       for (int t = threadIdx.x; t < TK * TM; t += 256) {
@@ -60,7 +63,7 @@ __global__ __launch_bounds__(256) void tile_gemm_kernel(int M, int Ncols, int K,
     for (int t = threadIdx.x; t < TK * TN; t += 256) {
       const int kk = t % TK, jj = t / TK;
       const int gk = k0 + kk, gj = j0 + jj;
-      Bs[kk][jj] = (gk < K && gj < Ncols) ? B[(long)gk + (long)gj * ldb] : 0.0;
+      Bs[kk][jj] = (gk < K && gj < Ncols && (MODE != 3 || gk >= gj)) ? B[(long)gk + (long)gj * ldb] : 0.0;
     }
     __syncthreads();
 #pragma unroll
@@ -82,11 +85,11 @@ __global__ __launch_bounds__(256) void tile_gemm_kernel(int M, int Ncols, int K,
 #pragma unroll
     for (int b = 0; b < RN; ++b) {
       const int gi = i0 + tx + 16 * a, gj = j0 + ty + 16 * b;
-      if (gi < M && gj < Ncols) C[(long)gi + (long)gj * ldc] = acc[a][b];
+      if (gi < M && gj < Ncols) C[(long)gi + (long)gj * ldc] = NEG ? -acc[a][b] : acc[a][b];
     }
 }
 
-template <int MODE>
+template <int MODE, bool NEG = false>
 void tile_gemm(int M, int Ncols, int K, const double* A, long lda, const double* B, long ldb, double* C, long ldc,
                hipStream_t s) {
   if (M <= 0 || Ncols <= 0) return;
@@ -94,10 +97,10 @@ void tile_gemm(int M, int Ncols, int K, const double* A, long lda, const double*
   const long blocks64 = (long)((M + 63) / 64) * ((Ncols + 63) / 64);
   if (blocks64 >= 512) {
     dim3 grid((M + 63) / 64, (Ncols + 63) / 64);
-    hipLaunchKernelGGL((tile_gemm_kernel<64, 64, MODE, 16>), grid, dim3(256), 0, s, M, Ncols, K, A, lda, B, ldb, C, ldc);
+    hipLaunchKernelGGL((tile_gemm_kernel<64, 64, MODE, 16, NEG>), grid, dim3(256), 0, s, M, Ncols, K, A, lda, B, ldb, C, ldc);
   } else {
     dim3 grid((M + 31) / 32, (Ncols + 15) / 16);
-    hipLaunchKernelGGL((tile_gemm_kernel<32, 16, MODE, 64>), grid, dim3(256), 0, s, M, Ncols, K, A, lda, B, ldb, C, ldc);
+    hipLaunchKernelGGL((tile_gemm_kernel<32, 16, MODE, 64, NEG>), grid, dim3(256), 0, s, M, Ncols, K, A, lda, B, ldb, C, ldc);
   }
   MOE_HIP_CHECK(hipGetLastError());
 }
@@ -163,49 +166,87 @@ __global__ __launch_bounds__(256) void gram_batch_kernel(GramMap gm, int K, cons
 constexpr int NB = 64;
 
 // Factor the nb x nb diagonal block at (k0,k0); write L_kk back (strict upper zeroed) and its inverse into Linv's
-// diagonal block.  One wavefront: lane t owns row t during the factorisation and column t of the inverse.
+// diagonal block.  One wavefront, everything fully unrolled so that lane t keeps ROW t of the block in registers (static
+// indices): per elimination step one wave-uniform pivot (v_readlane), one column broadcast through LDS, and 63 - k
+// independent fma -- no per-element LDS round trips.  The arithmetic (order of subtractions, division by the pivot's
+// square root, the 1e-16 pivot rule of gpp_linear_algebra.cpp:118) is the reference's outer-product algorithm.  Rows /
+// columns beyond nb (last, partial block) are padded with the identity.  Then lane t solves L x = e_t for column t of
+// the inverse, again in registers against broadcast reads of L from LDS.
+__device__ __forceinline__ double readlane_f64(double v, int lane) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+  return __hiloint2double(hi, lo);
+}
+
 __global__ __launch_bounds__(64) void chol_diag_kernel(double* __restrict__ A, long lda, double* __restrict__ Linv,
                                                       long ldl, int k0, int nb, int* __restrict__ info) {
-  __shared__ double S[NB][NB + 1];
+  __shared__ double S[NB][NB + 1];  // L, row-major
+  __shared__ double X[NB][NB + 1];  // X[c][r] = (L^-1)[r][c]
+  __shared__ double Ccol[NB];
   const int t = threadIdx.x;
   if (*info != 0) return;
-  for (int c = 0; c < nb; ++c)
-    if (t < nb) S[t][c] = (c <= t) ? A[(long)(k0 + t) + (long)(k0 + c) * lda] : 0.0;
-  __syncthreads();
-  for (int k = 0; k < nb; ++k) {
-    const double piv = S[k][k];
-    if (!(piv > 1.0e-16)) {  // gpp_linear_algebra.cpp:118
-      if (t == 0) *info = k0 + k + 1;
-      return;
-    }
+  double a[NB];
+#pragma clang loop unroll(full)
+  for (int c = 0; c < NB; ++c) {
+    double v = (c == t && t >= nb) ? 1.0 : 0.0;
+    if (t < nb && c < nb && c <= t) v = A[(long)(k0 + t) + (long)(k0 + c) * lda];
+    a[c] = v;
+  }
+  int bad = 0;
+#pragma clang loop unroll(full)
+  for (int k = 0; k < NB; ++k) {
+    const double piv = readlane_f64(a[k], k);
+    if (bad == 0 && !(piv > 1.0e-16)) bad = k0 + k + 1;  // gpp_linear_algebra.cpp:118 (first failing pivot; what follows it
+                                                          // is garbage that is never written back)
     const double lkk = sqrt(piv);
+    const double lik = (t == k) ? lkk : a[k] / lkk;
+    a[k] = lik;
+    Ccol[t] = lik;
     __syncthreads();
-    if (t == k) S[k][k] = lkk;
-    if (t > k && t < nb) S[t][k] = S[t][k] / lkk;
-    __syncthreads();
-    if (t > k && t < nb) {
-      const double lik = S[t][k];
-      for (int j = k + 1; j <= t; ++j) S[t][j] = S[t][j] - lik * S[j][k];
+    // column k of L, broadcast from LDS in groups of 16 reads issued back to back (one LDS latency per group instead
+    // of one per element); lanes t < j compute unused upper-triangle values
+#pragma clang loop unroll(full)
+    for (int j0 = ((k + 1) / 16) * 16; j0 < NB; j0 += 16) {
+      double c[16];
+#pragma clang loop unroll(full)
+      for (int jj = 0; jj < 16; ++jj) c[jj] = Ccol[j0 + jj];
+#pragma clang loop unroll(full)
+      for (int jj = 0; jj < 16; ++jj)
+        if (j0 + jj > k) a[j0 + jj] = a[j0 + jj] - lik * c[jj];
     }
     __syncthreads();
   }
+  if (bad != 0) {
+    if (t == 0) *info = bad;
+    return;
+  }
+#pragma clang loop unroll(full)
+  for (int c = 0; c < NB; ++c) {
+    const double v = (c <= t) ? a[c] : 0.0;
+    S[t][c] = v;
+    if (t < nb && c < nb) A[(long)(k0 + t) + (long)(k0 + c) * lda] = v;  // strict upper written as 0
+  }
+  __syncthreads();
+  // inverse: lane t solves L x = e_t by forward substitution (entries above t come out as exact zeros)
+  double x[NB];
+#pragma clang loop unroll(full)
+  for (int i = 0; i < NB; ++i) {
+    double sum = (i == t) ? 1.0 : 0.0;
+#pragma clang loop unroll(full)
+    for (int j0 = 0; j0 < i; j0 += 16) {  // row i of L in groups of 16 broadcast reads (see above)
+      double r[16];
+#pragma clang loop unroll(full)
+      for (int jj = 0; jj < 16; ++jj) r[jj] = S[i][j0 + jj];  // j0 + jj < 64 always; entries >= i are not used
+#pragma clang loop unroll(full)
+      for (int jj = 0; jj < 16; ++jj)
+        if (j0 + jj < i) sum -= r[jj] * x[j0 + jj];
+    }
+    x[i] = sum / S[i][i];
+    X[t][i] = x[i];
+  }
+  __syncthreads();
   for (int c = 0; c < nb; ++c)
-    if (t < nb) A[(long)(k0 + t) + (long)(k0 + c) * lda] = S[t][c];  // strict upper written as 0
-  // inverse: lane t solves L x = e_t (forward substitution, entries above t are 0)
-  if (t < nb) {
-    double x[NB];
-#pragma unroll 1
-    for (int i = 0; i < nb; ++i) {
-      if (i < t) {
-        x[i] = 0.0;
-      } else {
-        double sum = (i == t) ? 1.0 : 0.0;
-        for (int j = t; j < i; ++j) sum -= S[i][j] * x[j];
-        x[i] = sum / S[i][i];
-      }
-      Linv[(long)(k0 + i) + (long)(k0 + t) * ldl] = x[i];
-    }
-  }
+    if (t < nb) Linv[(long)(k0 + t) + (long)(k0 + c) * ldl] = X[c][t];
 }
 
 // Panel below the diagonal block: L_ik = A_ik * L_kk^-T, i.e. out[i][c] = sum_j A[i][j] * Linv_kk[c][j].
@@ -296,66 +337,6 @@ __global__ __launch_bounds__(256) void chol_update_kernel(double* __restrict__ A
     }
 }
 
-// Off-diagonal blocks of L^-1, block row bi: X_{bi,bk} = -Linv_{bi,bi} * sum_{bj=bk}^{bi-1} L_{bi,bj} X_{bj,bk}.
-__global__ __launch_bounds__(256) void trtri_row_kernel(const double* __restrict__ L, long lda, double* __restrict__ Linv,
-                                                       long ldl, int N, int bi, const int* __restrict__ info) {
-  __shared__ double As[TK][NB + 1];
-  __shared__ double Bs[TK][NB + 1];
-  __shared__ double Ssum[NB][NB + 1];
-  if (*info != 0) return;
-  const int bk = blockIdx.x;  // < bi
-  const int i0 = bi * NB, j0 = bk * NB;
-  const int ni = min(NB, N - i0);
-  const int tx = threadIdx.x % 16, ty = threadIdx.x / 16;
-  double acc[4][4];
-#pragma unroll
-  for (int a = 0; a < 4; ++a)
-#pragma unroll
-    for (int b = 0; b < 4; ++b) acc[a][b] = 0.0;
-  for (int k0 = j0; k0 < i0; k0 += TK) {
-    for (int t = threadIdx.x; t < TK * NB; t += 256) {
-      const int ii = t % NB, kk = t / NB;
-      As[kk][ii] = (ii < ni) ? L[(long)(i0 + ii) + (long)(k0 + kk) * lda] : 0.0;
-    }
-    for (int t = threadIdx.x; t < TK * NB; t += 256) {
-      const int kk = t % TK, jj = t / TK;
-      // X_{bj,bk} is lower triangular within the diagonal block bk (zero above its diagonal, which was zero-filled)
-      Bs[kk][jj] = Linv[(long)(k0 + kk) + (long)(j0 + jj) * ldl];
-    }
-    __syncthreads();
-#pragma unroll
-    for (int kk = 0; kk < TK; ++kk) {
-      double av[4], bv[4];
-#pragma unroll
-      for (int a = 0; a < 4; ++a) av[a] = As[kk][tx + 16 * a];
-#pragma unroll
-      for (int b = 0; b < 4; ++b) bv[b] = Bs[kk][ty + 16 * b];
-#pragma unroll
-      for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int b = 0; b < 4; ++b) acc[a][b] = fma(av[a], bv[b], acc[a][b]);
-    }
-    __syncthreads();
-  }
-#pragma unroll
-  for (int a = 0; a < 4; ++a)
-#pragma unroll
-    for (int b = 0; b < 4; ++b) Ssum[tx + 16 * a][ty + 16 * b] = acc[a][b];
-  __syncthreads();
-  // X = -Dinv_bi * Ssum ; Dinv_bi lower triangular (read straight from Linv's diagonal block, L2-resident)
-#pragma unroll
-  for (int a = 0; a < 4; ++a)
-#pragma unroll
-    for (int b = 0; b < 4; ++b) {
-      const int r = tx + 16 * a, c = ty + 16 * b;
-      if (r < ni) {
-        double sum = 0.0;
-        for (int k = 0; k <= r; ++k) sum = fma(Linv[(long)(i0 + r) + (long)(i0 + k) * ldl], Ssum[k][c], sum);
-        Linv[(long)(i0 + r) + (long)(j0 + c) * ldl] = -sum;
-      }
-    }
-}
-
 __global__ void zero_strict_upper_kernel(double* __restrict__ A, long lda, int N) {
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
   const long total = (long)N * N;
@@ -388,9 +369,28 @@ void launch_gram_batch(int E, int m, int ng, int A, int K, const double* V, long
   MOE_HIP_CHECK(hipGetLastError());
 }
 
-size_t cholesky_work_doubles(int) { return 1; }
 
-void launch_cholesky_and_inverse(int N, double* A, long lda, double* Linv, long ldl, double* /*work*/, int* info,
+namespace {
+void trtri_offdiag(const double* L, long lda, double* Linv, long ldl, int N, int lo, int hi, double* work, hipStream_t s) {
+  if (hi - lo <= 1) return;
+  const int mid = lo + (hi - lo + 1) / 2;
+  trtri_offdiag(L, lda, Linv, ldl, N, lo, mid, work, s);
+  trtri_offdiag(L, lda, Linv, ldl, N, mid, hi, work, s);
+  const int r0 = mid * NB, c0 = lo * NB;
+  const int rows = std::min(N, hi * NB) - r0, cols = r0 - c0;
+  // work (rows x cols) = L21 X11   (X11 lower triangular)
+  tile_gemm<3>(rows, cols, cols, L + r0 + (long)c0 * lda, lda, Linv + c0 + (long)c0 * ldl, ldl, work, rows, s);
+  // X21 = -X22 work   (X22 lower triangular)
+  tile_gemm<1, true>(rows, cols, rows, Linv + r0 + (long)r0 * ldl, ldl, work, rows, Linv + r0 + (long)c0 * ldl, ldl, s);
+}
+}  // namespace
+
+size_t cholesky_work_doubles(int N) {
+  const long nblk = (N + NB - 1) / NB, half = (nblk + 1) / 2;
+  return (size_t)(half * NB) * (size_t)(half * NB);
+}
+
+void launch_cholesky_and_inverse(int N, double* A, long lda, double* Linv, long ldl, double* work, int* info,
                                  hipStream_t s) {
   MOE_HIP_CHECK(hipMemsetAsync(info, 0, sizeof(int), s));
   MOE_HIP_CHECK(hipMemsetAsync(Linv, 0, sizeof(double) * (size_t)ldl * N, s));
@@ -409,8 +409,13 @@ void launch_cholesky_and_inverse(int N, double* A, long lda, double* Linv, long 
     const long total = (long)N * N;
     hipLaunchKernelGGL(zero_strict_upper_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, A, lda, N);
   }
-  for (int bi = 1; bi < nblk; ++bi)
-    hipLaunchKernelGGL(trtri_row_kernel, dim3(bi), dim3(256), 0, s, A, lda, Linv, ldl, N, bi, info);
+  // Off-diagonal blocks of L^-1 by recursive halving over the block range (diagonal blocks are already inverted):
+  //   inv [[L11, 0], [L21, L22]] = [[X11, 0], [-X22 (L21 X11), X22]]
+  // -- two triangular GEMMs per node, big and wide near the root, instead of one dependent block row after another.
+  if (nblk > 1) {
+    if (work == nullptr) throw Error(MOE_ERR_RUNTIME, "launch_cholesky_and_inverse: workspace missing");
+    trtri_offdiag(A, lda, Linv, ldl, N, 0, nblk, work, s);
+  }
   MOE_HIP_CHECK(hipGetLastError());
 }
 

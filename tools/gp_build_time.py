@@ -1,0 +1,19 @@
+"""GP construction (covariance build + blocked Cholesky + explicit inverse factor + K^-1 y) wall time at the BASELINE shapes."""
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
+from cornell_moe_amd.api import DeviceGP  # noqa: E402
+from cornell_moe_amd.workloads import make_workload  # noqa: E402
+
+for name in sys.argv[1:] or ["C2", "C3", "C5"]:
+    w = make_workload(name)
+    ts = []
+    for _ in range(4):
+        t0 = time.perf_counter()
+        G = DeviceGP(w.hyperparameters, w.X, w.y, w.noise, w.derivs)
+        ts.append(time.perf_counter() - t0)
+        del G
+    print("%s: N = %d  build %.2f ms (first %.1f ms)" % (name, w.n * (1 + len(w.derivs)), 1e3 * min(ts[1:]), 1e3 * ts[0]))
