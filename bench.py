@@ -98,12 +98,21 @@ def main():
     _lib.load()
     _lib.require_gpu()
     assert torch.cuda.is_available(), "bench.py needs a GPU"
+    # MOE_BENCH_BACKEND=gloo is a test hook: it lets the N > 1 code path run with several ranks sharing ONE GPU (collectives
+    # on host tensors); the measured configuration is always nccl (= RCCL), one rank per GPU.
+    backend = os.environ.get("MOE_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    cdev = dev if backend == "nccl" else None   # where collective buffers live
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         import torch.distributed as dist
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     R = args.restarts
     w = make_workload(args.config, num_restarts=R * world)
@@ -118,14 +127,15 @@ def main():
             grad = r["grad_sum"] / w.M
             if world > 1:
                 idx = list(range(rank * R, (rank + 1) * R))
-                kg, grad = mdist.gather_restarts(idx, kg, grad, R * world, device=dev)
+                kg, grad = mdist.gather_restarts(idx, kg, grad, R * world, device=cdev)
             return kg, grad, r
         first, count = mdist.shard_samples(w.M, rank, world)
         r = G.kg_batch(w.inner_gd, w.bounds, w.discrete, w.Xq_restarts[:R], None, w.M, best, w.kg_normals,
                        first_sample=first, num_local=count)
         kg, grad = r["kg_sum"], r["grad_sum"]
         if world > 1:
-            buf = torch.from_numpy(np.concatenate([kg[:, None], grad.reshape(R, -1)], axis=1)).to(dev)
+            buf = torch.from_numpy(np.concatenate([kg[:, None], grad.reshape(R, -1)], axis=1))
+            buf = buf.to(cdev) if cdev is not None else buf
             dist.all_reduce(buf)
             out = buf.cpu().numpy()
             kg, grad = out[:, 0], out[:, 1:].reshape(grad.shape)
@@ -155,7 +165,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=cdev if cdev is not None else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     assert np.all(np.isfinite(kg)) and np.all(np.isfinite(grad))
