@@ -629,6 +629,51 @@ def evaluate_EI_mcmc_at_point_list(gaussian_process_mcmc, initial_guesses, point
     return list(ei)
 
 
+# ---- log marginal likelihood (gpp_python_model_selection.cpp:43-69, 281-340) ----
+_LL_CACHE = {}  # data fingerprint -> api.LogLikelihood: a sampler evaluates thousands of hyper-parameter sets on the same data
+
+
+def _ll_handle(points_sampled, points_sampled_value, dim, num_sampled, derivatives, num_derivatives):
+    X = _flat(points_sampled, dim * num_sampled).reshape(num_sampled, dim)
+    y = _flat(points_sampled_value, num_sampled * (1 + num_derivatives)).reshape(num_sampled, 1 + num_derivatives)
+    derivs = tuple(int(v) for v in list(derivatives)[:num_derivatives])
+    key = (X.tobytes(), y.tobytes(), derivs)
+    h = _LL_CACHE.get(key)
+    if h is None:
+        if len(_LL_CACHE) >= 4:
+            _LL_CACHE.clear()
+        h = _LL_CACHE[key] = _api.LogLikelihood(X, y, derivs)
+    return h
+
+
+def _check_objective(objective_type):
+    if int(objective_type) != int(LogLikelihoodTypes.log_marginal_likelihood):
+        raise OptimalLearningException("ERROR: invalid objective mode choice. Setting log likelihood to -DBL_MAX.")
+
+
+def compute_log_likelihood(points_sampled, points_sampled_value, dim, num_sampled, objective_type, hyperparameters, derivatives,
+                           num_derivatives, noise_variance):
+    """ComputeLogLikelihoodWrapper (gpp_python_model_selection.cpp:43-69): log marginal likelihood with a Matern-5/2 kernel;
+    hyperparameters = [alpha, [lengths]] (cpp_utils.cppify_hyperparameters)."""
+    _check_objective(objective_type)
+    h = _ll_handle(points_sampled, points_sampled_value, dim, num_sampled, derivatives, num_derivatives)
+    hyper = np.r_[float(hyperparameters[0]), _flat(hyperparameters[1], dim), _flat(noise_variance, 1 + num_derivatives)]
+    return float(h.evaluate(hyper[None, :])[0])
+
+
+def evaluate_log_likelihood_at_hyperparameter_list(hyperparameter_list, points_sampled, points_sampled_value, dim, num_sampled,
+                                                   objective_mode, hyperparameters, noise_variance, derivatives,
+                                                   num_derivatives, num_multistarts, max_num_threads, status):
+    """EvaluateLogLikelihoodAtHyperparameterListWrapper (gpp_python_model_selection.cpp:281-340): hyperparameter_list is
+    flat [num_multistarts][1 + dim + 1 + num_derivatives]."""
+    _check_objective(objective_mode)
+    h = _ll_handle(points_sampled, points_sampled_value, dim, num_sampled, derivatives, num_derivatives)
+    width = 1 + dim + 1 + num_derivatives
+    vals = h.evaluate(_flat(hyperparameter_list, width * num_multistarts).reshape(num_multistarts, width))
+    status["evaluate_log_marginal_likelihood_at_hyperparameter_list"] = bool(len(vals) > 0 and np.max(vals) > -np.inf)
+    return list(vals)
+
+
 def run_cpp_tests():
     """The reference runs its C++ unit-test suite here (gpp_python_test.cpp:307-314); this backend's tests are the pytest
     suite under tests/ (returns 0 = no failures, like the reference on success)."""

@@ -540,3 +540,41 @@ class DeviceGPMCMC(object):
                                                   int(num_mc), best.ctypes.data_as(dp), npn, 1 if gradient_ascent else 0,
                                                   out.ctypes.data_as(dp), C.byref(val), C.byref(found), C.byref(err)), err)
         return out.reshape(q, self.d), val.value, bool(found.value)
+
+
+class LogLikelihood(object):
+    """Log marginal likelihood of fixed data under varying hyper-parameters (moe_ll_*): the evaluator a hyper-parameter
+    sampler calls thousands of times (LogMarginalLikelihoodEvaluator, gpp_model_selection.cpp:540-612)."""
+
+    def __init__(self, X, y, derivatives=(), cov_type=_lib.COV_MATERN_NU_2P5, device=0):
+        X = np.ascontiguousarray(X, dtype=np.float64)
+        self.n, self.d = X.shape
+        self.derivatives = [int(v) for v in derivatives]
+        self.g = len(self.derivatives)
+        y = np.ascontiguousarray(y, dtype=np.float64).reshape(self.n, 1 + self.g)
+        dv = np.ascontiguousarray(self.derivatives, dtype=np.int32)
+        self._h = C.c_void_p(None)
+        err = _lib.MoeError()
+        _check(_lib.load().moe_ll_create(int(cov_type), X.ctypes.data_as(dp), y.ctypes.data_as(dp),
+                                         dv.ctypes.data_as(ip) if self.g else None, self.g, self.d, self.n, int(device),
+                                         C.byref(self._h), C.byref(err)), err)
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            _lib.load().moe_ll_destroy(self._h)
+            self._h = C.c_void_p(None)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def evaluate(self, hyperparameters_all):
+        """hyperparameters_all [num_sets][1 + dim + 1 + g] = (alpha, lengths, noise variances) -> values [num_sets]
+        (-inf where K + noise is singular)."""
+        h = np.ascontiguousarray(hyperparameters_all, dtype=np.float64).reshape(-1, 1 + self.d + 1 + self.g)
+        out = np.zeros(h.shape[0])
+        err = _lib.MoeError()
+        _check(_lib.load().moe_ll_evaluate(self._h, h.ctypes.data_as(dp), h.shape[0], out.ctypes.data_as(dp), C.byref(err)), err)
+        return out

@@ -1,4 +1,5 @@
 // cornell_moe_amd/csrc/api.hip -- the C ABI of libmoe_hip.so (include/moe_hip.h).  Host code only.
+#include <memory>
 #include <algorithm>
 #include <cmath>
 #include <cstring>
@@ -51,6 +52,14 @@ moe::DerivList no_derivs() {
 }
 
 }  // namespace
+
+// moe_ll_t: the data of a log-likelihood problem + a lazily built device GP that is re-factored per hyper-parameter set.
+struct moe_ll {
+  int cov_type, g, d, n, device;
+  std::vector<double> X, y;
+  std::vector<int> derivs;
+  std::unique_ptr<moe::GpDev> gp;
+};
 
 extern "C" {
 
@@ -465,6 +474,59 @@ int moe_ei_mcmc_multistart(const moe_gp_t* const* gps, int num_mcmc, const moe_g
     const std::vector<moe::GpDev*> v = ensemble(gps, num_mcmc);
     moe::ei_mcmc_multistart(v, *outer_params, domain_bounds, start_points, num_starts, points_being_sampled, num_to_sample,
                             num_being_sampled, num_mc, best_so_far, normals, do_gradient_ascent, best_points, best_ei, found);
+  });
+}
+
+int moe_ll_create(int cov_type, const double* points_sampled, const double* points_sampled_value, const int* derivatives,
+                  int num_derivatives, int dim, int num_sampled, int device, moe_ll_t** ll_out, moe_error_t* err) {
+  return guarded(err, [&] {
+    require(ll_out != nullptr && points_sampled != nullptr && points_sampled_value != nullptr, "NULL argument");
+    *ll_out = nullptr;
+    if (dim <= 0 || dim > moe::kMaxDimPadded) throw moe::Error(MOE_ERR_BOUNDS, "dim out of range", dim, 1, moe::kMaxDimPadded);
+    if (num_derivatives < 0 || num_derivatives > moe::kMaxDerivs)
+      throw moe::Error(MOE_ERR_BOUNDS, "num_derivatives out of range", num_derivatives, 0, moe::kMaxDerivs);
+    if (num_sampled <= 0) throw moe::Error(MOE_ERR_BOUNDS, "num_sampled must be positive", num_sampled, 1, 1e9);
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0)
+      throw moe::Error(MOE_ERR_RUNTIME, "no HIP device visible: libmoe_hip has no CPU fallback");
+    auto ll = std::make_unique<moe_ll>();
+    ll->cov_type = cov_type;
+    ll->g = num_derivatives;
+    ll->d = dim;
+    ll->n = num_sampled;
+    ll->device = device;
+    ll->X.assign(points_sampled, points_sampled + (size_t)num_sampled * dim);
+    ll->y.assign(points_sampled_value, points_sampled_value + (size_t)num_sampled * (1 + num_derivatives));
+    if (num_derivatives > 0) ll->derivs.assign(derivatives, derivatives + num_derivatives);
+    *ll_out = ll.release();
+  });
+}
+
+int moe_ll_destroy(moe_ll_t* ll) {
+  delete ll;
+  return MOE_OK;
+}
+
+int moe_ll_evaluate(moe_ll_t* ll, const double* hyperparameters_all, int num_sets, double* values, moe_error_t* err) {
+  return guarded(err, [&] {
+    require(ll != nullptr && hyperparameters_all != nullptr && values != nullptr, "NULL argument");
+    const int g1 = 1 + ll->g, stride = 1 + ll->d + g1;
+    std::vector<double> noise(g1);
+    for (int i = 0; i < num_sets; ++i) {
+      const double* h = hyperparameters_all + (size_t)i * stride;
+      for (int a = 0; a < g1; ++a) noise[a] = h[1 + ll->d + a] + 1.0e-6;  // gpp_model_selection.cpp:546-549
+      try {
+        if (!ll->gp)
+          ll->gp.reset(new moe::GpDev(h, ll->cov_type, ll->X.data(), ll->y.data(), noise.data(),
+                                      ll->derivs.empty() ? nullptr : ll->derivs.data(), ll->g, ll->d, ll->n, ll->device));
+        else
+          ll->gp->set_hyperparameters(h, noise.data());
+        values[i] = ll->gp->log_marginal_likelihood();
+      } catch (const moe::Error& e) {
+        if (e.code != MOE_ERR_SINGULAR) throw;
+        values[i] = -INFINITY;
+      }
+    }
   });
 }
 

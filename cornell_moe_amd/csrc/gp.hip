@@ -23,18 +23,7 @@ GpDev::GpDev(const double* hyper, int cov_type, const double* X_in, const double
   cp.type = cov_type;
   cp.dim = d;
   cp.dp = dp;
-  cp.alpha = hyper[0];
-  if (!(cp.alpha > 0.0)) throw Error(MOE_ERR_BOUNDS, "alpha must be positive", cp.alpha, 0.0, INFINITY);
-  for (int k = 0; k < kMaxDimPadded; ++k) {
-    cp.inv_l2[k] = 0.0;
-    cp.inv_l[k] = 0.0;
-  }
-  for (int k = 0; k < d; ++k) {
-    const double l = hyper[1 + k];
-    if (!(l > 0.0)) throw Error(MOE_ERR_BOUNDS, "length scale must be positive", l, 0.0, INFINITY);  // gpp_covariance.cpp:85-92
-    cp.inv_l2[k] = 1.0 / (l * l);
-    cp.inv_l[k] = 1.0 / l;
-  }
+  set_covariance(hyper);
   derivs.g = g;
   for (int i = 0; i < kMaxDerivs; ++i) derivs.idx[i] = 0;
   for (int i = 0; i < g; ++i) {
@@ -52,6 +41,66 @@ GpDev::GpDev(const double* hyper, int cov_type, const double* X_in, const double
     if (prop.multiProcessorCount > 0) num_cu = prop.multiProcessorCount;
   }
   rebuild();
+}
+
+void GpDev::set_covariance(const double* hyper) {
+  cp.alpha = hyper[0];
+  if (!(cp.alpha > 0.0)) throw Error(MOE_ERR_BOUNDS, "alpha must be positive", cp.alpha, 0.0, INFINITY);
+  for (int k = 0; k < kMaxDimPadded; ++k) {
+    cp.inv_l2[k] = 0.0;
+    cp.inv_l[k] = 0.0;
+  }
+  for (int k = 0; k < d; ++k) {
+    const double l = hyper[1 + k];
+    if (!(l > 0.0)) throw Error(MOE_ERR_BOUNDS, "length scale must be positive", l, 0.0, INFINITY);  // gpp_covariance.cpp:85-92
+    cp.inv_l2[k] = 1.0 / (l * l);
+    cp.inv_l[k] = 1.0 / l;
+  }
+}
+
+void GpDev::set_hyperparameters(const double* hyper, const double* noise_in) {
+  set_covariance(hyper);
+  noise.assign(noise_in, noise_in + (1 + g));
+  rebuild();
+}
+
+namespace {
+// out[0] = sum_i log L_ii, out[1] = yc . K^-1 yc; one workgroup (N is a few thousand at most: two strided passes).
+__global__ __launch_bounds__(256) void ll_terms_kernel(const double* __restrict__ L, long ldl, int N,
+                                                       const double* __restrict__ yc, const double* __restrict__ KinvY,
+                                                       double* __restrict__ out) {
+  __shared__ double red[2][256];
+  double a = 0.0, b = 0.0;
+  for (int i = threadIdx.x; i < N; i += 256) {
+    a += log(L[(long)i + (long)i * ldl]);
+    b = fma(yc[i], KinvY[i], b);
+  }
+  red[0][threadIdx.x] = a;
+  red[1][threadIdx.x] = b;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if ((int)threadIdx.x < w) {
+      red[0][threadIdx.x] += red[0][threadIdx.x + w];
+      red[1][threadIdx.x] += red[1][threadIdx.x + w];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    out[0] = red[0][0];
+    out[1] = red[1][0];
+  }
+}
+}  // namespace
+
+double GpDev::log_marginal_likelihood() {
+  use_device();
+  // dTmp[0, N) still holds yc = y - mean on the value rows (rebuild), dTmp[N, 2N) is free scratch
+  hipLaunchKernelGGL(ll_terms_kernel, dim3(1), dim3(256), 0, stream, dL.p, (long)N, N, dTmp.p, dKinvY.p, dTmp.p + N);
+  MOE_HIP_CHECK(hipGetLastError());
+  double terms[2] = {0.0, 0.0};
+  MOE_HIP_CHECK(hipMemcpyAsync(terms, dTmp.p + N, sizeof(terms), hipMemcpyDeviceToHost, stream));
+  MOE_HIP_CHECK(hipStreamSynchronize(stream));
+  return -0.5 * terms[1] - terms[0] - 0.5 * (double)N * 1.8378770664093454835607;  // kLog2Pi, gpp_common.hpp:747
 }
 
 GpDev::~GpDev() {

@@ -42,8 +42,16 @@ struct GpDev {
   GpDev& operator=(const GpDev&) = delete;
 
   void use_device() const;
+  void set_covariance(const double* hyper);  // alpha, lengths -> cp (validated)
   void rebuild();  // K assembly + Cholesky + inverse + K^-1 (y - mean)  (RecomputeDerivedVariables, gpp_math.cpp:481-511)
   void add_points(const double* pts, const double* vals, int k);
+  // New covariance hyper-parameters [alpha, lengths...] and noise [1 + g] on the same data: rebuild in place (buffers and
+  // stream are kept) -- the inner step of hyper-parameter sampling (LogMarginalLikelihoodState::SetHyperparameters,
+  // gpp_model_selection.cpp:798-811).
+  void set_hyperparameters(const double* hyper, const double* noise_in);
+  // log p(y | X, theta) of the current factorisation = -1/2 yc^T K^-1 yc - sum log L_ii - N/2 log 2 pi
+  // (LogMarginalLikelihoodEvaluator::ComputeLogLikelihood, gpp_model_selection.cpp:593-612).
+  double log_marginal_likelihood();
   std::vector<double> padded(const double* pts, int k) const;  // [k][d] -> [k][DP]
 };
 

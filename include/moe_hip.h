@@ -241,6 +241,20 @@ int moe_ei_mcmc_multistart(const moe_gp_t* const* gps, int num_mcmc, const moe_g
                            const double* best_so_far, const double* normals, int do_gradient_ascent, double* best_points,
                            double* best_ei, int* found, moe_error_t* err);
 
+/* ---- log marginal likelihood of the data under the GP prior: compute_log_likelihood /
+ * evaluate_log_likelihood_at_hyperparameter_list (gpp_python_model_selection.cpp:43-69, 270-340 ->
+ * LogMarginalLikelihoodEvaluator, gpp_model_selection.cpp:540-612).  A handle keeps the data and the device buffers so
+ * that a hyper-parameter sampler's thousands of evaluations on the same data re-use them.
+ * hyperparameters_all[num_sets][1 + dim + 1 + num_derivatives] = (alpha, lengths[dim], noise_variance[1 + g]) per set, the
+ * layout of the reference's hyperparameter lists (gpp_python_model_selection.cpp:301-303).  Like the reference, 1e-6 is
+ * added to the diagonal of K + noise before it is factored (gpp_model_selection.cpp:546-549).  Where the reference
+ * ignores a failed factorisation (:551-553, "TODO(GH-211)") and returns a meaningless number, values[i] is -infinity. */
+typedef struct moe_ll moe_ll_t;
+int moe_ll_create(int cov_type, const double* points_sampled, const double* points_sampled_value, const int* derivatives,
+                  int num_derivatives, int dim, int num_sampled, int device, moe_ll_t** ll_out, moe_error_t* err);
+int moe_ll_destroy(moe_ll_t* ll);
+int moe_ll_evaluate(moe_ll_t* ll, const double* hyperparameters_all, int num_sets, double* values, moe_error_t* err);
+
 /* ---- covariance assembly (exposed for parity tests and the HBM-roofline measurement) ----
  * BuildMixCovarianceMatrix (gpp_math.cpp:309-335, 469-479): out[N x num_pts*(1+g2)] col-major = K(X, pts) with
  * derivative blocks; derivs2[g2] are the derivative observations carried by `pts`. */

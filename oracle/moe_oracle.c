@@ -340,6 +340,39 @@ static orc_gp* gp_alloc(const orc_cov* cov, int g, const int* derivs, int d, int
   return gp;
 }
 
+/* LogMarginalLikelihoodEvaluator::FillLogLikelihoodState + ComputeLogLikelihood (gpp_model_selection.cpp:540-612):
+ * K + noise, +1e-6 on the diagonal, Cholesky (a failing pivot is ignored by the reference; here it returns rc != 0 and
+ * *value is left untouched), y centred by the mean of the function values, LML = -1/2 y^T K^-1 y - sum log L_ii - N/2 log 2pi. */
+int orc_log_likelihood(int cov_type, double alpha, const double* lengths, const double* X, const double* y,
+                       const double* noise, const int* derivs, int g, int d, int n, double* value) {
+  orc_cov cov;
+  cov.type = cov_type;
+  cov.dim = d;
+  cov.alpha = alpha;
+  for (int i = 0; i < d; ++i) cov.lengths_sq[i] = SQ(lengths[i]);
+  orc_gp* gp = gp_alloc(&cov, g, derivs, d, n);
+  memcpy(gp->X, X, sizeof(double) * (size_t)n * d);
+  memcpy(gp->y, y, sizeof(double) * (size_t)gp->N);
+  memcpy(gp->noise, noise, sizeof(double) * (size_t)(1 + g));
+  const size_t N = (size_t)gp->N;
+  memset(gp->K_chol, 0, sizeof(double) * N * N);
+  build_K_with_noise(gp, gp->K_chol);
+  for (size_t i = 0; i < N; ++i) gp->K_chol[i + i * N] += 1.0e-6;
+  const int rc = orc_cholesky((int)N, gp->K_chol);
+  if (rc == 0) {
+    recompute_mean_variables(gp, 1); /* K_inv_y = K^-1 (y - mean on the value rows) */
+    double term1 = 0.0, term2 = 0.0;
+    for (size_t i = 0; i < N; ++i) {
+      const double yc = gp->y[i] - ((i % (size_t)(g + 1)) == 0 ? gp->mean : 0.0);
+      term1 += yc * gp->K_inv_y[i];
+      term2 -= log(gp->K_chol[i + i * N]);
+    }
+    *value = -0.5 * term1 + term2 - 0.5 * (double)N * 1.8378770664093454835607;
+  }
+  orc_gp_destroy(gp);
+  return rc;
+}
+
 /* GaussianProcess ctor gpp_math.cpp:553-573 + RecomputeDerivedVariables :481-511 */
 orc_gp* orc_gp_create(int cov_type, double alpha, const double* lengths, const double* X, const double* y,
                       const double* noise, const int* derivs, int g, int d, int n) {

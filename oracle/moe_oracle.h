@@ -72,6 +72,10 @@ int orc_gp_grad_chol_var(const orc_gp* gp, const double* pts, int k, int nd, dou
 int orc_ei(const orc_gp* gp, const double* Xq, const double* Xp, int q, int p, int M, double best_so_far,
            const double* normals, double* ei, double* grad);
 
+/* log marginal likelihood (gpp_model_selection.cpp:540-612; +1e-6 diagonal jitter like the reference).  rc != 0: K singular. */
+int orc_log_likelihood(int cov_type, double alpha, const double* lengths, const double* X, const double* y,
+                       const double* noise, const int* derivs, int g, int d, int n, double* value);
+
 /* analytic 1,0-EI and its gradient [dim] (gpp_math.cpp:2195-2259); either output may be NULL. */
 int orc_ei_analytic(const orc_gp* gp, const double* pt, double best_so_far, double* ei, double* grad);
 

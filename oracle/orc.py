@@ -54,6 +54,7 @@ def lib():
         L.orc_chol_solve.argtypes = [_dp, C.c_int, _dp]
         L.orc_tri_solve.argtypes = [_dp, C.c_char, C.c_int, C.c_int, _dp]
         L.orc_ei.argtypes = [C.c_void_p, _dp, _dp, C.c_int, C.c_int, C.c_int, C.c_double, _dp, _dp, _dp]
+        L.orc_log_likelihood.argtypes = [C.c_int, C.c_double, _dp, _dp, _dp, _dp, _ip, C.c_int, C.c_int, C.c_int, _dp]
         L.orc_ei_analytic.argtypes = [C.c_void_p, _dp, C.c_double, _dp, _dp]
         L.orc_kg.argtypes = [C.c_void_p, C.c_int, _dp, _dp, _dp, C.c_int, _dp, _dp, C.c_int, C.c_int, C.c_int, C.c_double,
                              _dp, C.c_int, _dp, _dp, _dp, _lp]
@@ -249,6 +250,22 @@ class OrcGP(object):
             raise SingularMatrix("singular at minor %d" % rc)
         return dict(kg=kg.value, grad=grad.reshape(q, self.d) if want_grad else None,
                     best_point=best_point.reshape(M, self.d), mean_evals=counters[0], grad_evals=counters[1])
+
+
+def log_likelihood(cov_type, alpha, lengths, X, y, noise, derivs):
+    """orc_log_likelihood: log marginal likelihood of the data under the GP prior (gpp_model_selection.cpp:540-612)."""
+    X = np.ascontiguousarray(X, dtype=np.float64)
+    n, d = X.shape
+    derivs = [int(v) for v in derivs]
+    ya, yp = _d(y)
+    na, np_ = _d(noise)
+    la, lp = _d(lengths)
+    da, dp = _i(derivs)
+    val = C.c_double(0.0)
+    rc = lib().orc_log_likelihood(cov_type, float(alpha), lp, X.ctypes.data_as(_dp), yp, np_, dp, len(derivs), d, n, C.byref(val))
+    if rc:
+        raise SingularMatrix("K singular at minor %d" % rc)
+    return val.value
 
 
 class OrcGPMCMC(object):

@@ -58,6 +58,7 @@ def lib():
                                      C.c_long, C.c_int, _dp, _dp]
         _lib.ref_ei_mcmc.argtypes = [C.c_void_p, _dp, _dp, C.c_int, C.c_int, C.c_int, _dp, _dp, _dp, _dp]
         _lib.ref_ei_mcmc_multistart_analytic.argtypes = [C.c_void_p, _dp, _dp, _dp, C.c_int, _dp, C.POINTER(C.c_int), _dp]
+        _lib.ref_log_likelihood.argtypes = [C.c_int, C.c_double, _dp, _dp, _dp, _dp, _ip, C.c_int, C.c_int, C.c_int, _dp]
         _lib.ref_kg.argtypes = [C.c_void_p, C.c_int, _dp, _dp, _dp, C.c_int, _dp, _dp, C.c_int, C.c_int, C.c_int,
                                 C.c_double, _dp, C.c_long, C.c_int, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp]
         _lib.ref_kg_grad_batch.argtypes = [C.c_void_p, C.c_int, _dp, _dp, _dp, C.c_int, _dp, C.c_int, C.c_int, C.c_int,
@@ -295,6 +296,20 @@ class RefGP(object):
 
 def num_procs():
     return lib().ref_num_procs()
+
+
+def log_likelihood(cov_type, alpha, lengths, X, y, noise, derivs):
+    """LogMarginalLikelihoodEvaluator::ComputeLogLikelihood on a fresh state (gpp_python_model_selection.cpp:43-69)."""
+    X = np.ascontiguousarray(X, dtype=np.float64)
+    n, d = X.shape
+    derivs = [int(v) for v in derivs]
+    ya, yp = _d(y)
+    na, np_ = _d(noise)
+    la, lp = _d(lengths)
+    da, dp = _i(derivs)
+    val = C.c_double(0.0)
+    _check(lib().ref_log_likelihood(cov_type, float(alpha), lp, X.ctypes.data_as(_dp), yp, np_, dp, len(derivs), d, n, C.byref(val)))
+    return val.value
 
 
 class RefGPMCMC(object):

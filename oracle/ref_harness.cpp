@@ -26,6 +26,7 @@
 #define private public
 #include "gpp_math.hpp"
 #undef private
+#include "gpp_model_selection.hpp"
 #include "gpp_common.hpp"
 #include "gpp_covariance.hpp"
 #include "gpp_domain.hpp"
@@ -414,6 +415,20 @@ int ref_ei_mcmc_multistart_analytic(void* hv, const double* gd, const double* bo
     ComputeEIMCMCOptimalPointsToSampleViaMultistartGradientDescent(*gpm, gdp, dom, sched, starts, &dummy, num_starts, 1, 0,
                                                                    best_so_far, 1, &rng, &found_flag, best_point);
     *found = found_flag ? 1 : 0;
+  });
+}
+
+// ---- log marginal likelihood (LogMarginalLikelihoodEvaluator::ComputeLogLikelihood, gpp_model_selection.cpp:540-612), driven
+// like ComputeLogLikelihoodWrapper (gpp_python_model_selection.cpp:43-69): Matern-5/2 unless cov_type == 0 ----
+int ref_log_likelihood(int cov_type, double alpha, const double* lengths, const double* X, const double* y, const double* noise,
+                       const int* derivs, int g, int d, int n, double* value) {
+  return guarded([&] {
+    CovarianceInterface* cov = make_cov(cov_type, d, alpha, lengths);
+    LogMarginalLikelihoodEvaluator ev(X, y, nn(derivs), g, d, n);
+    std::vector<double> nv(noise, noise + 1 + g);
+    LogMarginalLikelihoodState st(ev, *cov, nv);
+    *value = ev.ComputeLogLikelihood(st);
+    delete cov;
   });
 }
 

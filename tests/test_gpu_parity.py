@@ -111,6 +111,29 @@ def test_golden_analytic_ei_and_ei_multistart(api, golden):
     assert seen == 3
 
 
+def test_golden_log_likelihood(api, golden):
+    """moe_ll_evaluate against the reference's LogMarginalLikelihoodEvaluator (three hyper-parameter sets per case, one
+    handle per data set: the factorisation is redone in place per set); a singular K + noise gives -inf."""
+    cases, _ = golden
+    for c in cases:
+        i = c.inp
+        LL = api.LogLikelihood(i["X"], i["y"], list(i["derivs"]), cov_type=int(i["cov_type"]))
+        sets = np.array([np.r_[float(i["alpha"]) * s, i["lengths"] * s, i["noise"] * s] for s in (1.0, 0.7, 1.6)])
+        vals = LL.evaluate(sets)
+        assert np.abs(vals - c.out["log_likelihood"]).max() <= 1e-10 * np.abs(c.out["log_likelihood"]).max()
+        assert LL.evaluate(sets[1:2])[0] == vals[1]  # re-evaluation in place reproduces the value bit for bit
+    rng = np.random.default_rng(0)
+    X = rng.uniform(size=(70, 3))
+    X[5] = X[4]                       # duplicate point, (almost) no noise: singular even with the 1e-6 jitter? no -- the
+    y = rng.uniform(size=(70, 1))     # jitter keeps it factorable, like the reference; a NEGATIVE noise makes it singular
+    LL = api.LogLikelihood(X, y)
+    ok = LL.evaluate(np.array([[1.0, 0.5, 0.5, 0.5, 0.0]]))[0]
+    assert np.isfinite(ok)
+    assert LL.evaluate(np.array([[1.0, 0.5, 0.5, 0.5, -2.0]]))[0] == -np.inf
+    from oracle import orc
+    assert abs(ok - orc.log_likelihood(1, 1.0, [0.5, 0.5, 0.5], X, y, [0.0], ())) <= 1e-9 * abs(ok)
+
+
 def test_golden_kg(api, golden):
     cases, _ = golden
     ran = 0

@@ -128,6 +128,18 @@ def test_golden_mcmc_averaged_evaluators():
         assert abs(val - float(c.out["ms_best_ei"])) <= 1e-10 * abs(val)
 
 
+def test_golden_log_likelihood(golden):
+    """log marginal likelihood restatement (orc_log_likelihood) against the reference's
+    LogMarginalLikelihoodEvaluator at three hyper-parameter sets per golden case."""
+    cases, _ = golden
+    for c in cases:
+        i = c.inp
+        for k, scale in enumerate((1.0, 0.7, 1.6)):
+            v = orc.log_likelihood(int(i["cov_type"]), float(i["alpha"]) * scale, i["lengths"] * scale, i["X"], i["y"],
+                                   i["noise"] * scale, list(i["derivs"]))
+            assert abs(v - c.out["log_likelihood"][k]) <= 1e-11 * abs(c.out["log_likelihood"][k])
+
+
 def test_singular_detection():
     X = np.array([[0.1, 0.2], [0.1, 0.2], [0.5, 0.5]])
     with pytest.raises(orc.SingularMatrix):

@@ -17,3 +17,13 @@ for name in sys.argv[1:] or ["C2", "C3", "C5"]:
         ts.append(time.perf_counter() - t0)
         del G
     print("%s: N = %d  build %.2f ms (first %.1f ms)" % (name, w.n * (1 + len(w.derivs)), 1e3 * min(ts[1:]), 1e3 * ts[0]))
+
+from cornell_moe_amd.api import LogLikelihood  # noqa: E402
+for name in ["C2", "C3"]:
+    w = make_workload(name)
+    LL = LogLikelihood(w.X, w.y, w.derivs)
+    sets = np.tile(np.r_[w.hyperparameters, w.noise], (20, 1)) * np.linspace(0.8, 1.2, 20)[:, None]
+    LL.evaluate(sets[:2])
+    t0 = time.perf_counter()
+    LL.evaluate(sets)
+    print("%s: log marginal likelihood %.2f ms per hyper-parameter set" % (name, 1e3 * (time.perf_counter() - t0) / 20))

@@ -72,6 +72,12 @@ def run_case(c):
         out["ms_best_point"] = best
         out["ms_found"] = np.array(int(found))
         out["ms_best_ei"] = np.array(gp.ei_analytic(best, float(c["ei_best"]))[0])
+    # log marginal likelihood at the case's own hyper-parameters and at two perturbed sets (gpp_model_selection.cpp:540-612)
+    lls = []
+    for scale in (1.0, 0.7, 1.6):
+        lls.append(ref.log_likelihood(int(c["cov_type"]), float(c["alpha"]) * scale, c["lengths"] * scale, c["X"], c["y"],
+                                      c["noise"] * scale, list(c["derivs"])))
+    out["log_likelihood"] = np.array(lls)
     r = gp.kg(c["inner_gd"], c["bounds"], c["discrete"], c["Xq"], Xp, int(c["M"]), float(c["best_so_far"]), c["kg_normals"],
               want_grad=True, details=True)
     out["kg"] = np.array(r["kg"])
