@@ -34,30 +34,30 @@ __device__ __forceinline__ double exp_nonpos(double x) {
   return ldexp(p, static_cast<int>(n));
 }
 
-// Table-driven variant for the hottest loop (kg_mc.hpp): x = k ln2/32 + r, |r| <= ln2/64, e^x = 2^(k>>5) * T[k&31] * e^r
-// with T[j] = 2^(j/32) (correctly rounded, staged in LDS by the caller) and a degree-6 polynomial for e^r (truncation
-// 3.5e-18).  k is extracted with the 1.5*2^52 magic-number trick (no v_rndne / v_cvt).  12 FP64 + 3 integer VALU
-// instructions + one conflict-free ds_read_b64, against 17 FP64 for exp_nonpos.  Valid for -1e9 < x <= 0; <= 1.5 ulp.
-__device__ __forceinline__ double exp_nonpos_tab(double x, const double* __restrict__ tab32) {
+// Table-driven variant for the hottest loop (kg_mc.hpp): x = k ln2/64 + r, |r| <= ln2/128, e^x = 2^(k>>6) * T[k&63] * e^r
+// with T[j] = 2^(j/64) (correctly rounded, staged in LDS by the caller) and a degree-5 polynomial for e^r - 1 (truncation
+// r^6/720 <= 3.5e-17).  k is extracted with the 1.5*2^52 magic-number trick (no v_rndne / v_cvt); the reduction uses the
+// full-precision hi/lo split of ln2/64 (each product is exact inside its fma).  11 FP64 + 3 integer VALU instructions +
+// one ds_read_b64, against 17 FP64 for exp_nonpos.  Valid for -1e9 < x <= 0; <= 1.5 ulp (tools/mathcheck.hip).
+__device__ __forceinline__ double exp_nonpos_tab(double x, const double* __restrict__ tab64) {
   const double kMagic = 6755399441055744.0;  // 1.5 * 2^52
-  const double t = fma(x, 46.16624130844683, kMagic);
+  const double t = fma(x, 92.33248261689366, kMagic);  // 64 / ln2
   const double kf = t - kMagic;
-  double r = fma(kf, -0.02166084938653512, x);
-  r = fma(kf, -5.9631716539705866e-12, r);
+  double r = fma(kf, -0.010830424696249145, x);        // ln2 / 64, hi
+  r = fma(kf, -3.623510646634843e-19, r);              //           lo
   const int k = __double2loint(t);  // low mantissa word of t = k (two's complement)
-  const double T = tab32[k & 31];
+  const double T = tab64[k & 63];
   const double r2 = r * r;
-  double q = 1.0 / 720.0;
-  q = fma(q, r, 1.0 / 120.0);
+  double q = 1.0 / 120.0;
   q = fma(q, r, 1.0 / 24.0);
   q = fma(q, r, 1.0 / 6.0);
   q = fma(q, r, 0.5);
   const double sx = fma(r2, q, r);  // e^r - 1
-  return ldexp(fma(T, sx, T), k >> 5);
+  return ldexp(fma(T, sx, T), k >> 6);
 }
 
-// sqrt(s) for s > 0 (no clamp; callers guarantee s >= 1e-300): v_rsq_f64 seed, one coupled Newton step, one Heron
-// correction.  Measured correctly rounded (max 0.500 ulp) over 4e6 arguments in [1e-12, 630] (tools/mathcheck.hip); a
+// sqrt(s) for s > 0 (no clamp; callers guarantee s >= 1e-300): v_rsq_f64 seed, one Newton step, one Heron
+// correction (7 instructions).  Measured correctly rounded (max 0.500 ulp) over 4e6 arguments in [1e-12, 630] (tools/mathcheck.hip); a
 // second Heron correction changes nothing.
 __device__ __forceinline__ double sqrt_pos(double s) {
   const double y = __builtin_amdgcn_rsq(s);
@@ -65,47 +65,79 @@ __device__ __forceinline__ double sqrt_pos(double s) {
   double h = 0.5 * y;
   const double e = fma(-h, g, 0.5);
   g = fma(g, e, g);
-  h = fma(h, e, h);
+  // (h is not refined: it only scales the final correction d ~ 2^-45 g, where its seed accuracy of ~2^-22 is plenty)
   const double d = fma(-g, g, s);
   return fma(d, h, g);
 }
 
 __device__ __forceinline__ double sqrt_nonneg(double s) { return sqrt_pos(fmax(s, 1.0e-300)); }
 
-// 2^(j/32), j = 0..31, correctly rounded: the table exp_nonpos_tab expects (callers copy it into LDS).
-__device__ __constant__ const double kExp2Tab32[32] = {
+// 2^(j/64), j = 0..63, correctly rounded: the table exp_nonpos_tab expects (callers copy it into LDS).
+__device__ __constant__ const double kExp2Tab64[64] = {
     1.0,
+    1.0108892860517005,
     1.0218971486541166,
+    1.0330248790212284,
     1.0442737824274138,
+    1.0556451783605572,
     1.0671404006768237,
+    1.0787607977571199,
     1.0905077326652577,
+    1.102382583307841,
     1.1143867425958924,
+    1.1265216186082418,
     1.1387886347566916,
+    1.1511892299529827,
     1.1637248587775775,
+    1.1763969916502812,
     1.189207115002721,
+    1.202156731452703,
     1.215247359980469,
+    1.22848053610687,
     1.241857812073484,
+    1.255380757024691,
     1.2690509571917332,
+    1.2828700160787783,
     1.2968395546510096,
+    1.3109612115247644,
     1.3252366431597413,
+    1.339667524053303,
     1.3542555469368927,
+    1.3690024229745905,
     1.383909881963832,
+    1.3989796725383112,
     1.4142135623730951,
+    1.42961333839197,
     1.4451808069770467,
+    1.460917794180647,
     1.4768261459394993,
+    1.4929077282912648,
     1.5091644275934228,
+    1.5255981507445384,
     1.5422108254079407,
+    1.559004400237837,
     1.5759808451078865,
+    1.593142151342267,
     1.6104903319492543,
+    1.6280274218573478,
     1.645755478153965,
+    1.6636765803267364,
     1.681792830507429,
+    1.7001063537185235,
     1.718619298122478,
+    1.7373338352737062,
     1.7562521603732995,
+    1.7753764925265212,
     1.7947090750031072,
+    1.8142521755003989,
     1.8340080864093424,
+    1.8539791250833855,
     1.8741676341103,
+    1.8945759815869656,
     1.9152065613971474,
+    1.9360617934922943,
     1.9571441241754002,
+    1.978456026387951,
 };
 
 }  // namespace moe

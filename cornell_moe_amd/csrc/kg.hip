@@ -421,7 +421,10 @@ KgPending kg_launch(GpDev& gp, int num_fidelity, const moe_gd_params_t& gd, cons
   // ---- MC launch geometry: workgroup = `waves` wavefronts sharing one LDS coordinate table ----
   const size_t tab_bytes = sizeof(double) * (size_t)ntiles * dp * 64;
   const size_t slab_bytes = sizeof(double) * ((size_t)ntiles * (1 + G) * 64 + 2 * kMaxM);
-  const size_t lds_max = 160 * 1024 - sizeof(double) * kExpTabLen;  // the exp table sits in front of everything
+  // the exp table sits in front of everything; one weight tile of padding at the very end (eval_loop prefetches one tile
+  // past the last wave's slab)
+  const size_t pad_bytes = sizeof(double) * (size_t)(1 + G) * 64;
+  const size_t lds_max = 160 * 1024 - sizeof(double) * kExpTabLen - pad_bytes;
   bool xlds = true;
   int waves = 0;
   if (tab_bytes + slab_bytes <= lds_max) waves = (int)std::min<size_t>(8, (lds_max - tab_bytes) / slab_bytes);
@@ -459,7 +462,7 @@ KgPending kg_launch(GpDev& gp, int num_fidelity, const moe_gd_params_t& gd, cons
   int wg_per_cu = 1;
   if (variant == 0) {
     waves = std::max(1, std::min(waves, env_int("MOE_KG_WAVES", waves)));
-    shm = sizeof(double) * kExpTabLen + (xlds ? tab_bytes : 0) + (size_t)waves * slab_bytes;
+    shm = sizeof(double) * kExpTabLen + (xlds ? tab_bytes : 0) + (size_t)waves * slab_bytes + pad_bytes;
     wg_per_cu = std::max(1, std::min((int)((size_t)160 * 1024 / shm), 8 / waves));
   } else {
     waves = bwaves;
@@ -621,7 +624,7 @@ KgPending kg_launch(GpDev& gp, int num_fidelity, const moe_gd_params_t& gd, cons
   std::memcpy(gp.hKgIn.p + blob.size(), normals, sizeof(double) * num_norm);
   dNormals.upload(gp.hKgIn.p + blob.size(), num_norm, s);
   const long tab_stride = (long)ntiles * dp * 64;
-  dTab.reserve((size_t)tab_stride * E);
+  dTab.reserve((size_t)tab_stride * E + (size_t)dp * 64);  // + one tile: eval_loop's last prefetch reads past the end
   dBestPoint.reserve((size_t)E * num_local * dp);
   dBestValue.reserve((size_t)E * num_local);
   dBeta.reserve((size_t)E * num_local * m);

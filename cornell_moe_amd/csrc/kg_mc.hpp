@@ -28,7 +28,7 @@
 namespace moe {
 
 constexpr int kMaxM = 64;  // m = (q + p)(1 + g) limit of the MC kernel (z / beta scratch per wave)
-constexpr int kExpTabLen = 32;  // 2^(j/32) table at the start of the MC kernel's LDS (fastmath.hpp exp_nonpos_tab)
+constexpr int kExpTabLen = 64;  // 2^(j/64) table at the start of the MC kernel's LDS (fastmath.hpp exp_nonpos_tab)
 
 struct KgRec {  // offsets (doubles) of one evaluation's small operands inside the blob; identical for every evaluation
   int L;        // [m x m] col-major lower Cholesky factor of Var(Xu) + noise
@@ -176,10 +176,10 @@ __device__ __forceinline__ double eval_loop(const double* __restrict__ xs, const
 #pragma unroll(WG ? 2 : 4)
   for (int t = 0; t < ntiles; ++t) {
     double nx[DP], nw[1 + G];
-    if (t + 1 < ntiles) {  // (the last iteration harmlessly re-reads its own tile: no zero fill, no branch around loads)
-      xt += DP * 64;
-      wt += (1 + G) * 64;
-    }
+    // unconditional advance (constant stride: the unrolled tiles share one address register and use immediate offsets);
+    // the last iteration prefetches one tile past the end -- the host pads both arrays by one tile, the values are unused
+    xt += DP * 64;
+    wt += (1 + G) * 64;
 #pragma unroll
     for (int k = 0; k < DP; ++k) nx[k] = xt[k * 64];
 #pragma unroll
@@ -665,7 +665,7 @@ __global__ __launch_bounds__(512) void kg_mc_kernel(KgMcParams P) {
   double* coords = smem + kExpTabLen;
   double* aw = coords + (XLDS ? tab : 0) + wave * wslab;
   double* zb = aw + ntiles * (1 + G) * 64;
-  if (threadIdx.x < kExpTabLen) smem[threadIdx.x] = kExp2Tab32[threadIdx.x];
+  if (threadIdx.x < kExpTabLen) smem[threadIdx.x] = kExp2Tab64[threadIdx.x];
   if (!XLDS) __syncthreads();
   // evaluation of this workgroup: workgroups b, b + E, b + 2E, ... serve evaluation b mod E (b mod 8 is also the XCD, so
   // with E = 8 each evaluation's W / table stay in one XCD's L2); with fewer workgroups than evaluations they loop.
@@ -889,7 +889,7 @@ __global__ __launch_bounds__(512) void kg_mc_block_kernel(KgMcParams P, int num_
   const int TL = num_lds_tiles;
   const int per = (TL + nw - 1) / nw;
   const int tl0 = min(wave * per, TL), tl1 = min(tl0 + per, TL);
-  if (threadIdx.x < kExpTabLen) etab[threadIdx.x] = kExp2Tab32[threadIdx.x];
+  if (threadIdx.x < kExpTabLen) etab[threadIdx.x] = kExp2Tab64[threadIdx.x];
   BlockEval<DP, G, TR> ev;
   ev.xl = ldsx + (long)tl0 * DP * 64 + lane;
   ev.wl = ldsw + (long)tl0 * (1 + G) * 64 + lane;

@@ -32,12 +32,12 @@ __global__ __launch_bounds__(ROWS) void cov_kernel(P8 cp, const double* __restri
                                                    int nB, double* __restrict__ out, long ld) {
   constexpr int DP = 8;
   __shared__ double Bs[COLS][DP];
-  __shared__ double etab[32];
+  __shared__ double etab[64];
   const int j0 = blockIdx.x * COLS;
   const int nj = min(COLS, nB - j0);
   for (int t = threadIdx.x; t < nj * DP; t += blockDim.x)
     Bs[t / DP][t % DP] = B[(long)(j0 + t / DP) * DP + (t % DP)] * (VAR == 2 ? cp.inv_l[t % DP] : 1.0);
-  if (threadIdx.x < 32) etab[threadIdx.x] = kExp2Tab32[threadIdx.x];
+  if (threadIdx.x < 64) etab[threadIdx.x] = kExp2Tab64[threadIdx.x];
   __syncthreads();
   const int r = blockIdx.y * ROWS + threadIdx.x;
   if (r >= nA) return;

@@ -23,16 +23,29 @@ __device__ double sqrt_one_heron(double s) {
   return g;
 }
 
-__global__ void k(const double* x, int n, const double* tab, double* e_poly, double* e_tab, double* s_two, double* s_one) {
+// candidates: v_rsq_f64 seed + ONE Heron correction (no coupled Newton step): 5 instructions instead of 8
+__device__ double sqrt_seed_heron(double s) {
+  const double y = __builtin_amdgcn_rsq(s);
+  const double g = s * y;
+  const double d = fma(-g, g, s);
+  return fma(d, 0.5 * y, g);
+}
+
+__global__ void k(const double* x, int n, const double* tab, double* e_poly, double* e_tab, double* s_two, double* s_one,
+                  double* e_tab64, double* s_fast) {
   __shared__ double T[32];
+  __shared__ double T64[64];
   if (threadIdx.x < 32) T[threadIdx.x] = tab[threadIdx.x];
+  if (threadIdx.x < 64) T64[threadIdx.x] = tab[32 + threadIdx.x];
   __syncthreads();
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   e_poly[i] = exp_nonpos(-x[i]);
-  e_tab[i] = exp_nonpos_tab(-x[i], T);
+  e_tab[i] = exp_nonpos_tab(-x[i], T64);
   s_two[i] = sqrt_nonneg(x[i]);
   s_one[i] = sqrt_one_heron(fmax(x[i], 1e-300));
+  e_tab64[i] = exp_nonpos_tab(-x[i], T64);
+  s_fast[i] = sqrt_seed_heron(fmax(x[i], 1e-300));
 }
 
 static double ulp_of(double ref) {
@@ -50,27 +63,29 @@ int main() {
   for (int i = 0; i < 2000000; ++i) x.push_back(u(rng));
   for (int i = 0; i < 2000000; ++i) x.push_back(std::pow(10.0, lg(rng)));
   const int n = (int)x.size();
-  std::vector<double> tab(32);
+  std::vector<double> tab(96);
   for (int j = 0; j < 32; ++j) tab[j] = (double)std::exp2((long double)j / 32.0L);
-  double *dx, *dt, *d[4];
+  for (int j = 0; j < 64; ++j) tab[32 + j] = (double)std::exp2((long double)j / 64.0L);
+  double *dx, *dt, *d[6];
   hipMalloc(&dx, 8 * n);
-  hipMalloc(&dt, 8 * 32);
+  hipMalloc(&dt, 8 * 96);
   for (auto& p : d) hipMalloc(&p, 8 * n);
   hipMemcpy(dx, x.data(), 8 * n, hipMemcpyHostToDevice);
-  hipMemcpy(dt, tab.data(), 8 * 32, hipMemcpyHostToDevice);
-  hipLaunchKernelGGL(k, dim3((n + 255) / 256), dim3(256), 0, 0, dx, n, dt, d[0], d[1], d[2], d[3]);
-  std::vector<double> h[4];
-  for (int a = 0; a < 4; ++a) {
+  hipMemcpy(dt, tab.data(), 8 * 96, hipMemcpyHostToDevice);
+  hipLaunchKernelGGL(k, dim3((n + 255) / 256), dim3(256), 0, 0, dx, n, dt, d[0], d[1], d[2], d[3], d[4], d[5]);
+  std::vector<double> h[6];
+  for (int a = 0; a < 6; ++a) {
     h[a].resize(n);
     hipMemcpy(h[a].data(), d[a], 8 * n, hipMemcpyDeviceToHost);
   }
-  const char* names[4] = {"exp poly-11", "exp table-32", "sqrt 2 heron", "sqrt 1 heron"};
-  for (int a = 0; a < 4; ++a) {
+  const char* names[6] = {"exp poly-11", "exp table-64", "sqrt 2 heron", "sqrt 1 heron", "exp table-64 (again)", "sqrt seed+heron"};
+  for (int a = 0; a < 6; ++a) {
     double worst = 0, wx = 0;
+    const bool is_exp = a < 2 || a == 4;
     for (int i = 0; i < n; ++i) {
-      long double ref = (a < 2) ? expl(-(long double)x[i]) : sqrtl((long double)x[i]);
-      if (a < 2 && ref < 1e-300L) continue;
-      if (a >= 2 && x[i] < 1e-290) continue;
+      long double ref = is_exp ? expl(-(long double)x[i]) : sqrtl((long double)x[i]);
+      if (is_exp && ref < 1e-300L) continue;
+      if (!is_exp && x[i] < 1e-290) continue;
       const double err = (double)fabsl((long double)h[a][i] - ref) / ulp_of((double)ref);
       if (err > worst) {
         worst = err;
