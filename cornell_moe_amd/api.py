@@ -312,6 +312,8 @@ class DeviceGP(object):
         gd = self._gd(inner_params)
         bounds, bp = _d(bounds)
         discrete, dpp = _d(discrete)
+        if not 0 <= num_fidelity < self.d:
+            raise BoundsException("num_fidelity out of range", num_fidelity, 0, self.d - 1)
         P = discrete.reshape(-1, self.d - num_fidelity).shape[0]
         Xq, qp = _d(Xq)
         q = Xq.reshape(-1, self.d).shape[0]
@@ -350,6 +352,8 @@ class DeviceGP(object):
         gd = self._gd(inner_params)
         bounds, bp = _d(bounds)
         discrete, dpp = _d(discrete)
+        if not 0 <= num_fidelity < self.d:
+            raise BoundsException("num_fidelity out of range", num_fidelity, 0, self.d - 1)
         P = discrete.reshape(-1, self.d - num_fidelity).shape[0]
         Xq_all = np.ascontiguousarray(Xq_all, dtype=np.float64)
         R, q, _ = Xq_all.shape
@@ -380,6 +384,8 @@ class DeviceGP(object):
         go, gi = self._gd(outer_params), self._gd(inner_params)
         bounds, bp = _d(bounds)
         discrete, dpp = _d(discrete)
+        if not 0 <= num_fidelity < self.d:
+            raise BoundsException("num_fidelity out of range", num_fidelity, 0, self.d - 1)
         P = discrete.reshape(-1, self.d - num_fidelity).shape[0]
         starts = np.ascontiguousarray(starts, dtype=np.float64)
         S, q, _ = starts.shape
@@ -459,6 +465,8 @@ class DeviceGPMCMC(object):
         g = DeviceGP._gd(inner_params)
         bounds, bp = _d(bounds)
         disc = self._local(discrete_all)
+        if not 0 <= num_fidelity < self.d:
+            raise BoundsException("num_fidelity out of range", num_fidelity, 0, self.d - 1)
         P = disc.shape[1] // (self.d - num_fidelity)
         best = self._local(best_so_far).ravel()
         normals, npn = _d(normals)
@@ -510,6 +518,8 @@ class DeviceGPMCMC(object):
         go, gi = DeviceGP._gd(outer_params), DeviceGP._gd(inner_params)
         bounds, bp = _d(bounds)
         disc = self._local(discrete_all)
+        if not 0 <= num_fidelity < self.d:
+            raise BoundsException("num_fidelity out of range", num_fidelity, 0, self.d - 1)
         P = disc.shape[1] // (self.d - num_fidelity)
         best = self._local(best_so_far).ravel()
         normals, npn = _d(normals)

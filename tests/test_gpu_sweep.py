@@ -22,6 +22,14 @@ CASES = [
     (109, 200, 8, 4, 0, 10, 100, (), 1, 0, (1, 6, 1, 3, 0.0, 1.0, 0.1, 1e-10)),   # headline shape, small
     (110, 40, 12, 2, 0, 6, 30, (0, 5, 11), 1, 0, (1, 6, 1, 3, 0.0, 1.0, 0.1, 1e-10)),  # d = 12 (C5's dimension), g = 3
     (111, 33, 16, 1, 0, 3, 20, (), 0, 0, (1, 6, 1, 3, 0.0, 1.0, 0.1, 1e-10)),     # largest supported dimension
+    # extremes of the parameter space
+    (112, 1, 1, 1, 0, 1, 1, (), 1, 0, (1, 6, 1, 3, 0.0, 1.0, 0.1, 1e-10)),        # one training point, d = 1, ONE MC sample, P = 1
+    (113, 3, 2, 1, 0, 1, 2, (), 0, 0, (1, 1, 1, 3, 0.0, 1.0, 0.1, 1e-10)),        # one antithetic pair, a single GD step
+    (114, 45, 3, 16, 0, 4, 12, (0, 1, 2), 1, 0, (1, 3, 1, 3, 0.0, 1.0, 0.1, 1e-10)),  # m = (q+p)(1+g) = 64: the kernels' limit
+    (115, 40, 3, 13, 3, 4, 12, (1, 2, 0), 0, 0, (1, 3, 1, 3, 0.0, 1.0, 0.1, 1e-10)),  # m = 64 with points being sampled
+    (116, 30, 4, 2, 0, 5, 24, (), 1, 3, (1, 6, 1, 3, 0.0, 1.0, 0.1, 1e-10)),      # three of four dimensions are fidelities
+    (117, 70, 3, 2, 0, 5, 30, (), 1, 0, (1, 6, 1, 3, 0.0, 1.0, 0.1, 1.0)),        # loose tolerance: the inner GD stops at once
+    (118, 70, 3, 2, 0, 5, 30, (), 0, 0, (1, 6, 3, 3, 1.0, 2.5, 1.0, 1e-12)),      # big steps against the walls, 3 restarts
 ]
 
 
@@ -121,3 +129,35 @@ def test_ei_batch_matches_single_evaluations_and_oracle():
         eo, go = O.ei(Xq_all[e], w.Xp, w.M, eb, w.ei_normals)
         assert abs(eo - ei[e]) <= TOL["ei"] * max(abs(eo), 1e-3)
         assert np.abs(grad[e] - go).max() <= TOL["grad_ei"] * max(np.abs(go).max(), 1e-3)
+
+
+def test_limits_fail_loudly_and_ei_extremes():
+    """Beyond the kernels' limits the C ABI reports BoundsException (never a silent fallback); at the limits q,p-EI still
+    matches the oracle (u = q + p = 16, one MC sample)."""
+    from cornell_moe_amd import api
+    from cornell_moe_amd.workloads import make_workload
+    from oracle import orc
+    w = make_workload(seed=130, n=40, d=3, q=17, M=8, P=3, derivs=(0, 1, 2))
+    G = api.DeviceGP(w.hyperparameters, w.X, w.y, w.noise, w.derivs)
+    with pytest.raises(api.BoundsException):   # m = 17 * 4 = 68 > 64
+        G.kg(w.inner_gd, w.bounds, w.discrete, w.Xq, None, w.M, 0.0, w.kg_normals)
+    with pytest.raises(api.BoundsException):   # u = 17 > 16
+        G.ei(w.Xq, None, w.M, 0.0, w.ei_normals)
+    with pytest.raises(api.BoundsException):   # num_mc must be positive
+        G.kg(w.inner_gd, w.bounds, w.discrete, w.Xq[:2], None, 0, 0.0, w.kg_normals)
+    with pytest.raises(api.BoundsException):   # num_fidelity must leave at least one free dimension
+        G.kg(w.inner_gd, w.bounds[:0], w.discrete[:, :0], w.Xq[:2], None, w.M, 0.0, w.kg_normals, num_fidelity=3)
+    with pytest.raises(api.BoundsException):   # five observed derivatives: more slots than the MC kernels carry
+        w5 = make_workload(seed=131, n=20, d=5, q=1, M=8, P=3, derivs=(0, 1, 2, 3, 4))
+        G5 = api.DeviceGP(w5.hyperparameters, w5.X, w5.y, w5.noise, w5.derivs)
+        G5.kg(w5.inner_gd, w5.bounds, w5.discrete, w5.Xq, None, w5.M, 0.0, w5.kg_normals)
+    for q, p, M in ((16, 0, 1), (9, 7, 3), (1, 15, 64)):
+        w = make_workload(seed=140 + q, n=50, d=3, q=q, M=M, P=3, derivs=(), p=p)
+        O = orc.OrcGP(1, w.alpha, w.lengths, w.X, w.y, w.noise, ())
+        G = api.DeviceGP(w.hyperparameters, w.X, w.y, w.noise, ())
+        Xp = w.Xp if p else None
+        eb = float(np.median(w.y[:, 0]))
+        eo, go = O.ei(w.Xq, Xp, M, eb, w.ei_normals)
+        eg, gg = G.ei(w.Xq, Xp, M, eb, w.ei_normals)
+        assert abs(eo - eg) <= TOL["ei"] * max(abs(eo), 1e-3)
+        assert np.abs(gg - go).max() <= TOL["grad_ei"] * max(np.abs(go).max(), 1e-3)
