@@ -8,6 +8,8 @@
 //  * blocked right-looking Cholesky (NB = 64) + explicit inverse of the factor: replaces ComputeCholeskyFactorL
 //    (gpp_linear_algebra.cpp:109-148) and turns every TriangularMatrixVectorSolve (:160-187) of the reference into a
 //    GEMM against L^-1, which is what lets the posterior solves run wide instead of as 1000 dependent steps.
+#include <cstdlib>
+
 #include "kernels.hpp"
 
 namespace moe {
@@ -89,6 +91,103 @@ __global__ __launch_bounds__(256) void tile_gemm_kernel(int M, int Ncols, int K,
     }
 }
 
+// The same GEMM on the matrix pipe for big outputs: 64 x 64 tile per workgroup, 4 wavefronts, each owning a 32 x 32
+// quadrant as 2 x 2 v_mfma_f64_16x16x4_f64 tiles.  The FP64 MFMA peak equals the FP64 vector peak on gfx950, but one MFMA
+// retires 2048 flops from ONE operand pair (one f64 per lane each), so the LDS traffic per flop is 8x lower than the 4 x 4
+// register-tile FMA loop above, which is LDS-issue bound at ~50 % of peak.  Operands are fed transposed (MFMA's A <- B
+// tile, MFMA's B <- A tile) so that a result register's 16 consecutive lanes hold 16 consecutive ROWS of C: coalesced
+// column-major stores.  The next K tile travels global -> registers while the current one is multiplied out of LDS.
+using f64x4 = __attribute__((ext_vector_type(4))) double;
+
+template <int MODE, bool NEG>
+__global__ __launch_bounds__(256) void mfma_gemm_kernel(int M, int Ncols, int K, const double* __restrict__ A, long lda,
+                                                       const double* __restrict__ B, long ldb, double* __restrict__ C,
+                                                       long ldc, int xmul) {
+  constexpr int TM = 64, TN = 64, TK = 16, LD = 65;
+  __shared__ double As[TK][LD];
+  __shared__ double Bs[TK][LD];
+  // Triangular operands make a tile row's K range proportional to its index; all workgroups are resident at once, and the
+  // hardware hands consecutive ids to consecutive CUs, so row indices are scattered (multiplier co-prime with the row
+  // count) to give every CU a mix of long and short rows.
+  const int bx = (int)(((long)blockIdx.x * xmul + (long)blockIdx.y * 97) % gridDim.x);
+  const int i0 = bx * TM, j0 = blockIdx.y * TN;
+  int k_lo = 0, k_hi = K;
+  if (MODE == 1) k_hi = min(K, i0 + TM);
+  if (MODE == 2) k_lo = (i0 / TK) * TK;
+  if (MODE == 3) k_lo = (j0 / TK) * TK;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int wi = (wave & 1) * 32, wj = (wave >> 1) * 32;  // this wavefront's quadrant
+  const int lk = lane >> 4, lx = lane & 15;
+  f64x4 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) acc[a][b] = f64x4{0.0, 0.0, 0.0, 0.0};
+
+  // software pipeline: tile k0 + TK travels global -> registers while tile k0 is multiplied out of LDS
+  double ra[4], rb[4];
+  auto fetch = [&](int k0) {
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int t = threadIdx.x + 256 * it;
+      if (MODE == 1 || MODE == 3) {
+        const int ii = t % TM, kk = t / TM;
+        const int gi = i0 + ii, gk = k0 + kk;
+        ra[it] = (gi < M && gk < K && (MODE == 3 || gk <= gi)) ? A[(long)gi + (long)gk * lda] : 0.0;
+      } else {
+        const int kk = t % TK, ii = t / TK;
+        const int gi = i0 + ii, gk = k0 + kk;
+        bool ok = gi < M && gk < K;
+        if (MODE == 2) ok = ok && gk >= gi;
+        ra[it] = ok ? A[(long)gk + (long)gi * lda] : 0.0;
+      }
+      const int kk = t % TK, jj = t / TK;
+      const int gk = k0 + kk, gj = j0 + jj;
+      rb[it] = (gk < K && gj < Ncols && (MODE != 3 || gk >= gj)) ? B[(long)gk + (long)gj * ldb] : 0.0;
+    }
+  };
+  auto stash = [&]() {
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int t = threadIdx.x + 256 * it;
+      if (MODE == 1 || MODE == 3)
+        As[t / TM][t % TM] = ra[it];
+      else
+        As[t % TK][t / TK] = ra[it];
+      Bs[t % TK][t / TK] = rb[it];
+    }
+  };
+  if (k_lo < k_hi) fetch(k_lo);
+  for (int k0 = k_lo; k0 < k_hi; k0 += TK) {
+    stash();
+    __syncthreads();
+    if (k0 + TK < k_hi) fetch(k0 + TK);
+#pragma unroll
+    for (int k4 = 0; k4 < TK; k4 += 4) {
+      double fa[2], fb[2];
+#pragma unroll
+      for (int a = 0; a < 2; ++a) fa[a] = As[k4 + lk][wi + 16 * a + lx];  // -> MFMA's B operand: rows of C
+#pragma unroll
+      for (int b = 0; b < 2; ++b) fb[b] = Bs[k4 + lk][wj + 16 * b + lx];  // -> MFMA's A operand: columns of C
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb[b], fa[a], acc[a][b], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+  // D[x][y] = C[row = y][col = x]: lane holds y = lane & 15 (row of C), x = (lane >> 4) + 4 r (column of C)
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int gi = i0 + wi + 16 * a + lx, gj = j0 + wj + 16 * b + lk + 4 * r;
+        if (gi < M && gj < Ncols) C[(long)gi + (long)gj * ldc] = NEG ? -acc[a][b][r] : acc[a][b][r];
+      }
+}
+
 template <int MODE, bool NEG = false>
 void tile_gemm(int M, int Ncols, int K, const double* A, long lda, const double* B, long ldb, double* C, long ldc,
                hipStream_t s) {
@@ -97,7 +196,21 @@ void tile_gemm(int M, int Ncols, int K, const double* A, long lda, const double*
   const long blocks64 = (long)((M + 63) / 64) * ((Ncols + 63) / 64);
   if (blocks64 >= 512) {
     dim3 grid((M + 63) / 64, (Ncols + 63) / 64);
-    hipLaunchKernelGGL((tile_gemm_kernel<64, 64, MODE, 16, NEG>), grid, dim3(256), 0, s, M, Ncols, K, A, lda, B, ldb, C, ldc);
+    static const bool use_mfma = [] {
+      const char* v = std::getenv("MOE_GEMM_MFMA");
+      return !(v && *v == '0');
+    }();
+    if (use_mfma) {
+      int xmul = 1;
+      for (int cand : {37, 41, 43, 47, 53, 59})
+        if ((int)grid.x % cand != 0) {
+          xmul = cand;
+          break;
+        }
+      hipLaunchKernelGGL((mfma_gemm_kernel<MODE, NEG>), grid, dim3(256), 0, s, M, Ncols, K, A, lda, B, ldb, C, ldc, xmul);
+    }
+    else
+      hipLaunchKernelGGL((tile_gemm_kernel<64, 64, MODE, 16, NEG>), grid, dim3(256), 0, s, M, Ncols, K, A, lda, B, ldb, C, ldc);
   } else {
     dim3 grid((M + 31) / 32, (Ncols + 15) / 16);
     hipLaunchKernelGGL((tile_gemm_kernel<32, 16, MODE, 64, NEG>), grid, dim3(256), 0, s, M, Ncols, K, A, lda, B, ldb, C, ldc);

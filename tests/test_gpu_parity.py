@@ -44,6 +44,14 @@ def test_device_cholesky_known_answers(api, golden):
         L, Linv = api.debug_cholesky(A)
         assert rel(L @ L.T, A) < 1e-13 and np.allclose(np.triu(L, 1), 0.0)
         assert rel(Linv @ L, np.eye(n)) < 1e-12
+    # big enough that the recursive inversion's top GEMMs take the FP64-MFMA kernel (>= 512 output tiles of 64 x 64),
+    # with a ragged edge (3111 = 48 * 64 + 39)
+    n = 3111
+    B = rng.standard_normal((n, 64))
+    A = B @ B.T + np.diag(rng.uniform(1.0, 2.0, n))
+    L, Linv = api.debug_cholesky(A)
+    assert rel(L, np.linalg.cholesky(A)) < 1e-12
+    assert rel(Linv @ L, np.eye(n)) < 1e-11 and np.allclose(np.triu(Linv, 1), 0.0)
 
 
 def test_golden_gp_and_posterior(api, golden):
