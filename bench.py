@@ -184,9 +184,16 @@ def main():
         Gp = grad_passes / float(local_evals * n_local)   # counted value+gradient passes per sample
         flops = n_local * npts * (S * (3 * w.d + 32) + Gp * (5 * w.d + 34))   # SURVEY 8(d) per-point figures
         ach_tflops = flops / (mc_ms * 1e-3) / 1e12
-        cov_ms = ms_cov / args.steps
-        cov_bytes = 8.0 * (w.n * w.d + n_local * w.d + w.n * n_local)      # 8[nA d + nB d + nA nB]
-        cov_tbs = cov_bytes / (cov_ms * 1e-3) / 1e12 if cov_ms > 0 else 0.0
+        # ---- roofline of the covariance-assembly kernel (HBM write-bound) ----
+        # The q-KG gradient tail no longer materialises T = K(X, x*) (kg.hip: launch_fused_tail), so the assembly kernel
+        # (a3/a4: GP build, posterior queries, the d-KG tail) is measured live on the SAME N x M shape the tail used to
+        # build -- N = n training rows x (R * M) columns, 640 MB at C3 -- through moe_cov_build_probe (HIP events on the
+        # library's stream around `repeat` launches).
+        probe_pts = np.random.default_rng(7).uniform(size=(R * n_local, w.d))
+        cov_launch_ms, cov_bytes_launch = G.cov_build_probe(probe_pts, repeat=10)
+        cov_ms = cov_launch_ms / R
+        cov_bytes = cov_bytes_launch / R                                    # 8[nA d + nB d + nA nB]
+        cov_tbs = cov_bytes_launch / (cov_launch_ms * 1e-3) / 1e12 if cov_launch_ms > 0 else 0.0
         out = {
             "metric": "q-KG gradient evals/s (n=1000,d=8,q=4,10k MC)", "value": value, "unit": "evals/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
@@ -207,9 +214,12 @@ def main():
                                  "measured HBM bytes per launch (bytes, PMC), tiny next to the compute time"},
             "roofline_cov_build": {"bound": "hbm", "achieved": cov_tbs * 1e3, "peak": HBM_PEAK_TBS * 1e3, "unit": "GB/s",
                                    "frac": cov_tbs / HBM_PEAK_TBS, "traffic": measured_traffic("cov_build_kernel"),
-                                   "kernel": "cov_build_kernel (N x M per evaluation, one launch per step)",
-                                   "avg_launch_ms": cov_ms * R, "avg_ms_per_eval": cov_ms, "bytes_per_eval": cov_bytes},
-            "kernel_ms_per_eval": {"mc": mc_ms, "cov_build": cov_ms, "tail": ms_tail / args.steps,
+                                   "kernel": "cov_build_kernel, N x (R M) = %d x %d, measured by moe_cov_build_probe (the q-KG "
+                                             "tail itself no longer writes this matrix: it recomputes the entries where "
+                                             "they are consumed)" % (w.n, R * n_local),
+                                   "avg_launch_ms": cov_launch_ms, "bytes_per_launch": cov_bytes_launch,
+                                   "bytes_per_eval_equiv": cov_bytes},
+            "kernel_ms_per_eval": {"mc": mc_ms, "cov_build": ms_cov / args.steps, "tail": ms_tail / args.steps,
                                    "state_host": ms_state / args.steps},
         }
         if not args.no_cpu_baseline and world == 1:  # reported baseline: rank 0 at N = 1 only

@@ -97,7 +97,7 @@ struct KgTailParams {
   int out_stride;
 };
 
-constexpr int kTbChunk = 128;  // samples per workgroup of kg_tb_kernel
+constexpr int kTbChunk = 256;  // samples per workgroup of kg_tb_kernel / kg_fused_point_kernel
 
 // c_i = L^-1 ( K(Xu, x*_i)[:, 0] - W^T T_i ) for every sample; one wavefront per sample at a time, lane r owns component r.
 // S_W = W^T T_i comes either precomputed (P.SW: tile GEMM, large m) or is formed here by lanes striding the N rows with
@@ -216,14 +216,14 @@ __global__ __launch_bounds__(256) void kg_gtb_kernel(KgTailParams P) {
   if (threadIdx.x == 0) P.out[(long)e * P.out_stride + 1 + P.m * P.m + P.ngrad + gc] = tot;
 }
 
-// ZC[e][r + j m] = sum_i z_i[r] c_i[j]; workgroup (r, e); the r == 0 workgroup also forms
+// ZC[e][r + j m] = sum_i z_i[r] c_i[j]; workgroup (r, j, e); the (0, 0) workgroup also forms
 // kg_sum = sum_i (best_posterior + best_value_i)   (.cpp:196).
 __global__ __launch_bounds__(256) void kg_zc_kernel(KgTailParams P) {
   __shared__ double red[4];
-  const int r = blockIdx.x, e = blockIdx.y;
+  const int r = blockIdx.x, j = blockIdx.y, e = blockIdx.z;
   const int m = P.m;
   double* out = P.out + (long)e * P.out_stride;
-  for (int j = 0; j < m; ++j) {
+  {
     double acc = 0.0;
     for (int i = threadIdx.x; i < P.num_local; i += 256) {
       const int s = P.first_sample + i;
@@ -233,7 +233,7 @@ __global__ __launch_bounds__(256) void kg_zc_kernel(KgTailParams P) {
     const double tot = block_sum_256(acc, red);
     if (threadIdx.x == 0) out[1 + r + j * m] = tot;
   }
-  if (r == 0) {
+  if (r == 0 && j == 0) {
     const double bp = P.blob[(long)e * P.rec.stride + P.rec_bp];
     double acc = 0.0;
     for (int i = threadIdx.x; i < P.num_local; i += 256) acc += bp + P.best_value[(long)e * P.num_local + i];
@@ -330,6 +330,203 @@ void launch_tail(const KgTailParams& P, hipStream_t s) {
     hipLaunchKernelGGL((kg_tb_kernel<64>), gtb, dim3(256), 0, s, P);
   hipLaunchKernelGGL(kg_gtb_kernel, dim3(P.ngrad, P.E), dim3(256), 0, s, P);
   MOE_HIP_CHECK(hipGetLastError());
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Fused tail for q-KG (no derivative observations, m = q + p <= 8): the N x M matrix T = K(X, x*_i) is never written.
+// Its entries are recomputed where they are consumed -- once with a thread per SAMPLE (S_W = W^T T_i, then c_i), once with a
+// thread per training POINT (TB partials) -- which costs ~2 x 46 FP64 instructions per entry against 16 B written + 24 B
+// re-read per entry through HBM: at C3 the covariance build + S_W + TB kernels took 86 us per evaluation, these two take
+// about half.  Operands that are uniform over the workgroup (the point tile in the first kernel, the sample chunk in the
+// second) are staged in LDS pre-scaled by 1/length and read as broadcasts.
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int kFusedTile = 256;  // points (kernel A) / samples (kernel B) staged per LDS tile; == kTbChunk
+
+template <int COV>
+__device__ __forceinline__ double radial_base(double r2, const double* __restrict__ etab) {
+  if (COV == MOE_COV_SQUARE_EXPONENTIAL) return exp_nonpos_tab(-0.5 * r2, etab);
+  const double a = 2.236067977499789696409173668731276235 * sqrt_pos(r2);
+  return exp_nonpos_tab(-a, etab) * fma(a, fma(a, 1.0 / 3.0, 1.0), 1.0);
+}
+
+// thread = sample, blockIdx.z = slice of the training points: SWpart[e][i][slice][c] = sum over the slice of W[j, c] k(X_j, x*_i)
+// (the slices only exist to give the chip enough wavefronts: E * M / 64 alone is ~1 per SIMD at the headline shape)
+template <int DP, int MU, int COV>
+__global__ __launch_bounds__(256) void kg_fused_sample_kernel(KgTailParams P, const double* __restrict__ X, int n,
+                                                             double* __restrict__ SWpart) {
+  __shared__ double etab[kExpTabLen];
+  __shared__ double Xt[kFusedTile][DP];
+  __shared__ double Wt[kFusedTile][MU];
+  const int e = blockIdx.y, m = P.m, N = P.N;
+  const int slices = gridDim.z, slice = blockIdx.z;
+  const int per = ((n + slices - 1) / slices + 63) / 64 * 64;
+  const int j_lo = slice * per, j_hi = min(n, j_lo + per);
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  const bool ok = i < P.num_local;
+  const long w = (long)e * P.num_local + (ok ? i : 0);
+  if (threadIdx.x < kExpTabLen) etab[threadIdx.x] = kExp2Tab64[threadIdx.x];
+  double xs[DP], acc[MU];
+#pragma unroll
+  for (int k = 0; k < DP; ++k) xs[k] = P.best_point[w * DP + k] * P.cp.inv_l[k];
+#pragma unroll
+  for (int c = 0; c < MU; ++c) acc[c] = 0.0;
+  const double* We = P.W + (long)e * P.w_stride;
+  for (int j0 = j_lo; j0 < j_hi; j0 += kFusedTile) {
+    __syncthreads();
+    for (int t = threadIdx.x; t < kFusedTile * DP; t += 256) {
+      const int jj = t / DP, k = t % DP;
+      Xt[jj][k] = (j0 + jj < j_hi) ? X[(long)(j0 + jj) * DP + k] * P.cp.inv_l[k] : 0.0;
+    }
+    for (int t = threadIdx.x; t < kFusedTile * MU; t += 256) {
+      const int jj = t % kFusedTile, c = t / kFusedTile;  // W_e is [N x m] col-major: consecutive jj are contiguous
+      Wt[jj][c] = (j0 + jj < j_hi && c < m) ? We[(long)c * N + j0 + jj] : 0.0;  // zero weight: padded points drop out
+    }
+    __syncthreads();
+    const int cnt = min(kFusedTile, j_hi - j0);
+#pragma unroll 2
+    for (int jj = 0; jj < cnt; ++jj) {
+      double r2 = 1.0e-300;
+#pragma unroll
+      for (int k = 0; k < DP; ++k) {
+        const double dlt = Xt[jj][k] - xs[k];
+        r2 = fma(dlt, dlt, r2);
+      }
+      const double t = radial_base<COV>(r2, etab);
+#pragma unroll
+      for (int c = 0; c < MU; ++c) acc[c] = fma(Wt[jj][c], t, acc[c]);
+    }
+  }
+  if (!ok) return;
+#pragma unroll
+  for (int c = 0; c < MU; ++c) SWpart[(w * slices + slice) * MU + c] = acc[c];
+}
+
+// thread = sample: S_W = sum of the slices (fixed order); R_r = alpha (k(Xu_r, x*_i) - S_W[r]); c_i = L^-1 R by forward
+// substitution (L is m x m, column-major, workgroup-uniform)
+template <int DP, int MU, int COV>
+__global__ __launch_bounds__(256) void kg_fused_c_kernel(KgTailParams P, const double* __restrict__ SWpart, int slices) {
+  __shared__ double etab[kExpTabLen];
+  const int e = blockIdx.y, m = P.m;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (threadIdx.x < kExpTabLen) etab[threadIdx.x] = kExp2Tab64[threadIdx.x];
+  __syncthreads();
+  if (i >= P.num_local) return;
+  const long w = (long)e * P.num_local + i;
+  double xs[DP], sw[MU], cv[MU];
+#pragma unroll
+  for (int k = 0; k < DP; ++k) xs[k] = P.best_point[w * DP + k] * P.cp.inv_l[k];
+#pragma unroll
+  for (int c = 0; c < MU; ++c) {
+    sw[c] = 0.0;
+    for (int sl = 0; sl < slices; ++sl) sw[c] += SWpart[(w * slices + sl) * MU + c];
+  }
+  const double* rec = P.blob + (long)e * P.rec.stride;
+  const double* Lsm = rec + P.rec.L;
+#pragma unroll
+  for (int r = 0; r < MU; ++r) {
+    cv[r] = 0.0;
+    if (r < m) {
+      const double* Xu = rec + P.rec.XuP + (long)r * DP;
+      double r2 = 1.0e-300;
+#pragma unroll
+      for (int k = 0; k < DP; ++k) {
+        const double dlt = Xu[k] * P.cp.inv_l[k] - xs[k];
+        r2 = fma(dlt, dlt, r2);
+      }
+      double R = P.cp.alpha * (radial_base<COV>(r2, etab) - sw[r]);
+#pragma unroll
+      for (int c = 0; c < MU; ++c)
+        if (c < r) R -= Lsm[r + c * m] * cv[c];
+      cv[r] = R / Lsm[r + r * m];
+      P.C[w * m + r] = cv[r];
+    }
+  }
+}
+
+// thread = training point: TBpart[e][chunk][c][row] = sum over the chunk's samples of K(X_row, x*_i) beta_i[c]
+template <int DP, int MU, int COV>
+__global__ __launch_bounds__(256) void kg_fused_point_kernel(KgTailParams P, const double* __restrict__ X, int n) {
+  __shared__ double etab[kExpTabLen];
+  __shared__ double St[kFusedTile][DP];
+  __shared__ double Bt[kFusedTile][MU];
+  const int row = blockIdx.x * 256 + threadIdx.x;
+  const int chunk = blockIdx.y, e = blockIdx.z;
+  const int m = P.m;
+  const int i0 = chunk * kFusedTile, cnt = min(P.num_local - i0, kFusedTile);
+  if (threadIdx.x < kExpTabLen) etab[threadIdx.x] = kExp2Tab64[threadIdx.x];
+  for (int t = threadIdx.x; t < kFusedTile * DP; t += 256) {
+    const int ii = t / DP, k = t % DP;
+    St[ii][k] = (ii < cnt) ? P.best_point[((long)e * P.num_local + i0 + ii) * DP + k] * P.cp.inv_l[k] : 0.0;
+  }
+  for (int t = threadIdx.x; t < kFusedTile * MU; t += 256) {
+    const int ii = t / MU, c = t % MU;
+    Bt[ii][c] = (ii < cnt && c < m) ? P.beta[((long)e * P.num_local + i0 + ii) * m + c] : 0.0;
+  }
+  __syncthreads();
+  const bool ok = row < n;
+  double xr[DP], acc[MU];
+#pragma unroll
+  for (int k = 0; k < DP; ++k) xr[k] = ok ? X[(long)row * DP + k] * P.cp.inv_l[k] : 0.0;
+#pragma unroll
+  for (int c = 0; c < MU; ++c) acc[c] = 0.0;
+#pragma unroll 2
+  for (int ii = 0; ii < cnt; ++ii) {
+    double r2 = 1.0e-300;
+#pragma unroll
+    for (int k = 0; k < DP; ++k) {
+      const double dlt = xr[k] - St[ii][k];
+      r2 = fma(dlt, dlt, r2);
+    }
+    const double t = radial_base<COV>(r2, etab);
+#pragma unroll
+    for (int c = 0; c < MU; ++c) acc[c] = fma(t, Bt[ii][c], acc[c]);
+  }
+  if (ok) {
+    double* dst = P.TBpart + ((long)e * P.chunks + chunk) * m * P.N;
+#pragma unroll
+    for (int c = 0; c < MU; ++c)
+      if (c < m) dst[(long)c * P.N + row] = P.cp.alpha * acc[c];
+  }
+}
+
+template <int DP, int MU, int COV>
+void launch_fused_tail_cov(const KgTailParams& P, const double* X, int n, double* SWpart, int slices, hipStream_t s) {
+  dim3 ga((P.num_local + 255) / 256, P.E, slices), gc((P.num_local + 255) / 256, P.E), gb((n + 255) / 256, P.chunks, P.E);
+  hipLaunchKernelGGL((kg_fused_sample_kernel<DP, MU, COV>), ga, dim3(256), 0, s, P, X, n, SWpart);
+  hipLaunchKernelGGL((kg_fused_c_kernel<DP, MU, COV>), gc, dim3(256), 0, s, P, SWpart, slices);
+  hipLaunchKernelGGL((kg_dir_kernel<DP>), dim3(P.q, P.E), dim3(256), 0, s, P);
+  hipLaunchKernelGGL((kg_fused_point_kernel<DP, MU, COV>), gb, dim3(256), 0, s, P, X, n);
+  hipLaunchKernelGGL(kg_gtb_kernel, dim3(P.ngrad, P.E), dim3(256), 0, s, P);
+  MOE_HIP_CHECK(hipGetLastError());
+}
+
+template <int DP, int MU>
+void launch_fused_tail_inst(const KgTailParams& P, const double* X, int n, double* SWpart, int slices, hipStream_t s) {
+  if (P.cp.type == MOE_COV_SQUARE_EXPONENTIAL)
+    launch_fused_tail_cov<DP, MU, MOE_COV_SQUARE_EXPONENTIAL>(P, X, n, SWpart, slices, s);
+  else
+    launch_fused_tail_cov<DP, MU, MOE_COV_MATERN_NU_2P5>(P, X, n, SWpart, slices, s);
+}
+
+// number of point slices of kg_fused_sample_kernel: enough wavefronts for ~4 per SIMD
+int fused_tail_slices(int E, int num_local, int n, int num_cu) {
+  const long waves = (long)E * ((num_local + 255) / 256) * 4;
+  const long want = (long)num_cu * 4 * 4;
+  int s = (int)std::min<long>(8, std::max<long>(1, (want + waves - 1) / waves));
+  return std::max(1, std::min(s, (n + 63) / 64));
+}
+
+// T-free tail (requires g == 0, m <= 8, chunk size kTbChunk == kFusedTile)
+void launch_fused_tail(const KgTailParams& P, const double* X, int n, double* SWpart, int slices, hipStream_t s) {
+  static_assert(kFusedTile == kTbChunk, "the TB partial layout is shared with kg_gtb_kernel");
+  const bool m4 = P.m <= 4;
+  switch (P.cp.dp) {
+    case 4: m4 ? launch_fused_tail_inst<4, 4>(P, X, n, SWpart, slices, s) : launch_fused_tail_inst<4, 8>(P, X, n, SWpart, slices, s); break;
+    case 8: m4 ? launch_fused_tail_inst<8, 4>(P, X, n, SWpart, slices, s) : launch_fused_tail_inst<8, 8>(P, X, n, SWpart, slices, s); break;
+    case 12: m4 ? launch_fused_tail_inst<12, 4>(P, X, n, SWpart, slices, s) : launch_fused_tail_inst<12, 8>(P, X, n, SWpart, slices, s); break;
+    case 16: m4 ? launch_fused_tail_inst<16, 4>(P, X, n, SWpart, slices, s) : launch_fused_tail_inst<16, 8>(P, X, n, SWpart, slices, s); break;
+    default: throw Error(MOE_ERR_RUNTIME, "unsupported padded dimension");
+  }
 }
 
 // value-only finish: kg_sum per evaluation (same summation as the r == 0 workgroup of kg_zc_kernel)
@@ -632,8 +829,10 @@ KgPending kg_launch(GpDev& gp, int num_fidelity, const moe_gd_params_t& gd, cons
   const int chunks = (num_local + kTbChunk - 1) / kTbChunk;
   const int out_stride = 1 + m * m + 2 * ngrad;
   dOut.reserve((size_t)out_stride * E);
+  // q-KG fast path: the N x M covariance matrix of the tail is never materialised (see launch_fused_tail)
+  const bool fused_tail = want_grad && g == 0 && m <= 8 && env_int("MOE_KG_FUSED_TAIL", 1) != 0;
   if (want_grad) {
-    dT.reserve((size_t)N * E * num_local);
+    if (!fused_tail) dT.reserve((size_t)N * E * num_local);
     dC.reserve((size_t)E * num_local * m);
     dTB.reserve((size_t)E * chunks * m * N);
   }
@@ -733,7 +932,16 @@ KgPending kg_launch(GpDev& gp, int num_fidelity, const moe_gd_params_t& gd, cons
   tl.TBpart = dTB.p;
   tl.out = dOut.p;
   tl.out_stride = out_stride;
-  if (want_grad) {
+  if (fused_tail) {
+    t_cov.start(s);
+    t_cov.stop(s);  // no covariance matrix is built on this path
+    t_tail.start(s);
+    const int slices = fused_tail_slices(E, num_local, n, num_cu);
+    gp.kSW.reserve((size_t)E * num_local * slices * 8);  // [E][num_local][slices][MU <= 8]
+    launch_fused_tail(tl, gp.dX.p, n, gp.kSW.p, slices, s);
+    hipLaunchKernelGGL(kg_zc_kernel, dim3(m, m, E), dim3(256), 0, s, tl);
+    t_tail.stop(s);
+  } else if (want_grad) {
     t_cov.start(s);
     launch_cov_build(gp.cp, gp.dX.p, n, gp.derivs, dBestPoint.p, E * num_local, none, nullptr, dT.p, N, 0, s);
     t_cov.stop(s);
@@ -748,7 +956,7 @@ KgPending kg_launch(GpDev& gp, int num_fidelity, const moe_gd_params_t& gd, cons
       tl.SW = gp.kSW.p;
     }
     launch_tail(tl, s);
-    hipLaunchKernelGGL(kg_zc_kernel, dim3(m, E), dim3(256), 0, s, tl);
+    hipLaunchKernelGGL(kg_zc_kernel, dim3(m, m, E), dim3(256), 0, s, tl);
     t_tail.stop(s);
   } else {
     hipLaunchKernelGGL(kg_sum_kernel, dim3(E), dim3(256), 0, s, tl);

@@ -161,3 +161,22 @@ def test_limits_fail_loudly_and_ei_extremes():
         eg, gg = G.ei(w.Xq, Xp, M, eb, w.ei_normals)
         assert abs(eo - eg) <= TOL["ei"] * max(abs(eo), 1e-3)
         assert np.abs(gg - go).max() <= TOL["grad_ei"] * max(np.abs(go).max(), 1e-3)
+
+
+def test_fused_tail_matches_materialised_tail(monkeypatch):
+    """The T-free gradient tail (q-KG: g = 0, m <= 8) against the path that materialises T = K(X, x*) in HBM: same gradient to
+    rounding (the two differ only in summation order and in where 1/length is applied), for both kernels and m in {1..8}."""
+    from cornell_moe_amd import api
+    from cornell_moe_amd.workloads import make_workload
+    for seed, n, d, q, p, cov in ((150, 333, 8, 4, 0, 1), (151, 130, 3, 1, 0, 0), (152, 257, 5, 5, 3, 1), (153, 64, 12, 2, 1, 0)):
+        w = make_workload(seed=seed, n=n, d=d, q=q, M=300, P=6, derivs=(), p=p)
+        G = api.DeviceGP(w.hyperparameters, w.X, w.y, w.noise, (), cov_type=cov)
+        best = float(G.additional_mean(w.discrete).min())
+        Xp = w.Xp if p else None
+        monkeypatch.setenv("MOE_KG_FUSED_TAIL", "0")
+        a = G.kg(w.inner_gd, w.bounds, w.discrete, w.Xq, Xp, w.M, best, w.kg_normals)
+        monkeypatch.setenv("MOE_KG_FUSED_TAIL", "1")
+        b = G.kg(w.inner_gd, w.bounds, w.discrete, w.Xq, Xp, w.M, best, w.kg_normals)
+        assert a["kg_sum"] == b["kg_sum"]
+        scale = max(np.abs(a["grad_sum"]).max(), abs(a["kg_sum"]))
+        assert np.abs(a["grad_sum"] - b["grad_sum"]).max() <= 1e-11 * scale

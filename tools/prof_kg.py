@@ -29,3 +29,11 @@ for i in range(reps):
     print("rep %d: %.3f ms/eval wall; per-eval kernel ms: mc %.4f cov %.4f tail %.4f state %.4f; passes/sample: value %.2f grad %.2f"
           % (i, 1e3 * dt / R, km["mc"], km["cov_build"], km["tail"], km["state"], r["mean_evals"] / (R * w.M),
              r["grad_evals"] / (R * w.M)), flush=True)
+
+# the covariance-assembly kernel at the N x (R M) shape of bench.py's roofline_cov_build (the q-KG tail itself no longer
+# materialises this matrix), so that the PMC passes see it
+if cfg == "C3":
+    import numpy as np
+    pts = np.random.default_rng(7).uniform(size=(R * w.M, w.d))
+    ms, nbytes = G.cov_build_probe(pts, repeat=2)
+    print("cov_build probe %d x %d: %.4f ms per launch, %.0f GB/s" % (w.n, R * w.M, ms, nbytes / ms / 1e6), flush=True)
