@@ -194,7 +194,11 @@ void tile_gemm(int M, int Ncols, int K, const double* A, long lda, const double*
   if (M <= 0 || Ncols <= 0) return;
   // Skinny outputs: smaller tiles give the chip more workgroups to place.
   const long blocks64 = (long)((M + 63) / 64) * ((Ncols + 63) / 64);
-  if (blocks64 >= 512) {
+  static const long min_blocks = [] {
+    const char* v = std::getenv("MOE_GEMM_MFMA_MIN_BLOCKS");
+    return (v && *v) ? std::atol(v) : 48L;
+  }();
+  if (blocks64 >= min_blocks) {
     dim3 grid((M + 63) / 64, (Ncols + 63) / 64);
     static const bool use_mfma = [] {
       const char* v = std::getenv("MOE_GEMM_MFMA");
