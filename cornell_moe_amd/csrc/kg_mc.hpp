@@ -677,11 +677,14 @@ __global__ __launch_bounds__(512) void kg_mc_kernel(KgMcParams P) {
       xs = coords;
       __syncthreads();
     }
+    // sample tickets are drawn ONE AHEAD: the atomic's round trip to L2 overlaps the current sample instead of stalling
+    // the wave between samples (each wave ends up drawing one ticket it does not use)
+    unsigned int ticket = 0;
+    if (lane == 0) ticket = atomicAdd(&P.next_sample[e], 1u);
     while (true) {
-      unsigned int sl = 0;
-      if (lane == 0) sl = atomicAdd(&P.next_sample[e], 1u);
-      sl = (unsigned int)__builtin_amdgcn_readfirstlane((int)sl);
+      const unsigned int sl = (unsigned int)__builtin_amdgcn_readfirstlane((int)ticket);
       if (sl >= (unsigned int)P.num_local) break;
+      if (lane == 0) ticket = atomicAdd(&P.next_sample[e], 1u);
       kg_sample<DP, G>(P, e, (int)sl, xs, aw, zb, smem, lane);
     }
     if (gridDim.x >= (unsigned)P.E) break;
