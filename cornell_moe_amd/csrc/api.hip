@@ -118,9 +118,7 @@ int moe_gp_get_factor(const moe_gp_t* gp_c, double* K_chol, double* K_inv_y, dou
 int moe_gp_mean(const moe_gp_t* gp_c, const double* pts, int num_pts, double* out, moe_error_t* err) {
   return guarded(err, [&] {
     moe::GpDev& gp = const_cast<moe_gp_t*>(gp_c)->dev;
-    moe::StateHost h;
-    moe::compute_state(gp, pts, num_pts, no_derivs(), 0, nullptr, 0, false, nullptr, &h);
-    moe::host_mean(h, out);
+    gp.mean_of_points(pts, num_pts, out, nullptr);
   });
 }
 
@@ -202,18 +200,12 @@ int moe_posterior_mean(const moe_gp_t* gp_c, int num_fidelity, const double* poi
     require(num_fidelity >= 0 && num_fidelity < gp.d, "num_fidelity out of range");
     std::vector<double> pt(gp.d, 1.0);  // fidelity coordinates pinned to 1 (gpp_knowledge_gradient_optimization.cpp:353-357)
     for (int i = 0; i < gp.d - num_fidelity; ++i) pt[i] = point[i];
-    moe::StateHost h;
-    moe::compute_state(gp, pt.data(), 1, no_derivs(), grad ? 1 : 0, nullptr, 0, false, nullptr, &h);
-    if (value) {
-      double mu;
-      moe::host_mean(h, &mu);
-      *value = -mu;
-    }
-    if (grad) {
-      std::vector<double> g(gp.d);
-      moe::host_grad_mean(h, g.data());
+    double mu;
+    std::vector<double> g(gp.d);
+    gp.mean_of_points(pt.data(), 1, &mu, grad ? g.data() : nullptr);
+    if (value) *value = -mu;
+    if (grad)
       for (int i = 0; i < gp.d - num_fidelity; ++i) grad[i] = -g[i];
-    }
   });
 }
 

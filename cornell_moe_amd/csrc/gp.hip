@@ -153,6 +153,27 @@ void GpDev::rebuild() {
   MOE_HIP_CHECK(hipStreamSynchronize(stream));
 }
 
+void GpDev::mean_of_points(const double* pts, int k, double* mu, double* grad) {
+  use_device();
+  if (k <= 0) return;
+  const bool want_grad = grad != nullptr;
+  const int wdt = want_grad ? 1 + dp : 1;
+  hStateIn.reserve((size_t)k * dp);
+  for (int i = 0; i < k; ++i)
+    for (int j = 0; j < dp; ++j) hStateIn.p[(size_t)i * dp + j] = (j < d) ? pts[(size_t)i * d + j] : 0.0;
+  dPts.upload(hStateIn.p, (size_t)k * dp, stream);
+  dE.reserve((size_t)k * wdt);
+  launch_mean(cp, dX.p, n, derivs, dKinvY.p, dPts.p, k, mean, want_grad, dE.p, stream);
+  hStateOut.reserve((size_t)k * wdt);
+  dE.download(hStateOut.p, (size_t)k * wdt, stream);
+  MOE_HIP_CHECK(hipStreamSynchronize(stream));
+  for (int i = 0; i < k; ++i) {
+    mu[i] = hStateOut.p[(size_t)i * wdt];
+    if (want_grad)
+      for (int j = 0; j < d; ++j) grad[(size_t)i * d + j] = hStateOut.p[(size_t)i * wdt + 1 + j];
+  }
+}
+
 void GpDev::add_points(const double* pts, const double* vals, int k) {
   X.insert(X.end(), pts, pts + (size_t)k * d);
   y.insert(y.end(), vals, vals + (size_t)k * (1 + g));

@@ -53,6 +53,8 @@ struct GpDev {
   // (LogMarginalLikelihoodEvaluator::ComputeLogLikelihood, gpp_model_selection.cpp:593-612).
   double log_marginal_likelihood();
   std::vector<double> padded(const double* pts, int k) const;  // [k][d] -> [k][DP]
+  // Posterior mean of the function value at k points (one kernel, one copy each way): mu[k]; grad (may be NULL) [k][d].
+  void mean_of_points(const double* pts, int k, double* mu, double* grad);
 };
 
 // Device-side product of a state set-up.  Columns of E (ld = N): see StateLayout.

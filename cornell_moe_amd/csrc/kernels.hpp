@@ -37,6 +37,9 @@ void launch_cov_build(const CovParams& cp, const double* A, int nA, const DerivL
 
 // E[(j*(1+g)+n) + (col0 + (i*(1+gt)+m)*dim + dd) * ld] = d cov(P_i, X_j)[m, n] / d P_{i,dd}
 // (grad_K_star fill, gpp_math.cpp:616-637)
+// Posterior mean of the function value at nP points P[nP][DP] (+ gradient): out[nP] or out[nP][1 + DP] = (mu, d mu / d x).
+void launch_mean(const CovParams& cp, const double* X, int n, const DerivList& dX, const double* KinvY, const double* P,
+                 int nP, double mean, bool want_grad, double* out, hipStream_t s);
 void launch_grad_kstar(const CovParams& cp, const double* X, int n, const DerivList& dX, const double* P, int nP,
                        const DerivList& dP, double* out, long ld, long col0, hipStream_t s);
 

@@ -100,6 +100,70 @@ __global__ __launch_bounds__(256) void grad_kstar_kernel(CovParams cp, const dou
   }
 }
 
+
+// Posterior mean (and its spatial gradient) of the function value at nP query points in ONE launch:
+//   mu_p = mean + sum_rows K(x_p, X)[0, row] KinvY[row],   d mu_p / d x_p,dd likewise with the gradient blocks
+// (ComputeMeanOfPoints / ComputeGradMeanOfPoints for value rows, gpp_math.cpp:662-757).  One workgroup per query point,
+// threads stride the training points, fixed-order block reduction.  This is the latency path of the boundary
+// (compute_posterior_mean is called once per candidate point by the reference's Python loops): one kernel and one
+// copy each way instead of the general state set-up.
+template <int DP, bool GRAD>
+__global__ __launch_bounds__(256) void mean_kernel(CovParams cp, const double* __restrict__ X, int n, DerivList dX,
+                                                  const double* __restrict__ KinvY, const double* __restrict__ P,
+                                                  double mean, double* __restrict__ out) {
+  __shared__ double red[4][1 + DP];
+  const int p = blockIdx.x;
+  const int g1 = 1 + dX.g;
+  DerivList none;
+  none.g = 0;
+  double xp[DP];
+#pragma unroll
+  for (int k = 0; k < DP; ++k) xp[k] = P[(long)p * DP + k];
+  double acc = 0.0, accg[DP];
+#pragma unroll
+  for (int k = 0; k < DP; ++k) accg[k] = 0.0;
+  for (int j = threadIdx.x; j < n; j += 256) {
+    double diff[DP];
+    double r2 = 0.0;
+#pragma unroll
+    for (int k = 0; k < DP; ++k) {
+      diff[k] = xp[k] - X[(long)j * DP + k];
+      r2 = fma(diff[k] * diff[k], cp.inv_l2[k], r2);
+    }
+    const Radial rd = radial_scalars(cp.type, cp.alpha, r2);
+    for (int b = 0; b < g1; ++b) {
+      const double w = KinvY[(long)j * g1 + b];
+      acc = fma(cov_entry<DP>(cp, rd, diff, 0, b, none, dX), w, acc);
+      if (GRAD) {
+#pragma unroll
+        for (int dd = 0; dd < DP; ++dd)
+          if (dd < cp.dim) accg[dd] = fma(grad_cov_entry<DP>(cp, rd, diff, 0, b, dd, none, dX), w, accg[dd]);
+      }
+    }
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  double v = acc;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  if (lane == 0) red[wave][0] = v;
+  if (GRAD) {
+#pragma unroll
+    for (int dd = 0; dd < DP; ++dd) {
+      double u = accg[dd];
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) u += __shfl_xor(u, off, 64);
+      if (lane == 0) red[wave][1 + dd] = u;
+    }
+  }
+  __syncthreads();
+  constexpr int W = GRAD ? 1 + DP : 1;
+  if ((int)threadIdx.x < W) {
+    const int c = threadIdx.x;
+    const double tot = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
+    out[(long)p * W + c] = (c == 0) ? mean + tot : tot;
+  }
+}
+
 template <int DP>
 void cov_build_dp(const CovParams& cp, const double* A, int nA, const DerivList& dA, const double* B, int nB,
                   const DerivList& dB, const double* diag_noise, double* out, long ld, long col0, hipStream_t s) {
@@ -159,6 +223,27 @@ void launch_cov_build(const CovParams& cp, const double* A, int nA, const DerivL
     case 16: cov_build_dp<16>(cp, A, nA, dA, B, nB, dB, diag_noise, out, ld, col0, s); break;
     default: throw Error(MOE_ERR_RUNTIME, "unsupported padded dimension");
   }
+  MOE_HIP_CHECK(hipGetLastError());
+}
+
+void launch_mean(const CovParams& cp, const double* X, int n, const DerivList& dX, const double* KinvY, const double* P,
+                 int nP, double mean, bool want_grad, double* out, hipStream_t s) {
+  if (nP <= 0) return;
+#define MOE_MEAN_CASE(DPV)                                                                                                \
+  case DPV:                                                                                                               \
+    if (want_grad)                                                                                                        \
+      hipLaunchKernelGGL((mean_kernel<DPV, true>), dim3(nP), dim3(256), 0, s, cp, X, n, dX, KinvY, P, mean, out);        \
+    else                                                                                                                  \
+      hipLaunchKernelGGL((mean_kernel<DPV, false>), dim3(nP), dim3(256), 0, s, cp, X, n, dX, KinvY, P, mean, out);       \
+    break;
+  switch (cp.dp) {
+    MOE_MEAN_CASE(4)
+    MOE_MEAN_CASE(8)
+    MOE_MEAN_CASE(12)
+    MOE_MEAN_CASE(16)
+    default: throw Error(MOE_ERR_RUNTIME, "unsupported padded dimension");
+  }
+#undef MOE_MEAN_CASE
   MOE_HIP_CHECK(hipGetLastError());
 }
 

@@ -200,14 +200,10 @@ void posterior_mean_optimize(GpDev& gp, int num_fidelity, const moe_gd_params_t&
   std::vector<double> x(x0, x0 + size), pt(d, 1.0), g(size), trial(size), step(size), x_begin(size), gm(d);
   auto f = [&](const double* p, double* grad) {
     std::copy(p, p + size, pt.begin());
-    StateHost h;
-    compute_state(gp, pt.data(), 1, none, grad ? 1 : 0, nullptr, 0, false, nullptr, &h);
     double mu;
-    host_mean(h, &mu);
-    if (grad) {
-      host_grad_mean(h, gm.data());
+    gp.mean_of_points(pt.data(), 1, &mu, grad ? gm.data() : nullptr);
+    if (grad)
       for (int k = 0; k < size; ++k) grad[k] = -gm[k];
-    }
     return -mu;
   };
   double fcur = f(x.data(), nullptr);
