@@ -611,7 +611,7 @@ KgPending kg_launch(GpDev& gp, int num_fidelity, const moe_gd_params_t& gd, cons
   if (gd.max_num_steps <= 0) throw Error(MOE_ERR_BOUNDS, "max_num_steps must be positive", gd.max_num_steps, 1, 1e9);
   const int size = d - f;
   const int A = u + P;
-  const int G = (g == 0) ? 0 : (g <= 2 ? 2 : 4);  // derivative-weight slots of the MC kernel instantiation
+  const int G = g;  // derivative-weight slots of the MC kernel instantiation (one per observed derivative, 0..4)
   const int ntiles = (n + u + 63) / 64;
   const int ngrad = want_grad ? q * g1 * d : 0;
 

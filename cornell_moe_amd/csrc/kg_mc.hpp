@@ -997,7 +997,9 @@ template <int DP>
 inline void launch_block_dp(const KgMcParams& P, int G, int tr, int num_lds_tiles, int blocks, int waves, hipStream_t s) {
   switch (G) {
     case 0: launch_block_g<DP, 0>(P, tr, num_lds_tiles, blocks, waves, s); break;
+    case 1: launch_block_g<DP, 1>(P, tr, num_lds_tiles, blocks, waves, s); break;
     case 2: launch_block_g<DP, 2>(P, tr, num_lds_tiles, blocks, waves, s); break;
+    case 3: launch_block_g<DP, 3>(P, tr, num_lds_tiles, blocks, waves, s); break;
     case 4: launch_block_g<DP, 4>(P, tr, num_lds_tiles, blocks, waves, s); break;
     default: throw Error(MOE_ERR_RUNTIME, "unsupported derivative-slot count in the MC kernel");
   }
@@ -1017,8 +1019,14 @@ inline void launch_dp(const KgMcParams& P, int G, bool xlds, int blocks, int wav
     case 0:
       if (xlds) launch_inst<DP, 0, true>(P, blocks, waves, shm, s); else launch_inst<DP, 0, false>(P, blocks, waves, shm, s);
       break;
+    case 1:
+      if (xlds) launch_inst<DP, 1, true>(P, blocks, waves, shm, s); else launch_inst<DP, 1, false>(P, blocks, waves, shm, s);
+      break;
     case 2:
       if (xlds) launch_inst<DP, 2, true>(P, blocks, waves, shm, s); else launch_inst<DP, 2, false>(P, blocks, waves, shm, s);
+      break;
+    case 3:
+      if (xlds) launch_inst<DP, 3, true>(P, blocks, waves, shm, s); else launch_inst<DP, 3, false>(P, blocks, waves, shm, s);
       break;
     case 4:
       if (xlds) launch_inst<DP, 4, true>(P, blocks, waves, shm, s); else launch_inst<DP, 4, false>(P, blocks, waves, shm, s);
