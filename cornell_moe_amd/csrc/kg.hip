@@ -198,22 +198,37 @@ __global__ __launch_bounds__(256) void kg_tb_kernel(KgTailParams P) {
   }
 }
 
-// GTB[e][gc] = sum_row Gm_e[row, gc] * TB_e[row, col(gc)],  TB = sum of the chunk partials in chunk order;
-// gc = (k (1+g) + b) d + dd  ->  col = k (1+g) + b.
-__global__ __launch_bounds__(256) void kg_gtb_kernel(KgTailParams P) {
+// TB[e][c][row] = sum of the chunk partials in chunk order (one pass over TBpart instead of one per gradient column).
+__global__ __launch_bounds__(256) void kg_tbsum_kernel(KgTailParams P, double* __restrict__ TBsum) {
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;  // over m * N
+  const int e = blockIdx.y;
+  const long mn = (long)P.m * P.N;
+  if (idx >= mn) return;
+  const double* part = P.TBpart + (long)e * P.chunks * mn + idx;
+  double tb = 0.0;
+  for (int ch = 0; ch < P.chunks; ++ch) tb += part[(long)ch * mn];
+  TBsum[(long)e * mn + idx] = tb;
+}
+
+// GTB[e][gc] = sum_row Gm_e[row, gc] * TB_e[row, col(gc)];  gc = (k (1+g) + b) d + dd  ->  col = k (1+g) + b.
+__global__ __launch_bounds__(256) void kg_gtb_kernel(KgTailParams P, const double* __restrict__ TBsum) {
   __shared__ double red[4];
   const int gc = blockIdx.x, e = blockIdx.y;
   const int col = gc / P.cp.dim;
   const double* Gc = P.Gm + (long)e * P.g_stride + (long)gc * P.N;
-  const double* part = P.TBpart + (long)e * P.chunks * P.m * P.N + (long)col * P.N;
+  const double* tb = TBsum + ((long)e * P.m + col) * P.N;
   double acc = 0.0;
-  for (int row = threadIdx.x; row < P.N; row += 256) {
-    double tb = 0.0;
-    for (int ch = 0; ch < P.chunks; ++ch) tb += part[(long)ch * P.m * P.N + row];
-    acc = fma(Gc[row], tb, acc);
-  }
+  for (int row = threadIdx.x; row < P.N; row += 256) acc = fma(Gc[row], tb[row], acc);
   const double tot = block_sum_256(acc, red);
   if (threadIdx.x == 0) P.out[(long)e * P.out_stride + 1 + P.m * P.m + P.ngrad + gc] = tot;
+}
+
+// The summed TB lives behind the chunk partials in the same buffer (the host reserves E (chunks + 1) m N doubles).
+void launch_gtb(const KgTailParams& P, hipStream_t s) {
+  const long mn = (long)P.m * P.N;
+  double* TBsum = P.TBpart + (long)P.E * P.chunks * mn;
+  hipLaunchKernelGGL(kg_tbsum_kernel, dim3((unsigned)((mn + 255) / 256), P.E), dim3(256), 0, s, P, TBsum);
+  hipLaunchKernelGGL(kg_gtb_kernel, dim3(P.ngrad, P.E), dim3(256), 0, s, P, (const double*)TBsum);
 }
 
 // ZC[e][r + j m] = sum_i z_i[r] c_i[j]; workgroup (r, j, e); the (0, 0) workgroup also forms
@@ -328,7 +343,7 @@ void launch_tail(const KgTailParams& P, hipStream_t s) {
     hipLaunchKernelGGL((kg_tb_kernel<32>), gtb, dim3(256), 0, s, P);
   else
     hipLaunchKernelGGL((kg_tb_kernel<64>), gtb, dim3(256), 0, s, P);
-  hipLaunchKernelGGL(kg_gtb_kernel, dim3(P.ngrad, P.E), dim3(256), 0, s, P);
+  launch_gtb(P, s);
   MOE_HIP_CHECK(hipGetLastError());
 }
 
@@ -496,7 +511,7 @@ void launch_fused_tail_cov(const KgTailParams& P, const double* X, int n, double
   hipLaunchKernelGGL((kg_fused_c_kernel<DP, MU, COV>), gc, dim3(256), 0, s, P, SWpart, slices);
   hipLaunchKernelGGL((kg_dir_kernel<DP>), dim3(P.q, P.E), dim3(256), 0, s, P);
   hipLaunchKernelGGL((kg_fused_point_kernel<DP, MU, COV>), gb, dim3(256), 0, s, P, X, n);
-  hipLaunchKernelGGL(kg_gtb_kernel, dim3(P.ngrad, P.E), dim3(256), 0, s, P);
+  launch_gtb(P, s);
   MOE_HIP_CHECK(hipGetLastError());
 }
 
@@ -834,7 +849,7 @@ KgPending kg_launch(GpDev& gp, int num_fidelity, const moe_gd_params_t& gd, cons
   if (want_grad) {
     if (!fused_tail) dT.reserve((size_t)N * E * num_local);
     dC.reserve((size_t)E * num_local * m);
-    dTB.reserve((size_t)E * chunks * m * N);
+    dTB.reserve((size_t)E * (chunks + 1) * m * N);  // chunk partials + their sum
   }
   MOE_HIP_CHECK(hipMemsetAsync(dCounters.p, 0, sizeof(unsigned long long) * 3 * E, s));
 
