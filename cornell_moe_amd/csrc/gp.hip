@@ -243,7 +243,8 @@ void compute_state_batch(GpDev& gp, const double* U_all, int u, const DerivList&
     gp.dWE.reserve((size_t)N * cw);
     launch_tri_gemm('T', N, cw, gp.dLinv.p, N, gp.dVE.p, N, gp.dWE.p, N, s);
   }
-  launch_gram_batch(E, lay.m, ngrad, A, N, gp.dVE.p, N, gp.dGram.p, s);
+  gp.dEK.reserve((size_t)E * gram_batch_slices(E, c, N) * c * c);  // partial Grams of the K-sliced kernel
+  launch_gram_batch(E, lay.m, ngrad, A, N, gp.dVE.p, N, gp.dGram.p, gp.dEK.p, s);
   launch_gemm_tn((int)ctot, 1, N, gp.dE.p, N, gp.dKinvY.p, N, gp.dGram.p + nG, (int)ctot, s);
   gp.hStateOut.reserve(nG + ctot);
   gp.dGram.download(gp.hStateOut.p, nG + ctot, s);

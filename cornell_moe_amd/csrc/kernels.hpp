@@ -56,7 +56,10 @@ void launch_gemm_tn(int m, int n, int K, const double* A, long lda, const double
 
 // Batched Gram matrices over column groups of V (K x *, ldv): for eval e, G_e[c x c] (ld c, eval stride c*c) = V_e^T V_e
 // where V_e's column `l` is V's column  l < m ? e*m + l : l < m+ng ? E*m + e*ng + (l-m) : E*(m+ng) + e*A + (l-m-ng).
-void launch_gram_batch(int E, int m, int ng, int A, int K, const double* V, long ldv, double* G, hipStream_t s);
+// work (may be NULL: single pass): E * gram_batch_slices(E, c, K) * c * c doubles of scratch for the K-sliced version.
+int gram_batch_slices(int E, int c, int K);
+void launch_gram_batch(int E, int m, int ng, int A, int K, const double* V, long ldv, double* G, double* work,
+                       hipStream_t s);
 
 // In-place blocked Cholesky of the lower triangle of A (N x N, lda) + explicit inverse of the factor into Linv
 // (N x N, ldl, lower; strict upper zeroed).  info (device int): 0 or failing pivot index + 1 (pivot <= 1e-16).

@@ -234,24 +234,28 @@ struct GramMap {
 };
 
 __global__ __launch_bounds__(256) void gram_batch_kernel(GramMap gm, int K, const double* __restrict__ V, long ldv,
-                                                        double* __restrict__ G) {
+                                                        double* __restrict__ G, int slices) {
   constexpr int T = 32;
   constexpr int TK = 64;  // deep stages: the grid is tiny (c <= a few hundred), the K loop is latency-bound
   __shared__ double As[TK][T + 1];
   __shared__ double Bs[TK][T + 1];
   if (blockIdx.y > blockIdx.x) return;
   const int c = gm.m + gm.ng + gm.A;
-  const int e = blockIdx.z;
+  // blockIdx.z = evaluation * slices + K slice: with `slices` > 1 the output is a partial Gram per slice (summed in slice
+  // order by gram_sum_kernel), which gives the few output tiles enough workgroups to hide the K loop's latency
+  const int e = blockIdx.z / slices, sl = blockIdx.z % slices;
+  const int kper = ((K + slices - 1) / slices + TK - 1) / TK * TK;
+  const int k_begin = sl * kper, k_end = min(K, k_begin + kper);
   const int i0 = blockIdx.x * T, j0 = blockIdx.y * T;
   const int tx = threadIdx.x % 16, ty = threadIdx.x / 16;
   double acc[2][2] = {{0.0, 0.0}, {0.0, 0.0}};
-  for (int k0 = 0; k0 < K; k0 += TK) {
+  for (int k0 = k_begin; k0 < k_end; k0 += TK) {
     for (int t = threadIdx.x; t < TK * T; t += 256) {
       const int kk = t % TK, ii = t / TK;
       const int gk = k0 + kk;
       const int gi = i0 + ii, gj = j0 + ii;
-      As[kk][ii] = (gi < c && gk < K) ? V[(long)gk + gm.col(e, gi) * ldv] : 0.0;
-      Bs[kk][ii] = (gj < c && gk < K) ? V[(long)gk + gm.col(e, gj) * ldv] : 0.0;
+      As[kk][ii] = (gi < c && gk < k_end) ? V[(long)gk + gm.col(e, gi) * ldv] : 0.0;
+      Bs[kk][ii] = (gj < c && gk < k_end) ? V[(long)gk + gm.col(e, gj) * ldv] : 0.0;
     }
     __syncthreads();
 #pragma unroll
@@ -264,7 +268,7 @@ __global__ __launch_bounds__(256) void gram_batch_kernel(GramMap gm, int K, cons
     }
     __syncthreads();
   }
-  double* Ge = G + (long)e * c * c;
+  double* Ge = G + (long)blockIdx.z * c * c;
 #pragma unroll
   for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -505,12 +509,40 @@ void launch_gemm_tn(int m, int n, int K, const double* A, long lda, const double
   tile_gemm<0>(m, n, K, A, lda, B, ldb, C, ldc, s);
 }
 
-void launch_gram_batch(int E, int m, int ng, int A, int K, const double* V, long ldv, double* G, hipStream_t s) {
+namespace {
+// G[e] = sum over the K slices of the partial Grams, in slice order.
+__global__ __launch_bounds__(256) void gram_sum_kernel(const double* __restrict__ part, int slices, long cc, double* __restrict__ G) {
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  const int e = blockIdx.y;
+  if (idx >= cc) return;
+  const double* p = part + (long)e * slices * cc + idx;
+  double v = 0.0;
+  for (int sl = 0; sl < slices; ++sl) v += p[(long)sl * cc];
+  G[(long)e * cc + idx] = v;
+}
+}  // namespace
+
+int gram_batch_slices(int E, int c, int K) {
+  const long tiles = (long)((c + 31) / 32) * ((c + 31) / 32 + 1) / 2 * E;  // lower-triangular output tiles
+  const long want = 1024;                                                  // ~4 workgroups per CU
+  long s = (want + tiles - 1) / tiles;
+  s = std::min<long>(s, std::max(1, K / 256));                             // keep >= 4 stages of 64 per slice
+  return (int)std::max<long>(1, std::min<long>(s, 16));
+}
+
+void launch_gram_batch(int E, int m, int ng, int A, int K, const double* V, long ldv, double* G, double* work, hipStream_t s) {
   const int c = m + ng + A;
   if (c <= 0 || E <= 0) return;
   GramMap gm{E, m, ng, A};
-  dim3 grid((c + 31) / 32, (c + 31) / 32, E);
-  hipLaunchKernelGGL(gram_batch_kernel, grid, dim3(256), 0, s, gm, K, V, ldv, G);
+  const int slices = (work != nullptr) ? gram_batch_slices(E, c, K) : 1;
+  dim3 grid((c + 31) / 32, (c + 31) / 32, E * slices);
+  if (slices == 1) {
+    hipLaunchKernelGGL(gram_batch_kernel, grid, dim3(256), 0, s, gm, K, V, ldv, G, 1);
+  } else {
+    const long cc = (long)c * c;
+    hipLaunchKernelGGL(gram_batch_kernel, grid, dim3(256), 0, s, gm, K, V, ldv, work, slices);
+    hipLaunchKernelGGL(gram_sum_kernel, dim3((unsigned)((cc + 255) / 256), E), dim3(256), 0, s, (const double*)work, slices, cc, G);
+  }
   MOE_HIP_CHECK(hipGetLastError());
 }
 
