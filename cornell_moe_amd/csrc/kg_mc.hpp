@@ -471,13 +471,28 @@ __device__ __forceinline__ double line_search_lds(const KgMcParams& P, EV& ev, d
       double alpha_n = (P.gamma == 0.0) ? P.pre_mult : P.pre_mult * pow((double)(istep + 1), -P.gamma);
       int search = 0;
       double ftrial;
+      // Armijo back-tracking, two trial step sizes per pass (alpha and alpha / 2).  The sequence of decisions is the
+      // reference's (gpp_optimization.hpp:752-769): the second value is only looked at if the first one fails, and only
+      // consumed trials are counted -- the speculative one is wasted work when the first is accepted, which is cheap next
+      // to the pass's fixed cost in this kernel.
       while (true) {
+        const double a1 = alpha_n, a2 = 0.5 * alpha_n;
+        double tqb[DP], f1, f2;
 #pragma unroll
-        for (int r = 0; r < DP; ++r) tqp[r] = fma(alpha_n, sG[r], sX[r]) * P.inv_lp[r];
-        ftrial = ev.template eval<false>(tqp, gp);
+        for (int r = 0; r < DP; ++r) {
+          tqp[r] = fma(a1, sG[r], sX[r]) * P.inv_lp[r];
+          tqb[r] = fma(a2, sG[r], sX[r]) * P.inv_lp[r];
+        }
+        ev.eval2(tqp, tqb, f1, f2);
+        ftrial = f1;
         n_val++;
-        if (ftrial - f0 > 0.5 * alpha_n * norm) break;
-        alpha_n *= 0.5;
+        if (f1 - f0 > 0.5 * a1 * norm) break;
+        alpha_n = a2;
+        if (++search >= 30) break;
+        ftrial = f2;
+        n_val++;
+        if (f2 - f0 > 0.5 * a2 * norm) break;
+        alpha_n = 0.5 * a2;
         if (++search >= 30) break;
       }
       bool changed = false, nonzero = false;
@@ -785,6 +800,70 @@ struct BlockEval {
     // ---- register tiles ----
 #pragma unroll
     for (int t = 0; t < TR; ++t) point_terms<DP, G, WG, COV>(cx[t], cw[t], xq, etab, accf, accg, accd);
+  }
+
+  // Value of the objective at TWO query points in one sweep over the tiles (the coordinates and weights of a point are
+  // loaded once and used for both): the pass costs twice the arithmetic but ONE wave reduction round, one barrier and one
+  // decision round -- and in this kernel a pass is dominated by exactly those (see line_search_lds).
+  template <int COV>
+  __device__ __forceinline__ void accumulate2(const double (&xa)[DP], const double (&xb)[DP], double& fa, double& fb) {
+    double dg[DP], dd[G > 0 ? G : 1];  // unused gradient accumulators of the value-only instantiation
+    if (ntl > 0) {
+      const double* xt = xl;
+      const double* wt = wl;
+      double c0[DP], w0[1 + G];
+#pragma unroll
+      for (int k = 0; k < DP; ++k) c0[k] = xt[k * 64];
+#pragma unroll
+      for (int a = 0; a < 1 + G; ++a) w0[a] = wt[a * 64];
+#pragma unroll 1
+      for (int t = 0; t < ntl; ++t) {
+        double c1[DP], w1[1 + G];
+        if (t + 1 < ntl) {
+          xt += DP * 64;
+          wt += (1 + G) * 64;
+        }
+#pragma unroll
+        for (int k = 0; k < DP; ++k) c1[k] = xt[k * 64];
+#pragma unroll
+        for (int a = 0; a < 1 + G; ++a) w1[a] = wt[a * 64];
+        point_terms<DP, G, false, COV>(c0, w0, xa, etab, fa, dg, dd);
+        point_terms<DP, G, false, COV>(c0, w0, xb, etab, fb, dg, dd);
+#pragma unroll
+        for (int k = 0; k < DP; ++k) c0[k] = c1[k];
+#pragma unroll
+        for (int a = 0; a < 1 + G; ++a) w0[a] = w1[a];
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < TR; ++t) {
+      point_terms<DP, G, false, COV>(cx[t], cw[t], xa, etab, fa, dg, dd);
+      point_terms<DP, G, false, COV>(cx[t], cw[t], xb, etab, fb, dg, dd);
+    }
+  }
+
+  __device__ __forceinline__ void eval2(const double (&xa)[DP], const double (&xb)[DP], double& fa_out, double& fb_out) {
+    double fa = 0.0, fb = 0.0;
+    if (cov_type == MOE_COV_SQUARE_EXPONENTIAL)
+      accumulate2<MOE_COV_SQUARE_EXPONENTIAL>(xa, xb, fa, fb);
+    else
+      accumulate2<MOE_COV_MATERN_NU_2P5>(xa, xb, fa, fb);
+    double* slot = part + (par * kMaxBlockWaves + wave) * kPartLen;
+    const double sa = wave_sum_uniform(fa), sb = wave_sum_uniform(fb);
+    if (lane == 0) {
+      slot[0] = sa;
+      slot[1] = sb;
+    }
+    __syncthreads();
+    const double* all = part + par * kMaxBlockWaves * kPartLen;
+    par ^= 1;
+    double ta = 0.0, tb = 0.0;
+    for (int w = 0; w < nw; ++w) {
+      ta += all[w * kPartLen];
+      tb += all[w * kPartLen + 1];
+    }
+    fa_out = -(mean + uniform(ta));
+    fb_out = -(mean + uniform(tb));
   }
 
   template <bool WG>
