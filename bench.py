@@ -70,8 +70,8 @@ def measured_traffic(kernel):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--restarts", type=int, default=8, help="independent KG evaluations per GPU per step")
     ap.add_argument("--shard", choices=["restarts", "mc"], default="restarts")
     ap.add_argument("--config", default="C3")
