@@ -335,6 +335,9 @@ __device__ __forceinline__ double line_search(const KgMcParams& P, EV& ev, doubl
   }
   const double step_tolerance = P.tolerance / (double)P.max_num_steps;
   double fcur = 0.0;
+  // lane k < DP carries coordinate k's bounds for the lane-parallel LimitUpdate below
+  const int lane_id = (int)(threadIdx.x & 63u);
+  const double lo_l = P.bounds[2 * (lane_id < DP ? lane_id : 0)], hi_l = P.bounds[2 * (lane_id < DP ? lane_id : 0) + 1];
 
   // GradientDescentOptimizerLineSearch::Optimize (gpp_optimization.hpp:1242-1283) around
   // GradientDescentOptimizationLineSearch (:708-828), as plain nested wave-uniform loops.  The Armijo back-tracking loop --
@@ -380,15 +383,27 @@ __device__ __forceinline__ double line_search(const KgMcParams& P, EV& ev, doubl
           if (++search >= 30) break;
         }
         // ---- LimitUpdate, then accept only if f improves (.hpp:762-795) ----
-        bool changed = false, nonzero = false;
+        // One coordinate per LANE (lane k < DP handles coordinate k) instead of DP wave-uniform copies of the ~40
+        // instruction clamp: the coordinates are gathered into a lane vector with selects, clamped once, and the steps
+        // come back as wave-uniform values through v_readlane.  Same arithmetic per coordinate.
+        bool changed, nonzero;
+        {
+          double x_l = 0.0, want_l = 0.0;
 #pragma unroll
-        for (int k = 0; k < DP; ++k) {
-          step[k] = 0.0;
-          if ((P.free_mask >> k) & 1u) {
-            const double want = alpha_n * grad[k];
-            step[k] = limit_update_1d(P.bounds[2 * k], P.bounds[2 * k + 1], P.max_relative_change, x[k], want);
-            changed = changed || (step[k] != want);
-            nonzero = nonzero || (step[k] != 0.0);
+          for (int k = 0; k < DP; ++k) {
+            x_l = (lane_id == k) ? x[k] : x_l;
+            want_l = (lane_id == k) ? alpha_n * grad[k] : want_l;
+          }
+          const bool free_l = lane_id < DP && ((P.free_mask >> (lane_id & 31)) & 1u);
+          double step_l = 0.0;
+          if (free_l) step_l = limit_update_1d(lo_l, hi_l, P.max_relative_change, x_l, want_l);
+          changed = __ballot(free_l && step_l != want_l) != 0ull;
+          nonzero = __ballot(free_l && step_l != 0.0) != 0ull;
+#pragma unroll
+          for (int k = 0; k < DP; ++k) {
+            const int slo = __builtin_amdgcn_readlane(__double2loint(step_l), k);
+            const int shi = __builtin_amdgcn_readlane(__double2hiint(step_l), k);
+            step[k] = __hiloint2double(shi, slo);
           }
         }
         if (search == 30 || !nonzero) break;  // .hpp:781-785: x restored (a zero step re-evaluates f(x) == f0: rejected)
