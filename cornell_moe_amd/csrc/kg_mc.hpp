@@ -451,6 +451,8 @@ template <int DP, int G, class EV>
 __device__ __forceinline__ double line_search_lds(const KgMcParams& P, EV& ev, double* __restrict__ st, double (&x)[DP],
                                                   unsigned long long& n_val, unsigned long long& n_grad) {
   const double step_tolerance = P.tolerance / (double)P.max_num_steps;
+  const int lane_id = (int)(threadIdx.x & 63u);
+  const double lo_l = P.bounds[2 * (lane_id < DP ? lane_id : 0)], hi_l = P.bounds[2 * (lane_id < DP ? lane_id : 0) + 1];
   double* sX = st;
   double* sG = st + kMaxDimPadded;
   double* sS = st + 2 * kMaxDimPadded;
@@ -510,17 +512,18 @@ __device__ __forceinline__ double line_search_lds(const KgMcParams& P, EV& ev, d
         alpha_n = 0.5 * a2;
         if (++search >= 30) break;
       }
-      bool changed = false, nonzero = false;
-#pragma unroll
-      for (int k = 0; k < DP; ++k) {
-        double sk = 0.0;
-        if ((P.free_mask >> k) & 1u) {
-          const double want = alpha_n * sG[k];
-          sk = limit_update_1d(P.bounds[2 * k], P.bounds[2 * k + 1], P.max_relative_change, sX[k], want);
-          changed = changed || (sk != want);
-          nonzero = nonzero || (sk != 0.0);
-        }
-        sS[k] = sk;
+      // LimitUpdate with one coordinate per lane (the state already lives in per-wave LDS arrays, so lane k simply reads
+      // entry k): one clamp instead of DP wave-uniform copies
+      bool changed, nonzero;
+      {
+        const int lk = lane_id < DP ? lane_id : 0;
+        const bool free_l = lane_id < DP && ((P.free_mask >> (lane_id & 31)) & 1u);
+        const double want_l = alpha_n * sG[lk];
+        double step_l = 0.0;
+        if (free_l) step_l = limit_update_1d(lo_l, hi_l, P.max_relative_change, sX[lk], want_l);
+        changed = __ballot(free_l && step_l != want_l) != 0ull;
+        nonzero = __ballot(free_l && step_l != 0.0) != 0ull;
+        if (lane_id < DP) sS[lane_id] = step_l;  // read back below by every lane of this wave (in-order LDS, same wave)
       }
       if (search == 30 || !nonzero) break;
       double obj2 = ftrial;
