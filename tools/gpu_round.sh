@@ -6,7 +6,7 @@ R="$PWD"
 mkdir -p gpurun_out
 timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -15 | tee gpurun_out/pytest_gpu.log
 timeout 120 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -3 | tee gpurun_out/smoke.log
-timeout 600 python bench.py --steps 10 --warmup 2 2> gpurun_out/bench.err | tee gpurun_out/bench.json
+timeout 600 python bench.py 2> gpurun_out/bench.err | tee gpurun_out/bench.json
 tail -5 gpurun_out/bench.err
 export TMPDIR=/tmp
 cd /tmp
