@@ -180,3 +180,15 @@ def test_fused_tail_matches_materialised_tail(monkeypatch):
         assert a["kg_sum"] == b["kg_sum"]
         scale = max(np.abs(a["grad_sum"]).max(), abs(a["kg_sum"]))
         assert np.abs(a["grad_sum"] - b["grad_sum"]).max() <= 1e-11 * scale
+
+
+def test_randomised_parity_fuzz():
+    """tools/fuzz_parity.py: 60 random shapes / kernels / derivative sets / fidelity dimensions / optimiser settings, q-KG (both
+    MC kernels) and q-EI against the oracle -- no violation of the stated tolerances."""
+    import importlib.util
+    import os
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "fuzz_parity.py")
+    spec = importlib.util.spec_from_file_location("fuzz_parity", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    assert mod.run(60, 11) == 0

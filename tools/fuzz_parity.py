@@ -1,0 +1,76 @@
+"""Randomised parity sweep on the GPU: random shapes / kernels / derivative sets / fidelity dimensions / optimiser settings,
+device q-KG and q-EI against the plain-C oracle on the same normal tables.  Prints every violation of the stated tolerances.
+    python tools/fuzz_parity.py [num_cases] [seed]"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from cornell_moe_amd import api  # noqa: E402
+from cornell_moe_amd.workloads import make_workload  # noqa: E402
+from helpers import TOL  # noqa: E402
+from oracle import orc  # noqa: E402
+
+
+
+def run(num_cases, seed):
+  rng = np.random.default_rng(seed)
+  bad = 0
+  for case in range(num_cases):
+      d = int(rng.integers(1, 17))
+      g = int(rng.integers(0, min(4, d) + 1)) if rng.uniform() < 0.5 else 0
+      derivs = tuple(int(v) for v in rng.permutation(d)[:g])
+      umax = 64 // (1 + g)
+      q = int(rng.integers(1, min(4, umax) + 1))
+      p = int(rng.integers(0, min(3, umax - q) + 1))
+      n = int(rng.integers(1, 300))
+      P = int(rng.integers(1, 13))
+      M = int(rng.integers(1, 65))
+      cov = int(rng.integers(0, 2))
+      f = int(rng.integers(0, d)) if rng.uniform() < 0.3 else 0
+      gd = (1, int(rng.integers(1, 8)), int(rng.integers(1, 3)), 3, float(rng.choice([0.0, 0.5, 1.0])),
+            float(rng.choice([1.0, 0.3, 2.0])), float(rng.choice([0.1, 0.5, 1.0])), float(rng.choice([1e-10, 1e-6])))
+      w = make_workload(seed=10_000 + case, n=n, d=d, q=q, M=M, P=P, derivs=derivs, p=p)
+      disc = w.discrete[:, :d - f]
+      bounds = w.bounds[:2 * (d - f)]
+      try:
+          O = orc.OrcGP(cov, w.alpha, w.lengths, w.X, w.y, w.noise, derivs)
+      except Exception:
+          continue
+      G = api.DeviceGP(w.hyperparameters, w.X, w.y, w.noise, derivs, cov_type=cov)
+      full = np.hstack([disc, np.ones((disc.shape[0], f))])
+      best = float(O.additional_mean(full).min())
+      Xp = w.Xp if p else None
+      ro = O.kg(gd, bounds, disc, w.Xq, Xp, M, best, w.kg_normals, num_fidelity=f)
+      scale = max(float(np.abs(ro["grad"]).max()), abs(ro["kg"]), 1e-6)
+      for variant in ("0", "1"):
+          os.environ["MOE_KG_VARIANT"] = variant
+          rg = G.kg(gd, bounds, disc, w.Xq, Xp, M, best, w.kg_normals, num_fidelity=f, want_best_points=True)
+          ptol = 1e-8 if gd[1] * gd[2] <= 8 else 1e-6
+          mism = float((np.abs(rg["best_point"] - ro["best_point"]).max(axis=1) > ptol).mean())
+          e_kg = abs(rg["kg"] - ro["kg"]) / max(abs(ro["kg"]), 1e-6)
+          e_gr = float(np.abs(rg["grad"] - ro["grad"]).max()) / scale
+          if e_kg > TOL["kg"] or e_gr > TOL["grad_kg"] or mism > 0.05 or rg["grad_evals"] != ro["grad_evals"]:
+              bad += 1
+              print("KG MISMATCH case %d variant %s: n=%d d=%d q=%d p=%d g=%s f=%d P=%d M=%d cov=%d gd=%s: rel kg %.2e grad %.2e "
+                    "best-point mismatch %.3f grad passes %d vs %d" % (case, variant, n, d, q, p, derivs, f, P, M, cov, gd, e_kg,
+                                                                    e_gr, mism, rg["grad_evals"], ro["grad_evals"]), flush=True)
+      os.environ.pop("MOE_KG_VARIANT", None)
+      if q + p <= 16:
+          eb = float(np.median(w.y[:, 0]))
+          eo, go = O.ei(w.Xq, Xp, M, eb, w.ei_normals)
+          eg, gg = G.ei(w.Xq, Xp, M, eb, w.ei_normals)
+          if abs(eo - eg) > TOL["ei"] * max(abs(eo), 1e-3) or np.abs(gg - go).max() > TOL["grad_ei"] * max(np.abs(go).max(), 1e-3):
+              bad += 1
+              print("EI MISMATCH case %d: n=%d d=%d q=%d p=%d g=%s cov=%d: %.3e vs %.3e, grad err %.2e" % (
+                  case, n, d, q, p, derivs, cov, eg, eo, float(np.abs(gg - go).max())), flush=True)
+  print("fuzz: %d cases, %d violations" % (num_cases, bad))
+  return bad
+
+
+if __name__ == "__main__":
+  sys.exit(1 if run(int(sys.argv[1]) if len(sys.argv) > 1 else 100, int(sys.argv[2]) if len(sys.argv) > 2 else 2026) else 0)
+
