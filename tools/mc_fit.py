@@ -12,15 +12,16 @@ w = make_workload("C3", num_restarts=8)
 G = DeviceGP(w.hyperparameters, w.X, w.y, w.noise, ())
 best = float(G.additional_mean(w.discrete).min())
 rows = []
-for steps in (1, 2, 3, 4, 6, 8, 12):
-    gd = (1, steps, 1, 3, 0.0, 1.0, 0.1, 1e-10)
+import itertools
+for steps, pre in itertools.product((1, 3, 6, 12), (1.0, 0.125, 0.015625)):  # small pre_mult: fewer Armijo halvings per step
+    gd = (1, steps, 1, 3, 0.0, pre, 0.1, 1e-10)
     for _ in range(2):
         r = G.kg_batch(gd, w.bounds, w.discrete, w.Xq_restarts, None, w.M, best, w.kg_normals)
     km = G.last_kernel_ms()
     S = r["mean_evals"] / (8.0 * w.M)
     Gp = r["grad_evals"] / (8.0 * w.M)
     rows.append((steps, km["mc"], S, Gp))
-    print("steps %2d: mc %.4f ms/eval, value passes %.2f, grad passes %.2f" % rows[-1], flush=True)
+    print("steps %2d pre_mult %-8g: mc %.4f ms/eval, value passes %.2f, grad passes %.2f" % (steps, pre, km["mc"], S, Gp), flush=True)
 A = np.array([[1.0, s, g] for _, _, s, g in rows])
 y = np.array([t for _, t, _, _ in rows])
 coef, res, _, _ = np.linalg.lstsq(A, y, rcond=None)
