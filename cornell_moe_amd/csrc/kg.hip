@@ -840,7 +840,9 @@ KgPending kg_launch(GpDev& gp, int num_fidelity, const moe_gd_params_t& gd, cons
   dBestPoint.reserve((size_t)E * num_local * dp);
   dBestValue.reserve((size_t)E * num_local);
   dBeta.reserve((size_t)E * num_local * m);
-  dCounters.reserve((size_t)3 * E);
+  // [2 E] pass counters | [E] sample-ticket counters, one 128-byte line each (kTicketStride unsigned ints)
+  const size_t n_ctr = (size_t)2 * E + (size_t)E * (kTicketStride / 2) + 16;
+  dCounters.reserve(n_ctr);
   const int chunks = (num_local + kTbChunk - 1) / kTbChunk;
   const int out_stride = 1 + m * m + 2 * ngrad;
   dOut.reserve((size_t)out_stride * E);
@@ -851,7 +853,7 @@ KgPending kg_launch(GpDev& gp, int num_fidelity, const moe_gd_params_t& gd, cons
     dC.reserve((size_t)E * num_local * m);
     dTB.reserve((size_t)E * (chunks + 1) * m * N);  // chunk partials + their sum
   }
-  MOE_HIP_CHECK(hipMemsetAsync(dCounters.p, 0, sizeof(unsigned long long) * 3 * E, s));
+  MOE_HIP_CHECK(hipMemsetAsync(dCounters.p, 0, sizeof(unsigned long long) * n_ctr, s));
 
   // ---- coordinate tables ----
   {
@@ -905,7 +907,7 @@ KgPending kg_launch(GpDev& gp, int num_fidelity, const moe_gd_params_t& gd, cons
   mp.best_value = dBestValue.p;
   mp.beta = dBeta.p;
   mp.counters = dCounters.p;
-  mp.next_sample = reinterpret_cast<unsigned int*>(dCounters.p + 2 * E);
+  mp.next_sample = reinterpret_cast<unsigned int*>(dCounters.p + (((size_t)2 * E + 15) / 16) * 16);  // 128-byte aligned
   auto timers = std::make_shared<std::array<EventTimer, 3>>();
   EventTimer &t_mc = (*timers)[0], &t_cov = (*timers)[1], &t_tail = (*timers)[2];
   t_mc.start(s);
