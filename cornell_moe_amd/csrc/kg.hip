@@ -638,8 +638,10 @@ KgPending kg_launch(GpDev& gp, int num_fidelity, const moe_gd_params_t& gd, cons
   const size_t pad_bytes = sizeof(double) * (size_t)(1 + G) * 64;
   const size_t lds_max = 160 * 1024 - sizeof(double) * kExpTabLen - pad_bytes;
   bool xlds = true;
+  // few tiles per pass: a pass is a short dependent chain, so 16 wavefronts per workgroup (the <= 128-VGPR instantiation)
+  const int max_waves = (ntiles <= env_int("MOE_KG_SMALL_TILES", 4)) ? 16 : 8;
   int waves = 0;
-  if (tab_bytes + slab_bytes <= lds_max) waves = (int)std::min<size_t>(8, (lds_max - tab_bytes) / slab_bytes);
+  if (tab_bytes + slab_bytes <= lds_max) waves = (int)std::min<size_t>(max_waves, (lds_max - tab_bytes) / slab_bytes);
   if (waves < 4) {  // coordinates stay in L2: more wavefronts per workgroup fit
     const int w2 = (int)std::min<size_t>(8, lds_max / slab_bytes);
     if (w2 > waves) {
@@ -675,7 +677,7 @@ KgPending kg_launch(GpDev& gp, int num_fidelity, const moe_gd_params_t& gd, cons
   if (variant == 0) {
     waves = std::max(1, std::min(waves, env_int("MOE_KG_WAVES", waves)));
     shm = sizeof(double) * kExpTabLen + (xlds ? tab_bytes : 0) + (size_t)waves * slab_bytes + pad_bytes;
-    wg_per_cu = std::max(1, std::min((int)((size_t)160 * 1024 / shm), 8 / waves));
+    wg_per_cu = std::max(1, std::min((int)((size_t)160 * 1024 / shm), (waves > 8 ? 16 : 8) / waves));
   } else {
     waves = bwaves;
   }

@@ -154,7 +154,7 @@ __device__ __forceinline__ void radial3(double r2, const double* __restrict__ et
 // xq = scaled query coordinates in table-row order (wave-uniform).  xs = coordinate table [tile][DP][64] (LDS, or global
 // when it does not fit), aw = this wave's weights [tile][1+G][64] in LDS (zero beyond the real points, so padded lanes
 // contribute exactly 0).
-template <int DP, int G, bool WG, int COV>
+template <int DP, int G, bool WG, int COV, bool SMALL>
 __device__ __forceinline__ double eval_loop(const double* __restrict__ xs, const double* __restrict__ aw,
                                             const double* __restrict__ etab, int ntiles, double mean,
                                             const double (&xq)[DP], const double* inv_lp, double (&grad)[DP], int lane) {
@@ -174,7 +174,7 @@ __device__ __forceinline__ double eval_loop(const double* __restrict__ xs, const
   for (int k = 0; k < DP; ++k) cx[k] = xt[k * 64];
 #pragma unroll
   for (int a = 0; a < 1 + G; ++a) cw[a] = wt[a * 64];
-#pragma unroll(WG ? 2 : 4)
+#pragma unroll(SMALL ? 1 : (WG ? 2 : 4))
   for (int t = 0; t < ntiles; ++t) {
     double nx[DP], nw[1 + G];
     // unconditional advance (constant stride: the unrolled tiles share one address register and use immediate offsets);
@@ -232,13 +232,13 @@ __device__ __forceinline__ double eval_loop(const double* __restrict__ xs, const
 
 // The covariance type is wave-uniform: branch ONCE per pass (a branch inside the tile loop would split it into basic blocks
 // and stop the scheduler from interleaving the independent per-tile dependency chains).
-template <int DP, int G, bool WG>
+template <int DP, int G, bool WG, bool SMALL>
 __device__ __forceinline__ double eval_pass(const double* __restrict__ xs, const double* __restrict__ aw,
                                             const double* __restrict__ etab, int ntiles, int cov_type, double mean,
                                             const double (&xq)[DP], const double* inv_lp, double (&grad)[DP], int lane) {
   if (cov_type == MOE_COV_SQUARE_EXPONENTIAL)
-    return eval_loop<DP, G, WG, MOE_COV_SQUARE_EXPONENTIAL>(xs, aw, etab, ntiles, mean, xq, inv_lp, grad, lane);
-  return eval_loop<DP, G, WG, MOE_COV_MATERN_NU_2P5>(xs, aw, etab, ntiles, mean, xq, inv_lp, grad, lane);
+    return eval_loop<DP, G, WG, MOE_COV_SQUARE_EXPONENTIAL, SMALL>(xs, aw, etab, ntiles, mean, xq, inv_lp, grad, lane);
+  return eval_loop<DP, G, WG, MOE_COV_MATERN_NU_2P5, SMALL>(xs, aw, etab, ntiles, mean, xq, inv_lp, grad, lane);
 }
 
 // TensorProductDomain::LimitUpdate (gpp_domain.cpp:64-105) on one coordinate.
@@ -305,7 +305,7 @@ __device__ __forceinline__ void from_table_order(const double (&v)[DP], const in
 }
 
 // Evaluator of the wave-per-sample kernel: one pass = eval_pass over the LDS tables.
-template <int DP, int G>
+template <int DP, int G, bool SMALL>
 struct WaveEval {
   const double* __restrict__ xs;
   const double* __restrict__ aw;
@@ -316,7 +316,7 @@ struct WaveEval {
   int lane;
   template <bool WG>
   __device__ __forceinline__ double eval(const double (&xq)[DP], double (&grad)[DP]) {
-    return eval_pass<DP, G, WG>(xs, aw, etab, ntiles, cov_type, mean, xq, inv_lp, grad, lane);
+    return eval_pass<DP, G, WG, SMALL>(xs, aw, etab, ntiles, cov_type, mean, xq, inv_lp, grad, lane);
   }
 };
 
@@ -610,7 +610,7 @@ __device__ __forceinline__ int discrete_scan(const KgMcParams& P, const double* 
 }
 
 // One MC sample: weights, discretised-set scan, line-search gradient descent.  Called with the whole wave converged.
-template <int DP, int G>
+template <int DP, int G, bool SMALL>
 __device__ __forceinline__ void kg_sample(const KgMcParams& P, int e, int sl, const double* __restrict__ xs,
                                           double* __restrict__ aw, double* __restrict__ zb,
                                           const double* __restrict__ etab, int lane, unsigned long long& tot_val,
@@ -669,7 +669,7 @@ __device__ __forceinline__ void kg_sample(const KgMcParams& P, int e, int sl, co
   for (int k = 0; k < DP; ++k) x[k] = (k < size) ? disc[(long)best_j * size + k] : ((k < P.dim) ? 1.0 : 0.0);
 
   unsigned long long n_val = 0, n_grad = 0;  // passes over the n + u points (the A-point scan is O(A m), not counted)
-  WaveEval<DP, G> ev{xs, aw, etab, P.ntiles, P.cov_type, P.mean, P.inv_lp, lane};
+  WaveEval<DP, G, SMALL> ev{xs, aw, etab, P.ntiles, P.cov_type, P.mean, P.inv_lp, lane};
   const double fcur = line_search<DP, G>(P, ev, x, n_val, n_grad);
 
   const long so = (long)e * P.num_local + sl;
@@ -686,8 +686,11 @@ __device__ __forceinline__ void kg_sample(const KgMcParams& P, int e, int sl, co
   if (lane < m) P.beta[so * m + lane] = bc;
 }
 
-template <int DP, int G, bool XLDS>
-__global__ __launch_bounds__(512) void kg_mc_kernel(KgMcParams P) {
+// SMALL: the many-wavefront instantiation for point sets of a few tiles, where one pass is a short dependent chain (LDS
+// read -> ~43 dependent FP64 operations -> wave reduction -> decision) that two wavefronts per SIMD cannot cover: compiled
+// for 16 wavefronts per workgroup (<= 128 VGPRs, tile loop not unrolled) so that four wavefronts share each SIMD.
+template <int DP, int G, bool XLDS, bool SMALL>
+__global__ __launch_bounds__(SMALL ? 1024 : 512) void kg_mc_kernel(KgMcParams P) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
@@ -720,7 +723,7 @@ __global__ __launch_bounds__(512) void kg_mc_kernel(KgMcParams P) {
       const unsigned int sl = (unsigned int)__builtin_amdgcn_readfirstlane((int)ticket);
       if (sl >= (unsigned int)P.num_local) break;
       if (lane == 0) ticket = atomicAdd(next, 1u);
-      kg_sample<DP, G>(P, e, (int)sl, xs, aw, zb, smem, lane, tot_val, tot_grad);
+      kg_sample<DP, G, SMALL>(P, e, (int)sl, xs, aw, zb, smem, lane, tot_val, tot_grad);
     }
     if (lane == 0 && (tot_val | tot_grad) != 0) {
       atomicAdd(&P.counters[2 * e], tot_val);
@@ -1108,12 +1111,21 @@ inline void launch_block_dp(const KgMcParams& P, int G, int tr, int num_lds_tile
   }
 }
 
-template <int DP, int G, bool XLDS>
-inline void launch_inst(const KgMcParams& P, int blocks, int waves, size_t shm, hipStream_t s) {
-  auto kern = kg_mc_kernel<DP, G, XLDS>;
+template <int DP, int G, bool XLDS, bool SMALL>
+inline void launch_inst2(const KgMcParams& P, int blocks, int waves, size_t shm, hipStream_t s) {
+  auto kern = kg_mc_kernel<DP, G, XLDS, SMALL>;
   MOE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
   hipLaunchKernelGGL(kern, dim3(blocks), dim3(waves * 64), shm, s, P);
   MOE_HIP_CHECK(hipGetLastError());
+}
+
+// waves > 8 selects the many-wavefront instantiation (only built with the LDS coordinate table)
+template <int DP, int G, bool XLDS>
+inline void launch_inst(const KgMcParams& P, int blocks, int waves, size_t shm, hipStream_t s) {
+  if (XLDS && waves > 8)
+    launch_inst2<DP, G, XLDS, XLDS>(P, blocks, waves, shm, s);
+  else
+    launch_inst2<DP, G, XLDS, false>(P, blocks, waves, shm, s);
 }
 
 template <int DP>
