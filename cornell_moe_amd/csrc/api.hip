@@ -108,7 +108,9 @@ int moe_gp_get_factor(const moe_gp_t* gp_c, double* K_chol, double* K_inv_y, dou
   return guarded(err, [&] {
     moe::GpDev& gp = const_cast<moe_gp_t*>(gp_c)->dev;
     gp.use_device();
-    if (K_chol) gp.dL.download(K_chol, (size_t)gp.N * gp.N, gp.stream);
+    if (K_chol)
+      MOE_HIP_CHECK(hipMemcpy2DAsync(K_chol, sizeof(double) * gp.N, gp.dL.p, sizeof(double) * gp.ldL, sizeof(double) * gp.N,
+                                     gp.N, hipMemcpyDeviceToHost, gp.stream));
     if (K_inv_y) gp.dKinvY.download(K_inv_y, gp.N, gp.stream);
     MOE_HIP_CHECK(hipStreamSynchronize(gp.stream));
     if (mean) *mean = gp.mean;

@@ -6,6 +6,7 @@
 #include <cstring>
 #include <stdexcept>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../../include/moe_hip.h"
@@ -53,6 +54,10 @@ struct DevBuf {
   }
   void download(T* host, size_t n, hipStream_t s) const {
     if (n) MOE_HIP_CHECK(hipMemcpyAsync(host, p, n * sizeof(T), hipMemcpyDeviceToHost, s));
+  }
+  void swap(DevBuf& o) {
+    std::swap(p, o.p);
+    std::swap(cap, o.cap);
   }
 };
 

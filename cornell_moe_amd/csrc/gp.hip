@@ -1,10 +1,15 @@
 // cornell_moe_amd/csrc/gp.hip -- see gp.hpp.
 #include "gp.hpp"
 
+#include <cstdlib>
 #include <cmath>
 #include <cstring>
 
 namespace moe {
+
+namespace {
+constexpr int kAppendHeadroom = 128;  // rows of room left behind a rebuilt factorisation for add_points
+}
 
 GpDev::GpDev(const double* hyper, int cov_type, const double* X_in, const double* y_in, const double* noise_in,
              const int* derivs_in, int g_in, int d_in, int n_in, int device_in)
@@ -95,7 +100,7 @@ __global__ __launch_bounds__(256) void ll_terms_kernel(const double* __restrict_
 double GpDev::log_marginal_likelihood() {
   use_device();
   // dTmp[0, N) still holds yc = y - mean on the value rows (rebuild), dTmp[N, 2N) is free scratch
-  hipLaunchKernelGGL(ll_terms_kernel, dim3(1), dim3(256), 0, stream, dL.p, (long)N, N, dTmp.p, dKinvY.p, dTmp.p + N);
+  hipLaunchKernelGGL(ll_terms_kernel, dim3(1), dim3(256), 0, stream, dL.p, ldL, N, dTmp.p, dKinvY.p, dTmp.p + N);
   MOE_HIP_CHECK(hipGetLastError());
   double terms[2] = {0.0, 0.0};
   MOE_HIP_CHECK(hipMemcpyAsync(terms, dTmp.p + N, sizeof(terms), hipMemcpyDeviceToHost, stream));
@@ -125,14 +130,21 @@ void GpDev::rebuild() {
   const std::vector<double> Xp = padded(X.data(), n);
   dX.upload(Xp.data(), Xp.size(), stream);
   dNoise.upload(noise.data(), noise.size(), stream);
-  dL.reserve((size_t)N * N);
-  dLinv.reserve((size_t)N * N);
+  // head-room for rows appended later (add_points): a multiple of 16 doubles keeps columns 128-byte aligned
+  ldL = ((long)N + kAppendHeadroom + 15) / 16 * 16;
+  dL.reserve((size_t)ldL * ldL);
+  dLinv.reserve((size_t)ldL * ldL);
   dInfo.reserve(1);
   dKinvY.reserve(N);
   dTmp.reserve((size_t)2 * N);
-  launch_cov_build(cp, dX.p, n, derivs, dX.p, n, derivs, dNoise.p, dL.p, N, 0, stream);
+  launch_cov_build(cp, dX.p, n, derivs, dX.p, n, derivs, dNoise.p, dL.p, ldL, 0, stream);
   dWE.reserve(cholesky_work_doubles(N));  // the state workspace doubles as scratch of the recursive inversion
-  launch_cholesky_and_inverse(N, dL.p, N, dLinv.p, N, dWE.p, dInfo.p, stream);
+  launch_cholesky_and_inverse(N, dL.p, ldL, dLinv.p, ldL, dWE.p, dInfo.p, stream);
+  finish_factorisation();
+}
+
+// Checks the factorisation's status word, then mean_ and K^-1 (y - mean_) from the inverse factor (two triangular GEMVs).
+void GpDev::finish_factorisation() {
   int info = 0;
   dInfo.download(&info, 1, stream);
   // mean_ = average of the function-value column only (gpp_math.cpp:498-504)
@@ -148,8 +160,8 @@ void GpDev::rebuild() {
                 "Covariance matrix (K) singular. Check for duplicate points_sampled (with 0 noise) and/or extreme "
                 "hyperparameter values.",
                 N, info);
-  launch_tri_gemm('N', N, 1, dLinv.p, N, dTmp.p, N, dTmp.p + N, N, stream);
-  launch_tri_gemm('T', N, 1, dLinv.p, N, dTmp.p + N, N, dKinvY.p, N, stream);
+  launch_tri_gemm_skinny('N', N, 1, dLinv.p, ldL, dTmp.p, N, dTmp.p + N, N, stream);
+  launch_tri_gemm_skinny('T', N, 1, dLinv.p, ldL, dTmp.p + N, N, dKinvY.p, N, stream);
   MOE_HIP_CHECK(hipStreamSynchronize(stream));
 }
 
@@ -175,10 +187,47 @@ void GpDev::mean_of_points(const double* pts, int k, double* mu, double* grad) {
 }
 
 void GpDev::add_points(const double* pts, const double* vals, int k) {
+  if (k <= 0) return;
+  const int n0 = n, N0 = N, kk = k * (1 + g);
   X.insert(X.end(), pts, pts + (size_t)k * d);
   y.insert(y.end(), vals, vals + (size_t)k * (1 + g));
   n += k;
-  rebuild();
+  // A few new points against an existing factorisation: append a block row to L and L^-1 (O(N^2 k)) instead of
+  // rebuilding (O(N^3)).  MOE_GP_APPEND=0 forces the rebuild (A/B and tests).
+  static const bool allow_append = [] {
+    const char* e = std::getenv("MOE_GP_APPEND");
+    return !(e && std::atoi(e) == 0);
+  }();
+  const int N1 = N0 + kk;
+  if (!allow_append || n0 == 0 || N1 > ldL) {
+    rebuild();
+    return;
+  }
+  use_device();
+  bool singular = false;
+  {
+    // (dX is re-sent whole: a few KB, and its buffer may move when it grows)
+    const std::vector<double> Xp = padded(X.data(), n);
+    dX.upload(Xp.data(), Xp.size(), stream);
+    const double* dNew = dX.p + (size_t)n0 * dp;
+    dE.reserve((size_t)N0 * kk);
+    dGram.reserve((size_t)kk * kk);
+    dVE.reserve(cholesky_append_work_doubles(N0, kk));
+    launch_cov_build(cp, dX.p, n0, derivs, dNew, k, derivs, nullptr, dE.p, N0, 0, stream);
+    launch_cov_build(cp, dNew, k, derivs, dNew, k, derivs, dNoise.p, dGram.p, kk, 0, stream);
+    launch_cholesky_append(N0, kk, dL.p, ldL, dLinv.p, ldL, dE.p, dGram.p, dVE.p, dInfo.p, stream);
+    N = N1;
+    dKinvY.reserve(N1);
+    dTmp.reserve((size_t)2 * N1);
+    try {
+      finish_factorisation();
+    } catch (const Error& e) {
+      if (e.code != MOE_ERR_SINGULAR) throw;
+      singular = true;
+    }
+  }
+  // the Schur complement lost positive definiteness: report exactly as a full refactorisation does
+  if (singular) rebuild();
 }
 
 void compute_state_batch(GpDev& gp, const double* U_all, int u, const DerivList& dt, int nd, const double* extra_all, int A,
@@ -237,11 +286,11 @@ void compute_state_batch(GpDev& gp, const double* U_all, int u, const DerivList&
     for (int i = 0; i < kMaxDerivs; ++i) none.idx[i] = 0;
     launch_cov_build(gp.cp, gp.dX.p, gp.n, gp.derivs, dEp, E * A, none, nullptr, gp.dE.p, N, bl.col_extra0(0), s);
   }
-  launch_tri_gemm('N', N, (int)ctot, gp.dLinv.p, N, gp.dE.p, N, gp.dVE.p, N, s);
+  launch_tri_gemm('N', N, (int)ctot, gp.dLinv.p, gp.ldL, gp.dE.p, N, gp.dVE.p, N, s);
   if (need_W) {
     const int cw = E * (lay.m + ngrad);
     gp.dWE.reserve((size_t)N * cw);
-    launch_tri_gemm('T', N, cw, gp.dLinv.p, N, gp.dVE.p, N, gp.dWE.p, N, s);
+    launch_tri_gemm('T', N, cw, gp.dLinv.p, gp.ldL, gp.dVE.p, N, gp.dWE.p, N, s);
   }
   gp.dEK.reserve((size_t)E * gram_batch_slices(E, c, N) * c * c);  // partial Grams of the K-sliced kernel
   launch_gram_batch(E, lay.m, ngrad, A, N, gp.dVE.p, N, gp.dGram.p, gp.dEK.p, s);

@@ -12,13 +12,14 @@ namespace moe {
 
 // HBM-resident state of one GP (replaces GaussianProcess' K_chol_/K_inv_y_ members, gpp_math.hpp:840-868):
 //   dX     [n][DP]   padded training points
-//   dL     [N][N]    Cholesky factor of K + noise (lower; strict upper zero)
-//   dLinv  [N][N]    its explicit inverse (lower)
+//   dL     [N][N]    Cholesky factor of K + noise (lower; strict upper zero), column-major with leading dimension ldL
+//   dLinv  [N][N]    its explicit inverse (lower), same layout
 //   dKinvY [N]       K^-1 (y - mean)
 struct GpDev {
   int device = 0;
   hipStream_t stream = nullptr;
   int d = 0, dp = 0, n = 0, g = 0, N = 0;
+  long ldL = 0;  // leading dimension of dL / dLinv: N at the last rebuild + head-room for appended rows
   CovParams cp;
   DerivList derivs;
   std::vector<double> X, y, noise;  // host copies (reference keeps them too, gpp_math.hpp:846-856)
@@ -44,7 +45,10 @@ struct GpDev {
   void use_device() const;
   void set_covariance(const double* hyper);  // alpha, lengths -> cp (validated)
   void rebuild();  // K assembly + Cholesky + inverse + K^-1 (y - mean)  (RecomputeDerivedVariables, gpp_math.cpp:481-511)
+  // Appends k observations: a rank-k(1+g) block-row append to L and L^-1 while the head-room lasts (launch_cholesky_append),
+  // the full rebuild otherwise.  (AddPointsToGP, gpp_math.cpp:1699-1737, always refactorises.)
   void add_points(const double* pts, const double* vals, int k);
+  void finish_factorisation();
   // New covariance hyper-parameters [alpha, lengths...] and noise [1 + g] on the same data: rebuild in place (buffers and
   // stream are kept) -- the inner step of hyper-parameter sampling (LogMarginalLikelihoodState::SetHyperparameters,
   // gpp_model_selection.cpp:798-811).

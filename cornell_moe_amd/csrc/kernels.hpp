@@ -49,6 +49,11 @@ void launch_debug_math(const double* x, int n, double* e, double* r, hipStream_t
 // C[N x c] (ldc) = op(T) * B[N x c] (ldb); T lower-triangular N x N (ldt), op = 'N' or 'T'.
 void launch_tri_gemm(char op, int N, int c, const double* T, long ldt, const double* B, long ldb, double* C, long ldc,
                      hipStream_t s);
+// The same product through kernels shaped for c <= 16 columns (falls back to launch_tri_gemm above that).  A different
+// summation order: the per-evaluation state set-up keeps to launch_tri_gemm so that its results do not depend on how many
+// evaluations share a call; the GP-level solves (K^-1 (y - mean), the block row of an append) use this one.
+void launch_tri_gemm_skinny(char op, int N, int c, const double* T, long ldt, const double* B, long ldb, double* C,
+                            long ldc, hipStream_t s);
 
 // C[m x n] (ldc) = A^T B, A is K x m (lda), B is K x n (ldb); reduction over the K rows.
 void launch_gemm_tn(int m, int n, int K, const double* A, long lda, const double* B, long ldb, double* C, long ldc,
@@ -67,5 +72,16 @@ void launch_gram_batch(int E, int m, int ng, int A, int K, const double* V, long
 void launch_cholesky_and_inverse(int N, double* A, long lda, double* Linv, long ldl, double* work, int* info,
                                  hipStream_t s);
 size_t cholesky_work_doubles(int N);
+
+// Rank-kk append to a factorisation, in place: L / Linv hold the factor and inverse factor of K11 in their leading
+// N0 x N0 blocks and have room for kk more rows and columns (ldl, ldi >= N0 + kk).  Given B = K12 (N0 x kk, ld N0) and
+// C = K22 + noise (kk x kk, ld kk; overwritten by L22) the new block row is written:
+//   L21 = (L11^-1 K12)^T,  L22 = chol(K22 - L21 L21^T),  X21 = -L22^-1 L21 L11^-1,  X22 = L22^-1
+// -- O(N0^2 kk) instead of the O(N^3) refactorisation (the reference's TODO GH-192, gpp_math.cpp:1699-1737).  The old
+// block is not touched, so a failed append (info != 0: pivot index within the new block + 1) leaves it valid.
+// work: cholesky_append_work_doubles doubles.
+size_t cholesky_append_work_doubles(int N0, int kk);
+void launch_cholesky_append(int N0, int kk, double* L, long ldl, double* Linv, long ldi, const double* B, double* C,
+                            double* work, int* info, hipStream_t s);
 
 }  // namespace moe

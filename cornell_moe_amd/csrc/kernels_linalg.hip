@@ -468,12 +468,119 @@ __global__ void zero_strict_upper_kernel(double* __restrict__ A, long lda, int N
 
 }  // namespace
 
+namespace {
+// Skinny triangular products (c <= 16 columns: K^-1 (y - mean), the block row of an append).  A tile GEMM with one or two
+// column tiles leaves N / 64 workgroups walking the whole of K one 16-deep stage after the other (0.5 ms at N = 8000);
+// these read T once, coalesced, with every wavefront of the chip holding loads in flight.
+//
+// C = T B:  one workgroup per strip of 64 rows (a row per lane), the K range dealt out to its wavefronts round-robin (each
+// wavefront load is one 512-byte segment of a column), B[k, :] wave-uniform; partial sums meet in LDS in wavefront order.
+template <int CB, int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void tri_skinny_n_kernel(int N, const double* __restrict__ T, long ldt,
+                                                                  const double* __restrict__ B, long ldb, int c,
+                                                                  double* __restrict__ C, long ldc) {
+  __shared__ double red[WAVES][CB][64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int i0 = blockIdx.x * 64, i = i0 + lane, c0 = blockIdx.y * CB;
+  const int kend = min(N, i0 + 64);
+  const bool row_ok = i < N;
+  const double* Trow = T + (row_ok ? i : 0);
+  double acc[CB];
+#pragma unroll
+  for (int cc = 0; cc < CB; ++cc) acc[cc] = 0.0;
+#pragma unroll 4
+  for (int k = w; k < kend; k += WAVES) {
+    const double t = (row_ok && k <= i) ? Trow[(long)k * ldt] : 0.0;
+#pragma unroll
+    for (int cc = 0; cc < CB; ++cc) {
+      const double b = (c0 + cc < c) ? B[k + (long)(c0 + cc) * ldb] : 0.0;
+      acc[cc] = fma(t, b, acc[cc]);
+    }
+  }
+#pragma unroll
+  for (int cc = 0; cc < CB; ++cc) red[w][cc][lane] = acc[cc];
+  __syncthreads();
+  for (int t = threadIdx.x; t < CB * 64; t += WAVES * 64) {
+    const int cc = t >> 6, l = t & 63;
+    double v = 0.0;
+#pragma unroll
+    for (int ww = 0; ww < WAVES; ++ww) v += red[ww][cc][l];
+    if (i0 + l < N && c0 + cc < c) C[(long)(i0 + l) + (long)(c0 + cc) * ldc] = v;
+  }
+}
+
+// C = T^T B:  one wavefront per column of T (contiguous), lanes stride down the rows from the 64-aligned row at or above
+// the diagonal, fixed-order butterfly at the end.
+template <int CB>
+__global__ __launch_bounds__(256) void tri_skinny_t_kernel(int N, const double* __restrict__ T, long ldt,
+                                                          const double* __restrict__ B, long ldb, int c,
+                                                          double* __restrict__ C, long ldc) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int j = blockIdx.x * 4 + w, c0 = blockIdx.y * CB;
+  if (j >= N) return;
+  const double* col = T + (long)j * ldt;
+  double acc[CB];
+#pragma unroll
+  for (int cc = 0; cc < CB; ++cc) acc[cc] = 0.0;
+#pragma unroll 4
+  for (int i = (j & ~63) + lane; i < N; i += 64) {
+    const double t = (i >= j) ? col[i] : 0.0;
+#pragma unroll
+    for (int cc = 0; cc < CB; ++cc) {
+      const double b = (c0 + cc < c) ? B[i + (long)(c0 + cc) * ldb] : 0.0;
+      acc[cc] = fma(t, b, acc[cc]);
+    }
+  }
+#pragma unroll
+  for (int cc = 0; cc < CB; ++cc) {
+    double v = acc[cc];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    if (lane == 0 && c0 + cc < c) C[(long)j + (long)(c0 + cc) * ldc] = v;
+  }
+}
+
+template <int CB>
+void launch_tri_skinny(char op, int N, int c, const double* T, long ldt, const double* B, long ldb, double* C, long ldc,
+                       hipStream_t s) {
+  const int groups = (c + CB - 1) / CB;
+  if (op == 'N') {
+    if (N > 2048)
+      hipLaunchKernelGGL((tri_skinny_n_kernel<CB, 16>), dim3((N + 63) / 64, groups), dim3(1024), 0, s, N, T, ldt, B, ldb, c, C, ldc);
+    else
+      hipLaunchKernelGGL((tri_skinny_n_kernel<CB, 8>), dim3((N + 63) / 64, groups), dim3(512), 0, s, N, T, ldt, B, ldb, c, C, ldc);
+  } else {
+    hipLaunchKernelGGL((tri_skinny_t_kernel<CB>), dim3((N + 3) / 4, groups), dim3(256), 0, s, N, T, ldt, B, ldb, c, C, ldc);
+  }
+  MOE_HIP_CHECK(hipGetLastError());
+}
+}  // namespace
+
 void launch_tri_gemm(char op, int N, int c, const double* T, long ldt, const double* B, long ldb, double* C, long ldc,
                      hipStream_t s) {
   if (op == 'N')
     tile_gemm<1>(N, c, N, T, ldt, B, ldb, C, ldc, s);
   else
     tile_gemm<2>(N, c, N, T, ldt, B, ldb, C, ldc, s);
+}
+
+void launch_tri_gemm_skinny(char op, int N, int c, const double* T, long ldt, const double* B, long ldb, double* C,
+                            long ldc, hipStream_t s) {
+  if (N <= 0 || c <= 0) return;
+  static const bool skinny = [] {
+    const char* v = std::getenv("MOE_TRI_SKINNY");
+    return !(v && *v == '0');
+  }();
+  if (!skinny || c > 16 || N < 128) {
+    launch_tri_gemm(op, N, c, T, ldt, B, ldb, C, ldc, s);
+    return;
+  }
+  if (c == 1)
+    launch_tri_skinny<1>(op, N, c, T, ldt, B, ldb, C, ldc, s);
+  else if (c <= 4)
+    launch_tri_skinny<4>(op, N, c, T, ldt, B, ldb, C, ldc, s);
+  else
+    launch_tri_skinny<8>(op, N, c, T, ldt, B, ldb, C, ldc, s);
 }
 
 namespace {
@@ -593,6 +700,58 @@ void launch_cholesky_and_inverse(int N, double* A, long lda, double* Linv, long 
     if (work == nullptr) throw Error(MOE_ERR_RUNTIME, "launch_cholesky_and_inverse: workspace missing");
     trtri_offdiag(A, lda, Linv, ldl, N, 0, nblk, work, s);
   }
+  MOE_HIP_CHECK(hipGetLastError());
+}
+
+namespace {
+__global__ __launch_bounds__(256) void sub_inplace_kernel(double* __restrict__ C, const double* __restrict__ G, int count) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < count) C[i] -= G[i];
+}
+// The new block row: Lrow[i + j * ldl] = V[j + i * N0];  Xrow[i + j * ldi] = -sum_{l <= i} X22[i + l * kk] W[j + l * N0]
+// (column j per thread: V / W reads coalesced, kk contiguous doubles written per column).
+__global__ __launch_bounds__(256) void append_rows_kernel(const double* __restrict__ V, const double* __restrict__ W,
+                                                         const double* __restrict__ X22, int N0, int kk,
+                                                         double* __restrict__ Lrow, long ldl, double* __restrict__ Xrow,
+                                                         long ldi) {
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= N0) return;
+  for (int i = 0; i < kk; ++i) {
+    Lrow[i + (long)j * ldl] = V[j + (long)i * N0];
+    double acc = 0.0;
+    for (int l = 0; l <= i; ++l) acc = fma(X22[i + (long)l * kk], W[j + (long)l * N0], acc);
+    Xrow[i + (long)j * ldi] = -acc;
+  }
+}
+}  // namespace
+
+size_t cholesky_append_work_doubles(int N0, int kk) {
+  return (size_t)2 * N0 * kk + (size_t)2 * kk * kk + cholesky_work_doubles(kk);
+}
+
+void launch_cholesky_append(int N0, int kk, double* L, long ldl, double* Linv, long ldi, const double* B, double* C,
+                            double* work, int* info, hipStream_t s) {
+  double* V = work;                    // N0 x kk  (ld N0)   L11^-1 K12 = L21^T
+  double* W = V + (size_t)N0 * kk;     // N0 x kk  (ld N0)   L11^-T V   = (L21 X11)^T
+  double* G = W + (size_t)N0 * kk;     // kk x kk            V^T V
+  double* X22 = G + (size_t)kk * kk;   // kk x kk            L22^-1
+  double* cw = X22 + (size_t)kk * kk;  // scratch of the small factorisation
+  // strict upper part of the new columns
+  MOE_HIP_CHECK(hipMemset2DAsync(L + (size_t)N0 * ldl, sizeof(double) * ldl, 0, sizeof(double) * N0, kk, s));
+  MOE_HIP_CHECK(hipMemset2DAsync(Linv + (size_t)N0 * ldi, sizeof(double) * ldi, 0, sizeof(double) * N0, kk, s));
+  // V = L11^-1 K12;  Schur complement S = K22 - V^T V;  L22 = chol(S), X22 = L22^-1
+  launch_tri_gemm_skinny('N', N0, kk, Linv, ldi, B, N0, V, N0, s);
+  launch_gemm_tn(kk, kk, N0, V, N0, V, N0, G, kk, s);
+  hipLaunchKernelGGL(sub_inplace_kernel, dim3((kk * kk + 255) / 256), dim3(256), 0, s, C, (const double*)G, kk * kk);
+  launch_cholesky_and_inverse(kk, C, kk, X22, kk, cw, info, s);
+  MOE_HIP_CHECK(hipMemcpy2DAsync(L + N0 + (size_t)N0 * ldl, sizeof(double) * ldl, C, sizeof(double) * kk,
+                                 sizeof(double) * kk, kk, hipMemcpyDeviceToDevice, s));
+  MOE_HIP_CHECK(hipMemcpy2DAsync(Linv + N0 + (size_t)N0 * ldi, sizeof(double) * ldi, X22, sizeof(double) * kk,
+                                 sizeof(double) * kk, kk, hipMemcpyDeviceToDevice, s));
+  // L21 = V^T;  X21 = -X22 (L21 X11) = -X22 W^T
+  launch_tri_gemm_skinny('T', N0, kk, Linv, ldi, V, N0, W, N0, s);
+  hipLaunchKernelGGL(append_rows_kernel, dim3((N0 + 255) / 256), dim3(256), 0, s, (const double*)V, (const double*)W,
+                     (const double*)X22, N0, kk, L + N0, ldl, Linv + N0, ldi);
   MOE_HIP_CHECK(hipGetLastError());
 }
 

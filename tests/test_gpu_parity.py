@@ -294,7 +294,64 @@ def test_add_points_matches_fresh_build(api):
     a.add_points(X[40:], y[40:])
     b = api.DeviceGP([1.2, 0.5, 0.6, 0.7], X, y, [0.02])
     q = rng.uniform(size=(7, 3))
-    assert np.array_equal(a.mean(q), b.mean(q)) and np.array_equal(a.variance(q), b.variance(q))
+    assert np.abs(a.mean(q) - b.mean(q)).max() <= 1e-12 and np.abs(a.variance(q) - b.variance(q)).max() <= 1e-12
+    La, Lb = a.get_factor()[0], b.get_factor()[0]
+    assert np.abs(La - Lb).max() <= 1e-12
+    # more rows than the head-room behind the factorisation: the full rebuild, bit-identical to a fresh build
+    X2, y2 = rng.uniform(size=(200, 3)), rng.uniform(size=(200, 1))
+    a.add_points(X2, y2)
+    c = api.DeviceGP([1.2, 0.5, 0.6, 0.7], np.vstack([X, X2]), np.vstack([y, y2]), [0.02])
+    assert np.array_equal(a.mean(q), c.mean(q)) and np.array_equal(a.variance(q), c.variance(q))
+
+
+@pytest.mark.parametrize("n0,adds,d,derivs", [(60, [4], 3, []), (300, [1, 3, 8, 2], 5, []), (1000, [4, 4, 4], 8, []),
+                                              (90, [2, 5], 4, [0, 2]), (700, [16, 1], 6, [1])])
+def test_add_points_rank_k_append(api, n0, adds, d, derivs):
+    """A few new observations extend L and L^-1 by a block row (launch_cholesky_append) instead of refactorising
+    (AddPointsToGP, gpp_math.cpp:1699-1737, refactorises): posterior, gradients and q-KG must match a GP built on all
+    the points at once, and the oracle, at round-off level."""
+    from oracle import orc
+    rng = np.random.default_rng(n0 + d)
+    g = len(derivs)
+    n = n0 + sum(adds)
+    X = rng.uniform(size=(n, d))
+    y = np.sin(3 * X).sum(1, keepdims=True) + 0.1 * rng.uniform(size=(n, 1))
+    if g:
+        y = np.hstack([y] + [3 * np.cos(3 * X[:, [k]]) for k in derivs])
+    hyper = [1.1] + list(0.4 + 0.05 * np.arange(d))
+    noise = [0.01] * (1 + g)
+    a = api.DeviceGP(hyper, X[:n0], y[:n0], noise, derivatives=derivs)
+    at = n0
+    for k in adds:
+        a.add_points(X[at:at + k], y[at:at + k])
+        at += k
+    b = api.DeviceGP(hyper, X, y, noise, derivatives=derivs)
+    q = rng.uniform(size=(9, d))
+    for fa, fb in ((a.mean(q), b.mean(q)), (a.variance(q), b.variance(q)), (a.grad_mean(q), b.grad_mean(q)),
+                   (a.cholesky_variance(q[:4]), b.cholesky_variance(q[:4])),
+                   (a.grad_cholesky_variance(q[:3], 3), b.grad_cholesky_variance(q[:3], 3))):
+        scale = max(1.0, float(np.abs(fb).max()))
+        assert np.abs(np.asarray(fa) - np.asarray(fb)).max() <= 2e-10 * scale
+    o = orc.OrcGP(1, hyper[0], hyper[1:], X, y, noise, derivs)
+    assert np.abs(a.mean(q) - o.mean(q)).max() <= 1e-9
+    assert np.abs(a.variance(q) - o.var(q)).max() <= 1e-9
+    Z = rng.standard_normal((100, 3 * (1 + g)))
+    bounds = [0.0, 1.0] * d
+    gd = (1, 6, 1, 3, 0.0, 1.0, 0.1, 1e-10)
+    ra = a.kg(gd, bounds, q[:5], q[5:8], None, 200, 0.1, Z)
+    rb = b.kg(gd, bounds, q[:5], q[5:8], None, 200, 0.1, Z)
+    assert abs(ra["kg"] - rb["kg"]) <= 1e-8 * max(1.0, abs(rb["kg"]))
+    assert np.abs(ra["grad"] - rb["grad"]).max() <= 1e-7 * max(1.0, np.abs(rb["grad"]).max())
+
+
+def test_add_points_append_singular(api):
+    """A duplicate of a sampled point with zero noise makes the Schur complement singular: same error as a fresh build."""
+    rng = np.random.default_rng(3)
+    X = rng.uniform(size=(40, 2))
+    gp = api.DeviceGP([1.0, 0.5, 0.5], X, rng.uniform(size=(40, 1)), [0.0])
+    with pytest.raises(api.SingularMatrixException) as e:
+        gp.add_points(X[[7]], [[0.3]])
+    assert e.value.num_rows == 41
 
 
 def test_fastmath(api):
