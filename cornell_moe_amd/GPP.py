@@ -661,6 +661,16 @@ def compute_log_likelihood(points_sampled, points_sampled_value, dim, num_sample
     return float(h.evaluate(hyper[None, :])[0])
 
 
+def compute_hyperparameter_grad_log_likelihood(points_sampled, points_sampled_value, dim, num_sampled, objective_type,
+                                               hyperparameters, derivatives, num_derivatives, noise_variance):
+    """ComputeHyperparameterGradLogLikelihoodWrapper (gpp_python_model_selection.cpp:88-135): list of
+    1 + dim + 1 + num_derivatives partials wrt (alpha, lengths, noise variances), Matern-5/2 kernel."""
+    _check_objective(objective_type)
+    h = _ll_handle(points_sampled, points_sampled_value, dim, num_sampled, derivatives, num_derivatives)
+    hyper = np.r_[float(hyperparameters[0]), _flat(hyperparameters[1], dim), _flat(noise_variance, 1 + num_derivatives)]
+    return list(h.grad(hyper))
+
+
 def evaluate_log_likelihood_at_hyperparameter_list(hyperparameter_list, points_sampled, points_sampled_value, dim, num_sampled,
                                                    objective_mode, hyperparameters, noise_variance, derivatives,
                                                    num_derivatives, num_multistarts, max_num_threads, status):

@@ -588,3 +588,11 @@ class LogLikelihood(object):
         err = _lib.MoeError()
         _check(_lib.load().moe_ll_evaluate(self._h, h.ctypes.data_as(dp), h.shape[0], out.ctypes.data_as(dp), C.byref(err)), err)
         return out
+
+    def grad(self, hyperparameters):
+        """d log p / d (alpha, lengths, noise variances) at one hyper-parameter set [1 + dim + 1 + g] (moe_ll_grad)."""
+        h = np.ascontiguousarray(hyperparameters, dtype=np.float64).reshape(1 + self.d + 1 + self.g)
+        out = np.zeros(h.size)
+        err = _lib.MoeError()
+        _check(_lib.load().moe_ll_grad(self._h, h.ctypes.data_as(dp), out.ctypes.data_as(dp), C.byref(err)), err)
+        return out

@@ -524,6 +524,21 @@ int moe_ll_evaluate(moe_ll_t* ll, const double* hyperparameters_all, int num_set
   });
 }
 
+int moe_ll_grad(moe_ll_t* ll, const double* hyperparameters, double* grad, moe_error_t* err) {
+  return guarded(err, [&] {
+    require(ll != nullptr && hyperparameters != nullptr && grad != nullptr, "NULL argument");
+    const int g1 = 1 + ll->g;
+    std::vector<double> noise(g1);
+    for (int a = 0; a < g1; ++a) noise[a] = hyperparameters[1 + ll->d + a] + 1.0e-6;  // gpp_model_selection.cpp:546-549
+    if (!ll->gp)
+      ll->gp.reset(new moe::GpDev(hyperparameters, ll->cov_type, ll->X.data(), ll->y.data(), noise.data(),
+                                  ll->derivs.empty() ? nullptr : ll->derivs.data(), ll->g, ll->d, ll->n, ll->device));
+    else
+      ll->gp->set_hyperparameters(hyperparameters, noise.data());
+    ll->gp->grad_log_marginal_likelihood(grad);
+  });
+}
+
 int moe_posterior_mean_optimize(const moe_gp_t* gp_c, int num_fidelity, const moe_gd_params_t* params,
                                 const double* domain_bounds, const double* initial_guess, double* best_point,
                                 double* best_value, moe_error_t* err) {

@@ -1,6 +1,8 @@
 // cornell_moe_amd/csrc/gp.hip -- see gp.hpp.
 #include "gp.hpp"
 
+#include "device_cov.hpp"
+
 #include <cstdlib>
 #include <cmath>
 #include <cstring>
@@ -96,6 +98,133 @@ __global__ __launch_bounds__(256) void ll_terms_kernel(const double* __restrict_
   }
 }
 }  // namespace
+
+namespace {
+// Hyper-parameter gradient of the log marginal likelihood, covariance part: with w_ij = alpha_i alpha_j - K^-1_ij on the
+// function-value rows,
+//   part[block][0]     = sum w_ij  dK_ij/d alpha          (= base / alpha)
+//   part[block][1 + k] = sum w_ij  first_ij (x_ik - x_jk)^2   (dK_ij/d l_k = first * diff_k^2 / l_k^3; host scales)
+// over the block's 256 rows i x 64 columns j.  Row per thread (K^-1 reads coalesced), the 64 x_j broadcast from LDS.
+template <int DP>
+__global__ __launch_bounds__(256) void ll_grad_kernel(CovParams cp, const double* __restrict__ X, int n, int g1,
+                                                      const double* __restrict__ alpha, const double* __restrict__ Kinv,
+                                                      long ldk, double* __restrict__ part) {
+  __shared__ double Xj[64][DP];
+  __shared__ double aj[64];
+  __shared__ double red[4][1 + DP];
+  const int j0 = blockIdx.y * 64, nj = min(64, n - j0);
+  for (int t = threadIdx.x; t < nj * DP; t += 256) Xj[t / DP][t % DP] = X[(long)(j0 + t / DP) * DP + t % DP];
+  if ((int)threadIdx.x < nj) aj[threadIdx.x] = alpha[(long)(j0 + threadIdx.x) * g1];
+  __syncthreads();
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  double acc[1 + DP];
+#pragma unroll
+  for (int k = 0; k <= DP; ++k) acc[k] = 0.0;
+  if (i < n) {
+    double xi[DP];
+#pragma unroll
+    for (int k = 0; k < DP; ++k) xi[k] = X[(long)i * DP + k];
+    const double ai = alpha[(long)i * g1];
+    const double* Krow = Kinv + (long)i * g1;
+    for (int jj = 0; jj < nj; ++jj) {
+      double diff2[DP];
+      double r2 = 0.0;
+#pragma unroll
+      for (int k = 0; k < DP; ++k) {
+        const double dlt = xi[k] - Xj[jj][k];
+        diff2[k] = dlt * dlt;
+        r2 = fma(diff2[k], cp.inv_l2[k], r2);
+      }
+      const Radial rd = radial_scalars(cp.type, 1.0, r2);  // alpha = 1: base IS dK/d alpha
+      const double w = fma(ai, aj[jj], -Krow[(long)(j0 + jj) * g1 * ldk]);
+      acc[0] = fma(w, rd.base, acc[0]);
+      const double wf = w * rd.first;
+#pragma unroll
+      for (int k = 0; k < DP; ++k) acc[1 + k] = fma(wf, diff2[k], acc[1 + k]);
+    }
+  }
+#pragma unroll
+  for (int k = 0; k <= DP; ++k) {
+    double v = acc[k];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][k] = v;
+  }
+  __syncthreads();
+  if ((int)threadIdx.x <= DP) {
+    const int k = threadIdx.x;
+    part[((long)blockIdx.y * gridDim.x + blockIdx.x) * (1 + DP) + k] = (red[0][k] + red[1][k]) + (red[2][k] + red[3][k]);
+  }
+}
+
+// out[k] = sum over blocks of part[block][k] (k < width), then out[width + a] = sum_i alpha_{i,a}^2 - K^-1_{(i,a),(i,a)}
+// (the noise-variance gradients: dK/d sigma_a is the indicator of the rows of observation kind a).  One workgroup.
+__global__ __launch_bounds__(256) void ll_grad_finish_kernel(const double* __restrict__ part, int nblocks, int width, int n,
+                                                             int g1, const double* __restrict__ alpha,
+                                                             const double* __restrict__ Kinv, long ldk,
+                                                             double* __restrict__ out) {
+  __shared__ double red[256];
+  for (int k = 0; k < width + g1; ++k) {
+    double v = 0.0;
+    if (k < width) {
+      for (int b = threadIdx.x; b < nblocks; b += 256) v += part[(long)b * width + k];
+    } else {
+      const int a = k - width;
+      for (int i = threadIdx.x; i < n; i += 256) {
+        const long r = (long)i * g1 + a;
+        v += fma(alpha[r], alpha[r], -Kinv[r + r * ldk]);
+      }
+    }
+    red[threadIdx.x] = v;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+      if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) out[k] = red[0];
+    __syncthreads();
+  }
+}
+
+template <int DP>
+void launch_ll_grad(const CovParams& cp, const double* X, int n, int g1, const double* alpha, const double* Kinv, long ldk,
+                    double* part, double* out, hipStream_t s) {
+  dim3 grid((n + 255) / 256, (n + 63) / 64);
+  hipLaunchKernelGGL((ll_grad_kernel<DP>), grid, dim3(256), 0, s, cp, X, n, g1, alpha, Kinv, ldk, part);
+  hipLaunchKernelGGL(ll_grad_finish_kernel, dim3(1), dim3(256), 0, s, (const double*)part, (int)(grid.x * grid.y), 1 + DP, n,
+                     g1, alpha, Kinv, ldk, out);
+  MOE_HIP_CHECK(hipGetLastError());
+}
+}  // namespace
+
+void GpDev::grad_log_marginal_likelihood(double* grad) {
+  use_device();
+  if (cp.type == MOE_COV_SQUARE_EXPONENTIAL && g > 0)
+    throw Error(MOE_ERR_INVALID_VALUE,
+                "hyper-parameter gradient with derivative observations is provided for the Matern-5/2 kernel only "
+                "(the kernel the reference's Python boundary builds)");
+  // K^-1 = L^-T L^-1, explicitly: tr(K^-1 dK/d theta) needs every entry once per hyper-parameter
+  dVE.reserve((size_t)N * N);
+  launch_tri_gemm('T', N, N, dLinv.p, ldL, dLinv.p, ldL, dVE.p, N, stream);
+  const int g1 = 1 + g;
+  const size_t nblocks = (size_t)((n + 255) / 256) * ((n + 63) / 64);
+  dE.reserve(nblocks * (1 + dp) + (size_t)(1 + dp + g1));
+  double* out = dE.p + nblocks * (1 + dp);
+  switch (dp) {
+    case 4: launch_ll_grad<4>(cp, dX.p, n, g1, dKinvY.p, dVE.p, N, dE.p, out, stream); break;
+    case 8: launch_ll_grad<8>(cp, dX.p, n, g1, dKinvY.p, dVE.p, N, dE.p, out, stream); break;
+    case 12: launch_ll_grad<12>(cp, dX.p, n, g1, dKinvY.p, dVE.p, N, dE.p, out, stream); break;
+    case 16: launch_ll_grad<16>(cp, dX.p, n, g1, dKinvY.p, dVE.p, N, dE.p, out, stream); break;
+    default: throw Error(MOE_ERR_BOUNDS, "unsupported padded dimension", dp, 4, 16);
+  }
+  std::vector<double> h((size_t)(1 + dp + g1));
+  MOE_HIP_CHECK(hipMemcpyAsync(h.data(), out, sizeof(double) * h.size(), hipMemcpyDeviceToHost, stream));
+  MOE_HIP_CHECK(hipStreamSynchronize(stream));
+  // 0.5 alpha^T dK alpha - 0.5 tr(K^-1 dK)   (ComputeGradLogLikelihood, gpp_model_selection.cpp:629-677)
+  grad[0] = 0.5 * h[0];
+  for (int k = 0; k < d; ++k) grad[1 + k] = 0.5 * cp.alpha * h[1 + k] * cp.inv_l2[k] * cp.inv_l[k];
+  for (int a = 0; a < g1; ++a) grad[1 + d + a] = 0.5 * h[1 + dp + a];
+}
 
 double GpDev::log_marginal_likelihood() {
   use_device();

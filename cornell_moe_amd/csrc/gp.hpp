@@ -56,6 +56,11 @@ struct GpDev {
   // log p(y | X, theta) of the current factorisation = -1/2 yc^T K^-1 yc - sum log L_ii - N/2 log 2 pi
   // (LogMarginalLikelihoodEvaluator::ComputeLogLikelihood, gpp_model_selection.cpp:593-612).
   double log_marginal_likelihood();
+  // d log p / d [alpha, lengths[d], noise variances[1 + g]] of the current factorisation
+  // (LogMarginalLikelihoodEvaluator::ComputeGradLogLikelihood, gpp_model_selection.cpp:629-677; with the reference's
+  // Matern-5/2 convention that only the function-value block depends on the covariance hyper-parameters,
+  // gpp_covariance.cpp:461-487).
+  void grad_log_marginal_likelihood(double* grad);
   std::vector<double> padded(const double* pts, int k) const;  // [k][d] -> [k][DP]
   // Posterior mean of the function value at k points (one kernel, one copy each way): mu[k]; grad (may be NULL) [k][d].
   void mean_of_points(const double* pts, int k, double* mu, double* grad);

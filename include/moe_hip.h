@@ -254,6 +254,14 @@ int moe_ll_create(int cov_type, const double* points_sampled, const double* poin
                   int num_derivatives, int dim, int num_sampled, int device, moe_ll_t** ll_out, moe_error_t* err);
 int moe_ll_destroy(moe_ll_t* ll);
 int moe_ll_evaluate(moe_ll_t* ll, const double* hyperparameters_all, int num_sets, double* values, moe_error_t* err);
+/* compute_hyperparameter_grad_log_likelihood (gpp_python_model_selection.cpp:88-135 ->
+ * LogMarginalLikelihoodEvaluator::ComputeGradLogLikelihood, gpp_model_selection.cpp:629-677):
+ * grad[1 + dim + 1 + g] = d log p(y | X, theta) / d (alpha, lengths[dim], noise_variance[1 + g]) at ONE hyper-parameter set
+ * (layout as above) = 1/2 a^T (dK/dtheta) a - 1/2 tr(K^-1 dK/dtheta), a = K^-1 (y - mean).  The Matern-5/2 kernel follows
+ * the reference's convention that only the function-value block of K depends on (alpha, lengths)
+ * (MaternNu2p5::HyperparameterGradCovariance, gpp_covariance.cpp:461-487, fills that block alone); the squared
+ * exponential is provided without derivative observations.  A singular K + noise is MOE_ERR_SINGULAR. */
+int moe_ll_grad(moe_ll_t* ll, const double* hyperparameters, double* grad, moe_error_t* err);
 
 /* ---- covariance assembly (exposed for parity tests and the HBM-roofline measurement) ----
  * BuildMixCovarianceMatrix (gpp_math.cpp:309-335, 469-479): out[N x num_pts*(1+g2)] col-major = K(X, pts) with

@@ -373,6 +373,97 @@ int orc_log_likelihood(int cov_type, double alpha, const double* lengths, const 
   return rc;
 }
 
+/* CovarianceInterface::HyperparameterGradCovariance for the function-value entry: out[1 + d] = d cov(p1, p2) / d (alpha,
+ * lengths).  SquareExponential gpp_covariance.cpp:245-259; MaternNu2p5 :461-487 (which fills nothing but this entry: with
+ * derivative observations the other blocks of the matrix below stay at the zeros their buffer was created with,
+ * gpp_model_selection.cpp:398). */
+static void hyper_grad_cov_value(const orc_cov* c, const double* p1, const double* p2, double* out) {
+  const double nsq = norm_sq(c, p1, p2);
+  if (c->type == 0) {
+    const double cov = c->alpha * exp(-0.5 * nsq);
+    out[0] = cov / c->alpha;
+    for (int i = 0; i < c->dim; ++i) {
+      const double len = sqrt(c->lengths_sq[i]);
+      out[1 + i] = cov * SQ((p1[i] - p2[i]) / len) / len;
+    }
+    return;
+  }
+  if (nsq == 0.0) {
+    out[0] = 1.0;
+    for (int i = 0; i < c->dim; ++i) out[1 + i] = 0.0;
+    return;
+  }
+  const double matern_arg = kSqrt5 * sqrt(nsq);
+  const double poly_part = matern_arg + 5.0 / 3.0 * nsq;
+  const double exp_part = exp(-matern_arg);
+  out[0] = (1.0 + poly_part) * exp_part;
+  for (int i = 0; i < c->dim; ++i) {
+    const double len = sqrt(c->lengths_sq[i]);
+    const double dr2_dleni = -2.0 * SQ((p1[i] - p2[i]) / len) / len;
+    const double dr_dleni = 0.5 * dr2_dleni / sqrt(nsq);
+    out[1 + i] = c->alpha * exp_part * (5.0 / 3.0 * dr2_dleni - poly_part * kSqrt5 * dr_dleni);
+  }
+}
+
+/* LogMarginalLikelihoodEvaluator::ComputeGradLogLikelihood (gpp_model_selection.cpp:629-677) on the state of
+ * orc_log_likelihood: for every hyper-parameter theta in (alpha, lengths[d], noise variances[1 + g]) the matrix dK/dtheta
+ * (BuildHyperparameterGradCovarianceMatrix, :386-446), then  grad = 1/2 a^T dK a - 1/2 tr(K^-1 dK),  a = K^-1 (y - mean),
+ * with K^-1 dK by two triangular solves per column as the reference does (OL_USE_INVERSE 0).
+ * The squared exponential is restated for g = 0 only (returns -2 otherwise). */
+int orc_log_likelihood_grad(int cov_type, double alpha, const double* lengths, const double* X, const double* y,
+                            const double* noise, const int* derivs, int g, int d, int n, double* grad) {
+  if (cov_type == 0 && g > 0) return -2;
+  orc_cov cov;
+  cov.type = cov_type;
+  cov.dim = d;
+  cov.alpha = alpha;
+  for (int i = 0; i < d; ++i) cov.lengths_sq[i] = SQ(lengths[i]);
+  orc_gp* gp = gp_alloc(&cov, g, derivs, d, n);
+  memcpy(gp->X, X, sizeof(double) * (size_t)n * d);
+  memcpy(gp->y, y, sizeof(double) * (size_t)gp->N);
+  memcpy(gp->noise, noise, sizeof(double) * (size_t)(1 + g));
+  const size_t N = (size_t)gp->N;
+  const int g1 = 1 + g, nh = 1 + d + g1;
+  memset(gp->K_chol, 0, sizeof(double) * N * N);
+  build_K_with_noise(gp, gp->K_chol);
+  for (size_t i = 0; i < N; ++i) gp->K_chol[i + i * N] += 1.0e-6;
+  const int rc = orc_cholesky((int)N, gp->K_chol);
+  if (rc == 0) {
+    recompute_mean_variables(gp, 1);
+    double* dK = dalloc(N * N);
+    double* tmp = dalloc(N);
+    double* hg = dalloc((size_t)(1 + d));
+    for (int h = 0; h < nh; ++h) {
+      memset(dK, 0, sizeof(double) * N * N);
+      if (h < 1 + d) {
+        for (int i = 0; i < n; ++i)
+          for (int j = 0; j < n; ++j) {
+            hyper_grad_cov_value(&cov, X + (size_t)j * d, X + (size_t)i * d, hg);
+            dK[(size_t)j * g1 + (size_t)i * g1 * N] = hg[h];
+          }
+      } else {
+        const int m = h - 1 - d;
+        for (int i = 0; i < n; ++i) {
+          const size_t r = (size_t)i * g1 + m;
+          dK[r + r * N] = 1.0;
+        }
+      }
+      gemv(dK, 'N', gp->K_inv_y, 1.0, 0.0, (int)N, (int)N, (int)N, tmp);
+      double quad = 0.0;
+      for (size_t i = 0; i < N; ++i) quad += gp->K_inv_y[i] * tmp[i];
+      chol_solve_mat(gp->K_chol, (int)N, (int)N, dK);
+      double tr = 0.0;
+      for (size_t i = 0; i < N; ++i) tr += dK[i + i * N];
+      grad[h] = 0.5 * quad - 0.5 * tr;
+    }
+    free(dK);
+    free(tmp);
+    free(hg);
+  }
+  orc_gp_destroy(gp);
+  return rc;
+}
+
 /* GaussianProcess ctor gpp_math.cpp:553-573 + RecomputeDerivedVariables :481-511 */
 orc_gp* orc_gp_create(int cov_type, double alpha, const double* lengths, const double* X, const double* y,
                       const double* noise, const int* derivs, int g, int d, int n) {

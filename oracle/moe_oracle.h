@@ -75,6 +75,9 @@ int orc_ei(const orc_gp* gp, const double* Xq, const double* Xp, int q, int p, i
 /* log marginal likelihood (gpp_model_selection.cpp:540-612; +1e-6 diagonal jitter like the reference).  rc != 0: K singular. */
 int orc_log_likelihood(int cov_type, double alpha, const double* lengths, const double* X, const double* y,
                        const double* noise, const int* derivs, int g, int d, int n, double* value);
+/* d log p / d (alpha, lengths[d], noise[1 + g]) -> grad[1 + d + 1 + g]; rc as orc_log_likelihood, -2 = not restated. */
+int orc_log_likelihood_grad(int cov_type, double alpha, const double* lengths, const double* X, const double* y,
+                            const double* noise, const int* derivs, int g, int d, int n, double* grad);
 
 /* analytic 1,0-EI and its gradient [dim] (gpp_math.cpp:2195-2259); either output may be NULL. */
 int orc_ei_analytic(const orc_gp* gp, const double* pt, double best_so_far, double* ei, double* grad);

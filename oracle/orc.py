@@ -268,6 +268,26 @@ def log_likelihood(cov_type, alpha, lengths, X, y, noise, derivs):
     return val.value
 
 
+def log_likelihood_grad(cov_type, alpha, lengths, X, y, noise, derivs):
+    """orc_log_likelihood_grad: hyper-parameter gradient of the log marginal likelihood (gpp_model_selection.cpp:629-677).
+    Returns [1 + d + 1 + g] partials wrt (alpha, lengths, noise variances)."""
+    X = np.ascontiguousarray(X, dtype=np.float64)
+    n, d = X.shape
+    derivs = [int(v) for v in derivs]
+    ya, yp = _d(y)
+    na, np_ = _d(noise)
+    la, lp = _d(lengths)
+    da, dp = _i(derivs)
+    out = np.zeros(1 + d + 1 + len(derivs))
+    fn = lib().orc_log_likelihood_grad
+    fn.argtypes = [C.c_int, C.c_double, _dp, _dp, _dp, _dp, _ip, C.c_int, C.c_int, C.c_int, _dp]
+    fn.restype = C.c_int
+    rc = fn(cov_type, float(alpha), lp, X.ctypes.data_as(_dp), yp, np_, dp, len(derivs), d, n, out.ctypes.data_as(_dp))
+    if rc:
+        raise SingularMatrix("K singular at minor %d" % rc)
+    return out
+
+
 class OrcGPMCMC(object):
     """Restatement of the MCMC-averaged evaluators on top of OrcGP (numpy level): GaussianProcessMCMC builds one Matern-5/2 GP
     per hyper-parameter sample (gpp_knowledge_gradient_mcmc_optimization.cpp:24-49); the evaluators average the per-GP

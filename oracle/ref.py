@@ -312,6 +312,25 @@ def log_likelihood(cov_type, alpha, lengths, X, y, noise, derivs):
     return val.value
 
 
+def log_likelihood_grad(cov_type, alpha, lengths, X, y, noise, derivs):
+    """LogMarginalLikelihoodEvaluator::ComputeGradLogLikelihood on a fresh state (gpp_python_model_selection.cpp:88-135).
+    Returns [1 + d + 1 + g] partials wrt (alpha, lengths, noise variances)."""
+    X = np.ascontiguousarray(X, dtype=np.float64)
+    n, d = X.shape
+    derivs = [int(v) for v in derivs]
+    ya, yp = _d(y)
+    na, np_ = _d(noise)
+    la, lp = _d(lengths)
+    da, dp = _i(derivs)
+    out = np.zeros(1 + d + 1 + len(derivs))
+    fn = lib().ref_log_likelihood_grad
+    fn.argtypes = [C.c_int, C.c_double, _dp, _dp, _dp, _dp, _ip, C.c_int, C.c_int, C.c_int, _dp]
+    fn.restype = C.c_int
+    rc = fn(cov_type, float(alpha), lp, X.ctypes.data_as(_dp), yp, np_, dp, len(derivs), d, n, out.ctypes.data_as(_dp))
+    _check(rc)
+    return out
+
+
 class RefGPMCMC(object):
     """The reference GaussianProcessMCMC (gpp_knowledge_gradient_mcmc_optimization.hpp:140-198): one Matern-5/2 GP per
     hyper-parameter sample over the same data.  hypers [num_mcmc][1 + d] = (alpha, lengths), noises [num_mcmc][1 + g]."""

@@ -432,6 +432,20 @@ int ref_log_likelihood(int cov_type, double alpha, const double* lengths, const 
   });
 }
 
+// LogMarginalLikelihoodEvaluator::ComputeGradLogLikelihood (gpp_model_selection.cpp:629-677) driven like
+// ComputeHyperparameterGradLogLikelihoodWrapper (gpp_python_model_selection.cpp:88-135): grad[1 + d + 1 + g].
+int ref_log_likelihood_grad(int cov_type, double alpha, const double* lengths, const double* X, const double* y,
+                            const double* noise, const int* derivs, int g, int d, int n, double* grad) {
+  return guarded([&] {
+    CovarianceInterface* cov = make_cov(cov_type, d, alpha, lengths);
+    LogMarginalLikelihoodEvaluator ev(X, y, nn(derivs), g, d, n);
+    std::vector<double> nv(noise, noise + 1 + g);
+    LogMarginalLikelihoodState st(ev, *cov, nv);
+    ev.ComputeGradLogLikelihood(&st, grad);
+    delete cov;
+  });
+}
+
 // All-core CPU baseline the way the reference parallelises: independent evaluations under OpenMP, one State + RNG per
 // thread (gpp_optimization.hpp:1472-1546). Xq_all[R][q][d]; kg_out[R]; grad_out[R][q*d]. Returns wall seconds.
 int ref_kg_grad_batch(void* hv, int num_fidelity, const double* gd, const double* bounds, const double* discrete, int P,

@@ -31,6 +31,7 @@ HOT_PATH_EXPORTS = [
     ("multistart_expected_improvement_mcmc_optimization", 11), ("evaluate_EI_mcmc_at_point_list", 11),
     # log marginal likelihood: gpp_python_model_selection.cpp:43-51, 281-291
     ("compute_log_likelihood", 9), ("evaluate_log_likelihood_at_hyperparameter_list", 13),
+    ("compute_hyperparameter_grad_log_likelihood", 9),  # gpp_python_model_selection.cpp:88-96
 ]
 GP_METHODS = [  # gpp_python_gaussian_process.cpp:294-465 (self + listed arguments)
     ("compute_mean_of_points", 2), ("compute_mean_of_additional_points", 2), ("compute_grad_mean_of_points", 2),

@@ -142,6 +142,31 @@ def test_golden_log_likelihood(api, golden):
     assert abs(ok - orc.log_likelihood(1, 1.0, [0.5, 0.5, 0.5], X, y, [0.0], ())) <= 1e-9 * abs(ok)
 
 
+def test_golden_log_likelihood_grad(api):
+    """moe_ll_grad (one fused N x N pass over alpha alpha^T - K^-1 on the device) against the reference's
+    ComputeGradLogLikelihood fixtures and, at a larger size, against the restatement."""
+    from helpers import load_golden_ll_grad
+    from oracle import orc
+    for c in load_golden_ll_grad():
+        LL = api.LogLikelihood(c["X"], c["y"], list(c["derivs"]), cov_type=int(c["cov_type"]))
+        theta = np.r_[float(c["alpha"]), c["lengths"], c["noise"]]
+        g = LL.grad(theta)
+        assert np.abs(g - c["grad"]).max() <= 1e-9 * np.abs(c["grad"]).max(), (c["X"].shape, np.abs(g - c["grad"]).max())
+        assert abs(LL.evaluate(theta[None, :])[0] - float(c["value"])) <= 1e-10 * abs(float(c["value"]))
+    rng = np.random.default_rng(8)
+    n, d = 400, 8
+    X = rng.uniform(size=(n, d))
+    y = np.sin(3 * X).sum(1, keepdims=True) + 0.1 * rng.uniform(size=(n, 1))
+    theta = np.r_[1.2, rng.uniform(0.4, 1.0, size=d), 0.02]
+    g = api.LogLikelihood(X, y).grad(theta)
+    o = orc.log_likelihood_grad(1, theta[0], theta[1:1 + d], X, y, theta[1 + d:], ())
+    assert np.abs(g - o).max() <= 1e-9 * np.abs(o).max()
+    with pytest.raises(api.InvalidValueException):
+        api.LogLikelihood(X[:20], np.zeros((20, 2)), [0], cov_type=0).grad(np.r_[1.0, np.full(d, 0.5), 0.1, 0.1])
+    with pytest.raises(api.SingularMatrixException):
+        api.LogLikelihood(X[:20], np.zeros((20, 1))).grad(np.r_[1.0, np.full(d, 0.5), -2.0])
+
+
 def test_golden_kg(api, golden):
     cases, _ = golden
     ran = 0

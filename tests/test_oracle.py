@@ -140,6 +140,33 @@ def test_golden_log_likelihood(golden):
             assert abs(v - c.out["log_likelihood"][k]) <= 1e-11 * abs(c.out["log_likelihood"][k])
 
 
+def test_golden_log_likelihood_grad():
+    """Restatement of ComputeGradLogLikelihood (orc_log_likelihood_grad) against the reference's gradients, including its
+    Matern-5/2 convention with derivative observations (only the function-value block of dK/dtheta is filled)."""
+    from helpers import load_golden_ll_grad
+    cases = load_golden_ll_grad()
+    assert len(cases) >= 12
+    for c in cases:
+        g = orc.log_likelihood_grad(int(c["cov_type"]), float(c["alpha"]), c["lengths"], c["X"], c["y"], c["noise"],
+                                    list(c["derivs"]))
+        assert np.abs(g - c["grad"]).max() <= 1e-10 * np.abs(c["grad"]).max()
+        v = orc.log_likelihood(int(c["cov_type"]), float(c["alpha"]), c["lengths"], c["X"], c["y"], c["noise"],
+                               list(c["derivs"]))
+        assert abs(v - float(c["value"])) <= 1e-11 * abs(float(c["value"]))
+    # without derivative observations it IS the gradient of the value: central differences of the restated value
+    c = [c for c in cases if len(c["derivs"]) == 0 and c["X"].shape[0] >= 60][0]
+    d = c["X"].shape[1]
+    theta = np.r_[float(c["alpha"]), c["lengths"], c["noise"]]
+
+    def f(t):
+        return orc.log_likelihood(int(c["cov_type"]), t[0], t[1:1 + d], c["X"], c["y"], t[1 + d:], ())
+    for k in range(theta.size):
+        e = np.zeros_like(theta)
+        e[k] = 1e-6
+        fd = (f(theta + e) - f(theta - e)) / 2e-6
+        assert abs(fd - c["grad"][k]) <= 1e-5 * max(1.0, abs(c["grad"][k]))
+
+
 def test_singular_detection():
     X = np.array([[0.1, 0.2], [0.1, 0.2], [0.5, 0.5]])
     with pytest.raises(orc.SingularMatrix):

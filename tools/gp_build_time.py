@@ -27,3 +27,8 @@ for name in ["C2", "C3"]:
     t0 = time.perf_counter()
     LL.evaluate(sets)
     print("%s: log marginal likelihood %.2f ms per hyper-parameter set" % (name, 1e3 * (time.perf_counter() - t0) / 20))
+    LL.grad(sets[0])
+    t0 = time.perf_counter()
+    for k in range(10):
+        LL.grad(sets[k])
+    print("%s: hyper-parameter gradient of it %.2f ms per set (factorisation included)" % (name, 1e2 * (time.perf_counter() - t0)))

@@ -134,7 +134,42 @@ def mcmc_cases():
     return out
 
 
+OUT_LL = os.path.join(ROOT, "tests", "golden", "ref_ll_grad.npz")
+
+
+def ll_grad_fixtures():
+    """Hyper-parameter gradients of the log marginal likelihood from the reference's
+    LogMarginalLikelihoodEvaluator::ComputeGradLogLikelihood: Matern-5/2 with and without derivative observations (the
+    kernel the Python boundary builds) and the squared exponential without, at a few sizes and hyper-parameter sets."""
+    rng = np.random.default_rng(777)
+    blob, k = {}, 0
+    for (n, d, derivs, cov) in ((7, 3, (), 1), (7, 3, (0, 1, 2), 1), (40, 3, (0, 2), 1), (60, 4, (), 1), (60, 4, (), 0),
+                                (120, 6, (), 1), (90, 8, (1, 3), 1), (150, 10, (), 1)):
+        g = len(derivs)
+        X = rng.uniform(size=(n, d))
+        y = np.sin(3 * X).sum(1, keepdims=True) + 0.1 * rng.uniform(size=(n, 1))
+        if g:
+            y = np.hstack([y] + [3 * np.cos(3 * X[:, [j]]) for j in derivs])
+        for rep in range(2):
+            alpha = float(rng.uniform(0.5, 2.5))
+            lengths = rng.uniform(0.3, 1.5, size=d)
+            noise = rng.uniform(0.005, 0.2, size=1 + g)
+            grad = ref.log_likelihood_grad(cov, alpha, lengths, X, y, noise, list(derivs))
+            val = ref.log_likelihood(cov, alpha, lengths, X, y, noise, list(derivs))
+            for key, v in (("X", X), ("y", y), ("derivs", np.array(derivs, dtype=np.int32)), ("cov_type", cov), ("alpha", alpha),
+                           ("lengths", lengths), ("noise", noise), ("grad", grad), ("value", val)):
+                blob["g%d_%s" % (k, key)] = np.asarray(v)
+            k += 1
+    blob["num"] = np.array(k)
+    np.savez_compressed(OUT_LL, **blob)
+    print("wrote", OUT_LL, os.path.getsize(OUT_LL), "bytes,", k, "cases")
+
+
 def main():
+    if "--ll-grad" in sys.argv:
+        ll_grad_fixtures()
+        return
+    ll_grad_fixtures()
     cases = []
     inner_test = (1, 100, 10, 3, 0.0, 1.0, 0.1, 1e-10)   # inner GD of the reference's KG ping test (100 steps, 10 restarts)
     inner_prod = (1, 6, 1, 3, 0.0, 1.0, 0.1, 1e-10)      # examples/main.py:123-130
