@@ -631,7 +631,7 @@ KgPending kg_launch(GpDev& gp, int num_fidelity, const moe_gd_params_t& gd, cons
   const int ngrad = want_grad ? q * g1 * d : 0;
 
   // ---- MC launch geometry: workgroup = `waves` wavefronts sharing one LDS coordinate table ----
-  const size_t tab_bytes = sizeof(double) * (size_t)ntiles * dp * 64;
+  const size_t tab_bytes = sizeof(double) * (size_t)ntiles * (dp + 1) * 64;  // LDS copy: + the |x|^2 row (kg_mc.hpp eval_loop)
   const size_t slab_bytes = sizeof(double) * ((size_t)ntiles * (1 + G) * 64 + 2 * kMaxM);
   // the exp table sits in front of everything; one weight tile of padding at the very end (eval_loop prefetches one tile
   // past the last wave's slab)
@@ -876,6 +876,13 @@ KgPending kg_launch(GpDev& gp, int num_fidelity, const moe_gd_params_t& gd, cons
   for (int r = 0; r < kMaxDimPadded; ++r) {
     mp.inv_lp[r] = tp.inv_lp[r];
     mp.perm[r] = tp.perm[r];
+    // frame of the MC kernel's LDS coordinate table: centred on the training-set mean
+    double c = 0.0;
+    if (r < d) {
+      for (int j = 0; j < n; ++j) c += gp.X[(size_t)j * d + tp.perm[r]];
+      c /= n;
+    }
+    mp.center_s[r] = c * tp.inv_lp[r];
   }
   mp.n = n;
   mp.g = g;

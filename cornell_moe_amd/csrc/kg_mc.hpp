@@ -44,6 +44,7 @@ struct KgRec {  // offsets (doubles) of one evaluation's small operands inside t
 struct KgMcParams {
   int cov_type, dim;
   double alpha;
+  double center_s[kMaxDimPadded];  // training-set mean of table row r's coordinate, scaled by inv_lp (frame of the LDS table)
   double inv_lp[kMaxDimPadded];  // 1 / length of table row r (row r holds original dimension perm[r]); 0 in pad rows
   int perm[kMaxDimPadded];       // the GP's observed-derivative dimensions come first: perm[a] = derivatives[a], a < g
   int n, g, N, u, m, f, A, ntiles, E;
@@ -154,10 +155,43 @@ __device__ __forceinline__ void radial3(double r2, const double* __restrict__ et
 // xq = scaled query coordinates in table-row order (wave-uniform).  xs = coordinate table [tile][DP][64] (LDS, or global
 // when it does not fit), aw = this wave's weights [tile][1+G][64] in LDS (zero beyond the real points, so padded lanes
 // contribute exactly 0).
-template <int DP, int G, bool WG, int COV, bool SMALL>
+// Tile loads from LDS are volatile loads through an explicit LDS pointer: they must stay single ds_read_b64.  Merged into
+// ds_read2st64_b64 (what the load/store optimiser makes of two loads 512 B apart) they run at half the LDS rate on gfx950
+// -- 126 vs 218 B/clk/CU measured (tools/ldsbench.hip) -- and the tile loop moves 4.6 KB per tile and wavefront.
+typedef const volatile __attribute__((address_space(3))) double* lds_tile_ptr;
+template <bool LDS>
+struct tile_ptr {
+  typedef const double* type;
+};
+template <>
+struct tile_ptr<true> {
+  typedef lds_tile_ptr type;
+};
+
+//
+// With the table in LDS (XL) every tile carries one more row, |x_j - c|^2 of the centred scaled coordinates, and the value
+// passes -- nine in ten of all passes -- get the squared distance as |x_j|^2 + |q|^2 - 2 x_j . q: DP FMAs, one add and one
+// max per point instead of DP subtractions + DP FMAs (6 of 43 VALU instructions per point at DP = 8).  The coordinates
+// are centred on the training-set mean (`cs`, scaled, table-row order) so that the three terms are of the size of the
+// distance itself wherever the domain sits: the rounding error of r2 stays within a small multiple of the direct form's
+// (absolute ~1e-15 at unit-box scales; the kernel is smooth at r = 0, so close pairs lose nothing).  Gradient passes keep
+// the direct differences (they need them anyway).
+template <int DP, int G, bool WG, int COV, bool SMALL, bool XL>
 __device__ __forceinline__ double eval_loop(const double* __restrict__ xs, const double* __restrict__ aw,
                                             const double* __restrict__ etab, int ntiles, double mean,
-                                            const double (&xq)[DP], const double* inv_lp, double (&grad)[DP], int lane) {
+                                            const double (&xq_in)[DP], const double* inv_lp, const double* cs,
+                                            double (&grad)[DP], int lane) {
+  constexpr bool DOT = XL && !WG;      // squared distance from the |x|^2 row
+  constexpr int XR = DP + (XL ? 1 : 0);  // rows per coordinate tile
+  double xq[DP];                        // query in the table's frame (centred when the table is)
+  double q2[DP];
+  double qq = 1.0e-300;
+#pragma unroll
+  for (int k = 0; k < DP; ++k) {
+    xq[k] = XL ? xq_in[k] - cs[k] : xq_in[k];
+    q2[k] = -2.0 * xq[k];
+    qq = fma(xq[k], xq[k], qq);
+  }
   double accf = 0.0;
   double accg[DP];
   double accd[G > 0 ? G : 1];
@@ -167,30 +201,43 @@ __device__ __forceinline__ double eval_loop(const double* __restrict__ xs, const
   for (int a = 0; a < (G > 0 ? G : 1); ++a) accd[a] = 0.0;
   // Software-pipelined tile loop: the next tile's coordinates / weights are requested from LDS before the current
   // tile's ~55 FP64 instructions run, so the ds_read latency hides behind them instead of stalling every tile.
-  const double* xt = xs + lane;
-  const double* wt = aw + lane;
-  double cx[DP], cw[1 + G];
+  typename tile_ptr<XL>::type xt = (typename tile_ptr<XL>::type)(xs + lane);
+  lds_tile_ptr wt = (lds_tile_ptr)(aw + lane);
+  constexpr int NX = DP + (DOT ? 1 : 0);  // rows this pass reads: the |x|^2 row only where it is used
+  double cx[NX], cw[1 + G];
 #pragma unroll
-  for (int k = 0; k < DP; ++k) cx[k] = xt[k * 64];
+  for (int k = 0; k < NX; ++k) cx[k] = xt[k * 64];
 #pragma unroll
   for (int a = 0; a < 1 + G; ++a) cw[a] = wt[a * 64];
 #pragma unroll(SMALL ? 1 : (WG ? 2 : 4))
   for (int t = 0; t < ntiles; ++t) {
-    double nx[DP], nw[1 + G];
+    double nx[NX], nw[1 + G];
     // unconditional advance (constant stride: the unrolled tiles share one address register and use immediate offsets);
     // the last iteration prefetches one tile past the end -- the host pads both arrays by one tile, the values are unused
-    xt += DP * 64;
+    xt += XR * 64;
     wt += (1 + G) * 64;
 #pragma unroll
-    for (int k = 0; k < DP; ++k) nx[k] = xt[k * 64];
+    for (int k = 0; k < NX; ++k) nx[k] = xt[k * 64];
 #pragma unroll
     for (int a = 0; a < 1 + G; ++a) nw[a] = wt[a * 64];
     double diff[DP];
-    double r2 = 1.0e-300;  // keeps r2 > 0 for the rsq-based sqrt at no cost (invisible next to any r2 >= 1e-284)
+    double r2;
+    if (DOT) {
+      r2 = cx[DP] + qq;
 #pragma unroll
-    for (int k = 0; k < DP; ++k) {
-      diff[k] = cx[k] - xq[k];
-      r2 = fma(diff[k], diff[k], r2);
+      for (int k = 0; k < DP; ++k) r2 = fma(cx[k], q2[k], r2);
+      r2 = fmax(r2, 1.0e-300);  // rounding can leave a point that coincides with the query a hair below zero
+      if (G > 0) {
+#pragma unroll
+        for (int a = 0; a < G; ++a) diff[a] = cx[a] - xq[a];
+      }
+    } else {
+      r2 = 1.0e-300;  // keeps r2 > 0 for the rsq-based sqrt at no cost (invisible next to any r2 >= 1e-284)
+#pragma unroll
+      for (int k = 0; k < DP; ++k) {
+        diff[k] = cx[k] - xq[k];
+        r2 = fma(diff[k], diff[k], r2);
+      }
     }
     const double w0 = cw[0];  // alpha * (function-value weight)
     double base, first, second;
@@ -213,7 +260,7 @@ __device__ __forceinline__ double eval_loop(const double* __restrict__ xs, const
       for (int k = 0; k < DP; ++k) accg[k] = fma(coef, diff[k], accg[k]);
     }
 #pragma unroll
-    for (int k = 0; k < DP; ++k) cx[k] = nx[k];
+    for (int k = 0; k < NX; ++k) cx[k] = nx[k];
 #pragma unroll
     for (int a = 0; a < 1 + G; ++a) cw[a] = nw[a];
   }
@@ -232,13 +279,14 @@ __device__ __forceinline__ double eval_loop(const double* __restrict__ xs, const
 
 // The covariance type is wave-uniform: branch ONCE per pass (a branch inside the tile loop would split it into basic blocks
 // and stop the scheduler from interleaving the independent per-tile dependency chains).
-template <int DP, int G, bool WG, bool SMALL>
+template <int DP, int G, bool WG, bool SMALL, bool XL>
 __device__ __forceinline__ double eval_pass(const double* __restrict__ xs, const double* __restrict__ aw,
                                             const double* __restrict__ etab, int ntiles, int cov_type, double mean,
-                                            const double (&xq)[DP], const double* inv_lp, double (&grad)[DP], int lane) {
+                                            const double (&xq)[DP], const double* inv_lp, const double* cs,
+                                            double (&grad)[DP], int lane) {
   if (cov_type == MOE_COV_SQUARE_EXPONENTIAL)
-    return eval_loop<DP, G, WG, MOE_COV_SQUARE_EXPONENTIAL, SMALL>(xs, aw, etab, ntiles, mean, xq, inv_lp, grad, lane);
-  return eval_loop<DP, G, WG, MOE_COV_MATERN_NU_2P5, SMALL>(xs, aw, etab, ntiles, mean, xq, inv_lp, grad, lane);
+    return eval_loop<DP, G, WG, MOE_COV_SQUARE_EXPONENTIAL, SMALL, XL>(xs, aw, etab, ntiles, mean, xq, inv_lp, cs, grad, lane);
+  return eval_loop<DP, G, WG, MOE_COV_MATERN_NU_2P5, SMALL, XL>(xs, aw, etab, ntiles, mean, xq, inv_lp, cs, grad, lane);
 }
 
 // TensorProductDomain::LimitUpdate (gpp_domain.cpp:64-105) on one coordinate.
@@ -305,7 +353,7 @@ __device__ __forceinline__ void from_table_order(const double (&v)[DP], const in
 }
 
 // Evaluator of the wave-per-sample kernel: one pass = eval_pass over the LDS tables.
-template <int DP, int G, bool SMALL>
+template <int DP, int G, bool SMALL, bool XL>
 struct WaveEval {
   const double* __restrict__ xs;
   const double* __restrict__ aw;
@@ -313,10 +361,11 @@ struct WaveEval {
   int ntiles, cov_type;
   double mean;
   const double* inv_lp;
+  const double* cs;  // scaled centre of the LDS table's frame (table-row order)
   int lane;
   template <bool WG>
   __device__ __forceinline__ double eval(const double (&xq)[DP], double (&grad)[DP]) {
-    return eval_pass<DP, G, WG, SMALL>(xs, aw, etab, ntiles, cov_type, mean, xq, inv_lp, grad, lane);
+    return eval_pass<DP, G, WG, SMALL, XL>(xs, aw, etab, ntiles, cov_type, mean, xq, inv_lp, cs, grad, lane);
   }
 };
 
@@ -610,7 +659,7 @@ __device__ __forceinline__ int discrete_scan(const KgMcParams& P, const double* 
 }
 
 // One MC sample: weights, discretised-set scan, line-search gradient descent.  Called with the whole wave converged.
-template <int DP, int G, bool SMALL>
+template <int DP, int G, bool SMALL, bool XL>
 __device__ __forceinline__ void kg_sample(const KgMcParams& P, int e, int sl, const double* __restrict__ xs,
                                           double* __restrict__ aw, double* __restrict__ zb,
                                           const double* __restrict__ etab, int lane, unsigned long long& tot_val,
@@ -669,7 +718,7 @@ __device__ __forceinline__ void kg_sample(const KgMcParams& P, int e, int sl, co
   for (int k = 0; k < DP; ++k) x[k] = (k < size) ? disc[(long)best_j * size + k] : ((k < P.dim) ? 1.0 : 0.0);
 
   unsigned long long n_val = 0, n_grad = 0;  // passes over the n + u points (the A-point scan is O(A m), not counted)
-  WaveEval<DP, G, SMALL> ev{xs, aw, etab, P.ntiles, P.cov_type, P.mean, P.inv_lp, lane};
+  WaveEval<DP, G, SMALL, XL> ev{xs, aw, etab, P.ntiles, P.cov_type, P.mean, P.inv_lp, P.center_s, lane};
   const double fcur = line_search<DP, G>(P, ev, x, n_val, n_grad);
 
   const long so = (long)e * P.num_local + sl;
@@ -695,9 +744,9 @@ __global__ __launch_bounds__(SMALL ? 1024 : 512) void kg_mc_kernel(KgMcParams P)
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   const int ntiles = P.ntiles;
-  const int tab = ntiles * DP * 64;
+  const int tab = ntiles * (DP + 1) * 64;  // LDS copy: DP centred coordinate rows + the |x|^2 row per tile (see eval_loop)
   const int wslab = ntiles * (1 + G) * 64 + 2 * kMaxM;
-  // LDS: [32] exp table | [tab] coordinates (if XLDS) | per-wave slabs
+  // LDS: [64] exp table | [tab] coordinates (if XLDS) | per-wave slabs
   double* coords = smem + kExpTabLen;
   double* aw = coords + (XLDS ? tab : 0) + wave * wslab;
   double* zb = aw + ntiles * (1 + G) * 64;
@@ -709,7 +758,19 @@ __global__ __launch_bounds__(SMALL ? 1024 : 512) void kg_mc_kernel(KgMcParams P)
     const double* xs = P.XsTab + (long)e * P.tab_stride;
     if (XLDS) {
       __syncthreads();  // previous evaluation's readers are done
-      for (int t = threadIdx.x; t < tab; t += blockDim.x) coords[t] = xs[t];
+      for (int pt = threadIdx.x; pt < ntiles * 64; pt += blockDim.x) {  // one point per thread and step
+        const int tl = pt >> 6, l = pt & 63;
+        const double* src = xs + (long)tl * DP * 64 + l;
+        double* dst = coords + tl * (DP + 1) * 64 + l;
+        double xx = 0.0;
+#pragma unroll
+        for (int k = 0; k < DP; ++k) {
+          const double v = src[k * 64] - P.center_s[k];
+          dst[k * 64] = v;
+          xx = fma(v, v, xx);
+        }
+        dst[DP * 64] = xx;
+      }
       xs = coords;
       __syncthreads();
     }
@@ -723,7 +784,7 @@ __global__ __launch_bounds__(SMALL ? 1024 : 512) void kg_mc_kernel(KgMcParams P)
       const unsigned int sl = (unsigned int)__builtin_amdgcn_readfirstlane((int)ticket);
       if (sl >= (unsigned int)P.num_local) break;
       if (lane == 0) ticket = atomicAdd(next, 1u);
-      kg_sample<DP, G, SMALL>(P, e, (int)sl, xs, aw, zb, smem, lane, tot_val, tot_grad);
+      kg_sample<DP, G, SMALL, XLDS>(P, e, (int)sl, xs, aw, zb, smem, lane, tot_val, tot_grad);
     }
     if (lane == 0 && (tot_val | tot_grad) != 0) {
       atomicAdd(&P.counters[2 * e], tot_val);
@@ -799,8 +860,8 @@ struct BlockEval {
                                              double (&accd)[G > 0 ? G : 1]) {
     // ---- LDS tiles: software-pipelined (next tile requested before the current one is consumed) ----
     if (ntl > 0) {
-      const double* xt = xl;
-      const double* wt = wl;
+      lds_tile_ptr xt = (lds_tile_ptr)xl;  // single ds_read_b64 each (see lds_tile_ptr)
+      lds_tile_ptr wt = (lds_tile_ptr)wl;
       double c0[DP], w0[1 + G];
 #pragma unroll
       for (int k = 0; k < DP; ++k) c0[k] = xt[k * 64];
@@ -836,8 +897,8 @@ struct BlockEval {
   __device__ __forceinline__ void accumulate2(const double (&xa)[DP], const double (&xb)[DP], double& fa, double& fb) {
     double dg[DP], dd[G > 0 ? G : 1];  // unused gradient accumulators of the value-only instantiation
     if (ntl > 0) {
-      const double* xt = xl;
-      const double* wt = wl;
+      lds_tile_ptr xt = (lds_tile_ptr)xl;  // single ds_read_b64 each (see lds_tile_ptr)
+      lds_tile_ptr wt = (lds_tile_ptr)wl;
       double c0[DP], w0[1 + G];
 #pragma unroll
       for (int k = 0; k < DP; ++k) c0[k] = xt[k * 64];
