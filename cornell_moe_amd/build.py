@@ -19,6 +19,7 @@ SOURCES = ["kernels_cov.hip", "kernels_linalg.hip", "host_math.hip", "gp.hip", "
 HEADERS = ["common.hpp", "kernels.hpp", "device_cov.hpp", "fastmath.hpp", "host_math.hpp", "gp.hpp", "kg.hpp", "kg_mc.hpp",
            os.path.join("..", "..", "include", "moe_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function"]
+FLAGS += os.environ.get("MOE_EXTRA_FLAGS", "").split()  # e.g. -DMOE_BLOCK_PROF=1 (tools; rebuild with force)
 
 
 def _hipcc():

@@ -30,8 +30,9 @@ struct GpDev {
   DevBuf<double> dPts, dPtsGrad, dExtra, dE, dVE, dWE, dGram, dEK, dStateIn;
   PinnedBuf<double> hStateIn, hStateOut, hKgIn, hKgOut;  // pinned staging for the per-call operands / results
   // reusable workspaces of the KG evaluator (kg.hip)
-  DevBuf<double> kBlob, kNormals, kTab, kBestPoint, kBestValue, kBeta, kT, kC, kTB, kOut, kSW;
+  DevBuf<double> kBlob, kNormals, kTab, kBestPoint, kBestValue, kBeta, kT, kC, kTB, kOut, kSW, kV;
   DevBuf<unsigned long long> kCounters;
+  DevBuf<int> kBestJ;
   int num_cu = 256;
   // timing of the last KG call (ms): mc, cov-build, tail contraction, state, total
   double last_ms[5] = {0, 0, 0, 0, 0};

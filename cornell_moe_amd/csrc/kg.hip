@@ -580,6 +580,71 @@ int env_int(const char* name, int dflt) {
   return (v && *v) ? std::atoi(v) : dflt;
 }
 
+// z, beta = L^-T z and the discretised-set winner of EVERY sample (they depend on the normal draws alone): one wavefront
+// per sample, grid-stride, the same device functions the MC kernels use -- so the values are the ones they would compute.
+__global__ __launch_bounds__(256) void kg_sample_prep_kernel(KgMcParams P, int* __restrict__ best_j) {
+  __shared__ double zbs[4][2 * kMaxM];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  double* zb = zbs[wave];
+  const long total = (long)P.E * P.num_local;
+  for (long idx = (long)blockIdx.x * 4 + wave; idx < total; idx += (long)gridDim.x * 4) {
+    const int e = (int)(idx / P.num_local), sl = (int)(idx % P.num_local);
+    const double* rec = P.blob + (long)e * P.rec.stride;
+    double zc, bc;
+    mc::draw_z_beta(P, rec + P.rec.L, P.first_sample + sl, lane, zb, zc, bc);
+    const int bj = mc::discrete_scan(P, rec, zb, lane);
+    if (lane < P.m) P.beta[idx * P.m + lane] = bc;
+    if (lane == 0) best_j[idx] = bj;
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+// Per-sample weights of the training rows for every sample, V[(e, sl)][r] = scale_a (KinvY[r] - sum_c W_e[r, c] beta[(e, sl), c])
+// (r = (j, a); scale_0 = alpha, scale_a = -alpha / l_{d_a}): what point_weights computes inside the MC kernel, same
+// operation order, hence the same bits.  Inside the workgroup-per-sample kernel that computation reads all of W_e
+// (N x m) per sample and CU through a few dozen loads in flight -- a sixth of the kernel at m = 16; here one thread keeps
+// a row of W in registers, beta arrives through scalar loads, and the chip writes N x M doubles at streaming speed.
+template <int MB>
+__global__ __launch_bounds__(256) void kg_sample_weights_kernel(KgMcParams P, double* __restrict__ V, int samples_per_block) {
+  const int r = blockIdx.x * 256 + threadIdx.x;
+  const int e = blockIdx.z;
+  const int m = P.m, g1 = 1 + P.g;
+  const double* __restrict__ We = P.W + (long)e * P.w_stride;
+  const double* __restrict__ beta = P.beta;
+  double l[MB];
+  const int rr = min(r, P.N - 1);
+#pragma unroll
+  for (int c = 0; c < MB; ++c) {  // zero beyond m: the unconditional fma below then leaves v untouched
+    const double t = We[rr + (long)min(c, m - 1) * P.N];
+    l[c] = (c < m) ? t : 0.0;
+  }
+  const double kiy = P.KinvY[rr];
+  const int a = rr % g1;
+  const double scale = (a == 0) ? P.alpha : -P.alpha * P.inv_lp[a > 0 ? a - 1 : 0];
+  const int s0 = blockIdx.y * samples_per_block, s1 = min(P.num_local, s0 + samples_per_block);
+  for (int sl = s0; sl < s1; ++sl) {
+    const long so = (long)e * P.num_local + sl;
+    const double* __restrict__ bs = beta + so * m;
+    double v = kiy;
+#pragma unroll
+    for (int c = 0; c < MB; ++c) v = fma(-l[c], bs[c], v);  // uniform, contiguous: wide scalar loads (reads up to MB - m
+                                                            // doubles past the row: next rows / the zeroed pad, times l = 0)
+    if (r < P.N) V[so * P.N + r] = v * scale;
+  }
+}
+
+void launch_sample_weights(const KgMcParams& P, double* V, hipStream_t s) {
+  const int spb = 64;
+  dim3 grid((P.N + 255) / 256, (P.num_local + spb - 1) / spb, P.E);
+  if (P.m <= 16)
+    hipLaunchKernelGGL(kg_sample_weights_kernel<16>, grid, dim3(256), 0, s, P, V, spb);
+  else if (P.m <= 32)
+    hipLaunchKernelGGL(kg_sample_weights_kernel<32>, grid, dim3(256), 0, s, P, V, spb);
+  else
+    hipLaunchKernelGGL(kg_sample_weights_kernel<64>, grid, dim3(256), 0, s, P, V, spb);
+  MOE_HIP_CHECK(hipGetLastError());
+}
+
 void launch_mc(const KgMcParams& P, int dp, int G, bool xlds, int blocks, int waves, size_t shm, hipStream_t s) {
   switch (dp) {
     case 4: launch_kg_mc_dp4(P, G, xlds, blocks, waves, shm, s); break;
@@ -841,9 +906,9 @@ KgPending kg_launch(GpDev& gp, int num_fidelity, const moe_gd_params_t& gd, cons
   dTab.reserve((size_t)tab_stride * E + (size_t)dp * 64);  // + one tile: eval_loop's last prefetch reads past the end
   dBestPoint.reserve((size_t)E * num_local * dp);
   dBestValue.reserve((size_t)E * num_local);
-  dBeta.reserve((size_t)E * num_local * m);
+  dBeta.reserve((size_t)E * num_local * m + 64);  // + a zeroed pad: kg_sample_weights_kernel reads whole 16/32/64-blocks
   // [2 E] pass counters | [E] sample-ticket counters, one 128-byte line each (kTicketStride unsigned ints)
-  const size_t n_ctr = (size_t)2 * E + (size_t)E * (kTicketStride / 2) + 16;
+  const size_t n_ctr = (size_t)2 * E + (size_t)E * (kTicketStride / 2) + 32;  // (+16 alignment slack, +16 profiling words)
   dCounters.reserve(n_ctr);
   const int chunks = (num_local + kTbChunk - 1) / kTbChunk;
   const int out_stride = 1 + m * m + 2 * ngrad;
@@ -917,9 +982,29 @@ KgPending kg_launch(GpDev& gp, int num_fidelity, const moe_gd_params_t& gd, cons
   mp.beta = dBeta.p;
   mp.counters = dCounters.p;
   mp.next_sample = reinterpret_cast<unsigned int*>(dCounters.p + (((size_t)2 * E + 15) / 16) * 16);  // 128-byte aligned
+  mp.prof = dCounters.p + n_ctr - 16;
   auto timers = std::make_shared<std::array<EventTimer, 3>>();
   EventTimer &t_mc = (*timers)[0], &t_cov = (*timers)[1], &t_tail = (*timers)[2];
   t_mc.start(s);
+  mp.best_j = nullptr;
+  mp.V = nullptr;
+  if (variant == 1 && env_int("MOE_KG_PREP", 1) != 0) {
+    gp.kBestJ.reserve((size_t)E * num_local);
+    mp.best_j = gp.kBestJ.p;
+    const long total = (long)E * num_local;
+    const int pb = (int)std::min<long>((total + 3) / 4, (long)num_cu * 8);
+    hipLaunchKernelGGL(kg_sample_prep_kernel, dim3(pb), dim3(256), 0, s, mp, gp.kBestJ.p);
+    MOE_HIP_CHECK(hipGetLastError());
+    // the weight table: N doubles per sample (1.28 GB at C5); beyond MOE_KG_V_MAX_GB (default 24) the samples compute their
+    // weights in the kernel as before
+    const double v_gb = 8.0 * (double)N * (double)total / 1e9;
+    if (v_gb <= (double)env_int("MOE_KG_V_MAX_GB", 24)) {
+      gp.kV.reserve((size_t)N * (size_t)total);
+      MOE_HIP_CHECK(hipMemsetAsync(dBeta.p + (size_t)total * m, 0, sizeof(double) * 64, s));
+      mp.V = gp.kV.p;
+      launch_sample_weights(mp, gp.kV.p, s);
+    }
+  }
   if (variant == 0)
     launch_mc(mp, dp, G, xlds, blocks, waves, shm, s);
   else
@@ -995,6 +1080,10 @@ KgPending kg_launch(GpDev& gp, int num_fidelity, const moe_gd_params_t& gd, cons
   dOut.download(out, n_out, s);
   unsigned long long* counters = reinterpret_cast<unsigned long long*>(gp.hKgOut.p + n_out);
   dCounters.download(counters, (size_t)2 * E, s);
+#if MOE_BLOCK_PROF
+  auto prof_p = std::make_shared<std::vector<unsigned long long>>(16);
+  MOE_HIP_CHECK(hipMemcpyAsync(prof_p->data(), dCounters.p + n_ctr - 16, sizeof(unsigned long long) * 16, hipMemcpyDeviceToHost, s));
+#endif
   const bool fetch_bp = want_best_points && E == 1;
   auto bp_p = std::make_shared<std::vector<double>>();
   if (fetch_bp) {
@@ -1008,6 +1097,23 @@ KgPending kg_launch(GpDev& gp, int num_fidelity, const moe_gd_params_t& gd, cons
     gp.use_device();
     if (stats) std::memset(stats, 0, sizeof(*stats));
     MOE_HIP_CHECK(hipStreamSynchronize(s));
+#if MOE_BLOCK_PROF
+    {
+      const unsigned long long* w = prof_p->data();
+      const double tot = (double)(w[0] + w[1] + w[2] + w[3]);
+      if (tot > 0)
+        std::fprintf(stderr,
+                     "[moe prof] wave-0 cycles: ticket %.1f%%  z/beta/scan %.1f%%  weights %.1f%%  line search %.1f%%;  inside "
+                     "%llu passes: accumulate %.0f  reduce %.0f  barrier %.0f  post %.0f  (cycles per pass; line search total "
+                     "%.0f per pass)\n",
+                     100.0 * w[0] / tot, 100.0 * w[1] / tot, 100.0 * w[2] / tot, 100.0 * w[3] / tot, w[8],
+                     (double)w[4] / w[8], (double)w[5] / w[8], (double)w[6] / w[8], (double)w[7] / w[8], (double)w[3] / w[8]);
+      if (w[10] > 0)
+        std::fprintf(stderr, "[moe prof] gradient passes: %llu, %.0f cycles each (all phases); cycles per SAMPLE: total %.0f, in passes %.0f\n",
+                     w[10], (double)w[9] / w[10], tot / (w[10] / 6.0), (double)(w[4] + w[5] + w[6] + w[7]) / (w[10] / 6.0));
+      std::fprintf(stderr, "[moe prof] per sample: z/beta %.0f, scan %.0f cycles\n", (double)w[11] / (w[10] / 6.0), (double)w[12] / (w[10] / 6.0));
+    }
+#endif
     const std::vector<std::vector<double>>&grad_mu = *grad_mu_p, &Mk = *Mk_p;
     if (best_points && fetch_bp)
       for (int i = 0; i < num_local; ++i)

@@ -27,6 +27,11 @@
 
 namespace moe {
 
+// Phase timing of the workgroup-per-sample kernel (s_memtime cycles summed over samples by wave 0 into counters[...]):
+// build with -DMOE_BLOCK_PROF=1 (tools only; off in the product build).
+#ifndef MOE_BLOCK_PROF
+#define MOE_BLOCK_PROF 0
+#endif
 constexpr int kTicketStride = 32;  // unsigned ints between the sample-ticket counters of consecutive evaluations (128 B)
 constexpr int kMaxM = 64;  // m = (q + p)(1 + g) limit of the MC kernel (z / beta scratch per wave)
 constexpr int kExpTabLen = 64;  // 2^(j/64) table at the start of the MC kernel's LDS (fastmath.hpp exp_nonpos_tab)
@@ -67,6 +72,10 @@ struct KgMcParams {
   double* beta;        // [E][num_local][m]
   unsigned long long* counters;  // [E][2]: value passes, value + gradient passes
   unsigned int* next_sample;     // [E] work counters (zeroed before launch)
+  unsigned long long* prof;      // 16 spare words behind the counters (MOE_BLOCK_PROF builds)
+  const double* V;               // [E][num_local][N] per-sample weights alpha-scaled (kg_sample_weights_kernel, kg.hip), or NULL
+  const int* best_j;             // [E][num_local] start point of every sample's line search, precomputed with beta by
+                                 // kg_sample_prep_kernel (kg.hip); NULL = each sample computes them itself
 };
 
 // Launchers (one translation unit per padded dimension).  `waves` = wavefronts per workgroup, `shm` = dynamic LDS bytes.
@@ -617,12 +626,30 @@ __device__ __forceinline__ void draw_z_beta(const KgMcParams& P, const double* _
   const double sign = (s & 1) ? -1.0 : 1.0;
   zc = 0.0;
   if (lane < m) zc = sign * P.normals[(long)(s >> 1) * m + lane];
+  // Back substitution L^T beta = z, column-oriented: once beta_r is final it is broadcast and every lane l < r folds
+  // L[r][l] beta_r into its running sum -- no wave reduction per step, and row r of L does not depend on the recurrence, so
+  // eight rows are requested at a time (one round trip to L2 per eight steps instead of one per step).
   bc = 0.0;
-  for (int c = m - 1; c >= 0; --c) {
-    double part = 0.0;
-    if (lane > c && lane < m) part = Lsm[lane + c * m] * bc;
-    const double tot = wave_sum(part);
-    if (lane == c) bc = (zc - tot) / Lsm[c + c * m];
+  double acc = 0.0;
+  for (int r0 = m - 1; r0 >= 0; r0 -= 8) {
+    double Lrow[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      // unconditional loads from clamped addresses (a predicated load becomes a branch, and the eight loads would be
+      // waited for one by one); entries of lanes above the diagonal are never used
+      Lrow[i] = Lsm[max(r0 - i, 0) + min(lane, m - 1) * m];
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int r = r0 - i;
+      if (r >= 0) {
+        if (lane == r) bc = (zc - acc) / Lrow[i];
+        const int blo = __builtin_amdgcn_readlane(__double2loint(bc), r);
+        const int bhi = __builtin_amdgcn_readlane(__double2hiint(bc), r);
+        const double br = __hiloint2double(bhi, blo);
+        if (lane < r) acc = fma(Lrow[i], br, acc);
+      }
+    }
   }
   zb[lane] = zc;  // kMaxM == 64 == wavefront size
   zb[kMaxM + lane] = bc;
@@ -642,7 +669,14 @@ __device__ __forceinline__ int discrete_scan(const KgMcParams& P, const double* 
     double fj = -INFINITY;
     if (j < P.A) {
       double v = mu_disc[j];
-      for (int c = 0; c < m; ++c) v = fma(C_disc[(long)j * m + c], zb[c], v);
+      const double* Cj = C_disc + (long)j * m;
+      for (int c0 = 0; c0 < m; c0 += 8) {  // eight loads in flight, folded in the same order as one at a time
+        double cv[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) cv[i] = Cj[min(c0 + i, m - 1)];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v = fma(cv[i], (c0 + i < m) ? zb[min(c0 + i, kMaxM - 1)] : 0.0, v);
+      }
       fj = -v;
     }
     double wmax = fj;
@@ -854,6 +888,14 @@ struct BlockEval {
   const double* inv_lp;
   double mean;
   int nw, wave, lane, cov_type, par;
+#if MOE_BLOCK_PROF
+  unsigned long long c_acc = 0, c_red = 0, c_bar = 0, c_post = 0, c_n = 0, c_gtot = 0, c_gn = 0;
+#define MOE_PROF_T(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
+#define MOE_PROF_ADD(dst, a, b) dst += (b) - (a)
+#else
+#define MOE_PROF_T(var)
+#define MOE_PROF_ADD(dst, a, b)
+#endif
 
   template <bool WG, int COV>
   __device__ __forceinline__ void accumulate(const double (&xq)[DP], double& accf, double (&accg)[DP],
@@ -932,26 +974,39 @@ struct BlockEval {
 
   __device__ __forceinline__ void eval2(const double (&xa)[DP], const double (&xb)[DP], double& fa_out, double& fb_out) {
     double fa = 0.0, fb = 0.0;
+    MOE_PROF_T(t0);
     if (cov_type == MOE_COV_SQUARE_EXPONENTIAL)
       accumulate2<MOE_COV_SQUARE_EXPONENTIAL>(xa, xb, fa, fb);
     else
       accumulate2<MOE_COV_MATERN_NU_2P5>(xa, xb, fa, fb);
+    MOE_PROF_T(t1);
     double* slot = part + (par * kMaxBlockWaves + wave) * kPartLen;
     const double sa = wave_sum_uniform(fa), sb = wave_sum_uniform(fb);
     if (lane == 0) {
       slot[0] = sa;
       slot[1] = sb;
     }
+    MOE_PROF_T(t2);
     __syncthreads();
+    MOE_PROF_T(t3);
     const double* all = part + par * kMaxBlockWaves * kPartLen;
     par ^= 1;
     double ta = 0.0, tb = 0.0;
-    for (int w = 0; w < nw; ++w) {
-      ta += all[w * kPartLen];
-      tb += all[w * kPartLen + 1];
+#pragma unroll
+    for (int w = 0; w < kMaxBlockWaves; ++w) {  // fixed trip count: the eight reads are issued together
+      ta += (w < nw) ? all[w * kPartLen] : 0.0;
+      tb += (w < nw) ? all[w * kPartLen + 1] : 0.0;
     }
     fa_out = -(mean + uniform(ta));
     fb_out = -(mean + uniform(tb));
+    MOE_PROF_T(t4);
+    MOE_PROF_ADD(c_acc, t0, t1);
+    MOE_PROF_ADD(c_red, t1, t2);
+    MOE_PROF_ADD(c_bar, t2, t3);
+    MOE_PROF_ADD(c_post, t3, t4);
+#if MOE_BLOCK_PROF
+    c_n++;
+#endif
   }
 
   template <bool WG>
@@ -961,10 +1016,12 @@ struct BlockEval {
     for (int k = 0; k < DP; ++k) accg[k] = 0.0;
 #pragma unroll
     for (int a = 0; a < (G > 0 ? G : 1); ++a) accd[a] = 0.0;
+    MOE_PROF_T(t0);
     if (cov_type == MOE_COV_SQUARE_EXPONENTIAL)
       accumulate<WG, MOE_COV_SQUARE_EXPONENTIAL>(xq, accf, accg, accd);
     else
       accumulate<WG, MOE_COV_MATERN_NU_2P5>(xq, accf, accg, accd);
+    MOE_PROF_T(t1);
     double* slot = part + (par * kMaxBlockWaves + wave) * kPartLen;
     const double sf = wave_sum_uniform(accf);
     if (lane == 0) slot[0] = sf;
@@ -982,56 +1039,145 @@ struct BlockEval {
         }
       }
     }
+    MOE_PROF_T(t2);
     __syncthreads();
+    MOE_PROF_T(t3);
+    MOE_PROF_ADD(c_acc, t0, t1);
+    MOE_PROF_ADD(c_red, t1, t2);
+    MOE_PROF_ADD(c_bar, t2, t3);
+#if MOE_BLOCK_PROF
+    c_n++;
+#endif
     const double* all = part + par * kMaxBlockWaves * kPartLen;
     par ^= 1;
-    double f = 0.0;
-    for (int w = 0; w < nw; ++w) f += all[w * kPartLen];
+    double f;
     if (WG) {
+      // One component per LANE: lane l sums slot entry l over the waves (eight independent LDS reads, wave order), then the
+      // components come back as wave-uniform values through v_readlane -- instead of (1 + DP + G) x nw dependent
+      // broadcast reads, each a full LDS round trip (12k cycles per gradient pass at DP = 12, G = 3).
+      double comp = 0.0;
+      const int lc = lane < kPartLen ? lane : 0;
+#pragma unroll
+      for (int w = 0; w < kMaxBlockWaves; ++w) comp += (w < nw) ? all[w * kPartLen + lc] : 0.0;
+      auto take = [&](int idx) {
+        const int lo = __builtin_amdgcn_readlane(__double2loint(comp), idx);
+        const int hi = __builtin_amdgcn_readlane(__double2hiint(comp), idx);
+        return __hiloint2double(hi, lo);
+      };
+      f = take(0);
 #pragma unroll
       for (int k = 0; k < DP; ++k) {
-        double v = 0.0;
-        for (int w = 0; w < nw; ++w) v += all[w * kPartLen + 1 + k];
-        if (G > 0 && k < G) {
-          double dsum = 0.0;
-          for (int w = 0; w < nw; ++w) dsum += all[w * kPartLen + 1 + DP + (k < G ? k : 0)];
-          v -= dsum;
-        }
-        grad[k] = -(uniform(v) * inv_lp[k]);
+        double v = take(1 + k);
+        if (G > 0 && k < G) v -= take(1 + DP + (k < G ? k : 0));
+        grad[k] = -(v * inv_lp[k]);
       }
+    } else {
+      f = 0.0;
+#pragma unroll
+      for (int w = 0; w < kMaxBlockWaves; ++w) f += (w < nw) ? all[w * kPartLen] : 0.0;
     }
-    return -(mean + uniform(f));
+    const double fret = -(mean + uniform(f));
+    MOE_PROF_T(t4);
+    MOE_PROF_ADD(c_post, t3, t4);
+#if MOE_BLOCK_PROF
+    if (WG) {
+      c_gtot += t4 - t0;
+      c_gn++;
+    }
+#endif
+    return fret;
   }
 };
 
-// v(j, a) of the weight block for point j (see file header), alpha and the derivative scaling folded in.
+// v(j, a) of the weight block for point j (see file header), alpha and the derivative scaling folded in.  The W loads
+// of 16 columns x (1 + G) rows are issued together (64 independent L2 loads per lane and round at G = 3): issued four at a
+// time this phase took a quarter of the kernel at m = 16 (latency x 64 rounds per wave and sample).
 template <int G>
 __device__ __forceinline__ void point_weights(const KgMcParams& P, const double* __restrict__ We, const double* __restrict__ zb,
                                               int j, double (&w)[1 + G]) {
   const int n = P.n, u = P.u, m = P.m, g1 = 1 + P.g;
+  double v[1 + G];
+#pragma unroll
+  for (int a = 0; a < 1 + G; ++a) v[a] = (a < g1 && j < n) ? P.KinvY[(long)j * g1 + a] : 0.0;
+  if (j < n) {
+    // the 1 + G rows of a point are contiguous in a column of W: with an even row count they are read as 16-byte pairs, so
+    // that a wavefront's load covers each cache line once (row by row, a lane stride of (1 + G) doubles touches every line
+    // 1 + G times and the phase becomes L2 -> CU bandwidth: 4 MB per sample instead of 1 MB at g = 3)
+    typedef double d2 __attribute__((ext_vector_type(2)));
+    const bool pairs = (G & 1) == 1 && g1 == 1 + G && (P.N & 1) == 0 && (reinterpret_cast<size_t>(We) & 15) == 0;
+    for (int c0 = 0; c0 < m; c0 += 16) {
+      double l[1 + G][16];
+      if (pairs) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const d2* src = reinterpret_cast<const d2*>(We + (long)j * g1 + (long)min(c0 + i, m - 1) * P.N);
+#pragma unroll
+          for (int a2 = 0; a2 < (1 + G) / 2; ++a2) {
+            const d2 pr = src[a2];
+            l[2 * a2][i] = pr.x;
+            l[2 * a2 + ((1 + G) > 1 ? 1 : 0)][i] = pr.y;
+          }
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {  // column outer: the rows of one point share their cache lines
+#pragma unroll
+          for (int a = 0; a < 1 + G; ++a)
+            l[a][i] = We[(long)j * g1 + (a < g1 ? a : 0) + (long)min(c0 + i, m - 1) * P.N];
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const double beta = zb[kMaxM + min(c0 + i, kMaxM - 1)];  // 0 beyond m
+#pragma unroll
+        for (int a = 0; a < 1 + G; ++a) v[a] = fma(-l[a][i], beta, v[a]);
+      }
+    }
+  }
 #pragma unroll
   for (int a = 0; a < 1 + G; ++a) {
-    double v = 0.0;
+    double t = 0.0;
     if (a < g1) {
-      if (j < n) {
-        const long row = (long)j * g1 + a;
-        v = P.KinvY[row];
-        for (int c0 = 0; c0 < m; c0 += 4) {
-          const double l0 = We[row + (long)c0 * P.N];
-          const double l1 = We[row + (long)min(c0 + 1, m - 1) * P.N];
-          const double l2 = We[row + (long)min(c0 + 2, m - 1) * P.N];
-          const double l3 = We[row + (long)min(c0 + 3, m - 1) * P.N];
-          v = fma(-l0, zb[kMaxM + c0], v);
-          v = fma(-l1, zb[kMaxM + min(c0 + 1, kMaxM - 1)], v);
-          v = fma(-l2, zb[kMaxM + min(c0 + 2, kMaxM - 1)], v);
-          v = fma(-l3, zb[kMaxM + min(c0 + 3, kMaxM - 1)], v);
-        }
-      } else if (j < n + u) {
-        v = zb[kMaxM + (j - n) * g1 + a];
-      }
-      v *= (a == 0) ? P.alpha : -P.alpha * P.inv_lp[a > 0 ? a - 1 : 0];
+      t = v[a];
+      if (j >= n) t = (j < n + u) ? zb[kMaxM + (j - n) * g1 + a] : 0.0;
+      // fold alpha and, for derivative weights, the -1/l of (x - X)_{d_a} / l^2 = -diff_scaled[a] / l
+      t *= (a == 0) ? P.alpha : -P.alpha * P.inv_lp[a > 0 ? a - 1 : 0];
     }
-    w[a] = v;
+    w[a] = t;
+  }
+}
+
+// The same weights read back from the precomputed table V (kg_sample_weights_kernel): Vs = V + sample * N.  Rows of a
+// point are contiguous, so with an even row count they travel as 16-byte pairs (see point_weights).
+template <int G>
+__device__ __forceinline__ void point_weights_pre(const KgMcParams& P, const double* __restrict__ Vs,
+                                                  const double* __restrict__ zb, int j, double (&w)[1 + G]) {
+  const int n = P.n, u = P.u, g1 = 1 + P.g;
+  typedef double d2 __attribute__((ext_vector_type(2)));
+  const bool pairs = (G & 1) == 1 && g1 == 1 + G && (P.N & 1) == 0 && (reinterpret_cast<size_t>(Vs) & 15) == 0;
+  if (j < n) {
+    if (pairs) {
+      const d2* src = reinterpret_cast<const d2*>(Vs + (long)j * g1);
+#pragma unroll
+      for (int a2 = 0; a2 < (1 + G) / 2; ++a2) {
+        const d2 pr = src[a2];
+        w[2 * a2] = pr.x;
+        w[2 * a2 + ((1 + G) > 1 ? 1 : 0)] = pr.y;
+      }
+    } else {
+#pragma unroll
+      for (int a = 0; a < 1 + G; ++a) w[a] = (a < g1) ? Vs[(long)j * g1 + a] : 0.0;
+    }
+  } else {
+#pragma unroll
+    for (int a = 0; a < 1 + G; ++a) {
+      double t = 0.0;
+      if (a < g1 && j < n + u) {
+        t = zb[kMaxM + (j - n) * g1 + a];
+        t *= (a == 0) ? P.alpha : -P.alpha * P.inv_lp[a > 0 ? a - 1 : 0];
+      }
+      w[a] = t;
+    }
   }
 }
 
@@ -1086,33 +1232,69 @@ __global__ __launch_bounds__(512) void kg_mc_block_kernel(KgMcParams P, int num_
 #pragma unroll
       for (int k = 0; k < DP; ++k) ev.cx[t][k] = (tile < P.ntiles) ? tab[((long)tile * DP + k) * 64 + lane] : 0.0;
     }
+#if MOE_BLOCK_PROF
+    unsigned long long p_tick = 0, p_setup = 0, p_w = 0, p_ls = 0, p_zb = 0, p_scan = 0;
+#endif
     while (true) {
+      MOE_PROF_T(k0);
       if (threadIdx.x == 0) ctl[0] = (int)atomicAdd(&P.next_sample[(long)e * kTicketStride], 1u);
       __syncthreads();
       const int sl = ctl[0];
       if (sl >= P.num_local) break;
       const int s = P.first_sample + sl;
       double zc = 0.0, bc = 0.0;
+      MOE_PROF_T(k1);
       if (wave == 0) {
-        draw_z_beta(P, Lsm, s, lane, zb, zc, bc);
-        const int bj = discrete_scan(P, rec, zb, lane);
-        if (lane == 0) ctl[1] = bj;
+        MOE_PROF_T(k1a0);
+        if (P.best_j != nullptr) {
+          // beta and the discretised-set winner depend on z alone: a pre-pass computed them for every sample with the whole
+          // chip (here they cost one wavefront 10 % of the sample while seven wait at the barrier)
+          const long so0 = (long)e * P.num_local + sl;
+          bc = (lane < m) ? P.beta[so0 * m + lane] : 0.0;
+          zb[kMaxM + lane] = bc;
+          if (lane == 0) ctl[1] = P.best_j[so0];
+        } else {
+          draw_z_beta(P, Lsm, s, lane, zb, zc, bc);
+          const int bj = discrete_scan(P, rec, zb, lane);
+          if (lane == 0) ctl[1] = bj;
+        }
+        MOE_PROF_T(k1a);
+        MOE_PROF_T(k1b);
+        (void)zc;
+        MOE_PROF_ADD(p_zb, k1a0, k1a);
+        MOE_PROF_ADD(p_scan, k1a, k1b);
       }
       __syncthreads();
+      MOE_PROF_T(k2);
       // ---- weights of this wave's points for this sample: LDS tiles into the LDS slab, register tiles into registers ----
       {
         double* wdst = ldsw + (long)tl0 * (1 + G) * 64 + lane;
+        if (P.V != nullptr) {
+          const double* Vs = P.V + ((long)e * P.num_local + sl) * P.N;
+#pragma unroll 2
+          for (int t = tl0; t < tl1; ++t) {
+            double w[1 + G];
+            point_weights_pre<G>(P, Vs, zb, t * 64 + lane, w);
+#pragma unroll
+            for (int a = 0; a < 1 + G; ++a) wdst[a * 64] = w[a];  // read back only by this lane
+            wdst += (1 + G) * 64;
+          }
+#pragma unroll
+          for (int t = 0; t < TR; ++t) point_weights_pre<G>(P, Vs, zb, (TL + wave * TR + t) * 64 + lane, ev.cw[t]);
+        } else {
 #pragma unroll 1
-        for (int t = tl0; t < tl1; ++t) {
-          double w[1 + G];
-          point_weights<G>(P, We, zb, t * 64 + lane, w);
+          for (int t = tl0; t < tl1; ++t) {
+            double w[1 + G];
+            point_weights<G>(P, We, zb, t * 64 + lane, w);
 #pragma unroll
-          for (int a = 0; a < 1 + G; ++a) wdst[a * 64] = w[a];  // read back only by this lane
-          wdst += (1 + G) * 64;
+            for (int a = 0; a < 1 + G; ++a) wdst[a * 64] = w[a];  // read back only by this lane
+            wdst += (1 + G) * 64;
+          }
+#pragma unroll
+          for (int t = 0; t < TR; ++t) point_weights<G>(P, We, zb, (TL + wave * TR + t) * 64 + lane, ev.cw[t]);
         }
-#pragma unroll
-        for (int t = 0; t < TR; ++t) point_weights<G>(P, We, zb, (TL + wave * TR + t) * 64 + lane, ev.cw[t]);
       }
+      MOE_PROF_T(k3);
       const int best_j = ctl[1];
       const double* disc = rec + P.rec.disc;
       double x[DP];
@@ -1120,6 +1302,11 @@ __global__ __launch_bounds__(512) void kg_mc_block_kernel(KgMcParams P, int num_
       for (int k = 0; k < DP; ++k) x[k] = (k < size) ? disc[(long)best_j * size + k] : ((k < P.dim) ? 1.0 : 0.0);
       unsigned long long n_val = 0, n_grad = 0;
       const double fcur = line_search_lds<DP, G>(P, ev, stw, x, n_val, n_grad);
+      MOE_PROF_T(k4);
+      MOE_PROF_ADD(p_tick, k0, k1);
+      MOE_PROF_ADD(p_setup, k1, k2);
+      MOE_PROF_ADD(p_w, k2, k3);
+      MOE_PROF_ADD(p_ls, k3, k4);
       if (wave == 0) {
         const long so = (long)e * P.num_local + sl;
         if (lane == 0) {
@@ -1137,6 +1324,23 @@ __global__ __launch_bounds__(512) void kg_mc_block_kernel(KgMcParams P, int num_
         if (lane < m) P.beta[so * m + lane] = bc;
       }
     }
+#if MOE_BLOCK_PROF
+    if (threadIdx.x == 0) {  // wave 0's view: [0..3] ticket, z/beta/scan, weights, line search; [4..8] inside the passes
+      atomicAdd(&P.prof[0], p_tick);
+      atomicAdd(&P.prof[1], p_setup);
+      atomicAdd(&P.prof[2], p_w);
+      atomicAdd(&P.prof[3], p_ls);
+      atomicAdd(&P.prof[4], ev.c_acc);
+      atomicAdd(&P.prof[5], ev.c_red);
+      atomicAdd(&P.prof[6], ev.c_bar);
+      atomicAdd(&P.prof[7], ev.c_post);
+      atomicAdd(&P.prof[8], ev.c_n);
+      atomicAdd(&P.prof[9], ev.c_gtot);
+      atomicAdd(&P.prof[10], ev.c_gn);
+      atomicAdd(&P.prof[11], p_zb);
+      atomicAdd(&P.prof[12], p_scan);
+    }
+#endif
     if (gridDim.x >= (unsigned)P.E) break;
   }
 }
