@@ -51,9 +51,12 @@ __device__ __forceinline__ double block_sum_256(double v, double* red) {
 struct TabParams {
   int perm[kMaxDimPadded];
   double inv_lp[kMaxDimPadded];
+  double center[kMaxDimPadded];  // training-set mean per table row (unscaled)
 };
 
-// XsTab[e][tile][r][lane] = coordinate perm[r] of point (tile*64 + lane) of evaluation e, divided by its length scale:
+// XsTab[e][tile][r][lane] = coordinate perm[r] of point (tile*64 + lane) of evaluation e, minus the training-set mean of that
+// coordinate, divided by its length scale (centred first: the difference of two nearby numbers is exact, so the scaled
+// coordinates carry the precision of the distances however far from the origin the domain sits):
 // the n training points, then the u union points of that evaluation, zero beyond.
 __global__ void build_xs_tab_kernel(const double* __restrict__ X, int n, const double* __restrict__ XuAll, int u, int dp,
                                     int ntiles, TabParams tp, double* __restrict__ tab, long tab_stride) {
@@ -63,12 +66,12 @@ __global__ void build_xs_tab_kernel(const double* __restrict__ X, int n, const d
   const int l = idx & 63, r = (idx >> 6) % dp, t = (idx >> 6) / dp;
   const int j = t * 64 + l;
   const int k = tp.perm[r];
-  double v = 0.0;
+  double v = tp.center[r];  // padded points sit at the centre (zero weight; a far-away pad would only stress the exp)
   if (j < n)
     v = X[(long)j * dp + k];
   else if (j < n + u)
     v = XuAll[((long)e * u + (j - n)) * dp + k];
-  tab[(long)e * tab_stride + idx] = v * tp.inv_lp[r];
+  tab[(long)e * tab_stride + idx] = (v - tp.center[r]) * tp.inv_lp[r];
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -795,6 +798,25 @@ KgPending kg_launch(GpDev& gp, int num_fidelity, const moe_gd_params_t& gd, cons
     for (int r = 0; r < kMaxDimPadded; ++r) {
       tp.perm[r] = order[r];
       tp.inv_lp[r] = gp.cp.inv_l[order[r]];
+      double c = 0.0;  // training-set mean of the row's coordinate (0 for pad rows)
+      if (order[r] < d) {
+        for (int j = 0; j < n; ++j) c += gp.X[(size_t)j * d + order[r]];
+        c /= n;
+      }
+      tp.center[r] = c;
+      // the MC kernels' exponent arithmetic covers |x - c| / l up to kTableExtent for every tabulated point
+      if (order[r] < d) {
+        const int k = order[r];
+        double ext = 0.0;
+        for (int j = 0; j < n; ++j) ext = std::max(ext, std::fabs(gp.X[(size_t)j * d + k] - c));
+        for (int e = 0; e < E; ++e) {
+          for (int i = 0; i < q; ++i) ext = std::max(ext, std::fabs(Xq_all[((size_t)e * q + i) * d + k] - c));
+        }
+        for (int i = 0; i < p; ++i) ext = std::max(ext, std::fabs(Xp[(size_t)i * d + k] - c));
+        if (!(ext * tp.inv_lp[r] <= mc::kTableExtent))
+          throw Error(MOE_ERR_BOUNDS, "length scale too small for the extent of the points (|x - mean| / length > 1e5)",
+                      ext * tp.inv_lp[r], 0.0, mc::kTableExtent);
+      }
     }
   }
   // ---- host m x m algebra per evaluation -> one blob ----
@@ -941,13 +963,7 @@ KgPending kg_launch(GpDev& gp, int num_fidelity, const moe_gd_params_t& gd, cons
   for (int r = 0; r < kMaxDimPadded; ++r) {
     mp.inv_lp[r] = tp.inv_lp[r];
     mp.perm[r] = tp.perm[r];
-    // frame of the MC kernel's LDS coordinate table: centred on the training-set mean
-    double c = 0.0;
-    if (r < d) {
-      for (int j = 0; j < n; ++j) c += gp.X[(size_t)j * d + tp.perm[r]];
-      c /= n;
-    }
-    mp.center_s[r] = c * tp.inv_lp[r];
+    mp.center[r] = tp.center[r];
   }
   mp.n = n;
   mp.g = g;

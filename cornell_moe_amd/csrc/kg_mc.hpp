@@ -49,7 +49,8 @@ struct KgRec {  // offsets (doubles) of one evaluation's small operands inside t
 struct KgMcParams {
   int cov_type, dim;
   double alpha;
-  double center_s[kMaxDimPadded];  // training-set mean of table row r's coordinate, scaled by inv_lp (frame of the LDS table)
+  double center[kMaxDimPadded];  // training-set mean of table row r's coordinate: the tables and the queries are centred on it
+                                 // BEFORE scaling ((x - c) / l is exact to rounding wherever the domain sits)
   double inv_lp[kMaxDimPadded];  // 1 / length of table row r (row r holds original dimension perm[r]); 0 in pad rows
   int perm[kMaxDimPadded];       // the GP's observed-derivative dimensions come first: perm[a] = derivatives[a], a < g
   int n, g, N, u, m, f, A, ntiles, E;
@@ -141,6 +142,16 @@ __device__ __forceinline__ double uniform(double v) {
   return __hiloint2double(hi, lo);
 }
 
+// A coordinate in the frame of the tables: centred, scaled, and clamped at +-kQueryClamp length scales.  Armijo trial points
+// are not limited to the domain and can land anywhere; beyond 1e6 length scales from the centre every covariance with a
+// training point (all within kTableExtent = 1e5 of it, validated on the host) is exactly 0 either way, and the clamp keeps
+// sqrt(5 r2) * 64 / ln2 inside the 32-bit exponent arithmetic of exp_nonpos_tab at no cost in the tile loop.
+constexpr double kQueryClamp = 1.0e6;
+constexpr double kTableExtent = 1.0e5;
+__device__ __forceinline__ double to_frame(const KgMcParams& P, double v, int r) {
+  return fmin(fmax((v - P.center[r]) * P.inv_lp[r], -kQueryClamp), kQueryClamp);
+}
+
 // Radial scalars divided by alpha (alpha is folded into the weights): base = cov[0,0], first = first-derivative
 // coefficient, second = Hessian-product coefficient (device_cov.hpp).
 template <int COV, bool NEED_FIRST, bool NEED_SECOND>
@@ -148,7 +159,7 @@ __device__ __forceinline__ void radial3(double r2, const double* __restrict__ et
                                         double& second) {
   // r2 >= 1e-300 by construction (the distance accumulation starts from 1e-300, see eval_loop)
   if (COV == MOE_COV_SQUARE_EXPONENTIAL) {
-    base = exp_nonpos_tab(-0.5 * r2, etab);
+    base = exp_nonpos_tab(fmax(-0.5 * r2, -1000.0), etab);  // (r2 can reach 1e13 here: keep the table exp in range)
     first = base;
     second = base;
   } else {
@@ -181,23 +192,20 @@ struct tile_ptr<true> {
 // With the table in LDS (XL) every tile carries one more row, |x_j - c|^2 of the centred scaled coordinates, and the value
 // passes -- nine in ten of all passes -- get the squared distance as |x_j|^2 + |q|^2 - 2 x_j . q: DP FMAs, one add and one
 // max per point instead of DP subtractions + DP FMAs (6 of 43 VALU instructions per point at DP = 8).  The coordinates
-// are centred on the training-set mean (`cs`, scaled, table-row order) so that the three terms are of the size of the
-// distance itself wherever the domain sits: the rounding error of r2 stays within a small multiple of the direct form's
+// and the queries are centred on the training-set mean before they are scaled (KgMcParams::center) so that the three terms
+// are of the size of the distance itself wherever the domain sits: the rounding error of r2 stays within a small multiple of the direct form's
 // (absolute ~1e-15 at unit-box scales; the kernel is smooth at r = 0, so close pairs lose nothing).  Gradient passes keep
 // the direct differences (they need them anyway).
 template <int DP, int G, bool WG, int COV, bool SMALL, bool XL>
 __device__ __forceinline__ double eval_loop(const double* __restrict__ xs, const double* __restrict__ aw,
                                             const double* __restrict__ etab, int ntiles, double mean,
-                                            const double (&xq_in)[DP], const double* inv_lp, const double* cs,
-                                            double (&grad)[DP], int lane) {
+                                            const double (&xq)[DP], const double* inv_lp, double (&grad)[DP], int lane) {
   constexpr bool DOT = XL && !WG;      // squared distance from the |x|^2 row
   constexpr int XR = DP + (XL ? 1 : 0);  // rows per coordinate tile
-  double xq[DP];                        // query in the table's frame (centred when the table is)
   double q2[DP];
   double qq = 1.0e-300;
 #pragma unroll
   for (int k = 0; k < DP; ++k) {
-    xq[k] = XL ? xq_in[k] - cs[k] : xq_in[k];
     q2[k] = -2.0 * xq[k];
     qq = fma(xq[k], xq[k], qq);
   }
@@ -291,11 +299,10 @@ __device__ __forceinline__ double eval_loop(const double* __restrict__ xs, const
 template <int DP, int G, bool WG, bool SMALL, bool XL>
 __device__ __forceinline__ double eval_pass(const double* __restrict__ xs, const double* __restrict__ aw,
                                             const double* __restrict__ etab, int ntiles, int cov_type, double mean,
-                                            const double (&xq)[DP], const double* inv_lp, const double* cs,
-                                            double (&grad)[DP], int lane) {
+                                            const double (&xq)[DP], const double* inv_lp, double (&grad)[DP], int lane) {
   if (cov_type == MOE_COV_SQUARE_EXPONENTIAL)
-    return eval_loop<DP, G, WG, MOE_COV_SQUARE_EXPONENTIAL, SMALL, XL>(xs, aw, etab, ntiles, mean, xq, inv_lp, cs, grad, lane);
-  return eval_loop<DP, G, WG, MOE_COV_MATERN_NU_2P5, SMALL, XL>(xs, aw, etab, ntiles, mean, xq, inv_lp, cs, grad, lane);
+    return eval_loop<DP, G, WG, MOE_COV_SQUARE_EXPONENTIAL, SMALL, XL>(xs, aw, etab, ntiles, mean, xq, inv_lp, grad, lane);
+  return eval_loop<DP, G, WG, MOE_COV_MATERN_NU_2P5, SMALL, XL>(xs, aw, etab, ntiles, mean, xq, inv_lp, grad, lane);
 }
 
 // TensorProductDomain::LimitUpdate (gpp_domain.cpp:64-105) on one coordinate.
@@ -370,11 +377,10 @@ struct WaveEval {
   int ntiles, cov_type;
   double mean;
   const double* inv_lp;
-  const double* cs;  // scaled centre of the LDS table's frame (table-row order)
   int lane;
   template <bool WG>
   __device__ __forceinline__ double eval(const double (&xq)[DP], double (&grad)[DP]) {
-    return eval_pass<DP, G, WG, SMALL, XL>(xs, aw, etab, ntiles, cov_type, mean, xq, inv_lp, cs, grad, lane);
+    return eval_pass<DP, G, WG, SMALL, XL>(xs, aw, etab, ntiles, cov_type, mean, xq, inv_lp, grad, lane);
   }
 };
 
@@ -415,7 +421,7 @@ __device__ __forceinline__ double line_search(const KgMcParams& P, EV& ev, doubl
       for (int istep = 0; istep < P.max_num_steps;) {
         // ---- f(x), grad f(x) ----
         #pragma unroll
-        for (int r = 0; r < DP; ++r) tqp[r] = x[r] * P.inv_lp[r];
+        for (int r = 0; r < DP; ++r) tqp[r] = to_frame(P, x[r], r);
         const double f0 = ev.template eval<true>(tqp, gp);
         n_grad++;
         fcur = f0;
@@ -434,7 +440,7 @@ __device__ __forceinline__ double line_search(const KgMcParams& P, EV& ev, doubl
 #pragma unroll
           for (int k = 0; k < DP; ++k) tq[k] = fma(alpha_n, grad[k], x[k]);
 #pragma unroll
-          for (int r = 0; r < DP; ++r) tqp[r] = tq[r] * P.inv_lp[r];
+          for (int r = 0; r < DP; ++r) tqp[r] = to_frame(P, tq[r], r);
           ftrial = ev.template eval<false>(tqp, gp);
           n_val++;
           if (ftrial - f0 > 0.5 * alpha_n * norm) break;
@@ -471,7 +477,7 @@ __device__ __forceinline__ double line_search(const KgMcParams& P, EV& ev, doubl
 #pragma unroll
           for (int k = 0; k < DP; ++k) tq[k] = x[k] + step[k];
 #pragma unroll
-          for (int r = 0; r < DP; ++r) tqp[r] = tq[r] * P.inv_lp[r];
+          for (int r = 0; r < DP; ++r) tqp[r] = to_frame(P, tq[r], r);
           obj2 = ev.template eval<false>(tqp, gp);
           n_val++;
         }
@@ -533,7 +539,7 @@ __device__ __forceinline__ double line_search_lds(const KgMcParams& P, EV& ev, d
     for (int k = 0; k < DP; ++k) sX0[k] = sX[k];
     for (int istep = 0; istep < P.max_num_steps;) {
 #pragma unroll
-      for (int r = 0; r < DP; ++r) tqp[r] = sX[r] * P.inv_lp[r];
+      for (int r = 0; r < DP; ++r) tqp[r] = to_frame(P, sX[r], r);
       const double f0 = ev.template eval<true>(tqp, gp);
       n_grad++;
       fcur = f0;
@@ -556,8 +562,8 @@ __device__ __forceinline__ double line_search_lds(const KgMcParams& P, EV& ev, d
         double tqb[DP], f1, f2;
 #pragma unroll
         for (int r = 0; r < DP; ++r) {
-          tqp[r] = fma(a1, sG[r], sX[r]) * P.inv_lp[r];
-          tqb[r] = fma(a2, sG[r], sX[r]) * P.inv_lp[r];
+          tqp[r] = to_frame(P, fma(a1, sG[r], sX[r]), r);
+          tqb[r] = to_frame(P, fma(a2, sG[r], sX[r]), r);
         }
         ev.eval2(tqp, tqb, f1, f2);
         ftrial = f1;
@@ -588,7 +594,7 @@ __device__ __forceinline__ double line_search_lds(const KgMcParams& P, EV& ev, d
       double obj2 = ftrial;
       if (changed) {
 #pragma unroll
-        for (int r = 0; r < DP; ++r) tqp[r] = (sX[r] + sS[r]) * P.inv_lp[r];
+        for (int r = 0; r < DP; ++r) tqp[r] = to_frame(P, sX[r] + sS[r], r);
         obj2 = ev.template eval<false>(tqp, gp);
         n_val++;
       }
@@ -752,7 +758,7 @@ __device__ __forceinline__ void kg_sample(const KgMcParams& P, int e, int sl, co
   for (int k = 0; k < DP; ++k) x[k] = (k < size) ? disc[(long)best_j * size + k] : ((k < P.dim) ? 1.0 : 0.0);
 
   unsigned long long n_val = 0, n_grad = 0;  // passes over the n + u points (the A-point scan is O(A m), not counted)
-  WaveEval<DP, G, SMALL, XL> ev{xs, aw, etab, P.ntiles, P.cov_type, P.mean, P.inv_lp, P.center_s, lane};
+  WaveEval<DP, G, SMALL, XL> ev{xs, aw, etab, P.ntiles, P.cov_type, P.mean, P.inv_lp, lane};
   const double fcur = line_search<DP, G>(P, ev, x, n_val, n_grad);
 
   const long so = (long)e * P.num_local + sl;
@@ -778,7 +784,7 @@ __global__ __launch_bounds__(SMALL ? 1024 : 512) void kg_mc_kernel(KgMcParams P)
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   const int ntiles = P.ntiles;
-  const int tab = ntiles * (DP + 1) * 64;  // LDS copy: DP centred coordinate rows + the |x|^2 row per tile (see eval_loop)
+  const int tab = ntiles * (DP + 1) * 64;  // LDS copy: the DP coordinate rows + the |x|^2 row per tile (see eval_loop)
   const int wslab = ntiles * (1 + G) * 64 + 2 * kMaxM;
   // LDS: [64] exp table | [tab] coordinates (if XLDS) | per-wave slabs
   double* coords = smem + kExpTabLen;
@@ -799,7 +805,7 @@ __global__ __launch_bounds__(SMALL ? 1024 : 512) void kg_mc_kernel(KgMcParams P)
         double xx = 0.0;
 #pragma unroll
         for (int k = 0; k < DP; ++k) {
-          const double v = src[k * 64] - P.center_s[k];
+          const double v = src[k * 64];
           dst[k * 64] = v;
           xx = fma(v, v, xx);
         }

@@ -182,6 +182,34 @@ def test_fused_tail_matches_materialised_tail(monkeypatch):
         assert np.abs(a["grad_sum"] - b["grad_sum"]).max() <= 1e-11 * scale
 
 
+def test_offset_and_rescaled_domain():
+    """The MC kernel takes squared distances as |x|^2 + |q|^2 - 2 x.q in a frame centred on the training-set mean: a domain far
+    from the origin (x in [1000, 1001] and [-50, -40]) and anisotropic scales must not cost accuracy against the oracle,
+    which works on the coordinates as given."""
+    from cornell_moe_amd import api
+    from cornell_moe_amd.workloads import make_workload
+    from oracle import orc
+    gd = (1, 6, 1, 3, 0.0, 1.0, 0.1, 1e-10)
+    for n, d, q, M, derivs in ((600, 8, 4, 60, ()), (150, 6, 2, 40, (1, 4))):
+        w = make_workload(seed=321 + n, n=n, d=d, q=q, M=M, P=8, derivs=derivs)
+        shift = np.array([1000.0, -50.0, 0.0, 3.0e4, 10.0, -1.0, 100.0, 7.0])[:d]
+        scale = np.array([1.0, 10.0, 0.1, 1.0, 100.0, 1.0, 0.01, 1.0])[:d]
+        X, Xq, disc = (shift + scale * a for a in (w.X, w.Xq, w.discrete))
+        lengths = w.lengths * scale
+        bounds = np.column_stack([shift, shift + scale]).reshape(-1)
+        O = orc.OrcGP(1, w.alpha, lengths, X, w.y, w.noise, derivs)
+        G = api.DeviceGP(np.r_[w.alpha, lengths], X, w.y, w.noise, derivs)
+        best = float(O.additional_mean(disc).min())
+        ro = O.kg(gd, bounds, disc, Xq, None, M, best, w.kg_normals)
+        gscale = np.abs(ro["grad"] * scale).max()  # gradients carry 1 / scale per dimension
+        rg = G.kg(gd, bounds, disc, Xq, None, M, best, w.kg_normals, want_best_points=True)
+        assert abs(rg["kg"] - ro["kg"]) <= TOL["kg"] * max(abs(ro["kg"]), 1e-6)
+        assert np.abs((rg["grad"] - ro["grad"]) * scale).max() <= TOL["grad_kg"] * max(gscale, abs(ro["kg"]), 1e-6)
+        assert rg["grad_evals"] == ro["grad_evals"]
+        mism = np.abs((rg["best_point"] - ro["best_point"]) / scale).max(axis=1) > 1e-8
+        assert mism.mean() <= 0.02
+
+
 def test_randomised_parity_fuzz():
     """tools/fuzz_parity.py: 60 random shapes / kernels / derivative sets / fidelity dimensions / optimiser settings, q-KG (both
     MC kernels) and q-EI against the oracle -- no violation of the stated tolerances."""
