@@ -362,7 +362,7 @@ constexpr int kFusedTile = 256;  // points (kernel A) / samples (kernel B) stage
 
 template <int COV>
 __device__ __forceinline__ double radial_base(double r2, const double* __restrict__ etab) {
-  if (COV == MOE_COV_SQUARE_EXPONENTIAL) return exp_nonpos_tab(-0.5 * r2, etab);
+  if (COV == MOE_COV_SQUARE_EXPONENTIAL) return exp_nonpos_tab(fmax(-0.5 * r2, -1000.0), etab);  // (table exp range)
   const double a = 2.236067977499789696409173668731276235 * sqrt_pos(r2);
   return exp_nonpos_tab(-a, etab) * fma(a, fma(a, 1.0 / 3.0, 1.0), 1.0);
 }

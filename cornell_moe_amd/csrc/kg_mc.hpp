@@ -142,14 +142,27 @@ __device__ __forceinline__ double uniform(double v) {
   return __hiloint2double(hi, lo);
 }
 
-// A coordinate in the frame of the tables: centred, scaled, and clamped at +-kQueryClamp length scales.  Armijo trial points
-// are not limited to the domain and can land anywhere; beyond 1e6 length scales from the centre every covariance with a
-// training point (all within kTableExtent = 1e5 of it, validated on the host) is exactly 0 either way, and the clamp keeps
-// sqrt(5 r2) * 64 / ln2 inside the 32-bit exponent arithmetic of exp_nonpos_tab at no cost in the tile loop.
-constexpr double kQueryClamp = 1.0e6;
+// A coordinate in the frame of the tables: centred, then scaled.
+__device__ __forceinline__ double to_frame(const KgMcParams& P, double v, int r) { return (v - P.center[r]) * P.inv_lp[r]; }
+
+// Armijo trial points are not limited to the domain and, with small length scales (step ~ gradient ~ 1 / length), land
+// millions of length scales away, where sqrt(5 r2) * 64 / ln2 leaves the 32-bit exponent arithmetic of exp_nonpos_tab.
+// Every tabulated point lies within kTableExtent = 1e5 length scales of the centre per coordinate (validated on the host),
+// so a query beyond kFarRadius from the centre has covariance exactly 0 with all of them: the wave-per-sample kernel skips
+// such a pass (eval_loop), the workgroup-per-sample kernel pulls the query back to kQueryClamp per coordinate (same zeros).
+// One wave-uniform test per pass either way.
 constexpr double kTableExtent = 1.0e5;
-__device__ __forceinline__ double to_frame(const KgMcParams& P, double v, int r) {
-  return fmin(fmax((v - P.center[r]) * P.inv_lp[r], -kQueryClamp), kQueryClamp);
+constexpr double kFarRadius = 4.0e5 + 400.0;  // sqrt(kMaxDimPadded) * kTableExtent + 400
+constexpr double kQueryClamp = 1.0e6;
+template <int DP>
+__device__ __forceinline__ void clamp_query(double (&xq)[DP]) {
+  double qq = 0.0;
+#pragma unroll
+  for (int k = 0; k < DP; ++k) qq = fma(xq[k], xq[k], qq);
+  if (!(uniform(qq) <= kQueryClamp * kQueryClamp)) {
+#pragma unroll
+    for (int k = 0; k < DP; ++k) xq[k] = fmin(fmax(xq[k], -kQueryClamp), kQueryClamp);
+  }
 }
 
 // Radial scalars divided by alpha (alpha is folded into the weights): base = cov[0,0], first = first-derivative
@@ -202,13 +215,16 @@ __device__ __forceinline__ double eval_loop(const double* __restrict__ xs, const
                                             const double (&xq)[DP], const double* inv_lp, double (&grad)[DP], int lane) {
   constexpr bool DOT = XL && !WG;      // squared distance from the |x|^2 row
   constexpr int XR = DP + (XL ? 1 : 0);  // rows per coordinate tile
-  double q2[DP];
   double qq = 1.0e-300;
 #pragma unroll
-  for (int k = 0; k < DP; ++k) {
-    q2[k] = -2.0 * xq[k];
-    qq = fma(xq[k], xq[k], qq);
-  }
+  for (int k = 0; k < DP; ++k) qq = fma(xq[k], xq[k], qq);
+  // A trial point more than kFarRadius length scales from the centre is > 400 length scales from every tabulated point
+  // (all inside the ball of radius sqrt(16) * kTableExtent): every covariance underflows to exactly 0 and the posterior mean
+  // IS the prior mean -- the pass is skipped.  Closer than that, sqrt(5 r2) * 64 / ln2 < 2^31: exp_nonpos_tab is in range.
+  if (!WG && !(qq <= kFarRadius * kFarRadius)) return -mean;
+  double q2[DP];
+#pragma unroll
+  for (int k = 0; k < DP; ++k) q2[k] = -2.0 * xq[k];
   double accf = 0.0;
   double accg[DP];
   double accd[G > 0 ? G : 1];
@@ -978,8 +994,16 @@ struct BlockEval {
     }
   }
 
-  __device__ __forceinline__ void eval2(const double (&xa)[DP], const double (&xb)[DP], double& fa_out, double& fb_out) {
+  __device__ __forceinline__ void eval2(const double (&xa_in)[DP], const double (&xb_in)[DP], double& fa_out, double& fb_out) {
     double fa = 0.0, fb = 0.0;
+    double xa[DP], xb[DP];
+#pragma unroll
+    for (int k = 0; k < DP; ++k) {
+      xa[k] = xa_in[k];
+      xb[k] = xb_in[k];
+    }
+    clamp_query<DP>(xa);
+    clamp_query<DP>(xb);
     MOE_PROF_T(t0);
     if (cov_type == MOE_COV_SQUARE_EXPONENTIAL)
       accumulate2<MOE_COV_SQUARE_EXPONENTIAL>(xa, xb, fa, fb);
@@ -1016,8 +1040,12 @@ struct BlockEval {
   }
 
   template <bool WG>
-  __device__ __forceinline__ double eval(const double (&xq)[DP], double (&grad)[DP]) {
+  __device__ __forceinline__ double eval(const double (&xq_in)[DP], double (&grad)[DP]) {
     double accf = 0.0, accg[DP], accd[G > 0 ? G : 1];
+    double xq[DP];
+#pragma unroll
+    for (int k = 0; k < DP; ++k) xq[k] = xq_in[k];
+    clamp_query<DP>(xq);
 #pragma unroll
     for (int k = 0; k < DP; ++k) accg[k] = 0.0;
 #pragma unroll

@@ -2,6 +2,8 @@
 plain-C oracle on the same normal table -- fidelity dimensions, points being sampled, tile-boundary point counts, odd MC
 counts, both kernels, derivative observations on arbitrary dimensions, both MC kernel variants, many evaluations per
 batch, gamma != 0, several restarts of the inner optimiser, MC shards."""
+import os
+
 import numpy as np
 import pytest
 
@@ -208,6 +210,39 @@ def test_offset_and_rescaled_domain():
         assert rg["grad_evals"] == ro["grad_evals"]
         mism = np.abs((rg["best_point"] - ro["best_point"]) / scale).max(axis=1) > 1e-8
         assert mism.mean() <= 0.02
+
+
+@pytest.mark.parametrize("cov", [0, 1])
+def test_tiny_length_scales(cov):
+    """Length scales of 1/500 of the domain: squared distances reach 1e6 length scales^2 and Armijo trial points (unclamped,
+    step ~ gradient ~ 1 / length) land thousands of length scales outside the domain -- the table exp's 32-bit exponent
+    arithmetic must not wrap (it did for the squared exponential: 0 weight x inf = NaN).  Beyond 1e5 length scales of
+    extent the call is refused."""
+    from cornell_moe_amd import api
+    from cornell_moe_amd.workloads import make_workload
+    from oracle import orc
+    gd = (1, 6, 1, 3, 0.0, 1.0, 0.1, 1e-10)
+    w = make_workload(seed=909 + cov, n=120, d=3, q=2, M=40, P=6)
+    lengths = np.array([2e-3, 0.7, 5e-3])
+    O = orc.OrcGP(cov, w.alpha, lengths, w.X, w.y, w.noise, ())
+    G = api.DeviceGP(np.r_[w.alpha, lengths], w.X, w.y, w.noise, (), cov_type=cov)
+    best = float(O.additional_mean(w.discrete).min())
+    ro = O.kg(gd, w.bounds, w.discrete, w.Xq, None, w.M, best, w.kg_normals)
+    for variant in ("0", "1"):
+        os.environ["MOE_KG_VARIANT"] = variant
+        try:
+            rg = G.kg(gd, w.bounds, w.discrete, w.Xq, None, w.M, best, w.kg_normals)
+        finally:
+            os.environ.pop("MOE_KG_VARIANT", None)
+        assert np.isfinite(rg["kg"]) and np.all(np.isfinite(rg["grad"]))
+        assert abs(rg["kg"] - ro["kg"]) <= TOL["kg"] * max(abs(ro["kg"]), 1e-6)
+        # gradients carry 1 / length, and at these scales an x* moved by 1e-10 moves them by 10 %: the reference and its
+        # restatement differ by 4e-7 / 1.6e-7 (relative to KG) on this very case, so the bound here is 1e-6
+        gscale = max(np.abs(ro["grad"] * lengths).max(), abs(ro["kg"]), 1e-6)
+        assert np.abs((rg["grad"] - ro["grad"]) * lengths).max() <= 1e-6 * gscale
+    bad = api.DeviceGP(np.r_[w.alpha, [1e-7, 0.7, 0.7]], w.X, w.y, w.noise, (), cov_type=cov)
+    with pytest.raises(api.BoundsException):
+        bad.kg(gd, w.bounds, w.discrete, w.Xq, None, w.M, 0.0, w.kg_normals)
 
 
 def test_randomised_parity_fuzz():
