@@ -279,6 +279,17 @@ def test_workgroup_per_sample_kernel_matches_wave_per_sample(api, monkeypatch):
         a = G.kg(*args, want_best_points=True)
         monkeypatch.setenv("MOE_KG_VARIANT", "1")
         b = G.kg(*args, want_best_points=True)
+        # the workgroup-per-sample kernel takes beta / the discretised-set winner from a pre-pass and its weights from a
+        # streamed table; computing them inside the kernel (the fall-back for tables that do not fit) gives the same bits
+        monkeypatch.setenv("MOE_KG_PREP", "0")
+        c = G.kg(*args, want_best_points=True)
+        monkeypatch.delenv("MOE_KG_PREP")
+        monkeypatch.setenv("MOE_KG_V_MAX_GB", "0")
+        c2 = G.kg(*args, want_best_points=True)
+        monkeypatch.delenv("MOE_KG_V_MAX_GB")
+        for other in (c, c2):
+            assert other["kg_sum"] == b["kg_sum"] and np.array_equal(other["grad_sum"], b["grad_sum"])
+            assert np.array_equal(other["best_point"], b["best_point"])
         monkeypatch.delenv("MOE_KG_VARIANT")
         scale = max(np.abs(a["grad"]).max(), abs(a["kg"]))
         assert abs(a["kg"] - b["kg"]) <= 1e-10 * abs(a["kg"])
