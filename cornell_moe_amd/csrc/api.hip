@@ -58,7 +58,17 @@ struct moe_ll {
   int cov_type, g, d, n, device;
   std::vector<double> X, y;
   std::vector<int> derivs;
-  std::unique_ptr<moe::GpDev> gp;
+  std::unique_ptr<moe::GpDev> gp;  // moe_ll_grad's factorisation (with the inverse factor)
+  // moe_ll_evaluate: batches of bordered factorisations (kernels.hpp launch_cholesky_batch)
+  hipStream_t stream = nullptr;
+  moe::DevBuf<double> dX, dYc, dA, dLinv, dNoise, dOut;
+  moe::DevBuf<int> dInfo;
+  ~moe_ll() {
+    if (stream) {
+      (void)hipSetDevice(device);
+      (void)hipStreamDestroy(stream);
+    }
+  }
 };
 
 extern "C" {
@@ -504,22 +514,61 @@ int moe_ll_destroy(moe_ll_t* ll) {
 int moe_ll_evaluate(moe_ll_t* ll, const double* hyperparameters_all, int num_sets, double* values, moe_error_t* err) {
   return guarded(err, [&] {
     require(ll != nullptr && hyperparameters_all != nullptr && values != nullptr, "NULL argument");
-    const int g1 = 1 + ll->g, stride = 1 + ll->d + g1;
-    std::vector<double> noise(g1);
-    for (int i = 0; i < num_sets; ++i) {
-      const double* h = hyperparameters_all + (size_t)i * stride;
-      for (int a = 0; a < g1; ++a) noise[a] = h[1 + ll->d + a] + 1.0e-6;  // gpp_model_selection.cpp:546-549
-      try {
-        if (!ll->gp)
-          ll->gp.reset(new moe::GpDev(h, ll->cov_type, ll->X.data(), ll->y.data(), noise.data(),
-                                      ll->derivs.empty() ? nullptr : ll->derivs.data(), ll->g, ll->d, ll->n, ll->device));
-        else
-          ll->gp->set_hyperparameters(h, noise.data());
-        values[i] = ll->gp->log_marginal_likelihood();
-      } catch (const moe::Error& e) {
-        if (e.code != MOE_ERR_SINGULAR) throw;
-        values[i] = -INFINITY;
+    if (num_sets <= 0) return;
+    MOE_HIP_CHECK(hipSetDevice(ll->device));
+    const int g1 = 1 + ll->g, d = ll->d, n = ll->n, N = n * g1, stride = 1 + d + g1;
+    const int dp = moe::round_up(d, 4);
+    if (!ll->stream) {
+      MOE_HIP_CHECK(hipStreamCreate(&ll->stream));
+      std::vector<double> Xp((size_t)n * dp, 0.0), yc(ll->y);
+      for (int i = 0; i < n; ++i)
+        for (int k = 0; k < d; ++k) Xp[(size_t)i * dp + k] = ll->X[(size_t)i * d + k];
+      double mean = 0.0;  // centred on the mean of the function values (gpp_model_selection.cpp:555-563)
+      for (int i = 0; i < n; ++i) mean += ll->y[(size_t)i * g1];
+      mean /= n;
+      for (int i = 0; i < n; ++i) yc[(size_t)i * g1] -= mean;
+      ll->dX.upload(Xp.data(), Xp.size(), ll->stream);
+      ll->dYc.upload(yc.data(), yc.size(), ll->stream);
+      MOE_HIP_CHECK(hipStreamSynchronize(ll->stream));
+    }
+    hipStream_t s = ll->stream;
+    moe::DerivList dl;
+    dl.g = ll->g;
+    for (int i = 0; i < moe::kMaxDerivs; ++i) dl.idx[i] = (i < ll->g) ? ll->derivs[i] : 0;
+    // every set is a bordered (N + 1) x (N + 1) factorisation; as many at a time as fit ~2 GB, at most 64
+    const int Np = N + 1;
+    const long lda = ((long)Np + 15) / 16 * 16;
+    const long mat = lda * Np;
+    const int chunk = (int)std::max<long>(1, std::min<long>(64, (long)(2.0e9 / (16.0 * (double)mat))));
+    const int B = std::min(chunk, num_sets);
+    ll->dA.reserve((size_t)mat * B);
+    ll->dLinv.reserve((size_t)mat * B);
+    ll->dNoise.reserve((size_t)g1 * B);
+    ll->dOut.reserve((size_t)2 * B);
+    ll->dInfo.reserve(B);
+    std::vector<double> noise((size_t)g1 * B), out((size_t)2 * B);
+    std::vector<int> info(B);
+    std::vector<moe::CovParams> cps(B);
+    for (int i0 = 0; i0 < num_sets; i0 += B) {
+      const int nb = std::min(B, num_sets - i0);
+      for (int b = 0; b < nb; ++b) {
+        const double* h = hyperparameters_all + (size_t)(i0 + b) * stride;
+        moe::fill_cov_params(cps[b], ll->cov_type, d, h);
+        for (int a = 0; a < g1; ++a) noise[(size_t)b * g1 + a] = h[1 + d + a] + 1.0e-6;  // gpp_model_selection.cpp:546-549
       }
+      ll->dNoise.upload(noise.data(), (size_t)g1 * nb, s);
+      for (int b = 0; b < nb; ++b)
+        moe::launch_cov_build(cps[b], ll->dX.p, n, dl, ll->dX.p, n, dl, ll->dNoise.p + (size_t)b * g1,
+                              ll->dA.p + (size_t)b * mat, lda, 0, s);
+      moe::launch_ll_border(ll->dA.p, lda, mat, N, ll->dYc.p, nb, s);
+      moe::launch_cholesky_batch(Np, ll->dA.p, lda, mat, ll->dLinv.p, lda, mat, ll->dInfo.p, nb, s);
+      moe::launch_ll_terms_batch(ll->dA.p, lda, mat, N, ll->dOut.p, nb, s);
+      ll->dOut.download(out.data(), (size_t)2 * nb, s);
+      ll->dInfo.download(info.data(), nb, s);
+      MOE_HIP_CHECK(hipStreamSynchronize(s));
+      for (int b = 0; b < nb; ++b)
+        values[i0 + b] = (info[b] != 0) ? -INFINITY
+                                        : -0.5 * out[2 * b + 1] - out[2 * b] - 0.5 * (double)N * 1.8378770664093454835607;
     }
   });
 }

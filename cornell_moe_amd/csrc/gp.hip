@@ -50,7 +50,10 @@ GpDev::GpDev(const double* hyper, int cov_type, const double* X_in, const double
   rebuild();
 }
 
-void GpDev::set_covariance(const double* hyper) {
+void fill_cov_params(CovParams& cp, int cov_type, int d, const double* hyper) {
+  cp.type = cov_type;
+  cp.dim = d;
+  cp.dp = round_up(d, 4);
   cp.alpha = hyper[0];
   if (!(cp.alpha > 0.0)) throw Error(MOE_ERR_BOUNDS, "alpha must be positive", cp.alpha, 0.0, INFINITY);
   for (int k = 0; k < kMaxDimPadded; ++k) {
@@ -64,6 +67,8 @@ void GpDev::set_covariance(const double* hyper) {
     cp.inv_l[k] = 1.0 / l;
   }
 }
+
+void GpDev::set_covariance(const double* hyper) { fill_cov_params(cp, cp.type, d, hyper); }
 
 void GpDev::set_hyperparameters(const double* hyper, const double* noise_in) {
   set_covariance(hyper);

@@ -10,6 +10,9 @@
 
 namespace moe {
 
+// Validated covariance parameters from [alpha, lengths[d]] (throws MOE_ERR_BOUNDS on non-positive entries).
+void fill_cov_params(CovParams& cp, int cov_type, int d, const double* hyper);
+
 // HBM-resident state of one GP (replaces GaussianProcess' K_chol_/K_inv_y_ members, gpp_math.hpp:840-868):
 //   dX     [n][DP]   padded training points
 //   dL     [N][N]    Cholesky factor of K + noise (lower; strict upper zero), column-major with leading dimension ldL

@@ -84,4 +84,16 @@ size_t cholesky_append_work_doubles(int N0, int kk);
 void launch_cholesky_append(int N0, int kk, double* L, long ldl, double* Linv, long ldi, const double* B, double* C,
                             double* work, int* info, hipStream_t s);
 
+// ---- a batch of independent factorisations (the log-likelihood of many hyper-parameter sets on the same data) ----
+// In-place blocked Cholesky of `batch` matrices A + b * a_stride (N x N lower triangles, lda); the inverses of the diagonal
+// blocks go to Linv + b * l_stride (N x N layout, ldl; only the 64 x 64 diagonal blocks are written -- no full inverse
+// factor).  info[b]: 0 or failing pivot + 1.  Every step is ONE launch over the batch (grid.z).
+void launch_cholesky_batch(int N, double* A, long lda, long a_stride, double* Linv, long ldl, long l_stride, int* info,
+                           int batch, hipStream_t s);
+// The log-likelihood's quadratic form comes out of the same factorisation: with the centred data as an extra ROW N of the
+// matrix (corner 1e100) the factor's row N is v^T = (L^-1 yc)^T, and yc^T K^-1 yc = |v|^2 -- no triangular solve.
+// launch_ll_border writes that row; launch_ll_terms_batch returns out[b] = (sum log L_ii, |v|^2) over i, j < N.
+void launch_ll_border(double* A, long lda, long a_stride, int N, const double* yc, int batch, hipStream_t s);
+void launch_ll_terms_batch(const double* A, long lda, long a_stride, int N, double* out, int batch, hipStream_t s);
+
 }  // namespace moe

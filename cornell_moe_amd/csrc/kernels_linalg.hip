@@ -300,11 +300,15 @@ __device__ __forceinline__ double readlane_f64(double v, int lane) {
 }
 
 __global__ __launch_bounds__(64) void chol_diag_kernel(double* __restrict__ A, long lda, double* __restrict__ Linv,
-                                                      long ldl, int k0, int nb, int* __restrict__ info) {
+                                                      long ldl, int k0, int nb, int* __restrict__ info, long a_stride = 0,
+                                                      long l_stride = 0) {
   __shared__ double S[NB][NB + 1];  // L, row-major
   __shared__ double X[NB][NB + 1];  // X[c][r] = (L^-1)[r][c]
   __shared__ double Ccol[NB];
   const int t = threadIdx.x;
+  A += (long)blockIdx.z * a_stride;  // batch of independent matrices on grid.z (stride 0: one matrix)
+  Linv += (long)blockIdx.z * l_stride;
+  info += blockIdx.z;
   if (*info != 0) return;
   double a[NB];
 #pragma clang loop unroll(full)
@@ -373,9 +377,13 @@ __global__ __launch_bounds__(64) void chol_diag_kernel(double* __restrict__ A, l
 // Panel below the diagonal block: L_ik = A_ik * L_kk^-T, i.e. out[i][c] = sum_j A[i][j] * Linv_kk[c][j].
 // One workgroup per 64 panel rows; both operands staged in LDS, 4 x 4 outputs per thread.
 __global__ __launch_bounds__(256) void chol_panel_kernel(double* __restrict__ A, long lda, const double* __restrict__ Linv,
-                                                        long ldl, int N, int k0, int nb, const int* __restrict__ info) {
+                                                        long ldl, int N, int k0, int nb, const int* __restrict__ info,
+                                                        long a_stride = 0, long l_stride = 0) {
   __shared__ double D[NB][NB + 1];   // D[j][c] = Linv_kk[c][j]
   __shared__ double At[NB][NB + 1];  // At[j][i] = A[i0 + i][k0 + j]
+  A += (long)blockIdx.z * a_stride;
+  Linv += (long)blockIdx.z * l_stride;
+  info += blockIdx.z;
   if (*info != 0) return;
   const int i0 = k0 + nb + blockIdx.x * NB;
   for (int t = threadIdx.x; t < NB * NB; t += 256) {
@@ -413,9 +421,11 @@ __global__ __launch_bounds__(256) void chol_panel_kernel(double* __restrict__ A,
 
 // Trailing update: A[i][j] -= sum_c L[i][c] L[j][c], c over the panel, for 64 x 64 tiles with tile-row >= tile-col.
 __global__ __launch_bounds__(256) void chol_update_kernel(double* __restrict__ A, long lda, int N, int k0, int nb,
-                                                         const int* __restrict__ info) {
+                                                         const int* __restrict__ info, long a_stride = 0) {
   __shared__ double Ls_i[TK][NB + 1];
   __shared__ double Ls_j[TK][NB + 1];
+  A += (long)blockIdx.z * a_stride;
+  info += blockIdx.z;
   if (*info != 0) return;
   if (blockIdx.y > blockIdx.x) return;
   const int base = k0 + nb;
@@ -754,5 +764,71 @@ void launch_cholesky_append(int N0, int kk, double* L, long ldl, double* Linv, l
                      (const double*)X22, N0, kk, L + N0, ldl, Linv + N0, ldi);
   MOE_HIP_CHECK(hipGetLastError());
 }
+
+namespace {
+// Border of the log-likelihood factorisation: row N of matrix b = (y - mean)^T, corner = 1e100 (see launch_ll_batch).
+__global__ __launch_bounds__(256) void ll_border_kernel(double* __restrict__ A, long lda, long a_stride, int N,
+                                                        const double* __restrict__ yc) {
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  double* Ab = A + (long)blockIdx.y * a_stride;
+  if (j < N) Ab[(long)N + (long)j * lda] = yc[j];
+  if (j == N) Ab[(long)N + (long)N * lda] = 1.0e100;
+}
+// out[b] = (sum_i log L_ii, sum_j L[N][j]^2) of matrix b: one workgroup per matrix, fixed-order reduction.
+__global__ __launch_bounds__(256) void ll_terms_batch_kernel(const double* __restrict__ A, long lda, long a_stride, int N,
+                                                             double* __restrict__ out) {
+  __shared__ double red[2][256];
+  const double* Ab = A + (long)blockIdx.x * a_stride;
+  double a = 0.0, q = 0.0;
+  for (int i = threadIdx.x; i < N; i += 256) {
+    a += log(Ab[(long)i + (long)i * lda]);
+    const double v = Ab[(long)N + (long)i * lda];
+    q = fma(v, v, q);
+  }
+  red[0][threadIdx.x] = a;
+  red[1][threadIdx.x] = q;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if ((int)threadIdx.x < w) {
+      red[0][threadIdx.x] += red[0][threadIdx.x + w];
+      red[1][threadIdx.x] += red[1][threadIdx.x + w];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    out[2 * blockIdx.x] = red[0][0];
+    out[2 * blockIdx.x + 1] = red[1][0];
+  }
+}
+}  // namespace
+
+void launch_cholesky_batch(int N, double* A, long lda, long a_stride, double* Linv, long ldl, long l_stride, int* info,
+                           int batch, hipStream_t s) {
+  MOE_HIP_CHECK(hipMemsetAsync(info, 0, sizeof(int) * batch, s));
+  const int nblk = (N + NB - 1) / NB;
+  for (int b = 0; b < nblk; ++b) {
+    const int k0 = b * NB, nb = std::min(NB, N - k0);
+    hipLaunchKernelGGL(chol_diag_kernel, dim3(1, 1, batch), dim3(64), 0, s, A, lda, Linv, ldl, k0, nb, info, a_stride, l_stride);
+    const int below = N - k0 - nb;
+    if (below > 0) {
+      const int tb = (below + NB - 1) / NB;
+      hipLaunchKernelGGL(chol_panel_kernel, dim3(tb, 1, batch), dim3(256), 0, s, A, lda, (const double*)Linv, ldl, N, k0, nb,
+                         (const int*)info, a_stride, l_stride);
+      hipLaunchKernelGGL(chol_update_kernel, dim3(tb, tb, batch), dim3(256), 0, s, A, lda, N, k0, nb, (const int*)info, a_stride);
+    }
+  }
+  MOE_HIP_CHECK(hipGetLastError());
+}
+
+void launch_ll_border(double* A, long lda, long a_stride, int N, const double* yc, int batch, hipStream_t s) {
+  hipLaunchKernelGGL(ll_border_kernel, dim3((N + 1 + 255) / 256, batch), dim3(256), 0, s, A, lda, a_stride, N, yc);
+  MOE_HIP_CHECK(hipGetLastError());
+}
+
+void launch_ll_terms_batch(const double* A, long lda, long a_stride, int N, double* out, int batch, hipStream_t s) {
+  hipLaunchKernelGGL(ll_terms_batch_kernel, dim3(batch), dim3(256), 0, s, A, lda, a_stride, N, out);
+  MOE_HIP_CHECK(hipGetLastError());
+}
+
 
 }  // namespace moe

@@ -1,6 +1,6 @@
 """A complete Bayesian-optimisation loop on the device path, written against the same names a Cornell-MOE user script
-uses (cpp_wrappers mirror + GPP stand-in): sample GP hyper-parameters from their posterior (Metropolis on
-`compute_log_likelihood`), build the `GaussianProcessMCMC` ensemble, choose the next q points by multistart optimisation of the
+uses (cpp_wrappers mirror + GPP stand-in): sample GP hyper-parameters from their posterior (Metropolis walkers on
+`evaluate_log_likelihood_at_hyperparameter_list`, all proposals of a step factorised together on the device), build the `GaussianProcessMCMC` ensemble, choose the next q points by multistart optimisation of the
 MCMC-averaged q-KG, evaluate, add the points, report the minimiser of the averaged posterior mean.  The flow follows the
 reference's examples/main.py (KG branch, :104-260) with its emcee sampler replaced by a 40-line Metropolis sampler (emcee
 is not a dependency of this repository) and the per-point Python loops replaced by the batched calls the boundary offers.
@@ -23,29 +23,31 @@ def branin(x):
     return (b - 5.1 / (4 * np.pi ** 2) * a ** 2 + 5.0 / np.pi * a - 6.0) ** 2 + 10.0 * (1 - 1 / (8 * np.pi)) * np.cos(a) + 10.0
 
 
-def sample_hyperparameters(X, y, num_samples, rng, steps=300, noise=1e-4):
-    """Metropolis on log(alpha, lengths) with a flat prior on [-4, 4]: the role of log_likelihood_mcmc.py's emcee chain.
-    Every proposal costs one `compute_log_likelihood` call = one in-place re-factorisation on the device."""
-    dim = X.shape[1]
+def sample_hyperparameters(X, y, num_samples, rng, steps=150, noise=1e-4):
+    """Metropolis chains over log(alpha, lengths) under a flat prior on [-4, 4] (the role of emcee in the reference, which
+    the reference drives one `compute_log_likelihood` call per walker).  Here 2 x num_samples independent walkers move in
+    lockstep and every step is ONE `evaluate_log_likelihood_at_hyperparameter_list` call: the device factorises all
+    proposals together (one launch per factorisation step for the whole batch)."""
+    dim, n = X.shape[1], X.shape[0]
+    W = max(2 * num_samples, 16)
+    Xl, yl = list(X.ravel()), list(y)
 
-    def lnprob(h):
-        if np.any(np.abs(h) > 4.0):
-            return -np.inf
-        e = np.exp(h)
-        return GPP.compute_log_likelihood(list(X.ravel()), list(y), dim, X.shape[0], GPP.LogLikelihoodTypes.log_marginal_likelihood,
-                                          [float(e[0]), list(e[1:])], [], 0, [noise])
-    h = np.r_[np.log(np.var(y) + 1e-3), np.full(dim, np.log(0.3))]
-    lp = lnprob(h)
-    chain = []
+    def lnprob(H):
+        E = np.exp(H)
+        flat = np.hstack([E, np.full((H.shape[0], 1), noise)]).ravel()
+        lp = np.array(GPP.evaluate_log_likelihood_at_hyperparameter_list(
+            list(flat), Xl, yl, dim, n, GPP.LogLikelihoodTypes.log_marginal_likelihood, [1.0, [1.0] * dim], [noise], [], 0,
+            H.shape[0], 1, {}))
+        lp[np.any(np.abs(H) > 4.0, axis=1)] = -np.inf
+        return lp
+    H = np.r_[np.log(np.var(y) + 1e-3), np.full(dim, np.log(0.3))] + 0.1 * rng.standard_normal((W, 1 + dim))
+    lp = lnprob(H)
     for it in range(steps):
-        prop = h + 0.25 * rng.standard_normal(h.size)
+        prop = H + 0.25 * rng.standard_normal(H.shape)
         lpp = lnprob(prop)
-        if np.log(rng.uniform()) < lpp - lp:
-            h, lp = prop, lpp
-        if it >= steps // 2:
-            chain.append(np.exp(h))
-    idx = np.linspace(0, len(chain) - 1, num_samples).astype(int)
-    return np.array(chain)[idx]
+        acc = np.log(rng.uniform(size=W)) < lpp - lp
+        H[acc], lp[acc] = prop[acc], lpp[acc]
+    return np.exp(H[:num_samples])
 
 
 def main():

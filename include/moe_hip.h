@@ -248,7 +248,9 @@ int moe_ei_mcmc_multistart(const moe_gp_t* const* gps, int num_mcmc, const moe_g
  * hyperparameters_all[num_sets][1 + dim + 1 + num_derivatives] = (alpha, lengths[dim], noise_variance[1 + g]) per set, the
  * layout of the reference's hyperparameter lists (gpp_python_model_selection.cpp:301-303).  Like the reference, 1e-6 is
  * added to the diagonal of K + noise before it is factored (gpp_model_selection.cpp:546-549).  Where the reference
- * ignores a failed factorisation (:551-553, "TODO(GH-211)") and returns a meaningless number, values[i] is -infinity. */
+ * ignores a failed factorisation (:551-553, "TODO(GH-211)") and returns a meaningless number, values[i] is -infinity.
+ * The sets of one call are factorised together (up to 64 per device pass): a sampler that proposes for all its walkers at
+ * once should pass them in one call. */
 typedef struct moe_ll moe_ll_t;
 int moe_ll_create(int cov_type, const double* points_sampled, const double* points_sampled_value, const int* derivatives,
                   int num_derivatives, int dim, int num_sampled, int device, moe_ll_t** ll_out, moe_error_t* err);

@@ -27,6 +27,12 @@ for name in ["C2", "C3"]:
     t0 = time.perf_counter()
     LL.evaluate(sets)
     print("%s: log marginal likelihood %.2f ms per hyper-parameter set" % (name, 1e3 * (time.perf_counter() - t0) / 20))
+    big = np.tile(np.r_[w.hyperparameters, w.noise], (256, 1)) * np.linspace(0.7, 1.3, 256)[:, None]
+    LL.evaluate(big[:64])
+    for k in (1, 8, 64, 256):
+        t0 = time.perf_counter()
+        LL.evaluate(big[:k])
+        print("%s:   %3d sets per call: %.3f ms per set" % (name, k, 1e3 * (time.perf_counter() - t0) / k))
     LL.grad(sets[0])
     t0 = time.perf_counter()
     for k in range(10):
