@@ -262,6 +262,40 @@ def test_headline_shape_properties(api):
     assert whole["grad_evals"] <= 6 * w.M and whole["grad_evals"] >= w.M and whole["mean_evals"] >= w.M
 
 
+def test_dkg_shape_properties(api, monkeypatch):
+    """BASELINE config C5 at full size (d-KG: n=2000, d=12, 3 observed derivatives, q=8, M=20000; N = 8000, m = 32): what can
+    be said without an oracle run (the reference needs hours per evaluation here) -- determinism, MC shard-sum invariance,
+    the two MC kernels against each other, every optimum inside the domain, pass counters in range."""
+    from cornell_moe_amd import dist as mdist
+    from cornell_moe_amd.workloads import make_workload
+    w = make_workload("C5")
+    G = api.DeviceGP(w.hyperparameters, w.X, w.y, w.noise, w.derivs)
+    best = float(G.additional_mean(w.discrete).min())
+    args = (w.inner_gd, w.bounds, w.discrete, w.Xq, None, w.M, best, w.kg_normals)
+    whole = G.kg(*args, want_best_points=True)
+    again = G.kg(*args)
+    assert whole["kg_sum"] == again["kg_sum"] and np.array_equal(whole["grad_sum"], again["grad_sum"])
+    assert np.isfinite(whole["kg"]) and np.all(np.isfinite(whole["grad"])) and whole["kg"] > 0.0
+    bp = whole["best_point"]
+    assert bp.shape == (w.M, 12) and bp.min() >= 0.0 and bp.max() <= 1.0
+    assert w.M <= whole["grad_evals"] <= 6 * w.M and whole["mean_evals"] >= w.M
+    ks, gs = 0.0, np.zeros_like(whole["grad_sum"])
+    for r in range(4):
+        first, count = mdist.shard_samples(w.M, r, 4)
+        part = G.kg(*args, first_sample=first, num_local=count)
+        ks += part["kg_sum"]
+        gs += part["grad_sum"]
+    gscale = max(np.abs(whole["grad_sum"]).max(), abs(whole["kg_sum"]))
+    assert abs(ks - whole["kg_sum"]) <= 1e-12 * abs(whole["kg_sum"]) and np.abs(gs - whole["grad_sum"]).max() <= 1e-11 * gscale
+    monkeypatch.setenv("MOE_KG_VARIANT", "0")  # wave-per-sample kernel, coordinates streamed from L2 at this size
+    other = G.kg(*args, want_best_points=True)
+    monkeypatch.delenv("MOE_KG_VARIANT")
+    assert abs(other["kg"] - whole["kg"]) <= 1e-10 * abs(whole["kg"])
+    assert np.abs(other["grad"] - whole["grad"]).max() <= 1e-9 * max(np.abs(whole["grad"]).max(), abs(whole["kg"]))
+    assert (np.abs(other["best_point"] - bp).max(axis=1) > 1e-9).mean() <= 0.005
+    assert other["grad_evals"] == whole["grad_evals"]
+
+
 def test_workgroup_per_sample_kernel_matches_wave_per_sample(api, monkeypatch):
     """The two MC kernel variants (csrc/kg_mc.hpp: wave-per-sample with LDS tables, workgroup-per-sample with register
     tiles) implement the same algorithm with different summation trees: q-KG and d-KG results agree to rounding, and both
