@@ -38,7 +38,8 @@ __device__ __forceinline__ double exp_nonpos(double x) {
 // with T[j] = 2^(j/64) (correctly rounded, staged in LDS by the caller) and a degree-5 polynomial for e^r - 1 (truncation
 // r^6/720 <= 3.5e-17).  k is extracted with the 1.5*2^52 magic-number trick (no v_rndne / v_cvt); the reduction uses the
 // full-precision hi/lo split of ln2/64 (each product is exact inside its fma).  11 FP64 + 3 integer VALU instructions +
-// one ds_read_b64, against 17 FP64 for exp_nonpos.  <= 1.5 ulp (tools/mathcheck.hip).  Valid for -2.3e7 < x <= 0 (k must fit
+// one ds_read_b64, against 17 FP64 for exp_nonpos.  (A 512-entry table with a degree-4 polynomial -- one fma less, 1.00 ulp --
+// measured no faster: its lookups collide on LDS banks where the 64-entry table's mostly broadcast; and it costs 3.5 KB.)  <= 1.5 ulp (tools/mathcheck.hip).  Valid for -2.3e7 < x <= 0 (k must fit
 // 32 bits: beyond that the exponent wraps and the result can be anything, including inf) -- callers bound the argument:
 // sqrt(5) r <= 1e7 by construction of the tables (kg_mc.hpp to_frame / kTableExtent), -r2/2 by an explicit fmax.
 __device__ __forceinline__ double exp_nonpos_tab(double x, const double* __restrict__ tab64) {
