@@ -665,3 +665,87 @@ def multistart_expected_improvement_mcmc_optimization(ei_optimizer, num_multista
         [float(x) for x in cppify(ei_optimizer.domain.domain_bounds)], cppify(ei._points_being_sampled), num_to_sample,
         ei.num_being_sampled, cppify(numpy.array(ei._best_so_far_list)), ei._num_mc_iterations, max_num_threads, randomness, status)
     return uncppify(best, (num_to_sample, ei.dim))
+
+
+# ---- log likelihood (py/cpp_wrappers/log_likelihood.py) ----
+class GaussianProcessLogLikelihood(object):
+    """Log marginal likelihood of the historical data as a function of the hyper-parameters (covariance hyper-parameters
+    followed by the noise variances), the object the reference's hyper-parameter optimisers and its emcee driver evaluate
+    (log_likelihood.py:230-400).  compute_log_likelihood / compute_grad_log_likelihood go to the device
+    (GPP.compute_log_likelihood / compute_hyperparameter_grad_log_likelihood -> moe_ll_evaluate / moe_ll_grad)."""
+
+    def __init__(self, covariance_function, historical_data, noise_variance, derivatives,
+                 log_likelihood_type=C_GP.LogLikelihoodTypes.log_marginal_likelihood):
+        self._covariance = copy.deepcopy(covariance_function)
+        self._historical_data = copy.deepcopy(historical_data)
+        self._noise_variance = numpy.array(noise_variance, dtype=float, copy=True).ravel()
+        self._derivatives = [int(v) for v in derivatives]
+        self._num_derivatives = len(self._derivatives)
+        self.objective_type = log_likelihood_type
+
+    dim = property(lambda self: self._historical_data.dim)
+    num_hyperparameters = property(lambda self: self._covariance.num_hyperparameters + self._noise_variance.size)
+    problem_size = num_hyperparameters
+    cov_hyperparameters = property(lambda self: self._covariance.hyperparameters)
+    noise_variance = property(lambda self: self._noise_variance)
+    derivatives = property(lambda self: self._derivatives)
+    num_derivatives = property(lambda self: self._num_derivatives)
+    _num_sampled = property(lambda self: self._historical_data.num_sampled)
+    _points_sampled = property(lambda self: self._historical_data.points_sampled)
+    _points_sampled_value = property(lambda self: self._historical_data.points_sampled_value)
+    _points_sampled_noise_variance = property(lambda self: self._historical_data.points_sampled_noise_variance)
+
+    def get_hyperparameters(self):
+        return numpy.append(self._covariance.hyperparameters, self._noise_variance)
+
+    def set_hyperparameters(self, hyperparameters):
+        k = self._covariance.num_hyperparameters
+        self._covariance.hyperparameters = hyperparameters[:k]
+        self._noise_variance = numpy.array(hyperparameters[k:], dtype=float).ravel()
+
+    hyperparameters = property(get_hyperparameters, set_hyperparameters)
+    current_point = hyperparameters
+
+    def get_covariance_copy(self):
+        return copy.deepcopy(self._covariance)
+
+    def get_historical_data_copy(self):
+        return copy.deepcopy(self._historical_data)
+
+    def _args(self):
+        return (cppify(self._points_sampled), cppify(self._points_sampled_value), self.dim, self._num_sampled, self.objective_type,
+                cppify_hyperparameters(self.cov_hyperparameters), cppify(self._derivatives), self._num_derivatives,
+                cppify(self.noise_variance))
+
+    def compute_log_likelihood(self):
+        return C_GP.compute_log_likelihood(*self._args())
+
+    compute_objective_function = compute_log_likelihood
+
+    def compute_grad_log_likelihood(self):
+        return numpy.array(C_GP.compute_hyperparameter_grad_log_likelihood(*self._args()))
+
+    compute_grad_objective_function = compute_grad_log_likelihood
+
+
+class GaussianProcessLogMarginalLikelihood(GaussianProcessLogLikelihood):
+    """(log_likelihood.py:403-440)"""
+
+    def __init__(self, covariance_function, historical_data, noise_variance, derivatives):
+        super(GaussianProcessLogMarginalLikelihood, self).__init__(covariance_function, historical_data, noise_variance, derivatives,
+                                                                   C_GP.LogLikelihoodTypes.log_marginal_likelihood)
+
+
+def evaluate_log_likelihood_at_hyperparameter_list(log_likelihood_evaluator, hyperparameters_to_evaluate, max_num_threads=4,
+                                                   status=None):
+    """log_likelihood.py:179-227: the log likelihood at each row of hyperparameters_to_evaluate
+    [num_to_eval][num_hyperparameters]; the rows of one call are factorised together on the device."""
+    if status is None:
+        status = {}
+    h = numpy.asarray(hyperparameters_to_evaluate, dtype=float)
+    ev = log_likelihood_evaluator
+    return numpy.array(C_GP.evaluate_log_likelihood_at_hyperparameter_list(
+        cppify(h), cppify(ev._points_sampled), cppify(ev._points_sampled_value), ev.dim, ev._num_sampled, ev.objective_type,
+        cppify_hyperparameters(ev.cov_hyperparameters), cppify(ev.noise_variance), cppify(ev.derivatives), ev.num_derivatives,
+        h.shape[0], max_num_threads, status))
+

@@ -215,3 +215,39 @@ def test_multistart_knowledge_gradient_optimization():
                                                   list(x0), {}))
     assert xs.shape == (2,) and xs.min() >= 0.0 and xs.max() <= 1.0
     assert gp.compute_mean_of_points(xs[None, :])[0] <= gp.compute_mean_of_points(x0[None, :])[0] + 1e-12
+
+
+def test_log_likelihood_wrapper_flow():
+    """cpp_wrappers.GaussianProcessLogLikelihood (log_likelihood.py:230-400 in the reference): value, hyper-parameter
+    gradient and the list evaluator through the GPP stand-in, against the restatement; the gradient against central
+    differences of the device value (no derivative observations: it IS the gradient of the value)."""
+    import numpy as np
+    from cornell_moe_amd import cpp_wrappers as cw
+    from oracle import orc
+    rng = np.random.default_rng(12)
+    n, d = 80, 3
+    X = rng.uniform(size=(n, d))
+    y = np.sin(3 * X).sum(1) + 0.05 * rng.standard_normal(n)
+    hd = cw.HistoricalData(dim=d, num_derivatives=0)
+    hd.append_sample_points([cw.SamplePoint(X[i], [y[i]], 0.01) for i in range(n)])
+    cov = cw.SquareExponential(np.array([1.3, 0.5, 0.7, 0.9]))
+    ll = cw.GaussianProcessLogMarginalLikelihood(cov, hd, np.array([0.01]), [])
+    assert ll.num_hyperparameters == 5 and ll.dim == d
+    v = ll.compute_log_likelihood()
+    g = ll.compute_grad_log_likelihood()
+    theta = ll.hyperparameters
+    vo = orc.log_likelihood(1, theta[0], theta[1:4], X, y[:, None], theta[4:], ())
+    go = orc.log_likelihood_grad(1, theta[0], theta[1:4], X, y[:, None], theta[4:], ())
+    assert abs(v - vo) <= 1e-10 * abs(vo) and np.abs(g - go).max() <= 1e-9 * np.abs(go).max()
+    H = theta * np.linspace(0.8, 1.25, 7)[:, None]
+    vals = cw.evaluate_log_likelihood_at_hyperparameter_list(ll, H)
+    for k in range(7):
+        ll.hyperparameters = H[k]
+        assert abs(ll.compute_log_likelihood() - vals[k]) <= 1e-12 * abs(vals[k])
+    ll.hyperparameters = theta
+    for k in range(5):
+        e = np.zeros(5)
+        e[k] = 1e-6 * theta[k]
+        fd = np.diff(cw.evaluate_log_likelihood_at_hyperparameter_list(ll, np.array([theta - e, theta + e])))[0] / (2 * e[k])
+        assert abs(fd - g[k]) <= 1e-5 * max(1.0, abs(g[k]))
+
