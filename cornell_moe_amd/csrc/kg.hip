@@ -710,14 +710,17 @@ KgPending kg_launch(GpDev& gp, int num_fidelity, const moe_gd_params_t& gd, cons
   const int max_waves = (ntiles <= env_int("MOE_KG_SMALL_TILES", 4)) ? 16 : 8;
   int waves = 0;
   if (tab_bytes + slab_bytes <= lds_max) waves = (int)std::min<size_t>(max_waves, (lds_max - tab_bytes) / slab_bytes);
-  if (waves < 4) {  // coordinates stay in L2: more wavefronts per workgroup fit
+  // (3 wavefronts per CU on the LDS table still beat the workgroup-per-sample kernel without derivative observations --
+  //  n = 1500, d = 8: 2.1 vs 3.1 ms per evaluation; with 2 they lose -- n = 1700: 3.6 vs 3.4)
+  const int min_xlds_waves = env_int("MOE_KG_MIN_XLDS_WAVES", 3);
+  if (waves < min_xlds_waves) {  // coordinates stay in L2: more wavefronts per workgroup fit
     const int w2 = (int)std::min<size_t>(8, lds_max / slab_bytes);
     if (w2 > waves) {
       waves = w2;
       xlds = false;
     }
   }
-  // Variant selection: the wave-per-sample kernel needs the coordinate table AND >= 4 weight slabs in LDS; bigger point
+  // Variant selection: the wave-per-sample kernel needs the coordinate table AND >= 3 weight slabs in LDS; bigger point
   // sets (up to 32 tiles = 2048 points) go to the workgroup-per-sample kernel (coordinates in registers, 4 waves);
   // beyond that the wave-per-sample kernel streams coordinates from L2 (slow, but correct).
   // workgroup-per-sample geometry: 8 wavefronts; TR register tiles per wave, the remaining tiles in LDS
@@ -733,7 +736,7 @@ KgPending kg_launch(GpDev& gp, int num_fidelity, const moe_gd_params_t& gd, cons
   }
   tr = env_int("MOE_KG_TR", tr);
   if (tr >= 0) num_lds_tiles = std::max(0, ntiles - bwaves * tr);
-  int variant = (xlds && waves >= 4) ? 0 : (tr >= 0 ? 1 : 0);
+  int variant = (xlds && waves >= min_xlds_waves) ? 0 : (tr >= 0 ? 1 : 0);
   variant = env_int("MOE_KG_VARIANT", variant);
   if (variant == 1 && (tr < 0 || kg_mc_block_lds_bytes(dp, G, num_lds_tiles) > (size_t)160 * 1024))
     throw Error(MOE_ERR_RUNTIME, "point set too large for the workgroup-per-sample MC kernel");
