@@ -1014,10 +1014,10 @@ KgPending kg_launch(GpDev& gp, int num_fidelity, const moe_gd_params_t& gd, cons
     const int pb = (int)std::min<long>((total + 3) / 4, (long)num_cu * 8);
     hipLaunchKernelGGL(kg_sample_prep_kernel, dim3(pb), dim3(256), 0, s, mp, gp.kBestJ.p);
     MOE_HIP_CHECK(hipGetLastError());
-    // the weight table: N doubles per sample (1.28 GB at C5); beyond MOE_KG_V_MAX_GB (default 24) the samples compute their
-    // weights in the kernel as before
+    // the weight table: N doubles per sample (1.28 GB per evaluation at C5); beyond MOE_KG_V_MAX_GB (default 4: every GP
+    // handle of an MCMC ensemble owns one, next to its N x M tail matrix) the samples compute their weights in the kernel
     const double v_gb = 8.0 * (double)N * (double)total / 1e9;
-    if (v_gb <= (double)env_int("MOE_KG_V_MAX_GB", 24)) {
+    if (v_gb <= (double)env_int("MOE_KG_V_MAX_GB", 4)) {
       gp.kV.reserve((size_t)N * (size_t)total);
       MOE_HIP_CHECK(hipMemsetAsync(dBeta.p + (size_t)total * m, 0, sizeof(double) * 64, s));
       mp.V = gp.kV.p;
