@@ -99,11 +99,12 @@ __global__ __launch_bounds__(256) void tile_gemm_kernel(int M, int Ncols, int K,
 // column-major stores.  The next K tile travels global -> registers while the current one is multiplied out of LDS.
 using f64x4 = __attribute__((ext_vector_type(4))) double;
 
-template <int MODE, bool NEG>
+template <int MODE, bool NEG, int TKV = 16>
 __global__ __launch_bounds__(256) void mfma_gemm_kernel(int M, int Ncols, int K, const double* __restrict__ A, long lda,
                                                        const double* __restrict__ B, long ldb, double* __restrict__ C,
                                                        long ldc, int xmul) {
-  constexpr int TM = 64, TN = 64, TK = 16, LD = 65;
+  constexpr int TM = 64, TN = 64, TK = TKV, LD = 65;
+  constexpr int NF = TM * TK / 256;  // elements of each operand tile per thread
   __shared__ double As[TK][LD];
   __shared__ double Bs[TK][LD];
   // Triangular operands make a tile row's K range proportional to its index; all workgroups are resident at once, and the
@@ -125,10 +126,10 @@ __global__ __launch_bounds__(256) void mfma_gemm_kernel(int M, int Ncols, int K,
     for (int b = 0; b < 2; ++b) acc[a][b] = f64x4{0.0, 0.0, 0.0, 0.0};
 
   // software pipeline: tile k0 + TK travels global -> registers while tile k0 is multiplied out of LDS
-  double ra[4], rb[4];
+  double ra[NF], rb[NF];
   auto fetch = [&](int k0) {
 #pragma unroll
-    for (int it = 0; it < 4; ++it) {
+    for (int it = 0; it < NF; ++it) {
       const int t = threadIdx.x + 256 * it;
       if (MODE == 1 || MODE == 3) {
         const int ii = t % TM, kk = t / TM;
@@ -148,7 +149,7 @@ __global__ __launch_bounds__(256) void mfma_gemm_kernel(int M, int Ncols, int K,
   };
   auto stash = [&]() {
 #pragma unroll
-    for (int it = 0; it < 4; ++it) {
+    for (int it = 0; it < NF; ++it) {
       const int t = threadIdx.x + 256 * it;
       if (MODE == 1 || MODE == 3)
         As[t / TM][t % TM] = ra[it];
@@ -211,7 +212,14 @@ void tile_gemm(int M, int Ncols, int K, const double* A, long lda, const double*
           xmul = cand;
           break;
         }
-      hipLaunchKernelGGL((mfma_gemm_kernel<MODE, NEG>), grid, dim3(256), 0, s, M, Ncols, K, A, lda, B, ldb, C, ldc, xmul);
+      static const int tk = [] {
+        const char* v = std::getenv("MOE_GEMM_TK");
+        return (v && *v) ? std::atoi(v) : 16;
+      }();
+      if (tk == 32)
+        hipLaunchKernelGGL((mfma_gemm_kernel<MODE, NEG, 32>), grid, dim3(256), 0, s, M, Ncols, K, A, lda, B, ldb, C, ldc, xmul);
+      else
+        hipLaunchKernelGGL((mfma_gemm_kernel<MODE, NEG, 16>), grid, dim3(256), 0, s, M, Ncols, K, A, lda, B, ldb, C, ldc, xmul);
     }
     else
       hipLaunchKernelGGL((tile_gemm_kernel<64, 64, MODE, 16, NEG>), grid, dim3(256), 0, s, M, Ncols, K, A, lda, B, ldb, C, ldc);
