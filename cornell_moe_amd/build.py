@@ -18,7 +18,11 @@ SOURCES = ["kernels_cov.hip", "kernels_linalg.hip", "host_math.hip", "gp.hip", "
            "kg_mc_dp12.hip", "kg_mc_dp16.hip", "multistart.hip", "mcmc.hip", "ei.hip", "api.hip"]
 HEADERS = ["common.hpp", "kernels.hpp", "device_cov.hpp", "fastmath.hpp", "host_math.hpp", "gp.hpp", "kg.hpp", "kg_mc.hpp",
            os.path.join("..", "..", "include", "moe_hip.h")]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function",
+         # MFMA accumulators stay in VGPRs: left to its heuristics the compiler parks them in AGPRs and copies all of them
+         # out and back around every MFMA group (64 v_accvgpr moves per 16 MFMAs in mfma_gemm_kernel, each waiting for
+         # its MFMA to retire)
+         "-mllvm", "-amdgpu-mfma-vgpr-form"]
 FLAGS += os.environ.get("MOE_EXTRA_FLAGS", "").split()  # e.g. -DMOE_BLOCK_PROF=1 (tools; rebuild with force)
 
 
