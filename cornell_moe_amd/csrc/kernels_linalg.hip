@@ -102,91 +102,103 @@ using f64x4 = __attribute__((ext_vector_type(4))) double;
 template <int MODE, bool NEG, int TKV = 16>
 __global__ __launch_bounds__(256) void mfma_gemm_kernel(int M, int Ncols, int K, const double* __restrict__ A, long lda,
                                                        const double* __restrict__ B, long ldb, double* __restrict__ C,
-                                                       long ldc, int xmul) {
+                                                       long ldc, int xmul, int pair_rows) {
   constexpr int TM = 64, TN = 64, TK = TKV, LD = 65;
   constexpr int NF = TM * TK / 256;  // elements of each operand tile per thread
   __shared__ double As[TK][LD];
   __shared__ double Bs[TK][LD];
-  // Triangular operands make a tile row's K range proportional to its index; all workgroups are resident at once, and the
-  // hardware hands consecutive ids to consecutive CUs, so row indices are scattered (multiplier co-prime with the row
-  // count) to give every CU a mix of long and short rows.
-  const int bx = (int)(((long)blockIdx.x * xmul + (long)blockIdx.y * 97) % gridDim.x);
-  const int i0 = bx * TM, j0 = blockIdx.y * TN;
-  int k_lo = 0, k_hi = K;
-  if (MODE == 1) k_hi = min(K, i0 + TM);
-  if (MODE == 2) k_lo = (i0 / TK) * TK;
-  if (MODE == 3) k_lo = (j0 / TK) * TK;
+  // Column tiles are the FAST grid index: the workgroups that share a row tile of A (the big, streamed operand) are
+  // dispatched together.  Triangular operands make a row tile's K range proportional to its index, and every workgroup of
+  // the grid is resident from the start, so nothing rebalances a CU that drew long rows (measured: a third of the matrix
+  // peak).  With pair_rows a workgroup does row tile p AND its mirror R - 1 - p, one after the other: every workgroup then
+  // walks the same number of K steps.  Without it row indices are scattered (multiplier co-prime with the row count).
+  const int R = (M + TM - 1) / TM;
+  const int j0 = blockIdx.x * TN;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int wi = (wave & 1) * 32, wj = (wave >> 1) * 32;  // this wavefront's quadrant
   const int lk = lane >> 4, lx = lane & 15;
-  f64x4 acc[2][2];
+  for (int half = 0; half < (pair_rows ? 2 : 1); ++half) {
+    int bx;
+    if (pair_rows) {
+      bx = half == 0 ? (int)blockIdx.y : R - 1 - (int)blockIdx.y;
+      if (half == 1 && bx == (int)blockIdx.y) break;  // odd tile count: the middle tile has no mirror
+    } else {
+      bx = (int)(((long)blockIdx.y * xmul) % gridDim.y);
+    }
+    const int i0 = bx * TM;
+    int k_lo = 0, k_hi = K;
+    if (MODE == 1) k_hi = min(K, i0 + TM);
+    if (MODE == 2) k_lo = (i0 / TK) * TK;
+    if (MODE == 3) k_lo = (j0 / TK) * TK;
+    f64x4 acc[2][2];
 #pragma unroll
-  for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < 2; ++a)
 #pragma unroll
-    for (int b = 0; b < 2; ++b) acc[a][b] = f64x4{0.0, 0.0, 0.0, 0.0};
+      for (int b = 0; b < 2; ++b) acc[a][b] = f64x4{0.0, 0.0, 0.0, 0.0};
 
-  // software pipeline: tile k0 + TK travels global -> registers while tile k0 is multiplied out of LDS
-  double ra[NF], rb[NF];
-  auto fetch = [&](int k0) {
+    // software pipeline: tile k0 + TK travels global -> registers while tile k0 is multiplied out of LDS
+    double ra[NF], rb[NF];
+    auto fetch = [&](int k0) {
 #pragma unroll
-    for (int it = 0; it < NF; ++it) {
-      const int t = threadIdx.x + 256 * it;
-      if (MODE == 1 || MODE == 3) {
-        const int ii = t % TM, kk = t / TM;
-        const int gi = i0 + ii, gk = k0 + kk;
-        ra[it] = (gi < M && gk < K && (MODE == 3 || gk <= gi)) ? A[(long)gi + (long)gk * lda] : 0.0;
-      } else {
-        const int kk = t % TK, ii = t / TK;
-        const int gi = i0 + ii, gk = k0 + kk;
-        bool ok = gi < M && gk < K;
-        if (MODE == 2) ok = ok && gk >= gi;
-        ra[it] = ok ? A[(long)gk + (long)gi * lda] : 0.0;
+      for (int it = 0; it < NF; ++it) {
+        const int t = threadIdx.x + 256 * it;
+        if (MODE == 1 || MODE == 3) {
+          const int ii = t % TM, kk = t / TM;
+          const int gi = i0 + ii, gk = k0 + kk;
+          ra[it] = (gi < M && gk < K && (MODE == 3 || gk <= gi)) ? A[(long)gi + (long)gk * lda] : 0.0;
+        } else {
+          const int kk = t % TK, ii = t / TK;
+          const int gi = i0 + ii, gk = k0 + kk;
+          bool ok = gi < M && gk < K;
+          if (MODE == 2) ok = ok && gk >= gi;
+          ra[it] = ok ? A[(long)gk + (long)gi * lda] : 0.0;
+        }
+        const int kk = t % TK, jj = t / TK;
+        const int gk = k0 + kk, gj = j0 + jj;
+        rb[it] = (gk < K && gj < Ncols && (MODE != 3 || gk >= gj)) ? B[(long)gk + (long)gj * ldb] : 0.0;
       }
-      const int kk = t % TK, jj = t / TK;
-      const int gk = k0 + kk, gj = j0 + jj;
-      rb[it] = (gk < K && gj < Ncols && (MODE != 3 || gk >= gj)) ? B[(long)gk + (long)gj * ldb] : 0.0;
+    };
+    auto stash = [&]() {
+#pragma unroll
+      for (int it = 0; it < NF; ++it) {
+        const int t = threadIdx.x + 256 * it;
+        if (MODE == 1 || MODE == 3)
+          As[t / TM][t % TM] = ra[it];
+        else
+          As[t % TK][t / TK] = ra[it];
+        Bs[t % TK][t / TK] = rb[it];
+      }
+    };
+    if (k_lo < k_hi) fetch(k_lo);
+    for (int k0 = k_lo; k0 < k_hi; k0 += TK) {
+      stash();
+      __syncthreads();
+      if (k0 + TK < k_hi) fetch(k0 + TK);
+#pragma unroll
+      for (int k4 = 0; k4 < TK; k4 += 4) {
+        double fa[2], fb[2];
+#pragma unroll
+        for (int a = 0; a < 2; ++a) fa[a] = As[k4 + lk][wi + 16 * a + lx];  // -> MFMA's B operand: rows of C
+#pragma unroll
+        for (int b = 0; b < 2; ++b) fb[b] = Bs[k4 + lk][wj + 16 * b + lx];  // -> MFMA's A operand: columns of C
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+          for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb[b], fa[a], acc[a][b], 0, 0, 0);
+      }
+      __syncthreads();
     }
-  };
-  auto stash = [&]() {
+    // D[x][y] = C[row = y][col = x]: lane holds y = lane & 15 (row of C), x = (lane >> 4) + 4 r (column of C)
 #pragma unroll
-    for (int it = 0; it < NF; ++it) {
-      const int t = threadIdx.x + 256 * it;
-      if (MODE == 1 || MODE == 3)
-        As[t / TM][t % TM] = ra[it];
-      else
-        As[t % TK][t / TK] = ra[it];
-      Bs[t % TK][t / TK] = rb[it];
-    }
-  };
-  if (k_lo < k_hi) fetch(k_lo);
-  for (int k0 = k_lo; k0 < k_hi; k0 += TK) {
-    stash();
-    __syncthreads();
-    if (k0 + TK < k_hi) fetch(k0 + TK);
+    for (int a = 0; a < 2; ++a)
 #pragma unroll
-    for (int k4 = 0; k4 < TK; k4 += 4) {
-      double fa[2], fb[2];
+      for (int b = 0; b < 2; ++b)
 #pragma unroll
-      for (int a = 0; a < 2; ++a) fa[a] = As[k4 + lk][wi + 16 * a + lx];  // -> MFMA's B operand: rows of C
-#pragma unroll
-      for (int b = 0; b < 2; ++b) fb[b] = Bs[k4 + lk][wj + 16 * b + lx];  // -> MFMA's A operand: columns of C
-#pragma unroll
-      for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb[b], fa[a], acc[a][b], 0, 0, 0);
-    }
-    __syncthreads();
+        for (int r = 0; r < 4; ++r) {
+          const int gi = i0 + wi + 16 * a + lx, gj = j0 + wj + 16 * b + lk + 4 * r;
+          if (gi < M && gj < Ncols) C[(long)gi + (long)gj * ldc] = NEG ? -acc[a][b][r] : acc[a][b][r];
+        }
   }
-  // D[x][y] = C[row = y][col = x]: lane holds y = lane & 15 (row of C), x = (lane >> 4) + 4 r (column of C)
-#pragma unroll
-  for (int a = 0; a < 2; ++a)
-#pragma unroll
-    for (int b = 0; b < 2; ++b)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int gi = i0 + wi + 16 * a + lx, gj = j0 + wj + 16 * b + lk + 4 * r;
-        if (gi < M && gj < Ncols) C[(long)gi + (long)gj * ldc] = NEG ? -acc[a][b][r] : acc[a][b][r];
-      }
 }
 
 template <int MODE, bool NEG = false>
@@ -201,6 +213,14 @@ void tile_gemm(int M, int Ncols, int K, const double* A, long lda, const double*
   }();
   if (blocks64 >= min_blocks) {
     dim3 grid((M + 63) / 64, (Ncols + 63) / 64);
+    // mfma_gemm_kernel: x = column tile, y = row tile -- or, for the triangular modes with enough rows, a PAIR of row
+    // tiles (p, R - 1 - p) whose K ranges add up to the same total for every workgroup
+    static const int pair_env = [] {
+      const char* v = std::getenv("MOE_GEMM_PAIR_ROWS");
+      return (v && *v) ? std::atoi(v) : 1;
+    }();
+    const int pair_rows = (pair_env != 0 && (MODE == 1 || MODE == 2) && grid.x >= 16 && (long)grid.x * grid.y >= 512) ? 1 : 0;
+    const dim3 mgrid(grid.y, pair_rows ? (grid.x + 1) / 2 : grid.x);
     static const bool use_mfma = [] {
       const char* v = std::getenv("MOE_GEMM_MFMA");
       return !(v && *v == '0');
@@ -217,9 +237,9 @@ void tile_gemm(int M, int Ncols, int K, const double* A, long lda, const double*
         return (v && *v) ? std::atoi(v) : 16;
       }();
       if (tk == 32)
-        hipLaunchKernelGGL((mfma_gemm_kernel<MODE, NEG, 32>), grid, dim3(256), 0, s, M, Ncols, K, A, lda, B, ldb, C, ldc, xmul);
+        hipLaunchKernelGGL((mfma_gemm_kernel<MODE, NEG, 32>), mgrid, dim3(256), 0, s, M, Ncols, K, A, lda, B, ldb, C, ldc, xmul, pair_rows);
       else
-        hipLaunchKernelGGL((mfma_gemm_kernel<MODE, NEG, 16>), grid, dim3(256), 0, s, M, Ncols, K, A, lda, B, ldb, C, ldc, xmul);
+        hipLaunchKernelGGL((mfma_gemm_kernel<MODE, NEG, 16>), mgrid, dim3(256), 0, s, M, Ncols, K, A, lda, B, ldb, C, ldc, xmul, pair_rows);
     }
     else
       hipLaunchKernelGGL((tile_gemm_kernel<64, 64, MODE, 16, NEG>), grid, dim3(256), 0, s, M, Ncols, K, A, lda, B, ldb, C, ldc);
