@@ -1183,13 +1183,46 @@ KgPending kg_launch(GpDev& gp, int num_fidelity, const moe_gd_params_t& gd, cons
   return pending;
 }
 
+// How many evaluations one kg_launch may carry on this GP within `budget_gb` of device workspace (>= 1): the state
+// matrices E / VE / WE, the materialised tail matrix T (d-KG and m > 8) with its TB partials, the per-sample outputs.
+// A d-KG evaluation at C5 is 1.4 GB (N x M doubles of T alone), so a 200-start multistart cannot go down in one piece.
+int kg_max_batch(const GpDev& gp, int P, int q, int p, int num_local, bool want_grad, double budget_gb) {
+  const double N = gp.N, g1 = 1 + gp.g, u = q + p, m = u * g1, A = u + P;
+  const double ngrad = want_grad ? q * g1 * gp.d : 0.0;
+  const bool fused = want_grad && gp.g == 0 && m <= 8;
+  const double chunks = std::ceil((double)num_local / kTbChunk);
+  double doubles = 3.0 * N * (m + ngrad + A) + (double)num_local * (gp.dp + 1 + 2 * m);
+  if (want_grad) doubles += (fused ? 0.0 : N * (double)num_local) + (chunks + 1.0) * m * N;
+  const double per_eval_gb = 8.0 * doubles / 1e9;
+  return (int)std::max(1.0, std::floor(budget_gb / std::max(per_eval_gb, 1e-9)));
+}
+
 void kg_evaluate_batch(GpDev& gp, int num_fidelity, const moe_gd_params_t& gd, const double* bounds, const double* discrete,
                        int P, const double* Xq_all, int num_evals, const double* Xp, int q, int p, int num_mc,
                        double best_so_far, const double* normals, int first_sample, int num_local, bool want_grad,
                        double* kg_sum, double* grad_sum, double* best_points, moe_kg_stats_t* stats) {
-  KgPending pending = kg_launch(gp, num_fidelity, gd, bounds, discrete, P, Xq_all, num_evals, Xp, q, p, num_mc, best_so_far,
-                                normals, first_sample, num_local, want_grad, best_points != nullptr);
-  pending.collect(kg_sum, grad_sum, best_points, stats);
+  // batches beyond the workspace budget (MOE_KG_BATCH_GB, default 48) go down in pieces
+  const int max_e = kg_max_batch(gp, P, q, p, num_local, want_grad, (double)env_int("MOE_KG_BATCH_GB", 48));
+  if (num_evals <= max_e) {
+    KgPending pending = kg_launch(gp, num_fidelity, gd, bounds, discrete, P, Xq_all, num_evals, Xp, q, p, num_mc, best_so_far,
+                                  normals, first_sample, num_local, want_grad, best_points != nullptr);
+    pending.collect(kg_sum, grad_sum, best_points, stats);
+    return;
+  }
+  const size_t qd = (size_t)q * gp.d;
+  moe_kg_stats_t total{}, part{};
+  for (int e0 = 0; e0 < num_evals; e0 += max_e) {
+    const int ne = std::min(max_e, num_evals - e0);
+    KgPending pending = kg_launch(gp, num_fidelity, gd, bounds, discrete, P, Xq_all + (size_t)e0 * qd, ne, Xp, q, p, num_mc,
+                                  best_so_far, normals, first_sample, num_local, want_grad, false);
+    pending.collect(kg_sum + e0, grad_sum ? grad_sum + (size_t)e0 * qd : nullptr, nullptr, stats ? &part : nullptr);
+    total.posterior_mean_evals += part.posterior_mean_evals;
+    total.posterior_grad_evals += part.posterior_grad_evals;
+    total.ms_state += part.ms_state;
+    total.ms_mc += part.ms_mc;
+    total.ms_tail += part.ms_tail;
+  }
+  if (stats) *stats = total;
 }
 
 }  // namespace moe

@@ -33,6 +33,9 @@ void kg_evaluate_batch(GpDev& gp, int num_fidelity, const moe_gd_params_t& gd, c
 struct KgPending {
   std::function<void(double* kg_sum, double* grad_sum, double* best_points, moe_kg_stats_t* stats)> collect;
 };
+// Evaluations one kg_launch may carry within `budget_gb` of device workspace on this GP (see kg.hip).
+int kg_max_batch(const GpDev& gp, int P, int q, int p, int num_local, bool want_grad, double budget_gb);
+
 KgPending kg_launch(GpDev& gp, int num_fidelity, const moe_gd_params_t& gd, const double* bounds, const double* discrete, int P,
                     const double* Xq_all, int num_evals, const double* Xp, int q, int p, int num_mc, double best_so_far,
                     const double* normals, int first_sample, int num_local, bool want_grad, bool want_best_points);

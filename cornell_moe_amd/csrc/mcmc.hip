@@ -17,6 +17,8 @@
 #include "gp.hpp"
 #include "kg.hpp"
 
+#include <cstdlib>
+
 namespace moe {
 
 namespace {
@@ -43,16 +45,24 @@ void kg_mcmc_sums(const std::vector<GpDev*>& gps, int num_fidelity, const moe_gd
   const size_t disc_stride = (size_t)P * (d - num_fidelity);
   // launch every member (own stream, own workspaces), then collect: member i's kernels run while member i+1's state set-up
   // and host algebra are being prepared
-  std::vector<KgPending> pending;
-  pending.reserve(gps.size());
-  for (size_t i = 0; i < gps.size(); ++i)
-    pending.push_back(kg_launch(*gps[i], num_fidelity, inner, bounds, discrete_all + i * disc_stride, P, Xq_all, E, Xp, q, p,
-                                num_mc, best_so_far[i], normals, 0, num_mc, want_grad, false));
-  for (size_t i = 0; i < gps.size(); ++i) {
-    pending[i].collect(ks.data(), want_grad ? gs.data() : nullptr, nullptr, nullptr);
-    for (int e = 0; e < E; ++e) kg_sum[e] += ks[e] / (double)num_mc;
-    if (want_grad)
-      for (size_t j = 0; j < (size_t)E * qd; ++j) grad_sum[j] += gs[j] / (double)num_mc;
+  // (every member owns its workspaces: the batch each of them may carry is the budget divided by the ensemble size)
+  const char* bg = std::getenv("MOE_KG_BATCH_GB");
+  const double budget = ((bg && *bg) ? std::atof(bg) : 48.0) / (double)gps.size();
+  const int max_e = kg_max_batch(*gps[0], P, q, p, num_mc, want_grad, budget);
+  for (int e0 = 0; e0 < E; e0 += max_e) {
+    const int ne = std::min(max_e, E - e0);
+    std::vector<KgPending> pending;
+    pending.reserve(gps.size());
+    for (size_t i = 0; i < gps.size(); ++i)
+      pending.push_back(kg_launch(*gps[i], num_fidelity, inner, bounds, discrete_all + i * disc_stride, P,
+                                  Xq_all + (size_t)e0 * qd, ne, Xp, q, p, num_mc, best_so_far[i], normals, 0, num_mc, want_grad,
+                                  false));
+    for (size_t i = 0; i < gps.size(); ++i) {
+      pending[i].collect(ks.data(), want_grad ? gs.data() : nullptr, nullptr, nullptr);
+      for (int e = 0; e < ne; ++e) kg_sum[e0 + e] += ks[e] / (double)num_mc;
+      if (want_grad)
+        for (size_t j = 0; j < (size_t)ne * qd; ++j) grad_sum[(size_t)e0 * qd + j] += gs[j] / (double)num_mc;
+    }
   }
 }
 

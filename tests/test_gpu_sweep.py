@@ -93,6 +93,16 @@ def test_many_evaluations_per_batch(monkeypatch):
         for e in (0, 1, 255, 256, 299):
             one = G.kg(w.inner_gd, w.bounds, w.discrete, w.Xq_restarts[e], None, w.M, best, w.kg_normals)
             assert one["kg_sum"] == b["kg_sum"][e] and np.array_equal(one["grad_sum"], b["grad_sum"][e])
+    # a batch beyond the device-workspace budget goes down in pieces (kg_evaluate_batch): same results, same counters
+    monkeypatch.setenv("MOE_KG_BATCH_GB", "0")  # budget 0 -> one evaluation per piece
+    w2 = make_workload(seed=121, n=40, d=3, q=2, M=12, P=4, derivs=(1,), num_restarts=7)
+    G2 = api.DeviceGP(w2.hyperparameters, w2.X, w2.y, w2.noise, w2.derivs)
+    best2 = float(G2.additional_mean(w2.discrete).min())
+    pieces = G2.kg_batch(w2.inner_gd, w2.bounds, w2.discrete, w2.Xq_restarts, None, w2.M, best2, w2.kg_normals)
+    monkeypatch.delenv("MOE_KG_BATCH_GB")
+    whole = G2.kg_batch(w2.inner_gd, w2.bounds, w2.discrete, w2.Xq_restarts, None, w2.M, best2, w2.kg_normals)
+    assert np.array_equal(pieces["kg_sum"], whole["kg_sum"]) and np.array_equal(pieces["grad_sum"], whole["grad_sum"])
+    assert pieces["mean_evals"] == whole["mean_evals"] and pieces["grad_evals"] == whole["grad_evals"]
 
 
 def test_ei_against_oracle_sweep():
