@@ -675,7 +675,8 @@ void launch_mc_block(const KgMcParams& P, int dp, int G, int tr, int num_lds_til
 // workspaces) before collecting any of them overlaps one member's host algebra with the others' kernels.
 KgPending kg_launch(GpDev& gp, int num_fidelity, const moe_gd_params_t& gd, const double* bounds, const double* discrete, int P,
                     const double* Xq_all, int num_evals, const double* Xp, int q, int p, int num_mc, double best_so_far,
-                    const double* normals, int first_sample, int num_local, bool want_grad, bool want_best_points) {
+                    const double* normals, int first_sample, int num_local, bool want_grad, bool want_best_points,
+                    double weight_table_gb) {
   gp.use_device();
   hipStream_t s = gp.stream;
   const int d = gp.d, dp = gp.dp, f = num_fidelity, u = q + p, n = gp.n, g = gp.g, g1 = 1 + gp.g, N = gp.N;
@@ -1014,10 +1015,13 @@ KgPending kg_launch(GpDev& gp, int num_fidelity, const moe_gd_params_t& gd, cons
     const int pb = (int)std::min<long>((total + 3) / 4, (long)num_cu * 8);
     hipLaunchKernelGGL(kg_sample_prep_kernel, dim3(pb), dim3(256), 0, s, mp, gp.kBestJ.p);
     MOE_HIP_CHECK(hipGetLastError());
-    // the weight table: N doubles per sample (1.28 GB per evaluation at C5); beyond MOE_KG_V_MAX_GB (default 4: every GP
-    // handle of an MCMC ensemble owns one, next to its N x M tail matrix) the samples compute their weights in the kernel
+    // the weight table: N doubles per sample (1.28 GB per evaluation at C5); beyond its cap -- the caller's share of the
+    // workspace budget (kg_evaluate_batch, kg_mcmc_sums), MOE_KG_V_MAX_GB (default 4) for a bare kg_launch -- the samples
+    // compute their weights in the kernel
     const double v_gb = 8.0 * (double)N * (double)total / 1e9;
-    if (v_gb <= (double)env_int("MOE_KG_V_MAX_GB", 4)) {
+    const double v_cap = std::getenv("MOE_KG_V_MAX_GB") ? (double)env_int("MOE_KG_V_MAX_GB", 4)
+                                                        : (weight_table_gb >= 0.0 ? weight_table_gb : 4.0);
+    if (v_gb <= v_cap) {
       gp.kV.reserve((size_t)N * (size_t)total);
       MOE_HIP_CHECK(hipMemsetAsync(dBeta.p + (size_t)total * m, 0, sizeof(double) * 64, s));
       mp.V = gp.kV.p;
@@ -1193,6 +1197,7 @@ int kg_max_batch(const GpDev& gp, int P, int q, int p, int num_local, bool want_
   const double chunks = std::ceil((double)num_local / kTbChunk);
   double doubles = 3.0 * N * (m + ngrad + A) + (double)num_local * (gp.dp + 1 + 2 * m);
   if (want_grad) doubles += (fused ? 0.0 : N * (double)num_local) + (chunks + 1.0) * m * N;
+  if (gp.g > 0 || gp.n + u > 1500) doubles += N * (double)num_local;  // the workgroup-per-sample kernel's weight table
   const double per_eval_gb = 8.0 * doubles / 1e9;
   return (int)std::max(1.0, std::floor(budget_gb / std::max(per_eval_gb, 1e-9)));
 }
@@ -1202,10 +1207,11 @@ void kg_evaluate_batch(GpDev& gp, int num_fidelity, const moe_gd_params_t& gd, c
                        double best_so_far, const double* normals, int first_sample, int num_local, bool want_grad,
                        double* kg_sum, double* grad_sum, double* best_points, moe_kg_stats_t* stats) {
   // batches beyond the workspace budget (MOE_KG_BATCH_GB, default 48) go down in pieces
-  const int max_e = kg_max_batch(gp, P, q, p, num_local, want_grad, (double)env_int("MOE_KG_BATCH_GB", 48));
+  const double budget = (double)env_int("MOE_KG_BATCH_GB", 48);
+  const int max_e = kg_max_batch(gp, P, q, p, num_local, want_grad, budget);
   if (num_evals <= max_e) {
     KgPending pending = kg_launch(gp, num_fidelity, gd, bounds, discrete, P, Xq_all, num_evals, Xp, q, p, num_mc, best_so_far,
-                                  normals, first_sample, num_local, want_grad, best_points != nullptr);
+                                  normals, first_sample, num_local, want_grad, best_points != nullptr, budget);
     pending.collect(kg_sum, grad_sum, best_points, stats);
     return;
   }
@@ -1214,7 +1220,7 @@ void kg_evaluate_batch(GpDev& gp, int num_fidelity, const moe_gd_params_t& gd, c
   for (int e0 = 0; e0 < num_evals; e0 += max_e) {
     const int ne = std::min(max_e, num_evals - e0);
     KgPending pending = kg_launch(gp, num_fidelity, gd, bounds, discrete, P, Xq_all + (size_t)e0 * qd, ne, Xp, q, p, num_mc,
-                                  best_so_far, normals, first_sample, num_local, want_grad, false);
+                                  best_so_far, normals, first_sample, num_local, want_grad, false, budget);
     pending.collect(kg_sum + e0, grad_sum ? grad_sum + (size_t)e0 * qd : nullptr, nullptr, stats ? &part : nullptr);
     total.posterior_mean_evals += part.posterior_mean_evals;
     total.posterior_grad_evals += part.posterior_grad_evals;

@@ -38,7 +38,8 @@ int kg_max_batch(const GpDev& gp, int P, int q, int p, int num_local, bool want_
 
 KgPending kg_launch(GpDev& gp, int num_fidelity, const moe_gd_params_t& gd, const double* bounds, const double* discrete, int P,
                     const double* Xq_all, int num_evals, const double* Xp, int q, int p, int num_mc, double best_so_far,
-                    const double* normals, int first_sample, int num_local, bool want_grad, bool want_best_points);
+                    const double* normals, int first_sample, int num_local, bool want_grad, bool want_best_points,
+                    double weight_table_gb = -1.0);  // cap of the per-sample weight table; < 0: MOE_KG_V_MAX_GB (default 4)
 
 // ---- callers of the hot path (multistart.hip) ----
 // A maximisation objective evaluated at a BATCH of points [n][qd]: values [n], grads [n][qd].

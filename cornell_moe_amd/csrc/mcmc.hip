@@ -56,7 +56,7 @@ void kg_mcmc_sums(const std::vector<GpDev*>& gps, int num_fidelity, const moe_gd
     for (size_t i = 0; i < gps.size(); ++i)
       pending.push_back(kg_launch(*gps[i], num_fidelity, inner, bounds, discrete_all + i * disc_stride, P,
                                   Xq_all + (size_t)e0 * qd, ne, Xp, q, p, num_mc, best_so_far[i], normals, 0, num_mc, want_grad,
-                                  false));
+                                  false, budget));
     for (size_t i = 0; i < gps.size(); ++i) {
       pending[i].collect(ks.data(), want_grad ? gs.data() : nullptr, nullptr, nullptr);
       for (int e = 0; e < ne; ++e) kg_sum[e0 + e] += ks[e] / (double)num_mc;
