@@ -122,7 +122,29 @@ km = G.last_kernel_ms()
 c5["kernel_ms"] = {k: float(v) for k, v in km.items()}
 c5["note"] = ("reference CPU path not timed at this size: one evaluation re-factorises the (N+m)^2 = 8032^2 fantasy matrix "
               "(1.7e11 flop at ~2 GFLOP/s) and re-solves it for each of the 20000 samples (2.6e12 flop): hours")
+Xq4 = np.random.default_rng(5).uniform(0.05, 0.95, size=(4,) + w.Xq.shape)
+t4 = timeit(lambda: G.kg_batch(w.inner_gd, w.bounds, w.discrete, Xq4, None, w.M, best, w.kg_normals), reps=2)
+c5["gpu_batch_4_evals_per_s"] = 4.0 / t4
+t0 = time.perf_counter()
+G.add_points(np.random.default_rng(6).uniform(size=(4, 12)), np.zeros((4, 4)))
+c5["gpu_add_4_points_s"] = time.perf_counter() - t0
 ms, nbytes = G.cov_build_probe(np.random.default_rng(1).uniform(size=(20000, 12)), repeat=5)
 out["cov_build_N8000xM20000_derivative_rows"] = {"ms": ms, "GB_per_s": nbytes / ms / 1e6, "frac_of_8TBs": nbytes / ms / 1e6 / 8000.0}
 out["C5"] = c5
+
+# ---- log marginal likelihood and its hyper-parameter gradient at C3's data ----
+from cornell_moe_amd.api import LogLikelihood  # noqa: E402
+w = make_workload("C3")
+LL = LogLikelihood(w.X, w.y, ())
+sets = np.tile(np.r_[w.hyperparameters, w.noise], (64, 1)) * np.linspace(0.7, 1.3, 64)[:, None]
+LL.evaluate(sets)
+ll = {}
+for k in (1, 8, 64):
+    ll["ms_per_set_in_calls_of_%d" % k] = 1e3 * timeit(lambda: LL.evaluate(sets[:k]), reps=5) / k
+ll["grad_ms_per_set"] = 1e3 * timeit(lambda: LL.grad(sets[0]), reps=5)
+if HAVE_REF:
+    t0 = time.perf_counter()
+    ref.log_likelihood(1, w.alpha, w.lengths, w.X, w.y, w.noise, [])
+    ll["ref_1core_ms_per_set"] = 1e3 * (time.perf_counter() - t0)
+out["log_likelihood_n1000"] = ll
 print(json.dumps(out, indent=1))
