@@ -167,6 +167,31 @@ def test_golden_log_likelihood_grad(api):
         api.LogLikelihood(X[:20], np.zeros((20, 1))).grad(np.r_[1.0, np.full(d, 0.5), -2.0])
 
 
+def test_log_likelihood_and_append_edges(api):
+    """Sizes around the blocking of the factorisations (1, 2, 64, 65, 129 rows, with and without a derivative row per point),
+    an empty hyper-parameter list, and a GP grown one observation at a time from a single point."""
+    from oracle import orc
+    rng = np.random.default_rng(0)
+    for n, d, derivs in ((1, 1, ()), (2, 3, ()), (3, 2, (0,)), (65, 2, ()), (64, 2, (1,)), (129, 1, ())):
+        g = len(derivs)
+        X, y = rng.uniform(size=(n, d)), rng.uniform(size=(n, 1 + g))
+        th = np.r_[1.1, np.full(d, 0.6), np.full(1 + g, 0.05)]
+        LL = api.LogLikelihood(X, y, derivs)
+        v = LL.evaluate(np.array([th, th * 1.1]))[0]
+        gr = LL.grad(th)
+        vo = orc.log_likelihood(1, th[0], th[1:1 + d], X, y, th[1 + d:], derivs)
+        go = orc.log_likelihood_grad(1, th[0], th[1:1 + d], X, y, th[1 + d:], derivs)
+        assert abs(v - vo) <= 1e-10 * max(1.0, abs(vo)) and np.abs(gr - go).max() <= 1e-8 * max(1.0, np.abs(go).max())
+    assert LL.evaluate(np.zeros((0, th.size))).size == 0
+    X, y = rng.uniform(size=(40, 2)), rng.uniform(size=(40, 1))
+    a = api.DeviceGP([1.0, 0.5, 0.5], X[:1], y[:1], [0.01])
+    for i in range(1, 40):
+        a.add_points(X[i:i + 1], y[i:i + 1])
+    b = api.DeviceGP([1.0, 0.5, 0.5], X, y, [0.01])
+    q = rng.uniform(size=(5, 2))
+    assert np.abs(a.mean(q) - b.mean(q)).max() <= 1e-11 and np.abs(a.variance(q) - b.variance(q)).max() <= 1e-11
+
+
 def test_golden_kg(api, golden):
     cases, _ = golden
     ran = 0
