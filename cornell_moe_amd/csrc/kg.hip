@@ -185,13 +185,17 @@ __global__ __launch_bounds__(256) void kg_tb_kernel(KgTailParams P) {
 #pragma unroll
   for (int c = 0; c < MU; ++c) acc[c] = 0.0;
   const bool ok = row < P.N;
+  const double* __restrict__ Tcol = P.T + (ok ? row : 0);
+  const double* __restrict__ beta = P.beta;
+#pragma unroll 4
   for (int i = i0; i < i1; ++i) {
     const long w = (long)e * P.num_local + i;
-    const double t = ok ? P.T[w * P.N + row] : 0.0;
-    const double* b = P.beta + w * m;
+    const double t = Tcol[w * P.N];
+    const double* __restrict__ b = beta + w * m;
+    // all MU entries unconditionally (uniform, contiguous: wide scalar loads, no branch per entry); the entries beyond m
+    // belong to the next sample / the pad behind the buffer and only feed accumulators that are never stored
 #pragma unroll
-    for (int c = 0; c < MU; ++c)
-      if (c < m) acc[c] = fma(t, b[c], acc[c]);
+    for (int c = 0; c < MU; ++c) acc[c] = fma(t, b[c], acc[c]);
   }
   if (ok) {
     double* dst = P.TBpart + ((long)e * P.chunks + chunk) * m * P.N;
