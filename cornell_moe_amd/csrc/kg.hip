@@ -101,6 +101,7 @@ struct KgTailParams {
 };
 
 constexpr int kTbChunk = 256;  // samples per workgroup of kg_tb_kernel / kg_fused_point_kernel
+constexpr int kDirSlices = 32;  // sample ranges of kg_dir_kernel
 
 // c_i = L^-1 ( K(Xu, x*_i)[:, 0] - W^T T_i ) for every sample; one wavefront per sample at a time, lane r owns component r.
 // S_W = W^T T_i comes either precomputed (P.SW: tile GEMM, large m) or is formed here by lanes striding the N rows with
@@ -266,9 +267,13 @@ __global__ __launch_bounds__(256) void kg_zc_kernel(KgTailParams P) {
 
 // DIR[e][(k (1+g) + b) d + dd] = sum_i beta_i[(k,b)] * d cov(Xu_k, x*_i)[b, 0] / d Xu_k,dd ; workgroup (k, e).
 template <int DP>
-__global__ __launch_bounds__(256) void kg_dir_kernel(KgTailParams P) {
+__global__ __launch_bounds__(256) void kg_dir_kernel(KgTailParams P, double* __restrict__ part, int slices) {
   __shared__ double red[4];
-  const int k = blockIdx.x, e = blockIdx.y;
+  const int k = blockIdx.x, e = blockIdx.y, sl = blockIdx.z;
+  // the samples are cut into `slices` contiguous ranges (grid.z) so that q x E workgroups become q x E x slices -- at C5
+  // eight workgroups walked 20 000 samples each while 248 CUs idled; kg_dir_sum_kernel adds the partials in slice order
+  const int per = (P.num_local + slices - 1) / slices;
+  const int i_lo = sl * per, i_hi = min(P.num_local, i_lo + per);
   const int m = P.m, g1 = 1 + P.g, d = P.cp.dim;
   const double* Xu = P.blob + (long)e * P.rec.stride + P.rec.XuP + (long)k * DP;
   DerivList none;
@@ -280,7 +285,7 @@ __global__ __launch_bounds__(256) void kg_dir_kernel(KgTailParams P) {
     double acc[DP];
 #pragma unroll
     for (int dd = 0; dd < DP; ++dd) acc[dd] = 0.0;
-    for (int i = threadIdx.x; i < P.num_local; i += 256) {
+    for (int i = i_lo + threadIdx.x; i < i_hi; i += 256) {
       const long w = (long)e * P.num_local + i;
       const double* xs = P.best_point + w * DP;
       double diff[DP];
@@ -300,10 +305,29 @@ __global__ __launch_bounds__(256) void kg_dir_kernel(KgTailParams P) {
     for (int dd = 0; dd < DP; ++dd) {
       if (dd < d) {  // d is workgroup-uniform
         const double tot = block_sum_256(acc[dd], red);
-        if (threadIdx.x == 0) P.out[(long)e * P.out_stride + 1 + m * m + (k * g1 + b) * d + dd] = tot;
+        if (threadIdx.x == 0) part[((long)e * P.ngrad + (k * g1 + b) * d + dd) * slices + sl] = tot;
       }
     }
   }
+}
+
+__global__ __launch_bounds__(256) void kg_dir_sum_kernel(KgTailParams P, const double* __restrict__ part, int slices) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;  // over E * ngrad
+  if (idx >= P.E * P.ngrad) return;
+  const int e = idx / P.ngrad, gc = idx % P.ngrad;
+  double tot = 0.0;
+  for (int sl = 0; sl < slices; ++sl) tot += part[(long)idx * slices + sl];
+  P.out[(long)e * P.out_stride + 1 + P.m * P.m + gc] = tot;
+}
+
+template <int DP>
+void launch_dir(const KgTailParams& P, hipStream_t s) {
+  // partials live behind the summed TB in the TB buffer (the host reserves E * ngrad * kDirSlices doubles more)
+  const long mn = (long)P.m * P.N;
+  double* part = P.TBpart + (long)P.E * (P.chunks + 1) * mn;
+  const int slices = std::max(1, std::min(kDirSlices, (P.num_local + 255) / 256));
+  hipLaunchKernelGGL((kg_dir_kernel<DP>), dim3(P.q, P.E, slices), dim3(256), 0, s, P, part, slices);
+  hipLaunchKernelGGL(kg_dir_sum_kernel, dim3((P.E * P.ngrad + 255) / 256), dim3(256), 0, s, P, (const double*)part, slices);
 }
 
 template <int DP, int MU>
@@ -328,7 +352,7 @@ void launch_sw_dp(const KgTailParams& P, hipStream_t s) {
     launch_sw_inst<DP, 32>(P, s);
   else
     launch_sw_inst<DP, 64>(P, s);
-  hipLaunchKernelGGL((kg_dir_kernel<DP>), dim3(P.q, P.E), dim3(256), 0, s, P);
+  launch_dir<DP>(P, s);
 }
 
 void launch_tail(const KgTailParams& P, hipStream_t s) {
@@ -516,7 +540,7 @@ void launch_fused_tail_cov(const KgTailParams& P, const double* X, int n, double
   dim3 ga((P.num_local + 255) / 256, P.E, slices), gc((P.num_local + 255) / 256, P.E), gb((n + 255) / 256, P.chunks, P.E);
   hipLaunchKernelGGL((kg_fused_sample_kernel<DP, MU, COV>), ga, dim3(256), 0, s, P, X, n, SWpart);
   hipLaunchKernelGGL((kg_fused_c_kernel<DP, MU, COV>), gc, dim3(256), 0, s, P, SWpart, slices);
-  hipLaunchKernelGGL((kg_dir_kernel<DP>), dim3(P.q, P.E), dim3(256), 0, s, P);
+  launch_dir<DP>(P, s);
   hipLaunchKernelGGL((kg_fused_point_kernel<DP, MU, COV>), gb, dim3(256), 0, s, P, X, n);
   launch_gtb(P, s);
   MOE_HIP_CHECK(hipGetLastError());
@@ -948,7 +972,7 @@ KgPending kg_launch(GpDev& gp, int num_fidelity, const moe_gd_params_t& gd, cons
   if (want_grad) {
     if (!fused_tail) dT.reserve((size_t)N * E * num_local);
     dC.reserve((size_t)E * num_local * m);
-    dTB.reserve((size_t)E * (chunks + 1) * m * N);  // chunk partials + their sum
+    dTB.reserve((size_t)E * (chunks + 1) * m * N + (size_t)E * ngrad * kDirSlices);  // chunk partials + their sum + DIR partials
   }
   MOE_HIP_CHECK(hipMemsetAsync(dCounters.p, 0, sizeof(unsigned long long) * n_ctr, s));
 
