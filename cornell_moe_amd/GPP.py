@@ -469,7 +469,7 @@ class GaussianProcessMCMC(object):
     noise_variance_list flat [num_mcmc][1 + num_derivatives]."""
 
     def __init__(self, hyperparameters_list, noise_variance_list, points_sampled, points_sampled_value, derivatives, num_mcmc,
-                 num_derivatives, dim, num_sampled, device=0):
+                 num_derivatives, dim, num_sampled, device=None):
         self.dim = int(dim)
         self.num_mcmc = int(num_mcmc)
         self._g = int(num_derivatives)
@@ -478,6 +478,8 @@ class GaussianProcessMCMC(object):
         hyp = _flat(hyperparameters_list, self.num_mcmc * (dim + 1)).reshape(self.num_mcmc, dim + 1)
         noise = _flat(noise_variance_list, self.num_mcmc * (1 + self._g)).reshape(self.num_mcmc, 1 + self._g)
         derivs = [int(v) for v in list(derivatives)[:self._g]]
+        if device is None:  # one process per GPU: the ensemble lives on this rank's device, like GaussianProcess
+            device = int(os.environ.get("LOCAL_RANK", "0")) % max(_lib.device_count(), 1)
         self._dev = _api.DeviceGPMCMC(hyp, noise, X, y, derivs, device=device)
 
     num_sampled = property(lambda self: self._dev.n)

@@ -704,7 +704,7 @@ void launch_mc_block(const KgMcParams& P, int dp, int G, int tr, int num_lds_til
 KgPending kg_launch(GpDev& gp, int num_fidelity, const moe_gd_params_t& gd, const double* bounds, const double* discrete, int P,
                     const double* Xq_all, int num_evals, const double* Xp, int q, int p, int num_mc, double best_so_far,
                     const double* normals, int first_sample, int num_local, bool want_grad, bool want_best_points,
-                    double weight_table_gb) {
+                    double weight_table_gb, const double* disc_head) {
   gp.use_device();
   hipStream_t s = gp.stream;
   const int d = gp.d, dp = gp.dp, f = num_fidelity, u = q + p, n = gp.n, g = gp.g, g1 = 1 + gp.g, N = gp.N;
@@ -796,7 +796,12 @@ KgPending kg_launch(GpDev& gp, int num_fidelity, const moe_gd_params_t& gd, cons
     std::copy(Xq, Xq + (size_t)q * d, U);
     if (p > 0) std::copy(Xp, Xp + (size_t)p * d, U + (size_t)q * d);
     double* ds = &disc_all[(size_t)e * A * size];
-    for (int i = 0; i < u; ++i) std::copy(U + (size_t)i * d, U + (size_t)i * d + size, ds + (size_t)i * size);
+    // (disc_head: the state this evaluation runs on was BUILT at other points_to_sample and moved here with SetCurrentPoint,
+    //  which leaves the discretised set behind -- .cpp:232-243 vs 259-261; the reference's multistart drivers do that)
+    for (int i = 0; i < u; ++i) {
+      const double* src = (disc_head != nullptr && i < q) ? disc_head + (size_t)i * d : U + (size_t)i * d;
+      std::copy(src, src + size, ds + (size_t)i * size);
+    }
     std::copy(discrete, discrete + (size_t)P * size, ds + (size_t)u * size);
     double* ex = &extra_all[(size_t)e * A * d];
     for (int j = 0; j < A; ++j) {
@@ -845,6 +850,8 @@ KgPending kg_launch(GpDev& gp, int num_fidelity, const moe_gd_params_t& gd, cons
           for (int i = 0; i < q; ++i) ext = std::max(ext, std::fabs(Xq_all[((size_t)e * q + i) * d + k] - c));
         }
         for (int i = 0; i < p; ++i) ext = std::max(ext, std::fabs(Xp[(size_t)i * d + k] - c));
+        if (disc_head != nullptr)
+          for (int i = 0; i < q; ++i) ext = std::max(ext, std::fabs(disc_head[(size_t)i * d + k] - c));
         if (!(ext * tp.inv_lp[r] <= mc::kTableExtent))
           throw Error(MOE_ERR_BOUNDS, "length scale too small for the extent of the points (|x - mean| / length > 1e5)",
                       ext * tp.inv_lp[r], 0.0, mc::kTableExtent);
@@ -1233,13 +1240,13 @@ int kg_max_batch(const GpDev& gp, int P, int q, int p, int num_local, bool want_
 void kg_evaluate_batch(GpDev& gp, int num_fidelity, const moe_gd_params_t& gd, const double* bounds, const double* discrete,
                        int P, const double* Xq_all, int num_evals, const double* Xp, int q, int p, int num_mc,
                        double best_so_far, const double* normals, int first_sample, int num_local, bool want_grad,
-                       double* kg_sum, double* grad_sum, double* best_points, moe_kg_stats_t* stats) {
+                       double* kg_sum, double* grad_sum, double* best_points, moe_kg_stats_t* stats, const double* disc_head) {
   // batches beyond the workspace budget (MOE_KG_BATCH_GB, default 48) go down in pieces
   const double budget = (double)env_int("MOE_KG_BATCH_GB", 48);
   const int max_e = kg_max_batch(gp, P, q, p, num_local, want_grad, budget);
   if (num_evals <= max_e) {
     KgPending pending = kg_launch(gp, num_fidelity, gd, bounds, discrete, P, Xq_all, num_evals, Xp, q, p, num_mc, best_so_far,
-                                  normals, first_sample, num_local, want_grad, best_points != nullptr, budget);
+                                  normals, first_sample, num_local, want_grad, best_points != nullptr, budget, disc_head);
     pending.collect(kg_sum, grad_sum, best_points, stats);
     return;
   }
@@ -1248,7 +1255,7 @@ void kg_evaluate_batch(GpDev& gp, int num_fidelity, const moe_gd_params_t& gd, c
   for (int e0 = 0; e0 < num_evals; e0 += max_e) {
     const int ne = std::min(max_e, num_evals - e0);
     KgPending pending = kg_launch(gp, num_fidelity, gd, bounds, discrete, P, Xq_all + (size_t)e0 * qd, ne, Xp, q, p, num_mc,
-                                  best_so_far, normals, first_sample, num_local, want_grad, false, budget);
+                                  best_so_far, normals, first_sample, num_local, want_grad, false, budget, disc_head);
     pending.collect(kg_sum + e0, grad_sum ? grad_sum + (size_t)e0 * qd : nullptr, nullptr, stats ? &part : nullptr);
     total.posterior_mean_evals += part.posterior_mean_evals;
     total.posterior_grad_evals += part.posterior_grad_evals;

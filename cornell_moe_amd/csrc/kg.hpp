@@ -23,10 +23,16 @@ void ei_analytic_batch(GpDev& gp, const double* pts, int num_evals, double best_
 // KnowledgeGradientEvaluator::Compute[Grad]KnowledgeGradient (gpp_knowledge_gradient_optimization.cpp:69-227) for
 // `num_evals` independent points_to_sample sets; see include/moe_hip.h (moe_kg / moe_kg_batch) for argument meaning.
 // best_points (may be NULL) is only filled for num_evals == 1.
+// disc_head [q][dim] (or NULL): the points_to_sample the evaluating state was BUILT at.  KnowledgeGradientState's constructor
+// fills its discretised set with [union points ; discrete points] (.cpp:259-261) and SetCurrentPoint (.cpp:232-243) does not
+// refresh it, so the reference's multistart / point-list drivers -- which build their states at the first start and move them
+// (gpp_knowledge_gradient_optimization.hpp:886-889) -- score and start every inner optimisation from the FIRST start's points.
+// NULL = a fresh state per evaluation (the single-evaluation entry points, gpp_python_knowledge_gradient.cpp:74-154).
 void kg_evaluate_batch(GpDev& gp, int num_fidelity, const moe_gd_params_t& gd, const double* bounds, const double* discrete,
                        int P, const double* Xq_all, int num_evals, const double* Xp, int q, int p, int num_mc,
                        double best_so_far, const double* normals, int first_sample, int num_local, bool want_grad,
-                       double* kg_sum, double* grad_sum, double* best_points, moe_kg_stats_t* stats);
+                       double* kg_sum, double* grad_sum, double* best_points, moe_kg_stats_t* stats,
+                       const double* disc_head = nullptr);
 
 // kg_evaluate_batch split at its only wait: kg_launch does the state set-up, the host m x m algebra and every
 // asynchronous launch on gp.stream; collect() waits for the stream and assembles kg_sum / grad_sum (same meaning as above).
@@ -39,7 +45,8 @@ int kg_max_batch(const GpDev& gp, int P, int q, int p, int num_local, bool want_
 KgPending kg_launch(GpDev& gp, int num_fidelity, const moe_gd_params_t& gd, const double* bounds, const double* discrete, int P,
                     const double* Xq_all, int num_evals, const double* Xp, int q, int p, int num_mc, double best_so_far,
                     const double* normals, int first_sample, int num_local, bool want_grad, bool want_best_points,
-                    double weight_table_gb = -1.0);  // cap of the per-sample weight table; < 0: MOE_KG_V_MAX_GB (default 4)
+                    double weight_table_gb = -1.0,  // cap of the per-sample weight table; < 0: MOE_KG_V_MAX_GB (default 4)
+                    const double* disc_head = nullptr);
 
 // ---- callers of the hot path (multistart.hip) ----
 // A maximisation objective evaluated at a BATCH of points [n][qd]: values [n], grads [n][qd].
@@ -73,7 +80,12 @@ void posterior_mean_optimize(GpDev& gp, int num_fidelity, const moe_gd_params_t&
 // Sums over the given GPs of the per-GP KG / grad KG (each already divided by num_mc): kg_sum[E], grad_sum[E][q*d].
 void kg_mcmc_sums(const std::vector<GpDev*>& gps, int num_fidelity, const moe_gd_params_t& inner, const double* bounds,
                   const double* discrete_all, int P, const double* Xq_all, int num_evals, const double* Xp, int q, int p,
-                  int num_mc, const double* best_so_far, const double* normals, bool want_grad, double* kg_sum, double* grad_sum);
+                  int num_mc, const double* best_so_far, const double* normals, bool want_grad, double* kg_sum, double* grad_sum,
+                  const double* disc_head = nullptr);
+// The reference's top-20 selection, tie for tie: the order in which its std::priority_queue of (-value, index) pairs pops the
+// kept starts (gpp_knowledge_gradient_optimization.hpp:895-921, gpp_math.hpp:1717-1738) -- lowest kept value first, equal values
+// by descending index.  All starts are kept when there are fewer than 20 (the reference pops an under-filled queue).
+std::vector<int> top_k_order(const double* vals, int num_starts);
 // KnowledgeGradientMCMCEvaluator::Compute[Grad]KnowledgeGradient's last step (.cpp:84-180): divide by num_mcmc and by the
 // fidelity cost (and add the cost-gradient term).  In place; grad may be NULL.
 void kg_mcmc_finalize(double* kg, double* grad, const double* Xq_all, int num_evals, int q, int d, int num_fidelity, int num_mcmc);

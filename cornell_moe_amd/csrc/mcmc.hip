@@ -36,7 +36,8 @@ void check_ensemble(const std::vector<GpDev*>& gps) {
 
 void kg_mcmc_sums(const std::vector<GpDev*>& gps, int num_fidelity, const moe_gd_params_t& inner, const double* bounds,
                   const double* discrete_all, int P, const double* Xq_all, int num_evals, const double* Xp, int q, int p,
-                  int num_mc, const double* best_so_far, const double* normals, bool want_grad, double* kg_sum, double* grad_sum) {
+                  int num_mc, const double* best_so_far, const double* normals, bool want_grad, double* kg_sum, double* grad_sum,
+                  const double* disc_head) {
   check_ensemble(gps);
   const int d = gps[0]->d, qd = q * d, E = num_evals;
   std::fill(kg_sum, kg_sum + E, 0.0);
@@ -56,7 +57,7 @@ void kg_mcmc_sums(const std::vector<GpDev*>& gps, int num_fidelity, const moe_gd
     for (size_t i = 0; i < gps.size(); ++i)
       pending.push_back(kg_launch(*gps[i], num_fidelity, inner, bounds, discrete_all + i * disc_stride, P,
                                   Xq_all + (size_t)e0 * qd, ne, Xp, q, p, num_mc, best_so_far[i], normals, 0, num_mc, want_grad,
-                                  false, budget));
+                                  false, budget, disc_head));
     for (size_t i = 0; i < gps.size(); ++i) {
       pending[i].collect(ks.data(), want_grad ? gs.data() : nullptr, nullptr, nullptr);
       for (int e = 0; e < ne; ++e) kg_sum[e0 + e] += ks[e] / (double)num_mc;
@@ -122,26 +123,155 @@ void ei_mcmc_batch(const std::vector<GpDev*>& gps, const double* Xq_all, int num
     for (size_t j = 0; j < (size_t)E * qd; ++j) grad_ei[j] *= inv;
 }
 
+namespace {
+
+// TensorProductDomain::LimitUpdate (gpp_domain.cpp:64-105) on one coordinate.
+double limit_update_coord(double lo, double hi, double max_relative_change, double x, double desired) {
+  double dist = std::fmin(x - lo, hi - x);
+  if (std::fabs(desired) > max_relative_change * dist) desired = std::copysign(max_relative_change * dist, desired);
+  const double next = x + desired;
+  if (next < lo) {
+    desired = (x + desired * 0.5 < lo) ? (lo - x) * 0.5 : desired * 0.5;
+  } else if (next > hi) {
+    desired = (x + desired * 0.5 > hi) ? (hi - x) * 0.5 : desired * 0.5;
+  }
+  return desired;
+}
+
+// ComputeCost / ComputeGradCost (.cpp:84-127) on the points the MCMC state holds; gcost[qd] (may be NULL).
+double fidelity_cost(const double* x, int q, int d, int num_fidelity, double* gcost) {
+  if (gcost) std::fill(gcost, gcost + (size_t)q * d, 0.0);
+  if (num_fidelity == 0) return 1.0;
+  double cost = 0.0;
+  int index = -1;
+  for (int i = 0; i < q; ++i) {
+    double pc = 1.0;
+    for (int j = d - num_fidelity; j < d; ++j) pc *= x[i * d + j];
+    if (cost < pc) {
+      cost = pc;
+      index = i;
+    }
+  }
+  if (gcost && index >= 0)
+    for (int j = d - num_fidelity; j < d; ++j) gcost[index * d + j] = cost / x[index * d + j];
+  return cost;
+}
+
+}  // namespace
+
+// ComputeKGMCMCOptimalPointsToSampleViaMultistartGradientDescent / EvaluateKGMCMCAtPointList
+// (gpp_knowledge_gradient_mcmc_optimization.hpp:665-862) AS THE REFERENCE EXECUTES THEM.  Its KnowledgeGradientMCMCState
+//   * forwards all q points to the per-GP states in SetCurrentPoint but copies only the FIRST point into its own
+//     union_of_points (.cpp:186-195: `points_to_sample_in + dim`), which is what GetCurrentPoint returns (.hpp:439-441) and what
+//     the fidelity cost reads: the optimiser steps from, and reports, [moved first point ; the other points of the state's
+//     construction point = starts[0]], while the objective is evaluated where the per-GP states really are;
+//   * the evaluator's gradient accumulates into its output (.cpp:163-166), a vector GradientDescentOptimization allocates once
+//     per restart (gpp_optimization.hpp:626): step i sees G_i = ((G_{i-1} + sum_i) / num_mcmc * cost - KG * gradcost) / cost^2;
+//   * the per-GP states keep the discretised set of starts[0] (kg.hpp: disc_head).
+// With q = 1 and no fidelity dimension only the last two are visible.  Pinned to the reference's end point
+// (tests/golden/ref_kg_multistart.npz).  Every step evaluates all live restarts of all ensemble members in batched passes.
 void kg_mcmc_multistart(const std::vector<GpDev*>& gps, int num_fidelity, const moe_gd_params_t& outer,
                         const moe_gd_params_t& inner, const double* bounds, const double* discrete_all, int P,
                         const double* starts, int num_starts, const double* Xp, int q, int p, int num_mc,
                         const double* best_so_far, const double* normals, int do_gradient_ascent, double* best_points,
                         double* best_kg, int* found) {
   check_ensemble(gps);
-  const int d = gps[0]->d, qd = q * d, M = (int)gps.size();
-  BatchObjective f;
-  f.values = [&](const double* x_all, int n, double* values) {
-    kg_mcmc_sums(gps, num_fidelity, inner, bounds, discrete_all, P, x_all, n, Xp, q, p, num_mc, best_so_far, normals, false,
-                 values, nullptr);
-    kg_mcmc_finalize(values, nullptr, x_all, n, q, d, num_fidelity, M);
+  if (num_starts <= 0) throw Error(MOE_ERR_BOUNDS, "num_multistarts must be > 1", num_starts, 1, 1e9);
+  const int d = gps[0]->d, qd = q * d, nm = (int)gps.size();
+  const double* head = starts;
+  auto seen_of = [&](const double* actual, double* seen) {  // what GetCurrentPoint returns for a state moved to `actual`
+    std::copy(head, head + qd, seen);
+    std::copy(actual, actual + d, seen);
   };
-  f.grads = [&](const double* x_all, int n, double* grads) {
-    std::vector<double> vals(n);
-    kg_mcmc_sums(gps, num_fidelity, inner, bounds, discrete_all, P, x_all, n, Xp, q, p, num_mc, best_so_far, normals, true,
-                 vals.data(), grads);
-    kg_mcmc_finalize(vals.data(), grads, x_all, n, q, d, num_fidelity, M);
+  auto sums = [&](const double* x_all, int n, bool want_grad, double* ks, double* gs) {
+    kg_mcmc_sums(gps, num_fidelity, inner, bounds, discrete_all, P, x_all, n, Xp, q, p, num_mc, best_so_far, normals, want_grad, ks,
+                 gs, head);
   };
-  multistart(f, outer, bounds, d, qd, starts, num_starts, do_gradient_ascent, -INFINITY, best_points, best_kg, found);
+  *found = 0;
+  *best_kg = -INFINITY;
+  std::vector<double> seen(qd);
+  // value at every start: per-GP states at the start itself, cost from what the MCMC state holds
+  std::vector<double> vals(num_starts);
+  sums(starts, num_starts, false, vals.data(), nullptr);
+  for (int s = 0; s < num_starts; ++s) {
+    seen_of(starts + (size_t)s * qd, seen.data());
+    vals[s] /= (double)nm * fidelity_cost(seen.data(), q, d, num_fidelity, nullptr);
+  }
+  std::vector<int> order;
+  if (do_gradient_ascent) {
+    order = top_k_order(vals.data(), num_starts);
+  } else {
+    order.resize(num_starts);
+    for (int s = 0; s < num_starts; ++s) order[s] = s;
+  }
+  const int S = (int)order.size();
+  std::vector<double> actual((size_t)S * qd), seen_all((size_t)S * qd);
+  for (int s = 0; s < S; ++s) {
+    std::copy(starts + (size_t)order[s] * qd, starts + (size_t)(order[s] + 1) * qd, &actual[(size_t)s * qd]);
+    seen_of(&actual[(size_t)s * qd], &seen_all[(size_t)s * qd]);
+  }
+  std::copy(seen_all.begin(), seen_all.begin() + qd, best_points);  // the IO container's seed (.hpp:733 / point-list: first start)
+  std::vector<double> end_vals(S);
+  if (do_gradient_ascent && outer.max_num_restarts > 0) {
+    const double step_tol = outer.tolerance / (double)outer.max_num_steps;
+    std::vector<char> alive(S, 1), running(S);
+    std::vector<double> cur((size_t)S * qd), nxt((size_t)S * qd), G((size_t)S * qd), xs((size_t)S * qd), ks(S), gs((size_t)S * qd),
+        gcost(qd), step(qd);
+    std::vector<int> idx;
+    for (int r = 0; r < outer.max_num_restarts; ++r) {
+      if (std::none_of(alive.begin(), alive.end(), [](char c) { return c != 0; })) break;
+      cur = seen_all;
+      nxt = seen_all;
+      std::fill(G.begin(), G.end(), 0.0);
+      running = alive;
+      for (int i = 0; i < outer.max_num_steps; ++i) {
+        idx.clear();
+        for (int s = 0; s < S; ++s)
+          if (running[s]) idx.push_back(s);
+        if (idx.empty()) break;
+        const double alpha = outer.pre_mult * std::pow((double)(i + 1), -outer.gamma);
+        for (size_t k = 0; k < idx.size(); ++k)
+          std::copy(&actual[(size_t)idx[k] * qd], &actual[(size_t)(idx[k] + 1) * qd], &xs[k * qd]);
+        sums(xs.data(), (int)idx.size(), true, ks.data(), gs.data());
+        for (size_t k = 0; k < idx.size(); ++k) {
+          const int s = idx[k];
+          double* Gs = &G[(size_t)s * qd];
+          double* ns = &nxt[(size_t)s * qd];
+          const double cost = fidelity_cost(&seen_all[(size_t)s * qd], q, d, num_fidelity, gcost.data());
+          const double mean_kg = ks[k] / (double)nm;
+          for (int j = 0; j < qd; ++j) {
+            Gs[j] = ((Gs[j] + gs[k * qd + j]) / (double)nm * cost - mean_kg * gcost[j]) / (cost * cost);
+            const int dd = j % d;
+            step[j] = limit_update_coord(bounds[2 * dd], bounds[2 * dd + 1], outer.max_relative_change, ns[j], alpha * Gs[j]);
+            ns[j] += step[j];
+          }
+          std::copy(ns, ns + qd, &actual[(size_t)s * qd]);  // SetCurrentPoint: the per-GP states follow all q points ...
+          seen_of(ns, &seen_all[(size_t)s * qd]);            // ... the MCMC state only the first
+          double n2 = 0.0;
+          for (int j = 0; j < qd; ++j) n2 += step[j] * step[j];
+          if (std::sqrt(n2) < step_tol) running[s] = 0;
+        }
+      }
+      for (int s = 0; s < S; ++s) {
+        if (!alive[s]) continue;
+        double n2 = 0.0;
+        for (int j = 0; j < qd; ++j) {
+          const double dlt = cur[(size_t)s * qd + j] - seen_all[(size_t)s * qd + j];
+          n2 += dlt * dlt;
+        }
+        if (!(std::sqrt(n2) > outer.tolerance)) alive[s] = 0;
+      }
+    }
+  }
+  sums(actual.data(), S, false, end_vals.data(), nullptr);
+  for (int s = 0; s < S; ++s) {
+    const double v = end_vals[s] / ((double)nm * fidelity_cost(&seen_all[(size_t)s * qd], q, d, num_fidelity, nullptr));
+    if (v > *best_kg) {  // strict, like MultistartOptimizer's compare (gpp_optimization.hpp:1512)
+      *best_kg = v;
+      std::copy(&seen_all[(size_t)s * qd], &seen_all[(size_t)(s + 1) * qd], best_points);
+      *found = 1;
+    }
+  }
 }
 
 void ei_mcmc_multistart(const std::vector<GpDev*>& gps, const moe_gd_params_t& outer, const double* bounds, const double* starts,

@@ -13,7 +13,9 @@
 #include <cmath>
 #include <functional>
 #include <numeric>
+#include <queue>
 #include <random>
+#include <utility>
 
 #include "gp.hpp"
 #include "kg.hpp"
@@ -59,11 +61,11 @@ void latin_hypercube(unsigned int seed, const double* bounds, int dim, int num_p
 
 void kg_values(GpDev& gp, int num_fidelity, const moe_gd_params_t& inner, const double* inner_bounds, const double* discrete,
                int P, const double* Xq_all, int num_evals, const double* Xp, int q, int p, int num_mc, double best_so_far,
-               const double* normals, double* values) {
+               const double* normals, double* values, const double* disc_head) {
   if (num_evals <= 0) return;
   std::vector<double> sums(num_evals);
   kg_evaluate_batch(gp, num_fidelity, inner, inner_bounds, discrete, P, Xq_all, num_evals, Xp, q, p, num_mc, best_so_far,
-                    normals, 0, num_mc, false, sums.data(), nullptr, nullptr, nullptr);
+                    normals, 0, num_mc, false, sums.data(), nullptr, nullptr, nullptr, disc_head);
   for (int e = 0; e < num_evals; ++e) values[e] = sums[e] / (double)num_mc;
 }
 
@@ -110,6 +112,26 @@ void gradient_ascent(const BatchObjective& f, const moe_gd_params_t& outer, cons
 
 }  // namespace
 
+std::vector<int> top_k_order(const double* vals, int num_starts) {
+  // std::priority_queue<std::pair<double, int>> is a max-heap on (-value, index): its top is the lowest-valued kept start and,
+  // among equal values, the one with the larger index
+  std::priority_queue<std::pair<double, int>> pq;
+  for (int i = 0; i < num_starts; ++i) {
+    if (i < kTopK) {
+      pq.push(std::pair<double, int>(-vals[i], i));
+    } else if (pq.top().first > -vals[i]) {
+      pq.pop();
+      pq.push(std::pair<double, int>(-vals[i], i));
+    }
+  }
+  std::vector<int> order;
+  while (!pq.empty()) {
+    order.push_back(pq.top().second);
+    pq.pop();
+  }
+  return order;
+}
+
 // Value at every start, the best 20 kept, restarted ascent on each, value at every end point, best one returned if it
 // beats `floor_value` (MultistartOptimizer, gpp_optimization.hpp:1472-1546; the reference seeds its IO container with
 // -inf for KG, gpp_knowledge_gradient_optimization.hpp:924, and -1.0 for EI, gpp_math.hpp:1728).
@@ -124,15 +146,15 @@ void multistart(const BatchObjective& f, const moe_gd_params_t& outer, const dou
   std::vector<double> ends, end_vals;
   int S = num_starts;
   if (do_gradient_ascent) {
-    std::vector<int> order(num_starts);
-    std::iota(order.begin(), order.end(), 0);
-    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return vals[a] > vals[b]; });
-    S = std::min(num_starts, kTopK);
+    // the kept starts in the reference's own order (lowest kept value first): with MultistartOptimizer's strict compare the
+    // FIRST of equal end values in this order wins
+    const std::vector<int> order = top_k_order(vals.data(), num_starts);
+    S = (int)order.size();
     ends.resize((size_t)S * qd);
     for (int s = 0; s < S; ++s) std::copy(starts + (size_t)order[s] * qd, starts + (size_t)(order[s] + 1) * qd, &ends[(size_t)s * qd]);
     // what the reference returns when nothing beats floor_value: the point its IO container was seeded with, i.e. the first
     // entry popped from its top-20 queue = the lowest-valued kept start (gpp_math.hpp:1717-1728)
-    std::copy(&ends[(size_t)(S - 1) * qd], &ends[(size_t)S * qd], best_points);
+    std::copy(&ends[0], &ends[(size_t)qd], best_points);
     gradient_ascent(f, outer, bounds, d, qd, ends.data(), S);
     end_vals.resize(S);
     f.values(ends.data(), S, end_vals.data());
@@ -155,14 +177,18 @@ void kg_multistart(GpDev& gp, int num_fidelity, const moe_gd_params_t& outer, co
                    int num_mc, double best_so_far, const double* normals, int do_gradient_ascent, double* best_points,
                    double* best_kg, int* found) {
   const int d = gp.d, qd = q * d;
+  // The reference builds its evaluation states at the FIRST start and moves them with SetCurrentPoint, which leaves the
+  // discretised set behind (kg.hpp: disc_head): every evaluation of the run scores / starts its inner optimisation from the
+  // first start's q points.  Reproduced: the end point is pinned to the reference's (tests/golden/ref_kg_multistart.npz).
+  const double* head = (num_starts > 0) ? starts : nullptr;
   BatchObjective f;
   f.values = [&](const double* x_all, int n, double* values) {
-    kg_values(gp, num_fidelity, inner, bounds, discrete, P, x_all, n, Xp, q, p, num_mc, best_so_far, normals, values);
+    kg_values(gp, num_fidelity, inner, bounds, discrete, P, x_all, n, Xp, q, p, num_mc, best_so_far, normals, values, head);
   };
   f.grads = [&](const double* x_all, int n, double* grads) {
     std::vector<double> ksum(n);
     kg_evaluate_batch(gp, num_fidelity, inner, bounds, discrete, P, x_all, n, Xp, q, p, num_mc, best_so_far, normals, 0, num_mc,
-                      true, ksum.data(), grads, nullptr, nullptr);
+                      true, ksum.data(), grads, nullptr, nullptr, head);
     for (size_t j = 0; j < (size_t)n * qd; ++j) grads[j] /= (double)num_mc;
   };
   multistart(f, outer, bounds, d, qd, starts, num_starts, do_gradient_ascent, -INFINITY, best_points, best_kg, found);

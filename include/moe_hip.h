@@ -185,7 +185,15 @@ int moe_kg_batch(const moe_gp_t* gp, int num_fidelity, const moe_gd_params_t* in
  * (gpp_optimization.hpp:619-705, 1144-1185), best end point returned; with do_gradient_ascent == 0 the value search of
  * ...ViaLatinHypercubeSearch / EvaluateKGAtPointList (:1090-1141).  start_points[num_starts][q][dim] are supplied by
  * the caller (moe_latin_hypercube reproduces the reference's generator, gpp_random.cpp:173-194); domain_bounds[2*dim].
- * Every step evaluates all live restarts in ONE batched device pass.  *found = 1 iff a point with KG > -inf was found. */
+ * Every step evaluates all live restarts in ONE batched device pass.  *found = 1 iff a point with KG > -inf was found.
+ * Reproduced from the reference, because they decide which point is returned (pinned to the reference's own end points,
+ * tests/golden/ref_kg_multistart.npz): (1) the drivers build their KnowledgeGradientState at the FIRST start and move it with
+ * SetCurrentPoint, which does not refresh the state's discretised set (gpp_knowledge_gradient_optimization.cpp:232-243,
+ * 259-261): every evaluation of a run scores / starts its inner optimisation from start_points[0]'s q points (+ the
+ * points being sampled + discrete_pts), not from the points being evaluated -- moe_kg / moe_kg_batch, like the
+ * single-evaluation Python entry points, evaluate on a fresh state; (2) the best 20 starts are kept and walked in the order
+ * the reference's std::priority_queue pops them (lowest kept value first, equal values by descending index), and the first
+ * of equal end values wins. */
 int moe_kg_multistart(const moe_gp_t* gp, int num_fidelity, const moe_gd_params_t* outer_params,
                       const moe_gd_params_t* inner_params, const double* domain_bounds, const double* discrete_pts, int num_pts,
                       const double* start_points, int num_starts, const double* points_being_sampled, int num_to_sample,
@@ -228,7 +236,15 @@ int moe_ei_mcmc_batch(const moe_gp_t* const* gps, int num_mcmc, const double* po
 /* multistart_knowledge_gradient_mcmc_optimization / multistart_expected_improvement_mcmc_optimization from caller-supplied
  * starts (gpp_knowledge_gradient_mcmc_optimization.hpp:665-862, gpp_expected_improvement_mcmc_optimization.hpp:840-990):
  * same driver as moe_kg_multistart / moe_ei_multistart on the MCMC-averaged objective.  The EI driver reports found = 0
- * unless some end point has EI > 0 (the reference seeds it with 0.0, not -1.0). */
+ * unless some end point has EI > 0 (the reference seeds it with 0.0, not -1.0).
+ * moe_kg_mcmc_multistart follows the reference's EXECUTION, not its intent (end points pinned to the reference's,
+ * tests/golden/ref_kg_multistart.npz): KnowledgeGradientMCMCState::SetCurrentPoint copies only the first of the q points into
+ * the array GetCurrentPoint and the fidelity cost read (gpp_knowledge_gradient_mcmc_optimization.cpp:186-195, .hpp:439-441), so
+ * the optimiser steps from and returns [moved first point ; points 2..q of start_points[0]] while the objective is evaluated at
+ * the points really reached; ComputeGradKnowledgeGradient accumulates into its output (.cpp:163-166), which the optimiser
+ * allocates once per restart: step i sees ((G_{i-1} + sum of the per-GP gradients) / num_mcmc * cost - KG * gradcost) / cost^2;
+ * the per-GP states keep start_points[0]'s discretised set (see moe_kg_multistart).  With q = 1 and no fidelity dimension
+ * only the last two are visible. */
 int moe_kg_mcmc_multistart(const moe_gp_t* const* gps, int num_mcmc, int num_fidelity, const moe_gd_params_t* outer_params,
                            const moe_gd_params_t* inner_params, const double* domain_bounds, const double* discrete_pts_all,
                            int num_pts, const double* start_points, int num_starts, const double* points_being_sampled,

@@ -1098,6 +1098,21 @@ static void grad_cov_per_point(const orc_gp* gp, const pts_state* s, int diff, c
 int orc_kg(const orc_gp* gp, int f, const double* gd, const double* bounds, const double* discrete, int P,
            const double* Xq, const double* Xp, int q, int p, int M, double best_so_far, const double* normals,
            int want_grad, double* kg_out, double* grad_out, double* best_point_out, long* counters) {
+  return orc_kg_head(gp, f, gd, bounds, discrete, P, Xq, Xp, q, p, M, best_so_far, normals, want_grad, kg_out, grad_out,
+                     best_point_out, counters, NULL);
+}
+
+/* The same evaluation on a state whose discretised set was frozen when the state was BUILT: KnowledgeGradientState's
+ * constructor fills discretized_set = [union points without fidelity dims ; discrete points] (.cpp:259-261), and
+ * SetCurrentPoint (.cpp:232-243) refreshes union_of_points and the GP state but NOT discretized_set.  The multistart /
+ * point-list drivers build their states at the FIRST start (gpp_knowledge_gradient_optimization.hpp:886-889, 1117-1120) and
+ * then move them with SetCurrentPoint, so every evaluation they make scores and starts its inner optimisation from
+ * head_q = that first start's q points (+ points_being_sampled, which never change).  head_q[q][dim] or NULL (= Xq: a
+ * fresh state per evaluation, what the single-evaluation Python entry points do). */
+int orc_kg_head(const orc_gp* gp, int f, const double* gd, const double* bounds, const double* discrete, int P,
+                const double* Xq, const double* Xp, int q, int p, int M, double best_so_far, const double* normals,
+                int want_grad, double* kg_out, double* grad_out, double* best_point_out, long* counters,
+                const double* head_q) {
   const int dim = gp->dim, g = gp->g, u = q + p, m = u * (1 + g), N = gp->N;
   const int nd = want_grad ? q : 0;
   int rc = 0;
@@ -1108,7 +1123,8 @@ int orc_kg(const orc_gp* gp, int f, const double* gd, const double* bounds, cons
   if (p > 0) memcpy(U + (size_t)q * dim, Xp, sizeof(double) * (size_t)p * dim);
   const int A = u + P, size = dim - f;
   double* disc_set = dalloc((size_t)A * size);
-  for (int i = 0; i < u; ++i) memcpy(disc_set + (size_t)i * size, U + (size_t)i * dim, sizeof(double) * size);
+  for (int i = 0; i < u; ++i)
+    memcpy(disc_set + (size_t)i * size, (head_q && i < q ? head_q : U) + (size_t)i * dim, sizeof(double) * size);
   memcpy(disc_set + (size_t)u * size, discrete, sizeof(double) * (size_t)P * size);
   pts_state s;
   pts_state_fill(gp, &s, U, u, gp->derivs, g, nd, 1, want_grad ? 1 : 0);

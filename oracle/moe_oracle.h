@@ -89,6 +89,11 @@ int orc_ei_analytic(const orc_gp* gp, const double* pt, double best_so_far, doub
 int orc_kg(const orc_gp* gp, int num_fidelity, const double* gd, const double* bounds, const double* discrete, int P,
            const double* Xq, const double* Xp, int q, int p, int M, double best_so_far, const double* normals,
            int want_grad, double* kg, double* grad, double* best_point, long* counters);
+/* orc_kg on a state built at head_q and then moved to Xq with SetCurrentPoint (the reference's multistart drivers): the
+ * discretised set keeps head_q's points.  head_q == NULL: orc_kg. */
+int orc_kg_head(const orc_gp* gp, int num_fidelity, const double* gd, const double* bounds, const double* discrete, int P,
+           const double* Xq, const double* Xp, int q, int p, int M, double best_so_far, const double* normals,
+           int want_grad, double* kg, double* grad, double* best_point, long* counters, const double* head_q);
 
 #ifdef __cplusplus
 }

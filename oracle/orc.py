@@ -58,6 +58,7 @@ def lib():
         L.orc_ei_analytic.argtypes = [C.c_void_p, _dp, C.c_double, _dp, _dp]
         L.orc_kg.argtypes = [C.c_void_p, C.c_int, _dp, _dp, _dp, C.c_int, _dp, _dp, C.c_int, C.c_int, C.c_int, C.c_double,
                              _dp, C.c_int, _dp, _dp, _dp, _lp]
+        L.orc_kg_head.argtypes = L.orc_kg.argtypes + [_dp]
         _lib = L
     return _lib
 
@@ -227,7 +228,9 @@ class OrcGP(object):
         lib().orc_ei_analytic(self.h, pp, best_so_far, C.byref(ei), grad.ctypes.data_as(_dp) if want_grad else None)
         return ei.value, (grad if want_grad else None)
 
-    def kg(self, gd, bounds, discrete, Xq, Xp, M, best_so_far, normals, want_grad=True, num_fidelity=0):
+    def kg(self, gd, bounds, discrete, Xq, Xp, M, best_so_far, normals, want_grad=True, num_fidelity=0, head=None):
+        """head [q][d]: the points the evaluating state was BUILT at (the discretised set stays frozen there when the reference's
+        multistart drivers move a state with SetCurrentPoint); None = a fresh state at Xq."""
         gd, gdp = _d(gd)
         bounds, bp = _d(bounds)
         discrete, dp = _d(discrete)
@@ -244,8 +247,11 @@ class OrcGP(object):
         grad = np.zeros(q * self.d)
         best_point = np.zeros(M * self.d)
         counters = (C.c_long * 2)()
-        rc = lib().orc_kg(self.h, num_fidelity, gdp, bp, dp, P, qp, pp, q, p, M, best_so_far, npp, 1 if want_grad else 0,
-                          C.byref(kg), grad.ctypes.data_as(_dp), best_point.ctypes.data_as(_dp), counters)
+        hp = None
+        if head is not None:
+            head, hp = _d(head)
+        rc = lib().orc_kg_head(self.h, num_fidelity, gdp, bp, dp, P, qp, pp, q, p, M, best_so_far, npp, 1 if want_grad else 0,
+                               C.byref(kg), grad.ctypes.data_as(_dp), best_point.ctypes.data_as(_dp), counters, hp)
         if rc:
             raise SingularMatrix("singular at minor %d" % rc)
         return dict(kg=kg.value, grad=grad.reshape(q, self.d) if want_grad else None,
@@ -320,13 +326,13 @@ class OrcGPMCMC(object):
             grad[index, j] = cost / Xq[index, j]
         return cost, grad
 
-    def kg(self, gd, bounds, discrete_all, Xq, Xp, M, best_so_far, normals, want_grad=True, num_fidelity=0):
+    def kg(self, gd, bounds, discrete_all, Xq, Xp, M, best_so_far, normals, want_grad=True, num_fidelity=0, head=None):
         Xq = np.asarray(Xq, dtype=np.float64).reshape(-1, self.d)
         discrete_all = np.asarray(discrete_all, dtype=np.float64).reshape(self.num_mcmc, -1, self.d - num_fidelity)
         kg, grad = 0.0, np.zeros_like(Xq)
         for i, gp in enumerate(self.gps):
             r = gp.kg(gd, bounds, discrete_all[i], Xq, Xp, M, float(best_so_far[i]), normals, want_grad=want_grad,
-                      num_fidelity=num_fidelity)
+                      num_fidelity=num_fidelity, head=head)
             kg += r["kg"]
             if want_grad:
                 grad += r["grad"]

@@ -61,6 +61,11 @@ def lib():
         _lib.ref_log_likelihood.argtypes = [C.c_int, C.c_double, _dp, _dp, _dp, _dp, _ip, C.c_int, C.c_int, C.c_int, _dp]
         _lib.ref_kg.argtypes = [C.c_void_p, C.c_int, _dp, _dp, _dp, C.c_int, _dp, _dp, C.c_int, C.c_int, C.c_int,
                                 C.c_double, _dp, C.c_long, C.c_int, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp]
+        _lib.ref_normal_draws.argtypes = [C.c_uint, C.c_long, _dp]
+        _lib.ref_kg_multistart.argtypes = [C.c_void_p, C.c_int, _dp, _dp, _dp, _dp, _dp, C.c_int, _dp, C.c_int, _dp, C.c_int,
+                                           C.c_int, C.c_int, C.c_double, C.c_uint, C.POINTER(C.c_int), _dp]
+        _lib.ref_kg_mcmc_multistart.argtypes = [C.c_void_p, C.c_int, _dp, _dp, _dp, _dp, _dp, C.c_int, _dp, C.c_int, _dp, C.c_int,
+                                                C.c_int, C.c_int, _dp, C.c_uint, C.POINTER(C.c_int), _dp]
         _lib.ref_kg_grad_batch.argtypes = [C.c_void_p, C.c_int, _dp, _dp, _dp, C.c_int, _dp, C.c_int, C.c_int, C.c_int,
                                            C.c_double, _dp, C.c_long, C.c_int, _dp, _dp, _dp]
     return _lib
@@ -277,6 +282,30 @@ class RefGP(object):
                        chol_inverse_cov=cic.reshape(M, m))
         return out
 
+    def kg_multistart(self, gd_outer, gd_inner, bounds, discrete, starts, Xp, M, best_so_far, seed, num_fidelity=0):
+        """ComputeKGOptimalPointsToSampleViaMultistartGradientDescent (one thread) with NormalRNG(seed):
+        (best_points [q,d], found).  starts[S][q][d], S >= 20.  The normal table the run consumed is normal_draws(seed, ...)."""
+        gdo, gop = _d(gd_outer)
+        gdi, gip = _d(gd_inner)
+        bounds, bp = _d(bounds)
+        inner_bounds = np.ascontiguousarray(bounds.reshape(-1)[: 2 * (self.d - num_fidelity)])
+        discrete, dp = _d(discrete)
+        P = discrete.reshape(-1, self.d - num_fidelity).shape[0]
+        starts = np.ascontiguousarray(starts, dtype=np.float64)
+        S, q, _ = starts.shape
+        assert S >= 20, "the reference pops its top-20 queue unconditionally"
+        if Xp is None or len(Xp) == 0:
+            p, pp = 0, None
+        else:
+            Xp_, pp = _d(Xp)
+            p = Xp_.reshape(-1, self.d).shape[0]
+        found = C.c_int(0)
+        best = np.zeros(q * self.d)
+        _check(lib().ref_kg_multistart(self.h, num_fidelity, gop, gip, bp, inner_bounds.ctypes.data_as(_dp), dp, P,
+                                       starts.ctypes.data_as(_dp), S, pp, q, p, M, best_so_far, seed, C.byref(found),
+                                       best.ctypes.data_as(_dp)))
+        return best.reshape(q, self.d), bool(found.value)
+
     def kg_grad_batch(self, gd, bounds, discrete, Xq_all, M, best_so_far, normals, num_threads, num_fidelity=0):
         gd, gdp = _d(gd)
         bounds, bp = _d(bounds)
@@ -292,6 +321,13 @@ class RefGP(object):
                                        best_so_far, npp, normals.size, num_threads, kg.ctypes.data_as(_dp),
                                        grad.ctypes.data_as(_dp), C.byref(wall)))
         return kg, grad.reshape(R, q, self.d), wall.value
+
+
+def normal_draws(seed, count):
+    """The first `count` draws of the reference's NormalRNG(seed) (mt19937 + the shimmed normal distribution)."""
+    out = np.zeros(int(count))
+    _check(lib().ref_normal_draws(int(seed), int(count), out.ctypes.data_as(_dp)))
+    return out
 
 
 def num_procs():
@@ -406,3 +442,28 @@ class RefGPMCMC(object):
         best = np.zeros(self.d)
         _check(lib().ref_ei_mcmc_multistart_analytic(self.h, gdp, bp, sp, S, bsp, C.byref(found), best.ctypes.data_as(_dp)))
         return best, bool(found.value)
+
+    def kg_multistart(self, gd_outer, gd_inner, bounds, discrete_all, starts, Xp, M, best_so_far, seed, num_fidelity=0):
+        """ComputeKGMCMCOptimalPointsToSampleViaMultistartGradientDescent (one thread) with NormalRNG(seed):
+        (best_points [q,d], found).  discrete_all[num_mcmc][P][d - f]; best_so_far[num_mcmc]; starts[S][q][d], S >= 20."""
+        gdo, gop = _d(gd_outer)
+        gdi, gip = _d(gd_inner)
+        bounds, bp = _d(bounds)
+        inner_bounds = np.ascontiguousarray(bounds.reshape(-1)[: 2 * (self.d - num_fidelity)])
+        discrete_all, dp = _d(discrete_all)
+        P = discrete_all.reshape(self.num_mcmc, -1, self.d - num_fidelity).shape[1]
+        starts = np.ascontiguousarray(starts, dtype=np.float64)
+        S, q, _ = starts.shape
+        assert S >= 20, "the reference pops its top-20 queue unconditionally"
+        if Xp is None or len(Xp) == 0:
+            p, pp = 0, None
+        else:
+            Xp_, pp = _d(Xp)
+            p = Xp_.reshape(-1, self.d).shape[0]
+        best_so_far, bsp = _d(best_so_far)
+        found = C.c_int(0)
+        best = np.zeros(q * self.d)
+        _check(lib().ref_kg_mcmc_multistart(self.h, num_fidelity, gop, gip, bp, inner_bounds.ctypes.data_as(_dp), dp, P,
+                                            starts.ctypes.data_as(_dp), S, pp, q, p, M, bsp, seed, C.byref(found),
+                                            best.ctypes.data_as(_dp)))
+        return best.reshape(q, self.d), bool(found.value)

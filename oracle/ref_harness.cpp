@@ -472,6 +472,97 @@ int ref_kg_grad_batch(void* hv, int num_fidelity, const double* gd, const double
   return rc_all;
 }
 
+// ---- the KG outer optimiser: ComputeKGOptimalPointsToSampleViaMultistartGradientDescent
+// (gpp_knowledge_gradient_optimization.hpp:860-935) and its MCMC twin (gpp_knowledge_gradient_mcmc_optimization.hpp:665-760).
+// Both take a concrete NormalRNG* (not the interface), so explicit tables cannot be injected; instead the stream of
+// NormalRNG(seed) is exported (ref_normal_draws) and replayed by the device driver as its explicit table: every KG evaluation
+// rewinds the generator (gpp_knowledge_gradient_optimization.cpp:78, 139; ResetToMostRecentSeed re-seeds the engine AND resets
+// the distribution, gpp_random.cpp:101-115, 156-158), so each evaluation consumes the first ceil(M/2)*m draws of that stream.
+// One thread (thread_schedule.max_num_threads = 1): deterministic. ----
+int ref_normal_draws(unsigned int seed, long count, double* out) {
+  return guarded([&] {
+    NormalRNG rng(seed);
+    for (long i = 0; i < count; ++i) out[i] = rng();
+  });
+}
+
+// KG value through a seeded NormalRNG (the route the multistart drivers take), to check the exported stream against the
+// NormalRNGSimulator route of ref_kg.
+int ref_kg_seeded(void* hv, int num_fidelity, const double* gd, const double* bounds, const double* discrete, int P,
+                  const double* Xq, const double* Xp, int q, int p, int M, double best_so_far, unsigned int seed, double* kg) {
+  return guarded([&] {
+    GaussianProcess* gp = static_cast<RefGP*>(hv)->gp;
+    const int d = gp->dim();
+    std::vector<ClosedInterval> iv(d - num_fidelity);
+    for (int i = 0; i < d - num_fidelity; ++i) iv[i] = ClosedInterval(bounds[2 * i], bounds[2 * i + 1]);
+    TensorProductDomain dom(iv.data(), d - num_fidelity);
+    GradientDescentParameters gdp(static_cast<int>(gd[0]), static_cast<int>(gd[1]), static_cast<int>(gd[2]),
+                                  static_cast<int>(gd[3]), gd[4], gd[5], gd[6], gd[7]);
+    NormalRNG rng(seed);
+    double dummy = 0.0;
+    KnowledgeGradientEvaluator<TensorProductDomain> ev(*gp, num_fidelity, discrete, P, M, dom, gdp, best_so_far);
+    KnowledgeGradientEvaluator<TensorProductDomain>::StateType st(
+        ev, Xq, p > 0 ? Xp : &dummy, q, p, P, nn(gp->derivatives().data()), gp->num_derivatives(), false, &rng);
+    *kg = ev.ComputeKnowledgeGradient(&st);
+    *kg = ev.ComputeKnowledgeGradient(&st);  // twice: the second call must replay the same draws
+  });
+}
+
+// gd_outer / gd_inner as in ref_kg; bounds[2*d] (outer domain, all d coordinates), inner_bounds[2*(d-num_fidelity)];
+// starts[num_starts][q][d] (num_starts >= 20: the reference pops its 20-deep queue unconditionally); best_point[q][d].
+int ref_kg_multistart(void* hv, int num_fidelity, const double* gd_outer, const double* gd_inner, const double* bounds,
+                      const double* inner_bounds, const double* discrete, int P, const double* starts, int num_starts,
+                      const double* Xp, int q, int p, int M, double best_so_far, unsigned int seed, int* found,
+                      double* best_point) {
+  return guarded([&] {
+    GaussianProcess* gp = static_cast<RefGP*>(hv)->gp;
+    const int d = gp->dim();
+    std::vector<ClosedInterval> iv(d), ivi(d - num_fidelity);
+    for (int i = 0; i < d; ++i) iv[i] = ClosedInterval(bounds[2 * i], bounds[2 * i + 1]);
+    for (int i = 0; i < d - num_fidelity; ++i) ivi[i] = ClosedInterval(inner_bounds[2 * i], inner_bounds[2 * i + 1]);
+    TensorProductDomain dom(iv.data(), d), inner_dom(ivi.data(), d - num_fidelity);
+    GradientDescentParameters gdo(static_cast<int>(gd_outer[0]), static_cast<int>(gd_outer[1]), static_cast<int>(gd_outer[2]),
+                                  static_cast<int>(gd_outer[3]), gd_outer[4], gd_outer[5], gd_outer[6], gd_outer[7]);
+    GradientDescentParameters gdi(static_cast<int>(gd_inner[0]), static_cast<int>(gd_inner[1]), static_cast<int>(gd_inner[2]),
+                                  static_cast<int>(gd_inner[3]), gd_inner[4], gd_inner[5], gd_inner[6], gd_inner[7]);
+    ThreadSchedule sched(1, omp_sched_static);
+    NormalRNG rng(seed);
+    double dummy = 0.0;
+    bool found_flag = false;
+    ComputeKGOptimalPointsToSampleViaMultistartGradientDescent(*gp, num_fidelity, gdo, gdi, dom, inner_dom, sched, starts,
+                                                               p > 0 ? Xp : &dummy, discrete, num_starts, q, p, P, best_so_far,
+                                                               M, &rng, &found_flag, best_point);
+    *found = found_flag ? 1 : 0;
+  });
+}
+
+// MCMC twin: discrete_all[num_mcmc][P][d - num_fidelity], best_so_far[num_mcmc].
+int ref_kg_mcmc_multistart(void* hv, int num_fidelity, const double* gd_outer, const double* gd_inner, const double* bounds,
+                           const double* inner_bounds, const double* discrete_all, int P, const double* starts, int num_starts,
+                           const double* Xp, int q, int p, int M, const double* best_so_far, unsigned int seed, int* found,
+                           double* best_point) {
+  return guarded([&] {
+    GaussianProcessMCMC* gpm = static_cast<GaussianProcessMCMC*>(hv);
+    const int d = gpm->dim();
+    std::vector<ClosedInterval> iv(d), ivi(d - num_fidelity);
+    for (int i = 0; i < d; ++i) iv[i] = ClosedInterval(bounds[2 * i], bounds[2 * i + 1]);
+    for (int i = 0; i < d - num_fidelity; ++i) ivi[i] = ClosedInterval(inner_bounds[2 * i], inner_bounds[2 * i + 1]);
+    TensorProductDomain dom(iv.data(), d), inner_dom(ivi.data(), d - num_fidelity);
+    GradientDescentParameters gdo(static_cast<int>(gd_outer[0]), static_cast<int>(gd_outer[1]), static_cast<int>(gd_outer[2]),
+                                  static_cast<int>(gd_outer[3]), gd_outer[4], gd_outer[5], gd_outer[6], gd_outer[7]);
+    GradientDescentParameters gdi(static_cast<int>(gd_inner[0]), static_cast<int>(gd_inner[1]), static_cast<int>(gd_inner[2]),
+                                  static_cast<int>(gd_inner[3]), gd_inner[4], gd_inner[5], gd_inner[6], gd_inner[7]);
+    ThreadSchedule sched(1, omp_sched_static);
+    NormalRNG rng(seed);
+    double dummy = 0.0;
+    bool found_flag = false;
+    ComputeKGMCMCOptimalPointsToSampleViaMultistartGradientDescent(*gpm, num_fidelity, gdo, gdi, dom, inner_dom, sched, starts,
+                                                                   p > 0 ? Xp : &dummy, discrete_all, num_starts, q, p, P,
+                                                                   best_so_far, M, &rng, &found_flag, best_point);
+    *found = found_flag ? 1 : 0;
+  });
+}
+
 int ref_num_procs() { return omp_get_num_procs(); }
 
 }  // extern "C"

@@ -153,7 +153,7 @@ def test_wrapper_mirror_containers():
 
 def test_multistart_host_pieces():
     """LimitUpdate (gpp_domain.cpp:64-105) vectorised == a scalar restatement; Latin hypercube has one point per slice."""
-    from cornell_moe_amd import multistart as ms
+    import ms_restatement as ms
     rng = np.random.default_rng(3)
     bounds = np.array([[0.0, 1.0], [-2.0, 3.0], [5.0, 5.5]])
 

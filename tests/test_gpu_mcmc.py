@@ -56,29 +56,6 @@ def test_golden_ei_mcmc_multistart_analytic():
         assert found0 and val0 == all_ei.max() and np.array_equal(pt0.ravel(), i["ms_starts"][int(np.argmax(all_ei))])
 
 
-def test_kg_mcmc_multistart_driver_matches_restatement():
-    """moe_kg_mcmc_multistart (C++ driver over the averaged, cost-scaled objective) against the numpy restatement of the
-    same algorithm on top of moe_kg_mcmc_batch: same starts, same table; one fidelity dimension so the cost term is live."""
-    from cornell_moe_amd import multistart as ms
-    c = load_golden_mcmc()[1]
-    i = c.inp
-    d, f, M, q = int(i["d"]), int(i["num_fidelity"]), int(i["M"]), int(i["q"])
-    G = _dev(c)
-    rng = np.random.default_rng(8)
-    starts = rng.uniform(0.1, 0.9, size=(22, q, d))
-    bounds = i["bounds"]
-    inner, outer = tuple(i["inner_gd"]), (22, 6, 2, 4, 0.7, 0.02, 0.2, 1e-7)
-    cbest, cval, cfound = G.kg_multistart(outer, inner, bounds, i["discrete"], starts, i["Xp"], M, i["kg_best"], i["kg_normals"],
-                                          num_fidelity=f)
-    value_fn = lambda x: G.kg_batch(inner, bounds[:2 * (d - f)], i["discrete"], x, i["Xp"], M, i["kg_best"], i["kg_normals"],  # noqa: E731
-                                    want_grad=False, num_fidelity=f)[0]
-    grad_fn = lambda x: G.kg_batch(inner, bounds[:2 * (d - f)], i["discrete"], x, i["Xp"], M, i["kg_best"], i["kg_normals"],  # noqa: E731
-                                   num_fidelity=f)[1]
-    nbest, nval, nfound = ms.multistart_best(value_fn, grad_fn, outer, bounds, starts)
-    assert cfound and nfound and abs(cval - nval) <= 1e-10 * abs(nval) and np.abs(cbest - nbest).max() <= 1e-10
-    assert cval >= value_fn(starts).max() * (1 - 1e-12) - 1e-15
-
-
 def test_mcmc_wrapper_flow():
     """The reference's Python call sequence for the MCMC objects (knowledge_gradient_mcmc.py / expected_improvement_mcmc.py)
     on the mirror classes, checked against the oracle restatement fed the same normal tables."""

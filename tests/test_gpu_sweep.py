@@ -63,7 +63,7 @@ def test_kg_against_oracle(case, monkeypatch):
         assert abs(rg["kg"] - ro["kg"]) <= TOL["kg"] * max(abs(ro["kg"]), 1e-6), (variant, rg["kg"], ro["kg"])
         assert np.abs(rg["grad"] - ro["grad"]).max() <= TOL["grad_kg"] * max(scale, 1e-6), variant
         mism = np.abs(rg["best_point"] - ro["best_point"]).max(axis=1) > ptol
-        assert mism.mean() <= 0.02, (variant, mism.mean())
+        assert mism.mean() <= 0.002, (variant, mism.mean())  # <= 0.2 % of the samples
         assert rg["grad_evals"] == ro["grad_evals"] and rg["mean_evals"] <= ro["mean_evals"]
         rv = G.kg(gd, w.bounds_inner, w.discrete, w.Xq, Xp, w.M, best, w.kg_normals, num_fidelity=f, want_grad=False)
         assert rv["kg_sum"] == rg["kg_sum"]

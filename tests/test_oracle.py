@@ -70,7 +70,7 @@ def test_golden_analytic_ei_and_multistart(golden):
     """a20: analytic 1,0-EI (gpp_math.cpp:2195-2259) against the reference's values, and the numpy restatement of the
     multistart driver (cornell_moe_amd.multistart.multistart_best, the independent check of the C++ driver in the GPU
     tests) against the reference's ComputeOptimalPointsToSampleViaMultistartGradientDescent on the same start set."""
-    from cornell_moe_amd import multistart as ms
+    import ms_restatement as ms
     cases, _ = golden
     seen = 0
     for c in cases:
@@ -95,12 +95,71 @@ def test_golden_analytic_ei_and_multistart(golden):
     assert seen == 3
 
 
+def test_golden_kg_multistart_restatement():
+    """the KG OUTER optimiser.  The numpy restatement of the multistart driver (tests/ms_restatement.py)
+    on top of the C restatement's KG value / gradient reproduces the end point of the reference's
+    ComputeKGOptimalPointsToSampleViaMultistartGradientDescent (gpp_knowledge_gradient_optimization.hpp:860-935) and of its
+    MCMC twin (gpp_knowledge_gradient_mcmc_optimization.hpp:665-760) on the same 24 starts, replaying the exported NormalRNG
+    stream as the explicit table: q-KG, q,p-KG, d-KG, a fidelity dimension.  A reference quirk is part of the contract: those
+    drivers build their evaluation state at the FIRST start and move it with SetCurrentPoint, which does not refresh the
+    discretised set (gpp_knowledge_gradient_optimization.cpp:232-243, 259-261), so every evaluation scores / starts its inner
+    optimisation from the first start's points (head=starts[0]); without it the end points differ in the first digit."""
+    import ms_restatement as ms
+    from helpers import load_golden_kg_multistart
+    cases, mcmc = load_golden_kg_multistart()
+    assert len(cases) == 4 and len(mcmc) == 2
+    for c in cases:
+        i = c.inp
+        d, f, M = int(i["d"]), int(i["num_fidelity"]), int(i["M"])
+        gp = orc.OrcGP(1, float(i["alpha"]), i["lengths"], i["X"], i["y"], i["noise"], list(i["derivs"]))
+        Xp = i["Xp"] if int(i["p"]) > 0 else None
+        ib = i["bounds"][:2 * (d - f)]
+        best = float(i["best_so_far"])
+
+        def value_fn(x):
+            return np.array([gp.kg(i["inner_gd"], ib, i["discrete"], xx, Xp, M, best, i["normals"], want_grad=False,
+                                   num_fidelity=f, head=i["starts"][0])["kg"] for xx in x])
+
+        def grad_fn(x):
+            return np.array([gp.kg(i["inner_gd"], ib, i["discrete"], xx, Xp, M, best, i["normals"], num_fidelity=f,
+                                   head=i["starts"][0])["grad"] for xx in x])
+
+        pt, val, found = ms.multistart_best(value_fn, grad_fn, tuple(i["outer_gd"]), i["bounds"], i["starts"])
+        assert found == bool(c.out["found"])
+        assert np.abs(pt - c.out["best_point"]).max() <= 1e-6, (c.index, np.abs(pt - c.out["best_point"]).max())
+        fresh = gp.kg(i["inner_gd"], ib, i["discrete"], pt, Xp, M, best, i["normals"], want_grad=False, num_fidelity=f)["kg"]
+        assert abs(fresh - float(c.out["best_kg_fresh"])) <= 1e-6 * abs(float(c.out["best_kg_fresh"]))
+    for mk in mcmc:
+        i = mk.inp
+        O = orc.OrcGPMCMC(i["hypers"], i["noises"], i["X"], i["y"], ())
+        M, d, f = int(i["M"]), int(i["d"]), int(i["num_fidelity"])
+        head = i["starts"][0]
+        Xp = i["Xp"] if int(i["p"]) > 0 else None
+        ib = i["bounds"][:2 * (d - f)]
+
+        def kg_sum_fn(x):
+            return sum(g.kg(i["inner_gd"], ib, i["discrete"][k], x, Xp, M, float(i["best_so_far"][k]), i["normals"],
+                            want_grad=False, num_fidelity=f, head=head)["kg"] for k, g in enumerate(O.gps))
+
+        def grad_sum_fn(x):
+            rs = [g.kg(i["inner_gd"], ib, i["discrete"][k], x, Xp, M, float(i["best_so_far"][k]), i["normals"], num_fidelity=f,
+                       head=head) for k, g in enumerate(O.gps)]
+            return sum(r["kg"] for r in rs), sum(r["grad"] for r in rs)
+
+        # the MCMC driver as the reference executes it (its state object only tracks the first of the q points, and its gradient
+        # accumulates across the steps of a restart): see ms_restatement.kg_mcmc_multistart_reference
+        pt, val, found = ms.kg_mcmc_multistart_reference(kg_sum_fn, grad_sum_fn, int(i["num_mcmc"]), f, tuple(i["outer_gd"]),
+                                                         i["bounds"], i["starts"])
+        assert found == bool(mk.out["found"])
+        assert np.abs(pt - mk.out["best_point"]).max() <= 1e-6, (mk.index, np.abs(pt - mk.out["best_point"]).max())
+
+
 def test_golden_mcmc_averaged_evaluators():
     """the numpy-level restatement of the MCMC-averaged evaluators (oracle/orc.py: OrcGPMCMC -- per-GP oracle
     results averaged, KG divided by the fidelity cost with its gradient term) against the reference's GaussianProcessMCMC +
     KnowledgeGradientMCMCEvaluator / ExpectedImprovementMCMCEvaluator, and the multistart restatement on the averaged analytic
     EI against ComputeEIMCMCOptimalPointsToSampleViaMultistartGradientDescent."""
-    from cornell_moe_amd import multistart as ms
+    import ms_restatement as ms
     from helpers import load_golden_mcmc
     cases = load_golden_mcmc()
     assert len(cases) == 3
@@ -209,3 +268,27 @@ def test_restatement_vs_live_reference():
             er, gr_, _ = R.ei(Xq, Xp, M, float(np.median(y[:, 0])), en)
             eo, go_ = O.ei(Xq, Xp, M, float(np.median(y[:, 0])), en)
             assert abs(er - eo) < 1e-12 and rel(go_, gr_) < 1e-10
+
+
+def test_golden_benchmark_shapes():
+    """The C restatement against the reference's own results at the BENCHMARKED shapes (tests/golden/ref_shapes.npz): C2 in full,
+    the C3 shape at M = 1000, a C5-like d-KG case -- the same fixtures the device path is held to in tests/test_gpu_shapes.py."""
+    from cornell_moe_amd.workloads import make_workload
+    from helpers import load_golden_shapes, shape_checksum
+    z = load_golden_shapes()
+    w = make_workload("C2")
+    assert np.array_equal(shape_checksum(w), z["c2_check"])
+    O = orc.OrcGP(1, w.alpha, w.lengths, w.X, w.y, w.noise, ())
+    for tag in ("", "_median"):
+        ei, gei = O.ei(w.Xq, None, w.M, float(z["c2_best" + tag]), w.ei_normals)
+        assert abs(ei - float(z["c2_ei" + tag])) <= TOL["ei"] * max(abs(float(z["c2_ei" + tag])), 1e-3)
+        assert np.abs(gei - z["c2_grad_ei" + tag]).max() <= TOL["grad_ei"] * max(np.abs(z["c2_grad_ei" + tag]).max(), 1e-3)
+    for tag, kw in (("c3", dict(name="C3", M=1000)), ("c5", dict(name="C5", n=300, M=200))):
+        w = make_workload(**kw)
+        assert np.array_equal(shape_checksum(w), z[tag + "_check"])
+        O = orc.OrcGP(1, w.alpha, w.lengths, w.X, w.y, w.noise, w.derivs)
+        r = O.kg(w.inner_gd, w.bounds, w.discrete, w.Xq, None, w.M, float(z[tag + "_best_so_far"]), w.kg_normals)
+        scale = max(float(np.abs(z[tag + "_grad_kg"]).max()), abs(float(z[tag + "_kg"])))
+        assert abs(r["kg"] - float(z[tag + "_kg"])) <= TOL["kg"] * abs(float(z[tag + "_kg"]))
+        assert np.abs(r["grad"] - z[tag + "_grad_kg"]).max() <= TOL["grad_kg"] * scale
+        assert (np.abs(r["best_point"] - z[tag + "_best_point"]).max(axis=1) > 1e-8).mean() <= 0.002

@@ -165,11 +165,158 @@ def ll_grad_fixtures():
     print("wrote", OUT_LL, os.path.getsize(OUT_LL), "bytes,", k, "cases")
 
 
+OUT_SHAPES = os.path.join(ROOT, "tests", "golden", "ref_shapes.npz")
+
+
+def shape_fixtures():
+    """The BENCHMARKED shapes, from the unmodified reference: C2 in full (q-EI, n=500, d=4, q=2, M=1000),
+    the C3 shape (q-KG, n=1000, d=8, q=4, P=10) at M=1000, and a C5-like d-KG case (d=12, q=8, g=3, P=50, n=300, M=200).
+    Inputs are regenerated by cornell_moe_amd.workloads.make_workload from the stored keyword arguments (numpy's
+    default_rng streams are stable across versions); a checksum of X and of the normal table guards against drift."""
+    from cornell_moe_amd.workloads import make_workload
+    blob = {}
+
+    def checksum(w):
+        return np.array([float(w.X.sum()), float(w.kg_normals.sum()), float(w.Xq.sum()), float(w.discrete.sum())])
+
+    # C2 in full
+    w = make_workload("C2")
+    gp = ref.RefGP(1, w.alpha, w.lengths, w.X, w.y, w.noise, [])
+    best = float(w.y[:, 0].min())
+    ei, gei, _ = gp.ei(w.Xq, None, w.M, best, w.ei_normals)
+    blob["c2_ei"], blob["c2_grad_ei"], blob["c2_best"], blob["c2_check"] = np.array(ei), gei, np.array(best), checksum(w)
+    # (with best_so_far = min y the improvement is 0 for every sample at these points: also pin a live case, best = median y)
+    best_med = float(np.median(w.y[:, 0]))
+    ei_m, gei_m, _ = gp.ei(w.Xq, None, w.M, best_med, w.ei_normals)
+    blob["c2_ei_median"], blob["c2_grad_ei_median"], blob["c2_best_median"] = np.array(ei_m), gei_m, np.array(best_med)
+    print("C2 (best = median y): EI=%.15g" % ei_m)
+    blob["c2_mean"] = gp.mean(w.query)
+    blob["c2_var"] = gp.var(w.query[:4])
+    print("C2: EI=%.15g" % ei)
+    # C3 shape at M = 1000
+    for tag, kw in (("c3", dict(name="C3", M=1000)),
+                    ("c5", dict(name="C5", n=300, M=200))):
+        w = make_workload(**kw)
+        gp = ref.RefGP(1, w.alpha, w.lengths, w.X, w.y, w.noise, list(w.derivs))
+        best = float(gp.additional_mean(w.discrete).min())
+        r = gp.kg(w.inner_gd, w.bounds, w.discrete, w.Xq, None, w.M, best, w.kg_normals, want_grad=True, details=True)
+        rv = gp.kg(w.inner_gd, w.bounds, w.discrete, w.Xq, None, w.M, best, w.kg_normals, want_grad=False)
+        blob[tag + "_kw_n"], blob[tag + "_kw_M"] = np.array(w.n), np.array(w.M)
+        blob[tag + "_best_so_far"] = np.array(best)
+        blob[tag + "_kg"], blob[tag + "_grad_kg"], blob[tag + "_best_point"] = np.array(r["kg"]), r["grad"], r["best_point"]
+        blob[tag + "_kg_value_only"] = np.array(rv["kg"])
+        blob[tag + "_check"] = checksum(w)
+        blob[tag + "_seconds"] = np.array(r["seconds"])
+        print("%s: n=%d d=%d q=%d g=%d M=%d  KG=%.15g  (reference: %.2f s state + %.2f s evaluation)" % (
+            tag, w.n, w.d, w.q, w.g, w.M, r["kg"], r["seconds"][0], r["seconds"][1]))
+    np.savez_compressed(OUT_SHAPES, **blob)
+    print("wrote", OUT_SHAPES, os.path.getsize(OUT_SHAPES), "bytes")
+
+
+OUT_MS = os.path.join(ROOT, "tests", "golden", "ref_kg_multistart.npz")
+
+
+def kg_multistart_fixtures():
+    """The KG OUTER optimiser from the unmodified reference:
+    ComputeKGOptimalPointsToSampleViaMultistartGradientDescent (gpp_knowledge_gradient_optimization.hpp:860-935) and
+    ComputeKGMCMCOptimalPointsToSampleViaMultistartGradientDescent (gpp_knowledge_gradient_mcmc_optimization.hpp:665-760),
+    one thread, 24 starts, NormalRNG(seed) -- whose stream is stored as the explicit table the device driver replays."""
+    blob, k = {}, 0
+    inner = np.array((1, 6, 1, 3, 0.0, 1.0, 0.1, 1e-10))
+    for (seed, n, d, q, p, P, M, derivs, f, outer) in (
+            (5101, 40, 3, 2, 0, 8, 64, (), 0, (24, 6, 2, 4, 0.7, 0.1, 0.2, 1e-7)),
+            (5102, 50, 4, 2, 1, 8, 48, (), 0, (24, 5, 2, 4, 0.7, 0.08, 0.2, 1e-7)),
+            (5103, 10, 3, 2, 0, 6, 32, (0, 2), 0, (24, 5, 1, 4, 0.7, 0.1, 0.2, 1e-7)),
+            (5104, 36, 4, 1, 1, 6, 40, (), 1, (24, 6, 2, 4, 0.7, 0.1, 0.2, 1e-7))):
+        rng = np.random.default_rng(seed)
+        g = len(derivs)
+        c = dict(n=n, d=d, q=q, p=p, P=P, M=M, derivs=np.array(derivs, dtype=np.int32), num_fidelity=f, rng_seed=seed % 1000)
+        c["X"] = rng.uniform(0.05, 0.95, size=(n, d))
+        c["y"] = np.zeros((n, 1 + g))
+        c["y"][:, 0] = np.sin(3 * c["X"]).sum(1) + 0.1 * rng.uniform(size=n)
+        for a, dd in enumerate(derivs):
+            c["y"][:, 1 + a] = 3 * np.cos(3 * c["X"][:, dd])
+        c["alpha"] = 1.1
+        c["lengths"] = rng.uniform(0.5, 0.9, size=d)
+        c["noise"] = np.full(1 + g, 0.02)
+        c["bounds"] = np.tile([0.0, 1.0], d)
+        c["Xp"] = rng.uniform(0.1, 0.9, size=(p, d))
+        c["discrete"] = rng.uniform(0.0, 1.0, size=(P, d - f))
+        c["starts"] = rng.uniform(0.05, 0.95, size=(24, q, d))
+        c["outer_gd"], c["inner_gd"] = np.array(outer), inner
+        gp = ref.RefGP(1, c["alpha"], c["lengths"], c["X"], c["y"], c["noise"], list(derivs))
+        disc_full = np.hstack([c["discrete"], np.ones((P, f))]) if f else c["discrete"]
+        c["best_so_far"] = float(gp.additional_mean(disc_full).min())
+        m = (q + p) * (1 + g)
+        c["normals"] = ref.normal_draws(c["rng_seed"], ((M + 1) // 2) * m).reshape(-1, m)
+        Xp = c["Xp"] if p else None
+        best, found = gp.kg_multistart(c["outer_gd"], inner, c["bounds"], c["discrete"], c["starts"], Xp, M, c["best_so_far"],
+                                       c["rng_seed"], num_fidelity=f)
+        # KG of the returned point on a FRESH state through the table route (for information; the driver's own value is the
+        # frozen-head one, see oracle/moe_oracle.c: orc_kg_head)
+        kb = gp.kg(inner, c["bounds"][: 2 * (d - f)], c["discrete"], best, Xp, M, c["best_so_far"], c["normals"], want_grad=False,
+                   num_fidelity=f)["kg"]
+        o = dict(best_point=best, found=np.array(int(found)), best_kg_fresh=np.array(kb))
+        print("kg multistart case %d: n=%d d=%d q=%d p=%d g=%d f=%d  KG(best point, fresh state)=%.12g found=%d" % (
+            k, n, d, q, p, g, f, kb, found))
+        for key, val in c.items():
+            blob["k%d_in_%s" % (k, key)] = np.asarray(val)
+        for key, val in o.items():
+            blob["k%d_out_%s" % (k, key)] = np.asarray(val)
+        k += 1
+    blob["num"] = np.array(k)
+    # MCMC twin: without and with a fidelity dimension (cost and its gradient live), q = 2
+    for mi, (seed, n, d, q, p, P, M, nm, f, outer) in enumerate((
+            (6201, 30, 3, 2, 0, 6, 32, 3, 0, (24, 5, 2, 4, 0.7, 0.1, 0.2, 1e-7)),
+            (6202, 32, 4, 2, 1, 6, 32, 2, 1, (24, 4, 2, 4, 0.7, 0.05, 0.2, 1e-7)))):
+        rng = np.random.default_rng(seed)
+        c = dict(n=n, d=d, q=q, p=p, P=P, M=M, num_mcmc=nm, derivs=np.array((), dtype=np.int32), num_fidelity=f,
+                 rng_seed=77 + mi)
+        c["X"] = rng.uniform(0.05, 0.95, size=(n, d))
+        c["y"] = (np.sin(3 * c["X"]).sum(1) + 0.1 * rng.uniform(size=n))[:, None]
+        c["hypers"] = np.c_[rng.uniform(0.8, 1.5, nm), rng.uniform(0.5, 0.9, size=(nm, d))]
+        c["noises"] = rng.uniform(0.01, 0.05, size=(nm, 1))
+        c["bounds"] = np.tile([0.0, 1.0], d)
+        if f:
+            c["bounds"][2 * (d - f):] = np.tile([0.2, 1.0], f)  # fidelity coordinates stay away from 0 (the cost divides by them)
+        c["Xp"] = rng.uniform(0.25, 0.9, size=(p, d))
+        c["discrete"] = rng.uniform(0.0, 1.0, size=(nm, P, d - f))
+        c["starts"] = rng.uniform(0.25, 0.9, size=(24, q, d))
+        c["outer_gd"], c["inner_gd"] = np.array(outer), inner
+        R = ref.RefGPMCMC(c["hypers"], c["noises"], c["X"], c["y"], ())
+        bests = []
+        for i in range(nm):
+            gi = ref.RefGP(1, c["hypers"][i, 0], c["hypers"][i, 1:], c["X"], c["y"], c["noises"][i], [])
+            dfull = np.hstack([c["discrete"][i], np.ones((P, f))]) if f else c["discrete"][i]
+            bests.append(float(gi.additional_mean(dfull).min()))
+        c["best_so_far"] = np.array(bests)
+        m = q + p
+        c["normals"] = ref.normal_draws(c["rng_seed"], ((M + 1) // 2) * m).reshape(-1, m)
+        Xp = c["Xp"] if p else None
+        best, found = R.kg_multistart(c["outer_gd"], inner, c["bounds"], c["discrete"], c["starts"], Xp, M, c["best_so_far"],
+                                      c["rng_seed"], num_fidelity=f)
+        print("kg mcmc multistart %d: q=%d p=%d f=%d found=%d best=%s" % (mi, q, p, f, found, np.round(best.ravel(), 4)))
+        for key, val in c.items():
+            blob["mk%d_in_%s" % (mi, key)] = np.asarray(val)
+        blob["mk%d_out_best_point" % mi], blob["mk%d_out_found" % mi] = best, np.array(int(found))
+    blob["num_mcmc"] = np.array(2)
+    np.savez_compressed(OUT_MS, **blob)
+    print("wrote", OUT_MS, os.path.getsize(OUT_MS), "bytes")
+
+
 def main():
     if "--ll-grad" in sys.argv:
         ll_grad_fixtures()
         return
+    if "--shapes" in sys.argv:
+        shape_fixtures()
+        return
+    if "--kg-multistart" in sys.argv:
+        kg_multistart_fixtures()
+        return
     ll_grad_fixtures()
+    shape_fixtures()
+    kg_multistart_fixtures()
     cases = []
     inner_test = (1, 100, 10, 3, 0.0, 1.0, 0.1, 1e-10)   # inner GD of the reference's KG ping test (100 steps, 10 restarts)
     inner_prod = (1, 6, 1, 3, 0.0, 1.0, 0.1, 1e-10)      # examples/main.py:123-130
