@@ -60,6 +60,8 @@ SIGNATURES = {
                          dp, C.c_int, C.c_int, C.c_int, dp, dp, dp, C.POINTER(KgStats), _EP]),
     "moe_kg_batch": (C.c_int, [_GP, C.c_int, C.POINTER(GdParams), dp, dp, C.c_int, dp, C.c_int, dp, C.c_int, C.c_int,
                                C.c_int, C.c_double, dp, C.c_int, C.c_int, C.c_int, dp, dp, C.POINTER(KgStats), _EP]),
+    "moe_kg_batch_multi": (C.c_int, [_GPA, C.c_int, C.c_int, C.c_int, C.POINTER(GdParams), dp, dp, C.c_int, dp, C.c_int, dp,
+                                     C.c_int, C.c_int, C.c_int, C.c_double, dp, C.c_int, dp, dp, C.POINTER(KgStats), _EP]),
     "moe_kg_multistart": (C.c_int, [_GP, C.c_int, C.POINTER(GdParams), C.POINTER(GdParams), dp, dp, C.c_int, dp, C.c_int, dp,
                                     C.c_int, C.c_int, C.c_int, C.c_double, dp, C.c_int, dp, dp, ip, _EP]),
     "moe_kg_mcmc_batch": (C.c_int, [_GPA, C.c_int, C.c_int, C.POINTER(GdParams), dp, dp, C.c_int, dp, C.c_int, dp, C.c_int,

@@ -145,8 +145,10 @@ class DeviceGP(object):
         vals, vp = _d(vals)
         k = pts.reshape(-1, self.d).shape[0]
         err = _lib.MoeError()
-        _check(_lib.load().moe_gp_add_points(self._h, pp, vp, k, C.byref(err)), err)
-        self.n += k
+        try:
+            _check(_lib.load().moe_gp_add_points(self._h, pp, vp, k, C.byref(err)), err)
+        finally:  # a failed append rolls the handle back: always mirror what the device holds
+            self.n = int(_lib.load().moe_gp_num_sampled(self._h))
 
     def get_factor(self):
         N = self.N
@@ -419,6 +421,38 @@ class DeviceGP(object):
         out = np.zeros(5)
         _lib.load().moe_last_kernel_ms(self._h, out.ctypes.data_as(dp))
         return dict(mc=out[0], cov_build=out[1], tail=out[2], state=out[3], total=out[4])
+
+
+def kg_batch_multi(gps, shard, inner_params, bounds, discrete, Xq_all, Xp, num_mc, best_so_far, normals, want_grad=True,
+                   num_fidelity=0):
+    """moe_kg_batch_multi: the same GP on several devices (`gps`: DeviceGP objects built with device = 0 .. W-1), one host
+    thread per device inside the library; shard = "restarts" (evaluation e on handle e % W) or "mc" (every handle takes an
+    even-aligned slice of the samples, host-side fixed-order sum).  Returns the dict kg_batch returns."""
+    L = _lib.load()
+    g0 = gps[0]
+    gd = DeviceGP._gd(inner_params)
+    bounds, bp = _d(bounds)
+    discrete, dpp = _d(discrete)
+    P = discrete.reshape(-1, g0.d - num_fidelity).shape[0]
+    Xq_all = np.ascontiguousarray(Xq_all, dtype=np.float64)
+    R, q, _ = Xq_all.shape
+    if Xp is None or np.size(Xp) == 0:
+        p, ppp = 0, None
+    else:
+        Xp, ppp = _d(Xp)
+        p = Xp.reshape(-1, g0.d).shape[0]
+    normals, npn = _d(normals)
+    arr = (C.c_void_p * len(gps))(*[g._h.value for g in gps])
+    kg = np.zeros(R)
+    grad = np.zeros(R * q * g0.d)
+    stats = _lib.KgStats()
+    err = _lib.MoeError()
+    _check(L.moe_kg_batch_multi(arr, len(gps), {"restarts": 0, "mc": 1}[shard], int(num_fidelity), C.byref(gd), bp, dpp, P,
+                                Xq_all.ctypes.data_as(dp), R, ppp, q, p, int(num_mc), float(best_so_far), npn,
+                                1 if want_grad else 0, kg.ctypes.data_as(dp), grad.ctypes.data_as(dp), C.byref(stats),
+                                C.byref(err)), err)
+    return dict(kg_sum=kg, grad_sum=grad.reshape(R, q, g0.d) if want_grad else None, mean_evals=stats.posterior_mean_evals,
+                grad_evals=stats.posterior_grad_evals)
 
 
 class DeviceGPMCMC(object):

@@ -3,13 +3,19 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <mutex>
 #include <random>
+#include <thread>
 
 #include "gp.hpp"
 #include "kg.hpp"
 
 struct moe_gp {
   moe::GpDev dev;
+  // One call at a time per handle: every entry point works in the handle's own device workspaces, pinned staging buffers and
+  // stream (the reference's GaussianProcess is genuinely const; this one is const in what it represents only).  ctypes / cgo
+  // callers release their runtime's lock around a call, so two host threads sharing a handle would otherwise race.
+  std::mutex mu;
   moe_gp(const double* hyper, int cov_type, const double* X, const double* y, const double* noise, const int* derivs, int g,
          int d, int n, int device)
       : dev(hyper, cov_type, X, y, noise, derivs, g, d, n, device) {}
@@ -42,6 +48,14 @@ int guarded(moe_error_t* err, F&& f) {
 
 void require(bool cond, const char* what) {
   if (!cond) throw moe::Error(MOE_ERR_RUNTIME, what);
+}
+
+// The device GP behind a handle, with the handle locked for the caller's scope (NULL handles are an error, not a crash).
+moe::GpDev& lock_gp(const moe_gp_t* gp_c, std::unique_lock<std::mutex>& lk) {
+  require(gp_c != nullptr, "NULL GP handle");
+  moe_gp_t* gp = const_cast<moe_gp_t*>(gp_c);
+  lk = std::unique_lock<std::mutex>(gp->mu);
+  return gp->dev;
 }
 
 moe::DerivList no_derivs() {
@@ -84,6 +98,7 @@ int moe_device_count(int* count) {
 
 int moe_device_arch(int device, char* name, int name_len) {
   hipDeviceProp_t prop;
+  if (name == nullptr || name_len <= 0) return MOE_ERR_BOUNDS;
   if (hipGetDeviceProperties(&prop, device) != hipSuccess) return MOE_ERR_RUNTIME;
   std::strncpy(name, prop.gcnArchName, name_len - 1);
   name[name_len - 1] = '\0';
@@ -106,17 +121,23 @@ int moe_gp_destroy(moe_gp_t* gp) {
   return MOE_OK;
 }
 
-int moe_gp_dim(const moe_gp_t* gp) { return gp->dev.d; }
-int moe_gp_num_sampled(const moe_gp_t* gp) { return gp->dev.n; }
-int moe_gp_num_derivatives(const moe_gp_t* gp) { return gp->dev.g; }
+int moe_gp_dim(const moe_gp_t* gp) { return gp ? gp->dev.d : -1; }
+int moe_gp_num_sampled(const moe_gp_t* gp) { return gp ? gp->dev.n : -1; }
+int moe_gp_num_derivatives(const moe_gp_t* gp) { return gp ? gp->dev.g : -1; }
 
-int moe_gp_add_points(moe_gp_t* gp, const double* new_points, const double* new_values, int num_new, moe_error_t* err) {
-  return guarded(err, [&] { gp->dev.add_points(new_points, new_values, num_new); });
+int moe_gp_add_points(moe_gp_t* gp_c, const double* new_points, const double* new_values, int num_new, moe_error_t* err) {
+  return guarded(err, [&] {
+    std::unique_lock<std::mutex> lk;
+    moe::GpDev& gp = lock_gp(gp_c, lk);
+    require(num_new <= 0 || (new_points != nullptr && new_values != nullptr), "NULL argument");
+    gp.add_points(new_points, new_values, num_new);
+  });
 }
 
 int moe_gp_get_factor(const moe_gp_t* gp_c, double* K_chol, double* K_inv_y, double* mean, moe_error_t* err) {
   return guarded(err, [&] {
-    moe::GpDev& gp = const_cast<moe_gp_t*>(gp_c)->dev;
+    std::unique_lock<std::mutex> lk;
+    moe::GpDev& gp = lock_gp(gp_c, lk);
     gp.use_device();
     if (K_chol)
       MOE_HIP_CHECK(hipMemcpy2DAsync(K_chol, sizeof(double) * gp.N, gp.dL.p, sizeof(double) * gp.ldL, sizeof(double) * gp.N,
@@ -129,7 +150,8 @@ int moe_gp_get_factor(const moe_gp_t* gp_c, double* K_chol, double* K_inv_y, dou
 
 int moe_gp_mean(const moe_gp_t* gp_c, const double* pts, int num_pts, double* out, moe_error_t* err) {
   return guarded(err, [&] {
-    moe::GpDev& gp = const_cast<moe_gp_t*>(gp_c)->dev;
+    std::unique_lock<std::mutex> lk;
+    moe::GpDev& gp = lock_gp(gp_c, lk);
     gp.mean_of_points(pts, num_pts, out, nullptr);
   });
 }
@@ -140,7 +162,8 @@ int moe_gp_additional_mean(const moe_gp_t* gp, const double* pts, int num_pts, d
 
 int moe_gp_grad_mean(const moe_gp_t* gp_c, const double* pts, int num_pts, double* out, moe_error_t* err) {
   return guarded(err, [&] {
-    moe::GpDev& gp = const_cast<moe_gp_t*>(gp_c)->dev;
+    std::unique_lock<std::mutex> lk;
+    moe::GpDev& gp = lock_gp(gp_c, lk);
     moe::StateHost h;
     moe::compute_state(gp, pts, num_pts, gp.derivs, num_pts, nullptr, 0, false, nullptr, &h);
     moe::host_grad_mean(h, out);
@@ -149,7 +172,8 @@ int moe_gp_grad_mean(const moe_gp_t* gp_c, const double* pts, int num_pts, doubl
 
 int moe_gp_variance(const moe_gp_t* gp_c, const double* pts, int num_pts, double* out, moe_error_t* err) {
   return guarded(err, [&] {
-    moe::GpDev& gp = const_cast<moe_gp_t*>(gp_c)->dev;
+    std::unique_lock<std::mutex> lk;
+    moe::GpDev& gp = lock_gp(gp_c, lk);
     moe::StateHost h;
     moe::compute_state(gp, pts, num_pts, gp.derivs, 0, nullptr, 0, false, nullptr, &h);
     moe::host_variance(h, out);
@@ -158,7 +182,8 @@ int moe_gp_variance(const moe_gp_t* gp_c, const double* pts, int num_pts, double
 
 int moe_gp_cholesky_variance(const moe_gp_t* gp_c, const double* pts, int num_pts, double* out, moe_error_t* err) {
   return guarded(err, [&] {
-    moe::GpDev& gp = const_cast<moe_gp_t*>(gp_c)->dev;
+    std::unique_lock<std::mutex> lk;
+    moe::GpDev& gp = lock_gp(gp_c, lk);
     moe::StateHost h;
     moe::compute_state(gp, pts, num_pts, gp.derivs, 0, nullptr, 0, false, nullptr, &h);
     moe::host_variance(h, out);
@@ -175,7 +200,8 @@ int moe_gp_cholesky_variance(const moe_gp_t* gp_c, const double* pts, int num_pt
 int moe_gp_grad_variance(const moe_gp_t* gp_c, const double* pts, int num_pts, int num_derivs, double* out,
                          moe_error_t* err) {
   return guarded(err, [&] {
-    moe::GpDev& gp = const_cast<moe_gp_t*>(gp_c)->dev;
+    std::unique_lock<std::mutex> lk;
+    moe::GpDev& gp = lock_gp(gp_c, lk);
     require(num_derivs >= 0 && num_derivs <= num_pts, "num_derivs must be in [0, num_pts]");
     moe::StateHost h;
     moe::compute_state(gp, pts, num_pts, gp.derivs, num_derivs, nullptr, 0, false, nullptr, &h);
@@ -187,7 +213,8 @@ int moe_gp_grad_variance(const moe_gp_t* gp_c, const double* pts, int num_pts, i
 int moe_gp_grad_cholesky_variance(const moe_gp_t* gp_c, const double* pts, int num_pts, int num_derivs, double* out,
                                   moe_error_t* err) {
   return guarded(err, [&] {
-    moe::GpDev& gp = const_cast<moe_gp_t*>(gp_c)->dev;
+    std::unique_lock<std::mutex> lk;
+    moe::GpDev& gp = lock_gp(gp_c, lk);
     require(num_derivs >= 0 && num_derivs <= num_pts, "num_derivs must be in [0, num_pts]");
     moe::StateHost h;
     moe::compute_state(gp, pts, num_pts, gp.derivs, num_derivs, nullptr, 0, false, nullptr, &h);
@@ -208,7 +235,8 @@ int moe_gp_grad_cholesky_variance(const moe_gp_t* gp_c, const double* pts, int n
 int moe_posterior_mean(const moe_gp_t* gp_c, int num_fidelity, const double* point, double* value, double* grad,
                        moe_error_t* err) {
   return guarded(err, [&] {
-    moe::GpDev& gp = const_cast<moe_gp_t*>(gp_c)->dev;
+    std::unique_lock<std::mutex> lk;
+    moe::GpDev& gp = lock_gp(gp_c, lk);
     require(num_fidelity >= 0 && num_fidelity < gp.d, "num_fidelity out of range");
     std::vector<double> pt(gp.d, 1.0);  // fidelity coordinates pinned to 1 (gpp_knowledge_gradient_optimization.cpp:353-357)
     for (int i = 0; i < gp.d - num_fidelity; ++i) pt[i] = point[i];
@@ -239,7 +267,8 @@ int moe_normal_draws(unsigned int seed, long long count, double* out) {
 int moe_gp_mix_covariance(const moe_gp_t* gp_c, const double* pts, int num_pts, const int* derivs2, int g2, double* out,
                           moe_error_t* err) {
   return guarded(err, [&] {
-    moe::GpDev& gp = const_cast<moe_gp_t*>(gp_c)->dev;
+    std::unique_lock<std::mutex> lk;
+    moe::GpDev& gp = lock_gp(gp_c, lk);
     gp.use_device();
     moe::DerivList d2 = no_derivs();
     require(g2 >= 0 && g2 <= moe::kMaxDerivs, "g2 out of range");
@@ -258,7 +287,8 @@ int moe_gp_mix_covariance(const moe_gp_t* gp_c, const double* pts, int num_pts, 
 int moe_cov_build_probe(const moe_gp_t* gp_c, const double* pts, int num_pts, int repeat, double* avg_ms,
                         double* bytes_per_launch, moe_error_t* err) {
   return guarded(err, [&] {
-    moe::GpDev& gp = const_cast<moe_gp_t*>(gp_c)->dev;
+    std::unique_lock<std::mutex> lk;
+    moe::GpDev& gp = lock_gp(gp_c, lk);
     gp.use_device();
     const std::vector<double> P = gp.padded(pts, num_pts);
     moe::DevBuf<double> dP, dOut;
@@ -326,6 +356,7 @@ int moe_debug_math(int n, const double* x, int device, double* exp_neg, double* 
 }
 
 int moe_last_kernel_ms(const moe_gp_t* gp, double* out5) {
+  if (gp == nullptr || out5 == nullptr) return MOE_ERR_RUNTIME;
   for (int i = 0; i < 5; ++i) out5[i] = gp->dev.last_ms[i];
   return MOE_OK;
 }
@@ -334,7 +365,8 @@ int moe_ei(const moe_gp_t* gp_c, const double* points_to_sample, const double* p
            int num_being_sampled, int num_mc, double best_so_far, const double* normals, double* ei, double* grad_ei,
            moe_error_t* err) {
   return guarded(err, [&] {
-    moe::GpDev& gp = const_cast<moe_gp_t*>(gp_c)->dev;
+    std::unique_lock<std::mutex> lk;
+    moe::GpDev& gp = lock_gp(gp_c, lk);
     moe::ei_evaluate(gp, points_to_sample, points_being_sampled, num_to_sample, num_being_sampled, num_mc, best_so_far,
                      normals, ei, grad_ei);
   });
@@ -344,7 +376,8 @@ int moe_ei_batch(const moe_gp_t* gp_c, const double* points_to_sample_all, int n
                  int num_to_sample, int num_being_sampled, int num_mc, double best_so_far, const double* normals,
                  double* ei, double* grad_ei, moe_error_t* err) {
   return guarded(err, [&] {
-    moe::GpDev& gp = const_cast<moe_gp_t*>(gp_c)->dev;
+    std::unique_lock<std::mutex> lk;
+    moe::GpDev& gp = lock_gp(gp_c, lk);
     moe::ei_evaluate_batch(gp, points_to_sample_all, num_evals, points_being_sampled, num_to_sample, num_being_sampled, num_mc,
                            best_so_far, normals, ei, grad_ei);
   });
@@ -353,7 +386,8 @@ int moe_ei_batch(const moe_gp_t* gp_c, const double* points_to_sample_all, int n
 int moe_ei_analytic_batch(const moe_gp_t* gp_c, const double* points, int num_evals, double best_so_far, double* ei,
                           double* grad_ei, moe_error_t* err) {
   return guarded(err, [&] {
-    moe::GpDev& gp = const_cast<moe_gp_t*>(gp_c)->dev;
+    std::unique_lock<std::mutex> lk;
+    moe::GpDev& gp = lock_gp(gp_c, lk);
     require(points != nullptr, "NULL argument");
     moe::ei_analytic_batch(gp, points, num_evals, best_so_far, ei, grad_ei);
   });
@@ -364,7 +398,8 @@ int moe_ei_multistart(const moe_gp_t* gp_c, const moe_gd_params_t* outer_params,
                       int num_being_sampled, int num_mc, double best_so_far, const double* normals, int do_gradient_ascent,
                       double* best_points, double* best_ei, int* found, moe_error_t* err) {
   return guarded(err, [&] {
-    moe::GpDev& gp = const_cast<moe_gp_t*>(gp_c)->dev;
+    std::unique_lock<std::mutex> lk;
+    moe::GpDev& gp = lock_gp(gp_c, lk);
     require(outer_params && domain_bounds && start_points && best_points && best_ei && found, "NULL argument");
     moe::ei_multistart(gp, *outer_params, domain_bounds, start_points, num_starts, points_being_sampled, num_to_sample,
                        num_being_sampled, num_mc, best_so_far, normals, do_gradient_ascent, best_points, best_ei, found);
@@ -377,7 +412,9 @@ int moe_kg_batch(const moe_gp_t* gp_c, int num_fidelity, const moe_gd_params_t* 
                  double best_so_far, const double* normals, int first_sample, int num_local, int want_grad,
                  double* kg_sum, double* grad_sum, moe_kg_stats_t* stats, moe_error_t* err) {
   return guarded(err, [&] {
-    moe::GpDev& gp = const_cast<moe_gp_t*>(gp_c)->dev;
+    std::unique_lock<std::mutex> lk;
+    moe::GpDev& gp = lock_gp(gp_c, lk);
+    require(inner_params && domain_bounds && points_to_sample_all && normals && kg_sum, "NULL argument");
     moe::kg_evaluate_batch(gp, num_fidelity, *inner_params, domain_bounds, discrete_pts, num_pts, points_to_sample_all,
                            num_evals, points_being_sampled, num_to_sample, num_being_sampled, num_mc, best_so_far, normals,
                            first_sample, num_local, want_grad != 0, kg_sum, grad_sum, nullptr, stats);
@@ -390,7 +427,8 @@ int moe_kg_multistart(const moe_gp_t* gp_c, int num_fidelity, const moe_gd_param
                       int num_being_sampled, int num_mc, double best_so_far, const double* normals, int do_gradient_ascent,
                       double* best_points, double* best_kg, int* found, moe_error_t* err) {
   return guarded(err, [&] {
-    moe::GpDev& gp = const_cast<moe_gp_t*>(gp_c)->dev;
+    std::unique_lock<std::mutex> lk;
+    moe::GpDev& gp = lock_gp(gp_c, lk);
     require(outer_params && inner_params && best_points && best_kg && found, "NULL argument");
     moe::kg_multistart(gp, num_fidelity, *outer_params, *inner_params, domain_bounds, discrete_pts, num_pts, start_points,
                        num_starts, points_being_sampled, num_to_sample, num_being_sampled, num_mc, best_so_far, normals,
@@ -408,7 +446,112 @@ std::vector<moe::GpDev*> ensemble(const moe_gp_t* const* gps, int num_mcmc) {
   }
   return v;
 }
+
+// Every member of an ensemble locked for the caller's scope, in address order (two calls sharing members cannot deadlock).
+std::vector<std::unique_lock<std::mutex>> lock_ensemble(const moe_gp_t* const* gps, int num_mcmc) {
+  std::vector<moe_gp_t*> hs;
+  for (int i = 0; gps != nullptr && i < num_mcmc; ++i)
+    if (gps[i] != nullptr) hs.push_back(const_cast<moe_gp_t*>(gps[i]));
+  std::sort(hs.begin(), hs.end());
+  hs.erase(std::unique(hs.begin(), hs.end()), hs.end());
+  std::vector<std::unique_lock<std::mutex>> locks;
+  for (moe_gp_t* h : hs) locks.emplace_back(h->mu);
+  return locks;
+}
 }  // namespace
+
+// ---- one node, several devices, no torch: SURVEY 8b "multistart drivers taking num_devices" ----
+// gps[num_devices] are handles of the SAME GP built on different devices (moe_gp_create(..., device = k, ...)); one host
+// thread per handle drives its device.  shard_mode 0 (restarts): evaluation e runs whole on handle e % num_devices
+// (round-robin, like omp schedule(static,1) over the starts, gpp_optimization.hpp:1481-1535) -- results are those of
+// moe_kg_batch, bit for bit.  shard_mode 1 (MC samples): every handle evaluates every point set on its contiguous
+// EVEN-ALIGNED slice of the samples (antithetic pairs stay together) and the per-handle sums are added on the host in handle
+// order -- a fixed-order reduction of num_evals x (1 + q d) doubles, the all_reduce of the multi-process path
+// (cornell_moe_amd/dist.py) done in shared memory.
+int moe_kg_batch_multi(const moe_gp_t* const* gps, int num_devices, int shard_mode, int num_fidelity,
+                       const moe_gd_params_t* inner_params, const double* domain_bounds, const double* discrete_pts, int num_pts,
+                       const double* points_to_sample_all, int num_evals, const double* points_being_sampled,
+                       int num_to_sample, int num_being_sampled, int num_mc, double best_so_far, const double* normals,
+                       int want_grad, double* kg_sum, double* grad_sum, moe_kg_stats_t* stats, moe_error_t* err) {
+  return guarded(err, [&] {
+    require(gps != nullptr && num_devices > 0, "need at least one GP handle");
+    require(inner_params && domain_bounds && points_to_sample_all && normals && kg_sum, "NULL argument");
+    require(!want_grad || grad_sum != nullptr, "grad_sum is NULL");
+    require(shard_mode == 0 || shard_mode == 1, "shard_mode must be 0 (restarts) or 1 (MC samples)");
+    require(num_evals > 0, "num_evals must be positive");
+    const auto locks = lock_ensemble(gps, num_devices);
+    require((int)locks.size() == num_devices, "the handles must be distinct and non-NULL");
+    const int W = num_devices, E = num_evals;
+    const int d = gps[0]->dev.d, qd = num_to_sample * d;
+    for (int k = 1; k < W; ++k)
+      require(gps[k]->dev.d == d && gps[k]->dev.n == gps[0]->dev.n && gps[k]->dev.g == gps[0]->dev.g,
+              "the handles must hold the same GP");
+    // work lists
+    std::vector<std::vector<int>> mine(W);
+    std::vector<int> first(W, 0), count(W, num_mc);
+    if (shard_mode == 0) {
+      for (int e = 0; e < E; ++e) mine[e % W].push_back(e);
+    } else {
+      const int pairs = (num_mc + 1) / 2, base = pairs / W, rem = pairs % W;
+      for (int k = 0; k < W; ++k) {
+        const int p0 = k * base + std::min(k, rem), p1 = p0 + base + (k < rem ? 1 : 0);
+        first[k] = 2 * p0;
+        count[k] = std::max(std::min(2 * p1, num_mc) - first[k], 0);
+        for (int e = 0; e < E; ++e) mine[k].push_back(e);
+      }
+    }
+    std::vector<std::vector<double>> ks(W), gs(W), xs(W);
+    std::vector<moe_kg_stats_t> st(W);
+    std::vector<moe::Error> errors(W, moe::Error(MOE_OK, ""));
+    std::vector<char> failed(W, 0);
+    std::vector<std::thread> threads;
+    for (int k = 0; k < W; ++k) {
+      const int ne = (int)mine[k].size();
+      st[k] = moe_kg_stats_t{};
+      if (ne == 0 || count[k] == 0) continue;
+      ks[k].assign(ne, 0.0);
+      gs[k].assign(want_grad ? (size_t)ne * qd : 0, 0.0);
+      xs[k].resize((size_t)ne * qd);
+      for (int j = 0; j < ne; ++j)
+        std::copy(points_to_sample_all + (size_t)mine[k][j] * qd, points_to_sample_all + (size_t)(mine[k][j] + 1) * qd,
+                  &xs[k][(size_t)j * qd]);
+      threads.emplace_back([&, k, ne] {
+        try {
+          moe::kg_evaluate_batch(const_cast<moe_gp_t*>(gps[k])->dev, num_fidelity, *inner_params, domain_bounds, discrete_pts,
+                                 num_pts, xs[k].data(), ne, points_being_sampled, num_to_sample, num_being_sampled, num_mc,
+                                 best_so_far, normals, first[k], count[k], want_grad != 0, ks[k].data(),
+                                 want_grad ? gs[k].data() : nullptr, nullptr, &st[k]);
+        } catch (const moe::Error& e) {
+          errors[k] = e;
+          failed[k] = 1;
+        } catch (const std::exception& e) {
+          errors[k] = moe::Error(MOE_ERR_RUNTIME, e.what());
+          failed[k] = 1;
+        }
+      });
+    }
+    for (std::thread& t : threads) t.join();
+    for (int k = 0; k < W; ++k)
+      if (failed[k]) throw errors[k];
+    std::fill(kg_sum, kg_sum + E, 0.0);
+    if (want_grad) std::fill(grad_sum, grad_sum + (size_t)E * qd, 0.0);
+    moe_kg_stats_t total{};
+    for (int k = 0; k < W; ++k) {  // handle order: a fixed-order reduction
+      for (size_t j = 0; j < ks[k].size(); ++j) {
+        const int e = mine[k][j];
+        kg_sum[e] += ks[k][j];
+        if (want_grad)
+          for (int c = 0; c < qd; ++c) grad_sum[(size_t)e * qd + c] += gs[k][j * qd + c];
+      }
+      total.posterior_mean_evals += st[k].posterior_mean_evals;
+      total.posterior_grad_evals += st[k].posterior_grad_evals;
+      total.ms_state = std::max(total.ms_state, st[k].ms_state);  // the devices run side by side: the slowest one counts
+      total.ms_mc = std::max(total.ms_mc, st[k].ms_mc);
+      total.ms_tail = std::max(total.ms_tail, st[k].ms_tail);
+    }
+    if (stats) *stats = total;
+  });
+}
 
 int moe_kg_mcmc_batch(const moe_gp_t* const* gps, int num_mcmc, int num_fidelity, const moe_gd_params_t* inner_params,
                       const double* domain_bounds, const double* discrete_pts_all, int num_pts,
@@ -419,6 +562,7 @@ int moe_kg_mcmc_batch(const moe_gp_t* const* gps, int num_mcmc, int num_fidelity
     require(inner_params && domain_bounds && discrete_pts_all && points_to_sample_all && best_so_far && normals && kg,
             "NULL argument");
     require(num_evals > 0, "num_evals must be positive");
+    const auto locks = lock_ensemble(gps, num_mcmc);
     const std::vector<moe::GpDev*> v = ensemble(gps, num_mcmc);
     moe::kg_mcmc_sums(v, num_fidelity, *inner_params, domain_bounds, discrete_pts_all, num_pts, points_to_sample_all, num_evals,
                       points_being_sampled, num_to_sample, num_being_sampled, num_mc, best_so_far, normals, grad_kg != nullptr,
@@ -445,6 +589,7 @@ int moe_ei_mcmc_batch(const moe_gp_t* const* gps, int num_mcmc, const double* po
   return guarded(err, [&] {
     require(points_to_sample_all && best_so_far && (analytic || normals), "NULL argument");
     require(num_evals > 0, "num_evals must be positive");
+    const auto locks = lock_ensemble(gps, num_mcmc);
     const std::vector<moe::GpDev*> v = ensemble(gps, num_mcmc);
     moe::ei_mcmc_batch(v, points_to_sample_all, num_evals, points_being_sampled, num_to_sample, num_being_sampled, num_mc,
                        best_so_far, normals, analytic != 0, ei, grad_ei);
@@ -461,6 +606,7 @@ int moe_kg_mcmc_multistart(const moe_gp_t* const* gps, int num_mcmc, int num_fid
     require(outer_params && inner_params && domain_bounds && discrete_pts_all && start_points && best_so_far && normals &&
                 best_points && best_kg && found,
             "NULL argument");
+    const auto locks = lock_ensemble(gps, num_mcmc);
     const std::vector<moe::GpDev*> v = ensemble(gps, num_mcmc);
     moe::kg_mcmc_multistart(v, num_fidelity, *outer_params, *inner_params, domain_bounds, discrete_pts_all, num_pts, start_points,
                             num_starts, points_being_sampled, num_to_sample, num_being_sampled, num_mc, best_so_far, normals,
@@ -475,6 +621,7 @@ int moe_ei_mcmc_multistart(const moe_gp_t* const* gps, int num_mcmc, const moe_g
                            double* best_ei, int* found, moe_error_t* err) {
   return guarded(err, [&] {
     require(outer_params && domain_bounds && start_points && best_so_far && best_points && best_ei && found, "NULL argument");
+    const auto locks = lock_ensemble(gps, num_mcmc);
     const std::vector<moe::GpDev*> v = ensemble(gps, num_mcmc);
     moe::ei_mcmc_multistart(v, *outer_params, domain_bounds, start_points, num_starts, points_being_sampled, num_to_sample,
                             num_being_sampled, num_mc, best_so_far, normals, do_gradient_ascent, best_points, best_ei, found);
@@ -592,7 +739,8 @@ int moe_posterior_mean_optimize(const moe_gp_t* gp_c, int num_fidelity, const mo
                                 const double* domain_bounds, const double* initial_guess, double* best_point,
                                 double* best_value, moe_error_t* err) {
   return guarded(err, [&] {
-    moe::GpDev& gp = const_cast<moe_gp_t*>(gp_c)->dev;
+    std::unique_lock<std::mutex> lk;
+    moe::GpDev& gp = lock_gp(gp_c, lk);
     require(params && best_point, "NULL argument");
     moe::posterior_mean_optimize(gp, num_fidelity, *params, domain_bounds, initial_guess, best_point, best_value);
   });
@@ -610,7 +758,9 @@ int moe_kg(const moe_gp_t* gp_c, int num_fidelity, const moe_gd_params_t* inner_
            int first_sample, int num_local, int want_grad, double* kg_sum, double* grad_sum, double* best_points,
            moe_kg_stats_t* stats, moe_error_t* err) {
   return guarded(err, [&] {
-    moe::GpDev& gp = const_cast<moe_gp_t*>(gp_c)->dev;
+    std::unique_lock<std::mutex> lk;
+    moe::GpDev& gp = lock_gp(gp_c, lk);
+    require(inner_params && domain_bounds && points_to_sample && normals && kg_sum, "NULL argument");
     moe::kg_evaluate_batch(gp, num_fidelity, *inner_params, domain_bounds, discrete_pts, num_pts, points_to_sample, 1,
                            points_being_sampled, num_to_sample, num_being_sampled, num_mc, best_so_far, normals,
                            first_sample, num_local, want_grad != 0, kg_sum, grad_sum, best_points, stats);

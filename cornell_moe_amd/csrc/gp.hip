@@ -320,8 +320,25 @@ void GpDev::mean_of_points(const double* pts, int k, double* mu, double* grad) {
   }
 }
 
+// On failure (a singular matrix with the new points) the handle is rolled back to the data it held before the call and
+// refactorised, so it stays usable and consistent with the caller's own bookkeeping (the reference's AddPointsToGP leaves a
+// half-updated object behind; its Python wrapper then holds an unusable GP).
 void GpDev::add_points(const double* pts, const double* vals, int k) {
   if (k <= 0) return;
+  const size_t x_keep = X.size(), y_keep = y.size();
+  const int n_keep = n;
+  try {
+    add_points_unchecked(pts, vals, k);
+  } catch (...) {
+    X.resize(x_keep);
+    y.resize(y_keep);
+    n = n_keep;
+    rebuild();  // the old data factorised before: this restores L, L^-1, K^-1 y, N and the device copy of X
+    throw;
+  }
+}
+
+void GpDev::add_points_unchecked(const double* pts, const double* vals, int k) {
   const int n0 = n, N0 = N, kk = k * (1 + g);
   X.insert(X.end(), pts, pts + (size_t)k * d);
   y.insert(y.end(), vals, vals + (size_t)k * (1 + g));

@@ -52,6 +52,7 @@ struct GpDev {
   // Appends k observations: a rank-k(1+g) block-row append to L and L^-1 while the head-room lasts (launch_cholesky_append),
   // the full rebuild otherwise.  (AddPointsToGP, gpp_math.cpp:1699-1737, always refactorises.)
   void add_points(const double* pts, const double* vals, int k);
+  void add_points_unchecked(const double* pts, const double* vals, int k);
   void finish_factorisation();
   // New covariance hyper-parameters [alpha, lengths...] and noise [1 + g] on the same data: rebuild in place (buffers and
   // stream are kept) -- the inner step of hyper-parameter sampling (LogMarginalLikelihoodState::SetHyperparameters,

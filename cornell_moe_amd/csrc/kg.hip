@@ -735,6 +735,26 @@ KgPending kg_launch(GpDev& gp, int num_fidelity, const moe_gd_params_t& gd, cons
   const size_t pad_bytes = sizeof(double) * (size_t)(1 + G) * 64;
   const size_t lds_max = 160 * 1024 - sizeof(double) * kExpTabLen - pad_bytes;
   bool xlds = true;
+  // The value passes of the LDS-table kernel take r^2 as |x_j|^2 + |q|^2 - 2 x_j.q (kg_mc.hpp eval_loop), whose absolute error is
+  // ~eps (|x|^2 + |q|^2) in the centred, scaled frame of the tables: harmless while the point set spans tens of length
+  // scales, but 1e-9 .. 1e-5 of r^2 at 1e3 .. 1e5 length scales (short length scales of a hyper-parameter MCMC ensemble) --
+  // enough to break the 1e-8 parity with the reference.  Beyond a frame radius of 100 length scales the direct-difference
+  // kernels are used instead (coordinates streamed from L2, or the workgroup-per-sample kernel): slower, exact.
+  bool wide_frame = false;
+  {
+    double rad2 = 0.0;
+    for (int k = 0; k < d; ++k) {
+      double c = 0.0, ext = 0.0;
+      for (int j = 0; j < n; ++j) c += gp.X[(size_t)j * d + k];
+      c /= std::max(n, 1);
+      for (int j = 0; j < n; ++j) ext = std::max(ext, std::fabs(gp.X[(size_t)j * d + k] - c));
+      for (size_t i = 0; i < (size_t)E * q; ++i) ext = std::max(ext, std::fabs(Xq_all[i * d + k] - c));
+      for (int i = 0; i < p; ++i) ext = std::max(ext, std::fabs(Xp[(size_t)i * d + k] - c));
+      rad2 += (ext * gp.cp.inv_l[k]) * (ext * gp.cp.inv_l[k]);
+    }
+    wide_frame = !(rad2 <= (double)env_int("MOE_KG_DOT_MAX_RADIUS2", 10000));
+    if (wide_frame) xlds = false;
+  }
   // few tiles per pass: a pass is a short dependent chain, so 16 wavefronts per workgroup (the <= 128-VGPR instantiation)
   const int max_waves = (ntiles <= env_int("MOE_KG_SMALL_TILES", 4)) ? 16 : 8;
   int waves = 0;
@@ -742,9 +762,9 @@ KgPending kg_launch(GpDev& gp, int num_fidelity, const moe_gd_params_t& gd, cons
   // (3 wavefronts per CU on the LDS table still beat the workgroup-per-sample kernel without derivative observations --
   //  n = 1500, d = 8: 2.1 vs 3.1 ms per evaluation; with 2 they lose -- n = 1700: 3.6 vs 3.4)
   const int min_xlds_waves = env_int("MOE_KG_MIN_XLDS_WAVES", 3);
-  if (waves < min_xlds_waves) {  // coordinates stay in L2: more wavefronts per workgroup fit
+  if (waves < min_xlds_waves || wide_frame) {  // coordinates stay in L2: more wavefronts per workgroup fit
     const int w2 = (int)std::min<size_t>(8, lds_max / slab_bytes);
-    if (w2 > waves) {
+    if (w2 > waves || wide_frame) {  // (the instantiation without the LDS table is built for <= 8 wavefronts)
       waves = w2;
       xlds = false;
     }

@@ -60,7 +60,10 @@ typedef struct moe_kg_stats {
 } moe_kg_stats_t;
 
 typedef struct moe_gp moe_gp_t; /* opaque; replaces the heap GaussianProcess owned by the Python object
-                                   (gpp_python_gaussian_process.cpp:55-61) */
+                                   (gpp_python_gaussian_process.cpp:55-61).  `const moe_gp_t*` means the GP it represents is
+                                   not changed; every call works in the handle's own device workspaces, so calls on ONE handle
+                                   are serialised by a per-handle mutex (calls on different handles run concurrently).
+                                   NULL handles / NULL mandatory arguments return MOE_ERR_RUNTIME, never crash. */
 
 /* ---- runtime ---- */
 int moe_device_count(int* count);
@@ -177,6 +180,21 @@ int moe_kg_batch(const moe_gp_t* gp, int num_fidelity, const moe_gd_params_t* in
                  const double* points_being_sampled, int num_to_sample, int num_being_sampled, int num_mc,
                  double best_so_far, const double* normals, int first_sample, int num_local, int want_grad,
                  double* kg_sum, double* grad_sum, moe_kg_stats_t* stats, moe_error_t* err);
+
+/* ---- one node, several devices, from a plain C/C++ host (SURVEY 8b "multistart drivers taking num_devices"; the axis the
+ * reference runs as OpenMP iterations, gpp_optimization.hpp:1472-1546).  gps[num_devices] are handles of the SAME GP built on
+ * different devices (moe_gp_create with device = 0 .. num_devices-1; distinct handles on one device are accepted too); one
+ * host thread per handle drives its device.
+ *   shard_mode 0 (restarts): evaluation e runs whole on handle e % num_devices; results equal moe_kg_batch's bit for bit.
+ *   shard_mode 1 (MC samples): every handle evaluates every point set on its contiguous EVEN-ALIGNED slice of the samples and
+ *     the per-handle sums are added on the host in handle order (a fixed-order reduction of num_evals x (1 + q d) doubles).
+ * Outputs as moe_kg_batch (un-normalised sums over all num_mc samples); stats: pass counts summed, times = the slowest
+ * handle's.  The multi-PROCESS equivalent (one rank per GPU, RCCL) is cornell_moe_amd/dist.py. */
+int moe_kg_batch_multi(const moe_gp_t* const* gps, int num_devices, int shard_mode, int num_fidelity,
+                       const moe_gd_params_t* inner_params, const double* domain_bounds, const double* discrete_pts, int num_pts,
+                       const double* points_to_sample_all, int num_evals, const double* points_being_sampled,
+                       int num_to_sample, int num_being_sampled, int num_mc, double best_so_far, const double* normals,
+                       int want_grad, double* kg_sum, double* grad_sum, moe_kg_stats_t* stats, moe_error_t* err);
 
 /* ---- callers of the hot path: the outer optimisation over points_to_sample ----
  * multistart_knowledge_gradient_optimization (gpp_python_knowledge_gradient.cpp:243-313) ->

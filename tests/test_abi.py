@@ -57,3 +57,23 @@ def test_no_silent_cpu_fallback(lib):
     assert "no CPU fallback" in str(ei.value)
     with pytest.raises(api.OptimalLearningException):
         api.debug_cholesky(np.eye(3))
+
+
+def test_null_arguments_are_errors_not_crashes(lib):
+    """NULL handles / NULL mandatory arguments come back as MOE_ERR_* codes through every handle-taking entry point
+    that can be reached without a device (the checks run before any device work)."""
+    err = _lib.MoeError()
+    assert lib.moe_gp_dim(None) == -1 and lib.moe_gp_num_sampled(None) == -1 and lib.moe_gp_num_derivatives(None) == -1
+    assert lib.moe_last_kernel_ms(None, None) == _lib.MOE_ERR_RUNTIME
+    assert lib.moe_device_arch(0, None, 0) == _lib.MOE_ERR_BOUNDS
+    out = np.zeros(4)
+    dp = _lib.dp
+    assert lib.moe_gp_mean(None, out.ctypes.data_as(dp), 1, out.ctypes.data_as(dp), C.byref(err)) == _lib.MOE_ERR_RUNTIME
+    assert b"NULL GP handle" in err.message
+    assert lib.moe_kg_batch(None, 0, None, None, None, 0, None, 1, None, 1, 0, 2, 0.0, None, 0, 2, 1, None, None, None,
+                            C.byref(err)) == _lib.MOE_ERR_RUNTIME
+    assert lib.moe_kg(None, 0, None, None, None, 0, None, None, 1, 0, 2, 0.0, None, 0, 2, 1, None, None, None, None,
+                      C.byref(err)) == _lib.MOE_ERR_RUNTIME
+    assert lib.moe_kg_batch_multi(None, 0, 0, 0, None, None, None, 0, None, 1, None, 1, 0, 2, 0.0, None, 1, None, None, None,
+                                  C.byref(err)) == _lib.MOE_ERR_RUNTIME
+    assert lib.moe_gp_add_points(None, None, None, 1, C.byref(err)) == _lib.MOE_ERR_RUNTIME

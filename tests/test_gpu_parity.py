@@ -444,9 +444,16 @@ def test_add_points_append_singular(api):
     rng = np.random.default_rng(3)
     X = rng.uniform(size=(40, 2))
     gp = api.DeviceGP([1.0, 0.5, 0.5], X, rng.uniform(size=(40, 1)), [0.0])
+    q = rng.uniform(size=(5, 2))
+    before = (gp.mean(q), gp.variance(q))
     with pytest.raises(api.SingularMatrixException) as e:
         gp.add_points(X[[7]], [[0.3]])
     assert e.value.num_rows == 41
+    # the failed append was rolled back: the handle still holds the 40 points and answers as before, on both sides
+    assert gp.n == 40 and gp.N == 40
+    assert np.abs(gp.mean(q) - before[0]).max() <= 1e-12 and np.abs(gp.variance(q) - before[1]).max() <= 1e-12
+    gp.add_points(rng.uniform(size=(2, 2)), rng.uniform(size=(2, 1)))
+    assert gp.n == 42
 
 
 def test_fastmath(api):

@@ -142,3 +142,37 @@ def test_gloo_world2_mcmc_member_shards():
         assert abs(kg - ref_kg) <= 1e-8 * abs(ref_kg)
         assert np.abs(grad - ref_grad).max() <= 1e-8 * max(np.abs(ref_grad).max(), abs(ref_kg))
     assert ret[0][1] == ret[1][1] and np.array_equal(ret[0][2], ret[1][2])  # every rank holds the same reduced result
+
+
+def test_bench_self_launch_world2(tmp_path):
+    """`python bench.py --gpus N` called plainly re-launches itself under torch.distributed.run (bench.self_launch): the
+    launcher -- free port on 127.0.0.1, one process per rank, RANK / WORLD_SIZE in the environment, exit code relayed -- driven
+    here with a gloo stand-in script that does what bench.py's ranks do around the device work (rendezvous, the all_gather of
+    per-restart results, the MAX all_reduce of the elapsed time)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "standin.py"
+    out = tmp_path / "out.txt"
+    script.write_text('''
+import os, sys
+sys.path.insert(0, %r)
+import numpy as np, torch, torch.distributed as dist
+from cornell_moe_amd import dist as mdist
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+assert os.environ.get("MOE_BENCH_SELF_LAUNCHED") == "1" and os.environ["MASTER_ADDR"] == "127.0.0.1"
+dist.init_process_group("gloo", rank=rank, world_size=world)
+R = 3
+idx = list(range(rank * R, (rank + 1) * R))
+kg, grad = mdist.gather_restarts(idx, np.array(idx, dtype=float) + 0.5, np.ones((R, 2, 2)) * (rank + 1), R * world)
+t = torch.tensor([float(rank + 1)], dtype=torch.float64)
+dist.all_reduce(t, op=dist.ReduceOp.MAX)
+if rank == 0:
+    open(sys.argv[1], "w").write("%%d %%g %%s %%g" %% (world, t.item(), kg.tolist(), grad[R * world - 1, 0, 0]))
+dist.destroy_process_group()
+''' % root)
+    code = subprocess.call([sys.executable, "-c",
+                            "import sys; sys.path.insert(0, %r); import bench; sys.exit(bench.self_launch([%r], 2, script=%r))"
+                            % (root, str(out), str(script))], timeout=300)
+    assert code == 0
+    assert out.read_text() == "2 2 [0.5, 1.5, 2.5, 3.5, 4.5, 5.5] 2"
