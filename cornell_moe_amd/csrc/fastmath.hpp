@@ -36,9 +36,8 @@ __device__ __forceinline__ double exp_nonpos(double x) {
 
 // Table-driven variant for the hottest loop (kg_mc.hpp): x = k ln2/64 + r, |r| <= ln2/128, e^x = 2^(k>>6) * T[k&63] * e^r
 // with T[j] = 2^(j/64) (correctly rounded, staged in LDS by the caller) and a degree-5 polynomial for e^r - 1 (truncation
-// r^6/720 <= 3.5e-17).  k is extracted with the 1.5*2^52 magic-number trick (no v_rndne / v_cvt); the reduction uses the
-// full-precision hi/lo split of ln2/64 (each product is exact inside its fma).  11 FP64 + 3 integer VALU instructions +
-// one ds_read_b64, against 17 FP64 for exp_nonpos.  (A 512-entry table with a degree-4 polynomial -- one fma less, 1.00 ulp --
+// r^6/720 <= 3.5e-17).  k is extracted with the 1.5*2^52 magic-number trick (no v_rndne / v_cvt); the reduction is one fma
+// (the product is exact inside it).  10 FP64 + 3 integer VALU instructions + one ds_read_b64, against 17 FP64 for exp_nonpos.  (A 512-entry table with a degree-4 polynomial -- one fma less, 1.00 ulp --
 // measured no faster: its lookups collide on LDS banks where the 64-entry table's mostly broadcast; and it costs 3.5 KB.)  <= 1.5 ulp (tools/mathcheck.hip).  Valid for -2.3e7 < x <= 0 (k must fit
 // 32 bits: beyond that the exponent wraps and the result can be anything, including inf) -- callers bound the argument:
 // sqrt(5) r <= 1e7 by construction of the tables (kg_mc.hpp to_frame / kTableExtent), -r2/2 by an explicit fmax.
@@ -46,8 +45,10 @@ __device__ __forceinline__ double exp_nonpos_tab(double x, const double* __restr
   const double kMagic = 6755399441055744.0;  // 1.5 * 2^52
   const double t = fma(x, 92.33248261689366, kMagic);  // 64 / ln2
   const double kf = t - kMagic;
-  double r = fma(kf, -0.010830424696249145, x);        // ln2 / 64, hi
-  r = fma(kf, -3.623510646634843e-19, r);              //           lo
+  // (one-term reduction: ln2/64 as a double is 3.3e-17 relative off, i.e. r is off by |x| 3.3e-17 and e^x by the same RELATIVE
+  //  amount -- |x| e^x 3.3e-17 <= 1.3e-17 absolute for x <= 0, a tenth of an ulp of the O(1) covariances it feeds; the lo term
+  //  of the hi/lo split that used to follow cost one FP64 instruction per covariance entry)
+  const double r = fma(kf, -0.010830424696249145, x);  // ln2 / 64
   const int k = __double2loint(t);  // low mantissa word of t = k (two's complement)
   const double T = tab64[k & 63];
   const double r2 = r * r;

@@ -733,7 +733,8 @@ KgPending kg_launch(GpDev& gp, int num_fidelity, const moe_gd_params_t& gd, cons
   // the exp table sits in front of everything; one weight tile of padding at the very end (eval_loop prefetches one tile
   // past the last wave's slab)
   const size_t pad_bytes = sizeof(double) * (size_t)(1 + G) * 64;
-  const size_t lds_max = 160 * 1024 - sizeof(double) * kExpTabLen - pad_bytes;
+  const size_t fixed_bytes = sizeof(double) * (kExpTabLen + (size_t)mc::kCstRows * dp);  // exp table + frame constants
+  const size_t lds_max = 160 * 1024 - fixed_bytes - pad_bytes;
   bool xlds = true;
   // The value passes of the LDS-table kernel take r^2 as |x_j|^2 + |q|^2 - 2 x_j.q (kg_mc.hpp eval_loop), whose absolute error is
   // ~eps (|x|^2 + |q|^2) in the centred, scaled frame of the tables: harmless while the point set spans tens of length
@@ -796,7 +797,7 @@ KgPending kg_launch(GpDev& gp, int num_fidelity, const moe_gd_params_t& gd, cons
   int wg_per_cu = 1;
   if (variant == 0) {
     waves = std::max(1, std::min(waves, env_int("MOE_KG_WAVES", waves)));
-    shm = sizeof(double) * kExpTabLen + (xlds ? tab_bytes : 0) + (size_t)waves * slab_bytes + pad_bytes;
+    shm = fixed_bytes + (xlds ? tab_bytes : 0) + (size_t)waves * slab_bytes + pad_bytes;
     wg_per_cu = std::max(1, std::min((int)((size_t)160 * 1024 / shm), (waves > 8 ? 16 : 8) / waves));
   } else {
     waves = bwaves;
@@ -854,7 +855,8 @@ KgPending kg_launch(GpDev& gp, int num_fidelity, const moe_gd_params_t& gd, cons
     if (dp < G) throw Error(MOE_ERR_RUNTIME, "padded dimension smaller than the derivative-slot count");
     for (int r = 0; r < kMaxDimPadded; ++r) {
       tp.perm[r] = order[r];
-      tp.inv_lp[r] = gp.cp.inv_l[order[r]];
+      // frame scale: the Matern kernel's sqrt(5) is folded into it (kg_mc.hpp radial3)
+      tp.inv_lp[r] = gp.cp.inv_l[order[r]] * (gp.cp.type == MOE_COV_MATERN_NU_2P5 ? 2.236067977499789696409173668731276235 : 1.0);
       double c = 0.0;  // training-set mean of the row's coordinate (0 for pad rows)
       if (order[r] < d) {
         for (int j = 0; j < n; ++j) c += gp.X[(size_t)j * d + order[r]];

@@ -51,7 +51,8 @@ struct KgMcParams {
   double alpha;
   double center[kMaxDimPadded];  // training-set mean of table row r's coordinate: the tables and the queries are centred on it
                                  // BEFORE scaling ((x - c) / l is exact to rounding wherever the domain sits)
-  double inv_lp[kMaxDimPadded];  // 1 / length of table row r (row r holds original dimension perm[r]); 0 in pad rows
+  double inv_lp[kMaxDimPadded];  // frame scale of table row r (row r holds original dimension perm[r]): 1 / length for the squared
+                                 // exponential, sqrt(5) / length for Matern-5/2 (radial3 then needs no sqrt(5)); 0 in pad rows
   int perm[kMaxDimPadded];       // the GP's observed-derivative dimensions come first: perm[a] = derivatives[a], a < g
   int n, g, N, u, m, f, A, ntiles, E;
   double mean;
@@ -166,7 +167,10 @@ __device__ __forceinline__ void clamp_query(double (&xq)[DP]) {
 }
 
 // Radial scalars divided by alpha (alpha is folded into the weights): base = cov[0,0], first = first-derivative
-// coefficient, second = Hessian-product coefficient (device_cov.hpp).
+// coefficient, second = Hessian-product coefficient (device_cov.hpp), all in the FRAME of the tables.  For the Matern kernel
+// the frame's scale is sqrt(5) / length (KgMcParams::inv_lp carries the sqrt(5)), so r2 here is 5 r^2 and a = sqrt(r2) needs
+// no multiplication; with differences that are sqrt(5) times larger the derivative coefficients shrink by 5 and 25:
+//   d base / d q'_k = (1/3) e^-a (1 + a) (x'_k - q'_k),   d first / d (x' - q')_k = -(1/3) e^-a (x' - q')_k.
 template <int COV, bool NEED_FIRST, bool NEED_SECOND>
 __device__ __forceinline__ void radial3(double r2, const double* __restrict__ etab, double& base, double& first,
                                         double& second) {
@@ -176,11 +180,11 @@ __device__ __forceinline__ void radial3(double r2, const double* __restrict__ et
     first = base;
     second = base;
   } else {
-    const double a = 2.236067977499789696409173668731276235 * sqrt_pos(r2);
+    const double a = sqrt_pos(r2);
     const double e = exp_nonpos_tab(-a, etab);
-    base = e * fma(a, fma(a, 1.0 / 3.0, 1.0), 1.0);  // e^-a (1 + a + a^2/3)   [5 r2 / 3 == a^2 / 3]
-    first = NEED_FIRST ? (5.0 / 3.0) * (e * (a + 1.0)) : 0.0;
-    second = NEED_SECOND ? (25.0 / 3.0) * e : 0.0;
+    base = e * fma(a, fma(a, 1.0 / 3.0, 1.0), 1.0);  // e^-a (1 + a + a^2/3)
+    first = NEED_FIRST ? (1.0 / 3.0) * (e * (a + 1.0)) : 0.0;
+    second = NEED_SECOND ? (1.0 / 3.0) * e : 0.0;
   }
 }
 
@@ -209,22 +213,39 @@ struct tile_ptr<true> {
 // are of the size of the distance itself wherever the domain sits: the rounding error of r2 stays within a small multiple of the direct form's
 // (absolute ~1e-15 at unit-box scales; the kernel is smooth at r = 0, so close pairs lose nothing).  Gradient passes keep
 // the direct differences (they need them anyway).
-template <int DP, int G, bool WG, int COV, bool SMALL, bool XL>
+// Q2IN (value passes of the frame line search): `xq_in` holds q2 = -2 x (what the dot-product distances multiply the table rows
+// with), so a trial point costs DP fmas to set up instead of DP frame conversions + DP scalings.  FRAMEG: the gradient is
+// returned with respect to the FRAME coordinates (not multiplied by the frame scale).
+template <int DP, int G, bool WG, int COV, bool SMALL, bool XL, bool Q2IN = false, bool FRAMEG = false>
 __device__ __forceinline__ double eval_loop(const double* __restrict__ xs, const double* __restrict__ aw,
                                             const double* __restrict__ etab, int ntiles, double mean,
-                                            const double (&xq)[DP], const double* inv_lp, double (&grad)[DP], int lane) {
+                                            const double (&xq_in)[DP], const double* inv_lp, double (&grad)[DP], int lane) {
   constexpr bool DOT = XL && !WG;      // squared distance from the |x|^2 row
   constexpr int XR = DP + (XL ? 1 : 0);  // rows per coordinate tile
-  double qq = 1.0e-300;
+  double q2[DP], xq[DP];
+  double qq;
+  if (Q2IN) {
+    double ss = 0.0;
 #pragma unroll
-  for (int k = 0; k < DP; ++k) qq = fma(xq[k], xq[k], qq);
+    for (int k = 0; k < DP; ++k) {
+      q2[k] = xq_in[k];
+      ss = fma(q2[k], q2[k], ss);
+      if (!DOT || G > 0) xq[k] = -0.5 * q2[k];
+    }
+    qq = fma(ss, 0.25, 1.0e-300);
+  } else {
+    qq = 1.0e-300;
+#pragma unroll
+    for (int k = 0; k < DP; ++k) {
+      xq[k] = xq_in[k];
+      qq = fma(xq[k], xq[k], qq);
+      q2[k] = -2.0 * xq[k];
+    }
+  }
   // A trial point more than kFarRadius length scales from the centre is > 400 length scales from every tabulated point
   // (all inside the ball of radius sqrt(16) * kTableExtent): every covariance underflows to exactly 0 and the posterior mean
-  // IS the prior mean -- the pass is skipped.  Closer than that, sqrt(5 r2) * 64 / ln2 < 2^31: exp_nonpos_tab is in range.
+  // IS the prior mean -- the pass is skipped.  Closer than that, sqrt(r2) * 64 / ln2 < 2^31: exp_nonpos_tab is in range.
   if (!WG && !(qq <= kFarRadius * kFarRadius)) return -mean;
-  double q2[DP];
-#pragma unroll
-  for (int k = 0; k < DP; ++k) q2[k] = -2.0 * xq[k];
   double accf = 0.0;
   double accg[DP];
   double accd[G > 0 ? G : 1];
@@ -304,7 +325,7 @@ __device__ __forceinline__ double eval_loop(const double* __restrict__ xs, const
       // d mu / d x_k = inv_l[k] * ( sum coef (Xs_k - xq_k)  -  [k < G] sum first w_k );   f = -mu
       double v = wave_sum_uniform(accg[k]);
       if (G > 0 && k < G) v -= wave_sum_uniform(accd[k < G ? k : 0]);
-      grad[k] = -(v * inv_lp[k]);
+      grad[k] = FRAMEG ? -v : -(v * inv_lp[k]);
     }
   }
   return -mu;
@@ -312,13 +333,14 @@ __device__ __forceinline__ double eval_loop(const double* __restrict__ xs, const
 
 // The covariance type is wave-uniform: branch ONCE per pass (a branch inside the tile loop would split it into basic blocks
 // and stop the scheduler from interleaving the independent per-tile dependency chains).
-template <int DP, int G, bool WG, bool SMALL, bool XL>
+template <int DP, int G, bool WG, bool SMALL, bool XL, bool Q2IN = false, bool FRAMEG = false>
 __device__ __forceinline__ double eval_pass(const double* __restrict__ xs, const double* __restrict__ aw,
                                             const double* __restrict__ etab, int ntiles, int cov_type, double mean,
                                             const double (&xq)[DP], const double* inv_lp, double (&grad)[DP], int lane) {
   if (cov_type == MOE_COV_SQUARE_EXPONENTIAL)
-    return eval_loop<DP, G, WG, MOE_COV_SQUARE_EXPONENTIAL, SMALL, XL>(xs, aw, etab, ntiles, mean, xq, inv_lp, grad, lane);
-  return eval_loop<DP, G, WG, MOE_COV_MATERN_NU_2P5, SMALL, XL>(xs, aw, etab, ntiles, mean, xq, inv_lp, grad, lane);
+    return eval_loop<DP, G, WG, MOE_COV_SQUARE_EXPONENTIAL, SMALL, XL, Q2IN, FRAMEG>(xs, aw, etab, ntiles, mean, xq, inv_lp, grad,
+                                                                                      lane);
+  return eval_loop<DP, G, WG, MOE_COV_MATERN_NU_2P5, SMALL, XL, Q2IN, FRAMEG>(xs, aw, etab, ntiles, mean, xq, inv_lp, grad, lane);
 }
 
 // TensorProductDomain::LimitUpdate (gpp_domain.cpp:64-105) on one coordinate.
@@ -397,6 +419,15 @@ struct WaveEval {
   template <bool WG>
   __device__ __forceinline__ double eval(const double (&xq)[DP], double (&grad)[DP]) {
     return eval_pass<DP, G, WG, SMALL, XL>(xs, aw, etab, ntiles, cov_type, mean, xq, inv_lp, grad, lane);
+  }
+  // frame line search: f and its gradient with respect to the FRAME coordinates at the frame point xf; f at the point whose
+  // frame coordinates are -q2 / 2
+  __device__ __forceinline__ double eval_grad_frame(const double (&xf)[DP], double (&gradf)[DP]) {
+    return eval_pass<DP, G, true, SMALL, XL, false, true>(xs, aw, etab, ntiles, cov_type, mean, xf, inv_lp, gradf, lane);
+  }
+  __device__ __forceinline__ double eval_value_q2(const double (&q2)[DP]) {
+    double unused[DP];
+    return eval_pass<DP, G, false, SMALL, XL, true, false>(xs, aw, etab, ntiles, cov_type, mean, q2, inv_lp, unused, lane);
   }
 };
 
@@ -520,6 +551,164 @@ __device__ __forceinline__ double line_search(const KgMcParams& P, EV& ev, doubl
     from_table_order<DP, G>(x, P.perm, xo);
 #pragma unroll
     for (int k = 0; k < DP; ++k) x[k] = xo[k];
+  }
+  return fcur;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The line search of the wave-per-sample kernel, carried out in the FRAME of the tables (x' = (x - c) s per table row, s the
+// frame scale): the same sequence of decisions as line_search above (gpp_optimization.hpp:708-828, 1242-1283;
+// TensorProductDomain::LimitUpdate, gpp_domain.cpp:64-105 -- every comparison in them is invariant under a positive affine
+// map of a coordinate), but a pass no longer converts its point: with g the gradient in the original coordinates and
+// gf = g / s the one the evaluator returns,
+//     x + alpha g   <->   x' + alpha gf s^2,       |g|^2 = sum (gf s)^2,       |step|^2 = sum (step' / s)^2,
+// and the value passes take q2 = -2 (x' + alpha gf s^2) = fma(alpha, d2, x2) directly (eval_loop Q2IN).  The per-row
+// constants live in an LDS block `cst` (written once per workgroup): [0, DP) frame scale s | [DP, 2DP) 1 / s (0 in pad rows) |
+// [2DP, 3DP) centre c | [3DP, 4DP) lower bound' | [4DP, 5DP) upper bound' (bounds already in the frame).  Nothing of
+// KgMcParams' per-row arrays is touched between the first and the last pass of a sample: they used to sit in ~100 SGPRs and
+// were spilled to / reloaded from VGPR lanes (v_readlane -- a VALU slot each) around every pass.
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int kCstRows = 5;  // arrays of DP doubles in the LDS constant block
+
+template <int DP>
+__device__ __forceinline__ void fill_frame_constants(const KgMcParams& P, double* __restrict__ cst) {
+  const int r = threadIdx.x;
+  if (r < DP) {
+    const double sc = P.inv_lp[r];
+    cst[r] = sc;
+    cst[DP + r] = (sc != 0.0) ? 1.0 / sc : 0.0;
+    cst[2 * DP + r] = P.center[r];
+    cst[3 * DP + r] = (P.bounds[2 * r] - P.center[r]) * sc;
+    cst[4 * DP + r] = (P.bounds[2 * r + 1] - P.center[r]) * sc;
+  }
+}
+
+template <int DP, int G, class EV>
+__device__ __forceinline__ double line_search_frame(const KgMcParams& P, const double* __restrict__ cst, EV& ev, double (&x)[DP],
+                                                    unsigned long long& n_val, unsigned long long& n_grad) {
+  typedef const volatile __attribute__((address_space(3))) double* cst_ptr;  // (volatile: read where used, never hoisted)
+  cst_ptr C = (cst_ptr)cst;
+  const int lane_id = (int)(threadIdx.x & 63u);
+  const unsigned int free_mask = P.free_mask;
+  const int max_num_steps = P.max_num_steps, max_num_restarts = P.max_num_restarts;
+  const double tolerance = P.tolerance;
+  if (max_num_restarts <= 0) {
+    // reference returns without touching its outputs (.cpp:425-427): value 0, point filled with 1.0 (.cpp:163)
+#pragma unroll
+    for (int k = 0; k < DP; ++k) x[k] = (k < P.dim) ? 1.0 : 0.0;
+    return 0.0;
+  }
+  const double step_tolerance = tolerance / (double)max_num_steps;
+  // entry: table-row order, then into the frame (pinned rows -- fidelity coordinates, pads -- keep their frame value throughout)
+  double xf[DP], xkeep[DP];
+  {
+    double xp[DP];
+    to_table_order<DP, G>(x, P.perm, xp);
+#pragma unroll
+    for (int r = 0; r < DP; ++r) {
+      xkeep[r] = xp[r];
+      xf[r] = (xp[r] - C[2 * DP + r]) * C[r];
+    }
+  }
+  const int lk = lane_id < DP ? lane_id : 0;
+  const double lo_l = C[3 * DP + lk], hi_l = C[4 * DP + lk];
+  const bool free_l = lane_id < DP && ((free_mask >> (lane_id & 31)) & 1u);
+  double fcur = 0.0;
+  double gf[DP];
+#pragma unroll
+  for (int k = 0; k < DP; ++k) gf[k] = 0.0;
+  for (int restart = 0; restart < max_num_restarts; ++restart) {
+    double xstart[DP];
+#pragma unroll
+    for (int k = 0; k < DP; ++k) xstart[k] = xf[k];
+    for (int istep = 0; istep < max_num_steps;) {
+      // ---- f(x), grad f(x) ----
+      const double f0 = ev.eval_grad_frame(xf, gf);
+      n_grad++;
+      fcur = f0;
+      // d2 = -2 g s (the trial direction in the frame, pre-multiplied for q2), x2 = -2 x', |g|^2
+      double d2[DP], x2[DP];
+      double norm = 0.0;
+#pragma unroll
+      for (int k = 0; k < DP; ++k) {
+        const double sk = C[k];
+        const double g = ((free_mask >> k) & 1u) ? gf[k] * sk : 0.0;  // fidelity / pad coordinates stay pinned
+        norm = fma(g, g, norm);
+        d2[k] = -2.0 * (g * sk);
+        x2[k] = -2.0 * xf[k];
+      }
+      // pre_mult * (i+1)^-gamma (gpp_optimization.hpp:741); x^-0 == 1 exactly, so gamma == 0 needs no pow()
+      double alpha_n = (P.gamma == 0.0) ? P.pre_mult : P.pre_mult * pow((double)(istep + 1), -P.gamma);
+      // ---- Armijo back-tracking (.hpp:745-760): unclamped trial points ----
+      int search = 0;
+      double ftrial;
+      while (true) {
+        double q2[DP];
+#pragma unroll
+        for (int k = 0; k < DP; ++k) q2[k] = fma(alpha_n, d2[k], x2[k]);
+        ftrial = ev.eval_value_q2(q2);
+        n_val++;
+        if (ftrial - f0 > 0.5 * alpha_n * norm) break;
+        alpha_n *= 0.5;
+        if (++search >= 30) break;
+      }
+      // ---- LimitUpdate in the frame, one coordinate per lane, then accept only if f improves (.hpp:762-795) ----
+      bool changed, nonzero;
+      double step[DP];
+      {
+        double x_l = 0.0, d2_l = 0.0;
+#pragma unroll
+        for (int k = 0; k < DP; ++k) {
+          x_l = (lane_id == k) ? xf[k] : x_l;
+          d2_l = (lane_id == k) ? d2[k] : d2_l;
+        }
+        const double want_l = (-0.5 * alpha_n) * d2_l;  // alpha g s
+        double step_l = 0.0;
+        if (free_l) step_l = limit_update_1d(lo_l, hi_l, P.max_relative_change, x_l, want_l);
+        changed = __ballot(free_l && step_l != want_l) != 0ull;
+        nonzero = __ballot(free_l && step_l != 0.0) != 0ull;
+#pragma unroll
+        for (int k = 0; k < DP; ++k) {
+          const int slo = __builtin_amdgcn_readlane(__double2loint(step_l), k);
+          const int shi = __builtin_amdgcn_readlane(__double2hiint(step_l), k);
+          step[k] = __hiloint2double(shi, slo);
+        }
+      }
+      if (search == 30 || !nonzero) break;  // .hpp:781-785: x restored (a zero step re-evaluates f(x) == f0: rejected)
+      double obj2 = ftrial;  // the clamp left the step untouched: f(x + step) is the last trial value
+      if (changed) {
+        double q2[DP];
+#pragma unroll
+        for (int k = 0; k < DP; ++k) q2[k] = fma(-2.0, step[k], x2[k]);
+        obj2 = ev.eval_value_q2(q2);
+        n_val++;
+      }
+      if (obj2 <= f0) break;
+      double ss = 0.0;  // |step|^2 in the original coordinates
+#pragma unroll
+      for (int k = 0; k < DP; ++k) {
+        xf[k] += step[k];
+        const double so = step[k] * C[DP + k];
+        ss = fma(so, so, ss);
+      }
+      fcur = obj2;
+      istep += 1;
+      if (sqrt(ss) < step_tolerance) break;
+    }
+    double ds = 0.0;
+#pragma unroll
+    for (int k = 0; k < DP; ++k) {
+      const double dk = (xstart[k] - xf[k]) * C[DP + k];
+      ds = fma(dk, dk, ds);
+    }
+    if (!(sqrt(ds) > tolerance)) break;
+  }
+  // exit: back to the original coordinates (pinned rows return what came in) and the original dimension order
+  {
+    double xo[DP];
+#pragma unroll
+    for (int r = 0; r < DP; ++r) xo[r] = ((free_mask >> r) & 1u) ? fma(xf[r], C[DP + r], C[2 * DP + r]) : xkeep[r];
+    from_table_order<DP, G>(xo, P.perm, x);
   }
   return fcur;
 }
@@ -718,8 +907,8 @@ __device__ __forceinline__ int discrete_scan(const KgMcParams& P, const double* 
 template <int DP, int G, bool SMALL, bool XL>
 __device__ __forceinline__ void kg_sample(const KgMcParams& P, int e, int sl, const double* __restrict__ xs,
                                           double* __restrict__ aw, double* __restrict__ zb,
-                                          const double* __restrict__ etab, int lane, unsigned long long& tot_val,
-                                          unsigned long long& tot_grad) {
+                                          const double* __restrict__ etab, const double* __restrict__ cst, int lane,
+                                          unsigned long long& tot_val, unsigned long long& tot_grad) {
   const int m = P.m, u = P.u, n = P.n, g1 = 1 + P.g;
   const int s = P.first_sample + sl;  // global sample index
   const int size = P.dim - P.f;       // problem size of the inner optimisation
@@ -757,8 +946,8 @@ __device__ __forceinline__ void kg_sample(const KgMcParams& P, int e, int sl, co
         } else if (j < n + u) {
           v = zb[kMaxM + (j - n) * g1 + a];
         }
-        // fold alpha and, for derivative weights, the -1/l of (x - X)_{d_a} / l^2 = -diff_scaled[a] / l
-        v *= (a == 0) ? P.alpha : -P.alpha * P.inv_lp[a > 0 ? a - 1 : 0];
+        // fold alpha and, for derivative weights, the -(frame scale) of the derivative row (radial3)
+        v *= (a == 0) ? P.alpha : -P.alpha * cst[a > 0 ? a - 1 : 0];
       }
       w[a * 64] = v;
     }
@@ -775,7 +964,7 @@ __device__ __forceinline__ void kg_sample(const KgMcParams& P, int e, int sl, co
 
   unsigned long long n_val = 0, n_grad = 0;  // passes over the n + u points (the A-point scan is O(A m), not counted)
   WaveEval<DP, G, SMALL, XL> ev{xs, aw, etab, P.ntiles, P.cov_type, P.mean, P.inv_lp, lane};
-  const double fcur = line_search<DP, G>(P, ev, x, n_val, n_grad);
+  const double fcur = line_search_frame<DP, G>(P, cst, ev, x, n_val, n_grad);
 
   const long so = (long)e * P.num_local + sl;
   if (lane == 0) P.best_value[so] = fcur;
@@ -802,11 +991,13 @@ __global__ __launch_bounds__(SMALL ? 1024 : 512) void kg_mc_kernel(KgMcParams P)
   const int ntiles = P.ntiles;
   const int tab = ntiles * (DP + 1) * 64;  // LDS copy: the DP coordinate rows + the |x|^2 row per tile (see eval_loop)
   const int wslab = ntiles * (1 + G) * 64 + 2 * kMaxM;
-  // LDS: [64] exp table | [tab] coordinates (if XLDS) | per-wave slabs
-  double* coords = smem + kExpTabLen;
+  // LDS: [64] exp table | [kCstRows x DP] per-row constants of the frame line search | [tab] coordinates (if XLDS) | per-wave slabs
+  double* cst = smem + kExpTabLen;
+  double* coords = cst + kCstRows * DP;
   double* aw = coords + (XLDS ? tab : 0) + wave * wslab;
   double* zb = aw + ntiles * (1 + G) * 64;
   if (threadIdx.x < kExpTabLen) smem[threadIdx.x] = kExp2Tab64[threadIdx.x];
+  fill_frame_constants<DP>(P, cst);
   if (!XLDS) __syncthreads();
   // evaluation of this workgroup: workgroups b, b + E, b + 2E, ... serve evaluation b mod E (b mod 8 is also the XCD, so
   // with E = 8 each evaluation's W / table stay in one XCD's L2); with fewer workgroups than evaluations they loop.
@@ -840,7 +1031,7 @@ __global__ __launch_bounds__(SMALL ? 1024 : 512) void kg_mc_kernel(KgMcParams P)
       const unsigned int sl = (unsigned int)__builtin_amdgcn_readfirstlane((int)ticket);
       if (sl >= (unsigned int)P.num_local) break;
       if (lane == 0) ticket = atomicAdd(next, 1u);
-      kg_sample<DP, G, SMALL, XLDS>(P, e, (int)sl, xs, aw, zb, smem, lane, tot_val, tot_grad);
+      kg_sample<DP, G, SMALL, XLDS>(P, e, (int)sl, xs, aw, zb, smem, cst, lane, tot_val, tot_grad);
     }
     if (lane == 0 && (tot_val | tot_grad) != 0) {
       atomicAdd(&P.counters[2 * e], tot_val);
