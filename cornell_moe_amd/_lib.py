@@ -3,7 +3,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libmoe_hip.so")
+LIB_PATH = os.environ.get("MOE_LIB_PATH") or os.path.join(_HERE, "lib", "libmoe_hip.so")  # (MOE_LIB_PATH: A/B builds, tools only)
 
 dp = C.POINTER(C.c_double)
 ip = C.POINTER(C.c_int)

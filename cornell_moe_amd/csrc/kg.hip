@@ -1065,13 +1065,21 @@ KgPending kg_launch(GpDev& gp, int num_fidelity, const moe_gd_params_t& gd, cons
   t_mc.start(s);
   mp.best_j = nullptr;
   mp.V = nullptr;
-  if (variant == 1 && env_int("MOE_KG_PREP", 1) != 0) {
+  // the sample pre-pass (beta and the discretised-set winner of every sample, computed with the whole chip): for the
+  // workgroup-per-sample kernel, where seven wavefronts would wait for one; the wave-per-sample kernel hides those loads
+  // behind the other wavefront of its SIMD (measured: no difference at C3), so it only takes the pre-pass on request
+  // (MOE_KG_PREP=1; MOE_KG_PREP=0: never)
+  const int prep_mode = env_int("MOE_KG_PREP", -1);
+  if (prep_mode != 0 && (variant == 1 || prep_mode == 1)) {
     gp.kBestJ.reserve((size_t)E * num_local);
     mp.best_j = gp.kBestJ.p;
     const long total = (long)E * num_local;
     const int pb = (int)std::min<long>((total + 3) / 4, (long)num_cu * 8);
     hipLaunchKernelGGL(kg_sample_prep_kernel, dim3(pb), dim3(256), 0, s, mp, gp.kBestJ.p);
     MOE_HIP_CHECK(hipGetLastError());
+  }
+  if (variant == 1 && mp.best_j != nullptr) {
+    const long total = (long)E * num_local;
     // the weight table: N doubles per sample (1.28 GB per evaluation at C5); beyond its cap -- the caller's share of the
     // workspace budget (kg_evaluate_batch, kg_mcmc_sums), MOE_KG_V_MAX_GB (default 4) for a bare kg_launch -- the samples
     // compute their weights in the kernel
@@ -1181,7 +1189,7 @@ KgPending kg_launch(GpDev& gp, int num_fidelity, const moe_gd_params_t& gd, cons
     {
       const unsigned long long* w = prof_p->data();
       const double tot = (double)(w[0] + w[1] + w[2] + w[3]);
-      if (tot > 0)
+      if (tot > 0 && w[8] > 0)
         std::fprintf(stderr,
                      "[moe prof] wave-0 cycles: ticket %.1f%%  z/beta/scan %.1f%%  weights %.1f%%  line search %.1f%%;  inside "
                      "%llu passes: accumulate %.0f  reduce %.0f  barrier %.0f  post %.0f  (cycles per pass; line search total "
@@ -1191,7 +1199,15 @@ KgPending kg_launch(GpDev& gp, int num_fidelity, const moe_gd_params_t& gd, cons
       if (w[10] > 0)
         std::fprintf(stderr, "[moe prof] gradient passes: %llu, %.0f cycles each (all phases); cycles per SAMPLE: total %.0f, in passes %.0f\n",
                      w[10], (double)w[9] / w[10], tot / (w[10] / 6.0), (double)(w[4] + w[5] + w[6] + w[7]) / (w[10] / 6.0));
-      std::fprintf(stderr, "[moe prof] per sample: z/beta %.0f, scan %.0f cycles\n", (double)w[11] / (w[10] / 6.0), (double)w[12] / (w[10] / 6.0));
+      if (w[10] > 0)
+        std::fprintf(stderr, "[moe prof] per sample: z/beta %.0f, scan %.0f cycles\n", (double)w[11] / (w[10] / 6.0), (double)w[12] / (w[10] / 6.0));
+      if (w[13] > 0)  // wave-per-sample kernel (kg_mc.hpp kg_sample): clock ticks of lane 0 of every wave
+        std::fprintf(stderr,
+                     "[moe prof] wave-per-sample kernel, ticks per sample: z/beta %.0f  weights %.0f  scan %.0f  line search %.0f "
+                     "(of which %.1f value passes x %.0f + %.1f gradient passes x %.0f)\n",
+                     (double)w[0] / w[13], (double)w[1] / w[13], (double)w[2] / w[13], (double)w[3] / w[13], (double)w[6] / w[13],
+                     (double)w[4] / std::max<unsigned long long>(w[6], 1), (double)w[7] / w[13],
+                     (double)w[5] / std::max<unsigned long long>(w[7], 1));
     }
 #endif
     const std::vector<std::vector<double>>&grad_mu = *grad_mu_p, &Mk = *Mk_p;

@@ -32,6 +32,19 @@ namespace moe {
 #ifndef MOE_BLOCK_PROF
 #define MOE_BLOCK_PROF 0
 #endif
+// Gradient passes with dot-product distances (eval_loop GDOT): 5 fewer instructions per point, but the gradient then carries the
+// cancellation of sum coef x - q sum coef; where the inner optimiser is run to convergence (100 steps x 10 restarts, the
+// reference's own ping-test settings) the end points drift to 1.4e-6 from the reference's instead of 1e-7.  Off.
+#ifndef MOE_KG_GRAD_DOT
+#define MOE_KG_GRAD_DOT 0
+#endif
+#if MOE_BLOCK_PROF
+#define MOE_PROF_T(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
+#define MOE_PROF_ADD(dst, a, b) dst += (b) - (a)
+#else
+#define MOE_PROF_T(var)
+#define MOE_PROF_ADD(dst, a, b)
+#endif
 constexpr int kTicketStride = 32;  // unsigned ints between the sample-ticket counters of consecutive evaluations (128 B)
 constexpr int kMaxM = 64;  // m = (q + p)(1 + g) limit of the MC kernel (z / beta scratch per wave)
 constexpr int kExpTabLen = 64;  // 2^(j/64) table at the start of the MC kernel's LDS (fastmath.hpp exp_nonpos_tab)
@@ -136,6 +149,79 @@ __device__ __forceinline__ double wave_sum_uniform(double v) {
   return __hiloint2double(hi, lo);
 }
 
+// ---- packed wave reductions (gradient passes) ----
+// v_permlane32_swap / v_permlane16_swap (gfx950) exchange half-waves / 16-lane rows between TWO registers in one VALU
+// instruction, so two per-lane partial sums can be folded into one register with 3 instructions (2 word swaps + 1 add): the
+// lower / even part keeps summing value a, the upper / odd part value b.  Eight sums then cost 12 + 6 folding instructions and
+// TWO in-row DPP reductions instead of eight full ones (58 instead of 176 VALU instructions with the read-outs).
+__device__ __forceinline__ double fold32(double a, double b) {  // lanes 0-31: a.lo + a.hi, lanes 32-63: b.lo + b.hi
+  const auto lo = __builtin_amdgcn_permlane32_swap(__double2loint(a), __double2loint(b), false, false);
+  const auto hi = __builtin_amdgcn_permlane32_swap(__double2hiint(a), __double2hiint(b), false, false);
+  return __hiloint2double(hi[0], lo[0]) + __hiloint2double(hi[1], lo[1]);
+}
+__device__ __forceinline__ double fold16(double a, double b) {  // rows: a.r0 + a.r1 | b.r0 + b.r1 | a.r2 + a.r3 | b.r2 + b.r3
+  const auto lo = __builtin_amdgcn_permlane16_swap(__double2loint(a), __double2loint(b), false, false);
+  const auto hi = __builtin_amdgcn_permlane16_swap(__double2hiint(a), __double2hiint(b), false, false);
+  return __hiloint2double(hi[0], lo[0]) + __hiloint2double(hi[1], lo[1]);
+}
+__device__ __forceinline__ double row_sum(double v) {  // every lane: the sum over its 16-lane row (fixed tree)
+  v += dpp_move<0xB1, 0xf, true>(v);    // quad_perm [1,0,3,2]
+  v += dpp_move<0x4E, 0xf, true>(v);    // quad_perm [2,3,0,1]
+  v += dpp_move<0x141, 0xf, true>(v);   // row_half_mirror
+  v += dpp_move<0x140, 0xf, true>(v);   // row_mirror
+  return v;
+}
+__device__ __forceinline__ double lane_value(double v, int lane) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+  return __hiloint2double(hi, lo);
+}
+// out[i] = sum over the 64 lanes of v[i], wave-uniform, for four / eight values at a time
+__device__ __forceinline__ void wave_sum4_uniform(double v0, double v1, double v2, double v3, double (&out)[4]) {
+  const double q = row_sum(fold16(fold32(v0, v1), fold32(v2, v3)));  // rows hold v0 | v2 | v1 | v3
+  out[0] = lane_value(q, 0);
+  out[2] = lane_value(q, 16);
+  out[1] = lane_value(q, 32);
+  out[3] = lane_value(q, 48);
+}
+__device__ __forceinline__ void wave_sum2_uniform(double a, double b, double& sa, double& sb) {
+  const double p = fold32(a, b);
+  const double q = row_sum(fold16(p, p));
+  sa = lane_value(q, 0);
+  sb = lane_value(q, 32);
+}
+// The same with the results handed back through per-wave LDS scratch (N doubles at `scr`) as broadcast reads, i.e. wave-uniform
+// values in VGPRs: read out with v_readlane they land in SGPRs, and in the MC kernel -- whose scalar register file is full --
+// every one of them was spilled to a VGPR lane (v_writelane) and fetched back (v_readlane), two VALU slots each way.
+template <int N>
+__device__ __forceinline__ void wave_sum_packed_lds(const double (&v)[N], double* __restrict__ scr, int lane, double (&out)[N]) {
+  static_assert(N % 4 == 0, "packed reductions work on multiples of four values");
+  volatile __attribute__((address_space(3))) double* S = (volatile __attribute__((address_space(3))) double*)scr;
+  const int row = lane >> 4;
+  const int slot = ((row & 1) << 1) | (row >> 1);  // rows hold v0 | v2 | v1 | v3
+#pragma unroll
+  for (int i = 0; i < N; i += 4) {
+    const double q = row_sum(fold16(fold32(v[i], v[i + 1]), fold32(v[i + 2], v[i + 3])));
+    if ((lane & 15) == 0) S[i + slot] = q;
+  }
+#pragma unroll
+  for (int i = 0; i < N; ++i) out[i] = S[i];  // (LDS operations of one wave complete in order)
+}
+
+template <int N>
+__device__ __forceinline__ void wave_sum_packed(const double (&v)[N], double (&out)[N]) {
+  static_assert(N % 4 == 0, "packed reductions work on multiples of four values");
+#pragma unroll
+  for (int i = 0; i < N; i += 4) {
+    double o[4];
+    wave_sum4_uniform(v[i], v[i + 1], v[i + 2], v[i + 3], o);
+    out[i] = o[0];
+    out[i + 1] = o[1];
+    out[i + 2] = o[2];
+    out[i + 3] = o[3];
+  }
+}
+
 __device__ __forceinline__ double uniform(double v) {
   // all lanes hold the same bits after a butterfly; tell the compiler so (value moves to SGPRs, branches become scalar)
   const int lo = __builtin_amdgcn_readfirstlane(__double2loint(v));
@@ -219,8 +305,14 @@ struct tile_ptr<true> {
 template <int DP, int G, bool WG, int COV, bool SMALL, bool XL, bool Q2IN = false, bool FRAMEG = false>
 __device__ __forceinline__ double eval_loop(const double* __restrict__ xs, const double* __restrict__ aw,
                                             const double* __restrict__ etab, int ntiles, double mean,
-                                            const double (&xq_in)[DP], const double* inv_lp, double (&grad)[DP], int lane) {
-  constexpr bool DOT = XL && !WG;      // squared distance from the |x|^2 row
+                                            const double (&xq_in)[DP], const double* inv_lp, double (&grad)[DP], int lane,
+                                            double* __restrict__ scr = nullptr) {
+  // GDOT: the gradient pass in dot-product form too (no derivative observations): r2 from the |x|^2 row, and
+  //   grad = sum_j coef_j (x_j - q) = sum_j coef_j x_j - q sum_j coef_j
+  // needs no differences at all -- DP fmas + one add per point instead of DP subtractions + 2 DP fmas (in the centred frame
+  // the two terms are of the size of the gradient itself: same argument as for the distances).
+  constexpr bool GDOT = MOE_KG_GRAD_DOT && WG && XL && G == 0;
+  constexpr bool DOT = XL && (!WG || GDOT);  // squared distance from the |x|^2 row
   constexpr int XR = DP + (XL ? 1 : 0);  // rows per coordinate tile
   double q2[DP], xq[DP];
   double qq;
@@ -246,7 +338,7 @@ __device__ __forceinline__ double eval_loop(const double* __restrict__ xs, const
   // (all inside the ball of radius sqrt(16) * kTableExtent): every covariance underflows to exactly 0 and the posterior mean
   // IS the prior mean -- the pass is skipped.  Closer than that, sqrt(r2) * 64 / ln2 < 2^31: exp_nonpos_tab is in range.
   if (!WG && !(qq <= kFarRadius * kFarRadius)) return -mean;
-  double accf = 0.0;
+  double accf = 0.0, accs = 0.0;
   double accg[DP];
   double accd[G > 0 ? G : 1];
 #pragma unroll
@@ -303,7 +395,12 @@ __device__ __forceinline__ double eval_loop(const double* __restrict__ xs, const
     }
     accf = fma(w0, base, accf);
     if (G > 0) accf = fma(first, sd, accf);
-    if (WG) {
+    if (GDOT) {
+      const double coef = w0 * first;
+      accs += coef;
+#pragma unroll
+      for (int k = 0; k < DP; ++k) accg[k] = fma(coef, cx[k], accg[k]);
+    } else if (WG) {
       double coef = w0 * first;
       if (G > 0) {
         coef = fma(second, sd, coef);
@@ -318,12 +415,31 @@ __device__ __forceinline__ double eval_loop(const double* __restrict__ xs, const
 #pragma unroll
     for (int a = 0; a < 1 + G; ++a) cw[a] = nw[a];
   }
+  if (GDOT) {
+    double sg[DP], sf, ss;
+    if (scr != nullptr)
+      wave_sum_packed_lds<DP>(accg, scr, lane, sg);
+    else
+      wave_sum_packed<DP>(accg, sg);
+    wave_sum2_uniform(accf, accs, sf, ss);
+#pragma unroll
+    for (int k = 0; k < DP; ++k) {
+      const double v = fma(-xq[k], ss, sg[k]);  // sum coef x_k - q_k sum coef
+      grad[k] = FRAMEG ? -v : -(v * inv_lp[k]);
+    }
+    return -(mean + sf);
+  }
   const double mu = mean + wave_sum_uniform(accf);
   if (WG) {
+    double sg[DP];
+    if (scr != nullptr)
+      wave_sum_packed_lds<DP>(accg, scr, lane, sg);  // DP sums folded into DP / 4 in-row reductions
+    else
+      wave_sum_packed<DP>(accg, sg);
 #pragma unroll
     for (int k = 0; k < DP; ++k) {
       // d mu / d x_k = inv_l[k] * ( sum coef (Xs_k - xq_k)  -  [k < G] sum first w_k );   f = -mu
-      double v = wave_sum_uniform(accg[k]);
+      double v = sg[k];
       if (G > 0 && k < G) v -= wave_sum_uniform(accd[k < G ? k : 0]);
       grad[k] = FRAMEG ? -v : -(v * inv_lp[k]);
     }
@@ -336,11 +452,13 @@ __device__ __forceinline__ double eval_loop(const double* __restrict__ xs, const
 template <int DP, int G, bool WG, bool SMALL, bool XL, bool Q2IN = false, bool FRAMEG = false>
 __device__ __forceinline__ double eval_pass(const double* __restrict__ xs, const double* __restrict__ aw,
                                             const double* __restrict__ etab, int ntiles, int cov_type, double mean,
-                                            const double (&xq)[DP], const double* inv_lp, double (&grad)[DP], int lane) {
+                                            const double (&xq)[DP], const double* inv_lp, double (&grad)[DP], int lane,
+                                            double* __restrict__ scr = nullptr) {
   if (cov_type == MOE_COV_SQUARE_EXPONENTIAL)
     return eval_loop<DP, G, WG, MOE_COV_SQUARE_EXPONENTIAL, SMALL, XL, Q2IN, FRAMEG>(xs, aw, etab, ntiles, mean, xq, inv_lp, grad,
-                                                                                      lane);
-  return eval_loop<DP, G, WG, MOE_COV_MATERN_NU_2P5, SMALL, XL, Q2IN, FRAMEG>(xs, aw, etab, ntiles, mean, xq, inv_lp, grad, lane);
+                                                                                      lane, scr);
+  return eval_loop<DP, G, WG, MOE_COV_MATERN_NU_2P5, SMALL, XL, Q2IN, FRAMEG>(xs, aw, etab, ntiles, mean, xq, inv_lp, grad, lane,
+                                                                                 scr);
 }
 
 // TensorProductDomain::LimitUpdate (gpp_domain.cpp:64-105) on one coordinate.
@@ -416,6 +534,10 @@ struct WaveEval {
   double mean;
   const double* inv_lp;
   int lane;
+  double* __restrict__ scr;  // per-wave LDS scratch for the gradient sums (DP doubles), or NULL
+#if MOE_BLOCK_PROF
+  unsigned long long c_v = 0, c_g = 0, n_v = 0, n_g = 0;
+#endif
   template <bool WG>
   __device__ __forceinline__ double eval(const double (&xq)[DP], double (&grad)[DP]) {
     return eval_pass<DP, G, WG, SMALL, XL>(xs, aw, etab, ntiles, cov_type, mean, xq, inv_lp, grad, lane);
@@ -423,11 +545,27 @@ struct WaveEval {
   // frame line search: f and its gradient with respect to the FRAME coordinates at the frame point xf; f at the point whose
   // frame coordinates are -q2 / 2
   __device__ __forceinline__ double eval_grad_frame(const double (&xf)[DP], double (&gradf)[DP]) {
-    return eval_pass<DP, G, true, SMALL, XL, false, true>(xs, aw, etab, ntiles, cov_type, mean, xf, inv_lp, gradf, lane);
+#if MOE_BLOCK_PROF
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+#endif
+    const double f = eval_pass<DP, G, true, SMALL, XL, false, true>(xs, aw, etab, ntiles, cov_type, mean, xf, inv_lp, gradf, lane, scr);
+#if MOE_BLOCK_PROF
+    c_g += __builtin_amdgcn_s_memtime() - t0;
+    n_g++;
+#endif
+    return f;
   }
   __device__ __forceinline__ double eval_value_q2(const double (&q2)[DP]) {
     double unused[DP];
-    return eval_pass<DP, G, false, SMALL, XL, true, false>(xs, aw, etab, ntiles, cov_type, mean, q2, inv_lp, unused, lane);
+#if MOE_BLOCK_PROF
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+#endif
+    const double f = eval_pass<DP, G, false, SMALL, XL, true, false>(xs, aw, etab, ntiles, cov_type, mean, q2, inv_lp, unused, lane);
+#if MOE_BLOCK_PROF
+    c_v += __builtin_amdgcn_s_memtime() - t0;
+    n_v++;
+#endif
+    return f;
   }
 };
 
@@ -564,11 +702,13 @@ __device__ __forceinline__ double line_search(const KgMcParams& P, EV& ev, doubl
 //     x + alpha g   <->   x' + alpha gf s^2,       |g|^2 = sum (gf s)^2,       |step|^2 = sum (step' / s)^2,
 // and the value passes take q2 = -2 (x' + alpha gf s^2) = fma(alpha, d2, x2) directly (eval_loop Q2IN).  The per-row
 // constants live in an LDS block `cst` (written once per workgroup): [0, DP) frame scale s | [DP, 2DP) 1 / s (0 in pad rows) |
-// [2DP, 3DP) centre c | [3DP, 4DP) lower bound' | [4DP, 5DP) upper bound' (bounds already in the frame).  Nothing of
+// [2DP, 3DP) centre c | [3DP, 4DP) lower bound' | [4DP, 5DP) upper bound' (bounds already in the frame) | [5DP, 6DP) the value a
+// pinned row holds.  `scr` is 3 DP doubles of per-wave LDS scratch (the restart's starting point | the evaluator's gradient sums |
+// the clamped step).  Nothing of
 // KgMcParams' per-row arrays is touched between the first and the last pass of a sample: they used to sit in ~100 SGPRs and
 // were spilled to / reloaded from VGPR lanes (v_readlane -- a VALU slot each) around every pass.
 // ---------------------------------------------------------------------------------------------------------------------
-constexpr int kCstRows = 5;  // arrays of DP doubles in the LDS constant block
+constexpr int kCstRows = 6;  // arrays of DP doubles in the LDS constant block
 
 template <int DP>
 __device__ __forceinline__ void fill_frame_constants(const KgMcParams& P, double* __restrict__ cst) {
@@ -580,12 +720,14 @@ __device__ __forceinline__ void fill_frame_constants(const KgMcParams& P, double
     cst[2 * DP + r] = P.center[r];
     cst[3 * DP + r] = (P.bounds[2 * r] - P.center[r]) * sc;
     cst[4 * DP + r] = (P.bounds[2 * r + 1] - P.center[r]) * sc;
+    cst[5 * DP + r] = (P.perm[r] < P.dim) ? 1.0 : 0.0;  // what a pinned row holds: fidelity coordinates 1, pads 0 (.cpp:353-357)
   }
 }
 
 template <int DP, int G, class EV>
-__device__ __forceinline__ double line_search_frame(const KgMcParams& P, const double* __restrict__ cst, EV& ev, double (&x)[DP],
-                                                    unsigned long long& n_val, unsigned long long& n_grad) {
+__device__ __forceinline__ double line_search_frame(const KgMcParams& P, const double* __restrict__ cst, double* __restrict__ scr,
+                                                    EV& ev, double (&x)[DP], unsigned long long& n_val,
+                                                    unsigned long long& n_grad) {
   typedef const volatile __attribute__((address_space(3))) double* cst_ptr;  // (volatile: read where used, never hoisted)
   cst_ptr C = (cst_ptr)cst;
   const int lane_id = (int)(threadIdx.x & 63u);
@@ -600,16 +742,14 @@ __device__ __forceinline__ double line_search_frame(const KgMcParams& P, const d
   }
   const double step_tolerance = tolerance / (double)max_num_steps;
   // entry: table-row order, then into the frame (pinned rows -- fidelity coordinates, pads -- keep their frame value throughout)
-  double xf[DP], xkeep[DP];
+  double xf[DP];
   {
     double xp[DP];
     to_table_order<DP, G>(x, P.perm, xp);
 #pragma unroll
-    for (int r = 0; r < DP; ++r) {
-      xkeep[r] = xp[r];
-      xf[r] = (xp[r] - C[2 * DP + r]) * C[r];
-    }
+    for (int r = 0; r < DP; ++r) xf[r] = (xp[r] - C[2 * DP + r]) * C[r];
   }
+  volatile __attribute__((address_space(3))) double* S = (volatile __attribute__((address_space(3))) double*)scr;
   const int lk = lane_id < DP ? lane_id : 0;
   const double lo_l = C[3 * DP + lk], hi_l = C[4 * DP + lk];
   const bool free_l = lane_id < DP && ((free_mask >> (lane_id & 31)) & 1u);
@@ -617,13 +757,25 @@ __device__ __forceinline__ double line_search_frame(const KgMcParams& P, const d
   double gf[DP];
 #pragma unroll
   for (int k = 0; k < DP; ++k) gf[k] = 0.0;
+  // A clamped step needs f(x + step) before it is accepted (.hpp:771-786), and -- once accepted -- the next iteration starts by
+  // evaluating f and grad f at that very point.  While another iteration can follow, that evaluation is therefore done as ONE
+  // value + gradient pass and carried over (have_g): a step costs its Armijo trials + one pass instead of + two.  A carried
+  // gradient that ends up unused (step rejected, |step| below the tolerance, no further restart) is counted as the value pass
+  // it replaced, so the device counters never exceed what was computed.
+  bool have_g = false;
+  double f_carried = 0.0;
   for (int restart = 0; restart < max_num_restarts; ++restart) {
-    double xstart[DP];
 #pragma unroll
-    for (int k = 0; k < DP; ++k) xstart[k] = xf[k];
+    for (int k = 0; k < DP; ++k) S[k] = xf[k];  // the restart's starting point (every lane writes the same value)
     for (int istep = 0; istep < max_num_steps;) {
       // ---- f(x), grad f(x) ----
-      const double f0 = ev.eval_grad_frame(xf, gf);
+      double f0;
+      if (have_g) {
+        f0 = f_carried;
+        have_g = false;
+      } else {
+        f0 = ev.eval_grad_frame(xf, gf);
+      }
       n_grad++;
       fcur = f0;
       // d2 = -2 g s (the trial direction in the frame, pre-multiplied for q2), x2 = -2 x', |g|^2
@@ -667,23 +819,32 @@ __device__ __forceinline__ double line_search_frame(const KgMcParams& P, const d
         if (free_l) step_l = limit_update_1d(lo_l, hi_l, P.max_relative_change, x_l, want_l);
         changed = __ballot(free_l && step_l != want_l) != 0ull;
         nonzero = __ballot(free_l && step_l != 0.0) != 0ull;
+        if (lane_id < DP) S[2 * DP + lane_id] = step_l;  // back as wave-uniform values through the scratch (not SGPRs)
 #pragma unroll
-        for (int k = 0; k < DP; ++k) {
-          const int slo = __builtin_amdgcn_readlane(__double2loint(step_l), k);
-          const int shi = __builtin_amdgcn_readlane(__double2hiint(step_l), k);
-          step[k] = __hiloint2double(shi, slo);
-        }
+        for (int k = 0; k < DP; ++k) step[k] = S[2 * DP + k];
       }
       if (search == 30 || !nonzero) break;  // .hpp:781-785: x restored (a zero step re-evaluates f(x) == f0: rejected)
       double obj2 = ftrial;  // the clamp left the step untouched: f(x + step) is the last trial value
+      bool carried = false;
       if (changed) {
-        double q2[DP];
+        if (istep + 1 < max_num_steps || restart + 1 < max_num_restarts) {
+          double xn[DP];
 #pragma unroll
-        for (int k = 0; k < DP; ++k) q2[k] = fma(-2.0, step[k], x2[k]);
-        obj2 = ev.eval_value_q2(q2);
-        n_val++;
+          for (int k = 0; k < DP; ++k) xn[k] = xf[k] + step[k];
+          obj2 = ev.eval_grad_frame(xn, gf);  // (the old gradient is spent: d2 carries the direction)
+          carried = true;
+        } else {
+          double q2[DP];
+#pragma unroll
+          for (int k = 0; k < DP; ++k) q2[k] = fma(-2.0, step[k], x2[k]);
+          obj2 = ev.eval_value_q2(q2);
+          n_val++;
+        }
       }
-      if (obj2 <= f0) break;
+      if (obj2 <= f0) {
+        if (carried) n_val++;
+        break;
+      }
       double ss = 0.0;  // |step|^2 in the original coordinates
 #pragma unroll
       for (int k = 0; k < DP; ++k) {
@@ -693,21 +854,24 @@ __device__ __forceinline__ double line_search_frame(const KgMcParams& P, const d
       }
       fcur = obj2;
       istep += 1;
+      have_g = carried;
+      f_carried = obj2;
       if (sqrt(ss) < step_tolerance) break;
     }
     double ds = 0.0;
 #pragma unroll
     for (int k = 0; k < DP; ++k) {
-      const double dk = (xstart[k] - xf[k]) * C[DP + k];
+      const double dk = (S[k] - xf[k]) * C[DP + k];
       ds = fma(dk, dk, ds);
     }
     if (!(sqrt(ds) > tolerance)) break;
   }
+  if (have_g) n_val++;  // carried but never used
   // exit: back to the original coordinates (pinned rows return what came in) and the original dimension order
   {
     double xo[DP];
 #pragma unroll
-    for (int r = 0; r < DP; ++r) xo[r] = ((free_mask >> r) & 1u) ? fma(xf[r], C[DP + r], C[2 * DP + r]) : xkeep[r];
+    for (int r = 0; r < DP; ++r) xo[r] = ((free_mask >> r) & 1u) ? fma(xf[r], C[DP + r], C[2 * DP + r]) : C[5 * DP + r];
     from_table_order<DP, G>(xo, P.perm, x);
   }
   return fcur;
@@ -916,10 +1080,56 @@ __device__ __forceinline__ void kg_sample(const KgMcParams& P, int e, int sl, co
   const double* Lsm = rec + P.rec.L;
   const double* We = P.W + (long)e * P.w_stride;
 
-  double zc, bc;
-  draw_z_beta(P, Lsm, s, lane, zb, zc, bc);
+  double zc = 0.0, bc = 0.0;
+  MOE_PROF_T(w0);
+  const long so0 = (long)e * P.num_local + sl;
+  const bool prepped = P.best_j != nullptr;  // beta and the discretised-set winner come from the pre-pass (kg_sample_prep_kernel)
+  int best_j = 0;
+  if (prepped) {
+    bc = (lane < m) ? P.beta[so0 * m + lane] : 0.0;
+    best_j = P.best_j[so0];
+    zb[kMaxM + lane] = bc;
+    __builtin_amdgcn_wave_barrier();
+  } else {
+    draw_z_beta(P, Lsm, s, lane, zb, zc, bc);
+  }
+  MOE_PROF_T(w1);
   // ---- per-sample weights (see file header) into this wave's LDS slab ----
-  // v(j,a) = KinvY[(j,a)] - sum_c W[(j,a), c] beta_c.  The W loads are issued four columns at a time (column index clamped
+  // v(j,a) = KinvY[(j,a)] - sum_c W[(j,a), c] beta_c.
+  if (G == 0 && g1 == 1 && m <= 4) {
+    // q-KG with up to four fantasy points: the loads of EIGHT tiles (40 independent L2 reads per lane) are issued together, so a
+    // sample pays two round trips to L2 instead of one per pair of tiles (the phase is pure latency: 33k of a sample's 316k
+    // cycles before).  Same operation order as the general loop below.
+    const double b0 = zb[kMaxM], b1 = zb[kMaxM + 1], b2 = zb[kMaxM + 2], b3 = zb[kMaxM + 3];  // 0 beyond m
+    const long c1 = (long)min(1, m - 1) * P.N, c2 = (long)min(2, m - 1) * P.N, c3 = (long)min(3, m - 1) * P.N;
+    for (int t0 = 0; t0 < P.ntiles; t0 += 8) {
+      double ky[8], l0[8], l1[8], l2[8], l3[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const long row = min(min(t0 + i, P.ntiles - 1) * 64 + lane, n - 1);  // clamped: always a valid address
+        ky[i] = P.KinvY[row];
+        l0[i] = We[row];
+        l1[i] = We[row + c1];
+        l2[i] = We[row + c2];
+        l3[i] = We[row + c3];
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int t = t0 + i;
+        if (t < P.ntiles) {
+          const int j = t * 64 + lane;
+          double v = ky[i];
+          v = fma(-l0[i], b0, v);
+          v = fma(-l1[i], b1, v);
+          v = fma(-l2[i], b2, v);
+          v = fma(-l3[i], b3, v);
+          if (j >= n) v = (j < n + u) ? zb[kMaxM + min(j - n, kMaxM - 1)] : 0.0;
+          aw[(long)t * 64 + lane] = v * P.alpha;
+        }
+      }
+    }
+  } else {
+  // The W loads are issued four columns at a time (column index clamped
   // to m - 1; beta is 0 beyond m) and two tiles per iteration, so ~10 independent L2 loads are in flight per wait
   // instead of one dependent load per fma.
 #pragma unroll 2
@@ -952,10 +1162,13 @@ __device__ __forceinline__ void kg_sample(const KgMcParams& P, int e, int sl, co
       w[a * 64] = v;
     }
   }
+  }
   // (each lane only ever reads back the weight entries it wrote itself -- no cross-lane hazard; zb is read by every lane
   //  but was written before the wave-wide butterflies above/below execute, and LDS ops of one wave complete in order)
 
-  const int best_j = discrete_scan(P, rec, zb, lane);
+  MOE_PROF_T(w2);
+  if (!prepped) best_j = discrete_scan(P, rec, zb, lane);
+  MOE_PROF_T(w3);
 
   const double* disc = rec + P.rec.disc;
   double x[DP];
@@ -963,10 +1176,26 @@ __device__ __forceinline__ void kg_sample(const KgMcParams& P, int e, int sl, co
   for (int k = 0; k < DP; ++k) x[k] = (k < size) ? disc[(long)best_j * size + k] : ((k < P.dim) ? 1.0 : 0.0);
 
   unsigned long long n_val = 0, n_grad = 0;  // passes over the n + u points (the A-point scan is O(A m), not counted)
-  WaveEval<DP, G, SMALL, XL> ev{xs, aw, etab, P.ntiles, P.cov_type, P.mean, P.inv_lp, lane};
-  const double fcur = line_search_frame<DP, G>(P, cst, ev, x, n_val, n_grad);
+  WaveEval<DP, G, SMALL, XL> ev{xs, aw, etab, P.ntiles, P.cov_type, P.mean, P.inv_lp, lane, zb + DP};
+  const double fcur = line_search_frame<DP, G>(P, cst, zb, ev, x, n_val, n_grad);  // (z / beta scratch is idle by now)
+#if MOE_BLOCK_PROF
+  {
+    const unsigned long long w4 = __builtin_amdgcn_s_memtime();
+    if (lane == 0) {  // [0] z/beta [1] weights [2] scan [3] line search | [4] in value passes [5] in gradient passes | counts
+      atomicAdd(&P.prof[0], w1 - w0);
+      atomicAdd(&P.prof[1], w2 - w1);
+      atomicAdd(&P.prof[2], w3 - w2);
+      atomicAdd(&P.prof[3], w4 - w3);
+      atomicAdd(&P.prof[4], ev.c_v);
+      atomicAdd(&P.prof[5], ev.c_g);
+      atomicAdd(&P.prof[6], ev.n_v);
+      atomicAdd(&P.prof[7], ev.n_g);
+      atomicAdd(&P.prof[13], 1ull);
+    }
+  }
+#endif
 
-  const long so = (long)e * P.num_local + sl;
+  const long so = so0;
   if (lane == 0) P.best_value[so] = fcur;
   tot_val += n_val;  // flushed once per wave and evaluation by the caller: 10^4 samples x 2 atomics on one cache line per
   tot_grad += n_grad;  // evaluation serialise in the L2 atomic unit (and delay the sample tickets queued behind them)
@@ -977,7 +1206,7 @@ __device__ __forceinline__ void kg_sample(const KgMcParams& P, int e, int sl, co
       if (lane == k) v = x[k];
     P.best_point[so * DP + lane] = v;
   }
-  if (lane < m) P.beta[so * m + lane] = bc;
+  if (!prepped && lane < m) P.beta[so * m + lane] = bc;
 }
 
 // SMALL: the many-wavefront instantiation for point sets of a few tiles, where one pass is a short dependent chain (LDS
@@ -1103,11 +1332,6 @@ struct BlockEval {
   int nw, wave, lane, cov_type, par;
 #if MOE_BLOCK_PROF
   unsigned long long c_acc = 0, c_red = 0, c_bar = 0, c_post = 0, c_n = 0, c_gtot = 0, c_gn = 0;
-#define MOE_PROF_T(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
-#define MOE_PROF_ADD(dst, a, b) dst += (b) - (a)
-#else
-#define MOE_PROF_T(var)
-#define MOE_PROF_ADD(dst, a, b)
 #endif
 
   template <bool WG, int COV>

@@ -57,8 +57,10 @@ def test_kg_against_oracle(case, monkeypatch):
     ro = O.kg(gd, w.bounds_inner, w.discrete, w.Xq, Xp, w.M, best, w.kg_normals, num_fidelity=f)
     scale = max(float(np.abs(ro["grad"]).max()), abs(ro["kg"]))
     ptol = 1e-8 if gd[1] * gd[2] <= 8 else 1e-6
-    for variant in ("0", "1"):
+    # both MC kernels, and the wave-per-sample kernel with the sample pre-pass off (beta / discretised-set scan in the kernel)
+    for variant, prep in (("0", "1"), ("1", "1"), ("0", "0")):
         monkeypatch.setenv("MOE_KG_VARIANT", variant)
+        monkeypatch.setenv("MOE_KG_PREP", prep)
         rg = G.kg(gd, w.bounds_inner, w.discrete, w.Xq, Xp, w.M, best, w.kg_normals, num_fidelity=f, want_best_points=True)
         assert abs(rg["kg"] - ro["kg"]) <= TOL["kg"] * max(abs(ro["kg"]), 1e-6), (variant, rg["kg"], ro["kg"])
         assert np.abs(rg["grad"] - ro["grad"]).max() <= TOL["grad_kg"] * max(scale, 1e-6), variant
