@@ -77,6 +77,50 @@ def cpu_baseline(w, best, sample_mc, log, budget_s=45.0):
             "sample": "one orc_kg value+gradient at %d of %d MC samples, wall %.2f s, scaled linearly in M" % (sample_mc, w.M, wall)}
 
 
+def cpu_baseline_c5(w, log):
+    """C5 (d-KG, n=2000, g=3: N=8000, M=20 000) takes the reference hours per evaluation on one core, so its time is
+    EXTRAPOLATED: the unmodified reference (oracle/_ref) is timed at n in {250, 500, 1000} with two small sample
+    counts each, which separates the per-sample cost t_s(N) (two (N+m)^2 triangular sweeps + the inner optimisation's passes
+    over N entries: fitted as a N + b N^2) from the per-evaluation cost T_0(N) (state set-up and the (N+m)^3/3 refactorisation
+    of the fantasy GP: fitted as c N^2 + e N^3); then T(C5) = T_0(8000) + 20 000 t_s(8000)."""
+    from cornell_moe_amd.workloads import make_workload
+    from oracle import ref
+    if not ref.available():
+        return {"value": None, "unit": "evals/s", "cores": 1, "kind": "reference", "sample": "oracle/_ref not built"}
+    M1, M2 = 8, 24
+    Ns, ts, T0 = [], [], []
+    rows = []
+    for n in (250, 500, 1000):
+        ww = make_workload("C5", n=n, M=M2)
+        gp = ref.RefGP(1, ww.alpha, ww.lengths, ww.X, ww.y, ww.noise, list(ww.derivs))
+        best = float(gp.additional_mean(ww.discrete).min())
+        tt = []
+        for M in (M1, M2):
+            r = gp.kg(ww.inner_gd, ww.bounds, ww.discrete, ww.Xq, None, M, best, ww.kg_normals[: (M + 1) // 2])
+            tt.append(r["seconds"][0] + r["seconds"][1])
+        per_sample = (tt[1] - tt[0]) / float(M2 - M1)
+        fixed = tt[0] - M1 * per_sample
+        N = n * (1 + ww.g)
+        Ns.append(float(N))
+        ts.append(per_sample)
+        T0.append(fixed)
+        rows.append({"n": n, "N": N, "seconds_M%d" % M1: tt[0], "seconds_M%d" % M2: tt[1], "per_sample_s": per_sample, "fixed_s": fixed})
+        log("cpu_baseline C5: n=%d N=%d: %.2f s at M=%d, %.2f s at M=%d" % (n, N, tt[0], M1, tt[1], M2))
+    Ns = np.array(Ns)
+    ab = np.linalg.lstsq(np.c_[Ns, Ns ** 2], np.array(ts), rcond=None)[0]
+    ce = np.linalg.lstsq(np.c_[Ns ** 2, Ns ** 3], np.array(T0), rcond=None)[0]
+    Nc = float(w.n * (1 + w.g))
+    t_s = float(ab[0] * Nc + ab[1] * Nc ** 2)
+    t_0 = float(ce[0] * Nc ** 2 + ce[1] * Nc ** 3)
+    total = t_0 + w.M * t_s
+    return {"value": 1.0 / total, "unit": "evals/s", "cores": 1, "kind": "reference", "extrapolated_seconds_per_eval": total,
+            "model": "T = T0(N) + M t_s(N); t_s = a N + b N^2, T0 = c N^2 + e N^3 (least squares over the three sizes)",
+            "fit": {"a": float(ab[0]), "b": float(ab[1]), "c": float(ce[0]), "e": float(ce[1]), "t_s_at_C5": t_s, "T0_at_C5": t_0},
+            "measurements": rows,
+            "sample": "reference ComputeGradKnowledgeGradient (1 core) at n = 250, 500, 1000 (N = 1000, 2000, 4000) with %d and %d MC "
+                      "samples, extrapolated to N = %d, M = %d" % (M1, M2, int(Nc), w.M)}
+
+
 def committed_traffic():
     """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/hbm_traffic.json)."""
     try:
@@ -137,7 +181,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--restarts", type=int, default=8, help="independent KG evaluations per GPU per step")
+    ap.add_argument("--restarts", type=int, default=None, help="independent KG evaluations per GPU per step (default: 8 at C3, 2 at C5)")
     ap.add_argument("--shard", choices=["restarts", "mc"], default="restarts")
     ap.add_argument("--config", default="C3")
     ap.add_argument("--cpu-sample-mc", type=int, default=400)
@@ -183,7 +227,7 @@ def main():
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
 
-    R = args.restarts
+    R = args.restarts if args.restarts is not None else (2 if args.config == "C5" else 8)
     w = make_workload(args.config, num_restarts=R * world)
     G = DeviceGP(w.hyperparameters, w.X, w.y, w.noise, w.derivs, device=local_rank)
     best = float(G.additional_mean(w.discrete).min())  # knowledge_gradient.py:366-368
@@ -319,7 +363,10 @@ def main():
             traffic_src = "profiles/hbm_traffic.json (committed rocprofv3 PMC passes of an earlier run; %s)" % traffic_src
         mc_kernel = "kg_mc_kernel" if (w.g == 0 and w.n + w.q <= 1600) else "kg_mc_block_kernel"
         out = {
-            "metric": "q-KG gradient evals/s (n=1000,d=8,q=4,10k MC)", "value": value, "unit": "evals/s",
+            "metric": ("q-KG gradient evals/s (n=1000,d=8,q=4,10k MC)" if args.config in ("C3", "C4") else
+                       "%s gradient evals/s (n=%d,d=%d,q=%d,g=%d,%d MC) [secondary configuration %s]"
+                       % ("d-KG" if w.g else "q-KG", w.n, w.d, w.q, w.g, w.M, args.config)),
+            "value": value, "unit": "evals/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True, "scaling": "weak" if args.shard == "restarts" else "strong", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
@@ -355,7 +402,10 @@ def main():
                                    "state_host": ms_state / args.steps},
         }
         out.update(extras)
-        if not args.no_cpu_baseline and world == 1:  # reported baseline: rank 0 at N = 1 only
+        if not args.no_cpu_baseline and world == 1 and args.config == "C5":
+            out["cpu_baseline"] = cpu_baseline_c5(w, log)
+            out["speedup_vs_cpu_one_core"] = value / out["cpu_baseline"]["value"]
+        elif not args.no_cpu_baseline and world == 1:  # reported baseline: rank 0 at N = 1 only
             out["cpu_baseline"] = cpu_baseline(w, best, args.cpu_sample_mc, log)
             out["speedup_vs_cpu_best"] = value / out["cpu_baseline"]["value"]
             if "one_core_evals_per_s" in out["cpu_baseline"]:

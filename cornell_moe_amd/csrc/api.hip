@@ -297,10 +297,10 @@ int moe_cov_build_probe(const moe_gp_t* gp_c, const double* pts, int num_pts, in
     hipEvent_t e0, e1;
     MOE_HIP_CHECK(hipEventCreate(&e0));
     MOE_HIP_CHECK(hipEventCreate(&e1));
-    moe::launch_cov_build(gp.cp, gp.dX.p, gp.n, gp.derivs, dP.p, num_pts, no_derivs(), nullptr, dOut.p, gp.N, 0, gp.stream);
+    moe::launch_cov_build(gp.cp, gp.dX.p, gp.n, gp.derivs, dP.p, num_pts, no_derivs(), nullptr, dOut.p, gp.N, 0, gp.stream, true);
     MOE_HIP_CHECK(hipEventRecord(e0, gp.stream));
     for (int r = 0; r < repeat; ++r)
-      moe::launch_cov_build(gp.cp, gp.dX.p, gp.n, gp.derivs, dP.p, num_pts, no_derivs(), nullptr, dOut.p, gp.N, 0, gp.stream);
+      moe::launch_cov_build(gp.cp, gp.dX.p, gp.n, gp.derivs, dP.p, num_pts, no_derivs(), nullptr, dOut.p, gp.N, 0, gp.stream, true);
     MOE_HIP_CHECK(hipEventRecord(e1, gp.stream));
     MOE_HIP_CHECK(hipEventSynchronize(e1));
     float ms = 0.f;

@@ -59,6 +59,7 @@ void fill_cov_params(CovParams& cp, int cov_type, int d, const double* hyper) {
   for (int k = 0; k < kMaxDimPadded; ++k) {
     cp.inv_l2[k] = 0.0;
     cp.inv_l[k] = 0.0;
+    cp.center[k] = 0.0;
   }
   for (int k = 0; k < d; ++k) {
     const double l = hyper[1 + k];
@@ -261,6 +262,11 @@ std::vector<double> GpDev::padded(const double* pts, int k) const {
 void GpDev::rebuild() {
   use_device();
   N = n * (1 + g);
+  for (int k = 0; k < d; ++k) {  // frame centre of the value-only covariance builds: the training-set mean
+    double c = 0.0;
+    for (int j = 0; j < n; ++j) c += X[(size_t)j * d + k];
+    cp.center[k] = c / (double)n;
+  }
   const std::vector<double> Xp = padded(X.data(), n);
   dX.upload(Xp.data(), Xp.size(), stream);
   dNoise.upload(noise.data(), noise.size(), stream);

@@ -23,6 +23,9 @@ struct CovParams {
   double alpha;
   double inv_l2[kMaxDimPadded];  // 1 / length^2, 0 in padded slots
   double inv_l[kMaxDimPadded];   // 1 / length, 0 in padded slots
+  double center[kMaxDimPadded];  // a reference point near the data (the training-set mean; any point works): the value-only
+                                 // covariance build subtracts it before scaling so that pre-scaled coordinates keep the
+                                 // precision of the differences wherever the domain sits (kernels_cov.hip)
 };
 
 struct DerivList {
@@ -32,8 +35,13 @@ struct DerivList {
 
 // out[(i*(1+gA)+a) + (col0 + j*(1+gB)+b) * ld] = cov(A_i, B_j)[a, b]   (BuildMixCovarianceMatrix, gpp_math.cpp:309-335)
 // If diag_noise != nullptr (A == B, gA == gB): adds diag_noise[a] where row == col (gpp_math.cpp:426-455).
+// streaming = true: the big N x M cross-covariance builds (gradient tail, the roofline probe) may take the value-only fast path
+// (centred pre-scaled coordinates + table exp, <= 2 ulp per entry); the GP's own K(X, X), K* and the posterior queries keep the
+// general kernel, whose entries follow the reference's formulas operation for operation (a duplicate point must still be
+// reported singular at the same pivot).
 void launch_cov_build(const CovParams& cp, const double* A, int nA, const DerivList& dA, const double* B, int nB,
-                      const DerivList& dB, const double* diag_noise, double* out, long ld, long col0, hipStream_t s);
+                      const DerivList& dB, const double* diag_noise, double* out, long ld, long col0, hipStream_t s,
+                      bool streaming = false);
 
 // E[(j*(1+g)+n) + (col0 + (i*(1+gt)+m)*dim + dd) * ld] = d cov(P_i, X_j)[m, n] / d P_{i,dd}
 // (grad_K_star fill, gpp_math.cpp:616-637)

@@ -6,6 +6,7 @@
 // once in LDS and read as wave-uniform broadcasts, the A point stays in registers for the whole tile.
 // Algorithmic bytes per launch: 8 * [nA*d + nB*d + nA(1+gA) * nB(1+gB)].
 #include <algorithm>
+#include <cstdlib>
 
 #include "device_cov.hpp"
 
@@ -57,6 +58,64 @@ __global__ __launch_bounds__(kCovRows) void cov_build_kernel(CovParams cp, const
         out[(long)r + (col0 + colrel) * ld] = v;
       }
     }
+  }
+}
+
+// Value-only blocks (no derivative observations on either side -- K(X, X) of a q-KG GP, K*, the N x M gradient-tail matrix):
+// the same mapping, with the arithmetic per entry cut from ~55 to ~40 FP64 instructions, because at ~3.4 TB/s of stores this
+// kernel was FP64-issue co-limited, not store-limited (tools/covbench.hip):
+//   * coordinates are centred on cp.center and divided by the length scale ONCE (the A point when it is loaded, the B points
+//     when they are staged) -- sqrt(5) folded in for Matern -- so an entry needs DP subtractions + DP fmas instead of DP
+//     subtractions + DP multiplications + DP fmas (centred first: scaled coordinates keep the precision of the differences);
+//   * exp through the 64-entry table of fastmath.hpp (10 FP64 + 3 integer instructions, <= 1.5 ulp) instead of the degree-11
+//     polynomial (17), sqrt without the clamp (the accumulation starts from 1e-300).
+template <int DP>
+__global__ __launch_bounds__(kCovRows) void cov_build_value_kernel(CovParams cp, const double* __restrict__ A, int nA,
+                                                                  const double* __restrict__ B, int nB,
+                                                                  const double* __restrict__ diag_noise,
+                                                                  double* __restrict__ out, long ld, long col0) {
+  __shared__ double Bs[kCovCols][DP];
+  __shared__ double etab[64];
+  const bool matern = cp.type == MOE_COV_MATERN_NU_2P5;
+  const double s5 = matern ? 2.236067977499789696409173668731276235 : 1.0;
+  const int j0 = blockIdx.x * kCovCols;
+  const int nj = min(kCovCols, nB - j0);
+  if (threadIdx.x < 64) etab[threadIdx.x] = kExp2Tab64[threadIdx.x];
+  for (int t = threadIdx.x; t < nj * DP; t += blockDim.x) {
+    const int k = t % DP;
+    Bs[t / DP][k] = (B[(long)(j0 + t / DP) * DP + k] - cp.center[k]) * (cp.inv_l[k] * s5);
+  }
+  __syncthreads();
+  const int r = blockIdx.y * kCovRows + threadIdx.x;
+  if (r >= nA) return;
+  double xi[DP];
+#pragma unroll
+  for (int k = 0; k < DP; ++k) xi[k] = (A[(long)r * DP + k] - cp.center[k]) * (cp.inv_l[k] * s5);
+  const double noise = diag_noise != nullptr ? diag_noise[0] : 0.0;
+  // two columns per iteration: two independent distance / sqrt / exp chains in flight per thread
+  for (int jj = 0; jj < nj; jj += 2) {
+    const int j1 = min(jj + 1, nj - 1);
+    double ra = 1.0e-300, rb = 1.0e-300;
+#pragma unroll
+    for (int k = 0; k < DP; ++k) {
+      const double da = xi[k] - Bs[jj][k], db = xi[k] - Bs[j1][k];
+      ra = fma(da, da, ra);
+      rb = fma(db, db, rb);
+    }
+    double va, vb;
+    if (matern) {
+      const double aa = sqrt_pos(ra), ab = sqrt_pos(rb);  // = sqrt(5) r
+      va = (cp.alpha * exp_nonpos_tab(-aa, etab)) * fma(aa, fma(aa, 1.0 / 3.0, 1.0), 1.0);
+      vb = (cp.alpha * exp_nonpos_tab(-ab, etab)) * fma(ab, fma(ab, 1.0 / 3.0, 1.0), 1.0);
+    } else {
+      va = cp.alpha * exp_nonpos_tab(fmax(-0.5 * ra, -1000.0), etab);
+      vb = cp.alpha * exp_nonpos_tab(fmax(-0.5 * rb, -1000.0), etab);
+    }
+    const long col = col0 + j0 + jj;
+    if (diag_noise != nullptr && (long)r == col - col0) va += noise;
+    if (diag_noise != nullptr && (long)r == col + 1 - col0) vb += noise;
+    out[(long)r + col * ld] = va;
+    if (jj + 1 < nj) out[(long)r + (col + 1) * ld] = vb;
   }
 }
 
@@ -164,9 +223,14 @@ __global__ __launch_bounds__(256) void mean_kernel(CovParams cp, const double* _
   }
 }
 
+bool value_fast_path() {  // MOE_COV_FAST=0: the general kernel for value-only blocks too (A/B runs, tests)
+  const char* v = std::getenv("MOE_COV_FAST");
+  return !(v && *v == '0');
+}
+
 template <int DP>
 void cov_build_dp(const CovParams& cp, const double* A, int nA, const DerivList& dA, const double* B, int nB,
-                  const DerivList& dB, const double* diag_noise, double* out, long ld, long col0, hipStream_t s) {
+                  const DerivList& dB, const double* diag_noise, double* out, long ld, long col0, hipStream_t s, bool streaming) {
   const bool derivs = dA.g > 0 || dB.g > 0;
   const int rows = nA * (1 + dA.g);
   dim3 grid((nB + kCovCols - 1) / kCovCols, (rows + kCovRows - 1) / kCovRows);
@@ -174,6 +238,8 @@ void cov_build_dp(const CovParams& cp, const double* A, int nA, const DerivList&
   if (derivs)
     hipLaunchKernelGGL((cov_build_kernel<DP, true>), grid, dim3(kCovRows), 0, s, cp, A, nA, dA, B, nB, dB, diag_noise, out, ld,
                        col0);
+  else if (streaming && value_fast_path())
+    hipLaunchKernelGGL((cov_build_value_kernel<DP>), grid, dim3(kCovRows), 0, s, cp, A, nA, B, nB, diag_noise, out, ld, col0);
   else
     hipLaunchKernelGGL((cov_build_kernel<DP, false>), grid, dim3(kCovRows), 0, s, cp, A, nA, dA, B, nB, dB, diag_noise, out,
                        ld, col0);
@@ -215,12 +281,13 @@ void launch_debug_math(const double* x, int n, double* e, double* r, hipStream_t
 }
 
 void launch_cov_build(const CovParams& cp, const double* A, int nA, const DerivList& dA, const double* B, int nB,
-                      const DerivList& dB, const double* diag_noise, double* out, long ld, long col0, hipStream_t s) {
+                      const DerivList& dB, const double* diag_noise, double* out, long ld, long col0, hipStream_t s,
+                      bool streaming) {
   switch (cp.dp) {
-    case 4: cov_build_dp<4>(cp, A, nA, dA, B, nB, dB, diag_noise, out, ld, col0, s); break;
-    case 8: cov_build_dp<8>(cp, A, nA, dA, B, nB, dB, diag_noise, out, ld, col0, s); break;
-    case 12: cov_build_dp<12>(cp, A, nA, dA, B, nB, dB, diag_noise, out, ld, col0, s); break;
-    case 16: cov_build_dp<16>(cp, A, nA, dA, B, nB, dB, diag_noise, out, ld, col0, s); break;
+    case 4: cov_build_dp<4>(cp, A, nA, dA, B, nB, dB, diag_noise, out, ld, col0, s, streaming); break;
+    case 8: cov_build_dp<8>(cp, A, nA, dA, B, nB, dB, diag_noise, out, ld, col0, s, streaming); break;
+    case 12: cov_build_dp<12>(cp, A, nA, dA, B, nB, dB, diag_noise, out, ld, col0, s, streaming); break;
+    case 16: cov_build_dp<16>(cp, A, nA, dA, B, nB, dB, diag_noise, out, ld, col0, s, streaming); break;
     default: throw Error(MOE_ERR_RUNTIME, "unsupported padded dimension");
   }
   MOE_HIP_CHECK(hipGetLastError());

@@ -692,6 +692,239 @@ void launch_gram_batch(int E, int m, int ng, int A, int K, const double* V, long
 }
 
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Two-level blocked factorisation for large N (C5: N = 8000; its stretch point N = 26 000).  The one-level algorithm above
+// pays, per 64 columns, a single-wavefront diagonal kernel whose fully unrolled 64 x 64 body does not fit the instruction
+// cache (125 launches of ~150 us at N = 8000) and a rank-64 trailing update that re-reads and re-writes the whole trailing
+// matrix (HBM-bound: ~43 GB at N = 8000).  Here columns are grouped into OUTER blocks of kOuter (512):
+//   * inside an outer block the 64-column steps only update the columns of that block (a tall, narrow region);
+//   * the diagonal 64 x 64 factor + inverse is a 256-thread LDS kernel with rolled loops (chol_diag_lds_kernel);
+//   * once an outer block is done, ONE rank-512 update of the trailing matrix runs on the matrix pipe
+//     (syrk_mfma_kernel, v_mfma_f64_16x16x4_f64): the trailing matrix makes N / 512 round trips through HBM instead of N / 64,
+//     and 8 x more flops per byte is what lets the MFMA tiles run compute-bound.
+// Same pivot rule (1e-16, gpp_linear_algebra.cpp:118) and the same error report as the one-level path.
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int kOuter = 512;
+
+// Diagonal 64 x 64 block: factor AND invert, 256 threads, everything in LDS, in 16-column sub-steps:
+//   (1) the 16 x 16 diagonal sub-block is factored and inverted by 16 lanes holding one row each in registers (16 unrolled
+//       steps: v_readlane pivot, division by its square root, the 1e-16 pivot rule -- the reference's outer-product order);
+//   (2) the rows below it get  A_panel L16^-T  through that inverse;   (3) the remaining columns get their rank-16 update,
+//       folded in one column at a time (fma in k order: the unblocked algorithm's rounding);
+// then L^-1 by recursive halving (16 -> 32 -> 64) with small LDS GEMMs:  inv [[L11, 0], [L21, L22]] = [[X11, 0], [-X22 L21 X11, X22]].
+// ~10 us per block instead of ~110 us for a scalar 64-step loop with three barriers per column (measured), or the 46 - 250 us of
+// the register-resident single-wavefront kernel above, whose fully unrolled body does not fit the instruction cache.
+constexpr int SB = 16;
+
+// L (lower triangle incl. diagonal) and X = L^-1 (lower triangle) share ONE 64 x 65 LDS array: X[i][j], j <= i, lives in the
+// strict upper part at S[j][i + 1]  (50 KB of LDS for the kernel instead of 100).
+#define MOE_XS(i, j) S[(j)][(i) + 1]
+
+template <int LO, int MID, int HI>
+__device__ __forceinline__ void lds_tri_inv_offdiag(double (*S)[NB + 1], double (*W)[2 * SB + 1]) {
+  // Fixed trip counts with predicated terms (clamped addresses), fully unrolled: the loads of a dot product are issued together
+  // instead of one LDS round trip per term.
+  // W[r][c - LO] = sum_j L[r][j] X[j][c],  r in [MID, HI), c in [LO, MID), j in [c, MID)   (X11 lower triangular)
+  constexpr int rows = HI - MID, cols = MID - LO;
+  for (int idx = threadIdx.x; idx < rows * cols; idx += 256) {
+    const int r = MID + idx % rows, c = LO + idx / rows;
+    double acc = 0.0;
+#pragma unroll
+    for (int j = LO; j < MID; ++j) {
+      const double x = MOE_XS(max(j, c), c);  // (j < c: a valid but unused entry)
+      acc = fma(S[r][j], (j >= c) ? x : 0.0, acc);
+    }
+    W[r][c - LO] = acc;
+  }
+  __syncthreads();
+  // X[r][c] = -sum_j X[r][j] W[j][c],  j in [MID, r]   (X22 lower triangular)
+  for (int idx = threadIdx.x; idx < rows * cols; idx += 256) {
+    const int r = MID + idx % rows, c = LO + idx / rows;
+    double acc = 0.0;
+#pragma unroll
+    for (int j = MID; j < HI; ++j) {
+      const double x = MOE_XS(r, min(j, r));
+      acc = fma((j <= r) ? x : 0.0, W[j][c - LO], acc);
+    }
+    MOE_XS(r, c) = -acc;
+  }
+  __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void chol_diag_lds_kernel(double* __restrict__ A, long lda, double* __restrict__ Linv,
+                                                           long ldl, int k0, int nb, int* __restrict__ info) {
+  __shared__ double S[NB][NB + 1];      // S[i][j] = L[i][j] for j <= i;  (L^-1)[i][j] at S[j][i + 1]
+  __shared__ double W[NB][2 * SB + 1];  // scratch: panel / product blocks (up to 32 columns)
+  __shared__ int s_bad;
+  if (*info != 0) return;
+  const int t = threadIdx.x;
+  for (int idx = t; idx < NB * (NB + 1); idx += 256) {
+    const int i = idx % NB, j = idx / NB;  // j runs to NB: column 64 belongs to the packed inverse
+    double v = (i == j && i >= nb) ? 1.0 : 0.0;  // rows / columns beyond nb (last, partial block): identity
+    if (i < nb && j < nb && j <= i) v = A[(long)(k0 + i) + (long)(k0 + j) * lda];
+    S[i][j] = v;
+  }
+  if (t == 0) s_bad = 0;
+  __syncthreads();
+  for (int s0 = 0; s0 < NB; s0 += SB) {
+    // (1) 16 x 16 diagonal sub-block: the first wavefront, lane & 15 = row of the sub-block, that row in registers
+    if (t < 64) {
+      const int i = t & (SB - 1);
+      double a[SB];
+#pragma unroll
+      for (int c = 0; c < SB; ++c) a[c] = S[s0 + i][s0 + c];  // (c > i: whatever the packed inverse holds there -- never used)
+      int bad = 0;
+#pragma unroll
+      for (int k = 0; k < SB; ++k) {
+        const double piv = readlane_f64(a[k], k);
+        if (bad == 0 && !(piv > 1.0e-16)) bad = k0 + s0 + k + 1;  // gpp_linear_algebra.cpp:118
+        const double lkk = sqrt(piv);
+        const double lik = (i == k) ? lkk : a[k] / lkk;
+        a[k] = lik;
+#pragma unroll
+        for (int j = k + 1; j < SB; ++j) {
+          const double ljk = readlane_f64(lik, j);  // L[j][k] lives in lane j
+          a[j] = a[j] - lik * ljk;                   // (lanes i < j compute unused upper-triangle values)
+        }
+      }
+      // its inverse: lane i solves L16 x = e_i (column i of the inverse), entries above i are exact zeros
+      double x[SB];
+#pragma unroll
+      for (int r = 0; r < SB; ++r) {
+        double sum = (r == i) ? 1.0 : 0.0;
+#pragma unroll
+        for (int j = 0; j < r; ++j) sum -= readlane_f64(a[j], r) * x[j];  // L[r][j] lives in lane r
+        x[r] = sum / readlane_f64(a[r], r);
+      }
+      if (t < SB) {
+        if (bad != 0 && s_bad == 0) s_bad = bad;
+#pragma unroll
+        for (int c = 0; c < SB; ++c) {
+          if (c <= i) S[s0 + i][s0 + c] = a[c];
+          if (c >= i) MOE_XS(s0 + c, s0 + i) = x[c];  // x[c] = (L16^-1)[c][i]
+        }
+      }
+    }
+    __syncthreads();
+    const int below = NB - s0 - SB;
+    if (below > 0) {
+      // (2) panel: P[r][c] = sum_j A[r][s0 + j] X16[c][j]   (= A_panel L16^-T), r below the sub-block
+      for (int idx = t; idx < below * SB; idx += 256) {
+        const int r = s0 + SB + idx % below, c = idx / below;
+        double acc = 0.0;
+#pragma unroll
+        for (int j = 0; j < SB; ++j)
+          if (j <= c) acc = fma(S[r][s0 + j], MOE_XS(s0 + c, s0 + j), acc);
+        W[r][c] = acc;
+      }
+      __syncthreads();
+      for (int idx = t; idx < below * SB; idx += 256) {
+        const int r = s0 + SB + idx % below, c = idx / below;
+        S[r][s0 + c] = W[r][c];
+      }
+      __syncthreads();
+      // (3) the remaining columns: S[i][j] -= sum_c S[i][s0 + c] S[j][s0 + c], j <= i, one column at a time in k order
+      for (int idx = t; idx < below * below; idx += 256) {
+        const int i = s0 + SB + idx % below, j = s0 + SB + idx / below;
+        if (j <= i) {
+          double acc = S[i][j];
+#pragma unroll
+          for (int c = 0; c < SB; ++c) acc = acc - S[i][s0 + c] * S[j][s0 + c];
+          S[i][j] = acc;
+        }
+      }
+      __syncthreads();
+    }
+  }
+  if (s_bad != 0) {
+    if (t == 0) *info = s_bad;
+    return;
+  }
+  // L^-1: the diagonal 16-blocks are in place; off-diagonal blocks by recursive halving
+  lds_tri_inv_offdiag<0, 16, 32>(S, W);
+  lds_tri_inv_offdiag<32, 48, 64>(S, W);
+  lds_tri_inv_offdiag<0, 32, 64>(S, W);
+  for (int idx = t; idx < NB * NB; idx += 256) {
+    const int i = idx % NB, j = idx / NB;
+    if (i < nb && j < nb) {
+      A[(long)(k0 + i) + (long)(k0 + j) * lda] = (j <= i) ? S[i][j] : 0.0;  // strict upper written as 0
+      Linv[(long)(k0 + i) + (long)(k0 + j) * ldl] = (j <= i) ? MOE_XS(i, j) : 0.0;
+    }
+  }
+}
+#undef MOE_XS
+
+// A[i][j] -= sum_{k in [kp0, kp0 + kw)} A[i][k] A[j][k] for the trailing rows / columns i, j >= base, lower triangle only: the
+// rank-kw update of a right-looking factorisation on the matrix pipe.  64 x 64 tile per workgroup, each wavefront a 32 x 32
+// quadrant as 2 x 2 MFMA tiles; both operands are row panels of the same matrix (row index fastest in memory: coalesced);
+// the next K tile travels global -> registers while the current one is multiplied out of LDS.
+__global__ __launch_bounds__(256) void syrk_mfma_kernel(double* __restrict__ A, long lda, int N, int base, int kp0, int kw,
+                                                       const int* __restrict__ info) {
+  constexpr int TM = 64, TKS = 16, LD = 65;
+  constexpr int NF = TM * TKS / 256;
+  __shared__ double As[TKS][LD];
+  __shared__ double Bs[TKS][LD];
+  if (*info != 0) return;
+  // triangular grid folded into a rectangle: workgroup (x, y) of a T x ceil((T + 1) / 2) ... kept simple: skip the upper half
+  const int bi = blockIdx.y, bj = blockIdx.x;
+  if (bj > bi) return;
+  const int i0 = base + bi * TM, j0 = base + bj * TM;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int wi = (wave & 1) * 32, wj = (wave >> 1) * 32;
+  const int lk = lane >> 4, lx = lane & 15;
+  f64x4 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) acc[a][b] = f64x4{0.0, 0.0, 0.0, 0.0};
+  double ra[NF], rb[NF];
+  auto fetch = [&](int k) {
+#pragma unroll
+    for (int it = 0; it < NF; ++it) {
+      const int t = threadIdx.x + 256 * it;
+      const int ii = t % TM, kk = t / TM;
+      const bool kok = k + kk < kw;
+      const long col = (long)(kp0 + k + kk) * lda;
+      ra[it] = (kok && i0 + ii < N) ? A[(long)(i0 + ii) + col] : 0.0;
+      rb[it] = (kok && j0 + ii < N) ? A[(long)(j0 + ii) + col] : 0.0;
+    }
+  };
+  fetch(0);
+  for (int k = 0; k < kw; k += TKS) {
+#pragma unroll
+    for (int it = 0; it < NF; ++it) {
+      const int t = threadIdx.x + 256 * it;
+      As[t / TM][t % TM] = ra[it];
+      Bs[t / TM][t % TM] = rb[it];
+    }
+    __syncthreads();
+    if (k + TKS < kw) fetch(k + TKS);
+#pragma unroll
+    for (int k4 = 0; k4 < TKS; k4 += 4) {
+      double fa[2], fb[2];
+#pragma unroll
+      for (int a = 0; a < 2; ++a) fa[a] = As[k4 + lk][wi + 16 * a + lx];
+#pragma unroll
+      for (int b = 0; b < 2; ++b) fb[b] = Bs[k4 + lk][wj + 16 * b + lx];
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb[b], fa[a], acc[a][b], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+  // D[x][y] = C[row = y][col = x]: lane holds y = lane & 15 (row), x = (lane >> 4) + 4 r (column)
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int gi = i0 + wi + 16 * a + lx, gj = j0 + wj + 16 * b + lk + 4 * r;
+        if (gi < N && gj < N && gj <= gi) A[(long)gi + (long)gj * lda] -= acc[a][b][r];
+      }
+}
+
 namespace {
 void trtri_offdiag(const double* L, long lda, double* Linv, long ldl, int N, int lo, int hi, double* work, hipStream_t s) {
   if (hi - lo <= 1) return;
@@ -717,14 +950,39 @@ void launch_cholesky_and_inverse(int N, double* A, long lda, double* Linv, long 
   MOE_HIP_CHECK(hipMemsetAsync(info, 0, sizeof(int), s));
   MOE_HIP_CHECK(hipMemsetAsync(Linv, 0, sizeof(double) * (size_t)ldl * N, s));
   const int nblk = (N + NB - 1) / NB;
-  for (int b = 0; b < nblk; ++b) {
-    const int k0 = b * NB, nb = std::min(NB, N - k0);
-    hipLaunchKernelGGL(chol_diag_kernel, dim3(1), dim3(64), 0, s, A, lda, Linv, ldl, k0, nb, info);
-    const int below = N - k0 - nb;
-    if (below > 0) {
-      hipLaunchKernelGGL(chol_panel_kernel, dim3((below + NB - 1) / NB), dim3(256), 0, s, A, lda, Linv, ldl, N, k0, nb, info);
-      const int tb = (below + NB - 1) / NB;
-      hipLaunchKernelGGL(chol_update_kernel, dim3(tb, tb), dim3(256), 0, s, A, lda, N, k0, nb, info);
+  const char* tl_env = std::getenv("MOE_CHOL_TWO_LEVEL_MIN");  // (read per call: tests force the two-level path at small N)
+  const int two_level_min = (tl_env && *tl_env) ? std::atoi(tl_env) : 2048;
+  if (N >= two_level_min) {
+    for (int ko = 0; ko < N; ko += kOuter) {
+      const int wo = std::min(kOuter, N - ko);
+      for (int k0 = ko; k0 < ko + wo; k0 += NB) {
+        const int nb = std::min(NB, N - k0);
+        hipLaunchKernelGGL(chol_diag_lds_kernel, dim3(1), dim3(256), 0, s, A, lda, Linv, ldl, k0, nb, info);
+        const int below = N - k0 - nb;
+        if (below > 0) {
+          const int tb = (below + NB - 1) / NB;
+          hipLaunchKernelGGL(chol_panel_kernel, dim3(tb), dim3(256), 0, s, A, lda, Linv, ldl, N, k0, nb, info);
+          const int left = ko + wo - (k0 + nb);  // columns of this outer block still to be factored
+          if (left > 0)
+            hipLaunchKernelGGL(chol_update_kernel, dim3(tb, (left + NB - 1) / NB), dim3(256), 0, s, A, lda, N, k0, nb, info);
+        }
+      }
+      const int trailing = N - (ko + wo);
+      if (trailing > 0) {
+        const int tt = (trailing + 63) / 64;
+        hipLaunchKernelGGL(syrk_mfma_kernel, dim3(tt, tt), dim3(256), 0, s, A, lda, N, ko + wo, ko, wo, (const int*)info);
+      }
+    }
+  } else {
+    for (int b = 0; b < nblk; ++b) {
+      const int k0 = b * NB, nb = std::min(NB, N - k0);
+      hipLaunchKernelGGL(chol_diag_kernel, dim3(1), dim3(64), 0, s, A, lda, Linv, ldl, k0, nb, info);
+      const int below = N - k0 - nb;
+      if (below > 0) {
+        hipLaunchKernelGGL(chol_panel_kernel, dim3((below + NB - 1) / NB), dim3(256), 0, s, A, lda, Linv, ldl, N, k0, nb, info);
+        const int tb = (below + NB - 1) / NB;
+        hipLaunchKernelGGL(chol_update_kernel, dim3(tb, tb), dim3(256), 0, s, A, lda, N, k0, nb, info);
+      }
     }
   }
   {

@@ -715,7 +715,7 @@ KgPending kg_launch(GpDev& gp, int num_fidelity, const moe_gd_params_t& gd, cons
   if (E <= 0) throw Error(MOE_ERR_BOUNDS, "num_evals must be positive", E, 1, 1e9);
   if (m > kMaxM)
     throw Error(MOE_ERR_BOUNDS, "(q + p)(1 + num_derivatives) > 64 is not supported by the device kernels", m, 1, kMaxM);
-  if (g > 4) throw Error(MOE_ERR_BOUNDS, "d-KG with more than 4 observed derivatives is not supported by the device kernels yet", g, 0, 4);
+  if (g > 12) throw Error(MOE_ERR_BOUNDS, "d-KG with more than 12 observed derivatives is not supported by the device kernels", g, 0, 12);
   if (f < 0 || f >= d) throw Error(MOE_ERR_BOUNDS, "num_fidelity out of range", f, 0, d - 1);
   if (num_mc <= 0) throw Error(MOE_ERR_BOUNDS, "num_mc must be positive", num_mc, 1, 1e12);
   if (first_sample < 0 || (first_sample & 1) || num_local <= 0 || first_sample + num_local > num_mc)
@@ -723,7 +723,9 @@ KgPending kg_launch(GpDev& gp, int num_fidelity, const moe_gd_params_t& gd, cons
   if (gd.max_num_steps <= 0) throw Error(MOE_ERR_BOUNDS, "max_num_steps must be positive", gd.max_num_steps, 1, 1e9);
   const int size = d - f;
   const int A = u + P;
-  const int G = g;  // derivative-weight slots of the MC kernel instantiation (one per observed derivative, 0..4)
+  // derivative-weight slots of the MC kernel instantiation: one per observed derivative up to 4, then 8 or 12 (unused slots
+  // carry zero weights); more than 4 always take the workgroup-per-sample kernel
+  const int G = g <= 4 ? g : (g <= 8 ? 8 : 12);
   const int ntiles = (n + u + 63) / 64;
   const int ngrad = want_grad ? q * g1 * d : 0;
 
@@ -788,6 +790,7 @@ KgPending kg_launch(GpDev& gp, int num_fidelity, const moe_gd_params_t& gd, cons
   if (tr >= 0) num_lds_tiles = std::max(0, ntiles - bwaves * tr);
   int variant = (xlds && waves >= min_xlds_waves) ? 0 : (tr >= 0 ? 1 : 0);
   variant = env_int("MOE_KG_VARIANT", variant);
+  if (G > 4) variant = 1;  // (the wave-per-sample kernel is instantiated for up to four derivative slots)
   if (variant == 1 && (tr < 0 || kg_mc_block_lds_bytes(dp, G, num_lds_tiles) > (size_t)160 * 1024))
     throw Error(MOE_ERR_RUNTIME, "point set too large for the workgroup-per-sample MC kernel");
   if (variant == 0 && waves < 1)
@@ -1142,7 +1145,7 @@ KgPending kg_launch(GpDev& gp, int num_fidelity, const moe_gd_params_t& gd, cons
     t_tail.stop(s);
   } else if (want_grad) {
     t_cov.start(s);
-    launch_cov_build(gp.cp, gp.dX.p, n, gp.derivs, dBestPoint.p, E * num_local, none, nullptr, dT.p, N, 0, s);
+    launch_cov_build(gp.cp, gp.dX.p, n, gp.derivs, dBestPoint.p, E * num_local, none, nullptr, dT.p, N, 0, s, true);
     t_cov.stop(s);
     t_tail.start(s);
     if (m > 8 || (size_t)N * m * sizeof(double) > 96 * 1024) {

@@ -1282,7 +1282,7 @@ __global__ __launch_bounds__(SMALL ? 1024 : 512) void kg_mc_kernel(KgMcParams P)
 // each pass ends with one wavefront sum per wave, one LDS slot per wave, ONE __syncthreads, and a fixed-order sum of the
 // per-wave partials, so every wave takes bit-identical decisions.
 // =====================================================================================================================
-constexpr int kPartLen = 24;       // doubles per partial slot: f | DP gradient sums | G derivative sums (<= 1 + 16 + 4)
+constexpr int kPartLen = 32;       // doubles per partial slot: f | DP gradient sums | G derivative sums (<= 1 + 16 + 12)
 constexpr int kMaxBlockWaves = 8;
 
 // One point's contribution to the accumulators (shared by the LDS-tile loop and the register tiles).
@@ -1821,6 +1821,10 @@ inline void launch_block_dp(const KgMcParams& P, int G, int tr, int num_lds_tile
     case 2: launch_block_g<DP, 2>(P, tr, num_lds_tiles, blocks, waves, s); break;
     case 3: launch_block_g<DP, 3>(P, tr, num_lds_tiles, blocks, waves, s); break;
     case 4: launch_block_g<DP, 4>(P, tr, num_lds_tiles, blocks, waves, s); break;
+    // more observed derivatives (up to 12: every dimension of C5) run in the next larger slot count, the unused slots
+    // carrying zero weights; only this kernel is instantiated for them (the host never sends them to the wave-per-sample one)
+    case 8: launch_block_g<DP, 8>(P, tr, num_lds_tiles, blocks, waves, s); break;
+    case 12: launch_block_g<DP, 12>(P, tr, num_lds_tiles, blocks, waves, s); break;
     default: throw Error(MOE_ERR_RUNTIME, "unsupported derivative-slot count in the MC kernel");
   }
 }

@@ -471,3 +471,43 @@ def test_fastmath(api):
     ulp_r = np.abs(r[pos] - ref_r[pos]) / np.spacing(ref_r[pos])
     assert ulp_r.max() <= 1.0, ulp_r.max()
     assert r[0] == 1e-150 and e[0] == 1.0
+
+
+def test_two_level_cholesky(api, monkeypatch):
+    """The large-N factorisation (outer blocks of 512 columns, LDS diagonal kernel, rank-512 trailing update on the matrix pipe):
+    (1) forced at small sizes -- partial last blocks, derivative observations -- it gives the one-level path's factor, inverse
+    application and posterior to round-off, and reports a singular matrix at the same minor; (2) at N = 2600 (its own
+    territory) L L^T reproduces K to 1e-12 and L matches LAPACK's factor."""
+    rng = np.random.default_rng(19)
+    for n, d, derivs in ((300, 3, ()), (700, 4, ()), (260, 5, (0, 3))):
+        X = rng.uniform(size=(n, d))
+        g = len(derivs)
+        y = rng.uniform(size=(n, 1 + g))
+        hyper = [1.3] + list(0.3 + 0.1 * np.arange(d))
+        noise = [0.02] * (1 + g)
+        monkeypatch.delenv("MOE_CHOL_TWO_LEVEL_MIN", raising=False)
+        a = api.DeviceGP(hyper, X, y, noise, derivatives=derivs)
+        monkeypatch.setenv("MOE_CHOL_TWO_LEVEL_MIN", "64")
+        b = api.DeviceGP(hyper, X, y, noise, derivatives=derivs)
+        La, kiya, _ = a.get_factor()
+        Lb, kiyb, _ = b.get_factor()
+        assert np.abs(La - Lb).max() <= 1e-13 * np.abs(La).max()
+        assert np.abs(kiya - kiyb).max() <= 1e-10 * np.abs(kiya).max()
+        q = rng.uniform(size=(6, d))
+        assert np.abs(a.mean(q) - b.mean(q)).max() <= 1e-11 and np.abs(a.variance(q) - b.variance(q)).max() <= 1e-11
+    Xs = rng.uniform(size=(200, 2))
+    Xs[150] = Xs[20]
+    with pytest.raises(api.SingularMatrixException) as e:
+        api.DeviceGP([1.0, 0.5, 0.5], Xs, np.zeros((200, 1)), [0.0])
+    assert e.value.leading_minor_index == 151
+    monkeypatch.delenv("MOE_CHOL_TWO_LEVEL_MIN")
+    n, d = 2600, 6
+    X = rng.uniform(size=(n, d))
+    y = np.sin(3 * X).sum(1, keepdims=True)
+    G = api.DeviceGP([1.0] + [0.4] * d, X, y, [0.01])
+    L, kiy, mean = G.get_factor()
+    K = G.mix_covariance(X) + 0.01 * np.eye(n)
+    assert np.abs(L @ L.T - K).max() <= 1e-12 * np.abs(K).max()
+    Lref = np.linalg.cholesky(K)
+    assert np.abs(np.tril(L) - Lref).max() <= 1e-11 * np.abs(Lref).max()
+    assert np.abs(K @ kiy - (y[:, 0] - mean)).max() <= 1e-8 * np.abs(y).max()

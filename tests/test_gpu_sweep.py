@@ -32,6 +32,10 @@ CASES = [
     (116, 30, 4, 2, 0, 5, 24, (), 1, 3, (1, 6, 1, 3, 0.0, 1.0, 0.1, 1e-10)),      # three of four dimensions are fidelities
     (117, 70, 3, 2, 0, 5, 30, (), 1, 0, (1, 6, 1, 3, 0.0, 1.0, 0.1, 1.0)),        # loose tolerance: the inner GD stops at once
     (118, 70, 3, 2, 0, 5, 30, (), 0, 0, (1, 6, 3, 3, 1.0, 2.5, 1.0, 1e-12)),      # big steps against the walls, 3 restarts
+    # more than four observed derivatives (r2: up to 12, the 8- and 12-slot instantiations of the workgroup-per-sample kernel)
+    (119, 40, 8, 2, 0, 5, 24, (0, 1, 2, 4, 5, 7), 1, 0, (1, 6, 1, 3, 0.0, 1.0, 0.1, 1e-10)),          # g = 6 -> 8 slots
+    (120, 30, 12, 4, 0, 6, 20, tuple(range(12)), 1, 0, (1, 6, 1, 3, 0.0, 1.0, 0.1, 1e-10)),           # g = 12: all of C5's dims
+    (121, 36, 10, 2, 1, 4, 16, (9, 0, 3, 8, 1, 6, 2, 7, 5), 0, 0, (1, 5, 1, 3, 0.0, 1.0, 0.1, 1e-10)),  # g = 9, out of order, SE
 ]
 
 
@@ -59,6 +63,8 @@ def test_kg_against_oracle(case, monkeypatch):
     ptol = 1e-8 if gd[1] * gd[2] <= 8 else 1e-6
     # both MC kernels, and the wave-per-sample kernel with the sample pre-pass off (beta / discretised-set scan in the kernel)
     for variant, prep in (("0", "1"), ("1", "1"), ("0", "0")):
+        if len(w.derivs) > 4 and variant == "0":
+            continue  # more than four derivative slots: workgroup-per-sample kernel only
         monkeypatch.setenv("MOE_KG_VARIANT", variant)
         monkeypatch.setenv("MOE_KG_PREP", prep)
         rg = G.kg(gd, w.bounds_inner, w.discrete, w.Xq, Xp, w.M, best, w.kg_normals, num_fidelity=f, want_best_points=True)
@@ -161,8 +167,8 @@ def test_limits_fail_loudly_and_ei_extremes():
         G.kg(w.inner_gd, w.bounds, w.discrete, w.Xq[:2], None, 0, 0.0, w.kg_normals)
     with pytest.raises(api.BoundsException):   # num_fidelity must leave at least one free dimension
         G.kg(w.inner_gd, w.bounds[:0], w.discrete[:, :0], w.Xq[:2], None, w.M, 0.0, w.kg_normals, num_fidelity=3)
-    with pytest.raises(api.BoundsException):   # five observed derivatives: more slots than the MC kernels carry
-        w5 = make_workload(seed=131, n=20, d=5, q=1, M=8, P=3, derivs=(0, 1, 2, 3, 4))
+    with pytest.raises(api.BoundsException):   # thirteen observed derivatives: more slots than the MC kernels carry (12)
+        w5 = make_workload(seed=131, n=20, d=13, q=1, M=8, P=3, derivs=tuple(range(13)))
         G5 = api.DeviceGP(w5.hyperparameters, w5.X, w5.y, w5.noise, w5.derivs)
         G5.kg(w5.inner_gd, w5.bounds, w5.discrete, w5.Xq, None, w5.M, 0.0, w5.kg_normals)
     for q, p, M in ((16, 0, 1), (9, 7, 3), (1, 15, 64)):
