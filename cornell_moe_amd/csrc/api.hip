@@ -250,16 +250,40 @@ int moe_posterior_mean(const moe_gp_t* gp_c, int num_fidelity, const double* poi
 }
 
 int moe_normal_draws(unsigned int seed, long long count, double* out) {
-  // mt19937 + Box-Muller (polar-free form): u1,u2 in (0,1]; z0 = sqrt(-2 ln u1) cos(2 pi u2), z1 = ... sin(...).
+  // NormalRNG (gpp_random.hpp:204-303) = boost::mt19937 + boost::normal_distribution<double>.  The engine is bit-identical to
+  // std::mt19937; the normal algorithm is Boost-version dependent and the reference pins no draws.  What IS
+  // reproduced, draw for draw, is the reference as it builds in this repository (oracle/_ref: std-backed Boost shim, i.e.
+  // libstdc++'s std::normal_distribution -- Marsaglia's polar method on two generate_canonical<double, 53> uniforms, the
+  // second variate saved for the next call); tests/test_oracle.py pins this stream to oracle/_ref's NormalRNG.  Written out
+  // here so that the stream does not depend on the C++ library this file is compiled against.
+  if (count > 0 && out == nullptr) return MOE_ERR_RUNTIME;
   std::mt19937 eng(seed);
-  const double two_pi = 6.283185307179586476925286766559;
-  long long i = 0;
-  while (i < count) {
-    const double u1 = (static_cast<double>(eng()) + 1.0) / 4294967296.0;
-    const double u2 = (static_cast<double>(eng()) + 1.0) / 4294967296.0;
-    const double r = std::sqrt(-2.0 * std::log(u1));
-    out[i++] = r * std::cos(two_pi * u2);
-    if (i < count) out[i++] = r * std::sin(two_pi * u2);
+  auto canonical = [&eng]() {
+    // std::generate_canonical<double, 53>(mt19937): two 32-bit words, sum and scaling in double, as libstdc++ evaluates them
+    double sum = static_cast<double>(eng());
+    sum += static_cast<double>(eng()) * 4294967296.0;
+    double ret = sum / 18446744073709551616.0;
+    if (ret >= 1.0) ret = std::nextafter(1.0, 0.0);
+    return ret;
+  };
+  bool saved_available = false;
+  double saved = 0.0;
+  for (long long i = 0; i < count; ++i) {
+    if (saved_available) {
+      saved_available = false;
+      out[i] = saved;
+      continue;
+    }
+    double x, y, r2;
+    do {
+      x = 2.0 * canonical() - 1.0;
+      y = 2.0 * canonical() - 1.0;
+      r2 = x * x + y * y;
+    } while (r2 > 1.0 || r2 == 0.0);
+    const double mult = std::sqrt(-2.0 * std::log(r2) / r2);
+    saved = x * mult;
+    saved_available = true;
+    out[i] = y * mult;
   }
   return MOE_OK;
 }

@@ -113,9 +113,13 @@ int moe_posterior_mean(const moe_gp_t* gp, int num_fidelity, const double* point
                        moe_error_t* err);
 
 /* ---- normal draws ----
- * Fills out[count] with N(0,1) draws from mt19937(seed) + Box-Muller, the host-side stand-in for NormalRNG
- * (gpp_random.hpp:204-303).  boost::normal_distribution's draw algorithm is Boost-version dependent and the reference
- * pins no draws, so draw-for-draw parity with a given Boost is NOT claimed; parity runs pass explicit tables. */
+ * Fills out[count] with N(0,1) draws: the host-side stand-in for NormalRNG(seed) (gpp_random.hpp:204-303 = boost::mt19937 +
+ * boost::normal_distribution).  The engine is bit-identical to std::mt19937; boost::normal_distribution's algorithm is
+ * Boost-version dependent and the reference pins no draws, so parity with an arbitrary Boost is NOT claimed.
+ * The stream IS, draw for draw, that of the reference as it builds in this repository (oracle/_ref, Boost shimmed onto the
+ * C++ standard library: Marsaglia's polar method over generate_canonical<double, 53>) -- pinned by tests/test_oracle.py and
+ * the committed fixture tests/golden/ref_normal_stream.npz -- so a seeded RandomnessSourceContainer run reproduces that
+ * build's results; cross-implementation parity runs still pass explicit tables. */
 int moe_normal_draws(unsigned int seed, long long count, double* out);
 
 /* ---- q,p-EI by Monte Carlo: compute_expected_improvement / compute_grad_expected_improvement

@@ -66,6 +66,8 @@ def lib():
                                            C.c_int, C.c_int, C.c_double, C.c_uint, C.POINTER(C.c_int), _dp]
         _lib.ref_kg_mcmc_multistart.argtypes = [C.c_void_p, C.c_int, _dp, _dp, _dp, _dp, _dp, C.c_int, _dp, C.c_int, _dp, C.c_int,
                                                 C.c_int, C.c_int, _dp, C.c_uint, C.POINTER(C.c_int), _dp]
+        _lib.ref_kg_seeded.argtypes = [C.c_void_p, C.c_int, _dp, _dp, _dp, C.c_int, _dp, _dp, C.c_int, C.c_int, C.c_int, C.c_double,
+                                       C.c_uint, _dp]
         _lib.ref_kg_grad_batch.argtypes = [C.c_void_p, C.c_int, _dp, _dp, _dp, C.c_int, _dp, C.c_int, C.c_int, C.c_int,
                                            C.c_double, _dp, C.c_long, C.c_int, _dp, _dp, _dp]
     return _lib
@@ -305,6 +307,24 @@ class RefGP(object):
                                        starts.ctypes.data_as(_dp), S, pp, q, p, M, best_so_far, seed, C.byref(found),
                                        best.ctypes.data_as(_dp)))
         return best.reshape(q, self.d), bool(found.value)
+
+    def kg_seeded(self, gd, bounds, discrete, Xq, Xp, M, best_so_far, seed, num_fidelity=0):
+        """ComputeKnowledgeGradient on a fresh state drawing from NormalRNG(seed) -- the route the reference's Python entry
+        points take (gpp_python_knowledge_gradient.cpp:74-154) -- instead of an injected table."""
+        gd, gdp = _d(gd)
+        bounds, bp = _d(bounds)
+        discrete, dp = _d(discrete)
+        P = discrete.reshape(-1, self.d - num_fidelity).shape[0]
+        Xq, qp = _d(Xq)
+        q = Xq.reshape(-1, self.d).shape[0]
+        if Xp is None or len(Xp) == 0:
+            p, pp = 0, None
+        else:
+            Xp_, pp = _d(Xp)
+            p = Xp_.reshape(-1, self.d).shape[0]
+        kg = C.c_double(0.0)
+        _check(lib().ref_kg_seeded(self.h, num_fidelity, gdp, bp, dp, P, qp, pp, q, p, M, best_so_far, int(seed), C.byref(kg)))
+        return kg.value
 
     def kg_grad_batch(self, gd, bounds, discrete, Xq_all, M, best_so_far, normals, num_threads, num_fidelity=0):
         gd, gdp = _d(gd)

@@ -11,7 +11,7 @@ tail -5 gpurun_out/bench.err
 export TMPDIR=/tmp
 cd /tmp
 rm -rf $R/gpurun_out/prof $R/gpurun_out/hbm
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof -o kg -- python $R/bench.py --steps 30 --warmup 10 --no-cpu-baseline > $R/gpurun_out/prof_bench.json 2> $R/gpurun_out/prof.err
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof -o kg -- python $R/bench.py --steps 30 --warmup 10 --no-cpu-baseline --no-batch1 --no-traffic > $R/gpurun_out/prof_bench.json 2> $R/gpurun_out/prof.err
 # HBM traffic: FETCH_SIZE and WRITE_SIZE in their own passes (MI355X_MICROARCH.md: TCC slots; FETCH_SIZE reads 1/2 on gfx950)
 timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/hbm/fetch -o p -- python $R/tools/prof_kg.py C3 8 2 > /dev/null 2>&1
 timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/hbm/write -o p -- python $R/tools/prof_kg.py C3 8 2 > /dev/null 2>&1

@@ -256,7 +256,10 @@ def kg_multistart_fixtures():
         # frozen-head one, see oracle/moe_oracle.c: orc_kg_head)
         kb = gp.kg(inner, c["bounds"][: 2 * (d - f)], c["discrete"], best, Xp, M, c["best_so_far"], c["normals"], want_grad=False,
                    num_fidelity=f)["kg"]
-        o = dict(best_point=best, found=np.array(int(found)), best_kg_fresh=np.array(kb))
+        # the seeded route of the single-evaluation entry points: KG at the first three starts from NormalRNG(seed) itself
+        ks = [gp.kg_seeded(inner, c["bounds"][: 2 * (d - f)], c["discrete"], c["starts"][i], Xp, M, c["best_so_far"], c["rng_seed"],
+                           num_fidelity=f) for i in range(3)]
+        o = dict(best_point=best, found=np.array(int(found)), best_kg_fresh=np.array(kb), seeded_kg=np.array(ks))
         print("kg multistart case %d: n=%d d=%d q=%d p=%d g=%d f=%d  KG(best point, fresh state)=%.12g found=%d" % (
             k, n, d, q, p, g, f, kb, found))
         for key, val in c.items():
@@ -265,6 +268,9 @@ def kg_multistart_fixtures():
             blob["k%d_out_%s" % (k, key)] = np.asarray(val)
         k += 1
     blob["num"] = np.array(k)
+    # the reference build's NormalRNG stream itself (pins moe_normal_draws)
+    blob["stream_seeds"] = np.array([0, 7, 314, 2718, 123456789])
+    blob["stream_draws"] = np.array([ref.normal_draws(int(sd), 2001) for sd in blob["stream_seeds"]])
     # MCMC twin: without and with a fidelity dimension (cost and its gradient live), q = 2
     for mi, (seed, n, d, q, p, P, M, nm, f, outer) in enumerate((
             (6201, 30, 3, 2, 0, 6, 32, 3, 0, (24, 5, 2, 4, 0.7, 0.1, 0.2, 1e-7)),
