@@ -109,7 +109,8 @@ constexpr int kDirSlices = 32;  // sample ranges of kg_dir_kernel
 // re-reading W from L2 for every sample (N m 8 bytes each) made this the slowest kernel of the tail.
 constexpr int kSwChunk = 64;  // samples per workgroup (16 per wavefront); 16 when the batch is too small to fill the chip
 
-template <int DP, int MU>
+// SLOTS = 2: components lane and lane + 64 (m up to 128; S_W always precomputed there).
+template <int DP, int MU, int SLOTS = 1>
 __global__ __launch_bounds__(256) void kg_sw_kernel(KgTailParams P) {
   extern __shared__ __attribute__((aligned(16))) double Ws[];  // [m][N] when P.SW == nullptr
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -125,9 +126,13 @@ __global__ __launch_bounds__(256) void kg_sw_kernel(KgTailParams P) {
   const int i1 = min(P.num_local, (int)(blockIdx.x + 1) * P.sw_chunk);
   for (int i = blockIdx.x * P.sw_chunk + wave; i < i1; i += 4) {
     const long w = (long)e * P.num_local + i;
-    double mine = 0.0;
+    double mine[SLOTS];
+#pragma unroll
+    for (int sl = 0; sl < SLOTS; ++sl) mine[sl] = 0.0;
     if (P.SW != nullptr) {
-      if (lane < m) mine = P.SW[w * m + lane];
+#pragma unroll
+      for (int sl = 0; sl < SLOTS; ++sl)
+        if (lane + 64 * sl < m) mine[sl] = P.SW[w * m + lane + 64 * sl];
     } else {
       const double* Tc = P.T + w * N;
       double acc[MU];
@@ -143,41 +148,52 @@ __global__ __launch_bounds__(256) void kg_sw_kernel(KgTailParams P) {
 #pragma unroll
       for (int c = 0; c < MU; ++c) {
         const double v = wave_sum64(acc[c]);
-        if (lane == c) mine = v;
+        if (lane == c) mine[0] = v;
       }
     }
-    double R = 0.0;
-    if (lane < m) {
-      const int r = lane / g1, b = lane - r * g1;
-      const double* Xu = rec + P.rec.XuP + (long)r * DP;
-      const double* xs = P.best_point + w * DP;
-      double diff[DP];
-      double r2 = 0.0;
+    double R[SLOTS], cv[SLOTS];
 #pragma unroll
-      for (int k = 0; k < DP; ++k) {
-        diff[k] = Xu[k] - xs[k];
-        r2 = fma(diff[k] * diff[k], P.cp.inv_l2[k], r2);
+    for (int sl = 0; sl < SLOTS; ++sl) {
+      R[sl] = 0.0;
+      cv[sl] = 0.0;
+      const int comp = lane + 64 * sl;
+      if (comp < m) {
+        const int r = comp / g1, b = comp - r * g1;
+        const double* Xu = rec + P.rec.XuP + (long)r * DP;
+        const double* xs = P.best_point + w * DP;
+        double diff[DP];
+        double r2 = 0.0;
+#pragma unroll
+        for (int k = 0; k < DP; ++k) {
+          diff[k] = Xu[k] - xs[k];
+          r2 = fma(diff[k] * diff[k], P.cp.inv_l2[k], r2);
+        }
+        const Radial rd = radial_scalars(P.cp.type, P.cp.alpha, r2);
+        DerivList none;
+        none.g = 0;
+        R[sl] = cov_entry<DP>(P.cp, rd, diff, b, 0, P.derivs, none) - mine[sl];
       }
-      const Radial rd = radial_scalars(P.cp.type, P.cp.alpha, r2);
-      DerivList none;
-      none.g = 0;
-      R = cov_entry<DP>(P.cp, rd, diff, b, 0, P.derivs, none) - mine;
     }
-    double cv = 0.0;
     for (int r = 0; r < m; ++r) {
       double part = 0.0;
-      if (lane < r) part = Lsm[r + lane * m] * cv;
+#pragma unroll
+      for (int sl = 0; sl < SLOTS; ++sl)
+        if (lane + 64 * sl < r) part = fma(Lsm[r + (long)(lane + 64 * sl) * m], cv[sl], part);
       const double tot = wave_sum64(part);
-      if (lane == r) cv = (R - tot) / Lsm[r + r * m];
+#pragma unroll
+      for (int sl = 0; sl < SLOTS; ++sl)
+        if (lane + 64 * sl == r) cv[sl] = (R[sl] - tot) / Lsm[r + (long)r * m];
     }
-    if (lane < m) P.C[w * m + lane] = cv;
+#pragma unroll
+    for (int sl = 0; sl < SLOTS; ++sl)
+      if (lane + 64 * sl < m) P.C[w * m + lane + 64 * sl] = cv[sl];
   }
 }
 
 // TBpart[e][chunk][c][row] = sum over the chunk's samples of T[row, i] beta_i[c]   (thread = row; T read coalesced, the
 // beta row is wave-uniform).
 template <int MU>
-__global__ __launch_bounds__(256) void kg_tb_kernel(KgTailParams P) {
+__global__ __launch_bounds__(256) void kg_tb_kernel(KgTailParams P, int c_lo = 0) {  // columns [c_lo, c_lo + MU) of beta / TB
   const int row = blockIdx.x * 256 + threadIdx.x;
   const int chunk = blockIdx.y, e = blockIdx.z;
   const int m = P.m;
@@ -192,7 +208,7 @@ __global__ __launch_bounds__(256) void kg_tb_kernel(KgTailParams P) {
   for (int i = i0; i < i1; ++i) {
     const long w = (long)e * P.num_local + i;
     const double t = Tcol[w * P.N];
-    const double* __restrict__ b = beta + w * m;
+    const double* __restrict__ b = beta + w * m + c_lo;
     // all MU entries unconditionally (uniform, contiguous: wide scalar loads, no branch per entry); the entries beyond m
     // belong to the next sample / the pad behind the buffer and only feed accumulators that are never stored
 #pragma unroll
@@ -202,7 +218,7 @@ __global__ __launch_bounds__(256) void kg_tb_kernel(KgTailParams P) {
     double* dst = P.TBpart + ((long)e * P.chunks + chunk) * m * P.N;
 #pragma unroll
     for (int c = 0; c < MU; ++c)
-      if (c < m) dst[(long)c * P.N + row] = acc[c];
+      if (c_lo + c < m) dst[(long)(c_lo + c) * P.N + row] = acc[c];
   }
 }
 
@@ -350,8 +366,13 @@ void launch_sw_dp(const KgTailParams& P, hipStream_t s) {
     launch_sw_inst<DP, 16>(P, s);
   else if (P.m <= 32)
     launch_sw_inst<DP, 32>(P, s);
-  else
+  else if (P.m <= 64)
     launch_sw_inst<DP, 64>(P, s);
+  else {  // two components per lane; S_W comes precomputed (the host always forms it by GEMM for m > 8)
+    if (P.SW == nullptr) throw Error(MOE_ERR_RUNTIME, "m > 64 needs the precomputed W^T T");
+    dim3 grid((P.num_local + P.sw_chunk - 1) / P.sw_chunk, P.E);
+    hipLaunchKernelGGL((kg_sw_kernel<DP, 1, 2>), grid, dim3(256), 0, s, P);
+  }
   launch_dir<DP>(P, s);
 }
 
@@ -365,15 +386,16 @@ void launch_tail(const KgTailParams& P, hipStream_t s) {
   }
   dim3 gtb((P.N + 255) / 256, P.chunks, P.E);
   if (P.m <= 4)
-    hipLaunchKernelGGL((kg_tb_kernel<4>), gtb, dim3(256), 0, s, P);
+    hipLaunchKernelGGL((kg_tb_kernel<4>), gtb, dim3(256), 0, s, P, 0);
   else if (P.m <= 8)
-    hipLaunchKernelGGL((kg_tb_kernel<8>), gtb, dim3(256), 0, s, P);
+    hipLaunchKernelGGL((kg_tb_kernel<8>), gtb, dim3(256), 0, s, P, 0);
   else if (P.m <= 16)
-    hipLaunchKernelGGL((kg_tb_kernel<16>), gtb, dim3(256), 0, s, P);
+    hipLaunchKernelGGL((kg_tb_kernel<16>), gtb, dim3(256), 0, s, P, 0);
   else if (P.m <= 32)
-    hipLaunchKernelGGL((kg_tb_kernel<32>), gtb, dim3(256), 0, s, P);
-  else
-    hipLaunchKernelGGL((kg_tb_kernel<64>), gtb, dim3(256), 0, s, P);
+    hipLaunchKernelGGL((kg_tb_kernel<32>), gtb, dim3(256), 0, s, P, 0);
+  else {
+    for (int c_lo = 0; c_lo < P.m; c_lo += 64) hipLaunchKernelGGL((kg_tb_kernel<64>), gtb, dim3(256), 0, s, P, c_lo);
+  }
   launch_gtb(P, s);
   MOE_HIP_CHECK(hipGetLastError());
 }
@@ -630,6 +652,41 @@ __global__ __launch_bounds__(256) void kg_sample_prep_kernel(KgMcParams P, int* 
   }
 }
 
+// The same for m > 64 (more components than lanes): one THREAD per sample, serial O(m^2) back substitution and O(A m) scan
+// against operands in L2 -- a few hundred microseconds for 2 x 10^4 samples at m = 104; only the workgroup-per-sample kernel
+// consumes it.  z_i (antithetic pairs, .cpp:171-180), beta_i = L^-T z_i, first best discretised point (.cpp:436-449).
+__global__ __launch_bounds__(64) void kg_sample_prep_generic_kernel(KgMcParams P, int* __restrict__ best_j) {
+  const long idx = (long)blockIdx.x * 64 + threadIdx.x;
+  const long total = (long)P.E * P.num_local;
+  if (idx >= total) return;
+  const int e = (int)(idx / P.num_local), sl = (int)(idx % P.num_local);
+  const int m = P.m, s = P.first_sample + sl;
+  const double* rec = P.blob + (long)e * P.rec.stride;
+  const double* L = rec + P.rec.L;
+  const double sign = (s & 1) ? -1.0 : 1.0;
+  const double* zrow = P.normals + (long)(s >> 1) * m;
+  double beta[kMaxMB];
+  for (int r = m - 1; r >= 0; --r) {
+    double acc = 0.0;
+    for (int l = m - 1; l > r; --l) acc = fma(L[l + (long)r * m], beta[l], acc);
+    beta[r] = (sign * zrow[r] - acc) / L[r + (long)r * m];
+  }
+  for (int c = 0; c < m; ++c) P.beta[idx * m + c] = beta[c];
+  const double* mu_disc = rec + P.rec.mu_disc;
+  const double* C_disc = rec + P.rec.C_disc;
+  double best_f = -INFINITY;
+  int bj = 0;
+  for (int j = 0; j < P.A; ++j) {
+    double v = mu_disc[j];
+    for (int c = 0; c < m; ++c) v = fma(C_disc[(long)j * m + c], sign * zrow[c], v);
+    if (-v > best_f) {  // strict: the first best point wins
+      best_f = -v;
+      bj = j;
+    }
+  }
+  best_j[idx] = bj;
+}
+
 // Per-sample weights of the training rows for every sample, V[(e, sl)][r] = scale_a (KinvY[r] - sum_c W_e[r, c] beta[(e, sl), c])
 // (r = (j, a); scale_0 = alpha, scale_a = -alpha / l_{d_a}): what point_weights computes inside the MC kernel, same
 // operation order, hence the same bits.  Inside the workgroup-per-sample kernel that computation reads all of W_e
@@ -713,8 +770,8 @@ KgPending kg_launch(GpDev& gp, int num_fidelity, const moe_gd_params_t& gd, cons
   if (q <= 0) throw Error(MOE_ERR_BOUNDS, "num_to_sample must be positive", q, 1, 1e9);
   if (p < 0) throw Error(MOE_ERR_BOUNDS, "num_being_sampled must be non-negative", p, 0, 1e9);
   if (E <= 0) throw Error(MOE_ERR_BOUNDS, "num_evals must be positive", E, 1, 1e9);
-  if (m > kMaxM)
-    throw Error(MOE_ERR_BOUNDS, "(q + p)(1 + num_derivatives) > 64 is not supported by the device kernels", m, 1, kMaxM);
+  if (m > kMaxMB)
+    throw Error(MOE_ERR_BOUNDS, "(q + p)(1 + num_derivatives) > 128 is not supported by the device kernels", m, 1, kMaxMB);
   if (g > 12) throw Error(MOE_ERR_BOUNDS, "d-KG with more than 12 observed derivatives is not supported by the device kernels", g, 0, 12);
   if (f < 0 || f >= d) throw Error(MOE_ERR_BOUNDS, "num_fidelity out of range", f, 0, d - 1);
   if (num_mc <= 0) throw Error(MOE_ERR_BOUNDS, "num_mc must be positive", num_mc, 1, 1e12);
@@ -790,7 +847,7 @@ KgPending kg_launch(GpDev& gp, int num_fidelity, const moe_gd_params_t& gd, cons
   if (tr >= 0) num_lds_tiles = std::max(0, ntiles - bwaves * tr);
   int variant = (xlds && waves >= min_xlds_waves) ? 0 : (tr >= 0 ? 1 : 0);
   variant = env_int("MOE_KG_VARIANT", variant);
-  if (G > 4) variant = 1;  // (the wave-per-sample kernel is instantiated for up to four derivative slots)
+  if (G > 4 || m > kMaxM) variant = 1;  // (the wave-per-sample kernel: up to four derivative slots, one lane per component)
   if (variant == 1 && (tr < 0 || kg_mc_block_lds_bytes(dp, G, num_lds_tiles) > (size_t)160 * 1024))
     throw Error(MOE_ERR_RUNTIME, "point set too large for the workgroup-per-sample MC kernel");
   if (variant == 0 && waves < 1)
@@ -1073,12 +1130,16 @@ KgPending kg_launch(GpDev& gp, int num_fidelity, const moe_gd_params_t& gd, cons
   // behind the other wavefront of its SIMD (measured: no difference at C3), so it only takes the pre-pass on request
   // (MOE_KG_PREP=1; MOE_KG_PREP=0: never)
   const int prep_mode = env_int("MOE_KG_PREP", -1);
-  if (prep_mode != 0 && (variant == 1 || prep_mode == 1)) {
+  if (m > kMaxM || (prep_mode != 0 && (variant == 1 || prep_mode == 1))) {
     gp.kBestJ.reserve((size_t)E * num_local);
     mp.best_j = gp.kBestJ.p;
     const long total = (long)E * num_local;
-    const int pb = (int)std::min<long>((total + 3) / 4, (long)num_cu * 8);
-    hipLaunchKernelGGL(kg_sample_prep_kernel, dim3(pb), dim3(256), 0, s, mp, gp.kBestJ.p);
+    if (m > kMaxM) {  // more components than lanes: thread-per-sample pre-pass (mandatory there)
+      hipLaunchKernelGGL(kg_sample_prep_generic_kernel, dim3((unsigned)((total + 63) / 64)), dim3(64), 0, s, mp, gp.kBestJ.p);
+    } else {
+      const int pb = (int)std::min<long>((total + 3) / 4, (long)num_cu * 8);
+      hipLaunchKernelGGL(kg_sample_prep_kernel, dim3(pb), dim3(256), 0, s, mp, gp.kBestJ.p);
+    }
     MOE_HIP_CHECK(hipGetLastError());
   }
   if (variant == 1 && mp.best_j != nullptr) {
@@ -1089,7 +1150,7 @@ KgPending kg_launch(GpDev& gp, int num_fidelity, const moe_gd_params_t& gd, cons
     const double v_gb = 8.0 * (double)N * (double)total / 1e9;
     const double v_cap = std::getenv("MOE_KG_V_MAX_GB") ? (double)env_int("MOE_KG_V_MAX_GB", 4)
                                                         : (weight_table_gb >= 0.0 ? weight_table_gb : 4.0);
-    if (v_gb <= v_cap) {
+    if (v_gb <= v_cap && m <= kMaxM) {  // (the table kernel keeps a row of W in registers: m <= 64; beyond, weights in the kernel)
       gp.kV.reserve((size_t)N * (size_t)total);
       MOE_HIP_CHECK(hipMemsetAsync(dBeta.p + (size_t)total * m, 0, sizeof(double) * 64, s));
       mp.V = gp.kV.p;

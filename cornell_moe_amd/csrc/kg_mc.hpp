@@ -46,7 +46,9 @@ namespace moe {
 #define MOE_PROF_ADD(dst, a, b)
 #endif
 constexpr int kTicketStride = 32;  // unsigned ints between the sample-ticket counters of consecutive evaluations (128 B)
-constexpr int kMaxM = 64;  // m = (q + p)(1 + g) limit of the MC kernel (z / beta scratch per wave)
+constexpr int kMaxM = 64;   // m = (q + p)(1 + g) limit of the wave-per-sample kernel and of every "one lane per component" routine
+constexpr int kMaxMB = 128;  // limit of the workgroup-per-sample kernel (r2: q = 8 with all 12 derivatives of C5 observed is
+                             // m = 104): beta of the current sample lives at zb[kMaxMB ...), filled from the sample pre-pass
 constexpr int kExpTabLen = 64;  // 2^(j/64) table at the start of the MC kernel's LDS (fastmath.hpp exp_nonpos_tab)
 
 struct KgRec {  // offsets (doubles) of one evaluation's small operands inside the blob; identical for every evaluation
@@ -1577,7 +1579,7 @@ __device__ __forceinline__ void point_weights(const KgMcParams& P, const double*
       }
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
-        const double beta = zb[kMaxM + min(c0 + i, kMaxM - 1)];  // 0 beyond m
+        const double beta = zb[kMaxMB + min(c0 + i, kMaxMB - 1)];  // 0 beyond m
 #pragma unroll
         for (int a = 0; a < 1 + G; ++a) v[a] = fma(-l[a][i], beta, v[a]);
       }
@@ -1588,7 +1590,7 @@ __device__ __forceinline__ void point_weights(const KgMcParams& P, const double*
     double t = 0.0;
     if (a < g1) {
       t = v[a];
-      if (j >= n) t = (j < n + u) ? zb[kMaxM + (j - n) * g1 + a] : 0.0;
+      if (j >= n) t = (j < n + u) ? zb[kMaxMB + (j - n) * g1 + a] : 0.0;
       // fold alpha and, for derivative weights, the -1/l of (x - X)_{d_a} / l^2 = -diff_scaled[a] / l
       t *= (a == 0) ? P.alpha : -P.alpha * P.inv_lp[a > 0 ? a - 1 : 0];
     }
@@ -1622,7 +1624,7 @@ __device__ __forceinline__ void point_weights_pre(const KgMcParams& P, const dou
     for (int a = 0; a < 1 + G; ++a) {
       double t = 0.0;
       if (a < g1 && j < n + u) {
-        t = zb[kMaxM + (j - n) * g1 + a];
+        t = zb[kMaxMB + (j - n) * g1 + a];
         t *= (a == 0) ? P.alpha : -P.alpha * P.inv_lp[a > 0 ? a - 1 : 0];
       }
       w[a] = t;
@@ -1631,16 +1633,17 @@ __device__ __forceinline__ void point_weights_pre(const KgMcParams& P, const dou
 }
 
 // Fixed LDS words of the workgroup-per-sample kernel (doubles), before the tile data.
-constexpr int kBlockFixed = kExpTabLen + 2 * kMaxM + 2 * kMaxBlockWaves * kPartLen + 2 + kMaxBlockWaves * 4 * kMaxDimPadded;
+constexpr int kBlockFixed = kExpTabLen + 2 * kMaxMB + 2 * kMaxBlockWaves * kPartLen + 2 + kMaxBlockWaves * 4 * kMaxDimPadded;
 
 template <int DP, int G, int TR>
 __global__ __launch_bounds__(512) void kg_mc_block_kernel(KgMcParams P, int num_lds_tiles) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
-  // LDS: [32] exp table | z, beta scratch (2 kMaxM) | partial slots [2][8][kPartLen] | control words (2 doubles) |
+  // LDS: [64] exp table | z / beta scratch of draw_z_beta [0, 2 kMaxM) = [0, kMaxMB), beta of the sample [kMaxMB, 2 kMaxMB) |
+  //      partial slots [2][8][kPartLen] | control words (2 doubles) |
   //      line-search state [8][4 kMaxDimPadded] | coordinates of the LDS tiles [T_L][DP][64] | their weights [T_L][1+G][64]
   double* etab = smem;
   double* zb = smem + kExpTabLen;
-  double* part = zb + 2 * kMaxM;
+  double* part = zb + 2 * kMaxMB;
   int* ctl = reinterpret_cast<int*>(part + 2 * kMaxBlockWaves * kPartLen);  // [0] sample index, [1] best discretised point
   double* stw = part + 2 * kMaxBlockWaves * kPartLen + 2 + (threadIdx.x >> 6) * (4 * kMaxDimPadded);
   double* ldsx = smem + kBlockFixed;
@@ -1699,11 +1702,12 @@ __global__ __launch_bounds__(512) void kg_mc_block_kernel(KgMcParams P, int num_
           // beta and the discretised-set winner depend on z alone: a pre-pass computed them for every sample with the whole
           // chip (here they cost one wavefront 10 % of the sample while seven wait at the barrier)
           const long so0 = (long)e * P.num_local + sl;
-          bc = (lane < m) ? P.beta[so0 * m + lane] : 0.0;
-          zb[kMaxM + lane] = bc;
+          for (int c = lane; c < kMaxMB; c += 64) zb[kMaxMB + c] = (c < m) ? P.beta[so0 * m + c] : 0.0;
           if (lane == 0) ctl[1] = P.best_j[so0];
-        } else {
+        } else {  // (m <= 64 only: one lane per component)
           draw_z_beta(P, Lsm, s, lane, zb, zc, bc);
+          zb[kMaxMB + lane] = bc;
+          zb[kMaxMB + 64 + lane] = 0.0;
           const int bj = discrete_scan(P, rec, zb, lane);
           if (lane == 0) ctl[1] = bj;
         }
@@ -1770,7 +1774,7 @@ __global__ __launch_bounds__(512) void kg_mc_block_kernel(KgMcParams P, int num_
             if (lane == k) v = x[k];
           P.best_point[so * DP + lane] = v;
         }
-        if (lane < m) P.beta[so * m + lane] = bc;
+        if (P.best_j == nullptr && lane < m) P.beta[so * m + lane] = bc;  // (the pre-pass already stored it)
       }
     }
 #if MOE_BLOCK_PROF

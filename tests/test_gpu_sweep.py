@@ -36,6 +36,10 @@ CASES = [
     (119, 40, 8, 2, 0, 5, 24, (0, 1, 2, 4, 5, 7), 1, 0, (1, 6, 1, 3, 0.0, 1.0, 0.1, 1e-10)),          # g = 6 -> 8 slots
     (120, 30, 12, 4, 0, 6, 20, tuple(range(12)), 1, 0, (1, 6, 1, 3, 0.0, 1.0, 0.1, 1e-10)),           # g = 12: all of C5's dims
     (121, 36, 10, 2, 1, 4, 16, (9, 0, 3, 8, 1, 6, 2, 7, 5), 0, 0, (1, 5, 1, 3, 0.0, 1.0, 0.1, 1e-10)),  # g = 9, out of order, SE
+    # more components than lanes, m = (q + p)(1 + g) in (64, 128]: thread-per-sample pre-pass + workgroup-per-sample kernel
+    (122, 50, 12, 8, 0, 5, 16, tuple(range(12)), 1, 0, (1, 4, 1, 3, 0.0, 1.0, 0.1, 1e-10)),  # m = 104: q = 8, every C5 derivative
+    (123, 40, 3, 30, 2, 4, 12, (0, 1, 2), 0, 0, (1, 3, 1, 3, 0.0, 1.0, 0.1, 1e-10)),         # m = 128: the limit, with p = 2
+    (124, 70, 5, 10, 3, 6, 14, (4, 1, 0, 2), 1, 1, (1, 3, 1, 3, 0.0, 1.0, 0.1, 1e-10)),      # m = 65, one fidelity, 4 slots
 ]
 
 
@@ -63,8 +67,8 @@ def test_kg_against_oracle(case, monkeypatch):
     ptol = 1e-8 if gd[1] * gd[2] <= 8 else 1e-6
     # both MC kernels, and the wave-per-sample kernel with the sample pre-pass off (beta / discretised-set scan in the kernel)
     for variant, prep in (("0", "1"), ("1", "1"), ("0", "0")):
-        if len(w.derivs) > 4 and variant == "0":
-            continue  # more than four derivative slots: workgroup-per-sample kernel only
+        if (len(w.derivs) > 4 or (w.q + w.p) * (1 + len(w.derivs)) > 64) and variant == "0":
+            continue  # more than four derivative slots / more than 64 components: workgroup-per-sample kernel only
         monkeypatch.setenv("MOE_KG_VARIANT", variant)
         monkeypatch.setenv("MOE_KG_PREP", prep)
         rg = G.kg(gd, w.bounds_inner, w.discrete, w.Xq, Xp, w.M, best, w.kg_normals, num_fidelity=f, want_best_points=True)
@@ -157,11 +161,11 @@ def test_limits_fail_loudly_and_ei_extremes():
     from cornell_moe_amd import api
     from cornell_moe_amd.workloads import make_workload
     from oracle import orc
-    w = make_workload(seed=130, n=40, d=3, q=17, M=8, P=3, derivs=(0, 1, 2))
+    w = make_workload(seed=130, n=40, d=3, q=33, M=8, P=3, derivs=(0, 1, 2))
     G = api.DeviceGP(w.hyperparameters, w.X, w.y, w.noise, w.derivs)
-    with pytest.raises(api.BoundsException):   # m = 17 * 4 = 68 > 64
+    with pytest.raises(api.BoundsException):   # m = 33 * 4 = 132 > 128
         G.kg(w.inner_gd, w.bounds, w.discrete, w.Xq, None, w.M, 0.0, w.kg_normals)
-    with pytest.raises(api.BoundsException):   # u = 17 > 16
+    with pytest.raises(api.BoundsException):   # u = 33 > 16
         G.ei(w.Xq, None, w.M, 0.0, w.ei_normals)
     with pytest.raises(api.BoundsException):   # num_mc must be positive
         G.kg(w.inner_gd, w.bounds, w.discrete, w.Xq[:2], None, 0, 0.0, w.kg_normals)
