@@ -688,7 +688,7 @@ int moe_ll_evaluate(moe_ll_t* ll, const double* hyperparameters_all, int num_set
     if (num_sets <= 0) return;
     MOE_HIP_CHECK(hipSetDevice(ll->device));
     const int g1 = 1 + ll->g, d = ll->d, n = ll->n, N = n * g1, stride = 1 + d + g1;
-    const int dp = moe::round_up(d, 4);
+    const int dp = moe::padded_dim(d);
     if (!ll->stream) {
       MOE_HIP_CHECK(hipStreamCreate(&ll->stream));
       std::vector<double> Xp((size_t)n * dp, 0.0), yc(ll->y);

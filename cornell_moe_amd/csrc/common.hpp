@@ -83,5 +83,8 @@ struct PinnedBuf {
 };
 
 inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
+// Padded dimension the kernels are instantiated for: multiples of 4 up to 16, then 24 and 32 (padded coordinates are 0 and carry
+// inverse length 0, so they drop out of every distance and gradient).
+inline int padded_dim(int d) { return d <= 16 ? round_up(d, 4) : round_up(d, 8); }
 
 }  // namespace moe

@@ -25,7 +25,7 @@ GpDev::GpDev(const double* hyper, int cov_type, const double* X_in, const double
   if (hipGetDeviceCount(&count) != hipSuccess || count <= 0)
     throw Error(MOE_ERR_RUNTIME, "no HIP device visible: libmoe_hip has no CPU fallback");
   if (device < 0 || device >= count) throw Error(MOE_ERR_BOUNDS, "device index out of range", device, 0, count - 1);
-  dp = round_up(d, 4);
+  dp = padded_dim(d);
   N = n * (1 + g);
   cp.type = cov_type;
   cp.dim = d;
@@ -53,7 +53,7 @@ GpDev::GpDev(const double* hyper, int cov_type, const double* X_in, const double
 void fill_cov_params(CovParams& cp, int cov_type, int d, const double* hyper) {
   cp.type = cov_type;
   cp.dim = d;
-  cp.dp = round_up(d, 4);
+  cp.dp = padded_dim(d);
   cp.alpha = hyper[0];
   if (!(cp.alpha > 0.0)) throw Error(MOE_ERR_BOUNDS, "alpha must be positive", cp.alpha, 0.0, INFINITY);
   for (int k = 0; k < kMaxDimPadded; ++k) {
@@ -221,6 +221,8 @@ void GpDev::grad_log_marginal_likelihood(double* grad) {
     case 8: launch_ll_grad<8>(cp, dX.p, n, g1, dKinvY.p, dVE.p, N, dE.p, out, stream); break;
     case 12: launch_ll_grad<12>(cp, dX.p, n, g1, dKinvY.p, dVE.p, N, dE.p, out, stream); break;
     case 16: launch_ll_grad<16>(cp, dX.p, n, g1, dKinvY.p, dVE.p, N, dE.p, out, stream); break;
+    case 24: launch_ll_grad<24>(cp, dX.p, n, g1, dKinvY.p, dVE.p, N, dE.p, out, stream); break;
+    case 32: launch_ll_grad<32>(cp, dX.p, n, g1, dKinvY.p, dVE.p, N, dE.p, out, stream); break;
     default: throw Error(MOE_ERR_BOUNDS, "unsupported padded dimension", dp, 4, 16);
   }
   std::vector<double> h((size_t)(1 + dp + g1));

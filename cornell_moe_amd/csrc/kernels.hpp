@@ -13,7 +13,7 @@
 
 namespace moe {
 
-constexpr int kMaxDimPadded = 16;  // dims up to 16 (C5 has 12)
+constexpr int kMaxDimPadded = 32;  // dims up to 32 (C5 has 12); kernels are instantiated for padded_dim(d) in {4, 8, 12, 16, 24, 32}
 constexpr int kMaxDerivs = 16;
 
 struct CovParams {

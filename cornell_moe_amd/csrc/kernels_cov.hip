@@ -288,6 +288,8 @@ void launch_cov_build(const CovParams& cp, const double* A, int nA, const DerivL
     case 8: cov_build_dp<8>(cp, A, nA, dA, B, nB, dB, diag_noise, out, ld, col0, s, streaming); break;
     case 12: cov_build_dp<12>(cp, A, nA, dA, B, nB, dB, diag_noise, out, ld, col0, s, streaming); break;
     case 16: cov_build_dp<16>(cp, A, nA, dA, B, nB, dB, diag_noise, out, ld, col0, s, streaming); break;
+    case 24: cov_build_dp<24>(cp, A, nA, dA, B, nB, dB, diag_noise, out, ld, col0, s, streaming); break;
+    case 32: cov_build_dp<32>(cp, A, nA, dA, B, nB, dB, diag_noise, out, ld, col0, s, streaming); break;
     default: throw Error(MOE_ERR_RUNTIME, "unsupported padded dimension");
   }
   MOE_HIP_CHECK(hipGetLastError());
@@ -308,6 +310,8 @@ void launch_mean(const CovParams& cp, const double* X, int n, const DerivList& d
     MOE_MEAN_CASE(8)
     MOE_MEAN_CASE(12)
     MOE_MEAN_CASE(16)
+    MOE_MEAN_CASE(24)
+    MOE_MEAN_CASE(32)
     default: throw Error(MOE_ERR_RUNTIME, "unsupported padded dimension");
   }
 #undef MOE_MEAN_CASE
@@ -321,6 +325,8 @@ void launch_grad_kstar(const CovParams& cp, const double* X, int n, const DerivL
     case 8: grad_kstar_dp<8>(cp, X, n, dX, P, nP, dP, out, ld, col0, s); break;
     case 12: grad_kstar_dp<12>(cp, X, n, dX, P, nP, dP, out, ld, col0, s); break;
     case 16: grad_kstar_dp<16>(cp, X, n, dX, P, nP, dP, out, ld, col0, s); break;
+    case 24: grad_kstar_dp<24>(cp, X, n, dX, P, nP, dP, out, ld, col0, s); break;
+    case 32: grad_kstar_dp<32>(cp, X, n, dX, P, nP, dP, out, ld, col0, s); break;
     default: throw Error(MOE_ERR_RUNTIME, "unsupported padded dimension");
   }
   MOE_HIP_CHECK(hipGetLastError());

@@ -382,6 +382,8 @@ void launch_tail(const KgTailParams& P, hipStream_t s) {
     case 8: launch_sw_dp<8>(P, s); break;
     case 12: launch_sw_dp<12>(P, s); break;
     case 16: launch_sw_dp<16>(P, s); break;
+    case 24: launch_sw_dp<24>(P, s); break;
+    case 32: launch_sw_dp<32>(P, s); break;
     default: throw Error(MOE_ERR_RUNTIME, "unsupported padded dimension");
   }
   dim3 gtb((P.N + 255) / 256, P.chunks, P.E);
@@ -593,6 +595,8 @@ void launch_fused_tail(const KgTailParams& P, const double* X, int n, double* SW
     case 8: m4 ? launch_fused_tail_inst<8, 4>(P, X, n, SWpart, slices, s) : launch_fused_tail_inst<8, 8>(P, X, n, SWpart, slices, s); break;
     case 12: m4 ? launch_fused_tail_inst<12, 4>(P, X, n, SWpart, slices, s) : launch_fused_tail_inst<12, 8>(P, X, n, SWpart, slices, s); break;
     case 16: m4 ? launch_fused_tail_inst<16, 4>(P, X, n, SWpart, slices, s) : launch_fused_tail_inst<16, 8>(P, X, n, SWpart, slices, s); break;
+    case 24: m4 ? launch_fused_tail_inst<24, 4>(P, X, n, SWpart, slices, s) : launch_fused_tail_inst<24, 8>(P, X, n, SWpart, slices, s); break;
+    case 32: m4 ? launch_fused_tail_inst<32, 4>(P, X, n, SWpart, slices, s) : launch_fused_tail_inst<32, 8>(P, X, n, SWpart, slices, s); break;
     default: throw Error(MOE_ERR_RUNTIME, "unsupported padded dimension");
   }
 }
@@ -739,6 +743,8 @@ void launch_mc(const KgMcParams& P, int dp, int G, bool xlds, int blocks, int wa
     case 8: launch_kg_mc_dp8(P, G, xlds, blocks, waves, shm, s); break;
     case 12: launch_kg_mc_dp12(P, G, xlds, blocks, waves, shm, s); break;
     case 16: launch_kg_mc_dp16(P, G, xlds, blocks, waves, shm, s); break;
+    case 24: launch_kg_mc_dp24(P, G, xlds, blocks, waves, shm, s); break;
+    case 32: launch_kg_mc_dp32(P, G, xlds, blocks, waves, shm, s); break;
     default: throw Error(MOE_ERR_RUNTIME, "unsupported padded dimension");
   }
 }
@@ -749,6 +755,8 @@ void launch_mc_block(const KgMcParams& P, int dp, int G, int tr, int num_lds_til
     case 8: launch_kg_mc_block_dp8(P, G, tr, num_lds_tiles, blocks, waves, s); break;
     case 12: launch_kg_mc_block_dp12(P, G, tr, num_lds_tiles, blocks, waves, s); break;
     case 16: launch_kg_mc_block_dp16(P, G, tr, num_lds_tiles, blocks, waves, s); break;
+    case 24: launch_kg_mc_block_dp24(P, G, tr, num_lds_tiles, blocks, waves, s); break;
+    case 32: launch_kg_mc_block_dp32(P, G, tr, num_lds_tiles, blocks, waves, s); break;
     default: throw Error(MOE_ERR_RUNTIME, "unsupported padded dimension");
   }
 }
@@ -782,7 +790,9 @@ KgPending kg_launch(GpDev& gp, int num_fidelity, const moe_gd_params_t& gd, cons
   const int A = u + P;
   // derivative-weight slots of the MC kernel instantiation: one per observed derivative up to 4, then 8 or 12 (unused slots
   // carry zero weights); more than 4 always take the workgroup-per-sample kernel
-  const int G = g <= 4 ? g : (g <= 8 ? 8 : 12);
+  // (d > 16: slot counts {0, 4, 8, 12} only -- kg_mc.hpp launch_dp_wide)
+  const bool wide_dp = dp > 16;
+  const int G = wide_dp ? (g == 0 ? 0 : (g <= 4 ? 4 : (g <= 8 ? 8 : 12))) : (g <= 4 ? g : (g <= 8 ? 8 : 12));
   const int ntiles = (n + u + 63) / 64;
   const int ngrad = want_grad ? q * g1 * d : 0;
 
@@ -813,6 +823,9 @@ KgPending kg_launch(GpDev& gp, int num_fidelity, const moe_gd_params_t& gd, cons
       rad2 += (ext * gp.cp.inv_l[k]) * (ext * gp.cp.inv_l[k]);
     }
     wide_frame = !(rad2 <= (double)env_int("MOE_KG_DOT_MAX_RADIUS2", 10000));
+    // d > 16: the coordinate table of the wave-per-sample kernel would take (dp + 1) 512 bytes per tile; that kernel is built
+    // without it there, so these shapes take the same route as a wide frame
+    if (wide_dp) wide_frame = true;
     if (wide_frame) xlds = false;
   }
   // few tiles per pass: a pass is a short dependent chain, so 16 wavefronts per workgroup (the <= 128-VGPR instantiation)
@@ -836,6 +849,7 @@ KgPending kg_launch(GpDev& gp, int num_fidelity, const moe_gd_params_t& gd, cons
   const int bwaves = 8;
   int tr = -1, num_lds_tiles = 0;
   for (int cand : {0, 2, 4}) {
+    if (wide_dp && cand != 0) break;  // (d > 16: all tiles in LDS or the streaming wave-per-sample kernel)
     const int tl = std::max(0, ntiles - bwaves * cand);
     if (kg_mc_block_lds_bytes(dp, G, tl) <= (size_t)160 * 1024) {
       tr = cand;
@@ -843,7 +857,7 @@ KgPending kg_launch(GpDev& gp, int num_fidelity, const moe_gd_params_t& gd, cons
       break;
     }
   }
-  tr = env_int("MOE_KG_TR", tr);
+  if (!wide_dp) tr = env_int("MOE_KG_TR", tr);
   if (tr >= 0) num_lds_tiles = std::max(0, ntiles - bwaves * tr);
   int variant = (xlds && waves >= min_xlds_waves) ? 0 : (tr >= 0 ? 1 : 0);
   variant = env_int("MOE_KG_VARIANT", variant);

@@ -100,6 +100,10 @@ void launch_kg_mc_dp4(const KgMcParams& P, int G, bool xlds, int blocks, int wav
 void launch_kg_mc_dp8(const KgMcParams& P, int G, bool xlds, int blocks, int waves, size_t shm, hipStream_t s);
 void launch_kg_mc_dp12(const KgMcParams& P, int G, bool xlds, int blocks, int waves, size_t shm, hipStream_t s);
 void launch_kg_mc_dp16(const KgMcParams& P, int G, bool xlds, int blocks, int waves, size_t shm, hipStream_t s);
+// padded dimensions 24 and 32 (d = 17 .. 32) are built for a reduced set: derivative slots {0, 4} (wave-per-sample kernel,
+// coordinates streamed from L2 only) and {0, 4, 8, 12} with all tiles in LDS (workgroup-per-sample kernel)
+void launch_kg_mc_dp24(const KgMcParams& P, int G, bool xlds, int blocks, int waves, size_t shm, hipStream_t s);
+void launch_kg_mc_dp32(const KgMcParams& P, int G, bool xlds, int blocks, int waves, size_t shm, hipStream_t s);
 
 // Workgroup-per-sample variant: the first `num_lds_tiles` tiles of 64 points in LDS, `tr` (0, 2 or 4) register tiles per
 // wavefront for the rest; bytes of dynamic LDS = kg_mc_block_lds_bytes(...).
@@ -107,6 +111,8 @@ void launch_kg_mc_block_dp4(const KgMcParams& P, int G, int tr, int num_lds_tile
 void launch_kg_mc_block_dp8(const KgMcParams& P, int G, int tr, int num_lds_tiles, int blocks, int waves, hipStream_t s);
 void launch_kg_mc_block_dp12(const KgMcParams& P, int G, int tr, int num_lds_tiles, int blocks, int waves, hipStream_t s);
 void launch_kg_mc_block_dp16(const KgMcParams& P, int G, int tr, int num_lds_tiles, int blocks, int waves, hipStream_t s);
+void launch_kg_mc_block_dp24(const KgMcParams& P, int G, int tr, int num_lds_tiles, int blocks, int waves, hipStream_t s);
+void launch_kg_mc_block_dp32(const KgMcParams& P, int G, int tr, int num_lds_tiles, int blocks, int waves, hipStream_t s);
 size_t kg_mc_block_lds_bytes(int dp, int G, int num_lds_tiles);
 
 #if defined(__HIPCC__)
@@ -241,7 +247,7 @@ __device__ __forceinline__ double to_frame(const KgMcParams& P, double v, int r)
 // such a pass (eval_loop), the workgroup-per-sample kernel pulls the query back to kQueryClamp per coordinate (same zeros).
 // One wave-uniform test per pass either way.
 constexpr double kTableExtent = 1.0e5;
-constexpr double kFarRadius = 4.0e5 + 400.0;  // sqrt(kMaxDimPadded) * kTableExtent + 400
+constexpr double kFarRadius = 5.657e5 + 400.0;  // sqrt(kMaxDimPadded = 32) * kTableExtent + 400
 constexpr double kQueryClamp = 1.0e6;
 template <int DP>
 __device__ __forceinline__ void clamp_query(double (&xq)[DP]) {
@@ -337,7 +343,7 @@ __device__ __forceinline__ double eval_loop(const double* __restrict__ xs, const
     }
   }
   // A trial point more than kFarRadius length scales from the centre is > 400 length scales from every tabulated point
-  // (all inside the ball of radius sqrt(16) * kTableExtent): every covariance underflows to exactly 0 and the posterior mean
+  // (all inside the ball of radius sqrt(32) * kTableExtent): every covariance underflows to exactly 0 and the posterior mean
   // IS the prior mean -- the pass is skipped.  Closer than that, sqrt(r2) * 64 / ln2 < 2^31: exp_nonpos_tab is in range.
   if (!WG && !(qq <= kFarRadius * kFarRadius)) return -mean;
   double accf = 0.0, accs = 0.0;
@@ -1284,7 +1290,7 @@ __global__ __launch_bounds__(SMALL ? 1024 : 512) void kg_mc_kernel(KgMcParams P)
 // each pass ends with one wavefront sum per wave, one LDS slot per wave, ONE __syncthreads, and a fixed-order sum of the
 // per-wave partials, so every wave takes bit-identical decisions.
 // =====================================================================================================================
-constexpr int kPartLen = 32;       // doubles per partial slot: f | DP gradient sums | G derivative sums (<= 1 + 16 + 12)
+constexpr int kPartLen = 48;       // doubles per partial slot: f | DP gradient sums | G derivative sums (<= 1 + 32 + 12)
 constexpr int kMaxBlockWaves = 8;
 
 // One point's contribution to the accumulators (shared by the LDS-tile loop and the register tiles).
@@ -1868,6 +1874,29 @@ inline void launch_dp(const KgMcParams& P, int G, bool xlds, int blocks, int wav
     case 4:
       if (xlds) launch_inst<DP, 4, true>(P, blocks, waves, shm, s); else launch_inst<DP, 4, false>(P, blocks, waves, shm, s);
       break;
+    default: throw Error(MOE_ERR_RUNTIME, "unsupported derivative-slot count in the MC kernel");
+  }
+}
+
+// The reduced instantiation sets of the wide padded dimensions (24, 32).
+template <int DP>
+inline void launch_block_dp_wide(const KgMcParams& P, int G, int tr, int num_lds_tiles, int blocks, int waves, hipStream_t s) {
+  if (tr != 0) throw Error(MOE_ERR_RUNTIME, "d > 16: the workgroup-per-sample MC kernel is built with all tiles in LDS only");
+  switch (G) {
+    case 0: launch_block_inst<DP, 0, 0>(P, num_lds_tiles, blocks, waves, s); break;
+    case 4: launch_block_inst<DP, 4, 0>(P, num_lds_tiles, blocks, waves, s); break;
+    case 8: launch_block_inst<DP, 8, 0>(P, num_lds_tiles, blocks, waves, s); break;
+    case 12: launch_block_inst<DP, 12, 0>(P, num_lds_tiles, blocks, waves, s); break;
+    default: throw Error(MOE_ERR_RUNTIME, "unsupported derivative-slot count in the MC kernel");
+  }
+}
+
+template <int DP>
+inline void launch_dp_wide(const KgMcParams& P, int G, bool xlds, int blocks, int waves, size_t shm, hipStream_t s) {
+  if (xlds || waves > 8) throw Error(MOE_ERR_RUNTIME, "d > 16: the wave-per-sample MC kernel streams coordinates from L2 only");
+  switch (G) {
+    case 0: launch_inst2<DP, 0, false, false>(P, blocks, waves, shm, s); break;
+    case 4: launch_inst2<DP, 4, false, false>(P, blocks, waves, shm, s); break;
     default: throw Error(MOE_ERR_RUNTIME, "unsupported derivative-slot count in the MC kernel");
   }
 }

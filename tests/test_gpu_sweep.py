@@ -40,6 +40,13 @@ CASES = [
     (122, 50, 12, 8, 0, 5, 16, tuple(range(12)), 1, 0, (1, 4, 1, 3, 0.0, 1.0, 0.1, 1e-10)),  # m = 104: q = 8, every C5 derivative
     (123, 40, 3, 30, 2, 4, 12, (0, 1, 2), 0, 0, (1, 3, 1, 3, 0.0, 1.0, 0.1, 1e-10)),         # m = 128: the limit, with p = 2
     (124, 70, 5, 10, 3, 6, 14, (4, 1, 0, 2), 1, 1, (1, 3, 1, 3, 0.0, 1.0, 0.1, 1e-10)),      # m = 65, one fidelity, 4 slots
+    # d = 17 .. 32 (r2): the padded-dimension 24 and 32 instantiations, derivative slots {0, 4, 8, 12}
+    (125, 60, 17, 2, 0, 5, 24, (), 1, 0, (1, 6, 1, 3, 0.0, 1.0, 0.1, 1e-10)),                  # d = 17 -> 24 rows, 7 padded
+    (126, 50, 24, 2, 1, 4, 20, (3, 20), 0, 0, (1, 5, 1, 3, 0.0, 1.0, 0.1, 1e-10)),             # d = 24, g = 2 in 4 slots, SE
+    (127, 70, 32, 3, 0, 5, 20, (), 1, 1, (1, 5, 1, 3, 0.0, 1.0, 0.1, 1e-10)),                  # d = 32: the limit, one fidelity
+    (128, 40, 29, 2, 0, 4, 16, (0, 7, 15, 22, 28, 11), 1, 0, (1, 4, 1, 3, 0.0, 1.0, 0.1, 1e-10)),  # d = 29, g = 6 in 8 slots
+    (129, 30, 20, 1, 0, 3, 12, tuple(range(12)), 0, 0, (1, 4, 1, 3, 0.0, 1.0, 0.1, 1e-10)),    # d = 20, g = 12
+    (130, 200, 18, 2, 0, 6, 16, (5,), 1, 0, (1, 4, 1, 3, 0.0, 1.0, 0.1, 1e-10)),               # d = 18, 4 tiles, g = 1
 ]
 
 
@@ -69,6 +76,8 @@ def test_kg_against_oracle(case, monkeypatch):
     for variant, prep in (("0", "1"), ("1", "1"), ("0", "0")):
         if (len(w.derivs) > 4 or (w.q + w.p) * (1 + len(w.derivs)) > 64) and variant == "0":
             continue  # more than four derivative slots / more than 64 components: workgroup-per-sample kernel only
+        if w.d > 16 and prep == "0":
+            continue  # (one wave-per-sample configuration is enough for the reduced instantiation set of d > 16)
         monkeypatch.setenv("MOE_KG_VARIANT", variant)
         monkeypatch.setenv("MOE_KG_PREP", prep)
         rg = G.kg(gd, w.bounds_inner, w.discrete, w.Xq, Xp, w.M, best, w.kg_normals, num_fidelity=f, want_best_points=True)
@@ -115,6 +124,42 @@ def test_many_evaluations_per_batch(monkeypatch):
     whole = G2.kg_batch(w2.inner_gd, w2.bounds, w2.discrete, w2.Xq_restarts, None, w2.M, best2, w2.kg_normals)
     assert np.array_equal(pieces["kg_sum"], whole["kg_sum"]) and np.array_equal(pieces["grad_sum"], whole["grad_sum"])
     assert pieces["mean_evals"] == whole["mean_evals"] and pieces["grad_evals"] == whole["grad_evals"]
+
+
+def test_wide_dimensions_gp_posterior_and_likelihood():
+    """d = 17 .. 32 outside the KG kernels: posterior mean / variance and their gradients, q,p-EI, the log likelihood and its
+    hyper-parameter gradient, against the oracle."""
+    from cornell_moe_amd import api
+    from oracle import orc
+    rng = np.random.default_rng(77)
+    for d, derivs, cov in ((17, (), 1), (24, (2, 19), 0), (32, (31,), 1), (27, (), 0)):
+        n, g = 45, len(derivs)
+        X = rng.uniform(size=(n, d))
+        y = rng.normal(size=(n, 1 + g))
+        lengths = rng.uniform(1.0, 2.5, size=d)
+        noise = np.full(1 + g, 0.03)
+        O = orc.OrcGP(cov, 1.3, lengths, X, y, noise, derivs)
+        G = api.DeviceGP(np.r_[1.3, lengths], X, y, noise, derivs, cov_type=cov)
+        pts = rng.uniform(size=(4, d))
+        assert np.abs(G.mean(pts) - O.mean(pts)).max() <= 1e-10
+        assert np.abs(G.grad_mean(pts) - O.grad_mean(pts)).max() <= 1e-9
+        assert np.abs(G.variance(pts) - O.var(pts)).max() <= 1e-10
+        assert np.abs(G.grad_cholesky_variance(pts, 2) - O.grad_chol_var(pts, 2)).max() <= 1e-8
+        Mei = 40
+        zn = rng.normal(size=(Mei, 4))
+        eo, go = O.ei(pts[:3], pts[3:], Mei, float(np.median(y[:, 0])), zn)
+        eg, gg = G.ei(pts[:3], pts[3:], Mei, float(np.median(y[:, 0])), zn)
+        assert abs(eo - eg) <= TOL["ei"] * max(abs(eo), 1e-3)
+        assert np.abs(gg - go).max() <= TOL["grad_ei"] * max(np.abs(go).max(), 1e-3)
+        th = np.r_[1.3, lengths, noise]
+        LL = api.LogLikelihood(X, y, derivs, cov_type=cov)
+        vo = orc.log_likelihood(cov, th[0], lengths, X, y, noise, derivs)
+        assert abs(LL.evaluate(th[None, :])[0] - vo) <= 1e-10 * max(1.0, abs(vo))
+        if cov == 1 or g == 0:  # (the oracle restates the squared-exponential hyper-parameter gradient for g = 0 only)
+            go = orc.log_likelihood_grad(cov, th[0], lengths, X, y, noise, derivs)
+            assert np.abs(LL.grad(th) - go).max() <= 1e-8 * max(1.0, np.abs(go).max())
+    with pytest.raises(api.BoundsException):  # d = 33
+        api.DeviceGP(np.r_[1.0, np.ones(33)], rng.uniform(size=(5, 33)), rng.normal(size=(5, 1)), [0.1])
 
 
 def test_ei_against_oracle_sweep():
