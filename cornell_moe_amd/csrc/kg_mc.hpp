@@ -469,6 +469,85 @@ __device__ __forceinline__ double eval_pass(const double* __restrict__ xs, const
                                                                                  scr);
 }
 
+// T Armijo trial points x' + alpha_t g s^2, alpha_t = alpha0 / 2^t, in ONE sweep over the tiles (no derivative observations, LDS
+// table).  With x2 = -2 x' and d2 = -2 g s^2 (line_search_frame) the trial's q2 is x2 + alpha_t d2, so
+//   r2_t = |x_j|^2 + |q_t|^2 + x_j . q2_t = (|x_j|^2 + x_j . x2) + alpha_t (x_j . d2) + |q_t|^2:
+// the two projections p0, p1 are formed once per point (2 DP fmas) and every trial costs an add, an fma and a max on top of
+// its square root / exp / polynomial -- (2 DP + 1) / T + 3 instructions per point for r2 instead of DP + 2, and one set of
+// coordinate / weight loads, one reduction round and one decision round per T trials.  |q_t|^2 = (|x2|^2 + 2 alpha_t x2.d2 +
+// alpha_t^2 |d2|^2) / 4 (wave-uniform).  Returns false without evaluating when a trial lies beyond kFarRadius (see eval_loop;
+// |q(alpha)|^2 is convex in alpha, so the two ends of the bracket bound all trials).
+template <int DP, int COV, int T, bool SMALL>
+__device__ __forceinline__ bool eval_multi_loop(const double* __restrict__ xs, const double* __restrict__ aw,
+                                                const double* __restrict__ etab, int ntiles, double mean, const double (&x2)[DP],
+                                                const double (&d2)[DP], double alpha0, int lane, double (&f)[T]) {
+  double sxx = 0.0, sxd = 0.0, sdd = 0.0;
+#pragma unroll
+  for (int k = 0; k < DP; ++k) {
+    sxx = fma(x2[k], x2[k], sxx);
+    sxd = fma(x2[k], d2[k], sxd);
+    sdd = fma(d2[k], d2[k], sdd);
+  }
+  double al[T], qq[T];
+#pragma unroll
+  for (int t = 0; t < T; ++t) {
+    al[t] = (t == 0) ? alpha0 : 0.5 * al[t > 0 ? t - 1 : 0];
+    qq[t] = fma(0.25, fma(al[t], fma(al[t], sdd, 2.0 * sxd), sxx), 1.0e-300);
+  }
+  if (!(uniform(fmax(qq[0], 0.25 * sxx)) <= kFarRadius * kFarRadius)) return false;
+  double acc[T];
+#pragma unroll
+  for (int t = 0; t < T; ++t) acc[t] = 0.0;
+  lds_tile_ptr xt = (lds_tile_ptr)(xs + lane);
+  lds_tile_ptr wt = (lds_tile_ptr)(aw + lane);
+  double cx[DP + 1], cw;
+#pragma unroll
+  for (int k = 0; k < DP + 1; ++k) cx[k] = xt[k * 64];
+  cw = wt[0];
+#pragma unroll(SMALL ? 1 : 2)
+  for (int tile = 0; tile < ntiles; ++tile) {
+    double nx[DP + 1], nw;
+    xt += (DP + 1) * 64;  // (one tile of padding behind both arrays: see eval_loop)
+    wt += 64;
+#pragma unroll
+    for (int k = 0; k < DP + 1; ++k) nx[k] = xt[k * 64];
+    nw = wt[0];
+    double p0 = cx[DP];
+#pragma unroll
+    for (int k = 0; k < DP; ++k) p0 = fma(cx[k], x2[k], p0);
+    double p1 = cx[0] * d2[0];
+#pragma unroll
+    for (int k = 1; k < DP; ++k) p1 = fma(cx[k], d2[k], p1);
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+      const double r2 = fmax(fma(al[t], p1, p0 + qq[t]), 1.0e-300);
+      double base, first, second;
+      radial3<COV, false, false>(r2, etab, base, first, second);
+      acc[t] = fma(cw, base, acc[t]);
+    }
+#pragma unroll
+    for (int k = 0; k < DP + 1; ++k) cx[k] = nx[k];
+    cw = nw;
+  }
+  // T wave sums, folded four / two at a time (packed reductions above)
+  double sum[T];
+  constexpr int T4 = T / 4 * 4;
+#pragma unroll
+  for (int t = 0; t < T4; t += 4) {
+    double o[4];
+    wave_sum4_uniform(acc[t], acc[t + 1], acc[t + 2], acc[t + 3], o);
+    sum[t] = o[0];
+    sum[t + 1] = o[1];
+    sum[t + 2] = o[2];
+    sum[t + 3] = o[3];
+  }
+  if constexpr (T - T4 >= 2) wave_sum2_uniform(acc[T4], acc[T4 + 1], sum[T4], sum[T4 + 1]);
+  if constexpr (((T - T4) & 1) != 0) sum[T - 1] = wave_sum_uniform(acc[T - 1]);
+#pragma unroll
+  for (int t = 0; t < T; ++t) f[t] = -(mean + sum[t]);
+  return true;
+}
+
 // TensorProductDomain::LimitUpdate (gpp_domain.cpp:64-105) on one coordinate.
 __device__ __forceinline__ double limit_update_1d(double lo, double hi, double max_relative_change, double x, double desired) {
   double dist = fmin(x - lo, hi - x);
@@ -562,6 +641,61 @@ struct WaveEval {
     n_g++;
 #endif
     return f;
+  }
+  // up to kMaxTrials Armijo trials alpha / 2^t in one pass (eval_multi_loop): q-KG on the LDS table only
+  static constexpr int kMaxTrials = (XL && G == 0 && !SMALL) ? 5 : 1;
+  // T trials and the reference's sequence of decisions over them (gpp_optimization.hpp:752-769), with compile-time indices
+  // (a runtime-sized result array would live in scratch memory): stops at the first accepted trial (done), halves alpha and
+  // counts `search` for every rejected one, counts consumed trials only.  Returns false (nothing evaluated, nothing changed)
+  // when a trial lies beyond the far radius.
+  template <int T>
+  __device__ __forceinline__ bool armijo_t(const double (&x2)[DP], const double (&d2)[DP], double f0, double norm, double& alpha_n,
+                                           int& search, double& ftrial, bool& done, unsigned long long& n_val) {
+    double f[T];
+    const bool ok = (cov_type == MOE_COV_SQUARE_EXPONENTIAL)
+                        ? eval_multi_loop<DP, MOE_COV_SQUARE_EXPONENTIAL, T, SMALL>(xs, aw, etab, ntiles, mean, x2, d2, alpha_n, lane, f)
+                        : eval_multi_loop<DP, MOE_COV_MATERN_NU_2P5, T, SMALL>(xs, aw, etab, ntiles, mean, x2, d2, alpha_n, lane, f);
+    if (!ok) return false;
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+      if (!done) {
+        ftrial = f[t];
+        n_val++;
+#if MOE_BLOCK_PROF
+        n_v++;
+#endif
+        if (ftrial - f0 > 0.5 * alpha_n * norm) {
+          done = true;
+        } else {
+          alpha_n *= 0.5;
+          if (++search >= 30) done = true;
+        }
+      }
+    }
+    return true;
+  }
+  // one pass over min(want, kMaxTrials) >= 2 trials
+  __device__ __forceinline__ bool armijo_batch(int want, const double (&x2)[DP], const double (&d2)[DP], double f0, double norm,
+                                               double& alpha_n, int& search, double& ftrial, bool& done,
+                                               unsigned long long& n_val) {
+    if constexpr (kMaxTrials >= 5) {
+#if MOE_BLOCK_PROF
+      const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+#endif
+      bool ok;
+      switch (want) {
+        case 2: ok = armijo_t<2>(x2, d2, f0, norm, alpha_n, search, ftrial, done, n_val); break;
+        case 3: ok = armijo_t<3>(x2, d2, f0, norm, alpha_n, search, ftrial, done, n_val); break;
+        case 4: ok = armijo_t<4>(x2, d2, f0, norm, alpha_n, search, ftrial, done, n_val); break;
+        default: ok = armijo_t<5>(x2, d2, f0, norm, alpha_n, search, ftrial, done, n_val); break;
+      }
+#if MOE_BLOCK_PROF
+      c_v += __builtin_amdgcn_s_memtime() - t0;
+#endif
+      return ok;
+    } else {
+      return false;
+    }
   }
   __device__ __forceinline__ double eval_value_q2(const double (&q2)[DP]) {
     double unused[DP];
@@ -772,6 +906,7 @@ __device__ __forceinline__ double line_search_frame(const KgMcParams& P, const d
   // it replaced, so the device counters never exceed what was computed.
   bool have_g = false;
   double f_carried = 0.0;
+  int pred = 1;  // Armijo trials the previous step consumed (how many the next step evaluates in its first pass)
   for (int restart = 0; restart < max_num_restarts; ++restart) {
 #pragma unroll
     for (int k = 0; k < DP; ++k) S[k] = xf[k];  // the restart's starting point (every lane writes the same value)
@@ -800,17 +935,37 @@ __device__ __forceinline__ double line_search_frame(const KgMcParams& P, const d
       // pre_mult * (i+1)^-gamma (gpp_optimization.hpp:741); x^-0 == 1 exactly, so gamma == 0 needs no pow()
       double alpha_n = (P.gamma == 0.0) ? P.pre_mult : P.pre_mult * pow((double)(istep + 1), -P.gamma);
       // ---- Armijo back-tracking (.hpp:745-760): unclamped trial points ----
+      // The trial step sizes alpha, alpha / 2, alpha / 4, ... are known in advance, so several of them can be evaluated in
+      // one pass (EV::eval_value_multi, where the evaluator has it): as many as the previous step of THIS sample consumed
+      // (the first step of a sample starts with one; a sample's results therefore depend on nothing but the sample), then
+      // in pairs.  The sequence of decisions is the reference's; only consumed trials are counted.
       int search = 0;
-      double ftrial;
-      while (true) {
-        double q2[DP];
+      double ftrial = 0.0;
+      {
+        int batch = pred;
+        bool done = false;
+        while (!done) {
+          bool evaluated = false;
+          if (EV::kMaxTrials >= 2) {
+            const int want = min(batch, 30 - search);
+            if (want >= 2) evaluated = ev.armijo_batch(want, x2, d2, f0, norm, alpha_n, search, ftrial, done, n_val);
+          }
+          if (!evaluated) {
+            double q2[DP];
 #pragma unroll
-        for (int k = 0; k < DP; ++k) q2[k] = fma(alpha_n, d2[k], x2[k]);
-        ftrial = ev.eval_value_q2(q2);
-        n_val++;
-        if (ftrial - f0 > 0.5 * alpha_n * norm) break;
-        alpha_n *= 0.5;
-        if (++search >= 30) break;
+            for (int k = 0; k < DP; ++k) q2[k] = fma(alpha_n, d2[k], x2[k]);
+            ftrial = ev.eval_value_q2(q2);
+            n_val++;
+            if (ftrial - f0 > 0.5 * alpha_n * norm) {
+              done = true;
+            } else {
+              alpha_n *= 0.5;
+              if (++search >= 30) done = true;
+            }
+          }
+          batch = 2;
+        }
+        pred = min(search + 1, EV::kMaxTrials);
       }
       // ---- LimitUpdate in the frame, one coordinate per lane, then accept only if f improves (.hpp:762-795) ----
       bool changed, nonzero;

@@ -66,10 +66,14 @@ def main():
         f64 = sum(v for k, v in c.items() if k.startswith("v_") and "_f64" in k)
         lds = sum(v for k, v in c.items() if k.startswith("ds_"))
         kind = ("Matern" if rsq else "sq.exp.") + (" value+gradient" if c.get("v_add_f64", 0) >= 8 * tiles else " value")
+        # multi-trial value loops (eval_multi_loop): T Armijo trials share one set of coordinate loads -- fewer than 9 LDS reads per
+        # covariance evaluation; 'tiles' then counts tile x trial pairs
+        if "gradient" not in kind and lds < 9 * tiles:
+            kind += " x T trials"
         print("%-34s %6d %6d %6d %6d %6d %6d   %28.2f %5.2f %8.2f %5.2f" % (
             "%s (asm lines %d-%d)" % (kind, a + start, b + start), tiles, len(seg), valu, f64, rsq, lds, valu / tiles, f64 / tiles,
             (valu - f64) / tiles, lds / tiles))
-    print("\n(one VALU instruction processes 64 points: 'per tile' = per point and pass.  SURVEY 8(d) credits a value pass with 3d + 32"
+    print("\n(one VALU instruction processes 64 points: 'per tile' = per point and pass ('x T trials': per point and trial -- the 'tiles' column counts tile x trial pairs of one iteration).  SURVEY 8(d) credits a value pass with 3d + 32"
           " = 56 flops per point and a value+gradient pass with 5d + 34 = 74 at d = 8; an FP64 FMA slot is worth 2.)")
 
 
