@@ -45,29 +45,54 @@ __global__ __launch_bounds__(256) void tile_gemm_kernel(int M, int Ncols, int K,
 #pragma unroll
     for (int b = 0; b < RN; ++b) acc[a][b] = 0.0;
 
-  for (int k0 = k_lo; k0 < k_hi; k0 += TK) {
-    // stage A tile: As[kk][ii] = Aop(i0+ii, k0+kk)
-    if (MODE == 1 || MODE == 3) {
-      for (int t = threadIdx.x; t < TK * TM; t += 256) {
+  // The next stage's operand tiles travel global -> registers while the current stage is multiplied out of LDS: skinny
+  // outputs leave a handful of workgroups walking K, and without the prefetch every stage pays a full memory round trip
+  // (65 us for L^-1 (1000 x 1000) times 50 columns -- a quarter of a batch-1 q-KG evaluation's set-up).
+  constexpr int NA = TK * TM / 256, NBV = TK * TN / 256;
+  static_assert(TK * TM % 256 == 0 && TK * TN % 256 == 0, "operand tiles are whole multiples of the workgroup");
+  double pa[NA], pb[NBV];
+  auto fetch = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      const int t = threadIdx.x + i * 256;
+      if (MODE == 1 || MODE == 3) {
         const int ii = t % TM, kk = t / TM;
         const int gi = i0 + ii, gk = k0 + kk;
-        As[kk][ii] = (gi < M && gk < K && (MODE == 3 || gk <= gi)) ? A[(long)gi + (long)gk * lda] : 0.0;
-      }
-    } else {
-      for (int t = threadIdx.x; t < TK * TM; t += 256) {
+        pa[i] = (gi < M && gk < K && (MODE == 3 || gk <= gi)) ? A[(long)gi + (long)gk * lda] : 0.0;
+      } else {
         const int kk = t % TK, ii = t / TK;
         const int gi = i0 + ii, gk = k0 + kk;
         bool ok = gi < M && gk < K;
         if (MODE == 2) ok = ok && gk >= gi;
-        As[kk][ii] = ok ? A[(long)gk + (long)gi * lda] : 0.0;
+        pa[i] = ok ? A[(long)gk + (long)gi * lda] : 0.0;
       }
     }
-    for (int t = threadIdx.x; t < TK * TN; t += 256) {
+#pragma unroll
+    for (int i = 0; i < NBV; ++i) {
+      const int t = threadIdx.x + i * 256;
       const int kk = t % TK, jj = t / TK;
       const int gk = k0 + kk, gj = j0 + jj;
-      Bs[kk][jj] = (gk < K && gj < Ncols && (MODE != 3 || gk >= gj)) ? B[(long)gk + (long)gj * ldb] : 0.0;
+      pb[i] = (gk < K && gj < Ncols && (MODE != 3 || gk >= gj)) ? B[(long)gk + (long)gj * ldb] : 0.0;
+    }
+  };
+  if (k_lo < k_hi) fetch(k_lo);
+  for (int k0 = k_lo; k0 < k_hi; k0 += TK) {
+    // stage the tiles: As[kk][ii] = Aop(i0+ii, k0+kk), Bs[kk][jj] = B(k0+kk, j0+jj)
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      const int t = threadIdx.x + i * 256;
+      if (MODE == 1 || MODE == 3)
+        As[t / TM][t % TM] = pa[i];
+      else
+        As[t % TK][t / TK] = pa[i];
+    }
+#pragma unroll
+    for (int i = 0; i < NBV; ++i) {
+      const int t = threadIdx.x + i * 256;
+      Bs[t % TK][t / TK] = pb[i];
     }
     __syncthreads();
+    if (k0 + TK < k_hi) fetch(k0 + TK);
 #pragma unroll
     for (int kk = 0; kk < TK; ++kk) {
       double av[RM], bv[RN];
@@ -245,7 +270,7 @@ void tile_gemm(int M, int Ncols, int K, const double* A, long lda, const double*
       hipLaunchKernelGGL((tile_gemm_kernel<64, 64, MODE, 16, NEG>), grid, dim3(256), 0, s, M, Ncols, K, A, lda, B, ldb, C, ldc);
   } else {
     dim3 grid((M + 31) / 32, (Ncols + 15) / 16);
-    hipLaunchKernelGGL((tile_gemm_kernel<32, 16, MODE, 64, NEG>), grid, dim3(256), 0, s, M, Ncols, K, A, lda, B, ldb, C, ldc);
+    hipLaunchKernelGGL((tile_gemm_kernel<32, 16, MODE, 128, NEG>), grid, dim3(256), 0, s, M, Ncols, K, A, lda, B, ldb, C, ldc);
   }
   MOE_HIP_CHECK(hipGetLastError());
 }
@@ -671,7 +696,7 @@ int gram_batch_slices(int E, int c, int K) {
   const long tiles = (long)((c + 31) / 32) * ((c + 31) / 32 + 1) / 2 * E;  // lower-triangular output tiles
   const long want = 1024;                                                  // ~4 workgroups per CU
   long s = (want + tiles - 1) / tiles;
-  s = std::min<long>(s, std::max(1, K / 256));                             // keep >= 4 stages of 64 per slice
+  s = std::min<long>(s, std::max(1, K / 64));                              // at least one stage of 64 per slice
   return (int)std::max<long>(1, std::min<long>(s, 16));
 }
 

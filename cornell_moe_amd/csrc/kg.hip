@@ -81,6 +81,7 @@ struct KgTailParams {
   CovParams cp;
   DerivList derivs;  // the GP's derivative observations (carried by the union points too)
   int u, q, m, g, N, E, num_local, first_sample, ngrad, chunks, sw_chunk;
+  int chunk_len;  // samples per TB partial (kTbChunk, or kFusedChunk on the T-free q-KG path): chunks = ceil(num_local / chunk_len)
   const double* T;           // [N x E*num_local], ld N
   const double* SW;          // optional precomputed W^T T, [m x E*num_local] col-major (large m: tile GEMM); else null
   const double* W;           // evaluation e at W + e * w_stride, [N x m], ld N
@@ -100,7 +101,11 @@ struct KgTailParams {
   int out_stride;
 };
 
-constexpr int kTbChunk = 256;  // samples per workgroup of kg_tb_kernel / kg_fused_point_kernel
+constexpr int kTbChunk = 256;  // samples per workgroup of kg_tb_kernel
+// ... and of kg_fused_point_kernel: 128, so that ONE q-KG evaluation (n = 1000: 4 row blocks x 79 chunks) puts more than one
+// workgroup on every CU -- 40.7 -> ~20 us of a batch-1 evaluation's tail.  Fixed per path, not per batch size: an evaluation's
+// bits do not depend on what it is batched with.
+constexpr int kFusedChunk = 128;
 constexpr int kDirSlices = 32;  // sample ranges of kg_dir_kernel
 
 // c_i = L^-1 ( K(Xu, x*_i)[:, 0] - W^T T_i ) for every sample; one wavefront per sample at a time, lane r owns component r.
@@ -197,7 +202,7 @@ __global__ __launch_bounds__(256) void kg_tb_kernel(KgTailParams P, int c_lo = 0
   const int row = blockIdx.x * 256 + threadIdx.x;
   const int chunk = blockIdx.y, e = blockIdx.z;
   const int m = P.m;
-  const int i0 = chunk * kTbChunk, i1 = min(P.num_local, i0 + kTbChunk);
+  const int i0 = chunk * P.chunk_len, i1 = min(P.num_local, i0 + P.chunk_len);
   double acc[MU];
 #pragma unroll
   for (int c = 0; c < MU; ++c) acc[c] = 0.0;
@@ -230,7 +235,8 @@ __global__ __launch_bounds__(256) void kg_tbsum_kernel(KgTailParams P, double* _
   if (idx >= mn) return;
   const double* part = P.TBpart + (long)e * P.chunks * mn + idx;
   double tb = 0.0;
-  for (int ch = 0; ch < P.chunks; ++ch) tb += part[(long)ch * mn];
+#pragma unroll 8
+  for (int ch = 0; ch < P.chunks; ++ch) tb += part[(long)ch * mn];  // (independent loads, issued eight at a time)
   TBsum[(long)e * mn + idx] = tb;
 }
 
@@ -264,6 +270,7 @@ __global__ __launch_bounds__(256) void kg_zc_kernel(KgTailParams P) {
   double* out = P.out + (long)e * P.out_stride;
   {
     double acc = 0.0;
+#pragma unroll 8
     for (int i = threadIdx.x; i < P.num_local; i += 256) {
       const int s = P.first_sample + i;
       const double z = ((s & 1) ? -1.0 : 1.0) * P.normals[(long)(s >> 1) * m + r];
@@ -410,7 +417,7 @@ void launch_tail(const KgTailParams& P, hipStream_t s) {
 // about half.  Operands that are uniform over the workgroup (the point tile in the first kernel, the sample chunk in the
 // second) are staged in LDS pre-scaled by 1/length and read as broadcasts.
 // ---------------------------------------------------------------------------------------------------------------------
-constexpr int kFusedTile = 256;  // points (kernel A) / samples (kernel B) staged per LDS tile; == kTbChunk
+constexpr int kFusedTile = 256;  // points (kernel A) / samples (kernel B, at most: KgTailParams::chunk_len) staged per LDS tile
 
 template <int COV>
 __device__ __forceinline__ double radial_base(double r2, const double* __restrict__ etab) {
@@ -522,7 +529,7 @@ __global__ __launch_bounds__(256) void kg_fused_point_kernel(KgTailParams P, con
   const int row = blockIdx.x * 256 + threadIdx.x;
   const int chunk = blockIdx.y, e = blockIdx.z;
   const int m = P.m;
-  const int i0 = chunk * kFusedTile, cnt = min(P.num_local - i0, kFusedTile);
+  const int i0 = chunk * P.chunk_len, cnt = min(P.num_local - i0, P.chunk_len);  // (chunk_len <= kFusedTile)
   if (threadIdx.x < kExpTabLen) etab[threadIdx.x] = kExp2Tab64[threadIdx.x];
   for (int t = threadIdx.x; t < kFusedTile * DP; t += 256) {
     const int ii = t / DP, k = t % DP;
@@ -578,17 +585,18 @@ void launch_fused_tail_inst(const KgTailParams& P, const double* X, int n, doubl
     launch_fused_tail_cov<DP, MU, MOE_COV_MATERN_NU_2P5>(P, X, n, SWpart, slices, s);
 }
 
-// number of point slices of kg_fused_sample_kernel: enough wavefronts for ~4 per SIMD
-int fused_tail_slices(int E, int num_local, int n, int num_cu) {
-  const long waves = (long)E * ((num_local + 255) / 256) * 4;
+// number of point slices of kg_fused_sample_kernel: enough wavefronts for ~4 per SIMD when ONE evaluation runs alone.  It does not
+// depend on the batch size: the slices are summed in order, so an evaluation's bits would otherwise change with its batch.
+int fused_tail_slices(int /*E*/, int num_local, int n, int num_cu) {
+  const long waves = (long)((num_local + 255) / 256) * 4;
   const long want = (long)num_cu * 4 * 4;
   int s = (int)std::min<long>(8, std::max<long>(1, (want + waves - 1) / waves));
   return std::max(1, std::min(s, (n + 63) / 64));
 }
 
-// T-free tail (requires g == 0, m <= 8, chunk size kTbChunk == kFusedTile)
+// T-free tail (requires g == 0, m <= 8, chunk_len <= kFusedTile)
 void launch_fused_tail(const KgTailParams& P, const double* X, int n, double* SWpart, int slices, hipStream_t s) {
-  static_assert(kFusedTile == kTbChunk, "the TB partial layout is shared with kg_gtb_kernel");
+  static_assert(kFusedChunk <= kFusedTile, "a chunk of samples is staged in one LDS tile");
   const bool m4 = P.m <= 4;
   switch (P.cp.dp) {
     case 4: m4 ? launch_fused_tail_inst<4, 4>(P, X, n, SWpart, slices, s) : launch_fused_tail_inst<4, 8>(P, X, n, SWpart, slices, s); break;
@@ -1067,11 +1075,12 @@ KgPending kg_launch(GpDev& gp, int num_fidelity, const moe_gd_params_t& gd, cons
   // [2 E] pass counters | [E] sample-ticket counters, one 128-byte line each (kTicketStride unsigned ints)
   const size_t n_ctr = (size_t)2 * E + (size_t)E * (kTicketStride / 2) + 32;  // (+16 alignment slack, +16 profiling words)
   dCounters.reserve(n_ctr);
-  const int chunks = (num_local + kTbChunk - 1) / kTbChunk;
   const int out_stride = 1 + m * m + 2 * ngrad;
   dOut.reserve((size_t)out_stride * E);
   // q-KG fast path: the N x M covariance matrix of the tail is never materialised (see launch_fused_tail)
   const bool fused_tail = want_grad && g == 0 && m <= 8 && env_int("MOE_KG_FUSED_TAIL", 1) != 0;
+  const int chunk_len = fused_tail ? kFusedChunk : kTbChunk;
+  const int chunks = (num_local + chunk_len - 1) / chunk_len;
   if (want_grad) {
     if (!fused_tail) dT.reserve((size_t)N * E * num_local);
     dC.reserve((size_t)E * num_local * m);
@@ -1191,6 +1200,7 @@ KgPending kg_launch(GpDev& gp, int num_fidelity, const moe_gd_params_t& gd, cons
   tl.first_sample = first_sample;
   tl.ngrad = ngrad;
   tl.chunks = chunks;
+  tl.chunk_len = chunk_len;
   tl.sw_chunk = ((long)E * num_local / kSwChunk >= 1024) ? kSwChunk : 16;
   tl.T = dT.p;
   tl.SW = nullptr;
@@ -1345,7 +1355,7 @@ int kg_max_batch(const GpDev& gp, int P, int q, int p, int num_local, bool want_
   const double N = gp.N, g1 = 1 + gp.g, u = q + p, m = u * g1, A = u + P;
   const double ngrad = want_grad ? q * g1 * gp.d : 0.0;
   const bool fused = want_grad && gp.g == 0 && m <= 8;
-  const double chunks = std::ceil((double)num_local / kTbChunk);
+  const double chunks = std::ceil((double)num_local / (fused ? kFusedChunk : kTbChunk));
   double doubles = 3.0 * N * (m + ngrad + A) + (double)num_local * (gp.dp + 1 + 2 * m);
   if (want_grad) doubles += (fused ? 0.0 : N * (double)num_local) + (chunks + 1.0) * m * N;
   if (gp.g > 0 || gp.n + u > 1500) doubles += N * (double)num_local;  // the workgroup-per-sample kernel's weight table
