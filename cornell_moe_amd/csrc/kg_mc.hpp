@@ -1066,6 +1066,7 @@ __device__ __forceinline__ double line_search_lds(const KgMcParams& P, EV& ev, d
   for (int k = 0; k < DP; ++k) sX[k] = tq[k];
 #pragma unroll
   for (int k = 0; k < DP; ++k) gp[k] = 0.0;
+  int pred = 2;  // Armijo trials the previous step of this sample consumed (>= 2): the size of the next step's first batch
   for (int restart = 0; restart < P.max_num_restarts; ++restart) {
 #pragma unroll
     for (int k = 0; k < DP; ++k) sX0[k] = sX[k];
@@ -1085,29 +1086,56 @@ __device__ __forceinline__ double line_search_lds(const KgMcParams& P, EV& ev, d
       double alpha_n = (P.gamma == 0.0) ? P.pre_mult : P.pre_mult * pow((double)(istep + 1), -P.gamma);
       int search = 0;
       double ftrial;
-      // Armijo back-tracking, two trial step sizes per pass (alpha and alpha / 2).  The sequence of decisions is the
-      // reference's (gpp_optimization.hpp:752-769): the second value is only looked at if the first one fails, and only
-      // consumed trials are counted -- the speculative one is wasted work when the first is accepted, which is cheap next
-      // to the pass's fixed cost in this kernel.
-      while (true) {
-        const double a1 = alpha_n, a2 = 0.5 * alpha_n;
-        double tqb[DP], f1, f2;
+      // Armijo back-tracking, several trial step sizes per pass (alpha, alpha / 2, alpha / 4, ...: EV::armijo_batch): as many as
+      // the previous step of this sample consumed (at least two -- in this kernel a pass is dominated by its fixed cost), then
+      // in pairs.  The sequence of decisions is the reference's (gpp_optimization.hpp:752-769): a trial's value is only
+      // looked at if all earlier ones failed, and only consumed trials are counted.  A trial that would need clamp_query
+      // (millions of length scales away) sends the batch down the two-point path, which clamps.
+      {
+        double x0f[DP], dv[DP];
+        double dd = 0.0, q0 = 0.0, qa = 0.0;
 #pragma unroll
         for (int r = 0; r < DP; ++r) {
-          tqp[r] = to_frame(P, fma(a1, sG[r], sX[r]), r);
-          tqb[r] = to_frame(P, fma(a2, sG[r], sX[r]), r);
+          x0f[r] = to_frame(P, sX[r], r);
+          dv[r] = sG[r] * P.inv_lp[r];
+          dd = fma(dv[r], dv[r], dd);
+          q0 = fma(x0f[r], x0f[r], q0);
+          const double xa = fma(alpha_n, dv[r], x0f[r]);
+          qa = fma(xa, xa, qa);
         }
-        ev.eval2(tqp, tqb, f1, f2);
-        ftrial = f1;
-        n_val++;
-        if (f1 - f0 > 0.5 * a1 * norm) break;
-        alpha_n = a2;
-        if (++search >= 30) break;
-        ftrial = f2;
-        n_val++;
-        if (f2 - f0 > 0.5 * a2 * norm) break;
-        alpha_n = 0.5 * a2;
-        if (++search >= 30) break;
+        // (|x0 + alpha dv|^2 is convex in alpha: the two ends bound every trial of the bracket)
+        const bool near = uniform(fmax(q0, qa)) <= kQueryClamp * kQueryClamp;
+        int batch = pred;
+        bool done = false;
+        while (!done) {
+          const int want = min(batch, 30 - search);
+          if (near && want >= 2) {
+            ev.armijo_batch(want, x0f, dv, dd, f0, norm, alpha_n, search, ftrial, done, n_val);
+          } else {
+            const double a1 = alpha_n, a2 = 0.5 * alpha_n;
+            double tqb[DP], f1, f2;
+#pragma unroll
+            for (int r = 0; r < DP; ++r) {
+              tqp[r] = to_frame(P, fma(a1, sG[r], sX[r]), r);
+              tqb[r] = to_frame(P, fma(a2, sG[r], sX[r]), r);
+            }
+            ev.eval2(tqp, tqb, f1, f2);
+            ftrial = f1;
+            n_val++;
+            if (f1 - f0 > 0.5 * a1 * norm) break;
+            alpha_n = a2;
+            if (++search >= 30) break;
+            if (want >= 2) {  // (want == 1: the 30th trial -- the second value is not consumed)
+              ftrial = f2;
+              n_val++;
+              if (f2 - f0 > 0.5 * a2 * norm) break;
+              alpha_n = 0.5 * a2;
+              if (++search >= 30) break;
+            }
+          }
+          batch = 2;
+        }
+        pred = max(2, min(search + 1, EV::kMaxTrials));
       }
       // LimitUpdate with one coordinate per lane (the state already lives in per-wave LDS arrays, so lane k simply reads
       // entry k): one clamp instead of DP wave-uniform copies
@@ -1481,6 +1509,38 @@ __device__ __forceinline__ void point_terms(const double (&cx)[DP], const double
   }
 }
 
+// One point's contribution to T Armijo trial values f(x0 + alpha_t dv), alpha_t = al[t] (frame coordinates; see
+// eval_multi_loop for the idea).  With diff0 = x_j - x0:
+//   r2_t = |diff0 - alpha_t dv|^2 = A - 2 alpha_t B + alpha_t^2 |dv|^2,   A = |diff0|^2, B = diff0 . dv   (3 DP instructions once),
+//   sum_a w_a (diff0 - alpha_t dv)_a = sdA - alpha_t sdB                                                  (2 G once),
+// so a trial costs two fmas and a max for its distance instead of 2 DP, and one for its derivative-weight sum instead of G.
+// Centred on x0 (the current iterate, inside the domain), so A and B are of the size of the distances themselves.
+template <int DP, int G, int COV, int T>
+__device__ __forceinline__ void point_terms_multi(const double (&cx)[DP], const double (&cw)[1 + G], const double (&x0)[DP],
+                                                  const double (&dv)[DP], const double (&al)[T], double dd,
+                                                  const double* __restrict__ etab, double (&acc)[T]) {
+  double A = 1.0e-300, B = 0.0, sdA = 0.0, sdB = 0.0;
+#pragma unroll
+  for (int k = 0; k < DP; ++k) {
+    const double d0 = cx[k] - x0[k];
+    A = fma(d0, d0, A);
+    B = fma(d0, dv[k], B);
+    if (G > 0 && k < G) {
+      sdA = fma(cw[1 + (k < G ? k : 0)], d0, sdA);
+      sdB = fma(cw[1 + (k < G ? k : 0)], dv[k], sdB);
+    }
+  }
+  const double mB2 = -2.0 * B;
+#pragma unroll
+  for (int t = 0; t < T; ++t) {
+    const double r2 = fmax(fma(al[t], fma(al[t], dd, mB2), A), 1.0e-300);
+    double base, first, second;
+    radial3<COV, (G > 0), false>(r2, etab, base, first, second);
+    acc[t] = fma(cw[0], base, acc[t]);
+    if (G > 0) acc[t] = fma(first, fma(-al[t], sdB, sdA), acc[t]);
+  }
+}
+
 template <int DP, int G, int TR>
 struct BlockEval {
   double cx[TR > 0 ? TR : 1][DP];     // register tiles: scaled coordinates (resident for the kernel's life)
@@ -1569,6 +1629,112 @@ struct BlockEval {
     for (int t = 0; t < TR; ++t) {
       point_terms<DP, G, false, COV>(cx[t], cw[t], xa, etab, fa, dg, dd);
       point_terms<DP, G, false, COV>(cx[t], cw[t], xb, etab, fb, dg, dd);
+    }
+  }
+
+  // T trial values along one line in one sweep (point_terms_multi): one set of coordinate / weight loads, one reduction round,
+  // one barrier and one decision round per T trials.
+  template <int COV, int T>
+  __device__ __forceinline__ void accumulateT(const double (&x0)[DP], const double (&dv)[DP], const double (&al)[T], double dd,
+                                              double (&acc)[T]) {
+    if (ntl > 0) {
+      lds_tile_ptr xt = (lds_tile_ptr)xl;  // single ds_read_b64 each (see lds_tile_ptr)
+      lds_tile_ptr wt = (lds_tile_ptr)wl;
+      double c0[DP], w0[1 + G];
+#pragma unroll
+      for (int k = 0; k < DP; ++k) c0[k] = xt[k * 64];
+#pragma unroll
+      for (int a = 0; a < 1 + G; ++a) w0[a] = wt[a * 64];
+#pragma unroll 1
+      for (int t = 0; t < ntl; ++t) {
+        double c1[DP], w1[1 + G];
+        if (t + 1 < ntl) {
+          xt += DP * 64;
+          wt += (1 + G) * 64;
+        }
+#pragma unroll
+        for (int k = 0; k < DP; ++k) c1[k] = xt[k * 64];
+#pragma unroll
+        for (int a = 0; a < 1 + G; ++a) w1[a] = wt[a * 64];
+        point_terms_multi<DP, G, COV, T>(c0, w0, x0, dv, al, dd, etab, acc);
+#pragma unroll
+        for (int k = 0; k < DP; ++k) c0[k] = c1[k];
+#pragma unroll
+        for (int a = 0; a < 1 + G; ++a) w0[a] = w1[a];
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < TR; ++t) point_terms_multi<DP, G, COV, T>(cx[t], cw[t], x0, dv, al, dd, etab, acc);
+  }
+
+  // Up to kMaxTrials Armijo trials x0 + alpha 2^-t dv (frame coordinates) in one pass, followed by the reference's sequence of
+  // decisions over them with compile-time indices (gpp_optimization.hpp:752-769; see WaveEval::armijo_t).  The caller has
+  // checked that no trial needs clamp_query.
+  static constexpr int kMaxTrials = 5;
+  template <int T>
+  __device__ __forceinline__ void armijo_t(const double (&x0)[DP], const double (&dv)[DP], double dd, double f0, double norm,
+                                           double& alpha_n, int& search, double& ftrial, bool& done, unsigned long long& n_val) {
+    double al[T], acc[T];
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+      al[t] = (t == 0) ? alpha_n : 0.5 * al[t > 0 ? t - 1 : 0];
+      acc[t] = 0.0;
+    }
+    MOE_PROF_T(t0);
+    if (cov_type == MOE_COV_SQUARE_EXPONENTIAL)
+      accumulateT<MOE_COV_SQUARE_EXPONENTIAL, T>(x0, dv, al, dd, acc);
+    else
+      accumulateT<MOE_COV_MATERN_NU_2P5, T>(x0, dv, al, dd, acc);
+    MOE_PROF_T(t1);
+    double* slot = part + (par * kMaxBlockWaves + wave) * kPartLen;
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+      const double sv = wave_sum_uniform(acc[t]);
+      if (lane == 0) slot[t] = sv;
+    }
+    MOE_PROF_T(t2);
+    __syncthreads();
+    MOE_PROF_T(t3);
+    const double* all = part + par * kMaxBlockWaves * kPartLen;
+    par ^= 1;
+    double f[T];
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+      double tot = 0.0;
+#pragma unroll
+      for (int w = 0; w < kMaxBlockWaves; ++w) tot += (w < nw) ? all[w * kPartLen + t] : 0.0;  // (reads issued together)
+      f[t] = -(mean + uniform(tot));
+    }
+    MOE_PROF_T(t4);
+    MOE_PROF_ADD(c_acc, t0, t1);
+    MOE_PROF_ADD(c_red, t1, t2);
+    MOE_PROF_ADD(c_bar, t2, t3);
+    MOE_PROF_ADD(c_post, t3, t4);
+#if MOE_BLOCK_PROF
+    c_n++;
+#endif
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+      if (!done) {
+        ftrial = f[t];
+        n_val++;
+        if (ftrial - f0 > 0.5 * alpha_n * norm) {
+          done = true;
+        } else {
+          alpha_n *= 0.5;
+          if (++search >= 30) done = true;
+        }
+      }
+    }
+  }
+  __device__ __forceinline__ void armijo_batch(int want, const double (&x0)[DP], const double (&dv)[DP], double dd, double f0,
+                                               double norm, double& alpha_n, int& search, double& ftrial, bool& done,
+                                               unsigned long long& n_val) {
+    switch (want) {
+      case 2: armijo_t<2>(x0, dv, dd, f0, norm, alpha_n, search, ftrial, done, n_val); break;
+      case 3: armijo_t<3>(x0, dv, dd, f0, norm, alpha_n, search, ftrial, done, n_val); break;
+      case 4: armijo_t<4>(x0, dv, dd, f0, norm, alpha_n, search, ftrial, done, n_val); break;
+      default: armijo_t<5>(x0, dv, dd, f0, norm, alpha_n, search, ftrial, done, n_val); break;
     }
   }
 
