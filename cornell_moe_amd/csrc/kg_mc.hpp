@@ -963,7 +963,8 @@ __device__ __forceinline__ double line_search_frame(const KgMcParams& P, const d
               if (++search >= 30) done = true;
             }
           }
-          batch = 2;
+          // (a first trial that fails is usually followed by several halvings: four more at once, then pairs)
+          batch = (batch == 1 && search == 1) ? 4 : 2;
         }
         pred = min(search + 1, EV::kMaxTrials);
       }
