@@ -61,6 +61,62 @@ __global__ __launch_bounds__(kCovRows) void cov_build_kernel(CovParams cp, const
   }
 }
 
+// Derivative observations on the A side (K(X, X) of a d-KG GP, K*, the N x M gradient-tail matrix): one thread per A POINT
+// instead of per output row.  With g observed derivatives the 1 + g rows of a point used to be 1 + g threads that each
+// recomputed the pair's distance, square root and exponential (4 x the arithmetic at C5's g = 3, 13 x at g = 12) and the kernel
+// sat at 0.24 of HBM peak, FP64-issue bound.  Here the radial scalars of a pair are formed once and its (1 + gA) x (1 + gB) entries
+// come from the same cov_entry as before (bit-identical values); a wavefront's 64 (1 + gA) rows of one output column are
+// contiguous in memory, so they are transposed through a per-wave LDS stage and stored as full 512-byte runs.
+template <int DP>
+__global__ __launch_bounds__(256) void cov_build_points_kernel(CovParams cp, const double* __restrict__ A, int nA, DerivList dA,
+                                                              const double* __restrict__ B, int nB, DerivList dB,
+                                                              const double* __restrict__ diag_noise, double* __restrict__ out,
+                                                              long ld, long col0) {
+  __shared__ double Bs[kCovCols][DP];
+  __shared__ double stage_all[4][64 * (1 + kMaxDerivs)];
+  const int gA = dA.g, gB = dB.g, a1 = 1 + gA;
+  const int j0 = blockIdx.x * kCovCols;
+  const int nj = min(kCovCols, nB - j0);
+  for (int t = threadIdx.x; t < nj * DP; t += blockDim.x) Bs[t / DP][t % DP] = B[(long)(j0 + t / DP) * DP + (t % DP)];
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  volatile __attribute__((address_space(3))) double* stage =
+      (volatile __attribute__((address_space(3))) double*)&stage_all[wave][0];
+  const int p0 = blockIdx.y * 256 + wave * 64;  // first A point of this wavefront
+  if (p0 >= nA) return;
+  const int i = min(p0 + lane, nA - 1);  // (lanes beyond nA recompute the last point; their rows are not stored)
+  const long row0 = (long)p0 * a1;       // first output row of this wavefront
+  const long rows = (long)nA * a1;
+  double xi[DP];
+#pragma unroll
+  for (int k = 0; k < DP; ++k) xi[k] = A[(long)i * DP + k];
+  for (int jj = 0; jj < nj; ++jj) {
+    double diff[DP];
+    double r2 = 0.0;
+#pragma unroll
+    for (int k = 0; k < DP; ++k) {
+      diff[k] = xi[k] - Bs[jj][k];
+      r2 = fma(diff[k] * diff[k], cp.inv_l2[k], r2);
+    }
+    const Radial rd = radial_scalars(cp.type, cp.alpha, r2);
+    for (int b = 0; b <= gB; ++b) {
+      const long colrel = (long)(j0 + jj) * (1 + gB) + b;
+      for (int a = 0; a <= gA; ++a) {
+        double v = cov_entry<DP>(cp, rd, diff, a, b, dA, dB);
+        if (diag_noise != nullptr && (long)i * a1 + a == colrel) v += diag_noise[a];
+        stage[lane * a1 + a] = v;
+      }
+      // (LDS operations of one wavefront complete in order: the reads below see the writes above)
+      double* dst = out + (col0 + colrel) * ld + row0;
+      for (int t = 0; t <= gA; ++t) {
+        const int rr = lane + 64 * t;
+        const double v = stage[rr];
+        if (row0 + rr < rows) dst[rr] = v;
+      }
+    }
+  }
+}
+
 // Value-only blocks (no derivative observations on either side -- K(X, X) of a q-KG GP, K*, the N x M gradient-tail matrix):
 // the same mapping, with the arithmetic per entry cut from ~55 to ~40 FP64 instructions, because at ~3.4 TB/s of stores this
 // kernel was FP64-issue co-limited, not store-limited (tools/covbench.hip):
@@ -235,7 +291,10 @@ void cov_build_dp(const CovParams& cp, const double* A, int nA, const DerivList&
   const int rows = nA * (1 + dA.g);
   dim3 grid((nB + kCovCols - 1) / kCovCols, (rows + kCovRows - 1) / kCovRows);
   if (grid.x == 0 || grid.y == 0) return;
-  if (derivs)
+  if (dA.g > 0 && value_fast_path()) {  // thread per point, rows transposed through LDS (MOE_COV_FAST=0: the row-per-thread kernel)
+    dim3 pgrid(grid.x, (nA + 255) / 256);
+    hipLaunchKernelGGL((cov_build_points_kernel<DP>), pgrid, dim3(256), 0, s, cp, A, nA, dA, B, nB, dB, diag_noise, out, ld, col0);
+  } else if (derivs)
     hipLaunchKernelGGL((cov_build_kernel<DP, true>), grid, dim3(kCovRows), 0, s, cp, A, nA, dA, B, nB, dB, diag_noise, out, ld,
                        col0);
   else if (streaming && value_fast_path())

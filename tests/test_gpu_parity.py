@@ -456,6 +456,28 @@ def test_add_points_append_singular(api):
     assert gp.n == 42
 
 
+def test_point_per_thread_covariance_assembly_is_bit_identical(api, monkeypatch):
+    """K(X, X) and K(X, x*) with derivative observations: the thread-per-point kernel (radial scalars once per pair, rows
+    transposed through LDS) writes exactly the bits of the row-per-thread kernel (MOE_COV_FAST=0) -- sizes around the 64 / 256
+    point blocking, derivative lists out of order, both covariance types."""
+    rng = np.random.default_rng(31)
+    for n, d, derivs, cov in ((70, 3, (2,), 1), (257, 5, (4, 0, 2), 0), (64, 12, tuple(range(12)), 1), (300, 4, (1, 3), 1)):
+        g = len(derivs)
+        X = rng.uniform(size=(n, d))
+        y = rng.normal(size=(n, 1 + g))
+        hyper = np.r_[1.2, rng.uniform(0.4, 1.1, size=d)]
+        noise = np.full(1 + g, 0.05)
+        pts = rng.uniform(size=(37, d))
+        out = []
+        for fast in ("1", "0"):
+            monkeypatch.setenv("MOE_COV_FAST", fast)
+            G = api.DeviceGP(hyper, X, y, noise, derivs, cov_type=cov)
+            K, kiy, _ = G.get_factor()
+            out.append((K, kiy, G.mix_covariance(pts, list(derivs)), G.mix_covariance(pts), G.mean(pts), G.variance(pts)))
+        for a, b in zip(*out):
+            assert np.array_equal(a, b)
+
+
 def test_fastmath(api):
     """Device exp(-x) / sqrt(x) (csrc/fastmath.hpp) vs numpy: <= 2 ulp over the ranges the covariance loops produce."""
     rng = np.random.default_rng(5)
