@@ -745,6 +745,21 @@ constexpr int SB = 16;
 // strict upper part at S[j][i + 1]  (50 KB of LDS for the kernel instead of 100).
 #define MOE_XS(i, j) S[(j)][(i) + 1]
 
+#if defined(MOE_DIAG_PROF)  // tools/diagbench.hip: clock stamps of thread 0 -- [0..4] phase ends, [8..11] time inside the four parts of a sub-step
+__device__ unsigned long long moe_diag_prof[16];
+#define MOE_DIAG_T(i) \
+  if (threadIdx.x == 0) moe_diag_prof[i] = __builtin_amdgcn_s_memtime();
+#define MOE_DIAG_A(i)                                                     \
+  if (threadIdx.x == 0) {                                                 \
+    const unsigned long long now_ = __builtin_amdgcn_s_memtime();         \
+    if ((i) > 0) moe_diag_prof[8 + (i)] += now_ - diag_last_;             \
+    diag_last_ = now_;                                                    \
+  }
+#else
+#define MOE_DIAG_T(i)
+#define MOE_DIAG_A(i)
+#endif
+
 template <int LO, int MID, int HI>
 __device__ __forceinline__ void lds_tri_inv_offdiag(double (*S)[NB + 1], double (*W)[2 * SB + 1]) {
   // Fixed trip counts with predicated terms (clamped addresses), fully unrolled: the loads of a dot product are issued together
@@ -783,15 +798,37 @@ __global__ __launch_bounds__(256) void chol_diag_lds_kernel(double* __restrict__
   __shared__ int s_bad;
   if (*info != 0) return;
   const int t = threadIdx.x;
-  for (int idx = t; idx < NB * (NB + 1); idx += 256) {
-    const int i = idx % NB, j = idx / NB;  // j runs to NB: column 64 belongs to the packed inverse
-    double v = (i == j && i >= nb) ? 1.0 : 0.0;  // rows / columns beyond nb (last, partial block): identity
-    if (i < nb && j < nb && j <= i) v = A[(long)(k0 + i) + (long)(k0 + j) * lda];
-    S[i][j] = v;
+  MOE_DIAG_T(0);
+  // (unconditional loads from clamped addresses, all issued before the first use: one memory round trip instead of one per
+  //  guarded element -- 18 k of the kernel's 128 k cycles were this loop)
+  {
+    constexpr int PER = (NB * (NB + 1) + 255) / 256;
+    double v[PER];
+#pragma unroll
+    for (int q = 0; q < PER; ++q) {
+      const int idx = min(t + q * 256, NB * (NB + 1) - 1);
+      const int i = idx % NB, j = idx / NB;  // j runs to NB: column 64 belongs to the packed inverse
+      v[q] = A[(long)(k0 + min(i, nb - 1)) + (long)(k0 + min(j, nb - 1)) * lda];
+    }
+#pragma unroll
+    for (int q = 0; q < PER; ++q) {
+      const int idx = t + q * 256;
+      if (idx < NB * (NB + 1)) {
+        const int i = idx % NB, j = idx / NB;
+        double w = (i == j && i >= nb) ? 1.0 : 0.0;  // rows / columns beyond nb (last, partial block): identity
+        if (i < nb && j < nb && j <= i) w = v[q];
+        S[i][j] = w;
+      }
+    }
   }
   if (t == 0) s_bad = 0;
   __syncthreads();
+  MOE_DIAG_T(1);
+#if defined(MOE_DIAG_PROF)
+  unsigned long long diag_last_ = 0;
+#endif
   for (int s0 = 0; s0 < NB; s0 += SB) {
+    MOE_DIAG_A(0);
     // (1) 16 x 16 diagonal sub-block: the first wavefront, lane & 15 = row of the sub-block, that row in registers
     if (t < 64) {
       const int i = t & (SB - 1);
@@ -799,12 +836,21 @@ __global__ __launch_bounds__(256) void chol_diag_lds_kernel(double* __restrict__
 #pragma unroll
       for (int c = 0; c < SB; ++c) a[c] = S[s0 + i][s0 + c];  // (c > i: whatever the packed inverse holds there -- never used)
       int bad = 0;
+      double rdiag[SB];  // 1 / L[k][k], reused by the inverse below
 #pragma unroll
       for (int k = 0; k < SB; ++k) {
         const double piv = readlane_f64(a[k], k);
         if (bad == 0 && !(piv > 1.0e-16)) bad = k0 + s0 + k + 1;  // gpp_linear_algebra.cpp:118
-        const double lkk = sqrt(piv);
-        const double lik = (i == k) ? lkk : a[k] / lkk;
+        const double ps = fmax(piv, 1.0e-300);  // (a failed pivot is reported above; keep the arithmetic finite)
+        double r = __builtin_amdgcn_rsq(ps);
+        r = r * fma(-0.5 * ps * r, r, 1.5);  // Newton: r (3 - ps r^2) / 2
+        r = r * fma(-0.5 * ps * r, r, 1.5);
+        double lkk = ps * r;
+        lkk = fma(fma(-lkk, lkk, ps), 0.5 * r, lkk);  // Heron correction of sqrt(ps)
+        rdiag[k] = r;
+        double q = a[k] * r;
+        q = fma(fma(-q, lkk, a[k]), r, q);  // residual correction of a / lkk
+        const double lik = (i == k) ? lkk : q;
         a[k] = lik;
 #pragma unroll
         for (int j = k + 1; j < SB; ++j) {
@@ -819,7 +865,10 @@ __global__ __launch_bounds__(256) void chol_diag_lds_kernel(double* __restrict__
         double sum = (r == i) ? 1.0 : 0.0;
 #pragma unroll
         for (int j = 0; j < r; ++j) sum -= readlane_f64(a[j], r) * x[j];  // L[r][j] lives in lane r
-        x[r] = sum / readlane_f64(a[r], r);
+        const double lrr = readlane_f64(a[r], r);
+        double q = sum * rdiag[r];
+        q = fma(fma(-q, lrr, sum), rdiag[r], q);
+        x[r] = q;
       }
       if (t < SB) {
         if (bad != 0 && s_bad == 0) s_bad = bad;
@@ -831,6 +880,7 @@ __global__ __launch_bounds__(256) void chol_diag_lds_kernel(double* __restrict__
       }
     }
     __syncthreads();
+    MOE_DIAG_A(1);
     const int below = NB - s0 - SB;
     if (below > 0) {
       // (2) panel: P[r][c] = sum_j A[r][s0 + j] X16[c][j]   (= A_panel L16^-T), r below the sub-block
@@ -848,6 +898,7 @@ __global__ __launch_bounds__(256) void chol_diag_lds_kernel(double* __restrict__
         S[r][s0 + c] = W[r][c];
       }
       __syncthreads();
+      MOE_DIAG_A(2);
       // (3) the remaining columns: S[i][j] -= sum_c S[i][s0 + c] S[j][s0 + c], j <= i, one column at a time in k order
       for (int idx = t; idx < below * below; idx += 256) {
         const int i = s0 + SB + idx % below, j = s0 + SB + idx / below;
@@ -859,8 +910,10 @@ __global__ __launch_bounds__(256) void chol_diag_lds_kernel(double* __restrict__
         }
       }
       __syncthreads();
+      MOE_DIAG_A(3);
     }
   }
+  MOE_DIAG_T(2);
   if (s_bad != 0) {
     if (t == 0) *info = s_bad;
     return;
@@ -869,6 +922,7 @@ __global__ __launch_bounds__(256) void chol_diag_lds_kernel(double* __restrict__
   lds_tri_inv_offdiag<0, 16, 32>(S, W);
   lds_tri_inv_offdiag<32, 48, 64>(S, W);
   lds_tri_inv_offdiag<0, 32, 64>(S, W);
+  MOE_DIAG_T(3);
   for (int idx = t; idx < NB * NB; idx += 256) {
     const int i = idx % NB, j = idx / NB;
     if (i < nb && j < nb) {
@@ -876,6 +930,7 @@ __global__ __launch_bounds__(256) void chol_diag_lds_kernel(double* __restrict__
       Linv[(long)(k0 + i) + (long)(k0 + j) * ldl] = (j <= i) ? MOE_XS(i, j) : 0.0;
     }
   }
+  MOE_DIAG_T(4);
 }
 #undef MOE_XS
 
