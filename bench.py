@@ -107,14 +107,21 @@ def cpu_baseline_c5(w, log):
         rows.append({"n": n, "N": N, "seconds_M%d" % M1: tt[0], "seconds_M%d" % M2: tt[1], "per_sample_s": per_sample, "fixed_s": fixed})
         log("cpu_baseline C5: n=%d N=%d: %.2f s at M=%d, %.2f s at M=%d" % (n, N, tt[0], M1, tt[1], M2))
     Ns = np.array(Ns)
-    ab = np.linalg.lstsq(np.c_[Ns, Ns ** 2], np.array(ts), rcond=None)[0]
-    ce = np.linalg.lstsq(np.c_[Ns ** 2, Ns ** 3], np.array(T0), rcond=None)[0]
+    # non-negative least squares: with three noisy timings an unconstrained fit can return a negative coefficient, which at
+    # N = 8000 (twice the largest measured size) may even turn the extrapolated time negative
+    try:
+        from scipy.optimize import nnls
+        ab = nnls(np.c_[Ns, Ns ** 2], np.maximum(np.array(ts), 0.0))[0]
+        ce = nnls(np.c_[Ns ** 2, Ns ** 3], np.maximum(np.array(T0), 0.0))[0]
+    except ImportError:  # leading terms through the largest size
+        ab = np.array([0.0, max(ts[-1], 0.0) / Ns[-1] ** 2])
+        ce = np.array([0.0, max(T0[-1], 0.0) / Ns[-1] ** 3])
     Nc = float(w.n * (1 + w.g))
     t_s = float(ab[0] * Nc + ab[1] * Nc ** 2)
     t_0 = float(ce[0] * Nc ** 2 + ce[1] * Nc ** 3)
     total = t_0 + w.M * t_s
     return {"value": 1.0 / total, "unit": "evals/s", "cores": 1, "kind": "reference", "extrapolated_seconds_per_eval": total,
-            "model": "T = T0(N) + M t_s(N); t_s = a N + b N^2, T0 = c N^2 + e N^3 (least squares over the three sizes)",
+            "model": "T = T0(N) + M t_s(N); t_s = a N + b N^2, T0 = c N^2 + e N^3 (non-negative least squares over the three sizes)",
             "fit": {"a": float(ab[0]), "b": float(ab[1]), "c": float(ce[0]), "e": float(ce[1]), "t_s_at_C5": t_s, "T0_at_C5": t_0},
             "measurements": rows,
             "sample": "reference ComputeGradKnowledgeGradient (1 core) at n = 250, 500, 1000 (N = 1000, 2000, 4000) with %d and %d MC "
