@@ -884,16 +884,27 @@ __device__ __forceinline__ double line_search_frame(const KgMcParams& P, const d
   }
   const double step_tolerance = tolerance / (double)max_num_steps;
   // entry: table-row order, then into the frame (pinned rows -- fidelity coordinates, pads -- keep their frame value throughout)
+  // The point lives twice: xo_l -- lane r holds coordinate r in the ORIGINAL units, advanced by exactly the reference's operations
+  // (x += LimitUpdate(alpha grad), TensorProductDomain::LimitUpdate on the original bounds) -- and xf, its image in the frame,
+  // which only feeds the evaluator.  LimitUpdate's "would the step leave the domain" test is a knife edge when a step goes to the
+  // wall itself (max_relative_change = 1: x + (upper - x) is exactly upper in the original units, by Sterbenz, but can be one
+  // ulp beyond the wall's image in the centred frame -- which halves the step): the decisions must be taken where the reference
+  // takes them (found by tools/fuzz_parity.py, seed 101 case 93).
   double xf[DP];
+  double xo_l = 0.0;
   {
     double xp[DP];
     to_table_order<DP, G>(x, P.perm, xp);
 #pragma unroll
-    for (int r = 0; r < DP; ++r) xf[r] = (xp[r] - C[2 * DP + r]) * C[r];
+    for (int r = 0; r < DP; ++r) {
+      xf[r] = (xp[r] - C[2 * DP + r]) * C[r];
+      xo_l = (lane_id == r) ? xp[r] : xo_l;
+    }
   }
   volatile __attribute__((address_space(3))) double* S = (volatile __attribute__((address_space(3))) double*)scr;
   const int lk = lane_id < DP ? lane_id : 0;
-  const double lo_l = C[3 * DP + lk], hi_l = C[4 * DP + lk];
+  const double lo_l = P.bounds[2 * lk], hi_l = P.bounds[2 * lk + 1];  // original units, table-row order (once per sample)
+  const double s_l = C[lk];
   const bool free_l = lane_id < DP && ((free_mask >> (lane_id & 31)) & 1u);
   double fcur = 0.0;
   double gf[DP];
@@ -971,19 +982,21 @@ __device__ __forceinline__ double line_search_frame(const KgMcParams& P, const d
       // ---- LimitUpdate in the frame, one coordinate per lane, then accept only if f improves (.hpp:762-795) ----
       bool changed, nonzero;
       double step[DP];
+      double step_o = 0.0;  // this lane's coordinate of the step, original units
       {
-        double x_l = 0.0, d2_l = 0.0;
+        double g_l = 0.0, d2_l = 0.0;
 #pragma unroll
         for (int k = 0; k < DP; ++k) {
-          x_l = (lane_id == k) ? xf[k] : x_l;
+          g_l = (lane_id == k) ? gf[k] : g_l;
           d2_l = (lane_id == k) ? d2[k] : d2_l;
         }
-        const double want_l = (-0.5 * alpha_n) * d2_l;  // alpha g s
-        double step_l = 0.0;
-        if (free_l) step_l = limit_update_1d(lo_l, hi_l, P.max_relative_change, x_l, want_l);
-        changed = __ballot(free_l && step_l != want_l) != 0ull;
-        nonzero = __ballot(free_l && step_l != 0.0) != 0ull;
-        if (lane_id < DP) S[2 * DP + lane_id] = step_l;  // back as wave-uniform values through the scratch (not SGPRs)
+        const double want_o = alpha_n * (g_l * s_l);  // alpha grad_r in the original units (grad = frame gradient x scale)
+        if (free_l) step_o = limit_update_1d(lo_l, hi_l, P.max_relative_change, xo_l, want_o);
+        changed = __ballot(free_l && step_o != want_o) != 0ull;
+        nonzero = __ballot(free_l && step_o != 0.0) != 0ull;
+        // the step in the frame: the trial point's own offset where the clamp left it alone (its value is reused below)
+        const double step_f = changed ? step_o * s_l : (-0.5 * alpha_n) * d2_l;
+        if (lane_id < DP) S[2 * DP + lane_id] = free_l ? step_f : 0.0;  // back as wave-uniform values through the scratch
 #pragma unroll
         for (int k = 0; k < DP; ++k) step[k] = S[2 * DP + k];
       }
@@ -1016,6 +1029,7 @@ __device__ __forceinline__ double line_search_frame(const KgMcParams& P, const d
         const double so = step[k] * C[DP + k];
         ss = fma(so, so, ss);
       }
+      xo_l += step_o;
       fcur = obj2;
       istep += 1;
       have_g = carried;
@@ -1031,11 +1045,12 @@ __device__ __forceinline__ double line_search_frame(const KgMcParams& P, const d
     if (!(sqrt(ds) > tolerance)) break;
   }
   if (have_g) n_val++;  // carried but never used
-  // exit: back to the original coordinates (pinned rows return what came in) and the original dimension order
+  // exit: the original-unit state (pinned rows hold what a fidelity coordinate / pad row holds) in the original dimension order
   {
+    if (lane_id < DP) S[lane_id] = free_l ? xo_l : C[5 * DP + lk];
     double xo[DP];
 #pragma unroll
-    for (int r = 0; r < DP; ++r) xo[r] = ((free_mask >> r) & 1u) ? fma(xf[r], C[DP + r], C[2 * DP + r]) : C[5 * DP + r];
+    for (int r = 0; r < DP; ++r) xo[r] = S[r];
     from_table_order<DP, G>(xo, P.perm, x);
   }
   return fcur;

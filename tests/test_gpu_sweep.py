@@ -126,6 +126,48 @@ def test_many_evaluations_per_batch(monkeypatch):
     assert pieces["mean_evals"] == whole["mean_evals"] and pieces["grad_evals"] == whole["grad_evals"]
 
 
+def test_limit_update_decides_in_original_units(monkeypatch):
+    """max_relative_change = 1 lets a step go to the wall itself: x + (upper - x) is exactly `upper` in the reference's units but can
+    round one ulp past the wall's image in a centred, scaled frame -- and LimitUpdate then halves the step
+    (gpp_domain.cpp:80-101).  The wave-per-sample kernel's line search evaluates in its frame but takes these decisions on an
+    original-unit copy of the point; this is the case of tools/fuzz_parity.py (seed 101, case 93: domain offset by up to 1000,
+    rescaled per dimension, 7 steps x 2 restarts) in which one of 59 samples went to another optimum before that."""
+    from cornell_moe_amd import api
+    from cornell_moe_amd.workloads import make_workload
+    from oracle import orc
+    rng = np.random.default_rng(101)
+    for case in range(94):  # (replays the fuzzer's generator up to the case)
+        d = int(rng.integers(1, 17))
+        g = int(rng.integers(0, min(4, d) + 1)) if rng.uniform() < 0.5 else 0
+        derivs = tuple(int(v) for v in rng.permutation(d)[:g])
+        umax = 64 // (1 + g)
+        q = int(rng.integers(1, min(4, umax) + 1))
+        p = int(rng.integers(0, min(3, umax - q) + 1))
+        n, P, M, cov = int(rng.integers(1, 300)), int(rng.integers(1, 13)), int(rng.integers(1, 65)), int(rng.integers(0, 2))
+        f = int(rng.integers(0, d)) if rng.uniform() < 0.3 else 0
+        gd = (1, int(rng.integers(1, 8)), int(rng.integers(1, 3)), 3, float(rng.choice([0.0, 0.5, 1.0])),
+              float(rng.choice([1.0, 0.3, 2.0])), float(rng.choice([0.1, 0.5, 1.0])), float(rng.choice([1e-10, 1e-6])))
+        affine = rng.uniform() < 0.4
+        if affine:
+            shift = rng.choice([-50.0, 10.0, 100.0, 1000.0], size=d) * (rng.uniform(size=d) < 0.7)
+            scale = rng.choice([0.1, 1.0, 10.0], size=d)
+    assert (n, d, q, p, derivs, M, gd[6], affine) == (211, 10, 3, 3, (7, 5), 59, 1.0, True)
+    w = make_workload(seed=10_000 + 93, n=n, d=d, q=q, M=M, P=P, derivs=derivs, p=p)
+    for name in ("X", "Xq", "Xp", "discrete"):
+        setattr(w, name, shift + scale * getattr(w, name))
+    lengths = w.lengths * scale
+    bounds = np.column_stack([shift, shift + scale]).reshape(-1)
+    O = orc.OrcGP(cov, w.alpha, lengths, w.X, w.y, w.noise, derivs)
+    G = api.DeviceGP(np.r_[w.alpha, lengths], w.X, w.y, w.noise, derivs, cov_type=cov)
+    best = float(O.additional_mean(w.discrete).min())
+    ro = O.kg(gd, bounds, w.discrete, w.Xq, w.Xp, M, best, w.kg_normals)
+    for variant in ("0", "1"):
+        monkeypatch.setenv("MOE_KG_VARIANT", variant)
+        rg = G.kg(gd, bounds, w.discrete, w.Xq, w.Xp, M, best, w.kg_normals, want_best_points=True)
+        assert abs(rg["kg"] - ro["kg"]) <= TOL["kg"] * abs(ro["kg"]), (variant, rg["kg"], ro["kg"])
+        assert np.abs(rg["best_point"] - ro["best_point"]).max() <= 1e-6
+
+
 def test_wide_dimensions_gp_posterior_and_likelihood():
     """d = 17 .. 32 outside the KG kernels: posterior mean / variance and their gradients, q,p-EI, the log likelihood and its
     hyper-parameter gradient, against the oracle."""

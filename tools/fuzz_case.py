@@ -56,3 +56,14 @@ for variant in ("0", "1"):
     bad = ~np.isfinite(rg["best_point"]).all(axis=1)
     print("  non-finite best points:", int(bad.sum()), " max |dx*|", float(np.nanmax(np.abs(rg["best_point"] - ro["best_point"]))))
     print("  grad dev", np.asarray(rg["grad"]).ravel()[:4], "orc", np.asarray(ro["grad"]).ravel()[:4])
+    off = np.nonzero(np.abs(rg["best_point"] - ro["best_point"]).max(axis=1) > 1e-6)[0]
+    for i in off[:4]:
+        print("  sample", int(i), "dev x*", rg["best_point"][i], "\n             orc x*", ro["best_point"][i])
+if len(sys.argv) > 3:  # extra environment for a third run of the wave-per-sample kernel, e.g. MOE_KG_DOT_MAX_RADIUS2=0
+    for kv in sys.argv[3:]:
+        k, v = kv.split("=")
+        os.environ[k] = v
+    os.environ["MOE_KG_VARIANT"] = "0"
+    rg = G.kg(gd, bounds, disc, w.Xq, Xp, M, best, w.kg_normals, num_fidelity=f, want_best_points=True)
+    off = np.nonzero(np.abs(rg["best_point"] - ro["best_point"]).max(axis=1) > 1e-6)[0]
+    print("with", sys.argv[3:], ": kg dev", rg["kg"], "orc", ro["kg"], "samples off:", off)

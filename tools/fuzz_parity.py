@@ -1,6 +1,8 @@
 """Randomised parity sweep on the GPU: random shapes / kernels / derivative sets / fidelity dimensions / optimiser settings,
 device q-KG and q-EI against the plain-C oracle on the same normal tables.  Prints every violation of the stated tolerances.
-    python tools/fuzz_parity.py [num_cases] [seed]"""
+    python tools/fuzz_parity.py [num_cases] [seed] [n_max = 300] [d_max = 16] [g_max = 4]
+(n_max > 256 reaches the wave-per-sample kernel's many-tile instantiation and its multi-trial passes; d_max up to 32 and g_max up to
+12 reach the wide-dimension and 8 / 12-slot instantiations)"""
 import os
 import sys
 
@@ -16,17 +18,17 @@ from oracle import orc  # noqa: E402
 
 
 
-def run(num_cases, seed):
+def run(num_cases, seed, n_max=300, d_max=16, g_max=4):
   rng = np.random.default_rng(seed)
   bad = 0
   for case in range(num_cases):
-      d = int(rng.integers(1, 17))
-      g = int(rng.integers(0, min(4, d) + 1)) if rng.uniform() < 0.5 else 0
+      d = int(rng.integers(1, d_max + 1))
+      g = int(rng.integers(0, min(g_max, d) + 1)) if rng.uniform() < 0.5 else 0
       derivs = tuple(int(v) for v in rng.permutation(d)[:g])
-      umax = 64 // (1 + g)
+      umax = (64 if g_max <= 4 else 128) // (1 + g)
       q = int(rng.integers(1, min(4, umax) + 1))
       p = int(rng.integers(0, min(3, umax - q) + 1))
-      n = int(rng.integers(1, 300))
+      n = int(rng.integers(1, n_max))
       P = int(rng.integers(1, 13))
       M = int(rng.integers(1, 65))
       cov = int(rng.integers(0, 2))
@@ -58,7 +60,13 @@ def run(num_cases, seed):
       scale = max(float(np.abs(ro["grad"]).max()), abs(ro["kg"]), 1e-6)
       for variant in ("0", "1"):
           os.environ["MOE_KG_VARIANT"] = variant
-          rg = G.kg(gd, bounds, disc, w.Xq, Xp, M, best, w.kg_normals, num_fidelity=f, want_best_points=True)
+          try:
+              rg = G.kg(gd, bounds, disc, w.Xq, Xp, M, best, w.kg_normals, num_fidelity=f, want_best_points=True)
+          except api.OptimalLearningException as e:
+              # a FORCED kernel that cannot hold the point set (d > 16: all tiles in LDS only) refuses loudly -- not a parity case
+              if variant == "1" and "too large" in str(e):
+                  continue
+              raise
           # beyond the production depth of the inner optimiser (6 steps x 1 restart) samples reach stationary points where
           # accept / restart decisions hinge on differences below rounding: two correct FP64 implementations -- the
           # restatement and the reference itself -- then differ by ~1e-7 on x* and grad KG (tests/helpers.py kg_tolerances;
@@ -91,5 +99,6 @@ def run(num_cases, seed):
 
 
 if __name__ == "__main__":
-  sys.exit(1 if run(int(sys.argv[1]) if len(sys.argv) > 1 else 100, int(sys.argv[2]) if len(sys.argv) > 2 else 2026) else 0)
+  a = [int(v) for v in sys.argv[1:]]
+  sys.exit(1 if run(*a) else 0)
 
