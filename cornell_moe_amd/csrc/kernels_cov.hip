@@ -179,10 +179,13 @@ __global__ __launch_bounds__(kCovRows) void cov_build_value_kernel(CovParams cp,
 template <int DP, bool DERIVS>
 __global__ __launch_bounds__(256) void grad_kstar_kernel(CovParams cp, const double* __restrict__ X, int n, DerivList dX,
                                                         const double* __restrict__ P, int nP, DerivList dP,
-                                                        double* __restrict__ out, long ld, long col0) {
+                                                        double* __restrict__ out, long ld, long col0, int pts_per_block) {
   extern __shared__ double Ps[];  // [nP][DP]
   for (int t = threadIdx.x; t < nP * DP; t += blockDim.x) Ps[t] = P[t];
   __syncthreads();
+  // grid.y cuts the points into runs of pts_per_block: with a thread per training row alone, 8000 rows are 32 workgroups that
+  // each walk every point and column serially (336 us for two C5 evaluations' 768 columns, 0.15 TB/s)
+  const int i_lo = blockIdx.y * pts_per_block, i_hi = min(nP, i_lo + pts_per_block);
   const int g = DERIVS ? dX.g : 0, gt = DERIVS ? dP.g : 0;
   const int rows = n * (1 + g);
   const int r = blockIdx.x * blockDim.x + threadIdx.x;
@@ -192,7 +195,7 @@ __global__ __launch_bounds__(256) void grad_kstar_kernel(CovParams cp, const dou
   double xj[DP];
 #pragma unroll
   for (int k = 0; k < DP; ++k) xj[k] = X[(long)j * DP + k];
-  for (int i = 0; i < nP; ++i) {
+  for (int i = i_lo; i < i_hi; ++i) {
     double diff[DP];  // p1 - p2 = P_i - X_j
     double r2 = 0.0;
 #pragma unroll
@@ -310,18 +313,21 @@ void grad_kstar_dp(const CovParams& cp, const double* X, int n, const DerivList&
   const bool derivs = dX.g > 0 || dP.g > 0;
   const int rows = n * (1 + dX.g);
   if (rows == 0 || nP == 0) return;
-  dim3 grid((rows + 255) / 256);
   constexpr int kChunk = 256;  // points staged in LDS per launch (batched states pass E * nd points)
   for (int p0 = 0; p0 < nP; p0 += kChunk) {
     const int np = std::min(kChunk, nP - p0);
+    const int row_blocks = (rows + 255) / 256;
+    const int slices = std::min(np, std::max(1, 1024 / row_blocks));  // ~4 workgroups per CU
+    const int ppb = (np + slices - 1) / slices;
+    dim3 grid(row_blocks, (np + ppb - 1) / ppb);
     const size_t shm = sizeof(double) * (size_t)np * DP;
     const long c0 = col0 + (long)p0 * (1 + dP.g) * cp.dim;
     if (derivs)
       hipLaunchKernelGGL((grad_kstar_kernel<DP, true>), grid, dim3(256), shm, s, cp, X, n, dX, P + (long)p0 * DP, np, dP, out,
-                         ld, c0);
+                         ld, c0, ppb);
     else
       hipLaunchKernelGGL((grad_kstar_kernel<DP, false>), grid, dim3(256), shm, s, cp, X, n, dX, P + (long)p0 * DP, np, dP, out,
-                         ld, c0);
+                         ld, c0, ppb);
   }
 }
 

@@ -302,15 +302,30 @@ __global__ __launch_bounds__(256) void gram_batch_kernel(GramMap gm, int K, cons
   const int i0 = blockIdx.x * T, j0 = blockIdx.y * T;
   const int tx = threadIdx.x % 16, ty = threadIdx.x / 16;
   double acc[2][2] = {{0.0, 0.0}, {0.0, 0.0}};
-  for (int k0 = k_begin; k0 < k_end; k0 += TK) {
-    for (int t = threadIdx.x; t < TK * T; t += 256) {
+  // (the next stage's columns travel global -> registers while the current stage is multiplied out of LDS: see tile_gemm_kernel)
+  constexpr int NE = TK * T / 256;
+  double pa[NE], pb[NE];
+  auto fetch = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < NE; ++i) {
+      const int t = threadIdx.x + i * 256;
       const int kk = t % TK, ii = t / TK;
       const int gk = k0 + kk;
       const int gi = i0 + ii, gj = j0 + ii;
-      As[kk][ii] = (gi < c && gk < k_end) ? V[(long)gk + gm.col(e, gi) * ldv] : 0.0;
-      Bs[kk][ii] = (gj < c && gk < k_end) ? V[(long)gk + gm.col(e, gj) * ldv] : 0.0;
+      pa[i] = (gi < c && gk < k_end) ? V[(long)gk + gm.col(e, gi) * ldv] : 0.0;
+      pb[i] = (gj < c && gk < k_end) ? V[(long)gk + gm.col(e, gj) * ldv] : 0.0;
+    }
+  };
+  if (k_begin < k_end) fetch(k_begin);
+  for (int k0 = k_begin; k0 < k_end; k0 += TK) {
+#pragma unroll
+    for (int i = 0; i < NE; ++i) {
+      const int t = threadIdx.x + i * 256;
+      As[t % TK][t / TK] = pa[i];
+      Bs[t % TK][t / TK] = pb[i];
     }
     __syncthreads();
+    if (k0 + TK < k_end) fetch(k0 + TK);
 #pragma unroll
     for (int kk = 0; kk < TK; ++kk) {
       const double a0 = As[kk][tx], a1 = As[kk][tx + 16], b0 = Bs[kk][ty], b1 = Bs[kk][ty + 16];

@@ -1041,6 +1041,13 @@ KgPending kg_launch(GpDev& gp, int num_fidelity, const moe_gd_params_t& gd, cons
       grad_mu[e].resize((size_t)q * d);
       for (int k = 0; k < q; ++k)
         for (int dd = 0; dd < d; ++dd) grad_mu[e][(size_t)k * d + dd] = gm[dd + (size_t)k * g1 * d];  // .cpp:136-140
+      // (Mk is only read when the results are collected: it is formed below, AFTER the kernels are enqueued, while they run)
+    }
+  }
+  auto form_mk = [&]() {
+    for (int e = 0; e < E; ++e) {
+      const StateHost& sh = hosts[e];
+      const double* chol = &blob[(size_t)rec.stride * e] + rec.L;
       Mk[e].assign((size_t)q * d * m * m, 0.0);
       std::vector<double> gc((size_t)d * m * m), col(m);
       for (int k = 0; k < q; ++k) {
@@ -1055,7 +1062,7 @@ KgPending kg_launch(GpDev& gp, int num_fidelity, const moe_gd_params_t& gd, cons
         }
       }
     }
-  }
+  };
 
   // ---- device buffers ----
   DevBuf<double>&dBlob = gp.kBlob, &dNormals = gp.kNormals, &dTab = gp.kTab, &dBestPoint = gp.kBestPoint,
@@ -1266,6 +1273,9 @@ KgPending kg_launch(GpDev& gp, int num_fidelity, const moe_gd_params_t& gd, cons
     bp_p->resize((size_t)num_local * dp);
     dBestPoint.download(bp_p->data(), bp_p->size(), s);
   }
+  // host algebra that only the collection needs: L^-1 dL/dXq per point and dimension (O(q d m^3): ~1 ms per evaluation at C5),
+  // overlapped with the kernels enqueued above
+  if (want_grad) form_mk();
   GpDev* gpp = &gp;
   KgPending pending;
   pending.collect = [=](double* kg_sum, double* grad_sum, double* best_points, moe_kg_stats_t* stats) {
