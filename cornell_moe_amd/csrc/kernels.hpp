@@ -66,6 +66,10 @@ void launch_tri_gemm_skinny(char op, int N, int c, const double* T, long ldt, co
 // C[m x n] (ldc) = A^T B, A is K x m (lda), B is K x n (ldb); reduction over the K rows.
 void launch_gemm_tn(int m, int n, int K, const double* A, long lda, const double* B, long ldb, double* C, long ldc,
                     hipStream_t s);
+// The same with K cut into `slices` partial products (summed in slice order): skinny outputs over a long K.  C is m x n with
+// leading dimension m; work holds slices * m * n doubles.
+void launch_gemm_tn_splitk(int m, int n, int K, const double* A, long lda, const double* B, long ldb, double* C, double* work,
+                           int slices, hipStream_t s);
 
 // Batched Gram matrices over column groups of V (K x *, ldv): for eval e, G_e[c x c] (ld c, eval stride c*c) = V_e^T V_e
 // where V_e's column `l` is V's column  l < m ? e*m + l : l < m+ng ? E*m + e*ng + (l-m) : E*(m+ng) + e*A + (l-m-ng).

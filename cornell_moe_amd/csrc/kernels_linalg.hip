@@ -137,6 +137,18 @@ __global__ __launch_bounds__(256) void mfma_gemm_kernel(int M, int Ncols, int K,
   // the grid is resident from the start, so nothing rebalances a CU that drew long rows (measured: a third of the matrix
   // peak).  With pair_rows a workgroup does row tile p AND its mirror R - 1 - p, one after the other: every workgroup then
   // walks the same number of K steps.  Without it row indices are scattered (multiplier co-prime with the row count).
+  // Split K (MODE 0 only, gridDim.z slices): slice z multiplies rows [z ks, (z + 1) ks) of both operands into the z-th of gridDim.z
+  // partial results stacked behind C (ldc * Ncols doubles apart); launch_gemm_tn_splitk adds them in slice order.  For a skinny
+  // output with a long K (S_W = W^T T of the d-KG tail: 32 x 20 000 over K = 8000) the unsplit grid is one workgroup per CU walking
+  // 500 stages with one stage of loads in flight -- latency-bound at a third of what HBM delivers.
+  if (MODE == 0 && gridDim.z > 1) {
+    const int ks = ((K + (int)gridDim.z - 1) / (int)gridDim.z + TK - 1) / TK * TK;
+    const int kb = (int)blockIdx.z * ks;
+    A += kb;
+    B += kb;
+    K = max(0, min(ks, K - kb));
+    C += (long)blockIdx.z * ldc * Ncols;
+  }
   const int R = (M + TM - 1) / TM;
   const int j0 = blockIdx.x * TN;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -683,6 +695,34 @@ __global__ __launch_bounds__(256) void gemv_t_kernel(int K, const double* __rest
   if (threadIdx.x == 0) out[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 }  // namespace
+
+namespace {
+__global__ __launch_bounds__(256) void sum_slices_kernel(const double* __restrict__ part, int slices, long count,
+                                                        double* __restrict__ out) {
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= count) return;
+  double v = 0.0;
+  for (int z = 0; z < slices; ++z) v += part[(long)z * count + idx];  // slice order: fixed
+  out[idx] = v;
+}
+}  // namespace
+
+// C (m x n, ldc == m) = A^T B with K cut into `slices` (mfma_gemm_kernel's split-K); work holds slices * m * n doubles.
+void launch_gemm_tn_splitk(int m, int n, int K, const double* A, long lda, const double* B, long ldb, double* C, double* work,
+                           int slices, hipStream_t s) {
+  if (m <= 0 || n <= 0) return;
+  const dim3 mgrid((n + 63) / 64, (m + 63) / 64, slices);
+  int xmul = 1;
+  for (int cand : {37, 41, 43, 47, 53, 59})
+    if ((int)mgrid.y % cand != 0) {
+      xmul = cand;
+      break;
+    }
+  hipLaunchKernelGGL((mfma_gemm_kernel<0, false, 16>), mgrid, dim3(256), 0, s, m, n, K, A, lda, B, ldb, work, (long)m, xmul, 0);
+  const long count = (long)m * n;
+  hipLaunchKernelGGL(sum_slices_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, s, (const double*)work, slices, count, C);
+  MOE_HIP_CHECK(hipGetLastError());
+}
 
 void launch_gemm_tn(int m, int n, int K, const double* A, long lda, const double* B, long ldb, double* C, long ldc,
                     hipStream_t s) {

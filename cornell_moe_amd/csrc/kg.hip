@@ -1244,9 +1244,17 @@ KgPending kg_launch(GpDev& gp, int num_fidelity, const moe_gd_params_t& gd, cons
       // S_W = W_e^T T_e per evaluation as a tile GEMM (the one-wave-per-sample loop re-reads W from L2 for every sample,
       // N m 8 bytes each -- fine for q-KG's m = q + p, prohibitive for d-KG's m = (q + p)(1 + g))
       gp.kSW.reserve((size_t)m * E * num_local);
-      for (int e = 0; e < E; ++e)
-        launch_gemm_tn(m, num_local, N, tl.W + (long)e * tl.w_stride, N, dT.p + (size_t)e * num_local * N, N,
-                       gp.kSW.p + (size_t)e * num_local * m, m, s);
+      // (a skinny output over a long K: split K so that the chip holds several workgroups per CU -- kernels_linalg.hip)
+      const int sw_slices = (m <= 64 && N >= 2048) ? 8 : 1;
+      if (sw_slices > 1) gp.kSWpart.reserve((size_t)sw_slices * m * num_local);
+      for (int e = 0; e < E; ++e) {
+        if (sw_slices > 1)
+          launch_gemm_tn_splitk(m, num_local, N, tl.W + (long)e * tl.w_stride, N, dT.p + (size_t)e * num_local * N, N,
+                                gp.kSW.p + (size_t)e * num_local * m, gp.kSWpart.p, sw_slices, s);
+        else
+          launch_gemm_tn(m, num_local, N, tl.W + (long)e * tl.w_stride, N, dT.p + (size_t)e * num_local * N, N,
+                         gp.kSW.p + (size_t)e * num_local * m, m, s);
+      }
       tl.SW = gp.kSW.p;
     }
     launch_tail(tl, s);
