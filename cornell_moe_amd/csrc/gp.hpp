@@ -33,7 +33,7 @@ struct GpDev {
   DevBuf<double> dPts, dPtsGrad, dExtra, dE, dVE, dWE, dGram, dEK, dStateIn;
   PinnedBuf<double> hStateIn, hStateOut, hKgIn, hKgOut;  // pinned staging for the per-call operands / results
   // reusable workspaces of the KG evaluator (kg.hip)
-  DevBuf<double> kBlob, kNormals, kTab, kBestPoint, kBestValue, kBeta, kT, kC, kTB, kOut, kSW, kSWpart, kV;
+  DevBuf<double> kBlob, kNormals, kTab, kBestPoint, kBestValue, kBeta, kT, kC, kTB, kOut, kSW, kSWpart, kZcPart, kV;
   DevBuf<unsigned long long> kCounters;
   DevBuf<int> kBestJ;
   int num_cu = 256;

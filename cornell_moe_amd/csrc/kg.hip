@@ -288,6 +288,63 @@ __global__ __launch_bounds__(256) void kg_zc_kernel(KgTailParams P) {
   }
 }
 
+// The same sums for m <= 64 without the strided sample walk (one workgroup per (r, j) reading c_i[j] every m doubles: 254 us for two
+// C5 evaluations): a workgroup takes a chunk of kZcChunk samples, stages their z and c rows in LDS with coalesced loads and forms all
+// m x m partial products; kg_zc_sum_kernel adds the chunk partials in chunk order and forms kg_sum exactly as kg_sum_kernel does.
+constexpr int kZcChunk = 64;  // samples per chunk (32 for m > 32: the two staged blocks stay within 32 KB)
+inline int zc_chunk_len(int m) { return m > 32 ? kZcChunk / 2 : kZcChunk; }
+__global__ __launch_bounds__(256) void kg_zc_part_kernel(KgTailParams P, double* __restrict__ part, int chunks, int len) {
+  extern __shared__ __attribute__((aligned(16))) double zc_sm[];  // z [len][m] | c [len][m]
+  const int chunk = blockIdx.x, e = blockIdx.y, m = P.m;
+  const int i0 = chunk * len, cnt = min(len, P.num_local - i0);
+  double* zs = zc_sm;
+  double* cs = zc_sm + len * m;
+  for (int t = threadIdx.x; t < cnt * m; t += 256) {
+    const int ii = t / m, r = t - ii * m;
+    const int s = P.first_sample + i0 + ii;
+    zs[t] = ((s & 1) ? -1.0 : 1.0) * P.normals[(long)(s >> 1) * m + r];
+    cs[t] = P.C[((long)e * P.num_local + i0 + ii) * m + r];
+  }
+  __syncthreads();
+  for (int o = threadIdx.x; o < m * m; o += 256) {
+    const int r = o % m, j = o / m;
+    double acc = 0.0;
+#pragma unroll 4
+    for (int ii = 0; ii < cnt; ++ii) acc = fma(zs[ii * m + r], cs[ii * m + j], acc);
+    part[((long)e * chunks + chunk) * m * m + o] = acc;
+  }
+}
+
+__global__ __launch_bounds__(256) void kg_zc_sum_kernel(KgTailParams P, const double* __restrict__ part, int chunks) {
+  __shared__ double red[4];
+  const int e = blockIdx.y, m = P.m;
+  const int o = blockIdx.x * 256 + threadIdx.x;
+  double* out = P.out + (long)e * P.out_stride;
+  if (o < m * m) {
+    const double* p = part + (long)e * chunks * m * m + o;
+    double v = 0.0;
+#pragma unroll 8
+    for (int ch = 0; ch < chunks; ++ch) v += p[(long)ch * m * m];
+    out[1 + o] = v;
+  }
+  if (blockIdx.x == 0) {  // kg_sum = sum_i (best_posterior + best_value_i): the summation of kg_sum_kernel, bit for bit
+    const double bp = P.blob[(long)e * P.rec.stride + P.rec_bp];
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < P.num_local; i += 256) acc += bp + P.best_value[(long)e * P.num_local + i];
+    const double tot = block_sum_256(acc, red);
+    if (threadIdx.x == 0) out[0] = tot;
+  }
+}
+
+// host side of the two: part = E * chunks * m * m doubles of workspace
+void launch_zc(const KgTailParams& P, double* part, hipStream_t s) {
+  const int len = zc_chunk_len(P.m);
+  const int chunks = (P.num_local + len - 1) / len;
+  const size_t shm = sizeof(double) * 2 * len * P.m;
+  hipLaunchKernelGGL(kg_zc_part_kernel, dim3(chunks, P.E), dim3(256), shm, s, P, part, chunks, len);
+  hipLaunchKernelGGL(kg_zc_sum_kernel, dim3((P.m * P.m + 255) / 256, P.E), dim3(256), 0, s, P, (const double*)part, chunks);
+}
+
 // DIR[e][(k (1+g) + b) d + dd] = sum_i beta_i[(k,b)] * d cov(Xu_k, x*_i)[b, 0] / d Xu_k,dd ; workgroup (k, e).
 template <int DP>
 __global__ __launch_bounds__(256) void kg_dir_kernel(KgTailParams P, double* __restrict__ part, int slices) {
@@ -1233,7 +1290,12 @@ KgPending kg_launch(GpDev& gp, int num_fidelity, const moe_gd_params_t& gd, cons
     const int slices = fused_tail_slices(E, num_local, n, num_cu);
     gp.kSW.reserve((size_t)E * num_local * slices * 8);  // [E][num_local][slices][MU <= 8]
     launch_fused_tail(tl, gp.dX.p, n, gp.kSW.p, slices, s);
-    hipLaunchKernelGGL(kg_zc_kernel, dim3(m, m, E), dim3(256), 0, s, tl);
+    if (m <= 64) {
+      gp.kZcPart.reserve((size_t)E * ((num_local + zc_chunk_len(m) - 1) / zc_chunk_len(m)) * m * m);
+      launch_zc(tl, gp.kZcPart.p, s);
+    } else {
+      hipLaunchKernelGGL(kg_zc_kernel, dim3(m, m, E), dim3(256), 0, s, tl);
+    }
     t_tail.stop(s);
   } else if (want_grad) {
     t_cov.start(s);
@@ -1258,7 +1320,12 @@ KgPending kg_launch(GpDev& gp, int num_fidelity, const moe_gd_params_t& gd, cons
       tl.SW = gp.kSW.p;
     }
     launch_tail(tl, s);
-    hipLaunchKernelGGL(kg_zc_kernel, dim3(m, m, E), dim3(256), 0, s, tl);
+    if (m <= 64) {
+      gp.kZcPart.reserve((size_t)E * ((num_local + zc_chunk_len(m) - 1) / zc_chunk_len(m)) * m * m);
+      launch_zc(tl, gp.kZcPart.p, s);
+    } else {
+      hipLaunchKernelGGL(kg_zc_kernel, dim3(m, m, E), dim3(256), 0, s, tl);
+    }
     t_tail.stop(s);
   } else {
     hipLaunchKernelGGL(kg_sum_kernel, dim3(E), dim3(256), 0, s, tl);
