@@ -87,7 +87,9 @@ def test_kg_against_oracle(case, monkeypatch):
         assert mism.mean() <= 0.002, (variant, mism.mean())  # <= 0.2 % of the samples
         assert rg["grad_evals"] == ro["grad_evals"] and rg["mean_evals"] <= ro["mean_evals"]
         rv = G.kg(gd, w.bounds_inner, w.discrete, w.Xq, Xp, w.M, best, w.kg_normals, num_fidelity=f, want_grad=False)
-        assert rv["kg_sum"] == rg["kg_sum"]
+        # (the same MC kernel on the same operands; the state set-up of the value-only call has fewer columns, and where that
+        #  moves its L^-1 products from the MFMA GEMM to the tile GEMM the operands differ in the last bits)
+        assert abs(rv["kg_sum"] - rg["kg_sum"]) <= 1e-13 * abs(rg["kg_sum"])
         # two even-aligned MC shards add up to the whole
         h = 2 * ((w.M // 2 + 1) // 2)
         if 0 < h < w.M:
