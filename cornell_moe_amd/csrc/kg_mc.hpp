@@ -1070,6 +1070,8 @@ __device__ __forceinline__ double line_search_lds(const KgMcParams& P, EV& ev, d
   double* sG = st + kMaxDimPadded;
   double* sS = st + 2 * kMaxDimPadded;
   double* sX0 = st + 3 * kMaxDimPadded;
+  double* sF = st + 4 * kMaxDimPadded;  // x0 of the trial line, frame coordinates
+  double* sD = st + 5 * kMaxDimPadded;  // its direction dv
   double fcur = 0.0;
   if (P.max_num_restarts <= 0) {
 #pragma unroll
@@ -1108,15 +1110,19 @@ __device__ __forceinline__ double line_search_lds(const KgMcParams& P, EV& ev, d
       // looked at if all earlier ones failed, and only consumed trials are counted.  A trial that would need clamp_query
       // (millions of length scales away) sends the batch down the two-point path, which clamps.
       {
-        double x0f[DP], dv[DP];
+        // (x0 and dv go to the wave's LDS scratch and are read back inside each pass: as register arrays they stayed live
+        //  across the passes of the bracket -- 48 VGPRs of wave-uniform data next to the register tiles -- and the kernel's
+        //  scratch-memory spills sat exactly in this code between the passes)
         double dd = 0.0, q0 = 0.0, qa = 0.0;
 #pragma unroll
         for (int r = 0; r < DP; ++r) {
-          x0f[r] = to_frame(P, sX[r], r);
-          dv[r] = sG[r] * P.inv_lp[r];
-          dd = fma(dv[r], dv[r], dd);
-          q0 = fma(x0f[r], x0f[r], q0);
-          const double xa = fma(alpha_n, dv[r], x0f[r]);
+          const double x0r = to_frame(P, sX[r], r);
+          const double dvr = sG[r] * P.inv_lp[r];
+          sF[r] = x0r;
+          sD[r] = dvr;
+          dd = fma(dvr, dvr, dd);
+          q0 = fma(x0r, x0r, q0);
+          const double xa = fma(alpha_n, dvr, x0r);
           qa = fma(xa, xa, qa);
         }
         // (|x0 + alpha dv|^2 is convex in alpha: the two ends bound every trial of the bracket)
@@ -1126,7 +1132,7 @@ __device__ __forceinline__ double line_search_lds(const KgMcParams& P, EV& ev, d
         while (!done) {
           const int want = min(batch, 30 - search);
           if (near && want >= 2) {
-            ev.armijo_batch(want, x0f, dv, dd, f0, norm, alpha_n, search, ftrial, done, n_val);
+            ev.armijo_batch(want, sF, sD, dd, f0, norm, alpha_n, search, ftrial, done, n_val);
           } else {
             const double a1 = alpha_n, a2 = 0.5 * alpha_n;
             double tqb[DP], f1, f2;
@@ -1688,8 +1694,15 @@ struct BlockEval {
   // checked that no trial needs clamp_query.
   static constexpr int kMaxTrials = 5;
   template <int T>
-  __device__ __forceinline__ void armijo_t(const double (&x0)[DP], const double (&dv)[DP], double dd, double f0, double norm,
-                                           double& alpha_n, int& search, double& ftrial, bool& done, unsigned long long& n_val) {
+  __device__ __forceinline__ void armijo_t(const double* __restrict__ x0p, const double* __restrict__ dvp, double dd, double f0,
+                                           double norm, double& alpha_n, int& search, double& ftrial, bool& done,
+                                           unsigned long long& n_val) {
+    double x0[DP], dv[DP];  // (from the wave's LDS scratch: see line_search_lds)
+#pragma unroll
+    for (int k = 0; k < DP; ++k) {
+      x0[k] = x0p[k];
+      dv[k] = dvp[k];
+    }
     double al[T], acc[T];
 #pragma unroll
     for (int t = 0; t < T; ++t) {
@@ -1743,8 +1756,8 @@ struct BlockEval {
       }
     }
   }
-  __device__ __forceinline__ void armijo_batch(int want, const double (&x0)[DP], const double (&dv)[DP], double dd, double f0,
-                                               double norm, double& alpha_n, int& search, double& ftrial, bool& done,
+  __device__ __forceinline__ void armijo_batch(int want, const double* __restrict__ x0, const double* __restrict__ dv, double dd,
+                                               double f0, double norm, double& alpha_n, int& search, double& ftrial, bool& done,
                                                unsigned long long& n_val) {
     switch (want) {
       case 2: armijo_t<2>(x0, dv, dd, f0, norm, alpha_n, search, ftrial, done, n_val); break;
@@ -1976,19 +1989,20 @@ __device__ __forceinline__ void point_weights_pre(const KgMcParams& P, const dou
 }
 
 // Fixed LDS words of the workgroup-per-sample kernel (doubles), before the tile data.
-constexpr int kBlockFixed = kExpTabLen + 2 * kMaxMB + 2 * kMaxBlockWaves * kPartLen + 2 + kMaxBlockWaves * 4 * kMaxDimPadded;
+constexpr int kLsRows = 6;  // line-search vectors per wave in LDS: x | masked gradient | step | x at restart start | x0 and dv of the trial line (frame)
+constexpr int kBlockFixed = kExpTabLen + 2 * kMaxMB + 2 * kMaxBlockWaves * kPartLen + 2 + kMaxBlockWaves * kLsRows * kMaxDimPadded;
 
 template <int DP, int G, int TR>
 __global__ __launch_bounds__(512) void kg_mc_block_kernel(KgMcParams P, int num_lds_tiles) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   // LDS: [64] exp table | z / beta scratch of draw_z_beta [0, 2 kMaxM) = [0, kMaxMB), beta of the sample [kMaxMB, 2 kMaxMB) |
   //      partial slots [2][8][kPartLen] | control words (2 doubles) |
-  //      line-search state [8][4 kMaxDimPadded] | coordinates of the LDS tiles [T_L][DP][64] | their weights [T_L][1+G][64]
+  //      line-search state [8][kLsRows kMaxDimPadded] | coordinates of the LDS tiles [T_L][DP][64] | their weights [T_L][1+G][64]
   double* etab = smem;
   double* zb = smem + kExpTabLen;
   double* part = zb + 2 * kMaxMB;
   int* ctl = reinterpret_cast<int*>(part + 2 * kMaxBlockWaves * kPartLen);  // [0] sample index, [1] best discretised point
-  double* stw = part + 2 * kMaxBlockWaves * kPartLen + 2 + (threadIdx.x >> 6) * (4 * kMaxDimPadded);
+  double* stw = part + 2 * kMaxBlockWaves * kPartLen + 2 + (threadIdx.x >> 6) * (kLsRows * kMaxDimPadded);
   double* ldsx = smem + kBlockFixed;
   double* ldsw = ldsx + (long)num_lds_tiles * DP * 64;
   const int lane = threadIdx.x & 63;
