@@ -230,6 +230,23 @@ __device__ __forceinline__ void wave_sum_packed(const double (&v)[N], double (&o
   }
 }
 
+// dst[i] = sum over the 64 lanes of v[i], i < N (N padded to a multiple of four with zeros): the packed folds above, the four row
+// sums of a group written straight to memory by the first lane of each row -- for callers that only need the sums in LDS (the
+// workgroup-per-sample kernel's per-wave partial slots: 16 sums cost 4 folds + 4 in-row reductions instead of 16 full ones).
+template <int N>
+__device__ __forceinline__ void wave_sum_packed_store(const double (&v)[N], double* __restrict__ dst, int lane) {
+  constexpr int NP = (N + 3) / 4 * 4;
+  const int row = lane >> 4;
+  const int slot = ((row & 1) << 1) | (row >> 1);  // rows hold v0 | v2 | v1 | v3
+#pragma unroll
+  for (int i = 0; i < NP; i += 4) {
+    const double a = v[i], b = (i + 1 < N) ? v[i + 1 < N ? i + 1 : 0] : 0.0, c = (i + 2 < N) ? v[i + 2 < N ? i + 2 : 0] : 0.0,
+                 d = (i + 3 < N) ? v[i + 3 < N ? i + 3 : 0] : 0.0;
+    const double q = row_sum(fold16(fold32(a, b), fold32(c, d)));
+    if ((lane & 15) == 0 && i + slot < N) dst[i + slot] = q;
+  }
+}
+
 __device__ __forceinline__ double uniform(double v) {
   // all lanes hold the same bits after a butterfly; tell the compiler so (value moves to SGPRs, branches become scalar)
   const int lo = __builtin_amdgcn_readfirstlane(__double2loint(v));
@@ -1716,11 +1733,7 @@ struct BlockEval {
       accumulateT<MOE_COV_MATERN_NU_2P5, T>(x0, dv, al, dd, acc);
     MOE_PROF_T(t1);
     double* slot = part + (par * kMaxBlockWaves + wave) * kPartLen;
-#pragma unroll
-    for (int t = 0; t < T; ++t) {
-      const double sv = wave_sum_uniform(acc[t]);
-      if (lane == 0) slot[t] = sv;
-    }
+    wave_sum_packed_store<T>(acc, slot, lane);
     MOE_PROF_T(t2);
     __syncthreads();
     MOE_PROF_T(t3);
@@ -1830,21 +1843,19 @@ struct BlockEval {
       accumulate<WG, MOE_COV_MATERN_NU_2P5>(xq, accf, accg, accd);
     MOE_PROF_T(t1);
     double* slot = part + (par * kMaxBlockWaves + wave) * kPartLen;
-    const double sf = wave_sum_uniform(accf);
-    if (lane == 0) slot[0] = sf;
     if (WG) {
+      double all_sums[1 + DP + (G > 0 ? G : 0)];  // f | gradient sums | derivative-weight sums: one packed reduction
+      all_sums[0] = accf;
 #pragma unroll
-      for (int k = 0; k < DP; ++k) {
-        const double v = wave_sum_uniform(accg[k]);
-        if (lane == 0) slot[1 + k] = v;
-      }
+      for (int k = 0; k < DP; ++k) all_sums[1 + k] = accg[k];
       if (G > 0) {
 #pragma unroll
-        for (int a = 0; a < G; ++a) {
-          const double v = wave_sum_uniform(accd[a]);
-          if (lane == 0) slot[1 + DP + a] = v;
-        }
+        for (int a = 0; a < G; ++a) all_sums[1 + DP + a] = accd[a];
       }
+      wave_sum_packed_store<1 + DP + (G > 0 ? G : 0)>(all_sums, slot, lane);
+    } else {
+      const double sf = wave_sum_uniform(accf);
+      if (lane == 0) slot[0] = sf;
     }
     MOE_PROF_T(t2);
     __syncthreads();
