@@ -1035,7 +1035,9 @@ KgPending kg_launch(GpDev& gp, int num_fidelity, const moe_gd_params_t& gd, cons
   const int rec_bp = take(1);
   rec.Mk = 0;
   rec.stride = off;
-  std::vector<double> blob((size_t)rec.stride * E + 2 * kMaxDimPadded, 0.0);
+  // behind the records: [2 kMaxDimPadded] bounds | [kMaxDimPadded] frame centre | [kMaxDimPadded] frame scale, table-row order
+  // (the MC kernels read them one row per lane)
+  std::vector<double> blob((size_t)rec.stride * E + 4 * kMaxDimPadded, 0.0);
   const size_t o_bounds = (size_t)rec.stride * E;
   unsigned int free_mask = 0;  // table-row order: bounds of row r = bounds of original dimension perm[r]
   for (int r = 0; r < kMaxDimPadded; ++r) {
@@ -1045,6 +1047,8 @@ KgPending kg_launch(GpDev& gp, int num_fidelity, const moe_gd_params_t& gd, cons
       blob[o_bounds + 2 * r + 1] = bounds[2 * k + 1];
       free_mask |= 1u << r;
     }
+    blob[o_bounds + 2 * kMaxDimPadded + r] = tp.center[r];
+    blob[o_bounds + 3 * kMaxDimPadded + r] = tp.inv_lp[r];
   }
   std::vector<int> winner(E, -1);
   std::vector<double> best_posterior(E, best_so_far);

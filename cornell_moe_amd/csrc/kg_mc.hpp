@@ -1083,6 +1083,12 @@ __device__ __forceinline__ double line_search_lds(const KgMcParams& P, EV& ev, d
   const double step_tolerance = P.tolerance / (double)P.max_num_steps;
   const int lane_id = (int)(threadIdx.x & 63u);
   const double lo_l = P.bounds[2 * (lane_id < DP ? lane_id : 0)], hi_l = P.bounds[2 * (lane_id < DP ? lane_id : 0) + 1];
+  // frame centre and scale of this lane's row (behind the bounds in the blob): the conversions into the frame are done one row
+  // per lane and handed over through the wave's LDS scratch -- as wave-uniform arithmetic on KgMcParams' arrays they kept ~50
+  // SGPRs live across the whole line search, and the scalar file's spills (v_readlane / v_writelane) were this kernel's most
+  // frequent instructions
+  const double c_l = P.bounds[2 * kMaxDimPadded + (lane_id < DP ? lane_id : 0)];
+  const double s_l = P.bounds[3 * kMaxDimPadded + (lane_id < DP ? lane_id : 0)];
   double* sX = st;
   double* sG = st + kMaxDimPadded;
   double* sS = st + 2 * kMaxDimPadded;
@@ -1106,9 +1112,8 @@ __device__ __forceinline__ double line_search_lds(const KgMcParams& P, EV& ev, d
 #pragma unroll
     for (int k = 0; k < DP; ++k) sX0[k] = sX[k];
     for (int istep = 0; istep < P.max_num_steps;) {
-#pragma unroll
-      for (int r = 0; r < DP; ++r) tqp[r] = to_frame(P, sX[r], r);
-      const double f0 = ev.template eval<true>(tqp, gp);
+      if (lane_id < DP) sF[lane_id] = (sX[lane_id] - c_l) * s_l;  // the iterate in the frame: this pass's query AND the trial line's x0
+      const double f0 = ev.template eval_p<true>(sF, gp);
       n_grad++;
       fcur = f0;
       double norm = 0.0;
@@ -1131,12 +1136,11 @@ __device__ __forceinline__ double line_search_lds(const KgMcParams& P, EV& ev, d
         //  across the passes of the bracket -- 48 VGPRs of wave-uniform data next to the register tiles -- and the kernel's
         //  scratch-memory spills sat exactly in this code between the passes)
         double dd = 0.0, q0 = 0.0, qa = 0.0;
+        if (lane_id < DP) sD[lane_id] = sG[lane_id] * s_l;
 #pragma unroll
         for (int r = 0; r < DP; ++r) {
-          const double x0r = to_frame(P, sX[r], r);
-          const double dvr = sG[r] * P.inv_lp[r];
-          sF[r] = x0r;
-          sD[r] = dvr;
+          const double x0r = sF[r];
+          const double dvr = sD[r];
           dd = fma(dvr, dvr, dd);
           q0 = fma(x0r, x0r, q0);
           const double xa = fma(alpha_n, dvr, x0r);
@@ -1192,9 +1196,8 @@ __device__ __forceinline__ double line_search_lds(const KgMcParams& P, EV& ev, d
       if (search == 30 || !nonzero) break;
       double obj2 = ftrial;
       if (changed) {
-#pragma unroll
-        for (int r = 0; r < DP; ++r) tqp[r] = to_frame(P, sX[r] + sS[r], r);
-        obj2 = ev.template eval<false>(tqp, gp);
+        if (lane_id < DP) sF[lane_id] = ((sX[lane_id] + sS[lane_id]) - c_l) * s_l;
+        obj2 = ev.template eval_p<false>(sF, gp);
         n_val++;
       }
       if (obj2 <= f0) break;
@@ -1823,6 +1826,15 @@ struct BlockEval {
 #if MOE_BLOCK_PROF
     c_n++;
 #endif
+  }
+
+  // the query read from the wave's LDS scratch (line_search_lds)
+  template <bool WG>
+  __device__ __forceinline__ double eval_p(const double* __restrict__ xq_ptr, double (&grad)[DP]) {
+    double xq[DP];
+#pragma unroll
+    for (int k = 0; k < DP; ++k) xq[k] = xq_ptr[k];
+    return eval<WG>(xq, grad);
   }
 
   template <bool WG>
