@@ -1087,6 +1087,7 @@ __device__ __forceinline__ double line_search_lds(const KgMcParams& P, EV& ev, d
   // per lane and handed over through the wave's LDS scratch -- as wave-uniform arithmetic on KgMcParams' arrays they kept ~50
   // SGPRs live across the whole line search, and the scalar file's spills (v_readlane / v_writelane) were this kernel's most
   // frequent instructions
+  const bool free_l = lane_id < DP && ((P.free_mask >> (lane_id & 31)) & 1u);
   const double c_l = P.bounds[2 * kMaxDimPadded + (lane_id < DP ? lane_id : 0)];
   const double s_l = P.bounds[3 * kMaxDimPadded + (lane_id < DP ? lane_id : 0)];
   double* sX = st;
@@ -1113,14 +1114,15 @@ __device__ __forceinline__ double line_search_lds(const KgMcParams& P, EV& ev, d
     for (int k = 0; k < DP; ++k) sX0[k] = sX[k];
     for (int istep = 0; istep < P.max_num_steps;) {
       if (lane_id < DP) sF[lane_id] = (sX[lane_id] - c_l) * s_l;  // the iterate in the frame: this pass's query AND the trial line's x0
-      const double f0 = ev.template eval_p<true>(sF, gp);
+      double g_l;
+      const double f0 = ev.eval_p_lane(sF, s_l, g_l);
       n_grad++;
       fcur = f0;
+      if (lane_id < DP) sG[lane_id] = free_l ? g_l : 0.0;  // fidelity / pad coordinates stay pinned
       double norm = 0.0;
 #pragma unroll
       for (int k = 0; k < DP; ++k) {
-        const double gk = ((P.free_mask >> k) & 1u) ? gp[k] : 0.0;
-        sG[k] = gk;
+        const double gk = sG[k];
         norm = fma(gk, gk, norm);
       }
       double alpha_n = (P.gamma == 0.0) ? P.pre_mult : P.pre_mult * pow((double)(istep + 1), -P.gamma);
@@ -1185,7 +1187,6 @@ __device__ __forceinline__ double line_search_lds(const KgMcParams& P, EV& ev, d
       bool changed, nonzero;
       {
         const int lk = lane_id < DP ? lane_id : 0;
-        const bool free_l = lane_id < DP && ((P.free_mask >> (lane_id & 31)) & 1u);
         const double want_l = alpha_n * sG[lk];
         double step_l = 0.0;
         if (free_l) step_l = limit_update_1d(lo_l, hi_l, P.max_relative_change, sX[lk], want_l);
@@ -1836,9 +1837,19 @@ struct BlockEval {
     for (int k = 0; k < DP; ++k) xq[k] = xq_ptr[k];
     return eval<WG>(xq, grad);
   }
+  // value + gradient with the gradient handed back ONE COMPONENT PER LANE (lane k < DP: d f / d x_k in the original units,
+  // scale_l = this lane's frame scale): the cross-wave sums are lane-distributed anyway, and fetching them as wave-uniform
+  // values cost 2 (1 + DP + G) v_readlane into a scalar file that was already spilling
+  __device__ __forceinline__ double eval_p_lane(const double* __restrict__ xq_ptr, double scale_l, double& grad_l) {
+    double xq[DP], unused[DP];
+#pragma unroll
+    for (int k = 0; k < DP; ++k) xq[k] = xq_ptr[k];
+    return eval<true, true>(xq, unused, scale_l, &grad_l);
+  }
 
-  template <bool WG>
-  __device__ __forceinline__ double eval(const double (&xq_in)[DP], double (&grad)[DP]) {
+  template <bool WG, bool LANEOUT = false>
+  __device__ __forceinline__ double eval(const double (&xq_in)[DP], double (&grad)[DP], double scale_l = 0.0,
+                                         double* grad_l = nullptr) {
     double accf = 0.0, accg[DP], accd[G > 0 ? G : 1];
     double xq[DP];
 #pragma unroll
@@ -1895,11 +1906,25 @@ struct BlockEval {
         return __hiloint2double(hi, lo);
       };
       f = take(0);
+      if (LANEOUT) {
+        auto from_lane = [&](int src) {  // comp of lane `src` (per-lane index): two ds_bpermute_b32
+          const int lo = __builtin_amdgcn_ds_bpermute(src << 2, __double2loint(comp));
+          const int hi = __builtin_amdgcn_ds_bpermute(src << 2, __double2hiint(comp));
+          return __hiloint2double(hi, lo);
+        };
+        double v = from_lane(min(lane + 1, 63));
+        if (G > 0) {
+          const double vd = from_lane(min(lane + 1 + DP, 63));
+          if (lane < G) v -= vd;
+        }
+        *grad_l = -(v * scale_l);
+      } else {
 #pragma unroll
-      for (int k = 0; k < DP; ++k) {
-        double v = take(1 + k);
-        if (G > 0 && k < G) v -= take(1 + DP + (k < G ? k : 0));
-        grad[k] = -(v * inv_lp[k]);
+        for (int k = 0; k < DP; ++k) {
+          double v = take(1 + k);
+          if (G > 0 && k < G) v -= take(1 + DP + (k < G ? k : 0));
+          grad[k] = -(v * inv_lp[k]);
+        }
       }
     } else {
       f = 0.0;
