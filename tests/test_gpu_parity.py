@@ -478,6 +478,43 @@ def test_point_per_thread_covariance_assembly_is_bit_identical(api, monkeypatch)
             assert np.array_equal(a, b)
 
 
+def test_one_handle_from_several_threads(api):
+    """A handle serialises its callers (per-handle mutex at the C ABI; ctypes drops the GIL for the duration of a call): four
+    threads issuing KG evaluations, posterior queries and EI on ONE GP get exactly the results of the same calls made one after
+    the other."""
+    import threading
+    from cornell_moe_amd.workloads import make_workload
+    w = make_workload(seed=77, n=120, d=3, q=2, M=64, P=5, derivs=(), num_restarts=6)
+    G = api.DeviceGP(w.hyperparameters, w.X, w.y, w.noise, ())
+    best = float(G.additional_mean(w.discrete).min())
+
+    def job(i):
+        kg = G.kg(w.inner_gd, w.bounds, w.discrete, w.Xq_restarts[i], None, w.M, best, w.kg_normals)
+        mu = G.mean(w.Xq_restarts[i])
+        ei = G.ei(w.Xq_restarts[i], None, w.M, best, w.ei_normals)
+        return kg["kg_sum"], kg["grad_sum"].copy(), mu.copy(), ei[0], ei[1].copy()
+
+    serial = [job(i) for i in range(6)]
+    out = [None] * 6
+    errors = []
+
+    def run(i):
+        try:
+            for _ in range(3):
+                out[i] = job(i)
+        except Exception as e:  # noqa: BLE001
+            errors.append(e)
+
+    threads = [threading.Thread(target=run, args=(i,)) for i in range(6)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    for a, b in zip(serial, out):
+        assert a[0] == b[0] and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2]) and a[3] == b[3] and np.array_equal(a[4], b[4])
+
+
 def test_fastmath(api):
     """Device exp(-x) / sqrt(x) (csrc/fastmath.hpp) vs numpy: <= 2 ulp over the ranges the covariance loops produce."""
     rng = np.random.default_rng(5)
