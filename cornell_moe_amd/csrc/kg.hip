@@ -1378,7 +1378,10 @@ KgPending kg_launch(GpDev& gp, int num_fidelity, const moe_gd_params_t& gd, cons
                      w[10], (double)w[9] / w[10], tot / (w[10] / 6.0), (double)(w[4] + w[5] + w[6] + w[7]) / (w[10] / 6.0));
       if (w[10] > 0)
         std::fprintf(stderr, "[moe prof] per sample: z/beta %.0f, scan %.0f cycles\n", (double)w[11] / (w[10] / 6.0), (double)w[12] / (w[10] / 6.0));
-      if (w[13] > 0)  // wave-per-sample kernel (kg_mc.hpp kg_sample): clock ticks of lane 0 of every wave
+      if (w[10] > 0 && w[8] > 0)  // workgroup-per-sample kernel: line_search_lds outside its passes, per pass
+        std::fprintf(stderr, "[moe prof] outside the passes, cycles per pass: gradient post + trial-line set-up %.0f, Armijo dispatch / decisions %.0f, "
+                     "LimitUpdate + re-evaluation set-up + step end %.0f\n", (double)w[13] / w[8], (double)w[14] / w[8], (double)w[15] / w[8]);
+      if (w[13] > 0 && w[10] == 0)  // wave-per-sample kernel (kg_mc.hpp kg_sample): clock ticks of lane 0 of every wave
         std::fprintf(stderr,
                      "[moe prof] wave-per-sample kernel, ticks per sample: z/beta %.0f  weights %.0f  scan %.0f  line search %.0f "
                      "(of which %.1f value passes x %.0f + %.1f gradient passes x %.0f)\n",

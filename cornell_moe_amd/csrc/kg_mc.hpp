@@ -1109,11 +1109,17 @@ __device__ __forceinline__ double line_search_lds(const KgMcParams& P, EV& ev, d
 #pragma unroll
   for (int k = 0; k < DP; ++k) gp[k] = 0.0;
   int pred = 2;  // Armijo trials the previous step of this sample consumed (>= 2): the size of the next step's first batch
+#if MOE_BLOCK_PROF
+  ev.seg_last = __builtin_amdgcn_s_memtime();
+  ev.seg_tot = ev.c_tot;
+#endif
   for (int restart = 0; restart < P.max_num_restarts; ++restart) {
-#pragma unroll
-    for (int k = 0; k < DP; ++k) sX0[k] = sX[k];
+    if (lane_id < DP) sX0[lane_id] = sX[lane_id];
     for (int istep = 0; istep < P.max_num_steps;) {
       if (lane_id < DP) sF[lane_id] = (sX[lane_id] - c_l) * s_l;  // the iterate in the frame: this pass's query AND the trial line's x0
+#if MOE_BLOCK_PROF
+      ev.seg_mark(3);  // (3: step end -> this gradient pass, loop control, restart bookkeeping)
+#endif
       double g_l;
       const double f0 = ev.eval_p_lane(sF, s_l, g_l);
       n_grad++;
@@ -1152,6 +1158,9 @@ __device__ __forceinline__ double line_search_lds(const KgMcParams& P, EV& ev, d
         const bool near = uniform(fmax(q0, qa)) <= kQueryClamp * kQueryClamp;
         int batch = pred;
         bool done = false;
+#if MOE_BLOCK_PROF
+        ev.seg_mark(0);  // (0: gradient post-processing, norm, trial-line set-up)
+#endif
         while (!done) {
           const int want = min(batch, 30 - search);
           if (near && want >= 2) {
@@ -1181,6 +1190,9 @@ __device__ __forceinline__ double line_search_lds(const KgMcParams& P, EV& ev, d
           batch = 2;
         }
         pred = max(2, min(search + 1, EV::kMaxTrials));
+#if MOE_BLOCK_PROF
+        ev.seg_mark(1);  // (1: the Armijo loop outside its passes: dispatch, decisions)
+#endif
       }
       // LimitUpdate with one coordinate per lane (the state already lives in per-wave LDS arrays, so lane k simply reads
       // entry k): one clamp instead of DP wave-uniform copies
@@ -1201,12 +1213,17 @@ __device__ __forceinline__ double line_search_lds(const KgMcParams& P, EV& ev, d
         obj2 = ev.template eval_p<false>(sF, gp);
         n_val++;
       }
+#if MOE_BLOCK_PROF
+      ev.seg_mark(2);  // (2: LimitUpdate, clamped re-evaluation set-up)
+#endif
       if (obj2 <= f0) break;
+      // x += step one row per lane (as a wave-uniform loop the read-modify-writes of sX were twelve dependent LDS round trips:
+      // most of the 2.8 k cycles per pass this kernel spent between its passes); |step|^2 from the step row alone, in k order
+      if (lane_id < DP) sX[lane_id] = sX[lane_id] + sS[lane_id];
       double ss = 0.0;
 #pragma unroll
       for (int k = 0; k < DP; ++k) {
         const double sk = sS[k];
-        sX[k] = sX[k] + sk;
         ss = fma(sk, sk, ss);
       }
       fcur = obj2;
@@ -1598,6 +1615,15 @@ struct BlockEval {
   int nw, wave, lane, cov_type, par;
 #if MOE_BLOCK_PROF
   unsigned long long c_acc = 0, c_red = 0, c_bar = 0, c_post = 0, c_n = 0, c_gtot = 0, c_gn = 0;
+  unsigned long long c_tot = 0;        // cycles inside passes (all kinds)
+  unsigned long long seg[4] = {0, 0, 0, 0};  // line_search_lds: cycles OUTSIDE the passes, by segment of a step
+  unsigned long long seg_last = 0, seg_tot = 0;
+  __device__ __forceinline__ void seg_mark(int i) {  // closes segment i: wall clock since the last mark minus pass time since then
+    const unsigned long long now = __builtin_amdgcn_s_memtime();
+    seg[i] += (now - seg_last) - (c_tot - seg_tot);
+    seg_last = now;
+    seg_tot = c_tot;
+  }
 #endif
 
   template <bool WG, int COV>
@@ -1756,6 +1782,7 @@ struct BlockEval {
     MOE_PROF_ADD(c_red, t1, t2);
     MOE_PROF_ADD(c_bar, t2, t3);
     MOE_PROF_ADD(c_post, t3, t4);
+    MOE_PROF_ADD(c_tot, t0, t4);
 #if MOE_BLOCK_PROF
     c_n++;
 #endif
@@ -1824,6 +1851,7 @@ struct BlockEval {
     MOE_PROF_ADD(c_red, t1, t2);
     MOE_PROF_ADD(c_bar, t2, t3);
     MOE_PROF_ADD(c_post, t3, t4);
+    MOE_PROF_ADD(c_tot, t0, t4);
 #if MOE_BLOCK_PROF
     c_n++;
 #endif
@@ -1934,6 +1962,7 @@ struct BlockEval {
     const double fret = -(mean + uniform(f));
     MOE_PROF_T(t4);
     MOE_PROF_ADD(c_post, t3, t4);
+    MOE_PROF_ADD(c_tot, t0, t4);
 #if MOE_BLOCK_PROF
     if (WG) {
       c_gtot += t4 - t0;
@@ -2197,6 +2226,9 @@ __global__ __launch_bounds__(512) void kg_mc_block_kernel(KgMcParams P, int num_
       atomicAdd(&P.prof[10], ev.c_gn);
       atomicAdd(&P.prof[11], p_zb);
       atomicAdd(&P.prof[12], p_scan);
+      atomicAdd(&P.prof[13], ev.seg[0]);
+      atomicAdd(&P.prof[14], ev.seg[1]);
+      atomicAdd(&P.prof[15], ev.seg[2] + ev.seg[3]);
     }
 #endif
     if (gridDim.x >= (unsigned)P.E) break;
