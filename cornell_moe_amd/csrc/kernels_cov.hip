@@ -170,8 +170,9 @@ __global__ __launch_bounds__(kCovRows) void cov_build_value_kernel(CovParams cp,
     const long col = col0 + j0 + jj;
     if (diag_noise != nullptr && (long)r == col - col0) va += noise;
     if (diag_noise != nullptr && (long)r == col + 1 - col0) vb += noise;
-    out[(long)r + col * ld] = va;
-    if (jj + 1 < nj) out[(long)r + (col + 1) * ld] = vb;
+    // (streaming stores: the matrix is written once and read by a later kernel, nothing of it is reused from L2 here)
+    __builtin_nontemporal_store(va, &out[(long)r + col * ld]);
+    if (jj + 1 < nj) __builtin_nontemporal_store(vb, &out[(long)r + (col + 1) * ld]);
   }
 }
 
