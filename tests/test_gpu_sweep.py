@@ -128,6 +128,36 @@ def test_many_evaluations_per_batch(monkeypatch):
     assert pieces["mean_evals"] == whole["mean_evals"] and pieces["grad_evals"] == whole["grad_evals"]
 
 
+def test_batches_beyond_64_components_and_16_dimensions():
+    """Batches through the paths that only exist beyond the old limits: m = (q + p)(1 + g) = 78 > 64 (thread-per-sample pre-pass,
+    two-slot tail solve, chunked TB, the strided z c^T kernel) and d = 20 (padded dimension 24): every entry of a batch of three
+    is the single evaluation to round-off, value-only calls agree, and two MC shards add up."""
+    from cornell_moe_amd import api
+    from cornell_moe_amd.workloads import make_workload
+    for kwargs in (dict(seed=301, n=60, d=12, q=5, p=1, M=24, P=4, derivs=tuple(range(12))),   # m = 6 * 13 = 78
+                   dict(seed=302, n=90, d=20, q=2, p=0, M=32, P=5, derivs=(3, 17))):            # d = 20, g = 2 in 4 slots
+        w = make_workload(num_restarts=3, **kwargs)
+        G = api.DeviceGP(w.hyperparameters, w.X, w.y, w.noise, w.derivs)
+        best = float(G.additional_mean(w.discrete).min())
+        Xp = w.Xp if w.p else None
+        b = G.kg_batch(w.inner_gd, w.bounds, w.discrete, w.Xq_restarts, Xp, w.M, best, w.kg_normals)
+        assert np.all(np.isfinite(b["kg_sum"])) and np.all(np.isfinite(b["grad_sum"]))
+        for e in range(3):
+            one = G.kg(w.inner_gd, w.bounds, w.discrete, w.Xq_restarts[e], Xp, w.M, best, w.kg_normals)
+            # (to round-off, not bit for bit: at these widths the state set-up of one evaluation and of three may cut their
+            #  Gram sums into different numbers of K slices and take different GEMM kernels)
+            assert abs(one["kg_sum"] - b["kg_sum"][e]) <= 1e-13 * abs(b["kg_sum"][e])
+            assert np.abs(one["grad_sum"] - b["grad_sum"][e]).max() <= 1e-12 * max(np.abs(b["grad_sum"][e]).max(), abs(b["kg_sum"][e]))
+        v = G.kg_batch(w.inner_gd, w.bounds, w.discrete, w.Xq_restarts, Xp, w.M, best, w.kg_normals, want_grad=False)
+        assert np.abs(v["kg_sum"] - b["kg_sum"]).max() <= 1e-13 * np.abs(b["kg_sum"]).max()
+        h = w.M // 2
+        a1 = G.kg(w.inner_gd, w.bounds, w.discrete, w.Xq_restarts[1], Xp, w.M, best, w.kg_normals, first_sample=0, num_local=h)
+        a2 = G.kg(w.inner_gd, w.bounds, w.discrete, w.Xq_restarts[1], Xp, w.M, best, w.kg_normals, first_sample=h, num_local=w.M - h)
+        assert abs(a1["kg_sum"] + a2["kg_sum"] - b["kg_sum"][1]) <= 1e-11 * abs(b["kg_sum"][1])
+        gs = max(np.abs(b["grad_sum"][1]).max(), abs(b["kg_sum"][1]))
+        assert np.abs(a1["grad_sum"] + a2["grad_sum"] - b["grad_sum"][1]).max() <= 1e-10 * gs
+
+
 def test_limit_update_decides_in_original_units(monkeypatch):
     """max_relative_change = 1 lets a step go to the wall itself: x + (upper - x) is exactly `upper` in the reference's units but can
     round one ulp past the wall's image in a centred, scaled frame -- and LimitUpdate then halves the step
