@@ -458,14 +458,14 @@ __global__ __launch_bounds__(64) void chol_diag_kernel(double* __restrict__ A, l
 // One workgroup per 64 panel rows; both operands staged in LDS, 4 x 4 outputs per thread.
 __global__ __launch_bounds__(256) void chol_panel_kernel(double* __restrict__ A, long lda, const double* __restrict__ Linv,
                                                         long ldl, int N, int k0, int nb, const int* __restrict__ info,
-                                                        long a_stride = 0, long l_stride = 0) {
+                                                        long a_stride = 0, long l_stride = 0, int rb0 = 0) {
   __shared__ double D[NB][NB + 1];   // D[j][c] = Linv_kk[c][j]
   __shared__ double At[NB][NB + 1];  // At[j][i] = A[i0 + i][k0 + j]
   A += (long)blockIdx.z * a_stride;
   Linv += (long)blockIdx.z * l_stride;
   info += blockIdx.z;
   if (*info != 0) return;
-  const int i0 = k0 + nb + blockIdx.x * NB;
+  const int i0 = k0 + nb + (blockIdx.x + rb0) * NB;  // (rb0: first row block of this launch -- the look-ahead schedule splits the panel)
   for (int t = threadIdx.x; t < NB * NB; t += 256) {
     const int r = t % NB, c = t / NB;  // r walks rows (contiguous in memory)
     D[c][r] = (r < nb && c < nb) ? Linv[(long)(k0 + r) + (long)(k0 + c) * ldl] : 0.0;  // D[c][r] = Linv[r][c]
@@ -501,13 +501,14 @@ __global__ __launch_bounds__(256) void chol_panel_kernel(double* __restrict__ A,
 
 // Trailing update: A[i][j] -= sum_c L[i][c] L[j][c], c over the panel, for 64 x 64 tiles with tile-row >= tile-col.
 __global__ __launch_bounds__(256) void chol_update_kernel(double* __restrict__ A, long lda, int N, int k0, int nb,
-                                                         const int* __restrict__ info, long a_stride = 0) {
+                                                         const int* __restrict__ info, long a_stride = 0, int skip00 = 0) {
   __shared__ double Ls_i[TK][NB + 1];
   __shared__ double Ls_j[TK][NB + 1];
   A += (long)blockIdx.z * a_stride;
   info += blockIdx.z;
   if (*info != 0) return;
   if (blockIdx.y > blockIdx.x) return;
+  if (skip00 && blockIdx.x == 0 && blockIdx.y == 0) return;  // (the look-ahead schedule updates that tile ahead of the rest)
   const int base = k0 + nb;
   const int i0 = base + blockIdx.x * NB, j0 = base + blockIdx.y * NB;
   const int tx = threadIdx.x % 16, ty = threadIdx.x / 16;
@@ -1080,6 +1081,85 @@ size_t cholesky_work_doubles(int N) {
   return (size_t)(half * NB) * (size_t)(half * NB);
 }
 
+// The factorisation part of the two-level algorithm (L in place, the 64 x 64 diagonal blocks of L^-1 in Linv's diagonal blocks).
+// Look-ahead schedule (MOE_CHOL_LOOKAHEAD=1; default: everything on one stream, in order): the 125 diagonal-block kernels of an
+// N = 8000 factorisation are single-workgroup, latency-bound launches of ~50 us, and in stream order the panel and update kernels
+// of a step (17 + 23 us on the whole chip) wait for them and they for those.  With look-ahead stream `s` carries only what the
+// NEXT diagonal block needs -- diag(k), the panel's first row block, the update of tile (k+1, k+1) -- while a second stream does
+// the rest of panel(k) and update(k) behind it.  MEASURED SLOWER on MI355X / ROCm 7.2 (N = 8000 build 30.3 vs 23.7 ms): three
+// cross-queue event dependences and two more launches per 64-column step cost more than the ~25 us of overlap they buy.  Kept,
+// off, as the record of that experiment and as a second schedule for the bit-equality test.  Every tile still receives its updates in the same order (k ascending), so the factor is
+// bit-identical to the in-order schedule; the events below are the tile-level dependences:
+//   B waits for diag(k) (its inverse block) before panel_rest(k), and for panel0(k) before update_rest(k);
+//   A waits for update_rest(k-1) before panel0(k) / tile00(k) (column block k and tile (k+1, k+1) get step k-1's update there).
+void cholesky_factor_two_level(int N, double* A, long lda, double* Linv, long ldl, int* info, hipStream_t s) {
+  const char* la_env = std::getenv("MOE_CHOL_LOOKAHEAD");  // (read per call: the tests compare the two schedules)
+  const bool lookahead = la_env && *la_env == '1';  // OFF by default: measured slower, see the comment above
+  hipStream_t sb = nullptr;
+  hipEvent_t e_diag = nullptr, e_p0 = nullptr, e_rest = nullptr, e_fork = nullptr;
+  if (lookahead) {
+    MOE_HIP_CHECK(hipStreamCreateWithFlags(&sb, hipStreamNonBlocking));
+    MOE_HIP_CHECK(hipEventCreateWithFlags(&e_diag, hipEventDisableTiming));
+    MOE_HIP_CHECK(hipEventCreateWithFlags(&e_p0, hipEventDisableTiming));
+    MOE_HIP_CHECK(hipEventCreateWithFlags(&e_rest, hipEventDisableTiming));
+    MOE_HIP_CHECK(hipEventCreateWithFlags(&e_fork, hipEventDisableTiming));
+    // the second stream starts behind whatever `s` holds already (the covariance build, the memsets)
+    MOE_HIP_CHECK(hipEventRecord(e_fork, s));
+    MOE_HIP_CHECK(hipStreamWaitEvent(sb, e_fork, 0));
+  }
+  for (int ko = 0; ko < N; ko += kOuter) {
+    const int wo = std::min(kOuter, N - ko);
+    bool rest_pending = false;  // stream B holds panel_rest / update_rest of the previous step of this outer block
+    for (int k0 = ko; k0 < ko + wo; k0 += NB) {
+      const int nb = std::min(NB, N - k0);
+      hipLaunchKernelGGL(chol_diag_lds_kernel, dim3(1), dim3(256), 0, s, A, lda, Linv, ldl, k0, nb, info);
+      const int below = N - k0 - nb;
+      if (below <= 0) continue;
+      const int tb = (below + NB - 1) / NB;
+      const int left = ko + wo - (k0 + nb);  // columns of this outer block still to be factored
+      const int cb = (left + NB - 1) / NB;
+      if (!lookahead) {
+        hipLaunchKernelGGL(chol_panel_kernel, dim3(tb), dim3(256), 0, s, A, lda, Linv, ldl, N, k0, nb, info);
+        if (left > 0) hipLaunchKernelGGL(chol_update_kernel, dim3(tb, cb), dim3(256), 0, s, A, lda, N, k0, nb, info);
+        continue;
+      }
+      MOE_HIP_CHECK(hipEventRecord(e_diag, s));
+      if (rest_pending) MOE_HIP_CHECK(hipStreamWaitEvent(s, e_rest, 0));  // update_rest(k-1) done
+      hipLaunchKernelGGL(chol_panel_kernel, dim3(1), dim3(256), 0, s, A, lda, Linv, ldl, N, k0, nb, info, 0L, 0L, 0);
+      MOE_HIP_CHECK(hipEventRecord(e_p0, s));
+      if (left > 0) hipLaunchKernelGGL(chol_update_kernel, dim3(1, 1), dim3(256), 0, s, A, lda, N, k0, nb, info, 0L, 0);
+      // the rest of the step on stream B
+      MOE_HIP_CHECK(hipStreamWaitEvent(sb, e_diag, 0));
+      if (tb > 1)
+        hipLaunchKernelGGL(chol_panel_kernel, dim3(tb - 1), dim3(256), 0, sb, A, lda, Linv, ldl, N, k0, nb, info, 0L, 0L, 1);
+      MOE_HIP_CHECK(hipStreamWaitEvent(sb, e_p0, 0));
+      if (left > 0) hipLaunchKernelGGL(chol_update_kernel, dim3(tb, cb), dim3(256), 0, sb, A, lda, N, k0, nb, info, 0L, 1);
+      MOE_HIP_CHECK(hipEventRecord(e_rest, sb));
+      rest_pending = true;
+    }
+    if (lookahead && rest_pending) MOE_HIP_CHECK(hipStreamWaitEvent(s, e_rest, 0));  // every panel of the outer block is final
+    const int trailing = N - (ko + wo);
+    if (trailing > 0) {
+      const int tt = (trailing + 63) / 64;
+      hipLaunchKernelGGL(syrk_mfma_kernel, dim3(tt, tt), dim3(256), 0, s, A, lda, N, ko + wo, ko, wo, (const int*)info);
+      if (lookahead) {  // stream B's next kernels touch the matrix the rank-512 update is writing
+        MOE_HIP_CHECK(hipEventRecord(e_fork, s));
+        MOE_HIP_CHECK(hipStreamWaitEvent(sb, e_fork, 0));
+      }
+    }
+  }
+  MOE_HIP_CHECK(hipGetLastError());
+  if (lookahead) {
+    // (everything on stream B has been joined into `s` through e_rest; the objects can go once `s` has passed those waits)
+    MOE_HIP_CHECK(hipStreamSynchronize(sb));
+    MOE_HIP_CHECK(hipStreamDestroy(sb));
+    MOE_HIP_CHECK(hipEventDestroy(e_diag));
+    MOE_HIP_CHECK(hipEventDestroy(e_p0));
+    MOE_HIP_CHECK(hipEventDestroy(e_rest));
+    MOE_HIP_CHECK(hipEventDestroy(e_fork));
+  }
+}
+
 void launch_cholesky_and_inverse(int N, double* A, long lda, double* Linv, long ldl, double* work, int* info,
                                  hipStream_t s) {
   MOE_HIP_CHECK(hipMemsetAsync(info, 0, sizeof(int), s));
@@ -1088,26 +1168,7 @@ void launch_cholesky_and_inverse(int N, double* A, long lda, double* Linv, long 
   const char* tl_env = std::getenv("MOE_CHOL_TWO_LEVEL_MIN");  // (read per call: tests force the two-level path at small N)
   const int two_level_min = (tl_env && *tl_env) ? std::atoi(tl_env) : 2048;
   if (N >= two_level_min) {
-    for (int ko = 0; ko < N; ko += kOuter) {
-      const int wo = std::min(kOuter, N - ko);
-      for (int k0 = ko; k0 < ko + wo; k0 += NB) {
-        const int nb = std::min(NB, N - k0);
-        hipLaunchKernelGGL(chol_diag_lds_kernel, dim3(1), dim3(256), 0, s, A, lda, Linv, ldl, k0, nb, info);
-        const int below = N - k0 - nb;
-        if (below > 0) {
-          const int tb = (below + NB - 1) / NB;
-          hipLaunchKernelGGL(chol_panel_kernel, dim3(tb), dim3(256), 0, s, A, lda, Linv, ldl, N, k0, nb, info);
-          const int left = ko + wo - (k0 + nb);  // columns of this outer block still to be factored
-          if (left > 0)
-            hipLaunchKernelGGL(chol_update_kernel, dim3(tb, (left + NB - 1) / NB), dim3(256), 0, s, A, lda, N, k0, nb, info);
-        }
-      }
-      const int trailing = N - (ko + wo);
-      if (trailing > 0) {
-        const int tt = (trailing + 63) / 64;
-        hipLaunchKernelGGL(syrk_mfma_kernel, dim3(tt, tt), dim3(256), 0, s, A, lda, N, ko + wo, ko, wo, (const int*)info);
-      }
-    }
+    cholesky_factor_two_level(N, A, lda, Linv, ldl, info, s);
   } else {
     for (int b = 0; b < nblk; ++b) {
       const int k0 = b * NB, nb = std::min(NB, N - k0);
@@ -1226,6 +1287,18 @@ __global__ __launch_bounds__(256) void ll_terms_batch_kernel(const double* __res
 void launch_cholesky_batch(int N, double* A, long lda, long a_stride, double* Linv, long ldl, long l_stride, int* info,
                            int batch, hipStream_t s) {
   MOE_HIP_CHECK(hipMemsetAsync(info, 0, sizeof(int) * batch, s));
+  {
+    // large matrices (the log likelihood at C5's N = 8000): the two-level factorisation with its look-ahead schedule, one matrix
+    // after the other -- a single factorisation fills the chip there, and the one-level batch kernels below are 125 steps of a
+    // 150 us register-resident diagonal kernel
+    const char* tl_env = std::getenv("MOE_CHOL_TWO_LEVEL_MIN");
+    const int two_level_min = (tl_env && *tl_env) ? std::atoi(tl_env) : 2048;
+    if (N >= two_level_min) {
+      for (int b = 0; b < batch; ++b)
+        cholesky_factor_two_level(N, A + (size_t)b * a_stride, lda, Linv + (size_t)b * l_stride, ldl, info + b, s);
+      return;
+    }
+  }
   const int nblk = (N + NB - 1) / NB;
   for (int b = 0; b < nblk; ++b) {
     const int k0 = b * NB, nb = std::min(NB, N - k0);

@@ -559,6 +559,24 @@ def test_two_level_cholesky(api, monkeypatch):
     with pytest.raises(api.SingularMatrixException) as e:
         api.DeviceGP([1.0, 0.5, 0.5], Xs, np.zeros((200, 1)), [0.0])
     assert e.value.leading_minor_index == 151
+    # the look-ahead schedule (diagonal-block chain on one stream, the rest of each step on a second) gives the in-order
+    # schedule's factor and inverse BIT FOR BIT, run after run; the log likelihood's bordered factorisation takes the same route
+    monkeypatch.setenv("MOE_CHOL_TWO_LEVEL_MIN", "64")
+    X = rng.uniform(size=(900, 3))
+    y = rng.uniform(size=(900, 1))
+    facs = []
+    for la in ("0", "1", "1", "1"):
+        monkeypatch.setenv("MOE_CHOL_LOOKAHEAD", la)
+        L_, kiy_, _ = api.DeviceGP([1.1, 0.4, 0.5, 0.6], X, y, [0.03]).get_factor()
+        facs.append((L_, kiy_))
+    for L_, kiy_ in facs[1:]:
+        assert np.array_equal(L_, facs[0][0]) and np.array_equal(kiy_, facs[0][1])
+    th = np.array([[1.1, 0.4, 0.5, 0.6, 0.03], [0.9, 0.5, 0.5, 0.7, 0.05]])
+    ll_two = api.LogLikelihood(X, y).evaluate(th)
+    monkeypatch.setenv("MOE_CHOL_TWO_LEVEL_MIN", "1000000")
+    ll_one = api.LogLikelihood(X, y).evaluate(th)
+    assert np.abs(ll_two - ll_one).max() <= 1e-11 * np.abs(ll_one).max()
+    monkeypatch.delenv("MOE_CHOL_LOOKAHEAD")
     monkeypatch.delenv("MOE_CHOL_TWO_LEVEL_MIN")
     n, d = 2600, 6
     X = rng.uniform(size=(n, d))
