@@ -875,7 +875,7 @@ KgPending kg_launch(GpDev& gp, int num_fidelity, const moe_gd_params_t& gd, cons
   // scales, but 1e-9 .. 1e-5 of r^2 at 1e3 .. 1e5 length scales (short length scales of a hyper-parameter MCMC ensemble) --
   // enough to break the 1e-8 parity with the reference.  Beyond a frame radius of 100 length scales the direct-difference
   // kernels are used instead (coordinates streamed from L2, or the workgroup-per-sample kernel): slower, exact.
-  bool wide_frame = false;
+  bool wide_frame = false, far_frame = false;
   {
     double rad2 = 0.0;
     for (int k = 0; k < d; ++k) {
@@ -888,6 +888,7 @@ KgPending kg_launch(GpDev& gp, int num_fidelity, const moe_gd_params_t& gd, cons
       rad2 += (ext * gp.cp.inv_l[k]) * (ext * gp.cp.inv_l[k]);
     }
     wide_frame = !(rad2 <= (double)env_int("MOE_KG_DOT_MAX_RADIUS2", 10000));
+    far_frame = wide_frame;
     // d > 16: the coordinate table of the wave-per-sample kernel would take (dp + 1) 512 bytes per tile; that kernel is built
     // without it there, so these shapes take the same route as a wide frame
     if (wide_dp) wide_frame = true;
@@ -901,7 +902,7 @@ KgPending kg_launch(GpDev& gp, int num_fidelity, const moe_gd_params_t& gd, cons
   if (tab_bytes + slab_bytes <= lds_max) waves = (int)std::min<size_t>(max_waves, (lds_max - tab_bytes) / slab_bytes);
   // (3 wavefronts per CU on the LDS table still beat the workgroup-per-sample kernel without derivative observations --
   //  n = 1500, d = 8: 2.1 vs 3.1 ms per evaluation; with 2 they lose -- n = 1700: 3.6 vs 3.4)
-  const int min_xlds_waves = env_int("MOE_KG_MIN_XLDS_WAVES", 3);
+  const int min_xlds_waves = env_int("MOE_KG_MIN_XLDS_WAVES", 4);  // (r2: 4 -- with 3 the streaming kernel and its 8 wavefronts win, n = 1500: 1.15 vs 1.44 ms)
   if (waves < min_xlds_waves || wide_frame) {  // coordinates stay in L2: more wavefronts per workgroup fit
     const int w2 = (int)std::min<size_t>(8, lds_max / slab_bytes);
     if (w2 > waves || wide_frame) {  // (the instantiation without the LDS table is built for <= 8 wavefronts)
@@ -927,6 +928,11 @@ KgPending kg_launch(GpDev& gp, int num_fidelity, const moe_gd_params_t& gd, cons
   if (!wide_dp) tr = env_int("MOE_KG_TR", tr);
   if (tr >= 0) num_lds_tiles = std::max(0, ntiles - bwaves * tr);
   int variant = (xlds && waves >= min_xlds_waves) ? 0 : (tr >= 0 ? 1 : 0);
+  // Without derivative observations the wave-per-sample kernel streaming its coordinates from L2 now beats the workgroup-per-sample
+  // kernel at every size both can run (r2: its multi-trial passes sweep the coordinates once per five Armijo trials -- n = 1600:
+  // 1.23 vs 2.68 ms per evaluation, 2000: 1.39 vs 2.67, 3000: 2.15 vs 3.21, d = 8, q = 4, M = 1e4); far frames (single-trial
+  // passes) keep the old choice
+  if (G == 0 && !far_frame && waves >= 1) variant = 0;
   variant = env_int("MOE_KG_VARIANT", variant);
   if (G > 4 || m > kMaxM) variant = 1;  // (the wave-per-sample kernel: up to four derivative slots, one lane per component)
   if (variant == 1 && (tr < 0 || kg_mc_block_lds_bytes(dp, G, num_lds_tiles) > (size_t)160 * 1024))
@@ -1189,6 +1195,7 @@ KgPending kg_launch(GpDev& gp, int num_fidelity, const moe_gd_params_t& gd, cons
   mp.ntiles = ntiles;
   mp.E = E;
   mp.mean = gp.mean;
+  mp.multi_trial = far_frame ? 0 : 1;
   mp.XsTab = dTab.p;
   mp.tab_stride = tab_stride;
   mp.KinvY = gp.dKinvY.p;

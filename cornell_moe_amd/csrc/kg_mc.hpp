@@ -70,6 +70,8 @@ struct KgMcParams {
                                  // exponential, sqrt(5) / length for Matern-5/2 (radial3 then needs no sqrt(5)); 0 in pad rows
   int perm[kMaxDimPadded];       // the GP's observed-derivative dimensions come first: perm[a] = derivatives[a], a < g
   int n, g, N, u, m, f, A, ntiles, E;
+  int multi_trial;  // 0: one Armijo trial per pass only (point sets spanning > 100 length scales: the projected distances of the
+                    // multi-trial passes lose absolute accuracy with the square of the trial's offset)
   double mean;
   const double* XsTab;  // [E][ntiles][DP][64] scaled coordinates of X then Xu_e, zero padded
   long tab_stride;
@@ -494,7 +496,10 @@ __device__ __forceinline__ double eval_pass(const double* __restrict__ xs, const
 // coordinate / weight loads, one reduction round and one decision round per T trials.  |q_t|^2 = (|x2|^2 + 2 alpha_t x2.d2 +
 // alpha_t^2 |d2|^2) / 4 (wave-uniform).  Returns false without evaluating when a trial lies beyond kFarRadius (see eval_loop;
 // |q(alpha)|^2 is convex in alpha, so the two ends of the bracket bound all trials).
-template <int DP, int COV, int T, bool SMALL>
+// XL = false (coordinates streamed from L2: no |x|^2 row): the same with direct differences about x0' = -x2 / 2, as the
+// workgroup-per-sample kernel does (point_terms_multi): r2_t = |x_j - x0'|^2 - 2 alpha_t (x_j - x0') . dv + alpha_t^2 |dv|^2, dv = -d2 / 2
+// -- there one coordinate sweep through L2 serves T trials instead of one, which is most of what that kernel paid per trial.
+template <int DP, int COV, int T, bool SMALL, bool XL = true>
 __device__ __forceinline__ bool eval_multi_loop(const double* __restrict__ xs, const double* __restrict__ aw,
                                                 const double* __restrict__ etab, int ntiles, double mean, const double (&x2)[DP],
                                                 const double (&d2)[DP], double alpha0, int lane, double (&f)[T]) {
@@ -515,35 +520,64 @@ __device__ __forceinline__ bool eval_multi_loop(const double* __restrict__ xs, c
   double acc[T];
 #pragma unroll
   for (int t = 0; t < T; ++t) acc[t] = 0.0;
-  lds_tile_ptr xt = (lds_tile_ptr)(xs + lane);
+  constexpr int NX = DP + (XL ? 1 : 0);  // rows per coordinate tile
+  typename tile_ptr<XL>::type xt = (typename tile_ptr<XL>::type)(xs + lane);
   lds_tile_ptr wt = (lds_tile_ptr)(aw + lane);
-  double cx[DP + 1], cw;
+  double cx[NX], cw;
 #pragma unroll
-  for (int k = 0; k < DP + 1; ++k) cx[k] = xt[k * 64];
+  for (int k = 0; k < NX; ++k) cx[k] = xt[k * 64];
   cw = wt[0];
-#pragma unroll(SMALL ? 1 : 2)
-  for (int tile = 0; tile < ntiles; ++tile) {
-    double nx[DP + 1], nw;
-    xt += (DP + 1) * 64;  // (one tile of padding behind both arrays: see eval_loop)
-    wt += 64;
+  double x0[DP], dv[DP], tt[T];  // (direct-difference form only)
+  if (!XL) {
 #pragma unroll
-    for (int k = 0; k < DP + 1; ++k) nx[k] = xt[k * 64];
-    nw = wt[0];
-    double p0 = cx[DP];
-#pragma unroll
-    for (int k = 0; k < DP; ++k) p0 = fma(cx[k], x2[k], p0);
-    double p1 = cx[0] * d2[0];
-#pragma unroll
-    for (int k = 1; k < DP; ++k) p1 = fma(cx[k], d2[k], p1);
-#pragma unroll
-    for (int t = 0; t < T; ++t) {
-      const double r2 = fmax(fma(al[t], p1, p0 + qq[t]), 1.0e-300);
-      double base, first, second;
-      radial3<COV, false, false>(r2, etab, base, first, second);
-      acc[t] = fma(cw, base, acc[t]);
+    for (int k = 0; k < DP; ++k) {
+      x0[k] = -0.5 * x2[k];
+      dv[k] = -0.5 * d2[k];
     }
 #pragma unroll
-    for (int k = 0; k < DP + 1; ++k) cx[k] = nx[k];
+    for (int t = 0; t < T; ++t) tt[t] = (al[t] * al[t]) * (0.25 * sdd);  // alpha_t^2 |dv|^2
+  }
+#pragma unroll(SMALL ? 1 : 2)
+  for (int tile = 0; tile < ntiles; ++tile) {
+    double nx[NX], nw;
+    xt += NX * 64;  // (one tile of padding behind both arrays: see eval_loop)
+    wt += 64;
+#pragma unroll
+    for (int k = 0; k < NX; ++k) nx[k] = xt[k * 64];
+    nw = wt[0];
+    if (XL) {
+      double p0 = cx[XL ? DP : 0];
+#pragma unroll
+      for (int k = 0; k < DP; ++k) p0 = fma(cx[k], x2[k], p0);
+      double p1 = cx[0] * d2[0];
+#pragma unroll
+      for (int k = 1; k < DP; ++k) p1 = fma(cx[k], d2[k], p1);
+#pragma unroll
+      for (int t = 0; t < T; ++t) {
+        const double r2 = fmax(fma(al[t], p1, p0 + qq[t]), 1.0e-300);
+        double base, first, second;
+        radial3<COV, false, false>(r2, etab, base, first, second);
+        acc[t] = fma(cw, base, acc[t]);
+      }
+    } else {
+      double A = 1.0e-300, B = 0.0;
+#pragma unroll
+      for (int k = 0; k < DP; ++k) {
+        const double d0 = cx[k] - x0[k];
+        A = fma(d0, d0, A);
+        B = fma(d0, dv[k], B);
+      }
+      const double mB2 = -2.0 * B;
+#pragma unroll
+      for (int t = 0; t < T; ++t) {
+        const double r2 = fmax(fma(al[t], mB2, A + tt[t]), 1.0e-300);
+        double base, first, second;
+        radial3<COV, false, false>(r2, etab, base, first, second);
+        acc[t] = fma(cw, base, acc[t]);
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < NX; ++k) cx[k] = nx[k];
     cw = nw;
   }
   // T wave sums, folded four / two at a time (packed reductions above)
@@ -660,7 +694,7 @@ struct WaveEval {
     return f;
   }
   // up to kMaxTrials Armijo trials alpha / 2^t in one pass (eval_multi_loop): q-KG on the LDS table only
-  static constexpr int kMaxTrials = (XL && G == 0 && !SMALL) ? 5 : 1;
+  static constexpr int kMaxTrials = (G == 0 && !SMALL) ? 5 : 1;
   // T trials and the reference's sequence of decisions over them (gpp_optimization.hpp:752-769), with compile-time indices
   // (a runtime-sized result array would live in scratch memory): stops at the first accepted trial (done), halves alpha and
   // counts `search` for every rejected one, counts consumed trials only.  Returns false (nothing evaluated, nothing changed)
@@ -670,8 +704,8 @@ struct WaveEval {
                                            int& search, double& ftrial, bool& done, unsigned long long& n_val) {
     double f[T];
     const bool ok = (cov_type == MOE_COV_SQUARE_EXPONENTIAL)
-                        ? eval_multi_loop<DP, MOE_COV_SQUARE_EXPONENTIAL, T, SMALL>(xs, aw, etab, ntiles, mean, x2, d2, alpha_n, lane, f)
-                        : eval_multi_loop<DP, MOE_COV_MATERN_NU_2P5, T, SMALL>(xs, aw, etab, ntiles, mean, x2, d2, alpha_n, lane, f);
+                        ? eval_multi_loop<DP, MOE_COV_SQUARE_EXPONENTIAL, T, SMALL, XL>(xs, aw, etab, ntiles, mean, x2, d2, alpha_n, lane, f)
+                        : eval_multi_loop<DP, MOE_COV_MATERN_NU_2P5, T, SMALL, XL>(xs, aw, etab, ntiles, mean, x2, d2, alpha_n, lane, f);
     if (!ok) return false;
 #pragma unroll
     for (int t = 0; t < T; ++t) {
@@ -974,7 +1008,7 @@ __device__ __forceinline__ double line_search_frame(const KgMcParams& P, const d
         bool done = false;
         while (!done) {
           bool evaluated = false;
-          if (EV::kMaxTrials >= 2) {
+          if (EV::kMaxTrials >= 2 && P.multi_trial != 0) {
             const int want = min(batch, 30 - search);
             if (want >= 2) evaluated = ev.armijo_batch(want, x2, d2, f0, norm, alpha_n, search, ftrial, done, n_val);
           }

@@ -47,6 +47,9 @@ CASES = [
     (128, 40, 29, 2, 0, 4, 16, (0, 7, 15, 22, 28, 11), 1, 0, (1, 4, 1, 3, 0.0, 1.0, 0.1, 1e-10)),  # d = 29, g = 6 in 8 slots
     (129, 30, 20, 1, 0, 3, 12, tuple(range(12)), 0, 0, (1, 4, 1, 3, 0.0, 1.0, 0.1, 1e-10)),    # d = 20, g = 12
     (130, 200, 18, 2, 0, 6, 16, (5,), 1, 0, (1, 4, 1, 3, 0.0, 1.0, 0.1, 1e-10)),               # d = 18, 4 tiles, g = 1
+    # beyond the LDS coordinate table (r2): the wave-per-sample kernel streams coordinates from L2, multi-trial passes in
+    # direct-difference form; variant 1 = the workgroup-per-sample kernel on the same shape
+    (131, 1700, 8, 2, 0, 5, 16, (), 1, 0, (1, 6, 1, 3, 0.0, 1.0, 0.1, 1e-10)),
 ]
 
 
