@@ -1195,7 +1195,7 @@ KgPending kg_launch(GpDev& gp, int num_fidelity, const moe_gd_params_t& gd, cons
   mp.ntiles = ntiles;
   mp.E = E;
   mp.mean = gp.mean;
-  mp.multi_trial = far_frame ? 0 : 1;
+  mp.multi_trial = far_frame ? 0 : env_int("MOE_KG_MULTI_TRIAL", 1);  // (0: A/B runs)
   mp.XsTab = dTab.p;
   mp.tab_stride = tab_stride;
   mp.KinvY = gp.dKinvY.p;

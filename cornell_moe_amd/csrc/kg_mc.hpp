@@ -499,7 +499,10 @@ __device__ __forceinline__ double eval_pass(const double* __restrict__ xs, const
 // XL = false (coordinates streamed from L2: no |x|^2 row): the same with direct differences about x0' = -x2 / 2, as the
 // workgroup-per-sample kernel does (point_terms_multi): r2_t = |x_j - x0'|^2 - 2 alpha_t (x_j - x0') . dv + alpha_t^2 |dv|^2, dv = -d2 / 2
 // -- there one coordinate sweep through L2 serves T trials instead of one, which is most of what that kernel paid per trial.
-template <int DP, int COV, int T, bool SMALL, bool XL = true>
+// G > 0 (derivative observations; table rows a < G are the observed dimensions): a point also carries the derivative-weight sum
+// sum_a w_a (x_j - q_t)_a = sdA - alpha_t sdB,  sdA = sum_a w_a (x_j - x0')_a,  sdB = sum_a w_a dv_a  (2 G fmas once per point, one
+// fma per trial), multiplied by the first-derivative coefficient of the trial's distance.
+template <int DP, int COV, int T, bool SMALL, bool XL = true, int G = 0>
 __device__ __forceinline__ bool eval_multi_loop(const double* __restrict__ xs, const double* __restrict__ aw,
                                                 const double* __restrict__ etab, int ntiles, double mean, const double (&x2)[DP],
                                                 const double (&d2)[DP], double alpha0, int lane, double (&f)[T]) {
@@ -523,12 +526,13 @@ __device__ __forceinline__ bool eval_multi_loop(const double* __restrict__ xs, c
   constexpr int NX = DP + (XL ? 1 : 0);  // rows per coordinate tile
   typename tile_ptr<XL>::type xt = (typename tile_ptr<XL>::type)(xs + lane);
   lds_tile_ptr wt = (lds_tile_ptr)(aw + lane);
-  double cx[NX], cw;
+  double cx[NX], cwa[1 + G];
 #pragma unroll
   for (int k = 0; k < NX; ++k) cx[k] = xt[k * 64];
-  cw = wt[0];
-  double x0[DP], dv[DP], tt[T];  // (direct-difference form only)
-  if (!XL) {
+#pragma unroll
+  for (int a = 0; a < 1 + G; ++a) cwa[a] = wt[a * 64];
+  double x0[DP], dv[DP], tt[T];  // (direct-difference form, and the derivative-weight sums)
+  if (!XL || G > 0) {
 #pragma unroll
     for (int k = 0; k < DP; ++k) {
       x0[k] = -0.5 * x2[k];
@@ -539,12 +543,23 @@ __device__ __forceinline__ bool eval_multi_loop(const double* __restrict__ xs, c
   }
 #pragma unroll(SMALL ? 1 : 2)
   for (int tile = 0; tile < ntiles; ++tile) {
-    double nx[NX], nw;
+    double nx[NX], nwa[1 + G];
     xt += NX * 64;  // (one tile of padding behind both arrays: see eval_loop)
-    wt += 64;
+    wt += (1 + G) * 64;
 #pragma unroll
     for (int k = 0; k < NX; ++k) nx[k] = xt[k * 64];
-    nw = wt[0];
+#pragma unroll
+    for (int a = 0; a < 1 + G; ++a) nwa[a] = wt[a * 64];
+    const double cw = cwa[0];
+    // derivative-weight sum of trial t: sum_a w_a (x_ja - x0_a - alpha_t dv_a) = sdA - alpha_t sdB
+    double sdA = 0.0, sdB = 0.0;
+    if (G > 0) {
+#pragma unroll
+      for (int a = 0; a < G; ++a) {
+        sdA = fma(cwa[1 + a], cx[a] - x0[a], sdA);
+        sdB = fma(cwa[1 + a], dv[a], sdB);
+      }
+    }
     if (XL) {
       double p0 = cx[XL ? DP : 0];
 #pragma unroll
@@ -556,8 +571,9 @@ __device__ __forceinline__ bool eval_multi_loop(const double* __restrict__ xs, c
       for (int t = 0; t < T; ++t) {
         const double r2 = fmax(fma(al[t], p1, p0 + qq[t]), 1.0e-300);
         double base, first, second;
-        radial3<COV, false, false>(r2, etab, base, first, second);
+        radial3<COV, (G > 0), false>(r2, etab, base, first, second);
         acc[t] = fma(cw, base, acc[t]);
+        if (G > 0) acc[t] = fma(first, fma(-al[t], sdB, sdA), acc[t]);
       }
     } else {
       double A = 1.0e-300, B = 0.0;
@@ -572,13 +588,15 @@ __device__ __forceinline__ bool eval_multi_loop(const double* __restrict__ xs, c
       for (int t = 0; t < T; ++t) {
         const double r2 = fmax(fma(al[t], mB2, A + tt[t]), 1.0e-300);
         double base, first, second;
-        radial3<COV, false, false>(r2, etab, base, first, second);
+        radial3<COV, (G > 0), false>(r2, etab, base, first, second);
         acc[t] = fma(cw, base, acc[t]);
+        if (G > 0) acc[t] = fma(first, fma(-al[t], sdB, sdA), acc[t]);
       }
     }
 #pragma unroll
     for (int k = 0; k < NX; ++k) cx[k] = nx[k];
-    cw = nw;
+#pragma unroll
+    for (int a = 0; a < 1 + G; ++a) cwa[a] = nwa[a];
   }
   // T wave sums, folded four / two at a time (packed reductions above)
   double sum[T];
@@ -694,7 +712,7 @@ struct WaveEval {
     return f;
   }
   // up to kMaxTrials Armijo trials alpha / 2^t in one pass (eval_multi_loop): q-KG on the LDS table only
-  static constexpr int kMaxTrials = (G == 0 && !SMALL) ? 5 : 1;
+  static constexpr int kMaxTrials = !SMALL ? 5 : 1;
   // T trials and the reference's sequence of decisions over them (gpp_optimization.hpp:752-769), with compile-time indices
   // (a runtime-sized result array would live in scratch memory): stops at the first accepted trial (done), halves alpha and
   // counts `search` for every rejected one, counts consumed trials only.  Returns false (nothing evaluated, nothing changed)
@@ -704,8 +722,8 @@ struct WaveEval {
                                            int& search, double& ftrial, bool& done, unsigned long long& n_val) {
     double f[T];
     const bool ok = (cov_type == MOE_COV_SQUARE_EXPONENTIAL)
-                        ? eval_multi_loop<DP, MOE_COV_SQUARE_EXPONENTIAL, T, SMALL, XL>(xs, aw, etab, ntiles, mean, x2, d2, alpha_n, lane, f)
-                        : eval_multi_loop<DP, MOE_COV_MATERN_NU_2P5, T, SMALL, XL>(xs, aw, etab, ntiles, mean, x2, d2, alpha_n, lane, f);
+                        ? eval_multi_loop<DP, MOE_COV_SQUARE_EXPONENTIAL, T, SMALL, XL, G>(xs, aw, etab, ntiles, mean, x2, d2, alpha_n, lane, f)
+                        : eval_multi_loop<DP, MOE_COV_MATERN_NU_2P5, T, SMALL, XL, G>(xs, aw, etab, ntiles, mean, x2, d2, alpha_n, lane, f);
     if (!ok) return false;
 #pragma unroll
     for (int t = 0; t < T; ++t) {
