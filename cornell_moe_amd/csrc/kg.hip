@@ -933,6 +933,9 @@ KgPending kg_launch(GpDev& gp, int num_fidelity, const moe_gd_params_t& gd, cons
   // 1.23 vs 2.68 ms per evaluation, 2000: 1.39 vs 2.67, 3000: 2.15 vs 3.21, d = 8, q = 4, M = 1e4); far frames (single-trial
   // passes) keep the old choice
   if (G == 0 && !far_frame && waves >= 1) variant = 0;
+  // with derivative observations (a point's 1 + G weights make the slabs bigger) the streamed kernel wins while five of them fit:
+  // d = 12, g = 3, q = 8, M = 4000: n = 800 0.86 vs 1.10 ms; with four (n = 1200) 1.28 vs 1.21
+  if (G > 0 && G <= 4 && !far_frame && !xlds && waves >= 5) variant = 0;
   variant = env_int("MOE_KG_VARIANT", variant);
   if (G > 4 || m > kMaxM) variant = 1;  // (the wave-per-sample kernel: up to four derivative slots, one lane per component)
   if (variant == 1 && (tr < 0 || kg_mc_block_lds_bytes(dp, G, num_lds_tiles) > (size_t)160 * 1024))
