@@ -897,7 +897,10 @@ KgPending kg_launch(GpDev& gp, int num_fidelity, const moe_gd_params_t& gd, cons
   // one or two tiles per pass: a pass is a short dependent chain, so 16 wavefronts per workgroup (the <= 128-VGPR instantiation,
   // single-trial passes).  From three tiles on the 8-wavefront instantiation with its multi-trial passes is faster (r2: n = 150,
   // d = 6, q = 4: 19 600 vs 12 900 evals/s; n = 200: 17 700 vs 12 100; two tiles, n = 100: 47 000 vs 49 000)
-  const int max_waves = (ntiles <= env_int("MOE_KG_SMALL_TILES", 2)) ? 16 : 8;
+  // ... and only up to four dimensions: with eight or more coordinate rows the 128-VGPR instantiation spills heavily (0.5 - 1 KB of
+  // scratch per lane) -- n = 60, d = 8: 27 300 vs 44 500 evals/s on the 8-wavefront instantiation, d = 12: 9 500 vs 35 800,
+  // d = 16: 6 200 vs 25 200 (r2)
+  const int max_waves = (ntiles <= env_int("MOE_KG_SMALL_TILES", 2) && dp <= env_int("MOE_KG_SMALL_DP", 4)) ? 16 : 8;
   int waves = 0;
   if (tab_bytes + slab_bytes <= lds_max) waves = (int)std::min<size_t>(max_waves, (lds_max - tab_bytes) / slab_bytes);
   // (3 wavefronts per CU on the LDS table still beat the workgroup-per-sample kernel without derivative observations --
