@@ -7,16 +7,25 @@ N > 1 runs one rank per GPU over RCCL: either the driver launches this file unde
 --nproc-per-node N ...` (RANK / LOCAL_RANK / WORLD_SIZE in the environment), or -- when it is called plainly -- bench.py
 re-launches ITSELF that way (127.0.0.1 rendezvous on a free port) and relays rank 0's JSON line.
 
-A "step" is one pass of the hot path over one batch: every rank evaluates `--restarts` (default 8) independent q-KG
-value+gradient evaluations (different points_to_sample, same GP / discrete set / normal table = the multistart axis of
-ComputeKGOptimalPointsToSampleViaMultistartGradientDescent, gpp_knowledge_gradient_optimization.hpp:860-935; C4 is 64
-restarts over 8 GPUs = 8 per GPU), then -- when N > 1 -- all ranks exchange their (KG, grad KG) with ONE RCCL all_gather.
-Per-GPU work is fixed as N grows ("scaling": "weak").  `--shard mc` instead splits the 10k MC samples of each evaluation
-across ranks with one all_reduce per evaluation (strong scaling of a single evaluation); at N > 1 the default run times that
-mode too, AFTER the K timed steps of the headline measurement, and reports it as the extra object "mc_shard".
+A "step" is one pass of the hot path over one batch.  Round 3: the batch is BASELINE.json's C4 job itself -- 64 multistart
+restarts (independent points_to_sample sets, same GP / discrete set / normal table: the axis of
+ComputeKGOptimalPointsToSampleViaMultistartGradientDescent, gpp_knowledge_gradient_optimization.hpp:860-935) of the C3
+evaluation, SHARDED over the ranks: 64 / N q-KG value+gradient evaluations per GPU per step in ONE moe_kg_batch call, then --
+N > 1 -- ONE all_gather of the (KG, grad KG) rows.  Total work per step is fixed ("scaling": "strong"); at N = 1 a step is the
+whole C4 job on one GPU (~40 ms), at N = 8 it is C4 as BASELINE.json states it (8 restarts per GPU).  `--restarts R` fixes
+the per-GPU count instead ("weak").  `--shard mc` splits the 10k MC samples of each evaluation across ranks with one
+all_reduce per evaluation (strong scaling of a single evaluation); at N > 1 the default run times that mode too, AFTER the K
+timed steps, and reports it as the extra object "mc_shard".
 `value` = evaluations all ranks completed / max-over-ranks wall time of the K timed steps; the GP (K factor, K^-1 y) is
 resident in HBM before the timed region; per-call host inputs are the q x d query points, the P discrete points and the
 normal table (PCIe-inclusive by construction -- see DESIGN.md).
+
+First contact with a multi-GPU node (cornell_moe_amd/dist.py: bring_up): the control plane is a gloo group; RCCL is tried in
+a throw-away child process per rank first (bring-up + one checked all_reduce, 60 s limit) and only used when every rank's
+child passed -- otherwise the same measurement runs with its collectives on gloo and says so ("rccl_ranks": 0,
+"fallback": ...).  If not even the rendezvous works, rank 0 drives all N devices in-process through the C ABI
+(moe_kg_batch_multi) and the other ranks exit.  After the timed region rank 0 recomputes every restart on its own GPU and
+reports the largest difference to the gathered results ("determinism"; restarts are bit-identical, MC shards <= 1e-12).
 """
 import argparse
 import json
@@ -137,11 +146,12 @@ def committed_traffic():
         return {}
 
 
-def measure_traffic(restarts, log, timeout_s=150):
-    """HBM bytes per launch of the two reported kernels, measured NOW: two rocprofv3 passes (FETCH_SIZE, then WRITE_SIZE, each in
-    its own --pmc run with --kernel-trace only, as MI355X_MICROARCH.md prescribes; FETCH_SIZE doubled for gfx950) over
-    tools/prof_kg.py -- the same batched evaluation this file times -- reduced by tools/hbm_traffic.py.  Returns
-    (dict kernel -> bytes per launch, source string); falls back to the committed measurement when the profiler is missing."""
+def measure_traffic(config, restarts, log, timeout_s=180):
+    """HBM bytes per launch AND executed FP64 wave-instructions per launch of the reported kernels, measured NOW: three rocprofv3
+    passes (FETCH_SIZE; WRITE_SIZE; SQ_INSTS_VALU_{FMA,ADD,MUL,TRANS}_F64 -- each in its own --pmc run with --kernel-trace only,
+    as MI355X_MICROARCH.md prescribes; FETCH_SIZE doubled for gfx950) over tools/prof_kg.py -- the same batched evaluation this
+    file times -- reduced by tools/hbm_traffic.py.  Returns (dict kernel -> dict of per-launch figures, source string); falls
+    back to the committed measurement when the profiler is missing."""
     import shutil
     import subprocess
     import tempfile
@@ -151,17 +161,23 @@ def measure_traffic(restarts, log, timeout_s=150):
     tmp = tempfile.mkdtemp(prefix="moe_pmc_", dir="/tmp")
     env = dict(os.environ, TMPDIR="/tmp")
     try:
-        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
-            cmd = [exe, "--kernel-trace", "--pmc", ctr, "--output-format", "csv", "-d", os.path.join(tmp, ctr.lower()), "-o", "p",
-                   "--", sys.executable, os.path.join(ROOT, "tools", "prof_kg.py"), "C3", str(restarts), "2"]
-            subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout_s, check=True)
+        for tag, ctrs in (("fetch", ["FETCH_SIZE"]), ("write", ["WRITE_SIZE"]),
+                          ("fp64", ["SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_TRANS_F64"])):
+            cmd = [exe, "--kernel-trace", "--pmc"] + ctrs + ["--output-format", "csv", "-d", os.path.join(tmp, tag), "-o", "p",
+                   "--", sys.executable, os.path.join(ROOT, "tools", "prof_kg.py"), config, str(restarts), "2"]
+            try:
+                subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout_s, check=True)
+            except Exception as e:  # the FP64 pass is an extra: keep the traffic passes' result if only it fails
+                if tag != "fp64":
+                    raise
+                log("measure_traffic: FP64 instruction pass failed (%s)" % type(e).__name__)
         res = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "hbm_traffic.py"), tmp], stdout=subprocess.PIPE,
                              universal_newlines=True, timeout=60, check=True)
         data = json.loads(res.stdout.strip().splitlines()[-1])
-        out = {k: float(v["hbm_bytes_per_launch"]) for k, v in data.items()}
-        if "kg_mc_kernel" not in out:
-            return None, "rocprofv3 ran but reported no kg_mc_kernel rows"
-        return out, "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes run by this bench.py invocation"
+        if not any(k.startswith("kg_mc") for k in data):
+            return None, "rocprofv3 ran but reported no kg_mc kernel rows"
+        data["evals_per_launch"] = restarts
+        return data, "rocprofv3 --pmc passes (FETCH_SIZE | WRITE_SIZE | SQ_INSTS_VALU_*_F64) run by this bench.py invocation"
     except Exception as e:  # pragma: no cover
         log("measure_traffic failed: %s" % e)
         return None, "in-run PMC passes failed (%s)" % type(e).__name__
@@ -183,19 +199,38 @@ def self_launch(args_list, n, script=None):
     return subprocess.call(cmd, env=env)
 
 
+C4_RESTARTS = 64  # BASELINE.json configs[3]: "q-KG 64-multistart x 10k MC sharded across 8 x MI355X"
+
+
+def pass_flops(w):
+    """SURVEY 8(d) algorithmic flops of ONE posterior-mean pass of the inner optimisation over the n + u tabulated points:
+    (value pass, value + gradient pass).  Without derivative observations a point is one covariance entry: 3d + 32 and 5d + 34
+    flops (distance, sqrt, exp, Matern polynomial, accumulation).  With g observed derivatives the 1 + g entries of a POINT share
+    one distance / sqrt / exp (r3: VERDICT r2 weak 3 -- counting (n+u)(1+g) full entries overstated the work 3x at C5); what a
+    derivative slot adds is its weight's fma into the point's derivative sum (2 flops; 4 in a gradient pass, which also
+    accumulates first * w_a), plus one fma (value) / the second-derivative coefficient and its fma (gradient) per point."""
+    pts = w.n + w.q + w.p
+    val = 3 * w.d + 32 + ((2 * w.g + 2) if w.g else 0)
+    grad = 5 * w.d + 34 + ((4 * w.g + 6) if w.g else 0)
+    return pts, val, grad
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=40)
-    ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--restarts", type=int, default=None, help="independent KG evaluations per GPU per step (default: 8 at C3, 2 at C5)")
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--restarts", type=int, default=None,
+                    help="independent KG evaluations per GPU per step (weak scaling); default: C3 -- 64 per STEP shared by the "
+                         "ranks (the C4 job, strong scaling); C5 -- 2 per GPU")
     ap.add_argument("--shard", choices=["restarts", "mc"], default="restarts")
     ap.add_argument("--config", default="C3")
     ap.add_argument("--cpu-sample-mc", type=int, default=400)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-traffic", action="store_true", help="skip the in-run rocprofv3 PMC passes (HBM traffic)")
+    ap.add_argument("--no-traffic", action="store_true", help="skip the in-run rocprofv3 PMC passes (HBM traffic, executed FP64)")
     ap.add_argument("--no-mc-shard", action="store_true", help="N > 1: skip the extra MC-sharded measurement")
     ap.add_argument("--no-batch1", action="store_true", help="skip the extra one-at-a-time (batch-1 latency) measurement")
+    ap.add_argument("--no-extras", action="store_true", help="skip the extra roofline probes (K(X,X) builds)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -211,7 +246,7 @@ def main():
             print("[bench] " + msg, file=sys.stderr, flush=True)
 
     import torch
-    from cornell_moe_amd import _lib, dist as mdist
+    from cornell_moe_amd import _lib, api as mapi, dist as mdist
     from cornell_moe_amd.api import DeviceGP
     from cornell_moe_amd.workloads import make_workload
 
@@ -221,61 +256,74 @@ def main():
     # MOE_BENCH_BACKEND=gloo is a test hook: it lets the N > 1 code path run with several ranks sharing ONE GPU (collectives
     # on host tensors); the measured configuration is always nccl (= RCCL), one rank per GPU.
     backend = os.environ.get("MOE_BENCH_BACKEND", "nccl")
-    if backend != "nccl":
-        local_rank = local_rank % torch.cuda.device_count()
+    ndev = torch.cuda.device_count()
+    if backend != "nccl" or os.environ.get("MOE_BENCH_SHARE_GPU") == "1":   # (second test hook: ranks share a GPU, RCCL still preferred)
+        local_rank = local_rank % ndev
     torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    cdev = dev if backend == "nccl" else None   # where collective buffers live
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        import torch.distributed as dist
-        if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-        else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
 
-    R = args.restarts if args.restarts is not None else (2 if args.config == "C5" else 8)
+    # ---- process groups: gloo control plane, RCCL data plane behind a pre-flight (dist.bring_up) ----
+    multi_fallback = None   # last resort: rank 0 drives all devices in-process through moe_kg_batch_multi
+    try:
+        comm = mdist.bring_up(rank, world, local_rank, prefer=backend, log=log)
+    except Exception as e:  # not even the rendezvous came up
+        if rank != 0:
+            print("[bench] rank %d: process-group bring-up failed (%s); leaving the run to rank 0" % (rank, e), file=sys.stderr, flush=True)
+            return
+        multi_fallback = "process-group bring-up failed (%s: %s)" % (type(e).__name__, e)
+        log("NO PROCESS GROUP -- %s; rank 0 drives %d device(s) in-process through moe_kg_batch_multi" % (multi_fallback, min(world, ndev)))
+        comm = mdist.Comm(0, 1, "none", None, None, multi_fallback)
+
+    strong = args.restarts is None and args.config in ("C3", "C4") and args.shard == "restarts"
+    if strong:
+        if C4_RESTARTS % world:
+            raise SystemExit("the C4 job (64 restarts per step) does not divide over %d ranks; pass --restarts" % world)
+        R = C4_RESTARTS // world
+    else:
+        R = args.restarts if args.restarts is not None else (2 if args.config == "C5" else 8)
     w = make_workload(args.config, num_restarts=R * world)
-    G = DeviceGP(w.hyperparameters, w.X, w.y, w.noise, w.derivs, device=local_rank)
+    if multi_fallback is not None:
+        devs = list(range(min(world, ndev)))
+        gps = [DeviceGP(w.hyperparameters, w.X, w.y, w.noise, w.derivs, device=dv) for dv in devs]
+        G = gps[0]
+    else:
+        G = DeviceGP(w.hyperparameters, w.X, w.y, w.noise, w.derivs, device=local_rank)
     best = float(G.additional_mean(w.discrete).min())  # knowledge_gradient.py:366-368
-    my_restarts = w.Xq_restarts[rank * R:(rank + 1) * R]
+    my_restarts = w.Xq_restarts[rank * R:(rank + 1) * R] if multi_fallback is None else w.Xq_restarts
+    cw = comm.world
 
     def step(mode=None, restarts=None):
         mode = mode or args.shard
+        if multi_fallback is not None and restarts is None:
+            r = mapi.kg_batch_multi(gps, "restarts" if mode == "restarts" else "mc", w.inner_gd, w.bounds, w.discrete,
+                                    w.Xq_restarts if mode == "restarts" else w.Xq_restarts[:R], None, w.M, best, w.kg_normals)
+            return r["kg_sum"] / w.M, r["grad_sum"] / w.M, r
         if mode == "restarts":
             mine = my_restarts if restarts is None else restarts
             r = G.kg_batch(w.inner_gd, w.bounds, w.discrete, mine, None, w.M, best, w.kg_normals)
             kg = r["kg_sum"] / w.M
             grad = r["grad_sum"] / w.M
-            if world > 1 and restarts is None:
+            if cw > 1 and restarts is None:
                 idx = list(range(rank * R, (rank + 1) * R))
-                kg, grad = mdist.gather_restarts(idx, kg, grad, R * world, device=cdev)
+                kg, grad = mdist.gather_restarts(idx, kg, grad, R * cw, group=comm.group, device=comm.device)
             return kg, grad, r
-        first, count = mdist.shard_samples(w.M, rank, world)
-        Rm = R if restarts is None else len(restarts)
-        r = G.kg_batch(w.inner_gd, w.bounds, w.discrete, w.Xq_restarts[:Rm], None, w.M, best, w.kg_normals,
-                       first_sample=first, num_local=count)
+        first, count = mdist.shard_samples(w.M, rank, cw)
+        Xm = w.Xq_restarts[:R] if restarts is None else restarts
+        Rm = len(Xm)
+        r = G.kg_batch(w.inner_gd, w.bounds, w.discrete, Xm, None, w.M, best, w.kg_normals, first_sample=first, num_local=count)
         kg, grad = r["kg_sum"], r["grad_sum"]
-        if world > 1:
+        if cw > 1:
+            import torch.distributed as dist
             buf = torch.from_numpy(np.concatenate([kg[:, None], grad.reshape(Rm, -1)], axis=1))
-            buf = buf.to(cdev) if cdev is not None else buf
-            dist.all_reduce(buf)
+            buf = buf.to(comm.device) if comm.device is not None else buf
+            dist.all_reduce(buf, group=comm.group)
             out = buf.cpu().numpy()
             kg, grad = out[:, 0], out[:, 1:].reshape(grad.shape)
         return kg / w.M, grad / w.M, r
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
+        comm.barrier()
         torch.cuda.synchronize()
-
-    def max_over_ranks(x):
-        if world == 1:
-            return x
-        t = torch.tensor([x], dtype=torch.float64, device=cdev if cdev is not None else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        return float(t.item())
 
     for _ in range(args.warmup):
         step()
@@ -294,39 +342,64 @@ def main():
         grad_passes += r["grad_evals"]
     local_elapsed = time.perf_counter() - t0     # this rank's own time for its K steps (before the closing barrier)
     fence()
-    elapsed = max_over_ranks(time.perf_counter() - t0)
+    elapsed = comm.max_over_ranks(time.perf_counter() - t0)
     assert np.all(np.isfinite(kg)) and np.all(np.isfinite(grad))
 
-    evals_per_step = R * world if args.shard == "restarts" else R
+    eff_world = world if multi_fallback is None else len(gps)
+    if multi_fallback is not None:
+        evals_per_step = len(w.Xq_restarts) if args.shard == "restarts" else R
+    else:
+        evals_per_step = R * world if args.shard == "restarts" else R
     total_evals = evals_per_step * args.steps
     value = total_evals / elapsed
-    per_rank = [R * args.steps / local_elapsed if args.shard == "restarts" else args.steps * R / local_elapsed]
-    if world > 1:
-        t = torch.tensor(per_rank, dtype=torch.float64, device=cdev if cdev is not None else "cpu")
-        gathered = [torch.empty_like(t) for _ in range(world)]
-        dist.all_gather(gathered, t)
-        per_rank = [float(g.item()) for g in gathered]
+    per_rank = [r[0] for r in comm.gather_floats([(R if multi_fallback is None else evals_per_step) * args.steps / local_elapsed])]
 
     # ---- extras, OUTSIDE the timed region of `value` ----
     extras = {}
-    if world > 1 and args.shard == "restarts" and not args.no_mc_shard:
+    if cw > 1 and args.shard == "restarts":
+        # cross-rank determinism: rank 0 recomputes EVERY restart of the last step on its own GPU in one call and
+        # compares with what the ranks computed and gathered -- restarts are independent evaluations, so the results must be
+        # bit-identical whatever the sharding
+        if rank == 0:
+            ra = G.kg_batch(w.inner_gd, w.bounds, w.discrete, w.Xq_restarts, None, w.M, best, w.kg_normals)
+            kg1, grad1 = ra["kg_sum"] / w.M, ra["grad_sum"] / w.M
+            sc = max(float(np.abs(grad1).max()), float(np.abs(kg1).max()))
+            dmax = max(float(np.abs(kg - kg1).max()), float(np.abs(grad - grad1).max())) / sc
+            extras["determinism"] = {"max_rel_diff_vs_one_rank": dmax, "ok": bool(dmax <= 1e-12), "restarts": int(len(kg1)),
+                                     "note": "all %d restarts recomputed by rank 0 alone vs the gathered per-rank results" % len(kg1)}
+        fence()
+    elif cw == 1 and multi_fallback is None and args.shard == "restarts" and R > 1:
+        # N = 1: the same property across BATCHES -- the first restarts evaluated in a call of their own
+        k = min(R, 4)
+        rb = G.kg_batch(w.inner_gd, w.bounds, w.discrete, my_restarts[:k], None, w.M, best, w.kg_normals)
+        sc = max(float(np.abs(grad).max()), float(np.abs(kg).max()))
+        dmax = max(float(np.abs(rb["kg_sum"] / w.M - kg[:k]).max()), float(np.abs(rb["grad_sum"] / w.M - grad[:k]).max())) / sc
+        extras["determinism"] = {"max_rel_diff_vs_separate_call": dmax, "ok": bool(dmax <= 1e-12), "restarts": k,
+                                 "note": "the first %d restarts of the step evaluated in a call of their own" % k}
+    if cw > 1 and args.shard == "restarts" and not args.no_mc_shard:
         # MC-sample sharding of ONE evaluation at a time (strong scaling of the single-evaluation latency): every rank takes an
         # even-aligned slice of the 10k samples, ONE all_reduce of 1 + q d doubles per evaluation
         one = w.Xq_restarts[:1]
         ksteps = max(10, args.steps)
         for _ in range(3):
-            step("mc", one)
+            kgm, gradm, _r = step("mc", one)
         fence()
         t1 = time.perf_counter()
         for _ in range(ksteps):
-            step("mc", one)
+            kgm, gradm, _r = step("mc", one)
         fence()
-        dt = max_over_ranks(time.perf_counter() - t1)
+        dt = comm.max_over_ranks(time.perf_counter() - t1)
         extras["mc_shard"] = {"value": ksteps / dt, "unit": "evals/s", "ms_per_eval": 1e3 * dt / ksteps, "evals_per_step": 1,
-                              "samples_per_rank": mdist.shard_samples(w.M, 0, world)[1],
+                              "samples_per_rank": mdist.shard_samples(w.M, 0, cw)[1],
                               "collective": "one all_reduce(SUM) of %d doubles per evaluation" % (1 + w.q * w.d)}
-    if not args.no_batch1 and args.shard == "restarts":
-        # one evaluation per call (what compute_grad_knowledge_gradient does): the batch-1 latency next to the batch-R rate
+        if rank == 0:
+            r1 = G.kg_batch(w.inner_gd, w.bounds, w.discrete, one, None, w.M, best, w.kg_normals)
+            sc = max(float(np.abs(r1["grad_sum"]).max()), float(np.abs(r1["kg_sum"]).max())) / w.M
+            extras["mc_shard"]["max_rel_diff_vs_unsharded"] = max(float(np.abs(kgm - r1["kg_sum"] / w.M).max()),
+                                                                  float(np.abs(gradm - r1["grad_sum"] / w.M).max())) / sc
+        fence()
+    if not args.no_batch1 and args.shard == "restarts" and multi_fallback is None:
+        # one evaluation per call (what compute_grad_knowledge_gradient does): the batch-1 latency next to the batched rate
         one = my_restarts[:1]
         ksteps = max(20, args.steps)
         for _ in range(5):
@@ -339,76 +412,121 @@ def main():
         dt = time.perf_counter() - t1
         extras["batch1"] = {"value": ksteps / dt, "unit": "evals/s per GPU", "ms_per_eval": 1e3 * dt / ksteps,
                             "note": "one evaluation per moe_kg_batch call, one at a time (rank 0)"}
+        # and the batch of 8 the earlier rounds' headline was quoted on (comparable with BENCH_r01 / BENCH_r02)
+        if R >= 8:
+            eight = my_restarts[:8]
+            for _ in range(2):
+                step("restarts", eight)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(ksteps):
+                step("restarts", eight)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t1
+            extras["batch8"] = {"value": 8 * ksteps / dt, "unit": "evals/s per GPU", "ms_per_eval": 1e3 * dt / (8 * ksteps),
+                                "note": "8 evaluations per moe_kg_batch call (the step of rounds 1 and 2)"}
         fence()
 
     if rank == 0:
         # ---- roofline of the dominant kernel (MC inner optimisation: FP64 vector-ALU bound) ----
-        local_evals = R * args.steps                      # evaluations whose kernels this rank launched
-        mc_ms = ms_mc / args.steps                        # avg MC-kernel ms per evaluation (HIP events, library stream)
-        g1 = 1 + w.g
-        npts = (w.n + w.q) * g1                           # N + m covariance entries each pass walks
-        n_local = w.M if args.shard == "restarts" else mdist.shard_samples(w.M, 0, world)[1]
-        S = val_passes / float(local_evals * n_local)     # counted value passes per sample
-        Gp = grad_passes / float(local_evals * n_local)   # counted value+gradient passes per sample
-        flops = n_local * npts * (S * (3 * w.d + 32) + Gp * (5 * w.d + 34))   # SURVEY 8(d) per-entry figures
+        Rl = R if multi_fallback is None else (evals_per_step + len(gps) - 1) // len(gps)   # evaluations per launch on this device
+        local_evals = Rl * args.steps                     # evaluations whose kernels this rank launched
+        mc_ms = ms_mc / args.steps / (1 if multi_fallback is None else 1)   # avg MC-kernel ms per evaluation (HIP events, library stream)
+        npts, f_val, f_grad = pass_flops(w)
+        n_local = w.M if args.shard == "restarts" else mdist.shard_samples(w.M, 0, cw)[1]
+        if multi_fallback is not None:                    # counters are summed over the devices
+            S = val_passes / float(evals_per_step * args.steps * n_local)
+            Gp = grad_passes / float(evals_per_step * args.steps * n_local)
+        else:
+            S = val_passes / float(local_evals * n_local)     # counted value passes per sample
+            Gp = grad_passes / float(local_evals * n_local)   # counted value+gradient passes per sample
+        flops = n_local * npts * (S * f_val + Gp * f_grad)    # per evaluation
         ach_tflops = flops / (mc_ms * 1e-3) / 1e12
         # ---- roofline of the covariance-assembly kernel (HBM write-bound) ----
         # The q-KG gradient tail no longer materialises T = K(X, x*) (kg.hip: launch_fused_tail), so the assembly kernel
-        # (a3/a4: GP build, posterior queries, the d-KG tail) is measured live on the SAME N x M shape the tail used to
-        # build -- N = n training rows x (R * M) columns, 640 MB at C3 -- through moe_cov_build_probe (HIP events on the
+        # (a3/a4: GP build, posterior queries, the d-KG tail) is measured live on an N x M shape of the size the tail used to
+        # build -- N = n training rows x 80 000 columns, 640 MB at C3 -- through moe_cov_build_probe (HIP events on the
         # library's stream around `repeat` launches).
-        probe_pts = np.random.default_rng(7).uniform(size=(R * n_local, w.d))
+        Rp = min(Rl, 8)
+        probe_pts = np.random.default_rng(7).uniform(size=(Rp * n_local, w.d))
         cov_launch_ms, cov_bytes_launch = G.cov_build_probe(probe_pts, repeat=10)
-        cov_bytes = cov_bytes_launch / R                                    # 8[nA d + nB d + nA nB]
+        cov_bytes = cov_bytes_launch / Rp                                   # 8[nA d + nB d + nA nB]
         cov_tbs = cov_bytes_launch / (cov_launch_ms * 1e-3) / 1e12 if cov_launch_ms > 0 else 0.0
-        traffic, traffic_src = (None, "skipped (--no-traffic)")
-        if world == 1 and not args.no_traffic and args.config == "C3":
-            traffic, traffic_src = measure_traffic(R, log)
-        if traffic is None:
-            committed = committed_traffic()
-            traffic = {k: float(v["hbm_bytes_per_launch"]) for k, v in committed.items() if "hbm_bytes_per_launch" in v}
-            traffic_src = "profiles/hbm_traffic.json (committed rocprofv3 PMC passes of an earlier run; %s)" % traffic_src
         mc_kernel = "kg_mc_kernel" if (w.g == 0 and w.n + w.q <= 1600) else "kg_mc_block_kernel"
+        pmc, traffic_src = (None, "skipped (--no-traffic)")
+        if world == 1 and not args.no_traffic:
+            pmc, traffic_src = measure_traffic(args.config, Rl, log)
+        if pmc is None:
+            pmc = committed_traffic()
+            traffic_src = "profiles/hbm_traffic.json (committed rocprofv3 PMC passes of an earlier run, %d evaluations per launch; %s)" % (
+                int(pmc.get("evals_per_launch", 8)), traffic_src)
+        pk = pmc.get(mc_kernel, {}) if isinstance(pmc.get(mc_kernel, {}), dict) else {}
+        pmc_R = int(pmc.get("evals_per_launch", 8))   # (the committed file of rounds 1-2 was taken at 8 evaluations per launch)
+        traffic = pk.get("hbm_bytes_per_launch")
+        exec_flop = pk.get("executed_fp64_flop_per_launch")
+        launch_ms = mc_ms * Rl
+        executed = None
+        if exec_flop is not None and launch_ms > 0:
+            ex_tflops = exec_flop * (Rl / float(pmc_R)) / (launch_ms * 1e-3) / 1e12
+            executed = {"achieved": ex_tflops, "frac": ex_tflops / FP64_PEAK_TFLOPS, "flop_per_launch": exec_flop * (Rl / float(pmc_R)),
+                        "wave_insts_per_launch": {k: pk[k] for k in pk if k.startswith("SQ_INSTS_VALU")},
+                        "note": "EXECUTED FP64 flop (64 lanes x (2 FMA + ADD + MUL) wave-instructions, rocprofv3 PMC) / the same "
+                                "HIP-event launch time: how busy the FP64 pipe is, next to the algorithmic fraction `frac`"}
         out = {
             "metric": ("q-KG gradient evals/s (n=1000,d=8,q=4,10k MC)" if args.config in ("C3", "C4") else
                        "%s gradient evals/s (n=%d,d=%d,q=%d,g=%d,%d MC) [secondary configuration %s]"
                        % ("d-KG" if w.g else "q-KG", w.n, w.d, w.q, w.g, w.M, args.config)),
             "value": value, "unit": "evals/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
-            "higher_is_better": True, "scaling": "weak" if args.shard == "restarts" else "strong", "vs_baseline": None,
+            "higher_is_better": True, "scaling": "strong" if (strong or args.shard == "mc") else "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": "%s: %s value+gradient, n=%d d=%d q=%d g=%d M=%d MC, P=%d discrete pts, Matern-5/2, inner GD "
-                                   "(1,6,1,3,0,1,0.1,1e-10); %d evaluations per GPU per step"
-                                   % (args.config, "d-KG" if w.g else "q-KG", w.n, w.d, w.q, w.g, w.M, w.P, R),
-                       "shard": args.shard, "evals_per_step": evals_per_step},
-            "rccl_ranks": world if (world > 1 and backend == "nccl") else 0,
+                                   "(1,6,1,3,0,1,0.1,1e-10); %s"
+                                   % (args.config, "d-KG" if w.g else "q-KG", w.n, w.d, w.q, w.g, w.M, w.P,
+                                      ("one step = the C4 job: %d multistart restarts, %d per GPU" % (C4_RESTARTS, R)) if strong
+                                      else "%d evaluations per GPU per step" % R),
+                       "shard": args.shard, "evals_per_step": evals_per_step, "evals_per_gpu_per_step": Rl},
+            "rccl_ranks": comm.rccl_ranks,
+            "collective_backend": comm.backend if multi_fallback is None else "none (moe_kg_batch_multi, one host thread per device)",
+            "fallback": ("moe_kg_batch_multi: " + multi_fallback) if multi_fallback is not None else comm.fallback,
+            "devices_used": eff_world,
             "per_rank_evals_per_s": per_rank,
             "roofline": {"bound": "fp64_valu", "achieved": ach_tflops, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": ach_tflops / FP64_PEAK_TFLOPS,
-                         "traffic": traffic.get("kg_mc_kernel") if mc_kernel == "kg_mc_kernel" else None,
+                         "executed_frac": executed["frac"] if executed else None,
+                         "executed": executed,
+                         "traffic": traffic * (Rl / float(pmc_R)) if traffic is not None else None,
                          "traffic_source": traffic_src,
-                         "kernel": mc_kernel, "avg_launch_ms": mc_ms * R, "avg_ms_per_eval": mc_ms,
-                         "evals_per_launch": R, "value_passes_per_sample": S, "grad_passes_per_sample": Gp,
-                         "entries_per_pass": npts,
+                         "kernel": mc_kernel, "avg_launch_ms": launch_ms, "avg_ms_per_eval": mc_ms,
+                         "evals_per_launch": Rl, "value_passes_per_sample": S, "grad_passes_per_sample": Gp,
+                         "points_per_pass": npts, "flops_per_point_value_pass": f_val, "flops_per_point_gradient_pass": f_grad,
                          "note": "FP64 vector-ALU bound (sqrt + exp per covariance entry).  The kernel issues no MFMA: on gfx950 "
                                  "v_mfma_f64 and FP64 VALU instructions do not overlap (measured: profiles/"
                                  "r02_coissue_mfma_vs_valu.txt) and both peak at 78.6 TFLOP/s, the peak used here.  achieved = "
-                                 "SURVEY 8(d) algorithmic flops -- (n+u)(1+g) covariance entries per pass x [S (3d+32) + "
-                                 "G (5d+34)] with the DEVICE-COUNTED passes S, G -- / HIP-event kernel time on the library's "
-                                 "stream; one launch covers all evaluations of a step; traffic = HBM bytes per launch (PMC), "
-                                 "tiny next to the compute time"},
+                                 "SURVEY 8(d) algorithmic flops -- n + u points per pass x [S f_value + G f_gradient] with the "
+                                 "DEVICE-COUNTED passes S, G (bench.py: pass_flops; with derivative observations a point's 1 + g "
+                                 "entries share one sqrt / exp) -- / HIP-event kernel time on the library's stream; one launch "
+                                 "covers all evaluations of a step; traffic = HBM bytes per launch (PMC), tiny next to the "
+                                 "compute time"},
             "roofline_cov_build": {"bound": "hbm", "achieved": cov_tbs * 1e3, "peak": HBM_PEAK_TBS * 1e3, "unit": "GB/s",
-                                   "frac": cov_tbs / HBM_PEAK_TBS, "traffic": traffic.get("cov_build_kernel"),
+                                   "frac": cov_tbs / HBM_PEAK_TBS,
+                                   "traffic": (pmc.get("cov_build_kernel") or {}).get("hbm_bytes_per_launch") if Rp == pmc_R else None,
                                    "traffic_source": traffic_src,
-                                   "kernel": "cov_build_kernel, N x (R M) = %d x %d, measured by moe_cov_build_probe (the q-KG "
+                                   "kernel": "cov_build_kernel, N x M = %d x %d, measured by moe_cov_build_probe (the q-KG "
                                              "tail itself no longer writes this matrix: it recomputes the entries where "
-                                             "they are consumed)" % (w.n, R * n_local),
+                                             "they are consumed)" % (w.n, Rp * n_local),
                                    "avg_launch_ms": cov_launch_ms, "bytes_per_launch": cov_bytes_launch,
                                    "bytes_per_eval_equiv": cov_bytes},
             "kernel_ms_per_eval": {"mc": mc_ms, "cov_build": ms_cov / args.steps, "tail": ms_tail / args.steps,
                                    "state_host": ms_state / args.steps},
+            "rccl_preflight_s": comm.preflight_s,
         }
         out.update(extras)
+        if not args.no_extras and world == 1 and hasattr(mapi, "kxx_build_probe"):
+            try:
+                out["roofline_cov_build_kxx"] = mapi.kxx_build_probe(log)
+            except Exception as e:  # pragma: no cover
+                log("kxx_build_probe failed: %s" % e)
         if not args.no_cpu_baseline and world == 1 and args.config == "C5":
             out["cpu_baseline"] = cpu_baseline_c5(w, log)
             out["speedup_vs_cpu_one_core"] = value / out["cpu_baseline"]["value"]
@@ -418,9 +536,7 @@ def main():
             if "one_core_evals_per_s" in out["cpu_baseline"]:
                 out["speedup_vs_cpu_one_core"] = value / out["cpu_baseline"]["one_core_evals_per_s"]
         print(json.dumps(out), flush=True)
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+    comm.close()
 
 
 if __name__ == "__main__":

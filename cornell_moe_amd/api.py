@@ -58,6 +58,16 @@ def _d(a):
     return a, a.ctypes.data_as(dp)
 
 
+def set_reference_quirks(on):
+    """moe_set_reference_quirks: 1 = the multistart drivers reproduce the reference's execution, defects included (default);
+    0 = the drivers as the reference intends them (fresh states, all q points move); -1 = follow MOE_REFERENCE_QUIRKS."""
+    _lib.load().moe_set_reference_quirks(int(on))
+
+
+def get_reference_quirks():
+    return bool(_lib.load().moe_get_reference_quirks())
+
+
 def normal_draws(seed, count):
     out = np.empty(int(count), dtype=np.float64)
     _lib.load().moe_normal_draws(C.c_uint(int(seed) & 0xFFFFFFFF), int(count), out.ctypes.data_as(dp))
@@ -421,6 +431,13 @@ class DeviceGP(object):
         out = np.zeros(5)
         _lib.load().moe_last_kernel_ms(self._h, out.ctypes.data_as(dp))
         return dict(mc=out[0], cov_build=out[1], tail=out[2], state=out[3], total=out[4])
+
+
+    def last_kernel_info(self):
+        out = (C.c_int * 8)()
+        _lib.load().moe_last_kernel_info(self._h, out)
+        keys = ("variant", "xlds", "waves", "tr", "weight_table", "fused_tail", "blocks", "prep")
+        return dict(zip(keys, [int(v) for v in out]))
 
 
 def kg_batch_multi(gps, shard, inner_params, bounds, discrete, Xq_all, Xp, num_mc, best_so_far, normals, want_grad=True,

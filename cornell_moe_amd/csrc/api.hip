@@ -72,6 +72,7 @@ struct moe_ll {
   int cov_type, g, d, n, device;
   std::vector<double> X, y;
   std::vector<int> derivs;
+  std::mutex mu;                   // calls on one handle are serialised, like moe_gp_t's
   std::unique_ptr<moe::GpDev> gp;  // moe_ll_grad's factorisation (with the inverse factor)
   // moe_ll_evaluate: batches of bordered factorisations (kernels.hpp launch_cholesky_batch)
   hipStream_t stream = nullptr;
@@ -87,7 +88,13 @@ struct moe_ll {
 
 extern "C" {
 
-const char* moe_version(void) { return "cornell_moe_amd 0.1 (gfx950)"; }
+const char* moe_version(void) { return "cornell_moe_amd 0.3 (gfx950)"; }
+
+int moe_set_reference_quirks(int on) {
+  moe::set_reference_quirks(on);
+  return MOE_OK;
+}
+int moe_get_reference_quirks(void) { return moe::reference_quirks() ? 1 : 0; }
 
 int moe_device_count(int* count) {
   int c = 0;
@@ -381,7 +388,15 @@ int moe_debug_math(int n, const double* x, int device, double* exp_neg, double* 
 
 int moe_last_kernel_ms(const moe_gp_t* gp, double* out5) {
   if (gp == nullptr || out5 == nullptr) return MOE_ERR_RUNTIME;
+  std::lock_guard<std::mutex> lk(const_cast<moe_gp_t*>(gp)->mu);
   for (int i = 0; i < 5; ++i) out5[i] = gp->dev.last_ms[i];
+  return MOE_OK;
+}
+
+int moe_last_kernel_info(const moe_gp_t* gp, int* out8) {
+  if (gp == nullptr || out8 == nullptr) return MOE_ERR_RUNTIME;
+  std::lock_guard<std::mutex> lk(const_cast<moe_gp_t*>(gp)->mu);
+  for (int i = 0; i < 8; ++i) out8[i] = gp->dev.last_info[i];
   return MOE_OK;
 }
 
@@ -529,6 +544,16 @@ int moe_kg_batch_multi(const moe_gp_t* const* gps, int num_devices, int shard_mo
     std::vector<moe::Error> errors(W, moe::Error(MOE_OK, ""));
     std::vector<char> failed(W, 0);
     std::vector<std::thread> threads;
+    threads.reserve(W);
+    // (a thread that cannot be started -- std::system_error under thread exhaustion -- must not unwind past joinable threads:
+    //  that would be std::terminate; the started ones are joined first and the error is returned as a status code)
+    struct JoinAll {
+      std::vector<std::thread>& t;
+      ~JoinAll() {
+        for (std::thread& th : t)
+          if (th.joinable()) th.join();
+      }
+    } join_all{threads};
     for (int k = 0; k < W; ++k) {
       const int ne = (int)mine[k].size();
       st[k] = moe_kg_stats_t{};
@@ -686,6 +711,7 @@ int moe_ll_evaluate(moe_ll_t* ll, const double* hyperparameters_all, int num_set
   return guarded(err, [&] {
     require(ll != nullptr && hyperparameters_all != nullptr && values != nullptr, "NULL argument");
     if (num_sets <= 0) return;
+    std::lock_guard<std::mutex> lk(ll->mu);
     MOE_HIP_CHECK(hipSetDevice(ll->device));
     const int g1 = 1 + ll->g, d = ll->d, n = ll->n, N = n * g1, stride = 1 + d + g1;
     const int dp = moe::padded_dim(d);
@@ -747,6 +773,7 @@ int moe_ll_evaluate(moe_ll_t* ll, const double* hyperparameters_all, int num_set
 int moe_ll_grad(moe_ll_t* ll, const double* hyperparameters, double* grad, moe_error_t* err) {
   return guarded(err, [&] {
     require(ll != nullptr && hyperparameters != nullptr && grad != nullptr, "NULL argument");
+    std::lock_guard<std::mutex> lk(ll->mu);
     const int g1 = 1 + ll->g;
     std::vector<double> noise(g1);
     for (int a = 0; a < g1; ++a) noise[a] = hyperparameters[1 + ll->d + a] + 1.0e-6;  // gpp_model_selection.cpp:546-549

@@ -261,14 +261,22 @@ std::vector<double> GpDev::padded(const double* pts, int k) const {
   return out;
 }
 
+void GpDev::refresh_extent() {
+  for (int k = 0; k < d; ++k) {
+    double c = 0.0, ext = 0.0;
+    for (int j = 0; j < n; ++j) c += X[(size_t)j * d + k];
+    c /= (double)std::max(n, 1);
+    for (int j = 0; j < n; ++j) ext = std::max(ext, std::fabs(X[(size_t)j * d + k] - c));
+    x_mean[k] = c;
+    x_ext[k] = ext;
+  }
+}
+
 void GpDev::rebuild() {
   use_device();
   N = n * (1 + g);
-  for (int k = 0; k < d; ++k) {  // frame centre of the value-only covariance builds: the training-set mean
-    double c = 0.0;
-    for (int j = 0; j < n; ++j) c += X[(size_t)j * d + k];
-    cp.center[k] = c / (double)n;
-  }
+  refresh_extent();
+  for (int k = 0; k < d; ++k) cp.center[k] = x_mean[k];  // frame centre of the value-only covariance builds: the training-set mean
   const std::vector<double> Xp = padded(X.data(), n);
   dX.upload(Xp.data(), Xp.size(), stream);
   dNoise.upload(noise.data(), noise.size(), stream);
@@ -363,6 +371,7 @@ void GpDev::add_points_unchecked(const double* pts, const double* vals, int k) {
     return;
   }
   use_device();
+  refresh_extent();  // (cp.center stays: any point near the data serves the value-only builds)
   bool singular = false;
   {
     // (dX is re-sent whole: a few KB, and its buffer may move when it grows)

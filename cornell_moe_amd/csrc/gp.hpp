@@ -37,8 +37,17 @@ struct GpDev {
   DevBuf<unsigned long long> kCounters;
   DevBuf<int> kBestJ;
   int num_cu = 256;
+  // per-dimension mean and max |x - mean| of the training points (refreshed by rebuild() and by the append path of add_points):
+  // the frame centre of the KG coordinate tables and the extent the kernel selection needs, so that an evaluation does not
+  // re-walk the n x d coordinates on the host (r3, ADVICE)
+  double x_mean[kMaxDimPadded] = {0}, x_ext[kMaxDimPadded] = {0};
+  void refresh_extent();
   // timing of the last KG call (ms): mc, cov-build, tail contraction, state, total
   double last_ms[5] = {0, 0, 0, 0, 0};
+  // which MC kernel the last KG launch took (moe_last_kernel_info): variant (0 wave-per-sample, 1 workgroup-per-sample) |
+  // coordinate table in LDS | wavefronts per workgroup | register tiles per wavefront (variant 1) | streamed per-sample weight
+  // table | T-free gradient tail | workgroups | sample pre-pass
+  int last_info[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 
   GpDev(const double* hyper, int cov_type, const double* X_in, const double* y_in, const double* noise_in,
         const int* derivs_in, int g_in, int d_in, int n_in, int device_in);

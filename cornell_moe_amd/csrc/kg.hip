@@ -877,13 +877,19 @@ KgPending kg_launch(GpDev& gp, int num_fidelity, const moe_gd_params_t& gd, cons
   // kernels are used instead (coordinates streamed from L2, or the workgroup-per-sample kernel): slower, exact.
   bool wide_frame = false, far_frame = false;
   {
+    // The extent is taken from what does NOT depend on the batch -- the training points (cached in the GP), the points being
+    // sampled, and the DOMAIN box the restarts live in -- so that a restart takes the same kernel whether it is evaluated alone,
+    // in a batch, or in another rank's shard (r3, ADVICE: moe_kg_batch_multi / dist.py promise bit-identical restarts).  Only a
+    // point_to_sample outside the box (or a fidelity coordinate, which has no inner bound) adds its own distance.
     double rad2 = 0.0;
     for (int k = 0; k < d; ++k) {
-      double c = 0.0, ext = 0.0;
-      for (int j = 0; j < n; ++j) c += gp.X[(size_t)j * d + k];
-      c /= std::max(n, 1);
-      for (int j = 0; j < n; ++j) ext = std::max(ext, std::fabs(gp.X[(size_t)j * d + k] - c));
-      for (size_t i = 0; i < (size_t)E * q; ++i) ext = std::max(ext, std::fabs(Xq_all[i * d + k] - c));
+      const double c = gp.x_mean[k];
+      double ext = gp.x_ext[k];
+      if (k < size) ext = std::max(ext, std::max(std::fabs(bounds[2 * k] - c), std::fabs(bounds[2 * k + 1] - c)));
+      for (size_t i = 0; i < (size_t)E * q; ++i) {
+        const double v = Xq_all[i * d + k];
+        if (k >= size || v < bounds[2 * k] || v > bounds[2 * k + 1]) ext = std::max(ext, std::fabs(v - c));
+      }
       for (int i = 0; i < p; ++i) ext = std::max(ext, std::fabs(Xp[(size_t)i * d + k] - c));
       rad2 += (ext * gp.cp.inv_l[k]) * (ext * gp.cp.inv_l[k]);
     }
@@ -1010,17 +1016,12 @@ KgPending kg_launch(GpDev& gp, int num_fidelity, const moe_gd_params_t& gd, cons
       tp.perm[r] = order[r];
       // frame scale: the Matern kernel's sqrt(5) is folded into it (kg_mc.hpp radial3)
       tp.inv_lp[r] = gp.cp.inv_l[order[r]] * (gp.cp.type == MOE_COV_MATERN_NU_2P5 ? 2.236067977499789696409173668731276235 : 1.0);
-      double c = 0.0;  // training-set mean of the row's coordinate (0 for pad rows)
-      if (order[r] < d) {
-        for (int j = 0; j < n; ++j) c += gp.X[(size_t)j * d + order[r]];
-        c /= n;
-      }
+      const double c = (order[r] < d) ? gp.x_mean[order[r]] : 0.0;  // training-set mean of the row's coordinate (0 for pad rows)
       tp.center[r] = c;
       // the MC kernels' exponent arithmetic covers |x - c| / l up to kTableExtent for every tabulated point
       if (order[r] < d) {
         const int k = order[r];
-        double ext = 0.0;
-        for (int j = 0; j < n; ++j) ext = std::max(ext, std::fabs(gp.X[(size_t)j * d + k] - c));
+        double ext = gp.x_ext[k];
         for (int e = 0; e < E; ++e) {
           for (int i = 0; i < q; ++i) ext = std::max(ext, std::fabs(Xq_all[((size_t)e * q + i) * d + k] - c));
         }
@@ -1268,6 +1269,11 @@ KgPending kg_launch(GpDev& gp, int num_fidelity, const moe_gd_params_t& gd, cons
   else
     launch_mc_block(mp, dp, G, tr, num_lds_tiles, blocks, waves, s);
   t_mc.stop(s);
+  {
+    const int info[8] = {variant, (variant == 0 && xlds) ? 1 : 0, waves, variant == 1 ? tr : 0, mp.V != nullptr ? 1 : 0, 0, blocks,
+                         mp.best_j != nullptr ? 1 : 0};
+    std::copy(info, info + 8, gp.last_info);
+  }
 
   // ---- 3. gradient tail ----
   KgTailParams tl;
@@ -1302,6 +1308,7 @@ KgPending kg_launch(GpDev& gp, int num_fidelity, const moe_gd_params_t& gd, cons
   tl.TBpart = dTB.p;
   tl.out = dOut.p;
   tl.out_stride = out_stride;
+  gp.last_info[5] = fused_tail ? 1 : 0;
   if (fused_tail) {
     t_cov.start(s);
     t_cov.stop(s);  // no covariance matrix is built on this path

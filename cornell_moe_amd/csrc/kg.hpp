@@ -49,6 +49,12 @@ KgPending kg_launch(GpDev& gp, int num_fidelity, const moe_gd_params_t& gd, cons
                     const double* disc_head = nullptr);
 
 // ---- callers of the hot path (multistart.hip) ----
+// Whether the outer-optimisation drivers reproduce the reference's EXECUTION (state objects built at start_points[0] whose
+// discretised set is never refreshed; the KG-MCMC state's partial SetCurrentPoint and accumulating gradient) or its intent
+// (fresh state per evaluation, all q points move, plain gradient).  Default: on -- results identical to the reference's
+// (env MOE_REFERENCE_QUIRKS=0 or moe_set_reference_quirks(0) turn it off; include/moe_hip.h).
+bool reference_quirks();
+void set_reference_quirks(int on);  // < 0: back to the environment's setting
 // A maximisation objective evaluated at a BATCH of points [n][qd]: values [n], grads [n][qd].
 struct BatchObjective {
   std::function<void(const double* x_all, int n, double* values)> values;

@@ -178,6 +178,25 @@ void kg_mcmc_multistart(const std::vector<GpDev*>& gps, int num_fidelity, const 
   check_ensemble(gps);
   if (num_starts <= 0) throw Error(MOE_ERR_BOUNDS, "num_multistarts must be > 1", num_starts, 1, 1e9);
   const int d = gps[0]->d, qd = q * d, nm = (int)gps.size();
+  if (!reference_quirks()) {
+    // The driver as the reference INTENDS it (MOE_REFERENCE_QUIRKS=0 / moe_set_reference_quirks(0)): the generic multistart over
+    // the MCMC-averaged objective KG(x) = mean_i KG_i(x) / cost(x) -- fresh per-GP states at every evaluation, all q points move
+    // and are returned, the plain gradient ((mean grad) cost - KG grad cost) / cost^2 at every step.
+    BatchObjective f;
+    f.values = [&](const double* x_all, int n, double* values) {
+      kg_mcmc_sums(gps, num_fidelity, inner, bounds, discrete_all, P, x_all, n, Xp, q, p, num_mc, best_so_far, normals, false, values,
+                   nullptr, nullptr);
+      kg_mcmc_finalize(values, nullptr, x_all, n, q, d, num_fidelity, nm);
+    };
+    f.grads = [&](const double* x_all, int n, double* grads) {
+      std::vector<double> ks(n);
+      kg_mcmc_sums(gps, num_fidelity, inner, bounds, discrete_all, P, x_all, n, Xp, q, p, num_mc, best_so_far, normals, true, ks.data(),
+                   grads, nullptr);
+      kg_mcmc_finalize(ks.data(), grads, x_all, n, q, d, num_fidelity, nm);
+    };
+    multistart(f, outer, bounds, d, qd, starts, num_starts, do_gradient_ascent, -INFINITY, best_points, best_kg, found);
+    return;
+  }
   const double* head = starts;
   auto seen_of = [&](const double* actual, double* seen) {  // what GetCurrentPoint returns for a state moved to `actual`
     std::copy(head, head + qd, seen);

@@ -10,7 +10,9 @@
 // device pass (kg_evaluate_batch).  Every evaluation replays the same normal table (the reference rewinds its RNG before
 // each evaluation), so the ascent sees common random numbers.
 #include <algorithm>
+#include <atomic>
 #include <cmath>
+#include <cstdlib>
 #include <functional>
 #include <numeric>
 #include <queue>
@@ -21,6 +23,19 @@
 #include "kg.hpp"
 
 namespace moe {
+
+namespace {
+std::atomic<int> g_reference_quirks{-1};  // -1: follow the environment
+}
+
+bool reference_quirks() {
+  const int v = g_reference_quirks.load();
+  if (v >= 0) return v != 0;
+  const char* e = std::getenv("MOE_REFERENCE_QUIRKS");
+  return !(e && *e && std::atoi(e) == 0);
+}
+
+void set_reference_quirks(int on) { g_reference_quirks.store(on < 0 ? -1 : (on != 0 ? 1 : 0)); }
 
 namespace {
 
@@ -180,7 +195,9 @@ void kg_multistart(GpDev& gp, int num_fidelity, const moe_gd_params_t& outer, co
   // The reference builds its evaluation states at the FIRST start and moves them with SetCurrentPoint, which leaves the
   // discretised set behind (kg.hpp: disc_head): every evaluation of the run scores / starts its inner optimisation from the
   // first start's q points.  Reproduced: the end point is pinned to the reference's (tests/golden/ref_kg_multistart.npz).
-  const double* head = (num_starts > 0) ? starts : nullptr;
+  // With the quirks switched off every evaluation runs on a fresh state (its own q points in the discretised set), as the
+  // single-evaluation entry points do.
+  const double* head = (num_starts > 0 && reference_quirks()) ? starts : nullptr;
   BatchObjective f;
   f.values = [&](const double* x_all, int n, double* values) {
     kg_values(gp, num_fidelity, inner, bounds, discrete, P, x_all, n, Xp, q, p, num_mc, best_so_far, normals, values, head);

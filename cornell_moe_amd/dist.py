@@ -109,3 +109,152 @@ def kg_mcmc_sharded(local_sums, finalize, group=None, device=None):
     dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
     out = t.cpu().numpy()
     return finalize(out[:kg_sum.size].reshape(kg_sum.shape), out[kg_sum.size:].reshape(grad_sum.shape))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Process-group bring-up with a pre-flight (round 3).  The data plane is RCCL (`nccl`), one rank per GPU; but a first contact
+# with a multi-GPU node must not be able to hang or kill the job, so:
+#   1. the DEFAULT group is gloo (TCP on 127.0.0.1): the control plane -- agreement between ranks, timing reductions on host
+#      tensors -- never depends on RCCL;
+#   2. RCCL is tried first in a throw-away CHILD process per rank (`python -m cornell_moe_amd.dist --preflight`, its own
+#      rendezvous port): init_process_group("nccl", device_id=...), one all_reduce of a double, checked, exit 0.  The parent
+#      waits at most `timeout_s` and kills exactly the child it started; a hang or crash inside RCCL stays in the child;
+#   3. the ranks agree (gloo all_reduce MIN) on whether every child passed; only then the parent creates its own nccl group.
+#      Otherwise the collectives of the measurement run on the gloo group and the caller is told why (`Comm.fallback`).
+# ---------------------------------------------------------------------------------------------------------------------
+class Comm(object):
+    """What bring_up() hands back: `group` carries the data-plane collectives, `device` is where their buffers live (a cuda
+    device for nccl, None = host tensors for gloo), `backend` in {"nccl", "gloo", "none"}, `fallback` = None or the reason the
+    preferred backend was not used."""
+
+    def __init__(self, rank, world, backend, group, device, fallback, preflight_s=0.0):
+        self.rank, self.world, self.backend, self.group, self.device, self.fallback = rank, world, backend, group, device, fallback
+        self.preflight_s = preflight_s
+
+    @property
+    def rccl_ranks(self):
+        return self.world if (self.world > 1 and self.backend == "nccl") else 0
+
+    def barrier(self):
+        if self.world > 1:
+            import torch.distributed as dist
+            dist.barrier()  # control plane (gloo): never an RCCL call outside the measured collectives
+
+    def max_over_ranks(self, x):
+        if self.world == 1:
+            return float(x)
+        import torch
+        import torch.distributed as dist
+        t = torch.tensor([float(x)], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def gather_floats(self, values):
+        """all_gather of a few host doubles per rank over the control plane: returns a [world][len] list."""
+        if self.world == 1:
+            return [list(map(float, values))]
+        import torch
+        import torch.distributed as dist
+        t = torch.tensor(list(map(float, values)), dtype=torch.float64)
+        outs = [torch.empty_like(t) for _ in range(self.world)]
+        dist.all_gather(outs, t)
+        return [o.tolist() for o in outs]
+
+    def close(self):
+        if self.world > 1:
+            import torch.distributed as dist
+            try:
+                dist.barrier()
+                dist.destroy_process_group()
+            except Exception:  # pragma: no cover
+                pass
+
+
+def _preflight_child():
+    """The body of the throw-away child: RCCL bring-up + one checked all_reduce.  Exit code 0 = RCCL works for this rank."""
+    import datetime
+    import os
+    import sys
+    import torch
+    import torch.distributed as dist
+    rank, world, local = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"]), int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available() or torch.cuda.device_count() <= local:
+        sys.exit(3)
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev, timeout=datetime.timedelta(seconds=60))
+    t = torch.full((1,), float(rank + 1), dtype=torch.float64, device=dev)
+    dist.all_reduce(t)
+    torch.cuda.synchronize()
+    ok = abs(float(t.item()) - world * (world + 1) / 2.0) < 1e-12
+    dist.destroy_process_group()
+    sys.exit(0 if ok else 4)
+
+
+def _free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def bring_up(rank, world, local_rank, prefer="nccl", timeout_s=60.0, log=None):
+    """Default (control) group on gloo, data group on `prefer` when its pre-flight passes on EVERY rank; see the block comment."""
+    import datetime
+    import os
+    import subprocess
+    import sys
+    import time
+    log = log or (lambda m: None)
+    if world <= 1:
+        return Comm(rank, 1, "none", None, None, None)
+    import torch
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if os.environ.get("MOE_DIST_FAIL") == "rendezvous":  # test hook: what the caller does when no process group comes up
+        raise RuntimeError("MOE_DIST_FAIL=rendezvous")
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=600))
+    if prefer != "nccl":
+        return Comm(rank, world, "gloo", None, None, None)
+    t0 = time.time()
+    port = [_free_port() if rank == 0 else 0]
+    dist.broadcast_object_list(port, src=0)
+    env = dict(os.environ, MASTER_PORT=str(port[0]), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    env.pop("TORCHELASTIC_RUN_ID", None)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    child = subprocess.Popen([sys.executable, "-m", "cornell_moe_amd.dist", "--preflight"], env=env, cwd=root,
+                             stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, universal_newlines=True)
+    why = None
+    try:
+        _, err = child.communicate(timeout=timeout_s)
+        if child.returncode != 0:
+            why = "rccl pre-flight failed on rank %d (exit %d): %s" % (rank, child.returncode, (err or "").strip().splitlines()[-1:] or "")
+    except subprocess.TimeoutExpired:
+        child.kill()  # exactly the process started above
+        child.communicate()
+        why = "rccl pre-flight timed out after %.0f s on rank %d" % (timeout_s, rank)
+    flag = torch.tensor([0.0 if why else 1.0], dtype=torch.float64)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    whys = [None] * world
+    dist.all_gather_object(whys, why)
+    took = time.time() - t0
+    if float(flag.item()) < 0.5:
+        reason = next((w for w in whys if w), "rccl pre-flight failed")
+        log("RCCL NOT USED -- %s; collectives run on gloo (host tensors)" % reason)
+        return Comm(rank, world, "gloo", None, None, reason, took)
+    dev = torch.device("cuda", local_rank)
+    try:
+        grp = dist.new_group(backend="nccl", timeout=datetime.timedelta(seconds=120), device_id=dev)
+    except TypeError:  # older signature without device_id
+        grp = dist.new_group(backend="nccl", timeout=datetime.timedelta(seconds=120))
+    t = torch.ones(1, dtype=torch.float64, device=dev)
+    dist.all_reduce(t, group=grp)
+    torch.cuda.synchronize()
+    assert abs(float(t.item()) - world) < 1e-12
+    return Comm(rank, world, "nccl", grp, dev, None, took)
+
+
+if __name__ == "__main__":
+    import sys
+    if "--preflight" in sys.argv:
+        _preflight_child()

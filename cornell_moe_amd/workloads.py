@@ -17,6 +17,19 @@ CONFIGS = {
     "C5": dict(seed=1005, n=2000, d=12, q=8, M=20000, P=50, derivs=(0, 1, 2)),
 }
 
+# Parity-test cases of round 3 (tools/make_golden.py: shape_fixtures_r3 -> tests/golden/ref_shapes_r3.npz; the other configs
+# are parity-test cases, not bench lines): the EXACT headline configuration, C5's d-KG at n = 1000 (big enough for the
+# workgroup-per-sample kernel + streamed weight table), and the sizes lifted in round 2 (d > 16, g > 4, m > 64).
+R3_PARITY_CASES = (
+    ("c3full", dict(name="C3")),                                                                   # M = 10 000
+    ("c5n1000", dict(name="C5", n=1000, M=64)),                                                    # N = 4000, m = 32: 16 tiles x 4 weights
+    ("d24g2", dict(seed=3301, n=40, d=24, q=2, p=0, M=16, P=8, derivs=(3, 17))),                   # padded dimension 24
+    ("d32g0", dict(seed=3302, n=48, d=32, q=4, p=1, M=32, P=6, derivs=())),                        # padded dimension 32
+    ("d12g12", dict(seed=3303, n=40, d=12, q=8, p=0, M=16, P=10, derivs=tuple(range(12)))),        # C5 with all 12 derivatives: m = 104
+    ("m128", dict(seed=3304, n=40, d=8, q=12, p=4, M=16, P=6, derivs=(0, 1, 2, 3, 4, 5, 6))),      # m = 16 x 8 = 128 (the limit)
+    ("d20g8", dict(seed=3305, n=36, d=20, q=3, p=1, M=16, P=6, derivs=(0, 2, 4, 6, 8, 10, 12, 14))),  # 8 derivative slots, d > 16
+)
+
 
 class Workload(object):
     pass

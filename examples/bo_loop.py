@@ -12,8 +12,11 @@ import time
 
 import numpy as np
 
-sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
-from cornell_moe_amd import GPP, cpp_wrappers as cw  # noqa: E402
+_ROOT = __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__)))
+sys.path.insert(0, _ROOT)
+sys.path.insert(0, __import__("os").path.join(_ROOT, "tests"))  # the wrapper mirror is test infrastructure (tests/wrappers_mirror.py);
+from cornell_moe_amd import GPP  # noqa: E402                     # with the reference installed, its own cpp_wrappers take this place
+import wrappers_mirror as cw  # noqa: E402
 
 
 def branin(x):

@@ -15,6 +15,15 @@
  *     (the Python shim applies the same symmetrisation / transposition as gpp_python_gaussian_process.cpp:136-185).
  * There is NO CPU fallback: every compute entry point requires a visible gfx950 device and fails with
  * MOE_ERR_RUNTIME otherwise.
+ *
+ * SIZE LIMITS of the device kernels (the reference has none: gpp_knowledge_gradient_optimization.hpp:310-480 allocates by
+ * size).  Beyond them the KG entry points return MOE_ERR_BOUNDS (payload: value, min, max) and compute nothing:
+ *   - dim <= 32                       (coordinate tables are built for padded dimensions 4, 8, 12, 16, 24, 32);
+ *   - num_derivatives <= 12           (derivative-weight slots of the d-KG Monte-Carlo kernels: 0..4, 8, 12);
+ *   - (num_to_sample + num_being_sampled) * (1 + num_derivatives) <= 128   (m, the fantasy-observation count of one evaluation);
+ *   - |x - mean(X)| / length <= 1e5 per coordinate for every tabulated point (32-bit exponent arithmetic of the table exp).
+ * Every configuration BASELINE.json names is inside them (C5 with all 12 derivatives observed: m = 104).  The GP itself
+ * (moe_gp_*, moe_ll_*) is limited by device memory only (N = 26 000 builds in 0.3 s; two N x N matrices stay resident).
  */
 #ifndef MOE_HIP_H_
 #define MOE_HIP_H_
@@ -118,7 +127,7 @@ int moe_posterior_mean(const moe_gp_t* gp, int num_fidelity, const double* point
  * Boost-version dependent and the reference pins no draws, so parity with an arbitrary Boost is NOT claimed.
  * The stream IS, draw for draw, that of the reference as it builds in this repository (oracle/_ref, Boost shimmed onto the
  * C++ standard library: Marsaglia's polar method over generate_canonical<double, 53>) -- pinned by tests/test_oracle.py and
- * the committed fixture tests/golden/ref_normal_stream.npz -- so a seeded RandomnessSourceContainer run reproduces that
+ * the committed fixture tests/golden/ref_kg_multistart.npz (keys stream_seeds / stream_draws) -- so a seeded RandomnessSourceContainer run reproduces that
  * build's results; cross-implementation parity runs still pass explicit tables. */
 int moe_normal_draws(unsigned int seed, long long count, double* out);
 
@@ -189,7 +198,9 @@ int moe_kg_batch(const moe_gp_t* gp, int num_fidelity, const moe_gd_params_t* in
  * reference runs as OpenMP iterations, gpp_optimization.hpp:1472-1546).  gps[num_devices] are handles of the SAME GP built on
  * different devices (moe_gp_create with device = 0 .. num_devices-1; distinct handles on one device are accepted too); one
  * host thread per handle drives its device.
- *   shard_mode 0 (restarts): evaluation e runs whole on handle e % num_devices; results equal moe_kg_batch's bit for bit.
+ *   shard_mode 0 (restarts): evaluation e runs whole on handle e % num_devices; results equal moe_kg_batch's bit for bit
+ *     (which kernel an evaluation takes is decided from the training set, points_being_sampled and the domain box alone --
+ *     never from the other evaluations of its batch -- as long as its points_to_sample lie inside domain_bounds).
  *   shard_mode 1 (MC samples): every handle evaluates every point set on its contiguous EVEN-ALIGNED slice of the samples and
  *     the per-handle sums are added on the host in handle order (a fixed-order reduction of num_evals x (1 + q d) doubles).
  * Outputs as moe_kg_batch (un-normalised sums over all num_mc samples); stats: pass counts summed, times = the slowest
@@ -221,6 +232,17 @@ int moe_kg_multistart(const moe_gp_t* gp, int num_fidelity, const moe_gd_params_
                       const double* start_points, int num_starts, const double* points_being_sampled, int num_to_sample,
                       int num_being_sampled, int num_mc, double best_so_far, const double* normals, int do_gradient_ascent,
                       double* best_points, double* best_kg, int* found, moe_error_t* err);
+/* The outer-optimisation drivers (moe_kg_multistart, moe_kg_mcmc_multistart) reproduce the reference's EXECUTION by default --
+ * the frozen discretised set, and for KG-MCMC the partially-updated state and the accumulating gradient described at
+ * moe_kg_mcmc_multistart -- because the bar of this library is "the reference's results on the reference's inputs".  Those
+ * behaviours are defects of the reference's drivers, and for q > 1 the KG-MCMC one optimises only the first point.  Switch:
+ *   moe_set_reference_quirks(0)  (or MOE_REFERENCE_QUIRKS=0 in the environment)  -> the drivers as the reference intends them:
+ *     every evaluation on a fresh state, all q points move and are returned, the plain gradient at every step;
+ *   moe_set_reference_quirks(1)  -> bug-compatible (the default);  moe_set_reference_quirks(-1) -> back to the environment.
+ * Process-wide; the single-evaluation entry points (moe_kg, moe_kg_batch, moe_kg_mcmc_batch) are unaffected: they always build
+ * a fresh state per call, as the reference's Python boundary does. */
+int moe_set_reference_quirks(int on);
+int moe_get_reference_quirks(void);
 /* posterior_mean_optimization (gpp_python_knowledge_gradient.cpp:315-342) -> ComputeOptimalPosteriorMean from ONE initial
  * guess: line-search ascent on -mu with fidelity coordinates pinned to 1.  best_point[dim - num_fidelity]. */
 int moe_posterior_mean_optimize(const moe_gp_t* gp, int num_fidelity, const moe_gd_params_t* params, const double* domain_bounds,
@@ -327,6 +349,11 @@ int moe_debug_math(int n, const double* x, int device, double* exp_neg, double* 
  * out[0] = MC inner-optimisation kernel ms, out[1] = N x M covariance-build ms, out[2] = tail contraction ms,
  * out[3] = state set-up ms, out[4] = total device ms. */
 int moe_last_kernel_ms(const moe_gp_t* gp, double* out5);
+/* Which Monte-Carlo kernel the last moe_kg* call on this handle launched (diagnostics; the tests use it to assert that a
+ * fixture really exercised the path it was built for): out[0] = variant (0 wave-per-sample, 1 workgroup-per-sample),
+ * out[1] = coordinate table in LDS, out[2] = wavefronts per workgroup, out[3] = register tiles per wavefront (variant 1),
+ * out[4] = streamed per-sample weight table, out[5] = T-free gradient tail, out[6] = workgroups, out[7] = sample pre-pass. */
+int moe_last_kernel_info(const moe_gp_t* gp, int* out8);
 
 #ifdef __cplusplus
 }

@@ -136,7 +136,7 @@ def test_normal_draws_are_standard_normal():
 
 
 def test_wrapper_mirror_containers():
-    from cornell_moe_amd import cpp_wrappers as cw
+    import wrappers_mirror as cw
     hd = cw.HistoricalData(2, 1)
     hd.append_sample_points([cw.SamplePoint([0.1, 0.2], [1.0, 0.5], 0.01), ([0.3, 0.4], [2.0, -0.5], 0.01)])
     assert hd.num_sampled == 2 and hd.points_sampled.shape == (2, 2) and hd.points_sampled_value.shape == (2, 2)

@@ -13,19 +13,49 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_bench_gpus2_self_launch():
-    env = dict(os.environ, MOE_BENCH_BACKEND="gloo")
+def _run(extra_env, *flags):
+    env = dict(os.environ, **extra_env)
     env.pop("WORLD_SIZE", None)
     env.pop("RANK", None)
     res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
-                          "--restarts", "2", "--no-cpu-baseline", "--no-traffic"], env=env, stdout=subprocess.PIPE,
-                         stderr=subprocess.PIPE, universal_newlines=True, timeout=600)
+                          "--no-cpu-baseline", "--no-traffic", "--no-extras"] + list(flags), env=env, stdout=subprocess.PIPE,
+                         stderr=subprocess.PIPE, universal_newlines=True, timeout=900)
     assert res.returncode == 0, res.stderr[-2000:]
     lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
-    assert len(lines) == 1
-    out = json.loads(lines[0])
+    assert len(lines) == 1, res.stdout[-2000:]
+    return json.loads(lines[0]), res.stderr
+
+
+def test_bench_gpus2_self_launch():
+    out, _ = _run({"MOE_BENCH_BACKEND": "gloo"}, "--restarts", "2")
     assert out["n_gpus"] == 2 and out["config"]["evals_per_step"] == 4 and out["scaling"] == "weak"
     assert len(out["per_rank_evals_per_s"]) == 2 and all(v > 0 for v in out["per_rank_evals_per_s"])
     assert out["value"] > 0 and out["mc_shard"]["value"] > 0 and out["mc_shard"]["samples_per_rank"] == 5000
     assert out["roofline"]["bound"] == "fp64_valu" and 0.05 < out["roofline"]["frac"] < 1.0
     assert "cpu_baseline" not in out  # rank 0 at N = 1 only
+    # cross-rank determinism: every restart recomputed by rank 0 alone is bit-identical; an MC-sharded evaluation agrees to 1e-12
+    assert out["determinism"]["ok"] and out["determinism"]["max_rel_diff_vs_one_rank"] == 0.0 and out["determinism"]["restarts"] == 4
+    assert out["mc_shard"]["max_rel_diff_vs_unsharded"] <= 1e-12
+    assert out["collective_backend"] == "gloo" and out["rccl_ranks"] == 0 and out["fallback"] is None
+
+
+def test_bench_rccl_preflight_failure_falls_back_to_gloo():
+    """RCCL preferred, but its pre-flight cannot pass (two ranks, one GPU): the run must go on with gloo collectives and say so."""
+    out, err = _run({"MOE_BENCH_SHARE_GPU": "1"}, "--restarts", "1", "--no-mc-shard", "--no-batch1")
+    assert out["rccl_ranks"] == 0 and out["collective_backend"] == "gloo" and "pre-flight" in out["fallback"]
+    assert "RCCL NOT USED" in err
+    assert out["value"] > 0 and out["determinism"]["ok"] and out["n_gpus"] == 2
+
+
+def test_bench_no_process_group_falls_back_to_c_abi_driver():
+    """Not even the rendezvous works: rank 0 drives the visible devices in-process through moe_kg_batch_multi, rank 1 leaves."""
+    out, err = _run({"MOE_BENCH_SHARE_GPU": "1", "MOE_DIST_FAIL": "rendezvous"}, "--restarts", "1")
+    assert out["fallback"].startswith("moe_kg_batch_multi") and out["rccl_ranks"] == 0 and out["devices_used"] == 1
+    assert out["value"] > 0 and out["config"]["evals_per_step"] == 2 and "NO PROCESS GROUP" in err
+
+
+def test_bench_default_step_is_the_c4_job():
+    """Without --restarts a step is 64 restarts shared by the ranks (C4), strong scaling."""
+    out, _ = _run({"MOE_BENCH_BACKEND": "gloo"}, "--no-mc-shard", "--no-batch1")
+    assert out["config"]["evals_per_step"] == 64 and out["config"]["evals_per_gpu_per_step"] == 32 and out["scaling"] == "strong"
+    assert out["determinism"]["ok"] and out["determinism"]["restarts"] == 64

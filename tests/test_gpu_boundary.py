@@ -9,7 +9,7 @@ pytestmark = pytest.mark.gpu
 
 
 def _setup(seed=31, n=120, d=3, q=2, p=1, P=7, M=300, derivs=()):
-    from cornell_moe_amd import cpp_wrappers as cw
+    import wrappers_mirror as cw
     from cornell_moe_amd.workloads import make_workload
     w = make_workload(seed=seed, n=n, d=d, q=q, M=M, P=P, derivs=derivs, p=p)
     hd = cw.HistoricalData(dim=d, num_derivatives=len(derivs))
@@ -213,7 +213,7 @@ def test_log_likelihood_wrapper_flow():
     gradient and the list evaluator through the GPP stand-in, against the restatement; the gradient against central
     differences of the device value (no derivative observations: it IS the gradient of the value)."""
     import numpy as np
-    from cornell_moe_amd import cpp_wrappers as cw
+    import wrappers_mirror as cw
     from oracle import orc
     rng = np.random.default_rng(12)
     n, d = 80, 3

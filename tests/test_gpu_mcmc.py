@@ -59,7 +59,8 @@ def test_golden_ei_mcmc_multistart_analytic():
 def test_mcmc_wrapper_flow():
     """The reference's Python call sequence for the MCMC objects (knowledge_gradient_mcmc.py / expected_improvement_mcmc.py)
     on the mirror classes, checked against the oracle restatement fed the same normal tables."""
-    from cornell_moe_amd import GPP, cpp_wrappers as cw
+    from cornell_moe_amd import GPP
+    import wrappers_mirror as cw
     from cornell_moe_amd.api import normal_draws
     from cornell_moe_amd.workloads import make_workload
     from oracle import orc

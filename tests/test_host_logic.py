@@ -176,3 +176,35 @@ dist.destroy_process_group()
                             % (root, str(out), str(script))], timeout=300)
     assert code == 0
     assert out.read_text() == "2 2 [0.5, 1.5, 2.5, 3.5, 4.5, 5.5] 2"
+
+
+def _bringup_worker(rank, world, port, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["RANK"], os.environ["WORLD_SIZE"], os.environ["LOCAL_RANK"] = str(rank), str(world), str(rank)
+    msgs = []
+    comm = mdist.bring_up(rank, world, rank, prefer="nccl", timeout_s=120.0, log=msgs.append)
+    try:
+        # the measurement's collectives on whatever data plane came up
+        idx = mdist.shard_restarts(4, rank, world)
+        kg, grad = mdist.gather_restarts(idx, [1.0 + i for i in idx], np.ones((len(idx), 1, 2)) * (rank + 1), 4, group=comm.group,
+                                         device=comm.device)
+        ret[rank] = (comm.backend, comm.rccl_ranks, comm.fallback, kg.tolist(), comm.max_over_ranks(rank + 1.0),
+                     comm.gather_floats([rank * 10.0]), msgs)
+    finally:
+        comm.close()
+
+
+def test_bring_up_falls_back_to_gloo_when_rccl_preflight_fails():
+    """dist.bring_up on a box without GPUs: the RCCL pre-flight children exit non-zero, every rank agrees over the gloo control
+    plane, and the collectives of the measurement run on gloo -- loudly (Comm.fallback, the log line)."""
+    import torch.multiprocessing as mp
+    world = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_bringup_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+    for r in range(world):
+        backend, rccl, fallback, kg, mx, gathered, msgs = ret[r]
+        assert backend == "gloo" and rccl == 0 and "pre-flight" in fallback
+        assert kg == [1.0, 2.0, 3.0, 4.0] and mx == 2.0 and gathered == [[0.0], [10.0]]
+        assert any("RCCL NOT USED" in m for m in msgs)

@@ -1,8 +1,9 @@
 """Host-side mirror of ``moe.optimal_learning.python.cpp_wrappers`` for the hot path: same class names, constructor
 arguments, method names, array shapes and error behaviour as the reference's wrappers, written against ``cornell_moe_amd.GPP``
-(this package's stand-in for ``moe.build.GPP``).  The reference's own wrapper files run unchanged on top of that module
-(INTEGRATION.md); this mirror exists because the reference tree (and its ``future`` dependency) is not importable on the
-GPU box, and so that the parity tests read like the reference's tests.
+(this package's stand-in for ``moe.build.GPP``).  TEST INFRASTRUCTURE, not a deliverable (r3: moved out of the package): what
+ships is the C ABI + ``GPP.py``, and the reference's own wrapper files run unchanged on top of that module (INTEGRATION.md
+route A).  This mirror exists because the reference tree (and its ``future`` dependency) is not importable on the GPU box,
+so that the parity tests can drive the boundary through the reference's call sequence.
 
 Mirrored (reference file under moe/optimal_learning/python/): data_containers.py:19-260 (SamplePoint, HistoricalData),
 cpp_wrappers/covariance.py:15-98, domain.py:15-105, optimization.py:250-437, gaussian_process.py:18-387,
@@ -13,7 +14,7 @@ import copy
 
 import numpy
 
-from . import GPP as C_GP
+from cornell_moe_amd import GPP as C_GP
 
 DEFAULT_EXPECTED_IMPROVEMENT_MC_ITERATIONS = 10000  # moe/optimal_learning/python/constant.py
 DEFAULT_MAX_NUM_THREADS = 4

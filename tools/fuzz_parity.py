@@ -18,7 +18,7 @@ from oracle import orc  # noqa: E402
 
 
 
-def run(num_cases, seed, n_max=300, d_max=16, g_max=4):
+def run(num_cases=100, seed=2026, n_max=300, d_max=16, g_max=4):
   rng = np.random.default_rng(seed)
   bad = 0
   for case in range(num_cases):

@@ -16,7 +16,7 @@ for f in glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recursiv
     with open(f) as fh:
         for row in csv.DictReader(fh):
             name = row["Kernel_Name"]
-            key = "kg_mc_kernel" if "kg_mc_kernel" in name else (
+            key = "kg_mc_block_kernel" if "kg_mc_block_kernel" in name else "kg_mc_kernel" if "kg_mc_kernel" in name else (
                 "cov_build_kernel" if ("cov_build_kernel" in name or "cov_build_value_kernel" in name) else None)
             if key == "cov_build_kernel" and int(row["Grid_Size"]) < 1_000_000:
                 continue  # only the N x (E M) gradient-tail build, not the small state builds
@@ -28,4 +28,12 @@ for k, c in acc.items():
     write = sum(c.get("WRITE_SIZE", [0])) / max(len(c.get("WRITE_SIZE", [1])), 1)
     out[k] = {"fetch_size_raw_kb": fetch, "write_size_raw_kb": write,
               "hbm_bytes_per_launch": (2.0 * fetch + write) * 1024.0, "launches": len(c.get("FETCH_SIZE", []))}
+    # FP64 wave-instruction counters of the same kernel, when a pass collected them (bench.py: roofline.executed_frac):
+    # executed flop per launch = 64 lanes x (2 FMA + ADD + MUL)
+    for ctr in ("SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_TRANS_F64", "SQ_INSTS_VALU"):
+        if ctr in c:
+            out[k][ctr] = sum(c[ctr]) / len(c[ctr])
+    if "SQ_INSTS_VALU_FMA_F64" in out[k]:
+        out[k]["executed_fp64_flop_per_launch"] = 64.0 * (2.0 * out[k]["SQ_INSTS_VALU_FMA_F64"] + out[k].get("SQ_INSTS_VALU_ADD_F64", 0.0)
+                                                          + out[k].get("SQ_INSTS_VALU_MUL_F64", 0.0))
 print(json.dumps(out))

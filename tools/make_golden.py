@@ -213,6 +213,38 @@ def shape_fixtures():
     print("wrote", OUT_SHAPES, os.path.getsize(OUT_SHAPES), "bytes")
 
 
+OUT_SHAPES3 = os.path.join(ROOT, "tests", "golden", "ref_shapes_r3.npz")
+
+from cornell_moe_amd.workloads import R3_PARITY_CASES as R3_CASES  # noqa: E402  (shared with tests/)
+
+
+def shape_fixtures_r3():
+    """Round 3: the EXACT headline configuration (C3 at M = 10 000 -- the reference needs ~20 s for it), C5's d-KG at n = 1000
+    (N = 4000: the streamed weight table + workgroup-per-sample kernel are what the device picks there) and the lifted-size set,
+    all from the unmodified reference.  Per-sample end points are stored for every case (C3: 10 000 x 8)."""
+    from cornell_moe_amd.workloads import make_workload
+    blob = {}
+    for tag, kw in R3_CASES:
+        w = make_workload(**kw)
+        gp = ref.RefGP(1, w.alpha, w.lengths, w.X, w.y, w.noise, list(w.derivs))
+        best = float(gp.additional_mean(w.discrete).min())
+        Xp = w.Xp if w.p else None
+        r = gp.kg(w.inner_gd, w.bounds, w.discrete, w.Xq, Xp, w.M, best, w.kg_normals, want_grad=True, details=True)
+        blob[tag + "_best_so_far"] = np.array(best)
+        blob[tag + "_kg"], blob[tag + "_grad_kg"], blob[tag + "_best_point"] = np.array(r["kg"]), r["grad"], r["best_point"]
+        blob[tag + "_check"] = np.array([float(w.X.sum()), float(w.kg_normals.sum()), float(w.Xq.sum()), float(w.discrete.sum())])
+        blob[tag + "_seconds"] = np.array(r["seconds"])
+        if tag != "c3full":
+            rv = gp.kg(w.inner_gd, w.bounds, w.discrete, w.Xq, Xp, w.M, best, w.kg_normals, want_grad=False)
+            blob[tag + "_kg_value_only"] = np.array(rv["kg"])
+            pts = w.query[:3]
+            blob[tag + "_q_mean"], blob[tag + "_q_grad_mean"], blob[tag + "_q_var"] = gp.mean(pts), gp.grad_mean(pts), gp.var(pts)
+        print("%s: n=%d d=%d q=%d p=%d g=%d m=%d M=%d  KG=%.15g  (reference: %.2f s state + %.2f s evaluation)" % (
+            tag, w.n, w.d, w.q, w.p, w.g, w.m, w.M, r["kg"], r["seconds"][0], r["seconds"][1]), flush=True)
+    np.savez_compressed(OUT_SHAPES3, **blob)
+    print("wrote", OUT_SHAPES3, os.path.getsize(OUT_SHAPES3), "bytes")
+
+
 OUT_MS = os.path.join(ROOT, "tests", "golden", "ref_kg_multistart.npz")
 
 
@@ -317,11 +349,15 @@ def main():
     if "--shapes" in sys.argv:
         shape_fixtures()
         return
+    if "--shapes-r3" in sys.argv:
+        shape_fixtures_r3()
+        return
     if "--kg-multistart" in sys.argv:
         kg_multistart_fixtures()
         return
     ll_grad_fixtures()
     shape_fixtures()
+    shape_fixtures_r3()
     kg_multistart_fixtures()
     cases = []
     inner_test = (1, 100, 10, 3, 0.0, 1.0, 0.1, 1e-10)   # inner GD of the reference's KG ping test (100 steps, 10 restarts)
