@@ -230,7 +230,9 @@ def main():
     ap.add_argument("--no-traffic", action="store_true", help="skip the in-run rocprofv3 PMC passes (HBM traffic, executed FP64)")
     ap.add_argument("--no-mc-shard", action="store_true", help="N > 1: skip the extra MC-sharded measurement")
     ap.add_argument("--no-batch1", action="store_true", help="skip the extra one-at-a-time (batch-1 latency) measurement")
-    ap.add_argument("--no-extras", action="store_true", help="skip the extra roofline probes (K(X,X) builds)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the extra roofline probes (K(X,X) builds, sustained FP64 rate)")
+    ap.add_argument("--no-determinism", action="store_true",
+                    help="skip the recompute-and-compare check (profiling runs: every kg_mc_kernel launch is then a timed step's)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -356,7 +358,9 @@ def main():
 
     # ---- extras, OUTSIDE the timed region of `value` ----
     extras = {}
-    if cw > 1 and args.shard == "restarts":
+    if args.no_determinism:
+        pass
+    elif cw > 1 and args.shard == "restarts":
         # cross-rank determinism: rank 0 recomputes EVERY restart of the last step on its own GPU in one call and
         # compares with what the ranks computed and gathered -- restarts are independent evaluations, so the results must be
         # bit-identical whatever the sharding
@@ -522,6 +526,15 @@ def main():
             "rccl_preflight_s": comm.preflight_s,
         }
         out.update(extras)
+        if not args.no_extras:
+            try:   # what the chip sustains on pure FP64 FMA chains (the clock does not hold 2.4 GHz under FP64 load)
+                sus = mapi.fp64_rate(local_rank)
+                out["roofline"]["sustained_fma_tflops"] = sus
+                out["roofline"]["frac_of_sustained"] = ach_tflops / sus
+                if executed:
+                    out["roofline"]["executed_frac_of_sustained"] = executed["achieved"] / sus
+            except Exception as e:  # pragma: no cover
+                log("fp64_rate failed: %s" % e)
         if not args.no_extras and world == 1 and hasattr(mapi, "kxx_build_probe"):
             try:
                 out["roofline_cov_build_kxx"] = mapi.kxx_build_probe(log)

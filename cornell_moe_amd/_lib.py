@@ -82,6 +82,8 @@ SIGNATURES = {
     "moe_cov_build_probe": (C.c_int, [_GP, dp, C.c_int, C.c_int, dp, dp, _EP]),
     "moe_debug_cholesky": (C.c_int, [C.c_int, dp, C.c_int, dp, dp, ip, _EP]),
     "moe_debug_math": (C.c_int, [C.c_int, dp, C.c_int, dp, dp, _EP]),
+    "moe_kxx_build_probe": (C.c_int, [_GP, C.c_int, dp, dp, _EP]),
+    "moe_debug_fp64_rate": (C.c_int, [C.c_int, dp, _EP]),
     "moe_set_reference_quirks": (C.c_int, [C.c_int]),
     "moe_get_reference_quirks": (C.c_int, []),
     "moe_last_kernel_ms": (C.c_int, [_GP, dp]),

@@ -58,6 +58,35 @@ def _d(a):
     return a, a.ctypes.data_as(dp)
 
 
+def fp64_rate(device=0):
+    """moe_debug_fp64_rate: sustained FP64 FMA rate of the chip in TFLOP/s."""
+    v = C.c_double(0.0)
+    err = _lib.MoeError()
+    _check(_lib.load().moe_debug_fp64_rate(int(device), C.byref(v), C.byref(err)), err)
+    return v.value
+
+
+def kxx_build_probe(log=None, device=0):
+    """bench.py's `roofline_cov_build_kxx`: the GP's own covariance assembly where SURVEY 8(d) says it is the meaningful HBM
+    measurement -- K(X, X) with derivative-observation rows at C5 (n = 2000, d = 12, g = 3: N = 8000, 512 MB) and at C5 with all
+    12 partial derivatives observed (N = 26 000, 5.4 GB) -- against the 8 TB/s HBM peak."""
+    from .workloads import make_workload
+    out = {"bound": "hbm", "peak": 8000.0, "unit": "GB/s", "kernel": "cov_build_points_kernel (GpDev::rebuild's launch)", "cases": []}
+    for derivs in ((0, 1, 2), tuple(range(12))):
+        w = make_workload("C5", M=2, derivs=derivs)
+        G = DeviceGP(w.hyperparameters, w.X, w.y, w.noise, w.derivs, device=device)
+        ms, nbytes = G.kxx_build_probe(repeat=5 if len(derivs) > 3 else 20)
+        gbs = nbytes / (ms * 1e-3) / 1e9
+        out["cases"].append({"n": w.n, "d": w.d, "g": w.g, "N": w.n * (1 + w.g), "avg_launch_ms": ms, "bytes_per_launch": nbytes,
+                             "achieved": gbs, "frac": gbs / 8000.0})
+        if log:
+            log("K(X,X) build N=%d: %.3f ms, %.0f GB/s" % (w.n * (1 + w.g), ms, gbs))
+        G.close()
+    out["achieved"] = out["cases"][0]["achieved"]
+    out["frac"] = out["cases"][0]["frac"]
+    return out
+
+
 def set_reference_quirks(on):
     """moe_set_reference_quirks: 1 = the multistart drivers reproduce the reference's execution, defects included (default);
     0 = the drivers as the reference intends them (fresh states, all q points move); -1 = follow MOE_REFERENCE_QUIRKS."""
@@ -219,6 +248,13 @@ class DeviceGP(object):
         ms, nbytes = C.c_double(0.0), C.c_double(0.0)
         err = _lib.MoeError()
         _check(_lib.load().moe_cov_build_probe(self._h, pp, k, int(repeat), C.byref(ms), C.byref(nbytes), C.byref(err)), err)
+        return ms.value, nbytes.value
+
+    def kxx_build_probe(self, repeat=10):
+        """moe_kxx_build_probe: (average ms per launch, algorithmic bytes per launch) of the GP's own K(X, X) assembly."""
+        ms, nbytes = C.c_double(0.0), C.c_double(0.0)
+        err = _lib.MoeError()
+        _check(_lib.load().moe_kxx_build_probe(self._h, int(repeat), C.byref(ms), C.byref(nbytes), C.byref(err)), err)
         return ms.value, nbytes.value
 
     def posterior_mean(self, point, num_fidelity=0, want_grad=True):

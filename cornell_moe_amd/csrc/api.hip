@@ -344,6 +344,82 @@ int moe_cov_build_probe(const moe_gp_t* gp_c, const double* pts, int num_pts, in
   });
 }
 
+int moe_kxx_build_probe(const moe_gp_t* gp_c, int repeat, double* avg_ms, double* bytes_per_launch, moe_error_t* err) {
+  return guarded(err, [&] {
+    std::unique_lock<std::mutex> lk;
+    moe::GpDev& gp = lock_gp(gp_c, lk);
+    gp.use_device();
+    moe::DevBuf<double> dOut;
+    dOut.reserve((size_t)gp.ldL * gp.N);
+    hipEvent_t e0, e1;
+    MOE_HIP_CHECK(hipEventCreate(&e0));
+    MOE_HIP_CHECK(hipEventCreate(&e1));
+    auto launch = [&] {  // exactly the call of GpDev::rebuild (gp.hip): K(X, X) + noise on the diagonal, leading dimension ldL
+      moe::launch_cov_build(gp.cp, gp.dX.p, gp.n, gp.derivs, gp.dX.p, gp.n, gp.derivs, gp.dNoise.p, dOut.p, gp.ldL, 0, gp.stream);
+    };
+    launch();
+    MOE_HIP_CHECK(hipEventRecord(e0, gp.stream));
+    for (int r = 0; r < repeat; ++r) launch();
+    MOE_HIP_CHECK(hipEventRecord(e1, gp.stream));
+    MOE_HIP_CHECK(hipEventSynchronize(e1));
+    float ms = 0.f;
+    MOE_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    if (avg_ms) *avg_ms = ms / std::max(repeat, 1);
+    if (bytes_per_launch) *bytes_per_launch = 8.0 * (2.0 * (double)gp.n * gp.d + (double)gp.N * gp.N);
+  });
+}
+
+namespace {
+// Sustained FP64 FMA rate of the whole chip: 8 independent dependent-FMA chains per lane, 16 wavefronts per CU.
+__global__ __launch_bounds__(256) void fp64_rate_kernel(double* __restrict__ out, double a, double b, int iters) {
+  double x0 = a + threadIdx.x, x1 = x0 + 1, x2 = x0 + 2, x3 = x0 + 3, x4 = x0 + 4, x5 = x0 + 5, x6 = x0 + 6, x7 = x0 + 7;
+  for (int i = 0; i < iters; ++i) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      x0 = fma(x0, a, b);
+      x1 = fma(x1, a, b);
+      x2 = fma(x2, a, b);
+      x3 = fma(x3, a, b);
+      x4 = fma(x4, a, b);
+      x5 = fma(x5, a, b);
+      x6 = fma(x6, a, b);
+      x7 = fma(x7, a, b);
+    }
+  }
+  out[(size_t)blockIdx.x * blockDim.x + threadIdx.x] = ((x0 + x1) + (x2 + x3)) + ((x4 + x5) + (x6 + x7));
+}
+}  // namespace
+
+int moe_debug_fp64_rate(int device, double* tflops, moe_error_t* err) {
+  return guarded(err, [&] {
+    require(tflops != nullptr, "NULL argument");
+    MOE_HIP_CHECK(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    MOE_HIP_CHECK(hipGetDeviceProperties(&prop, device));
+    const int blocks = prop.multiProcessorCount * 4, iters = 20000;
+    moe::DevBuf<double> dOut;
+    dOut.reserve((size_t)blocks * 256);
+    hipStream_t s = nullptr;
+    MOE_HIP_CHECK(hipStreamCreate(&s));
+    hipEvent_t e0, e1;
+    MOE_HIP_CHECK(hipEventCreate(&e0));
+    MOE_HIP_CHECK(hipEventCreate(&e1));
+    hipLaunchKernelGGL(fp64_rate_kernel, dim3(blocks), dim3(256), 0, s, dOut.p, 0.999999, 1.0e-6, 2000);  // warm-up, clocks up
+    MOE_HIP_CHECK(hipEventRecord(e0, s));
+    hipLaunchKernelGGL(fp64_rate_kernel, dim3(blocks), dim3(256), 0, s, dOut.p, 0.999999, 1.0e-6, iters);
+    MOE_HIP_CHECK(hipEventRecord(e1, s));
+    MOE_HIP_CHECK(hipEventSynchronize(e1));
+    float ms = 0.f;
+    MOE_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    (void)hipStreamDestroy(s);
+    *tflops = 2.0 * 64.0 * (double)iters * (double)blocks * 256.0 / (ms * 1e-3) / 1e12;
+  });
+}
+
 int moe_debug_cholesky(int n, const double* a, int device, double* chol, double* chol_inv, int* info, moe_error_t* err) {
   return guarded(err, [&] {
     require(n > 0, "n must be positive");

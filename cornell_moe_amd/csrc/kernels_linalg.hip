@@ -748,8 +748,12 @@ __global__ __launch_bounds__(256) void gram_sum_kernel(const double* __restrict_
 }
 }  // namespace
 
-int gram_batch_slices(int E, int c, int K) {
-  const long tiles = (long)((c + 31) / 32) * ((c + 31) / 32 + 1) / 2 * E;  // lower-triangular output tiles
+int gram_batch_slices(int /*E*/, int c, int K) {
+  // The K split fixes the summation order of every Gram entry, so it must not depend on how many evaluations share the call
+  // (r3: a restart evaluated alone, in a batch of 8 or in a batch of 64 has to give the same bits -- with the batch size in
+  // this formula a batch of 64 took 6 slices where smaller ones took 15 and the results moved by an ulp): sized for ONE
+  // evaluation; bigger batches simply bring more workgroups.
+  const long tiles = (long)((c + 31) / 32) * ((c + 31) / 32 + 1) / 2;  // lower-triangular output tiles of one evaluation
   const long want = 1024;                                                  // ~4 workgroups per CU
   long s = (want + tiles - 1) / tiles;
   s = std::min<long>(s, std::max(1, K / 64));                              // at least one stage of 64 per slice

@@ -335,6 +335,15 @@ int moe_gp_mix_covariance(const moe_gp_t* gp, const double* pts, int num_pts, co
 int moe_cov_build_probe(const moe_gp_t* gp, const double* pts, int num_pts, int repeat, double* avg_ms,
                         double* bytes_per_launch, moe_error_t* err);
 
+/* Timing probe of the GP's own covariance assembly: K(X, X) + noise on the diagonal, N x N with the derivative-observation
+ * blocks (BuildCovarianceMatrixWithNoiseVariance, gpp_math.cpp:391-455) -- the launch GaussianProcess construction makes --
+ * `repeat` times into a scratch matrix; average kernel ms (HIP events) and the algorithmic bytes 8 [2 n d + N^2]. */
+int moe_kxx_build_probe(const moe_gp_t* gp, int repeat, double* avg_ms, double* bytes_per_launch, moe_error_t* err);
+/* What the chip sustains on nothing but dependent FP64 FMA chains (8 per lane, 16 wavefronts per CU), TFLOP/s: the rate the
+ * FP64-bound kernels can be held against next to the 78.6 TFLOP/s of the data sheet (the clock does not hold 2.4 GHz under
+ * FP64 load). */
+int moe_debug_fp64_rate(int device, double* tflops, moe_error_t* err);
+
 /* Parity probe of the device factorisation used by moe_gp_create: factors the SPD matrix a[n*n] (column-major, lower
  * triangle read) with the blocked device Cholesky that replaces ComputeCholeskyFactorL (gpp_linear_algebra.cpp:109-148);
  * writes the factor to chol[n*n] (strict upper = 0) and its explicit inverse to chol_inv[n*n]; *info = 0 or the failing

@@ -15,7 +15,7 @@ tail -5 gpurun_out/${TAG}_bench.err
 export TMPDIR=/tmp
 cd /tmp
 rm -rf $R/gpurun_out/prof
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof -o kg -- python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-traffic --no-extras > $R/gpurun_out/${TAG}_bench_under_rocprof.json 2> $R/gpurun_out/prof.err
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof -o kg -- python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-traffic --no-extras --no-batch1 --no-determinism > $R/gpurun_out/${TAG}_bench_under_rocprof.json 2> $R/gpurun_out/prof.err
 cd $R
 cp $(find gpurun_out/prof -name "*kernel_stats.csv" | head -1) gpurun_out/${TAG}_bench_kernel_stats.csv
 head -8 gpurun_out/${TAG}_bench_kernel_stats.csv

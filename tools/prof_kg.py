@@ -18,7 +18,10 @@ if ":" in cfg:  # e.g. C3:n=60,M=2000  -- override fields of a named configurati
     for kv in tail.split(","):
         k, v = kv.split("=")
         over[k] = int(v)
+steps = over.pop("steps", None)   # inner GD steps per restart (instruction-count fits: tools/mc_overhead.sh)
 w = make_workload(cfg, num_restarts=R, **over)
+if steps is not None:
+    w.inner_gd = (w.inner_gd[0], steps) + tuple(w.inner_gd[2:])
 G = DeviceGP(w.hyperparameters, w.X, w.y, w.noise, w.derivs)
 best = float(G.additional_mean(w.discrete).min())
 for i in range(reps):
