@@ -76,7 +76,7 @@ struct moe_ll {
   std::unique_ptr<moe::GpDev> gp;  // moe_ll_grad's factorisation (with the inverse factor)
   // moe_ll_evaluate: batches of bordered factorisations (kernels.hpp launch_cholesky_batch)
   hipStream_t stream = nullptr;
-  moe::DevBuf<double> dX, dYc, dA, dLinv, dNoise, dOut;
+  moe::DevBuf<double> dX, dYc, dA, dLinv, dNoise, dOut, dScratch;
   moe::DevBuf<int> dInfo;
   ~moe_ll() {
     if (stream) {
@@ -834,7 +834,8 @@ int moe_ll_evaluate(moe_ll_t* ll, const double* hyperparameters_all, int num_set
         moe::launch_cov_build(cps[b], ll->dX.p, n, dl, ll->dX.p, n, dl, ll->dNoise.p + (size_t)b * g1,
                               ll->dA.p + (size_t)b * mat, lda, 0, s);
       moe::launch_ll_border(ll->dA.p, lda, mat, N, ll->dYc.p, nb, s);
-      moe::launch_cholesky_batch(Np, ll->dA.p, lda, mat, ll->dLinv.p, lda, mat, ll->dInfo.p, nb, s);
+      ll->dScratch.reserve(moe::chol_scratch_doubles(Np));
+      moe::launch_cholesky_batch(Np, ll->dA.p, lda, mat, ll->dLinv.p, lda, mat, ll->dInfo.p, nb, s, ll->dScratch.p);
       moe::launch_ll_terms_batch(ll->dA.p, lda, mat, N, ll->dOut.p, nb, s);
       ll->dOut.download(out.data(), (size_t)2 * nb, s);
       ll->dInfo.download(info.data(), nb, s);

@@ -84,6 +84,8 @@ void launch_gram_batch(int E, int m, int ng, int A, int K, const double* V, long
 void launch_cholesky_and_inverse(int N, double* A, long lda, double* Linv, long ldl, double* work, int* info,
                                  hipStream_t s);
 size_t cholesky_work_doubles(int N);
+// scratch of the two-level factorisation's step kernel (two N x 64 column-block buffers), in doubles
+size_t chol_scratch_doubles(int N);
 
 // Rank-kk append to a factorisation, in place: L / Linv hold the factor and inverse factor of K11 in their leading
 // N0 x N0 blocks and have room for kk more rows and columns (ldl, ldi >= N0 + kk).  Given B = K12 (N0 x kk, ld N0) and
@@ -101,7 +103,7 @@ void launch_cholesky_append(int N0, int kk, double* L, long ldl, double* Linv, l
 // blocks go to Linv + b * l_stride (N x N layout, ldl; only the 64 x 64 diagonal blocks are written -- no full inverse
 // factor).  info[b]: 0 or failing pivot + 1.  Every step is ONE launch over the batch (grid.z).
 void launch_cholesky_batch(int N, double* A, long lda, long a_stride, double* Linv, long ldl, long l_stride, int* info,
-                           int batch, hipStream_t s);
+                           int batch, hipStream_t s, double* scratch = nullptr);
 // The log-likelihood's quadratic form comes out of the same factorisation: with the centred data as an extra ROW N of the
 // matrix (corner 1e100) the factor's row N is v^T = (L^-1 yc)^T, and yc^T K^-1 yc = |v|^2 -- no triangular solve.
 // launch_ll_border writes that row; launch_ll_terms_batch returns out[b] = (sum log L_ii, |v|^2) over i, j < N.

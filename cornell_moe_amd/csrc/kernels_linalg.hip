@@ -9,6 +9,7 @@
 //    (gpp_linear_algebra.cpp:109-148) and turns every TriangularMatrixVectorSolve (:160-187) of the reference into a
 //    GEMM against L^-1, which is what lets the posterior solves run wide instead of as 1000 dependent steps.
 #include <cstdlib>
+#include <unordered_map>
 
 #include "kernels.hpp"
 
@@ -127,7 +128,8 @@ using f64x4 = __attribute__((ext_vector_type(4))) double;
 template <int MODE, bool NEG, int TKV = 16>
 __global__ __launch_bounds__(256) void mfma_gemm_kernel(int M, int Ncols, int K, const double* __restrict__ A, long lda,
                                                        const double* __restrict__ B, long ldb, double* __restrict__ C,
-                                                       long ldc, int xmul, int pair_rows) {
+                                                       long ldc, int xmul, int pair_rows, long sA = 0, long sB = 0,
+                                                       long sC = 0, int m_total = 0, int m_step = 0) {
   constexpr int TM = 64, TN = 64, TK = TKV, LD = 65;
   constexpr int NF = TM * TK / 256;  // elements of each operand tile per thread
   __shared__ double As[TK][LD];
@@ -141,6 +143,19 @@ __global__ __launch_bounds__(256) void mfma_gemm_kernel(int M, int Ncols, int K,
   // partial results stacked behind C (ldc * Ncols doubles apart); launch_gemm_tn_splitk adds them in slice order.  For a skinny
   // output with a long K (S_W = W^T T of the d-KG tail: 32 x 20 000 over K = 8000) the unsplit grid is one workgroup per CU walking
   // 500 stages with one stage of loads in flight -- latency-bound at a third of what HBM delivers.
+  // Batch (MODE != 0, gridDim.z problems of the same shape at element strides sA / sB / sC -- the nodes of one level of the
+  // triangular inversion): problem z has min(M, m_total - z m_step) rows (the last node of a level may be cut off by the matrix
+  // edge); for the triangular MODE 1 its K shrinks with it.
+  if (MODE != 0 && gridDim.z > 1) {
+    A += (long)blockIdx.z * sA;
+    B += (long)blockIdx.z * sB;
+    C += (long)blockIdx.z * sC;
+    if (m_step > 0) {
+      const int mz = min(M, m_total - (int)blockIdx.z * m_step);
+      if (MODE == 1) K = min(K, mz);
+      M = mz;
+    }
+  }
   if (MODE == 0 && gridDim.z > 1) {
     const int ks = ((K + (int)gridDim.z - 1) / (int)gridDim.z + TK - 1) / TK * TK;
     const int kb = (int)blockIdx.z * ks;
@@ -851,14 +866,10 @@ __device__ __forceinline__ void lds_tri_inv_offdiag(double (*S)[NB + 1], double 
   __syncthreads();
 }
 
-__global__ __launch_bounds__(256) void chol_diag_lds_kernel(double* __restrict__ A, long lda, double* __restrict__ Linv,
-                                                           long ldl, int k0, int nb, int* __restrict__ info) {
-  __shared__ double S[NB][NB + 1];      // S[i][j] = L[i][j] for j <= i;  (L^-1)[i][j] at S[j][i + 1]
-  __shared__ double W[NB][2 * SB + 1];  // scratch: panel / product blocks (up to 32 columns)
-  __shared__ int s_bad;
-  if (*info != 0) return;
+// The diagonal-block work as device functions (shared by chol_diag_lds_kernel and the look-ahead of chol_step_kernel).
+// diag_load: the nb x nb block at (k0, k0) into S (lower triangle; identity beyond nb).
+__device__ __forceinline__ void diag_load(const double* __restrict__ A, long lda, int k0, int nb, double (*S)[NB + 1]) {
   const int t = threadIdx.x;
-  MOE_DIAG_T(0);
   // (unconditional loads from clamped addresses, all issued before the first use: one memory round trip instead of one per
   //  guarded element -- 18 k of the kernel's 128 k cycles were this loop)
   {
@@ -881,9 +892,13 @@ __global__ __launch_bounds__(256) void chol_diag_lds_kernel(double* __restrict__
       }
     }
   }
-  if (t == 0) s_bad = 0;
-  __syncthreads();
-  MOE_DIAG_T(1);
+}
+
+// diag_factor: S <- its Cholesky factor (lower) with the inverses of the four 16 x 16 diagonal sub-blocks packed above the
+// diagonal; *s_bad = first failing pivot (global index + 1) or 0.  Ends with a barrier.
+__device__ __forceinline__ void diag_factor(double (*S)[NB + 1], double (*W)[2 * SB + 1], int* s_bad_p, int k0) {
+  const int t = threadIdx.x;
+  int& s_bad = *s_bad_p;
 #if defined(MOE_DIAG_PROF)
   unsigned long long diag_last_ = 0;
 #endif
@@ -973,16 +988,20 @@ __global__ __launch_bounds__(256) void chol_diag_lds_kernel(double* __restrict__
       MOE_DIAG_A(3);
     }
   }
-  MOE_DIAG_T(2);
-  if (s_bad != 0) {
-    if (t == 0) *info = s_bad;
-    return;
-  }
+}
+
+// diag_invert: the off-diagonal blocks of the 64 x 64 inverse by recursive halving (the packed layout of MOE_XS).
+__device__ __forceinline__ void diag_invert(double (*S)[NB + 1], double (*W)[2 * SB + 1]) {
   // L^-1: the diagonal 16-blocks are in place; off-diagonal blocks by recursive halving
   lds_tri_inv_offdiag<0, 16, 32>(S, W);
   lds_tri_inv_offdiag<32, 48, 64>(S, W);
   lds_tri_inv_offdiag<0, 32, 64>(S, W);
-  MOE_DIAG_T(3);
+}
+
+// diag_store: L (strict upper written as 0) into A's block, L^-1 into Linv's block.
+__device__ __forceinline__ void diag_store(double* __restrict__ A, long lda, double* __restrict__ Linv, long ldl, int k0, int nb,
+                                           double (*S)[NB + 1]) {
+  const int t = threadIdx.x;
   for (int idx = t; idx < NB * NB; idx += 256) {
     const int i = idx % NB, j = idx / NB;
     if (i < nb && j < nb) {
@@ -990,7 +1009,170 @@ __global__ __launch_bounds__(256) void chol_diag_lds_kernel(double* __restrict__
       Linv[(long)(k0 + i) + (long)(k0 + j) * ldl] = (j <= i) ? MOE_XS(i, j) : 0.0;
     }
   }
+}
+
+__global__ __launch_bounds__(256) void chol_diag_lds_kernel(double* __restrict__ A, long lda, double* __restrict__ Linv,
+                                                           long ldl, int k0, int nb, int* __restrict__ info) {
+  __shared__ double S[NB][NB + 1];      // S[i][j] = L[i][j] for j <= i;  (L^-1)[i][j] at S[j][i + 1]
+  __shared__ double W[NB][2 * SB + 1];  // scratch: panel / product blocks (up to 32 columns)
+  __shared__ int s_bad;
+  if (*info != 0) return;
+  const int t = threadIdx.x;
+  MOE_DIAG_T(0);
+  diag_load(A, lda, k0, nb, S);
+  if (t == 0) s_bad = 0;
+  __syncthreads();
+  MOE_DIAG_T(1);
+  diag_factor(S, W, &s_bad, k0);
+  MOE_DIAG_T(2);
+  if (s_bad != 0) {
+    if (t == 0) *info = s_bad;
+    return;
+  }
+  diag_invert(S, W);
+  MOE_DIAG_T(3);
+  diag_store(A, lda, Linv, ldl, k0, nb, S);
   MOE_DIAG_T(4);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// One 64-column step of the two-level factorisation in ONE launch (r3; before: diagonal kernel -> panel kernel -> update kernel,
+// three dependent launches of 50 + 17 + 23 us, 125 times at N = 8000), with the next diagonal block factored AHEAD inside it.
+// Grid (cb + 1, tb): y = row tile bi (i0 = k0 + nb + 64 bi), x = 0: the panel solve of that row tile, x = 1 + j: the update of
+// tile (bi, j), j < cb the column tiles this outer block still has to factor.  No workgroup waits for another one:
+//   * the UNSOLVED column block of this step is read from a scratch copy `Ccur` (N x 64, rows by absolute index), never from A;
+//     P_i = C_i L_kk^-T is what workgroup (0, bi) writes into A (the final L panel) -- nobody reads that part of A meanwhile;
+//   * an update workgroup recomputes the two panels it needs, P_i and P_j, from Ccur and the inverted diagonal block (two extra
+//     64^3 products on the matrix pipe, ~1 us each) instead of waiting for their owners, then A_ij -= P_i P_j^T;
+//   * tiles of the NEXT column block (j = 0) are written to the other scratch buffer `Cnext` -- they are the next step's Ccur;
+//   * LOOK-AHEAD: workgroup (1, 0) holds the updated tile (k+1, k+1) and factors and inverts it on the spot (diag_factor /
+//     diag_invert), so the diagonal-block chain -- 47 us a link, the critical path of the whole factorisation -- no longer
+//     waits for the panel and update launches of its own step: the next launch finds its diagonal block done.
+// All 64 x 64 x 64 products run on the matrix pipe (v_mfma_f64_16x16x4_f64, a 32 x 32 quadrant per wavefront).
+// ---------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void mfma_64(const double (*As)[NB + 1], const double (*Bs)[NB + 1], f64x4 (&acc)[2][2], int wi, int wj,
+                                        int lk, int lx) {
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) acc[a][b] = f64x4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll 4
+  for (int k4 = 0; k4 < NB; k4 += 4) {
+    double fa[2], fb[2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a) fa[a] = As[k4 + lk][wi + 16 * a + lx];
+#pragma unroll
+    for (int b = 0; b < 2; ++b) fb[b] = Bs[k4 + lk][wj + 16 * b + lx];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb[b], fa[a], acc[a][b], 0, 0, 0);
+  }
+}
+
+// the unsolved column block k0 (rows below its diagonal block) into the scratch buffer: the start of an outer block
+__global__ __launch_bounds__(256) void chol_colcopy_kernel(const double* __restrict__ A, long lda, int N, int k0, int nb,
+                                                          double* __restrict__ C, long ldc) {
+  const long r = (long)k0 + nb + (long)blockIdx.x * 256 + threadIdx.x;
+  if (r >= N) return;
+  for (int c = 0; c < nb; ++c) C[r + (long)c * ldc] = A[r + (long)(k0 + c) * lda];
+}
+
+__global__ __launch_bounds__(256) void chol_step_kernel(double* __restrict__ A, long lda, double* __restrict__ Linv, long ldl, int N,
+                                                       int k0, int nb, int cb, int* __restrict__ info,
+                                                       const double* __restrict__ Ccur, double* __restrict__ Cnext, long ldc,
+                                                       int lookahead) {
+  extern __shared__ __attribute__((aligned(16))) double step_smem[];
+  double (*Ds)[NB + 1] = reinterpret_cast<double (*)[NB + 1]>(step_smem);                        // Ds[j][c] = Linv_kk[c][j]
+  double (*Pi)[NB + 1] = reinterpret_cast<double (*)[NB + 1]>(step_smem + NB * (NB + 1));        // C_i^T, then Pt_i[k][r]
+  double (*Pj)[NB + 1] = reinterpret_cast<double (*)[NB + 1]>(step_smem + 2 * NB * (NB + 1));    // C_j^T, then Pt_j[k][c]
+  __shared__ int s_bad;
+  if (*info != 0) return;
+  const int bi = blockIdx.y, jc = blockIdx.x;
+  const int j = jc - 1;
+  if (j > bi) return;  // (upper triangle)
+  const int base = k0 + nb;
+  const int i0 = base + bi * NB;
+  const int t = threadIdx.x;
+  const int wave = t >> 6, lane = t & 63;
+  const int wi = (wave & 1) * 32, wj = (wave >> 1) * 32;
+  const int lk = lane >> 4, lx = lane & 15;
+  const bool need_j = j >= 0 && j != bi;
+  const int j0 = base + max(j, 0) * NB;
+  for (int q = t; q < NB * NB; q += 256) {
+    const int r = q % NB, c = q / NB;  // r walks rows (contiguous in memory)
+    Ds[c][r] = (r < nb && c < nb) ? Linv[(long)(k0 + r) + (long)(k0 + c) * ldl] : 0.0;  // Ds[c][r] = Linv[r][c]
+    Pi[c][r] = (i0 + r < N && c < nb) ? Ccur[(long)(i0 + r) + (long)c * ldc] : 0.0;
+    if (need_j) Pj[c][r] = (j0 + r < N && c < nb) ? Ccur[(long)(j0 + r) + (long)c * ldc] : 0.0;
+  }
+  __syncthreads();
+  f64x4 acc[2][2], accj[2][2];
+  mfma_64(Pi, Ds, acc, wi, wj, lk, lx);  // P_i[r][c] = sum_j C_i[r][j] Linv[c][j]
+  if (need_j) mfma_64(Pj, Ds, accj, wi, wj, lk, lx);
+  __syncthreads();
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int rr = wi + 16 * a + lx, cc = wj + 16 * b + lk + 4 * r;
+        if (jc == 0) {
+          if (i0 + rr < N && cc < nb) A[(long)(i0 + rr) + (long)(k0 + cc) * lda] = acc[a][b][r];  // the final L panel
+        } else {
+          Pi[cc][rr] = acc[a][b][r];
+          if (need_j) Pj[cc][rr] = accj[a][b][r];
+        }
+      }
+  if (jc == 0) return;
+  __syncthreads();
+  mfma_64(Pi, need_j ? Pj : Pi, acc, wi, wj, lk, lx);  // U[r][c] = sum_k P_i[r][k] P_j[c][k]
+  const bool ahead = lookahead && bi == 0 && j == 0;    // tile (k+1, k+1): the next diagonal block
+  if (!ahead) {
+    // the next column block (j == 0) goes to the scratch buffer the next step reads, everything else is updated in place
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int gi = i0 + wi + 16 * a + lx, cj = wj + 16 * b + lk + 4 * r, gj = j0 + cj;
+          if (gi < N && gj < N && gj <= gi) {
+            const double v = A[(long)gi + (long)gj * lda] - acc[a][b][r];
+            if (j == 0)
+              Cnext[(long)gi + (long)cj * ldc] = v;
+            else
+              A[(long)gi + (long)gj * lda] = v;
+          }
+        }
+    return;
+  }
+  // the updated tile (k+1, k+1) goes straight into the diagonal-block layout: S = Ds's storage, W = Pj's
+  const int nb1 = min(NB, N - i0);
+  double (*S)[NB + 1] = Ds;
+  double (*W)[2 * SB + 1] = reinterpret_cast<double (*)[2 * SB + 1]>(step_smem + 2 * NB * (NB + 1));
+  __syncthreads();  // everybody is done reading Pi / Ds
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int ii = wi + 16 * a + lx, jj = wj + 16 * b + lk + 4 * r;
+        double w = (ii == jj && ii >= nb1) ? 1.0 : 0.0;  // rows / columns beyond nb1 (last, partial block): identity
+        if (ii < nb1 && jj < nb1 && jj <= ii) w = A[(long)(i0 + ii) + (long)(i0 + jj) * lda] - acc[a][b][r];
+        S[ii][jj] = w;
+      }
+  if (t < NB) S[t][NB] = 0.0;  // (column 64 belongs to the packed inverse)
+  if (t == 0) s_bad = 0;
+  __syncthreads();
+  diag_factor(S, W, &s_bad, i0);
+  if (s_bad != 0) {
+    if (t == 0) *info = s_bad;
+    return;
+  }
+  diag_invert(S, W);
+  diag_store(A, lda, Linv, ldl, i0, nb1, S);
 }
 #undef MOE_XS
 
@@ -999,14 +1181,14 @@ __global__ __launch_bounds__(256) void chol_diag_lds_kernel(double* __restrict__
 // quadrant as 2 x 2 MFMA tiles; both operands are row panels of the same matrix (row index fastest in memory: coalesced);
 // the next K tile travels global -> registers while the current one is multiplied out of LDS.
 __global__ __launch_bounds__(256) void syrk_mfma_kernel(double* __restrict__ A, long lda, int N, int base, int kp0, int kw,
-                                                       const int* __restrict__ info) {
+                                                       const int* __restrict__ info, int cj0 = 0) {
   constexpr int TM = 64, TKS = 16, LD = 65;
   constexpr int NF = TM * TKS / 256;
   __shared__ double As[TKS][LD];
   __shared__ double Bs[TKS][LD];
   if (*info != 0) return;
   // triangular grid folded into a rectangle: workgroup (x, y) of a T x ceil((T + 1) / 2) ... kept simple: skip the upper half
-  const int bi = blockIdx.y, bj = blockIdx.x;
+  const int bi = blockIdx.y, bj = blockIdx.x + cj0;  // (cj0: first column tile of this launch -- the update is issued in two parts)
   if (bj > bi) return;
   const int i0 = base + bi * TM, j0 = base + bj * TM;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -1066,102 +1248,156 @@ __global__ __launch_bounds__(256) void syrk_mfma_kernel(double* __restrict__ A, 
 }
 
 namespace {
-void trtri_offdiag(const double* L, long lda, double* Linv, long ldl, int N, int lo, int hi, double* work, hipStream_t s) {
-  if (hi - lo <= 1) return;
-  const int mid = lo + (hi - lo + 1) / 2;
-  trtri_offdiag(L, lda, Linv, ldl, N, lo, mid, work, s);
-  trtri_offdiag(L, lda, Linv, ldl, N, mid, hi, work, s);
-  const int r0 = mid * NB, c0 = lo * NB;
-  const int rows = std::min(N, hi * NB) - r0, cols = r0 - c0;
-  // work (rows x cols) = L21 X11   (X11 lower triangular)
-  tile_gemm<3>(rows, cols, cols, L + r0 + (long)c0 * lda, lda, Linv + c0 + (long)c0 * ldl, ldl, work, rows, s);
-  // X21 = -X22 work   (X22 lower triangular)
-  tile_gemm<1, true>(rows, cols, rows, Linv + r0 + (long)r0 * ldl, ldl, work, rows, Linv + r0 + (long)c0 * ldl, ldl, s);
+// Off-diagonal blocks of L^-1 (the 64 x 64 diagonal blocks are already inverted), LEVEL BY LEVEL: at block size B = 64, 128, ...
+// node k pairs the inverted diagonal blocks [2kB, (2k+1)B) and [(2k+1)B, (2k+2)B):
+//     inv [[L11, 0], [L21, L22]] = [[X11, 0], [-X22 (L21 X11), X22]],
+// two triangular GEMMs per node -- and ALL nodes of a level go down in one batched launch of each (grid.z = node).  The
+// recursion this replaces issued them node by node: 248 launches at N = 8000, most of them 64 .. 256-wide products that are
+// pure launch latency (~2.5 of the inverse's 7 ms).  r3.
+void trtri_levels(const double* L, long lda, double* Linv, long ldl, int N, double* work, hipStream_t s) {
+  for (long B = NB; B < N; B *= 2) {
+    const int nn = (int)((N - B + 2 * B - 1) / (2 * B));  // nodes with a non-empty lower block: (2k + 1) B < N
+    const int rows_max = (int)std::min<long>(B, N - B);
+    const long ldw = rows_max;
+    const int rt = (rows_max + 63) / 64, ct = (int)((B + 63) / 64);
+    int xmul = 1;
+    for (int cand : {37, 41, 43, 47, 53, 59})
+      if (rt % cand != 0) {
+        xmul = cand;
+        break;
+      }
+    // work_k (rows x B) = L21 X11   (X11 lower triangular: MODE 3)
+    hipLaunchKernelGGL((mfma_gemm_kernel<3, false, 16>), dim3(ct, rt, nn), dim3(256), 0, s, rows_max, (int)B, (int)B, L + B, lda,
+                       (const double*)Linv, ldl, work, ldw, xmul, 0, 2 * B * (1 + lda), 2 * B * (1 + ldl), ldw * B, (int)(N - B),
+                       (int)(2 * B));
+    // X21 = -X22 work_k   (X22 lower triangular: MODE 1, negated).  A single big node (the top levels) pairs row tile p with its
+    // mirror so that every workgroup walks the same number of K steps (see mfma_gemm_kernel).
+    const int pair = (nn == 1 && rt >= 16) ? 1 : 0;
+    hipLaunchKernelGGL((mfma_gemm_kernel<1, true, 16>), dim3(ct, pair ? (rt + 1) / 2 : rt, nn), dim3(256), 0, s, rows_max, (int)B,
+                       rows_max, (const double*)(Linv + B + B * ldl), ldl, (const double*)work, ldw, Linv + B, ldl, xmul, pair,
+                       2 * B * (1 + ldl), ldw * B, 2 * B * (1 + ldl), (int)(N - B), (int)(2 * B));
+  }
 }
 }  // namespace
 
 size_t cholesky_work_doubles(int N) {
-  const long nblk = (N + NB - 1) / NB, half = (nblk + 1) / 2;
-  return (size_t)(half * NB) * (size_t)(half * NB);
+  size_t need = 1;  // the largest level of trtri_levels: nodes x (rows x B)
+  for (long B = NB; B < N; B *= 2) {
+    const long nn = (N - B + 2 * B - 1) / (2 * B), rows_max = std::min<long>(B, N - B);
+    need = std::max(need, (size_t)(nn * rows_max * B));
+  }
+  return need;
 }
 
 // The factorisation part of the two-level algorithm (L in place, the 64 x 64 diagonal blocks of L^-1 in Linv's diagonal blocks).
-// Look-ahead schedule (MOE_CHOL_LOOKAHEAD=1; default: everything on one stream, in order): the 125 diagonal-block kernels of an
-// N = 8000 factorisation are single-workgroup, latency-bound launches of ~50 us, and in stream order the panel and update kernels
-// of a step (17 + 23 us on the whole chip) wait for them and they for those.  With look-ahead stream `s` carries only what the
-// NEXT diagonal block needs -- diag(k), the panel's first row block, the update of tile (k+1, k+1) -- while a second stream does
-// the rest of panel(k) and update(k) behind it.  MEASURED SLOWER on MI355X / ROCm 7.2 (N = 8000 build 30.3 vs 23.7 ms): three
-// cross-queue event dependences and two more launches per 64-column step cost more than the ~25 us of overlap they buy.  Kept,
-// off, as the record of that experiment and as a second schedule for the bit-equality test.  Every tile still receives its updates in the same order (k ascending), so the factor is
-// bit-identical to the in-order schedule; the events below are the tile-level dependences:
-//   B waits for diag(k) (its inverse block) before panel_rest(k), and for panel0(k) before update_rest(k);
-//   A waits for update_rest(k-1) before panel0(k) / tile00(k) (column block k and tile (k+1, k+1) get step k-1's update there).
-void cholesky_factor_two_level(int N, double* A, long lda, double* Linv, long ldl, int* info, hipStream_t s) {
-  const char* la_env = std::getenv("MOE_CHOL_LOOKAHEAD");  // (read per call: the tests compare the two schedules)
-  const bool lookahead = la_env && *la_env == '1';  // OFF by default: measured slower, see the comment above
-  hipStream_t sb = nullptr;
-  hipEvent_t e_diag = nullptr, e_p0 = nullptr, e_rest = nullptr, e_fork = nullptr;
-  if (lookahead) {
-    MOE_HIP_CHECK(hipStreamCreateWithFlags(&sb, hipStreamNonBlocking));
-    MOE_HIP_CHECK(hipEventCreateWithFlags(&e_diag, hipEventDisableTiming));
-    MOE_HIP_CHECK(hipEventCreateWithFlags(&e_p0, hipEventDisableTiming));
-    MOE_HIP_CHECK(hipEventCreateWithFlags(&e_rest, hipEventDisableTiming));
-    MOE_HIP_CHECK(hipEventCreateWithFlags(&e_fork, hipEventDisableTiming));
-    // the second stream starts behind whatever `s` holds already (the covariance build, the memsets)
-    MOE_HIP_CHECK(hipEventRecord(e_fork, s));
-    MOE_HIP_CHECK(hipStreamWaitEvent(sb, e_fork, 0));
+// Default schedule (r3): per 64-column step ONE launch of chol_step_kernel -- panel solve, update of the outer block's remaining
+// columns, and the NEXT diagonal block factored ahead by the workgroup that owns it; a stand-alone diagonal kernel (and a copy of
+// the column block into the step kernel's scratch buffer) only at the start of each outer block, whose first tiles are final only
+// after the rank-512 update.  MOE_CHOL_FUSED_STEP=0: the round-2 schedule, three dependent launches per step (diagonal, panel,
+// update) -- kept for A/B runs and as the second implementation the tests compare against.  (Round 2 also tried a look-ahead over
+// two HIP streams with events: slower than in-order -- three cross-queue dependences and two more launches per step cost more
+// than the overlap; the in-kernel look-ahead replaces it.  A first fused kernel with one workgroup per ROW tile and release /
+// acquire flags between workgroups was no faster than three launches at N = 8000 -- each workgroup walked eight dependent
+// load-multiply-store rounds -- and 2.7x slower at N = 26 000, where its 406 workgroups of 100 KB LDS are not co-resident.)
+// `scratch`: chol_scratch_doubles(N) doubles for the step kernel's two column-block buffers (NULL: taken from the stream's pool).
+size_t chol_scratch_doubles(int N) { return (size_t)2 * (((size_t)N + 15) / 16 * 16) * NB; }
+
+void cholesky_factor_two_level(int N, double* A, long lda, double* Linv, long ldl, int* info, hipStream_t s, double* scratch) {
+  const char* fs_env = std::getenv("MOE_CHOL_FUSED_STEP");  // (read per call: the tests compare the two schedules)
+  // beyond ~16 k rows the step kernel's recomputed panels cost more than the look-ahead buys (N = 26 000: 330 vs 299 ms -- the
+  // rank-512 updates dominate there and the diagonal chain hides behind nothing anyway): the three-launch schedule
+  const bool fused = (fs_env && *fs_env) ? (*fs_env != '0') : (N <= 16384);
+  constexpr size_t kStepSmem = sizeof(double) * 3 * NB * (NB + 1);
+  double* cbuf = nullptr;
+  const long ldc = ((long)N + 15) / 16 * 16;
+  if (fused) {
+    static const bool attr_set = [] {
+      MOE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(chol_step_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)kStepSmem));
+      return true;
+    }();
+    (void)attr_set;
+    cbuf = scratch;
+    if (cbuf == nullptr) MOE_HIP_CHECK(hipMallocAsync(reinterpret_cast<void**>(&cbuf), sizeof(double) * (size_t)2 * ldc * NB, s));
   }
+  // The rank-512 update of outer block o is issued in two parts: the columns of the NEXT outer block on `s` (the inner steps need
+  // them), everything to their right on a second stream, where it overlaps those inner steps -- a latency-bound chain of
+  // ~60 us launches that leaves most of the chip idle.  Per tile the updates still arrive in outer-block order (part two of
+  // block o-1 and part one of block o touch the same tiles: an event orders them), so the factor is bit-identical to the
+  // one-stream schedule (MOE_CHOL_SYRK_OVERLAP=0).  Two events per outer block -- not the per-step event traffic that made
+  // round 2's two-stream look-ahead slower than in-order.
+  struct Aux {
+    hipStream_t sb = nullptr;
+    hipEvent_t e_panel = nullptr, e_rest = nullptr;
+  };
+  static thread_local std::unordered_map<hipStream_t, Aux> aux_cache;  // (streams are long-lived: one per GP handle)
+  const char* ov_env = std::getenv("MOE_CHOL_SYRK_OVERLAP");
+  const bool overlap = fused && (ov_env && *ov_env == '1') && N > 2 * kOuter;  // OFF by default: measured 19.45 -> 19.2 ms at N = 8000, within the noise -- the bulk update's workgroups take the CUs the chain needs (profiles/r03_c_chol_time.txt)
+  Aux aux;
+  if (overlap) {
+    Aux& a = aux_cache[s];
+    if (a.sb == nullptr) {
+      // (lowest priority: the chain on `s` must get its workgroups placed ahead of the bulk update's ~1 800)
+      int prio_lo = 0, prio_hi = 0;
+      MOE_HIP_CHECK(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
+      MOE_HIP_CHECK(hipStreamCreateWithPriority(&a.sb, hipStreamNonBlocking, prio_lo));
+      MOE_HIP_CHECK(hipEventCreateWithFlags(&a.e_panel, hipEventDisableTiming));
+      MOE_HIP_CHECK(hipEventCreateWithFlags(&a.e_rest, hipEventDisableTiming));
+    }
+    aux = a;
+  }
+  bool rest_pending = false;
+  int cur = 0;
   for (int ko = 0; ko < N; ko += kOuter) {
     const int wo = std::min(kOuter, N - ko);
-    bool rest_pending = false;  // stream B holds panel_rest / update_rest of the previous step of this outer block
+    bool ahead_done = false;  // the diagonal block and the scratch copy of this step's column block come from the previous step
     for (int k0 = ko; k0 < ko + wo; k0 += NB) {
       const int nb = std::min(NB, N - k0);
-      hipLaunchKernelGGL(chol_diag_lds_kernel, dim3(1), dim3(256), 0, s, A, lda, Linv, ldl, k0, nb, info);
       const int below = N - k0 - nb;
+      if (!ahead_done) {
+        hipLaunchKernelGGL(chol_diag_lds_kernel, dim3(1), dim3(256), 0, s, A, lda, Linv, ldl, k0, nb, info);
+        if (fused && below > 0)
+          hipLaunchKernelGGL(chol_colcopy_kernel, dim3((below + 255) / 256), dim3(256), 0, s, (const double*)A, lda, N, k0, nb,
+                             cbuf + (size_t)cur * ldc * NB, ldc);
+      }
+      ahead_done = false;
       if (below <= 0) continue;
       const int tb = (below + NB - 1) / NB;
       const int left = ko + wo - (k0 + nb);  // columns of this outer block still to be factored
       const int cb = (left + NB - 1) / NB;
-      if (!lookahead) {
+      if (!fused) {
         hipLaunchKernelGGL(chol_panel_kernel, dim3(tb), dim3(256), 0, s, A, lda, Linv, ldl, N, k0, nb, info);
         if (left > 0) hipLaunchKernelGGL(chol_update_kernel, dim3(tb, cb), dim3(256), 0, s, A, lda, N, k0, nb, info);
         continue;
       }
-      MOE_HIP_CHECK(hipEventRecord(e_diag, s));
-      if (rest_pending) MOE_HIP_CHECK(hipStreamWaitEvent(s, e_rest, 0));  // update_rest(k-1) done
-      hipLaunchKernelGGL(chol_panel_kernel, dim3(1), dim3(256), 0, s, A, lda, Linv, ldl, N, k0, nb, info, 0L, 0L, 0);
-      MOE_HIP_CHECK(hipEventRecord(e_p0, s));
-      if (left > 0) hipLaunchKernelGGL(chol_update_kernel, dim3(1, 1), dim3(256), 0, s, A, lda, N, k0, nb, info, 0L, 0);
-      // the rest of the step on stream B
-      MOE_HIP_CHECK(hipStreamWaitEvent(sb, e_diag, 0));
-      if (tb > 1)
-        hipLaunchKernelGGL(chol_panel_kernel, dim3(tb - 1), dim3(256), 0, sb, A, lda, Linv, ldl, N, k0, nb, info, 0L, 0L, 1);
-      MOE_HIP_CHECK(hipStreamWaitEvent(sb, e_p0, 0));
-      if (left > 0) hipLaunchKernelGGL(chol_update_kernel, dim3(tb, cb), dim3(256), 0, sb, A, lda, N, k0, nb, info, 0L, 1);
-      MOE_HIP_CHECK(hipEventRecord(e_rest, sb));
-      rest_pending = true;
+      hipLaunchKernelGGL(chol_step_kernel, dim3(cb + 1, tb), dim3(256), kStepSmem, s, A, lda, Linv, ldl, N, k0, nb, cb, info,
+                         (const double*)(cbuf + (size_t)cur * ldc * NB), cbuf + (size_t)(1 - cur) * ldc * NB, ldc, left > 0 ? 1 : 0);
+      if (left > 0) {
+        cur = 1 - cur;
+        ahead_done = true;
+      }
     }
-    if (lookahead && rest_pending) MOE_HIP_CHECK(hipStreamWaitEvent(s, e_rest, 0));  // every panel of the outer block is final
     const int trailing = N - (ko + wo);
     if (trailing > 0) {
       const int tt = (trailing + 63) / 64;
-      hipLaunchKernelGGL(syrk_mfma_kernel, dim3(tt, tt), dim3(256), 0, s, A, lda, N, ko + wo, ko, wo, (const int*)info);
-      if (lookahead) {  // stream B's next kernels touch the matrix the rank-512 update is writing
-        MOE_HIP_CHECK(hipEventRecord(e_fork, s));
-        MOE_HIP_CHECK(hipStreamWaitEvent(sb, e_fork, 0));
+      const int first = std::min(tt, kOuter / 64);  // column tiles of the next outer block
+      if (!overlap || tt <= first) {
+        hipLaunchKernelGGL(syrk_mfma_kernel, dim3(tt, tt), dim3(256), 0, s, A, lda, N, ko + wo, ko, wo, (const int*)info);
+      } else {
+        MOE_HIP_CHECK(hipEventRecord(aux.e_panel, s));                          // the panel of this outer block is final
+        if (rest_pending) MOE_HIP_CHECK(hipStreamWaitEvent(s, aux.e_rest, 0));  // part two of the previous block wrote these tiles
+        hipLaunchKernelGGL(syrk_mfma_kernel, dim3(first, tt), dim3(256), 0, s, A, lda, N, ko + wo, ko, wo, (const int*)info, 0);
+        MOE_HIP_CHECK(hipStreamWaitEvent(aux.sb, aux.e_panel, 0));
+        hipLaunchKernelGGL(syrk_mfma_kernel, dim3(tt - first, tt), dim3(256), 0, aux.sb, A, lda, N, ko + wo, ko, wo,
+                           (const int*)info, first);
+        MOE_HIP_CHECK(hipEventRecord(aux.e_rest, aux.sb));
+        rest_pending = true;
       }
     }
   }
+  if (rest_pending) MOE_HIP_CHECK(hipStreamWaitEvent(s, aux.e_rest, 0));
   MOE_HIP_CHECK(hipGetLastError());
-  if (lookahead) {
-    // (everything on stream B has been joined into `s` through e_rest; the objects can go once `s` has passed those waits)
-    MOE_HIP_CHECK(hipStreamSynchronize(sb));
-    MOE_HIP_CHECK(hipStreamDestroy(sb));
-    MOE_HIP_CHECK(hipEventDestroy(e_diag));
-    MOE_HIP_CHECK(hipEventDestroy(e_p0));
-    MOE_HIP_CHECK(hipEventDestroy(e_rest));
-    MOE_HIP_CHECK(hipEventDestroy(e_fork));
-  }
+  if (cbuf != nullptr && scratch == nullptr) MOE_HIP_CHECK(hipFreeAsync(cbuf, s));
 }
 
 void launch_cholesky_and_inverse(int N, double* A, long lda, double* Linv, long ldl, double* work, int* info,
@@ -1172,7 +1408,9 @@ void launch_cholesky_and_inverse(int N, double* A, long lda, double* Linv, long 
   const char* tl_env = std::getenv("MOE_CHOL_TWO_LEVEL_MIN");  // (read per call: tests force the two-level path at small N)
   const int two_level_min = (tl_env && *tl_env) ? std::atoi(tl_env) : 2048;
   if (N >= two_level_min) {
-    cholesky_factor_two_level(N, A, lda, Linv, ldl, info, s);
+    // (the inversion's workspace is idle during the factorisation: it lends the step kernel its column-block buffers)
+    cholesky_factor_two_level(N, A, lda, Linv, ldl, info, s,
+                              (work != nullptr && cholesky_work_doubles(N) >= chol_scratch_doubles(N)) ? work : nullptr);
   } else {
     for (int b = 0; b < nblk; ++b) {
       const int k0 = b * NB, nb = std::min(NB, N - k0);
@@ -1194,7 +1432,7 @@ void launch_cholesky_and_inverse(int N, double* A, long lda, double* Linv, long 
   // -- two triangular GEMMs per node, big and wide near the root, instead of one dependent block row after another.
   if (nblk > 1) {
     if (work == nullptr) throw Error(MOE_ERR_RUNTIME, "launch_cholesky_and_inverse: workspace missing");
-    trtri_offdiag(A, lda, Linv, ldl, N, 0, nblk, work, s);
+    trtri_levels(A, lda, Linv, ldl, N, work, s);
   }
   MOE_HIP_CHECK(hipGetLastError());
 }
@@ -1289,7 +1527,7 @@ __global__ __launch_bounds__(256) void ll_terms_batch_kernel(const double* __res
 }  // namespace
 
 void launch_cholesky_batch(int N, double* A, long lda, long a_stride, double* Linv, long ldl, long l_stride, int* info,
-                           int batch, hipStream_t s) {
+                           int batch, hipStream_t s, double* scratch) {
   MOE_HIP_CHECK(hipMemsetAsync(info, 0, sizeof(int) * batch, s));
   {
     // large matrices (the log likelihood at C5's N = 8000): the two-level factorisation with its look-ahead schedule, one matrix
@@ -1299,7 +1537,7 @@ void launch_cholesky_batch(int N, double* A, long lda, long a_stride, double* Li
     const int two_level_min = (tl_env && *tl_env) ? std::atoi(tl_env) : 2048;
     if (N >= two_level_min) {
       for (int b = 0; b < batch; ++b)
-        cholesky_factor_two_level(N, A + (size_t)b * a_stride, lda, Linv + (size_t)b * l_stride, ldl, info + b, s);
+        cholesky_factor_two_level(N, A + (size_t)b * a_stride, lda, Linv + (size_t)b * l_stride, ldl, info + b, s, scratch);
       return;
     }
   }

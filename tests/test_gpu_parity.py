@@ -559,24 +559,37 @@ def test_two_level_cholesky(api, monkeypatch):
     with pytest.raises(api.SingularMatrixException) as e:
         api.DeviceGP([1.0, 0.5, 0.5], Xs, np.zeros((200, 1)), [0.0])
     assert e.value.leading_minor_index == 151
-    # the look-ahead schedule (diagonal-block chain on one stream, the rest of each step on a second) gives the in-order
-    # schedule's factor and inverse BIT FOR BIT, run after run; the log likelihood's bordered factorisation takes the same route
+    # r3: the fused step schedule (one launch per 64-column step: panel solve, update, the next diagonal block factored ahead
+    # inside the kernel; in-kernel release / acquire flags between workgroups) against the round-2 schedule of three launches
+    # per step: same factor and K^-1 y to round-off (the 64^3 products run on the matrix pipe in one and on FMA tiles in the
+    # other), and bit for bit the same from run to run; sizes with a partial last block and a single outer block included
     monkeypatch.setenv("MOE_CHOL_TWO_LEVEL_MIN", "64")
+    for n_ in (900, 1100, 130):
+        X = rng.uniform(size=(n_, 3))
+        y = rng.uniform(size=(n_, 1))
+        facs = []
+        for fs in ("0", "1", "1", "1"):
+            monkeypatch.setenv("MOE_CHOL_FUSED_STEP", fs)
+            L_, kiy_, _ = api.DeviceGP([1.1, 0.4, 0.5, 0.6], X, y, [0.03]).get_factor()
+            facs.append((L_, kiy_))
+        assert np.abs(facs[1][0] - facs[0][0]).max() <= 1e-13 * np.abs(facs[0][0]).max()
+        assert np.abs(facs[1][1] - facs[0][1]).max() <= 1e-10 * np.abs(facs[0][1]).max()
+        for L_, kiy_ in facs[2:]:
+            assert np.array_equal(L_, facs[1][0]) and np.array_equal(kiy_, facs[1][1])
+    monkeypatch.delenv("MOE_CHOL_FUSED_STEP")
+    # a singular matrix is reported at the same minor by the in-kernel look-ahead (the duplicate sits in the second 64-block)
+    Xd = rng.uniform(size=(300, 2))
+    Xd[100] = Xd[7]
+    with pytest.raises(api.SingularMatrixException) as e2:
+        api.DeviceGP([1.0, 0.5, 0.5], Xd, np.zeros((300, 1)), [0.0])
+    assert e2.value.leading_minor_index == 101
     X = rng.uniform(size=(900, 3))
     y = rng.uniform(size=(900, 1))
-    facs = []
-    for la in ("0", "1", "1", "1"):
-        monkeypatch.setenv("MOE_CHOL_LOOKAHEAD", la)
-        L_, kiy_, _ = api.DeviceGP([1.1, 0.4, 0.5, 0.6], X, y, [0.03]).get_factor()
-        facs.append((L_, kiy_))
-    for L_, kiy_ in facs[1:]:
-        assert np.array_equal(L_, facs[0][0]) and np.array_equal(kiy_, facs[0][1])
     th = np.array([[1.1, 0.4, 0.5, 0.6, 0.03], [0.9, 0.5, 0.5, 0.7, 0.05]])
     ll_two = api.LogLikelihood(X, y).evaluate(th)
     monkeypatch.setenv("MOE_CHOL_TWO_LEVEL_MIN", "1000000")
     ll_one = api.LogLikelihood(X, y).evaluate(th)
     assert np.abs(ll_two - ll_one).max() <= 1e-11 * np.abs(ll_one).max()
-    monkeypatch.delenv("MOE_CHOL_LOOKAHEAD")
     monkeypatch.delenv("MOE_CHOL_TWO_LEVEL_MIN")
     n, d = 2600, 6
     X = rng.uniform(size=(n, d))

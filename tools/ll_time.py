@@ -18,7 +18,7 @@ for n, d, g, batch in ((1000, 8, 0, 16), (2000, 12, 3, 4)):
     sets = np.array([th * (1.0 + 0.01 * i) for i in range(batch)])
     for label, fn, per in (("evaluate x1", lambda: LL.evaluate(sets[:1]), 1), ("evaluate x%d" % batch, lambda: LL.evaluate(sets), batch),
                            ("grad", lambda: LL.grad(th), 1)):
-        fn()
+        v0 = fn()
         t0 = time.perf_counter()
         reps = 3
         for _ in range(reps):
@@ -27,3 +27,4 @@ for n, d, g, batch in ((1000, 8, 0, 16), (2000, 12, 3, 4)):
         N = n * (1 + g)
         print("n=%d d=%d g=%d N=%d  %-12s %8.2f ms per call, %8.2f ms per hyper-parameter set  (factorisation alone: %.1f TFLOP/s)"
               % (n, d, g, N, label, 1e3 * dt, 1e3 * dt / per, per * N ** 3 / 3.0 / dt / 1e12), flush=True)
+        print("      first values: %s" % np.array2string(np.ravel(v0)[:3], precision=12), flush=True)
