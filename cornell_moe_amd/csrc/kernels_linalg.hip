@@ -835,37 +835,6 @@ __device__ unsigned long long moe_diag_prof[16];
 #define MOE_DIAG_A(i)
 #endif
 
-template <int LO, int MID, int HI>
-__device__ __forceinline__ void lds_tri_inv_offdiag(double (*S)[NB + 1], double (*W)[2 * SB + 1]) {
-  // Fixed trip counts with predicated terms (clamped addresses), fully unrolled: the loads of a dot product are issued together
-  // instead of one LDS round trip per term.
-  // W[r][c - LO] = sum_j L[r][j] X[j][c],  r in [MID, HI), c in [LO, MID), j in [c, MID)   (X11 lower triangular)
-  constexpr int rows = HI - MID, cols = MID - LO;
-  for (int idx = threadIdx.x; idx < rows * cols; idx += 256) {
-    const int r = MID + idx % rows, c = LO + idx / rows;
-    double acc = 0.0;
-#pragma unroll
-    for (int j = LO; j < MID; ++j) {
-      const double x = MOE_XS(max(j, c), c);  // (j < c: a valid but unused entry)
-      acc = fma(S[r][j], (j >= c) ? x : 0.0, acc);
-    }
-    W[r][c - LO] = acc;
-  }
-  __syncthreads();
-  // X[r][c] = -sum_j X[r][j] W[j][c],  j in [MID, r]   (X22 lower triangular)
-  for (int idx = threadIdx.x; idx < rows * cols; idx += 256) {
-    const int r = MID + idx % rows, c = LO + idx / rows;
-    double acc = 0.0;
-#pragma unroll
-    for (int j = MID; j < HI; ++j) {
-      const double x = MOE_XS(r, min(j, r));
-      acc = fma((j <= r) ? x : 0.0, W[j][c - LO], acc);
-    }
-    MOE_XS(r, c) = -acc;
-  }
-  __syncthreads();
-}
-
 // The diagonal-block work as device functions (shared by chol_diag_lds_kernel and the look-ahead of chol_step_kernel).
 // diag_load: the nb x nb block at (k0, k0) into S (lower triangle; identity beyond nb).
 __device__ __forceinline__ void diag_load(const double* __restrict__ A, long lda, int k0, int nb, double (*S)[NB + 1]) {
@@ -894,27 +863,36 @@ __device__ __forceinline__ void diag_load(const double* __restrict__ A, long lda
   }
 }
 
-// diag_factor: S <- its Cholesky factor (lower) with the inverses of the four 16 x 16 diagonal sub-blocks packed above the
-// diagonal; *s_bad = first failing pivot (global index + 1) or 0.  Ends with a barrier.
+// diag_factor (r3 form): S <- its Cholesky factor (lower) and the inverses of the four 16 x 16 diagonal sub-blocks packed above
+// the diagonal; *s_bad = first failing pivot (global index + 1) or 0.  Ends with a barrier.  In 16-column sub-steps:
+//   (1) the first wavefront, LANE = ROW of the 64 x 64 block, holds its 16 entries of the column block in registers and runs the
+//       reference's unblocked outer-product elimination over them (v_readlane pivot, division by its square root, the 1e-16
+//       pivot rule): the rows BELOW the 16 x 16 diagonal sub-block ride along in the same instructions, so the panel
+//       A_panel L16^-T comes out of the elimination itself -- the inverse of the sub-block is not on the chain any more
+//       (round 2 factored and inverted 16 rows, then formed the panel through that inverse: 4.75 us per sub-step, one
+//       wavefront working, three waiting);
+//   (2) the trailing 16 x 16 blocks get their rank-16 update on the matrix pipe (v_mfma_f64_16x16x4_f64, one block per
+//       wavefront and round);
+// then (3) the four 16 x 16 inverses, one per wavefront, column per lane, forward substitution against broadcast reads.
 __device__ __forceinline__ void diag_factor(double (*S)[NB + 1], double (*W)[2 * SB + 1], int* s_bad_p, int k0) {
-  const int t = threadIdx.x;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   int& s_bad = *s_bad_p;
+  double* Rd = &W[32][0];  // 1 / L[k][k], k < 64 (rows 32 .. 33 of the scratch; rows 0 .. 31 hold diag_invert's product block)
 #if defined(MOE_DIAG_PROF)
   unsigned long long diag_last_ = 0;
 #endif
+#pragma unroll 1
   for (int s0 = 0; s0 < NB; s0 += SB) {
     MOE_DIAG_A(0);
-    // (1) 16 x 16 diagonal sub-block: the first wavefront, lane & 15 = row of the sub-block, that row in registers
-    if (t < 64) {
-      const int i = t & (SB - 1);
+    if (wave == 0) {
+      const int ri = lane;
       double a[SB];
 #pragma unroll
-      for (int c = 0; c < SB; ++c) a[c] = S[s0 + i][s0 + c];  // (c > i: whatever the packed inverse holds there -- never used)
+      for (int c = 0; c < SB; ++c) a[c] = S[ri][s0 + c];  // (rows above s0 and entries above the diagonal: loaded, never used)
       int bad = 0;
-      double rdiag[SB];  // 1 / L[k][k], reused by the inverse below
 #pragma unroll
       for (int k = 0; k < SB; ++k) {
-        const double piv = readlane_f64(a[k], k);
+        const double piv = readlane_f64(a[k], s0 + k);
         if (bad == 0 && !(piv > 1.0e-16)) bad = k0 + s0 + k + 1;  // gpp_linear_algebra.cpp:118
         const double ps = fmax(piv, 1.0e-300);  // (a failed pivot is reported above; keep the arithmetic finite)
         double r = __builtin_amdgcn_rsq(ps);
@@ -922,80 +900,132 @@ __device__ __forceinline__ void diag_factor(double (*S)[NB + 1], double (*W)[2 *
         r = r * fma(-0.5 * ps * r, r, 1.5);
         double lkk = ps * r;
         lkk = fma(fma(-lkk, lkk, ps), 0.5 * r, lkk);  // Heron correction of sqrt(ps)
-        rdiag[k] = r;
+        if (lane == 0) Rd[s0 + k] = r;
         double q = a[k] * r;
         q = fma(fma(-q, lkk, a[k]), r, q);  // residual correction of a / lkk
-        const double lik = (i == k) ? lkk : q;
+        const double lik = (ri == s0 + k) ? lkk : q;
         a[k] = lik;
 #pragma unroll
         for (int j = k + 1; j < SB; ++j) {
-          const double ljk = readlane_f64(lik, j);  // L[j][k] lives in lane j
-          a[j] = a[j] - lik * ljk;                   // (lanes i < j compute unused upper-triangle values)
+          const double ljk = readlane_f64(lik, s0 + j);  // L[s0 + j][s0 + k] lives in lane s0 + j
+          a[j] = a[j] - lik * ljk;                       // (rows above s0 + j compute unused upper-triangle values)
         }
       }
-      // its inverse: lane i solves L16 x = e_i (column i of the inverse), entries above i are exact zeros
-      double x[SB];
+      if (ri >= s0) {
 #pragma unroll
-      for (int r = 0; r < SB; ++r) {
-        double sum = (r == i) ? 1.0 : 0.0;
-#pragma unroll
-        for (int j = 0; j < r; ++j) sum -= readlane_f64(a[j], r) * x[j];  // L[r][j] lives in lane r
-        const double lrr = readlane_f64(a[r], r);
-        double q = sum * rdiag[r];
-        q = fma(fma(-q, lrr, sum), rdiag[r], q);
-        x[r] = q;
+        for (int c = 0; c < SB; ++c)
+          if (ri >= s0 + SB || c <= ri - s0) S[ri][s0 + c] = a[c];  // (the diagonal sub-block: lower triangle only)
       }
-      if (t < SB) {
-        if (bad != 0 && s_bad == 0) s_bad = bad;
-#pragma unroll
-        for (int c = 0; c < SB; ++c) {
-          if (c <= i) S[s0 + i][s0 + c] = a[c];
-          if (c >= i) MOE_XS(s0 + c, s0 + i) = x[c];  // x[c] = (L16^-1)[c][i]
-        }
-      }
+      if (lane == 0 && bad != 0 && s_bad == 0) s_bad = bad;
     }
     __syncthreads();
     MOE_DIAG_A(1);
-    const int below = NB - s0 - SB;
-    if (below > 0) {
-      // (2) panel: P[r][c] = sum_j A[r][s0 + j] X16[c][j]   (= A_panel L16^-T), r below the sub-block
-      for (int idx = t; idx < below * SB; idx += 256) {
-        const int r = s0 + SB + idx % below, c = idx / below;
-        double acc = 0.0;
+    // (2) S[i][j] -= sum_c P[i][c] P[j][c] over the 16 x 16 blocks below / right of the sub-block, lower block triangle
+    const int nbk = (NB - s0 - SB) / SB;
+    int bidx = 0;
+    for (int ib = 0; ib < nbk; ++ib)
+      for (int jb = 0; jb <= ib; ++jb, ++bidx) {
+        if ((bidx & 3) != wave) continue;
+        const int r0i = s0 + SB + ib * SB, r0j = s0 + SB + jb * SB;
+        f64x4 acc = f64x4{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-        for (int j = 0; j < SB; ++j)
-          if (j <= c) acc = fma(S[r][s0 + j], MOE_XS(s0 + c, s0 + j), acc);
-        W[r][c] = acc;
-      }
-      __syncthreads();
-      for (int idx = t; idx < below * SB; idx += 256) {
-        const int r = s0 + SB + idx % below, c = idx / below;
-        S[r][s0 + c] = W[r][c];
-      }
-      __syncthreads();
-      MOE_DIAG_A(2);
-      // (3) the remaining columns: S[i][j] -= sum_c S[i][s0 + c] S[j][s0 + c], j <= i, one column at a time in k order
-      for (int idx = t; idx < below * below; idx += 256) {
-        const int i = s0 + SB + idx % below, j = s0 + SB + idx / below;
-        if (j <= i) {
-          double acc = S[i][j];
+        for (int kk = 0; kk < SB; kk += 4) {
+          const double av = S[r0i + (lane & 15)][s0 + kk + (lane >> 4)];
+          const double bv = S[r0j + (lane & 15)][s0 + kk + (lane >> 4)];
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+        }
 #pragma unroll
-          for (int c = 0; c < SB; ++c) acc = acc - S[i][s0 + c] * S[j][s0 + c];
-          S[i][j] = acc;
+        for (int r = 0; r < 4; ++r) {
+          const int m = 4 * r + (lane >> 4), n = lane & 15;
+          if (ib != jb || n <= m) S[r0i + m][r0j + n] -= acc[r];
         }
       }
-      __syncthreads();
-      MOE_DIAG_A(3);
+    __syncthreads();
+    MOE_DIAG_A(2);
+  }
+  // (3) the inverses of the four 16 x 16 diagonal sub-blocks, one per wavefront: lane & 15 = column i of the inverse, forward
+  // substitution L16 x = e_i in column order (once x_r is final every later row folds it in: independent fmas, the same
+  // left-to-right sums as a row-by-row solve); entries above i are exact zeros
+  {
+    const int b0 = wave * SB, i = lane & (SB - 1);
+    double sum[SB], x[SB];
+#pragma unroll
+    for (int r = 0; r < SB; ++r) sum[r] = (r == i) ? 1.0 : 0.0;
+#pragma unroll
+    for (int r = 0; r < SB; ++r) {
+      const double lrr = S[b0 + r][b0 + r], rd = Rd[b0 + r];
+      double q = sum[r] * rd;
+      q = fma(fma(-q, lrr, sum[r]), rd, q);
+      x[r] = q;
+#pragma unroll
+      for (int r2 = r + 1; r2 < SB; ++r2) sum[r2] = fma(-S[b0 + r2][b0 + r], q, sum[r2]);
+      __builtin_amdgcn_sched_barrier(0);  // (keeps the scheduler from hoisting all 120 broadcast reads to the top: 240 VGPRs)
+    }
+    if (lane < SB) {
+#pragma unroll
+      for (int c = 0; c < SB; ++c)
+        if (c >= i) MOE_XS(b0 + c, b0 + i) = x[c];  // x[c] = (L16^-1)[c][i]
     }
   }
+  __syncthreads();
+  MOE_DIAG_A(3);
 }
 
-// diag_invert: the off-diagonal blocks of the 64 x 64 inverse by recursive halving (the packed layout of MOE_XS).
+// diag_invert: the off-diagonal blocks of the 64 x 64 inverse by recursive halving on the matrix pipe,
+//     inv [[L11, 0], [L21, L22]] = [[X11, 0], [-X22 (L21 X11), X22]],
+// 16 x 16 nodes (0,16,32) and (32,48,64) on wavefronts 0 and 1 -- the product L21 X11 stays in the MFMA result registers, whose
+// layout IS the B-operand layout of the second product -- then the 32 x 32 node (0,32,64) on all four wavefronts (its product
+// block goes through the scratch W).  The packed layout of MOE_XS; triangular operands are masked on the fly.
 __device__ __forceinline__ void diag_invert(double (*S)[NB + 1], double (*W)[2 * SB + 1]) {
-  // L^-1: the diagonal 16-blocks are in place; off-diagonal blocks by recursive halving
-  lds_tri_inv_offdiag<0, 16, 32>(S, W);
-  lds_tri_inv_offdiag<32, 48, 64>(S, W);
-  lds_tri_inv_offdiag<0, 32, 64>(S, W);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int l16 = lane & 15, l4 = lane >> 4;
+  if (wave < 2) {
+    const int LO = wave * 32, MID = LO + SB;
+    f64x4 w = f64x4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int kk = 0; kk < SB; kk += 4) {  // W = L21 X11
+      const int k = kk + l4;
+      const double av = S[MID + l16][LO + k];                          // L21[m = l16][k]
+      const double xv = MOE_XS(LO + max(k, l16), LO + l16);            // X11[k][n = l16], lower triangular
+      w = __builtin_amdgcn_mfma_f64_16x16x4f64(av, (k >= l16) ? xv : 0.0, w, 0, 0, 0);
+    }
+    f64x4 x = f64x4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {  // X21 = -X22 W: register r of W is the B operand of k-step 4 r
+      const int k = 4 * r + l4;
+      const double xv = MOE_XS(MID + max(l16, k), MID + k);           // X22[m = l16][k], lower triangular
+      x = __builtin_amdgcn_mfma_f64_16x16x4f64((l16 >= k) ? xv : 0.0, w[r], x, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) MOE_XS(MID + 4 * r + l4, LO + l16) = -x[r];
+  }
+  __syncthreads();
+  {
+    const int mb = wave >> 1, nb = wave & 1;  // 16 x 16 output block of the 32 x 32 node
+    f64x4 w = f64x4{0.0, 0.0, 0.0, 0.0};
+    for (int kb = nb; kb < 2; ++kb)  // W[mb][nb] = sum_kb L21[mb][kb] X11[kb][nb]   (X11 lower: kb >= nb)
+#pragma unroll
+      for (int kk = 0; kk < SB; kk += 4) {
+        const int k = kb * SB + kk + l4, n = nb * SB + l16;
+        const double av = S[32 + mb * SB + l16][k];
+        const double xv = MOE_XS(max(k, n), n);
+        w = __builtin_amdgcn_mfma_f64_16x16x4f64(av, (k >= n) ? xv : 0.0, w, 0, 0, 0);
+      }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) W[mb * SB + 4 * r + l4][nb * SB + l16] = w[r];
+    __syncthreads();
+    f64x4 x = f64x4{0.0, 0.0, 0.0, 0.0};
+    for (int kb = 0; kb <= mb; ++kb)  // X21[mb][nb] = -sum_kb X22[mb][kb] W[kb][nb]   (X22 lower: kb <= mb)
+#pragma unroll
+      for (int kk = 0; kk < SB; kk += 4) {
+        const int m = mb * SB + l16, k = kb * SB + kk + l4;
+        const double xv = MOE_XS(32 + max(m, k), 32 + k);
+        x = __builtin_amdgcn_mfma_f64_16x16x4f64((m >= k) ? xv : 0.0, W[k][nb * SB + l16], x, 0, 0, 0);
+      }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) MOE_XS(32 + mb * SB + 4 * r + l4, nb * SB + l16) = -x[r];
+  }
+  __syncthreads();
 }
 
 // diag_store: L (strict upper written as 0) into A's block, L^-1 into Linv's block.
@@ -1082,10 +1112,11 @@ __global__ __launch_bounds__(256) void chol_step_kernel(double* __restrict__ A, 
                                                        int k0, int nb, int cb, int* __restrict__ info,
                                                        const double* __restrict__ Ccur, double* __restrict__ Cnext, long ldc,
                                                        int lookahead) {
+  // two 64 x 65 LDS buffers (66.5 KB: two workgroups per CU): B0 = Ds, then Pt_i, then the diagonal-block layout S;
+  // B1 = C_i^T, then C_j^T, then Pt_j, then the diagonal block's scratch W
   extern __shared__ __attribute__((aligned(16))) double step_smem[];
-  double (*Ds)[NB + 1] = reinterpret_cast<double (*)[NB + 1]>(step_smem);                        // Ds[j][c] = Linv_kk[c][j]
-  double (*Pi)[NB + 1] = reinterpret_cast<double (*)[NB + 1]>(step_smem + NB * (NB + 1));        // C_i^T, then Pt_i[k][r]
-  double (*Pj)[NB + 1] = reinterpret_cast<double (*)[NB + 1]>(step_smem + 2 * NB * (NB + 1));    // C_j^T, then Pt_j[k][c]
+  double (*B0)[NB + 1] = reinterpret_cast<double (*)[NB + 1]>(step_smem);
+  double (*B1)[NB + 1] = reinterpret_cast<double (*)[NB + 1]>(step_smem + NB * (NB + 1));
   __shared__ int s_bad;
   if (*info != 0) return;
   const int bi = blockIdx.y, jc = blockIdx.x;
@@ -1099,17 +1130,70 @@ __global__ __launch_bounds__(256) void chol_step_kernel(double* __restrict__ A, 
   const int lk = lane >> 4, lx = lane & 15;
   const bool need_j = j >= 0 && j != bi;
   const int j0 = base + max(j, 0) * NB;
-  for (int q = t; q < NB * NB; q += 256) {
-    const int r = q % NB, c = q / NB;  // r walks rows (contiguous in memory)
-    Ds[c][r] = (r < nb && c < nb) ? Linv[(long)(k0 + r) + (long)(k0 + c) * ldl] : 0.0;  // Ds[c][r] = Linv[r][c]
-    Pi[c][r] = (i0 + r < N && c < nb) ? Ccur[(long)(i0 + r) + (long)c * ldc] : 0.0;
-    if (need_j) Pj[c][r] = (j0 + r < N && c < nb) ? Ccur[(long)(j0 + r) + (long)c * ldc] : 0.0;
+  const bool ahead = lookahead && bi == 0 && j == 0;  // tile (k+1, k+1): the next diagonal block
+  constexpr int PER = NB * NB / 256;  // elements of a 64 x 64 tile per thread
+  // Global loads are issued in two batches, each from clamped addresses into registers and only then staged: one memory round
+  // trip per batch instead of one per staged element (guarded loads inside a staging loop cost a round trip each: 16 in a row).
+  // The second batch (the other panel's rows, the tile to update) is requested before the first product and lands behind it.
+  double rD[PER], rI[PER];
+#pragma unroll
+  for (int u = 0; u < PER; ++u) {
+    const int q = t + u * 256, r = q % NB, c = q / NB;  // r walks rows (contiguous in memory)
+    const int rc = min(r, nb - 1), cc = min(c, nb - 1);
+    rD[u] = Linv[(long)(k0 + rc) + (long)(k0 + cc) * ldl];
+    rI[u] = Ccur[(long)min(i0 + r, N - 1) + (long)cc * ldc];
+  }
+#pragma unroll
+  for (int u = 0; u < PER; ++u) {
+    const int q = t + u * 256, r = q % NB, c = q / NB;
+    B0[c][r] = (r < nb && c < nb) ? rD[u] : 0.0;          // Ds[c][r] = Linv_kk[r][c]
+    B1[c][r] = (i0 + r < N && c < nb) ? rI[u] : 0.0;      // C_i^T
+  }
+  double rJ[PER], rC[PER];
+  if (need_j) {
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+      const int q = t + u * 256, r = q % NB, c = q / NB;
+      rJ[u] = Ccur[(long)min(j0 + r, N - 1) + (long)min(c, nb - 1) * ldc];
+    }
+  }
+  if (jc > 0) {  // the tile this workgroup updates, in the result layout of the products below
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int gi = i0 + wi + 16 * a + lx, gj = j0 + wj + 16 * b + lk + 4 * r;
+          rC[(a * 2 + b) * 4 + r] = A[(long)min(gi, N - 1) + (long)min(gj, N - 1) * lda];
+        }
   }
   __syncthreads();
   f64x4 acc[2][2], accj[2][2];
-  mfma_64(Pi, Ds, acc, wi, wj, lk, lx);  // P_i[r][c] = sum_j C_i[r][j] Linv[c][j]
-  if (need_j) mfma_64(Pj, Ds, accj, wi, wj, lk, lx);
-  __syncthreads();
+  mfma_64(B1, B0, acc, wi, wj, lk, lx);  // P_i[r][c] = sum_j C_i[r][j] Linv[c][j]
+  if (jc == 0) {
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int rr = wi + 16 * a + lx, cc = wj + 16 * b + lk + 4 * r;
+          if (i0 + rr < N && cc < nb) A[(long)(i0 + rr) + (long)(k0 + cc) * lda] = acc[a][b][r];  // the final L panel
+        }
+    return;
+  }
+  if (need_j) {
+    __syncthreads();  // everybody is done reading C_i^T
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+      const int q = t + u * 256, r = q % NB, c = q / NB;
+      B1[c][r] = (j0 + r < N && c < nb) ? rJ[u] : 0.0;  // C_j^T
+    }
+    __syncthreads();
+    mfma_64(B1, B0, accj, wi, wj, lk, lx);
+  }
+  __syncthreads();  // everybody is done with Ds and C^T
 #pragma unroll
   for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -1117,17 +1201,11 @@ __global__ __launch_bounds__(256) void chol_step_kernel(double* __restrict__ A, 
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int rr = wi + 16 * a + lx, cc = wj + 16 * b + lk + 4 * r;
-        if (jc == 0) {
-          if (i0 + rr < N && cc < nb) A[(long)(i0 + rr) + (long)(k0 + cc) * lda] = acc[a][b][r];  // the final L panel
-        } else {
-          Pi[cc][rr] = acc[a][b][r];
-          if (need_j) Pj[cc][rr] = accj[a][b][r];
-        }
+        B0[cc][rr] = acc[a][b][r];               // Pt_i[k][r]
+        if (need_j) B1[cc][rr] = accj[a][b][r];  // Pt_j[k][c]
       }
-  if (jc == 0) return;
   __syncthreads();
-  mfma_64(Pi, need_j ? Pj : Pi, acc, wi, wj, lk, lx);  // U[r][c] = sum_k P_i[r][k] P_j[c][k]
-  const bool ahead = lookahead && bi == 0 && j == 0;    // tile (k+1, k+1): the next diagonal block
+  mfma_64(B0, need_j ? B1 : B0, acc, wi, wj, lk, lx);  // U[r][c] = sum_k P_i[r][k] P_j[c][k]
   if (!ahead) {
     // the next column block (j == 0) goes to the scratch buffer the next step reads, everything else is updated in place
 #pragma unroll
@@ -1138,7 +1216,7 @@ __global__ __launch_bounds__(256) void chol_step_kernel(double* __restrict__ A, 
         for (int r = 0; r < 4; ++r) {
           const int gi = i0 + wi + 16 * a + lx, cj = wj + 16 * b + lk + 4 * r, gj = j0 + cj;
           if (gi < N && gj < N && gj <= gi) {
-            const double v = A[(long)gi + (long)gj * lda] - acc[a][b][r];
+            const double v = rC[(a * 2 + b) * 4 + r] - acc[a][b][r];
             if (j == 0)
               Cnext[(long)gi + (long)cj * ldc] = v;
             else
@@ -1147,11 +1225,11 @@ __global__ __launch_bounds__(256) void chol_step_kernel(double* __restrict__ A, 
         }
     return;
   }
-  // the updated tile (k+1, k+1) goes straight into the diagonal-block layout: S = Ds's storage, W = Pj's
+  // the updated tile (k+1, k+1) goes straight into the diagonal-block layout: S = B0, W = B1
   const int nb1 = min(NB, N - i0);
-  double (*S)[NB + 1] = Ds;
-  double (*W)[2 * SB + 1] = reinterpret_cast<double (*)[2 * SB + 1]>(step_smem + 2 * NB * (NB + 1));
-  __syncthreads();  // everybody is done reading Pi / Ds
+  double (*S)[NB + 1] = B0;
+  double (*W)[2 * SB + 1] = reinterpret_cast<double (*)[2 * SB + 1]>(step_smem + NB * (NB + 1));
+  __syncthreads();  // everybody is done reading Pt_i
 #pragma unroll
   for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -1160,7 +1238,7 @@ __global__ __launch_bounds__(256) void chol_step_kernel(double* __restrict__ A, 
       for (int r = 0; r < 4; ++r) {
         const int ii = wi + 16 * a + lx, jj = wj + 16 * b + lk + 4 * r;
         double w = (ii == jj && ii >= nb1) ? 1.0 : 0.0;  // rows / columns beyond nb1 (last, partial block): identity
-        if (ii < nb1 && jj < nb1 && jj <= ii) w = A[(long)(i0 + ii) + (long)(i0 + jj) * lda] - acc[a][b][r];
+        if (ii < nb1 && jj < nb1 && jj <= ii) w = rC[(a * 2 + b) * 4 + r] - acc[a][b][r];
         S[ii][jj] = w;
       }
   if (t < NB) S[t][NB] = 0.0;  // (column 64 belongs to the packed inverse)
@@ -1235,7 +1313,10 @@ __global__ __launch_bounds__(256) void syrk_mfma_kernel(double* __restrict__ A, 
     }
     __syncthreads();
   }
-  // D[x][y] = C[row = y][col = x]: lane holds y = lane & 15 (row), x = (lane >> 4) + 4 r (column)
+  // D[x][y] = C[row = y][col = x]: lane holds y = lane & 15 (row), x = (lane >> 4) + 4 r (column).  The 16 elements are LOADED
+  // first (clamped addresses), then updated and stored: written as 16 read-modify-writes the loads cannot move above the stores
+  // to the same array, and each pays its own memory round trip (r3: a third of this kernel's time at K = 512)
+  double cv[16];
 #pragma unroll
   for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -1243,7 +1324,16 @@ __global__ __launch_bounds__(256) void syrk_mfma_kernel(double* __restrict__ A, 
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int gi = i0 + wi + 16 * a + lx, gj = j0 + wj + 16 * b + lk + 4 * r;
-        if (gi < N && gj < N && gj <= gi) A[(long)gi + (long)gj * lda] -= acc[a][b][r];
+        cv[(a * 2 + b) * 4 + r] = A[(long)min(gi, N - 1) + (long)min(gj, N - 1) * lda];
+      }
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int gi = i0 + wi + 16 * a + lx, gj = j0 + wj + 16 * b + lk + 4 * r;
+        if (gi < N && gj < N && gj <= gi) A[(long)gi + (long)gj * lda] = cv[(a * 2 + b) * 4 + r] - acc[a][b][r];
       }
 }
 
@@ -1307,7 +1397,7 @@ void cholesky_factor_two_level(int N, double* A, long lda, double* Linv, long ld
   // beyond ~16 k rows the step kernel's recomputed panels cost more than the look-ahead buys (N = 26 000: 330 vs 299 ms -- the
   // rank-512 updates dominate there and the diagonal chain hides behind nothing anyway): the three-launch schedule
   const bool fused = (fs_env && *fs_env) ? (*fs_env != '0') : (N <= 16384);
-  constexpr size_t kStepSmem = sizeof(double) * 3 * NB * (NB + 1);
+  constexpr size_t kStepSmem = sizeof(double) * 2 * NB * (NB + 1);
   double* cbuf = nullptr;
   const long ldc = ((long)N + 15) / 16 * 16;
   if (fused) {

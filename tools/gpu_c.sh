@@ -1,10 +1,10 @@
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 mkdir -p gpurun_out
-timeout 600 python -m pytest tests/test_gpu_parity.py -q -x -k "two_level or golden_gp or cholesky or add_points or wide_dim" 2>&1 | tail -5 | tee gpurun_out/r03_c_pytest.txt
-for cfg in "0 0" "1 0" "1 1"; do
-  set -- $cfg
-  echo "MOE_CHOL_FUSED_STEP=$1 MOE_CHOL_SYRK_OVERLAP=$2"
-  MOE_CHOL_FUSED_STEP=$1 MOE_CHOL_SYRK_OVERLAP=$2 timeout 300 python tools/chol_time.py 3 2>&1 | grep two-level
+tools/bin/diagbench 2>&1 | tail -3
+timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_abi.py -q -x 2>&1 | tail -5 | tee gpurun_out/r03_c_pytest.txt
+for cfg in "0" "1"; do
+  echo "MOE_CHOL_FUSED_STEP=$cfg"
+  MOE_CHOL_FUSED_STEP=$cfg timeout 300 python tools/chol_time.py 3 2>&1 | grep two-level
 done | tee gpurun_out/r03_c_chol_time.txt
 timeout 300 python tools/chol_time.py 12 2>&1 | grep two-level | tee -a gpurun_out/r03_c_chol_time.txt
 timeout 300 python tools/ll_time.py 2>&1 | tail -8 | tee gpurun_out/r03_c_ll_time.txt
