@@ -1496,7 +1496,10 @@ void launch_cholesky_and_inverse(int N, double* A, long lda, double* Linv, long 
   MOE_HIP_CHECK(hipMemsetAsync(Linv, 0, sizeof(double) * (size_t)ldl * N, s));
   const int nblk = (N + NB - 1) / NB;
   const char* tl_env = std::getenv("MOE_CHOL_TWO_LEVEL_MIN");  // (read per call: tests force the two-level path at small N)
-  const int two_level_min = (tl_env && *tl_env) ? std::atoi(tl_env) : 2048;
+  // r3: 256 (was 2048) -- with one launch per 64-column step and the 25 us diagonal block the two-level schedule also wins at
+  // BO-sized training sets: factor + inverse at N = 1000 0.9 instead of 1.7 ms (one-level: three launches per step and a
+  // 46 us single-wavefront diagonal kernel)
+  const int two_level_min = (tl_env && *tl_env) ? std::atoi(tl_env) : 256;
   if (N >= two_level_min) {
     // (the inversion's workspace is idle during the factorisation: it lends the step kernel its column-block buffers)
     cholesky_factor_two_level(N, A, lda, Linv, ldl, info, s,
@@ -1623,8 +1626,10 @@ void launch_cholesky_batch(int N, double* A, long lda, long a_stride, double* Li
     // large matrices (the log likelihood at C5's N = 8000): the two-level factorisation with its look-ahead schedule, one matrix
     // after the other -- a single factorisation fills the chip there, and the one-level batch kernels below are 125 steps of a
     // 150 us register-resident diagonal kernel
+    // (a single BO-sized matrix too: 0.65 instead of 1.38 ms at N = 1000; batches keep the one-level kernels, whose every
+    //  launch covers the whole batch -- 0.05 ms per set in calls of 64)
     const char* tl_env = std::getenv("MOE_CHOL_TWO_LEVEL_MIN");
-    const int two_level_min = (tl_env && *tl_env) ? std::atoi(tl_env) : 2048;
+    const int two_level_min = (tl_env && *tl_env) ? std::atoi(tl_env) : (batch == 1 ? 256 : 2048);
     if (N >= two_level_min) {
       for (int b = 0; b < batch; ++b)
         cholesky_factor_two_level(N, A + (size_t)b * a_stride, lda, Linv + (size_t)b * l_stride, ldl, info + b, s, scratch);

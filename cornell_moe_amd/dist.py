@@ -171,21 +171,29 @@ class Comm(object):
 
 
 def _preflight_child():
-    """The body of the throw-away child: RCCL bring-up + one checked all_reduce.  Exit code 0 = RCCL works for this rank."""
+    """The body of the throw-away child: RCCL bring-up + one checked all_reduce.  Exit code 0 = RCCL works for this rank.
+    (MOE_DIST_DATA_BACKEND=gloo -- a test hook -- runs the same steps on gloo / host tensors, so that the whole success path of
+    bring_up can be exercised on a box without GPUs.)"""
     import datetime
     import os
     import sys
     import torch
     import torch.distributed as dist
     rank, world, local = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"]), int(os.environ.get("LOCAL_RANK", "0"))
-    if not torch.cuda.is_available() or torch.cuda.device_count() <= local:
-        sys.exit(3)
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
-    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev, timeout=datetime.timedelta(seconds=60))
+    backend = os.environ.get("MOE_DIST_DATA_BACKEND", "nccl")
+    if backend == "nccl":
+        if not torch.cuda.is_available() or torch.cuda.device_count() <= local:
+            sys.exit(3)
+        torch.cuda.set_device(local)
+        dev = torch.device("cuda", local)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev, timeout=datetime.timedelta(seconds=60))
+    else:
+        dev = torch.device("cpu")
+        dist.init_process_group(backend, rank=rank, world_size=world, timeout=datetime.timedelta(seconds=60))
     t = torch.full((1,), float(rank + 1), dtype=torch.float64, device=dev)
     dist.all_reduce(t)
-    torch.cuda.synchronize()
+    if backend == "nccl":
+        torch.cuda.synchronize()
     ok = abs(float(t.item()) - world * (world + 1) / 2.0) < 1e-12
     dist.destroy_process_group()
     sys.exit(0 if ok else 4)
@@ -198,7 +206,20 @@ def _free_port():
         return sk.getsockname()[1]
 
 
-def bring_up(rank, world, local_rank, prefer="nccl", timeout_s=60.0, log=None):
+def preflight_env(port):
+    """Environment of the pre-flight child: this rank's RANK / LOCAL_RANK / WORLD_SIZE, its OWN rendezvous port, and none of the
+    launcher's TORCHELASTIC_* variables -- with TORCHELASTIC_USE_AGENT_STORE=True (what torch.distributed.run sets) env://
+    initialisation connects to the launcher's store at MASTER_PORT as a client instead of starting one, and the children, whose
+    port nobody serves, would wait for it until they time out."""
+    import os
+    env = {k: v for k, v in os.environ.items() if not k.startswith("TORCHELASTIC_")}
+    env["MASTER_ADDR"] = os.environ.get("MASTER_ADDR", "127.0.0.1")
+    env["MASTER_PORT"] = str(port)
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return env
+
+
+def bring_up(rank, world, local_rank, prefer="nccl", timeout_s=150.0, log=None):
     """Default (control) group on gloo, data group on `prefer` when its pre-flight passes on EVERY rank; see the block comment."""
     import datetime
     import os
@@ -219,11 +240,9 @@ def bring_up(rank, world, local_rank, prefer="nccl", timeout_s=60.0, log=None):
     t0 = time.time()
     port = [_free_port() if rank == 0 else 0]
     dist.broadcast_object_list(port, src=0)
-    env = dict(os.environ, MASTER_PORT=str(port[0]), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
-    env.pop("TORCHELASTIC_RUN_ID", None)
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    child = subprocess.Popen([sys.executable, "-m", "cornell_moe_amd.dist", "--preflight"], env=env, cwd=root,
-                             stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, universal_newlines=True)
+    child = subprocess.Popen([sys.executable, "-m", "cornell_moe_amd.dist", "--preflight"], env=preflight_env(port[0]),
+                             cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), stdout=subprocess.DEVNULL,
+                             stderr=subprocess.PIPE, universal_newlines=True)
     why = None
     try:
         _, err = child.communicate(timeout=timeout_s)
@@ -242,6 +261,13 @@ def bring_up(rank, world, local_rank, prefer="nccl", timeout_s=60.0, log=None):
         reason = next((w for w in whys if w), "rccl pre-flight failed")
         log("RCCL NOT USED -- %s; collectives run on gloo (host tensors)" % reason)
         return Comm(rank, world, "gloo", None, None, reason, took)
+    data_backend = os.environ.get("MOE_DIST_DATA_BACKEND", "nccl")  # (test hook, see _preflight_child)
+    if data_backend != "nccl":
+        grp = dist.new_group(backend=data_backend, timeout=datetime.timedelta(seconds=120))
+        t = torch.ones(1, dtype=torch.float64)
+        dist.all_reduce(t, group=grp)
+        assert abs(float(t.item()) - world) < 1e-12
+        return Comm(rank, world, data_backend + " (test hook)", grp, None, None, took)
     dev = torch.device("cuda", local_rank)
     try:
         grp = dist.new_group(backend="nccl", timeout=datetime.timedelta(seconds=120), device_id=dev)

@@ -59,3 +59,22 @@ def test_bench_default_step_is_the_c4_job():
     out, _ = _run({"MOE_BENCH_BACKEND": "gloo"}, "--no-mc-shard", "--no-batch1")
     assert out["config"]["evals_per_step"] == 64 and out["config"]["evals_per_gpu_per_step"] == 32 and out["scaling"] == "strong"
     assert out["determinism"]["ok"] and out["determinism"]["restarts"] == 64
+
+
+def test_rccl_preflight_child_passes_under_a_launcher_environment():
+    """The pre-flight child of dist.bring_up as a rank would start it UNDER torch.distributed.run -- TORCHELASTIC_* variables set,
+    its own rendezvous port -- with the one GPU of the test box as a world of 1: RCCL bring-up, one checked all_reduce, exit 0.
+    (With TORCHELASTIC_USE_AGENT_STORE inherited the child would look for the launcher's store on a port nobody serves.)"""
+    from cornell_moe_amd import dist as mdist
+    saved = dict(os.environ)
+    try:
+        os.environ.update(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="1",
+                          TORCHELASTIC_USE_AGENT_STORE="True", TORCHELASTIC_RUN_ID="none", TORCHELASTIC_MAX_RESTARTS="0")
+        env = mdist.preflight_env(mdist._free_port())
+    finally:
+        os.environ.clear()
+        os.environ.update(saved)
+    assert not any(k.startswith("TORCHELASTIC_") for k in env) and env["MASTER_PORT"] != "1"
+    res = subprocess.run([sys.executable, "-m", "cornell_moe_amd.dist", "--preflight"], env=env, cwd=ROOT, stdout=subprocess.PIPE,
+                         stderr=subprocess.PIPE, universal_newlines=True, timeout=300)
+    assert res.returncode == 0, res.stderr[-2000:]

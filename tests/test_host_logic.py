@@ -208,3 +208,38 @@ def test_bring_up_falls_back_to_gloo_when_rccl_preflight_fails():
         assert backend == "gloo" and rccl == 0 and "pre-flight" in fallback
         assert kg == [1.0, 2.0, 3.0, 4.0] and mx == 2.0 and gathered == [[0.0], [10.0]]
         assert any("RCCL NOT USED" in m for m in msgs)
+
+
+def test_bring_up_success_path_under_torch_distributed_run(tmp_path):
+    """The SUCCESS path of dist.bring_up the way the driver runs it -- two ranks started by torch.distributed.run (which sets
+    TORCHELASTIC_USE_AGENT_STORE=True: the pre-flight children must not look for the launcher's store on their own port), the
+    pre-flight children rendezvous among themselves, every rank agrees, the data group is created next to the gloo control group
+    and carries the measurement's collectives.  On this box the data plane is gloo (MOE_DIST_DATA_BACKEND, a test hook); the
+    steps are the ones RCCL takes."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "standin.py"
+    out = tmp_path / "out.txt"
+    script.write_text('''
+import os, sys
+sys.path.insert(0, %r)
+import numpy as np
+from cornell_moe_amd import dist as mdist
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+assert os.environ.get("TORCHELASTIC_USE_AGENT_STORE") == "True"
+msgs = []
+comm = mdist.bring_up(rank, world, int(os.environ["LOCAL_RANK"]), prefer="nccl", timeout_s=120.0, log=msgs.append)
+idx = mdist.shard_restarts(4, rank, world)
+kg, grad = mdist.gather_restarts(idx, [1.0 + i for i in idx], np.ones((len(idx), 1, 2)) * (rank + 1), 4, group=comm.group, device=comm.device)
+mx = comm.max_over_ranks(rank + 1.0)
+if rank == 0:
+    open(sys.argv[1], "w").write("%%s|%%s|%%s|%%g|%%d" %% (comm.backend, comm.fallback, kg.tolist(), mx, len(msgs)))
+comm.close()
+''' % root)
+    env = dict(os.environ, MOE_DIST_DATA_BACKEND="gloo")
+    code = subprocess.call([sys.executable, "-c",
+                            "import sys; sys.path.insert(0, %r); import bench; sys.exit(bench.self_launch([%r], 2, script=%r))"
+                            % (root, str(out), str(script))], env=env, timeout=600)
+    assert code == 0
+    assert out.read_text() == "gloo (test hook)|None|[1.0, 2.0, 3.0, 4.0]|2|0"
