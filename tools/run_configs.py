@@ -64,6 +64,16 @@ c2 = {"gpu_ei_grad_evals_per_s": 1.0 / t, "gpu_ms_per_eval": 1e3 * t}
 Xq64 = np.random.default_rng(2).uniform(0.05, 0.95, size=(64,) + w.Xq.shape)
 tb = timeit(lambda: G.ei_batch(Xq64, None, w.M, best, w.ei_normals), reps=10)
 c2["gpu_batch_64_evals_per_s"] = 64.0 / tb
+# SURVEY 8(d)'s roofline entry for q-EI: M (u^2 + 2u + 2 q d u) flops over 8 [M u + d u^2 q] bytes per evaluation -- 40 kflop and
+# 16 KB at C2: the evaluation is launch / sync latency (one sample per lane, 4 workgroups), so the fraction says how far a
+# latency-bound call is from either roof, nothing about the kernel
+u_, q_, d_ = w.q, w.q, w.d
+fl = w.M * (u_ * u_ + 2 * u_ + 2 * q_ * d_ * u_)
+by = 8.0 * (w.M * u_ + d_ * u_ * u_ * q_)
+c2["roofline"] = {"bound": "hbm", "algorithmic_bytes_per_eval": by, "algorithmic_flops_per_eval": fl,
+                  "achieved_GB_per_s_batch64": by * 64.0 / tb / 1e9, "frac_of_8TBs_batch64": by * 64.0 / tb / 8e12,
+                  "achieved_GFLOP_per_s_batch64": fl * 64.0 / tb / 1e9,
+                  "note": "latency-bound: 16 KB and 40 kflop per evaluation; one at a time %.0f us per call" % (1e6 * t)}
 if HAVE_REF:
     R = ref.RefGP(1, w.alpha, w.lengths, w.X, w.y, w.noise, ())
     tr = timeit(lambda: R.ei(w.Xq, None, w.M, best, w.ei_normals), reps=5)
@@ -113,7 +123,11 @@ del GM
 w = make_workload("C5")
 t0 = time.perf_counter()
 G = DeviceGP(w.hyperparameters, w.X, w.y, w.noise, w.derivs)
-c5 = {"gpu_build_s_N8000": time.perf_counter() - t0}
+c5 = {"gpu_build_s_N8000_first": time.perf_counter() - t0}
+del G
+t0 = time.perf_counter()
+G = DeviceGP(w.hyperparameters, w.X, w.y, w.noise, w.derivs)
+c5["gpu_build_s_N8000"] = time.perf_counter() - t0
 best = float(G.additional_mean(w.discrete).min())
 t = timeit(lambda: G.kg(w.inner_gd, w.bounds, w.discrete, w.Xq, None, w.M, best, w.kg_normals), reps=2)
 c5["gpu_dkg_grad_evals_per_s"] = 1.0 / t
@@ -147,4 +161,10 @@ if HAVE_REF:
     ref.log_likelihood(1, w.alpha, w.lengths, w.X, w.y, w.noise, [])
     ll["ref_1core_ms_per_set"] = 1e3 * (time.perf_counter() - t0)
 out["log_likelihood_n1000"] = ll
+w = make_workload("C5")
+LL = LogLikelihood(w.X, w.y, w.derivs)
+th = np.r_[w.hyperparameters, w.noise]
+LL.evaluate(th[None])
+out["log_likelihood_N8000"] = {"ms_per_set": 1e3 * timeit(lambda: LL.evaluate(th[None]), reps=3),
+                               "grad_ms_per_set": 1e3 * timeit(lambda: LL.grad(th), reps=2)}
 print(json.dumps(out, indent=1))
