@@ -269,10 +269,19 @@ def bring_up(rank, world, local_rank, prefer="nccl", timeout_s=150.0, log=None):
         assert abs(float(t.item()) - world) < 1e-12
         return Comm(rank, world, data_backend + " (test hook)", grp, None, None, took)
     dev = torch.device("cuda", local_rank)
-    try:
-        grp = dist.new_group(backend="nccl", timeout=datetime.timedelta(seconds=120), device_id=dev)
-    except TypeError:  # older signature without device_id
-        grp = dist.new_group(backend="nccl", timeout=datetime.timedelta(seconds=120))
+    grp, err = None, None
+    for kwargs in (dict(device_id=dev), dict()):  # (an API-level refusal of device_id is the same on every rank: retry without)
+        try:
+            grp = dist.new_group(backend="nccl", timeout=datetime.timedelta(seconds=120), **kwargs)
+            break
+        except Exception as e:  # noqa: BLE001
+            err = "%s: %s" % (type(e).__name__, e)
+    flag = torch.tensor([1.0 if grp is not None else 0.0], dtype=torch.float64)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    if float(flag.item()) < 0.5:
+        reason = "rccl group creation failed after a passing pre-flight (%s)" % err
+        log("RCCL NOT USED -- %s; collectives run on gloo (host tensors)" % reason)
+        return Comm(rank, world, "gloo", None, None, reason, took)
     t = torch.ones(1, dtype=torch.float64, device=dev)
     dist.all_reduce(t, group=grp)
     torch.cuda.synchronize()
