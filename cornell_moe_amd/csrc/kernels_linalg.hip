@@ -473,14 +473,14 @@ __global__ __launch_bounds__(64) void chol_diag_kernel(double* __restrict__ A, l
 // One workgroup per 64 panel rows; both operands staged in LDS, 4 x 4 outputs per thread.
 __global__ __launch_bounds__(256) void chol_panel_kernel(double* __restrict__ A, long lda, const double* __restrict__ Linv,
                                                         long ldl, int N, int k0, int nb, const int* __restrict__ info,
-                                                        long a_stride = 0, long l_stride = 0, int rb0 = 0) {
+                                                        long a_stride = 0, long l_stride = 0) {
   __shared__ double D[NB][NB + 1];   // D[j][c] = Linv_kk[c][j]
   __shared__ double At[NB][NB + 1];  // At[j][i] = A[i0 + i][k0 + j]
   A += (long)blockIdx.z * a_stride;
   Linv += (long)blockIdx.z * l_stride;
   info += blockIdx.z;
   if (*info != 0) return;
-  const int i0 = k0 + nb + (blockIdx.x + rb0) * NB;  // (rb0: first row block of this launch -- the look-ahead schedule splits the panel)
+  const int i0 = k0 + nb + blockIdx.x * NB;
   for (int t = threadIdx.x; t < NB * NB; t += 256) {
     const int r = t % NB, c = t / NB;  // r walks rows (contiguous in memory)
     D[c][r] = (r < nb && c < nb) ? Linv[(long)(k0 + r) + (long)(k0 + c) * ldl] : 0.0;  // D[c][r] = Linv[r][c]
@@ -516,14 +516,13 @@ __global__ __launch_bounds__(256) void chol_panel_kernel(double* __restrict__ A,
 
 // Trailing update: A[i][j] -= sum_c L[i][c] L[j][c], c over the panel, for 64 x 64 tiles with tile-row >= tile-col.
 __global__ __launch_bounds__(256) void chol_update_kernel(double* __restrict__ A, long lda, int N, int k0, int nb,
-                                                         const int* __restrict__ info, long a_stride = 0, int skip00 = 0) {
+                                                         const int* __restrict__ info, long a_stride = 0) {
   __shared__ double Ls_i[TK][NB + 1];
   __shared__ double Ls_j[TK][NB + 1];
   A += (long)blockIdx.z * a_stride;
   info += blockIdx.z;
   if (*info != 0) return;
   if (blockIdx.y > blockIdx.x) return;
-  if (skip00 && blockIdx.x == 0 && blockIdx.y == 0) return;  // (the look-ahead schedule updates that tile ahead of the rest)
   const int base = k0 + nb;
   const int i0 = base + blockIdx.x * NB, j0 = base + blockIdx.y * NB;
   const int tx = threadIdx.x % 16, ty = threadIdx.x / 16;
