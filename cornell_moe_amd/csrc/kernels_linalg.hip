@@ -9,7 +9,6 @@
 //    (gpp_linear_algebra.cpp:109-148) and turns every TriangularMatrixVectorSolve (:160-187) of the reference into a
 //    GEMM against L^-1, which is what lets the posterior solves run wide instead of as 1000 dependent steps.
 #include <cstdlib>
-#include <unordered_map>
 
 #include "kernels.hpp"
 
@@ -877,6 +876,8 @@ __device__ __forceinline__ void diag_factor(double (*S)[NB + 1], double (*W)[2 *
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   int& s_bad = *s_bad_p;
   double* Rd = &W[32][0];  // 1 / L[k][k], k < 64 (rows 32 .. 33 of the scratch; rows 0 .. 31 hold diag_invert's product block)
+  volatile __attribute__((address_space(3))) double* Lc =
+      (volatile __attribute__((address_space(3))) double*)&W[36][0];  // the current pivot column, 64 entries (rows 36 .. 37)
 #if defined(MOE_DIAG_PROF)
   unsigned long long diag_last_ = 0;
 #endif
@@ -889,26 +890,48 @@ __device__ __forceinline__ void diag_factor(double (*S)[NB + 1], double (*W)[2 *
 #pragma unroll
       for (int c = 0; c < SB; ++c) a[c] = S[ri][s0 + c];  // (rows above s0 and entries above the diagonal: loaded, never used)
       int bad = 0;
+      // rank-1 updates are applied ONE PIVOT LATE, except to the next pivot's own column: a[j] -= L[i][k] L[s0 + j][k] needs the
+      // second factor from lane s0 + j.  For j = k + 1 it is fetched with v_readlane and applied at once (it feeds the next pivot:
+      // the critical path); for j >= k + 2 every lane writes its L[i][k] to an LDS column, the factors come back as broadcast
+      // reads (off the vector ALU: with two v_readlane per factor and the scalar-register spills they caused, the loop was ~90 VALU
+      // instructions per pivot on ONE wavefront, issue-bound), and the fmas that consume them sit in the NEXT pivot's iteration,
+      // in the shadow of its square-root chain -- applied in place they either wait for the LDS round trip or, sunk by the
+      // scheduler to their first use, pile up to k dependent fmas in front of pivot k.
+      double p_lik = 0.0, p_ljk[SB];
+#pragma unroll
+      for (int j = 0; j < SB; ++j) p_ljk[j] = 0.0;
 #pragma unroll
       for (int k = 0; k < SB; ++k) {
         const double piv = readlane_f64(a[k], s0 + k);
         if (bad == 0 && !(piv > 1.0e-16)) bad = k0 + s0 + k + 1;  // gpp_linear_algebra.cpp:118
-        const double ps = fmax(piv, 1.0e-300);  // (a failed pivot is reported above; keep the arithmetic finite)
-        double r = __builtin_amdgcn_rsq(ps);
-        r = r * fma(-0.5 * ps * r, r, 1.5);  // Newton: r (3 - ps r^2) / 2
-        r = r * fma(-0.5 * ps * r, r, 1.5);
-        double lkk = ps * r;
-        lkk = fma(fma(-lkk, lkk, ps), 0.5 * r, lkk);  // Heron correction of sqrt(ps)
+        const double ps = piv;  // (a failed pivot is reported above; what follows it -- NaN, inf -- is never written back)
+        // sqrt and reciprocal sqrt TOGETHER (the coupled iteration of fastmath.hpp's sqrt_pos): g -> sqrt(ps), h -> 1 / (2 sqrt(ps)),
+        // one step on both from the v_rsq_f64 seed (2^-22 -> 2^-44), then the Heron correction makes lkk the correctly rounded
+        // square root.  r = 2 h is good to 2^-44, which is all the divisions below need: each is followed by its residual
+        // correction against lkk.
+        const double y = __builtin_amdgcn_rsq(ps);
+        // (the previous pivot's deferred updates: independent of the chain above / below)
+#pragma unroll
+        for (int j = k + 1; j < SB; ++j) a[j] = a[j] - p_lik * p_ljk[j];
+        double g = ps * y, h = 0.5 * y;
+        const double e = fma(-h, g, 0.5);
+        g = fma(g, e, g);
+        h = fma(h, e, h);
+        const double lkk = fma(fma(-g, g, ps), h, g);
+        const double r = h + h;
         if (lane == 0) Rd[s0 + k] = r;
         double q = a[k] * r;
         q = fma(fma(-q, lkk, a[k]), r, q);  // residual correction of a / lkk
         const double lik = (ri == s0 + k) ? lkk : q;
         a[k] = lik;
-#pragma unroll
-        for (int j = k + 1; j < SB; ++j) {
-          const double ljk = readlane_f64(lik, s0 + j);  // L[s0 + j][s0 + k] lives in lane s0 + j
-          a[j] = a[j] - lik * ljk;                       // (rows above s0 + j compute unused upper-triangle values)
+        Lc[ri] = lik;
+        if (k + 1 < SB) {
+          const double ljk = readlane_f64(q, s0 + k + 1);  // (lane s0 + k + 1 is below the diagonal: its lik IS its q)
+          a[k + 1 < SB ? k + 1 : k] = a[k + 1 < SB ? k + 1 : k] - lik * ljk;
         }
+        p_lik = lik;
+#pragma unroll
+        for (int j = 0; j < SB; ++j) p_ljk[j] = (j >= k + 2) ? Lc[s0 + (j >= k + 2 ? j : 0)] : 0.0;  // (this pivot's column, in order)
       }
       if (ri >= s0) {
 #pragma unroll
@@ -1102,9 +1125,11 @@ __device__ __forceinline__ void mfma_64(const double (*As)[NB + 1], const double
 // the unsolved column block k0 (rows below its diagonal block) into the scratch buffer: the start of an outer block
 __global__ __launch_bounds__(256) void chol_colcopy_kernel(const double* __restrict__ A, long lda, int N, int k0, int nb,
                                                           double* __restrict__ C, long ldc) {
+  // grid (row chunks, nb columns): one element per thread (a thread walking its row's 64 columns was 64 dependent strided
+  // round trips: 20 us for 4 MB)
   const long r = (long)k0 + nb + (long)blockIdx.x * 256 + threadIdx.x;
-  if (r >= N) return;
-  for (int c = 0; c < nb; ++c) C[r + (long)c * ldc] = A[r + (long)(k0 + c) * lda];
+  const int c = blockIdx.y;
+  if (r < N) C[r + (long)c * ldc] = A[r + (long)(k0 + c) * lda];
 }
 
 __global__ __launch_bounds__(256) void chol_step_kernel(double* __restrict__ A, long lda, double* __restrict__ Linv, long ldl, int N,
@@ -1409,33 +1434,18 @@ void cholesky_factor_two_level(int N, double* A, long lda, double* Linv, long ld
     cbuf = scratch;
     if (cbuf == nullptr) MOE_HIP_CHECK(hipMallocAsync(reinterpret_cast<void**>(&cbuf), sizeof(double) * (size_t)2 * ldc * NB, s));
   }
-  // The rank-512 update of outer block o is issued in two parts: the columns of the NEXT outer block on `s` (the inner steps need
-  // them), everything to their right on a second stream, where it overlaps those inner steps -- a latency-bound chain of
-  // ~60 us launches that leaves most of the chip idle.  Per tile the updates still arrive in outer-block order (part two of
-  // block o-1 and part one of block o touch the same tiles: an event orders them), so the factor is bit-identical to the
-  // one-stream schedule (MOE_CHOL_SYRK_OVERLAP=0).  Two events per outer block -- not the per-step event traffic that made
-  // round 2's two-stream look-ahead slower than in-order.
-  struct Aux {
-    hipStream_t sb = nullptr;
-    hipEvent_t e_panel = nullptr, e_rest = nullptr;
+  // (Measured and not kept in this round, both bit-identical to the one-stream order: the far columns of the rank-512 update on a
+  //  second, low-priority stream next to the inner steps -- 19.45 -> 19.2 ms at N = 8000, within the noise: the bulk update's
+  //  workgroups take the CUs the diagonal chain needs; and the next outer block's first diagonal kernel + column copy on a second
+  //  stream next to the far columns of the update -- 15.58 vs 15.77 ms: the 320-VGPR diagonal workgroup finds no CU to start on
+  //  until the update drains.  profiles/r03_c2_chol_overlap.txt, r03_k_chol_time.txt.)
+  auto diag_and_copy = [&](int k0, hipStream_t st, int buf) {  // the start of an outer block
+    const int nb = std::min(NB, N - k0), below = N - k0 - nb;
+    hipLaunchKernelGGL(chol_diag_lds_kernel, dim3(1), dim3(256), 0, st, A, lda, Linv, ldl, k0, nb, info);
+    if (fused && below > 0)
+      hipLaunchKernelGGL(chol_colcopy_kernel, dim3((below + 255) / 256, nb), dim3(256), 0, st, (const double*)A, lda, N, k0, nb,
+                         cbuf + (size_t)buf * ldc * NB, ldc);
   };
-  static thread_local std::unordered_map<hipStream_t, Aux> aux_cache;  // (streams are long-lived: one per GP handle)
-  const char* ov_env = std::getenv("MOE_CHOL_SYRK_OVERLAP");
-  const bool overlap = fused && (ov_env && *ov_env == '1') && N > 2 * kOuter;  // OFF by default: measured 19.45 -> 19.2 ms at N = 8000, within the noise -- the bulk update's workgroups take the CUs the chain needs (profiles/r03_c_chol_time.txt)
-  Aux aux;
-  if (overlap) {
-    Aux& a = aux_cache[s];
-    if (a.sb == nullptr) {
-      // (lowest priority: the chain on `s` must get its workgroups placed ahead of the bulk update's ~1 800)
-      int prio_lo = 0, prio_hi = 0;
-      MOE_HIP_CHECK(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
-      MOE_HIP_CHECK(hipStreamCreateWithPriority(&a.sb, hipStreamNonBlocking, prio_lo));
-      MOE_HIP_CHECK(hipEventCreateWithFlags(&a.e_panel, hipEventDisableTiming));
-      MOE_HIP_CHECK(hipEventCreateWithFlags(&a.e_rest, hipEventDisableTiming));
-    }
-    aux = a;
-  }
-  bool rest_pending = false;
   int cur = 0;
   for (int ko = 0; ko < N; ko += kOuter) {
     const int wo = std::min(kOuter, N - ko);
@@ -1443,12 +1453,7 @@ void cholesky_factor_two_level(int N, double* A, long lda, double* Linv, long ld
     for (int k0 = ko; k0 < ko + wo; k0 += NB) {
       const int nb = std::min(NB, N - k0);
       const int below = N - k0 - nb;
-      if (!ahead_done) {
-        hipLaunchKernelGGL(chol_diag_lds_kernel, dim3(1), dim3(256), 0, s, A, lda, Linv, ldl, k0, nb, info);
-        if (fused && below > 0)
-          hipLaunchKernelGGL(chol_colcopy_kernel, dim3((below + 255) / 256), dim3(256), 0, s, (const double*)A, lda, N, k0, nb,
-                             cbuf + (size_t)cur * ldc * NB, ldc);
-      }
+      if (!ahead_done) diag_and_copy(k0, s, cur);
       ahead_done = false;
       if (below <= 0) continue;
       const int tb = (below + NB - 1) / NB;
@@ -1469,22 +1474,9 @@ void cholesky_factor_two_level(int N, double* A, long lda, double* Linv, long ld
     const int trailing = N - (ko + wo);
     if (trailing > 0) {
       const int tt = (trailing + 63) / 64;
-      const int first = std::min(tt, kOuter / 64);  // column tiles of the next outer block
-      if (!overlap || tt <= first) {
-        hipLaunchKernelGGL(syrk_mfma_kernel, dim3(tt, tt), dim3(256), 0, s, A, lda, N, ko + wo, ko, wo, (const int*)info);
-      } else {
-        MOE_HIP_CHECK(hipEventRecord(aux.e_panel, s));                          // the panel of this outer block is final
-        if (rest_pending) MOE_HIP_CHECK(hipStreamWaitEvent(s, aux.e_rest, 0));  // part two of the previous block wrote these tiles
-        hipLaunchKernelGGL(syrk_mfma_kernel, dim3(first, tt), dim3(256), 0, s, A, lda, N, ko + wo, ko, wo, (const int*)info, 0);
-        MOE_HIP_CHECK(hipStreamWaitEvent(aux.sb, aux.e_panel, 0));
-        hipLaunchKernelGGL(syrk_mfma_kernel, dim3(tt - first, tt), dim3(256), 0, aux.sb, A, lda, N, ko + wo, ko, wo,
-                           (const int*)info, first);
-        MOE_HIP_CHECK(hipEventRecord(aux.e_rest, aux.sb));
-        rest_pending = true;
-      }
+      hipLaunchKernelGGL(syrk_mfma_kernel, dim3(tt, tt), dim3(256), 0, s, A, lda, N, ko + wo, ko, wo, (const int*)info, 0);
     }
   }
-  if (rest_pending) MOE_HIP_CHECK(hipStreamWaitEvent(s, aux.e_rest, 0));
   MOE_HIP_CHECK(hipGetLastError());
   if (cbuf != nullptr && scratch == nullptr) MOE_HIP_CHECK(hipFreeAsync(cbuf, s));
 }
