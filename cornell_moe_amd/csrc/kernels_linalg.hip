@@ -164,18 +164,27 @@ __global__ __launch_bounds__(256) void mfma_gemm_kernel(int M, int Ncols, int K,
     C += (long)blockIdx.z * ldc * Ncols;
   }
   const int R = (M + TM - 1) / TM;
-  const int j0 = blockIdx.x * TN;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int wi = (wave & 1) * 32, wj = (wave >> 1) * 32;  // this wavefront's quadrant
   const int lk = lane >> 4, lx = lane & 15;
+  // pair_rows == 2 (MODE 3, r3): the triangular operand is B, whose K range shrinks with the COLUMN tile -- a workgroup does column
+  // tile p and its mirror Ct - 1 - p (grid.x = ceil(Ct / 2)): the same balance for the L21 X11 product of the triangular inversion
+  // (34 -> 45 TFLOP/s at the top level, where it is a third of the inversion's time)
+  const bool pair_cols = MODE == 3 && pair_rows == 2;
+  const int Ct = (Ncols + TN - 1) / TN;
   for (int half = 0; half < (pair_rows ? 2 : 1); ++half) {
-    int bx;
-    if (pair_rows) {
+    int bx, jt = blockIdx.x;
+    if (pair_cols) {
+      bx = (int)(((long)blockIdx.y * xmul) % gridDim.y);
+      jt = half == 0 ? (int)blockIdx.x : Ct - 1 - (int)blockIdx.x;
+      if (half == 1 && jt == (int)blockIdx.x) break;
+    } else if (pair_rows) {
       bx = half == 0 ? (int)blockIdx.y : R - 1 - (int)blockIdx.y;
       if (half == 1 && bx == (int)blockIdx.y) break;  // odd tile count: the middle tile has no mirror
     } else {
       bx = (int)(((long)blockIdx.y * xmul) % gridDim.y);
     }
+    const int j0 = jt * TN;
     const int i0 = bx * TM;
     int k_lo = 0, k_hi = K;
     if (MODE == 1) k_hi = min(K, i0 + TM);
@@ -1381,9 +1390,10 @@ void trtri_levels(const double* L, long lda, double* Linv, long ldl, int N, doub
         break;
       }
     // work_k (rows x B) = L21 X11   (X11 lower triangular: MODE 3)
-    hipLaunchKernelGGL((mfma_gemm_kernel<3, false, 16>), dim3(ct, rt, nn), dim3(256), 0, s, rows_max, (int)B, (int)B, L + B, lda,
-                       (const double*)Linv, ldl, work, ldw, xmul, 0, 2 * B * (1 + lda), 2 * B * (1 + ldl), ldw * B, (int)(N - B),
-                       (int)(2 * B));
+    const int pairc = (ct >= 16) ? 2 : 0;  // (column pairing: see mfma_gemm_kernel)
+    hipLaunchKernelGGL((mfma_gemm_kernel<3, false, 16>), dim3(pairc ? (ct + 1) / 2 : ct, rt, nn), dim3(256), 0, s, rows_max, (int)B,
+                       (int)B, L + B, lda, (const double*)Linv, ldl, work, ldw, xmul, pairc, 2 * B * (1 + lda), 2 * B * (1 + ldl),
+                       ldw * B, (int)(N - B), (int)(2 * B));
     // X21 = -X22 work_k   (X22 lower triangular: MODE 1, negated).  A single big node (the top levels) pairs row tile p with its
     // mirror so that every workgroup walks the same number of K steps (see mfma_gemm_kernel).
     const int pair = (nn == 1 && rt >= 16) ? 1 : 0;
