@@ -8,6 +8,7 @@
 #include <cmath>
 #include <cstring>
 
+#include "device_cov.hpp"
 #include "kg.hpp"
 
 namespace moe {
@@ -95,21 +96,202 @@ __global__ __launch_bounds__(256) void ei_mc_kernel(EiParams P) {
 
 __global__ __launch_bounds__(256) void sum_partials_kernel(const double* __restrict__ partial, int num_blocks, int ncomp,
                                                           double* __restrict__ out) {
+  // one workgroup per evaluation; component c is summed by the 256 / ncomp' lanes that share c = lane % ncomp' (block order within a
+  // lane, then a fixed-order tree over the lanes of the component): one pass and one barrier round instead of ncomp of them
   __shared__ double red[256];
-  partial += (long)blockIdx.x * num_blocks * ncomp;  // one workgroup per evaluation
+  partial += (long)blockIdx.x * num_blocks * ncomp;
   out += (long)blockIdx.x * ncomp;
-  for (int comp = 0; comp < ncomp; ++comp) {
+  for (int c0 = 0; c0 < ncomp; c0 += 256) {
+    const int nc = min(256, ncomp - c0);              // components of this round
+    int stride = 1;
+    while (stride * 2 * nc <= 256) stride *= 2;        // lanes per component (a power of two)
+    const int comp = threadIdx.x % nc, part = threadIdx.x / nc;
     double acc = 0.0;
-    for (int b = threadIdx.x; b < num_blocks; b += 256) acc += partial[(long)b * ncomp + comp];
+    if (part < stride)
+      for (int b = part; b < num_blocks; b += stride) acc += partial[(long)b * ncomp + c0 + comp];
     red[threadIdx.x] = acc;
     __syncthreads();
-    for (int off = 128; off > 0; off >>= 1) {
-      if (threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+    for (int off = stride / 2; off > 0; off >>= 1) {
+      if (part < off) red[threadIdx.x] += red[threadIdx.x + off * nc];
       __syncthreads();
     }
-    if (threadIdx.x == 0) out[comp] = red[0];
+    if (part == 0 && threadIdx.x < nc) out[c0 + comp] = red[threadIdx.x];
     __syncthreads();
   }
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The u x u algebra of an EI evaluation ON THE DEVICE (r3): what ei_evaluate_batch did on the host between two stream syncs --
+// mean, Var + 1e-6 I, its Cholesky factor, grad mean, Smith's derivative of the factor (host_math.hip: host_mean, host_variance,
+// host_cholesky, host_grad_mean, host_grad_cholesky_per_point; EI points carry no derivative observations) -- from the Gram
+// matrix and E^T K^-1 y the state kernels leave in device memory, straight into the record the MC kernel reads.  One wavefront
+// per evaluation; lane = row for the factorisation, lane = dimension for the factor's derivative (every dimension is an
+// independent Smith recursion).  An evaluation then needs ONE sync and no mid-way round trip through the host.  The same
+// formulas as the host code with the device's exp / sqrt, whose results differ from libm's in the last bit: EI agrees with the
+// host-algebra path (MOE_EI_DEVICE_ALGEBRA=0) to ~1e-15 (tests/test_gpu_parity.py).  What it buys at C2, one evaluation at a time:
+// value only 80 -> 71 us, value + gradient 93 -> 93 (profiles/r03_n_latency.txt) -- a kernel trace shows why it is not more: the
+// GPU is busy for the whole call, nine back-to-back kernels of 3 - 18 us each (the 500 x 500 triangular product alone 18), so
+// the call is bound by the small kernels' own latencies, not by launches or syncs.
+// ---------------------------------------------------------------------------------------------------------------------
+struct EiStateParams {
+  CovParams cp;
+  double mean;
+  const double* gram;  // [E][c][c] col-major, c = u + nd d
+  const double* ek;    // [ctot]: K* block of evaluation e at e u, gradient block at E u + e nd d
+  const double* U;     // [E][u][dp] padded union points
+  int E, u, nd, d, dp, want_grad;
+  double* blob;        // records: mu [u] | L [u x u] | grad_mu [nd d] | gchol [nd][u][u][d]
+  long rec, o_mu, o_L, o_gmu, o_gc;
+  int* flags;          // [E]: 0, or the failing leading minor of the variance matrix
+};
+
+// d chol(Var + 1e-6 I) / d Xs_{k, dd} for one differentiated point k and one dimension dd: host_grad_variance_per_point (no
+// derivative observations) followed by Smith's recursion (gpp_math.cpp:1389-1452), in a lane-private array; out[j u d + i d + dd] =
+// d chol[j][i] / d x for i <= j (first index i, second j, as host_math.hip's GC macro).
+template <int UM>
+__device__ __forceinline__ void ei_grad_chol_lane(const EiStateParams& P, const double* __restrict__ G, const double* __restrict__ U,
+                                                  const double* __restrict__ Ls, int c, int k, int dd, double* __restrict__ out) {
+  const int u = P.u, d = P.d;
+  const double kMinimumStdDev = 2.220446049250313e-16;  // gpp_math.hpp:291
+  double gc[UM * UM];
+#define MOE_GC(i, j) gc[(j)*UM + (i)]
+#pragma unroll
+  for (int j = 0; j < UM; ++j)
+#pragma unroll
+    for (int i = 0; i < UM; ++i) MOE_GC(i, j) = 0.0;
+  // grad variance: column block k, the (k, k) entry, d Kss / d Xs_k
+  const int cg = u + k * d + dd;
+#pragma unroll
+  for (int row = 0; row < UM; ++row)
+    if (row < u) {
+      const double v = -G[cg + (long)row * c];
+#pragma unroll
+      for (int kk = 0; kk < UM; ++kk)
+        if (kk == k) MOE_GC(row, kk) = v;
+    }
+#pragma unroll
+  for (int j = 0; j < UM; ++j)
+    if (j < u) {
+      double r2 = 0.0, dfd = 0.0;
+      for (int kk = 0; kk < d; ++kk) {
+        const double df = U[k * P.dp + kk] - U[j * P.dp + kk];
+        r2 = fma(df * df, P.cp.inv_l2[kk], r2);
+        if (kk == dd) dfd = df;
+      }
+      const double tmp = (-dfd * P.cp.inv_l2[dd]) * radial_scalars(P.cp.type, P.cp.alpha, r2).first;  // grad_cov_entry(0, 0, dd)
+#pragma unroll
+      for (int kk = 0; kk < UM; ++kk)
+        if (kk == k) {
+          if (j == k)
+            MOE_GC(j, kk) = (MOE_GC(j, kk) + MOE_GC(j, kk)) + (tmp + tmp);  // (the (k, k) entry: both factors depend on Xs_k)
+          else
+            MOE_GC(j, kk) += tmp;
+        }
+    }
+  // mirror block column k into block row k, keep first <= second
+#pragma unroll
+  for (int j = 0; j < UM; ++j)
+#pragma unroll
+    for (int kk = 0; kk < UM; ++kk)
+      if (kk == k && j != k) MOE_GC(kk, j) = MOE_GC(j, kk);
+#pragma unroll
+  for (int i = 0; i < UM; ++i)
+#pragma unroll
+    for (int i2 = i + 1; i2 < UM; ++i2) MOE_GC(i2, i) = 0.0;
+#define MOE_CH(i, j) Ls[(i) + (j)*u]
+#pragma unroll
+  for (int kk = 0; kk < UM; ++kk)
+    if (kk < u) {
+      const double Lkk = MOE_CH(kk, kk);
+      if (Lkk > kMinimumStdDev) {
+        MOE_GC(kk, kk) = 0.5 * MOE_GC(kk, kk) / Lkk;
+#pragma unroll
+        for (int j = kk + 1; j < UM; ++j)
+          if (j < u) MOE_GC(kk, j) = (MOE_GC(kk, j) - MOE_CH(j, kk) * MOE_GC(kk, kk)) / Lkk;
+#pragma unroll
+        for (int j = kk + 1; j < UM; ++j)
+#pragma unroll
+          for (int i = j; i < UM; ++i)
+            if (i < u) MOE_GC(j, i) = MOE_GC(j, i) - MOE_GC(kk, i) * MOE_CH(j, kk) - MOE_CH(i, kk) * MOE_GC(kk, j);
+      }
+    }
+#undef MOE_CH
+#pragma unroll
+  for (int j = 0; j < UM; ++j)
+#pragma unroll
+    for (int i = 0; i < UM; ++i)
+      if (i < u && j < u) out[(long)j * u * d + (long)i * d + dd] = MOE_GC(i, j);
+#undef MOE_GC
+}
+
+__global__ __launch_bounds__(64) void ei_state_kernel(EiStateParams P) {
+  __shared__ double Ls[kMaxUnionEi * kMaxUnionEi];
+  __shared__ int s_bad;
+  const int e = blockIdx.x, lane = threadIdx.x;
+  const int u = P.u, d = P.d, c = u + P.nd * d;
+  const double* G = P.gram + (long)e * c * c;
+  const double* ek_k = P.ek + (long)e * u;
+  const double* ek_g = P.ek + (long)P.E * u + (long)e * P.nd * d;
+  const double* U = P.U + (long)e * u * P.dp;
+  double* r = P.blob + (long)e * P.rec;
+  if (lane == 0) s_bad = 0;
+  if (lane < u) r[P.o_mu + lane] = P.mean + ek_k[lane];  // host_mean
+  for (int idx = lane; idx < u * u; idx += 64) {          // host_variance, + 1e-6 on the diagonal (gpp_math.cpp:2000-2002)
+    const int i = idx % u, j = idx / u;
+    double r2 = 0.0;
+    for (int k = 0; k < d; ++k) {
+      const double df = U[i * P.dp + k] - U[j * P.dp + k];
+      r2 = fma(df * df, P.cp.inv_l2[k], r2);
+    }
+    double v = radial_scalars(P.cp.type, P.cp.alpha, r2).base - G[i + (long)j * c];
+    if (i == j) v += 1.0e-6;
+    Ls[i + j * u] = v;
+  }
+  __syncthreads();
+  // host_cholesky (ComputeCholeskyFactorL, gpp_linear_algebra.cpp:109-148): lane = row
+  for (int k = 0; k < u; ++k) {
+    const double akk = Ls[k + k * u];
+    if (!(akk > 1.0e-16)) {
+      if (lane == 0) s_bad = k + 1;
+      break;
+    }
+    const double lkk = sqrt(akk);
+    __syncthreads();
+    if (lane == k) Ls[k + k * u] = lkk;
+    if (lane > k && lane < u) Ls[lane + k * u] = Ls[lane + k * u] / lkk;
+    __syncthreads();
+    for (int j = k + 1; j < u; ++j)
+      if (lane >= j && lane < u) Ls[lane + j * u] = Ls[lane + j * u] - Ls[lane + k * u] * Ls[j + k * u];
+    __syncthreads();
+  }
+  __syncthreads();
+  if (lane == 0) P.flags[e] = s_bad;
+  if (s_bad != 0) return;
+  for (int idx = lane; idx < u * u; idx += 64) {
+    const int i = idx % u, j = idx / u;
+    r[P.o_L + idx] = (j <= i) ? Ls[idx] : 0.0;
+  }
+  if (!P.want_grad) return;
+  for (int idx = lane; idx < P.nd * d; idx += 64) r[P.o_gmu + idx] = ek_g[idx];  // host_grad_mean
+  // host_grad_cholesky_per_point for every differentiated point k; lane = dimension dd (independent recursions), each in a
+  // lane-private u x u array (registers for u <= 4 / 8) written to the record once
+  for (int dd = lane; dd < d; dd += 64) {
+    for (int k = 0; k < P.nd; ++k) {
+      double* gc = r + P.o_gc + (long)k * d * u * u;
+      if (u <= 4)
+        ei_grad_chol_lane<4>(P, G, U, Ls, c, k, dd, gc);
+      else if (u <= 8)
+        ei_grad_chol_lane<8>(P, G, U, Ls, c, k, dd, gc);
+      else
+        ei_grad_chol_lane<kMaxUnionEi>(P, G, U, Ls, c, k, dd, gc);
+    }
+  }
+}
+
+bool ei_device_algebra() {  // MOE_EI_DEVICE_ALGEBRA=0: the host-algebra path (two syncs per call; A/B runs and tests)
+  const char* v = std::getenv("MOE_EI_DEVICE_ALGEBRA");
+  return !(v && *v == '0');
 }
 
 }  // namespace
@@ -134,14 +316,45 @@ void ei_evaluate_batch(GpDev& gp, const double* Xq_all, int num_evals, const dou
   none.g = 0;
   for (int i = 0; i < kMaxDerivs; ++i) none.idx[i] = 0;
   // EI points carry no derivative observations even when the GP does (ExpectedImprovementState, gpp_math.cpp:2149-2150)
-  std::vector<StateHost> hosts;
-  compute_state_batch(gp, U_all.data(), u, none, want_grad ? q : 0, nullptr, 0, false, E, nullptr, &hosts);
   // per-evaluation record: mu [u] | L [u*u] | grad_mu [q*d] | gchol [q*d*u*u]
   const size_t o_mu = 0, o_L = u, o_gmu = o_L + (size_t)u * u, o_gc = o_gmu + (size_t)q * d;
   const size_t rec = o_gc + (want_grad ? (size_t)q * d * u * u : 0);
   const size_t n_norm = (size_t)num_mc * u;
+  const bool on_device = ei_device_algebra();
   gp.hKgIn.reserve(rec * E + n_norm);
   double* blob = gp.hKgIn.p;
+  DevBuf<double>& dBlobDev = gp.kBlob;
+  if (on_device) {
+    // ---- r3: the whole evaluation stays on the device: state kernels -> u x u algebra kernel -> MC -> ONE sync ----
+    const StateEnqueued se = enqueue_state_batch(gp, U_all.data(), u, none, want_grad ? q : 0, nullptr, 0, false, E);
+    dBlobDev.reserve(rec * E + n_norm);
+    gp.kBestJ.reserve((size_t)E);  // (int workspace: the singular-matrix flags)
+    EiStateParams sp;
+    sp.cp = gp.cp;
+    sp.mean = gp.mean;
+    sp.gram = gp.dGram.p;
+    sp.ek = gp.dGram.p + se.nG;
+    sp.U = gp.dPts.p;
+    sp.E = E;
+    sp.u = u;
+    sp.nd = want_grad ? q : 0;
+    sp.d = d;
+    sp.dp = gp.dp;
+    sp.want_grad = want_grad ? 1 : 0;
+    sp.blob = dBlobDev.p;
+    sp.rec = (long)rec;
+    sp.o_mu = (long)o_mu;
+    sp.o_L = (long)o_L;
+    sp.o_gmu = (long)o_gmu;
+    sp.o_gc = (long)o_gc;
+    sp.flags = gp.kBestJ.p;
+    hipLaunchKernelGGL(ei_state_kernel, dim3(E), dim3(64), 0, s, sp);
+    MOE_HIP_CHECK(hipGetLastError());
+    std::memcpy(blob, normals, sizeof(double) * n_norm);  // (pinned staging, then one copy behind the records)
+    MOE_HIP_CHECK(hipMemcpyAsync(dBlobDev.p + rec * E, blob, sizeof(double) * n_norm, hipMemcpyHostToDevice, s));
+  } else {
+  std::vector<StateHost> hosts;
+  compute_state_batch(gp, U_all.data(), u, none, want_grad ? q : 0, nullptr, 0, false, E, nullptr, &hosts);
   for (int e = 0; e < E; ++e) {
     const StateHost& sh = hosts[e];
     double* r = blob + rec * e;
@@ -161,11 +374,12 @@ void ei_evaluate_batch(GpDev& gp, const double* Xq_all, int num_evals, const dou
     }
   }
   std::memcpy(blob + rec * E, normals, sizeof(double) * n_norm);
+  gp.kBlob.upload(blob, rec * E + n_norm, s);
+  }
   const int ncomp = 1 + (want_grad ? q * d : 0);
   const int blocks = (num_mc + 255) / 256;
   // persistent workspaces (hipMalloc / hipFree per call cost more than the whole evaluation)
   DevBuf<double>&dBlob = gp.kBlob, &dPartial = gp.kTB, &dOut = gp.kOut;
-  dBlob.upload(blob, rec * E + n_norm, s);
   dPartial.reserve((size_t)E * blocks * ncomp);
   dOut.reserve((size_t)E * ncomp);
   EiParams P;
@@ -185,10 +399,19 @@ void ei_evaluate_batch(GpDev& gp, const double* Xq_all, int num_evals, const dou
   hipLaunchKernelGGL(ei_mc_kernel, dim3(blocks, E), dim3(256), 0, s, P);
   hipLaunchKernelGGL(sum_partials_kernel, dim3(E), dim3(256), 0, s, dPartial.p, blocks, ncomp, dOut.p);
   MOE_HIP_CHECK(hipGetLastError());
-  gp.hKgOut.reserve((size_t)E * ncomp);
+  gp.hKgOut.reserve((size_t)E * ncomp + (size_t)(E + 1) / 2 + 1);
   double* out = gp.hKgOut.p;
   dOut.download(out, (size_t)E * ncomp, s);
+  int* flags_h = reinterpret_cast<int*>(out + (size_t)E * ncomp);
+  if (on_device) MOE_HIP_CHECK(hipMemcpyAsync(flags_h, gp.kBestJ.p, sizeof(int) * E, hipMemcpyDeviceToHost, s));
   MOE_HIP_CHECK(hipStreamSynchronize(s));
+  if (on_device)
+    for (int e = 0; e < E; ++e)
+      if (flags_h[e] != 0)
+        throw Error(MOE_ERR_SINGULAR,
+                    "GP-Variance matrix singular. Check for duplicate points_to_sample/being_sampled or "
+                    "points_to_sample/being_sampled duplicating points_sampled with 0 noise.",
+                    u, flags_h[e]);
   for (int e = 0; e < E; ++e) {
     if (ei) ei[e] = out[(size_t)e * ncomp] / (double)num_mc;
     if (want_grad)

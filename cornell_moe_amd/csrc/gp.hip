@@ -398,8 +398,8 @@ void GpDev::add_points_unchecked(const double* pts, const double* vals, int k) {
   if (singular) rebuild();
 }
 
-void compute_state_batch(GpDev& gp, const double* U_all, int u, const DerivList& dt, int nd, const double* extra_all, int A,
-                         bool need_W, int num_evals, BatchLayout* blay, std::vector<StateHost>* hosts) {
+StateEnqueued enqueue_state_batch(GpDev& gp, const double* U_all, int u, const DerivList& dt, int nd, const double* extra_all,
+                                  int A, bool need_W, int num_evals) {
   gp.use_device();
   hipStream_t s = gp.stream;
   const int E = num_evals;
@@ -463,6 +463,25 @@ void compute_state_batch(GpDev& gp, const double* U_all, int u, const DerivList&
   gp.dEK.reserve((size_t)E * gram_batch_slices(E, c, N) * c * c);  // partial Grams of the K-sliced kernel
   launch_gram_batch(E, lay.m, ngrad, A, N, gp.dVE.p, N, gp.dGram.p, gp.dEK.p, s);
   launch_gemm_tn((int)ctot, 1, N, gp.dE.p, N, gp.dKinvY.p, N, gp.dGram.p + nG, (int)ctot, s);
+  StateEnqueued se;
+  se.bl = bl;
+  se.lay = lay;
+  se.nG = nG;
+  se.ctot = ctot;
+  return se;
+}
+
+void compute_state_batch(GpDev& gp, const double* U_all, int u, const DerivList& dt, int nd, const double* extra_all, int A,
+                         bool need_W, int num_evals, BatchLayout* blay, std::vector<StateHost>* hosts) {
+  const StateEnqueued se = enqueue_state_batch(gp, U_all, u, dt, nd, extra_all, A, need_W, num_evals);
+  hipStream_t s = gp.stream;
+  const int E = num_evals;
+  const BatchLayout& bl = se.bl;
+  const StateLayout& lay = se.lay;
+  const int c = lay.c();
+  const int ngrad = nd * (1 + dt.g) * gp.d;
+  const size_t nG = se.nG;
+  const long ctot = se.ctot;
   gp.hStateOut.reserve(nG + ctot);
   gp.dGram.download(gp.hStateOut.p, nG + ctot, s);
   MOE_HIP_CHECK(hipStreamSynchronize(s));

