@@ -261,6 +261,11 @@ def main():
     ndev = torch.cuda.device_count()
     if backend != "nccl" or os.environ.get("MOE_BENCH_SHARE_GPU") == "1":   # (second test hook: ranks share a GPU, RCCL still preferred)
         local_rank = local_rank % ndev
+    elif ndev == 1 and local_rank > 0:
+        # a launcher that narrows every rank's visibility to its own GPU (HIP_VISIBLE_DEVICES per process): the one visible
+        # device IS this rank's
+        print("[bench] rank %d: LOCAL_RANK=%d but one visible device -- using device 0" % (rank, local_rank), file=sys.stderr, flush=True)
+        local_rank = 0
     torch.cuda.set_device(local_rank)
 
     # ---- process groups: gloo control plane, RCCL data plane behind a pre-flight (dist.bring_up) ----

@@ -182,7 +182,11 @@ def _preflight_child():
     rank, world, local = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"]), int(os.environ.get("LOCAL_RANK", "0"))
     backend = os.environ.get("MOE_DIST_DATA_BACKEND", "nccl")
     if backend == "nccl":
-        if not torch.cuda.is_available() or torch.cuda.device_count() <= local:
+        if not torch.cuda.is_available():
+            sys.exit(3)
+        if torch.cuda.device_count() == 1 and os.environ.get("MOE_BENCH_SHARE_GPU") != "1":
+            local = 0  # (a launcher that narrows every rank's visibility to its own GPU: see bench.py)
+        if torch.cuda.device_count() <= local:
             sys.exit(3)
         torch.cuda.set_device(local)
         dev = torch.device("cuda", local)
