@@ -59,7 +59,7 @@ struct TabParams {
 // coordinates carry the precision of the distances however far from the origin the domain sits):
 // the n training points, then the u union points of that evaluation, zero beyond.
 __global__ void build_xs_tab_kernel(const double* __restrict__ X, int n, const double* __restrict__ XuAll, int u, int dp,
-                                    int ntiles, TabParams tp, double* __restrict__ tab, long tab_stride) {
+                                    int ntiles, TabParams tp, double* __restrict__ tab, long tab_stride, int pair_rows) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   const int e = blockIdx.y;
   if (idx >= ntiles * dp * 64) return;
@@ -71,7 +71,9 @@ __global__ void build_xs_tab_kernel(const double* __restrict__ X, int n, const d
     v = X[(long)j * dp + k];
   else if (j < n + u)
     v = XuAll[((long)e * u + (j - n)) * dp + k];
-  tab[(long)e * tab_stride + idx] = (v - tp.center[r]) * tp.inv_lp[r];
+  // (pair_rows: the rows of a point in pairs, [tile][dp / 2][64][2] -- one 16-byte load per lane and pair, kg_mc.hpp WideEval)
+  const long out = pair_rows ? (((long)t * (dp / 2) + (r >> 1)) * 64 + l) * 2 + (r & 1) : idx;
+  tab[(long)e * tab_stride + out] = (v - tp.center[r]) * tp.inv_lp[r];
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -864,6 +866,8 @@ KgPending kg_launch(GpDev& gp, int num_fidelity, const moe_gd_params_t& gd, cons
   // ---- MC launch geometry: workgroup = `waves` wavefronts sharing one LDS coordinate table ----
   const size_t tab_bytes = sizeof(double) * (size_t)ntiles * (dp + 1) * 64;  // LDS copy: + the |x|^2 row (kg_mc.hpp eval_loop)
   const size_t slab_bytes = sizeof(double) * ((size_t)ntiles * (1 + G) * 64 + 2 * kMaxM);
+  // (streamed coordinates: + the wave's line-search vectors and packed-sum slot -- kg_mc.hpp WideEval)
+  const size_t slab_stream_bytes = slab_bytes + (mc::wide_eval(dp, false) ? sizeof(double) * mc::kWideScratch : 0);
   // the exp table sits in front of everything; one weight tile of padding at the very end (eval_loop prefetches one tile
   // past the last wave's slab)
   const size_t pad_bytes = sizeof(double) * (size_t)(1 + G) * 64;
@@ -913,7 +917,7 @@ KgPending kg_launch(GpDev& gp, int num_fidelity, const moe_gd_params_t& gd, cons
   //  n = 1500, d = 8: 2.1 vs 3.1 ms per evaluation; with 2 they lose -- n = 1700: 3.6 vs 3.4)
   const int min_xlds_waves = env_int("MOE_KG_MIN_XLDS_WAVES", 4);  // (r2: 4 -- with 3 the streaming kernel and its 8 wavefronts win, n = 1500: 1.15 vs 1.44 ms)
   if (waves < min_xlds_waves || wide_frame) {  // coordinates stay in L2: more wavefronts per workgroup fit
-    const int w2 = (int)std::min<size_t>(8, lds_max / slab_bytes);
+    const int w2 = (int)std::min<size_t>(8, lds_max / slab_stream_bytes);
     if (w2 > waves || wide_frame) {  // (the instantiation without the LDS table is built for <= 8 wavefronts)
       waves = w2;
       xlds = false;
@@ -953,11 +957,17 @@ KgPending kg_launch(GpDev& gp, int num_fidelity, const moe_gd_params_t& gd, cons
     throw Error(MOE_ERR_RUNTIME, "training set too large for the MC kernel (one sample's weights exceed LDS)");
   const int num_cu = gp.num_cu;
   size_t shm = 0;
-  int wg_per_cu = 1;
+  int wg_per_cu = 1, wide_lds_tiles = 0;
   if (variant == 0) {
     waves = std::max(1, std::min(waves, env_int("MOE_KG_WAVES", waves)));
-    shm = fixed_bytes + (xlds ? tab_bytes : 0) + (size_t)waves * slab_bytes + pad_bytes;
+    shm = fixed_bytes + (xlds ? tab_bytes + (size_t)waves * slab_bytes : (size_t)waves * slab_stream_bytes) + pad_bytes;
     wg_per_cu = std::max(1, std::min((int)((size_t)160 * 1024 / shm), (waves > 8 ? 16 : 8) / waves));
+    if (mc::wide_eval(dp, xlds)) {  // what the slabs leave of a workgroup's share of LDS holds the leading tiles of the table (kg_mc.hpp WideEval)
+      const size_t share = (size_t)160 * 1024 / wg_per_cu;
+      wide_lds_tiles = (int)std::min<size_t>((size_t)ntiles, (share - shm) / (sizeof(double) * dp * 64));
+      wide_lds_tiles = std::max(0, std::min(wide_lds_tiles, env_int("MOE_KG_WIDE_LDS_TILES", wide_lds_tiles)));
+      shm += sizeof(double) * (size_t)wide_lds_tiles * dp * 64;
+    }
   } else {
     waves = bwaves;
   }
@@ -1174,7 +1184,8 @@ KgPending kg_launch(GpDev& gp, int num_fidelity, const moe_gd_params_t& gd, cons
   // ---- coordinate tables ----
   {
     dim3 grid((unsigned)((tab_stride + 255) / 256), E);
-    hipLaunchKernelGGL(build_xs_tab_kernel, grid, dim3(256), 0, s, gp.dX.p, n, gp.dPts.p, u, dp, ntiles, tp, dTab.p, tab_stride);
+    hipLaunchKernelGGL(build_xs_tab_kernel, grid, dim3(256), 0, s, gp.dX.p, n, gp.dPts.p, u, dp, ntiles, tp, dTab.p, tab_stride,
+                       (wide_dp || (variant == 0 && mc::wide_eval(dp, xlds))) ? 1 : 0);
     MOE_HIP_CHECK(hipGetLastError());
   }
   const double ms_state = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wall0).count();
@@ -1205,6 +1216,7 @@ KgPending kg_launch(GpDev& gp, int num_fidelity, const moe_gd_params_t& gd, cons
   mp.multi_trial = far_frame ? 0 : env_int("MOE_KG_MULTI_TRIAL", 1);  // (0: A/B runs)
   mp.XsTab = dTab.p;
   mp.tab_stride = tab_stride;
+  mp.wide_lds_tiles = wide_lds_tiles;
   mp.KinvY = gp.dKinvY.p;
   mp.W = gp.dWE.p + bl.col_kstar0(0) * N;
   mp.w_stride = (long)m * N;
@@ -1270,7 +1282,7 @@ KgPending kg_launch(GpDev& gp, int num_fidelity, const moe_gd_params_t& gd, cons
     launch_mc_block(mp, dp, G, tr, num_lds_tiles, blocks, waves, s);
   t_mc.stop(s);
   {
-    const int info[8] = {variant, (variant == 0 && xlds) ? 1 : 0, waves, variant == 1 ? tr : 0, mp.V != nullptr ? 1 : 0, 0, blocks,
+    const int info[8] = {variant, (variant == 0 && xlds) ? 1 : 0, waves, variant == 1 ? tr : wide_lds_tiles, mp.V != nullptr ? 1 : 0, 0, blocks,
                          mp.best_j != nullptr ? 1 : 0};
     std::copy(info, info + 8, gp.last_info);
   }

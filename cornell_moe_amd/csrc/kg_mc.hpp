@@ -74,6 +74,8 @@ struct KgMcParams {
                     // multi-trial passes lose absolute accuracy with the square of the trial's offset)
   double mean;
   const double* XsTab;  // [E][ntiles][DP][64] scaled coordinates of X then Xu_e, zero padded
+                        // (pair_rows: rows in pairs, [E][ntiles][DP / 2][64][2] -- WideEval: the streamed wave-per-sample kernel and d > 16)
+  int wide_lds_tiles;   // streamed wave-per-sample kernel: leading tiles of the table copied to LDS per workgroup
   long tab_stride;
   const double* KinvY;  // [N], entry (j, a) at j (1 + g) + a
   const double* W;      // K^-1 K*: evaluation e at W + e * w_stride, [N x m], ld N
@@ -679,6 +681,15 @@ __device__ __forceinline__ void from_table_order(const double (&v)[DP], const in
     }
   }
 }
+
+constexpr int kPartLen = 48;  // doubles per partial slot of a packed reduction: f | DP gradient sums | sum of coefficients | G derivative sums (<= 1 + 32 + 1 + 12)
+constexpr int kLsRows = 6;    // line-search vectors per wave in LDS (line_search_lds): x | masked gradient | step | x at restart start | x0 and dv of the trial line (frame)
+// per-wave LDS scratch of the wide-dimension evaluator (WideEval, d > 16) behind the z / beta scratch of a weight slab
+constexpr int kWideScratch = kLsRows * kMaxDimPadded + kPartLen;
+// Which wave-per-sample instantiations use it: the streamed ones from 16 coordinate rows on.  (r3, streamed tables at 8 / 12 rows:
+// the evaluator above with its fused value + gradient passes stays ahead -- n = 1500 .. 3000, d = 8: 1.15 / 1.39 / 2.15 ms per
+// evaluation against 1.24 / 1.62 / 2.52; at 16 rows WideEval wins, n = 1000: 0.27 against 0.345 ms.)
+constexpr bool wide_eval(int dp, bool xlds) { return !xlds && dp >= 16; }
 
 // Evaluator of the wave-per-sample kernel: one pass = eval_pass over the LDS tables.
 template <int DP, int G, bool SMALL, bool XL>
@@ -1296,6 +1307,287 @@ __device__ __forceinline__ double line_search_lds(const KgMcParams& P, EV& ev, d
   return fcur;
 }
 
+// Evaluator of the wave-per-sample kernel for the WIDE padded dimensions (d = 17 .. 32), used with line_search_lds.
+// At 24 / 32 coordinate rows the evaluator above needs x2, d2, x0, dv, the current and the prefetched tile -- 6 DP doubles, 384
+// VGPRs at DP = 32 -- inside its tile loop and compiled to 2.3 KB of scratch per lane with the spills in the loop (r3: d = 32
+// ran 15x slower than d = 16, d = 24 5x).  Here the line-search state lives in the wave's LDS scratch and a pass keeps only what
+// its loop needs:
+//   value passes (T trials along one line):   x0, dv (2 DP) + a ring of PF rows + T accumulators  -- 80 + T doubles at DP = 32
+//   gradient pass:                            xq, grad sums (2 DP) + the tile's rows (DP)          -- 96 doubles at DP = 32; the
+//     gradient is accumulated as sum_j coef_j x_j - q sum_j coef_j (the centred frame keeps both terms of the size of the
+//     gradient: see eval_loop GDOT), so a row is dead -- and refilled from the next tile -- right after its fma.
+// The table of the wide dimensions holds the rows in PAIRS, [tile][DP / 2][64][2]: a lane fetches rows 2i, 2i + 1 of its point
+// with one 16-byte load (8-byte loads run at 0.54 - 0.70x the 16-byte rate out of L2, and these passes are bound by exactly
+// that stream: ~200 KB per sweep and wave at n = 1000, d = 24).  The first `ntl` tiles are served from an LDS copy shared by
+// the workgroup's waves (whatever the weight slabs leave of the 160 KB), the rest from L2; a sweep is the same loop over the
+// two segments (the ring's slot indices are static: PF divides DP).
+// Same arithmetic as BlockEval (direct differences about x0); queries beyond kQueryClamp are pulled back (clamp_query).
+typedef double d2t __attribute__((ext_vector_type(2)));
+typedef const __attribute__((address_space(3))) d2t* lds_pair_ptr;
+
+template <int DP, int G>
+struct WideEval {
+  const d2t* __restrict__ xg;   // coordinate table of this evaluation in global memory (one tile of padding behind), + lane
+  lds_pair_ptr xl;              // LDS copy of its first `ntl` tiles, + lane
+  const double* __restrict__ aw;    // this wave's weights [tile][1 + G][64] in LDS
+  const double* __restrict__ etab;
+  double* __restrict__ red;         // kPartLen doubles of LDS, private to the wave: packed sums of a gradient pass
+  int ntiles, ntl, cov_type, lane;
+  double mean;
+  static constexpr int kMaxTrials = 5;
+  static constexpr int HP = DP / 2;                        // row pairs per tile
+  static constexpr int PF2 = (HP <= 8) ? HP : ((HP % 8 == 0) ? 8 : 6);  // ring depth in row pairs
+  static_assert(HP % PF2 == 0 && PF2 <= HP, "ring slots must be static");
+#if MOE_BLOCK_PROF
+  unsigned long long c_tot = 0, seg_last = 0, seg_tot = 0;
+  __device__ __forceinline__ void seg_mark(int) {}
+#endif
+
+  // one segment (LDS or L2 tiles) of a T-trial value sweep; `wt` walks on through the weight slab
+  template <int COV, int T, class PP>
+  __device__ __forceinline__ void segT(PP xt, lds_tile_ptr& wt, int nt, const double (&x0)[DP], const double (&dv)[DP],
+                                       const double (&al)[T], double dd, double (&acc)[T]) {
+    if (nt <= 0) return;
+    d2t ring[PF2];
+    double cw[1 + G];
+#pragma unroll
+    for (int i = 0; i < PF2; ++i) ring[i] = xt[i * 64];
+#pragma unroll
+    for (int a = 0; a < 1 + G; ++a) cw[a] = wt[a * 64];
+#pragma unroll 1
+    for (int tile = 0; tile < nt; ++tile) {
+      double A = 1.0e-300, B = 0.0, sdA = 0.0, sdB = 0.0;
+#pragma unroll
+      for (int i = 0; i < HP; ++i) {
+        const d2t c = ring[i % PF2];
+        ring[i % PF2] = xt[(i + PF2) * 64];  // pair i + PF2 of the stream (runs into the next tile; behind the segment: unused)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int k = 2 * i + h;
+          const double d0 = (h == 0 ? c.x : c.y) - x0[k];
+          A = fma(d0, d0, A);
+          B = fma(d0, dv[k], B);
+          if (G > 0 && k < G) {
+            sdA = fma(cw[1 + (k < G ? k : 0)], d0, sdA);
+            sdB = fma(cw[1 + (k < G ? k : 0)], dv[k], sdB);
+          }
+        }
+      }
+      xt += HP * 64;
+      wt += (1 + G) * 64;
+      double nw[1 + G];
+#pragma unroll
+      for (int a = 0; a < 1 + G; ++a) nw[a] = wt[a * 64];
+      const double mB2 = -2.0 * B;
+#pragma unroll
+      for (int t = 0; t < T; ++t) {
+        const double r2 = fmax(fma(al[t], fma(al[t], dd, mB2), A), 1.0e-300);
+        double base, first, second;
+        radial3<COV, (G > 0), false>(r2, etab, base, first, second);
+        acc[t] = fma(cw[0], base, acc[t]);
+        if (G > 0) acc[t] = fma(first, fma(-al[t], sdB, sdA), acc[t]);
+      }
+#pragma unroll
+      for (int a = 0; a < 1 + G; ++a) cw[a] = nw[a];
+    }
+  }
+
+  template <int T>
+  __device__ __forceinline__ void values(const double (&x0)[DP], const double (&dv)[DP], const double (&al)[T], double dd,
+                                         double (&f)[T]) {
+    double acc[T];
+#pragma unroll
+    for (int t = 0; t < T; ++t) acc[t] = 0.0;
+    lds_tile_ptr wt = (lds_tile_ptr)(aw + lane);
+    if (cov_type == MOE_COV_SQUARE_EXPONENTIAL) {
+      segT<MOE_COV_SQUARE_EXPONENTIAL, T>(xl, wt, ntl, x0, dv, al, dd, acc);
+      segT<MOE_COV_SQUARE_EXPONENTIAL, T>(xg + (long)ntl * HP * 64, wt, ntiles - ntl, x0, dv, al, dd, acc);
+    } else {
+      segT<MOE_COV_MATERN_NU_2P5, T>(xl, wt, ntl, x0, dv, al, dd, acc);
+      segT<MOE_COV_MATERN_NU_2P5, T>(xg + (long)ntl * HP * 64, wt, ntiles - ntl, x0, dv, al, dd, acc);
+    }
+    double sum[T];
+    constexpr int T4 = T / 4 * 4;
+#pragma unroll
+    for (int t = 0; t < T4; t += 4) {
+      double o[4];
+      wave_sum4_uniform(acc[t], acc[t + 1], acc[t + 2], acc[t + 3], o);
+      sum[t] = o[0];
+      sum[t + 1] = o[1];
+      sum[t + 2] = o[2];
+      sum[t + 3] = o[3];
+    }
+    if constexpr (T - T4 >= 2) wave_sum2_uniform(acc[T4], acc[T4 + 1], sum[T4], sum[T4 + 1]);
+    if constexpr (((T - T4) & 1) != 0) sum[T - 1] = wave_sum_uniform(acc[T - 1]);
+#pragma unroll
+    for (int t = 0; t < T; ++t) f[t] = -(mean + sum[t]);
+  }
+
+  // up to kMaxTrials Armijo trials x0 + alpha 2^-t dv in one pass and the reference's decisions over them (see BlockEval::armijo_t)
+  template <int T>
+  __device__ __forceinline__ void armijo_t(const double* __restrict__ x0p, const double* __restrict__ dvp, double dd, double f0,
+                                           double norm, double& alpha_n, int& search, double& ftrial, bool& done,
+                                           unsigned long long& n_val) {
+    double x0[DP], dv[DP];
+#pragma unroll
+    for (int k = 0; k < DP; ++k) {
+      x0[k] = x0p[k];
+      dv[k] = dvp[k];
+    }
+    double al[T], f[T];
+#pragma unroll
+    for (int t = 0; t < T; ++t) al[t] = (t == 0) ? alpha_n : 0.5 * al[t > 0 ? t - 1 : 0];
+    values<T>(x0, dv, al, dd, f);
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+      if (!done) {
+        ftrial = f[t];
+        n_val++;
+        if (ftrial - f0 > 0.5 * alpha_n * norm) {
+          done = true;
+        } else {
+          alpha_n *= 0.5;
+          if (++search >= 30) done = true;
+        }
+      }
+    }
+  }
+  __device__ __forceinline__ void armijo_batch(int want, const double* __restrict__ x0, const double* __restrict__ dv, double dd,
+                                               double f0, double norm, double& alpha_n, int& search, double& ftrial, bool& done,
+                                               unsigned long long& n_val) {
+    switch (want) {
+      case 2: armijo_t<2>(x0, dv, dd, f0, norm, alpha_n, search, ftrial, done, n_val); break;
+      case 3: armijo_t<3>(x0, dv, dd, f0, norm, alpha_n, search, ftrial, done, n_val); break;
+      case 4: armijo_t<4>(x0, dv, dd, f0, norm, alpha_n, search, ftrial, done, n_val); break;
+      default: armijo_t<5>(x0, dv, dd, f0, norm, alpha_n, search, ftrial, done, n_val); break;
+    }
+  }
+
+  // f at one point: a one-trial sweep along the zero direction
+  __device__ __forceinline__ double value_at(const double (&xq_in)[DP]) {
+    double xq[DP], dv[DP];
+#pragma unroll
+    for (int k = 0; k < DP; ++k) {
+      xq[k] = xq_in[k];
+      dv[k] = 0.0;
+    }
+    clamp_query<DP>(xq);
+    const double al[1] = {0.0};
+    double f[1];
+    values<1>(xq, dv, al, 0.0, f);
+    return f[0];
+  }
+  __device__ __forceinline__ void eval2(const double (&xa)[DP], const double (&xb)[DP], double& fa, double& fb) {
+    fa = value_at(xa);
+    fb = value_at(xb);
+  }
+  template <bool WG>
+  __device__ __forceinline__ double eval_p(const double* __restrict__ xq_ptr, double (&)[DP]) {
+    static_assert(!WG, "gradient passes of the wide evaluator go through eval_p_lane");
+    double xq[DP];
+#pragma unroll
+    for (int k = 0; k < DP; ++k) xq[k] = xq_ptr[k];
+    return value_at(xq);
+  }
+
+  // one segment of a gradient sweep
+  template <int COV, class PP>
+  __device__ __forceinline__ void segG(PP xt, lds_tile_ptr& wt, int nt, const double (&xq)[DP], double& accf, double& accs,
+                                       double (&accg)[DP], double (&accd)[G > 0 ? G : 1]) {
+    if (nt <= 0) return;
+    d2t cx[HP];
+    double cw[1 + G];
+#pragma unroll
+    for (int i = 0; i < HP; ++i) cx[i] = xt[i * 64];
+#pragma unroll
+    for (int a = 0; a < 1 + G; ++a) cw[a] = wt[a * 64];
+#pragma unroll 1
+    for (int tile = 0; tile < nt; ++tile) {
+      double r2 = 1.0e-300, sd = 0.0;
+#pragma unroll
+      for (int k = 0; k < DP; ++k) {
+        const double d0 = ((k & 1) ? cx[k / 2].y : cx[k / 2].x) - xq[k];
+        r2 = fma(d0, d0, r2);
+        if (G > 0 && k < G) sd = fma(cw[1 + (k < G ? k : 0)], d0, sd);
+      }
+      double base, first, second;
+      radial3<COV, true, (G > 0)>(r2, etab, base, first, second);
+      const double w0 = cw[0];
+      accf = fma(w0, base, accf);
+      double coef = w0 * first;
+      if (G > 0) {
+        accf = fma(first, sd, accf);
+        coef = fma(second, sd, coef);
+#pragma unroll
+        for (int a = 0; a < G; ++a) accd[a] = fma(first, cw[1 + a], accd[a]);
+      }
+      accs += coef;
+      xt += HP * 64;
+      wt += (1 + G) * 64;
+#pragma unroll
+      for (int i = 0; i < HP; ++i) {
+        accg[2 * i] = fma(coef, cx[i].x, accg[2 * i]);
+        accg[2 * i + 1] = fma(coef, cx[i].y, accg[2 * i + 1]);
+        cx[i] = xt[i * 64];  // the pair's slot is free: the next tile's rows (behind the segment: unused)
+      }
+#pragma unroll
+      for (int a = 0; a < 1 + G; ++a) cw[a] = wt[a * 64];
+    }
+  }
+
+  // value + gradient, the gradient handed back one component per lane in the original units (scale_l = this lane's frame scale)
+  __device__ __forceinline__ double eval_p_lane(const double* __restrict__ xq_ptr, double scale_l, double& grad_l) {
+    constexpr int NS = 2 + DP + (G > 0 ? G : 0);
+    static_assert(NS <= kPartLen, "packed sums of a gradient pass exceed the wave's scratch");
+    double xq[DP];
+#pragma unroll
+    for (int k = 0; k < DP; ++k) xq[k] = xq_ptr[k];
+    clamp_query<DP>(xq);
+    double q_l = 0.0;  // this lane's (clamped) query coordinate
+#pragma unroll
+    for (int k = 0; k < DP; ++k)
+      if (lane == k) q_l = xq[k];
+    double accf = 0.0, accs = 0.0, accg[DP], accd[G > 0 ? G : 1];
+#pragma unroll
+    for (int k = 0; k < DP; ++k) accg[k] = 0.0;
+#pragma unroll
+    for (int a = 0; a < (G > 0 ? G : 1); ++a) accd[a] = 0.0;
+    lds_tile_ptr wt = (lds_tile_ptr)(aw + lane);
+    if (cov_type == MOE_COV_SQUARE_EXPONENTIAL) {
+      segG<MOE_COV_SQUARE_EXPONENTIAL>(xl, wt, ntl, xq, accf, accs, accg, accd);
+      segG<MOE_COV_SQUARE_EXPONENTIAL>(xg + (long)ntl * HP * 64, wt, ntiles - ntl, xq, accf, accs, accg, accd);
+    } else {
+      segG<MOE_COV_MATERN_NU_2P5>(xl, wt, ntl, xq, accf, accs, accg, accd);
+      segG<MOE_COV_MATERN_NU_2P5>(xg + (long)ntl * HP * 64, wt, ntiles - ntl, xq, accf, accs, accg, accd);
+    }
+    double sums[NS];
+    sums[0] = accf;
+#pragma unroll
+    for (int k = 0; k < DP; ++k) sums[1 + k] = accg[k];
+    sums[1 + DP] = accs;
+    if (G > 0) {
+#pragma unroll
+      for (int a = 0; a < G; ++a) sums[2 + DP + a] = accd[a];
+    }
+    wave_sum_packed_store<NS>(sums, red, lane);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    volatile __attribute__((address_space(3))) double* R = (volatile __attribute__((address_space(3))) double*)red;
+    const double f = R[0];
+    const double ss = R[1 + DP];
+    double v = R[1 + (lane < DP ? lane : 0)];
+    v = fma(-q_l, ss, v);  // sum coef x_k - q_k sum coef
+    if (G > 0) {
+      const double vd = R[2 + DP + (lane < G ? lane : 0)];
+      if (lane < G) v -= vd;
+    }
+    grad_l = -(v * scale_l);
+    __builtin_amdgcn_wave_barrier();  // (the next pass's sums overwrite the slot only after every lane has read it: in-order LDS)
+    return -(mean + uniform(f));
+  }
+};
+
 // z_i (antithetic pairs, .cpp:171-180) and beta = L^-T z for global sample index s: lane c owns component c; copies go to
 // the LDS scratch zb ([0, kMaxM) = z, [kMaxM, 2 kMaxM) = beta) for the uniform reads of the weight loop and the scan.
 __device__ __forceinline__ void draw_z_beta(const KgMcParams& P, const double* __restrict__ Lsm, int s, int lane,
@@ -1479,24 +1771,33 @@ __device__ __forceinline__ void kg_sample(const KgMcParams& P, int e, int sl, co
   for (int k = 0; k < DP; ++k) x[k] = (k < size) ? disc[(long)best_j * size + k] : ((k < P.dim) ? 1.0 : 0.0);
 
   unsigned long long n_val = 0, n_grad = 0;  // passes over the n + u points (the A-point scan is O(A m), not counted)
-  WaveEval<DP, G, SMALL, XL> ev{xs, aw, etab, P.ntiles, P.cov_type, P.mean, P.inv_lp, lane, zb + DP};
-  const double fcur = line_search_frame<DP, G>(P, cst, zb, ev, x, n_val, n_grad);  // (z / beta scratch is idle by now)
+  double fcur;
+  if constexpr (wide_eval(DP, XL)) {
+    double* st = zb + 2 * kMaxM;  // line-search vectors | packed-sum slot: kWideScratch doubles behind the z / beta scratch
+    const d2t* xg = reinterpret_cast<const d2t*>(xs) + lane;
+    lds_pair_ptr xl = (lds_pair_ptr)(cst + kCstRows * DP) + lane;  // the workgroup's LDS copy of the first tiles (kg_mc_kernel)
+    WideEval<DP, G> ev{xg, xl, aw, etab, st + kLsRows * kMaxDimPadded, P.ntiles, P.wide_lds_tiles, P.cov_type, lane, P.mean};
+    fcur = line_search_lds<DP, G>(P, ev, st, x, n_val, n_grad);
+  } else {
+    WaveEval<DP, G, SMALL, XL> ev{xs, aw, etab, P.ntiles, P.cov_type, P.mean, P.inv_lp, lane, zb + DP};
+    fcur = line_search_frame<DP, G>(P, cst, zb, ev, x, n_val, n_grad);  // (z / beta scratch is idle by now)
 #if MOE_BLOCK_PROF
-  {
-    const unsigned long long w4 = __builtin_amdgcn_s_memtime();
-    if (lane == 0) {  // [0] z/beta [1] weights [2] scan [3] line search | [4] in value passes [5] in gradient passes | counts
-      atomicAdd(&P.prof[0], w1 - w0);
-      atomicAdd(&P.prof[1], w2 - w1);
-      atomicAdd(&P.prof[2], w3 - w2);
-      atomicAdd(&P.prof[3], w4 - w3);
-      atomicAdd(&P.prof[4], ev.c_v);
-      atomicAdd(&P.prof[5], ev.c_g);
-      atomicAdd(&P.prof[6], ev.n_v);
-      atomicAdd(&P.prof[7], ev.n_g);
-      atomicAdd(&P.prof[13], 1ull);
+    {
+      const unsigned long long w4 = __builtin_amdgcn_s_memtime();
+      if (lane == 0) {  // [0] z/beta [1] weights [2] scan [3] line search | [4] in value passes [5] in gradient passes | counts
+        atomicAdd(&P.prof[0], w1 - w0);
+        atomicAdd(&P.prof[1], w2 - w1);
+        atomicAdd(&P.prof[2], w3 - w2);
+        atomicAdd(&P.prof[3], w4 - w3);
+        atomicAdd(&P.prof[4], ev.c_v);
+        atomicAdd(&P.prof[5], ev.c_g);
+        atomicAdd(&P.prof[6], ev.n_v);
+        atomicAdd(&P.prof[7], ev.n_g);
+        atomicAdd(&P.prof[13], 1ull);
+      }
     }
-  }
 #endif
+  }
 
   const long so = so0;
   if (lane == 0) P.best_value[so] = fcur;
@@ -1522,11 +1823,12 @@ __global__ __launch_bounds__(SMALL ? 1024 : 512) void kg_mc_kernel(KgMcParams P)
   const int wave = threadIdx.x >> 6;
   const int ntiles = P.ntiles;
   const int tab = ntiles * (DP + 1) * 64;  // LDS copy: the DP coordinate rows + the |x|^2 row per tile (see eval_loop)
-  const int wslab = ntiles * (1 + G) * 64 + 2 * kMaxM;
+  const int wslab = ntiles * (1 + G) * 64 + 2 * kMaxM + (wide_eval(DP, XLDS) ? kWideScratch : 0);
   // LDS: [64] exp table | [kCstRows x DP] per-row constants of the frame line search | [tab] coordinates (if XLDS) | per-wave slabs
   double* cst = smem + kExpTabLen;
   double* coords = cst + kCstRows * DP;
-  double* aw = coords + (XLDS ? tab : 0) + wave * wslab;
+  const int wtab = wide_eval(DP, XLDS) ? P.wide_lds_tiles * DP * 64 : 0;  // streamed table: its leading tiles (paired rows: WideEval)
+  double* aw = coords + (XLDS ? tab : wtab) + wave * wslab;
   double* zb = aw + ntiles * (1 + G) * 64;
   if (threadIdx.x < kExpTabLen) smem[threadIdx.x] = kExp2Tab64[threadIdx.x];
   fill_frame_constants<DP>(P, cst);
@@ -1551,6 +1853,13 @@ __global__ __launch_bounds__(SMALL ? 1024 : 512) void kg_mc_kernel(KgMcParams P)
         dst[DP * 64] = xx;
       }
       xs = coords;
+      __syncthreads();
+    }
+    if constexpr (wide_eval(DP, XLDS)) {
+      __syncthreads();  // previous evaluation's readers are done
+      const d2t* src = reinterpret_cast<const d2t*>(xs);
+      d2t* dst = reinterpret_cast<d2t*>(coords);
+      for (int i = threadIdx.x; i < wtab / 2; i += blockDim.x) dst[i] = src[i];
       __syncthreads();
     }
     // sample tickets are drawn ONE AHEAD: the atomic's round trip to L2 overlaps the current sample instead of stalling
@@ -1585,7 +1894,6 @@ __global__ __launch_bounds__(SMALL ? 1024 : 512) void kg_mc_kernel(KgMcParams P)
 // each pass ends with one wavefront sum per wave, one LDS slot per wave, ONE __syncthreads, and a fixed-order sum of the
 // per-wave partials, so every wave takes bit-identical decisions.
 // =====================================================================================================================
-constexpr int kPartLen = 48;       // doubles per partial slot: f | DP gradient sums | G derivative sums (<= 1 + 32 + 12)
 constexpr int kMaxBlockWaves = 8;
 
 // One point's contribution to the accumulators (shared by the LDS-tile loop and the register tiles).
@@ -2118,7 +2426,6 @@ __device__ __forceinline__ void point_weights_pre(const KgMcParams& P, const dou
 }
 
 // Fixed LDS words of the workgroup-per-sample kernel (doubles), before the tile data.
-constexpr int kLsRows = 6;  // line-search vectors per wave in LDS: x | masked gradient | step | x at restart start | x0 and dv of the trial line (frame)
 constexpr int kBlockFixed = kExpTabLen + 2 * kMaxMB + 2 * kMaxBlockWaves * kPartLen + 2 + kMaxBlockWaves * kLsRows * kMaxDimPadded;
 
 template <int DP, int G, int TR>
@@ -2163,7 +2470,14 @@ __global__ __launch_bounds__(512) void kg_mc_block_kernel(KgMcParams P, int num_
     const double* Lsm = rec + P.rec.L;
     const double* We = P.W + (long)e * P.w_stride;
     __syncthreads();  // previous evaluation's readers of the LDS coordinates are done
-    for (int t = threadIdx.x; t < TL * DP * 64; t += blockDim.x) ldsx[t] = tab[t];
+    if constexpr (DP > 16) {  // (the table of the wide dimensions holds its rows in pairs: WideEval)
+      for (int t = threadIdx.x; t < TL * DP * 64; t += blockDim.x) {
+        const int l = t & 63, r = (t >> 6) % DP, tile = (t >> 6) / DP;
+        ldsx[t] = tab[(((long)tile * (DP / 2) + (r >> 1)) * 64 + l) * 2 + (r & 1)];
+      }
+    } else {
+      for (int t = threadIdx.x; t < TL * DP * 64; t += blockDim.x) ldsx[t] = tab[t];
+    }
 #pragma unroll
     for (int t = 0; t < TR; ++t) {
       const int tile = TL + wave * TR + t;

@@ -360,7 +360,8 @@ int moe_debug_math(int n, const double* x, int device, double* exp_neg, double* 
 int moe_last_kernel_ms(const moe_gp_t* gp, double* out5);
 /* Which Monte-Carlo kernel the last moe_kg* call on this handle launched (diagnostics; the tests use it to assert that a
  * fixture really exercised the path it was built for): out[0] = variant (0 wave-per-sample, 1 workgroup-per-sample),
- * out[1] = coordinate table in LDS, out[2] = wavefronts per workgroup, out[3] = register tiles per wavefront (variant 1),
+ * out[1] = coordinate table in LDS, out[2] = wavefronts per workgroup, out[3] = register tiles per wavefront (variant 1) or
+ * leading tiles of the paired-row table kept in LDS (variant 0, d > 16),
  * out[4] = streamed per-sample weight table, out[5] = T-free gradient tail, out[6] = workgroups, out[7] = sample pre-pass. */
 int moe_last_kernel_info(const moe_gp_t* gp, int* out8);
 
