@@ -781,6 +781,11 @@ __global__ __launch_bounds__(256) void kg_sample_weights_kernel(KgMcParams P, do
   const int a = rr % g1;
   const double scale = (a == 0) ? P.alpha : -P.alpha * P.inv_lp[a > 0 ? a - 1 : 0];
   const int s0 = blockIdx.y * samples_per_block, s1 = min(P.num_local, s0 + samples_per_block);
+  // rows behind the training set (v_stride > N: the streamed-weights MC kernel reads whole tiles): the fantasy points' weights are the
+  // sample's beta itself, scaled like a training row (kg_mc.hpp kg_sample), then zeros up to the end of the last tile
+  const int cf = r - P.N;
+  const bool fantasy = cf >= 0 && cf < m;
+  const double fscale = ((cf % g1) == 0) ? P.alpha : -P.alpha * P.inv_lp[max(cf % g1, 1) - 1];
   for (int sl = s0; sl < s1; ++sl) {
     const long so = (long)e * P.num_local + sl;
     const double* __restrict__ bs = beta + so * m;
@@ -788,13 +793,16 @@ __global__ __launch_bounds__(256) void kg_sample_weights_kernel(KgMcParams P, do
 #pragma unroll
     for (int c = 0; c < MB; ++c) v = fma(-l[c], bs[c], v);  // uniform, contiguous: wide scalar loads (reads up to MB - m
                                                             // doubles past the row: next rows / the zeroed pad, times l = 0)
-    if (r < P.N) __builtin_nontemporal_store(v * scale, &V[so * P.N + r]);  // (streaming: 1.28 GB at C5, read once by the MC kernel)
+    if (r < P.N)
+      __builtin_nontemporal_store(v * scale, &V[so * P.v_stride + r]);  // (streaming: 1.28 GB at C5, read once by the MC kernel)
+    else if (r < P.v_stride)
+      V[so * P.v_stride + r] = fantasy ? bs[min(cf, m - 1)] * fscale : 0.0;
   }
 }
 
 void launch_sample_weights(const KgMcParams& P, double* V, hipStream_t s) {
   const int spb = 64;
-  dim3 grid((P.N + 255) / 256, (P.num_local + spb - 1) / spb, P.E);
+  dim3 grid((unsigned)((P.v_stride + 255) / 256), (P.num_local + spb - 1) / spb, P.E);
   if (P.m <= 16)
     hipLaunchKernelGGL(kg_sample_weights_kernel<16>, grid, dim3(256), 0, s, P, V, spb);
   else if (P.m <= 32)
@@ -812,6 +820,18 @@ void launch_mc(const KgMcParams& P, int dp, int G, bool xlds, int blocks, int wa
     case 16: launch_kg_mc_dp16(P, G, xlds, blocks, waves, shm, s); break;
     case 24: launch_kg_mc_dp24(P, G, xlds, blocks, waves, shm, s); break;
     case 32: launch_kg_mc_dp32(P, G, xlds, blocks, waves, shm, s); break;
+    default: throw Error(MOE_ERR_RUNTIME, "unsupported padded dimension");
+  }
+}
+
+void launch_mc_stream(const KgMcParams& P, int dp, int G, int blocks, int waves, size_t shm, hipStream_t s) {
+  switch (dp) {
+    case 4: launch_kg_mc_stream_dp4(P, G, blocks, waves, shm, s); break;
+    case 8: launch_kg_mc_stream_dp8(P, G, blocks, waves, shm, s); break;
+    case 12: launch_kg_mc_stream_dp12(P, G, blocks, waves, shm, s); break;
+    case 16: launch_kg_mc_stream_dp16(P, G, blocks, waves, shm, s); break;
+    case 24: launch_kg_mc_stream_dp24(P, G, blocks, waves, shm, s); break;
+    case 32: launch_kg_mc_stream_dp32(P, G, blocks, waves, shm, s); break;
     default: throw Error(MOE_ERR_RUNTIME, "unsupported padded dimension");
   }
 }
@@ -949,8 +969,30 @@ KgPending kg_launch(GpDev& gp, int num_fidelity, const moe_gd_params_t& gd, cons
   // with derivative observations (a point's 1 + G weights make the slabs bigger) the streamed kernel wins while five of them fit:
   // d = 12, g = 3, q = 8, M = 4000: n = 800 0.86 vs 1.10 ms; with four (n = 1200) 1.28 vs 1.21
   if (G > 0 && G <= 4 && !far_frame && !xlds && waves >= 5) variant = 0;
-  variant = env_int("MOE_KG_VARIANT", variant);
   if (G > 4 || m > kMaxM) variant = 1;  // (the wave-per-sample kernel: up to four derivative slots, one lane per component)
+  // Variant 2, the streamed-weights wave-per-sample kernel (kg_mc.hpp kg_mc_stream_kernel), takes what would go to the
+  // workgroup-per-sample kernel whenever the per-sample weight table (fantasy points and tile padding included) fits its cap and
+  // every derivative slot is an observed derivative (a point's table rows ARE its weights)
+  const int prep_mode = env_int("MOE_KG_PREP", -1);
+  const long v_stride_tiles = (long)ntiles * 64 * g1;
+  const double v_cap = std::getenv("MOE_KG_V_MAX_GB") ? (double)env_int("MOE_KG_V_MAX_GB", 4)
+                                                      : (weight_table_gb >= 0.0 ? weight_table_gb : 4.0);
+  const bool stream_ok = g1 == 1 + G && G <= 4 && m <= kMaxM && prep_mode != 0 &&
+                         8.0 * (double)v_stride_tiles * (double)E * (double)num_local / 1e9 <= v_cap;
+  if (stream_ok && env_int("MOE_KG_STREAM_WEIGHTS", 1) != 0) {
+    // (r3, ms of MC per evaluation, `profiles/r03_variant2_sweep.txt`: C5 7.9 -> 5.0; d = 12, g = 3, q = 8, M = 4000: n = 1200 1.24 -> 0.68 against the
+    //  workgroup-per-sample kernel, n = 800 0.80 -> 0.48 against the wave-per-sample kernel streaming its coordinates with five weight
+    //  slabs in LDS; without derivative observations it pays once fewer than five slabs fit: n = 6000, d = 8 5.79 -> 4.96, but n = 3000
+    //  -- six slabs -- 2.18 -> 2.34)
+    if (variant == 1) variant = 2;
+    else if (variant == 0 && !xlds && (G > 0 || waves <= 4)) variant = 2;
+  }
+  {
+    const int forced = env_int("MOE_KG_VARIANT", variant);
+    if (forced == 2 && !stream_ok)
+      throw Error(MOE_ERR_RUNTIME, "the streamed-weights MC kernel needs the weight table within its cap, (q + p)(1 + g) <= 64 and g <= 4");
+    if (!(forced != variant && (G > 4 || m > kMaxM))) variant = forced;  // (shapes only the workgroup-per-sample kernel is built for stay there)
+  }
   if (variant == 1 && (tr < 0 || kg_mc_block_lds_bytes(dp, G, num_lds_tiles) > (size_t)160 * 1024))
     throw Error(MOE_ERR_RUNTIME, "point set too large for the workgroup-per-sample MC kernel");
   if (variant == 0 && waves < 1)
@@ -968,6 +1010,12 @@ KgPending kg_launch(GpDev& gp, int num_fidelity, const moe_gd_params_t& gd, cons
       wide_lds_tiles = std::max(0, std::min(wide_lds_tiles, env_int("MOE_KG_WIDE_LDS_TILES", wide_lds_tiles)));
       shm += sizeof(double) * (size_t)wide_lds_tiles * dp * 64;
     }
+  } else if (variant == 2) {
+    waves = std::max(1, std::min(8, env_int("MOE_KG_WAVES", 8)));
+    shm = sizeof(double) * (kExpTabLen + (size_t)waves * mc::kWideScratch);
+    wide_lds_tiles = (int)std::min<size_t>((size_t)ntiles, ((size_t)160 * 1024 - shm) / (sizeof(double) * dp * 64));
+    wide_lds_tiles = std::max(0, std::min(wide_lds_tiles, env_int("MOE_KG_WIDE_LDS_TILES", wide_lds_tiles)));
+    shm += sizeof(double) * (size_t)wide_lds_tiles * dp * 64;
   } else {
     waves = bwaves;
   }
@@ -1185,7 +1233,7 @@ KgPending kg_launch(GpDev& gp, int num_fidelity, const moe_gd_params_t& gd, cons
   {
     dim3 grid((unsigned)((tab_stride + 255) / 256), E);
     hipLaunchKernelGGL(build_xs_tab_kernel, grid, dim3(256), 0, s, gp.dX.p, n, gp.dPts.p, u, dp, ntiles, tp, dTab.p, tab_stride,
-                       (wide_dp || (variant == 0 && mc::wide_eval(dp, xlds))) ? 1 : 0);
+                       (wide_dp || variant == 2 || (variant == 0 && mc::wide_eval(dp, xlds))) ? 1 : 0);
     MOE_HIP_CHECK(hipGetLastError());
   }
   const double ms_state = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wall0).count();
@@ -1248,8 +1296,7 @@ KgPending kg_launch(GpDev& gp, int num_fidelity, const moe_gd_params_t& gd, cons
   // workgroup-per-sample kernel, where seven wavefronts would wait for one; the wave-per-sample kernel hides those loads
   // behind the other wavefront of its SIMD (measured: no difference at C3), so it only takes the pre-pass on request
   // (MOE_KG_PREP=1; MOE_KG_PREP=0: never)
-  const int prep_mode = env_int("MOE_KG_PREP", -1);
-  if (m > kMaxM || (prep_mode != 0 && (variant == 1 || prep_mode == 1))) {
+  if (m > kMaxM || (prep_mode != 0 && (variant >= 1 || prep_mode == 1))) {
     gp.kBestJ.reserve((size_t)E * num_local);
     mp.best_j = gp.kBestJ.p;
     const long total = (long)E * num_local;
@@ -1261,23 +1308,26 @@ KgPending kg_launch(GpDev& gp, int num_fidelity, const moe_gd_params_t& gd, cons
     }
     MOE_HIP_CHECK(hipGetLastError());
   }
-  if (variant == 1 && mp.best_j != nullptr) {
+  mp.v_stride = (variant == 2) ? v_stride_tiles : N;
+  if (variant >= 1 && mp.best_j != nullptr) {
     const long total = (long)E * num_local;
     // the weight table: N doubles per sample (1.28 GB per evaluation at C5); beyond its cap -- the caller's share of the
     // workspace budget (kg_evaluate_batch, kg_mcmc_sums), MOE_KG_V_MAX_GB (default 4) for a bare kg_launch -- the samples
-    // compute their weights in the kernel
-    const double v_gb = 8.0 * (double)N * (double)total / 1e9;
-    const double v_cap = std::getenv("MOE_KG_V_MAX_GB") ? (double)env_int("MOE_KG_V_MAX_GB", 4)
-                                                        : (weight_table_gb >= 0.0 ? weight_table_gb : 4.0);
+    // compute their weights in the kernel (workgroup-per-sample kernel only: the streamed-weights one is not chosen beyond the cap)
+    const double v_gb = 8.0 * (double)mp.v_stride * (double)total / 1e9;
     if (v_gb <= v_cap && m <= kMaxM) {  // (the table kernel keeps a row of W in registers: m <= 64; beyond, weights in the kernel)
-      gp.kV.reserve((size_t)N * (size_t)total);
+      gp.kV.reserve((size_t)mp.v_stride * (size_t)total + (size_t)64 * g1);  // (+ one tile: the sweeps prefetch one tile ahead)
       MOE_HIP_CHECK(hipMemsetAsync(dBeta.p + (size_t)total * m, 0, sizeof(double) * 64, s));
       mp.V = gp.kV.p;
       launch_sample_weights(mp, gp.kV.p, s);
     }
   }
+  if (variant == 2 && (mp.V == nullptr || mp.best_j == nullptr))
+    throw Error(MOE_ERR_RUNTIME, "streamed-weights MC kernel selected without its weight table");
   if (variant == 0)
     launch_mc(mp, dp, G, xlds, blocks, waves, shm, s);
+  else if (variant == 2)
+    launch_mc_stream(mp, dp, G, blocks, waves, shm, s);
   else
     launch_mc_block(mp, dp, G, tr, num_lds_tiles, blocks, waves, s);
   t_mc.stop(s);

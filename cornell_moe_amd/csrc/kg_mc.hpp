@@ -94,7 +94,9 @@ struct KgMcParams {
   unsigned long long* counters;  // [E][2]: value passes, value + gradient passes
   unsigned int* next_sample;     // [E] work counters (zeroed before launch)
   unsigned long long* prof;      // 16 spare words behind the counters (MOE_BLOCK_PROF builds)
-  const double* V;               // [E][num_local][N] per-sample weights alpha-scaled (kg_sample_weights_kernel, kg.hip), or NULL
+  const double* V;               // [E][num_local][v_stride] per-sample weights alpha-scaled (kg_sample_weights_kernel, kg.hip), or NULL
+  long v_stride;                 // N (workgroup-per-sample kernel) or ntiles * 64 * (1 + g): the fantasy points' weights and the zero
+                                 // padding included (streamed-weights kernel, kg_mc_stream_kernel)
   const int* best_j;             // [E][num_local] start point of every sample's line search, precomputed with beta by
                                  // kg_sample_prep_kernel (kg.hip); NULL = each sample computes them itself
 };
@@ -108,6 +110,14 @@ void launch_kg_mc_dp16(const KgMcParams& P, int G, bool xlds, int blocks, int wa
 // coordinates streamed from L2 only) and {0, 4, 8, 12} with all tiles in LDS (workgroup-per-sample kernel)
 void launch_kg_mc_dp24(const KgMcParams& P, int G, bool xlds, int blocks, int waves, size_t shm, hipStream_t s);
 void launch_kg_mc_dp32(const KgMcParams& P, int G, bool xlds, int blocks, int waves, size_t shm, hipStream_t s);
+
+// Streamed-weights wave-per-sample kernel (kg_mc_stream_kernel): weights from the table P.V, P.wide_lds_tiles tiles of coordinates in LDS.
+void launch_kg_mc_stream_dp4(const KgMcParams& P, int G, int blocks, int waves, size_t shm, hipStream_t s);
+void launch_kg_mc_stream_dp8(const KgMcParams& P, int G, int blocks, int waves, size_t shm, hipStream_t s);
+void launch_kg_mc_stream_dp12(const KgMcParams& P, int G, int blocks, int waves, size_t shm, hipStream_t s);
+void launch_kg_mc_stream_dp16(const KgMcParams& P, int G, int blocks, int waves, size_t shm, hipStream_t s);
+void launch_kg_mc_stream_dp24(const KgMcParams& P, int G, int blocks, int waves, size_t shm, hipStream_t s);
+void launch_kg_mc_stream_dp32(const KgMcParams& P, int G, int blocks, int waves, size_t shm, hipStream_t s);
 
 // Workgroup-per-sample variant: the first `num_lds_tiles` tiles of 64 points in LDS, `tr` (0, 2 or 4) register tiles per
 // wavefront for the rest; bytes of dynamic LDS = kg_mc_block_lds_bytes(...).
@@ -682,6 +692,9 @@ __device__ __forceinline__ void from_table_order(const double (&v)[DP], const in
   }
 }
 
+#ifndef MOE_KG_STREAM_TRIALS
+#define MOE_KG_STREAM_TRIALS 8
+#endif
 constexpr int kPartLen = 48;  // doubles per partial slot of a packed reduction: f | DP gradient sums | sum of coefficients | G derivative sums (<= 1 + 32 + 1 + 12)
 constexpr int kLsRows = 6;    // line-search vectors per wave in LDS (line_search_lds): x | masked gradient | step | x at restart start | x0 and dv of the trial line (frame)
 // per-wave LDS scratch of the wide-dimension evaluator (WideEval, d > 16) behind the z / beta scratch of a weight slab
@@ -1325,16 +1338,50 @@ __device__ __forceinline__ double line_search_lds(const KgMcParams& P, EV& ev, d
 typedef double d2t __attribute__((ext_vector_type(2)));
 typedef const __attribute__((address_space(3))) d2t* lds_pair_ptr;
 
-template <int DP, int G>
+// Where a sweep takes the 1 + G weights of a lane's point from: the wave's LDS slab [tile][1 + G][64] (+ lane), or the sample's row of
+// the weight table in global memory, [point][1 + G] (+ lane (1 + G)) -- the rows of a point travel as 16-byte pairs when there is an
+// even number of them.
+template <int G, bool WS>
+struct WeightPtr {
+  lds_tile_ptr p;
+  __device__ __forceinline__ void load(double (&cw)[1 + G]) const {
+#pragma unroll
+    for (int a = 0; a < 1 + G; ++a) cw[a] = p[a * 64];
+  }
+  __device__ __forceinline__ void next() { p += (1 + G) * 64; }
+};
+template <int G>
+struct WeightPtr<G, true> {
+  const double* __restrict__ p;
+  __device__ __forceinline__ void load(double (&cw)[1 + G]) const {
+    if constexpr (((1 + G) & 1) == 0) {
+      const d2t* q = reinterpret_cast<const d2t*>(p);
+#pragma unroll
+      for (int a2 = 0; a2 < (1 + G) / 2; ++a2) {
+        const d2t v = q[a2];
+        cw[2 * a2] = v.x;
+        cw[2 * a2 + ((1 + G) > 1 ? 1 : 0)] = v.y;
+      }
+    } else {
+#pragma unroll
+      for (int a = 0; a < 1 + G; ++a) cw[a] = p[a];
+    }
+  }
+  __device__ __forceinline__ void next() { p += 64 * (1 + G); }
+};
+
+template <int DP, int G, bool WS = false>
 struct WideEval {
   const d2t* __restrict__ xg;   // coordinate table of this evaluation in global memory (one tile of padding behind), + lane
   lds_pair_ptr xl;              // LDS copy of its first `ntl` tiles, + lane
-  const double* __restrict__ aw;    // this wave's weights [tile][1 + G][64] in LDS
+  WeightPtr<G, WS> w0;              // this sample's weights, first tile (see WeightPtr)
   const double* __restrict__ etab;
   double* __restrict__ red;         // kPartLen doubles of LDS, private to the wave: packed sums of a gradient pass
   int ntiles, ntl, cov_type, lane;
   double mean;
-  static constexpr int kMaxTrials = 5;
+  // Armijo trials per sweep: with the weights streamed from the table a sweep is bound by that stream (64 KB per sample and sweep at
+  // C5), so a step's whole bracket goes into ONE sweep whenever the previous step's bracket predicts up to eight trials
+  static constexpr int kMaxTrials = WS ? MOE_KG_STREAM_TRIALS : 5;
   static constexpr int HP = DP / 2;                        // row pairs per tile
   static constexpr int PF2 = (HP <= 8) ? HP : ((HP % 8 == 0) ? 8 : 6);  // ring depth in row pairs
   static_assert(HP % PF2 == 0 && PF2 <= HP, "ring slots must be static");
@@ -1345,15 +1392,14 @@ struct WideEval {
 
   // one segment (LDS or L2 tiles) of a T-trial value sweep; `wt` walks on through the weight slab
   template <int COV, int T, class PP>
-  __device__ __forceinline__ void segT(PP xt, lds_tile_ptr& wt, int nt, const double (&x0)[DP], const double (&dv)[DP],
+  __device__ __forceinline__ void segT(PP xt, WeightPtr<G, WS>& wt, int nt, const double (&x0)[DP], const double (&dv)[DP],
                                        const double (&al)[T], double dd, double (&acc)[T]) {
     if (nt <= 0) return;
     d2t ring[PF2];
     double cw[1 + G];
 #pragma unroll
     for (int i = 0; i < PF2; ++i) ring[i] = xt[i * 64];
-#pragma unroll
-    for (int a = 0; a < 1 + G; ++a) cw[a] = wt[a * 64];
+    wt.load(cw);
 #pragma unroll 1
     for (int tile = 0; tile < nt; ++tile) {
       double A = 1.0e-300, B = 0.0, sdA = 0.0, sdB = 0.0;
@@ -1374,10 +1420,9 @@ struct WideEval {
         }
       }
       xt += HP * 64;
-      wt += (1 + G) * 64;
+      wt.next();
       double nw[1 + G];
-#pragma unroll
-      for (int a = 0; a < 1 + G; ++a) nw[a] = wt[a * 64];
+      wt.load(nw);  // (the last tile's prefetch reads one tile past the sample's weights: padded / the next sample's, unused)
       const double mB2 = -2.0 * B;
 #pragma unroll
       for (int t = 0; t < T; ++t) {
@@ -1398,7 +1443,7 @@ struct WideEval {
     double acc[T];
 #pragma unroll
     for (int t = 0; t < T; ++t) acc[t] = 0.0;
-    lds_tile_ptr wt = (lds_tile_ptr)(aw + lane);
+    WeightPtr<G, WS> wt = w0;
     if (cov_type == MOE_COV_SQUARE_EXPONENTIAL) {
       segT<MOE_COV_SQUARE_EXPONENTIAL, T>(xl, wt, ntl, x0, dv, al, dd, acc);
       segT<MOE_COV_SQUARE_EXPONENTIAL, T>(xg + (long)ntl * HP * 64, wt, ntiles - ntl, x0, dv, al, dd, acc);
@@ -1459,7 +1504,18 @@ struct WideEval {
       case 2: armijo_t<2>(x0, dv, dd, f0, norm, alpha_n, search, ftrial, done, n_val); break;
       case 3: armijo_t<3>(x0, dv, dd, f0, norm, alpha_n, search, ftrial, done, n_val); break;
       case 4: armijo_t<4>(x0, dv, dd, f0, norm, alpha_n, search, ftrial, done, n_val); break;
-      default: armijo_t<5>(x0, dv, dd, f0, norm, alpha_n, search, ftrial, done, n_val); break;
+      case 5: armijo_t<5>(x0, dv, dd, f0, norm, alpha_n, search, ftrial, done, n_val); break;
+      default:
+        if constexpr (kMaxTrials > 5) {
+          switch (want) {
+            case 6: armijo_t<6>(x0, dv, dd, f0, norm, alpha_n, search, ftrial, done, n_val); break;
+            case 7: armijo_t<7>(x0, dv, dd, f0, norm, alpha_n, search, ftrial, done, n_val); break;
+            default: armijo_t<8>(x0, dv, dd, f0, norm, alpha_n, search, ftrial, done, n_val); break;
+          }
+        } else {
+          armijo_t<5>(x0, dv, dd, f0, norm, alpha_n, search, ftrial, done, n_val);
+        }
+        break;
     }
   }
 
@@ -1492,15 +1548,14 @@ struct WideEval {
 
   // one segment of a gradient sweep
   template <int COV, class PP>
-  __device__ __forceinline__ void segG(PP xt, lds_tile_ptr& wt, int nt, const double (&xq)[DP], double& accf, double& accs,
+  __device__ __forceinline__ void segG(PP xt, WeightPtr<G, WS>& wt, int nt, const double (&xq)[DP], double& accf, double& accs,
                                        double (&accg)[DP], double (&accd)[G > 0 ? G : 1]) {
     if (nt <= 0) return;
     d2t cx[HP];
     double cw[1 + G];
 #pragma unroll
     for (int i = 0; i < HP; ++i) cx[i] = xt[i * 64];
-#pragma unroll
-    for (int a = 0; a < 1 + G; ++a) cw[a] = wt[a * 64];
+    wt.load(cw);
 #pragma unroll 1
     for (int tile = 0; tile < nt; ++tile) {
       double r2 = 1.0e-300, sd = 0.0;
@@ -1523,15 +1578,14 @@ struct WideEval {
       }
       accs += coef;
       xt += HP * 64;
-      wt += (1 + G) * 64;
+      wt.next();
 #pragma unroll
       for (int i = 0; i < HP; ++i) {
         accg[2 * i] = fma(coef, cx[i].x, accg[2 * i]);
         accg[2 * i + 1] = fma(coef, cx[i].y, accg[2 * i + 1]);
         cx[i] = xt[i * 64];  // the pair's slot is free: the next tile's rows (behind the segment: unused)
       }
-#pragma unroll
-      for (int a = 0; a < 1 + G; ++a) cw[a] = wt[a * 64];
+      wt.load(cw);
     }
   }
 
@@ -1552,7 +1606,7 @@ struct WideEval {
     for (int k = 0; k < DP; ++k) accg[k] = 0.0;
 #pragma unroll
     for (int a = 0; a < (G > 0 ? G : 1); ++a) accd[a] = 0.0;
-    lds_tile_ptr wt = (lds_tile_ptr)(aw + lane);
+    WeightPtr<G, WS> wt = w0;
     if (cov_type == MOE_COV_SQUARE_EXPONENTIAL) {
       segG<MOE_COV_SQUARE_EXPONENTIAL>(xl, wt, ntl, xq, accf, accs, accg, accd);
       segG<MOE_COV_SQUARE_EXPONENTIAL>(xg + (long)ntl * HP * 64, wt, ntiles - ntl, xq, accf, accs, accg, accd);
@@ -1776,7 +1830,7 @@ __device__ __forceinline__ void kg_sample(const KgMcParams& P, int e, int sl, co
     double* st = zb + 2 * kMaxM;  // line-search vectors | packed-sum slot: kWideScratch doubles behind the z / beta scratch
     const d2t* xg = reinterpret_cast<const d2t*>(xs) + lane;
     lds_pair_ptr xl = (lds_pair_ptr)(cst + kCstRows * DP) + lane;  // the workgroup's LDS copy of the first tiles (kg_mc_kernel)
-    WideEval<DP, G> ev{xg, xl, aw, etab, st + kLsRows * kMaxDimPadded, P.ntiles, P.wide_lds_tiles, P.cov_type, lane, P.mean};
+    WideEval<DP, G> ev{xg, xl, {(lds_tile_ptr)(aw + lane)}, etab, st + kLsRows * kMaxDimPadded, P.ntiles, P.wide_lds_tiles, P.cov_type, lane, P.mean};
     fcur = line_search_lds<DP, G>(P, ev, st, x, n_val, n_grad);
   } else {
     WaveEval<DP, G, SMALL, XL> ev{xs, aw, etab, P.ntiles, P.cov_type, P.mean, P.inv_lp, lane, zb + DP};
@@ -1879,6 +1933,104 @@ __global__ __launch_bounds__(SMALL ? 1024 : 512) void kg_mc_kernel(KgMcParams P)
       atomicAdd(&P.counters[2 * e + 1], tot_grad);
     }
     if (gridDim.x >= (unsigned)P.E) break;
+  }
+}
+
+// =====================================================================================================================
+// Streamed-weights variant of the wave-per-sample kernel (r3), for point sets whose per-sample weights are too large for eight
+// LDS slabs (d-KG at n = 2000 with 3 observed derivatives: 64 KB per sample).  The sample pre-pass (kg_sample_prep_kernel) and the
+// weight table V (kg_sample_weights_kernel: every sample's weights, the fantasy points' and the zero padding included) exist
+// already for the workgroup-per-sample kernel; here a WAVE owns a sample and reads its row of V inside the sweeps (16-byte loads, two per
+// point at g = 3; a sample's 64 KB are re-read once per sweep -- eight waves x 256 CUs keep 131 MB of rows live, which the
+// Infinity Cache holds), so the 160 KB of LDS serve the COORDINATES, shared by the workgroup's eight waves (22 of C5's 32
+// tiles; the rest streams from L2).  No barrier, no lock-step line search: the passes are WideEval's.
+// LDS: [64] exp table | leading tiles of the paired-row table | per wave: kWideScratch doubles.
+// =====================================================================================================================
+template <int DP, int G>
+__global__ __launch_bounds__(512) void kg_mc_stream_kernel(KgMcParams P) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int wtab = P.wide_lds_tiles * DP * 64;
+  double* coords = smem + kExpTabLen;
+  double* st = coords + wtab + wave * kWideScratch;
+  if (threadIdx.x < kExpTabLen) smem[threadIdx.x] = kExp2Tab64[threadIdx.x];
+  const int size = P.dim - P.f;
+  for (int e = blockIdx.x % P.E; e < P.E; e += (gridDim.x < (unsigned)P.E ? gridDim.x : P.E)) {
+    const double* xs = P.XsTab + (long)e * P.tab_stride;
+    const double* rec = P.blob + (long)e * P.rec.stride;
+    __syncthreads();  // previous evaluation's readers are done (and the exp table is visible)
+    {
+      const d2t* src = reinterpret_cast<const d2t*>(xs);
+      d2t* dst = reinterpret_cast<d2t*>(coords);
+      for (int i = threadIdx.x; i < wtab / 2; i += blockDim.x) dst[i] = src[i];
+    }
+    __syncthreads();
+    unsigned int ticket = 0;  // drawn one ahead (see kg_mc_kernel)
+    unsigned int* next = P.next_sample + (long)e * kTicketStride;
+    if (lane == 0) ticket = atomicAdd(next, 1u);
+    unsigned long long tot_val = 0, tot_grad = 0;
+    while (true) {
+      const unsigned int sl = (unsigned int)__builtin_amdgcn_readfirstlane((int)ticket);
+      if (sl >= (unsigned int)P.num_local) break;
+      if (lane == 0) ticket = atomicAdd(next, 1u);
+      const long so = (long)e * P.num_local + sl;
+      const int best_j = P.best_j[so];
+      const double* disc = rec + P.rec.disc;
+      double x[DP];
+#pragma unroll
+      for (int k = 0; k < DP; ++k) x[k] = (k < size) ? disc[(long)best_j * size + k] : ((k < P.dim) ? 1.0 : 0.0);
+      const d2t* xg = reinterpret_cast<const d2t*>(xs) + lane;
+      lds_pair_ptr xl = (lds_pair_ptr)coords + lane;
+      WideEval<DP, G, true> ev{xg, xl, {P.V + so * P.v_stride + (long)lane * (1 + G)}, smem, st + kLsRows * kMaxDimPadded,
+                               P.ntiles, P.wide_lds_tiles, P.cov_type, lane, P.mean};
+      unsigned long long n_val = 0, n_grad = 0;
+      const double fcur = line_search_lds<DP, G>(P, ev, st, x, n_val, n_grad);
+      if (lane == 0) P.best_value[so] = fcur;
+      tot_val += n_val;
+      tot_grad += n_grad;
+      if (lane < DP) {
+        double v = 0.0;
+#pragma unroll
+        for (int k = 0; k < DP; ++k)
+          if (lane == k) v = x[k];
+        P.best_point[so * DP + lane] = v;
+      }
+    }
+    if (lane == 0 && (tot_val | tot_grad) != 0) {
+      atomicAdd(&P.counters[2 * e], tot_val);
+      atomicAdd(&P.counters[2 * e + 1], tot_grad);
+    }
+    if (gridDim.x >= (unsigned)P.E) break;
+  }
+}
+
+template <int DP, int G>
+inline void launch_stream_inst(const KgMcParams& P, int blocks, int waves, size_t shm, hipStream_t s) {
+  auto kern = kg_mc_stream_kernel<DP, G>;
+  MOE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+  hipLaunchKernelGGL(kern, dim3(blocks), dim3(waves * 64), shm, s, P);
+  MOE_HIP_CHECK(hipGetLastError());
+}
+
+// built for 1 .. 4 derivative slots with every slot observed (1 + g == 1 + G: the table rows of a point are its weights)
+template <int DP>
+inline void launch_stream_dp(const KgMcParams& P, int G, int blocks, int waves, size_t shm, hipStream_t s) {
+  switch (G) {
+    case 0: launch_stream_inst<DP, 0>(P, blocks, waves, shm, s); break;
+    case 1: launch_stream_inst<DP, 1>(P, blocks, waves, shm, s); break;
+    case 2: launch_stream_inst<DP, 2>(P, blocks, waves, shm, s); break;
+    case 3: launch_stream_inst<DP, 3>(P, blocks, waves, shm, s); break;
+    case 4: launch_stream_inst<DP, 4>(P, blocks, waves, shm, s); break;
+    default: throw Error(MOE_ERR_RUNTIME, "unsupported derivative-slot count in the streamed-weights MC kernel");
+  }
+}
+template <int DP>
+inline void launch_stream_dp_wide(const KgMcParams& P, int G, int blocks, int waves, size_t shm, hipStream_t s) {
+  switch (G) {
+    case 0: launch_stream_inst<DP, 0>(P, blocks, waves, shm, s); break;
+    case 4: launch_stream_inst<DP, 4>(P, blocks, waves, shm, s); break;
+    default: throw Error(MOE_ERR_RUNTIME, "unsupported derivative-slot count in the streamed-weights MC kernel");
   }
 }
 
@@ -2523,7 +2675,7 @@ __global__ __launch_bounds__(512) void kg_mc_block_kernel(KgMcParams P, int num_
       {
         double* wdst = ldsw + (long)tl0 * (1 + G) * 64 + lane;
         if (P.V != nullptr) {
-          const double* Vs = P.V + ((long)e * P.num_local + sl) * P.N;
+          const double* Vs = P.V + ((long)e * P.num_local + sl) * P.v_stride;
 #pragma unroll 2
           for (int t = tl0; t < tl1; ++t) {
             double w[1 + G];

@@ -12,4 +12,8 @@ void launch_kg_mc_block_dp24(const KgMcParams& P, int G, int tr, int num_lds_til
   mc::launch_block_dp_wide<24>(P, G, tr, num_lds_tiles, blocks, waves, s);
 }
 
+void launch_kg_mc_stream_dp24(const KgMcParams& P, int G, int blocks, int waves, size_t shm, hipStream_t s) {
+  mc::launch_stream_dp_wide<24>(P, G, blocks, waves, shm, s);
+}
+
 }  // namespace moe

@@ -15,4 +15,8 @@ size_t kg_mc_block_lds_bytes(int dp, int G, int num_lds_tiles) {
   return sizeof(double) * (mc::kBlockFixed + (size_t)num_lds_tiles * (dp + 1 + G) * 64);
 }
 
+void launch_kg_mc_stream_dp4(const KgMcParams& P, int G, int blocks, int waves, size_t shm, hipStream_t s) {
+  mc::launch_stream_dp<4>(P, G, blocks, waves, shm, s);
+}
+
 }  // namespace moe

@@ -11,4 +11,8 @@ void launch_kg_mc_block_dp8(const KgMcParams& P, int G, int tr, int num_lds_tile
   mc::launch_block_dp<8>(P, G, tr, num_lds_tiles, blocks, waves, s);
 }
 
+void launch_kg_mc_stream_dp8(const KgMcParams& P, int G, int blocks, int waves, size_t shm, hipStream_t s) {
+  mc::launch_stream_dp<8>(P, G, blocks, waves, shm, s);
+}
+
 }  // namespace moe
