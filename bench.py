@@ -461,7 +461,8 @@ def main():
         cov_launch_ms, cov_bytes_launch = G.cov_build_probe(probe_pts, repeat=10)
         cov_bytes = cov_bytes_launch / Rp                                   # 8[nA d + nB d + nA nB]
         cov_tbs = cov_bytes_launch / (cov_launch_ms * 1e-3) / 1e12 if cov_launch_ms > 0 else 0.0
-        mc_kernel = "kg_mc_kernel" if (w.g == 0 and w.n + w.q <= 1600) else "kg_mc_block_kernel"
+        # (which MC kernel the library launched for this shape: wave-per-sample, workgroup-per-sample, or streamed-weights -- r3)
+        mc_kernel = {0: "kg_mc_kernel", 1: "kg_mc_block_kernel", 2: "kg_mc_stream_kernel"}[G.last_kernel_info()["variant"]]
         pmc, traffic_src = (None, "skipped (--no-traffic)")
         if world == 1 and not args.no_traffic:
             pmc, traffic_src = measure_traffic(args.config, Rl, log)

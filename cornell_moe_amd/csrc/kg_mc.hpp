@@ -695,6 +695,12 @@ __device__ __forceinline__ void from_table_order(const double (&v)[DP], const in
 #ifndef MOE_KG_STREAM_TRIALS
 #define MOE_KG_STREAM_TRIALS 8
 #endif
+#ifndef MOE_KG_STREAM_FIRST
+#define MOE_KG_STREAM_FIRST 6
+#endif
+#ifndef MOE_KG_STREAM_FOLLOWUP
+#define MOE_KG_STREAM_FOLLOWUP 4
+#endif
 constexpr int kPartLen = 48;  // doubles per partial slot of a packed reduction: f | DP gradient sums | sum of coefficients | G derivative sums (<= 1 + 32 + 1 + 12)
 constexpr int kLsRows = 6;    // line-search vectors per wave in LDS (line_search_lds): x | masked gradient | step | x at restart start | x0 and dv of the trial line (frame)
 // per-wave LDS scratch of the wide-dimension evaluator (WideEval, d > 16) behind the z / beta scratch of a weight slab
@@ -1184,7 +1190,9 @@ __device__ __forceinline__ double line_search_lds(const KgMcParams& P, EV& ev, d
   for (int k = 0; k < DP; ++k) sX[k] = tq[k];
 #pragma unroll
   for (int k = 0; k < DP; ++k) gp[k] = 0.0;
-  int pred = 2;  // Armijo trials the previous step of this sample consumed (>= 2): the size of the next step's first batch
+  // Armijo trials the previous step of this sample consumed (>= 2): the size of the next step's first batch.  (A sample's first step:
+  // two -- or six where a sweep is bound by the weight stream, the streamed-weights kernel: a bracket there is ~6 trials long.)
+  int pred = (EV::kMaxTrials > 5) ? MOE_KG_STREAM_FIRST : 2;
 #if MOE_BLOCK_PROF
   ev.seg_last = __builtin_amdgcn_s_memtime();
   ev.seg_tot = ev.c_tot;
@@ -1263,7 +1271,9 @@ __device__ __forceinline__ double line_search_lds(const KgMcParams& P, EV& ev, d
               if (++search >= 30) break;
             }
           }
-          batch = 2;
+          // follow-up batches: pairs -- or fours where a sweep is bound by the weight stream, not by its trials (streamed-weights
+          // kernel: kMaxTrials > 5), so that a bracket longer than predicted costs one more sweep, not two or three
+          batch = (EV::kMaxTrials > 5) ? MOE_KG_STREAM_FOLLOWUP : 2;
         }
         pred = max(2, min(search + 1, EV::kMaxTrials));
 #if MOE_BLOCK_PROF
