@@ -1534,7 +1534,8 @@ int kg_max_batch(const GpDev& gp, int P, int q, int p, int num_local, bool want_
   const double chunks = std::ceil((double)num_local / (fused ? kFusedChunk : kTbChunk));
   double doubles = 3.0 * N * (m + ngrad + A) + (double)num_local * (gp.dp + 1 + 2 * m);
   if (want_grad) doubles += (fused ? 0.0 : N * (double)num_local) + (chunks + 1.0) * m * N;
-  if (gp.g > 0 || gp.n + u > 1500) doubles += N * (double)num_local;  // the workgroup-per-sample kernel's weight table
+  // the per-sample weight table of the workgroup-per-sample / streamed-weights kernels (the latter: whole tiles, fantasy points included)
+  if (gp.g > 0 || gp.n + u > 1500) doubles += (N + (u + 64.0) * g1) * (double)num_local;
   const double per_eval_gb = 8.0 * doubles / 1e9;
   return (int)std::max(1.0, std::floor(budget_gb / std::max(per_eval_gb, 1e-9)));
 }

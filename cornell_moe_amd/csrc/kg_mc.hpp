@@ -1390,8 +1390,10 @@ struct WideEval {
   int ntiles, ntl, cov_type, lane;
   double mean;
   // Armijo trials per sweep: with the weights streamed from the table a sweep is bound by that stream (64 KB per sample and sweep at
-  // C5), so a step's whole bracket goes into ONE sweep whenever the previous step's bracket predicts up to eight trials
-  static constexpr int kMaxTrials = WS ? MOE_KG_STREAM_TRIALS : 5;
+  // C5), so a step's whole bracket goes into ONE sweep whenever the previous step's bracket predicts up to eight trials.
+  // (the L2-streamed sweeps of 16 / 24 rows gain too -- n = 1000: d = 16 0.257 -> 0.230 ms, d = 24 0.306 -> 0.296; at 32 rows the eight
+  //  accumulators cost more registers than the saved sweeps give back: 0.403 -> 0.429 -- r3, `profiles/r03_dim_sweep_after.txt`)
+  static constexpr int kMaxTrials = (WS || DP <= 24) ? MOE_KG_STREAM_TRIALS : 5;
   static constexpr int HP = DP / 2;                        // row pairs per tile
   static constexpr int PF2 = (HP <= 8) ? HP : ((HP % 8 == 0) ? 8 : 6);  // ring depth in row pairs
   static_assert(HP % PF2 == 0 && PF2 <= HP, "ring slots must be static");

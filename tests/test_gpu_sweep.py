@@ -76,14 +76,21 @@ def test_kg_against_oracle(case, monkeypatch):
     scale = max(float(np.abs(ro["grad"]).max()), abs(ro["kg"]))
     ptol = 1e-8 if gd[1] * gd[2] <= 8 else 1e-6
     # both MC kernels, and the wave-per-sample kernel with the sample pre-pass off (beta / discretised-set scan in the kernel)
-    for variant, prep in (("0", "1"), ("1", "1"), ("0", "0")):
-        if (len(w.derivs) > 4 or (w.q + w.p) * (1 + len(w.derivs)) > 64) and variant == "0":
+    # (r3: and the streamed-weights wave-per-sample kernel, variant 2, wherever it is built for the shape)
+    for variant, prep in (("0", "1"), ("1", "1"), ("0", "0"), ("2", "1")):
+        if (len(w.derivs) > 4 or (w.q + w.p) * (1 + len(w.derivs)) > 64) and variant != "1":
             continue  # more than four derivative slots / more than 64 components: workgroup-per-sample kernel only
         if w.d > 16 and prep == "0":
             continue  # (one wave-per-sample configuration is enough for the reduced instantiation set of d > 16)
         monkeypatch.setenv("MOE_KG_VARIANT", variant)
         monkeypatch.setenv("MOE_KG_PREP", prep)
-        rg = G.kg(gd, w.bounds_inner, w.discrete, w.Xq, Xp, w.M, best, w.kg_normals, num_fidelity=f, want_best_points=True)
+        try:
+            rg = G.kg(gd, w.bounds_inner, w.discrete, w.Xq, Xp, w.M, best, w.kg_normals, num_fidelity=f, want_best_points=True)
+        except api.OptimalLearningException as e:
+            if variant == "2" and "streamed-weights" in str(e):
+                continue  # (d > 16 with 1 .. 3 observed derivatives: they occupy four slots, the table rows are not the weights)
+            raise
+        assert G.last_kernel_info()["variant"] == int(variant)
         assert abs(rg["kg"] - ro["kg"]) <= TOL["kg"] * max(abs(ro["kg"]), 1e-6), (variant, rg["kg"], ro["kg"])
         assert np.abs(rg["grad"] - ro["grad"]).max() <= TOL["grad_kg"] * max(scale, 1e-6), variant
         mism = np.abs(rg["best_point"] - ro["best_point"]).max(axis=1) > ptol
