@@ -20,6 +20,10 @@
 
 #include <algorithm>
 #include <array>
+#include <atomic>
+#include <exception>
+#include <mutex>
+#include <thread>
 #include <memory>
 #include <chrono>
 #include <cmath>
@@ -986,6 +990,10 @@ KgPending kg_launch(GpDev& gp, int num_fidelity, const moe_gd_params_t& gd, cons
     //  -- six slabs -- 2.18 -> 2.34)
     if (variant == 1) variant = 2;
     else if (variant == 0 && !xlds && (G > 0 || waves <= 4)) variant = 2;
+    // with derivative observations also against the LDS-table kernel, from 12 table rows on or once it runs fewer than eight waves
+    // (`profiles/r03_variant2_small.txt`: n = 300 / 500, d = 12, g = 3: 0.29 -> 0.21 / 0.45 -> 0.30 ms; n = 600, d = 8, g = 4, four
+    //  slabs: 0.49 -> 0.33; but n = 400, d = 8, g = 2 on eight waves: 0.18 against 0.20 -- stays)
+    else if (variant == 0 && xlds && G > 0 && (dp >= 12 || waves < 8)) variant = 2;
   }
   {
     const int forced = env_int("MOE_KG_VARIANT", variant);
@@ -1178,24 +1186,53 @@ KgPending kg_launch(GpDev& gp, int num_fidelity, const moe_gd_params_t& gd, cons
       // (Mk is only read when the results are collected: it is formed below, AFTER the kernels are enqueued, while they run)
     }
   }
+  // One task per (evaluation, point to sample): Smith's derivative of the factor for the d coordinates of that point, then m
+  // triangular solves per coordinate -- q d m^3 (5/6) flop per evaluation, 2.6 Mflop at C5's m = 32 of plain scalar code.  It runs while
+  // the kernels do, but for d-KG at a few hundred points the kernels take less than a millisecond per evaluation and this loop was what
+  // a call waited for (r3: n = 300, d = 12, g = 3, q = 8: 1.10 ms of wall per evaluation against 0.65 of device time): the tasks are
+  // independent and go to host threads once there is enough of them (no HIP call inside; results land in disjoint slices).
   auto form_mk = [&]() {
-    for (int e = 0; e < E; ++e) {
+    for (int e = 0; e < E; ++e) Mk[e].assign((size_t)q * d * m * m, 0.0);
+    auto task = [&](int t) {
+      const int e = t / q, k = t % q;
       const StateHost& sh = hosts[e];
       const double* chol = &blob[(size_t)rec.stride * e] + rec.L;
-      Mk[e].assign((size_t)q * d * m * m, 0.0);
       std::vector<double> gc((size_t)d * m * m), col(m);
-      for (int k = 0; k < q; ++k) {
-        host_grad_cholesky_per_point(sh, k, chol, gc.data());
-        for (int dd = 0; dd < d; ++dd) {
-          double* M = &Mk[e][((size_t)k * d + dd) * m * m];
-          for (int j = 0; j < m; ++j) {  // column j of dL: entries (l, j), l >= j, stored at gc[dd + j*d + l*d*m]
-            for (int l = 0; l < m; ++l) col[l] = (l >= j) ? gc[dd + (size_t)j * d + (size_t)l * d * m] : 0.0;
-            host_tri_solve(chol, 'N', m, col.data());
-            for (int l = 0; l < m; ++l) M[l + (size_t)j * m] = col[l];
-          }
+      host_grad_cholesky_per_point(sh, k, chol, gc.data());
+      for (int dd = 0; dd < d; ++dd) {
+        double* M = &Mk[e][((size_t)k * d + dd) * m * m];
+        for (int j = 0; j < m; ++j) {  // column j of dL: entries (l, j), l >= j, stored at gc[dd + j*d + l*d*m]
+          for (int l = 0; l < m; ++l) col[l] = (l >= j) ? gc[dd + (size_t)j * d + (size_t)l * d * m] : 0.0;
+          host_tri_solve(chol, 'N', m, col.data());
+          for (int l = 0; l < m; ++l) M[l + (size_t)j * m] = col[l];
         }
       }
+    };
+    const int tasks = E * q;
+    const double flop_per_task = (double)d * m * m * m;
+    int nthreads = 1;
+    if (tasks >= 2 && flop_per_task * tasks >= 2.0e6)  // (C3's m = 4: 512 flop per task -- stays on the calling thread)
+      nthreads = std::max(1, std::min({tasks, env_int("MOE_HOST_THREADS", 16), (int)std::thread::hardware_concurrency()}));
+    if (nthreads == 1) {
+      for (int t = 0; t < tasks; ++t) task(t);
+      return;
     }
+    std::atomic<int> next{0};
+    std::exception_ptr err;
+    std::mutex err_mu;
+    auto worker = [&]() {
+      try {
+        for (int t = next.fetch_add(1); t < tasks; t = next.fetch_add(1)) task(t);
+      } catch (...) {
+        std::lock_guard<std::mutex> lk(err_mu);
+        if (!err) err = std::current_exception();
+      }
+    };
+    std::vector<std::thread> pool;
+    for (int i = 1; i < nthreads; ++i) pool.emplace_back(worker);
+    worker();
+    for (auto& th : pool) th.join();
+    if (err) std::rethrow_exception(err);
   };
 
   // ---- device buffers ----
