@@ -695,6 +695,9 @@ __device__ __forceinline__ void from_table_order(const double (&v)[DP], const in
 #ifndef MOE_KG_STREAM_TRIALS
 #define MOE_KG_STREAM_TRIALS 8
 #endif
+#ifndef MOE_KG_LDS_CARRY
+#define MOE_KG_LDS_CARRY 1
+#endif
 #ifndef MOE_KG_STREAM_FIRST
 #define MOE_KG_STREAM_FIRST 6
 #endif
@@ -1197,6 +1200,12 @@ __device__ __forceinline__ double line_search_lds(const KgMcParams& P, EV& ev, d
   ev.seg_last = __builtin_amdgcn_s_memtime();
   ev.seg_tot = ev.c_tot;
 #endif
+  // A clamped step needs f(x + step) before it is accepted, and -- once accepted -- the next iteration starts with f and grad f at that
+  // very point: while another iteration can follow, that evaluation is ONE value + gradient pass carried over (as in
+  // line_search_frame: a step costs its Armijo sweeps + one pass instead of + two -- r3: with max_relative_change = 0.1 nearly every
+  // step is clamped, so a sample saves five of its ~21 sweeps).  A carried gradient that ends up unused is counted as the value pass it replaced.
+  bool have_g = false;
+  double f_carried = 0.0, g_carried_l = 0.0;
   for (int restart = 0; restart < P.max_num_restarts; ++restart) {
     if (lane_id < DP) sX0[lane_id] = sX[lane_id];
     for (int istep = 0; istep < P.max_num_steps;) {
@@ -1205,7 +1214,14 @@ __device__ __forceinline__ double line_search_lds(const KgMcParams& P, EV& ev, d
       ev.seg_mark(3);  // (3: step end -> this gradient pass, loop control, restart bookkeeping)
 #endif
       double g_l;
-      const double f0 = ev.eval_p_lane(sF, s_l, g_l);
+      double f0;
+      if (have_g) {
+        f0 = f_carried;
+        g_l = g_carried_l;
+        have_g = false;
+      } else {
+        f0 = ev.eval_p_lane(sF, s_l, g_l);
+      }
       n_grad++;
       fcur = f0;
       if (lane_id < DP) sG[lane_id] = free_l ? g_l : 0.0;  // fidelity / pad coordinates stay pinned
@@ -1294,15 +1310,25 @@ __device__ __forceinline__ double line_search_lds(const KgMcParams& P, EV& ev, d
       }
       if (search == 30 || !nonzero) break;
       double obj2 = ftrial;
+      bool carried = false;
+      double gn_l = 0.0;
       if (changed) {
         if (lane_id < DP) sF[lane_id] = ((sX[lane_id] + sS[lane_id]) - c_l) * s_l;
-        obj2 = ev.template eval_p<false>(sF, gp);
-        n_val++;
+        if (MOE_KG_LDS_CARRY && (istep + 1 < P.max_num_steps || restart + 1 < P.max_num_restarts)) {
+          obj2 = ev.eval_p_lane(sF, s_l, gn_l);
+          carried = true;
+        } else {
+          obj2 = ev.template eval_p<false>(sF, gp);
+          n_val++;
+        }
       }
 #if MOE_BLOCK_PROF
       ev.seg_mark(2);  // (2: LimitUpdate, clamped re-evaluation set-up)
 #endif
-      if (obj2 <= f0) break;
+      if (obj2 <= f0) {
+        if (carried) n_val++;
+        break;
+      }
       // x += step one row per lane (as a wave-uniform loop the read-modify-writes of sX were twelve dependent LDS round trips:
       // most of the 2.8 k cycles per pass this kernel spent between its passes); |step|^2 from the step row alone, in k order
       if (lane_id < DP) sX[lane_id] = sX[lane_id] + sS[lane_id];
@@ -1314,6 +1340,9 @@ __device__ __forceinline__ double line_search_lds(const KgMcParams& P, EV& ev, d
       }
       fcur = obj2;
       istep += 1;
+      have_g = carried;
+      f_carried = obj2;
+      g_carried_l = gn_l;
       if (sqrt(ss) < step_tolerance) break;
     }
     double ds = 0.0;
@@ -1324,6 +1353,7 @@ __device__ __forceinline__ double line_search_lds(const KgMcParams& P, EV& ev, d
     }
     if (!(sqrt(ds) > P.tolerance)) break;
   }
+  if (have_g) n_val++;  // carried but never used
 #pragma unroll
   for (int k = 0; k < DP; ++k) tq[k] = sX[k];
   from_table_order<DP, G>(tq, P.perm, x);
