@@ -695,6 +695,11 @@ __device__ __forceinline__ void from_table_order(const double (&v)[DP], const in
 #ifndef MOE_KG_STREAM_TRIALS
 #define MOE_KG_STREAM_TRIALS 8
 #endif
+// (one trial more than the previous step consumed in a step's first sweep: measured slower everywhere -- C5 MC 4.22 -> 4.44 ms, d = 16 at
+//  n = 1000 0.188 -> 0.197 -- kept as a switch, off)
+#ifndef MOE_KG_STREAM_PRED_EXTRA
+#define MOE_KG_STREAM_PRED_EXTRA 0
+#endif
 #ifndef MOE_KG_LDS_CARRY
 #define MOE_KG_LDS_CARRY 1
 #endif
@@ -1291,7 +1296,7 @@ __device__ __forceinline__ double line_search_lds(const KgMcParams& P, EV& ev, d
           // kernel: kMaxTrials > 5), so that a bracket longer than predicted costs one more sweep, not two or three
           batch = (EV::kMaxTrials > 5) ? MOE_KG_STREAM_FOLLOWUP : 2;
         }
-        pred = max(2, min(search + 1, EV::kMaxTrials));
+        pred = max(2, min(search + 1 + ((EV::kMaxTrials > 5) ? MOE_KG_STREAM_PRED_EXTRA : 0), EV::kMaxTrials));
 #if MOE_BLOCK_PROF
         ev.seg_mark(1);  // (1: the Armijo loop outside its passes: dispatch, decisions)
 #endif
