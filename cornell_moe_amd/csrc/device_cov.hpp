@@ -50,9 +50,10 @@ __host__ __device__ __forceinline__ Radial radial_scalars(int type, double alpha
 
 // cov(p1, p2)[a, b]; a indexes p1's observation (0 = value, 1+m = d/dx_{d1[m]}), b likewise for p2.
 // diff[k] = p1[k] - p2[k]  (so u_m = -diff[d1m] / l^2, v_n = +diff[d2n] / l^2).
-template <int DP>
-__host__ __device__ __forceinline__ double cov_entry(const CovParams& cp, const Radial& rd, const double (&diff)[DP], int a, int b,
-                                            const DerivList& d1, const DerivList& d2) {
+// (`Diff`: anything indexable -- the register array of the streaming kernels, or PointDiff below for the small m x m algebra)
+template <class Diff>
+__host__ __device__ __forceinline__ double cov_entry_g(const CovParams& cp, const Radial& rd, const Diff& diff, int a, int b,
+                                              const DerivList& d1, const DerivList& d2) {
   if (a == 0 && b == 0) return rd.base;
   if (b == 0) {
     const int i1 = d1.idx[a - 1];
@@ -69,10 +70,16 @@ __host__ __device__ __forceinline__ double cov_entry(const CovParams& cp, const 
   return val;
 }
 
-// d cov(p1, p2)[a, b] / d p1_dd   (GradCovariance, gpp_covariance.cpp:171-234 / 389-459)
 template <int DP>
-__host__ __device__ __forceinline__ double grad_cov_entry(const CovParams& cp, const Radial& rd, const double (&diff)[DP], int a,
-                                                 int b, int dd, const DerivList& d1, const DerivList& d2) {
+__host__ __device__ __forceinline__ double cov_entry(const CovParams& cp, const Radial& rd, const double (&diff)[DP], int a, int b,
+                                            const DerivList& d1, const DerivList& d2) {
+  return cov_entry_g(cp, rd, diff, a, b, d1, d2);
+}
+
+// d cov(p1, p2)[a, b] / d p1_dd   (GradCovariance, gpp_covariance.cpp:171-234 / 389-459)
+template <class Diff>
+__host__ __device__ __forceinline__ double grad_cov_entry_g(const CovParams& cp, const Radial& rd, const Diff& diff, int a,
+                                                   int b, int dd, const DerivList& d1, const DerivList& d2) {
   const double di = -diff[dd] * cp.inv_l2[dd];  // (p2 - p1) / l^2
   if (a == 0 && b == 0) return di * rd.first;
   if (b == 0) {
@@ -103,6 +110,28 @@ __host__ __device__ __forceinline__ double grad_cov_entry(const CovParams& cp, c
   if (i2 == dd) t += rd.second * u * cp.inv_l2[i2];
   if (i1 == i2) t += rd.second * di * cp.inv_l2[i1];
   return t;
+}
+
+template <int DP>
+__host__ __device__ __forceinline__ double grad_cov_entry(const CovParams& cp, const Radial& rd, const double (&diff)[DP], int a,
+                                                 int b, int dd, const DerivList& d1, const DerivList& d2) {
+  return grad_cov_entry_g(cp, rd, diff, a, b, dd, d1, d2);
+}
+
+// p1 - p2 taken where it is read, and the radial scalars of the pair: for the m x m algebra of a points state (kg_state.hip), where a
+// thread owns one matrix entry and a register array of differences would be indexed dynamically.
+struct PointDiff {
+  const double* p1;
+  const double* p2;
+  __host__ __device__ __forceinline__ double operator[](int k) const { return p1[k] - p2[k]; }
+};
+__host__ __device__ __forceinline__ Radial pair_radial(const CovParams& cp, const PointDiff& df, int d) {
+  double r2 = 0.0;
+  for (int k = 0; k < d; ++k) {
+    const double v = df[k];
+    r2 = fma(v * v, cp.inv_l2[k], r2);
+  }
+  return radial_scalars(cp.type, cp.alpha, r2);
 }
 
 }  // namespace moe

@@ -1,6 +1,8 @@
 // cornell_moe_amd/csrc/gp.hip -- see gp.hpp.
 #include "gp.hpp"
 
+#include <algorithm>
+
 #include "device_cov.hpp"
 
 #include <cstdlib>
@@ -398,11 +400,12 @@ void GpDev::add_points_unchecked(const double* pts, const double* vals, int k) {
   if (singular) rebuild();
 }
 
-StateEnqueued enqueue_state_batch(GpDev& gp, const double* U_all, int u, const DerivList& dt, int nd, const double* extra_all,
-                                  int A, bool need_W, int num_evals) {
-  gp.use_device();
+namespace {
+// Shared front half of the state set-ups: the padded points of all evaluations in ONE upload, then E = [K* | dK* | K(X, extra)] for the
+// whole batch (columns grouped by kind, BatchLayout).  Returns the device pointer of the extra points.
+const double* build_state_matrix(GpDev& gp, const double* U_all, int u, const DerivList& dt, int nd, const double* extra_all, int A,
+                                 int E, StateLayout* lay_out, BatchLayout* bl_out) {
   hipStream_t s = gp.stream;
-  const int E = num_evals;
   StateLayout lay;
   lay.d = gp.d;
   lay.u = u;
@@ -410,7 +413,6 @@ StateEnqueued enqueue_state_batch(GpDev& gp, const double* U_all, int u, const D
   lay.m = u * (1 + dt.g);
   lay.nd = nd;
   lay.A = A;
-  const int c = lay.c();
   const int ngrad = nd * (1 + dt.g) * gp.d;
   const int N = gp.N;
   BatchLayout bl;
@@ -443,9 +445,6 @@ StateEnqueued enqueue_state_batch(GpDev& gp, const double* U_all, int u, const D
   gp.dPts.reserve(nU);
   MOE_HIP_CHECK(hipMemcpyAsync(gp.dPts.p, dUp, sizeof(double) * nU, hipMemcpyDeviceToDevice, s));
   gp.dE.reserve((size_t)N * ctot);
-  gp.dVE.reserve((size_t)N * ctot);
-  const size_t nG = (size_t)c * c * E;
-  gp.dGram.reserve(nG + ctot);  // gram matrices followed by ek: one download
   launch_cov_build(gp.cp, gp.dX.p, gp.n, gp.derivs, dUp, E * u, dt, nullptr, gp.dE.p, N, bl.col_kstar0(0), s);
   if (nd > 0) launch_grad_kstar(gp.cp, gp.dX.p, gp.n, gp.derivs, dDp, E * nd, dt, gp.dE.p, N, bl.col_grad0(0), s);
   if (A > 0) {
@@ -454,6 +453,27 @@ StateEnqueued enqueue_state_batch(GpDev& gp, const double* U_all, int u, const D
     for (int i = 0; i < kMaxDerivs; ++i) none.idx[i] = 0;
     launch_cov_build(gp.cp, gp.dX.p, gp.n, gp.derivs, dEp, E * A, none, nullptr, gp.dE.p, N, bl.col_extra0(0), s);
   }
+  *lay_out = lay;
+  *bl_out = bl;
+  return dEp;
+}
+}  // namespace
+
+StateEnqueued enqueue_state_batch(GpDev& gp, const double* U_all, int u, const DerivList& dt, int nd, const double* extra_all,
+                                  int A, bool need_W, int num_evals) {
+  gp.use_device();
+  hipStream_t s = gp.stream;
+  const int E = num_evals;
+  StateLayout lay;
+  BatchLayout bl;
+  build_state_matrix(gp, U_all, u, dt, nd, extra_all, A, E, &lay, &bl);
+  const int c = lay.c();
+  const int ngrad = bl.ngrad;
+  const int N = gp.N;
+  const long ctot = bl.total();
+  gp.dVE.reserve((size_t)N * ctot);
+  const size_t nG = (size_t)c * c * E;
+  gp.dGram.reserve(nG + ctot);  // gram matrices followed by ek: one download
   launch_tri_gemm('N', N, (int)ctot, gp.dLinv.p, gp.ldL, gp.dE.p, N, gp.dVE.p, N, s);
   if (need_W) {
     const int cw = E * (lay.m + ngrad);
@@ -468,6 +488,43 @@ StateEnqueued enqueue_state_batch(GpDev& gp, const double* U_all, int u, const D
   se.lay = lay;
   se.nG = nG;
   se.ctot = ctot;
+  return se;
+}
+
+// The KG state (r4): L^-1 and L^-T are applied to the m columns of K* only --
+//   V = L^-1 K*,  W = L^-T V = K^-1 K*,  gkk = V^T V,  gx = [dK* | K(X, discretised set)]^T W,  ek = E^T K^-1 (y - mean)
+// -- which is how the reference forms the gradient of the variance (grad_K_star^T K_inv_times_K_star, gpp_math.cpp:1277-1290) and what
+// its covariance with other points reduces to once K^-1 K* is at hand (gpp_math.cpp:815-821).  Until r3 both triangular products ran
+// over all m + ngrad + A columns of the state matrix (474 per evaluation at C5, 32 of them K*: 2 x 3e10 flop per evaluation against 4e9).
+KgStateEnqueued enqueue_kg_state_batch(GpDev& gp, const double* U_all, int u, int nd, const double* extra_all, int A, int num_evals) {
+  gp.use_device();
+  hipStream_t s = gp.stream;
+  const int E = num_evals;
+  StateLayout lay;
+  BatchLayout bl;
+  const double* dEp = build_state_matrix(gp, U_all, u, gp.derivs, nd, extra_all, A, E, &lay, &bl);
+  const int m = lay.m, ng = bl.ngrad, R = ng + A, N = gp.N;
+  const long ctot = bl.total();
+  const long cm = (long)E * m;
+  gp.dVE.reserve((size_t)N * cm * 2);  // (the second half: workspace of the gradient tail's K^-1 TB, kg.hip)
+  gp.dWE.reserve((size_t)N * cm);
+  // (one workspace for the split-K partials of the triangular products -- here and in the gradient tail -- and of the Gram kernels)
+  gp.dEK.reserve(std::max({(size_t)E * gram_batch_slices(E, m, N) * m * m, (size_t)E * gram_cross_slices(m, ng, A, N) * R * m,
+                           tri_cols_work_doubles(N, (int)cm)}));
+  launch_tri_gemm_cols('N', N, (int)cm, m, gp.dLinv.p, gp.ldL, gp.dE.p + bl.col_kstar0(0) * N, N, gp.dVE.p, N, gp.dEK.p, s);
+  launch_tri_gemm_cols('T', N, (int)cm, m, gp.dLinv.p, gp.ldL, gp.dVE.p, N, gp.dWE.p, N, gp.dEK.p, s);
+  const size_t n_kk = (size_t)E * m * m, n_x = (size_t)E * R * m;
+  gp.dGram.reserve(n_kk + n_x + ctot);
+  launch_gram_batch(E, m, 0, 0, N, gp.dVE.p, N, gp.dGram.p, gp.dEK.p, s);
+  launch_gram_cross_batch(E, m, ng, A, N, gp.dE.p, N, gp.dWE.p, N, gp.dGram.p + n_kk, gp.dEK.p, s);
+  launch_gemm_tn((int)ctot, 1, N, gp.dE.p, N, gp.dKinvY.p, N, gp.dGram.p + n_kk + n_x, (int)ctot, s);
+  KgStateEnqueued se;
+  se.bl = bl;
+  se.gkk = gp.dGram.p;
+  se.gx = gp.dGram.p + n_kk;
+  se.ek = gp.dGram.p + n_kk + n_x;
+  se.U = gp.dPts.p;
+  se.extra = dEp;
   return se;
 }
 

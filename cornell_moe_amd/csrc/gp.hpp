@@ -35,7 +35,8 @@ struct GpDev {
   // reusable workspaces of the KG evaluator (kg.hip)
   DevBuf<double> kBlob, kNormals, kTab, kBestPoint, kBestValue, kBeta, kT, kC, kTB, kOut, kSW, kSWpart, kZcPart, kV;
   DevBuf<unsigned long long> kCounters;
-  DevBuf<int> kBestJ;
+  DevBuf<int> kBestJ, kStateI;   // kStateI: singular flags | winners of a KG batch (kg_state.hip)
+  DevBuf<double> kStateD;        // grad mu | d chol / d Xq (packed) | final [kg_sum | grad] per evaluation
   int num_cu = 256;
   // per-dimension mean and max |x - mean| of the training points (refreshed by rebuild() and by the append path of add_points):
   // the frame centre of the KG coordinate tables and the extent the kernel selection needs, so that an evaluation does not
@@ -112,6 +113,16 @@ struct StateEnqueued {
 };
 StateEnqueued enqueue_state_batch(GpDev& gp, const double* U_all, int u, const DerivList& dt, int nd, const double* extra_all,
                                   int A, bool need_W, int num_evals);
+// The KG evaluator's state set-up (r4), everything left on the device for kg_state.hip: see gp.hip.
+struct KgStateEnqueued {
+  BatchLayout bl;
+  const double* gkk = nullptr;    // [E][m x m]
+  const double* gx = nullptr;     // [E][(ngrad + A) x m]
+  const double* ek = nullptr;     // [E m | E ngrad | E A]
+  const double* U = nullptr;      // [E][u][dp]
+  const double* extra = nullptr;  // [E][A][dp]
+};
+KgStateEnqueued enqueue_kg_state_batch(GpDev& gp, const double* U_all, int u, int nd, const double* extra_all, int A, int num_evals);
 void compute_state_batch(GpDev& gp, const double* U_all, int u, const DerivList& dt, int nd, const double* extra_all, int A,
                          bool need_W, int num_evals, BatchLayout* blay, std::vector<StateHost>* hosts);
 

@@ -63,6 +63,14 @@ void launch_tri_gemm(char op, int N, int c, const double* T, long ldt, const dou
 void launch_tri_gemm_skinny(char op, int N, int c, const double* T, long ldt, const double* B, long ldb, double* C,
                             long ldc, hipStream_t s);
 
+// op(T) B for a right-hand side that is a row of independent problems of `cols_per_problem` columns each (the evaluations of a KG
+// batch): the kernel is chosen from N and cols_per_problem alone and every column's summation order is fixed by N, so a problem's
+// result does not depend on how many share the call.  <= 16 columns per problem: the skinny kernels; otherwise split K on the matrix
+// pipe (kernels_linalg.hip tri_splitk_kernel).  work: tri_cols_work_doubles(N, c) doubles.
+size_t tri_cols_work_doubles(int N, int c);
+void launch_tri_gemm_cols(char op, int N, int c, int cols_per_problem, const double* T, long ldt, const double* B, long ldb,
+                          double* C, long ldc, double* work, hipStream_t s);
+
 // C[m x n] (ldc) = A^T B, A is K x m (lda), B is K x n (ldb); reduction over the K rows.
 void launch_gemm_tn(int m, int n, int K, const double* A, long lda, const double* B, long ldb, double* C, long ldc,
                     hipStream_t s);
@@ -77,6 +85,13 @@ void launch_gemm_tn_splitk(int m, int n, int K, const double* A, long lda, const
 int gram_batch_slices(int E, int c, int K);
 void launch_gram_batch(int E, int m, int ng, int A, int K, const double* V, long ldv, double* G, double* work,
                        hipStream_t s);
+
+// Batched cross products of the KG state (r4): for eval e, G_e[(ng + A) x m] (ld ng + A, eval stride (ng + A) m) = S_e^T W_e, where
+// S_e = the evaluation's gradient and extra columns of S (column map of launch_gram_batch, l >= m) and W_e = columns e m .. of W.
+// work: E * gram_cross_slices(m, ng, A, K) * (ng + A) * m doubles.
+int gram_cross_slices(int m, int ng, int A, int K);
+void launch_gram_cross_batch(int E, int m, int ng, int A, int K, const double* S, long lds, const double* W, long ldw, double* G,
+                             double* work, hipStream_t s);
 
 // In-place blocked Cholesky of the lower triangle of A (N x N, lda) + explicit inverse of the factor into Linv
 // (N x N, ldl, lower; strict upper zeroed).  info (device int): 0 or failing pivot index + 1 (pivot <= 1e-16).

@@ -8,6 +8,7 @@
 //  * blocked right-looking Cholesky (NB = 64) + explicit inverse of the factor: replaces ComputeCholeskyFactorL
 //    (gpp_linear_algebra.cpp:109-148) and turns every TriangularMatrixVectorSolve (:160-187) of the reference into a
 //    GEMM against L^-1, which is what lets the posterior solves run wide instead of as 1000 dependent steps.
+#include <algorithm>
 #include <cstdlib>
 
 #include "kernels.hpp"
@@ -384,6 +385,68 @@ __global__ __launch_bounds__(256) void gram_batch_kernel(GramMap gm, int K, cons
     }
 }
 
+// Batched cross products X_e[r x m] = S_e^T W_e (r4, the KG state): S_e = the evaluation's `ng` gradient columns and `A` extra
+// columns of the state matrix E (column map as in GramMap, rows l = 0 .. ng + A - 1 <-> GramMap column m + l), W_e = K^-1 K*_e
+// (columns e m .. e m + m - 1 of W).  This is how the reference itself forms these blocks -- dK*^T (K^-1 K*), gpp_math.cpp:1277-1290 --
+// and it means L^-1 is never applied to the gradient / extra columns (474 columns per evaluation at C5 against 32 of K*).
+// 32 x 32 output tile per workgroup, blockIdx.z = evaluation * slices + K slice (partials summed in slice order).
+__global__ __launch_bounds__(256) void gram_cross_batch_kernel(GramMap gm, int K, const double* __restrict__ S, long lds,
+                                                              const double* __restrict__ W, long ldw, double* __restrict__ G,
+                                                              int slices) {
+  constexpr int T = 32;
+  constexpr int TK = 64;
+  __shared__ double As[TK][T + 1];
+  __shared__ double Bs[TK][T + 1];
+  const int r = gm.ng + gm.A;
+  const int e = blockIdx.z / slices, sl = blockIdx.z % slices;
+  const int kper = ((K + slices - 1) / slices + TK - 1) / TK * TK;
+  const int k_begin = sl * kper, k_end = min(K, k_begin + kper);
+  const int i0 = blockIdx.x * T, j0 = blockIdx.y * T;
+  const int tx = threadIdx.x % 16, ty = threadIdx.x / 16;
+  double acc[2][2] = {{0.0, 0.0}, {0.0, 0.0}};
+  constexpr int NE = TK * T / 256;
+  double pa[NE], pb[NE];
+  auto fetch = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < NE; ++i) {
+      const int t = threadIdx.x + i * 256;
+      const int kk = t % TK, ii = t / TK;
+      const int gk = k0 + kk;
+      const int gi = i0 + ii, gj = j0 + ii;
+      pa[i] = (gi < r && gk < k_end) ? S[(long)gk + gm.col(e, gm.m + gi) * lds] : 0.0;
+      pb[i] = (gj < gm.m && gk < k_end) ? W[(long)gk + ((long)e * gm.m + gj) * ldw] : 0.0;
+    }
+  };
+  if (k_begin < k_end) fetch(k_begin);
+  for (int k0 = k_begin; k0 < k_end; k0 += TK) {
+#pragma unroll
+    for (int i = 0; i < NE; ++i) {
+      const int t = threadIdx.x + i * 256;
+      As[t % TK][t / TK] = pa[i];
+      Bs[t % TK][t / TK] = pb[i];
+    }
+    __syncthreads();
+    if (k0 + TK < k_end) fetch(k0 + TK);
+#pragma unroll
+    for (int kk = 0; kk < TK; ++kk) {
+      const double a0 = As[kk][tx], a1 = As[kk][tx + 16], b0 = Bs[kk][ty], b1 = Bs[kk][ty + 16];
+      acc[0][0] = fma(a0, b0, acc[0][0]);
+      acc[0][1] = fma(a0, b1, acc[0][1]);
+      acc[1][0] = fma(a1, b0, acc[1][0]);
+      acc[1][1] = fma(a1, b1, acc[1][1]);
+    }
+    __syncthreads();
+  }
+  double* Ge = G + (long)blockIdx.z * r * gm.m;
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const int gi = i0 + tx + 16 * a, gj = j0 + ty + 16 * b;
+      if (gi < r && gj < gm.m) Ge[(long)gi + (long)gj * r] = acc[a][b];
+    }
+}
+
 // ------------------------------------------------------------------------------------------------------------------
 // Blocked Cholesky (lower, in place) with explicit inverse factor.
 // ------------------------------------------------------------------------------------------------------------------
@@ -669,6 +732,147 @@ void launch_tri_skinny(char op, int N, int c, const double* T, long ldt, const d
 }
 }  // namespace
 
+namespace {
+// Triangular product against a SKINNY right-hand side (r4: the KG state applies L^-1 / L^-T to the m columns of K* per evaluation, and
+// the gradient tail to the m columns of TB -- 32 at C5, where the plain tiled kernels leave N / 64 workgroups walking K = 8000 each:
+// 0.5 ms for 8 GFLOP, 16 TFLOP/s, a sixth of what reading T from HBM costs).  Split K on the matrix pipe: workgroup (column tile,
+// row tile, slice) multiplies the 64 x 64 output tile over ONE slice [sl KS, (sl + 1) KS) of the k range its row tile needs and
+// stores the partial product to work[sl]; tri_splitk_sum_kernel adds the partials of a row in ascending slice order.  KS depends on N
+// alone, so an entry's summation order does not depend on how many columns (evaluations) share the call.
+// MODE 1: C = T B (T lower: row tile r needs k < (r + 1) 64).  MODE 2: C = T^T B (k >= r 64).
+template <int MODE>
+__global__ __launch_bounds__(256) void tri_splitk_kernel(int N, int c, int KS, const double* __restrict__ T, long ldt,
+                                                        const double* __restrict__ B, long ldb, double* __restrict__ work) {
+  constexpr int TM = 64, TK = 16, LD = 65;
+  constexpr int NF = TM * TK / 256;
+  __shared__ double As[TK][LD];
+  __shared__ double Bs[TK][LD];
+  const int j0 = blockIdx.x * 64, i0 = blockIdx.y * TM, sl = blockIdx.z;
+  int k_lo = sl * KS, k_hi = min(N, k_lo + KS);
+  if (MODE == 1) k_hi = min(k_hi, min(N, i0 + TM));
+  if (MODE == 2) k_lo = max(k_lo, (i0 / TK) * TK);
+  if (k_lo >= k_hi) return;  // this row tile has no work in this slice (tri_splitk_sum_kernel skips it, too)
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int wi = (wave & 1) * 32, wj = (wave >> 1) * 32;
+  const int lk = lane >> 4, lx = lane & 15;
+  f64x4 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) acc[a][b] = f64x4{0.0, 0.0, 0.0, 0.0};
+  double ra[NF], rb[NF];
+  auto fetch = [&](int k0) {
+#pragma unroll
+    for (int it = 0; it < NF; ++it) {
+      const int t = threadIdx.x + 256 * it;
+      if (MODE == 1) {
+        const int ii = t % TM, kk = t / TM;
+        const int gi = i0 + ii, gk = k0 + kk;
+        ra[it] = (gi < N && gk < k_hi && gk <= gi) ? T[(long)gi + (long)gk * ldt] : 0.0;
+      } else {
+        const int kk = t % TK, ii = t / TK;
+        const int gi = i0 + ii, gk = k0 + kk;
+        ra[it] = (gi < N && gk < k_hi && gk >= gi) ? T[(long)gk + (long)gi * ldt] : 0.0;
+      }
+      const int kk = t % TK, jj = t / TK;
+      const int gk = k0 + kk, gj = j0 + jj;
+      rb[it] = (gk < k_hi && gj < c) ? B[(long)gk + (long)gj * ldb] : 0.0;
+    }
+  };
+  fetch(k_lo);
+  for (int k0 = k_lo; k0 < k_hi; k0 += TK) {
+#pragma unroll
+    for (int it = 0; it < NF; ++it) {
+      const int t = threadIdx.x + 256 * it;
+      if (MODE == 1)
+        As[t / TM][t % TM] = ra[it];
+      else
+        As[t % TK][t / TK] = ra[it];
+      Bs[t % TK][t / TK] = rb[it];
+    }
+    __syncthreads();
+    if (k0 + TK < k_hi) fetch(k0 + TK);
+#pragma unroll
+    for (int k4 = 0; k4 < TK; k4 += 4) {
+      double fa[2], fb[2];
+#pragma unroll
+      for (int a = 0; a < 2; ++a) fa[a] = As[k4 + lk][wi + 16 * a + lx];
+#pragma unroll
+      for (int b = 0; b < 2; ++b) fb[b] = Bs[k4 + lk][wj + 16 * b + lx];
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb[b], fa[a], acc[a][b], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+  double* W = work + (long)sl * N * c;
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int gi = i0 + wi + 16 * a + lx, gj = j0 + wj + 16 * b + lk + 4 * r;
+        if (gi < N && gj < c) W[(long)gi + (long)gj * N] = acc[a][b][r];
+      }
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256) void tri_splitk_sum_kernel(int N, int c, int KS, int slices, const double* __restrict__ work,
+                                                            double* __restrict__ C, long ldc) {
+  const int i = blockIdx.x * 256 + threadIdx.x, j = blockIdx.y;
+  if (i >= N) return;
+  const int rt = i / 64;  // the slices row tile rt took part in (the k ranges of tri_splitk_kernel)
+  int s_lo = 0, s_hi = slices;
+  if (MODE == 1) s_hi = min(slices, (min(N, (rt + 1) * 64) - 1) / KS + 1);
+  if (MODE == 2) s_lo = ((rt * 64) / 16 * 16) / KS;
+  double v = 0.0;
+  for (int sl = s_lo; sl < s_hi; ++sl) v += work[((long)sl * c + j) * N + i];
+  C[(long)i + (long)j * ldc] = v;
+}
+}  // namespace
+
+int tri_cols_slices(int N, int* ks_out) {
+  const int tiles = (N + 63) / 64;
+  const int ks = 64 * std::max(1, (tiles + 7) / 8);
+  if (ks_out) *ks_out = ks;
+  return (N + ks - 1) / ks;
+}
+size_t tri_cols_work_doubles(int N, int c) { return (size_t)tri_cols_slices(N, nullptr) * (size_t)N * (size_t)c; }
+
+void launch_tri_gemm_cols(char op, int N, int c, int cols_per_problem, const double* T, long ldt, const double* B, long ldb,
+                          double* C, long ldc, double* work, hipStream_t s) {
+  if (N <= 0 || c <= 0) return;
+  static const int mode = [] {
+    const char* v = std::getenv("MOE_TRI_COLS");  // 0: the plain tiled kernels (A/B runs)
+    return (v && *v) ? std::atoi(v) : 1;
+  }();
+  if (mode == 0) {
+    launch_tri_gemm(op, N, c, T, ldt, B, ldb, C, ldc, s);
+    return;
+  }
+  if (cols_per_problem <= 16 && N >= 128) {  // a handful of columns per problem: the row-strip / column-per-wavefront kernels
+    if (cols_per_problem <= 4)
+      launch_tri_skinny<4>(op, N, c, T, ldt, B, ldb, C, ldc, s);
+    else
+      launch_tri_skinny<8>(op, N, c, T, ldt, B, ldb, C, ldc, s);
+    return;
+  }
+  int KS = 0;
+  const int slices = tri_cols_slices(N, &KS);
+  const dim3 grid((c + 63) / 64, (N + 63) / 64, slices);
+  const dim3 sgrid((N + 255) / 256, c);
+  if (op == 'N') {
+    hipLaunchKernelGGL(tri_splitk_kernel<1>, grid, dim3(256), 0, s, N, c, KS, T, ldt, B, ldb, work);
+    hipLaunchKernelGGL(tri_splitk_sum_kernel<1>, sgrid, dim3(256), 0, s, N, c, KS, slices, (const double*)work, C, ldc);
+  } else {
+    hipLaunchKernelGGL(tri_splitk_kernel<2>, grid, dim3(256), 0, s, N, c, KS, T, ldt, B, ldb, work);
+    hipLaunchKernelGGL(tri_splitk_sum_kernel<2>, sgrid, dim3(256), 0, s, N, c, KS, slices, (const double*)work, C, ldc);
+  }
+  MOE_HIP_CHECK(hipGetLastError());
+}
+
 void launch_tri_gemm(char op, int N, int c, const double* T, long ldt, const double* B, long ldb, double* C, long ldc,
                      hipStream_t s) {
   if (op == 'N')
@@ -780,6 +984,32 @@ int gram_batch_slices(int /*E*/, int c, int K) {
   long s = (want + tiles - 1) / tiles;
   s = std::min<long>(s, std::max(1, K / 64));                              // at least one stage of 64 per slice
   return (int)std::max<long>(1, std::min<long>(s, 16));
+}
+
+// K slices of gram_cross_batch_kernel: sized for ONE evaluation (the summation order must not depend on the batch size)
+int gram_cross_slices(int m, int ng, int A, int K) {
+  const long tiles = (long)((ng + A + 31) / 32) * ((m + 31) / 32);
+  if (tiles <= 0) return 1;
+  long s = (512 + tiles - 1) / tiles;
+  s = std::min<long>(s, std::max(1, K / 64));
+  return (int)std::max<long>(1, std::min<long>(s, 16));
+}
+
+void launch_gram_cross_batch(int E, int m, int ng, int A, int K, const double* S, long lds, const double* W, long ldw, double* G,
+                             double* work, hipStream_t s) {
+  const int r = ng + A;
+  if (r <= 0 || m <= 0 || E <= 0) return;
+  GramMap gm{E, m, ng, A};
+  const int slices = gram_cross_slices(m, ng, A, K);
+  dim3 grid((r + 31) / 32, (m + 31) / 32, E * slices);
+  if (slices == 1) {
+    hipLaunchKernelGGL(gram_cross_batch_kernel, grid, dim3(256), 0, s, gm, K, S, lds, W, ldw, G, 1);
+  } else {
+    const long cc = (long)r * m;
+    hipLaunchKernelGGL(gram_cross_batch_kernel, grid, dim3(256), 0, s, gm, K, S, lds, W, ldw, work, slices);
+    hipLaunchKernelGGL(gram_sum_kernel, dim3((unsigned)((cc + 255) / 256), E), dim3(256), 0, s, (const double*)work, slices, cc, G);
+  }
+  MOE_HIP_CHECK(hipGetLastError());
 }
 
 void launch_gram_batch(int E, int m, int ng, int A, int K, const double* V, long ldv, double* G, double* work, hipStream_t s) {
@@ -1435,12 +1665,10 @@ void cholesky_factor_two_level(int N, double* A, long lda, double* Linv, long ld
   double* cbuf = nullptr;
   const long ldc = ((long)N + 15) / 16 * 16;
   if (fused) {
-    static const bool attr_set = [] {
-      MOE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(chol_step_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                        (int)kStepSmem));
-      return true;
-    }();
-    (void)attr_set;
+    // (on every factorisation: the opt-in is per device where the runtime enforces it, and one process may build GPs on several
+    //  devices -- moe_kg_batch_multi, bench.py's in-process fallback)
+    MOE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(chol_step_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      (int)kStepSmem));
     cbuf = scratch;
     if (cbuf == nullptr) MOE_HIP_CHECK(hipMallocAsync(reinterpret_cast<void**>(&cbuf), sizeof(double) * (size_t)2 * ldc * NB, s));
   }

@@ -32,6 +32,7 @@
 #include "device_cov.hpp"
 #include "fastmath.hpp"
 #include "kg_mc.hpp"
+#include "kg_state.hpp"
 
 namespace moe {
 
@@ -92,8 +93,12 @@ struct KgTailParams {
   const double* SW;          // optional precomputed W^T T, [m x E*num_local] col-major (large m: tile GEMM); else null
   const double* W;           // evaluation e at W + e * w_stride, [N x m], ld N
   long w_stride;
-  const double* Gm;          // K^-1 dK*/dXq: evaluation e at Gm + e * g_stride, [N x ngrad], ld N
+  const double* Gm;          // dK*/dXq: evaluation e at Gm + e * g_stride, [N x ngrad], ld N
   long g_stride;
+  const double* Linv;        // the GP's explicit inverse factor (ld ldL) and 2 N E m doubles of workspace: K^-1 TB (launch_gtb)
+  long ldL;
+  double* work;
+  double* tri_work;          // tri_cols_work_doubles(N, E m) doubles (split-K partials)
   const double* blob;
   KgRec rec;
   int rec_bp;                // offset of best_posterior inside a record
@@ -246,7 +251,7 @@ __global__ __launch_bounds__(256) void kg_tbsum_kernel(KgTailParams P, double* _
   TBsum[(long)e * mn + idx] = tb;
 }
 
-// GTB[e][gc] = sum_row Gm_e[row, gc] * TB_e[row, col(gc)];  gc = (k (1+g) + b) d + dd  ->  col = k (1+g) + b.
+// GTB[e][gc] = sum_row dK*_e[row, gc] * (K^-1 TB_e)[row, col(gc)];  gc = (k (1+g) + b) d + dd  ->  col = k (1+g) + b.
 __global__ __launch_bounds__(256) void kg_gtb_kernel(KgTailParams P, const double* __restrict__ TBsum) {
   __shared__ double red[4];
   const int gc = blockIdx.x, e = blockIdx.y;
@@ -264,7 +269,14 @@ void launch_gtb(const KgTailParams& P, hipStream_t s) {
   const long mn = (long)P.m * P.N;
   double* TBsum = P.TBpart + (long)P.E * P.chunks * mn;
   hipLaunchKernelGGL(kg_tbsum_kernel, dim3((unsigned)((mn + 255) / 256), P.E), dim3(256), 0, s, P, TBsum);
-  hipLaunchKernelGGL(kg_gtb_kernel, dim3(P.ngrad, P.E), dim3(256), 0, s, P, (const double*)TBsum);
+  // (K^-1 dK*)^T TB = dK*^T (K^-1 TB): the two triangular products run over the m columns of TB, not over the q (1 + g) d columns of
+  // dK* (r4: 32 against 384 per evaluation at C5)
+  const int cm = P.E * P.m;
+  double* half = P.work;
+  double* KinvTB = P.work + (long)P.N * cm;
+  launch_tri_gemm_cols('N', P.N, cm, P.m, P.Linv, P.ldL, TBsum, P.N, half, P.N, P.tri_work, s);
+  launch_tri_gemm_cols('T', P.N, cm, P.m, P.Linv, P.ldL, half, P.N, KinvTB, P.N, P.tri_work, s);
+  hipLaunchKernelGGL(kg_gtb_kernel, dim3(P.ngrad, P.E), dim3(256), 0, s, P, (const double*)KinvTB);
 }
 
 // ZC[e][r + j m] = sum_i z_i[r] c_i[j]; workgroup (r, j, e); the (0, 0) workgroup also forms
@@ -981,8 +993,10 @@ KgPending kg_launch(GpDev& gp, int num_fidelity, const moe_gd_params_t& gd, cons
   const long v_stride_tiles = (long)ntiles * 64 * g1;
   const double v_cap = std::getenv("MOE_KG_V_MAX_GB") ? (double)env_int("MOE_KG_V_MAX_GB", 4)
                                                       : (weight_table_gb >= 0.0 ? weight_table_gb : 4.0);
+  // (the size test is per EVALUATION: which kernel an evaluation takes must not depend on the batch it shares a call with -- the
+  //  callers size their batches with kg_max_batch, which budgets every evaluation's table)
   const bool stream_ok = g1 == 1 + G && G <= 4 && m <= kMaxM && prep_mode != 0 &&
-                         8.0 * (double)v_stride_tiles * (double)E * (double)num_local / 1e9 <= v_cap;
+                         8.0 * (double)v_stride_tiles * (double)num_local / 1e9 <= v_cap;
   if (stream_ok && env_int("MOE_KG_STREAM_WEIGHTS", 1) != 0) {
     // (r3, ms of MC per evaluation, `profiles/r03_variant2_sweep.txt`: C5 7.9 -> 5.0; d = 12, g = 3, q = 8, M = 4000: n = 1200 1.24 -> 0.68 against the
     //  workgroup-per-sample kernel, n = 800 0.80 -> 0.48 against the wave-per-sample kernel streaming its coordinates with five weight
@@ -1058,10 +1072,12 @@ KgPending kg_launch(GpDev& gp, int num_fidelity, const moe_gd_params_t& gd, cons
   DerivList none;
   none.g = 0;
   for (int i = 0; i < kMaxDerivs; ++i) none.idx[i] = 0;
-  BatchLayout bl;
-  std::vector<StateHost> hosts;
-  compute_state_batch(gp, U_all.data(), u, gp.derivs, want_grad ? q : 0, extra_all.data(), A, true, E, &bl, &hosts);
-  const double ms_dev_state = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wall0).count();
+  auto timers = std::make_shared<std::array<EventTimer, 4>>();
+  EventTimer &t_mc = (*timers)[0], &t_cov = (*timers)[1], &t_tail = (*timers)[2], &t_state = (*timers)[3];
+  t_state.start(s);
+  // everything N-sized of the state, left on the device (gp.hip): no wait, no download -- the m x m algebra follows as kernels
+  const KgStateEnqueued se = enqueue_kg_state_batch(gp, U_all.data(), u, want_grad ? q : 0, extra_all.data(), A, E);
+  const BatchLayout& bl = se.bl;
 
   // ---- table-row order of the dimensions ----
   TabParams tp;
@@ -1100,7 +1116,8 @@ KgPending kg_launch(GpDev& gp, int num_fidelity, const moe_gd_params_t& gd, cons
       }
     }
   }
-  // ---- host m x m algebra per evaluation -> one blob ----
+  // ---- per-evaluation records: the host fills what it knows (discretised set, padded union points); mu, the factor of
+  // Var + noise, the discretised set's mu_n / c_j and the best posterior mean are written by kg_state_kernel ----
   KgRec rec;
   int off = 0;
   auto take = [&](int cnt) {
@@ -1118,8 +1135,12 @@ KgPending kg_launch(GpDev& gp, int num_fidelity, const moe_gd_params_t& gd, cons
   rec.stride = off;
   // behind the records: [2 kMaxDimPadded] bounds | [kMaxDimPadded] frame centre | [kMaxDimPadded] frame scale, table-row order
   // (the MC kernels read them one row per lane)
-  std::vector<double> blob((size_t)rec.stride * E + 4 * kMaxDimPadded, 0.0);
+  const size_t blob_size = (size_t)rec.stride * E + 4 * kMaxDimPadded;
   const size_t o_bounds = (size_t)rec.stride * E;
+  const long num_norm = (long)((num_mc + 1) / 2) * m;
+  gp.hKgIn.reserve(blob_size + (size_t)num_norm);
+  double* blob = gp.hKgIn.p;
+  std::memset(blob, 0, sizeof(double) * blob_size);
   unsigned int free_mask = 0;  // table-row order: bounds of row r = bounds of original dimension perm[r]
   for (int r = 0; r < kMaxDimPadded; ++r) {
     const int k = tp.perm[r];
@@ -1131,120 +1152,59 @@ KgPending kg_launch(GpDev& gp, int num_fidelity, const moe_gd_params_t& gd, cons
     blob[o_bounds + 2 * kMaxDimPadded + r] = tp.center[r];
     blob[o_bounds + 3 * kMaxDimPadded + r] = tp.inv_lp[r];
   }
-  std::vector<int> winner(E, -1);
-  std::vector<double> best_posterior(E, best_so_far);
-  auto grad_mu_p = std::make_shared<std::vector<std::vector<double>>>(E);
-  auto Mk_p = std::make_shared<std::vector<std::vector<double>>>(E);
-  std::vector<std::vector<double>>&grad_mu = *grad_mu_p, &Mk = *Mk_p;
   for (int e = 0; e < E; ++e) {
-    const StateHost& sh = hosts[e];
     const double* U = &U_all[(size_t)e * u * d];
-    const double* ex = &extra_all[(size_t)e * A * d];
     double* r = &blob[(size_t)rec.stride * e];
-    // PreCompute (.cpp:292-317): mu(Xu), chol(Var + noise)
-    std::vector<double> mu(m);
-    double* chol = r + rec.L;
-    host_mean(sh, mu.data());
-    host_variance(sh, chol);
-    for (int i = 0; i < u; ++i)
-      for (int b = 0; b < g1; ++b) chol[(i * g1 + b) + (size_t)(i * g1 + b) * m] += gp.noise[b];  // .cpp:304-309
-    const int lm = host_cholesky(m, chol);
-    if (lm != 0)
-      throw Error(MOE_ERR_SINGULAR,
-                  "GP-Variance matrix singular. Check for duplicate points_to_sample/being_sampled or "
-                  "points_to_sample/being_sampled duplicating points_sampled with 0 noise.",
-                  m, lm);
-    for (int c = 0; c < m; ++c)
-      for (int rr = 0; rr < c; ++rr) chol[rr + (size_t)c * m] = 0.0;
-    for (int j = 0; j < u; ++j)  // .cpp:146-154: function-value entries only
-      if (mu[(size_t)j * g1] < best_posterior[e]) {
-        winner[e] = j;
-        best_posterior[e] = mu[(size_t)j * g1];
-      }
-    r[rec_bp] = best_posterior[e];
-    // discretised set: mu_n(x_j), c_j = L^-1 cov_n(Xu, x_j)
-    std::vector<double> cv(m), blk(g1);
-    for (int j = 0; j < A; ++j) {
-      r[rec.mu_disc + j] = sh.mean + sh.ek[sh.lay.col_extra(j)];
-      for (int i = 0; i < u; ++i) {
-        host_cov(gp.cp, U + (size_t)i * d, gp.derivs, ex + (size_t)j * d, none, blk.data());
-        for (int b = 0; b < g1; ++b) cv[i * g1 + b] = blk[b] - sh.G(sh.lay.col_kstar(i, b), sh.lay.col_extra(j));
-      }
-      host_tri_solve(chol, 'N', m, cv.data());
-      for (int c = 0; c < m; ++c) r[rec.C_disc + (size_t)j * m + c] = cv[c];
-    }
     std::copy(&disc_all[(size_t)e * A * size], &disc_all[(size_t)(e + 1) * A * size], r + rec.disc);
     for (int i = 0; i < u; ++i)
       for (int k = 0; k < d; ++k) r[rec.XuP + (size_t)i * dp + k] = U[(size_t)i * d + k];
-    // gradient pieces: grad mu (value rows), Mk = L^-1 dL/dXq (Smith's derivative of the factor, gpp_math.cpp:1389-1452)
-    if (want_grad) {
-      std::vector<double> gm((size_t)q * g1 * d);
-      host_grad_mean(sh, gm.data());
-      grad_mu[e].resize((size_t)q * d);
-      for (int k = 0; k < q; ++k)
-        for (int dd = 0; dd < d; ++dd) grad_mu[e][(size_t)k * d + dd] = gm[dd + (size_t)k * g1 * d];  // .cpp:136-140
-      // (Mk is only read when the results are collected: it is formed below, AFTER the kernels are enqueued, while they run)
-    }
   }
-  // One task per (evaluation, point to sample): Smith's derivative of the factor for the d coordinates of that point, then m
-  // triangular solves per coordinate -- q d m^3 (5/6) flop per evaluation, 2.6 Mflop at C5's m = 32 of plain scalar code.  It runs while
-  // the kernels do, but for d-KG at a few hundred points the kernels take less than a millisecond per evaluation and this loop was what
-  // a call waited for (r3: n = 300, d = 12, g = 3, q = 8: 1.10 ms of wall per evaluation against 0.65 of device time): the tasks are
-  // independent and go to host threads once there is enough of them (no HIP call inside; results land in disjoint slices).
-  auto form_mk = [&]() {
-    for (int e = 0; e < E; ++e) Mk[e].assign((size_t)q * d * m * m, 0.0);
-    auto task = [&](int t) {
-      const int e = t / q, k = t % q;
-      const StateHost& sh = hosts[e];
-      const double* chol = &blob[(size_t)rec.stride * e] + rec.L;
-      std::vector<double> gc((size_t)d * m * m), col(m);
-      host_grad_cholesky_per_point(sh, k, chol, gc.data());
-      for (int dd = 0; dd < d; ++dd) {
-        double* M = &Mk[e][((size_t)k * d + dd) * m * m];
-        for (int j = 0; j < m; ++j) {  // column j of dL: entries (l, j), l >= j, stored at gc[dd + j*d + l*d*m]
-          for (int l = 0; l < m; ++l) col[l] = (l >= j) ? gc[dd + (size_t)j * d + (size_t)l * d * m] : 0.0;
-          host_tri_solve(chol, 'N', m, col.data());
-          for (int l = 0; l < m; ++l) M[l + (size_t)j * m] = col[l];
-        }
-      }
-    };
-    const int tasks = E * q;
-    const double flop_per_task = (double)d * m * m * m;
-    int nthreads = 1;
-    if (tasks >= 2 && flop_per_task * tasks >= 2.0e6)  // (C3's m = 4: 512 flop per task -- stays on the calling thread)
-      nthreads = std::max(1, std::min({tasks, env_int("MOE_HOST_THREADS", 16), (int)std::thread::hardware_concurrency()}));
-    if (nthreads == 1) {
-      for (int t = 0; t < tasks; ++t) task(t);
-      return;
-    }
-    std::atomic<int> next{0};
-    std::exception_ptr err;
-    std::mutex err_mu;
-    auto worker = [&]() {
-      try {
-        for (int t = next.fetch_add(1); t < tasks; t = next.fetch_add(1)) task(t);
-      } catch (...) {
-        std::lock_guard<std::mutex> lk(err_mu);
-        if (!err) err = std::current_exception();
-      }
-    };
-    std::vector<std::thread> pool;
-    for (int i = 1; i < nthreads; ++i) pool.emplace_back(worker);
-    worker();
-    for (auto& th : pool) th.join();
-    if (err) std::rethrow_exception(err);
-  };
 
   // ---- device buffers ----
   DevBuf<double>&dBlob = gp.kBlob, &dNormals = gp.kNormals, &dTab = gp.kTab, &dBestPoint = gp.kBestPoint,
   &dBestValue = gp.kBestValue, &dBeta = gp.kBeta, &dT = gp.kT, &dC = gp.kC, &dTB = gp.kTB, &dOut = gp.kOut;
   DevBuf<unsigned long long>& dCounters = gp.kCounters;
-  gp.hKgIn.reserve(blob.size() + (size_t)((num_mc + 1) / 2) * m);
-  std::memcpy(gp.hKgIn.p, blob.data(), sizeof(double) * blob.size());
-  dBlob.upload(gp.hKgIn.p, blob.size(), s);
-  const long num_norm = (long)((num_mc + 1) / 2) * m;
-  std::memcpy(gp.hKgIn.p + blob.size(), normals, sizeof(double) * num_norm);
-  dNormals.upload(gp.hKgIn.p + blob.size(), num_norm, s);
+  dBlob.upload(blob, blob_size, s);
+  std::memcpy(blob + blob_size, normals, sizeof(double) * num_norm);
+  dNormals.upload(blob + blob_size, num_norm, s);
+  // ---- the m x m algebra of the state, on the device (kg_state.hip) ----
+  const int qd = q * d;
+  const int tri = m * (m + 1) / 2;
+  gp.kStateI.reserve((size_t)2 * E);
+  gp.kStateD.reserve((size_t)E * qd * (1 + (want_grad ? tri : 0)) + (size_t)E * (1 + qd) + (size_t)E * tri);
+  KgStateParams sp;
+  sp.cp = gp.cp;
+  sp.derivs = gp.derivs;
+  for (int b = 0; b <= kMaxDerivs; ++b) sp.noise[b] = (b < g1) ? gp.noise[b] : 0.0;
+  sp.mean = gp.mean;
+  sp.best_so_far = best_so_far;
+  sp.E = E;
+  sp.u = u;
+  sp.q = q;
+  sp.m = m;
+  sp.g = g;
+  sp.d = d;
+  sp.dp = dp;
+  sp.A = A;
+  sp.ng = ngrad;
+  sp.gkk = se.gkk;
+  sp.gx = se.gx;
+  sp.ek = se.ek;
+  sp.U = se.U;
+  sp.extra = se.extra;
+  sp.blob = dBlob.p;
+  sp.rec_stride = rec.stride;
+  sp.rec_L = rec.L;
+  sp.rec_mu_disc = rec.mu_disc;
+  sp.rec_C_disc = rec.C_disc;
+  sp.rec_bp = rec_bp;
+  sp.flags = gp.kStateI.p;
+  sp.winner = gp.kStateI.p + E;
+  sp.gmu = gp.kStateD.p;
+  sp.dL = gp.kStateD.p + (size_t)E * qd;
+  double* dFin = gp.kStateD.p + (size_t)E * qd * (1 + (want_grad ? tri : 0));
+  launch_kg_state(sp, s);
+  if (want_grad) launch_kg_dchol(sp, s);
   const long tab_stride = (long)ntiles * dp * 64;
   dTab.reserve((size_t)tab_stride * E + (size_t)dp * 64);  // + one tile: eval_loop's last prefetch reads past the end
   dBestPoint.reserve((size_t)E * num_local * dp);
@@ -1273,10 +1233,7 @@ KgPending kg_launch(GpDev& gp, int num_fidelity, const moe_gd_params_t& gd, cons
                        (wide_dp || variant == 2 || (variant == 0 && mc::wide_eval(dp, xlds))) ? 1 : 0);
     MOE_HIP_CHECK(hipGetLastError());
   }
-  const double ms_state = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wall0).count();
-  if (env_int("MOE_TRACE", 0))
-    std::fprintf(stderr, "[moe] state: device part + sync %.3f ms, host algebra + uploads %.3f ms (E = %d)\n", ms_dev_state,
-                 ms_state - ms_dev_state, E);
+  t_state.stop(s);
 
   // ---- 2. MC kernel ----
   KgMcParams mp;
@@ -1324,8 +1281,6 @@ KgPending kg_launch(GpDev& gp, int num_fidelity, const moe_gd_params_t& gd, cons
   mp.counters = dCounters.p;
   mp.next_sample = reinterpret_cast<unsigned int*>(dCounters.p + (((size_t)2 * E + 15) / 16) * 16);  // 128-byte aligned
   mp.prof = dCounters.p + n_ctr - 16;
-  auto timers = std::make_shared<std::array<EventTimer, 3>>();
-  EventTimer &t_mc = (*timers)[0], &t_cov = (*timers)[1], &t_tail = (*timers)[2];
   t_mc.start(s);
   mp.best_j = nullptr;
   mp.V = nullptr;
@@ -1351,7 +1306,7 @@ KgPending kg_launch(GpDev& gp, int num_fidelity, const moe_gd_params_t& gd, cons
     // the weight table: N doubles per sample (1.28 GB per evaluation at C5); beyond its cap -- the caller's share of the
     // workspace budget (kg_evaluate_batch, kg_mcmc_sums), MOE_KG_V_MAX_GB (default 4) for a bare kg_launch -- the samples
     // compute their weights in the kernel (workgroup-per-sample kernel only: the streamed-weights one is not chosen beyond the cap)
-    const double v_gb = 8.0 * (double)mp.v_stride * (double)total / 1e9;
+    const double v_gb = 8.0 * (double)mp.v_stride * (double)num_local / 1e9;  // (per evaluation, as above)
     if (v_gb <= v_cap && m <= kMaxM) {  // (the table kernel keeps a row of W in registers: m <= 64; beyond, weights in the kernel)
       gp.kV.reserve((size_t)mp.v_stride * (size_t)total + (size_t)64 * g1);  // (+ one tile: the sweeps prefetch one tile ahead)
       MOE_HIP_CHECK(hipMemsetAsync(dBeta.p + (size_t)total * m, 0, sizeof(double) * 64, s));
@@ -1394,8 +1349,12 @@ KgPending kg_launch(GpDev& gp, int num_fidelity, const moe_gd_params_t& gd, cons
   tl.SW = nullptr;
   tl.W = mp.W;
   tl.w_stride = mp.w_stride;
-  tl.Gm = gp.dWE.p + bl.col_grad0(0) * N;
+  tl.Gm = gp.dE.p + bl.col_grad0(0) * N;  // dK*/dXq itself: K^-1 goes onto the m columns of TB instead (launch_gtb)
   tl.g_stride = (long)ngrad * N;
+  tl.Linv = gp.dLinv.p;
+  tl.ldL = gp.ldL;
+  tl.tri_work = gp.dEK.p;  // (reserved by enqueue_kg_state_batch; the state's own use of it is behind us in stream order)
+  tl.work = gp.dVE.p;  // [2][N x E m]: enqueue_kg_state_batch reserves it; V = L^-1 K* is not needed any more
   tl.blob = dBlob.p;
   tl.rec = rec;
   tl.rec_bp = rec_bp;
@@ -1421,7 +1380,6 @@ KgPending kg_launch(GpDev& gp, int num_fidelity, const moe_gd_params_t& gd, cons
     } else {
       hipLaunchKernelGGL(kg_zc_kernel, dim3(m, m, E), dim3(256), 0, s, tl);
     }
-    t_tail.stop(s);
   } else if (want_grad) {
     t_cov.start(s);
     launch_cov_build(gp.cp, gp.dX.p, n, gp.derivs, dBestPoint.p, E * num_local, none, nullptr, dT.p, N, 0, s, true);
@@ -1451,18 +1409,43 @@ KgPending kg_launch(GpDev& gp, int num_fidelity, const moe_gd_params_t& gd, cons
     } else {
       hipLaunchKernelGGL(kg_zc_kernel, dim3(m, m, E), dim3(256), 0, s, tl);
     }
-    t_tail.stop(s);
   } else {
     hipLaunchKernelGGL(kg_sum_kernel, dim3(E), dim3(256), 0, s, tl);
   }
   MOE_HIP_CHECK(hipGetLastError());
-  // results through pinned memory: [out_stride * E doubles | 2 E counters]
-  const size_t n_out = (size_t)out_stride * E;
-  gp.hKgOut.reserve(n_out + 2 * (size_t)E);
+  // ---- grad KG from the sample sums, on the device (kg_state.hip) ----
+  if (want_grad) {
+    KgFinishParams fp;
+    fp.E = E;
+    fp.q = q;
+    fp.m = m;
+    fp.g = g;
+    fp.d = d;
+    fp.ng = ngrad;
+    fp.num_mc = num_mc;
+    fp.first_sample = first_sample;
+    fp.blob = dBlob.p;
+    fp.rec_stride = rec.stride;
+    fp.rec_L = rec.L;
+    fp.out = dOut.p;
+    fp.out_stride = out_stride;
+    fp.winner = sp.winner;
+    fp.gmu = sp.gmu;
+    fp.dL = sp.dL;
+    fp.fin = dFin;
+    launch_kg_finish(fp, dFin + (size_t)E * (1 + qd), s);
+    t_tail.stop(s);
+  }
+  // results through pinned memory: [fin: E (1 + q d) doubles (value only: E x out_stride = 1) | 2 E counters | E flags]
+  const int fin_stride = want_grad ? 1 + qd : out_stride;
+  const size_t n_out = (size_t)fin_stride * E;
+  gp.hKgOut.reserve(n_out + 2 * (size_t)E + (size_t)(E + 1) / 2 + 1);
   double* out = gp.hKgOut.p;
-  dOut.download(out, n_out, s);
+  MOE_HIP_CHECK(hipMemcpyAsync(out, want_grad ? dFin : dOut.p, sizeof(double) * n_out, hipMemcpyDeviceToHost, s));
   unsigned long long* counters = reinterpret_cast<unsigned long long*>(gp.hKgOut.p + n_out);
   dCounters.download(counters, (size_t)2 * E, s);
+  int* flags_h = reinterpret_cast<int*>(gp.hKgOut.p + n_out + 2 * (size_t)E);
+  MOE_HIP_CHECK(hipMemcpyAsync(flags_h, gp.kStateI.p, sizeof(int) * E, hipMemcpyDeviceToHost, s));
 #if MOE_BLOCK_PROF
   auto prof_p = std::make_shared<std::vector<unsigned long long>>(16);
   MOE_HIP_CHECK(hipMemcpyAsync(prof_p->data(), dCounters.p + n_ctr - 16, sizeof(unsigned long long) * 16, hipMemcpyDeviceToHost, s));
@@ -1473,9 +1456,6 @@ KgPending kg_launch(GpDev& gp, int num_fidelity, const moe_gd_params_t& gd, cons
     bp_p->resize((size_t)num_local * dp);
     dBestPoint.download(bp_p->data(), bp_p->size(), s);
   }
-  // host algebra that only the collection needs: L^-1 dL/dXq per point and dimension (O(q d m^3): ~1 ms per evaluation at C5),
-  // overlapped with the kernels enqueued above
-  if (want_grad) form_mk();
   GpDev* gpp = &gp;
   KgPending pending;
   pending.collect = [=](double* kg_sum, double* grad_sum, double* best_points, moe_kg_stats_t* stats) {
@@ -1511,34 +1491,20 @@ KgPending kg_launch(GpDev& gp, int num_fidelity, const moe_gd_params_t& gd, cons
                      (double)w[5] / std::max<unsigned long long>(w[7], 1));
     }
 #endif
-    const std::vector<std::vector<double>>&grad_mu = *grad_mu_p, &Mk = *Mk_p;
+    for (int e = 0; e < E; ++e)
+      if (flags_h[e] != 0)
+        throw Error(MOE_ERR_SINGULAR,
+                    "GP-Variance matrix singular. Check for duplicate points_to_sample/being_sampled or "
+                    "points_to_sample/being_sampled duplicating points_sampled with 0 noise.",
+                    m, flags_h[e]);
     if (best_points && fetch_bp)
       for (int i = 0; i < num_local; ++i)
         for (int k = 0; k < d; ++k) best_points[(size_t)i * d + k] = (*bp_p)[(size_t)i * dp + k];
 
-    // ---- host assembly of the gradient ----
     for (int e = 0; e < E; ++e) {
-      const double* o = &out[(size_t)out_stride * e];
+      const double* o = &out[(size_t)fin_stride * e];
       kg_sum[e] = o[0];
-      if (want_grad) {
-        const double* ZC = o + 1;
-        const double* DIR = o + 1 + m * m;
-        const double* GTB = DIR + ngrad;
-        for (int k = 0; k < q; ++k)
-          for (int dd = 0; dd < d; ++dd) {
-            double direct = 0.0;
-            for (int b = 0; b < g1; ++b) direct += DIR[(k * g1 + b) * d + dd] - GTB[(k * g1 + b) * d + dd];
-            const double* M = &Mk[e][((size_t)k * d + dd) * m * m];
-            double zmc = 0.0;
-            for (int j = 0; j < m; ++j)
-              for (int r = j; r < m; ++r) zmc = std::fma(M[r + (size_t)j * m], ZC[r + (size_t)j * m], zmc);
-            grad_sum[(size_t)e * q * d + (size_t)k * d + dd] = -(direct - zmc);  // aggregate -= gic . z   (.cpp:214-221)
-          }
-        // winner term: + M * grad_mu[winner]  (.cpp:157-161); added once, by the shard that owns sample 0
-        if (winner[e] >= 0 && winner[e] < q && first_sample == 0)
-          for (int k = 0; k < d; ++k)
-            grad_sum[(size_t)e * q * d + (size_t)winner[e] * d + k] += (double)num_mc * grad_mu[e][(size_t)winner[e] * d + k];
-      }
+      if (want_grad) std::copy(o + 1, o + 1 + qd, grad_sum + (size_t)e * qd);
       if (stats) {
         stats->posterior_mean_evals += (long long)counters[2 * e];
         stats->posterior_grad_evals += (long long)counters[2 * e + 1];
@@ -1550,6 +1516,7 @@ KgPending kg_launch(GpDev& gp, int num_fidelity, const moe_gd_params_t& gd, cons
     gp.last_ms[0] = ms_mc / E;
     gp.last_ms[1] = ms_cov / E;
     gp.last_ms[2] = ms_tail / E;
+    const double ms_state = (*timers)[3].ms();
     gp.last_ms[3] = ms_state / E;
     gp.last_ms[4] = wall / E;
     if (stats) {
@@ -1569,10 +1536,14 @@ int kg_max_batch(const GpDev& gp, int P, int q, int p, int num_local, bool want_
   const double ngrad = want_grad ? q * g1 * gp.d : 0.0;
   const bool fused = want_grad && gp.g == 0 && m <= 8;
   const double chunks = std::ceil((double)num_local / (fused ? kFusedChunk : kTbChunk));
-  double doubles = 3.0 * N * (m + ngrad + A) + (double)num_local * (gp.dp + 1 + 2 * m);
+  // state matrix E (all columns), V = L^-1 K* with the tail's K^-1 TB workspace behind it, W = K^-1 K*; the packed d chol / d Xq
+  double doubles = N * (m + ngrad + A) + 3.0 * N * m + (double)num_local * (gp.dp + 1 + 2 * m) +
+                   (want_grad ? (double)q * gp.d * m * (m + 1) / 2 : 0.0);
   if (want_grad) doubles += (fused ? 0.0 : N * (double)num_local) + (chunks + 1.0) * m * N;
   // the per-sample weight table of the workgroup-per-sample / streamed-weights kernels (the latter: whole tiles, fantasy points included)
-  if (gp.g > 0 || gp.n + u > 1500) doubles += (N + (u + 64.0) * g1) * (double)num_local;
+  // (always: whether an evaluation takes one of those kernels is decided per evaluation in kg_launch -- far frames send small
+  //  q-KG shapes there too -- and the batch must fit whatever it decides)
+  doubles += (N + (u + 64.0) * g1) * (double)num_local;
   const double per_eval_gb = 8.0 * doubles / 1e9;
   return (int)std::max(1.0, std::floor(budget_gb / std::max(per_eval_gb, 1e-9)));
 }

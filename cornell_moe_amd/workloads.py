@@ -30,6 +30,14 @@ R3_PARITY_CASES = (
     ("d20g8", dict(seed=3305, n=36, d=20, q=3, p=1, M=16, P=6, derivs=(0, 2, 4, 6, 8, 10, 12, 14))),  # 8 derivative slots, d > 16
 )
 
+# Round 4 (tools/make_golden.py: shape_fixtures_r4 -> tests/golden/ref_shapes_r4.npz): BASELINE.json configs[4] at its REAL
+# size (n = 2000, N = 8000, m = 32; M = 64 keeps the reference to minutes: two N^3/3 factorisations + ~0.07 s per sample),
+# and C5's stretch point (all 12 derivatives observed, m = 104) at the largest n the reference finishes in a few minutes.
+R4_PARITY_CASES = (
+    ("c5full", dict(name="C5", M=64)),                                                             # N = 8000, 32 tiles
+    ("c5g12", dict(name="C5", n=600, M=32, derivs=tuple(range(12)))),                              # N = 7800, m = 104
+)
+
 
 class Workload(object):
     pass

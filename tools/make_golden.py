@@ -245,6 +245,34 @@ def shape_fixtures_r3():
     print("wrote", OUT_SHAPES3, os.path.getsize(OUT_SHAPES3), "bytes")
 
 
+OUT_SHAPES4 = os.path.join(ROOT, "tests", "golden", "ref_shapes_r4.npz")
+
+
+def shape_fixtures_r4():
+    """Round 4: BASELINE.json configs[4] EXACTLY (n = 2000, d = 12, q = 8, g = 3, P = 50; M = 64 samples) and
+    the stretch point g = 12 (m = 104) at n = 600 (N = 7800), from the unmodified reference: KG, grad KG, every end point, and
+    the value-only evaluation."""
+    from cornell_moe_amd.workloads import make_workload, R4_PARITY_CASES
+    blob = {}
+    for tag, kw in R4_PARITY_CASES:
+        w = make_workload(**kw)
+        gp = ref.RefGP(1, w.alpha, w.lengths, w.X, w.y, w.noise, list(w.derivs))
+        best = float(gp.additional_mean(w.discrete).min())
+        r = gp.kg(w.inner_gd, w.bounds, w.discrete, w.Xq, None, w.M, best, w.kg_normals, want_grad=True, details=True)
+        blob[tag + "_best_so_far"] = np.array(best)
+        blob[tag + "_kg"], blob[tag + "_grad_kg"], blob[tag + "_best_point"] = np.array(r["kg"]), r["grad"], r["best_point"]
+        blob[tag + "_check"] = np.array([float(w.X.sum()), float(w.kg_normals.sum()), float(w.Xq.sum()), float(w.discrete.sum())])
+        blob[tag + "_seconds"] = np.array(r["seconds"])
+        rv = gp.kg(w.inner_gd, w.bounds, w.discrete, w.Xq, None, w.M, best, w.kg_normals, want_grad=False)
+        blob[tag + "_kg_value_only"] = np.array(rv["kg"])
+        pts = w.query[:3]
+        blob[tag + "_q_mean"], blob[tag + "_q_grad_mean"], blob[tag + "_q_var"] = gp.mean(pts), gp.grad_mean(pts), gp.var(pts)
+        print("%s: n=%d d=%d q=%d g=%d m=%d M=%d  KG=%.15g  (reference: %.2f s state + %.2f s evaluation)" % (
+            tag, w.n, w.d, w.q, w.g, w.m, w.M, r["kg"], r["seconds"][0], r["seconds"][1]), flush=True)
+    np.savez_compressed(OUT_SHAPES4, **blob)
+    print("wrote", OUT_SHAPES4, os.path.getsize(OUT_SHAPES4), "bytes")
+
+
 OUT_MS = os.path.join(ROOT, "tests", "golden", "ref_kg_multistart.npz")
 
 
@@ -351,6 +379,9 @@ def main():
         return
     if "--shapes-r3" in sys.argv:
         shape_fixtures_r3()
+        return
+    if "--shapes-r4" in sys.argv:
+        shape_fixtures_r4()
         return
     if "--kg-multistart" in sys.argv:
         kg_multistart_fixtures()
