@@ -162,15 +162,19 @@ def measure_traffic(config, restarts, log, timeout_s=180):
     env = dict(os.environ, TMPDIR="/tmp")
     try:
         for tag, ctrs in (("fetch", ["FETCH_SIZE"]), ("write", ["WRITE_SIZE"]),
-                          ("fp64", ["SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_TRANS_F64"])):
+                          ("fp64", ["SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_TRANS_F64"]),
+                          # r4: the clock the kernel actually ran at and how busy its vector ALUs were, IN the kernel
+                          ("clock", ["GRBM_GUI_ACTIVE", "GRBM_COUNT"]),
+                          ("busy", ["SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES", "SQ_ACTIVE_INST_VALU", "SQ_INST_CYCLES_SALU"]),
+                          ("insts", ["SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY"])):
             cmd = [exe, "--kernel-trace", "--pmc"] + ctrs + ["--output-format", "csv", "-d", os.path.join(tmp, tag), "-o", "p",
                    "--", sys.executable, os.path.join(ROOT, "tools", "prof_kg.py"), config, str(restarts), "2"]
             try:
                 subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout_s, check=True)
             except Exception as e:  # the FP64 pass is an extra: keep the traffic passes' result if only it fails
-                if tag != "fp64":
+                if tag in ("fetch", "write"):
                     raise
-                log("measure_traffic: FP64 instruction pass failed (%s)" % type(e).__name__)
+                log("measure_traffic: %s counter pass failed (%s)" % (tag, type(e).__name__))
         res = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "hbm_traffic.py"), tmp], stdout=subprocess.PIPE,
                              universal_newlines=True, timeout=60, check=True)
         data = json.loads(res.stdout.strip().splitlines()[-1])
@@ -225,6 +229,9 @@ def main():
                          "ranks (the C4 job, strong scaling); C5 -- 2 per GPU")
     ap.add_argument("--shard", choices=["restarts", "mc"], default="restarts")
     ap.add_argument("--config", default="C3")
+    ap.add_argument("--derivs", type=int, default=None,
+                    help="observe the first G partial derivatives instead of the configuration's own list (C5's stretch point of "
+                         "SURVEY 8(d): --config C5 --derivs 12 -> N = 26 000, m = 104)")
     ap.add_argument("--cpu-sample-mc", type=int, default=400)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-traffic", action="store_true", help="skip the in-run rocprofv3 PMC passes (HBM traffic, executed FP64)")
@@ -286,8 +293,9 @@ def main():
             raise SystemExit("the C4 job (64 restarts per step) does not divide over %d ranks; pass --restarts" % world)
         R = C4_RESTARTS // world
     else:
-        R = args.restarts if args.restarts is not None else (2 if args.config == "C5" else 8)
-    w = make_workload(args.config, num_restarts=R * world)
+        R = args.restarts if args.restarts is not None else ((1 if args.derivs else 2) if args.config == "C5" else 8)
+    w = make_workload(args.config, num_restarts=R * world,
+                      derivs=None if args.derivs is None else tuple(range(args.derivs)))
     if multi_fallback is not None:
         devs = list(range(min(world, ndev)))
         gps = [DeviceGP(w.hyperparameters, w.X, w.y, w.noise, w.derivs, device=dv) for dv in devs]
@@ -465,7 +473,7 @@ def main():
         mc_kernel = {0: "kg_mc_kernel", 1: "kg_mc_block_kernel", 2: "kg_mc_stream_kernel"}[G.last_kernel_info()["variant"]]
         pmc, traffic_src = (None, "skipped (--no-traffic)")
         if world == 1 and not args.no_traffic:
-            pmc, traffic_src = measure_traffic(args.config, Rl, log)
+            pmc, traffic_src = measure_traffic(args.config if args.derivs is None else "%s:g=%d" % (args.config, args.derivs), Rl, log)
         if pmc is None:
             pmc = committed_traffic()
             traffic_src = "profiles/hbm_traffic.json (committed rocprofv3 PMC passes of an earlier run, %d evaluations per launch; %s)" % (
@@ -482,6 +490,24 @@ def main():
                         "wave_insts_per_launch": {k: pk[k] for k in pk if k.startswith("SQ_INSTS_VALU")},
                         "note": "EXECUTED FP64 flop (64 lanes x (2 FMA + ADD + MUL) wave-instructions, rocprofv3 PMC) / the same "
                                 "HIP-event launch time: how busy the FP64 pipe is, next to the algorithmic fraction `frac`"}
+        # r4: effective clock and VALU-busy fraction of the MC kernel from its own PMC passes (tools/hbm_traffic.py): GRBM_GUI_ACTIVE
+        # summed over the 8 XCDs / kernel time = clock; SQ_ACTIVE_INST_VALU (quad-cycles, summed over the SIMDs) / CUs / GUI_ACTIVE
+        # per XCD = the fraction of cycles a CU's vector ALUs execute an instruction (rocprofv3's own VALUBusy expression)
+        in_kernel = None
+        if pk.get("effective_clock_ghz") is not None:
+            in_kernel = {k: pk.get(k) for k in ("effective_clock_ghz", "valu_busy", "salu_busy", "valu_insts_per_launch",
+                                                 "valu_quad_cycles_per_inst", "wait_inst_frac_of_wave_cycles", "kernel_ms_under_pmc")}
+            in_kernel["fp64_peak_at_effective_clock_tflops"] = 256 * 4 * 16 * 2 * pk["effective_clock_ghz"] / 1e3
+            if executed and pk.get("kernel_ms_under_pmc"):
+                in_kernel["executed_frac_of_peak_at_effective_clock"] = (
+                    exec_flop / (pk["kernel_ms_under_pmc"] * 1e-3) / 1e12 / in_kernel["fp64_peak_at_effective_clock_tflops"])
+            if pk.get("valu_insts_per_launch") and exec_flop:
+                fp64_insts = sum(pk.get(k, 0.0) for k in ("SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64",
+                                                           "SQ_INSTS_VALU_TRANS_F64"))
+                in_kernel["fp64_share_of_valu_insts"] = fp64_insts / pk["valu_insts_per_launch"]
+                in_kernel["fma_share_of_fp64_insts"] = pk.get("SQ_INSTS_VALU_FMA_F64", 0.0) / fp64_insts if fp64_insts else None
+            in_kernel["note"] = ("PMC passes over tools/prof_kg.py (the same batched evaluation, kernel time taken from the pass itself: "
+                                 "profiled runs clock lower than the timed region)")
         out = {
             "metric": ("q-KG gradient evals/s (n=1000,d=8,q=4,10k MC)" if args.config in ("C3", "C4") else
                        "%s gradient evals/s (n=%d,d=%d,q=%d,g=%d,%d MC) [secondary configuration %s]"
@@ -505,6 +531,7 @@ def main():
                          "frac": ach_tflops / FP64_PEAK_TFLOPS,
                          "executed_frac": executed["frac"] if executed else None,
                          "executed": executed,
+                         "in_kernel": in_kernel,
                          "traffic": traffic * (Rl / float(pmc_R)) if traffic is not None else None,
                          "traffic_source": traffic_src,
                          "kernel": mc_kernel, "avg_launch_ms": launch_ms, "avg_ms_per_eval": mc_ms,
@@ -546,10 +573,10 @@ def main():
                 out["roofline_cov_build_kxx"] = mapi.kxx_build_probe(log)
             except Exception as e:  # pragma: no cover
                 log("kxx_build_probe failed: %s" % e)
-        if not args.no_cpu_baseline and world == 1 and args.config == "C5":
+        if not args.no_cpu_baseline and world == 1 and args.config == "C5" and args.derivs is None:
             out["cpu_baseline"] = cpu_baseline_c5(w, log)
             out["speedup_vs_cpu_one_core"] = value / out["cpu_baseline"]["value"]
-        elif not args.no_cpu_baseline and world == 1:  # reported baseline: rank 0 at N = 1 only
+        elif not args.no_cpu_baseline and world == 1 and args.derivs is None:  # reported baseline: rank 0 at N = 1 only
             out["cpu_baseline"] = cpu_baseline(w, best, args.cpu_sample_mc, log)
             out["speedup_vs_cpu_best"] = value / out["cpu_baseline"]["value"]
             if "one_core_evals_per_s" in out["cpu_baseline"]:

@@ -779,8 +779,11 @@ __global__ __launch_bounds__(64) void kg_sample_prep_generic_kernel(KgMcParams P
 // operation order, hence the same bits.  Inside the workgroup-per-sample kernel that computation reads all of W_e
 // (N x m) per sample and CU through a few dozen loads in flight -- a sixth of the kernel at m = 16; here one thread keeps
 // a row of W in registers, beta arrives through scalar loads, and the chip writes N x M doubles at streaming speed.
+// m > 64 (r4): the columns go down in passes of 64 -- pass [c_lo, c_lo + MB) continues the fma chain from the partial sum the previous
+// pass left in V (plain store), the last pass scales and streams the result out; one pass (first = last) is the code of m <= 64.
 template <int MB>
-__global__ __launch_bounds__(256) void kg_sample_weights_kernel(KgMcParams P, double* __restrict__ V, int samples_per_block) {
+__global__ __launch_bounds__(256) void kg_sample_weights_kernel(KgMcParams P, double* __restrict__ V, int samples_per_block,
+                                                               int c_lo = 0, int first = 1, int last = 1) {
   const int r = blockIdx.x * 256 + threadIdx.x;
   const int e = blockIdx.z;
   const int m = P.m, g1 = 1 + P.g;
@@ -790,8 +793,8 @@ __global__ __launch_bounds__(256) void kg_sample_weights_kernel(KgMcParams P, do
   const int rr = min(r, P.N - 1);
 #pragma unroll
   for (int c = 0; c < MB; ++c) {  // zero beyond m: the unconditional fma below then leaves v untouched
-    const double t = We[rr + (long)min(c, m - 1) * P.N];
-    l[c] = (c < m) ? t : 0.0;
+    const double t = We[rr + (long)min(c_lo + c, m - 1) * P.N];
+    l[c] = (c_lo + c < m) ? t : 0.0;
   }
   const double kiy = P.KinvY[rr];
   const int a = rr % g1;
@@ -804,15 +807,19 @@ __global__ __launch_bounds__(256) void kg_sample_weights_kernel(KgMcParams P, do
   const double fscale = ((cf % g1) == 0) ? P.alpha : -P.alpha * P.inv_lp[max(cf % g1, 1) - 1];
   for (int sl = s0; sl < s1; ++sl) {
     const long so = (long)e * P.num_local + sl;
-    const double* __restrict__ bs = beta + so * m;
-    double v = kiy;
+    const double* __restrict__ bs = beta + so * m + c_lo;
+    double v = first ? kiy : V[so * P.v_stride + rr];
 #pragma unroll
     for (int c = 0; c < MB; ++c) v = fma(-l[c], bs[c], v);  // uniform, contiguous: wide scalar loads (reads up to MB - m
                                                             // doubles past the row: next rows / the zeroed pad, times l = 0)
-    if (r < P.N)
-      __builtin_nontemporal_store(v * scale, &V[so * P.v_stride + r]);  // (streaming: 1.28 GB at C5, read once by the MC kernel)
-    else if (r < P.v_stride)
-      V[so * P.v_stride + r] = fantasy ? bs[min(cf, m - 1)] * fscale : 0.0;
+    if (r < P.N) {
+      if (last)
+        __builtin_nontemporal_store(v * scale, &V[so * P.v_stride + r]);  // (streaming: 1.28 GB at C5, read once by the MC kernel)
+      else
+        V[so * P.v_stride + r] = v;
+    } else if (r < P.v_stride && last) {
+      V[so * P.v_stride + r] = fantasy ? beta[so * m + min(cf, m - 1)] * fscale : 0.0;
+    }
   }
 }
 
@@ -824,7 +831,8 @@ void launch_sample_weights(const KgMcParams& P, double* V, hipStream_t s) {
   else if (P.m <= 32)
     hipLaunchKernelGGL(kg_sample_weights_kernel<32>, grid, dim3(256), 0, s, P, V, spb);
   else
-    hipLaunchKernelGGL(kg_sample_weights_kernel<64>, grid, dim3(256), 0, s, P, V, spb);
+    for (int c_lo = 0; c_lo < P.m; c_lo += 64)
+      hipLaunchKernelGGL(kg_sample_weights_kernel<64>, grid, dim3(256), 0, s, P, V, spb, c_lo, c_lo == 0 ? 1 : 0, c_lo + 64 >= P.m ? 1 : 0);
   MOE_HIP_CHECK(hipGetLastError());
 }
 
@@ -995,7 +1003,9 @@ KgPending kg_launch(GpDev& gp, int num_fidelity, const moe_gd_params_t& gd, cons
                                                       : (weight_table_gb >= 0.0 ? weight_table_gb : 4.0);
   // (the size test is per EVALUATION: which kernel an evaluation takes must not depend on the batch it shares a call with -- the
   //  callers size their batches with kg_max_batch, which budgets every evaluation's table)
-  const bool stream_ok = g1 == 1 + G && G <= 4 && m <= kMaxM && prep_mode != 0 &&
+  // (r4: 8 and 12 observed derivatives and m > 64 too -- the kernel itself needs neither m nor beta once the sample pre-pass and the
+  //  weight table are there)
+  const bool stream_ok = g1 == 1 + G && prep_mode != 0 &&
                          8.0 * (double)v_stride_tiles * (double)num_local / 1e9 <= v_cap;
   if (stream_ok && env_int("MOE_KG_STREAM_WEIGHTS", 1) != 0) {
     // (r3, ms of MC per evaluation, `profiles/r03_variant2_sweep.txt`: C5 7.9 -> 5.0; d = 12, g = 3, q = 8, M = 4000: n = 1200 1.24 -> 0.68 against the
@@ -1012,8 +1022,9 @@ KgPending kg_launch(GpDev& gp, int num_fidelity, const moe_gd_params_t& gd, cons
   {
     const int forced = env_int("MOE_KG_VARIANT", variant);
     if (forced == 2 && !stream_ok)
-      throw Error(MOE_ERR_RUNTIME, "the streamed-weights MC kernel needs the weight table within its cap, (q + p)(1 + g) <= 64 and g <= 4");
-    if (!(forced != variant && (G > 4 || m > kMaxM))) variant = forced;  // (shapes only the workgroup-per-sample kernel is built for stay there)
+      throw Error(MOE_ERR_RUNTIME, "the streamed-weights MC kernel needs the weight table within its cap and every derivative slot observed");
+    // (shapes the LDS-slab wave-per-sample kernel is not built for keep to the other two)
+    if (!(forced == 0 && (G > 4 || m > kMaxM))) variant = forced;
   }
   if (variant == 1 && (tr < 0 || kg_mc_block_lds_bytes(dp, G, num_lds_tiles) > (size_t)160 * 1024))
     throw Error(MOE_ERR_RUNTIME, "point set too large for the workgroup-per-sample MC kernel");
@@ -1307,7 +1318,7 @@ KgPending kg_launch(GpDev& gp, int num_fidelity, const moe_gd_params_t& gd, cons
     // workspace budget (kg_evaluate_batch, kg_mcmc_sums), MOE_KG_V_MAX_GB (default 4) for a bare kg_launch -- the samples
     // compute their weights in the kernel (workgroup-per-sample kernel only: the streamed-weights one is not chosen beyond the cap)
     const double v_gb = 8.0 * (double)mp.v_stride * (double)num_local / 1e9;  // (per evaluation, as above)
-    if (v_gb <= v_cap && m <= kMaxM) {  // (the table kernel keeps a row of W in registers: m <= 64; beyond, weights in the kernel)
+    if (v_gb <= v_cap) {  // (m > 64: the table kernel takes the columns of W 64 at a time, r4)
       gp.kV.reserve((size_t)mp.v_stride * (size_t)total + (size_t)64 * g1);  // (+ one tile: the sweeps prefetch one tile ahead)
       MOE_HIP_CHECK(hipMemsetAsync(dBeta.p + (size_t)total * m, 0, sizeof(double) * 64, s));
       mp.V = gp.kV.p;

@@ -2069,6 +2069,23 @@ inline void launch_stream_dp(const KgMcParams& P, int G, int blocks, int waves, 
     case 2: launch_stream_inst<DP, 2>(P, blocks, waves, shm, s); break;
     case 3: launch_stream_inst<DP, 3>(P, blocks, waves, shm, s); break;
     case 4: launch_stream_inst<DP, 4>(P, blocks, waves, shm, s); break;
+    // r4: 8 and 12 observed derivatives (C5's stretch point, g = 12: a sample's weights are 13 doubles per point, 213 KB at n = 2000 --
+    // they fit no on-chip store, and the workgroup-per-sample kernel's all-register instantiation spilt them to scratch: 713 GB of
+    // traffic per evaluation; here they stream once per sweep)
+    case 8:
+      if constexpr (DP >= 8) {
+        launch_stream_inst<DP, 8>(P, blocks, waves, shm, s);
+        break;
+      }
+      [[fallthrough]];
+    case 12:
+      if constexpr (DP >= 12) {
+        if (G == 12) {
+          launch_stream_inst<DP, 12>(P, blocks, waves, shm, s);
+          break;
+        }
+      }
+      [[fallthrough]];
     default: throw Error(MOE_ERR_RUNTIME, "unsupported derivative-slot count in the streamed-weights MC kernel");
   }
 }
@@ -2077,6 +2094,8 @@ inline void launch_stream_dp_wide(const KgMcParams& P, int G, int blocks, int wa
   switch (G) {
     case 0: launch_stream_inst<DP, 0>(P, blocks, waves, shm, s); break;
     case 4: launch_stream_inst<DP, 4>(P, blocks, waves, shm, s); break;
+    case 8: launch_stream_inst<DP, 8>(P, blocks, waves, shm, s); break;
+    case 12: launch_stream_inst<DP, 12>(P, blocks, waves, shm, s); break;
     default: throw Error(MOE_ERR_RUNTIME, "unsupported derivative-slot count in the streamed-weights MC kernel");
   }
 }

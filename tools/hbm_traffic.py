@@ -22,6 +22,8 @@ for f in glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recursiv
                 continue  # only the N x (E M) gradient-tail build, not the small state builds
             if key:
                 acc[key][row["Counter_Name"]].append(float(row["Counter_Value"]))
+                if row["Counter_Name"] == "GRBM_GUI_ACTIVE" and "End_Timestamp" in row:
+                    acc[key]["_dur_ns"].append(float(row["End_Timestamp"]) - float(row["Start_Timestamp"]))
 out = {}
 for k, c in acc.items():
     fetch = sum(c.get("FETCH_SIZE", [0])) / max(len(c.get("FETCH_SIZE", [1])), 1)
@@ -33,6 +35,25 @@ for k, c in acc.items():
     for ctr in ("SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_TRANS_F64", "SQ_INSTS_VALU"):
         if ctr in c:
             out[k][ctr] = sum(c[ctr]) / len(c[ctr])
+    # r4: effective clock and VALU busy of the kernel (bench.py roofline.in_kernel).  GRBM_GUI_ACTIVE comes back summed over the 8
+    # XCDs of the chip (18e9 "cycles" per second otherwise); SQ_* are sums over the SIMDs in quad-cycles (MI355X_MICROARCH.md)
+    NUM_XCD, NUM_CU = 8, 256
+    mean = lambda v: sum(v) / len(v)
+    if c.get("GRBM_GUI_ACTIVE") and c.get("_dur_ns"):
+        # the LAST launch of each pass (the first carries first-touch allocation stalls)
+        gui, dur = c["GRBM_GUI_ACTIVE"][-1] / NUM_XCD, c["_dur_ns"][-1]
+        out[k]["effective_clock_ghz"] = gui / dur
+        out[k]["kernel_ms_under_pmc"] = dur / 1e6
+        if c.get("SQ_ACTIVE_INST_VALU"):
+            out[k]["valu_busy"] = c["SQ_ACTIVE_INST_VALU"][-1] / NUM_CU / gui
+        if c.get("SQ_INST_CYCLES_SALU"):
+            out[k]["salu_busy"] = c["SQ_INST_CYCLES_SALU"][-1] / NUM_CU / gui
+        if c.get("SQ_INSTS_VALU"):
+            out[k]["valu_insts_per_launch"] = mean(c["SQ_INSTS_VALU"])
+            if c.get("SQ_ACTIVE_INST_VALU"):
+                out[k]["valu_quad_cycles_per_inst"] = c["SQ_ACTIVE_INST_VALU"][-1] / c["SQ_INSTS_VALU"][-1]
+        if c.get("SQ_WAIT_INST_ANY") and c.get("SQ_WAVE_CYCLES"):
+            out[k]["wait_inst_frac_of_wave_cycles"] = c["SQ_WAIT_INST_ANY"][-1] / c["SQ_WAVE_CYCLES"][-1]
     if "SQ_INSTS_VALU_FMA_F64" in out[k]:
         out[k]["executed_fp64_flop_per_launch"] = 64.0 * (2.0 * out[k]["SQ_INSTS_VALU_FMA_F64"] + out[k].get("SQ_INSTS_VALU_ADD_F64", 0.0)
                                                           + out[k].get("SQ_INSTS_VALU_MUL_F64", 0.0))

@@ -19,6 +19,8 @@ if ":" in cfg:  # e.g. C3:n=60,M=2000  -- override fields of a named configurati
         k, v = kv.split("=")
         over[k] = int(v)
 steps = over.pop("steps", None)   # inner GD steps per restart (instruction-count fits: tools/mc_overhead.sh)
+if "g" in over:                   # observe the first g partial derivatives (bench.py --derivs)
+    over["derivs"] = tuple(range(over.pop("g")))
 w = make_workload(cfg, num_restarts=R, **over)
 if steps is not None:
     w.inner_gd = (w.inner_gd[0], steps) + tuple(w.inner_gd[2:])
