@@ -355,7 +355,8 @@ int moe_kxx_build_probe(const moe_gp_t* gp_c, int repeat, double* avg_ms, double
     MOE_HIP_CHECK(hipEventCreate(&e0));
     MOE_HIP_CHECK(hipEventCreate(&e1));
     auto launch = [&] {  // exactly the call of GpDev::rebuild (gp.hip): K(X, X) + noise on the diagonal, leading dimension ldL
-      moe::launch_cov_build(gp.cp, gp.dX.p, gp.n, gp.derivs, gp.dX.p, gp.n, gp.derivs, gp.dNoise.p, dOut.p, gp.ldL, 0, gp.stream);
+      moe::launch_cov_build(gp.cp, gp.dX.p, gp.n, gp.derivs, gp.dX.p, gp.n, gp.derivs, gp.dNoise.p, dOut.p, gp.ldL, 0, gp.stream,
+                            false, true);
     };
     launch();
     MOE_HIP_CHECK(hipEventRecord(e0, gp.stream));
@@ -367,7 +368,8 @@ int moe_kxx_build_probe(const moe_gp_t* gp_c, int repeat, double* avg_ms, double
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
     if (avg_ms) *avg_ms = ms / std::max(repeat, 1);
-    if (bytes_per_launch) *bytes_per_launch = 8.0 * (2.0 * (double)gp.n * gp.d + (double)gp.N * gp.N);
+    // SURVEY 8(d), symmetric case: 8 [n d + N (N + 1) / 2] -- the points once, the lower triangle once (r4: what the launch writes)
+    if (bytes_per_launch) *bytes_per_launch = 8.0 * ((double)gp.n * gp.d + 0.5 * (double)gp.N * ((double)gp.N + 1.0));
   });
 }
 

@@ -289,9 +289,17 @@ void GpDev::rebuild() {
   dInfo.reserve(1);
   dKinvY.reserve(N);
   dTmp.reserve((size_t)2 * N);
-  launch_cov_build(cp, dX.p, n, derivs, dX.p, n, derivs, dNoise.p, dL.p, ldL, 0, stream);
+  // K(X, X) + noise, lower triangle only (r4: 8 [n d + N (N + 1) / 2] bytes, SURVEY 8(d)'s symmetric count -- the full square and the
+  // pass that zeroed its upper half afterwards wrote three times that).  The strict upper triangle of dL is cleared once per buffer
+  // SHAPE: neither this build nor the factorisation writes there, so rebuilds in place (hyper-parameter sampling) find it zero.
+  if (dL.p != zeroed_L || ldL != zeroed_ld) {
+    MOE_HIP_CHECK(hipMemsetAsync(dL.p, 0, sizeof(double) * (size_t)ldL * ldL, stream));
+    zeroed_L = dL.p;
+    zeroed_ld = ldL;
+  }
+  launch_cov_build(cp, dX.p, n, derivs, dX.p, n, derivs, dNoise.p, dL.p, ldL, 0, stream, false, true);
   dWE.reserve(cholesky_work_doubles(N));  // the state workspace doubles as scratch of the recursive inversion
-  launch_cholesky_and_inverse(N, dL.p, ldL, dLinv.p, ldL, dWE.p, dInfo.p, stream);
+  launch_cholesky_and_inverse(N, dL.p, ldL, dLinv.p, ldL, dWE.p, dInfo.p, stream, true);
   finish_factorisation();
 }
 

@@ -23,6 +23,8 @@ struct GpDev {
   hipStream_t stream = nullptr;
   int d = 0, dp = 0, n = 0, g = 0, N = 0;
   long ldL = 0;  // leading dimension of dL / dLinv: N at the last rebuild + head-room for appended rows
+  const double* zeroed_L = nullptr;  // the buffer / leading dimension dL's strict upper triangle was last cleared for (rebuild)
+  long zeroed_ld = 0;
   CovParams cp;
   DerivList derivs;
   std::vector<double> X, y, noise;  // host copies (reference keeps them too, gpp_math.hpp:846-856)

@@ -39,9 +39,11 @@ struct DerivList {
 // (centred pre-scaled coordinates + table exp, <= 2 ulp per entry); the GP's own K(X, X), K* and the posterior queries keep the
 // general kernel, whose entries follow the reference's formulas operation for operation (a duplicate point must still be
 // reported singular at the same pivot).
+// lower_only = true (A == B: the symmetric K(X, X) a factorisation consumes): only entries with row >= column are computed and
+// written -- 8 [n d + N (N + 1) / 2] bytes, SURVEY 8(d)'s symmetric count -- and the strict upper triangle of `out` is left untouched.
 void launch_cov_build(const CovParams& cp, const double* A, int nA, const DerivList& dA, const double* B, int nB,
                       const DerivList& dB, const double* diag_noise, double* out, long ld, long col0, hipStream_t s,
-                      bool streaming = false);
+                      bool streaming = false, bool lower_only = false);
 
 // E[(j*(1+g)+n) + (col0 + (i*(1+gt)+m)*dim + dd) * ld] = d cov(P_i, X_j)[m, n] / d P_{i,dd}
 // (grad_K_star fill, gpp_math.cpp:616-637)
@@ -96,8 +98,10 @@ void launch_gram_cross_batch(int E, int m, int ng, int A, int K, const double* S
 // In-place blocked Cholesky of the lower triangle of A (N x N, lda) + explicit inverse of the factor into Linv
 // (N x N, ldl, lower; strict upper zeroed).  info (device int): 0 or failing pivot index + 1 (pivot <= 1e-16).
 // work: cholesky_work_doubles(N) doubles of device scratch for the recursive inversion.
+// upper_is_zero: the caller guarantees that A's strict upper triangle already holds zeros (a lower_only covariance build into a
+// cleared buffer); otherwise it is zeroed here after the factorisation.
 void launch_cholesky_and_inverse(int N, double* A, long lda, double* Linv, long ldl, double* work, int* info,
-                                 hipStream_t s);
+                                 hipStream_t s, bool upper_is_zero = false);
 size_t cholesky_work_doubles(int N);
 // scratch of the two-level factorisation's step kernel (two N x 64 column-block buffers), in doubles
 size_t chol_scratch_doubles(int N);

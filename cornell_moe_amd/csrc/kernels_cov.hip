@@ -21,12 +21,15 @@ template <int DP, bool DERIVS>
 __global__ __launch_bounds__(kCovRows) void cov_build_kernel(CovParams cp, const double* __restrict__ A, int nA,
                                                             DerivList dA, const double* __restrict__ B, int nB,
                                                             DerivList dB, const double* __restrict__ diag_noise,
-                                                            double* __restrict__ out, long ld, long col0) {
+                                                            double* __restrict__ out, long ld, long col0, int lower_only) {
   __shared__ double Bs[kCovCols][DP];
   const int gA = DERIVS ? dA.g : 0, gB = DERIVS ? dB.g : 0;
   const int rows = nA * (1 + gA);
   const int j0 = blockIdx.x * kCovCols;  // column tiles on grid.x (up to 2^31-1 tiles: N x M builds have M >> 65535*16)
   const int nj = min(kCovCols, nB - j0);
+  // lower_only (K(X, X) for the factorisation, r4): tiles above the diagonal are not visited and entries above it not stored -- the
+  // strict upper triangle of the destination stays what it is (zero: GpDev::rebuild clears the buffer when its shape changes)
+  if (lower_only && (long)blockIdx.y * kCovRows + kCovRows - 1 < (long)j0 * (1 + gB)) return;
   for (int t = threadIdx.x; t < nj * DP; t += blockDim.x) Bs[t / DP][t % DP] = B[(long)(j0 + t / DP) * DP + (t % DP)];
   __syncthreads();
   const int r = blockIdx.y * kCovRows + threadIdx.x;
@@ -49,13 +52,13 @@ __global__ __launch_bounds__(kCovRows) void cov_build_kernel(CovParams cp, const
       double v = rd.base;
       const long col = col0 + j0 + jj;
       if (diag_noise != nullptr && (long)r == col - col0) v += diag_noise[0];
-      out[(long)r + col * ld] = v;
+      if (!lower_only || (long)r >= col - col0) out[(long)r + col * ld] = v;
     } else {
       for (int b = 0; b < 1 + gB; ++b) {
         double v = cov_entry<DP>(cp, rd, diff, a, b, dA, dB);
         const long colrel = (long)(j0 + jj) * (1 + gB) + b;
         if (diag_noise != nullptr && (long)r == colrel) v += diag_noise[a];
-        out[(long)r + (col0 + colrel) * ld] = v;
+        if (!lower_only || (long)r >= colrel) out[(long)r + (col0 + colrel) * ld] = v;
       }
     }
   }
@@ -71,12 +74,13 @@ template <int DP>
 __global__ __launch_bounds__(256) void cov_build_points_kernel(CovParams cp, const double* __restrict__ A, int nA, DerivList dA,
                                                               const double* __restrict__ B, int nB, DerivList dB,
                                                               const double* __restrict__ diag_noise, double* __restrict__ out,
-                                                              long ld, long col0) {
+                                                              long ld, long col0, int lower_only) {
   __shared__ double Bs[kCovCols][DP];
   __shared__ double stage_all[4][64 * (1 + kMaxDerivs)];
   const int gA = dA.g, gB = dB.g, a1 = 1 + gA;
   const int j0 = blockIdx.x * kCovCols;
   const int nj = min(kCovCols, nB - j0);
+  if (lower_only && ((long)blockIdx.y * 256 + 256) * a1 - 1 < (long)j0 * (1 + gB)) return;  // (see cov_build_kernel)
   for (int t = threadIdx.x; t < nj * DP; t += blockDim.x) Bs[t / DP][t % DP] = B[(long)(j0 + t / DP) * DP + (t % DP)];
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -101,6 +105,7 @@ __global__ __launch_bounds__(256) void cov_build_points_kernel(CovParams cp, con
     const Radial rd = radial_scalars(cp.type, cp.alpha, r2);
     for (int b = 0; b <= gB; ++b) {
       const long colrel = (long)(j0 + jj) * (1 + gB) + b;
+      if (lower_only && row0 + 64 * a1 - 1 < colrel) continue;  // this wavefront's rows all lie above the diagonal in this column
       for (int a = 0; a <= gA; ++a) {
         double v = cov_entry<DP>(cp, rd, diff, a, b, dA, dB);
         if (diag_noise != nullptr && (long)i * a1 + a == colrel) v += diag_noise[a];
@@ -111,7 +116,7 @@ __global__ __launch_bounds__(256) void cov_build_points_kernel(CovParams cp, con
       for (int t = 0; t <= gA; ++t) {
         const int rr = lane + 64 * t;
         const double v = stage[rr];
-        if (row0 + rr < rows) dst[rr] = v;
+        if (row0 + rr < rows && (!lower_only || row0 + rr >= colrel)) dst[rr] = v;
       }
     }
   }
@@ -290,22 +295,24 @@ bool value_fast_path() {  // MOE_COV_FAST=0: the general kernel for value-only b
 
 template <int DP>
 void cov_build_dp(const CovParams& cp, const double* A, int nA, const DerivList& dA, const double* B, int nB,
-                  const DerivList& dB, const double* diag_noise, double* out, long ld, long col0, hipStream_t s, bool streaming) {
+                  const DerivList& dB, const double* diag_noise, double* out, long ld, long col0, hipStream_t s, bool streaming,
+                  bool lower_only) {
+  const int lo = lower_only ? 1 : 0;
   const bool derivs = dA.g > 0 || dB.g > 0;
   const int rows = nA * (1 + dA.g);
   dim3 grid((nB + kCovCols - 1) / kCovCols, (rows + kCovRows - 1) / kCovRows);
   if (grid.x == 0 || grid.y == 0) return;
   if (dA.g > 0 && value_fast_path()) {  // thread per point, rows transposed through LDS (MOE_COV_FAST=0: the row-per-thread kernel)
     dim3 pgrid(grid.x, (nA + 255) / 256);
-    hipLaunchKernelGGL((cov_build_points_kernel<DP>), pgrid, dim3(256), 0, s, cp, A, nA, dA, B, nB, dB, diag_noise, out, ld, col0);
+    hipLaunchKernelGGL((cov_build_points_kernel<DP>), pgrid, dim3(256), 0, s, cp, A, nA, dA, B, nB, dB, diag_noise, out, ld, col0, lo);
   } else if (derivs)
     hipLaunchKernelGGL((cov_build_kernel<DP, true>), grid, dim3(kCovRows), 0, s, cp, A, nA, dA, B, nB, dB, diag_noise, out, ld,
-                       col0);
-  else if (streaming && value_fast_path())
+                       col0, lo);
+  else if (streaming && value_fast_path() && !lower_only)
     hipLaunchKernelGGL((cov_build_value_kernel<DP>), grid, dim3(kCovRows), 0, s, cp, A, nA, B, nB, diag_noise, out, ld, col0);
   else
     hipLaunchKernelGGL((cov_build_kernel<DP, false>), grid, dim3(kCovRows), 0, s, cp, A, nA, dA, B, nB, dB, diag_noise, out,
-                       ld, col0);
+                       ld, col0, lo);
 }
 
 template <int DP>
@@ -348,14 +355,14 @@ void launch_debug_math(const double* x, int n, double* e, double* r, hipStream_t
 
 void launch_cov_build(const CovParams& cp, const double* A, int nA, const DerivList& dA, const double* B, int nB,
                       const DerivList& dB, const double* diag_noise, double* out, long ld, long col0, hipStream_t s,
-                      bool streaming) {
+                      bool streaming, bool lower_only) {
   switch (cp.dp) {
-    case 4: cov_build_dp<4>(cp, A, nA, dA, B, nB, dB, diag_noise, out, ld, col0, s, streaming); break;
-    case 8: cov_build_dp<8>(cp, A, nA, dA, B, nB, dB, diag_noise, out, ld, col0, s, streaming); break;
-    case 12: cov_build_dp<12>(cp, A, nA, dA, B, nB, dB, diag_noise, out, ld, col0, s, streaming); break;
-    case 16: cov_build_dp<16>(cp, A, nA, dA, B, nB, dB, diag_noise, out, ld, col0, s, streaming); break;
-    case 24: cov_build_dp<24>(cp, A, nA, dA, B, nB, dB, diag_noise, out, ld, col0, s, streaming); break;
-    case 32: cov_build_dp<32>(cp, A, nA, dA, B, nB, dB, diag_noise, out, ld, col0, s, streaming); break;
+    case 4: cov_build_dp<4>(cp, A, nA, dA, B, nB, dB, diag_noise, out, ld, col0, s, streaming, lower_only); break;
+    case 8: cov_build_dp<8>(cp, A, nA, dA, B, nB, dB, diag_noise, out, ld, col0, s, streaming, lower_only); break;
+    case 12: cov_build_dp<12>(cp, A, nA, dA, B, nB, dB, diag_noise, out, ld, col0, s, streaming, lower_only); break;
+    case 16: cov_build_dp<16>(cp, A, nA, dA, B, nB, dB, diag_noise, out, ld, col0, s, streaming, lower_only); break;
+    case 24: cov_build_dp<24>(cp, A, nA, dA, B, nB, dB, diag_noise, out, ld, col0, s, streaming, lower_only); break;
+    case 32: cov_build_dp<32>(cp, A, nA, dA, B, nB, dB, diag_noise, out, ld, col0, s, streaming, lower_only); break;
     default: throw Error(MOE_ERR_RUNTIME, "unsupported padded dimension");
   }
   MOE_HIP_CHECK(hipGetLastError());

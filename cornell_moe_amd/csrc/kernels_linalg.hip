@@ -1720,7 +1720,7 @@ void cholesky_factor_two_level(int N, double* A, long lda, double* Linv, long ld
 }
 
 void launch_cholesky_and_inverse(int N, double* A, long lda, double* Linv, long ldl, double* work, int* info,
-                                 hipStream_t s) {
+                                 hipStream_t s, bool upper_is_zero) {
   MOE_HIP_CHECK(hipMemsetAsync(info, 0, sizeof(int), s));
   MOE_HIP_CHECK(hipMemsetAsync(Linv, 0, sizeof(double) * (size_t)ldl * N, s));
   const int nblk = (N + NB - 1) / NB;
@@ -1745,7 +1745,7 @@ void launch_cholesky_and_inverse(int N, double* A, long lda, double* Linv, long 
       }
     }
   }
-  {
+  if (!upper_is_zero) {
     const long total = (long)N * N;
     hipLaunchKernelGGL(zero_strict_upper_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, A, lda, N);
   }
