@@ -21,12 +21,13 @@ template <int DP, bool DERIVS>
 __global__ __launch_bounds__(kCovRows) void cov_build_kernel(CovParams cp, const double* __restrict__ A, int nA,
                                                             DerivList dA, const double* __restrict__ B, int nB,
                                                             DerivList dB, const double* __restrict__ diag_noise,
-                                                            double* __restrict__ out, long ld, long col0, int lower_only) {
+                                                            double* __restrict__ out, long ld, long col0, int lower_only,
+                                                            int cols_per_wg) {
   __shared__ double Bs[kCovCols][DP];
   const int gA = DERIVS ? dA.g : 0, gB = DERIVS ? dB.g : 0;
   const int rows = nA * (1 + gA);
-  const int j0 = blockIdx.x * kCovCols;  // column tiles on grid.x (up to 2^31-1 tiles: N x M builds have M >> 65535*16)
-  const int nj = min(kCovCols, nB - j0);
+  const int j0 = blockIdx.x * cols_per_wg;  // column tiles on grid.x (up to 2^31-1 tiles: N x M builds have M >> 65535*16)
+  const int nj = min(cols_per_wg, nB - j0);
   // lower_only (K(X, X) for the factorisation, r4): tiles above the diagonal are not visited and entries above it not stored -- the
   // strict upper triangle of the destination stays what it is (zero: GpDev::rebuild clears the buffer when its shape changes)
   if (lower_only && (long)blockIdx.y * kCovRows + kCovRows - 1 < (long)j0 * (1 + gB)) return;
@@ -74,12 +75,12 @@ template <int DP>
 __global__ __launch_bounds__(256) void cov_build_points_kernel(CovParams cp, const double* __restrict__ A, int nA, DerivList dA,
                                                               const double* __restrict__ B, int nB, DerivList dB,
                                                               const double* __restrict__ diag_noise, double* __restrict__ out,
-                                                              long ld, long col0, int lower_only) {
+                                                              long ld, long col0, int lower_only, int cols_per_wg) {
   __shared__ double Bs[kCovCols][DP];
   __shared__ double stage_all[4][64 * (1 + kMaxDerivs)];
   const int gA = dA.g, gB = dB.g, a1 = 1 + gA;
-  const int j0 = blockIdx.x * kCovCols;
-  const int nj = min(kCovCols, nB - j0);
+  const int j0 = blockIdx.x * cols_per_wg;
+  const int nj = min(cols_per_wg, nB - j0);
   if (lower_only && ((long)blockIdx.y * 256 + 256) * a1 - 1 < (long)j0 * (1 + gB)) return;  // (see cov_build_kernel)
   for (int t = threadIdx.x; t < nj * DP; t += blockDim.x) Bs[t / DP][t % DP] = B[(long)(j0 + t / DP) * DP + (t % DP)];
   __syncthreads();
@@ -300,19 +301,26 @@ void cov_build_dp(const CovParams& cp, const double* A, int nA, const DerivList&
   const int lo = lower_only ? 1 : 0;
   const bool derivs = dA.g > 0 || dB.g > 0;
   const int rows = nA * (1 + dA.g);
-  dim3 grid((nB + kCovCols - 1) / kCovCols, (rows + kCovRows - 1) / kCovRows);
+  // column tile of a workgroup: 16 B points; the triangular build visits half the tiles and would leave the chip with ~2 workgroups
+  // per CU at N = 8000 -- 2 points per workgroup there (r4, TB/s of stores by the symmetric byte count, N = 8000 / 26 000: 16 columns 2.4 / 2.7, 8: 3.2 / 3.6, 4: 3.9 / 4.5, 2: 4.1 / 4.8, 1: 3.8 / 5.0)
+  static const int kxx_cols = [] {
+    const char* v = std::getenv("MOE_KXX_COLS");
+    return (v && *v) ? std::max(1, std::min(kCovCols, std::atoi(v))) : 2;
+  }();
+  const int cpw = lower_only ? kxx_cols : kCovCols;
+  dim3 grid((nB + cpw - 1) / cpw, (rows + kCovRows - 1) / kCovRows);
   if (grid.x == 0 || grid.y == 0) return;
   if (dA.g > 0 && value_fast_path()) {  // thread per point, rows transposed through LDS (MOE_COV_FAST=0: the row-per-thread kernel)
     dim3 pgrid(grid.x, (nA + 255) / 256);
-    hipLaunchKernelGGL((cov_build_points_kernel<DP>), pgrid, dim3(256), 0, s, cp, A, nA, dA, B, nB, dB, diag_noise, out, ld, col0, lo);
+    hipLaunchKernelGGL((cov_build_points_kernel<DP>), pgrid, dim3(256), 0, s, cp, A, nA, dA, B, nB, dB, diag_noise, out, ld, col0, lo, cpw);
   } else if (derivs)
     hipLaunchKernelGGL((cov_build_kernel<DP, true>), grid, dim3(kCovRows), 0, s, cp, A, nA, dA, B, nB, dB, diag_noise, out, ld,
-                       col0, lo);
+                       col0, lo, cpw);
   else if (streaming && value_fast_path() && !lower_only)
     hipLaunchKernelGGL((cov_build_value_kernel<DP>), grid, dim3(kCovRows), 0, s, cp, A, nA, B, nB, diag_noise, out, ld, col0);
   else
     hipLaunchKernelGGL((cov_build_kernel<DP, false>), grid, dim3(kCovRows), 0, s, cp, A, nA, dA, B, nB, dB, diag_noise, out,
-                       ld, col0, lo);
+                       ld, col0, lo, cpw);
 }
 
 template <int DP>
