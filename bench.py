@@ -306,6 +306,8 @@ def main():
     my_restarts = w.Xq_restarts[rank * R:(rank + 1) * R] if multi_fallback is None else w.Xq_restarts
     cw = comm.world
 
+    coll = {"s": 0.0, "n": 0}   # time inside the restart-gather of the timed steps
+
     def step(mode=None, restarts=None):
         mode = mode or args.shard
         if multi_fallback is not None and restarts is None:
@@ -319,7 +321,10 @@ def main():
             grad = r["grad_sum"] / w.M
             if cw > 1 and restarts is None:
                 idx = list(range(rank * R, (rank + 1) * R))
+                tc = time.perf_counter()
                 kg, grad = mdist.gather_restarts(idx, kg, grad, R * cw, group=comm.group, device=comm.device)
+                coll["s"] += time.perf_counter() - tc   # host tensor -> (device) -> all_gather -> host: the step's whole exchange
+                coll["n"] += 1
             return kg, grad, r
         first, count = mdist.shard_samples(w.M, rank, cw)
         Xm = w.Xq_restarts[:R] if restarts is None else restarts
@@ -343,6 +348,7 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
+    coll["s"], coll["n"] = 0.0, 0
     t0 = time.perf_counter()
     ms_mc = ms_cov = ms_tail = ms_state = 0.0
     val_passes = grad_passes = 0
@@ -356,6 +362,7 @@ def main():
         val_passes += r["mean_evals"]
         grad_passes += r["grad_evals"]
     local_elapsed = time.perf_counter() - t0     # this rank's own time for its K steps (before the closing barrier)
+    coll_us = 1e6 * coll["s"] / coll["n"] if coll["n"] else 0.0
     fence()
     elapsed = comm.max_over_ranks(time.perf_counter() - t0)
     assert np.all(np.isfinite(kg)) and np.all(np.isfinite(grad))
@@ -371,6 +378,13 @@ def main():
 
     # ---- extras, OUTSIDE the timed region of `value` ----
     extras = {}
+    if cw > 1 and args.shard == "restarts":
+        # per step, the slowest rank: it includes the wait for the slowest rank's compute (the gather is the step's only barrier),
+        # so rank 0's own figure -- usually the smallest -- is reported next to it
+        cmax = comm.max_over_ranks(coll_us)
+        extras["collective_us_per_step"] = {"max_over_ranks": cmax, "rank0": coll_us,
+                                            "what": "dist.gather_restarts: pack, host->device, all_gather of %d x %d doubles, device->host, unpack"
+                                                    % (R, 2 + w.q * w.d)}
     if args.no_determinism:
         pass
     elif cw > 1 and args.shard == "restarts":

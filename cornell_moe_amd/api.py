@@ -473,7 +473,10 @@ class DeviceGP(object):
         out = (C.c_int * 8)()
         _lib.load().moe_last_kernel_info(self._h, out)
         keys = ("variant", "xlds", "waves", "tr", "weight_table", "fused_tail", "blocks", "prep")
-        return dict(zip(keys, [int(v) for v in out]))
+        info = dict(zip(keys, [int(v) for v in out]))
+        info["far_frame"], info["wide_frame"] = (info["xlds"] >> 1) & 1, (info["xlds"] >> 2) & 1
+        info["xlds"] &= 1
+        return info
 
 
 def kg_batch_multi(gps, shard, inner_params, bounds, discrete, Xq_all, Xp, num_mc, best_so_far, normals, want_grad=True,

@@ -16,6 +16,15 @@ namespace moe {
 namespace {
 
 constexpr int kMaxUnionEi = 16;
+#ifndef MOE_EI_PROF
+#define MOE_EI_PROF 0
+#endif
+#if MOE_EI_PROF
+__device__ unsigned long long g_ei_prof[16];
+#define MOE_EI_T(i) if (threadIdx.x == 0 && blockIdx.x == 0) g_ei_prof[i] = __builtin_amdgcn_s_memtime()
+#else
+#define MOE_EI_T(i)
+#endif
 
 struct EiParams {
   int u, q, d, num_mc;
@@ -28,6 +37,8 @@ struct EiParams {
   double* partial;        // [E][gridDim.x][1 + q*d]
   int want_grad;
   long blob_stride;       // doubles between consecutive evaluations' (mu, L, grad_mu, gchol) records
+  double* out;            // [E][1 + q*d]: the block sums added up by the LAST workgroup of an evaluation to finish (r4); or NULL
+  unsigned int* ticket;   // [E] arrival counters, zero before the launch and zero again after it
 };
 
 __device__ __forceinline__ double wave_sum_ei(double v) {
@@ -36,9 +47,36 @@ __device__ __forceinline__ double wave_sum_ei(double v) {
   return v;
 }
 
+// out[c] = sum over the workgroups of partial[b][c], one workgroup of 256 threads: component c is summed by the 256 / ncomp' lanes that
+// share c = lane % ncomp' (block order within a lane, then a fixed-order tree over the lanes of the component): one pass and one barrier
+// round instead of ncomp of them.  (Until r3 a launch of its own, sum_partials_kernel; the order of the additions is unchanged.)
+__device__ __forceinline__ void sum_partials_body(const double* __restrict__ partial, int num_blocks, int ncomp,
+                                                  double* __restrict__ out, double* __restrict__ red) {
+  for (int c0 = 0; c0 < ncomp; c0 += 256) {
+    const int nc = min(256, ncomp - c0);              // components of this round
+    int stride = 1;
+    while (stride * 2 * nc <= 256) stride *= 2;        // lanes per component (a power of two)
+    const int comp = threadIdx.x % nc, part = threadIdx.x / nc;
+    double acc = 0.0;
+    if (part < stride)
+      for (int b = part; b < num_blocks; b += stride)  // (device-scope loads: the sums come from other CUs, past this CU's L1)
+        acc += __hip_atomic_load(&partial[(long)b * ncomp + c0 + comp], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int off = stride / 2; off > 0; off >>= 1) {
+      if (part < off) red[threadIdx.x] += red[threadIdx.x + off * nc];
+      __syncthreads();
+    }
+    if (part == 0 && threadIdx.x < nc) out[c0 + comp] = red[threadIdx.x];
+    __syncthreads();
+  }
+}
+
 __global__ __launch_bounds__(256) void ei_mc_kernel(EiParams P) {
   constexpr int MU = kMaxUnionEi;
   __shared__ double red[4];
+  __shared__ double red256[256];
+  __shared__ int s_last;
   const long eoff = (long)blockIdx.y * P.blob_stride;  // this evaluation's record
   P.mu += eoff;
   P.L += eoff;
@@ -92,34 +130,20 @@ __global__ __launch_bounds__(256) void ei_mc_kernel(EiParams P) {
       P.partial[((long)blockIdx.y * gridDim.x + blockIdx.x) * ncomp + comp] = (red[0] + red[1]) + (red[2] + red[3]);
     __syncthreads();
   }
-}
-
-__global__ __launch_bounds__(256) void sum_partials_kernel(const double* __restrict__ partial, int num_blocks, int ncomp,
-                                                          double* __restrict__ out) {
-  // one workgroup per evaluation; component c is summed by the 256 / ncomp' lanes that share c = lane % ncomp' (block order within a
-  // lane, then a fixed-order tree over the lanes of the component): one pass and one barrier round instead of ncomp of them
-  __shared__ double red[256];
-  partial += (long)blockIdx.x * num_blocks * ncomp;
-  out += (long)blockIdx.x * ncomp;
-  for (int c0 = 0; c0 < ncomp; c0 += 256) {
-    const int nc = min(256, ncomp - c0);              // components of this round
-    int stride = 1;
-    while (stride * 2 * nc <= 256) stride *= 2;        // lanes per component (a power of two)
-    const int comp = threadIdx.x % nc, part = threadIdx.x / nc;
-    double acc = 0.0;
-    if (part < stride)
-      for (int b = part; b < num_blocks; b += stride) acc += partial[(long)b * ncomp + c0 + comp];
-    red[threadIdx.x] = acc;
-    __syncthreads();
-    for (int off = stride / 2; off > 0; off >>= 1) {
-      if (part < off) red[threadIdx.x] += red[threadIdx.x + off * nc];
-      __syncthreads();
-    }
-    if (part == 0 && threadIdx.x < nc) out[c0 + comp] = red[threadIdx.x];
-    __syncthreads();
+  if (P.out == nullptr) return;
+  // the workgroup that arrives last adds the block sums up (r4: one launch less on the latency path; the order of the additions
+  // is fixed, whoever performs them)
+  if (threadIdx.x == 0) {
+    __threadfence();
+    const unsigned int t = atomicAdd(&P.ticket[blockIdx.y], 1u);
+    s_last = (t == gridDim.x - 1) ? 1 : 0;
   }
+  __syncthreads();
+  if (!s_last) return;
+  __threadfence();
+  sum_partials_body(P.partial + (long)blockIdx.y * gridDim.x * ncomp, (int)gridDim.x, ncomp, P.out + (long)blockIdx.y * ncomp, red256);
+  if (threadIdx.x == 0) P.ticket[blockIdx.y] = 0u;
 }
-
 
 // ---------------------------------------------------------------------------------------------------------------------
 // The u x u algebra of an EI evaluation ON THE DEVICE (r3): what ei_evaluate_batch did on the host between two stream syncs --
@@ -143,7 +167,12 @@ struct EiStateParams {
   int E, u, nd, d, dp, want_grad;
   double* blob;        // records: mu [u] | L [u x u] | grad_mu [nd d] | gchol [nd][u][u][d]
   long rec, o_mu, o_L, o_gmu, o_gc;
-  int* flags;          // [E]: 0, or the failing leading minor of the variance matrix
+  double* flags;       // [E]: 0, or the failing leading minor of the variance matrix (doubles: they travel behind the results in
+                       // the call's one device->host copy)
+  // small states (fused != 0): gram / ek above are not read -- the kernel forms them from V = L^-1 E and E (N rows, ld N, columns
+  // grouped by kind) and K^-1 (y - mean)
+  int fused, N;
+  const double *V, *Emat, *KinvY;
 };
 
 // d chol(Var + 1e-6 I) / d Xs_{k, dd} for one differentiated point k and one dimension dd: host_grad_variance_per_point (no
@@ -225,19 +254,145 @@ __device__ __forceinline__ void ei_grad_chol_lane(const EiStateParams& P, const 
 #undef MOE_GC
 }
 
-__global__ __launch_bounds__(64) void ei_state_kernel(EiStateParams P) {
+// r4, small states (FUSED: the evaluation's columns of V = L^-1 E and of E fit LDS -- every q-EI call at C2): the Gram matrix V^T V and
+// E^T K^-1 (y - mean) are formed HERE, by the evaluation's own workgroup, from ONE batch of loads -- every thread issues its share of
+// the N x c entries of V and E at once -- instead of by the K-sliced Gram kernel, its slice sum and a gemv: three launches whose K loops
+// paid a memory round trip of 2 - 3 us per stage (7.5 + 4.7 + 5.4 us at C2).  An output is one wavefront's lane-strided dot product
+// and a fixed butterfly: deterministic, and a function of the evaluation alone.
+// (UM: the union-size class the factor-derivative recursion is unrolled for -- one kernel per class: with all three classes in one
+//  kernel the register allocation and the scratch spills of the 16 x 16 class were paid by every call)
+template <bool FUSED, int UM>
+__global__ __launch_bounds__(256) void ei_state_kernel(EiStateParams P) {
   __shared__ double Ls[kMaxUnionEi * kMaxUnionEi];
   __shared__ int s_bad;
+  extern __shared__ __attribute__((aligned(16))) double ei_sm[];  // FUSED: Gs [c][c] | eks [c] | ys [N] | Vs [c][N] | Es [c][N]
+  __shared__ double Us[kMaxUnionEi * kMaxDimPadded];
   const int e = blockIdx.x, lane = threadIdx.x;
   const int u = P.u, d = P.d, c = u + P.nd * d;
   const double* G = P.gram + (long)e * c * c;
   const double* ek_k = P.ek + (long)e * u;
   const double* ek_g = P.ek + (long)P.E * u + (long)e * P.nd * d;
-  const double* U = P.U + (long)e * u * P.dp;
+  MOE_EI_T(0);
+  if constexpr (FUSED) {
+    const int N = P.N, ng = P.nd * d;
+    double* Gs = ei_sm;
+    double* eks = Gs + c * c;
+    double* ys = eks + c;
+    double* Vs = ys + N;
+    double* Es = Vs + (long)c * N;
+    // every global load of a batch is issued before the first LDS store (a store straight behind its load makes each step wait for
+    // its own round trip of 2 - 3 us); the first batch carries the union points and K^-1 (y - mean) along, so a state of up to
+    // 256 x 24 entries -- C2 with its gradient columns: 5000 -- costs ONE round trip
+    constexpr int NB = 24;
+    double uv[2], yv[4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) uv[i] = P.U[(long)e * u * P.dp + min(lane + 256 * i, u * P.dp - 1)];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) yv[i] = P.KinvY[min(lane + 256 * i, N - 1)];
+    for (int t0 = 0; t0 < N * c; t0 += 256 * NB) {
+      double va[NB], ea[NB];
+#pragma unroll
+      for (int i = 0; i < NB; ++i) {
+        const int t = min(t0 + i * 256 + lane, N * c - 1);
+        const int l = t / N, k = t - l * N;
+        const long col = (l < u) ? ((long)e * u + l) : ((long)P.E * u + (long)e * ng + (l - u));  // columns grouped by kind (BatchLayout)
+        va[i] = P.V[k + col * N];
+        ea[i] = P.Emat[k + col * N];
+      }
+#pragma unroll
+      for (int i = 0; i < NB; ++i) {
+        const int t = t0 + i * 256 + lane;
+        if (t < N * c) {
+          Vs[t] = va[i];
+          Es[t] = ea[i];
+        }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+      if (lane + 256 * i < u * P.dp) Us[lane + 256 * i] = uv[i];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      if (lane + 256 * i < N) ys[lane + 256 * i] = yv[i];
+    for (int k = lane + 1024; k < N; k += 256) ys[k] = P.KinvY[k];
+    __syncthreads();
+    MOE_EI_T(1);
+    // one output per 8-lane group at a time (32 groups): lanes stride k with two accumulators, three in-group butterfly steps; the
+    // outputs are enumerated without gaps (the pairs, then the c entries of ek)
+    // Only the entries the algebra below reads: G(K*, K*) and G(dK*, K*) -- pairs (i <= j) with i < u; the dK* x dK* block (36 of the 55
+    // pairs at C2) is never used.
+    const int tri_u = u * (u + 1) / 2;
+    const int npair = tri_u + (c - u) * u;
+    const int gid = lane >> 3, gl = lane & 7;
+    for (int o = gid; o < npair + c; o += 32) {
+      const double *a, *b;
+      int i = 0, j = 0;
+      if (o < npair) {
+        if (o < tri_u) {
+          int rem = o;
+          while (rem > j) {  // column j of the upper triangle holds j + 1 pairs
+            rem -= j + 1;
+            ++j;
+          }
+          i = rem;
+        } else {
+          const int o2 = o - tri_u;
+          j = u + o2 / u;
+          i = o2 - (j - u) * u;
+        }
+        a = Vs + (long)i * N;
+        b = Vs + (long)j * N;
+      } else {
+        i = o - npair;
+        a = Es + (long)i * N;
+        b = ys;
+      }
+      // (eight LDS reads per operand in flight: one read per step would make the loop a chain of LDS latencies)
+      double acc0 = 0.0, acc1 = 0.0;
+      int k = gl;
+      for (; k + 7 * 8 < N; k += 8 * 8) {
+        double av[8], bv[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+          av[t] = a[k + 8 * t];
+          bv[t] = b[k + 8 * t];
+        }
+#pragma unroll
+        for (int t = 0; t < 8; t += 2) {
+          acc0 = fma(av[t], bv[t], acc0);
+          acc1 = fma(av[t + 1], bv[t + 1], acc1);
+        }
+      }
+      for (; k < N; k += 8) acc0 = fma(a[k], b[k], acc0);
+      double acc = acc0 + acc1;
+#pragma unroll
+      for (int off = 4; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 8);
+      if (gl == 0) {
+        if (o < npair) {
+          Gs[i + j * c] = acc;
+          Gs[j + i * c] = acc;
+        } else {
+          eks[i] = acc;
+        }
+      }
+    }
+    __syncthreads();
+    MOE_EI_T(2);
+    G = Gs;
+    ek_k = eks;
+    ek_g = eks + u;
+  }
+  // the union points in LDS: the distance loops below (runtime trip count d, two loads per step) otherwise pay a memory round trip
+  // per step -- 16 of them in a row in the factor-derivative part at C2
+  if constexpr (!FUSED) {
+    for (int t = lane; t < u * P.dp; t += 256) Us[t] = P.U[(long)e * u * P.dp + t];
+    __syncthreads();
+  }
+  const double* U = Us;
   double* r = P.blob + (long)e * P.rec;
   if (lane == 0) s_bad = 0;
   if (lane < u) r[P.o_mu + lane] = P.mean + ek_k[lane];  // host_mean
-  for (int idx = lane; idx < u * u; idx += 64) {          // host_variance, + 1e-6 on the diagonal (gpp_math.cpp:2000-2002)
+  for (int idx = lane; idx < u * u; idx += 256) {         // host_variance, + 1e-6 on the diagonal (gpp_math.cpp:2000-2002)
     const int i = idx % u, j = idx / u;
     double r2 = 0.0;
     for (int k = 0; k < d; ++k) {
@@ -249,6 +404,7 @@ __global__ __launch_bounds__(64) void ei_state_kernel(EiStateParams P) {
     Ls[i + j * u] = v;
   }
   __syncthreads();
+  MOE_EI_T(3);
   // host_cholesky (ComputeCholeskyFactorL, gpp_linear_algebra.cpp:109-148): lane = row
   for (int k = 0; k < u; ++k) {
     const double akk = Ls[k + k * u];
@@ -266,27 +422,24 @@ __global__ __launch_bounds__(64) void ei_state_kernel(EiStateParams P) {
     __syncthreads();
   }
   __syncthreads();
-  if (lane == 0) P.flags[e] = s_bad;
+  if (lane == 0) P.flags[e] = (double)s_bad;
   if (s_bad != 0) return;
-  for (int idx = lane; idx < u * u; idx += 64) {
+  for (int idx = lane; idx < u * u; idx += 256) {
     const int i = idx % u, j = idx / u;
     r[P.o_L + idx] = (j <= i) ? Ls[idx] : 0.0;
   }
+  MOE_EI_T(4);
   if (!P.want_grad) return;
-  for (int idx = lane; idx < P.nd * d; idx += 64) r[P.o_gmu + idx] = ek_g[idx];  // host_grad_mean
+  for (int idx = lane; idx < P.nd * d; idx += 256) r[P.o_gmu + idx] = ek_g[idx];  // host_grad_mean
   // host_grad_cholesky_per_point for every differentiated point k; lane = dimension dd (independent recursions), each in a
   // lane-private u x u array (registers for u <= 4 / 8) written to the record once
-  for (int dd = lane; dd < d; dd += 64) {
-    for (int k = 0; k < P.nd; ++k) {
-      double* gc = r + P.o_gc + (long)k * d * u * u;
-      if (u <= 4)
-        ei_grad_chol_lane<4>(P, G, U, Ls, c, k, dd, gc);
-      else if (u <= 8)
-        ei_grad_chol_lane<8>(P, G, U, Ls, c, k, dd, gc);
-      else
-        ei_grad_chol_lane<kMaxUnionEi>(P, G, U, Ls, c, k, dd, gc);
-    }
+  // (r4: one lane per (point, dimension) pair -- nd d independent recursions -- instead of one per dimension looping over the points)
+  for (int t = lane; t < P.nd * d; t += 256) {
+    const int k = t / d, dd = t - k * d;
+    double* gc = r + P.o_gc + (long)k * d * u * u;
+    ei_grad_chol_lane<UM>(P, G, U, Ls, c, k, dd, gc);
   }
+  MOE_EI_T(5);
 }
 
 bool ei_device_algebra() {  // MOE_EI_DEVICE_ALGEBRA=0: the host-algebra path (two syncs per call; A/B runs and tests)
@@ -321,20 +474,29 @@ void ei_evaluate_batch(GpDev& gp, const double* Xq_all, int num_evals, const dou
   const size_t rec = o_gc + (want_grad ? (size_t)q * d * u * u : 0);
   const size_t n_norm = (size_t)num_mc * u;
   const bool on_device = ei_device_algebra();
-  gp.hKgIn.reserve(rec * E + n_norm);
-  double* blob = gp.hKgIn.p;
+  const int ncomp = 1 + (want_grad ? q * d : 0);
+  const int blocks = (num_mc + 255) / 256;
   DevBuf<double>& dBlobDev = gp.kBlob;
+  DevBuf<double>&dPartial = gp.kTB, &dOut = gp.kOut;
+  dPartial.reserve((size_t)E * blocks * ncomp);
+  dOut.reserve((size_t)E * ncomp + (size_t)E);  // results | singular-matrix flags (doubles): one device->host copy
+  const double* d_normals = nullptr;
+  double* blob = nullptr;
   if (on_device) {
-    // ---- r3: the whole evaluation stays on the device: state kernels -> u x u algebra kernel -> MC -> ONE sync ----
-    const StateEnqueued se = enqueue_state_batch(gp, U_all.data(), u, none, want_grad ? q : 0, nullptr, 0, false, E);
-    dBlobDev.reserve(rec * E + n_norm);
-    gp.kBestJ.reserve((size_t)E);  // (int workspace: the singular-matrix flags)
+    // ---- the whole evaluation stays on the device: state kernels -> u x u algebra kernel -> MC (+ final sum) -> ONE sync; r4: the
+    // normal draws ride down with the points in the state set-up's copy, the flags ride up with the results (5 copies -> 2) ----
+    StateAppendix apx;
+    apx.doubles = n_norm;
+    apx.fill = [&](double* dst) { std::memcpy(dst, normals, sizeof(double) * n_norm); };
+    const StateEnqueued se = enqueue_state_batch(gp, U_all.data(), u, none, want_grad ? q : 0, nullptr, 0, false, E, &apx, true);
+    d_normals = gp.dAppendix;
+    dBlobDev.reserve(rec * E);
     EiStateParams sp;
     sp.cp = gp.cp;
     sp.mean = gp.mean;
     sp.gram = gp.dGram.p;
     sp.ek = gp.dGram.p + se.nG;
-    sp.U = gp.dPts.p;
+    sp.U = gp.dUnion;
     sp.E = E;
     sp.u = u;
     sp.nd = want_grad ? q : 0;
@@ -347,12 +509,38 @@ void ei_evaluate_batch(GpDev& gp, const double* Xq_all, int num_evals, const dou
     sp.o_L = (long)o_L;
     sp.o_gmu = (long)o_gmu;
     sp.o_gc = (long)o_gc;
-    sp.flags = gp.kBestJ.p;
-    hipLaunchKernelGGL(ei_state_kernel, dim3(E), dim3(64), 0, s, sp);
+    sp.flags = dOut.p + (size_t)E * ncomp;
+    sp.fused = se.fused ? 1 : 0;
+    sp.N = gp.N;
+    sp.V = gp.dVE.p;
+    sp.Emat = gp.dE.p;
+    sp.KinvY = gp.dKinvY.p;
+    const int cst = u + (want_grad ? q : 0) * d;
+    const size_t shm = se.fused ? sizeof(double) * ((size_t)cst * cst + cst + gp.N + 2 * (size_t)cst * gp.N) : 0;
+    auto launch_state = [&](auto kern) {
+      if (shm > 48 * 1024)
+        MOE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+      hipLaunchKernelGGL(kern, dim3(E), dim3(256), shm, s, sp);
+    };
+    if (se.fused) {
+      if (u <= 4)
+        launch_state(ei_state_kernel<true, 4>);
+      else if (u <= 8)
+        launch_state(ei_state_kernel<true, 8>);
+      else
+        launch_state(ei_state_kernel<true, kMaxUnionEi>);
+    } else {
+      if (u <= 4)
+        launch_state(ei_state_kernel<false, 4>);
+      else if (u <= 8)
+        launch_state(ei_state_kernel<false, 8>);
+      else
+        launch_state(ei_state_kernel<false, kMaxUnionEi>);
+    }
     MOE_HIP_CHECK(hipGetLastError());
-    std::memcpy(blob, normals, sizeof(double) * n_norm);  // (pinned staging, then one copy behind the records)
-    MOE_HIP_CHECK(hipMemcpyAsync(dBlobDev.p + rec * E, blob, sizeof(double) * n_norm, hipMemcpyHostToDevice, s));
   } else {
+  gp.hKgIn.reserve(rec * E + n_norm);
+  blob = gp.hKgIn.p;
   std::vector<StateHost> hosts;
   compute_state_batch(gp, U_all.data(), u, none, want_grad ? q : 0, nullptr, 0, false, E, nullptr, &hosts);
   for (int e = 0; e < E; ++e) {
@@ -375,13 +563,14 @@ void ei_evaluate_batch(GpDev& gp, const double* Xq_all, int num_evals, const dou
   }
   std::memcpy(blob + rec * E, normals, sizeof(double) * n_norm);
   gp.kBlob.upload(blob, rec * E + n_norm, s);
+  d_normals = gp.kBlob.p + rec * E;
   }
-  const int ncomp = 1 + (want_grad ? q * d : 0);
-  const int blocks = (num_mc + 255) / 256;
   // persistent workspaces (hipMalloc / hipFree per call cost more than the whole evaluation)
-  DevBuf<double>&dBlob = gp.kBlob, &dPartial = gp.kTB, &dOut = gp.kOut;
-  dPartial.reserve((size_t)E * blocks * ncomp);
-  dOut.reserve((size_t)E * ncomp);
+  DevBuf<double>& dBlob = gp.kBlob;
+  if (gp.kEiTicket.cap < (size_t)E) {  // arrival counters of ei_mc_kernel: zero at allocation, left zero by every launch
+    gp.kEiTicket.reserve((size_t)E);
+    MOE_HIP_CHECK(hipMemsetAsync(gp.kEiTicket.p, 0, sizeof(unsigned int) * gp.kEiTicket.cap, s));
+  }
   EiParams P;
   P.u = u;
   P.q = q;
@@ -392,26 +581,34 @@ void ei_evaluate_batch(GpDev& gp, const double* Xq_all, int num_evals, const dou
   P.L = dBlob.p + o_L;
   P.grad_mu = dBlob.p + o_gmu;
   P.gchol = dBlob.p + o_gc;
-  P.normals = dBlob.p + rec * E;
+  P.normals = d_normals;
   P.partial = dPartial.p;
   P.want_grad = want_grad ? 1 : 0;
   P.blob_stride = (long)rec;
+  P.out = dOut.p;
+  P.ticket = gp.kEiTicket.p;
   hipLaunchKernelGGL(ei_mc_kernel, dim3(blocks, E), dim3(256), 0, s, P);
-  hipLaunchKernelGGL(sum_partials_kernel, dim3(E), dim3(256), 0, s, dPartial.p, blocks, ncomp, dOut.p);
   MOE_HIP_CHECK(hipGetLastError());
-  gp.hKgOut.reserve((size_t)E * ncomp + (size_t)(E + 1) / 2 + 1);
+  const size_t n_down = (size_t)E * ncomp + (on_device ? (size_t)E : 0);
+  gp.hKgOut.reserve(n_down);
   double* out = gp.hKgOut.p;
-  dOut.download(out, (size_t)E * ncomp, s);
-  int* flags_h = reinterpret_cast<int*>(out + (size_t)E * ncomp);
-  if (on_device) MOE_HIP_CHECK(hipMemcpyAsync(flags_h, gp.kBestJ.p, sizeof(int) * E, hipMemcpyDeviceToHost, s));
+  dOut.download(out, n_down, s);
   MOE_HIP_CHECK(hipStreamSynchronize(s));
+#if MOE_EI_PROF
+  {
+    unsigned long long h[16];
+    MOE_HIP_CHECK(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_ei_prof), sizeof(h)));
+    std::fprintf(stderr, "[ei prof] ticks (100 MHz): load %llu dots %llu var %llu chol+L %llu grad %llu\n", h[1] - h[0], h[2] - h[1], h[3] - h[2],
+                 h[4] - h[3], want_grad ? h[5] - h[4] : 0ull);
+  }
+#endif
   if (on_device)
     for (int e = 0; e < E; ++e)
-      if (flags_h[e] != 0)
+      if (out[(size_t)E * ncomp + e] != 0.0)
         throw Error(MOE_ERR_SINGULAR,
                     "GP-Variance matrix singular. Check for duplicate points_to_sample/being_sampled or "
                     "points_to_sample/being_sampled duplicating points_sampled with 0 noise.",
-                    u, flags_h[e]);
+                    u, out[(size_t)E * ncomp + e]);
   for (int e = 0; e < E; ++e) {
     if (ei) ei[e] = out[(size_t)e * ncomp] / (double)num_mc;
     if (want_grad)

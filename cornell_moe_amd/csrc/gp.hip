@@ -412,7 +412,7 @@ namespace {
 // Shared front half of the state set-ups: the padded points of all evaluations in ONE upload, then E = [K* | dK* | K(X, extra)] for the
 // whole batch (columns grouped by kind, BatchLayout).  Returns the device pointer of the extra points.
 const double* build_state_matrix(GpDev& gp, const double* U_all, int u, const DerivList& dt, int nd, const double* extra_all, int A,
-                                 int E, StateLayout* lay_out, BatchLayout* bl_out) {
+                                 int E, StateLayout* lay_out, BatchLayout* bl_out, const StateAppendix* apx = nullptr) {
   hipStream_t s = gp.stream;
   StateLayout lay;
   lay.d = gp.d;
@@ -431,8 +431,10 @@ const double* build_state_matrix(GpDev& gp, const double* U_all, int u, const De
   const long ctot = bl.total();
   // padded point upload: all evaluations' union points | the differentiated subset (first nd of each) | the extras,
   // packed into ONE pinned staging buffer and ONE copy
+  // (+ the caller's appendix -- records, normal draws -- so that a call's host operands go down in ONE copy, r4)
   const size_t nU = (size_t)E * u * gp.dp, nD = (size_t)E * nd * gp.dp, nX = (size_t)E * A * gp.dp;
-  gp.hStateIn.reserve(nU + nD + nX);
+  const size_t nApx = apx ? apx->doubles : 0;
+  gp.hStateIn.reserve(nU + nD + nX + nApx);
   std::memset(gp.hStateIn.p, 0, sizeof(double) * (nU + nD + nX));
   double* Up = gp.hStateIn.p;
   double* Dp = Up + nU;
@@ -445,13 +447,13 @@ const double* build_state_matrix(GpDev& gp, const double* U_all, int u, const De
     for (int j = 0; j < A; ++j)
       for (int k = 0; k < gp.d; ++k) Ep[((size_t)e * A + j) * gp.dp + k] = extra_all[((size_t)e * A + j) * gp.d + k];
   }
-  gp.dStateIn.upload(gp.hStateIn.p, nU + nD + nX, s);
+  if (apx) apx->fill(gp.hStateIn.p + nU + nD + nX);
+  gp.dStateIn.upload(gp.hStateIn.p, nU + nD + nX + nApx, s);
   double* dUp = gp.dStateIn.p;
   double* dDp = dUp + nU;
   double* dEp = dDp + nD;
-  // (kg.hip reads the union points back through gp.dPts)
-  gp.dPts.reserve(nU);
-  MOE_HIP_CHECK(hipMemcpyAsync(gp.dPts.p, dUp, sizeof(double) * nU, hipMemcpyDeviceToDevice, s));
+  gp.dUnion = dUp;  // (kg.hip / ei.hip read the padded union points back from here)
+  gp.dAppendix = dEp + nX;
   gp.dE.reserve((size_t)N * ctot);
   launch_cov_build(gp.cp, gp.dX.p, gp.n, gp.derivs, dUp, E * u, dt, nullptr, gp.dE.p, N, bl.col_kstar0(0), s);
   if (nd > 0) launch_grad_kstar(gp.cp, gp.dX.p, gp.n, gp.derivs, dDp, E * nd, dt, gp.dE.p, N, bl.col_grad0(0), s);
@@ -468,13 +470,13 @@ const double* build_state_matrix(GpDev& gp, const double* U_all, int u, const De
 }  // namespace
 
 StateEnqueued enqueue_state_batch(GpDev& gp, const double* U_all, int u, const DerivList& dt, int nd, const double* extra_all,
-                                  int A, bool need_W, int num_evals) {
+                                  int A, bool need_W, int num_evals, const StateAppendix* apx, bool consumer_forms_gram) {
   gp.use_device();
   hipStream_t s = gp.stream;
   const int E = num_evals;
   StateLayout lay;
   BatchLayout bl;
-  build_state_matrix(gp, U_all, u, dt, nd, extra_all, A, E, &lay, &bl);
+  build_state_matrix(gp, U_all, u, dt, nd, extra_all, A, E, &lay, &bl, apx);
   const int c = lay.c();
   const int ngrad = bl.ngrad;
   const int N = gp.N;
@@ -482,16 +484,27 @@ StateEnqueued enqueue_state_batch(GpDev& gp, const double* U_all, int u, const D
   gp.dVE.reserve((size_t)N * ctot);
   const size_t nG = (size_t)c * c * E;
   gp.dGram.reserve(nG + ctot);  // gram matrices followed by ek: one download
-  launch_tri_gemm('N', N, (int)ctot, gp.dLinv.p, gp.ldL, gp.dE.p, N, gp.dVE.p, N, s);
+  // (r4: a state of at most 16 columns per evaluation -- every q-EI call -- takes the skinny row-strip kernels for the triangular
+  //  product, 18.6 -> ~6 us at C2, chosen from the per-evaluation column count so that a batch does not change an evaluation's bits;
+  //  wider states keep the tiled kernels)
+  if (c <= 16) {
+    launch_tri_gemm_cols('N', N, (int)ctot, c, gp.dLinv.p, gp.ldL, gp.dE.p, N, gp.dVE.p, N, nullptr, s);
+  } else {
+    launch_tri_gemm('N', N, (int)ctot, gp.dLinv.p, gp.ldL, gp.dE.p, N, gp.dVE.p, N, s);
+  }
   if (need_W) {
     const int cw = E * (lay.m + ngrad);
     gp.dWE.reserve((size_t)N * cw);
     launch_tri_gemm('T', N, cw, gp.dLinv.p, gp.ldL, gp.dVE.p, N, gp.dWE.p, N, s);
   }
-  gp.dEK.reserve((size_t)E * gram_batch_slices(E, c, N) * c * c);  // partial Grams of the K-sliced kernel
-  launch_gram_batch(E, lay.m, ngrad, A, N, gp.dVE.p, N, gp.dGram.p, gp.dEK.p, s);
-  launch_gemm_tn((int)ctot, 1, N, gp.dE.p, N, gp.dKinvY.p, N, gp.dGram.p + nG, (int)ctot, s);
+  const bool fused = consumer_forms_gram && A == 0 && state_fits_lds(N, c);
+  if (!fused) {
+    gp.dEK.reserve((size_t)E * gram_batch_slices(E, c, N) * c * c);  // partial Grams of the K-sliced kernel
+    launch_gram_batch(E, lay.m, ngrad, A, N, gp.dVE.p, N, gp.dGram.p, gp.dEK.p, s);
+    launch_gemm_tn((int)ctot, 1, N, gp.dE.p, N, gp.dKinvY.p, N, gp.dGram.p + nG, (int)ctot, s);
+  }
   StateEnqueued se;
+  se.fused = fused;
   se.bl = bl;
   se.lay = lay;
   se.nG = nG;
@@ -504,13 +517,14 @@ StateEnqueued enqueue_state_batch(GpDev& gp, const double* U_all, int u, const D
 // -- which is how the reference forms the gradient of the variance (grad_K_star^T K_inv_times_K_star, gpp_math.cpp:1277-1290) and what
 // its covariance with other points reduces to once K^-1 K* is at hand (gpp_math.cpp:815-821).  Until r3 both triangular products ran
 // over all m + ngrad + A columns of the state matrix (474 per evaluation at C5, 32 of them K*: 2 x 3e10 flop per evaluation against 4e9).
-KgStateEnqueued enqueue_kg_state_batch(GpDev& gp, const double* U_all, int u, int nd, const double* extra_all, int A, int num_evals) {
+KgStateEnqueued enqueue_kg_state_batch(GpDev& gp, const double* U_all, int u, int nd, const double* extra_all, int A, int num_evals,
+                                       const StateAppendix* apx) {
   gp.use_device();
   hipStream_t s = gp.stream;
   const int E = num_evals;
   StateLayout lay;
   BatchLayout bl;
-  const double* dEp = build_state_matrix(gp, U_all, u, gp.derivs, nd, extra_all, A, E, &lay, &bl);
+  const double* dEp = build_state_matrix(gp, U_all, u, gp.derivs, nd, extra_all, A, E, &lay, &bl, apx);
   const int m = lay.m, ng = bl.ngrad, R = ng + A, N = gp.N;
   const long ctot = bl.total();
   const long cm = (long)E * m;
@@ -531,7 +545,7 @@ KgStateEnqueued enqueue_kg_state_batch(GpDev& gp, const double* U_all, int u, in
   se.gkk = gp.dGram.p;
   se.gx = gp.dGram.p + n_kk;
   se.ek = gp.dGram.p + n_kk + n_x;
-  se.U = gp.dPts.p;
+  se.U = gp.dUnion;
   se.extra = dEp;
   return se;
 }

@@ -1,6 +1,7 @@
 // cornell_moe_amd/csrc/gp.hpp -- device-resident Gaussian process (the object behind moe_gp_t) and the per-call
 // "points state" set-up shared by the posterior queries, q-EI and q-KG.
 #pragma once
+#include <functional>
 #include <memory>
 #include <vector>
 
@@ -33,10 +34,14 @@ struct GpDev {
   DevBuf<int> dInfo;
   // reusable workspaces for states
   DevBuf<double> dPts, dPtsGrad, dExtra, dE, dVE, dWE, dGram, dEK, dStateIn;
+  // inside dStateIn after a state set-up: the padded union points of the batch [E][u][dp], and the caller's appendix (StateAppendix)
+  const double* dUnion = nullptr;
+  const double* dAppendix = nullptr;
   PinnedBuf<double> hStateIn, hStateOut, hKgIn, hKgOut;  // pinned staging for the per-call operands / results
   // reusable workspaces of the KG evaluator (kg.hip)
   DevBuf<double> kBlob, kNormals, kTab, kBestPoint, kBestValue, kBeta, kT, kC, kTB, kOut, kSW, kSWpart, kZcPart, kV;
   DevBuf<unsigned long long> kCounters;
+  DevBuf<unsigned int> kEiTicket;  // arrival counters of ei_mc_kernel's fused final sum (ei.hip)
   DevBuf<int> kBestJ, kStateI;   // kStateI: singular flags | winners of a KG batch (kg_state.hip)
   DevBuf<double> kStateD;        // grad mu | d chol / d Xq (packed) | final [kg_sum | grad] per evaluation
   int num_cu = 256;
@@ -106,15 +111,27 @@ struct BatchLayout {
   long total() const { return (long)E * (m + ngrad + A); }
 };
 // The device half of compute_state_batch -- uploads and kernels on gp.stream, NO sync: Gram matrices [E][c][c] followed by ek [ctot]
-// are left in gp.dGram, the padded union points in gp.dPts.  For callers that keep going on the device (ei.hip).
+// are left in gp.dGram, the padded union points at gp.dUnion.  For callers that keep going on the device (ei.hip).
+// Host operands of the CALLER that ride along in the state set-up's single host->device copy (r4: a q-EI evaluation made five
+// copies of ~3 us each, a q-KG one seven): `doubles` doubles written by fill() into the pinned staging buffer behind the points;
+// their device address afterwards is GpDev::dAppendix.
+struct StateAppendix {
+  size_t doubles = 0;
+  std::function<void(double*)> fill;
+};
 struct StateEnqueued {
   BatchLayout bl;
   StateLayout lay;
   size_t nG = 0;   // doubles of Gram matrices in front of ek
   long ctot = 0;
+  bool fused = false;  // small state, caller asked for it: neither the Gram matrices nor ek were formed -- V = L^-1 E (gp.dVE) and E
+                       // (gp.dE) are left for a consumer that forms them itself (ei.hip: ei_state_kernel)
 };
+// whether a state of c columns over N rows is "small": its V and E columns fit the LDS of the workgroup that consumes them
+inline bool state_fits_lds(int N, int c) { return c <= 48 && sizeof(double) * ((size_t)c * c + c + N + 2 * (size_t)c * N) <= 144 * 1024; }
 StateEnqueued enqueue_state_batch(GpDev& gp, const double* U_all, int u, const DerivList& dt, int nd, const double* extra_all,
-                                  int A, bool need_W, int num_evals);
+                                  int A, bool need_W, int num_evals, const StateAppendix* apx = nullptr,
+                                  bool consumer_forms_gram = false);
 // The KG evaluator's state set-up (r4), everything left on the device for kg_state.hip: see gp.hip.
 struct KgStateEnqueued {
   BatchLayout bl;
@@ -124,7 +141,8 @@ struct KgStateEnqueued {
   const double* U = nullptr;      // [E][u][dp]
   const double* extra = nullptr;  // [E][A][dp]
 };
-KgStateEnqueued enqueue_kg_state_batch(GpDev& gp, const double* U_all, int u, int nd, const double* extra_all, int A, int num_evals);
+KgStateEnqueued enqueue_kg_state_batch(GpDev& gp, const double* U_all, int u, int nd, const double* extra_all, int A, int num_evals,
+                                       const StateAppendix* apx = nullptr);
 void compute_state_batch(GpDev& gp, const double* U_all, int u, const DerivList& dt, int nd, const double* extra_all, int A,
                          bool need_W, int num_evals, BatchLayout* blay, std::vector<StateHost>* hosts);
 

@@ -655,7 +655,18 @@ template <int CB, int WAVES>
 __global__ __launch_bounds__(WAVES * 64) void tri_skinny_n_kernel(int N, const double* __restrict__ T, long ldt,
                                                                   const double* __restrict__ B, long ldb, int c,
                                                                   double* __restrict__ C, long ldc) {
-  __shared__ double red[WAVES][CB][64];
+  // r4: the k range goes down in chunks of KC = 32 WAVES; per chunk a lane issues its 32 loads of T in ONE batch and the chunk's rows
+  // of B are staged in LDS by the whole workgroup (coalesced), so a chunk costs one memory round trip -- the per-k version (one T load
+  // and CB wave-uniform B loads per iteration, four iterations in flight) paid a round trip of 2 - 4 us every few k: 34 us for the
+  // 500 x 500 factor of C2 against 10 columns.  Summation order of an entry: wave w adds its k = w, w + WAVES, ... in ascending order,
+  // the waves' partial sums are added in wave order -- fixed by N alone.
+  constexpr int TPL = 32;            // T loads per lane and chunk
+  constexpr int KC = TPL * WAVES;    // k per chunk
+  constexpr int HW = WAVES / 2;
+  // dynamic LDS: red [WAVES / 2][CB][64] | Bs [KC][CB]   (64 KB at CB = 8 with 16 waves: opted in by the launcher)
+  extern __shared__ __attribute__((aligned(16))) double sk_sm[];
+  double(*red)[CB][64] = reinterpret_cast<double(*)[CB][64]>(sk_sm);
+  double(*Bs)[CB] = reinterpret_cast<double(*)[CB]>(sk_sm + HW * CB * 64);
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int i0 = blockIdx.x * 64, i = i0 + lane, c0 = blockIdx.y * CB;
   const int kend = min(N, i0 + 64);
@@ -664,23 +675,45 @@ __global__ __launch_bounds__(WAVES * 64) void tri_skinny_n_kernel(int N, const d
   double acc[CB];
 #pragma unroll
   for (int cc = 0; cc < CB; ++cc) acc[cc] = 0.0;
-#pragma unroll 4
-  for (int k = w; k < kend; k += WAVES) {
-    const double t = (row_ok && k <= i) ? Trow[(long)k * ldt] : 0.0;
+  for (int k0 = 0; k0 < kend; k0 += KC) {
+    double tv[TPL];
 #pragma unroll
-    for (int cc = 0; cc < CB; ++cc) {
-      const double b = (c0 + cc < c) ? B[k + (long)(c0 + cc) * ldb] : 0.0;
-      acc[cc] = fma(t, b, acc[cc]);
+    for (int t = 0; t < TPL; ++t) tv[t] = Trow[(long)min(k0 + w + WAVES * t, kend - 1) * ldt];  // (clamped; masked below)
+    for (int t = threadIdx.x; t < KC * CB; t += WAVES * 64) {
+      const int kk = t % KC, cc = t / KC;
+      Bs[kk][cc] = (k0 + kk < kend && c0 + cc < c) ? B[(long)(k0 + kk) + (long)(c0 + cc) * ldb] : 0.0;
     }
-  }
+    __syncthreads();
 #pragma unroll
-  for (int cc = 0; cc < CB; ++cc) red[w][cc][lane] = acc[cc];
+    for (int t = 0; t < TPL; ++t) {
+      const int kk = w + WAVES * t, k = k0 + kk;
+      const double tm = (row_ok && k <= i && k < kend) ? tv[t] : 0.0;
+#pragma unroll
+      for (int cc = 0; cc < CB; ++cc) acc[cc] = fma(tm, Bs[kk][cc], acc[cc]);
+    }
+    __syncthreads();
+  }
+  // waves HW .. WAVES - 1 hand their sums to waves 0 .. HW - 1 (w + HW -> w), then the HW partial sums are added in wave order
+  if (w >= HW) {
+#pragma unroll
+    for (int cc = 0; cc < CB; ++cc) red[w - HW][cc][lane] = acc[cc];
+  }
+  __syncthreads();
+  if (w < HW) {
+#pragma unroll
+    for (int cc = 0; cc < CB; ++cc) acc[cc] += red[w][cc][lane];
+  }
+  __syncthreads();
+  if (w < HW) {
+#pragma unroll
+    for (int cc = 0; cc < CB; ++cc) red[w][cc][lane] = acc[cc];
+  }
   __syncthreads();
   for (int t = threadIdx.x; t < CB * 64; t += WAVES * 64) {
     const int cc = t >> 6, l = t & 63;
     double v = 0.0;
 #pragma unroll
-    for (int ww = 0; ww < WAVES; ++ww) v += red[ww][cc][l];
+    for (int ww = 0; ww < HW; ++ww) v += red[ww][cc][l];
     if (i0 + l < N && c0 + cc < c) C[(long)(i0 + l) + (long)(c0 + cc) * ldc] = v;
   }
 }
@@ -698,14 +731,15 @@ __global__ __launch_bounds__(256) void tri_skinny_t_kernel(int N, const double* 
   double acc[CB];
 #pragma unroll
   for (int cc = 0; cc < CB; ++cc) acc[cc] = 0.0;
-#pragma unroll 4
-  for (int i = (j & ~63) + lane; i < N; i += 64) {
-    const double t = (i >= j) ? col[i] : 0.0;
+  const double* Bc[CB];
 #pragma unroll
-    for (int cc = 0; cc < CB; ++cc) {
-      const double b = (c0 + cc < c) ? B[i + (long)(c0 + cc) * ldb] : 0.0;
-      acc[cc] = fma(t, b, acc[cc]);
-    }
+  for (int cc = 0; cc < CB; ++cc) Bc[cc] = B + (long)min(c0 + cc, c - 1) * ldb;
+#pragma unroll 8
+  for (int i = (j & ~63) + lane; i < N; i += 64) {  // (unconditional loads, masked afterwards: see tri_skinny_n_kernel)
+    const double tv = col[i];
+    const double t = (i >= j) ? tv : 0.0;
+#pragma unroll
+    for (int cc = 0; cc < CB; ++cc) acc[cc] = fma(t, Bc[cc][i], acc[cc]);
   }
 #pragma unroll
   for (int cc = 0; cc < CB; ++cc) {
@@ -721,10 +755,12 @@ void launch_tri_skinny(char op, int N, int c, const double* T, long ldt, const d
                        hipStream_t s) {
   const int groups = (c + CB - 1) / CB;
   if (op == 'N') {
-    if (N > 2048)
-      hipLaunchKernelGGL((tri_skinny_n_kernel<CB, 16>), dim3((N + 63) / 64, groups), dim3(1024), 0, s, N, T, ldt, B, ldb, c, C, ldc);
-    else
-      hipLaunchKernelGGL((tri_skinny_n_kernel<CB, 8>), dim3((N + 63) / 64, groups), dim3(512), 0, s, N, T, ldt, B, ldb, c, C, ldc);
+    // (LDS: reduction slots 8 x CB x 64 + B chunk 512 x CB doubles: 64 KB at CB = 8)
+    auto kern = tri_skinny_n_kernel<CB, 16>;
+    const size_t shm = sizeof(double) * ((size_t)8 * CB * 64 + (size_t)512 * CB);
+    if (shm > 48 * 1024)
+      MOE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+    hipLaunchKernelGGL(kern, dim3((N + 63) / 64, groups), dim3(1024), shm, s, N, T, ldt, B, ldb, c, C, ldc);
   } else {
     hipLaunchKernelGGL((tri_skinny_t_kernel<CB>), dim3((N + 3) / 4, groups), dim3(256), 0, s, N, T, ldt, B, ldb, c, C, ldc);
   }
@@ -848,11 +884,11 @@ void launch_tri_gemm_cols(char op, int N, int c, int cols_per_problem, const dou
     const char* v = std::getenv("MOE_TRI_COLS");  // 0: the plain tiled kernels (A/B runs)
     return (v && *v) ? std::atoi(v) : 1;
   }();
-  if (mode == 0) {
+  if (mode == 0 || N < 128) {  // (tiny factors: one or two row tiles, the plain tiled kernel)
     launch_tri_gemm(op, N, c, T, ldt, B, ldb, C, ldc, s);
     return;
   }
-  if (cols_per_problem <= 16 && N >= 128) {  // a handful of columns per problem: the row-strip / column-per-wavefront kernels
+  if (cols_per_problem <= 16) {  // a handful of columns per problem: the row-strip / column-per-wavefront kernels
     if (cols_per_problem <= 4)
       launch_tri_skinny<4>(op, N, c, T, ldt, B, ldb, C, ldc, s);
     else

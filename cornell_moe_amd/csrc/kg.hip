@@ -1240,7 +1240,7 @@ KgPending kg_launch(GpDev& gp, int num_fidelity, const moe_gd_params_t& gd, cons
   // ---- coordinate tables ----
   {
     dim3 grid((unsigned)((tab_stride + 255) / 256), E);
-    hipLaunchKernelGGL(build_xs_tab_kernel, grid, dim3(256), 0, s, gp.dX.p, n, gp.dPts.p, u, dp, ntiles, tp, dTab.p, tab_stride,
+    hipLaunchKernelGGL(build_xs_tab_kernel, grid, dim3(256), 0, s, gp.dX.p, n, gp.dUnion, u, dp, ntiles, tp, dTab.p, tab_stride,
                        (wide_dp || variant == 2 || (variant == 0 && mc::wide_eval(dp, xlds))) ? 1 : 0);
     MOE_HIP_CHECK(hipGetLastError());
   }
@@ -1335,7 +1335,9 @@ KgPending kg_launch(GpDev& gp, int num_fidelity, const moe_gd_params_t& gd, cons
     launch_mc_block(mp, dp, G, tr, num_lds_tiles, blocks, waves, s);
   t_mc.stop(s);
   {
-    const int info[8] = {variant, (variant == 0 && xlds) ? 1 : 0, waves, variant == 1 ? tr : wide_lds_tiles, mp.V != nullptr ? 1 : 0, 0, blocks,
+    // (bits 1 / 2 of the second word, r4: the frame-extent decisions -- a domain box or point set wider than 100 length scales
+    //  silently costs the LDS-table kernel and the multi-trial passes; this is where a caller can see it)
+    const int info[8] = {variant, ((variant == 0 && xlds) ? 1 : 0) | (far_frame ? 2 : 0) | (wide_frame ? 4 : 0), waves, variant == 1 ? tr : wide_lds_tiles, mp.V != nullptr ? 1 : 0, 0, blocks,
                          mp.best_j != nullptr ? 1 : 0};
     std::copy(info, info + 8, gp.last_info);
   }

@@ -251,7 +251,8 @@ def bring_up(rank, world, local_rank, prefer="nccl", timeout_s=150.0, log=None):
     try:
         _, err = child.communicate(timeout=timeout_s)
         if child.returncode != 0:
-            why = "rccl pre-flight failed on rank %d (exit %d): %s" % (rank, child.returncode, (err or "").strip().splitlines()[-1:] or "")
+            tail = (err or "").strip().splitlines()
+            why = "rccl pre-flight failed on rank %d (exit %d): %s" % (rank, child.returncode, tail[-1] if tail else "no message")
     except subprocess.TimeoutExpired:
         child.kill()  # exactly the process started above
         child.communicate()
@@ -273,16 +274,28 @@ def bring_up(rank, world, local_rank, prefer="nccl", timeout_s=150.0, log=None):
         assert abs(float(t.item()) - world) < 1e-12
         return Comm(rank, world, data_backend + " (test hook)", grp, None, None, took)
     dev = torch.device("cuda", local_rank)
-    grp, err = None, None
-    for kwargs in (dict(device_id=dev), dict()):  # (an API-level refusal of device_id is the same on every rank: retry without)
+    # The pre-flight child isolated the FIRST contact with RCCL; the group created here, in the parent, is protected by its 120 s
+    # timeout only.  new_group is collective over the default group, so the ranks must make the same sequence of calls: after
+    # each attempt they agree over gloo (MIN) whether it succeeded EVERYWHERE, and only then does anyone move on to the attempt
+    # without device_id -- a rank whose attempt raised alone must not retry alone.
+    grp, err, all_ok = None, None, False
+    for kwargs in (dict(device_id=dev), dict()):
+        mine = None
         try:
-            grp = dist.new_group(backend="nccl", timeout=datetime.timedelta(seconds=120), **kwargs)
-            break
+            mine = dist.new_group(backend="nccl", timeout=datetime.timedelta(seconds=120), **kwargs)
         except Exception as e:  # noqa: BLE001
             err = "%s: %s" % (type(e).__name__, e)
-    flag = torch.tensor([1.0 if grp is not None else 0.0], dtype=torch.float64)
-    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-    if float(flag.item()) < 0.5:
+        flag = torch.tensor([1.0 if mine is not None else 0.0], dtype=torch.float64)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if float(flag.item()) >= 0.5:
+            grp, all_ok = mine, True
+            break
+        if mine is not None:  # it came up here but not everywhere: drop it, everybody takes the next attempt
+            try:
+                dist.destroy_process_group(mine)
+            except Exception:  # noqa: BLE001  # pragma: no cover
+                pass
+    if not all_ok:
         reason = "rccl group creation failed after a passing pre-flight (%s)" % err
         log("RCCL NOT USED -- %s; collectives run on gloo (host tensors)" % reason)
         return Comm(rank, world, "gloo", None, None, reason, took)

@@ -359,8 +359,12 @@ int moe_debug_math(int n, const double* x, int device, double* exp_neg, double* 
  * out[3] = state set-up ms, out[4] = total device ms. */
 int moe_last_kernel_ms(const moe_gp_t* gp, double* out5);
 /* Which Monte-Carlo kernel the last moe_kg* call on this handle launched (diagnostics; the tests use it to assert that a
- * fixture really exercised the path it was built for): out[0] = variant (0 wave-per-sample, 1 workgroup-per-sample),
- * out[1] = coordinate table in LDS, out[2] = wavefronts per workgroup, out[3] = register tiles per wavefront (variant 1) or
+ * fixture really exercised the path it was built for): out[0] = variant (0 wave-per-sample, 1 workgroup-per-sample, 2 streamed-weights wave-per-sample),
+ * out[1] = bit 0: coordinate table in LDS; bit 1: FAR FRAME -- the training set, the points being sampled or the inner domain box
+ *          span more than 100 length scales from the training-set mean, so the evaluation took the direct-difference kernels with
+ *          single-trial passes (exact, slower: typical triggers are the short length scales of a hyper-parameter MCMC ensemble or a
+ *          search box far wider than the data); bit 2: coordinates streamed from L2 (far frame, or d > 16),
+ * out[2] = wavefronts per workgroup, out[3] = register tiles per wavefront (variant 1) or
  * leading tiles of the paired-row table kept in LDS (variant 0, d > 16),
  * out[4] = streamed per-sample weight table, out[5] = T-free gradient tail, out[6] = workgroups, out[7] = sample pre-pass. */
 int moe_last_kernel_info(const moe_gp_t* gp, int* out8);

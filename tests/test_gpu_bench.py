@@ -13,11 +13,11 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _run(extra_env, *flags):
+def _run(extra_env, *flags, gpus=2):
     env = dict(os.environ, **extra_env)
     env.pop("WORLD_SIZE", None)
     env.pop("RANK", None)
-    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(gpus), "--steps", "2", "--warmup", "1",
                           "--no-cpu-baseline", "--no-traffic", "--no-extras"] + list(flags), env=env, stdout=subprocess.PIPE,
                          stderr=subprocess.PIPE, universal_newlines=True, timeout=900)
     assert res.returncode == 0, res.stderr[-2000:]
@@ -59,6 +59,18 @@ def test_bench_default_step_is_the_c4_job():
     out, _ = _run({"MOE_BENCH_BACKEND": "gloo"}, "--no-mc-shard", "--no-batch1")
     assert out["config"]["evals_per_step"] == 64 and out["config"]["evals_per_gpu_per_step"] == 32 and out["scaling"] == "strong"
     assert out["determinism"]["ok"] and out["determinism"]["restarts"] == 64
+
+
+def test_bench_world8_c4_job_on_one_gpu():
+    """The C4 job at its REAL world size: eight ranks under torch.distributed.run -- rendezvous, gloo control
+    plane, the data-plane group, gather_restarts with 8 restarts per rank, the determinism check over all 64 -- sharing the test
+    box's one GPU (the collectives on gloo: the test hook); what the driver's 8-GPU run does differently is RCCL and one GPU each."""
+    out, _ = _run({"MOE_BENCH_BACKEND": "gloo"}, "--no-mc-shard", "--no-batch1", gpus=8)
+    assert out["n_gpus"] == 8 and out["scaling"] == "strong"
+    assert out["config"]["evals_per_step"] == 64 and out["config"]["evals_per_gpu_per_step"] == 8
+    assert len(out["per_rank_evals_per_s"]) == 8 and all(v > 0 for v in out["per_rank_evals_per_s"])
+    assert out["determinism"]["ok"] and out["determinism"]["restarts"] == 64 and out["determinism"]["max_rel_diff_vs_one_rank"] == 0.0
+    assert out["collective_us_per_step"]["rank0"] > 0 and out["collective_backend"] == "gloo"
 
 
 def test_rccl_preflight_child_passes_under_a_launcher_environment():

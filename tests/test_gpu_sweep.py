@@ -424,6 +424,8 @@ def test_wide_frame_takes_direct_differences(monkeypatch):
         else:
             monkeypatch.setenv("MOE_KG_DOT_MAX_RADIUS2", radius2)
         rg = G.kg(gd, bounds, disc, Xq, None, M, best, Z)
+        # (r4: the decision is visible to the caller -- moe_last_kernel_info, bit 1 of the second word)
+        assert G.last_kernel_info()["far_frame"] == (1 if radius2 is None else 0)
         errs[label] = (abs(rg["kg"] - ro["kg"]) / abs(ro["kg"]), np.abs((rg["grad"] - ro["grad"]) * lengths).max() / scale)
         print("wide frame, %s: KG rel. error %.2e, grad KG rel. error %.2e" % ((label,) + errs[label]))
     e = errs["direct differences (default)"]
