@@ -76,6 +76,17 @@ __device__ __forceinline__ double sqrt_pos(double s) {
 
 __device__ __forceinline__ double sqrt_nonneg(double s) { return sqrt_pos(fmax(s, 1.0e-300)); }
 
+// The same without the coupled Newton step: v_rsq_f64 seed (relative error d <= 5e-8) and ONE Heron correction, which leaves
+// -1.5 d^2: at most 36 ulp = 4e-15 relative (tools/mathcheck.hip, "sqrt seed+heron"), two FP64 instructions less (1 + 4 instead of
+// 1 + 6).  For the Monte-Carlo kernels' distance -> covariance chain (r4): a relative error e in a = sqrt(5) r moves the Matern
+// covariance by a e e^-a (...) <= 2e-15 relative -- the size of the rounding the chain's other ~25 operations add up to.
+__device__ __forceinline__ double sqrt_pos_fast(double s) {
+  const double y = __builtin_amdgcn_rsq(s);
+  const double g = s * y;
+  const double d = fma(-g, g, s);
+  return fma(d, 0.5 * y, g);
+}
+
 // 2^(j/64), j = 0..63, correctly rounded: the table exp_nonpos_tab expects (callers copy it into LDS).
 __device__ __constant__ const double kExp2Tab64[64] = {
     1.0,

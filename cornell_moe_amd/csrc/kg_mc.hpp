@@ -38,6 +38,10 @@ namespace moe {
 #ifndef MOE_KG_GRAD_DOT
 #define MOE_KG_GRAD_DOT 0
 #endif
+// radial3's square root: 1 = seed + one Heron step (<= 36 ulp, two instructions less per covariance entry), 0 = correctly rounded
+#ifndef MOE_KG_FAST_SQRT
+#define MOE_KG_FAST_SQRT 1
+#endif
 #if MOE_BLOCK_PROF
 #define MOE_PROF_T(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
 #define MOE_PROF_ADD(dst, a, b) dst += (b) - (a)
@@ -305,7 +309,11 @@ __device__ __forceinline__ void radial3(double r2, const double* __restrict__ et
     first = base;
     second = base;
   } else {
+#if MOE_KG_FAST_SQRT
+    const double a = sqrt_pos_fast(r2);
+#else
     const double a = sqrt_pos(r2);
+#endif
     const double e = exp_nonpos_tab(-a, etab);
     base = e * fma(a, fma(a, 1.0 / 3.0, 1.0), 1.0);  // e^-a (1 + a + a^2/3)
     first = NEED_FIRST ? (1.0 / 3.0) * (e * (a + 1.0)) : 0.0;
