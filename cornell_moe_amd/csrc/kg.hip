@@ -333,21 +333,27 @@ __global__ __launch_bounds__(256) void kg_zc_part_kernel(KgTailParams P, double*
   }
 }
 
-__global__ __launch_bounds__(256) void kg_zc_sum_kernel(KgTailParams P, const double* __restrict__ part, int chunks) {
+// (r4: `gs` lanes share an output -- a power of two, m m gs <= 256 -- and stride the chunks, then a fixed butterfly: a lane per output
+//  walked all the chunks in batches of eight loads, one memory round trip per batch: 19 us for the 157 chunks of one C3 evaluation)
+__global__ __launch_bounds__(256) void kg_zc_sum_kernel(KgTailParams P, const double* __restrict__ part, int chunks, int gs) {
   __shared__ double red[4];
   const int e = blockIdx.y, m = P.m;
-  const int o = blockIdx.x * 256 + threadIdx.x;
+  const int per_block = 256 / gs;
+  const int o = blockIdx.x * per_block + (int)threadIdx.x / gs, g = (int)threadIdx.x % gs;
   double* out = P.out + (long)e * P.out_stride;
-  if (o < m * m) {
-    const double* p = part + (long)e * chunks * m * m + o;
+  {
+    const bool ok = o < m * m;
+    const double* p = part + (long)e * chunks * m * m + (ok ? o : 0);
     double v = 0.0;
 #pragma unroll 8
-    for (int ch = 0; ch < chunks; ++ch) v += p[(long)ch * m * m];
-    out[1 + o] = v;
+    for (int ch = g; ch < chunks; ch += gs) v += p[(long)ch * m * m];
+    for (int off = gs >> 1; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    if (ok && g == 0) out[1 + o] = v;
   }
   if (blockIdx.x == 0) {  // kg_sum = sum_i (best_posterior + best_value_i): the summation of kg_sum_kernel, bit for bit
     const double bp = P.blob[(long)e * P.rec.stride + P.rec_bp];
     double acc = 0.0;
+#pragma unroll 8
     for (int i = threadIdx.x; i < P.num_local; i += 256) acc += bp + P.best_value[(long)e * P.num_local + i];
     const double tot = block_sum_256(acc, red);
     if (threadIdx.x == 0) out[0] = tot;
@@ -360,7 +366,10 @@ void launch_zc(const KgTailParams& P, double* part, hipStream_t s) {
   const int chunks = (P.num_local + len - 1) / len;
   const size_t shm = sizeof(double) * 2 * len * P.m;
   hipLaunchKernelGGL(kg_zc_part_kernel, dim3(chunks, P.E), dim3(256), shm, s, P, part, chunks, len);
-  hipLaunchKernelGGL(kg_zc_sum_kernel, dim3((P.m * P.m + 255) / 256, P.E), dim3(256), 0, s, P, (const double*)part, chunks);
+  int gs = 1;
+  while (gs < 64 && P.m * P.m * gs * 2 <= 256) gs *= 2;
+  const int per_block = 256 / gs;
+  hipLaunchKernelGGL(kg_zc_sum_kernel, dim3((P.m * P.m + per_block - 1) / per_block, P.E), dim3(256), 0, s, P, (const double*)part, chunks, gs);
 }
 
 // DIR[e][(k (1+g) + b) d + dd] = sum_i beta_i[(k,b)] * d cov(Xu_k, x*_i)[b, 0] / d Xu_k,dd ; workgroup (k, e).
@@ -685,14 +694,20 @@ void launch_fused_tail(const KgTailParams& P, const double* X, int n, double* SW
 }
 
 // value-only finish: kg_sum per evaluation (same summation as the r == 0 workgroup of kg_zc_kernel)
-__global__ __launch_bounds__(256) void kg_sum_kernel(KgTailParams P) {
+__global__ __launch_bounds__(256) void kg_sum_kernel(KgTailParams P, double* __restrict__ fin, const unsigned long long* __restrict__ counters,
+                                                     const int* __restrict__ flags) {
   __shared__ double red[4];
   const int e = blockIdx.x;
   const double bp = P.blob[(long)e * P.rec.stride + P.rec_bp];
   double acc = 0.0;
   for (int i = threadIdx.x; i < P.num_local; i += 256) acc += bp + P.best_value[(long)e * P.num_local + i];
   const double tot = block_sum_256(acc, red);
-  if (threadIdx.x == 0) P.out[(long)e * P.out_stride] = tot;
+  if (threadIdx.x == 0) {  // the record the host reads back: kg_sum | value passes | gradient passes | singular flag
+    fin[4 * e] = tot;
+    fin[4 * e + 1] = (double)counters[2 * e];
+    fin[4 * e + 2] = (double)counters[2 * e + 1];
+    fin[4 * e + 3] = (double)flags[e];
+  }
 }
 
 struct EventTimer {
@@ -1080,16 +1095,6 @@ KgPending kg_launch(GpDev& gp, int num_fidelity, const moe_gd_params_t& gd, cons
       for (int k = size; k < d; ++k) ex[(size_t)j * d + k] = 1.0;
     }
   }
-  DerivList none;
-  none.g = 0;
-  for (int i = 0; i < kMaxDerivs; ++i) none.idx[i] = 0;
-  auto timers = std::make_shared<std::array<EventTimer, 4>>();
-  EventTimer &t_mc = (*timers)[0], &t_cov = (*timers)[1], &t_tail = (*timers)[2], &t_state = (*timers)[3];
-  t_state.start(s);
-  // everything N-sized of the state, left on the device (gp.hip): no wait, no download -- the m x m algebra follows as kernels
-  const KgStateEnqueued se = enqueue_kg_state_batch(gp, U_all.data(), u, want_grad ? q : 0, extra_all.data(), A, E);
-  const BatchLayout& bl = se.bl;
-
   // ---- table-row order of the dimensions ----
   TabParams tp;
   {
@@ -1149,7 +1154,7 @@ KgPending kg_launch(GpDev& gp, int num_fidelity, const moe_gd_params_t& gd, cons
   const size_t blob_size = (size_t)rec.stride * E + 4 * kMaxDimPadded;
   const size_t o_bounds = (size_t)rec.stride * E;
   const long num_norm = (long)((num_mc + 1) / 2) * m;
-  gp.hKgIn.reserve(blob_size + (size_t)num_norm);
+  gp.hKgIn.reserve(blob_size);  // (host-side assembly area; it travels inside the state set-up's staging buffer)
   double* blob = gp.hKgIn.p;
   std::memset(blob, 0, sizeof(double) * blob_size);
   unsigned int free_mask = 0;  // table-row order: bounds of row r = bounds of original dimension perm[r]
@@ -1171,18 +1176,34 @@ KgPending kg_launch(GpDev& gp, int num_fidelity, const moe_gd_params_t& gd, cons
       for (int k = 0; k < d; ++k) r[rec.XuP + (size_t)i * dp + k] = U[(size_t)i * d + k];
   }
 
+  DerivList none;
+  none.g = 0;
+  for (int i = 0; i < kMaxDerivs; ++i) none.idx[i] = 0;
+  auto timers = std::make_shared<std::array<EventTimer, 4>>();
+  EventTimer &t_mc = (*timers)[0], &t_cov = (*timers)[1], &t_tail = (*timers)[2], &t_state = (*timers)[3];
+  t_state.start(s);
+  // everything N-sized of the state, left on the device (gp.hip): no wait, no download -- the m x m algebra follows as kernels.
+  // The records and the normal draws ride down in the same host->device copy as the points (r4: one copy per call instead of three).
+  StateAppendix apx;
+  apx.doubles = blob_size + (size_t)num_norm;
+  apx.fill = [&](double* dst) {
+    std::memcpy(dst, blob, sizeof(double) * blob_size);
+    std::memcpy(dst + blob_size, normals, sizeof(double) * num_norm);
+  };
+  const KgStateEnqueued se = enqueue_kg_state_batch(gp, U_all.data(), u, want_grad ? q : 0, extra_all.data(), A, E, &apx);
+  const BatchLayout& bl = se.bl;
+  double* dBlobP = const_cast<double*>(gp.dAppendix);  // (kg_state_kernel completes the records in place)
+  const double* dNormalsP = gp.dAppendix + blob_size;
+
   // ---- device buffers ----
-  DevBuf<double>&dBlob = gp.kBlob, &dNormals = gp.kNormals, &dTab = gp.kTab, &dBestPoint = gp.kBestPoint,
-  &dBestValue = gp.kBestValue, &dBeta = gp.kBeta, &dT = gp.kT, &dC = gp.kC, &dTB = gp.kTB, &dOut = gp.kOut;
+  DevBuf<double>&dTab = gp.kTab, &dBestPoint = gp.kBestPoint, &dBestValue = gp.kBestValue, &dBeta = gp.kBeta, &dT = gp.kT, &dC = gp.kC,
+  &dTB = gp.kTB, &dOut = gp.kOut;
   DevBuf<unsigned long long>& dCounters = gp.kCounters;
-  dBlob.upload(blob, blob_size, s);
-  std::memcpy(blob + blob_size, normals, sizeof(double) * num_norm);
-  dNormals.upload(blob + blob_size, num_norm, s);
   // ---- the m x m algebra of the state, on the device (kg_state.hip) ----
   const int qd = q * d;
   const int tri = m * (m + 1) / 2;
   gp.kStateI.reserve((size_t)2 * E);
-  gp.kStateD.reserve((size_t)E * qd * (1 + (want_grad ? tri : 0)) + (size_t)E * (1 + qd) + (size_t)E * tri);
+  gp.kStateD.reserve((size_t)E * qd * (1 + (want_grad ? tri : 0)) + (size_t)E * (1 + qd + 3) + (size_t)E * tri);
   KgStateParams sp;
   sp.cp = gp.cp;
   sp.derivs = gp.derivs;
@@ -1203,7 +1224,7 @@ KgPending kg_launch(GpDev& gp, int num_fidelity, const moe_gd_params_t& gd, cons
   sp.ek = se.ek;
   sp.U = se.U;
   sp.extra = se.extra;
-  sp.blob = dBlob.p;
+  sp.blob = dBlobP;
   sp.rec_stride = rec.stride;
   sp.rec_L = rec.L;
   sp.rec_mu_disc = rec.mu_disc;
@@ -1273,11 +1294,11 @@ KgPending kg_launch(GpDev& gp, int num_fidelity, const moe_gd_params_t& gd, cons
   mp.KinvY = gp.dKinvY.p;
   mp.W = gp.dWE.p + bl.col_kstar0(0) * N;
   mp.w_stride = (long)m * N;
-  mp.blob = dBlob.p;
+  mp.blob = dBlobP;
   mp.rec = rec;
-  mp.bounds = dBlob.p + o_bounds;
+  mp.bounds = dBlobP + o_bounds;
   mp.free_mask = free_mask;
-  mp.normals = dNormals.p;
+  mp.normals = dNormalsP;
   mp.first_sample = first_sample;
   mp.num_local = num_local;
   mp.max_num_steps = gd.max_num_steps;
@@ -1368,13 +1389,13 @@ KgPending kg_launch(GpDev& gp, int num_fidelity, const moe_gd_params_t& gd, cons
   tl.ldL = gp.ldL;
   tl.tri_work = gp.dEK.p;  // (reserved by enqueue_kg_state_batch; the state's own use of it is behind us in stream order)
   tl.work = gp.dVE.p;  // [2][N x E m]: enqueue_kg_state_batch reserves it; V = L^-1 K* is not needed any more
-  tl.blob = dBlob.p;
+  tl.blob = dBlobP;
   tl.rec = rec;
   tl.rec_bp = rec_bp;
   tl.best_point = dBestPoint.p;
   tl.best_value = dBestValue.p;
   tl.beta = dBeta.p;
-  tl.normals = dNormals.p;
+  tl.normals = dNormalsP;
   tl.C = dC.p;
   tl.TBpart = dTB.p;
   tl.out = dOut.p;
@@ -1423,7 +1444,7 @@ KgPending kg_launch(GpDev& gp, int num_fidelity, const moe_gd_params_t& gd, cons
       hipLaunchKernelGGL(kg_zc_kernel, dim3(m, m, E), dim3(256), 0, s, tl);
     }
   } else {
-    hipLaunchKernelGGL(kg_sum_kernel, dim3(E), dim3(256), 0, s, tl);
+    hipLaunchKernelGGL(kg_sum_kernel, dim3(E), dim3(256), 0, s, tl, dFin, (const unsigned long long*)dCounters.p, (const int*)gp.kStateI.p);
   }
   MOE_HIP_CHECK(hipGetLastError());
   // ---- grad KG from the sample sums, on the device (kg_state.hip) ----
@@ -1437,7 +1458,7 @@ KgPending kg_launch(GpDev& gp, int num_fidelity, const moe_gd_params_t& gd, cons
     fp.ng = ngrad;
     fp.num_mc = num_mc;
     fp.first_sample = first_sample;
-    fp.blob = dBlob.p;
+    fp.blob = dBlobP;
     fp.rec_stride = rec.stride;
     fp.rec_L = rec.L;
     fp.out = dOut.p;
@@ -1446,19 +1467,17 @@ KgPending kg_launch(GpDev& gp, int num_fidelity, const moe_gd_params_t& gd, cons
     fp.gmu = sp.gmu;
     fp.dL = sp.dL;
     fp.fin = dFin;
-    launch_kg_finish(fp, dFin + (size_t)E * (1 + qd), s);
+    fp.counters = dCounters.p;
+    fp.flags = gp.kStateI.p;
+    launch_kg_finish(fp, dFin + (size_t)E * (1 + qd + 3), s);
     t_tail.stop(s);
   }
-  // results through pinned memory: [fin: E (1 + q d) doubles (value only: E x out_stride = 1) | 2 E counters | E flags]
-  const int fin_stride = want_grad ? 1 + qd : out_stride;
+  // results through pinned memory in ONE copy: per evaluation kg_sum | grad_sum (q d) | value passes | gradient passes | flag
+  const int fin_stride = (want_grad ? 1 + qd : 1) + 3;
   const size_t n_out = (size_t)fin_stride * E;
-  gp.hKgOut.reserve(n_out + 2 * (size_t)E + (size_t)(E + 1) / 2 + 1);
+  gp.hKgOut.reserve(n_out);
   double* out = gp.hKgOut.p;
-  MOE_HIP_CHECK(hipMemcpyAsync(out, want_grad ? dFin : dOut.p, sizeof(double) * n_out, hipMemcpyDeviceToHost, s));
-  unsigned long long* counters = reinterpret_cast<unsigned long long*>(gp.hKgOut.p + n_out);
-  dCounters.download(counters, (size_t)2 * E, s);
-  int* flags_h = reinterpret_cast<int*>(gp.hKgOut.p + n_out + 2 * (size_t)E);
-  MOE_HIP_CHECK(hipMemcpyAsync(flags_h, gp.kStateI.p, sizeof(int) * E, hipMemcpyDeviceToHost, s));
+  MOE_HIP_CHECK(hipMemcpyAsync(out, dFin, sizeof(double) * n_out, hipMemcpyDeviceToHost, s));
 #if MOE_BLOCK_PROF
   auto prof_p = std::make_shared<std::vector<unsigned long long>>(16);
   MOE_HIP_CHECK(hipMemcpyAsync(prof_p->data(), dCounters.p + n_ctr - 16, sizeof(unsigned long long) * 16, hipMemcpyDeviceToHost, s));
@@ -1505,11 +1524,11 @@ KgPending kg_launch(GpDev& gp, int num_fidelity, const moe_gd_params_t& gd, cons
     }
 #endif
     for (int e = 0; e < E; ++e)
-      if (flags_h[e] != 0)
+      if (out[(size_t)fin_stride * (e + 1) - 1] != 0.0)
         throw Error(MOE_ERR_SINGULAR,
                     "GP-Variance matrix singular. Check for duplicate points_to_sample/being_sampled or "
                     "points_to_sample/being_sampled duplicating points_sampled with 0 noise.",
-                    m, flags_h[e]);
+                    m, out[(size_t)fin_stride * (e + 1) - 1]);
     if (best_points && fetch_bp)
       for (int i = 0; i < num_local; ++i)
         for (int k = 0; k < d; ++k) best_points[(size_t)i * d + k] = (*bp_p)[(size_t)i * dp + k];
@@ -1519,8 +1538,8 @@ KgPending kg_launch(GpDev& gp, int num_fidelity, const moe_gd_params_t& gd, cons
       kg_sum[e] = o[0];
       if (want_grad) std::copy(o + 1, o + 1 + qd, grad_sum + (size_t)e * qd);
       if (stats) {
-        stats->posterior_mean_evals += (long long)counters[2 * e];
-        stats->posterior_grad_evals += (long long)counters[2 * e + 1];
+        stats->posterior_mean_evals += (long long)o[fin_stride - 3];
+        stats->posterior_grad_evals += (long long)o[fin_stride - 2];
       }
     }
     const double wall = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wall0).count();

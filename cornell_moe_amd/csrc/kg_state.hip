@@ -256,8 +256,14 @@ __global__ __launch_bounds__(64) void kg_finish_kernel(KgFinishParams P, const d
     double val = -(direct - zmc);  // aggregate -= gic . z  (.cpp:214-221)
     // winner term: + M grad mu[winner]  (.cpp:157-161); added once, by the shard that owns sample 0
     if (P.winner[e] == k && P.first_sample == 0) val += (double)P.num_mc * P.gmu[(long)e * qd + idx];
-    P.fin[(long)e * (1 + qd) + 1 + idx] = val;
-    if (idx == 0) P.fin[(long)e * (1 + qd)] = o[0];
+    double* fin = P.fin + (long)e * (1 + qd + 3);
+    fin[1 + idx] = val;
+    if (idx == 0) {
+      fin[0] = o[0];
+      fin[1 + qd] = (double)P.counters[2 * e];
+      fin[2 + qd] = (double)P.counters[2 * e + 1];
+      fin[3 + qd] = (double)P.flags[e];
+    }
   }
 }
 

@@ -45,7 +45,10 @@ struct KgFinishParams {
   const int* winner;
   const double* gmu;
   const double* dL;
-  double* fin;         // [E][1 + q d]: kg_sum | grad_sum
+  double* fin;         // [E][1 + q d + 3]: kg_sum | grad_sum | value passes | gradient passes | singular flag -- everything the host
+                       // reads back, in ONE copy
+  const unsigned long long* counters;  // [E][2] pass counters of the MC kernel
+  const int* flags;                    // [E] kg_state_kernel's singular-matrix flags
 };
 // grad KG from the sample sums: < L^-1 dL, ZC > taken as < dL, L^-T tril(ZC) > (one m-column back substitution per evaluation
 // instead of q d m forward ones), the DIR - GTB terms and the winner's grad mu.  Y: E m (m + 1) / 2 doubles of workspace.
