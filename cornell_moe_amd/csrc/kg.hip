@@ -799,9 +799,14 @@ __global__ __launch_bounds__(64) void kg_sample_prep_generic_kernel(KgMcParams P
 template <int MB>
 __global__ __launch_bounds__(256) void kg_sample_weights_kernel(KgMcParams P, double* __restrict__ V, int samples_per_block,
                                                                int c_lo = 0, int first = 1, int last = 1) {
-  const int r = blockIdx.x * 256 + threadIdx.x;
+  // table entry t = (point j, slot a) <-> row r = j (1 + g) + a of the N training rows / the m fantasy rows; slots beyond the GP's
+  // 1 + g (r4: a streamed-weights instantiation with more derivative slots than observed derivatives) hold zeros
+  const int t = blockIdx.x * 256 + threadIdx.x;
   const int e = blockIdx.z;
   const int m = P.m, g1 = 1 + P.g;
+  const int pj = t / P.v_slots1, pa = t - pj * P.v_slots1;
+  const bool slot_ok = pa < g1;
+  const int r = slot_ok ? pj * g1 + pa : P.N + m;  // (an unused slot: behind everything, stored as 0)
   const double* __restrict__ We = P.W + (long)e * P.w_stride;
   const double* __restrict__ beta = P.beta;
   double l[MB];
@@ -823,17 +828,18 @@ __global__ __launch_bounds__(256) void kg_sample_weights_kernel(KgMcParams P, do
   for (int sl = s0; sl < s1; ++sl) {
     const long so = (long)e * P.num_local + sl;
     const double* __restrict__ bs = beta + so * m + c_lo;
-    double v = first ? kiy : V[so * P.v_stride + rr];
+    double v = first ? kiy : V[so * P.v_stride + min(t, (int)P.v_stride - 1)];
 #pragma unroll
     for (int c = 0; c < MB; ++c) v = fma(-l[c], bs[c], v);  // uniform, contiguous: wide scalar loads (reads up to MB - m
                                                             // doubles past the row: next rows / the zeroed pad, times l = 0)
+    if (t >= P.v_stride) continue;
     if (r < P.N) {
       if (last)
-        __builtin_nontemporal_store(v * scale, &V[so * P.v_stride + r]);  // (streaming: 1.28 GB at C5, read once by the MC kernel)
+        __builtin_nontemporal_store(v * scale, &V[so * P.v_stride + t]);  // (streaming: 1.28 GB at C5, read once by the MC kernel)
       else
-        V[so * P.v_stride + r] = v;
-    } else if (r < P.v_stride && last) {
-      V[so * P.v_stride + r] = fantasy ? beta[so * m + min(cf, m - 1)] * fscale : 0.0;
+        V[so * P.v_stride + t] = v;
+    } else if (last) {
+      V[so * P.v_stride + t] = fantasy ? beta[so * m + min(cf, m - 1)] * fscale : 0.0;
     }
   }
 }
@@ -1013,14 +1019,15 @@ KgPending kg_launch(GpDev& gp, int num_fidelity, const moe_gd_params_t& gd, cons
   // workgroup-per-sample kernel whenever the per-sample weight table (fantasy points and tile padding included) fits its cap and
   // every derivative slot is an observed derivative (a point's table rows ARE its weights)
   const int prep_mode = env_int("MOE_KG_PREP", -1);
-  const long v_stride_tiles = (long)ntiles * 64 * g1;
+  const long v_stride_tiles = (long)ntiles * 64 * (1 + G);  // (the table of the streamed-weights kernel: 1 + G slots per point)
   const double v_cap = std::getenv("MOE_KG_V_MAX_GB") ? (double)env_int("MOE_KG_V_MAX_GB", 4)
                                                       : (weight_table_gb >= 0.0 ? weight_table_gb : 4.0);
   // (the size test is per EVALUATION: which kernel an evaluation takes must not depend on the batch it shares a call with -- the
   //  callers size their batches with kg_max_batch, which budgets every evaluation's table)
   // (r4: 8 and 12 observed derivatives and m > 64 too -- the kernel itself needs neither m nor beta once the sample pre-pass and the
   //  weight table are there)
-  const bool stream_ok = g1 == 1 + G && prep_mode != 0 &&
+  // (r4: and any number of observed derivatives up to the slot count -- the table pads a point's weights to 1 + G)
+  const bool stream_ok = prep_mode != 0 &&
                          8.0 * (double)v_stride_tiles * (double)num_local / 1e9 <= v_cap;
   if (stream_ok && env_int("MOE_KG_STREAM_WEIGHTS", 1) != 0) {
     // (r3, ms of MC per evaluation, `profiles/r03_variant2_sweep.txt`: C5 7.9 -> 5.0; d = 12, g = 3, q = 8, M = 4000: n = 1200 1.24 -> 0.68 against the
@@ -1037,7 +1044,7 @@ KgPending kg_launch(GpDev& gp, int num_fidelity, const moe_gd_params_t& gd, cons
   {
     const int forced = env_int("MOE_KG_VARIANT", variant);
     if (forced == 2 && !stream_ok)
-      throw Error(MOE_ERR_RUNTIME, "the streamed-weights MC kernel needs the weight table within its cap and every derivative slot observed");
+      throw Error(MOE_ERR_RUNTIME, "the streamed-weights MC kernel needs the weight table within its cap");
     // (shapes the LDS-slab wave-per-sample kernel is not built for keep to the other two)
     if (!(forced == 0 && (G > 4 || m > kMaxM))) variant = forced;
   }
@@ -1333,6 +1340,7 @@ KgPending kg_launch(GpDev& gp, int num_fidelity, const moe_gd_params_t& gd, cons
     MOE_HIP_CHECK(hipGetLastError());
   }
   mp.v_stride = (variant == 2) ? v_stride_tiles : N;
+  mp.v_slots1 = (variant == 2) ? 1 + G : g1;
   if (variant >= 1 && mp.best_j != nullptr) {
     const long total = (long)E * num_local;
     // the weight table: N doubles per sample (1.28 GB per evaluation at C5); beyond its cap -- the caller's share of the
@@ -1340,7 +1348,7 @@ KgPending kg_launch(GpDev& gp, int num_fidelity, const moe_gd_params_t& gd, cons
     // compute their weights in the kernel (workgroup-per-sample kernel only: the streamed-weights one is not chosen beyond the cap)
     const double v_gb = 8.0 * (double)mp.v_stride * (double)num_local / 1e9;  // (per evaluation, as above)
     if (v_gb <= v_cap) {  // (m > 64: the table kernel takes the columns of W 64 at a time, r4)
-      gp.kV.reserve((size_t)mp.v_stride * (size_t)total + (size_t)64 * g1);  // (+ one tile: the sweeps prefetch one tile ahead)
+      gp.kV.reserve((size_t)mp.v_stride * (size_t)total + (size_t)64 * mp.v_slots1);  // (+ one tile: the sweeps prefetch one tile ahead)
       MOE_HIP_CHECK(hipMemsetAsync(dBeta.p + (size_t)total * m, 0, sizeof(double) * 64, s));
       mp.V = gp.kV.p;
       launch_sample_weights(mp, gp.kV.p, s);
@@ -1575,7 +1583,8 @@ int kg_max_batch(const GpDev& gp, int P, int q, int p, int num_local, bool want_
   // the per-sample weight table of the workgroup-per-sample / streamed-weights kernels (the latter: whole tiles, fantasy points included)
   // (always: whether an evaluation takes one of those kernels is decided per evaluation in kg_launch -- far frames send small
   //  q-KG shapes there too -- and the batch must fit whatever it decides)
-  doubles += (N + (u + 64.0) * g1) * (double)num_local;
+  const double slots1 = gp.g <= 4 ? g1 : (gp.g <= 8 ? 9.0 : 13.0);  // (the streamed-weights table pads a point's weights to 1 + G)
+  doubles += (gp.n + u + 64.0) * slots1 * (double)num_local;
   const double per_eval_gb = 8.0 * doubles / 1e9;
   return (int)std::max(1.0, std::floor(budget_gb / std::max(per_eval_gb, 1e-9)));
 }

@@ -99,8 +99,10 @@ struct KgMcParams {
   unsigned int* next_sample;     // [E] work counters (zeroed before launch)
   unsigned long long* prof;      // 16 spare words behind the counters (MOE_BLOCK_PROF builds)
   const double* V;               // [E][num_local][v_stride] per-sample weights alpha-scaled (kg_sample_weights_kernel, kg.hip), or NULL
-  long v_stride;                 // N (workgroup-per-sample kernel) or ntiles * 64 * (1 + g): the fantasy points' weights and the zero
+  long v_stride;                 // N (workgroup-per-sample kernel) or ntiles * 64 * v_slots1: the fantasy points' weights and the zero
                                  // padding included (streamed-weights kernel, kg_mc_stream_kernel)
+  int v_slots1;                  // weights per point in the table: 1 + g, or 1 + G of the streamed-weights instantiation when it has
+                                 // more derivative slots than the GP observes (g = 5 .. 7 -> 8, 9 .. 11 -> 12: the extra slots hold 0)
   const int* best_j;             // [E][num_local] start point of every sample's line search, precomputed with beta by
                                  // kg_sample_prep_kernel (kg.hip); NULL = each sample computes them itself
 };
