@@ -776,10 +776,10 @@ namespace {
 // stores the partial product to work[sl]; tri_splitk_sum_kernel adds the partials of a row in ascending slice order.  KS depends on N
 // alone, so an entry's summation order does not depend on how many columns (evaluations) share the call.
 // MODE 1: C = T B (T lower: row tile r needs k < (r + 1) 64).  MODE 2: C = T^T B (k >= r 64).
-template <int MODE>
+template <int MODE, int TK = 16>
 __global__ __launch_bounds__(256) void tri_splitk_kernel(int N, int c, int KS, const double* __restrict__ T, long ldt,
                                                         const double* __restrict__ B, long ldb, double* __restrict__ work) {
-  constexpr int TM = 64, TK = 16, LD = 65;
+  constexpr int TM = 64, LD = 65;
   constexpr int NF = TM * TK / 256;
   __shared__ double As[TK][LD];
   __shared__ double Bs[TK][LD];
@@ -899,11 +899,21 @@ void launch_tri_gemm_cols(char op, int N, int c, int cols_per_problem, const dou
   const int slices = tri_cols_slices(N, &KS);
   const dim3 grid((c + 63) / 64, (N + 63) / 64, slices);
   const dim3 sgrid((N + 255) / 256, c);
+  static const int tk = [] {
+    const char* v = std::getenv("MOE_TRI_SPLITK_TK");
+    return (v && *v) ? std::atoi(v) : 16;
+  }();
   if (op == 'N') {
-    hipLaunchKernelGGL(tri_splitk_kernel<1>, grid, dim3(256), 0, s, N, c, KS, T, ldt, B, ldb, work);
+    if (tk == 32)
+      hipLaunchKernelGGL((tri_splitk_kernel<1, 32>), grid, dim3(256), 0, s, N, c, KS, T, ldt, B, ldb, work);
+    else
+      hipLaunchKernelGGL((tri_splitk_kernel<1, 16>), grid, dim3(256), 0, s, N, c, KS, T, ldt, B, ldb, work);
     hipLaunchKernelGGL(tri_splitk_sum_kernel<1>, sgrid, dim3(256), 0, s, N, c, KS, slices, (const double*)work, C, ldc);
   } else {
-    hipLaunchKernelGGL(tri_splitk_kernel<2>, grid, dim3(256), 0, s, N, c, KS, T, ldt, B, ldb, work);
+    if (tk == 32)
+      hipLaunchKernelGGL((tri_splitk_kernel<2, 32>), grid, dim3(256), 0, s, N, c, KS, T, ldt, B, ldb, work);
+    else
+      hipLaunchKernelGGL((tri_splitk_kernel<2, 16>), grid, dim3(256), 0, s, N, c, KS, T, ldt, B, ldb, work);
     hipLaunchKernelGGL(tri_splitk_sum_kernel<2>, sgrid, dim3(256), 0, s, N, c, KS, slices, (const double*)work, C, ldc);
   }
   MOE_HIP_CHECK(hipGetLastError());

@@ -279,38 +279,12 @@ void launch_gtb(const KgTailParams& P, hipStream_t s) {
   hipLaunchKernelGGL(kg_gtb_kernel, dim3(P.ngrad, P.E), dim3(256), 0, s, P, (const double*)KinvTB);
 }
 
-// ZC[e][r + j m] = sum_i z_i[r] c_i[j]; workgroup (r, j, e); the (0, 0) workgroup also forms
-// kg_sum = sum_i (best_posterior + best_value_i)   (.cpp:196).
-__global__ __launch_bounds__(256) void kg_zc_kernel(KgTailParams P) {
-  __shared__ double red[4];
-  const int r = blockIdx.x, j = blockIdx.y, e = blockIdx.z;
-  const int m = P.m;
-  double* out = P.out + (long)e * P.out_stride;
-  {
-    double acc = 0.0;
-#pragma unroll 8
-    for (int i = threadIdx.x; i < P.num_local; i += 256) {
-      const int s = P.first_sample + i;
-      const double z = ((s & 1) ? -1.0 : 1.0) * P.normals[(long)(s >> 1) * m + r];
-      acc = fma(z, P.C[((long)e * P.num_local + i) * m + j], acc);
-    }
-    const double tot = block_sum_256(acc, red);
-    if (threadIdx.x == 0) out[1 + r + j * m] = tot;
-  }
-  if (r == 0 && j == 0) {
-    const double bp = P.blob[(long)e * P.rec.stride + P.rec_bp];
-    double acc = 0.0;
-    for (int i = threadIdx.x; i < P.num_local; i += 256) acc += bp + P.best_value[(long)e * P.num_local + i];
-    const double tot = block_sum_256(acc, red);
-    if (threadIdx.x == 0) out[0] = tot;
-  }
-}
-
-// The same sums for m <= 64 without the strided sample walk (one workgroup per (r, j) reading c_i[j] every m doubles: 254 us for two
+// ZC[e][r + j m] = sum_i z_i[r] c_i[j] and kg_sum = sum_i (best_posterior + best_value_i)   (.cpp:196).
+// Without a strided sample walk (round 1: one workgroup per (r, j) reading c_i[j] every m doubles: 254 us for two
 // C5 evaluations): a workgroup takes a chunk of kZcChunk samples, stages their z and c rows in LDS with coalesced loads and forms all
 // m x m partial products; kg_zc_sum_kernel adds the chunk partials in chunk order and forms kg_sum exactly as kg_sum_kernel does.
 constexpr int kZcChunk = 64;  // samples per chunk (32 for m > 32: the two staged blocks stay within 32 KB)
-inline int zc_chunk_len(int m) { return m > 32 ? kZcChunk / 2 : kZcChunk; }
+inline int zc_chunk_len(int m) { return m > 32 ? kZcChunk / 2 : kZcChunk; }  // (r4: m > 64 too -- 2 x 32 x 128 doubles: 64 KB, opted in)
 __global__ __launch_bounds__(256) void kg_zc_part_kernel(KgTailParams P, double* __restrict__ part, int chunks, int len) {
   extern __shared__ __attribute__((aligned(16))) double zc_sm[];  // z [len][m] | c [len][m]
   const int chunk = blockIdx.x, e = blockIdx.y, m = P.m;
@@ -365,6 +339,8 @@ void launch_zc(const KgTailParams& P, double* part, hipStream_t s) {
   const int len = zc_chunk_len(P.m);
   const int chunks = (P.num_local + len - 1) / len;
   const size_t shm = sizeof(double) * 2 * len * P.m;
+  if (shm > 48 * 1024)
+    MOE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kg_zc_part_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
   hipLaunchKernelGGL(kg_zc_part_kernel, dim3(chunks, P.E), dim3(256), shm, s, P, part, chunks, len);
   int gs = 1;
   while (gs < 64 && P.m * P.m * gs * 2 <= 256) gs *= 2;
@@ -693,7 +669,7 @@ void launch_fused_tail(const KgTailParams& P, const double* X, int n, double* SW
   }
 }
 
-// value-only finish: kg_sum per evaluation (same summation as the r == 0 workgroup of kg_zc_kernel)
+// value-only finish: kg_sum per evaluation (same summation as block 0 of kg_zc_sum_kernel)
 __global__ __launch_bounds__(256) void kg_sum_kernel(KgTailParams P, double* __restrict__ fin, const unsigned long long* __restrict__ counters,
                                                      const int* __restrict__ flags) {
   __shared__ double red[4];
@@ -1416,12 +1392,9 @@ KgPending kg_launch(GpDev& gp, int num_fidelity, const moe_gd_params_t& gd, cons
     const int slices = fused_tail_slices(E, num_local, n, num_cu);
     gp.kSW.reserve((size_t)E * num_local * slices * 8);  // [E][num_local][slices][MU <= 8]
     launch_fused_tail(tl, gp.dX.p, n, gp.kSW.p, slices, s);
-    if (m <= 64) {
-      gp.kZcPart.reserve((size_t)E * ((num_local + zc_chunk_len(m) - 1) / zc_chunk_len(m)) * m * m);
-      launch_zc(tl, gp.kZcPart.p, s);
-    } else {
-      hipLaunchKernelGGL(kg_zc_kernel, dim3(m, m, E), dim3(256), 0, s, tl);
-    }
+    // (r4: m > 64 too -- one workgroup per entry of ZC walking every sample with a stride of m doubles took 1.8 ms per evaluation at m = 104)
+    gp.kZcPart.reserve((size_t)E * ((num_local + zc_chunk_len(m) - 1) / zc_chunk_len(m)) * m * m);
+    launch_zc(tl, gp.kZcPart.p, s);
   } else if (want_grad) {
     t_cov.start(s);
     launch_cov_build(gp.cp, gp.dX.p, n, gp.derivs, dBestPoint.p, E * num_local, none, nullptr, dT.p, N, 0, s, true);
@@ -1445,12 +1418,9 @@ KgPending kg_launch(GpDev& gp, int num_fidelity, const moe_gd_params_t& gd, cons
       tl.SW = gp.kSW.p;
     }
     launch_tail(tl, s);
-    if (m <= 64) {
-      gp.kZcPart.reserve((size_t)E * ((num_local + zc_chunk_len(m) - 1) / zc_chunk_len(m)) * m * m);
-      launch_zc(tl, gp.kZcPart.p, s);
-    } else {
-      hipLaunchKernelGGL(kg_zc_kernel, dim3(m, m, E), dim3(256), 0, s, tl);
-    }
+    // (r4: m > 64 too -- one workgroup per entry of ZC walking every sample with a stride of m doubles took 1.8 ms per evaluation at m = 104)
+    gp.kZcPart.reserve((size_t)E * ((num_local + zc_chunk_len(m) - 1) / zc_chunk_len(m)) * m * m);
+    launch_zc(tl, gp.kZcPart.p, s);
   } else {
     hipLaunchKernelGGL(kg_sum_kernel, dim3(E), dim3(256), 0, s, tl, dFin, (const unsigned long long*)dCounters.p, (const int*)gp.kStateI.p);
   }
