@@ -20,19 +20,10 @@ numpy restatement of the same algorithm lives with the tests (tests/ms_restateme
 import numpy as np
 
 
-
-
-
-
-
 def _gd(params):
     p = params.optimizer_parameters
     return (int(p.num_multistarts), int(p.max_num_steps), int(p.max_num_restarts), int(p.num_steps_averaged), float(p.gamma),
             float(p.pre_mult), float(p.max_relative_change), float(p.tolerance))
-
-
-
-
 
 
 def kg_optimal_points(dev_gp, num_fidelity, optimizer_parameters, optimizer_parameters_inner, bounds, discrete, Xp,
