@@ -50,6 +50,24 @@ class DomainTypes(object):
     simplex = _Enum("DomainTypes.simplex", 1)
 
 
+def _check_domain_type(optimizer_parameters, kg=False):
+    """The dispatch of gpp_python_knowledge_gradient.cpp:288-296 / gpp_python_expected_improvement.cpp:262-271: tensor product or its
+    intersection with the unit simplex; anything else is the reference's "invalid domain choice".  The EI optimisers take both (r4).
+    For KG the reference builds the INNER domain of every sample's posterior-mean optimisation as a simplex intersection too; the
+    device's MC kernels run that optimisation over a tensor product only, so KG over the simplex is refused rather than optimised
+    over the wrong set."""
+    if int(optimizer_parameters.domain_type) not in (int(DomainTypes.tensor_product), int(DomainTypes.simplex)):
+        raise OptimalLearningException("ERROR: invalid domain choice. Setting all coordinates to 0.0.")
+    if kg and int(optimizer_parameters.domain_type) != int(DomainTypes.tensor_product):
+        raise OptimalLearningException("knowledge gradient over DomainTypes.simplex is not implemented on the device path "
+                                       "(the inner optimisation would have to run over the simplex as well)")
+
+
+def _domain_name(optimizer_parameters):
+    """DomainType::kName (gpp_domain.hpp:76, 229): part of the status keys the wrappers fill."""
+    return "simplex_tensor_product" if int(optimizer_parameters.domain_type) == int(DomainTypes.simplex) else "tensor_product"
+
+
 class LogLikelihoodTypes(object):
     log_marginal_likelihood = _Enum("LogLikelihoodTypes.log_marginal_likelihood", 0)
     leave_one_out_log_likelihood = _Enum("LogLikelihoodTypes.leave_one_out_log_likelihood", 1)
@@ -352,8 +370,7 @@ def multistart_expected_improvement_optimization(optimizer_parameters, gaussian_
     if max_num_threads > randomness_source.num_normal_rng:
         raise BoundsException("Fewer randomness_sources than max_num_threads.", randomness_source.num_normal_rng,
                               max_num_threads, 1e9)
-    if int(optimizer_parameters.domain_type) != int(DomainTypes.tensor_product):
-        raise OptimalLearningException("only the tensor-product domain is implemented on the device path")
+    _check_domain_type(optimizer_parameters)
     if int(optimizer_parameters.optimizer_type) not in (int(OptimizerTypes.null), int(OptimizerTypes.gradient_descent)):
         raise OptimalLearningException("ERROR: invalid optimizer choice. Setting all coordinates to 0.0.")
     gp = gaussian_process
@@ -361,7 +378,7 @@ def multistart_expected_improvement_optimization(optimizer_parameters, gaussian_
     best, found = multistart.ei_optimal_points(gp._dev, optimizer_parameters, _flat(domain_bounds, 2 * gp.dim), Xp,
                                                int(num_to_sample), float(best_so_far), int(max_int_steps), randomness_source)
     kind = "gradient_descent" if int(optimizer_parameters.optimizer_type) == int(OptimizerTypes.gradient_descent) else "lhc"
-    status["%s_tensor_product_domain_found_update" % kind] = bool(found)
+    status["%s_%s_domain_found_update" % (kind, _domain_name(optimizer_parameters))] = bool(found)
     return list(np.asarray(best).ravel())
 
 
@@ -436,8 +453,7 @@ def multistart_knowledge_gradient_optimization(optimizer_parameters, optimizer_p
     if max_num_threads > randomness_source.num_normal_rng:
         raise BoundsException("Fewer randomness_sources than max_num_threads.", randomness_source.num_normal_rng,
                               max_num_threads, 1e9)
-    if int(optimizer_parameters.domain_type) != int(DomainTypes.tensor_product):
-        raise OptimalLearningException("only the tensor-product domain is implemented on the device path")
+    _check_domain_type(optimizer_parameters, kg=True)
     gp = gaussian_process
     size = gp.dim - num_fidelity
     discrete = _flat(discrete_pts, size * num_pts).reshape(num_pts, size)
@@ -447,7 +463,7 @@ def multistart_knowledge_gradient_optimization(optimizer_parameters, optimizer_p
         gp._dev, int(num_fidelity), optimizer_parameters, optimizer_parameters_inner, bounds, discrete, Xp,
         int(num_to_sample), float(best_so_far), int(max_int_steps), randomness_source)
     kind = "gradient_descent" if int(optimizer_parameters.optimizer_type) == int(OptimizerTypes.gradient_descent) else "lhc"
-    status["%s_tensor_product_domain_found_update" % kind] = bool(found)
+    status["%s_%s_domain_found_update" % (kind, _domain_name(optimizer_parameters))] = bool(found)
     return list(np.asarray(best).ravel())
 
 
@@ -455,8 +471,7 @@ def posterior_mean_optimization(gaussian_process, num_fidelity, optimizer_parame
     """ComputeOptimalPosteriorMeanWrapper (gpp_python_knowledge_gradient.cpp:315-342): line-search descent on the posterior
     mean from one initial guess; returns the best point (dim - num_fidelity coordinates)."""
     from . import multistart
-    if int(optimizer_parameters.domain_type) != int(DomainTypes.tensor_product):
-        raise OptimalLearningException("only the tensor-product domain is implemented on the device path")
+    _check_domain_type(optimizer_parameters, kg=True)
     best, _ = multistart.posterior_mean_optimization(gaussian_process._dev, int(num_fidelity), optimizer_parameters,
                                                      _flat(domain_bounds), _flat(initial_guess))
     return list(best)
@@ -528,8 +543,7 @@ def multistart_knowledge_gradient_mcmc_optimization(optimizer_parameters, optimi
     if max_num_threads > randomness_source.num_normal_rng:
         raise BoundsException("Fewer randomness_sources than max_num_threads.", randomness_source.num_normal_rng,
                               max_num_threads, 1e9)
-    if int(optimizer_parameters.domain_type) != int(DomainTypes.tensor_product):
-        raise OptimalLearningException("only the tensor-product domain is implemented on the device path")
+    _check_domain_type(optimizer_parameters, kg=True)
     gp = gaussian_process_mcmc
     size = gp.dim - num_fidelity
     discrete = _flat(discrete_pts, gp.num_mcmc * num_pts * size).reshape(gp.num_mcmc, num_pts, size)
@@ -538,7 +552,7 @@ def multistart_knowledge_gradient_mcmc_optimization(optimizer_parameters, optimi
         gp._dev, int(num_fidelity), optimizer_parameters, optimizer_parameters_inner, _flat(domain_bounds, 2 * gp.dim), discrete,
         Xp, int(num_to_sample), _flat(best_so_far, gp.num_mcmc), int(max_int_steps), randomness_source)
     kind = "gradient_descent" if int(optimizer_parameters.optimizer_type) == int(OptimizerTypes.gradient_descent) else "lhc"
-    status["%s_tensor_product_domain_found_update" % kind] = bool(found)
+    status["%s_%s_domain_found_update" % (kind, _domain_name(optimizer_parameters))] = bool(found)
     return list(np.asarray(best).ravel())
 
 
@@ -600,15 +614,14 @@ def multistart_expected_improvement_mcmc_optimization(optimizer_parameters, gaus
     if max_num_threads > randomness_source.num_normal_rng:
         raise BoundsException("Fewer randomness_sources than max_num_threads.", randomness_source.num_normal_rng,
                               max_num_threads, 1e9)
-    if int(optimizer_parameters.domain_type) != int(DomainTypes.tensor_product):
-        raise OptimalLearningException("only the tensor-product domain is implemented on the device path")
+    _check_domain_type(optimizer_parameters)
     gp = gaussian_process_mcmc
     Xp = _being_sampled(gp, points_being_sampled, num_being_sampled)
     best, found = multistart.ei_mcmc_optimal_points(gp._dev, optimizer_parameters, _flat(domain_bounds, 2 * gp.dim), Xp,
                                                     int(num_to_sample), _flat(best_so_far, gp.num_mcmc), int(max_int_steps),
                                                     randomness_source)
     kind = "gradient_descent" if int(optimizer_parameters.optimizer_type) == int(OptimizerTypes.gradient_descent) else "lhc"
-    status["%s_tensor_product_domain_found_update" % kind] = bool(found)
+    status["%s_%s_domain_found_update" % (kind, _domain_name(optimizer_parameters))] = bool(found)
     return list(np.asarray(best).ravel())
 
 

@@ -19,7 +19,7 @@ class MoeError(C.Structure):
 class GdParams(C.Structure):
     _fields_ = [("num_multistarts", C.c_int), ("max_num_steps", C.c_int), ("max_num_restarts", C.c_int),
                 ("num_steps_averaged", C.c_int), ("gamma", C.c_double), ("pre_mult", C.c_double),
-                ("max_relative_change", C.c_double), ("tolerance", C.c_double)]
+                ("max_relative_change", C.c_double), ("tolerance", C.c_double), ("domain_type", C.c_int)]
 
 
 class KgStats(C.Structure):

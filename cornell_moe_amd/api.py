@@ -350,6 +350,7 @@ class DeviceGP(object):
         g = _lib.GdParams()
         (g.num_multistarts, g.max_num_steps, g.max_num_restarts, g.num_steps_averaged) = [int(v) for v in params[:4]]
         (g.gamma, g.pre_mult, g.max_relative_change, g.tolerance) = [float(v) for v in params[4:8]]
+        g.domain_type = int(params[8]) if len(params) > 8 else 0   # (outer optimisers: 1 = simplex intersection, moe_hip.h)
         return g
 
     def kg(self, inner_params, bounds, discrete, Xq, Xp, num_mc, best_so_far, normals, want_grad=True, num_fidelity=0,

@@ -1,6 +1,7 @@
 // cornell_moe_amd/csrc/kg.hpp -- Monte-Carlo acquisition evaluators (q-EI, q-KG) on the device GP.
 #pragma once
 #include <functional>
+#include <memory>
 #include <vector>
 
 #include "gp.hpp"
@@ -59,6 +60,21 @@ void set_reference_quirks(int on);  // < 0: back to the environment's setting
 struct BatchObjective {
   std::function<void(const double* x_all, int n, double* values)> values;
   std::function<void(const double* x_all, int n, double* grads)> grads;
+};
+// RepeatedDomain<DomainType>::LimitUpdate of the outer optimisers (gpp_domain.hpp:509-520): bounds[2 d] apply to each of the qd / d
+// points; outer.domain_type selects TensorProductDomain::LimitUpdate (gpp_domain.cpp:64-105) or
+// SimplexIntersectTensorProductDomain::LimitUpdate (:234-290; the constructor's clipping to the unit hypercube and its emptiness
+// test included: MOE_ERR_BOUNDS).  step is limited in place.
+struct DomainLimiter {
+  DomainLimiter(const moe_gd_params_t& outer, const double* bounds, int d);
+  ~DomainLimiter();
+  void apply(double max_relative_change, const double* x, double* step, int qd) const;
+
+ private:
+  struct Impl;
+  int d;
+  const double* bounds;
+  std::unique_ptr<Impl> impl;
 };
 // MultistartOptimizer over a batched objective: see multistart.hip.  bounds[2*d] apply to each of the qd/d points.
 void multistart(const BatchObjective& f, const moe_gd_params_t& outer, const double* bounds, int d, int qd, const double* starts,

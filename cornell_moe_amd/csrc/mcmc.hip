@@ -175,6 +175,9 @@ void kg_mcmc_multistart(const std::vector<GpDev*>& gps, int num_fidelity, const 
                         const double* starts, int num_starts, const double* Xp, int q, int p, int num_mc,
                         const double* best_so_far, const double* normals, int do_gradient_ascent, double* best_points,
                         double* best_kg, int* found) {
+  if (outer.domain_type != MOE_DOMAIN_TENSOR_PRODUCT)
+    throw Error(MOE_ERR_INVALID_VALUE, "KG over the simplex domain is not implemented (see kg_multistart); the EI optimisers take it",
+                outer.domain_type, 0, 0);
   check_ensemble(gps);
   if (num_starts <= 0) throw Error(MOE_ERR_BOUNDS, "num_multistarts must be > 1", num_starts, 1, 1e9);
   const int d = gps[0]->d, qd = q * d, nm = (int)gps.size();
@@ -233,6 +236,7 @@ void kg_mcmc_multistart(const std::vector<GpDev*>& gps, int num_fidelity, const 
   std::vector<double> end_vals(S);
   if (do_gradient_ascent && outer.max_num_restarts > 0) {
     const double step_tol = outer.tolerance / (double)outer.max_num_steps;
+    const DomainLimiter limiter(outer, bounds, d);
     std::vector<char> alive(S, 1), running(S);
     std::vector<double> cur((size_t)S * qd), nxt((size_t)S * qd), G((size_t)S * qd), xs((size_t)S * qd), ks(S), gs((size_t)S * qd),
         gcost(qd), step(qd);
@@ -260,10 +264,10 @@ void kg_mcmc_multistart(const std::vector<GpDev*>& gps, int num_fidelity, const 
           const double mean_kg = ks[k] / (double)nm;
           for (int j = 0; j < qd; ++j) {
             Gs[j] = ((Gs[j] + gs[k * qd + j]) / (double)nm * cost - mean_kg * gcost[j]) / (cost * cost);
-            const int dd = j % d;
-            step[j] = limit_update_coord(bounds[2 * dd], bounds[2 * dd + 1], outer.max_relative_change, ns[j], alpha * Gs[j]);
-            ns[j] += step[j];
+            step[j] = alpha * Gs[j];
           }
+          limiter.apply(outer.max_relative_change, ns, step.data(), qd);
+          for (int j = 0; j < qd; ++j) ns[j] += step[j];
           std::copy(ns, ns + qd, &actual[(size_t)s * qd]);  // SetCurrentPoint: the per-GP states follow all q points ...
           seen_of(ns, &seen_all[(size_t)s * qd]);            // ... the MCMC state only the first
           double n2 = 0.0;

@@ -14,6 +14,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <functional>
+#include <memory>
 #include <numeric>
 #include <queue>
 #include <random>
@@ -60,7 +61,109 @@ double norm2(const double* v, int n) {
   return std::sqrt(s);
 }
 
+// VectorNorm (gpp_linear_algebra.cpp:53-72): the scaled, overflow-safe recurrence -- the simplex update divides by it, so it is
+// restated operation for operation.
+double vector_norm_scaled(const double* v, int n) {
+  if (n == 1) return std::fabs(v[0]);
+  double scale = 0.0, scaled = 1.0;
+  for (int i = 0; i < n; ++i) {
+    if (v[i] != 0.0) {
+      const double a = std::fabs(v[i]);
+      if (scale < a) {
+        const double t = scale / a;
+        scaled = 1.0 + scaled * (t * t);
+        scale = a;
+      } else {
+        const double t = a / scale;
+        scaled += t * t;
+      }
+    }
+  }
+  return scale * std::sqrt(scaled);
+}
+
+// CheckPointInUnitSimplex (gpp_geometry.hpp:313-325)
+bool in_unit_simplex(const double* pt, int d) {
+  double sum = 0.0;
+  for (int i = 0; i < d; ++i) {
+    if (pt[i] < 0.0) return false;
+    sum += pt[i];
+  }
+  return (sum - 4.0 * 2.220446049250313e-16) <= 1.0;
+}
+
+// SimplexIntersectTensorProductDomain (gpp_domain.hpp:215-349, gpp_domain.cpp:107-141): the box clipped to the unit hypercube, the
+// emptiness test of its constructor, and its LimitUpdate (:234-290) on ONE point -- the tensor-product limit first, then, if the
+// proposed point leaves the simplex, half the distance to the diagonal face along the (limited) direction.
+struct SimplexDomain {
+  int d;
+  std::vector<double> box;  // clipped bounds
+  double inv_sqrt_d;
+  SimplexDomain(const double* bounds, int dim) : d(dim), box(2 * (size_t)dim), inv_sqrt_d(1.0 / std::sqrt((double)dim)) {
+    double corner_sum = 0.0;
+    bool empty = false;
+    for (int i = 0; i < d; ++i) {
+      box[2 * i] = std::fmax(bounds[2 * i], 0.0);
+      box[2 * i + 1] = std::fmin(bounds[2 * i + 1], 1.0);
+      empty = empty || box[2 * i] > box[2 * i + 1];
+      corner_sum += box[2 * i];
+    }
+    if (corner_sum >= 1.0 || empty)
+      throw Error(MOE_ERR_BOUNDS,
+                  "Simplex/Tensor product intersection is EMPTY; 'lower left' corner coordinate sum out of bounds or bounding "
+                  "boxes do not intersect.",
+                  corner_sum, 0.0, 1.0);
+  }
+  void limit_update(double max_relative_change, const double* x, double* step) const {
+    if (max_relative_change == 1.0) max_relative_change -= 4.0 * 2.220446049250313e-16;  // kRelativeChangeEpsilonTweak
+    for (int j = 0; j < d; ++j) step[j] = limit_update_1d(box[2 * j], box[2 * j + 1], max_relative_change, x[j], step[j]);
+    double norm = vector_norm_scaled(step, d);
+    if (norm == 0.0) norm = 2.2250738585072014e-308;
+    std::vector<double> dir(d), next(d);
+    for (int j = 0; j < d; ++j) {
+      dir[j] = step[j] / norm;
+      next[j] = x[j] + step[j];
+    }
+    if (!in_unit_simplex(next.data(), d)) {
+      // Plane::DistanceToPlaneAlongVector (gpp_geometry.hpp:252-272) for the plane -1/sqrt(d) + sum x_i / sqrt(d) = 0
+      double xn = 0.0, vn = 0.0;
+      for (int j = 0; j < d; ++j) {
+        xn += x[j] * inv_sqrt_d;
+        vn += dir[j] * inv_sqrt_d;
+      }
+      const double numerator = inv_sqrt_d - xn;  // -offset - x . n, offset = -1/sqrt(d)
+      double dist = (vn == 0.0) ? (numerator == 0.0 ? 0.0 : INFINITY) : numerator / vn;
+      if (dist < 0.0) dist = 0.0;
+      const double relaxed = 0.5 * dist;  // kInvalidStepScaleFactor
+      for (int j = 0; j < d; ++j) step[j] = relaxed * dir[j];
+    }
+  }
+};
+
 }  // namespace
+
+struct DomainLimiter::Impl {
+  std::unique_ptr<SimplexDomain> simplex;
+};
+
+DomainLimiter::DomainLimiter(const moe_gd_params_t& outer, const double* bounds_in, int dim) : d(dim), bounds(bounds_in), impl(new Impl) {
+  if (outer.domain_type == MOE_DOMAIN_SIMPLEX)
+    impl->simplex.reset(new SimplexDomain(bounds, d));
+  else if (outer.domain_type != MOE_DOMAIN_TENSOR_PRODUCT)
+    throw Error(MOE_ERR_INVALID_VALUE, "unknown domain_type (0 = tensor product, 1 = simplex)", outer.domain_type, 0, 1);
+}
+DomainLimiter::~DomainLimiter() = default;
+
+void DomainLimiter::apply(double max_relative_change, const double* x, double* step, int qd) const {
+  if (impl->simplex) {
+    for (int pt = 0; pt < qd / d; ++pt) impl->simplex->limit_update(max_relative_change, x + (size_t)pt * d, step + (size_t)pt * d);
+  } else {
+    for (int j = 0; j < qd; ++j) {
+      const int dd = j % d;
+      step[j] = limit_update_1d(bounds[2 * dd], bounds[2 * dd + 1], max_relative_change, x[j], step[j]);
+    }
+  }
+}
 
 void latin_hypercube(unsigned int seed, const double* bounds, int dim, int num_points, double* out) {
   std::mt19937 eng(seed);
@@ -92,6 +195,8 @@ void gradient_ascent(const BatchObjective& f, const moe_gd_params_t& outer, cons
                      int S) {
   if (outer.max_num_restarts <= 0 || S <= 0) return;
   const double step_tol = outer.tolerance / (double)outer.max_num_steps;
+  // (r4) RepeatedDomain<DomainType>::LimitUpdate: the tensor-product or simplex update, point by point (gpp_domain.hpp:509-520)
+  const DomainLimiter limiter(outer, bounds, d);
   std::vector<char> alive(S, 1), running(S);
   std::vector<double> x_begin((size_t)S * qd), xs((size_t)S * qd), grad((size_t)S * qd), step(qd);
   std::vector<int> idx;
@@ -109,11 +214,9 @@ void gradient_ascent(const BatchObjective& f, const moe_gd_params_t& outer, cons
       f.grads(xs.data(), (int)idx.size(), grad.data());
       for (size_t k = 0; k < idx.size(); ++k) {
         double* xk = x + (size_t)idx[k] * qd;
-        for (int j = 0; j < qd; ++j) {
-          const int dd = j % d;
-          step[j] = limit_update_1d(bounds[2 * dd], bounds[2 * dd + 1], outer.max_relative_change, xk[j], alpha * grad[k * qd + j]);
-          xk[j] += step[j];
-        }
+        for (int j = 0; j < qd; ++j) step[j] = alpha * grad[k * qd + j];
+        limiter.apply(outer.max_relative_change, xk, step.data(), qd);
+        for (int j = 0; j < qd; ++j) xk[j] += step[j];
         if (norm2(step.data(), qd) < step_tol) running[idx[k]] = 0;
       }
     }
@@ -192,6 +295,11 @@ void kg_multistart(GpDev& gp, int num_fidelity, const moe_gd_params_t& outer, co
                    int num_mc, double best_so_far, const double* normals, int do_gradient_ascent, double* best_points,
                    double* best_kg, int* found) {
   const int d = gp.d, qd = q * d;
+  if (outer.domain_type != MOE_DOMAIN_TENSOR_PRODUCT)
+    throw Error(MOE_ERR_INVALID_VALUE,
+                "KG over the simplex domain is not implemented: the reference then runs every sample's INNER optimisation over the "
+                "simplex as well (gpp_python_knowledge_gradient.cpp:288-296); the EI optimisers take it",
+                outer.domain_type, 0, 0);
   // The reference builds its evaluation states at the FIRST start and moves them with SetCurrentPoint, which leaves the
   // discretised set behind (kg.hpp: disc_head): every evaluation of the run scores / starts its inner optimisation from the
   // first start's q points.  Reproduced: the end point is pinned to the reference's (tests/golden/ref_kg_multistart.npz).

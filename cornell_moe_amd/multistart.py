@@ -20,10 +20,63 @@ numpy restatement of the same algorithm lives with the tests (tests/ms_restateme
 import numpy as np
 
 
-def _gd(params):
+def _gd(params, domain_type=0):
     p = params.optimizer_parameters
     return (int(p.num_multistarts), int(p.max_num_steps), int(p.max_num_restarts), int(p.num_steps_averaged), float(p.gamma),
-            float(p.pre_mult), float(p.max_relative_change), float(p.tolerance))
+            float(p.pre_mult), float(p.max_relative_change), float(p.tolerance), int(domain_type))
+
+
+def _domain_type(optimizer_parameters):
+    """0 = tensor product, 1 = simplex intersection (GPP.DomainTypes; the dispatch of gpp_python_knowledge_gradient.cpp:288-296)."""
+    return int(getattr(optimizer_parameters, "domain_type", 0))
+
+
+def _simplex_box(bounds, d):
+    """SimplexIntersectTensorProductDomain's constructor (gpp_domain.cpp:107-141): the box clipped to the unit hypercube."""
+    b = np.asarray(bounds, dtype=np.float64).reshape(d, 2).copy()
+    b[:, 0] = np.maximum(b[:, 0], 0.0)
+    b[:, 1] = np.minimum(b[:, 1], 1.0)
+    return b.reshape(-1)
+
+
+def _in_unit_simplex(pts):
+    """CheckPointInUnitSimplex (gpp_geometry.hpp:313-325), rows of pts."""
+    return np.all(pts >= 0.0, axis=1) & (pts.sum(axis=1) - 4.0 * np.finfo(float).eps <= 1.0)
+
+
+def _domain_points(randomness, bounds, count, d, domain_type):
+    """DomainType::GenerateUniformPointsInDomain: a Latin hypercube in the box; for the simplex intersection the points outside the
+    unit simplex are rejected and the draw is repeated with more points, the reference's retry rule (gpp_domain.cpp:179-232: at most
+    ten attempts, content with 90 % of the request, growth 1 / ratio capped at 5 x).  May return fewer than `count` points."""
+    from . import api
+    if domain_type == 0:
+        return api.latin_hypercube(randomness._next_uniform_seed(), bounds, count)
+    box = _simplex_box(bounds, d)
+    n_local = max(10, count)
+    kept = np.empty((0, d))
+    for _ in range(10):
+        pts = api.latin_hypercube(randomness._next_uniform_seed(), box, n_local)
+        kept = pts[_in_unit_simplex(pts)][:count]
+        if len(kept) >= 0.9 * count:
+            break
+        ratio = len(kept) / float(count)
+        n_local = n_local * 5 if ratio < 0.2 else int(np.ceil(n_local / ratio))
+    return kept
+
+
+def _starts(randomness, bounds, count, q, d, domain_type=0):
+    """RepeatedDomain::GenerateUniformPointsInDomain (gpp_domain.hpp:490-510): one point set per repeat, transposed; when a repeat
+    comes up short (simplex rejection) every start set is cut to the shortest."""
+    sets = []
+    n = count
+    for _ in range(q):
+        pts = _domain_points(randomness, bounds, n, d, domain_type)
+        n = min(n, len(pts))
+        sets.append(pts)
+    out = np.empty((n, q, d))
+    for r in range(q):
+        out[:, r, :] = sets[r][:n]
+    return out
 
 
 def kg_optimal_points(dev_gp, num_fidelity, optimizer_parameters, optimizer_parameters_inner, bounds, discrete, Xp,
@@ -40,16 +93,15 @@ def kg_optimal_points(dev_gp, num_fidelity, optimizer_parameters, optimizer_para
     m = (q + p) * (1 + dev_gp.g)
     normals = randomness.normal_rng_vec[0].table(((num_mc + 1) // 2) * m)
 
-    def lhc(count):  # RepeatedDomain::GenerateUniformPointsInDomain: one hypercube per repeat (gpp_domain.hpp:490-504)
-        out = np.empty((count, q, d))
-        for r in range(q):
-            out[:, r, :] = api.latin_hypercube(randomness._next_uniform_seed(), bounds, count)
-        return out
+    dom = _domain_type(optimizer_parameters)
+
+    def lhc(count):
+        return _starts(randomness, bounds, count, q, d, dom)
 
     use_gd = int(optimizer_parameters.optimizer_type) == int(GPP.OptimizerTypes.gradient_descent)
     best, found = np.zeros((q, d)), False
     if use_gd:
-        gd = _gd(optimizer_parameters)
+        gd = _gd(optimizer_parameters, dom)
         if starts is None:
             starts = lhc(gd[0])
         starts = np.asarray(starts, dtype=np.float64).reshape(-1, q, d)
@@ -75,16 +127,15 @@ def ei_optimal_points(dev_gp, optimizer_parameters, bounds, Xp, num_to_sample, b
     p = 0 if Xp is None else np.asarray(Xp).reshape(-1, d).shape[0]
     normals = None if (q == 1 and p == 0) else randomness.normal_rng_vec[0].table(int(num_mc) * (q + p))
 
+    dom = _domain_type(optimizer_parameters)
+
     def lhc(count):
-        out = np.empty((count, q, d))
-        for r in range(q):
-            out[:, r, :] = api.latin_hypercube(randomness._next_uniform_seed(), bounds, count)
-        return out
+        return _starts(randomness, bounds, count, q, d, dom)
 
     use_gd = int(optimizer_parameters.optimizer_type) == int(GPP.OptimizerTypes.gradient_descent)
     best, found = np.zeros((q, d)), False
     if use_gd:
-        gd = _gd(optimizer_parameters)
+        gd = _gd(optimizer_parameters, dom)
         best, _, found = dev_gp.ei_multistart(gd, bounds, lhc(gd[0]), Xp, num_mc, best_so_far, normals, gradient_ascent=True)
     if not found:
         n_lhc = int(optimizer_parameters.num_random_samples or 0)
@@ -95,13 +146,6 @@ def ei_optimal_points(dev_gp, optimizer_parameters, bounds, Xp, num_to_sample, b
     return best, found
 
 
-def _lhc_starts(randomness, bounds, count, q, d):
-    """RepeatedDomain::GenerateUniformPointsInDomain: one Latin hypercube per repeat (gpp_domain.hpp:490-504)."""
-    from . import api
-    out = np.empty((count, q, d))
-    for r in range(q):
-        out[:, r, :] = api.latin_hypercube(randomness._next_uniform_seed(), bounds, count)
-    return out
 
 
 def kg_mcmc_optimal_points(dev_mcmc, num_fidelity, optimizer_parameters, optimizer_parameters_inner, bounds, discrete_all, Xp,
@@ -116,15 +160,16 @@ def kg_mcmc_optimal_points(dev_mcmc, num_fidelity, optimizer_parameters, optimiz
     normals = randomness.normal_rng_vec[0].table(((num_mc + 1) // 2) * (q + p) * (1 + dev_mcmc.g))
     use_gd = int(optimizer_parameters.optimizer_type) == int(GPP.OptimizerTypes.gradient_descent)
     best, found = np.zeros((q, d)), False
+    dom = _domain_type(optimizer_parameters)
     if use_gd:
-        gd = _gd(optimizer_parameters)
-        best, _, found = dev_mcmc.kg_multistart(gd, inner_gd, bounds, discrete_all, _lhc_starts(randomness, bounds, gd[0], q, d), Xp,
+        gd = _gd(optimizer_parameters, dom)
+        best, _, found = dev_mcmc.kg_multistart(gd, inner_gd, bounds, discrete_all, _starts(randomness, bounds, gd[0], q, d, dom), Xp,
                                                 num_mc, best_so_far, normals, gradient_ascent=True, num_fidelity=num_fidelity)
     if not found:
         n_lhc = int(optimizer_parameters.num_random_samples or 0)
         if n_lhc > 0:
             best, _, found = dev_mcmc.kg_multistart(inner_gd, inner_gd, bounds, discrete_all,
-                                                    _lhc_starts(randomness, bounds, n_lhc, q, d), Xp, num_mc, best_so_far, normals,
+                                                    _starts(randomness, bounds, n_lhc, q, d, dom), Xp, num_mc, best_so_far, normals,
                                                     gradient_ascent=False, num_fidelity=num_fidelity)
     return best, found
 
@@ -139,15 +184,16 @@ def ei_mcmc_optimal_points(dev_mcmc, optimizer_parameters, bounds, Xp, num_to_sa
     normals = None if (q == 1 and p == 0) else randomness.normal_rng_vec[0].table(int(num_mc) * (q + p))
     use_gd = int(optimizer_parameters.optimizer_type) == int(GPP.OptimizerTypes.gradient_descent)
     best, found = np.zeros((q, d)), False
+    dom = _domain_type(optimizer_parameters)
     if use_gd:
-        gd = _gd(optimizer_parameters)
-        best, _, found = dev_mcmc.ei_multistart(gd, bounds, _lhc_starts(randomness, bounds, gd[0], q, d), Xp, num_mc, best_so_far,
+        gd = _gd(optimizer_parameters, dom)
+        best, _, found = dev_mcmc.ei_multistart(gd, bounds, _starts(randomness, bounds, gd[0], q, d, dom), Xp, num_mc, best_so_far,
                                                 normals, gradient_ascent=True)
     if not found:
         n_lhc = int(optimizer_parameters.num_random_samples or 0)
         if n_lhc > 0:
             best, _, found = dev_mcmc.ei_multistart((1, 1, 0, 0, 1.0, 1.0, 1.0, 0.0), bounds,
-                                                    _lhc_starts(randomness, bounds, n_lhc, q, d), Xp, num_mc, best_so_far, normals,
+                                                    _starts(randomness, bounds, n_lhc, q, d, dom), Xp, num_mc, best_so_far, normals,
                                                     gradient_ascent=False)
     return best, found
 

@@ -57,7 +57,13 @@ typedef struct moe_gd_params {
   double pre_mult;
   double max_relative_change;
   double tolerance;
+  int domain_type; /* OUTER optimisers only (r4): 0 = tensor-product domain, 1 = its intersection with the unit simplex
+                      {x_i >= 0, sum x_i <= 1} applied to each of the q points (SimplexIntersectTensorProductDomain,
+                      gpp_domain.hpp:215-349; the dispatch of gpp_python_knowledge_gradient.cpp:288-296).  Ignored for the
+                      inner optimisation of a KG evaluation, whose domain is always a tensor product. */
 } moe_gd_params_t;
+#define MOE_DOMAIN_TENSOR_PRODUCT 0
+#define MOE_DOMAIN_SIMPLEX 1
 
 /* Counters the device fills during one KG evaluation (S and G must be counted on device). */
 typedef struct moe_kg_stats {

@@ -51,6 +51,7 @@ def lib():
         _lib.ref_ei.argtypes = [C.c_void_p, _dp, _dp, C.c_int, C.c_int, C.c_int, C.c_double, _dp, _dp, _dp, _dp]
         _lib.ref_ei_analytic.argtypes = [C.c_void_p, _dp, C.c_double, _dp, _dp]
         _lib.ref_ei_multistart_analytic.argtypes = [C.c_void_p, _dp, _dp, _dp, C.c_int, C.c_double, C.POINTER(C.c_int), _dp]
+        _lib.ref_ei_multistart_analytic_dom.argtypes = [C.c_void_p, _dp, _dp, _dp, C.c_int, C.c_double, C.c_int, C.POINTER(C.c_int), _dp]
         _lib.ref_gpmcmc_create.restype = C.c_void_p
         _lib.ref_gpmcmc_create.argtypes = [_dp, _dp, C.c_int, _dp, _dp, _ip, C.c_int, C.c_int, C.c_int]
         _lib.ref_gpmcmc_destroy.argtypes = [C.c_void_p]
@@ -236,8 +237,9 @@ class RefGP(object):
         _check(lib().ref_ei_analytic(self.h, pp, best_so_far, C.byref(ei), grad.ctypes.data_as(_dp)))
         return ei.value, grad
 
-    def ei_multistart_analytic(self, gd, bounds, starts, best_so_far):
-        """ComputeOptimalPointsToSampleViaMultistartGradientDescent at q = 1, p = 0: (best_point [d], found)."""
+    def ei_multistart_analytic(self, gd, bounds, starts, best_so_far, domain_type=0):
+        """ComputeOptimalPointsToSampleViaMultistartGradientDescent at q = 1, p = 0: (best_point [d], found).
+        domain_type 1: over SimplexIntersectTensorProductDomain."""
         gd, gdp = _d(gd)
         bounds, bp = _d(bounds)
         starts, sp = _d(starts)
@@ -245,8 +247,8 @@ class RefGP(object):
         assert S >= 20, "the reference pops its top-20 queue unconditionally"
         found = C.c_int(0)
         best = np.zeros(self.d)
-        _check(lib().ref_ei_multistart_analytic(self.h, gdp, bp, sp, S, best_so_far, C.byref(found),
-                                                best.ctypes.data_as(_dp)))
+        _check(lib().ref_ei_multistart_analytic_dom(self.h, gdp, bp, sp, S, best_so_far, int(domain_type), C.byref(found),
+                                                    best.ctypes.data_as(_dp)))
         return best, bool(found.value)
 
     def kg(self, gd, bounds, discrete, Xq, Xp, M, best_so_far, normals, want_grad=True, num_fidelity=0, details=False):

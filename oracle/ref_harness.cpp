@@ -264,24 +264,36 @@ int ref_ei_analytic(void* hv, const double* pt, double best_so_far, double* ei, 
 // ---- 1,0-EI multistart gradient descent from a given start set (ComputeOptimalPointsToSampleViaMultistartGradientDescent,
 // gpp_math.hpp:1683-1742).  q = 1, p = 0 takes the analytic evaluator, so no random source is involved and the result is a
 // deterministic function of the inputs.  num_starts must be >= 20 (the reference pops its top-20 queue unconditionally). ----
-int ref_ei_multistart_analytic(void* hv, const double* gd, const double* bounds, const double* starts, int num_starts,
-                               double best_so_far, int* found, double* best_point) {
+// domain_type: 0 = TensorProductDomain, 1 = SimplexIntersectTensorProductDomain (the dispatch of gpp_python_expected_improvement.cpp:262-271)
+int ref_ei_multistart_analytic_dom(void* hv, const double* gd, const double* bounds, const double* starts, int num_starts,
+                                   double best_so_far, int domain_type, int* found, double* best_point) {
   return guarded([&] {
     GaussianProcess* gp = static_cast<RefGP*>(hv)->gp;
     const int d = gp->dim();
     std::vector<ClosedInterval> iv(d);
     for (int i = 0; i < d; ++i) iv[i] = ClosedInterval(bounds[2 * i], bounds[2 * i + 1]);
-    TensorProductDomain dom(iv.data(), d);
     GradientDescentParameters gdp(static_cast<int>(gd[0]), static_cast<int>(gd[1]), static_cast<int>(gd[2]),
                                   static_cast<int>(gd[3]), gd[4], gd[5], gd[6], gd[7]);
     ThreadSchedule sched(1, omp_sched_static);
     NormalRNG rng(1);
     double dummy = 0.0;
     bool found_flag = false;
-    ComputeOptimalPointsToSampleViaMultistartGradientDescent(*gp, gdp, dom, sched, starts, &dummy, num_starts, 1, 0,
-                                                             best_so_far, 1, &rng, &found_flag, best_point);
+    if (domain_type == 1) {
+      SimplexIntersectTensorProductDomain dom(iv.data(), d);
+      ComputeOptimalPointsToSampleViaMultistartGradientDescent(*gp, gdp, dom, sched, starts, &dummy, num_starts, 1, 0,
+                                                               best_so_far, 1, &rng, &found_flag, best_point);
+    } else {
+      TensorProductDomain dom(iv.data(), d);
+      ComputeOptimalPointsToSampleViaMultistartGradientDescent(*gp, gdp, dom, sched, starts, &dummy, num_starts, 1, 0,
+                                                               best_so_far, 1, &rng, &found_flag, best_point);
+    }
     *found = found_flag ? 1 : 0;
   });
+}
+
+int ref_ei_multistart_analytic(void* hv, const double* gd, const double* bounds, const double* starts, int num_starts,
+                               double best_so_far, int* found, double* best_point) {
+  return ref_ei_multistart_analytic_dom(hv, gd, bounds, starts, num_starts, best_so_far, 0, found, best_point);
 }
 
 // ---- q-KG / d-KG (gpp_knowledge_gradient_optimization.cpp:69-227) ----

@@ -243,3 +243,42 @@ comm.close()
                             % (root, str(out), str(script))], env=env, timeout=600)
     assert code == 0
     assert out.read_text() == "gloo (test hook)|None|[1.0, 2.0, 3.0, 4.0]|2|0"
+
+
+def test_simplex_domain_start_generation_and_dispatch():
+    """r4: the host side of DomainTypes.simplex -- start sets by rejection from a Latin hypercube in the clipped box
+    (SimplexIntersectTensorProductDomain::GenerateUniformPointsInDomain, gpp_domain.cpp:179-232, RepeatedDomain's transposition and
+    cut to the shortest repeat), the status-key name, and the KG entry points' refusal."""
+    from cornell_moe_amd import GPP, multistart
+
+    class Rng(object):
+        def __init__(self):
+            self.seed = 100
+
+        def _next_uniform_seed(self):
+            self.seed += 1
+            return self.seed
+
+    import cornell_moe_amd.api as api_mod
+    real = api_mod.latin_hypercube
+    api_mod.latin_hypercube = lambda seed, bounds, count: np.random.default_rng(seed).uniform(
+        np.asarray(bounds)[0::2], np.asarray(bounds)[1::2], size=(count, len(bounds) // 2))   # (no GPU library on this box)
+    try:
+        st = multistart._starts(Rng(), np.tile([-0.5, 2.0], 3), 40, 2, 3, domain_type=1)
+    finally:
+        api_mod.latin_hypercube = real
+    assert st.shape[1:] == (2, 3) and 10 <= st.shape[0] <= 40
+    flat = st.reshape(-1, 3)
+    assert flat.min() >= 0.0 and flat.max() <= 1.0 and np.all(flat.sum(axis=1) <= 1.0 + 1e-12)
+    assert np.array_equal(multistart._simplex_box(np.tile([-0.5, 2.0], 3), 3), np.tile([0.0, 1.0], 3))
+
+    class P(object):
+        domain_type = GPP.DomainTypes.simplex
+
+    assert GPP._domain_name(P()) == "simplex_tensor_product"
+    GPP._check_domain_type(P())
+    with pytest.raises(GPP.OptimalLearningException):
+        GPP._check_domain_type(P(), kg=True)
+    assert multistart._gd(type("O", (), {"optimizer_parameters": type("Q", (), dict(
+        num_multistarts=3, max_num_steps=4, max_num_restarts=1, num_steps_averaged=0, gamma=0.5, pre_mult=1.0,
+        max_relative_change=0.3, tolerance=1e-6))()})(), 1)[8] == 1

@@ -273,6 +273,47 @@ def shape_fixtures_r4():
     print("wrote", OUT_SHAPES4, os.path.getsize(OUT_SHAPES4), "bytes")
 
 
+OUT_SIMPLEX = os.path.join(ROOT, "tests", "golden", "ref_simplex.npz")
+
+
+def simplex_fixtures():
+    """Round 4: the EI outer optimiser over SimplexIntersectTensorProductDomain (gpp_domain.hpp:215-349) from the unmodified reference --
+    ComputeOptimalPointsToSampleViaMultistartGradientDescent<SimplexIntersectTensorProductDomain> at q = 1, p = 0 (analytic EI), 24 starts
+    inside the simplex, data whose good region lies beyond the diagonal face so that the simplex limit of LimitUpdate (half the distance to
+    the face along the tensor-limited direction) is what shapes the ascent; max_relative_change = 1.0 in one case (the epsilon tweak)."""
+    blob, k = {}, 0
+    for (seed, n, d, box, outer) in ((7101, 40, 3, (0.0, 1.0), (24, 40, 3, 4, 0.6, 0.5, 1.0, 1e-9)),
+                                     (7102, 30, 2, (0.0, 1.0), (24, 30, 2, 4, 0.7, 0.3, 0.5, 1e-9)),
+                                     (7103, 50, 4, (-0.2, 0.8), (24, 25, 2, 4, 0.7, 0.4, 0.8, 1e-9))):
+        rng = np.random.default_rng(seed)
+        c = dict(n=n, d=d, rng_seed=seed)
+        c["X"] = rng.uniform(0.0, 0.6, size=(n, d))
+        c["y"] = (-np.sum(c["X"], axis=1) + 0.2 * np.sin(5 * c["X"]).sum(1) + 0.05 * rng.uniform(size=n))[:, None]  # lower = better beyond the face
+        c["alpha"], c["lengths"], c["noise"] = 1.0, rng.uniform(0.3, 0.6, size=d), np.array([0.01])
+        c["bounds"] = np.tile(np.array(box), d)
+        starts = []
+        while len(starts) < 24:
+            x = rng.uniform(max(box[0], 0.0), min(box[1], 1.0), size=d)
+            if x.sum() <= 0.95:
+                starts.append(x)
+        c["starts"] = np.array(starts)
+        c["outer_gd"] = np.array(outer)
+        c["best_so_far"] = float(c["y"].min())
+        gp = ref.RefGP(1, c["alpha"], c["lengths"], c["X"], c["y"], c["noise"], [])
+        best, found = gp.ei_multistart_analytic(c["outer_gd"], c["bounds"], c["starts"], c["best_so_far"], domain_type=1)
+        best_tp, found_tp = gp.ei_multistart_analytic(c["outer_gd"], c["bounds"], c["starts"], c["best_so_far"], domain_type=0)
+        print("simplex EI multistart case %d: d=%d best=%s (sum %.6f) found=%d; tensor-product best=%s (sum %.4f)" % (
+            k, d, np.array2string(best, precision=6), best.sum(), found, np.array2string(best_tp, precision=4), best_tp.sum()))
+        for key, val in c.items():
+            blob["s%d_in_%s" % (k, key)] = np.asarray(val)
+        blob["s%d_out_best_point" % k], blob["s%d_out_found" % k] = best, np.array(int(found))
+        blob["s%d_out_best_point_tensor" % k] = best_tp
+        k += 1
+    blob["num"] = np.array(k)
+    np.savez_compressed(OUT_SIMPLEX, **blob)
+    print("wrote", OUT_SIMPLEX, os.path.getsize(OUT_SIMPLEX), "bytes")
+
+
 OUT_MS = os.path.join(ROOT, "tests", "golden", "ref_kg_multistart.npz")
 
 
@@ -382,6 +423,9 @@ def main():
         return
     if "--shapes-r4" in sys.argv:
         shape_fixtures_r4()
+        return
+    if "--simplex" in sys.argv:
+        simplex_fixtures()
         return
     if "--kg-multistart" in sys.argv:
         kg_multistart_fixtures()
