@@ -34,7 +34,7 @@ def test_header_symbols_exported(lib):
 
 def test_version_and_struct_layout(lib):
     assert b"gfx950" in lib.moe_version()
-    assert C.sizeof(_lib.GdParams) == 4 * 4 + 4 * 8
+    assert C.sizeof(_lib.GdParams) == 4 * 4 + 4 * 8 + 8   # (+ domain_type, r4: an int padded to the struct's 8-byte alignment)
     assert C.sizeof(_lib.MoeError) == 4 + 480 + 4 + 3 * 8  # int, char[480], pad to 8, double[3]
 
 
