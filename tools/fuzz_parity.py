@@ -83,12 +83,22 @@ def run(num_cases=100, seed=2026, n_max=300, d_max=16, g_max=4):
           loose = gd[1] * gd[2] > 8
           ptol = 1e-6 if loose else 1e-8
           gtol = 1e-6 if loose else TOL["grad_kg"]
+          ktol = TOL["kg"]
+          if R is not None:
+              # (r4, with the reference as the checker) the same effect at production depth, measured instead of assumed: where the
+              # restatement and the reference THEMSELVES differ beyond the tight tolerance (case 71 of seed 31337: one free dimension,
+              # SE kernel, max_relative_change = 1 -- 6 of 18 end points differ by up to 9e-8 between the two CPU codes), the device
+              # is held to four times that distance from the reference
+              dis_p = float(np.abs(ro["best_point"] - rc["best_point"]).max())
+              dis_g = float(np.abs(ro["grad"] - rc["grad"]).max()) / scale
+              dis_k = abs(ro["kg"] - rc["kg"]) / max(abs(rc["kg"]), 1e-6)
+              ptol, gtol, ktol = max(ptol, 4.0 * dis_p), max(gtol, 4.0 * dis_g), max(ktol, 4.0 * dis_k)
           mism = float((np.abs(rg["best_point"] - rc["best_point"]).max(axis=1) > ptol).mean())
           e_kg = abs(rg["kg"] - rc["kg"]) / max(abs(rc["kg"]), 1e-6)
           e_gr = float(np.abs(rg["grad"] - rc["grad"]).max()) / scale
           # (a sample or two may sit on a decision boundary of the line search -- the reference itself does against its
           #  restatement -- without moving KG or its gradient)
-          if e_kg > TOL["kg"] or e_gr > gtol or mism > max(0.05, 2.5 / M) or (not loose and rg["grad_evals"] != ro["grad_evals"]):
+          if e_kg > ktol or e_gr > gtol or mism > max(0.05, 2.5 / M) or (not loose and rg["grad_evals"] != ro["grad_evals"]):
               bad += 1
               print("KG MISMATCH" + aff + " case %d variant %s: n=%d d=%d q=%d p=%d g=%s f=%d P=%d M=%d cov=%d gd=%s: rel kg %.2e grad %.2e "
                     "best-point mismatch %.3f grad passes %d vs %d" % (case, variant, n, d, q, p, derivs, f, P, M, cov, gd, e_kg,
