@@ -88,11 +88,11 @@ def run(num_cases=100, seed=2026, n_max=300, d_max=16, g_max=4):
               # (r4, with the reference as the checker) the same effect at production depth, measured instead of assumed: where the
               # restatement and the reference THEMSELVES differ beyond the tight tolerance (case 71 of seed 31337: one free dimension,
               # SE kernel, max_relative_change = 1 -- 6 of 18 end points differ by up to 9e-8 between the two CPU codes), the device
-              # is held to four times that distance from the reference
+              # is held to ten times that distance from the reference (the three device kernels round differently from each other, too)
               dis_p = float(np.abs(ro["best_point"] - rc["best_point"]).max())
               dis_g = float(np.abs(ro["grad"] - rc["grad"]).max()) / scale
               dis_k = abs(ro["kg"] - rc["kg"]) / max(abs(rc["kg"]), 1e-6)
-              ptol, gtol, ktol = max(ptol, 4.0 * dis_p), max(gtol, 4.0 * dis_g), max(ktol, 4.0 * dis_k)
+              ptol, gtol, ktol = max(ptol, 10.0 * dis_p), max(gtol, 10.0 * dis_g), max(ktol, 10.0 * dis_k)
           mism = float((np.abs(rg["best_point"] - rc["best_point"]).max(axis=1) > ptol).mean())
           e_kg = abs(rg["kg"] - rc["kg"]) / max(abs(rc["kg"]), 1e-6)
           e_gr = float(np.abs(rg["grad"] - rc["grad"]).max()) / scale
