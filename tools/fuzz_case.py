@@ -9,7 +9,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 from cornell_moe_amd import api  # noqa: E402
 from cornell_moe_amd.workloads import make_workload  # noqa: E402
-from oracle import orc  # noqa: E402
+from oracle import orc, ref  # noqa: E402
 
 seed, want = int(sys.argv[1]), int(sys.argv[2])
 rng = np.random.default_rng(seed)
@@ -49,14 +49,19 @@ full = np.hstack([disc, np.ones((disc.shape[0], f))])
 best = float(O.additional_mean(full).min())
 Xp = w.Xp if p else None
 ro = O.kg(gd, bounds, disc, w.Xq, Xp, M, best, w.kg_normals, num_fidelity=f)
-for variant in ("0", "1"):
+if ref.available():  # (r4) the reference itself next to its restatement
+    R = ref.RefGP(cov, w.alpha, w.lengths, w.X, w.y, w.noise, list(derivs))
+    rr = R.kg(gd, bounds, disc, w.Xq, Xp, M, best, w.kg_normals, num_fidelity=f)
+    print("restatement vs reference: kg", ro["kg"], rr["kg"], "max |dx*|", float(np.abs(ro["best_point"] - rr["best_point"]).max()),
+          "max |dgrad|", float(np.abs(ro["grad"] - rr["grad"]).max()))
+for variant in ("0", "1", "2"):
     os.environ["MOE_KG_VARIANT"] = variant
     rg = G.kg(gd, bounds, disc, w.Xq, Xp, M, best, w.kg_normals, num_fidelity=f, want_best_points=True)
     print("variant", variant, "kg dev", rg["kg"], "orc", ro["kg"], "grad evals", rg["grad_evals"], ro["grad_evals"])
     bad = ~np.isfinite(rg["best_point"]).all(axis=1)
     print("  non-finite best points:", int(bad.sum()), " max |dx*|", float(np.nanmax(np.abs(rg["best_point"] - ro["best_point"]))))
     print("  grad dev", np.asarray(rg["grad"]).ravel()[:4], "orc", np.asarray(ro["grad"]).ravel()[:4])
-    off = np.nonzero(np.abs(rg["best_point"] - ro["best_point"]).max(axis=1) > 1e-6)[0]
+    off = np.nonzero(np.abs(rg["best_point"] - ro["best_point"]).max(axis=1) > 1e-8)[0]
     for i in off[:4]:
         print("  sample", int(i), "dev x*", rg["best_point"][i], "\n             orc x*", ro["best_point"][i])
 if len(sys.argv) > 3:  # extra environment for a third run of the wave-per-sample kernel, e.g. MOE_KG_DOT_MAX_RADIUS2=0
