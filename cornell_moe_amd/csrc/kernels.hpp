@@ -59,6 +59,11 @@ void launch_debug_math(const double* x, int n, double* e, double* r, hipStream_t
 // C[N x c] (ldc) = op(T) * B[N x c] (ldb); T lower-triangular N x N (ldt), op = 'N' or 'T'.
 void launch_tri_gemm(char op, int N, int c, const double* T, long ldt, const double* B, long ldb, double* C, long ldc,
                      hipStream_t s);
+// G (c x c, ldg) = S^T S for S = the columns 0, stride, 2 stride, ... of the lower-triangular T (N x N, explicit zeros above the
+// diagonal): with T = L^-1 the rows / columns i stride of K^-1 = L^-T L^-1 -- all the hyper-parameter gradient of the log marginal
+// likelihood reads off the diagonal (the function-value rows: 1 / (1 + g)^2 of the matrix).  diag (or NULL): the N squared column
+// norms of T = diag(K^-1).
+void launch_tri_gram_strided(int N, int c, int stride, const double* T, long ldt, double* G, long ldg, double* diag, hipStream_t s);
 // The same product through kernels shaped for c <= 16 columns (falls back to launch_tri_gemm above that).  A different
 // summation order: the per-evaluation state set-up keeps to launch_tri_gemm so that its results do not depend on how many
 // evaluations share a call; the GP-level solves (K^-1 (y - mean), the block row of an append) use this one.

@@ -129,7 +129,7 @@ template <int MODE, bool NEG, int TKV = 16>
 __global__ __launch_bounds__(256) void mfma_gemm_kernel(int M, int Ncols, int K, const double* __restrict__ A, long lda,
                                                        const double* __restrict__ B, long ldb, double* __restrict__ C,
                                                        long ldc, int xmul, int pair_rows, long sA = 0, long sB = 0,
-                                                       long sC = 0, int m_total = 0, int m_step = 0) {
+                                                       long sC = 0, int m_total = 0, int m_step = 0, int tri_scale = 1) {
   constexpr int TM = 64, TN = 64, TK = TKV, LD = 65;
   constexpr int NF = TM * TK / 256;  // elements of each operand tile per thread
   __shared__ double As[TK][LD];
@@ -189,7 +189,7 @@ __global__ __launch_bounds__(256) void mfma_gemm_kernel(int M, int Ncols, int K,
     const int i0 = bx * TM;
     int k_lo = 0, k_hi = K;
     if (MODE == 1) k_hi = min(K, i0 + TM);
-    if (MODE == 2) k_lo = (i0 / TK) * TK;
+    if (MODE == 2) k_lo = (int)(((long)i0 * tri_scale) / TK) * TK;  // (tri_scale: row i of A^T is column i * tri_scale of the triangle)
     if (MODE == 3) k_lo = (j0 / TK) * TK;
     f64x4 acc[2][2];
 #pragma unroll
@@ -211,7 +211,7 @@ __global__ __launch_bounds__(256) void mfma_gemm_kernel(int M, int Ncols, int K,
           const int kk = t % TK, ii = t / TK;
           const int gi = i0 + ii, gk = k0 + kk;
           bool ok = gi < M && gk < K;
-          if (MODE == 2) ok = ok && gk >= gi;
+          if (MODE == 2) ok = ok && gk >= gi * tri_scale;
           ra[it] = ok ? A[(long)gk + (long)gi * lda] : 0.0;
         }
         const int kk = t % TK, jj = t / TK;
@@ -264,7 +264,7 @@ __global__ __launch_bounds__(256) void mfma_gemm_kernel(int M, int Ncols, int K,
 
 template <int MODE, bool NEG = false>
 void tile_gemm(int M, int Ncols, int K, const double* A, long lda, const double* B, long ldb, double* C, long ldc,
-               hipStream_t s) {
+               hipStream_t s, int tri_scale = 1) {
   if (M <= 0 || Ncols <= 0) return;
   // Skinny outputs: smaller tiles give the chip more workgroups to place.
   const long blocks64 = (long)((M + 63) / 64) * ((Ncols + 63) / 64);
@@ -298,9 +298,11 @@ void tile_gemm(int M, int Ncols, int K, const double* A, long lda, const double*
         return (v && *v) ? std::atoi(v) : 16;
       }();
       if (tk == 32)
-        hipLaunchKernelGGL((mfma_gemm_kernel<MODE, NEG, 32>), mgrid, dim3(256), 0, s, M, Ncols, K, A, lda, B, ldb, C, ldc, xmul, pair_rows);
+        hipLaunchKernelGGL((mfma_gemm_kernel<MODE, NEG, 32>), mgrid, dim3(256), 0, s, M, Ncols, K, A, lda, B, ldb, C, ldc, xmul, pair_rows,
+                           0L, 0L, 0L, 0, 0, tri_scale);
       else
-        hipLaunchKernelGGL((mfma_gemm_kernel<MODE, NEG, 16>), mgrid, dim3(256), 0, s, M, Ncols, K, A, lda, B, ldb, C, ldc, xmul, pair_rows);
+        hipLaunchKernelGGL((mfma_gemm_kernel<MODE, NEG, 16>), mgrid, dim3(256), 0, s, M, Ncols, K, A, lda, B, ldb, C, ldc, xmul, pair_rows,
+                           0L, 0L, 0L, 0, 0, tri_scale);
     }
     else
       hipLaunchKernelGGL((tile_gemm_kernel<64, 64, MODE, 16, NEG>), grid, dim3(256), 0, s, M, Ncols, K, A, lda, B, ldb, C, ldc);
@@ -925,6 +927,31 @@ void launch_tri_gemm(char op, int N, int c, const double* T, long ldt, const dou
     tile_gemm<1>(N, c, N, T, ldt, B, ldb, C, ldc, s);
   else
     tile_gemm<2>(N, c, N, T, ldt, B, ldb, C, ldc, s);
+}
+
+namespace {
+// out[r] = sum_k T[k + r ldt]^2 over k >= r: the squared column norms of a lower-triangular matrix (diag of T^T T).  One
+// wavefront per column, fixed summation order.
+__global__ __launch_bounds__(256) void tri_colnorm2_kernel(int N, const double* __restrict__ T, long ldt, double* __restrict__ out) {
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (r >= N) return;
+  const double* col = T + (long)r * ldt;
+  double v = 0.0;
+  for (int k = r + lane; k < N; k += 64) v = fma(col[k], col[k], v);
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  if (lane == 0) out[r] = v;
+}
+}  // namespace
+
+void launch_tri_gram_strided(int N, int c, int stride, const double* T, long ldt, double* G, long ldg, double* diag, hipStream_t s) {
+  // rows of S^T = every stride-th column of T: A(i, k) = T[k + (i stride) ldt] -- a transposed triangular operand with leading
+  // dimension stride * ldt whose row i starts at k = i stride
+  tile_gemm<2>(c, c, N, T, (long)stride * ldt, T, (long)stride * ldt, G, ldg, s, stride);
+  if (diag != nullptr) {
+    hipLaunchKernelGGL(tri_colnorm2_kernel, dim3((N + 3) / 4), dim3(256), 0, s, N, T, ldt, diag);
+    MOE_HIP_CHECK(hipGetLastError());
+  }
 }
 
 void launch_tri_gemm_skinny(char op, int N, int c, const double* T, long ldt, const double* B, long ldb, double* C,
