@@ -11,6 +11,7 @@
 #include <algorithm>
 #include <cstdlib>
 
+#include "gemm128.hpp"
 #include "kernels.hpp"
 
 namespace moe {
@@ -311,6 +312,34 @@ void tile_gemm(int M, int Ncols, int K, const double* A, long lda, const double*
     hipLaunchKernelGGL((tile_gemm_kernel<32, 16, MODE, 128, NEG>), grid, dim3(256), 0, s, M, Ncols, K, A, lda, B, ldb, C, ldc);
   }
   MOE_HIP_CHECK(hipGetLastError());
+}
+
+// gemm128.hpp's kernel: `batch` problems (GemmArgs strides), the LDS opt-in set on every call (it is per device).
+template <bool AKC, int AMASK, bool BKC, int BMASK, bool NEG>
+void launch_gemm128(const g128::GemmArgs& g, int batch, hipStream_t s) {
+  if (g.M <= 0 || g.N <= 0 || batch <= 0) return;
+  auto kern = g128::gemm128_kernel<AKC, AMASK, BKC, BMASK, NEG>;
+  MOE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)g128::kSmemBytes));
+  const int R = (g.M + g128::TM - 1) / g128::TM, Ct = (g.N + g128::TM - 1) / g128::TM;
+  g128::GemmArgs ga = g;
+  ga.batch = batch;
+  hipLaunchKernelGGL(kern, dim3((unsigned)(R * Ct * batch)), dim3(256), g128::kSmemBytes, s, ga);
+  MOE_HIP_CHECK(hipGetLastError());
+}
+// Whether the 128-tile kernel is taken for an output of rows x cols (x batch): it needs a few hundred tiles to fill 256 CUs twice;
+// below that the 64-tile kernel's four times as many workgroups balance better.  MOE_GEMM128=0: never (A/B runs).
+inline bool use_gemm128(long rows, long cols, long batch) {
+  static const int mode = [] {
+    const char* v = std::getenv("MOE_GEMM128");
+    return (v && *v) ? std::atoi(v) : 1;
+  }();
+  static const long min_tiles = [] {
+    const char* v = std::getenv("MOE_GEMM128_MIN_TILES");
+    return (v && *v) ? std::atol(v) : 192L;
+  }();
+  if (mode == 0) return false;
+  return ((rows + 127) / 128) * ((cols + 127) / 128) * batch >= min_tiles;
 }
 
 // Batched Gram matrices G_e = V_e^T V_e over column groups of V (see kernels.hpp): 32 x 32 output tile per workgroup,
@@ -1692,6 +1721,38 @@ void trtri_levels(const double* L, long lda, double* Linv, long ldl, int N, doub
         xmul = cand;
         break;
       }
+    if (B >= 128 && use_gemm128(rows_max, B, nn)) {
+      // r4: both products through the 128-tile kernel (gemm128.hpp), the level's nodes as its batch
+      g128::GemmArgs g1{};
+      g1.A = g128::Operand{L + B, lda, rows_max, (int)B, 1};            // L21: rows contiguous
+      g1.B = g128::Operand{Linv, ldl, (int)B, (int)B, 1};               // X11: lower triangular, K contiguous
+      g1.C = work;
+      g1.ldc = ldw;
+      g1.M = rows_max;
+      g1.N = (int)B;
+      g1.K = (int)B;
+      g1.sA = 2 * B * (1 + lda);
+      g1.sB = 2 * B * (1 + ldl);
+      g1.sC = ldw * B;
+      g1.m_total = (int)(N - B);
+      g1.m_step = (int)(2 * B);
+      launch_gemm128<false, 0, true, 2, false>(g1, nn, s);
+      g128::GemmArgs g2{};
+      g2.A = g128::Operand{Linv + B + B * ldl, ldl, rows_max, rows_max, 1};  // X22: lower triangular, rows contiguous
+      g2.B = g128::Operand{work, ldw, (int)B, rows_max, 1};                  // L21 X11: K contiguous
+      g2.C = Linv + B;
+      g2.ldc = ldl;
+      g2.M = rows_max;
+      g2.N = (int)B;
+      g2.K = rows_max;
+      g2.sA = 2 * B * (1 + ldl);
+      g2.sB = ldw * B;
+      g2.sC = 2 * B * (1 + ldl);
+      g2.m_total = (int)(N - B);
+      g2.m_step = (int)(2 * B);
+      launch_gemm128<false, 1, true, 0, true>(g2, nn, s);
+      continue;
+    }
     // work_k (rows x B) = L21 X11   (X11 lower triangular: MODE 3)
     const int pairc = (ct >= 16) ? 2 : 0;  // (column pairing: see mfma_gemm_kernel)
     hipLaunchKernelGGL((mfma_gemm_kernel<3, false, 16>), dim3(pairc ? (ct + 1) / 2 : ct, rt, nn), dim3(256), 0, s, rows_max, (int)B,
@@ -1784,8 +1845,16 @@ void cholesky_factor_two_level(int N, double* A, long lda, double* Linv, long ld
     }
     const int trailing = N - (ko + wo);
     if (trailing > 0) {
-      const int tt = (trailing + 63) / 64;
-      hipLaunchKernelGGL(syrk_mfma_kernel, dim3(tt, tt), dim3(256), 0, s, A, lda, N, ko + wo, ko, wo, (const int*)info, 0);
+      const int t128 = (trailing + 127) / 128;
+      if (use_gemm128(trailing, trailing, 1)) {  // (half of the square's tiles are visited)
+        MOE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(g128::syrk128_kernel),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)g128::kSmemBytes));
+        hipLaunchKernelGGL(g128::syrk128_kernel, dim3(t128 * (t128 + 1) / 2), dim3(256), g128::kSmemBytes, s, A, lda, N, ko + wo, ko,
+                           wo, (const int*)info);
+      } else {
+        const int tt = (trailing + 63) / 64;
+        hipLaunchKernelGGL(syrk_mfma_kernel, dim3(tt, tt), dim3(256), 0, s, A, lda, N, ko + wo, ko, wo, (const int*)info, 0);
+      }
     }
   }
   MOE_HIP_CHECK(hipGetLastError());
