@@ -328,17 +328,14 @@ void launch_gemm128(const g128::GemmArgs& g, int batch, hipStream_t s) {
   MOE_HIP_CHECK(hipGetLastError());
 }
 // Whether the 128-tile kernel is taken for an output of rows x cols (x batch): it needs a few hundred tiles to fill 256 CUs twice;
-// below that the 64-tile kernel's four times as many workgroups balance better.  MOE_GEMM128=0: never (A/B runs).
+// below that the 64-tile kernel's four times as many workgroups balance better.  MOE_GEMM128=0: never; MOE_GEMM128_MIN_TILES: the
+// threshold (A/B runs, tests).
 inline bool use_gemm128(long rows, long cols, long batch) {
-  static const int mode = [] {
-    const char* v = std::getenv("MOE_GEMM128");
-    return (v && *v) ? std::atoi(v) : 1;
-  }();
-  static const long min_tiles = [] {
-    const char* v = std::getenv("MOE_GEMM128_MIN_TILES");
-    return (v && *v) ? std::atol(v) : 192L;
-  }();
-  if (mode == 0) return false;
+  // (read per call: the tests force both kernels at small sizes)
+  const char* v = std::getenv("MOE_GEMM128");
+  if (v && *v == '0') return false;
+  const char* t = std::getenv("MOE_GEMM128_MIN_TILES");
+  const long min_tiles = (t && *t) ? std::atol(t) : 192L;
   return ((rows + 127) / 128) * ((cols + 127) / 128) * batch >= min_tiles;
 }
 

@@ -603,6 +603,39 @@ def test_two_level_cholesky(api, monkeypatch):
     assert np.abs(K @ kiy - (y[:, 0] - mean)).max() <= 1e-8 * np.abs(y).max()
 
 
+def test_gemm128_products_of_the_build(api, monkeypatch):
+    """r4: the 128-tile matrix-pipe kernel (csrc/gemm128.hpp) behind the inverse factor's two products per level and the rank-512
+    update, forced at sizes where the 64-tile kernel is the default -- row / column counts that are no multiple of 128, K ranges that
+    are no multiple of 16, a level whose last node is cut off by the matrix edge: same factor, K^-1 y, posterior and log-likelihood
+    gradient as the 64-tile kernels to round-off, L^-1 L = I, and bit-identical from run to run."""
+    rng = np.random.default_rng(23)
+    for n, d, derivs in ((1300, 3, ()), (650, 4, (1,)), (2100, 2, ())):
+        X = rng.uniform(size=(n, d))
+        g = len(derivs)
+        y = rng.uniform(size=(n, 1 + g))
+        hyper = [1.2] + list(0.25 + 0.1 * np.arange(d))
+        noise = [0.02] * (1 + g)
+        monkeypatch.setenv("MOE_GEMM128", "0")
+        a = api.DeviceGP(hyper, X, y, noise, derivatives=derivs)
+        monkeypatch.setenv("MOE_GEMM128", "1")
+        monkeypatch.setenv("MOE_GEMM128_MIN_TILES", "1")
+        b = api.DeviceGP(hyper, X, y, noise, derivatives=derivs)
+        b2 = api.DeviceGP(hyper, X, y, noise, derivatives=derivs)
+        La, kiya, _ = a.get_factor()
+        Lb, kiyb, _ = b.get_factor()
+        Lb2, kiyb2, _ = b2.get_factor()
+        assert np.array_equal(Lb, Lb2) and np.array_equal(kiyb, kiyb2)
+        assert np.abs(La - Lb).max() <= 1e-13 * np.abs(La).max()
+        assert np.abs(kiya - kiyb).max() <= 1e-10 * np.abs(kiya).max()
+        q = rng.uniform(size=(5, d))
+        assert np.abs(a.mean(q) - b.mean(q)).max() <= 1e-11 and np.abs(a.variance(q) - b.variance(q)).max() <= 1e-11
+        if g == 0:  # K^-1 y = L^-T (L^-1 yc) must solve the system (both products of the inverse factor enter)
+            K = b.mix_covariance(X) + noise[0] * np.eye(n)
+            assert np.abs(K @ kiyb - (y[:, 0] - b.get_factor()[2])).max() <= 1e-8 * np.abs(y).max()
+        monkeypatch.delenv("MOE_GEMM128_MIN_TILES")
+        monkeypatch.delenv("MOE_GEMM128")
+
+
 def test_ei_device_algebra_matches_host_algebra(api, golden, monkeypatch):
     """r3: the u x u algebra of an EI evaluation on the device (ei.hip: ei_state_kernel -- one sync per call) against the host
     algebra it replaces (MOE_EI_DEVICE_ALGEBRA=0: two syncs): same formulas, the device's exp / sqrt instead of libm's, so the
