@@ -9,6 +9,7 @@
 //    (gpp_linear_algebra.cpp:109-148) and turns every TriangularMatrixVectorSolve (:160-187) of the reference into a
 //    GEMM against L^-1, which is what lets the posterior solves run wide instead of as 1000 dependent steps.
 #include <algorithm>
+#include <cmath>
 #include <cstdlib>
 
 #include "gemm128.hpp"
@@ -327,16 +328,42 @@ void launch_gemm128(const g128::GemmArgs& g, int batch, hipStream_t s) {
   hipLaunchKernelGGL(kern, dim3((unsigned)(R * Ct * batch)), dim3(256), g128::kSmemBytes, s, ga);
   MOE_HIP_CHECK(hipGetLastError());
 }
-// Whether the 128-tile kernel is taken for an output of rows x cols (x batch): it needs a few hundred tiles to fill 256 CUs twice;
-// below that the 64-tile kernel's four times as many workgroups balance better.  MOE_GEMM128=0: never; MOE_GEMM128_MIN_TILES: the
-// threshold (A/B runs, tests).
-inline bool use_gemm128(long rows, long cols, long batch) {
-  // (read per call: the tests force both kernels at small sizes)
-  const char* v = std::getenv("MOE_GEMM128");
-  if (v && *v == '0') return false;
-  const char* t = std::getenv("MOE_GEMM128_MIN_TILES");
-  const long min_tiles = (t && *t) ? std::atol(t) : 192L;
-  return ((rows + 127) / 128) * ((cols + 127) / 128) * batch >= min_tiles;
+// Which kernel a big product of the build takes: a cost estimate for either, from measured rates (MI355X, r4).  The 128-tile
+// kernel retires a K step of 16 per tile in 2.1 us per CU with two workgroups resident (81 % of the matrix peak), 2.65 us with one;
+// its launch lasts as long as its busiest CU, so few tiles (< 2 per workgroup slot) or one long tile among short ones (the
+// triangular levels) cost it what the 64-tile kernels -- 44 - 46 TFLOP/s whatever the shape, four times as many workgroups, row /
+// column pairing -- do not.  A function of the shape alone.  MOE_GEMM128 = 0 / 2: never / always (A/B runs, tests).
+struct Gemm128Estimate {
+  double total_units = 0.0, longest = 0.0, flops = 0.0;  // K steps of 16 over all tiles, of the longest tile; 2 x multiply-adds
+  void add_tile(double k_len, double count = 1.0) {
+    const double units = std::ceil(k_len / 16.0);
+    total_units += units * count;
+    longest = std::max(longest, units);
+    flops += 2.0 * 128.0 * 128.0 * k_len * count;
+  }
+  double us128() const { return 1.25 * std::max(total_units * 2.1 / 256.0, longest * 2.65); }
+  double us64() const { return flops / 44.0e6 + 10.0; }
+};
+inline int gemm128_mode() {
+  const char* v = std::getenv("MOE_GEMM128");  // (read per call: the tests force both kernels at small sizes)
+  return (v && *v) ? std::atoi(v) : 1;
+}
+inline bool use_gemm128(const Gemm128Estimate& e) {
+  const int mode = gemm128_mode();
+  if (mode == 0) return false;
+  if (mode == 2) return true;
+  return e.us128() < e.us64();
+}
+// the rank-kw update of a trailing block of `trailing` rows: equal tiles, whole rounds of 2 x 256 workgroups
+inline bool use_syrk128(int trailing, int kw) {
+  const int mode = gemm128_mode();
+  if (mode == 0) return false;
+  if (mode == 2) return true;
+  const long T = (trailing + 127) / 128, tiles = T * (T + 1) / 2;
+  const double per_round = kw / 16.0 * 4.2 * 1.02, alone = kw / 16.0 * 2.75;
+  const double us128 = tiles <= 256 ? alone : std::ceil(tiles / 512.0) * per_round;
+  const double us64 = (double)trailing * trailing * kw / 46.0e6 + 10.0;
+  return us128 < us64;
 }
 
 // Batched Gram matrices G_e = V_e^T V_e over column groups of V (see kernels.hpp): 32 x 32 output tile per workgroup,
@@ -1718,7 +1745,19 @@ void trtri_levels(const double* L, long lda, double* Linv, long ldl, int N, doub
         xmul = cand;
         break;
       }
-    if (B >= 128 && use_gemm128(rows_max, B, nn)) {
+    // cost estimates of the level's two products (the nodes' tiles together: they are dispatched longest first across the batch)
+    Gemm128Estimate e1, e2;
+    for (int z = 0; z < nn; ++z) {
+      const long mz = std::min<long>(rows_max, (N - B) - (long)z * 2 * B);
+      const double rtiles = (double)((mz + 127) / 128);
+      for (long j0 = 0; j0 < B; j0 += 128) e1.add_tile((double)(B - j0), rtiles);                       // L21 X11: k >= j0
+      for (long i0 = 0; i0 < mz; i0 += 128) e2.add_tile((double)std::min<long>(mz, i0 + 128), (double)((B + 127) / 128));  // X22 W: k < i0 + 128
+    }
+    Gemm128Estimate both = e1;
+    both.total_units += e2.total_units;
+    both.flops += e2.flops;
+    both.longest = std::max(e1.longest, e2.longest) * 2.0;  // (two launches: their busiest CUs add up)
+    if (B >= 128 && use_gemm128(both)) {
       // r4: both products through the 128-tile kernel (gemm128.hpp), the level's nodes as its batch
       g128::GemmArgs g1{};
       g1.A = g128::Operand{L + B, lda, rows_max, (int)B, 1};            // L21: rows contiguous
@@ -1843,7 +1882,7 @@ void cholesky_factor_two_level(int N, double* A, long lda, double* Linv, long ld
     const int trailing = N - (ko + wo);
     if (trailing > 0) {
       const int t128 = (trailing + 127) / 128;
-      if (use_gemm128(trailing, trailing, 1)) {  // (half of the square's tiles are visited)
+      if (use_syrk128(trailing, wo)) {
         MOE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(g128::syrk128_kernel),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)g128::kSmemBytes));
         hipLaunchKernelGGL(g128::syrk128_kernel, dim3(t128 * (t128 + 1) / 2), dim3(256), g128::kSmemBytes, s, A, lda, N, ko + wo, ko,

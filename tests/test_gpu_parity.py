@@ -617,8 +617,7 @@ def test_gemm128_products_of_the_build(api, monkeypatch):
         noise = [0.02] * (1 + g)
         monkeypatch.setenv("MOE_GEMM128", "0")
         a = api.DeviceGP(hyper, X, y, noise, derivatives=derivs)
-        monkeypatch.setenv("MOE_GEMM128", "1")
-        monkeypatch.setenv("MOE_GEMM128_MIN_TILES", "1")
+        monkeypatch.setenv("MOE_GEMM128", "2")
         b = api.DeviceGP(hyper, X, y, noise, derivatives=derivs)
         b2 = api.DeviceGP(hyper, X, y, noise, derivatives=derivs)
         La, kiya, _ = a.get_factor()
@@ -632,7 +631,6 @@ def test_gemm128_products_of_the_build(api, monkeypatch):
         if g == 0:  # K^-1 y = L^-T (L^-1 yc) must solve the system (both products of the inverse factor enter)
             K = b.mix_covariance(X) + noise[0] * np.eye(n)
             assert np.abs(K @ kiyb - (y[:, 0] - b.get_factor()[2])).max() <= 1e-8 * np.abs(y).max()
-        monkeypatch.delenv("MOE_GEMM128_MIN_TILES")
         monkeypatch.delenv("MOE_GEMM128")
 
 
