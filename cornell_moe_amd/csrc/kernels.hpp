@@ -81,10 +81,11 @@ void launch_tri_gemm_cols(char op, int N, int c, int cols_per_problem, const dou
 // C[m x n] (ldc) = A^T B, A is K x m (lda), B is K x n (ldb); reduction over the K rows.
 void launch_gemm_tn(int m, int n, int K, const double* A, long lda, const double* B, long ldb, double* C, long ldc,
                     hipStream_t s);
-// The same with K cut into `slices` partial products (summed in slice order): skinny outputs over a long K.  C is m x n with
-// leading dimension m; work holds slices * m * n doubles.
+// The same for `batch` problems of one shape in ONE launch (problem e: A + e sA, B + e sB; its result dense, m x n with leading
+// dimension m, at C + e m n), with K cut into `slices` partial products summed in slice order: skinny outputs over a long K.
+// work holds slices * batch * m * n doubles (unused for slices == 1).
 void launch_gemm_tn_splitk(int m, int n, int K, const double* A, long lda, const double* B, long ldb, double* C, double* work,
-                           int slices, hipStream_t s);
+                           int slices, hipStream_t s, int batch = 1, long sA = 0, long sB = 0);
 
 // Batched Gram matrices over column groups of V (K x *, ldv): for eval e, G_e[c x c] (ld c, eval stride c*c) = V_e^T V_e
 // where V_e's column `l` is V's column  l < m ? e*m + l : l < m+ng ? E*m + e*ng + (l-m) : E*(m+ng) + e*A + (l-m-ng).

@@ -159,12 +159,16 @@ __global__ __launch_bounds__(256) void mfma_gemm_kernel(int M, int Ncols, int K,
     }
   }
   if (MODE == 0 && gridDim.z > 1) {
-    const int ks = ((K + (int)gridDim.z - 1) / (int)gridDim.z + TK - 1) / TK * TK;
-    const int kb = (int)blockIdx.z * ks;
-    A += kb;
-    B += kb;
+    // (m_total = number of problems of the launch, 0 / 1: one; gridDim.z = problems x slices: z = slice * problems + problem.  The
+    //  partial results of slice s, all problems, sit s * problems * ldc * Ncols behind C; problem e's at e * sC inside that)
+    const int nprob = max(m_total, 1), slices = (int)gridDim.z / nprob;
+    const int e = (int)blockIdx.z % nprob, sl = (int)blockIdx.z / nprob;
+    const int ks = ((K + slices - 1) / slices + TK - 1) / TK * TK;
+    const int kb = sl * ks;
+    A += (long)e * sA + kb;
+    B += (long)e * sB + kb;
     K = max(0, min(ks, K - kb));
-    C += (long)blockIdx.z * ldc * Ncols;
+    C += (long)sl * nprob * ldc * Ncols + (long)e * sC;
   }
   const int R = (M + TM - 1) / TM;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -1062,18 +1066,22 @@ __global__ __launch_bounds__(256) void sum_slices_kernel(const double* __restric
 
 // C (m x n, ldc == m) = A^T B with K cut into `slices` (mfma_gemm_kernel's split-K); work holds slices * m * n doubles.
 void launch_gemm_tn_splitk(int m, int n, int K, const double* A, long lda, const double* B, long ldb, double* C, double* work,
-                           int slices, hipStream_t s) {
-  if (m <= 0 || n <= 0) return;
-  const dim3 mgrid((n + 63) / 64, (m + 63) / 64, slices);
+                           int slices, hipStream_t s, int batch, long sA, long sB) {
+  if (m <= 0 || n <= 0 || batch <= 0) return;
+  const dim3 mgrid((n + 63) / 64, (m + 63) / 64, slices * batch);
   int xmul = 1;
   for (int cand : {37, 41, 43, 47, 53, 59})
     if ((int)mgrid.y % cand != 0) {
       xmul = cand;
       break;
     }
-  hipLaunchKernelGGL((mfma_gemm_kernel<0, false, 16>), mgrid, dim3(256), 0, s, m, n, K, A, lda, B, ldb, work, (long)m, xmul, 0);
-  const long count = (long)m * n;
-  hipLaunchKernelGGL(sum_slices_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, s, (const double*)work, slices, count, C);
+  // problem e's m x n result is dense (ldc == m) at e * m * n, in C and inside every slice of work
+  hipLaunchKernelGGL((mfma_gemm_kernel<0, false, 16>), mgrid, dim3(256), 0, s, m, n, K, A, lda, B, ldb, slices > 1 ? work : C, (long)m,
+                     xmul, 0, sA, sB, (long)m * n, batch, 0, 1);
+  if (slices > 1) {
+    const long count = (long)m * n * batch;
+    hipLaunchKernelGGL(sum_slices_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, s, (const double*)work, slices, count, C);
+  }
   MOE_HIP_CHECK(hipGetLastError());
 }
 

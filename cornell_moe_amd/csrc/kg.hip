@@ -1405,17 +1405,12 @@ KgPending kg_launch(GpDev& gp, int num_fidelity, const moe_gd_params_t& gd, cons
       // S_W = W_e^T T_e per evaluation as a tile GEMM (the one-wave-per-sample loop re-reads W from L2 for every sample,
       // N m 8 bytes each -- fine for q-KG's m = q + p, prohibitive for d-KG's m = (q + p)(1 + g))
       gp.kSW.reserve((size_t)m * E * num_local);
-      // (a skinny output over a long K: split K so that the chip holds several workgroups per CU -- kernels_linalg.hip)
-      const int sw_slices = (m <= 64 && N >= 2048) ? 8 : 1;
-      if (sw_slices > 1) gp.kSWpart.reserve((size_t)sw_slices * m * num_local);
-      for (int e = 0; e < E; ++e) {
-        if (sw_slices > 1)
-          launch_gemm_tn_splitk(m, num_local, N, tl.W + (long)e * tl.w_stride, N, dT.p + (size_t)e * num_local * N, N,
-                                gp.kSW.p + (size_t)e * num_local * m, gp.kSWpart.p, sw_slices, s);
-        else
-          launch_gemm_tn(m, num_local, N, tl.W + (long)e * tl.w_stride, N, dT.p + (size_t)e * num_local * N, N,
-                         gp.kSW.p + (size_t)e * num_local * m, m, s);
-      }
+      // A skinny output (m x samples) over a long K (N): every evaluation of the call in ONE launch, K cut into slices so that the chip
+      // holds several workgroups per CU (r4: one launch per evaluation, unsplit below N = 2048, was 62 % of the d-KG tail at n = 500 --
+      // 63 workgroups walking 125 dependent stages, eight times per call).  The slice count is a function of (m, N) alone.
+      const int sw_slices = (m <= 64) ? (N >= 1024 ? 8 : (N >= 256 ? 4 : 1)) : 1;
+      if (sw_slices > 1) gp.kSWpart.reserve((size_t)sw_slices * m * num_local * E);
+      launch_gemm_tn_splitk(m, num_local, N, tl.W, N, dT.p, N, gp.kSW.p, gp.kSWpart.p, sw_slices, s, E, tl.w_stride, (long)num_local * N);
       tl.SW = gp.kSW.p;
     }
     launch_tail(tl, s);
@@ -1551,6 +1546,7 @@ int kg_max_batch(const GpDev& gp, int P, int q, int p, int num_local, bool want_
   double doubles = N * (m + ngrad + A) + 3.0 * N * m + (double)num_local * (gp.dp + 1 + 2 * m) +
                    (want_grad ? (double)q * gp.d * m * (m + 1) / 2 : 0.0);
   if (want_grad) doubles += (fused ? 0.0 : N * (double)num_local) + (chunks + 1.0) * m * N;
+  if (want_grad && !fused) doubles += 9.0 * m * (double)num_local;  // S_W = W^T T and its (up to eight) K slices
   // the per-sample weight table of the workgroup-per-sample / streamed-weights kernels (the latter: whole tiles, fantasy points included)
   // (always: whether an evaluation takes one of those kernels is decided per evaluation in kg_launch -- far frames send small
   //  q-KG shapes there too -- and the batch must fit whatever it decides)
