@@ -93,6 +93,10 @@ def run(num_cases=100, seed=2026, n_max=300, d_max=16, g_max=4):
               dis_g = float(np.abs(ro["grad"] - rc["grad"]).max()) / scale
               dis_k = abs(ro["kg"] - rc["kg"]) / max(abs(rc["kg"]), 1e-6)
               ptol, gtol, ktol = max(ptol, 10.0 * dis_p), max(gtol, 10.0 * dis_g), max(ktol, 10.0 * dis_k)
+              # (and where the two CPU codes end a sample 1e-9 or more apart, one of them took a step the other did not: the
+              #  restatement's pass count is then not the reference's -- seed 2024 case 127, one free dimension again: 1.0e-8 between
+              #  the CPU codes, the device within 3e-9 of the restatement with one gradient pass more)
+              loose = loose or dis_p > 1.0e-9
           mism = float((np.abs(rg["best_point"] - rc["best_point"]).max(axis=1) > ptol).mean())
           e_kg = abs(rg["kg"] - rc["kg"]) / max(abs(rc["kg"]), 1e-6)
           e_gr = float(np.abs(rg["grad"] - rc["grad"]).max()) / scale
