@@ -51,16 +51,12 @@ class DomainTypes(object):
 
 
 def _check_domain_type(optimizer_parameters, kg=False):
-    """The dispatch of gpp_python_knowledge_gradient.cpp:288-296 / gpp_python_expected_improvement.cpp:262-271: tensor product or its
-    intersection with the unit simplex; anything else is the reference's "invalid domain choice".  The EI optimisers take both (r4).
-    For KG the reference builds the INNER domain of every sample's posterior-mean optimisation as a simplex intersection too; the
-    device's MC kernels run that optimisation over a tensor product only, so KG over the simplex is refused rather than optimised
-    over the wrong set."""
+    """The dispatch of gpp_python_knowledge_gradient.cpp:279-296, 327-341 / gpp_python_expected_improvement.cpp:262-271: tensor
+    product or its intersection with the unit simplex; anything else is the reference's "invalid domain choice".  For KG the
+    reference builds the INNER domain of every sample's posterior-mean optimisation of the same type; the MC kernels' line search
+    takes it (r4: csrc/kg_mc.hpp simplex_limit)."""
     if int(optimizer_parameters.domain_type) not in (int(DomainTypes.tensor_product), int(DomainTypes.simplex)):
         raise OptimalLearningException("ERROR: invalid domain choice. Setting all coordinates to 0.0.")
-    if kg and int(optimizer_parameters.domain_type) != int(DomainTypes.tensor_product):
-        raise OptimalLearningException("knowledge gradient over DomainTypes.simplex is not implemented on the device path "
-                                       "(the inner optimisation would have to run over the simplex as well)")
 
 
 def _domain_name(optimizer_parameters):

@@ -896,6 +896,9 @@ KgPending kg_launch(GpDev& gp, int num_fidelity, const moe_gd_params_t& gd, cons
     throw Error(MOE_ERR_INVALID_VALUE, "MC shard must be an even-aligned slice of [0, num_mc)", first_sample, 0, 0);
   if (gd.max_num_steps <= 0) throw Error(MOE_ERR_BOUNDS, "max_num_steps must be positive", gd.max_num_steps, 1, 1e9);
   const int size = d - f;
+  if (gd.domain_type != MOE_DOMAIN_TENSOR_PRODUCT && gd.domain_type != MOE_DOMAIN_SIMPLEX)
+    throw Error(MOE_ERR_INVALID_VALUE, "unknown domain_type (0 = tensor product, 1 = simplex)", gd.domain_type, 0, 1);
+  const bool simplex = gd.domain_type == MOE_DOMAIN_SIMPLEX;  // the inner optimisations' domain (r4)
   const int A = u + P;
   // derivative-weight slots of the MC kernel instantiation: one per observed derivative up to 4, then 8 or 12 (unused slots
   // carry zero weights); more than 4 always take the workgroup-per-sample kernel
@@ -1025,6 +1028,8 @@ KgPending kg_launch(GpDev& gp, int num_fidelity, const moe_gd_params_t& gd, cons
     // (shapes the LDS-slab wave-per-sample kernel is not built for keep to the other two)
     if (!(forced == 0 && (G > 4 || m > kMaxM))) variant = forced;
   }
+  // (the simplex update lives in line_search_lds: the streamed-weights or the workgroup-per-sample kernel)
+  if (simplex && variant == 0) variant = stream_ok ? 2 : 1;
   if (variant == 1 && (tr < 0 || kg_mc_block_lds_bytes(dp, G, num_lds_tiles) > (size_t)160 * 1024))
     throw Error(MOE_ERR_RUNTIME, "point set too large for the workgroup-per-sample MC kernel");
   if (variant == 0 && waves < 1)
@@ -1142,11 +1147,29 @@ KgPending kg_launch(GpDev& gp, int num_fidelity, const moe_gd_params_t& gd, cons
   double* blob = gp.hKgIn.p;
   std::memset(blob, 0, sizeof(double) * blob_size);
   unsigned int free_mask = 0;  // table-row order: bounds of row r = bounds of original dimension perm[r]
+  // (simplex inner domain, SimplexIntersectTensorProductDomain's constructor, gpp_domain.cpp:107-141: the box clipped to the unit
+  //  hypercube; an empty intersection is the reference's BoundsException)
+  std::vector<double> box(bounds, bounds + 2 * (size_t)size);
+  if (simplex) {
+    double corner_sum = 0.0;
+    bool empty = false;
+    for (int k = 0; k < size; ++k) {
+      box[2 * k] = std::fmax(bounds[2 * k], 0.0);
+      box[2 * k + 1] = std::fmin(bounds[2 * k + 1], 1.0);
+      empty = empty || box[2 * k] > box[2 * k + 1];
+      corner_sum += box[2 * k];
+    }
+    if (corner_sum >= 1.0 || empty)
+      throw Error(MOE_ERR_BOUNDS,
+                  "Simplex/Tensor product intersection is EMPTY; 'lower left' corner coordinate sum out of bounds or bounding "
+                  "boxes do not intersect.",
+                  corner_sum, 0.0, 1.0);
+  }
   for (int r = 0; r < kMaxDimPadded; ++r) {
     const int k = tp.perm[r];
     if (k < size) {
-      blob[o_bounds + 2 * r] = bounds[2 * k];
-      blob[o_bounds + 2 * r + 1] = bounds[2 * k + 1];
+      blob[o_bounds + 2 * r] = box[2 * k];
+      blob[o_bounds + 2 * r + 1] = box[2 * k + 1];
       free_mask |= 1u << r;
     }
     blob[o_bounds + 2 * kMaxDimPadded + r] = tp.center[r];
@@ -1290,6 +1313,13 @@ KgPending kg_launch(GpDev& gp, int num_fidelity, const moe_gd_params_t& gd, cons
   mp.gamma = gd.gamma;
   mp.pre_mult = gd.pre_mult;
   mp.max_relative_change = gd.max_relative_change;
+  // (gpp_domain.cpp:245-247: the simplex update never lands precisely on a wall -- kRelativeChangeEpsilonTweak)
+  if (simplex && mp.max_relative_change == 1.0) mp.max_relative_change -= 4.0 * 2.220446049250313e-16;
+  mp.simplex = simplex ? 1 : 0;
+  mp.inv_sqrt_size = 1.0 / std::sqrt((double)size);
+  for (int r = 0; r < kMaxDimPadded; ++r) mp.inv_perm[r] = 0;
+  for (int r = 0; r < kMaxDimPadded; ++r)
+    if (tp.perm[r] >= 0 && tp.perm[r] < kMaxDimPadded) mp.inv_perm[tp.perm[r]] = r;
   mp.tolerance = gd.tolerance;
   mp.best_point = dBestPoint.p;
   mp.best_value = dBestValue.p;

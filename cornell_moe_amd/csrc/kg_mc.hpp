@@ -73,6 +73,10 @@ struct KgMcParams {
   double inv_lp[kMaxDimPadded];  // frame scale of table row r (row r holds original dimension perm[r]): 1 / length for the squared
                                  // exponential, sqrt(5) / length for Matern-5/2 (radial3 then needs no sqrt(5)); 0 in pad rows
   int perm[kMaxDimPadded];       // the GP's observed-derivative dimensions come first: perm[a] = derivatives[a], a < g
+  int inv_perm[kMaxDimPadded];   // table row of original dimension j (the simplex update walks the coordinates in the reference's order)
+  int simplex;                   // inner domain: 0 = tensor product, 1 = its intersection with the unit simplex (line_search_lds only:
+                                 // kg_launch keeps such evaluations off the LDS-slab wave-per-sample kernel)
+  double inv_sqrt_size;          // 1 / sqrt(dim - f): the components of the diagonal face's unit normal
   int n, g, N, u, m, f, A, ntiles, E;
   int multi_trial;  // 0: one Armijo trial per pass only (point sets spanning > 100 length scales: the projected distances of the
                     // multi-trial passes lose absolute accuracy with the square of the trial's offset)
@@ -1173,6 +1177,62 @@ __device__ __forceinline__ double line_search_frame(const KgMcParams& P, const d
   return fcur;
 }
 
+// SimplexIntersectTensorProductDomain::LimitUpdate's second half (gpp_domain.cpp:255-289) on the wave's LDS rows: xs / ss = the
+// current point and the step AFTER the tensor-product limit (table-row order; pinned rows hold a zero step), walked in the reference's
+// coordinate order j = 0 .. size - 1 through inv_perm.  If the proposed point leaves the unit simplex the step becomes
+// relaxed * (step / norm) -- half the distance to the diagonal face along its own direction; returns whether it does.  Every lane
+// computes the same scalars (uniform LDS reads).
+__device__ __forceinline__ bool simplex_limit(const KgMcParams& P, const double* __restrict__ xs, const double* __restrict__ ss,
+                                              double& relaxed, double& norm) {
+  const int size = P.dim - P.f;
+  // VectorNorm (gpp_linear_algebra.cpp:53-72): the scaled recurrence
+  if (size == 1) {
+    norm = fabs(ss[P.inv_perm[0]]);
+  } else {
+    double sc = 0.0, scaled = 1.0;
+    for (int j = 0; j < size; ++j) {
+      const double v = ss[P.inv_perm[j]];
+      if (v != 0.0) {
+        const double a = fabs(v);
+        if (sc < a) {
+          const double t = sc / a;
+          scaled = 1.0 + scaled * (t * t);
+          sc = a;
+        } else {
+          const double t = a / sc;
+          scaled += t * t;
+        }
+      }
+    }
+    norm = sc * sqrt(scaled);
+  }
+  if (norm == 0.0) norm = 2.2250738585072014e-308;
+  // CheckPointInUnitSimplex (gpp_geometry.hpp:313-325) on x + step
+  bool inside = true;
+  double sum = 0.0;
+  for (int j = 0; j < size; ++j) {
+    const int r = P.inv_perm[j];
+    const double nx = xs[r] + ss[r];
+    if (nx < 0.0) inside = false;
+    sum += nx;
+  }
+  inside = inside && (sum - 4.0 * 2.220446049250313e-16) <= 1.0;
+  relaxed = 0.0;
+  if (inside) return false;
+  // Plane::DistanceToPlaneAlongVector (gpp_geometry.hpp:252-272) for the plane sum x_i / sqrt(size) - 1 / sqrt(size) = 0
+  double xn = 0.0, vn = 0.0;
+  for (int j = 0; j < size; ++j) {
+    const int r = P.inv_perm[j];
+    xn += xs[r] * P.inv_sqrt_size;
+    vn += (ss[r] / norm) * P.inv_sqrt_size;
+  }
+  const double numerator = P.inv_sqrt_size - xn;
+  double dist = (vn == 0.0) ? (numerator == 0.0 ? 0.0 : INFINITY) : numerator / vn;
+  if (dist < 0.0) dist = 0.0;
+  relaxed = 0.5 * dist;  // kInvalidStepScaleFactor
+  return true;
+}
+
 // The same line search with its wave-uniform vectors (x, grad, step, x at restart start) parked in an LDS scratch `st`
 // (4 x kMaxDimPadded doubles, private to the wave) between evaluations, for kernels whose registers are better spent on
 // point data (workgroup-per-sample variant: the evaluator's __syncthreads is an LDS fence, so nothing is cached across
@@ -1319,6 +1379,13 @@ __device__ __forceinline__ double line_search_lds(const KgMcParams& P, EV& ev, d
         const double want_l = alpha_n * sG[lk];
         double step_l = 0.0;
         if (free_l) step_l = limit_update_1d(lo_l, hi_l, P.max_relative_change, sX[lk], want_l);
+        if (P.simplex != 0) {  // (the bounds are the box clipped to the unit hypercube, max_relative_change carries the reference's tweak)
+          if (lane_id < DP) sS[lane_id] = step_l;
+          __builtin_amdgcn_wave_barrier();
+          double relaxed, vnorm;
+          if (simplex_limit(P, sX, sS, relaxed, vnorm)) step_l = free_l ? relaxed * (step_l / vnorm) : 0.0;
+          __builtin_amdgcn_wave_barrier();
+        }
         changed = __ballot(free_l && step_l != want_l) != 0ull;
         nonzero = __ballot(free_l && step_l != 0.0) != 0ull;
         if (lane_id < DP) sS[lane_id] = step_l;  // read back below by every lane of this wave (in-order LDS, same wave)

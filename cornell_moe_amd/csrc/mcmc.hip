@@ -175,9 +175,6 @@ void kg_mcmc_multistart(const std::vector<GpDev*>& gps, int num_fidelity, const 
                         const double* starts, int num_starts, const double* Xp, int q, int p, int num_mc,
                         const double* best_so_far, const double* normals, int do_gradient_ascent, double* best_points,
                         double* best_kg, int* found) {
-  if (outer.domain_type != MOE_DOMAIN_TENSOR_PRODUCT)
-    throw Error(MOE_ERR_INVALID_VALUE, "KG over the simplex domain is not implemented (see kg_multistart); the EI optimisers take it",
-                outer.domain_type, 0, 0);
   check_ensemble(gps);
   if (num_starts <= 0) throw Error(MOE_ERR_BOUNDS, "num_multistarts must be > 1", num_starts, 1, 1e9);
   const int d = gps[0]->d, qd = q * d, nm = (int)gps.size();

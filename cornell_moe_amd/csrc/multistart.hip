@@ -295,11 +295,8 @@ void kg_multistart(GpDev& gp, int num_fidelity, const moe_gd_params_t& outer, co
                    int num_mc, double best_so_far, const double* normals, int do_gradient_ascent, double* best_points,
                    double* best_kg, int* found) {
   const int d = gp.d, qd = q * d;
-  if (outer.domain_type != MOE_DOMAIN_TENSOR_PRODUCT)
-    throw Error(MOE_ERR_INVALID_VALUE,
-                "KG over the simplex domain is not implemented: the reference then runs every sample's INNER optimisation over the "
-                "simplex as well (gpp_python_knowledge_gradient.cpp:288-296); the EI optimisers take it",
-                outer.domain_type, 0, 0);
+  // (the reference builds outer AND inner domain of one type, gpp_python_knowledge_gradient.cpp:288-296; here each parameter struct
+  //  carries its own: the MC kernels' line search takes the inner one -- kg.hip kg_launch)
   // The reference builds its evaluation states at the FIRST start and moves them with SetCurrentPoint, which leaves the
   // discretised set behind (kg.hpp: disc_head): every evaluation of the run scores / starts its inner optimisation from the
   // first start's q points.  Reproduced: the end point is pinned to the reference's (tests/golden/ref_kg_multistart.npz).
@@ -358,6 +355,7 @@ void posterior_mean_optimize(GpDev& gp, int num_fidelity, const moe_gd_params_t&
     return -mu;
   };
   double fcur = f(x.data(), nullptr);
+  const DomainLimiter limiter(gd, bounds, size);
   const double step_tol = gd.tolerance / (double)std::max(gd.max_num_steps, 1);
   for (int r = 0; r < gd.max_num_restarts; ++r) {
     x_begin = x;
@@ -375,10 +373,10 @@ void posterior_mean_optimize(GpDev& gp, int num_fidelity, const moe_gd_params_t&
         alpha *= 0.5;
       }
       bool changed = false, nonzero = false;
+      for (int k = 0; k < size; ++k) step[k] = alpha * g[k];
+      limiter.apply(gd.max_relative_change, x.data(), step.data(), size);  // (tensor product or simplex: gd.domain_type)
       for (int k = 0; k < size; ++k) {
-        const double want = alpha * g[k];
-        step[k] = limit_update_1d(bounds[2 * k], bounds[2 * k + 1], gd.max_relative_change, x[k], want);
-        changed = changed || step[k] != want;
+        changed = changed || step[k] != alpha * g[k];
         nonzero = nonzero || step[k] != 0.0;
       }
       if (search == 30 || !nonzero) break;

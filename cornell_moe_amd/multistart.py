@@ -88,12 +88,13 @@ def kg_optimal_points(dev_gp, num_fidelity, optimizer_parameters, optimizer_para
     d = dev_gp.d
     q = int(num_to_sample)
     bounds = np.asarray(bounds, dtype=np.float64).reshape(-1)[:2 * d]
-    inner_gd = _gd(optimizer_parameters_inner)
+    # (the reference builds the inner domain -- every sample's posterior-mean optimisation -- of the OUTER parameters' type,
+    #  gpp_python_knowledge_gradient.cpp:279-296)
+    dom = _domain_type(optimizer_parameters)
+    inner_gd = _gd(optimizer_parameters_inner, dom)
     p = 0 if Xp is None else np.asarray(Xp).reshape(-1, d).shape[0]
     m = (q + p) * (1 + dev_gp.g)
     normals = randomness.normal_rng_vec[0].table(((num_mc + 1) // 2) * m)
-
-    dom = _domain_type(optimizer_parameters)
 
     def lhc(count):
         return _starts(randomness, bounds, count, q, d, dom)
@@ -110,7 +111,7 @@ def kg_optimal_points(dev_gp, num_fidelity, optimizer_parameters, optimizer_para
     if not found:
         n_lhc = int(optimizer_parameters.num_random_samples or 0)
         if n_lhc > 0:
-            best, _, found = dev_gp.kg_multistart(_gd(optimizer_parameters_inner), inner_gd, bounds, discrete, lhc(n_lhc), Xp,
+            best, _, found = dev_gp.kg_multistart(inner_gd, inner_gd, bounds, discrete, lhc(n_lhc), Xp,
                                                   num_mc, best_so_far, normals, gradient_ascent=False,
                                                   num_fidelity=num_fidelity)
     return best, found
@@ -155,12 +156,12 @@ def kg_mcmc_optimal_points(dev_mcmc, num_fidelity, optimizer_parameters, optimiz
     from . import GPP
     d, q = dev_mcmc.d, int(num_to_sample)
     bounds = np.asarray(bounds, dtype=np.float64).reshape(-1)[:2 * d]
-    inner_gd = _gd(optimizer_parameters_inner)
+    dom = _domain_type(optimizer_parameters)
+    inner_gd = _gd(optimizer_parameters_inner, dom)
     p = 0 if Xp is None else np.asarray(Xp).reshape(-1, d).shape[0]
     normals = randomness.normal_rng_vec[0].table(((num_mc + 1) // 2) * (q + p) * (1 + dev_mcmc.g))
     use_gd = int(optimizer_parameters.optimizer_type) == int(GPP.OptimizerTypes.gradient_descent)
     best, found = np.zeros((q, d)), False
-    dom = _domain_type(optimizer_parameters)
     if use_gd:
         gd = _gd(optimizer_parameters, dom)
         best, _, found = dev_mcmc.kg_multistart(gd, inner_gd, bounds, discrete_all, _starts(randomness, bounds, gd[0], q, d, dom), Xp,
@@ -201,6 +202,7 @@ def ei_mcmc_optimal_points(dev_mcmc, optimizer_parameters, bounds, Xp, num_to_sa
 def posterior_mean_optimization(dev_gp, num_fidelity, optimizer_parameters, bounds, initial_guess):
     """ComputeOptimalPosteriorMean from ONE start (moe_posterior_mean_optimize).  Returns (best_point, found_flag)."""
     size = dev_gp.d - num_fidelity
-    best, _ = dev_gp.posterior_mean_optimize(_gd(optimizer_parameters), np.asarray(bounds, dtype=np.float64).reshape(-1)[:2 * size],
+    gd = _gd(optimizer_parameters, _domain_type(optimizer_parameters))  # (gpp_python_knowledge_gradient.cpp:327-341)
+    best, _ = dev_gp.posterior_mean_optimize(gd, np.asarray(bounds, dtype=np.float64).reshape(-1)[:2 * size],
                                              np.asarray(initial_guess, dtype=np.float64).reshape(-1)[:size], num_fidelity)
     return best, True

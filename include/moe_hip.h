@@ -57,10 +57,13 @@ typedef struct moe_gd_params {
   double pre_mult;
   double max_relative_change;
   double tolerance;
-  int domain_type; /* OUTER optimisers only (r4): 0 = tensor-product domain, 1 = its intersection with the unit simplex
-                      {x_i >= 0, sum x_i <= 1} applied to each of the q points (SimplexIntersectTensorProductDomain,
-                      gpp_domain.hpp:215-349; the dispatch of gpp_python_knowledge_gradient.cpp:288-296).  Ignored for the
-                      inner optimisation of a KG evaluation, whose domain is always a tensor product. */
+  int domain_type; /* (r4) 0 = tensor-product domain, 1 = its intersection with the unit simplex {x_i >= 0, sum x_i <= 1}
+                      (SimplexIntersectTensorProductDomain, gpp_domain.hpp:215-349; gpp_domain.cpp:234-290).  In the OUTER parameters
+                      of a multistart driver: applied to each of the q points (RepeatedDomain).  In the INNER parameters of a KG
+                      evaluation / driver and in moe_posterior_mean_optimize: the domain of every sample's posterior-mean
+                      optimisation over the dim - num_fidelity free coordinates (the reference builds both of one type:
+                      gpp_python_knowledge_gradient.cpp:279-296, 327-341; its single-evaluation entry points always pass a
+                      tensor product: :97-144). */
 } moe_gd_params_t;
 #define MOE_DOMAIN_TENSOR_PRODUCT 0
 #define MOE_DOMAIN_SIMPLEX 1

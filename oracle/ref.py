@@ -62,6 +62,10 @@ def lib():
         _lib.ref_log_likelihood.argtypes = [C.c_int, C.c_double, _dp, _dp, _dp, _dp, _ip, C.c_int, C.c_int, C.c_int, _dp]
         _lib.ref_kg.argtypes = [C.c_void_p, C.c_int, _dp, _dp, _dp, C.c_int, _dp, _dp, C.c_int, C.c_int, C.c_int,
                                 C.c_double, _dp, C.c_long, C.c_int, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp]
+        _lib.ref_kg_dom.argtypes = [C.c_void_p, C.c_int, _dp, _dp, _dp, C.c_int, _dp, _dp, C.c_int, C.c_int, C.c_int,
+                                    C.c_double, _dp, C.c_long, C.c_int, C.c_int, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp]
+        _lib.ref_kg_multistart_dom.argtypes = [C.c_void_p, C.c_int, _dp, _dp, _dp, _dp, _dp, C.c_int, _dp, C.c_int, _dp, C.c_int,
+                                               C.c_int, C.c_int, C.c_double, C.c_uint, C.c_int, C.POINTER(C.c_int), _dp]
         _lib.ref_normal_draws.argtypes = [C.c_uint, C.c_long, _dp]
         _lib.ref_kg_multistart.argtypes = [C.c_void_p, C.c_int, _dp, _dp, _dp, _dp, _dp, C.c_int, _dp, C.c_int, _dp, C.c_int,
                                            C.c_int, C.c_int, C.c_double, C.c_uint, C.POINTER(C.c_int), _dp]
@@ -251,8 +255,10 @@ class RefGP(object):
                                                     best.ctypes.data_as(_dp)))
         return best, bool(found.value)
 
-    def kg(self, gd, bounds, discrete, Xq, Xp, M, best_so_far, normals, want_grad=True, num_fidelity=0, details=False):
-        """Returns dict(kg, grad[q,d], best_point[M,d], seconds=(state, eval), ...)."""
+    def kg(self, gd, bounds, discrete, Xq, Xp, M, best_so_far, normals, want_grad=True, num_fidelity=0, details=False,
+           domain_type=0):
+        """Returns dict(kg, grad[q,d], best_point[M,d], seconds=(state, eval), ...).  domain_type 1: the inner optimisations over
+        SimplexIntersectTensorProductDomain (what the reference builds for DomainTypes::kSimplex)."""
         gd, gdp = _d(gd)
         bounds, bp = _d(bounds)
         discrete, dp = _d(discrete)
@@ -276,9 +282,9 @@ class RefGP(object):
         cic = np.zeros(m * M)
         sec = np.zeros(2)
         P_ = lambda a: a.ctypes.data_as(_dp)  # noqa: E731
-        _check(lib().ref_kg(self.h, num_fidelity, gdp, bp, dp, P, qp, pp, q, p, M, best_so_far, npp, normals.size,
-                            1 if want_grad else 0, C.byref(kg), P_(grad), P_(best_point), P_(tsm), P_(chol), P_(gchol),
-                            P_(cic), P_(sec)))
+        _check(lib().ref_kg_dom(self.h, num_fidelity, gdp, bp, dp, P, qp, pp, q, p, M, best_so_far, npp, normals.size,
+                                1 if want_grad else 0, int(domain_type), C.byref(kg), P_(grad), P_(best_point), P_(tsm), P_(chol),
+                                P_(gchol), P_(cic), P_(sec)))
         out = dict(kg=kg.value, grad=grad.reshape(q, self.d) if want_grad else None,
                    best_point=best_point.reshape(M, self.d), seconds=(sec[0], sec[1]))
         if details:
@@ -286,9 +292,10 @@ class RefGP(object):
                        chol_inverse_cov=cic.reshape(M, m))
         return out
 
-    def kg_multistart(self, gd_outer, gd_inner, bounds, discrete, starts, Xp, M, best_so_far, seed, num_fidelity=0):
+    def kg_multistart(self, gd_outer, gd_inner, bounds, discrete, starts, Xp, M, best_so_far, seed, num_fidelity=0, domain_type=0):
         """ComputeKGOptimalPointsToSampleViaMultistartGradientDescent (one thread) with NormalRNG(seed):
-        (best_points [q,d], found).  starts[S][q][d], S >= 20.  The normal table the run consumed is normal_draws(seed, ...)."""
+        (best_points [q,d], found).  starts[S][q][d], S >= 20.  The normal table the run consumed is normal_draws(seed, ...).
+        domain_type 1: outer AND inner domain SimplexIntersectTensorProductDomain."""
         gdo, gop = _d(gd_outer)
         gdi, gip = _d(gd_inner)
         bounds, bp = _d(bounds)
@@ -305,9 +312,9 @@ class RefGP(object):
             p = Xp_.reshape(-1, self.d).shape[0]
         found = C.c_int(0)
         best = np.zeros(q * self.d)
-        _check(lib().ref_kg_multistart(self.h, num_fidelity, gop, gip, bp, inner_bounds.ctypes.data_as(_dp), dp, P,
-                                       starts.ctypes.data_as(_dp), S, pp, q, p, M, best_so_far, seed, C.byref(found),
-                                       best.ctypes.data_as(_dp)))
+        _check(lib().ref_kg_multistart_dom(self.h, num_fidelity, gop, gip, bp, inner_bounds.ctypes.data_as(_dp), dp, P,
+                                           starts.ctypes.data_as(_dp), S, pp, q, p, M, best_so_far, seed, int(domain_type),
+                                           C.byref(found), best.ctypes.data_as(_dp)))
         return best.reshape(q, self.d), bool(found.value)
 
     def kg_seeded(self, gd, bounds, discrete, Xq, Xp, M, best_so_far, seed, num_fidelity=0):

@@ -302,46 +302,75 @@ int ref_ei_multistart_analytic(void* hv, const double* gd, const double* bounds,
 // normals: table of ceil(M/2)*m values, m = (q+p)(1+g) (only even samples draw; odd ones are antithetic, .cpp:171-180).
 // Optional outputs (may be NULL): grad[q*d]; best_point[M*d]; to_sample_mean[m]; chol_var[m*m]; grad_chol[d*m*m*q];
 // chol_inverse_cov[m*M]; seconds[2] = {state construction, evaluation}.
+}  // extern "C"
+
+namespace {
+// ref_kg's body for either inner domain (DomainTypes::kTensorProduct / kSimplex, gpp_python_knowledge_gradient.cpp:288-296: the
+// inner optimisations of a KG evaluation run over the SAME domain type as the outer one)
+template <typename DomainT>
+void kg_body(GaussianProcess* gp, int num_fidelity, const double* gd, const double* bounds, const double* discrete, int P,
+             const double* Xq, const double* Xp, int q, int p, int M, double best_so_far, const double* normals,
+             long num_normals, int want_grad, double* kg, double* grad, double* best_point, double* to_sample_mean,
+             double* chol_var, double* grad_chol, double* chol_inverse_cov, double* seconds) {
+  const int d = gp->dim();
+  std::vector<ClosedInterval> iv(d - num_fidelity);
+  for (int i = 0; i < d - num_fidelity; ++i) iv[i] = ClosedInterval(bounds[2 * i], bounds[2 * i + 1]);
+  DomainT dom(iv.data(), d - num_fidelity);
+  GradientDescentParameters gdp(static_cast<int>(gd[0]), static_cast<int>(gd[1]), static_cast<int>(gd[2]),
+                                static_cast<int>(gd[3]), gd[4], gd[5], gd[6], gd[7]);
+  std::vector<double> table(normals, normals + num_normals);
+  NormalRNGSimulator rng(table);
+  double dummy = 0.0;
+  auto t0 = std::chrono::steady_clock::now();
+  KnowledgeGradientEvaluator<DomainT> ev(*gp, num_fidelity, discrete, P, M, dom, gdp, best_so_far);
+  typename KnowledgeGradientEvaluator<DomainT>::StateType st(ev, Xq, p > 0 ? Xp : &dummy, q, p, P, nn(gp->derivatives().data()),
+                                                            gp->num_derivatives(), want_grad != 0, &rng);
+  auto t1 = std::chrono::steady_clock::now();
+  double val;
+  if (want_grad) {
+    std::vector<double> gtmp(static_cast<size_t>(q) * d);
+    val = ev.ComputeGradKnowledgeGradient(&st, gtmp.data());
+    if (grad) std::copy(gtmp.begin(), gtmp.end(), grad);
+  } else {
+    val = ev.ComputeKnowledgeGradient(&st);
+  }
+  auto t2 = std::chrono::steady_clock::now();
+  if (kg) *kg = val;
+  if (best_point) std::copy(st.best_point.begin(), st.best_point.end(), best_point);
+  if (to_sample_mean) std::copy(st.to_sample_mean_.begin(), st.to_sample_mean_.end(), to_sample_mean);
+  if (chol_var) std::copy(st.cholesky_to_sample_var.begin(), st.cholesky_to_sample_var.end(), chol_var);
+  if (grad_chol && want_grad) std::copy(st.grad_chol_decomp.begin(), st.grad_chol_decomp.end(), grad_chol);
+  if (chol_inverse_cov && want_grad) std::copy(st.chol_inverse_cov.begin(), st.chol_inverse_cov.end(), chol_inverse_cov);
+  if (seconds) {
+    seconds[0] = std::chrono::duration<double>(t1 - t0).count();
+    seconds[1] = std::chrono::duration<double>(t2 - t1).count();
+  }
+}
+}  // namespace
+
+extern "C" {
+int ref_kg_dom(void* hv, int num_fidelity, const double* gd, const double* bounds, const double* discrete, int P,
+               const double* Xq, const double* Xp, int q, int p, int M, double best_so_far, const double* normals,
+               long num_normals, int want_grad, int domain_type, double* kg, double* grad, double* best_point,
+               double* to_sample_mean, double* chol_var, double* grad_chol, double* chol_inverse_cov, double* seconds) {
+  return guarded([&] {
+    GaussianProcess* gp = static_cast<RefGP*>(hv)->gp;
+    if (domain_type == 1)
+      kg_body<SimplexIntersectTensorProductDomain>(gp, num_fidelity, gd, bounds, discrete, P, Xq, Xp, q, p, M, best_so_far, normals,
+                                                   num_normals, want_grad, kg, grad, best_point, to_sample_mean, chol_var,
+                                                   grad_chol, chol_inverse_cov, seconds);
+    else
+      kg_body<TensorProductDomain>(gp, num_fidelity, gd, bounds, discrete, P, Xq, Xp, q, p, M, best_so_far, normals, num_normals,
+                                   want_grad, kg, grad, best_point, to_sample_mean, chol_var, grad_chol, chol_inverse_cov, seconds);
+  });
+}
+
 int ref_kg(void* hv, int num_fidelity, const double* gd, const double* bounds, const double* discrete, int P,
            const double* Xq, const double* Xp, int q, int p, int M, double best_so_far, const double* normals,
            long num_normals, int want_grad, double* kg, double* grad, double* best_point, double* to_sample_mean,
            double* chol_var, double* grad_chol, double* chol_inverse_cov, double* seconds) {
-  return guarded([&] {
-    GaussianProcess* gp = static_cast<RefGP*>(hv)->gp;
-    const int d = gp->dim();
-    std::vector<ClosedInterval> iv(d - num_fidelity);
-    for (int i = 0; i < d - num_fidelity; ++i) iv[i] = ClosedInterval(bounds[2 * i], bounds[2 * i + 1]);
-    TensorProductDomain dom(iv.data(), d - num_fidelity);
-    GradientDescentParameters gdp(static_cast<int>(gd[0]), static_cast<int>(gd[1]), static_cast<int>(gd[2]),
-                                  static_cast<int>(gd[3]), gd[4], gd[5], gd[6], gd[7]);
-    std::vector<double> table(normals, normals + num_normals);
-    NormalRNGSimulator rng(table);
-    double dummy = 0.0;
-    auto t0 = std::chrono::steady_clock::now();
-    KnowledgeGradientEvaluator<TensorProductDomain> ev(*gp, num_fidelity, discrete, P, M, dom, gdp, best_so_far);
-    KnowledgeGradientEvaluator<TensorProductDomain>::StateType st(
-        ev, Xq, p > 0 ? Xp : &dummy, q, p, P, nn(gp->derivatives().data()), gp->num_derivatives(), want_grad != 0, &rng);
-    auto t1 = std::chrono::steady_clock::now();
-    double val;
-    if (want_grad) {
-      std::vector<double> gtmp(static_cast<size_t>(q) * d);
-      val = ev.ComputeGradKnowledgeGradient(&st, gtmp.data());
-      if (grad) std::copy(gtmp.begin(), gtmp.end(), grad);
-    } else {
-      val = ev.ComputeKnowledgeGradient(&st);
-    }
-    auto t2 = std::chrono::steady_clock::now();
-    if (kg) *kg = val;
-    if (best_point) std::copy(st.best_point.begin(), st.best_point.end(), best_point);
-    if (to_sample_mean) std::copy(st.to_sample_mean_.begin(), st.to_sample_mean_.end(), to_sample_mean);
-    if (chol_var) std::copy(st.cholesky_to_sample_var.begin(), st.cholesky_to_sample_var.end(), chol_var);
-    if (grad_chol && want_grad) std::copy(st.grad_chol_decomp.begin(), st.grad_chol_decomp.end(), grad_chol);
-    if (chol_inverse_cov && want_grad) std::copy(st.chol_inverse_cov.begin(), st.chol_inverse_cov.end(), chol_inverse_cov);
-    if (seconds) {
-      seconds[0] = std::chrono::duration<double>(t1 - t0).count();
-      seconds[1] = std::chrono::duration<double>(t2 - t1).count();
-    }
-  });
+  return ref_kg_dom(hv, num_fidelity, gd, bounds, discrete, P, Xq, Xp, q, p, M, best_so_far, normals, num_normals, want_grad, 0, kg,
+                    grad, best_point, to_sample_mean, chol_var, grad_chol, chol_inverse_cov, seconds);
 }
 
 // ---- MCMC-averaged evaluators: GaussianProcessMCMC (gpp_knowledge_gradient_mcmc_optimization.cpp:24-49),
@@ -522,30 +551,56 @@ int ref_kg_seeded(void* hv, int num_fidelity, const double* gd, const double* bo
 
 // gd_outer / gd_inner as in ref_kg; bounds[2*d] (outer domain, all d coordinates), inner_bounds[2*(d-num_fidelity)];
 // starts[num_starts][q][d] (num_starts >= 20: the reference pops its 20-deep queue unconditionally); best_point[q][d].
+}  // extern "C"
+
+namespace {
+template <typename DomainT>
+void kg_multistart_body(GaussianProcess* gp, int num_fidelity, const double* gd_outer, const double* gd_inner, const double* bounds,
+                        const double* inner_bounds, const double* discrete, int P, const double* starts, int num_starts,
+                        const double* Xp, int q, int p, int M, double best_so_far, unsigned int seed, int* found,
+                        double* best_point) {
+  const int d = gp->dim();
+  std::vector<ClosedInterval> iv(d), ivi(d - num_fidelity);
+  for (int i = 0; i < d; ++i) iv[i] = ClosedInterval(bounds[2 * i], bounds[2 * i + 1]);
+  for (int i = 0; i < d - num_fidelity; ++i) ivi[i] = ClosedInterval(inner_bounds[2 * i], inner_bounds[2 * i + 1]);
+  DomainT dom(iv.data(), d), inner_dom(ivi.data(), d - num_fidelity);
+  GradientDescentParameters gdo(static_cast<int>(gd_outer[0]), static_cast<int>(gd_outer[1]), static_cast<int>(gd_outer[2]),
+                                static_cast<int>(gd_outer[3]), gd_outer[4], gd_outer[5], gd_outer[6], gd_outer[7]);
+  GradientDescentParameters gdi(static_cast<int>(gd_inner[0]), static_cast<int>(gd_inner[1]), static_cast<int>(gd_inner[2]),
+                                static_cast<int>(gd_inner[3]), gd_inner[4], gd_inner[5], gd_inner[6], gd_inner[7]);
+  ThreadSchedule sched(1, omp_sched_static);
+  NormalRNG rng(seed);
+  double dummy = 0.0;
+  bool found_flag = false;
+  ComputeKGOptimalPointsToSampleViaMultistartGradientDescent(*gp, num_fidelity, gdo, gdi, dom, inner_dom, sched, starts,
+                                                             p > 0 ? Xp : &dummy, discrete, num_starts, q, p, P, best_so_far, M,
+                                                             &rng, &found_flag, best_point);
+  *found = found_flag ? 1 : 0;
+}
+}  // namespace
+
+extern "C" {
+int ref_kg_multistart_dom(void* hv, int num_fidelity, const double* gd_outer, const double* gd_inner, const double* bounds,
+                          const double* inner_bounds, const double* discrete, int P, const double* starts, int num_starts,
+                          const double* Xp, int q, int p, int M, double best_so_far, unsigned int seed, int domain_type, int* found,
+                          double* best_point) {
+  return guarded([&] {
+    GaussianProcess* gp = static_cast<RefGP*>(hv)->gp;
+    if (domain_type == 1)
+      kg_multistart_body<SimplexIntersectTensorProductDomain>(gp, num_fidelity, gd_outer, gd_inner, bounds, inner_bounds, discrete, P,
+                                                              starts, num_starts, Xp, q, p, M, best_so_far, seed, found, best_point);
+    else
+      kg_multistart_body<TensorProductDomain>(gp, num_fidelity, gd_outer, gd_inner, bounds, inner_bounds, discrete, P, starts,
+                                              num_starts, Xp, q, p, M, best_so_far, seed, found, best_point);
+  });
+}
+
 int ref_kg_multistart(void* hv, int num_fidelity, const double* gd_outer, const double* gd_inner, const double* bounds,
                       const double* inner_bounds, const double* discrete, int P, const double* starts, int num_starts,
                       const double* Xp, int q, int p, int M, double best_so_far, unsigned int seed, int* found,
                       double* best_point) {
-  return guarded([&] {
-    GaussianProcess* gp = static_cast<RefGP*>(hv)->gp;
-    const int d = gp->dim();
-    std::vector<ClosedInterval> iv(d), ivi(d - num_fidelity);
-    for (int i = 0; i < d; ++i) iv[i] = ClosedInterval(bounds[2 * i], bounds[2 * i + 1]);
-    for (int i = 0; i < d - num_fidelity; ++i) ivi[i] = ClosedInterval(inner_bounds[2 * i], inner_bounds[2 * i + 1]);
-    TensorProductDomain dom(iv.data(), d), inner_dom(ivi.data(), d - num_fidelity);
-    GradientDescentParameters gdo(static_cast<int>(gd_outer[0]), static_cast<int>(gd_outer[1]), static_cast<int>(gd_outer[2]),
-                                  static_cast<int>(gd_outer[3]), gd_outer[4], gd_outer[5], gd_outer[6], gd_outer[7]);
-    GradientDescentParameters gdi(static_cast<int>(gd_inner[0]), static_cast<int>(gd_inner[1]), static_cast<int>(gd_inner[2]),
-                                  static_cast<int>(gd_inner[3]), gd_inner[4], gd_inner[5], gd_inner[6], gd_inner[7]);
-    ThreadSchedule sched(1, omp_sched_static);
-    NormalRNG rng(seed);
-    double dummy = 0.0;
-    bool found_flag = false;
-    ComputeKGOptimalPointsToSampleViaMultistartGradientDescent(*gp, num_fidelity, gdo, gdi, dom, inner_dom, sched, starts,
-                                                               p > 0 ? Xp : &dummy, discrete, num_starts, q, p, P, best_so_far,
-                                                               M, &rng, &found_flag, best_point);
-    *found = found_flag ? 1 : 0;
-  });
+  return ref_kg_multistart_dom(hv, num_fidelity, gd_outer, gd_inner, bounds, inner_bounds, discrete, P, starts, num_starts, Xp, q, p,
+                               M, best_so_far, seed, 0, found, best_point);
 }
 
 // MCMC twin: discrete_all[num_mcmc][P][d - num_fidelity], best_so_far[num_mcmc].

@@ -248,7 +248,7 @@ comm.close()
 def test_simplex_domain_start_generation_and_dispatch():
     """r4: the host side of DomainTypes.simplex -- start sets by rejection from a Latin hypercube in the clipped box
     (SimplexIntersectTensorProductDomain::GenerateUniformPointsInDomain, gpp_domain.cpp:179-232, RepeatedDomain's transposition and
-    cut to the shortest repeat), the status-key name, and the KG entry points' refusal."""
+    cut to the shortest repeat), the status-key name, and the dispatch's refusal of an unknown domain type."""
     from cornell_moe_amd import GPP, multistart
 
     class Rng(object):
@@ -277,8 +277,13 @@ def test_simplex_domain_start_generation_and_dispatch():
 
     assert GPP._domain_name(P()) == "simplex_tensor_product"
     GPP._check_domain_type(P())
+    GPP._check_domain_type(P(), kg=True)   # (r4: KG takes the simplex too -- the MC kernels' line search carries the update)
+
+    class Bad(object):
+        domain_type = 7
+
     with pytest.raises(GPP.OptimalLearningException):
-        GPP._check_domain_type(P(), kg=True)
+        GPP._check_domain_type(Bad(), kg=True)
     assert multistart._gd(type("O", (), {"optimizer_parameters": type("Q", (), dict(
         num_multistarts=3, max_num_steps=4, max_num_restarts=1, num_steps_averaged=0, gamma=0.5, pre_mult=1.0,
         max_relative_change=0.3, tolerance=1e-6))()})(), 1)[8] == 1

@@ -314,6 +314,110 @@ def simplex_fixtures():
     print("wrote", OUT_SIMPLEX, os.path.getsize(OUT_SIMPLEX), "bytes")
 
 
+OUT_SIMPLEX_KG = os.path.join(ROOT, "tests", "golden", "ref_simplex_kg.npz")
+
+
+def simplex_kg_fixtures():
+    """Round 4: KG with the INNER optimisations over SimplexIntersectTensorProductDomain, from the unmodified reference
+    (KnowledgeGradientEvaluator<SimplexIntersectTensorProductDomain>, the instantiation behind DomainTypes::kSimplex in
+    gpp_python_knowledge_gradient.cpp:288-296), and its multistart driver with outer AND inner simplex domain.  Data whose posterior
+    mean falls towards the diagonal face, discretised points inside the simplex, inner optimisers that take enough steps to reach the
+    face; one case with max_relative_change = 1 (the epsilon tweak), one with a fidelity coordinate (the simplex then spans the free
+    coordinates only), one with an observed derivative (table rows permuted: the update must still walk the coordinates in order)."""
+    blob, k = {}, 0
+    for (seed, n, d, q, p, P, M, derivs, f, box, inner) in (
+            (8101, 40, 3, 2, 0, 6, 40, (), 0, (0.0, 1.0), (1, 20, 2, 3, 0.0, 1.0, 0.5, 1e-10)),
+            (8102, 36, 2, 2, 1, 5, 32, (), 0, (0.0, 1.0), (1, 15, 2, 3, 0.0, 2.0, 1.0, 1e-10)),
+            (8103, 40, 4, 2, 0, 6, 32, (), 1, (-0.1, 0.9), (1, 12, 2, 3, 0.0, 1.0, 0.3, 1e-10)),
+            (8104, 14, 3, 2, 0, 6, 32, (1,), 0, (0.0, 1.0), (1, 12, 1, 3, 0.0, 1.0, 0.4, 1e-10))):
+        rng = np.random.default_rng(seed)
+        g, size = len(derivs), d - f
+        c = dict(n=n, d=d, q=q, p=p, P=P, M=M, derivs=np.array(derivs, dtype=np.int32), num_fidelity=f, rng_seed=seed)
+
+        def in_simplex(count, hi):
+            pts = []
+            while len(pts) < count:
+                x = rng.uniform(max(box[0], 0.0) + 0.01, min(box[1], 1.0), size=size)
+                if x.sum() <= hi:
+                    pts.append(x)
+            return np.array(pts)
+        Xs = in_simplex(n, 0.9)
+        c["X"] = np.hstack([Xs, rng.uniform(0.3, 1.0, size=(n, f))]) if f else Xs
+        c["y"] = np.zeros((n, 1 + g))
+        c["y"][:, 0] = -1.5 * Xs.sum(1) + 0.2 * np.sin(5 * Xs).sum(1) + 0.05 * rng.uniform(size=n)   # lower = better beyond the face
+        for a, dd in enumerate(derivs):
+            c["y"][:, 1 + a] = -1.5 + np.cos(5 * c["X"][:, dd])
+        c["alpha"], c["lengths"], c["noise"] = 1.0, rng.uniform(0.3, 0.6, size=d), np.full(1 + g, 0.01)
+        c["bounds"] = np.tile(np.array(box), d)
+        if f:
+            c["bounds"][2 * size:] = np.tile([0.3, 1.0], f)
+        xq = in_simplex(q, 0.8)
+        c["Xq"] = np.hstack([xq, rng.uniform(0.4, 0.9, size=(q, f))]) if f else xq
+        xp = in_simplex(p, 0.8) if p else np.zeros((0, size))
+        c["Xp"] = (np.hstack([xp, rng.uniform(0.4, 0.9, size=(p, f))]) if f else xp) if p else np.zeros((0, d))
+        c["discrete"] = in_simplex(P, 0.85)
+        c["inner_gd"] = np.array(inner)
+        gp = ref.RefGP(1, c["alpha"], c["lengths"], c["X"], c["y"], c["noise"], list(derivs))
+        disc_full = np.hstack([c["discrete"], np.ones((P, f))]) if f else c["discrete"]
+        c["best_so_far"] = float(gp.additional_mean(disc_full).min())
+        m = (q + p) * (1 + g)
+        c["normals"] = rng.standard_normal((((M + 1) // 2), m))
+        Xp = c["Xp"] if p else None
+        r = gp.kg(c["inner_gd"], c["bounds"][: 2 * size], c["discrete"], c["Xq"], Xp, M, c["best_so_far"], c["normals"], num_fidelity=f,
+                  domain_type=1)
+        rt = gp.kg(c["inner_gd"], c["bounds"][: 2 * size], c["discrete"], c["Xq"], Xp, M, c["best_so_far"], c["normals"], num_fidelity=f,
+                   domain_type=0)
+        sums = r["best_point"][:, :size].sum(1)
+        print("simplex KG case %d: d=%d f=%d g=%d q=%d p=%d  KG=%.12g (tensor product: %.12g)  end points with sum > 0.99: %d of %d, max sum %.12f; "
+              "end points that differ from the tensor-product run: %d" % (k, d, f, g, q, p, r["kg"], rt["kg"], int((sums > 0.99).sum()), M,
+                                                                         sums.max(), int((np.abs(r["best_point"] - rt["best_point"]).max(1) > 1e-9).sum())))
+        for key, val in c.items():
+            blob["e%d_in_%s" % (k, key)] = np.asarray(val)
+        blob["e%d_out_kg" % k], blob["e%d_out_grad" % k], blob["e%d_out_best_point" % k] = np.array(r["kg"]), r["grad"], r["best_point"]
+        blob["e%d_out_kg_tensor" % k] = np.array(rt["kg"])
+        k += 1
+    blob["num_eval"] = np.array(k)
+    # the multistart driver, outer and inner domain simplex
+    k = 0
+    inner = np.array((1, 8, 1, 3, 0.0, 1.0, 0.3, 1e-10))
+    for (seed, n, d, q, P, M, outer) in ((8201, 40, 3, 1, 6, 32, (24, 6, 2, 4, 0.7, 0.3, 0.5, 1e-7)),
+                                         (8202, 36, 2, 2, 5, 32, (24, 5, 2, 4, 0.7, 0.2, 1.0, 1e-7))):
+        rng = np.random.default_rng(seed)
+        c = dict(n=n, d=d, q=q, p=0, P=P, M=M, derivs=np.array((), dtype=np.int32), num_fidelity=0, rng_seed=seed % 1000)
+
+        def in_simplex(count, hi):
+            pts = []
+            while len(pts) < count:
+                x = rng.uniform(0.01, 1.0, size=d)
+                if x.sum() <= hi:
+                    pts.append(x)
+            return np.array(pts)
+        c["X"] = in_simplex(n, 0.9)
+        c["y"] = (-1.5 * c["X"].sum(1) + 0.2 * np.sin(5 * c["X"]).sum(1) + 0.05 * rng.uniform(size=n))[:, None]
+        c["alpha"], c["lengths"], c["noise"] = 1.0, rng.uniform(0.3, 0.6, size=d), np.array([0.01])
+        c["bounds"] = np.tile([0.0, 1.0], d)
+        c["discrete"] = in_simplex(P, 0.85)
+        c["starts"] = in_simplex(24 * q, 0.9).reshape(24, q, d)
+        c["outer_gd"], c["inner_gd"] = np.array(outer), inner
+        gp = ref.RefGP(1, c["alpha"], c["lengths"], c["X"], c["y"], c["noise"], [])
+        c["best_so_far"] = float(gp.additional_mean(c["discrete"]).min())
+        c["normals"] = ref.normal_draws(c["rng_seed"], ((M + 1) // 2) * q).reshape(-1, q)
+        best, found = gp.kg_multistart(c["outer_gd"], inner, c["bounds"], c["discrete"], c["starts"], None, M, c["best_so_far"], c["rng_seed"],
+                                       domain_type=1)
+        best_tp, _ = gp.kg_multistart(c["outer_gd"], inner, c["bounds"], c["discrete"], c["starts"], None, M, c["best_so_far"], c["rng_seed"],
+                                      domain_type=0)
+        print("simplex KG multistart case %d: d=%d q=%d best=%s (sums %s) found=%d; tensor-product best=%s" % (
+            k, d, q, np.array2string(best, precision=6), np.array2string(best.sum(1), precision=6), found, np.array2string(best_tp, precision=4)))
+        for key, val in c.items():
+            blob["m%d_in_%s" % (k, key)] = np.asarray(val)
+        blob["m%d_out_best_point" % k], blob["m%d_out_found" % k] = best, np.array(int(found))
+        blob["m%d_out_best_point_tensor" % k] = best_tp
+        k += 1
+    blob["num_ms"] = np.array(k)
+    np.savez_compressed(OUT_SIMPLEX_KG, **blob)
+    print("wrote", OUT_SIMPLEX_KG, os.path.getsize(OUT_SIMPLEX_KG), "bytes")
+
+
 OUT_MS = os.path.join(ROOT, "tests", "golden", "ref_kg_multistart.npz")
 
 
@@ -423,6 +527,9 @@ def main():
         return
     if "--shapes-r4" in sys.argv:
         shape_fixtures_r4()
+        return
+    if "--simplex-kg" in sys.argv:
+        simplex_kg_fixtures()
         return
     if "--simplex" in sys.argv:
         simplex_fixtures()
