@@ -249,7 +249,7 @@ __global__ __launch_bounds__(256, 2) void gemm128_kernel(GemmArgs g) {
 // P = A[base.., kp0 .. kp0 + kw): the rank-kw update of a right-looking Cholesky factorisation.  gridDim.x = T (T + 1) / 2
 // lower-triangle tiles of 128 (T = ceil((N - base) / 128)), walked column by column.
 // ---------------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256, 2) void syrk128_kernel(double* __restrict__ Amat, long lda, int N, int base, int kp0, int kw,
+inline __global__ __launch_bounds__(256, 2) void syrk128_kernel(double* __restrict__ Amat, long lda, int N, int base, int kp0, int kw,
                                                          const int* __restrict__ info) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   if (*info != 0) return;

@@ -87,6 +87,9 @@ void launch_gemm_tn(int m, int n, int K, const double* A, long lda, const double
 void launch_gemm_tn_splitk(int m, int n, int K, const double* A, long lda, const double* B, long ldb, double* C, double* work,
                            int slices, hipStream_t s, int batch = 1, long sA = 0, long sB = 0);
 
+// C[i] = sum over the `slices` partial results work[sl * count + i], in slice order.
+void launch_sum_slices(const double* work, int slices, long count, double* C, hipStream_t s);
+
 // Batched Gram matrices over column groups of V (K x *, ldv): for eval e, G_e[c x c] (ld c, eval stride c*c) = V_e^T V_e
 // where V_e's column `l` is V's column  l < m ? e*m + l : l < m+ng ? E*m + e*ng + (l-m) : E*(m+ng) + e*A + (l-m-ng).
 // work (may be NULL: single pass): E * gram_batch_slices(E, c, K) * c * c doubles of scratch for the K-sliced version.

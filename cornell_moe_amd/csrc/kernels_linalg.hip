@@ -1085,6 +1085,11 @@ void launch_gemm_tn_splitk(int m, int n, int K, const double* A, long lda, const
   MOE_HIP_CHECK(hipGetLastError());
 }
 
+void launch_sum_slices(const double* work, int slices, long count, double* C, hipStream_t s) {
+  hipLaunchKernelGGL(sum_slices_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, s, work, slices, count, C);
+  MOE_HIP_CHECK(hipGetLastError());
+}
+
 void launch_gemm_tn(int m, int n, int K, const double* A, long lda, const double* B, long ldb, double* C, long ldc,
                     hipStream_t s) {
   if (n == 1 && m > 0) {

@@ -31,6 +31,7 @@
 
 #include "device_cov.hpp"
 #include "fastmath.hpp"
+#include "gemm128.hpp"
 #include "kg_mc.hpp"
 #include "kg_state.hpp"
 
@@ -113,6 +114,7 @@ struct KgTailParams {
 };
 
 constexpr int kTbChunk = 256;  // samples per workgroup of kg_tb_kernel
+constexpr int kTbChunkWide = 2048;  // m > 64: samples per partial of the matrix-pipe TB product (kg_tb128_kernel)
 // ... and of kg_fused_point_kernel: 128, so that ONE q-KG evaluation (n = 1000: 4 row blocks x 79 chunks) puts more than one
 // workgroup on every CU -- 40.7 -> ~20 us of a batch-1 evaluation's tail.  Fixed per path, not per batch size: an evaluation's
 // bits do not depend on what it is batched with.
@@ -236,6 +238,62 @@ __global__ __launch_bounds__(256) void kg_tb_kernel(KgTailParams P, int c_lo = 0
     for (int c = 0; c < MU; ++c)
       if (c_lo + c < m) dst[(long)(c_lo + c) * P.N + row] = acc[c];
   }
+}
+
+// The same partial sums for m > 64 (r4; the stretch point's m = 104) as a product on the matrix pipe: TBpart[e][chunk] (N x m) =
+// T_e[:, chunk] (N x len) beta_e[chunk, :] (len x m) through gemm128.hpp's tile core -- one pass over T instead of one per 64 columns
+// of beta, chunks of kTbChunkWide samples (ten partials instead of 79 at M = 20 000).  Grid (row tiles of 128, chunks, E).
+__global__ __launch_bounds__(256, 2) void kg_tb128_kernel(KgTailParams P) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  const int chunk = blockIdx.y, e = blockIdx.z, m = P.m;
+  const int i0 = chunk * P.chunk_len, len = min(P.num_local - i0, P.chunk_len);
+  const long w0 = (long)e * P.num_local + i0;
+  g128::Operand A{P.T + w0 * P.N, (long)P.N, P.N, len, 1};     // T[row + sample N]: rows contiguous
+  g128::Operand B{P.beta + w0 * m, (long)m, m, len, 1};        // beta[sample m + c]: the output column contiguous
+  g128::f64x4 acc[4][4];
+  const int r0 = blockIdx.x * g128::TM;
+  g128::tile_product<false, false>(A, B, r0, 0, 0, len, smem, acc);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int wi = (wave & 1) * 64, wj = (wave >> 1) * 64;
+  const int lk = lane >> 4, lx = lane & 15;
+  double* dst = P.TBpart + ((long)e * P.chunks + chunk) * m * P.N;
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = r0 + wi + 16 * a + lx, c = wj + 16 * b + lk + 4 * r;
+        if (row < P.N && c < m) dst[(long)c * P.N + row] = acc[a][b][r];
+      }
+}
+
+// S_W = W_e^T T_e (m x samples) for 64 < m <= 128 on the same tile core: one 128-row tile holds all m rows, so T is read ONCE (the
+// 64-tile kernel reads it once per row tile: twice at m = 104).  K = N is cut into `slices`; slice sl of evaluation e goes to
+// SWpart[sl][e] (dense m x num_local), summed in slice order by sum_slices_kernel.  Grid (column tiles of 128 samples, slices, E).
+__global__ __launch_bounds__(256, 2) void kg_sw128_kernel(KgTailParams P, double* __restrict__ SWpart, int slices) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  const int sl = blockIdx.y, e = blockIdx.z, m = P.m;
+  const int ks = ((P.N + slices - 1) / slices + g128::TK - 1) / g128::TK * g128::TK;
+  const int k_lo = sl * ks, k_hi = min(P.N, k_lo + ks);
+  g128::Operand A{P.W + (long)e * P.w_stride, (long)P.N, m, P.N, 1};                        // W[row + c N]: K (= row) contiguous
+  g128::Operand B{P.T + (long)e * P.num_local * P.N, (long)P.N, P.num_local, P.N, 1};      // T[row + sample N]: K contiguous
+  g128::f64x4 acc[4][4];
+  const int j0 = blockIdx.x * g128::TM;
+  g128::tile_product<true, true>(A, B, 0, j0, k_lo, k_hi, smem, acc);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int wi = (wave & 1) * 64, wj = (wave >> 1) * 64;
+  const int lk = lane >> 4, lx = lane & 15;
+  double* dst = SWpart + ((long)sl * P.E + e) * m * P.num_local;
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int c = wi + 16 * a + lx, smp = j0 + wj + 16 * b + lk + 4 * r;
+        if (c < m && smp < P.num_local) dst[(long)smp * m + c] = acc[a][b][r];
+      }
 }
 
 // TB[e][c][row] = sum of the chunk partials in chunk order (one pass over TBpart instead of one per gradient column).
@@ -462,8 +520,12 @@ void launch_tail(const KgTailParams& P, hipStream_t s) {
     hipLaunchKernelGGL((kg_tb_kernel<16>), gtb, dim3(256), 0, s, P, 0);
   else if (P.m <= 32)
     hipLaunchKernelGGL((kg_tb_kernel<32>), gtb, dim3(256), 0, s, P, 0);
-  else {
-    for (int c_lo = 0; c_lo < P.m; c_lo += 64) hipLaunchKernelGGL((kg_tb_kernel<64>), gtb, dim3(256), 0, s, P, c_lo);
+  else if (P.m <= 64) {
+    hipLaunchKernelGGL((kg_tb_kernel<64>), gtb, dim3(256), 0, s, P, 0);
+  } else {  // (m <= kMaxMB = 128: one column tile)
+    MOE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kg_tb128_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      (int)g128::kSmemBytes));
+    hipLaunchKernelGGL(kg_tb128_kernel, dim3((P.N + g128::TM - 1) / g128::TM, P.chunks, P.E), dim3(256), g128::kSmemBytes, s, P);
   }
   launch_gtb(P, s);
   MOE_HIP_CHECK(hipGetLastError());
@@ -1256,7 +1318,7 @@ KgPending kg_launch(GpDev& gp, int num_fidelity, const moe_gd_params_t& gd, cons
   dOut.reserve((size_t)out_stride * E);
   // q-KG fast path: the N x M covariance matrix of the tail is never materialised (see launch_fused_tail)
   const bool fused_tail = want_grad && g == 0 && m <= 8 && env_int("MOE_KG_FUSED_TAIL", 1) != 0;
-  const int chunk_len = fused_tail ? kFusedChunk : kTbChunk;
+  const int chunk_len = fused_tail ? kFusedChunk : (m > 64 ? kTbChunkWide : kTbChunk);
   const int chunks = (num_local + chunk_len - 1) / chunk_len;
   if (want_grad) {
     if (!fused_tail) dT.reserve((size_t)N * E * num_local);
@@ -1438,9 +1500,19 @@ KgPending kg_launch(GpDev& gp, int num_fidelity, const moe_gd_params_t& gd, cons
       // A skinny output (m x samples) over a long K (N): every evaluation of the call in ONE launch, K cut into slices so that the chip
       // holds several workgroups per CU (r4: one launch per evaluation, unsplit below N = 2048, was 62 % of the d-KG tail at n = 500 --
       // 63 workgroups walking 125 dependent stages, eight times per call).  The slice count is a function of (m, N) alone.
-      const int sw_slices = (m <= 64) ? (N >= 1024 ? 8 : (N >= 256 ? 4 : 1)) : 1;
+      const int sw_slices = N >= 1024 ? 8 : (N >= 256 ? 4 : 1);  // (m > 64 too: the stretch point's 104 x 20 000 over N = 26 000 walked 1625 stages unsplit)
       if (sw_slices > 1) gp.kSWpart.reserve((size_t)sw_slices * m * num_local * E);
-      launch_gemm_tn_splitk(m, num_local, N, tl.W, N, dT.p, N, gp.kSW.p, gp.kSWpart.p, sw_slices, s, E, tl.w_stride, (long)num_local * N);
+      if (m > 64 && sw_slices > 1) {  // (T is set in `tl` below: the kernel takes W / T / strides from it)
+        KgTailParams tq = tl;
+        tq.T = dT.p;
+        MOE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kg_sw128_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          (int)g128::kSmemBytes));
+        hipLaunchKernelGGL(kg_sw128_kernel, dim3((num_local + g128::TM - 1) / g128::TM, sw_slices, E), dim3(256), g128::kSmemBytes, s, tq,
+                           gp.kSWpart.p, sw_slices);
+        launch_sum_slices(gp.kSWpart.p, sw_slices, (long)m * num_local * E, gp.kSW.p, s);
+      } else {
+        launch_gemm_tn_splitk(m, num_local, N, tl.W, N, dT.p, N, gp.kSW.p, gp.kSWpart.p, sw_slices, s, E, tl.w_stride, (long)num_local * N);
+      }
       tl.SW = gp.kSW.p;
     }
     launch_tail(tl, s);
@@ -1571,7 +1643,7 @@ int kg_max_batch(const GpDev& gp, int P, int q, int p, int num_local, bool want_
   const double N = gp.N, g1 = 1 + gp.g, u = q + p, m = u * g1, A = u + P;
   const double ngrad = want_grad ? q * g1 * gp.d : 0.0;
   const bool fused = want_grad && gp.g == 0 && m <= 8;
-  const double chunks = std::ceil((double)num_local / (fused ? kFusedChunk : kTbChunk));
+  const double chunks = std::ceil((double)num_local / (fused ? kFusedChunk : (m > 64 ? kTbChunkWide : kTbChunk)));
   // state matrix E (all columns), V = L^-1 K* with the tail's K^-1 TB workspace behind it, W = K^-1 K*; the packed d chol / d Xq
   double doubles = N * (m + ngrad + A) + 3.0 * N * m + (double)num_local * (gp.dp + 1 + 2 * m) +
                    (want_grad ? (double)q * gp.d * m * (m + 1) / 2 : 0.0);
