@@ -882,7 +882,62 @@ __global__ __launch_bounds__(256) void kg_sample_weights_kernel(KgMcParams P, do
   }
 }
 
+// The same table for m > 64 (r4; the stretch point's m = 104) with its sums on the matrix pipe: V_e (table rows x samples) = K^-1 y -
+// W_e beta_e^T through gemm128.hpp's tile core, scaled and written ONCE (the kernel above needs two passes over a partially written
+// table there: 2 x 5.1 ms per evaluation against the MC kernel's own 9.4).  Needs the table's rows to BE the training rows
+// (v_slots1 == 1 + g).  The sums are formed in the MFMA's order, not in the c-order of the in-kernel weights: for these shapes a result
+// depends at rounding level on whether the table fitted its cap (the m <= 64 paths keep their bit-for-bit equality).
+// Grid (row tiles of 128 table entries, column tiles of 128 samples, E).
+__global__ __launch_bounds__(256, 2) void kg_table128_kernel(KgMcParams P, double* __restrict__ V) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  const int e = blockIdx.z, m = P.m, g1 = 1 + P.g;
+  const long s0 = (long)e * P.num_local;
+  g128::Operand A{P.W + (long)e * P.w_stride, (long)P.N, P.N, m, 1};   // W[t + c N]: table rows contiguous
+  g128::Operand B{P.beta + s0 * m, (long)m, P.num_local, m, 1};        // beta[sample m + c]: K (= c) contiguous
+  g128::f64x4 acc[4][4];
+  const int t0 = blockIdx.x * g128::TM, j0 = blockIdx.y * g128::TM;
+  if (t0 < P.N) g128::tile_product<false, true>(A, B, t0, j0, 0, m, smem, acc);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int wi = (wave & 1) * 64, wj = (wave >> 1) * 64;
+  const int lk = lane >> 4, lx = lane & 15;
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {
+    const int t = t0 + wi + 16 * a + lx;
+    const int tt = min(t, P.N - 1);
+    const double kiy = P.KinvY[tt];
+    const int sa = tt % g1;
+    const double scale = (sa == 0) ? P.alpha : -P.alpha * P.inv_lp[sa > 0 ? sa - 1 : 0];
+    // rows behind the training set: the fantasy points' weights are the sample's beta itself, scaled like a training row, then zeros
+    const int cf = t - P.N;
+    const bool fantasy = cf >= 0 && cf < m;
+    const double fscale = ((cf % g1) == 0) ? P.alpha : -P.alpha * P.inv_lp[max(cf % g1, 1) - 1];
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int smp = j0 + wj + 16 * b + lk + 4 * r;
+        if (t < P.v_stride && smp < P.num_local) {
+          const long so = s0 + smp;
+          double v;
+          if (t < P.N)
+            v = (kiy - acc[a][b][r]) * scale;
+          else
+            v = fantasy ? P.beta[so * m + min(cf, m - 1)] * fscale : 0.0;
+          __builtin_nontemporal_store(v, &V[so * P.v_stride + t]);
+        }
+      }
+  }
+}
+
 void launch_sample_weights(const KgMcParams& P, double* V, hipStream_t s) {
+  if (P.m > 64 && P.v_slots1 == 1 + P.g) {
+    MOE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kg_table128_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      (int)g128::kSmemBytes));
+    hipLaunchKernelGGL(kg_table128_kernel, dim3((unsigned)((P.v_stride + g128::TM - 1) / g128::TM), (P.num_local + g128::TM - 1) / g128::TM, P.E),
+                       dim3(256), g128::kSmemBytes, s, P, V);
+    MOE_HIP_CHECK(hipGetLastError());
+    return;
+  }
   const int spb = 64;
   dim3 grid((unsigned)((P.v_stride + 255) / 256), (P.num_local + spb - 1) / spb, P.E);
   if (P.m <= 16)
