@@ -35,8 +35,10 @@ void kg_evaluate_batch(GpDev& gp, int num_fidelity, const moe_gd_params_t& gd, c
                        double* kg_sum, double* grad_sum, double* best_points, moe_kg_stats_t* stats,
                        const double* disc_head = nullptr);
 
-// kg_evaluate_batch split at its only wait: kg_launch does the state set-up, the host m x m algebra and every
-// asynchronous launch on gp.stream; collect() waits for the stream and assembles kg_sum / grad_sum (same meaning as above).
+// kg_evaluate_batch split at its only wait: kg_launch enqueues the whole evaluation on gp.stream -- one host->device copy, the
+// state set-up with its m x m algebra (kg_state.hip), the MC kernel, the gradient tail -- and collect() waits for the stream and
+// hands out kg_sum / grad_sum (same meaning as above).  gd.domain_type selects the inner optimisations' domain (tensor product
+// or its intersection with the unit simplex).
 struct KgPending {
   std::function<void(double* kg_sum, double* grad_sum, double* best_points, moe_kg_stats_t* stats)> collect;
 };
