@@ -332,3 +332,27 @@ def test_normal_stream_pinned_to_reference_build():
     rnd.SetExplicitNormalRNGSeed(314)  # thread i is seeded seed + i (gpp_python_common.cpp:131-198)
     assert np.array_equal(rnd.normal_rng_vec[0].table(50), z["stream_draws"][2][:50])
     assert np.array_equal(rnd.normal_rng_vec[1].table(50), api.normal_draws(315, 50))
+
+
+@pytest.mark.skipif(not ref.available(), reason="oracle/_ref not built (reference tree absent)")
+def test_simplex_fixtures_reproduce_from_the_live_reference():
+    """r4: tests/golden/ref_simplex_kg.npz is what the reference's own SimplexIntersectTensorProductDomain instantiations return
+    (oracle/ref_harness.cpp: ref_kg_dom, ref_kg_multistart_dom) -- one evaluation and one driver run recomputed here, bit for bit;
+    the same evaluation over the tensor product gives the fixture's other KG (the simplex run is not the default run by accident)."""
+    import os
+    from helpers import GOLDEN
+    z = np.load(os.path.join(os.path.dirname(GOLDEN), "ref_simplex_kg.npz"))
+    g = lambda name: z["e0_in_%s" % name]  # noqa: E731
+    d, f, M = int(g("d")), int(g("num_fidelity")), int(g("M"))
+    R = ref.RefGP(1, float(g("alpha")), g("lengths"), g("X"), g("y"), g("noise"), [int(v) for v in g("derivs")])
+    args = (tuple(g("inner_gd")), g("bounds")[: 2 * (d - f)], g("discrete"), g("Xq"), g("Xp") if int(g("p")) else None, M,
+            float(g("best_so_far")), g("normals"))
+    r = R.kg(*args, num_fidelity=f, domain_type=1)
+    assert r["kg"] == float(z["e0_out_kg"]) and np.array_equal(r["grad"], z["e0_out_grad"]) and np.array_equal(r["best_point"], z["e0_out_best_point"])
+    assert R.kg(*args, num_fidelity=f, domain_type=0, want_grad=False)["kg"] == float(z["e0_out_kg_tensor"])
+    assert abs(float(z["e0_out_kg"]) - float(z["e0_out_kg_tensor"])) > 1e-3
+    g = lambda name: z["m0_in_%s" % name]  # noqa: E731
+    R = ref.RefGP(1, float(g("alpha")), g("lengths"), g("X"), g("y"), g("noise"), [])
+    best, found = R.kg_multistart(tuple(g("outer_gd")), tuple(g("inner_gd")), g("bounds"), g("discrete"), g("starts"), None, int(g("M")),
+                                  float(g("best_so_far")), int(g("rng_seed")), domain_type=1)
+    assert np.array_equal(best, z["m0_out_best_point"]) and found == bool(z["m0_out_found"])
