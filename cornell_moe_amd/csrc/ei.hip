@@ -567,10 +567,14 @@ void ei_evaluate_batch(GpDev& gp, const double* Xq_all, int num_evals, const dou
   }
   // persistent workspaces (hipMalloc / hipFree per call cost more than the whole evaluation)
   DevBuf<double>& dBlob = gp.kBlob;
-  if (gp.kEiTicket.cap < (size_t)E) {  // arrival counters of ei_mc_kernel: zero at allocation, left zero by every launch
+  // arrival counters of ei_mc_kernel: zero at allocation, left zero by every launch that COMPLETES; a launch that was enqueued and
+  // never seen to finish (a device fault, a sticky error from an earlier kernel: the wait below throws) leaves them undefined, and a
+  // non-zero counter would keep every later call from electing its last workgroup -- so such a call is followed by a clear
+  if (gp.kEiTicket.cap < (size_t)E || gp.ei_ticket_dirty) {
     gp.kEiTicket.reserve((size_t)E);
     MOE_HIP_CHECK(hipMemsetAsync(gp.kEiTicket.p, 0, sizeof(unsigned int) * gp.kEiTicket.cap, s));
   }
+  gp.ei_ticket_dirty = true;
   EiParams P;
   P.u = u;
   P.q = q;
@@ -594,6 +598,7 @@ void ei_evaluate_batch(GpDev& gp, const double* Xq_all, int num_evals, const dou
   double* out = gp.hKgOut.p;
   dOut.download(out, n_down, s);
   MOE_HIP_CHECK(hipStreamSynchronize(s));
+  gp.ei_ticket_dirty = false;
 #if MOE_EI_PROF
   {
     unsigned long long h[16];

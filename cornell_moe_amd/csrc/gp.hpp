@@ -42,6 +42,8 @@ struct GpDev {
   DevBuf<double> kBlob, kNormals, kTab, kBestPoint, kBestValue, kBeta, kT, kC, kTB, kOut, kSW, kSWpart, kZcPart, kV;
   DevBuf<unsigned long long> kCounters;
   DevBuf<unsigned int> kEiTicket;  // arrival counters of ei_mc_kernel's fused final sum (ei.hip)
+  bool ei_ticket_dirty = false;  // a launch of ei_mc_kernel was enqueued and its completion not yet seen: an aborted launch leaves
+                                  // the arrival counters non-zero, so the next call clears them first
   DevBuf<int> kBestJ, kStateI;   // kStateI: singular flags | winners of a KG batch (kg_state.hip)
   DevBuf<double> kStateD;        // grad mu | d chol / d Xq (packed) | final [kg_sum | grad] per evaluation
   int num_cu = 256;

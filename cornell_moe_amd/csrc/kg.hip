@@ -963,6 +963,16 @@ void launch_mc(const KgMcParams& P, int dp, int G, bool xlds, int blocks, int wa
   }
 }
 
+void launch_mc_lane(const KgMcParams& P, int dp, int G, int rec_head, int blocks, int waves, size_t shm, hipStream_t s) {
+  switch (dp) {
+    case 4: launch_kg_mc_lane_dp4(P, G, rec_head, blocks, waves, shm, s); break;
+    case 8: launch_kg_mc_lane_dp8(P, G, rec_head, blocks, waves, shm, s); break;
+    case 12: launch_kg_mc_lane_dp12(P, G, rec_head, blocks, waves, shm, s); break;
+    case 16: launch_kg_mc_lane_dp16(P, G, rec_head, blocks, waves, shm, s); break;
+    default: throw Error(MOE_ERR_RUNTIME, "unsupported padded dimension in the lane-parked MC kernel");
+  }
+}
+
 void launch_mc_stream(const KgMcParams& P, int dp, int G, int blocks, int waves, size_t shm, hipStream_t s) {
   switch (dp) {
     case 4: launch_kg_mc_stream_dp4(P, G, blocks, waves, shm, s); break;
@@ -1154,9 +1164,21 @@ KgPending kg_launch(GpDev& gp, int num_fidelity, const moe_gd_params_t& gd, cons
   const int num_cu = gp.num_cu;
   size_t shm = 0;
   int wg_per_cu = 1, wide_lds_tiles = 0;
+  // r5: the lane-parked form of the LDS-table kernel (kg_mc_lane.hpp) wherever it holds as many wavefronts: its LDS also carries the
+  // evaluation's record head [L | mu_disc | C_disc | disc] (the same for every evaluation of a call and every batch: the choice
+  // depends on the evaluation's shape alone).  Same results bit for bit (MOE_KG_LANE=0: the frame line search of rounds 2-4).
+  auto even = [](int v) { return (v + 1) & ~1; };
+  const int rec_head = even(m * m) + even(A) + even(A * m) + even(A * size);
+  bool lane_kernel = false;
+  if (variant == 0 && xlds && waves <= 8 && !simplex && dp <= 16 && env_int("MOE_KG_LANE", 1) != 0) {
+    const size_t lane_fixed = kg_mc_lane_fixed_bytes(dp, rec_head);
+    const int wl = std::min(waves, env_int("MOE_KG_WAVES", waves));
+    lane_kernel = wl >= 1 && lane_fixed + tab_bytes + (size_t)wl * slab_bytes + pad_bytes <= (size_t)160 * 1024;
+  }
   if (variant == 0) {
     waves = std::max(1, std::min(waves, env_int("MOE_KG_WAVES", waves)));
-    shm = fixed_bytes + (xlds ? tab_bytes + (size_t)waves * slab_bytes : (size_t)waves * slab_stream_bytes) + pad_bytes;
+    shm = (lane_kernel ? kg_mc_lane_fixed_bytes(dp, rec_head) : fixed_bytes) +
+          (xlds ? tab_bytes + (size_t)waves * slab_bytes : (size_t)waves * slab_stream_bytes) + pad_bytes;
     wg_per_cu = std::max(1, std::min((int)((size_t)160 * 1024 / shm), (waves > 8 ? 16 : 8) / waves));
     if (mc::wide_eval(dp, xlds)) {  // what the slabs leave of a workgroup's share of LDS holds the leading tiles of the table (kg_mc.hpp WideEval)
       const size_t share = (size_t)160 * 1024 / wg_per_cu;
@@ -1251,6 +1273,7 @@ KgPending kg_launch(GpDev& gp, int num_fidelity, const moe_gd_params_t& gd, cons
   rec.mu_disc = take(A);
   rec.C_disc = take(A * m);
   rec.disc = take(A * size);
+  if (off != rec_head) throw Error(MOE_ERR_RUNTIME, "record head layout mismatch (lane-parked MC kernel)");
   rec.XuP = take(u * dp);
   const int rec_bp = take(1);
   rec.Mk = 0;
@@ -1480,7 +1503,9 @@ KgPending kg_launch(GpDev& gp, int num_fidelity, const moe_gd_params_t& gd, cons
   }
   if (variant == 2 && (mp.V == nullptr || mp.best_j == nullptr))
     throw Error(MOE_ERR_RUNTIME, "streamed-weights MC kernel selected without its weight table");
-  if (variant == 0)
+  if (variant == 0 && lane_kernel)
+    launch_mc_lane(mp, dp, G, rec_head, blocks, waves, shm, s);
+  else if (variant == 0)
     launch_mc(mp, dp, G, xlds, blocks, waves, shm, s);
   else if (variant == 2)
     launch_mc_stream(mp, dp, G, blocks, waves, shm, s);
@@ -1490,7 +1515,7 @@ KgPending kg_launch(GpDev& gp, int num_fidelity, const moe_gd_params_t& gd, cons
   {
     // (bits 1 / 2 of the second word, r4: the frame-extent decisions -- a domain box or point set wider than 100 length scales
     //  silently costs the LDS-table kernel and the multi-trial passes; this is where a caller can see it)
-    const int info[8] = {variant, ((variant == 0 && xlds) ? 1 : 0) | (far_frame ? 2 : 0) | (wide_frame ? 4 : 0), waves, variant == 1 ? tr : wide_lds_tiles, mp.V != nullptr ? 1 : 0, 0, blocks,
+    const int info[8] = {variant, ((variant == 0 && xlds) ? 1 : 0) | (far_frame ? 2 : 0) | (wide_frame ? 4 : 0) | (lane_kernel ? 8 : 0), waves, variant == 1 ? tr : wide_lds_tiles, mp.V != nullptr ? 1 : 0, 0, blocks,
                          mp.best_j != nullptr ? 1 : 0};
     std::copy(info, info + 8, gp.last_info);
   }

@@ -121,6 +121,14 @@ void launch_kg_mc_dp16(const KgMcParams& P, int G, bool xlds, int blocks, int wa
 void launch_kg_mc_dp24(const KgMcParams& P, int G, bool xlds, int blocks, int waves, size_t shm, hipStream_t s);
 void launch_kg_mc_dp32(const KgMcParams& P, int G, bool xlds, int blocks, int waves, size_t shm, hipStream_t s);
 
+// Lane-parked wave-per-sample kernel (r5, kg_mc_lane.hpp): the LDS-table kernel above with the line search's vectors one row per lane and
+// the evaluation's record head ([L | mu_disc | C_disc | disc]: `rec_head` doubles) in LDS; 8 wavefronts, padded dimension <= 16.
+void launch_kg_mc_lane_dp4(const KgMcParams& P, int G, int rec_head, int blocks, int waves, size_t shm, hipStream_t s);
+void launch_kg_mc_lane_dp8(const KgMcParams& P, int G, int rec_head, int blocks, int waves, size_t shm, hipStream_t s);
+void launch_kg_mc_lane_dp12(const KgMcParams& P, int G, int rec_head, int blocks, int waves, size_t shm, hipStream_t s);
+void launch_kg_mc_lane_dp16(const KgMcParams& P, int G, int rec_head, int blocks, int waves, size_t shm, hipStream_t s);
+size_t kg_mc_lane_fixed_bytes(int dp, int rec_head);  // LDS in front of the coordinate table
+
 // Streamed-weights wave-per-sample kernel (kg_mc_stream_kernel): weights from the table P.V, P.wide_lds_tiles tiles of coordinates in LDS.
 void launch_kg_mc_stream_dp4(const KgMcParams& P, int G, int blocks, int waves, size_t shm, hipStream_t s);
 void launch_kg_mc_stream_dp8(const KgMcParams& P, int G, int blocks, int waves, size_t shm, hipStream_t s);
@@ -390,7 +398,7 @@ __device__ __forceinline__ double eval_loop(const double* __restrict__ xs, const
   // A trial point more than kFarRadius length scales from the centre is > 400 length scales from every tabulated point
   // (all inside the ball of radius sqrt(32) * kTableExtent): every covariance underflows to exactly 0 and the posterior mean
   // IS the prior mean -- the pass is skipped.  Closer than that, sqrt(r2) * 64 / ln2 < 2^31: exp_nonpos_tab is in range.
-  if (!WG && !(qq <= kFarRadius * kFarRadius)) return -mean;
+  if (!WG && !(uniform(qq) <= kFarRadius * kFarRadius)) return -mean;  // (uniform: a scalar branch, and the callers' Armijo decisions stay scalar)
   double accf = 0.0, accs = 0.0;
   double accg[DP];
   double accd[G > 0 ? G : 1];
@@ -528,17 +536,13 @@ __device__ __forceinline__ double eval_pass(const double* __restrict__ xs, const
 // G > 0 (derivative observations; table rows a < G are the observed dimensions): a point also carries the derivative-weight sum
 // sum_a w_a (x_j - q_t)_a = sdA - alpha_t sdB,  sdA = sum_a w_a (x_j - x0')_a,  sdB = sum_a w_a dv_a  (2 G fmas once per point, one
 // fma per trial), multiplied by the first-derivative coefficient of the trial's distance.
+// (eval_multi_loop_s: the three sums |x2|^2, x2.d2, |d2|^2 -- fixed along a trial line -- handed in by a caller that forms them once
+//  per bracket, kg_mc_lane.hpp; eval_multi_loop forms them itself, in the same order)
 template <int DP, int COV, int T, bool SMALL, bool XL = true, int G = 0>
-__device__ __forceinline__ bool eval_multi_loop(const double* __restrict__ xs, const double* __restrict__ aw,
-                                                const double* __restrict__ etab, int ntiles, double mean, const double (&x2)[DP],
-                                                const double (&d2)[DP], double alpha0, int lane, double (&f)[T]) {
-  double sxx = 0.0, sxd = 0.0, sdd = 0.0;
-#pragma unroll
-  for (int k = 0; k < DP; ++k) {
-    sxx = fma(x2[k], x2[k], sxx);
-    sxd = fma(x2[k], d2[k], sxd);
-    sdd = fma(d2[k], d2[k], sdd);
-  }
+__device__ __forceinline__ bool eval_multi_loop_s(const double* __restrict__ xs, const double* __restrict__ aw,
+                                                  const double* __restrict__ etab, int ntiles, double mean, const double (&x2)[DP],
+                                                  const double (&d2)[DP], double sxx, double sxd, double sdd, double alpha0, int lane,
+                                                  double (&f)[T]) {
   double al[T], qq[T];
 #pragma unroll
   for (int t = 0; t < T; ++t) {
@@ -641,6 +645,20 @@ __device__ __forceinline__ bool eval_multi_loop(const double* __restrict__ xs, c
 #pragma unroll
   for (int t = 0; t < T; ++t) f[t] = -(mean + sum[t]);
   return true;
+}
+
+template <int DP, int COV, int T, bool SMALL, bool XL = true, int G = 0>
+__device__ __forceinline__ bool eval_multi_loop(const double* __restrict__ xs, const double* __restrict__ aw,
+                                                const double* __restrict__ etab, int ntiles, double mean, const double (&x2)[DP],
+                                                const double (&d2)[DP], double alpha0, int lane, double (&f)[T]) {
+  double sxx = 0.0, sxd = 0.0, sdd = 0.0;
+#pragma unroll
+  for (int k = 0; k < DP; ++k) {
+    sxx = fma(x2[k], x2[k], sxx);
+    sxd = fma(x2[k], d2[k], sxd);
+    sdd = fma(d2[k], d2[k], sdd);
+  }
+  return eval_multi_loop_s<DP, COV, T, SMALL, XL, G>(xs, aw, etab, ntiles, mean, x2, d2, sxx, sxd, sdd, alpha0, lane, f);
 }
 
 // TensorProductDomain::LimitUpdate (gpp_domain.cpp:64-105) on one coordinate.
@@ -2930,6 +2948,8 @@ inline void launch_block_dp(const KgMcParams& P, int G, int tr, int num_lds_tile
     default: throw Error(MOE_ERR_RUNTIME, "unsupported derivative-slot count in the MC kernel");
   }
 }
+
+#include "kg_mc_lane.hpp"
 
 template <int DP, int G, bool XLDS, bool SMALL>
 inline void launch_inst2(const KgMcParams& P, int blocks, int waves, size_t shm, hipStream_t s) {

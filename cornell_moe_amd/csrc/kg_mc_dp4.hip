@@ -15,8 +15,16 @@ size_t kg_mc_block_lds_bytes(int dp, int G, int num_lds_tiles) {
   return sizeof(double) * (mc::kBlockFixed + (size_t)num_lds_tiles * (dp + 1 + G) * 64);
 }
 
+size_t kg_mc_lane_fixed_bytes(int dp, int rec_head) {
+  return sizeof(double) * ((size_t)kExpTabLen + (size_t)mc::kLaneCstRows * dp + (size_t)((rec_head + 1) & ~1));
+}
+
 void launch_kg_mc_stream_dp4(const KgMcParams& P, int G, int blocks, int waves, size_t shm, hipStream_t s) {
   mc::launch_stream_dp<4>(P, G, blocks, waves, shm, s);
+}
+
+void launch_kg_mc_lane_dp4(const KgMcParams& P, int G, int rec_head, int blocks, int waves, size_t shm, hipStream_t s) {
+  mc::launch_lane_dp<4>(P, G, rec_head, blocks, waves, shm, s);
 }
 
 }  // namespace moe

@@ -32,10 +32,18 @@ def _domain_type(optimizer_parameters):
 
 
 def _simplex_box(bounds, d):
-    """SimplexIntersectTensorProductDomain's constructor (gpp_domain.cpp:107-141): the box clipped to the unit hypercube."""
+    """SimplexIntersectTensorProductDomain's constructor (gpp_domain.cpp:107-141): the box clipped to the unit hypercube; an empty
+    intersection -- an empty clipped interval, or a 'lower left' corner whose coordinates sum to >= 1 -- is the reference's
+    BoundsException, raised HERE, before any point is drawn (the rejection loop below would otherwise grow its draw
+    5 x per attempt and never keep a point)."""
+    from . import api
     b = np.asarray(bounds, dtype=np.float64).reshape(d, 2).copy()
     b[:, 0] = np.maximum(b[:, 0], 0.0)
     b[:, 1] = np.minimum(b[:, 1], 1.0)
+    corner_sum = float(b[:, 0].sum())
+    if corner_sum >= 1.0 or bool(np.any(b[:, 0] > b[:, 1])):
+        raise api.BoundsException("Simplex/Tensor product intersection is EMPTY; 'lower left' corner coordinate sum out of bounds or "
+                                  "bounding boxes do not intersect.", corner_sum, 0.0, 1.0)
     return b.reshape(-1)
 
 
@@ -61,12 +69,19 @@ def _domain_points(randomness, bounds, count, d, domain_type):
             break
         ratio = len(kept) / float(count)
         n_local = n_local * 5 if ratio < 0.2 else int(np.ceil(n_local / ratio))
+        if n_local * d > _MAX_DRAW_DOUBLES:  # (a sliver of an intersection: the reference would keep multiplying; bounded here)
+            break
     return kept
+
+
+_MAX_DRAW_DOUBLES = 1 << 26  # 512 MB per Latin-hypercube draw of the simplex rejection loop
 
 
 def _starts(randomness, bounds, count, q, d, domain_type=0):
     """RepeatedDomain::GenerateUniformPointsInDomain (gpp_domain.hpp:490-510): one point set per repeat, transposed; when a repeat
-    comes up short (simplex rejection) every start set is cut to the shortest."""
+    comes up short (simplex rejection) every start set is cut to the shortest.  NO surviving start is not handled here: the multistart
+    entry points refuse num_starts = 0 with the reference's BoundsException ("num_multistarts must be > 1", gpp_optimization.hpp:1478),
+    which is what its own drivers do with the count GenerateUniformPointsInDomain returns."""
     sets = []
     n = count
     for _ in range(q):

@@ -372,7 +372,8 @@ int moe_last_kernel_ms(const moe_gp_t* gp, double* out5);
  * out[1] = bit 0: coordinate table in LDS; bit 1: FAR FRAME -- the training set, the points being sampled or the inner domain box
  *          span more than 100 length scales from the training-set mean, so the evaluation took the direct-difference kernels with
  *          single-trial passes (exact, slower: typical triggers are the short length scales of a hyper-parameter MCMC ensemble or a
- *          search box far wider than the data); bit 2: coordinates streamed from L2 (far frame, or d > 16),
+ *          search box far wider than the data); bit 2: coordinates streamed from L2 (far frame, or d > 16); bit 3 (r5): the lane-parked
+ *          form of the LDS-table kernel (kg_mc_lane.hpp; MOE_KG_LANE=0 selects the round-4 form -- same results bit for bit),
  * out[2] = wavefronts per workgroup, out[3] = register tiles per wavefront (variant 1) or
  * leading tiles of the paired-row table kept in LDS (variant 0, d > 16),
  * out[4] = streamed per-sample weight table, out[5] = T-free gradient tail, out[6] = workgroups, out[7] = sample pre-pass. */

@@ -448,3 +448,29 @@ def test_randomised_parity_fuzz():
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     assert mod.run(60, 11) == 0
+
+
+@pytest.mark.parametrize("case", [CASES[i] for i in (0, 3, 4, 5, 7, 8, 9, 10, 17)], ids=lambda c: str(c[0]))
+def test_lane_kernel_bit_identical_to_frame_kernel(case, monkeypatch):
+    """r5: the lane-parked wave-per-sample kernel (kg_mc_lane.hpp) against the frame line search it replaces (MOE_KG_LANE=0): every
+    sum, every sample's end point and value, and both pass counters agree BIT FOR BIT -- the two take the row-order sums (|grad|^2,
+    |step|^2, the trial line's three sums) in the same order over the same values; q-KG and d-KG, both covariances, fidelity
+    dimensions, gamma != 0, several restarts, d = 12 / 16."""
+    from cornell_moe_amd import api
+    w, cov, f, gd = _mk(case)
+    G = api.DeviceGP(w.hyperparameters, w.X, w.y, w.noise, w.derivs, cov_type=cov)
+    full = np.hstack([w.discrete, np.ones((w.discrete.shape[0], f))])
+    best = float(G.additional_mean(full).min())
+    Xp = w.Xp if w.p else None
+    monkeypatch.setenv("MOE_KG_VARIANT", "0")
+    res = {}
+    for lane in ("1", "0"):
+        monkeypatch.setenv("MOE_KG_LANE", lane)
+        res[lane] = G.kg(gd, w.bounds_inner, w.discrete, w.Xq, Xp, w.M, best, w.kg_normals, num_fidelity=f, want_best_points=True)
+        info = G.last_kernel_info()
+        # (one or two tiles at d <= 4 take the 16-wavefront instantiation of the frame kernel either way: case 101)
+        assert info["variant"] == 0 and info["xlds"] == 1 and info["lane"] == (int(lane) if info["waves"] <= 8 else 0), info
+    a, b = res["1"], res["0"]
+    assert a["kg_sum"] == b["kg_sum"] and np.array_equal(a["grad_sum"], b["grad_sum"])
+    assert np.array_equal(a["best_point"], b["best_point"])
+    assert a["grad_evals"] == b["grad_evals"] and a["mean_evals"] == b["mean_evals"]

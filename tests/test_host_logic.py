@@ -271,6 +271,25 @@ def test_simplex_domain_start_generation_and_dispatch():
     flat = st.reshape(-1, 3)
     assert flat.min() >= 0.0 and flat.max() <= 1.0 and np.all(flat.sum(axis=1) <= 1.0 + 1e-12)
     assert np.array_equal(multistart._simplex_box(np.tile([-0.5, 2.0], 3), 3), np.tile([0.0, 1.0], 3))
+    # r5: an EMPTY intersection is the reference's BoundsException before any point is drawn (gpp_domain.cpp:107-141) --
+    # 'lower left' corner sum >= 1, or an interval emptied by the clip -- not ten rounds of 5 x larger rejection draws
+    calls = []
+    api_mod.latin_hypercube = lambda seed, bounds, count: calls.append(count)
+    try:
+        for empty in (np.tile([0.4, 0.9], 3), np.array([0.1, 0.2, 1.5, 2.0, 0.0, 0.3]), np.array([0.5, 0.6, 0.5, 0.6])):
+            with pytest.raises(api_mod.BoundsException):
+                multistart._starts(Rng(), empty, 200, 2, len(empty) // 2, domain_type=1)
+    finally:
+        api_mod.latin_hypercube = real
+    assert calls == []
+    # a sliver that rejects every draw: the loop stops within its memory bound and returns no start (the multistart entry points then
+    # refuse num_starts = 0 with "num_multistarts must be > 1", as the reference's drivers do)
+    api_mod.latin_hypercube = lambda seed, bounds, count: (calls.append(count), np.full((count, 2), 0.75))[1]
+    try:
+        none = multistart._starts(Rng(), np.tile([0.0, 1.0], 2), 200, 1, 2, domain_type=1)
+    finally:
+        api_mod.latin_hypercube = real
+    assert none.shape == (0, 1, 2) and max(calls) * 2 <= multistart._MAX_DRAW_DOUBLES
 
     class P(object):
         domain_type = GPP.DomainTypes.simplex
