@@ -27,6 +27,13 @@ class KgStats(C.Structure):
                 ("ms_mc", C.c_double), ("ms_tail", C.c_double)]
 
 
+ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, dp, dp, C.c_int)  # moe_allgather_fn
+
+
+class Comm(C.Structure):  # moe_comm_t
+    _fields_ = [("rank", C.c_int), ("world", C.c_int), ("allgather", ALLGATHER_FN), ("ctx", C.c_void_p)]
+
+
 # every symbol include/moe_hip.h declares: (restype, argtypes)
 _EP = C.POINTER(MoeError)
 _GP = C.c_void_p
@@ -70,6 +77,17 @@ SIGNATURES = {
     "moe_ei_mcmc_batch": (C.c_int, [_GPA, C.c_int, dp, C.c_int, dp, C.c_int, C.c_int, C.c_int, dp, dp, C.c_int, dp, dp, _EP]),
     "moe_kg_mcmc_multistart": (C.c_int, [_GPA, C.c_int, C.c_int, C.POINTER(GdParams), C.POINTER(GdParams), dp, dp, C.c_int, dp,
                                          C.c_int, dp, C.c_int, C.c_int, C.c_int, dp, dp, C.c_int, dp, dp, ip, _EP]),
+    "moe_debug_sharded_items": (C.c_int, [C.POINTER(Comm), C.c_int, C.c_int, C.c_double, C.c_int, dp, _EP]),
+    "moe_kg_multistart_comm": (C.c_int, [_GP, C.POINTER(Comm), C.c_int, C.POINTER(GdParams), C.POINTER(GdParams), dp, dp, C.c_int,
+                                         dp, C.c_int, dp, C.c_int, C.c_int, C.c_int, C.c_double, dp, C.c_int, dp, dp, ip, _EP]),
+    "moe_kg_mcmc_multistart_comm": (C.c_int, [_GPA, C.c_int, C.c_int, C.POINTER(Comm), C.c_int, C.POINTER(GdParams),
+                                              C.POINTER(GdParams), dp, dp, C.c_int, dp, C.c_int, dp, C.c_int, C.c_int, C.c_int,
+                                              dp, dp, C.c_int, dp, dp, ip, _EP]),
+    "moe_kg_multistart_multi": (C.c_int, [_GPA, C.c_int, C.c_int, C.POINTER(GdParams), C.POINTER(GdParams), dp, dp, C.c_int, dp,
+                                          C.c_int, dp, C.c_int, C.c_int, C.c_int, C.c_double, dp, C.c_int, dp, dp, ip, _EP]),
+    "moe_kg_mcmc_multistart_multi": (C.c_int, [_GPA, C.c_int, C.c_int, C.c_int, C.POINTER(GdParams), C.POINTER(GdParams), dp, dp,
+                                               C.c_int, dp, C.c_int, dp, C.c_int, C.c_int, C.c_int, dp, dp, C.c_int, dp, dp, ip,
+                                               _EP]),
     "moe_ei_mcmc_multistart": (C.c_int, [_GPA, C.c_int, C.POINTER(GdParams), dp, dp, C.c_int, dp, C.c_int, C.c_int, C.c_int, dp,
                                          dp, C.c_int, dp, dp, ip, _EP]),
     "moe_ll_create": (C.c_int, [C.c_int, dp, dp, ip, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p), _EP]),

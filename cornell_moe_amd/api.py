@@ -427,8 +427,10 @@ class DeviceGP(object):
                     grad_evals=stats.posterior_grad_evals, ms_state=stats.ms_state, ms_mc=stats.ms_mc, ms_tail=stats.ms_tail)
 
     def kg_multistart(self, outer_params, inner_params, bounds, discrete, starts, Xp, num_mc, best_so_far, normals,
-                      gradient_ascent=True, num_fidelity=0):
-        """moe_kg_multistart: starts [S][q][dim] -> (best_points [q][dim], best_kg, found)."""
+                      gradient_ascent=True, num_fidelity=0, comm=None):
+        """moe_kg_multistart: starts [S][q][dim] -> (best_points [q][dim], best_kg, found).  comm (r5: a dist.Exchange, or None):
+        moe_kg_multistart_comm -- the restarts of every batched evaluation are dealt to the ranks, one all-gather each; every rank
+        returns the single-rank result bit for bit."""
         L = _lib.load()
         go, gi = self._gd(outer_params), self._gd(inner_params)
         bounds, bp = _d(bounds)
@@ -448,9 +450,17 @@ class DeviceGP(object):
         best_kg = C.c_double(0.0)
         found = C.c_int(0)
         err = _lib.MoeError()
-        _check(L.moe_kg_multistart(self._h, int(num_fidelity), C.byref(go), C.byref(gi), bp, dpp, P, starts.ctypes.data_as(dp), S,
-                                   ppp, q, p, int(num_mc), float(best_so_far), npn, 1 if gradient_ascent else 0,
-                                   best.ctypes.data_as(dp), C.byref(best_kg), C.byref(found), C.byref(err)), err)
+        if comm is not None and comm.world > 1:
+            rc = L.moe_kg_multistart_comm(self._h, C.byref(comm.c_struct), int(num_fidelity), C.byref(go), C.byref(gi), bp, dpp, P,
+                                          starts.ctypes.data_as(dp), S, ppp, q, p, int(num_mc), float(best_so_far), npn,
+                                          1 if gradient_ascent else 0, best.ctypes.data_as(dp), C.byref(best_kg), C.byref(found),
+                                          C.byref(err))
+            comm.reraise()  # (an exception inside the exchange callback cannot cross the C frames: it is kept and raised here)
+            _check(rc, err)
+        else:
+            _check(L.moe_kg_multistart(self._h, int(num_fidelity), C.byref(go), C.byref(gi), bp, dpp, P, starts.ctypes.data_as(dp), S,
+                                       ppp, q, p, int(num_mc), float(best_so_far), npn, 1 if gradient_ascent else 0,
+                                       best.ctypes.data_as(dp), C.byref(best_kg), C.byref(found), C.byref(err)), err)
         return best.reshape(q, self.d), best_kg.value, bool(found.value)
 
     def posterior_mean_optimize(self, params, bounds, initial_guess, num_fidelity=0):
@@ -603,8 +613,11 @@ class DeviceGPMCMC(object):
         return ei, (grad if want_grad else None)
 
     def kg_multistart(self, outer_params, inner_params, bounds, discrete_all, starts, Xp, num_mc, best_so_far, normals,
-                      gradient_ascent=True, num_fidelity=0):
-        """moe_kg_mcmc_multistart: starts [S][q][dim] -> (best_points [q][dim], best_kg, found)."""
+                      gradient_ascent=True, num_fidelity=0, comm=None):
+        """moe_kg_mcmc_multistart: starts [S][q][dim] -> (best_points [q][dim], best_kg, found).  comm (r5: a dist.Exchange):
+        moe_kg_mcmc_multistart_comm -- this object holds members rank, rank + world, ... (DeviceGPMCMC(members=dist.shard_members(...)));
+        discrete_all / best_so_far are the WHOLE ensemble's, the local rows are picked here; the per-member values of every batched
+        evaluation are exchanged and added in global member order: the single-rank result bit for bit."""
         starts, S, q, Xp, p, ppp = self._common(starts, Xp)
         go, gi = DeviceGP._gd(outer_params), DeviceGP._gd(inner_params)
         bounds, bp = _d(bounds)
@@ -618,6 +631,18 @@ class DeviceGPMCMC(object):
         val = C.c_double(0.0)
         found = C.c_int(0)
         err = _lib.MoeError()
+        if comm is not None and comm.world > 1:
+            if self.members != list(range(comm.rank, self.total_num_mcmc, comm.world)):
+                raise InvalidValueException("member-sharded optimisation: this rank must hold members rank, rank + world, ...",
+                                            len(self.members), 0, 0)
+            rc = _lib.load().moe_kg_mcmc_multistart_comm(self._arr, len(self.gps), self.total_num_mcmc, C.byref(comm.c_struct),
+                                                         int(num_fidelity), C.byref(go), C.byref(gi), bp, disc.ctypes.data_as(dp), P,
+                                                         starts.ctypes.data_as(dp), S, ppp, q, p, int(num_mc),
+                                                         best.ctypes.data_as(dp), npn, 1 if gradient_ascent else 0,
+                                                         out.ctypes.data_as(dp), C.byref(val), C.byref(found), C.byref(err))
+            comm.reraise()
+            _check(rc, err)
+            return out.reshape(q, self.d), val.value, bool(found.value)
         _check(_lib.load().moe_kg_mcmc_multistart(self._arr, len(self.gps), int(num_fidelity), C.byref(go), C.byref(gi), bp,
                                                   disc.ctypes.data_as(dp), P, starts.ctypes.data_as(dp), S, ppp, q, p, int(num_mc),
                                                   best.ctypes.data_as(dp), npn, 1 if gradient_ascent else 0,
@@ -641,6 +666,55 @@ class DeviceGPMCMC(object):
                                                   int(num_mc), best.ctypes.data_as(dp), npn, 1 if gradient_ascent else 0,
                                                   out.ctypes.data_as(dp), C.byref(val), C.byref(found), C.byref(err)), err)
         return out.reshape(q, self.d), val.value, bool(found.value)
+
+
+def kg_multistart_multi(gps, outer_params, inner_params, bounds, discrete, starts, Xp, num_mc, best_so_far, normals,
+                        gradient_ascent=True, num_fidelity=0):
+    """moe_kg_multistart_multi (r5): the outer optimiser with its restarts dealt to `gps` -- DeviceGP objects holding the same GP on
+    devices 0 .. W-1 -- one host thread per handle, the exchange in shared memory.  (best_points [q][dim], best_kg, found): bit for
+    bit DeviceGP.kg_multistart's."""
+    g0 = gps[0]
+    go, gi = DeviceGP._gd(outer_params), DeviceGP._gd(inner_params)
+    bounds, bp = _d(bounds)
+    discrete, dpp = _d(discrete)
+    P = discrete.reshape(-1, g0.d - num_fidelity).shape[0]
+    starts = np.ascontiguousarray(starts, dtype=np.float64)
+    S, q, _ = starts.shape
+    if Xp is None or np.size(Xp) == 0:
+        p, ppp = 0, None
+    else:
+        Xp, ppp = _d(Xp)
+        p = Xp.reshape(-1, g0.d).shape[0]
+    normals, npn = _d(normals)
+    arr = (C.c_void_p * len(gps))(*[g._h.value for g in gps])
+    best = np.zeros(q * g0.d)
+    val, found, err = C.c_double(0.0), C.c_int(0), _lib.MoeError()
+    _check(_lib.load().moe_kg_multistart_multi(arr, len(gps), int(num_fidelity), C.byref(go), C.byref(gi), bp, dpp, P,
+                                               starts.ctypes.data_as(dp), S, ppp, q, p, int(num_mc), float(best_so_far), npn,
+                                               1 if gradient_ascent else 0, best.ctypes.data_as(dp), C.byref(val), C.byref(found),
+                                               C.byref(err)), err)
+    return best.reshape(q, g0.d), val.value, bool(found.value)
+
+
+def kg_mcmc_multistart_multi(mcmc, num_workers, outer_params, inner_params, bounds, discrete_all, starts, Xp, num_mc, best_so_far,
+                             normals, gradient_ascent=True, num_fidelity=0):
+    """moe_kg_mcmc_multistart_multi (r5): `mcmc` = a DeviceGPMCMC holding the WHOLE ensemble (member g built on device
+    g % num_workers by the caller); worker k -- a host thread -- takes members k, k + num_workers, ...  Result: bit for bit
+    DeviceGPMCMC.kg_multistart's."""
+    starts, S, q, Xp, p, ppp = mcmc._common(starts, Xp)
+    go, gi = DeviceGP._gd(outer_params), DeviceGP._gd(inner_params)
+    bounds, bp = _d(bounds)
+    disc = mcmc._local(discrete_all)
+    P = disc.shape[1] // (mcmc.d - num_fidelity)
+    best = mcmc._local(best_so_far).ravel()
+    normals, npn = _d(normals)
+    out = np.zeros(q * mcmc.d)
+    val, found, err = C.c_double(0.0), C.c_int(0), _lib.MoeError()
+    _check(_lib.load().moe_kg_mcmc_multistart_multi(mcmc._arr, len(mcmc.gps), int(num_workers), int(num_fidelity), C.byref(go),
+                                                    C.byref(gi), bp, disc.ctypes.data_as(dp), P, starts.ctypes.data_as(dp), S, ppp,
+                                                    q, p, int(num_mc), best.ctypes.data_as(dp), npn, 1 if gradient_ascent else 0,
+                                                    out.ctypes.data_as(dp), C.byref(val), C.byref(found), C.byref(err)), err)
+    return out.reshape(q, mcmc.d), val.value, bool(found.value)
 
 
 class LogLikelihood(object):

@@ -5,6 +5,7 @@
 #include <cstring>
 #include <mutex>
 #include <random>
+#include <condition_variable>
 #include <thread>
 
 #include "gp.hpp"
@@ -738,6 +739,234 @@ int moe_kg_mcmc_multistart(const moe_gp_t* const* gps, int num_mcmc, int num_fid
     moe::kg_mcmc_multistart(v, num_fidelity, *outer_params, *inner_params, domain_bounds, discrete_pts_all, num_pts, start_points,
                             num_starts, points_being_sampled, num_to_sample, num_being_sampled, num_mc, best_so_far, normals,
                             do_gradient_ascent, best_points, best_kg, found);
+  });
+}
+
+// ---- r5: the outer optimisers on several ranks (include/moe_hip.h: moe_comm_t) ----
+namespace {
+
+moe::Comm make_comm(const moe_comm_t* c) {
+  require(c != nullptr, "NULL moe_comm_t");
+  require(c->world >= 1 && c->rank >= 0 && c->rank < c->world, "moe_comm_t: rank must lie in [0, world)");
+  require(c->world == 1 || c->allgather != nullptr, "moe_comm_t: world > 1 needs an allgather function");
+  moe::Comm comm;
+  comm.rank = c->rank;
+  comm.world = c->world;
+  moe_allgather_fn fn = c->allgather;
+  void* ctx = c->ctx;
+  comm.allgather = [fn, ctx](const double* send, double* recv, int count) {
+    if (fn(ctx, send, recv, count) != 0) throw moe::Error(MOE_ERR_RUNTIME, "the caller's allgather function reported a failure");
+  };
+  return comm;
+}
+
+// The exchange between the host threads of ONE process that drive several devices: an all-gather through a shared buffer.  Two
+// buffers: a rank may enter the next round as soon as it has left this one, but that round cannot complete before every rank has.
+struct LocalExchange {
+  explicit LocalExchange(int world) : W(world) {}
+  int W;
+  std::mutex m;
+  std::condition_variable cv;
+  int arrived = 0, count = 0;
+  long generation = 0;
+  bool aborted = false;
+  std::vector<double> filling, ready;
+  void abort() {
+    std::lock_guard<std::mutex> lk(m);
+    aborted = true;
+    cv.notify_all();
+  }
+  void allgather(int rank, const double* send, double* recv, int n) {
+    std::unique_lock<std::mutex> lk(m);
+    if (aborted) throw moe::Error(MOE_ERR_RUNTIME, "another worker of the multi-device optimisation failed");
+    if (arrived == 0) {
+      count = n;
+      filling.assign((size_t)W * n, 0.0);
+    }
+    if (n != count) {
+      aborted = true;
+      cv.notify_all();
+      throw moe::Error(MOE_ERR_RUNTIME, "multi-device optimisation: the workers disagree on the size of an exchange", n, count, 0);
+    }
+    std::copy(send, send + n, filling.begin() + (size_t)rank * n);
+    const long mine = generation;
+    if (++arrived == W) {
+      arrived = 0;
+      ready.swap(filling);
+      ++generation;
+      cv.notify_all();
+    } else {
+      cv.wait(lk, [&] { return generation != mine || aborted; });
+      if (generation == mine) throw moe::Error(MOE_ERR_RUNTIME, "another worker of the multi-device optimisation failed");
+    }
+    std::copy(ready.begin(), ready.begin() + (size_t)W * n, recv);
+  }
+};
+
+// One host thread per worker, each running `body(rank, comm)`; the first failure (by rank) is rethrown after all have been joined.
+void run_workers(int W, const std::function<void(int, const moe::Comm&)>& body) {
+  LocalExchange ex(W);
+  std::vector<moe::Error> errors(W, moe::Error(MOE_OK, ""));
+  std::vector<char> failed(W, 0);
+  std::vector<std::thread> threads;
+  threads.reserve(W);
+  struct JoinAll {
+    std::vector<std::thread>& t;
+    LocalExchange& ex;
+    ~JoinAll() {
+      bool pending = false;
+      for (std::thread& th : t) pending = pending || th.joinable();
+      if (pending) ex.abort();  // (only reached when a thread could not be started: release the ones already waiting)
+      for (std::thread& th : t)
+        if (th.joinable()) th.join();
+    }
+  } join_all{threads, ex};
+  for (int k = 0; k < W; ++k) {
+    threads.emplace_back([&, k] {
+      moe::Comm comm;
+      comm.rank = k;
+      comm.world = W;
+      comm.allgather = [&ex, k](const double* send, double* recv, int n) { ex.allgather(k, send, recv, n); };
+      try {
+        body(k, comm);
+      } catch (const moe::Error& e) {
+        errors[k] = e;
+        failed[k] = 1;
+        ex.abort();
+      } catch (const std::exception& e) {
+        errors[k] = moe::Error(MOE_ERR_RUNTIME, e.what());
+        failed[k] = 1;
+        ex.abort();
+      }
+    });
+  }
+  for (std::thread& t : threads) t.join();
+  // (a worker released by another's failure reports "another worker ... failed": prefer the original error)
+  int first = -1;
+  for (int k = 0; k < W; ++k)
+    if (failed[k] && (first < 0 || (std::string(errors[first].what()).find("another worker") != std::string::npos &&
+                                    std::string(errors[k].what()).find("another worker") == std::string::npos)))
+      first = k;
+  if (first >= 0) throw errors[first];
+}
+
+}  // namespace
+
+// The deal-and-exchange step of the multi-rank optimisers on synthetic items -- item i's result is width copies of
+// seed + i + j / 1000 -- with no device work: what the CPU tests drive over gloo.  fail_item >= 0: the rank that owns that item
+// throws (MOE_ERR_SINGULAR), and every rank must come back with that code.
+int moe_debug_sharded_items(const moe_comm_t* comm_c, int n, int width, double seed, int fail_item, double* out, moe_error_t* err) {
+  return guarded(err, [&] {
+    require(out != nullptr && n >= 0 && width >= 1, "bad argument");
+    const moe::Comm comm = make_comm(comm_c);
+    moe::sharded_items(comm, n, width, [&](const std::vector<int>& idx, double* out_local) {
+      for (size_t k = 0; k < idx.size(); ++k) {
+        if (idx[k] == fail_item) throw moe::Error(MOE_ERR_SINGULAR, "synthetic failure", (double)fail_item, 1.0, 2.0);
+        for (int j = 0; j < width; ++j) out_local[k * (size_t)width + j] = seed + idx[k] + j / 1000.0;
+      }
+    }, out);
+  });
+}
+
+int moe_kg_multistart_comm(const moe_gp_t* gp_c, const moe_comm_t* comm_c, int num_fidelity, const moe_gd_params_t* outer_params,
+                           const moe_gd_params_t* inner_params, const double* domain_bounds, const double* discrete_pts,
+                           int num_pts, const double* start_points, int num_starts, const double* points_being_sampled,
+                           int num_to_sample, int num_being_sampled, int num_mc, double best_so_far, const double* normals,
+                           int do_gradient_ascent, double* best_points, double* best_kg, int* found, moe_error_t* err) {
+  return guarded(err, [&] {
+    std::unique_lock<std::mutex> lk;
+    moe::GpDev& gp = lock_gp(gp_c, lk);
+    require(outer_params && inner_params && best_points && best_kg && found, "NULL argument");
+    const moe::Comm comm = make_comm(comm_c);
+    moe::kg_multistart(gp, num_fidelity, *outer_params, *inner_params, domain_bounds, discrete_pts, num_pts, start_points,
+                       num_starts, points_being_sampled, num_to_sample, num_being_sampled, num_mc, best_so_far, normals,
+                       do_gradient_ascent, best_points, best_kg, found, &comm);
+  });
+}
+
+int moe_kg_mcmc_multistart_comm(const moe_gp_t* const* local_gps, int num_local, int total_num_mcmc, const moe_comm_t* comm_c,
+                                int num_fidelity, const moe_gd_params_t* outer_params, const moe_gd_params_t* inner_params,
+                                const double* domain_bounds, const double* discrete_pts_local, int num_pts,
+                                const double* start_points, int num_starts, const double* points_being_sampled,
+                                int num_to_sample, int num_being_sampled, int num_mc, const double* best_so_far_local,
+                                const double* normals, int do_gradient_ascent, double* best_points, double* best_kg, int* found,
+                                moe_error_t* err) {
+  return guarded(err, [&] {
+    require(outer_params && inner_params && domain_bounds && discrete_pts_local && start_points && best_so_far_local && normals &&
+                best_points && best_kg && found,
+            "NULL argument");
+    const auto locks = lock_ensemble(local_gps, num_local);
+    const std::vector<moe::GpDev*> v = ensemble(local_gps, num_local);
+    const moe::Comm comm = make_comm(comm_c);
+    moe::kg_mcmc_multistart(v, num_fidelity, *outer_params, *inner_params, domain_bounds, discrete_pts_local, num_pts, start_points,
+                            num_starts, points_being_sampled, num_to_sample, num_being_sampled, num_mc, best_so_far_local, normals,
+                            do_gradient_ascent, best_points, best_kg, found, total_num_mcmc, &comm);
+  });
+}
+
+int moe_kg_multistart_multi(const moe_gp_t* const* gps, int num_devices, int num_fidelity, const moe_gd_params_t* outer_params,
+                            const moe_gd_params_t* inner_params, const double* domain_bounds, const double* discrete_pts,
+                            int num_pts, const double* start_points, int num_starts, const double* points_being_sampled,
+                            int num_to_sample, int num_being_sampled, int num_mc, double best_so_far, const double* normals,
+                            int do_gradient_ascent, double* best_points, double* best_kg, int* found, moe_error_t* err) {
+  return guarded(err, [&] {
+    require(gps != nullptr && num_devices > 0, "need at least one GP handle");
+    require(outer_params && inner_params && best_points && best_kg && found, "NULL argument");
+    const auto locks = lock_ensemble(gps, num_devices);
+    require((int)locks.size() == num_devices, "the handles must be distinct and non-NULL");
+    const int W = num_devices, qd = num_to_sample * gps[0]->dev.d;
+    for (int k = 1; k < W; ++k)
+      require(gps[k]->dev.d == gps[0]->dev.d && gps[k]->dev.n == gps[0]->dev.n && gps[k]->dev.g == gps[0]->dev.g,
+              "the handles must hold the same GP");
+    std::vector<std::vector<double>> pts(W, std::vector<double>((size_t)std::max(qd, 1)));
+    std::vector<double> val(W, 0.0);
+    std::vector<int> fnd(W, 0);
+    run_workers(W, [&](int k, const moe::Comm& comm) {
+      moe::kg_multistart(const_cast<moe_gp_t*>(gps[k])->dev, num_fidelity, *outer_params, *inner_params, domain_bounds, discrete_pts,
+                         num_pts, start_points, num_starts, points_being_sampled, num_to_sample, num_being_sampled, num_mc,
+                         best_so_far, normals, do_gradient_ascent, pts[k].data(), &val[k], &fnd[k], &comm);
+    });
+    std::copy(pts[0].begin(), pts[0].begin() + qd, best_points);  // (every worker holds the same answer)
+    *best_kg = val[0];
+    *found = fnd[0];
+  });
+}
+
+int moe_kg_mcmc_multistart_multi(const moe_gp_t* const* gps, int num_mcmc, int num_workers, int num_fidelity,
+                                 const moe_gd_params_t* outer_params, const moe_gd_params_t* inner_params,
+                                 const double* domain_bounds, const double* discrete_pts_all, int num_pts,
+                                 const double* start_points, int num_starts, const double* points_being_sampled,
+                                 int num_to_sample, int num_being_sampled, int num_mc, const double* best_so_far,
+                                 const double* normals, int do_gradient_ascent, double* best_points, double* best_kg, int* found,
+                                 moe_error_t* err) {
+  return guarded(err, [&] {
+    require(outer_params && inner_params && domain_bounds && discrete_pts_all && start_points && best_so_far && normals &&
+                best_points && best_kg && found,
+            "NULL argument");
+    require(num_workers >= 1 && num_workers <= num_mcmc, "num_workers must lie in [1, num_mcmc]");
+    const auto locks = lock_ensemble(gps, num_mcmc);
+    const std::vector<moe::GpDev*> all = ensemble(gps, num_mcmc);
+    const int W = num_workers, d = all[0]->d, qd = num_to_sample * d;
+    require(num_fidelity >= 0 && num_fidelity < d, "num_fidelity out of range");
+    const size_t disc_stride = (size_t)num_pts * (d - num_fidelity);
+    // worker k holds members k, k + W, ...: its rows of the per-member arrays, gathered
+    std::vector<std::vector<moe::GpDev*>> mem(W);
+    std::vector<std::vector<double>> disc(W), best(W), pts(W, std::vector<double>((size_t)std::max(qd, 1)));
+    for (int g = 0; g < num_mcmc; ++g) {
+      mem[g % W].push_back(all[g]);
+      disc[g % W].insert(disc[g % W].end(), discrete_pts_all + g * disc_stride, discrete_pts_all + (g + 1) * disc_stride);
+      best[g % W].push_back(best_so_far[g]);
+    }
+    std::vector<double> val(W, 0.0);
+    std::vector<int> fnd(W, 0);
+    run_workers(W, [&](int k, const moe::Comm& comm) {
+      moe::kg_mcmc_multistart(mem[k], num_fidelity, *outer_params, *inner_params, domain_bounds, disc[k].data(), num_pts, start_points,
+                              num_starts, points_being_sampled, num_to_sample, num_being_sampled, num_mc, best[k].data(), normals,
+                              do_gradient_ascent, pts[k].data(), &val[k], &fnd[k], num_mcmc, &comm);
+    });
+    std::copy(pts[0].begin(), pts[0].begin() + qd, best_points);
+    *best_kg = val[0];
+    *found = fnd[0];
   });
 }
 

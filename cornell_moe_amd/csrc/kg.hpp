@@ -58,6 +58,21 @@ KgPending kg_launch(GpDev& gp, int num_fidelity, const moe_gd_params_t& gd, cons
 // (env MOE_REFERENCE_QUIRKS=0 or moe_set_reference_quirks(0) turn it off; include/moe_hip.h).
 bool reference_quirks();
 void set_reference_quirks(int on);  // < 0: back to the environment's setting
+// The exchange step of an outer optimisation that runs on several ranks (r5): an all-gather of `count` doubles per rank, every rank
+// receiving recv[world][count] in rank order.  One process per GPU passes torch.distributed's collective through the C ABI
+// (moe_comm_t: RCCL over xGMI, or gloo); one process driving several devices gets an in-memory exchange between its host threads
+// (moe_kg_multistart_multi).  The optimisers call it once per batched evaluation -- the merge the reference does under
+// `omp critical` (gpp_optimization.hpp:1537-1545) -- and every rank then takes the same decisions on the same bits.
+struct Comm {
+  int rank = 0, world = 1;
+  std::function<void(const double* send, double* recv, int count)> allgather;
+};
+// `width` doubles per item for `n` items, item i evaluated by rank i % world (the reference's omp schedule(static, 1)): eval_local
+// fills out_local[n_local][width] for the items idx[0 .. n_local); the result out[n][width] is complete on every rank.  A rank
+// whose evaluation throws still takes part in the exchange, and then EVERY rank throws that error (no rank is left waiting).
+void sharded_items(const Comm& comm, int n, int width,
+                   const std::function<void(const std::vector<int>& idx, double* out_local)>& eval_local, double* out);
+
 // A maximisation objective evaluated at a BATCH of points [n][qd]: values [n], grads [n][qd].
 struct BatchObjective {
   std::function<void(const double* x_all, int n, double* values)> values;
@@ -86,10 +101,12 @@ void multistart(const BatchObjective& f, const moe_gd_params_t& outer, const dou
 void latin_hypercube(unsigned int seed, const double* bounds, int dim, int num_points, double* out);
 // ComputeKGOptimalPointsToSampleViaMultistartGradientDescent / ...ViaLatinHypercubeSearch
 // (gpp_knowledge_gradient_optimization.hpp:860-1141) from caller-supplied starts [num_starts][q][d].
+// comm != NULL (r5): the restarts of every batched evaluation are dealt to the ranks (rank r evaluates items r, r + world, ...) and
+// exchanged; every rank returns the same point, bit for bit the single-rank one (an evaluation's bits do not depend on its batch).
 void kg_multistart(GpDev& gp, int num_fidelity, const moe_gd_params_t& outer, const moe_gd_params_t& inner, const double* bounds,
                    const double* discrete, int P, const double* starts, int num_starts, const double* Xp, int q, int p,
                    int num_mc, double best_so_far, const double* normals, int do_gradient_ascent, double* best_points,
-                   double* best_kg, int* found);
+                   double* best_kg, int* found, const Comm* comm = nullptr);
 // ComputeOptimalPointsToSampleViaMultistartGradientDescent / EvaluateEIAtPointList (gpp_math.hpp:1683-1800,
 // gpp_math.cpp:2305-2356) from caller-supplied starts [num_starts][q][d]; q = 1, p = 0 takes the analytic evaluator.
 void ei_multistart(GpDev& gp, const moe_gd_params_t& outer, const double* bounds, const double* starts, int num_starts,
@@ -115,11 +132,19 @@ std::vector<int> top_k_order(const double* vals, int num_starts);
 void kg_mcmc_finalize(double* kg, double* grad, const double* Xq_all, int num_evals, int q, int d, int num_fidelity, int num_mcmc);
 void ei_mcmc_batch(const std::vector<GpDev*>& gps, const double* Xq_all, int num_evals, const double* Xp, int q, int p, int num_mc,
                    const double* best_so_far, const double* normals, bool analytic, double* ei, double* grad_ei);
+// comm != NULL (r5): `gps` are THIS rank's members of an ensemble of total_num_mcmc -- member g lives on rank g % world, local
+// index g / world (discrete_all / best_so_far hold the local members' rows) -- every batched evaluation exchanges the per-member
+// values and every rank adds them up in global member order: the single-rank sums, bit for bit.
 void kg_mcmc_multistart(const std::vector<GpDev*>& gps, int num_fidelity, const moe_gd_params_t& outer,
                         const moe_gd_params_t& inner, const double* bounds, const double* discrete_all, int P,
                         const double* starts, int num_starts, const double* Xp, int q, int p, int num_mc,
                         const double* best_so_far, const double* normals, int do_gradient_ascent, double* best_points,
-                        double* best_kg, int* found);
+                        double* best_kg, int* found, int total_num_mcmc = -1, const Comm* comm = nullptr);
+// Per-member values of a batch (each already divided by num_mc): kg_mem[num_members][E], grad_mem[num_members][E][q*d] (NULL = values only).
+void kg_mcmc_members(const std::vector<GpDev*>& gps, int num_fidelity, const moe_gd_params_t& inner, const double* bounds,
+                     const double* discrete_all, int P, const double* Xq_all, int num_evals, const double* Xp, int q, int p,
+                     int num_mc, const double* best_so_far, const double* normals, bool want_grad, double* kg_mem, double* grad_mem,
+                     const double* disc_head = nullptr);
 void ei_mcmc_multistart(const std::vector<GpDev*>& gps, const moe_gd_params_t& outer, const double* bounds, const double* starts,
                         int num_starts, const double* Xp, int q, int p, int num_mc, const double* best_so_far,
                         const double* normals, int do_gradient_ascent, double* best_points, double* best_ei, int* found);

@@ -42,6 +42,10 @@ namespace moe {
 #ifndef MOE_KG_FAST_SQRT
 #define MOE_KG_FAST_SQRT 1
 #endif
+// trial counts up to which the multi-trial sweeps unroll four tiles instead of two (0: never -- the measured default, see DESIGN)
+#ifndef MOE_KG_MULTI_UNROLL4_MAXT
+#define MOE_KG_MULTI_UNROLL4_MAXT 0
+#endif
 #if MOE_BLOCK_PROF
 #define MOE_PROF_T(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
 #define MOE_PROF_ADD(dst, a, b) dst += (b) - (a)
@@ -571,7 +575,7 @@ __device__ __forceinline__ bool eval_multi_loop_s(const double* __restrict__ xs,
 #pragma unroll
     for (int t = 0; t < T; ++t) tt[t] = (al[t] * al[t]) * (0.25 * sdd);  // alpha_t^2 |dv|^2
   }
-#pragma unroll(SMALL ? 1 : 2)
+#pragma unroll(SMALL ? 1 : (T <= MOE_KG_MULTI_UNROLL4_MAXT ? 4 : 2))
   for (int tile = 0; tile < ntiles; ++tile) {
     double nx[NX], nwa[1 + G];
     xt += NX * 64;  // (one tile of padding behind both arrays: see eval_loop)

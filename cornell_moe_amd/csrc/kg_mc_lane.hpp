@@ -28,6 +28,9 @@
 #define MOE_LANE_SGPR 1
 #endif
 
+#ifndef MOE_LANE_GRAD_UNROLL
+#define MOE_LANE_GRAD_UNROLL 4
+#endif
 #ifndef MOE_LANE_RELOAD_ARGS
 #define MOE_LANE_RELOAD_ARGS 1
 #endif
@@ -104,7 +107,7 @@ __device__ __forceinline__ double grad_pass_parked(const double* __restrict__ xs
   for (int k = 0; k < DP; ++k) cx[k] = xt[k * 64];
 #pragma unroll
   for (int a = 0; a < 1 + G; ++a) cw[a] = wt[a * 64];
-#pragma unroll 2
+#pragma unroll MOE_LANE_GRAD_UNROLL
   for (int t = 0; t < ntiles; ++t) {
     double nx[DP], nw[1 + G];
     xt += XR * 64;

@@ -34,18 +34,16 @@ void check_ensemble(const std::vector<GpDev*>& gps) {
 
 }  // namespace
 
-void kg_mcmc_sums(const std::vector<GpDev*>& gps, int num_fidelity, const moe_gd_params_t& inner, const double* bounds,
-                  const double* discrete_all, int P, const double* Xq_all, int num_evals, const double* Xp, int q, int p,
-                  int num_mc, const double* best_so_far, const double* normals, bool want_grad, double* kg_sum, double* grad_sum,
-                  const double* disc_head) {
+// The per-member values of a batch, not yet added up (r5): what the ranks of a member-sharded optimisation exchange, so that every
+// rank can add the members up in GLOBAL order -- the order kg_mcmc_sums adds them in on one rank.
+void kg_mcmc_members(const std::vector<GpDev*>& gps, int num_fidelity, const moe_gd_params_t& inner, const double* bounds,
+                     const double* discrete_all, int P, const double* Xq_all, int num_evals, const double* Xp, int q, int p,
+                     int num_mc, const double* best_so_far, const double* normals, bool want_grad, double* kg_mem, double* grad_mem,
+                     const double* disc_head) {
   check_ensemble(gps);
   const int d = gps[0]->d, qd = q * d, E = num_evals;
-  std::fill(kg_sum, kg_sum + E, 0.0);
-  if (want_grad) std::fill(grad_sum, grad_sum + (size_t)E * qd, 0.0);
   std::vector<double> ks(E), gs(want_grad ? (size_t)E * qd : 0);
   const size_t disc_stride = (size_t)P * (d - num_fidelity);
-  // launch every member (own stream, own workspaces), then collect: member i's kernels run while member i+1's state set-up
-  // and host algebra are being prepared
   // (every member owns its workspaces: the batch each of them may carry is the budget divided by the ensemble size)
   const char* bg = std::getenv("MOE_KG_BATCH_GB");
   const double budget = ((bg && *bg) ? std::atof(bg) : 48.0) / (double)gps.size();
@@ -60,10 +58,30 @@ void kg_mcmc_sums(const std::vector<GpDev*>& gps, int num_fidelity, const moe_gd
                                   false, budget, disc_head));
     for (size_t i = 0; i < gps.size(); ++i) {
       pending[i].collect(ks.data(), want_grad ? gs.data() : nullptr, nullptr, nullptr);
-      for (int e = 0; e < ne; ++e) kg_sum[e0 + e] += ks[e] / (double)num_mc;
+      for (int e = 0; e < ne; ++e) kg_mem[i * (size_t)E + e0 + e] = ks[e] / (double)num_mc;
       if (want_grad)
-        for (size_t j = 0; j < (size_t)ne * qd; ++j) grad_sum[(size_t)e0 * qd + j] += gs[j] / (double)num_mc;
+        for (size_t j = 0; j < (size_t)ne * qd; ++j) grad_mem[(i * (size_t)E + e0) * qd + j] = gs[j] / (double)num_mc;
     }
+  }
+}
+
+void kg_mcmc_sums(const std::vector<GpDev*>& gps, int num_fidelity, const moe_gd_params_t& inner, const double* bounds,
+                  const double* discrete_all, int P, const double* Xq_all, int num_evals, const double* Xp, int q, int p,
+                  int num_mc, const double* best_so_far, const double* normals, bool want_grad, double* kg_sum, double* grad_sum,
+                  const double* disc_head) {
+  check_ensemble(gps);
+  const int d = gps[0]->d, qd = q * d, E = num_evals;
+  // launch every member (own stream, own workspaces), then collect: member i's kernels run while member i+1's state set-up
+  // and host algebra are being prepared (kg_mcmc_members); the members are added up in their order
+  std::vector<double> km(gps.size() * (size_t)E), gm(want_grad ? gps.size() * (size_t)E * qd : 0);
+  kg_mcmc_members(gps, num_fidelity, inner, bounds, discrete_all, P, Xq_all, E, Xp, q, p, num_mc, best_so_far, normals, want_grad,
+                  km.data(), want_grad ? gm.data() : nullptr, disc_head);
+  std::fill(kg_sum, kg_sum + E, 0.0);
+  if (want_grad) std::fill(grad_sum, grad_sum + (size_t)E * qd, 0.0);
+  for (size_t i = 0; i < gps.size(); ++i) {
+    for (int e = 0; e < E; ++e) kg_sum[e] += km[i * (size_t)E + e];
+    if (want_grad)
+      for (size_t j = 0; j < (size_t)E * qd; ++j) grad_sum[j] += gm[i * (size_t)E * qd + j];
   }
 }
 
@@ -174,24 +192,61 @@ void kg_mcmc_multistart(const std::vector<GpDev*>& gps, int num_fidelity, const 
                         const moe_gd_params_t& inner, const double* bounds, const double* discrete_all, int P,
                         const double* starts, int num_starts, const double* Xp, int q, int p, int num_mc,
                         const double* best_so_far, const double* normals, int do_gradient_ascent, double* best_points,
-                        double* best_kg, int* found) {
+                        double* best_kg, int* found, int total_num_mcmc, const Comm* comm) {
   check_ensemble(gps);
   if (num_starts <= 0) throw Error(MOE_ERR_BOUNDS, "num_multistarts must be > 1", num_starts, 1, 1e9);
-  const int d = gps[0]->d, qd = q * d, nm = (int)gps.size();
+  const bool shard = comm != nullptr && comm->world > 1;
+  const int d = gps[0]->d, qd = q * d, nm = shard ? total_num_mcmc : (int)gps.size();
+  if (shard) {
+    // member g lives on rank g % world at local index g / world
+    const int W = comm->world, mine = (total_num_mcmc - comm->rank + W - 1) / W;
+    if (total_num_mcmc < W || mine != (int)gps.size())
+      throw Error(MOE_ERR_INVALID_VALUE, "member-sharded KG-MCMC optimisation: this rank must hold members rank, rank + world, ... "
+                  "of total_num_mcmc >= world", (double)gps.size(), (double)mine, 0);
+  }
+  // Sums over ALL members of a batch of evaluations.  One rank: kg_mcmc_sums.  Sharded (r5): every rank evaluates its members,
+  // ONE exchange of the per-member values, and every rank adds them up in global member order -- the bits of the single-rank sum.
+  auto all_sums = [&](const double* x_all, int n, bool want_grad, double* ks, double* gs, const double* head_pts) {
+    if (!shard) {
+      kg_mcmc_sums(gps, num_fidelity, inner, bounds, discrete_all, P, x_all, n, Xp, q, p, num_mc, best_so_far, normals, want_grad, ks, gs,
+                   head_pts);
+      return;
+    }
+    const int W = comm->world, per = (total_num_mcmc + W - 1) / W, width = n * (1 + (want_grad ? qd : 0));
+    std::vector<double> all((size_t)W * per * width);
+    // items = (rank, slot) pairs: item k * per + j is member j * W + k (or a pad); dealt so that rank k evaluates exactly its own
+    sharded_items(Comm{comm->rank, W, comm->allgather}, W, per * width, [&](const std::vector<int>&, double* out_local) {
+      std::vector<double> km(gps.size() * (size_t)n), gm(want_grad ? gps.size() * (size_t)n * qd : 0);
+      kg_mcmc_members(gps, num_fidelity, inner, bounds, discrete_all, P, x_all, n, Xp, q, p, num_mc, best_so_far, normals, want_grad,
+                      km.data(), want_grad ? gm.data() : nullptr, head_pts);
+      std::fill(out_local, out_local + (size_t)per * width, 0.0);
+      for (size_t j = 0; j < gps.size(); ++j) {
+        double* slot = out_local + j * (size_t)width;
+        std::copy(&km[j * (size_t)n], &km[(j + 1) * (size_t)n], slot);
+        if (want_grad) std::copy(&gm[j * (size_t)n * qd], &gm[(j + 1) * (size_t)n * qd], slot + n);
+      }
+    }, all.data());
+    std::fill(ks, ks + n, 0.0);
+    if (want_grad) std::fill(gs, gs + (size_t)n * qd, 0.0);
+    for (int g = 0; g < total_num_mcmc; ++g) {
+      const double* slot = &all[((size_t)(g % W) * per + (size_t)(g / W)) * width];
+      for (int e = 0; e < n; ++e) ks[e] += slot[e];
+      if (want_grad)
+        for (size_t j = 0; j < (size_t)n * qd; ++j) gs[j] += slot[n + j];
+    }
+  };
   if (!reference_quirks()) {
     // The driver as the reference INTENDS it (MOE_REFERENCE_QUIRKS=0 / moe_set_reference_quirks(0)): the generic multistart over
     // the MCMC-averaged objective KG(x) = mean_i KG_i(x) / cost(x) -- fresh per-GP states at every evaluation, all q points move
     // and are returned, the plain gradient ((mean grad) cost - KG grad cost) / cost^2 at every step.
     BatchObjective f;
     f.values = [&](const double* x_all, int n, double* values) {
-      kg_mcmc_sums(gps, num_fidelity, inner, bounds, discrete_all, P, x_all, n, Xp, q, p, num_mc, best_so_far, normals, false, values,
-                   nullptr, nullptr);
+      all_sums(x_all, n, false, values, nullptr, nullptr);
       kg_mcmc_finalize(values, nullptr, x_all, n, q, d, num_fidelity, nm);
     };
     f.grads = [&](const double* x_all, int n, double* grads) {
       std::vector<double> ks(n);
-      kg_mcmc_sums(gps, num_fidelity, inner, bounds, discrete_all, P, x_all, n, Xp, q, p, num_mc, best_so_far, normals, true, ks.data(),
-                   grads, nullptr);
+      all_sums(x_all, n, true, ks.data(), grads, nullptr);
       kg_mcmc_finalize(ks.data(), grads, x_all, n, q, d, num_fidelity, nm);
     };
     multistart(f, outer, bounds, d, qd, starts, num_starts, do_gradient_ascent, -INFINITY, best_points, best_kg, found);
@@ -202,10 +257,7 @@ void kg_mcmc_multistart(const std::vector<GpDev*>& gps, int num_fidelity, const 
     std::copy(head, head + qd, seen);
     std::copy(actual, actual + d, seen);
   };
-  auto sums = [&](const double* x_all, int n, bool want_grad, double* ks, double* gs) {
-    kg_mcmc_sums(gps, num_fidelity, inner, bounds, discrete_all, P, x_all, n, Xp, q, p, num_mc, best_so_far, normals, want_grad, ks,
-                 gs, head);
-  };
+  auto sums = [&](const double* x_all, int n, bool want_grad, double* ks, double* gs) { all_sums(x_all, n, want_grad, ks, gs, head); };
   *found = 0;
   *best_kg = -INFINITY;
   std::vector<double> seen(qd);

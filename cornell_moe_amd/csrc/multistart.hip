@@ -290,10 +290,50 @@ void multistart(const BatchObjective& f, const moe_gd_params_t& outer, const dou
   }
 }
 
+void sharded_items(const Comm& comm, int n, int width,
+                   const std::function<void(const std::vector<int>& idx, double* out_local)>& eval_local, double* out) {
+  const int W = std::max(comm.world, 1), r = comm.rank;
+  std::vector<int> idx;
+  for (int i = r; i < n; i += W) idx.push_back(i);
+  const int per = (n + W - 1) / W;  // items per rank, padded: ONE fixed-size exchange
+  // payload of a rank: [status | value | lo | hi | per x width results]; a failed rank's status travels with zeros
+  const int count = 4 + per * width;
+  std::vector<double> send((size_t)count, 0.0), recv((size_t)count * W, 0.0);
+  Error mine(MOE_OK, "");
+  try {
+    if (!idx.empty()) eval_local(idx, send.data() + 4);
+  } catch (const Error& e) {
+    mine = e;
+    send[0] = (double)e.code;
+    send[1] = e.payload[0];
+    send[2] = e.payload[1];
+    send[3] = e.payload[2];
+    std::fill(send.begin() + 4, send.end(), 0.0);
+  }
+  if (W > 1) {
+    if (!comm.allgather) throw Error(MOE_ERR_RUNTIME, "multi-rank optimisation without an exchange function");
+    comm.allgather(send.data(), recv.data(), count);
+  } else {
+    recv = send;
+  }
+  for (int k = 0; k < W; ++k) {
+    const double* rk = &recv[(size_t)k * count];
+    if (rk[0] != 0.0) {
+      if (k == r) throw mine;  // (this rank's own message)
+      throw Error((int)rk[0], "an evaluation failed on another rank of the multi-rank optimisation (its message is on that rank)",
+                  rk[1], rk[2], rk[3]);
+    }
+  }
+  for (int i = 0; i < n; ++i) {
+    const double* src = &recv[(size_t)(i % W) * count + 4 + (size_t)(i / W) * width];
+    std::copy(src, src + width, out + (size_t)i * width);
+  }
+}
+
 void kg_multistart(GpDev& gp, int num_fidelity, const moe_gd_params_t& outer, const moe_gd_params_t& inner, const double* bounds,
                    const double* discrete, int P, const double* starts, int num_starts, const double* Xp, int q, int p,
                    int num_mc, double best_so_far, const double* normals, int do_gradient_ascent, double* best_points,
-                   double* best_kg, int* found) {
+                   double* best_kg, int* found, const Comm* comm) {
   const int d = gp.d, qd = q * d;
   // (the reference builds outer AND inner domain of one type, gpp_python_knowledge_gradient.cpp:288-296; here each parameter struct
   //  carries its own: the MC kernels' line search takes the inner one -- kg.hip kg_launch)
@@ -313,6 +353,29 @@ void kg_multistart(GpDev& gp, int num_fidelity, const moe_gd_params_t& outer, co
                       true, ksum.data(), grads, nullptr, nullptr, head);
     for (size_t j = 0; j < (size_t)n * qd; ++j) grads[j] /= (double)num_mc;
   };
+  if (comm != nullptr && comm->world > 1) {
+    // r5: the restarts dealt to the ranks -- each rank's share in one batched device pass, one exchange per evaluation of the
+    // optimiser (the reference's omp-parallel restarts with their critical-section merge, gpp_optimization.hpp:1472-1546)
+    const BatchObjective local = f;
+    auto gather = [&](const double* x_all, const std::vector<int>& idx, std::vector<double>& xl) {
+      xl.resize(idx.size() * (size_t)qd);
+      for (size_t k = 0; k < idx.size(); ++k) std::copy(x_all + (size_t)idx[k] * qd, x_all + (size_t)(idx[k] + 1) * qd, &xl[k * qd]);
+    };
+    f.values = [&, local](const double* x_all, int n, double* values) {
+      sharded_items(*comm, n, 1, [&](const std::vector<int>& idx, double* out_local) {
+        std::vector<double> xl;
+        gather(x_all, idx, xl);
+        local.values(xl.data(), (int)idx.size(), out_local);
+      }, values);
+    };
+    f.grads = [&, local](const double* x_all, int n, double* grads) {
+      sharded_items(*comm, n, qd, [&](const std::vector<int>& idx, double* out_local) {
+        std::vector<double> xl;
+        gather(x_all, idx, xl);
+        local.grads(xl.data(), (int)idx.size(), out_local);
+      }, grads);
+    };
+  }
   multistart(f, outer, bounds, d, qd, starts, num_starts, do_gradient_ascent, -INFINITY, best_points, best_kg, found);
 }
 

@@ -90,6 +90,60 @@ def gather_restarts(local_idx, local_kg, local_grad, num_restarts, group=None, d
     return kg, grad
 
 
+class Exchange(object):
+    """moe_comm_t for the multi-rank outer optimisers (r5; include/moe_hip.h: moe_kg_multistart_comm, moe_kg_mcmc_multistart_comm):
+    the library's all-gather of `count` doubles per rank, carried by torch.distributed -- `group` / `device` as Comm hands them out
+    (backend nccl = RCCL over xGMI with the buffers on `device`, gloo with host tensors).  Counts exchanges and bytes for the
+    benchmark lines.  An exception raised inside the callback cannot unwind through the C frames: it is stored, the library gets a
+    failure code, and the caller re-raises it (reraise)."""
+
+    def __init__(self, rank, world, group=None, device=None, allgather=None):
+        from . import _lib
+        import ctypes as C
+        self.rank, self.world, self.group, self.device = int(rank), int(world), group, device
+        self.calls, self.doubles, self.seconds = 0, 0, 0.0
+        self._exc = None
+        self._impl = allgather or self._torch_allgather
+        self._cb = _lib.ALLGATHER_FN(self._callback)  # (kept alive with the object)
+        self.c_struct = _lib.Comm(self.rank, self.world, self._cb, None)
+        self._C = C
+
+    @classmethod
+    def from_comm(cls, comm):
+        """From dist.bring_up()'s Comm (world 1: an Exchange that is never called)."""
+        return cls(comm.rank, comm.world, comm.group, comm.device)
+
+    def _torch_allgather(self, send):
+        import torch
+        import torch.distributed as dist
+        t = torch.from_numpy(send)
+        if self.device is not None:
+            t = t.to(self.device)
+        outs = [torch.empty_like(t) for _ in range(self.world)]
+        dist.all_gather(outs, t, group=self.group)
+        return np.concatenate([o.cpu().numpy() for o in outs])
+
+    def _callback(self, ctx, send, recv, count):
+        import time
+        try:
+            t0 = time.perf_counter()
+            a = np.ctypeslib.as_array(send, shape=(count,)).copy()
+            out = np.asarray(self._impl(a), dtype=np.float64).reshape(self.world * count)
+            np.ctypeslib.as_array(recv, shape=(self.world * count,))[:] = out
+            self.calls += 1
+            self.doubles += count
+            self.seconds += time.perf_counter() - t0
+            return 0
+        except BaseException as e:  # noqa: BLE001 -- nothing may propagate into the C caller
+            self._exc = e
+            return 1
+
+    def reraise(self):
+        if self._exc is not None:
+            e, self._exc = self._exc, None
+            raise e
+
+
 def shard_members(num_mcmc, rank, world):
     """GP indices of an MCMC ensemble that `rank` builds and evaluates (round-robin)."""
     return list(range(rank, num_mcmc, world))

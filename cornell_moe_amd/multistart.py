@@ -95,10 +95,14 @@ def _starts(randomness, bounds, count, q, d, domain_type=0):
 
 
 def kg_optimal_points(dev_gp, num_fidelity, optimizer_parameters, optimizer_parameters_inner, bounds, discrete, Xp,
-                      num_to_sample, best_so_far, num_mc, randomness, starts=None):
+                      num_to_sample, best_so_far, num_mc, randomness, starts=None, comm=None):
     """ComputeKGOptimalPointsToSample (gpp_knowledge_gradient_optimization.cpp:490-551): multistart gradient ascent from
     Latin-hypercube starts, Latin-hypercube value search as the fall-back / null-optimiser path.
-    Returns (best_points [q][dim], found_flag)."""
+    Returns (best_points [q][dim], found_flag).
+    comm (r5: dist.Exchange): one process per GPU, every rank calling this with the same arguments and the same `randomness` seeds
+    (the start sets and the normal table are drawn identically on every rank) and a GP over the same data on its own device: the
+    restarts of every optimiser step are dealt to the ranks, one all-gather per step (moe_kg_multistart_comm), and every rank
+    returns the single-rank answer bit for bit."""
     from . import GPP, api
     d = dev_gp.d
     q = int(num_to_sample)
@@ -122,13 +126,13 @@ def kg_optimal_points(dev_gp, num_fidelity, optimizer_parameters, optimizer_para
             starts = lhc(gd[0])
         starts = np.asarray(starts, dtype=np.float64).reshape(-1, q, d)
         best, _, found = dev_gp.kg_multistart(gd, inner_gd, bounds, discrete, starts, Xp, num_mc, best_so_far, normals,
-                                              gradient_ascent=True, num_fidelity=num_fidelity)
+                                              gradient_ascent=True, num_fidelity=num_fidelity, comm=comm)
     if not found:
         n_lhc = int(optimizer_parameters.num_random_samples or 0)
         if n_lhc > 0:
             best, _, found = dev_gp.kg_multistart(inner_gd, inner_gd, bounds, discrete, lhc(n_lhc), Xp,
                                                   num_mc, best_so_far, normals, gradient_ascent=False,
-                                                  num_fidelity=num_fidelity)
+                                                  num_fidelity=num_fidelity, comm=comm)
     return best, found
 
 
@@ -165,9 +169,13 @@ def ei_optimal_points(dev_gp, optimizer_parameters, bounds, Xp, num_to_sample, b
 
 
 def kg_mcmc_optimal_points(dev_mcmc, num_fidelity, optimizer_parameters, optimizer_parameters_inner, bounds, discrete_all, Xp,
-                           num_to_sample, best_so_far, num_mc, randomness):
+                           num_to_sample, best_so_far, num_mc, randomness, comm=None):
     """ComputeKGMCMCOptimalPointsToSample (gpp_knowledge_gradient_mcmc_optimization.cpp:236-296): kg_optimal_points on the
-    MCMC-averaged, cost-scaled objective.  Returns (best_points [q][dim], found)."""
+    MCMC-averaged, cost-scaled objective.  Returns (best_points [q][dim], found).
+    comm (r5: dist.Exchange): the ensemble's MEMBERS are dealt to the ranks -- dev_mcmc = DeviceGPMCMC(..., members=
+    dist.shard_members(num_mcmc, rank, world)) on this rank's device, discrete_all / best_so_far for the whole ensemble, the same
+    `randomness` seeds everywhere; one all-gather of the per-member values per optimiser step (moe_kg_mcmc_multistart_comm), the
+    single-rank answer bit for bit on every rank."""
     from . import GPP
     d, q = dev_mcmc.d, int(num_to_sample)
     bounds = np.asarray(bounds, dtype=np.float64).reshape(-1)[:2 * d]
@@ -180,13 +188,14 @@ def kg_mcmc_optimal_points(dev_mcmc, num_fidelity, optimizer_parameters, optimiz
     if use_gd:
         gd = _gd(optimizer_parameters, dom)
         best, _, found = dev_mcmc.kg_multistart(gd, inner_gd, bounds, discrete_all, _starts(randomness, bounds, gd[0], q, d, dom), Xp,
-                                                num_mc, best_so_far, normals, gradient_ascent=True, num_fidelity=num_fidelity)
+                                                num_mc, best_so_far, normals, gradient_ascent=True, num_fidelity=num_fidelity,
+                                                comm=comm)
     if not found:
         n_lhc = int(optimizer_parameters.num_random_samples or 0)
         if n_lhc > 0:
             best, _, found = dev_mcmc.kg_multistart(inner_gd, inner_gd, bounds, discrete_all,
                                                     _starts(randomness, bounds, n_lhc, q, d, dom), Xp, num_mc, best_so_far, normals,
-                                                    gradient_ascent=False, num_fidelity=num_fidelity)
+                                                    gradient_ascent=False, num_fidelity=num_fidelity, comm=comm)
     return best, found
 
 

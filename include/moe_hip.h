@@ -304,6 +304,59 @@ int moe_kg_mcmc_multistart(const moe_gp_t* const* gps, int num_mcmc, int num_fid
                            int num_to_sample, int num_being_sampled, int num_mc, const double* best_so_far,
                            const double* normals, int do_gradient_ascent, double* best_points, double* best_kg, int* found,
                            moe_error_t* err);
+/* ---- r5: a whole suggestion on several GPUs (SURVEY 8e + 8f rank 1 / 2).  The reference parallelises its outer optimisers over
+ * the restarts -- omp-parallel GradientDescentOptimizer runs merged under `omp critical`
+ * (gpp_optimization.hpp:1472-1546, gpp_knowledge_gradient_optimization.hpp:860-935) -- and its MCMC-averaged objective is a sum
+ * over independent GPs (gpp_knowledge_gradient_mcmc_optimization.hpp:666-1023).  Here every batched evaluation of the optimiser is
+ * dealt to the ranks and followed by ONE all-gather; every rank then takes the same decisions on the same bits and returns the
+ * same point:
+ *   - moe_kg_multistart_comm: the restarts are dealt (evaluation i of a batch on rank i % world): the result is moe_kg_multistart's
+ *     BIT FOR BIT, for any world size (an evaluation's bits do not depend on the batch it shares a call with);
+ *   - moe_kg_mcmc_multistart_comm: the ensemble members are dealt -- member g is built and evaluated on rank g % world, which passes
+ *     its members (ascending g) with their rows of discrete_pts / best_so_far; the per-member values are exchanged and every rank
+ *     adds them up in global member order: moe_kg_mcmc_multistart's result bit for bit.
+ * The exchange is the caller's: one process per GPU hands in its collective (cornell_moe_amd/dist.py: torch.distributed all_gather,
+ * backend nccl = RCCL over xGMI, or gloo); a rank whose evaluation fails still takes part in the exchange and then EVERY rank
+ * returns that error -- no rank is left waiting in a collective.  Payloads are small (a GD step of 20 restarts at q d = 32:
+ * 5 KB per rank). */
+typedef int (*moe_allgather_fn)(void* ctx, const double* send, double* recv, int count); /* recv[world][count], rank order; 0 = ok */
+typedef struct moe_comm {
+  int rank;  /* this process */
+  int world; /* number of processes; 1 = no exchange (allgather may be NULL) */
+  moe_allgather_fn allgather;
+  void* ctx; /* passed back to allgather */
+} moe_comm_t;
+/* (diagnostic) the deal-and-exchange step alone, on synthetic items -- out[n][width], item i = seed + i + j / 1000; fail_item >= 0
+ * makes its owner fail with MOE_ERR_SINGULAR, which every rank must then report.  No device work: the CPU tests run it over gloo. */
+int moe_debug_sharded_items(const moe_comm_t* comm, int n, int width, double seed, int fail_item, double* out, moe_error_t* err);
+int moe_kg_multistart_comm(const moe_gp_t* gp, const moe_comm_t* comm, int num_fidelity, const moe_gd_params_t* outer_params,
+                           const moe_gd_params_t* inner_params, const double* domain_bounds, const double* discrete_pts,
+                           int num_pts, const double* start_points, int num_starts, const double* points_being_sampled,
+                           int num_to_sample, int num_being_sampled, int num_mc, double best_so_far, const double* normals,
+                           int do_gradient_ascent, double* best_points, double* best_kg, int* found, moe_error_t* err);
+int moe_kg_mcmc_multistart_comm(const moe_gp_t* const* local_gps, int num_local, int total_num_mcmc, const moe_comm_t* comm,
+                                int num_fidelity, const moe_gd_params_t* outer_params, const moe_gd_params_t* inner_params,
+                                const double* domain_bounds, const double* discrete_pts_local, int num_pts,
+                                const double* start_points, int num_starts, const double* points_being_sampled,
+                                int num_to_sample, int num_being_sampled, int num_mc, const double* best_so_far_local,
+                                const double* normals, int do_gradient_ascent, double* best_points, double* best_kg, int* found,
+                                moe_error_t* err);
+/* The same for ONE process that drives several devices (a C / C++ host without torch; the twins of moe_kg_batch_multi): one host
+ * thread per worker, the exchange in shared memory.  moe_kg_multistart_multi: gps[num_devices] hold the SAME GP on different
+ * devices.  moe_kg_mcmc_multistart_multi: gps[num_mcmc] is the whole ensemble (the caller builds member g on device
+ * g % num_workers); worker k takes members k, k + num_workers, ...  Results as above: bit for bit the single-device ones. */
+int moe_kg_multistart_multi(const moe_gp_t* const* gps, int num_devices, int num_fidelity, const moe_gd_params_t* outer_params,
+                            const moe_gd_params_t* inner_params, const double* domain_bounds, const double* discrete_pts,
+                            int num_pts, const double* start_points, int num_starts, const double* points_being_sampled,
+                            int num_to_sample, int num_being_sampled, int num_mc, double best_so_far, const double* normals,
+                            int do_gradient_ascent, double* best_points, double* best_kg, int* found, moe_error_t* err);
+int moe_kg_mcmc_multistart_multi(const moe_gp_t* const* gps, int num_mcmc, int num_workers, int num_fidelity,
+                                 const moe_gd_params_t* outer_params, const moe_gd_params_t* inner_params,
+                                 const double* domain_bounds, const double* discrete_pts_all, int num_pts,
+                                 const double* start_points, int num_starts, const double* points_being_sampled,
+                                 int num_to_sample, int num_being_sampled, int num_mc, const double* best_so_far,
+                                 const double* normals, int do_gradient_ascent, double* best_points, double* best_kg, int* found,
+                                 moe_error_t* err);
 int moe_ei_mcmc_multistart(const moe_gp_t* const* gps, int num_mcmc, const moe_gd_params_t* outer_params,
                            const double* domain_bounds, const double* start_points, int num_starts,
                            const double* points_being_sampled, int num_to_sample, int num_being_sampled, int num_mc,

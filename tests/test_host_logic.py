@@ -144,6 +144,97 @@ def test_gloo_world2_mcmc_member_shards():
     assert ret[0][1] == ret[1][1] and np.array_equal(ret[0][2], ret[1][2])  # every rank holds the same reduced result
 
 
+def _sharded_items(ex, n, width, seed, fail_item=-1):
+    import ctypes as C
+    from cornell_moe_amd import _lib
+    out = np.full(n * width, -1.0)
+    err = _lib.MoeError()
+    rc = _lib.load().moe_debug_sharded_items(C.byref(ex.c_struct), n, width, seed, fail_item, out.ctypes.data_as(_lib.dp), C.byref(err))
+    ex.reraise()
+    return rc, out.reshape(n, width), err
+
+
+def _exchange_worker(rank, world, port, ret):
+    """r5: the deal-and-exchange step of the multi-rank outer optimisers (moe_kg_multistart_comm / moe_kg_mcmc_multistart_comm) with
+    its all-gather carried by torch.distributed over gloo: dist.Exchange -> moe_comm_t -> csrc sharded_items."""
+    import torch.distributed as dist
+    from cornell_moe_amd import _lib
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        ex = mdist.Exchange(rank, world)
+        res = []
+        for n, width in ((7, 3), (1, 1), (2, 5), (20, 33)):   # fewer items than ranks, ragged last round, a GD step's shape
+            rc, out, _ = _sharded_items(ex, n, width, 100.0 * width)
+            res.append((rc, out))
+        rc_fail, _, err = _sharded_items(ex, 5, 2, 0.0, fail_item=3)   # item 3 belongs to rank 3 % world
+        ret[rank] = (res, rc_fail, err.message.decode(), list(err.payload), ex.calls, ex.doubles)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_gloo_world2_exchange_of_the_multi_rank_optimisers():
+    import torch.multiprocessing as mp
+    from cornell_moe_amd import _lib
+    world = 2
+    port = _free_port()
+    ret = mp.Manager().dict()
+    mp.spawn(_exchange_worker, args=(world, port, ret), nprocs=world, join=True)
+    for r in range(world):
+        res, rc_fail, msg, payload, calls, doubles = ret[r]
+        for (rc, out), (n, width) in zip(res, ((7, 3), (1, 1), (2, 5), (20, 33))):
+            assert rc == 0
+            want = 100.0 * width + np.arange(n)[:, None] + np.arange(width)[None, :] / 1000.0
+            assert np.array_equal(out, want)   # complete, in item order, on every rank
+        # the failure of ONE rank comes back from EVERY rank (nobody is left in a collective), with its code and payload
+        assert rc_fail == _lib.MOE_ERR_SINGULAR and payload == [3.0, 1.0, 2.0]
+        assert ("synthetic failure" in msg) == (r == 3 % world) and (("another rank" in msg) == (r != 3 % world))
+        assert calls == 5 and doubles == sum(4 + -(-n // world) * w for n, w in ((7, 3), (1, 1), (2, 5), (20, 33), (5, 2)))
+
+
+def test_exchange_three_ranks_in_threads_and_callback_errors():
+    """The same with three ranks as threads of this process (ctypes releases the GIL around the library call, the callback takes it
+    back): an in-memory all-gather handed to dist.Exchange; and an exception INSIDE the callback comes back as the library's failure
+    code and is re-raised by Exchange.reraise -- it never unwinds through the C frames."""
+    import threading
+    from cornell_moe_amd import _lib
+    world = 3
+    barrier = threading.Barrier(world)
+    slots = [None] * world
+
+    def make(rank):
+        def allgather(send):
+            slots[rank] = send
+            barrier.wait()
+            out = np.concatenate(slots)
+            barrier.wait()
+            return out
+        return mdist.Exchange(rank, world, allgather=allgather)
+
+    results = [None] * world
+
+    def run(rank):
+        results[rank] = _sharded_items(make(rank), 10, 4, 7.0)
+
+    threads = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    [t.start() for t in threads]
+    [t.join() for t in threads]
+    want = 7.0 + np.arange(10)[:, None] + np.arange(4)[None, :] / 1000.0
+    for rc, out, _ in results:
+        assert rc == 0 and np.array_equal(out, want)
+
+    def broken(send):
+        raise ValueError("transport down")
+
+    ex = mdist.Exchange(0, 2, allgather=broken)
+    with pytest.raises(ValueError, match="transport down"):
+        _sharded_items(ex, 4, 1, 0.0)
+    one = mdist.Exchange(0, 1)   # world 1: no exchange at all
+    rc, out, _ = _sharded_items(one, 3, 2, 1.0)
+    assert rc == 0 and np.array_equal(out, 1.0 + np.arange(3)[:, None] + np.arange(2)[None, :] / 1000.0) and one.calls == 0
+
+
 def test_bench_self_launch_world2(tmp_path):
     """`python bench.py --gpus N` called plainly re-launches itself under torch.distributed.run (bench.self_launch): the
     launcher -- free port on 127.0.0.1, one process per rank, RANK / WORLD_SIZE in the environment, exit code relayed -- driven
