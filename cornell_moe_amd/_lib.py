@@ -77,6 +77,7 @@ SIGNATURES = {
     "moe_ei_mcmc_batch": (C.c_int, [_GPA, C.c_int, dp, C.c_int, dp, C.c_int, C.c_int, C.c_int, dp, dp, C.c_int, dp, dp, _EP]),
     "moe_kg_mcmc_multistart": (C.c_int, [_GPA, C.c_int, C.c_int, C.POINTER(GdParams), C.POINTER(GdParams), dp, dp, C.c_int, dp,
                                          C.c_int, dp, C.c_int, C.c_int, C.c_int, dp, dp, C.c_int, dp, dp, ip, _EP]),
+    "moe_multistart_trace": (C.c_int, [dp, C.c_int]),
     "moe_debug_sharded_items": (C.c_int, [C.POINTER(Comm), C.c_int, C.c_int, C.c_double, C.c_int, dp, _EP]),
     "moe_kg_multistart_comm": (C.c_int, [_GP, C.POINTER(Comm), C.c_int, C.POINTER(GdParams), C.POINTER(GdParams), dp, dp, C.c_int,
                                          dp, C.c_int, dp, C.c_int, C.c_int, C.c_int, C.c_double, dp, C.c_int, dp, dp, ip, _EP]),

@@ -87,6 +87,15 @@ def kxx_build_probe(log=None, device=0):
     return out
 
 
+def multistart_trace():
+    """moe_multistart_trace: rows (kind 0 values / 1 gradients, items, ms) of the last outer optimisation of this process."""
+    L = _lib.load()
+    n = L.moe_multistart_trace(None, 0)
+    out = np.zeros((max(n, 1), 3))
+    L.moe_multistart_trace(out.ctypes.data_as(dp), n)
+    return out[:n]
+
+
 def set_reference_quirks(on):
     """moe_set_reference_quirks: 1 = the multistart drivers reproduce the reference's execution, defects included (default);
     0 = the drivers as the reference intends them (fresh states, all q points move); -1 = follow MOE_REFERENCE_QUIRKS."""

@@ -852,6 +852,8 @@ void run_workers(int W, const std::function<void(int, const moe::Comm&)>& body) 
 
 }  // namespace
 
+int moe_multistart_trace(double* out, int cap) { return moe::multistart_trace_get(out, cap); }
+
 // The deal-and-exchange step of the multi-rank optimisers on synthetic items -- item i's result is width copies of
 // seed + i + j / 1000 -- with no device work: what the CPU tests drive over gloo.  fail_item >= 0: the rank that owns that item
 // throws (MOE_ERR_SINGULAR), and every rank must come back with that code.

@@ -73,6 +73,12 @@ struct Comm {
 void sharded_items(const Comm& comm, int n, int width,
                    const std::function<void(const std::vector<int>& idx, double* out_local)>& eval_local, double* out);
 
+// Timeline of the last outer optimisation of this process (r5; moe_multistart_trace): one row per batched evaluation the optimiser
+// issued -- kind (0 = values, 1 = gradients), items, wall milliseconds (device work + exchange).  Recorded on rank 0 / worker 0 only.
+void multistart_trace_begin(bool enabled);
+void multistart_trace_add(int kind, int items, double ms);
+int multistart_trace_get(double* out, int cap);
+
 // A maximisation objective evaluated at a BATCH of points [n][qd]: values [n], grads [n][qd].
 struct BatchObjective {
   std::function<void(const double* x_all, int n, double* values)> values;

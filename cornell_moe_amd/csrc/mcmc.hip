@@ -12,6 +12,7 @@
 // axis: kg_mcmc_sums returns plain sums over the GPs it was given so ranks holding disjoint GP subsets can all-reduce them
 // before kg_mcmc_finalize (cornell_moe_amd/dist.py).
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 
 #include "gp.hpp"
@@ -197,6 +198,7 @@ void kg_mcmc_multistart(const std::vector<GpDev*>& gps, int num_fidelity, const 
   if (num_starts <= 0) throw Error(MOE_ERR_BOUNDS, "num_multistarts must be > 1", num_starts, 1, 1e9);
   const bool shard = comm != nullptr && comm->world > 1;
   const int d = gps[0]->d, qd = q * d, nm = shard ? total_num_mcmc : (int)gps.size();
+  multistart_trace_begin(comm == nullptr || comm->rank == 0);
   if (shard) {
     // member g lives on rank g % world at local index g / world
     const int W = comm->world, mine = (total_num_mcmc - comm->rank + W - 1) / W;
@@ -207,6 +209,14 @@ void kg_mcmc_multistart(const std::vector<GpDev*>& gps, int num_fidelity, const 
   // Sums over ALL members of a batch of evaluations.  One rank: kg_mcmc_sums.  Sharded (r5): every rank evaluates its members,
   // ONE exchange of the per-member values, and every rank adds them up in global member order -- the bits of the single-rank sum.
   auto all_sums = [&](const double* x_all, int n, bool want_grad, double* ks, double* gs, const double* head_pts) {
+    struct Timed {  // (the quirk-free branch goes through multistart(), which records its own rows: only the direct calls below count)
+      bool on;
+      int kind, items;
+      std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+      ~Timed() {
+        if (on) multistart_trace_add(kind, items, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+      }
+    } timed{head_pts != nullptr, want_grad ? 1 : 0, n};
     if (!shard) {
       kg_mcmc_sums(gps, num_fidelity, inner, bounds, discrete_all, P, x_all, n, Xp, q, p, num_mc, best_so_far, normals, want_grad, ks, gs,
                    head_pts);

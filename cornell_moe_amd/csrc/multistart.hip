@@ -12,9 +12,11 @@
 #include <algorithm>
 #include <atomic>
 #include <cmath>
+#include <chrono>
 #include <cstdlib>
 #include <functional>
 #include <memory>
+#include <mutex>
 #include <numeric>
 #include <queue>
 #include <random>
@@ -39,6 +41,41 @@ bool reference_quirks() {
 void set_reference_quirks(int on) { g_reference_quirks.store(on < 0 ? -1 : (on != 0 ? 1 : 0)); }
 
 namespace {
+std::mutex g_trace_mu;
+std::vector<double> g_trace;
+thread_local bool tl_trace = false;
+}  // namespace
+
+void multistart_trace_begin(bool enabled) {
+  tl_trace = enabled;
+  if (enabled) {
+    std::lock_guard<std::mutex> lk(g_trace_mu);
+    g_trace.clear();
+  }
+}
+void multistart_trace_add(int kind, int items, double ms) {
+  if (!tl_trace) return;
+  std::lock_guard<std::mutex> lk(g_trace_mu);
+  g_trace.push_back((double)kind);
+  g_trace.push_back((double)items);
+  g_trace.push_back(ms);
+}
+int multistart_trace_get(double* out, int cap) {
+  std::lock_guard<std::mutex> lk(g_trace_mu);
+  const int rows = (int)(g_trace.size() / 3);
+  for (int i = 0; out != nullptr && i < std::min(rows, cap); ++i)
+    for (int j = 0; j < 3; ++j) out[3 * i + j] = g_trace[3 * (size_t)i + j];
+  return rows;
+}
+
+namespace {
+
+struct TraceTimer {
+  int kind, items;
+  std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+  TraceTimer(int k, int n) : kind(k), items(n) {}
+  ~TraceTimer() { multistart_trace_add(kind, items, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count()); }
+};
 
 constexpr int kTopK = 20;  // gpp_knowledge_gradient_optimization.hpp:901
 
@@ -211,7 +248,10 @@ void gradient_ascent(const BatchObjective& f, const moe_gd_params_t& outer, cons
       if (idx.empty()) break;
       const double alpha = outer.pre_mult * std::pow((double)(i + 1), -outer.gamma);
       for (size_t k = 0; k < idx.size(); ++k) std::copy(x + (size_t)idx[k] * qd, x + (size_t)(idx[k] + 1) * qd, &xs[k * qd]);
-      f.grads(xs.data(), (int)idx.size(), grad.data());
+      {
+        TraceTimer tt(1, (int)idx.size());
+        f.grads(xs.data(), (int)idx.size(), grad.data());
+      }
       for (size_t k = 0; k < idx.size(); ++k) {
         double* xk = x + (size_t)idx[k] * qd;
         for (int j = 0; j < qd; ++j) step[j] = alpha * grad[k * qd + j];
@@ -260,7 +300,10 @@ void multistart(const BatchObjective& f, const moe_gd_params_t& outer, const dou
   *found = 0;
   *best_value = floor_value;
   std::vector<double> vals(num_starts);
-  f.values(starts, num_starts, vals.data());
+  {
+    TraceTimer tt(0, num_starts);
+    f.values(starts, num_starts, vals.data());
+  }
   std::vector<double> ends, end_vals;
   int S = num_starts;
   if (do_gradient_ascent) {
@@ -275,6 +318,7 @@ void multistart(const BatchObjective& f, const moe_gd_params_t& outer, const dou
     std::copy(&ends[0], &ends[(size_t)qd], best_points);
     gradient_ascent(f, outer, bounds, d, qd, ends.data(), S);
     end_vals.resize(S);
+    TraceTimer tt(0, S);
     f.values(ends.data(), S, end_vals.data());
   } else {
     ends.assign(starts, starts + (size_t)num_starts * qd);
@@ -343,6 +387,7 @@ void kg_multistart(GpDev& gp, int num_fidelity, const moe_gd_params_t& outer, co
   // With the quirks switched off every evaluation runs on a fresh state (its own q points in the discretised set), as the
   // single-evaluation entry points do.
   const double* head = (num_starts > 0 && reference_quirks()) ? starts : nullptr;
+  multistart_trace_begin(comm == nullptr || comm->rank == 0);
   BatchObjective f;
   f.values = [&](const double* x_all, int n, double* values) {
     kg_values(gp, num_fidelity, inner, bounds, discrete, P, x_all, n, Xp, q, p, num_mc, best_so_far, normals, values, head);

@@ -326,6 +326,10 @@ typedef struct moe_comm {
   moe_allgather_fn allgather;
   void* ctx; /* passed back to allgather */
 } moe_comm_t;
+/* Timeline of the LAST outer optimisation this process ran (moe_kg_multistart*, moe_kg_mcmc_multistart*; rank 0 / worker 0): one row
+ * per batched evaluation the optimiser issued, out[3 i ..] = kind (0 values, 1 gradients), items in the batch, wall milliseconds
+ * (device work + exchange).  Returns the number of rows (out may be NULL / cap 0 to ask). */
+int moe_multistart_trace(double* out, int cap);
 /* (diagnostic) the deal-and-exchange step alone, on synthetic items -- out[n][width], item i = seed + i + j / 1000; fail_item >= 0
  * makes its owner fail with MOE_ERR_SINGULAR, which every rank must then report.  No device work: the CPU tests run it over gloo. */
 int moe_debug_sharded_items(const moe_comm_t* comm, int n, int width, double seed, int fail_item, double* out, moe_error_t* err);

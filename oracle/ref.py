@@ -58,6 +58,9 @@ def lib():
         _lib.ref_kg_mcmc.argtypes = [C.c_void_p, C.c_int, _dp, _dp, _dp, C.c_int, _dp, _dp, C.c_int, C.c_int, C.c_int, _dp, _dp,
                                      C.c_long, C.c_int, _dp, _dp]
         _lib.ref_ei_mcmc.argtypes = [C.c_void_p, _dp, _dp, C.c_int, C.c_int, C.c_int, _dp, _dp, _dp, _dp]
+        if hasattr(_lib, "ref_kg_mcmc_multistart_mt"):   # (a prebuilt oracle/_ref of an earlier round does not have it)
+            _lib.ref_kg_mcmc_multistart_mt.argtypes = [C.c_void_p, C.c_int, _dp, _dp, _dp, _dp, _dp, C.c_int, _dp, C.c_int, _dp, C.c_int,
+                                                       C.c_int, C.c_int, _dp, C.c_uint, C.c_int, _ip, _dp, _dp]
         _lib.ref_ei_mcmc_multistart_analytic.argtypes = [C.c_void_p, _dp, _dp, _dp, C.c_int, _dp, C.POINTER(C.c_int), _dp]
         _lib.ref_log_likelihood.argtypes = [C.c_int, C.c_double, _dp, _dp, _dp, _dp, _ip, C.c_int, C.c_int, C.c_int, _dp]
         _lib.ref_kg.argtypes = [C.c_void_p, C.c_int, _dp, _dp, _dp, C.c_int, _dp, _dp, C.c_int, C.c_int, C.c_int,
@@ -496,3 +499,27 @@ class RefGPMCMC(object):
                                             starts.ctypes.data_as(_dp), S, pp, q, p, M, bsp, seed, C.byref(found),
                                             best.ctypes.data_as(_dp)))
         return best.reshape(q, self.d), bool(found.value)
+
+    def kg_multistart_mt(self, gd_outer, gd_inner, bounds, discrete_all, starts, Xp, M, best_so_far, seed, num_threads, num_fidelity=0):
+        """The same under `num_threads` OpenMP threads (the reference's own drivers pass 20): (best_points [q,d], found, wall seconds)."""
+        gdo, gop = _d(gd_outer)
+        gdi, gip = _d(gd_inner)
+        bounds, bp = _d(bounds)
+        inner_bounds = np.ascontiguousarray(bounds.reshape(-1)[: 2 * (self.d - num_fidelity)])
+        discrete_all, dp = _d(discrete_all)
+        P = discrete_all.reshape(self.num_mcmc, -1, self.d - num_fidelity).shape[1]
+        starts = np.ascontiguousarray(starts, dtype=np.float64)
+        S, q, _ = starts.shape
+        assert S >= 20, "the reference pops its top-20 queue unconditionally"
+        if Xp is None or len(Xp) == 0:
+            p, pp = 0, None
+        else:
+            Xp_, pp = _d(Xp)
+            p = Xp_.reshape(-1, self.d).shape[0]
+        best_so_far, bsp = _d(best_so_far)
+        found, wall = C.c_int(0), C.c_double(0.0)
+        best = np.zeros(q * self.d)
+        _check(lib().ref_kg_mcmc_multistart_mt(self.h, num_fidelity, gop, gip, bp, inner_bounds.ctypes.data_as(_dp), dp, P,
+                                               starts.ctypes.data_as(_dp), S, pp, q, p, M, bsp, seed, int(num_threads), C.byref(found),
+                                               best.ctypes.data_as(_dp), C.byref(wall)))
+        return best.reshape(q, self.d), bool(found.value), wall.value

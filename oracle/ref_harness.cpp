@@ -630,6 +630,38 @@ int ref_kg_mcmc_multistart(void* hv, int num_fidelity, const double* gd_outer, c
   });
 }
 
+// The same with `num_threads` OpenMP threads, the way the reference's own Python drivers call it (examples/bayesian_optimization.py:
+// max_num_threads = 20): one NormalRNG per thread, all seeded alike (every evaluation rewinds its generator, so the stream a restart
+// sees does not depend on the thread that runs it).  *wall_s = the optimiser's wall time.  bench.py --config suggest.
+int ref_kg_mcmc_multistart_mt(void* hv, int num_fidelity, const double* gd_outer, const double* gd_inner, const double* bounds,
+                              const double* inner_bounds, const double* discrete_all, int P, const double* starts, int num_starts,
+                              const double* Xp, int q, int p, int M, const double* best_so_far, unsigned int seed, int num_threads,
+                              int* found, double* best_point, double* wall_s) {
+  return guarded([&] {
+    GaussianProcessMCMC* gpm = static_cast<GaussianProcessMCMC*>(hv);
+    const int d = gpm->dim();
+    std::vector<ClosedInterval> iv(d), ivi(d - num_fidelity);
+    for (int i = 0; i < d; ++i) iv[i] = ClosedInterval(bounds[2 * i], bounds[2 * i + 1]);
+    for (int i = 0; i < d - num_fidelity; ++i) ivi[i] = ClosedInterval(inner_bounds[2 * i], inner_bounds[2 * i + 1]);
+    TensorProductDomain dom(iv.data(), d), inner_dom(ivi.data(), d - num_fidelity);
+    GradientDescentParameters gdo(static_cast<int>(gd_outer[0]), static_cast<int>(gd_outer[1]), static_cast<int>(gd_outer[2]),
+                                  static_cast<int>(gd_outer[3]), gd_outer[4], gd_outer[5], gd_outer[6], gd_outer[7]);
+    GradientDescentParameters gdi(static_cast<int>(gd_inner[0]), static_cast<int>(gd_inner[1]), static_cast<int>(gd_inner[2]),
+                                  static_cast<int>(gd_inner[3]), gd_inner[4], gd_inner[5], gd_inner[6], gd_inner[7]);
+    const int T = num_threads > 0 ? num_threads : 1;
+    ThreadSchedule sched(T, omp_sched_dynamic);  // (gpp_python_knowledge_gradient_mcmc.cpp: omp_sched_dynamic, chunk as the default)
+    std::vector<NormalRNG> rngs(T, NormalRNG(seed));
+    double dummy = 0.0;
+    bool found_flag = false;
+    const double t0 = omp_get_wtime();
+    ComputeKGMCMCOptimalPointsToSampleViaMultistartGradientDescent(*gpm, num_fidelity, gdo, gdi, dom, inner_dom, sched, starts,
+                                                                   p > 0 ? Xp : &dummy, discrete_all, num_starts, q, p, P,
+                                                                   best_so_far, M, rngs.data(), &found_flag, best_point);
+    *wall_s = omp_get_wtime() - t0;
+    *found = found_flag ? 1 : 0;
+  });
+}
+
 int ref_num_procs() { return omp_get_num_procs(); }
 
 }  // extern "C"

@@ -39,6 +39,7 @@ for i in range(reps):
 # materialises this matrix), so that the PMC passes see it
 if cfg == "C3":
     import numpy as np
-    pts = np.random.default_rng(7).uniform(size=(R * w.M, w.d))
+    Rp = min(R, 8)   # (bench.py's roofline_cov_build shape: at most 8 evaluations' worth of columns, 640 MB)
+    pts = np.random.default_rng(7).uniform(size=(Rp * w.M, w.d))
     ms, nbytes = G.cov_build_probe(pts, repeat=2)
-    print("cov_build probe %d x %d: %.4f ms per launch, %.0f GB/s" % (w.n, R * w.M, ms, nbytes / ms / 1e6), flush=True)
+    print("cov_build probe %d x %d: %.4f ms per launch, %.0f GB/s" % (w.n, Rp * w.M, ms, nbytes / ms / 1e6), flush=True)
