@@ -695,6 +695,64 @@ def evaluate_log_likelihood_at_hyperparameter_list(hyperparameter_list, points_s
     return list(vals)
 
 
+def _hyper_guesses(randomness_source, domain_log10, count):
+    """ConvertFromLogToLinearDomainAndBuildInitialGuesses (gpp_model_selection.hpp:841-858): a Latin hypercube in LOG-10 space,
+    exponentiated.  (The reference draws it from randomness_source.uniform_generator, whose stream depends on its Boost version;
+    here the generator of moe_latin_hypercube is seeded from the container's uniform seed -- reproducible for a given seed.)"""
+    pts = _api.latin_hypercube(randomness_source._next_uniform_seed(), np.asarray(domain_log10, dtype=np.float64).reshape(-1), count)
+    return 10.0 ** pts
+
+
+def multistart_hyperparameter_optimization(optimizer_parameters, hyperparameter_domain, points_sampled, points_sampled_value, dim,
+                                           num_sampled, hyperparameters, noise_variance, derivatives, num_derivatives,
+                                           max_num_threads, randomness_source, status):
+    """MultistartHyperparameterOptimizationWrapper (gpp_python_model_selection.cpp:218-279 -> DispatchHyperparameterOptimization,
+    :150-216): maximum-likelihood hyper-parameters [alpha, lengths..., noise variances...] over hyperparameter_domain (LOG-10 space,
+    [n_hyper][2]).  optimizer_type gradient_descent: MultistartGradientDescentHyperparameterOptimization
+    (gpp_model_selection.hpp:1063-1103) -- num_multistarts Latin-hypercube guesses, restarted gradient ascent from each, all of them
+    stepped together on the device (moe_ll_multistart); null: the Latin-hypercube value search (:1342-1363) over num_random_samples
+    points.  status gets the reference's key."""
+    opt = optimizer_parameters
+    _check_objective(getattr(opt, "objective_type", LogLikelihoodTypes.log_marginal_likelihood))
+    h = _ll_handle(points_sampled, points_sampled_value, dim, num_sampled, derivatives, num_derivatives)
+    nh = 1 + dim + 1 + num_derivatives
+    dom = _flat(hyperparameter_domain, 2 * nh).reshape(nh, 2)
+    if int(opt.optimizer_type) == int(OptimizerTypes.gradient_descent):
+        gd = _gd_params(opt)
+        guesses = _hyper_guesses(randomness_source, dom, int(gd[0]))
+        best, _, found = h.multistart(gd, dom, guesses)
+        status["log_marginal_likelihood_gradient_descent_found_update"] = bool(found)
+        return list(best)
+    if int(opt.optimizer_type) == int(OptimizerTypes.null):
+        n_lhc = int(opt.num_random_samples)
+        if n_lhc <= 0:
+            raise BoundsException("num_multistarts must be > 1", n_lhc, 1, 0)
+        guesses = _hyper_guesses(randomness_source, dom, n_lhc)
+        vals = h.evaluate(guesses)
+        k = int(np.argmax(vals))   # (first of equal values, like MultistartOptimizer's strict compare)
+        found = bool(vals[k] > -np.inf)
+        status["log_marginal_likelihood_lhc_found_update"] = found
+        return list(guesses[k] if found else guesses[0])
+    raise OptimalLearningException("ERROR: invalid optimizer choice. Setting all hyperparameters to 1.0.")
+
+
+def restarted_hyperparameter_optimization(optimizer_parameters, hyperparameter_domain, points_sampled, points_sampled_value, dim,
+                                          num_sampled, hyperparameters, noise_variance, derivatives, num_derivatives, status):
+    """RestartedGradientDescentHyperparameterOptimizationWrapper (gpp_python_model_selection.cpp:342-375 ->
+    RestartedGradientDescentHyperparameterOptimizationTensor, gpp_model_selection.hpp:989-1012): restarted gradient ascent from the
+    caller's CURRENT hyper-parameters (hyperparameters = [alpha, [lengths]], noise_variance) inside the LOG-10 domain; returns the
+    point the ascent ends at (the reference does not compare it with the start)."""
+    h = _ll_handle(points_sampled, points_sampled_value, dim, num_sampled, derivatives, num_derivatives)
+    nh = 1 + dim + 1 + num_derivatives
+    dom = _flat(hyperparameter_domain, 2 * nh).reshape(nh, 2)
+    x0 = np.r_[float(hyperparameters[0]), _flat(hyperparameters[1], dim), _flat(noise_variance, 1 + num_derivatives)]
+    gd = _gd_params(optimizer_parameters)
+    if int(gd[2]) <= 0:   # max_num_restarts <= 0: the reference returns without touching its output (:995-997)
+        return list(np.zeros(nh))
+    end = h.ascend(gd, dom, x0)
+    return list(end)
+
+
 def run_cpp_tests():
     """The reference runs its C++ unit-test suite here (gpp_python_test.cpp:307-314); this backend's tests are the pytest
     suite under tests/ (returns 0 = no failures, like the reference on success)."""

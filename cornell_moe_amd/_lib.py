@@ -95,6 +95,8 @@ SIGNATURES = {
     "moe_ll_destroy": (C.c_int, [C.c_void_p]),
     "moe_ll_evaluate": (C.c_int, [C.c_void_p, dp, C.c_int, dp, _EP]),
     "moe_ll_grad": (C.c_int, [C.c_void_p, dp, dp, _EP]),
+    "moe_ll_ascend": (C.c_int, [C.c_void_p, C.POINTER(GdParams), dp, dp, dp, _EP]),
+    "moe_ll_multistart": (C.c_int, [C.c_void_p, C.POINTER(GdParams), dp, dp, C.c_int, dp, dp, ip, _EP]),
     "moe_posterior_mean_optimize": (C.c_int, [_GP, C.c_int, C.POINTER(GdParams), dp, dp, dp, dp, _EP]),
     "moe_latin_hypercube": (C.c_int, [C.c_uint, dp, C.c_int, C.c_int, dp]),
     "moe_gp_mix_covariance": (C.c_int, [_GP, dp, C.c_int, ip, C.c_int, dp, _EP]),

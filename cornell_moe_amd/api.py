@@ -763,6 +763,30 @@ class LogLikelihood(object):
         _check(_lib.load().moe_ll_evaluate(self._h, h.ctypes.data_as(dp), h.shape[0], out.ctypes.data_as(dp), C.byref(err)), err)
         return out
 
+    def multistart(self, gd_params, domain_log10, initial_guesses):
+        """moe_ll_multistart: maximum-likelihood hyper-parameters by restarted gradient ascent from initial_guesses [S][1 + dim + 1 + g]
+        (linear space) inside domain_log10 [n_hyper][2] (log-10 space) -> (best [n_hyper], best log likelihood, found)."""
+        nh = 1 + self.d + 1 + self.g
+        g = DeviceGP._gd(gd_params)
+        dom, dpp = _d(domain_log10)
+        x0 = np.ascontiguousarray(initial_guesses, dtype=np.float64).reshape(-1, nh)
+        out = np.zeros(nh)
+        val, found, err = C.c_double(0.0), C.c_int(0), _lib.MoeError()
+        _check(_lib.load().moe_ll_multistart(self._h, C.byref(g), dpp, x0.ctypes.data_as(dp), x0.shape[0], out.ctypes.data_as(dp),
+                                             C.byref(val), C.byref(found), C.byref(err)), err)
+        return out, val.value, bool(found.value)
+
+    def ascend(self, gd_params, domain_log10, x0):
+        """moe_ll_ascend: the end point of the restarted gradient ascent from x0 [1 + dim + 1 + g] (linear space)."""
+        nh = 1 + self.d + 1 + self.g
+        g = DeviceGP._gd(gd_params)
+        dom, dpp = _d(domain_log10)
+        x0 = np.ascontiguousarray(x0, dtype=np.float64).reshape(nh)
+        out = np.zeros(nh)
+        err = _lib.MoeError()
+        _check(_lib.load().moe_ll_ascend(self._h, C.byref(g), dpp, x0.ctypes.data_as(dp), out.ctypes.data_as(dp), C.byref(err)), err)
+        return out
+
     def grad(self, hyperparameters):
         """d log p / d (alpha, lengths, noise variances) at one hyper-parameter set [1 + dim + 1 + g] (moe_ll_grad)."""
         h = np.ascontiguousarray(hyperparameters, dtype=np.float64).reshape(1 + self.d + 1 + self.g)

@@ -182,6 +182,10 @@ int moe_gp_variance(const moe_gp_t* gp_c, const double* pts, int num_pts, double
   return guarded(err, [&] {
     std::unique_lock<std::mutex> lk;
     moe::GpDev& gp = lock_gp(gp_c, lk);
+    if (num_pts * (1 + gp.g) >= moe::kDeviceVarianceMinM) {  // r5: hundreds of query points -- the m x m algebra on the device too
+      moe::variance_on_device(gp, pts, num_pts, false, out);
+      return;
+    }
     moe::StateHost h;
     moe::compute_state(gp, pts, num_pts, gp.derivs, 0, nullptr, 0, false, nullptr, &h);
     moe::host_variance(h, out);
@@ -192,6 +196,10 @@ int moe_gp_cholesky_variance(const moe_gp_t* gp_c, const double* pts, int num_pt
   return guarded(err, [&] {
     std::unique_lock<std::mutex> lk;
     moe::GpDev& gp = lock_gp(gp_c, lk);
+    if (num_pts * (1 + gp.g) >= moe::kDeviceVarianceMinM) {
+      moe::variance_on_device(gp, pts, num_pts, true, out);
+      return;
+    }
     moe::StateHost h;
     moe::compute_state(gp, pts, num_pts, gp.derivs, 0, nullptr, 0, false, nullptr, &h);
     moe::host_variance(h, out);
@@ -1016,11 +1024,29 @@ int moe_ll_destroy(moe_ll_t* ll) {
   return MOE_OK;
 }
 
+}  // extern "C"
+
+namespace {
+void ll_evaluate_locked(moe_ll_t* ll, const double* hyperparameters_all, int num_sets, double* values);
+void ll_grad_locked(moe_ll_t* ll, const double* hyperparameters, double* grad);
+}  // namespace
+
+extern "C" {
+
 int moe_ll_evaluate(moe_ll_t* ll, const double* hyperparameters_all, int num_sets, double* values, moe_error_t* err) {
   return guarded(err, [&] {
     require(ll != nullptr && hyperparameters_all != nullptr && values != nullptr, "NULL argument");
     if (num_sets <= 0) return;
     std::lock_guard<std::mutex> lk(ll->mu);
+    ll_evaluate_locked(ll, hyperparameters_all, num_sets, values);
+  });
+}
+
+}  // extern "C"
+
+namespace {
+void ll_evaluate_locked(moe_ll_t* ll, const double* hyperparameters_all, int num_sets, double* values) {
+  {
     MOE_HIP_CHECK(hipSetDevice(ll->device));
     const int g1 = 1 + ll->g, d = ll->d, n = ll->n, N = n * g1, stride = 1 + d + g1;
     const int dp = moe::padded_dim(d);
@@ -1077,13 +1103,11 @@ int moe_ll_evaluate(moe_ll_t* ll, const double* hyperparameters_all, int num_set
         values[i0 + b] = (info[b] != 0) ? -INFINITY
                                         : -0.5 * out[2 * b + 1] - out[2 * b] - 0.5 * (double)N * 1.8378770664093454835607;
     }
-  });
+  }
 }
 
-int moe_ll_grad(moe_ll_t* ll, const double* hyperparameters, double* grad, moe_error_t* err) {
-  return guarded(err, [&] {
-    require(ll != nullptr && hyperparameters != nullptr && grad != nullptr, "NULL argument");
-    std::lock_guard<std::mutex> lk(ll->mu);
+void ll_grad_locked(moe_ll_t* ll, const double* hyperparameters, double* grad) {
+  {
     const int g1 = 1 + ll->g;
     std::vector<double> noise(g1);
     for (int a = 0; a < g1; ++a) noise[a] = hyperparameters[1 + ll->d + a] + 1.0e-6;  // gpp_model_selection.cpp:546-549
@@ -1093,6 +1117,85 @@ int moe_ll_grad(moe_ll_t* ll, const double* hyperparameters, double* grad, moe_e
     else
       ll->gp->set_hyperparameters(hyperparameters, noise.data());
     ll->gp->grad_log_marginal_likelihood(grad);
+  }
+}
+}  // namespace
+
+extern "C" {
+
+int moe_ll_grad(moe_ll_t* ll, const double* hyperparameters, double* grad, moe_error_t* err) {
+  return guarded(err, [&] {
+    require(ll != nullptr && hyperparameters != nullptr && grad != nullptr, "NULL argument");
+    std::lock_guard<std::mutex> lk(ll->mu);
+    ll_grad_locked(ll, hyperparameters, grad);
+  });
+}
+
+// RestartedGradientDescentHyperparameterOptimizationTensor (gpp_model_selection.hpp:989-1012): where the restarted ascent from x0 ENDS
+// (the reference reads the state's current point back; it does not compare it with the start).
+int moe_ll_ascend(moe_ll_t* ll, const moe_gd_params_t* gd, const double* domain_log10, const double* x0, double* end_point,
+                  moe_error_t* err) {
+  return guarded(err, [&] {
+    require(ll != nullptr && gd != nullptr && domain_log10 != nullptr && x0 != nullptr && end_point != nullptr, "NULL argument");
+    std::lock_guard<std::mutex> lk(ll->mu);
+    const int nh = 1 + ll->d + 1 + ll->g;
+    std::vector<double> lin(2 * (size_t)nh);
+    for (int j = 0; j < 2 * nh; ++j) lin[j] = std::pow(10.0, domain_log10[j]);
+    moe::BatchObjective f;
+    f.values = [&](const double* x_all, int n, double* values) { ll_evaluate_locked(ll, x_all, n, values); };
+    f.grads = [&](const double* x_all, int n, double* grads) {
+      for (int i = 0; i < n; ++i) ll_grad_locked(ll, x_all + (size_t)i * nh, grads + (size_t)i * nh);
+    };
+    std::copy(x0, x0 + nh, end_point);
+    moe_gd_params_t g = *gd;
+    g.domain_type = MOE_DOMAIN_TENSOR_PRODUCT;
+    moe::gradient_ascent_batch(f, g, lin.data(), nh, nh, end_point, 1);
+  });
+}
+
+// MultistartGradientDescentHyperparameterOptimization / RestartedGradientDescentHyperparameterOptimizationTensor
+// (gpp_model_selection.hpp:967-1103) from caller-supplied initial guesses: see include/moe_hip.h.
+int moe_ll_multistart(moe_ll_t* ll, const moe_gd_params_t* gd, const double* domain_log10, const double* initial_guesses, int num_starts,
+                      double* best_hyperparameters, double* best_value, int* found, moe_error_t* err) {
+  return guarded(err, [&] {
+    require(ll != nullptr && gd != nullptr && domain_log10 != nullptr && initial_guesses != nullptr && best_hyperparameters != nullptr,
+            "NULL argument");
+    if (num_starts <= 0) throw moe::Error(MOE_ERR_BOUNDS, "num_multistarts must be > 1", num_starts, 1, 1e9);
+    std::lock_guard<std::mutex> lk(ll->mu);
+    const int nh = 1 + ll->d + 1 + ll->g;
+    std::vector<double> lin(2 * (size_t)nh);
+    for (int j = 0; j < 2 * nh; ++j) lin[j] = std::pow(10.0, domain_log10[j]);  // ConvertFromLogToLinearDomain (:862-869)
+    moe::BatchObjective f;
+    f.values = [&](const double* x_all, int n, double* values) { ll_evaluate_locked(ll, x_all, n, values); };
+    f.grads = [&](const double* x_all, int n, double* grads) {
+      for (int i = 0; i < n; ++i) ll_grad_locked(ll, x_all + (size_t)i * nh, grads + (size_t)i * nh);
+    };
+    // InitializeBestKnownPoint (:911-930): the best of the initial guesses seeds the result (found stays false)
+    std::vector<double> v0(num_starts);
+    f.values(initial_guesses, num_starts, v0.data());
+    double best = -INFINITY;
+    std::copy(initial_guesses, initial_guesses + nh, best_hyperparameters);
+    for (int i = 0; i < num_starts; ++i)
+      if (best < v0[i]) {
+        best = v0[i];
+        std::copy(initial_guesses + (size_t)i * nh, initial_guesses + (size_t)(i + 1) * nh, best_hyperparameters);
+      }
+    int fnd = 0;
+    // MultistartOptimizer (gpp_optimization.hpp:1472-1546): restarted gradient ascent from EVERY guess -- all of them stepped together,
+    // one batched pass per step -- the end points compared in start order with the strict test of :1512
+    std::vector<double> ends(initial_guesses, initial_guesses + (size_t)num_starts * nh), ve(num_starts);
+    moe_gd_params_t g = *gd;
+    g.domain_type = MOE_DOMAIN_TENSOR_PRODUCT;
+    moe::gradient_ascent_batch(f, g, lin.data(), nh, nh, ends.data(), num_starts);
+    f.values(ends.data(), num_starts, ve.data());
+    for (int i = 0; i < num_starts; ++i)
+      if (ve[i] > best) {
+        best = ve[i];
+        std::copy(&ends[(size_t)i * nh], &ends[(size_t)(i + 1) * nh], best_hyperparameters);
+        fnd = 1;
+      }
+    if (best_value) *best_value = best;
+    if (found) *found = fnd;
   });
 }
 

@@ -553,6 +553,70 @@ KgStateEnqueued enqueue_kg_state_batch(GpDev& gp, const double* U_all, int u, in
   return se;
 }
 
+namespace {
+// var = Kss - gram in place (Kss in `var`), col-major m x m
+__global__ __launch_bounds__(256) void var_sub_kernel(double* __restrict__ var, const double* __restrict__ gram, long n) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) var[i] = var[i] - gram[i];
+}
+// out = lower triangle (diagonal included) of `chol`, strict upper triangle of `var`
+__global__ __launch_bounds__(256) void chol_merge_kernel(double* __restrict__ out, const double* __restrict__ chol,
+                                                         const double* __restrict__ var, int m) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i < (long)m * m) {
+    const int row = (int)(i % m), col = (int)(i / m);
+    out[i] = (row >= col) ? chol[i] : var[i];
+  }
+}
+}  // namespace
+
+// ComputeVarianceOfPoints (gpp_math.cpp:924-970) and its Cholesky factor (ComputeCholeskyFactorL, gpp_linear_algebra.cpp:109-148, pivot
+// rule 1e-16) with the m x m algebra ON THE DEVICE (r5): Kss by the covariance-assembly kernel on the query points
+// themselves, the subtraction of the Gram matrix, the factorisation by the GP's own blocked kernels -- for query sets of hundreds of
+// points, where the host algebra of host_math.hip costs O(m^2 d) covariance calls and O(m^3) scalar operations.  out [m x m] col-major:
+// the variance, or (cholesky) its factor in the lower triangle with the variance's entries left above the diagonal, as the host path
+// leaves them (the reference's ZeroUpperTriangle call is the Python boundary's, GPP.py).
+void variance_on_device(GpDev& gp, const double* pts, int k, bool cholesky, double* out) {
+  gp.use_device();
+  hipStream_t s = gp.stream;
+  const StateEnqueued se = enqueue_state_batch(gp, pts, k, gp.derivs, 0, nullptr, 0, false, 1);
+  const int m = se.lay.m;
+  const size_t mm = (size_t)m * m;
+  const size_t work = cholesky ? cholesky_work_doubles(m) : 0;
+  // [var | factor workspace | inverse factor (unused by the caller) | scratch | merged output]
+  gp.dVarWork.reserve(mm * (cholesky ? 4 : 1) + work);
+  double* dVar = gp.dVarWork.p;
+  launch_cov_build(gp.cp, gp.dUnion, k, gp.derivs, gp.dUnion, k, gp.derivs, nullptr, dVar, m, 0, s);
+  hipLaunchKernelGGL(var_sub_kernel, dim3((unsigned)((mm + 255) / 256)), dim3(256), 0, s, dVar, gp.dGram.p, (long)mm);
+  MOE_HIP_CHECK(hipGetLastError());
+  gp.hStateOut.reserve(mm + 1);
+  if (!cholesky) {
+    MOE_HIP_CHECK(hipMemcpyAsync(gp.hStateOut.p, dVar, sizeof(double) * mm, hipMemcpyDeviceToHost, s));
+    MOE_HIP_CHECK(hipStreamSynchronize(s));
+    std::copy(gp.hStateOut.p, gp.hStateOut.p + mm, out);
+    return;
+  }
+  double* dChol = dVar + mm;
+  double* dInv = dChol + mm;
+  double* dOut = dInv + mm;
+  double* dWork = dOut + mm;
+  MOE_HIP_CHECK(hipMemcpyAsync(dChol, dVar, sizeof(double) * mm, hipMemcpyDeviceToDevice, s));
+  gp.dInfo.reserve(1);
+  launch_cholesky_and_inverse(m, dChol, m, dInv, m, dWork, gp.dInfo.p, s);
+  hipLaunchKernelGGL(chol_merge_kernel, dim3((unsigned)((mm + 255) / 256)), dim3(256), 0, s, dOut, dChol, dVar, m);
+  MOE_HIP_CHECK(hipGetLastError());
+  int info = 0;
+  gp.dInfo.download(&info, 1, s);
+  MOE_HIP_CHECK(hipMemcpyAsync(gp.hStateOut.p, dOut, sizeof(double) * mm, hipMemcpyDeviceToHost, s));
+  MOE_HIP_CHECK(hipStreamSynchronize(s));
+  if (info != 0)
+    throw Error(MOE_ERR_SINGULAR,
+                "GP-Variance matrix singular. Check for duplicate points_to_sample or points_to_sample "
+                "duplicating points_sampled with 0 noise.",
+                m, info);
+  std::copy(gp.hStateOut.p, gp.hStateOut.p + mm, out);
+}
+
 void compute_state_batch(GpDev& gp, const double* U_all, int u, const DerivList& dt, int nd, const double* extra_all, int A,
                          bool need_W, int num_evals, BatchLayout* blay, std::vector<StateHost>* hosts) {
   const StateEnqueued se = enqueue_state_batch(gp, U_all, u, dt, nd, extra_all, A, need_W, num_evals);

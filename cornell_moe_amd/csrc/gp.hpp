@@ -31,6 +31,7 @@ struct GpDev {
   std::vector<double> X, y, noise;  // host copies (reference keeps them too, gpp_math.hpp:846-856)
   double mean = 0.0;
   DevBuf<double> dX, dL, dLinv, dKinvY, dNoise, dTmp;
+  DevBuf<double> dVarWork;  // variance_on_device (dTmp keeps y - mean for the log likelihood)
   DevBuf<int> dInfo;
   // reusable workspaces for states
   DevBuf<double> dPts, dPtsGrad, dExtra, dE, dVE, dWE, dGram, dEK, dStateIn;
@@ -147,5 +148,9 @@ KgStateEnqueued enqueue_kg_state_batch(GpDev& gp, const double* U_all, int u, in
                                        const StateAppendix* apx = nullptr);
 void compute_state_batch(GpDev& gp, const double* U_all, int u, const DerivList& dt, int nd, const double* extra_all, int A,
                          bool need_W, int num_evals, BatchLayout* blay, std::vector<StateHost>* hosts);
+// Variance (or its Cholesky factor) of k query points with the m x m algebra on the device: gp.hip.  For large query sets; small ones
+// keep the host algebra (kDeviceVarianceMinM).
+constexpr int kDeviceVarianceMinM = 33;
+void variance_on_device(GpDev& gp, const double* pts, int k, bool cholesky, double* out);
 
 }  // namespace moe

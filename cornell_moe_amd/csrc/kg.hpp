@@ -99,6 +99,9 @@ struct DomainLimiter {
   const double* bounds;
   std::unique_ptr<Impl> impl;
 };
+// GradientDescentOptimizer::Optimize (gpp_optimization.hpp:619-705, 1144-1185) for S starts at once, x [S][qd] in place; every step
+// evaluates the gradients of all running starts in one f.grads call.  bounds[2 d] apply to each of the qd / d points.
+void gradient_ascent_batch(const BatchObjective& f, const moe_gd_params_t& outer, const double* bounds, int d, int qd, double* x, int S);
 // MultistartOptimizer over a batched objective: see multistart.hip.  bounds[2*d] apply to each of the qd/d points.
 void multistart(const BatchObjective& f, const moe_gd_params_t& outer, const double* bounds, int d, int qd, const double* starts,
                 int num_starts, int do_gradient_ascent, double floor_value, double* best_points, double* best_value,

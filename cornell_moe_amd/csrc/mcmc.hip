@@ -19,6 +19,7 @@
 #include "kg.hpp"
 
 #include <cstdlib>
+#include <thread>
 
 namespace moe {
 
@@ -51,12 +52,58 @@ void kg_mcmc_members(const std::vector<GpDev*>& gps, int num_fidelity, const moe
   const int max_e = kg_max_batch(*gps[0], P, q, p, num_mc, want_grad, budget);
   for (int e0 = 0; e0 < E; e0 += max_e) {
     const int ne = std::min(max_e, E - e0);
-    std::vector<KgPending> pending;
-    pending.reserve(gps.size());
-    for (size_t i = 0; i < gps.size(); ++i)
-      pending.push_back(kg_launch(*gps[i], num_fidelity, inner, bounds, discrete_all + i * disc_stride, P,
-                                  Xq_all + (size_t)e0 * qd, ne, Xp, q, p, num_mc, best_so_far[i], normals, 0, num_mc, want_grad,
-                                  false, budget, disc_head));
+    // Every member's evaluation is ~30 small launches on its own stream: at BO sizes (n = tens of points, M = 2^7 -- the regime of a
+    // whole suggestion, bench.py --config suggest) issuing them costs the host more than running them costs the device, so the
+    // members are issued by host threads side by side (r5: 2.0 -> ms per optimiser step of 16 members x 20 restarts; MOE_MCMC_THREADS=1:
+    // one after another, as in round 4).  Each member owns its stream, workspaces and staging buffers; results are collected in order.
+    std::vector<KgPending> pending(gps.size());
+    auto issue = [&](size_t i) {
+      pending[i] = kg_launch(*gps[i], num_fidelity, inner, bounds, discrete_all + i * disc_stride, P, Xq_all + (size_t)e0 * qd, ne, Xp, q,
+                             p, num_mc, best_so_far[i], normals, 0, num_mc, want_grad, false, budget, disc_head);
+    };
+    const char* mt = std::getenv("MOE_MCMC_THREADS");
+    const size_t nthreads = std::min(gps.size(), (size_t)std::max(1, (mt && *mt) ? std::atoi(mt) : 16));
+    if (nthreads <= 1) {
+      for (size_t i = 0; i < gps.size(); ++i) issue(i);
+    } else {
+      std::vector<Error> errors(nthreads, Error(MOE_OK, ""));
+      std::vector<char> failed(nthreads, 0);
+      std::vector<std::thread> threads;
+      threads.reserve(nthreads);
+      struct JoinAll {
+        std::vector<std::thread>& t;
+        ~JoinAll() {
+          for (std::thread& th : t)
+            if (th.joinable()) th.join();
+        }
+      } join_all{threads};
+      for (size_t k = 0; k < nthreads; ++k)
+        threads.emplace_back([&, k] {
+          try {
+            for (size_t i = k; i < gps.size(); i += nthreads) issue(i);
+          } catch (const Error& e) {
+            errors[k] = e;
+            failed[k] = 1;
+          } catch (const std::exception& e) {
+            errors[k] = Error(MOE_ERR_RUNTIME, e.what());
+            failed[k] = 1;
+          }
+        });
+      for (std::thread& t : threads) t.join();
+      for (size_t k = 0; k < nthreads; ++k)
+        if (failed[k]) {
+          // (members already in flight finish on their own streams; their workspaces are not touched again before the next call's
+          //  stream-ordered work)
+          for (size_t i = 0; i < gps.size(); ++i)
+            if (pending[i].collect) {
+              try {
+                pending[i].collect(ks.data(), want_grad ? gs.data() : nullptr, nullptr, nullptr);
+              } catch (...) {
+              }
+            }
+          throw errors[k];
+        }
+    }
     for (size_t i = 0; i < gps.size(); ++i) {
       pending[i].collect(ks.data(), want_grad ? gs.data() : nullptr, nullptr, nullptr);
       for (int e = 0; e < ne; ++e) kg_mem[i * (size_t)E + e0 + e] = ks[e] / (double)num_mc;

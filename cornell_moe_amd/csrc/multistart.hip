@@ -270,6 +270,10 @@ void gradient_ascent(const BatchObjective& f, const moe_gd_params_t& outer, cons
 
 }  // namespace
 
+void gradient_ascent_batch(const BatchObjective& f, const moe_gd_params_t& outer, const double* bounds, int d, int qd, double* x, int S) {
+  gradient_ascent(f, outer, bounds, d, qd, x, S);
+}
+
 std::vector<int> top_k_order(const double* vals, int num_starts) {
   // std::priority_queue<std::pair<double, int>> is a max-heap on (-value, index): its top is the lowest-valued kept start and,
   // among equal values, the one with the larger index

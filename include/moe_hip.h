@@ -390,6 +390,22 @@ int moe_ll_evaluate(moe_ll_t* ll, const double* hyperparameters_all, int num_set
  * (MaternNu2p5::HyperparameterGradCovariance, gpp_covariance.cpp:461-487, fills that block alone); the squared
  * exponential is provided without derivative observations.  A singular K + noise is MOE_ERR_SINGULAR. */
 int moe_ll_grad(moe_ll_t* ll, const double* hyperparameters, double* grad, moe_error_t* err);
+/* r5 -- multistart_hyperparameter_optimization / restarted_hyperparameter_optimization (gpp_python_model_selection.cpp:428-474 ->
+ * MultistartGradientDescentHyperparameterOptimization / RestartedGradientDescentHyperparameterOptimizationTensor,
+ * gpp_model_selection.hpp:967-1103) from caller-supplied initial guesses: the maximum-likelihood hyper-parameters by restarted gradient
+ * ascent (GradientDescentOptimizer, gpp_optimization.hpp:619-705, 1144-1185) on log p(y | X, theta) over
+ * theta = (alpha, lengths[dim], noise_variance[1 + g]) in LINEAR space, inside the tensor-product domain domain_log10[n_hyper][2] given
+ * in LOG-10 space (as the reference's boundary takes it).  initial_guesses[num_starts][n_hyper] are linear-space points (the reference
+ * draws a Latin hypercube in log space and exponentiates, :841-858; moe_latin_hypercube reproduces the generator).  As in the reference
+ * the best initial guess seeds the result (InitializeBestKnownPoint, :911-930) and *found reports whether an optimised end point beat
+ * it.  num_starts = 1 is the restarted (single-start) optimiser.  Every ascent step evaluates the gradients of all running starts. */
+int moe_ll_multistart(moe_ll_t* ll, const moe_gd_params_t* gd_params, const double* domain_log10, const double* initial_guesses,
+                      int num_starts, double* best_hyperparameters, double* best_value, int* found, moe_error_t* err);
+/* restarted_hyperparameter_optimization (RestartedGradientDescentHyperparameterOptimizationTensor, gpp_model_selection.hpp:989-1012):
+ * the point the restarted ascent from x0[n_hyper] (linear space) ENDS at -- the reference returns the state's current point, whether
+ * or not it improved on the start. */
+int moe_ll_ascend(moe_ll_t* ll, const moe_gd_params_t* gd_params, const double* domain_log10, const double* x0, double* end_point,
+                  moe_error_t* err);
 
 /* ---- covariance assembly (exposed for parity tests and the HBM-roofline measurement) ----
  * BuildMixCovarianceMatrix (gpp_math.cpp:309-335, 469-479): out[N x num_pts*(1+g2)] col-major = K(X, pts) with

@@ -380,6 +380,30 @@ def log_likelihood(cov_type, alpha, lengths, X, y, noise, derivs):
     return val.value
 
 
+def ll_multistart(cov_type, alpha, lengths, X, y, noise, derivs, gd, domain_log10, initial_guesses, num_threads=1):
+    """MultistartGradientDescentHyperparameterOptimization from caller-supplied linear-space guesses (ref_harness.cpp:
+    ref_ll_multistart): (best [1 + d + 1 + g], best log likelihood, found)."""
+    X = np.ascontiguousarray(X, dtype=np.float64)
+    n, d = X.shape
+    lengths, lp = _d(lengths)
+    ya, yp = _d(y)
+    noise, nop = _d(noise)
+    dv, dvp = _i(list(derivs))
+    g = len(derivs)
+    gd, gdp = _d(gd)
+    dom, dmp = _d(domain_log10)
+    x0 = np.ascontiguousarray(initial_guesses, dtype=np.float64).reshape(-1, 1 + d + 1 + g)
+    found, val = C.c_int(0), C.c_double(0.0)
+    best = np.zeros(1 + d + 1 + g)
+    L = lib()
+    L.ref_ll_multistart.argtypes = [C.c_int, C.c_double, _dp, _dp, _dp, _dp, _ip, C.c_int, C.c_int, C.c_int, _dp, _dp, _dp, C.c_int,
+                                    C.c_int, _ip, _dp, _dp]
+    _check(L.ref_ll_multistart(int(cov_type), float(alpha), lp, X.ctypes.data_as(_dp), yp, nop, dvp, g, d, n, gdp, dmp,
+                               x0.ctypes.data_as(_dp), x0.shape[0], int(num_threads), C.byref(found), best.ctypes.data_as(_dp),
+                               C.byref(val)))
+    return best, val.value, bool(found.value)
+
+
 def log_likelihood_grad(cov_type, alpha, lengths, X, y, noise, derivs):
     """LogMarginalLikelihoodEvaluator::ComputeGradLogLikelihood on a fresh state (gpp_python_model_selection.cpp:88-135).
     Returns [1 + d + 1 + g] partials wrt (alpha, lengths, noise variances)."""

@@ -487,6 +487,39 @@ int ref_log_likelihood_grad(int cov_type, double alpha, const double* lengths, c
   });
 }
 
+// MultistartGradientDescentHyperparameterOptimization (gpp_model_selection.hpp:1063-1103) from CALLER-SUPPLIED initial guesses
+// (linear space): the function's own body -- linear-space domain, SetupLogLikelihoodState, InitializeBestKnownPoint,
+// MultistartOptimizer over GradientDescentOptimizer -- minus the Latin-hypercube draw, whose uniform stream is not pinned across
+// Boost versions.  hyper0 = (alpha, lengths) of the covariance object the states are built from (the reference's wrapper passes the
+// caller's current hyper-parameters, gpp_python_model_selection.cpp:176-260); domain_log10[nh][2]; best[nh].
+int ref_ll_multistart(int cov_type, double alpha, const double* lengths, const double* X, const double* y, const double* noise,
+                      const int* derivs, int g, int d, int n, const double* gd, const double* domain_log10,
+                      const double* initial_guesses, int num_starts, int num_threads, int* found, double* best, double* best_value) {
+  return guarded([&] {
+    CovarianceInterface* cov = make_cov(cov_type, d, alpha, lengths);
+    LogMarginalLikelihoodEvaluator ev(X, y, nn(derivs), g, d, n);
+    std::vector<double> nv(noise, noise + 1 + g);
+    GradientDescentParameters gdp(static_cast<int>(gd[0]), static_cast<int>(gd[1]), static_cast<int>(gd[2]), static_cast<int>(gd[3]),
+                                  gd[4], gd[5], gd[6], gd[7]);
+    const int nh = cov->GetNumberOfHyperparameters() + 1 + g;
+    std::vector<ClosedInterval> dom(nh);
+    for (int i = 0; i < nh; ++i) dom[i] = ClosedInterval(std::pow(10.0, domain_log10[2 * i]), std::pow(10.0, domain_log10[2 * i + 1]));
+    TensorProductDomain domain_linearspace(dom.data(), nh);
+    ThreadSchedule sched(num_threads > 0 ? num_threads : 1, omp_sched_static);
+    std::vector<LogMarginalLikelihoodState> states;
+    SetupLogLikelihoodState(ev, *cov, nv, sched.max_num_threads, &states);
+    OptimizationIOContainer io(states[0].GetProblemSize());
+    InitializeBestKnownPoint(ev, initial_guesses, nh, num_starts, states.data(), &io);
+    GradientDescentOptimizer<LogMarginalLikelihoodEvaluator, TensorProductDomain> gd_opt;
+    MultistartOptimizer<GradientDescentOptimizer<LogMarginalLikelihoodEvaluator, TensorProductDomain> > ms;
+    ms.MultistartOptimize(gd_opt, ev, gdp, domain_linearspace, sched, initial_guesses, num_starts, states.data(), nullptr, &io);
+    *found = io.found_flag ? 1 : 0;
+    std::copy(io.best_point.begin(), io.best_point.end(), best);
+    if (best_value) *best_value = io.best_objective_value_so_far;
+    delete cov;
+  });
+}
+
 // All-core CPU baseline the way the reference parallelises: independent evaluations under OpenMP, one State + RNG per
 // thread (gpp_optimization.hpp:1472-1546). Xq_all[R][q][d]; kg_out[R]; grad_out[R][q*d]. Returns wall seconds.
 int ref_kg_grad_batch(void* hv, int num_fidelity, const double* gd, const double* bounds, const double* discrete, int P,

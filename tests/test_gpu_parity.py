@@ -668,3 +668,112 @@ def test_ei_device_algebra_matches_host_algebra(api, golden, monkeypatch):
         e, g = gp.ei(Xq, None, 16, float(i["ei_best"]), np.random.default_rng(5).standard_normal((16, 2)))
         assert np.isfinite(e) and np.all(np.isfinite(g))
     monkeypatch.delenv("MOE_EI_DEVICE_ALGEBRA")
+
+
+def test_variance_of_hundreds_of_points_on_the_device():
+    """r5: compute_variance_of_points / compute_cholesky_variance_of_points for query sets of hundreds of points take
+    the device algebra (gp.hip: variance_on_device -- Kss by the covariance kernel, the Gram subtraction, the GP's blocked Cholesky)
+    instead of the host's O(m^2 d) covariance calls and O(m^3) scalar factorisation: k = 512 points (and 150 points with two observed
+    derivatives: m = 450) against the unmodified reference / the restatement; the small-set host path and the device path agree
+    where they meet; the log likelihood still sees its own workspace afterwards; a duplicate point is reported singular."""
+    import time
+    from cornell_moe_amd import api
+    from cornell_moe_amd.workloads import make_workload
+    from oracle import orc
+    from helpers import reference_checker
+    for n, d, derivs, k in ((400, 4, (), 512), (300, 3, (0, 2), 150)):
+        w = make_workload(seed=500 + k, n=n, d=d, q=2, M=8, P=4, derivs=derivs)
+        noise = np.maximum(w.noise, 1e-3)
+        G = api.DeviceGP(w.hyperparameters, w.X, w.y, noise, derivs)
+        R = reference_checker(1, w.alpha, w.lengths, w.X, w.y, noise, derivs) or orc.OrcGP(1, w.alpha, w.lengths, w.X, w.y, noise, derivs)
+        pts = np.random.default_rng(k).uniform(0.02, 0.98, size=(k, d))
+        m = k * (1 + len(derivs))
+        ll0 = G.log_likelihood() if hasattr(G, "log_likelihood") else None
+        t0 = time.perf_counter()
+        var = G.variance(pts).reshape(m, m)
+        t_var = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        chol = G.cholesky_variance(pts).reshape(m, m)
+        t_chol = time.perf_counter() - t0
+        vr = np.asarray(R.var(pts)).reshape(m, m)
+        scale = np.abs(vr).max()
+        assert np.abs(var - vr).max() <= 1e-10 * scale, np.abs(var - vr).max() / scale
+        L = np.tril(chol.T)                       # (flat col-major: row-major view is the transpose)
+        assert np.abs(L @ L.T - vr).max() <= 1e-9 * scale
+        assert np.array_equal(np.triu(chol.T, 1), np.triu(var.T, 1))   # the variance's entries stay above the diagonal (host path's layout)
+        cr = np.asarray(R.chol_var(pts)).reshape(m, m)
+        assert np.abs(L - np.tril(cr.T)).max() <= 1e-8 * np.sqrt(scale)
+        if ll0 is not None:
+            assert G.log_likelihood() == ll0
+        # the device path at its threshold against the host path just below it (same points, one fewer)
+        small = pts[: max(1, 32 // (1 + len(derivs)))]
+        big = pts[: 33 // (1 + len(derivs)) + 1]
+        vs, vb = G.variance(small), G.variance(big)
+        ms, mb = len(small) * (1 + len(derivs)), len(big) * (1 + len(derivs))
+        assert np.abs(vb.reshape(mb, mb)[:ms, :ms] - vs.reshape(ms, ms)).max() <= 1e-12 * scale
+        print("variance of %d points (m = %d): %.1f ms, Cholesky variance %.1f ms" % (k, m, 1e3 * t_var, 1e3 * t_chol))
+        dup = np.vstack([pts[:40], pts[:1]])
+        Gz = api.DeviceGP(w.hyperparameters, w.X, w.y, np.zeros_like(noise), derivs)
+        with pytest.raises(api.SingularMatrixException):
+            Gz.cholesky_variance(np.vstack([dup, w.X[:1]]))
+
+
+def test_hyperparameter_optimisers_against_reference():
+    """r5 (SURVEY 8b 'next'): moe_ll_multistart -- MultistartGradientDescentHyperparameterOptimization
+    (gpp_model_selection.hpp:1063-1103) from explicit linear-space guesses, every start's restarted gradient ascent stepped together on the
+    device -- against the unmodified reference (tests/golden/ref_ll_multistart.npz, tools/make_golden.py --ll-multistart: the reference's
+    own function body minus its Latin-hypercube draw): the maximum-likelihood hyper-parameters to 1e-6 relative, its log likelihood to
+    1e-9, the found flag; and the boundary functions GPP.multistart_hyperparameter_optimization / restarted_hyperparameter_optimization."""
+    import os
+    from cornell_moe_amd import GPP, api
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_ll_multistart.npz"))
+    for k in range(int(z["num"])):
+        X, y, derivs = z["s%d_X" % k], z["s%d_y" % k], [int(v) for v in z["s%d_derivs" % k]]
+        gd, dom, guesses = tuple(z["s%d_gd" % k]), z["s%d_domain_log10" % k], z["s%d_guesses" % k]
+        LL = api.LogLikelihood(X, y, derivs)
+        v0 = LL.evaluate(guesses)
+        assert np.abs(v0 - z["s%d_initial_values" % k]).max() <= 1e-9 * np.abs(z["s%d_initial_values" % k]).max()
+        best, val, found = LL.multistart(gd, dom, guesses)
+        rb, rv = z["s%d_best" % k], float(z["s%d_best_value" % k])
+        assert found == bool(z["s%d_found" % k])
+        assert abs(val - rv) <= 1e-9 * max(abs(rv), 1.0), (k, val, rv)
+        assert np.abs(best / rb - 1.0).max() <= 1e-6, (k, best, rb)
+        lo, hi = 10.0 ** dom[:, 0], 10.0 ** dom[:, 1]
+        assert np.all(best >= lo) and np.all(best <= hi)
+        # restarted optimiser from the first guess: ends where the reference's single-start run ends (case 1 IS a single-start run)
+        end = LL.ascend(gd, dom, guesses[0])
+        if guesses.shape[0] == 1:
+            assert np.abs(end / rb - 1.0).max() <= 1e-6
+        assert LL.evaluate(end[None, :])[0] >= v0[0]
+    # the boundary: names / argument order of gpp_python_model_selection.cpp:428-474
+    k = 0
+    X, y = z["s0_X"], z["s0_y"]
+    n, d = X.shape
+
+    class Opt(object):
+        objective_type = GPP.LogLikelihoodTypes.log_marginal_likelihood
+        optimizer_type = GPP.OptimizerTypes.gradient_descent
+        num_random_samples = 64
+        optimizer_parameters = GPP.GradientDescentParameters(4, 40, 2, 0, 0.5, 0.5, 0.02, 1.0e-7)
+
+    rnd = GPP.RandomnessSourceContainer(1)
+    rnd.SetExplicitUniformGeneratorSeed(7)
+    status = {}
+    dom = z["s0_domain_log10"]
+    got = GPP.multistart_hyperparameter_optimization(Opt(), list(dom.ravel()), list(X.ravel()), list(y.ravel()), d, n, [1.0, [0.5] * d],
+                                                     [0.1], [], 0, 4, rnd, status)
+    assert len(got) == 1 + d + 1 and "log_marginal_likelihood_gradient_descent_found_update" in status
+    ll_got = GPP.compute_log_likelihood(list(X.ravel()), list(y.ravel()), d, n, GPP.LogLikelihoodTypes.log_marginal_likelihood,
+                                        [got[0], list(got[1:1 + d])], [], 0, [got[1 + d]])
+    start = GPP.compute_log_likelihood(list(X.ravel()), list(y.ravel()), d, n, GPP.LogLikelihoodTypes.log_marginal_likelihood,
+                                       [1.0, [0.5] * d], [], 0, [0.1])
+    assert ll_got > start
+    Opt.optimizer_type = GPP.OptimizerTypes.null
+    st2 = {}
+    lhc = GPP.multistart_hyperparameter_optimization(Opt(), list(dom.ravel()), list(X.ravel()), list(y.ravel()), d, n, [1.0, [0.5] * d],
+                                                     [0.1], [], 0, 4, rnd, st2)
+    assert st2["log_marginal_likelihood_lhc_found_update"] is True and len(lhc) == 1 + d + 1
+    Opt.optimizer_type = GPP.OptimizerTypes.gradient_descent
+    end = GPP.restarted_hyperparameter_optimization(Opt(), list(dom.ravel()), list(X.ravel()), list(y.ravel()), d, n, [1.0, [0.5] * d],
+                                                    [0.1], [], 0, {})
+    assert len(end) == 1 + d + 1 and np.all(np.isfinite(end))

@@ -515,7 +515,49 @@ def kg_multistart_fixtures():
     print("wrote", OUT_MS, os.path.getsize(OUT_MS), "bytes")
 
 
+def ll_multistart_fixtures():
+    """r5: the maximum-likelihood hyper-parameter optimisers (SURVEY 8b 'next'; gpp_model_selection.hpp:967-1103) from explicit
+    linear-space initial guesses (oracle/ref_harness.cpp: ref_ll_multistart -- the body of
+    MultistartGradientDescentHyperparameterOptimization minus its Latin-hypercube draw) -> tests/golden/ref_ll_multistart.npz.
+    GD settings of the reference's own tests (gpp_model_selection_test.cpp:700-710, 892-900: gamma 0.5, pre_mult 0.5,
+    max_relative_change 0.02)."""
+    out = {}
+    k = 0
+    for seed, n, d, derivs, S, steps, restarts in ((11, 30, 2, (), 6, 60, 3), (12, 45, 3, (), 1, 80, 4), (13, 24, 2, (1,), 4, 40, 2)):
+        rng = np.random.default_rng(seed)
+        g = len(derivs)
+        X = rng.uniform(0.0, 1.0, size=(n, d))
+        true_len = rng.uniform(0.3, 0.6, size=d)
+        # a smooth function + a little noise; derivative observations from finite formulas of the same function
+        f = lambda x: np.sin(x / true_len).sum(axis=-1)
+        y = np.zeros((n, 1 + g))
+        y[:, 0] = f(X) + 0.05 * rng.standard_normal(n)
+        for a, dd in enumerate(derivs):
+            y[:, 1 + a] = np.cos(X[:, dd] / true_len[dd]) / true_len[dd] + 0.05 * rng.standard_normal(n)
+        nh = 1 + d + 1 + g
+        domain_log10 = np.tile([-2.0, 1.0], (nh, 1))
+        domain_log10[1 + d:, :] = [-3.0, 0.0]          # noise variances in [1e-3, 1]
+        guesses = 10.0 ** (domain_log10[:, 0] + (domain_log10[:, 1] - domain_log10[:, 0]) * rng.uniform(0.25, 0.75, size=(S, nh)))
+        gd = np.array((S, steps, restarts, 0, 0.5, 0.5, 0.02, 1.0e-7))
+        hyper0 = guesses[0]
+        best, val, found = ref.ll_multistart(1, hyper0[0], hyper0[1:1 + d], X, y, hyper0[1 + d:], derivs, gd, domain_log10, guesses)
+        v0 = [ref.log_likelihood(1, h[0], h[1:1 + d], X, y, h[1 + d:], derivs) for h in guesses]
+        print("ll multistart case %d: n=%d d=%d g=%d S=%d  best LL %.10g (best initial %.10g) found=%s" % (k, n, d, g, S, val, max(v0), found))
+        for key, v in (("X", X), ("y", y), ("derivs", np.array(derivs, dtype=np.int64)), ("gd", gd), ("domain_log10", domain_log10),
+                       ("guesses", guesses), ("best", best), ("best_value", np.array(val)), ("found", np.array(int(found))),
+                       ("initial_values", np.array(v0))):
+            out["s%d_%s" % (k, key)] = v
+        k += 1
+    out["num"] = np.array(k)
+    path = os.path.join(os.path.dirname(OUT), "ref_ll_multistart.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, os.path.getsize(path), "bytes")
+
+
 def main():
+    if "--ll-multistart" in sys.argv:
+        ll_multistart_fixtures()
+        return
     if "--ll-grad" in sys.argv:
         ll_grad_fixtures()
         return
