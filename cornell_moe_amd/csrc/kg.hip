@@ -1734,6 +1734,9 @@ int kg_max_batch(const GpDev& gp, int P, int q, int p, int num_local, bool want_
   //  q-KG shapes there too -- and the batch must fit whatever it decides)
   const double slots1 = gp.g <= 4 ? g1 : (gp.g <= 8 ? 9.0 : 13.0);  // (the streamed-weights table pads a point's weights to 1 + G)
   doubles += (gp.n + u + 64.0) * slots1 * (double)num_local;
+  //  the split-K workspace of the state's triangular / Gram products (gp.dEK: ~8 N m per evaluation) and the evaluation's
+  // share of the staging appendix (its record: L, mu_disc, C_disc, the discretised set, the padded union points)
+  doubles += 8.0 * N * m + (m * m + A * (1.0 + m + gp.d) + u * gp.dp + 8.0);
   const double per_eval_gb = 8.0 * doubles / 1e9;
   return (int)std::max(1.0, std::floor(budget_gb / std::max(per_eval_gb, 1e-9)));
 }

@@ -421,6 +421,12 @@ def test_add_points_rank_k_append(api, n0, adds, d, derivs):
         a.add_points(X[at:at + k], y[at:at + k])
         at += k
     b = api.DeviceGP(hyper, X, y, noise, derivatives=derivs)
+    #  the factor's strict upper triangle holds EXACT zeros after every append (and after the rebuild an append beyond the
+    # head-room falls back to): the buffer is cleared once per shape and every writer -- covariance build, panel / update / diagonal
+    # kernels, the append -- stays on or below the diagonal; trtri_levels and the K_chol download read it as an operand with explicit zeros
+    La, Lb = a.get_factor()[0], b.get_factor()[0]   # [row][col]
+    assert np.count_nonzero(np.triu(La, 1)) == 0 and np.all(np.isfinite(La))
+    assert np.abs(np.tril(La) - np.tril(Lb)).max() <= 1e-10 * np.abs(Lb).max()
     q = rng.uniform(size=(9, d))
     for fa, fb in ((a.mean(q), b.mean(q)), (a.variance(q), b.variance(q)), (a.grad_mean(q), b.grad_mean(q)),
                    (a.cholesky_variance(q[:4]), b.cholesky_variance(q[:4])),

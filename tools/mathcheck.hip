@@ -62,6 +62,11 @@ int main() {
   std::uniform_real_distribution<double> u(0.0, 40.0), lg(-12.0, 2.8);
   for (int i = 0; i < 2000000; ++i) x.push_back(u(rng));
   for (int i = 0; i < 2000000; ++i) x.push_back(std::pow(10.0, lg(rng)));
+  // r5: the whole range of squared distances the MC kernels can hand to sqrt_pos_fast -- 1e-300 (the floor of the distance
+  // accumulation, coincident points) up to 1e14 (trial points of far frames) -- log-uniform
+  const size_t n_narrow = x.size();
+  std::uniform_real_distribution<double> lgw(-300.0, 14.0);
+  for (int i = 0; i < 2000000; ++i) x.push_back(std::pow(10.0, lgw(rng)));
   const int n = (int)x.size();
   std::vector<double> tab(96);
   for (int j = 0; j < 32; ++j) tab[j] = (double)std::exp2((long double)j / 32.0L);
@@ -93,6 +98,18 @@ int main() {
       }
     }
     std::printf("%-14s max error %.3f ulp at x = %.17g\n", names[a], worst, wx);
+    if (a == 5) {  // sqrt seed + heron (sqrt_pos_fast): the wide range on its own
+      double ww = 0, wwx = 0;
+      for (size_t i = n_narrow; i < (size_t)n; ++i) {
+        const long double ref = sqrtl((long double)x[i]);
+        const double err = (double)fabsl((long double)h[a][i] - ref) / ulp_of((double)ref);
+        if (err > ww) {
+          ww = err;
+          wwx = x[i];
+        }
+      }
+      std::printf("%-14s over [1e-300, 1e14] (2e6 log-uniform arguments): max error %.3f ulp at x = %.17g\n", names[a], ww, wwx);
+    }
   }
   std::printf("exp(-0) poly %.17g tab %.17g ; exp(-745.2) poly %g tab %g ; exp(-800) poly %g tab %g\n", h[0][0], h[1][0], h[0][12],
               h[1][12], h[0][14], h[1][14]);
