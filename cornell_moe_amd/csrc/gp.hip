@@ -1,4 +1,5 @@
 // cornell_moe_amd/csrc/gp.hip -- see gp.hpp.
+#include <chrono>
 #include "gp.hpp"
 
 #include <algorithm>
@@ -43,13 +44,18 @@ GpDev::GpDev(const double* hyper, int cov_type, const double* X_in, const double
   y.assign(y_in, y_in + (size_t)N);
   noise.assign(noise_in, noise_in + (1 + g));
   use_device();
-  MOE_HIP_CHECK(hipStreamCreate(&stream));
+  stream = DevicePool::get().take_stream(device);
   {
-    hipDeviceProp_t prop;
-    MOE_HIP_CHECK(hipGetDeviceProperties(&prop, device));
-    if (prop.multiProcessorCount > 0) num_cu = prop.multiProcessorCount;
+    const int cu = DevicePool::get().num_cu(device);
+    if (cu > 0) num_cu = cu;
   }
-  rebuild();
+  try {
+    rebuild();
+  } catch (...) {  // (a singular K: no destructor runs for a constructor that throws)
+    DevicePool::get().give_stream(device, stream);
+    stream = nullptr;
+    throw;
+  }
 }
 
 void fill_cov_params(CovParams& cp, int cov_type, int d, const double* hyper) {
@@ -253,7 +259,7 @@ double GpDev::log_marginal_likelihood() {
 GpDev::~GpDev() {
   if (stream) {
     (void)hipSetDevice(device);
-    (void)hipStreamDestroy(stream);
+    DevicePool::get().give_stream(device, stream);
   }
 }
 
@@ -279,6 +285,12 @@ void GpDev::refresh_extent() {
 
 void GpDev::rebuild() {
   use_device();
+  // MOE_BUILD_TRACE=1: host-clock split of a build on stderr (buffers | launches queued | device done | K^-1 y)
+  static const bool trace = std::getenv("MOE_BUILD_TRACE") != nullptr && std::atoi(std::getenv("MOE_BUILD_TRACE")) != 0;
+  const auto t0 = std::chrono::steady_clock::now();
+  auto ms_since = [&](std::chrono::steady_clock::time_point t) {
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t).count();
+  };
   N = n * (1 + g);
   refresh_extent();
   for (int k = 0; k < d; ++k) cp.center[k] = x_mean[k];  // frame centre of the value-only covariance builds: the training-set mean
@@ -295,6 +307,7 @@ void GpDev::rebuild() {
   // K(X, X) + noise, lower triangle only (r4: 8 [n d + N (N + 1) / 2] bytes, SURVEY 8(d)'s symmetric count -- the full square and the
   // pass that zeroed its upper half afterwards wrote three times that).  The strict upper triangle of dL is cleared once per buffer
   // SHAPE: neither this build nor the factorisation writes there, so rebuilds in place (hyper-parameter sampling) find it zero.
+  const double t_buf = trace ? ms_since(t0) : 0.0;
   if (dL.p != zeroed_L || ldL != zeroed_ld) {
     MOE_HIP_CHECK(hipMemsetAsync(dL.p, 0, sizeof(double) * (size_t)ldL * ldL, stream));
     zeroed_L = dL.p;
@@ -303,7 +316,13 @@ void GpDev::rebuild() {
   launch_cov_build(cp, dX.p, n, derivs, dX.p, n, derivs, dNoise.p, dL.p, ldL, 0, stream, false, true);
   dWE.reserve(cholesky_work_doubles(N));  // the state workspace doubles as scratch of the recursive inversion
   launch_cholesky_and_inverse(N, dL.p, ldL, dLinv.p, ldL, dWE.p, dInfo.p, stream, true);
+  const double t_queued = trace ? ms_since(t0) : 0.0;
+  if (trace) MOE_HIP_CHECK(hipStreamSynchronize(stream));
+  const double t_dev = trace ? ms_since(t0) : 0.0;
   finish_factorisation();
+  if (trace)
+    std::fprintf(stderr, "[moe build] N=%d: buffers %.3f ms, launches queued at %.3f, device done at %.3f, K^-1 y done at %.3f\n", N, t_buf,
+                 t_queued, t_dev, ms_since(t0));
 }
 
 // Checks the factorisation's status word, then mean_ and K^-1 (y - mean_) from the inverse factor (two triangular GEMVs).
