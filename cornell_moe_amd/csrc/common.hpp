@@ -121,6 +121,40 @@ class DevicePool {
     }
     (void)hipStreamDestroy(s);
   }
+  // pinned host staging buffers (hipHostMalloc: 0.1 ms and more each; a GP holds two and a KG workspace several)
+  void* take_host(size_t bytes, size_t* got) {
+    const size_t want = round_size(bytes);
+    if (enabled_) {
+      std::lock_guard<std::mutex> lock(mu_);
+      auto it = host_.lower_bound(want);
+      if (it != host_.end() && it->first <= want + want / 2) {
+        void* p = it->second;
+        *got = it->first;
+        host_held_ -= it->first;
+        host_.erase(it);
+        return p;
+      }
+    }
+    void* p = nullptr;
+    hipError_t e = hipHostMalloc(&p, want, hipHostMallocDefault);
+    if (e != hipSuccess)
+      throw Error(MOE_ERR_RUNTIME, std::string("HIP error: ") + hipGetErrorString(e) + " (hipHostMalloc of " + std::to_string(want) + " bytes)");
+    *got = want;
+    return p;
+  }
+  // (the owner has synchronised the stream its copies ran on: every entry point ends with one)
+  void give_host(void* p, size_t bytes) {
+    if (p == nullptr) return;
+    if (enabled_) {
+      std::lock_guard<std::mutex> lock(mu_);
+      if (host_held_ + bytes <= kMaxHostHeld) {
+        host_.emplace(bytes, p);
+        host_held_ += bytes;
+        return;
+      }
+    }
+    (void)hipHostFree(p);
+  }
   int num_cu(int dev) {
     {
       std::lock_guard<std::mutex> lock(mu_);
@@ -140,6 +174,9 @@ class DevicePool {
       for (auto& b : dev.second) (void)hipFree(b.second);
     free_.clear();
     held_ = 0;
+    for (auto& b : host_) (void)hipHostFree(b.second);
+    host_.clear();
+    host_held_ = 0;
   }
   size_t held() {
     std::lock_guard<std::mutex> lock(mu_);
@@ -166,6 +203,9 @@ class DevicePool {
   std::mutex mu_;
   std::map<int, std::multimap<size_t, void*>> free_;
   std::map<int, std::vector<hipStream_t>> streams_;
+  std::multimap<size_t, void*> host_;
+  size_t host_held_ = 0;
+  static constexpr size_t kMaxHostHeld = (size_t)4 << 30;
   std::map<int, int> num_cu_;
   size_t held_ = 0, max_held_ = 0;
   bool enabled_ = true;
@@ -211,17 +251,18 @@ template <typename T>
 struct PinnedBuf {
   T* p = nullptr;
   size_t cap = 0;
+  size_t bytes = 0;  // size of the pool block behind p
   PinnedBuf() = default;
   PinnedBuf(const PinnedBuf&) = delete;
   PinnedBuf& operator=(const PinnedBuf&) = delete;
-  ~PinnedBuf() {
-    if (p) (void)hipHostFree(p);
-  }
+  ~PinnedBuf() { DevicePool::get().give_host(p, bytes); }
   void reserve(size_t n) {
     if (n <= cap) return;
-    if (p) MOE_HIP_CHECK(hipHostFree(p));
+    DevicePool::get().give_host(p, bytes);
     p = nullptr;
-    MOE_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&p), n * sizeof(T), hipHostMallocDefault));
+    cap = 0;
+    bytes = 0;
+    p = static_cast<T*>(DevicePool::get().take_host(n * sizeof(T), &bytes));
     cap = n;
   }
 };

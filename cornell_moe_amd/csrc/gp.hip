@@ -325,26 +325,28 @@ void GpDev::rebuild() {
                  t_queued, t_dev, ms_since(t0));
 }
 
-// Checks the factorisation's status word, then mean_ and K^-1 (y - mean_) from the inverse factor (two triangular GEMVs).
+// mean_ and K^-1 (y - mean_) from the inverse factor (two triangular GEMVs), queued behind the factorisation without a host round
+// trip (r5: the centred data travel from a pinned buffer); the factorisation's status word is checked once everything has run.
 void GpDev::finish_factorisation() {
-  int info = 0;
-  dInfo.download(&info, 1, stream);
   // mean_ = average of the function-value column only (gpp_math.cpp:498-504)
   mean = 0.0;
   for (int i = 0; i < n; ++i) mean += y[(size_t)i * (1 + g)];
   mean /= n;
-  std::vector<double> ymm(y);
-  for (int i = 0; i < n; ++i) ymm[(size_t)i * (1 + g)] -= mean;
-  MOE_HIP_CHECK(hipMemcpyAsync(dTmp.p, ymm.data(), sizeof(double) * N, hipMemcpyHostToDevice, stream));
+  hYc.reserve((size_t)N + 1);
+  for (int i = 0; i < N; ++i) hYc.p[i] = y[i];
+  for (int i = 0; i < n; ++i) hYc.p[(size_t)i * (1 + g)] -= mean;
+  MOE_HIP_CHECK(hipMemcpyAsync(dTmp.p, hYc.p, sizeof(double) * N, hipMemcpyHostToDevice, stream));
+  launch_tri_gemm_skinny('N', N, 1, dLinv.p, ldL, dTmp.p, N, dTmp.p + N, N, stream);
+  launch_tri_gemm_skinny('T', N, 1, dLinv.p, ldL, dTmp.p + N, N, dKinvY.p, N, stream);
+  int* info = reinterpret_cast<int*>(hYc.p + N);
+  *info = 0;
+  MOE_HIP_CHECK(hipMemcpyAsync(info, dInfo.p, sizeof(int), hipMemcpyDeviceToHost, stream));
   MOE_HIP_CHECK(hipStreamSynchronize(stream));
-  if (info != 0)
+  if (*info != 0)
     throw Error(MOE_ERR_SINGULAR,
                 "Covariance matrix (K) singular. Check for duplicate points_sampled (with 0 noise) and/or extreme "
                 "hyperparameter values.",
-                N, info);
-  launch_tri_gemm_skinny('N', N, 1, dLinv.p, ldL, dTmp.p, N, dTmp.p + N, N, stream);
-  launch_tri_gemm_skinny('T', N, 1, dLinv.p, ldL, dTmp.p + N, N, dKinvY.p, N, stream);
-  MOE_HIP_CHECK(hipStreamSynchronize(stream));
+                N, *info);
 }
 
 void GpDev::mean_of_points(const double* pts, int k, double* mu, double* grad) {

@@ -39,6 +39,7 @@ struct GpDev {
   const double* dUnion = nullptr;
   const double* dAppendix = nullptr;
   PinnedBuf<double> hStateIn, hStateOut, hKgIn, hKgOut;  // pinned staging for the per-call operands / results
+  PinnedBuf<double> hYc;  // y - mean on its way to the device, and the factorisation's status word on its way back
   // reusable workspaces of the KG evaluator (kg.hip)
   DevBuf<double> kBlob, kNormals, kTab, kBestPoint, kBestValue, kBeta, kT, kC, kTB, kOut, kSW, kSWpart, kZcPart, kV;
   DevBuf<unsigned long long> kCounters;
