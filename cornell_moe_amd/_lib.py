@@ -78,6 +78,8 @@ SIGNATURES = {
     "moe_kg_mcmc_multistart": (C.c_int, [_GPA, C.c_int, C.c_int, C.POINTER(GdParams), C.POINTER(GdParams), dp, dp, C.c_int, dp,
                                          C.c_int, dp, C.c_int, C.c_int, C.c_int, dp, dp, C.c_int, dp, dp, ip, _EP]),
     "moe_multistart_trace": (C.c_int, [dp, C.c_int]),
+    "moe_pool_held_bytes": (C.c_longlong, []),
+    "moe_pool_trim": (C.c_int, []),
     "moe_debug_sharded_items": (C.c_int, [C.POINTER(Comm), C.c_int, C.c_int, C.c_double, C.c_int, dp, _EP]),
     "moe_kg_multistart_comm": (C.c_int, [_GP, C.POINTER(Comm), C.c_int, C.POINTER(GdParams), C.POINTER(GdParams), dp, dp, C.c_int,
                                          dp, C.c_int, dp, C.c_int, C.c_int, C.c_int, C.c_double, dp, C.c_int, dp, dp, ip, _EP]),

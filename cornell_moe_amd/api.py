@@ -87,6 +87,16 @@ def kxx_build_probe(log=None, device=0):
     return out
 
 
+def pool_held_bytes():
+    """moe_pool_held_bytes: device bytes the library's pool holds (released by destroyed objects, not yet reused)."""
+    return int(_lib.load().moe_pool_held_bytes())
+
+
+def pool_trim():
+    """moe_pool_trim: give every pooled device / pinned buffer back to the runtime."""
+    _lib.load().moe_pool_trim()
+
+
 def multistart_trace():
     """moe_multistart_trace: rows (kind 0 values / 1 gradients, items, ms) of the last outer optimisation of this process."""
     L = _lib.load()

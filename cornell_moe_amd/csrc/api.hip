@@ -860,6 +860,12 @@ void run_workers(int W, const std::function<void(int, const moe::Comm&)>& body) 
 
 }  // namespace
 
+long long moe_pool_held_bytes(void) { return (long long)moe::DevicePool::get().held(); }
+
+int moe_pool_trim(void) {
+  return guarded(nullptr, [&] { moe::DevicePool::get().trim(); });
+}
+
 int moe_multistart_trace(double* out, int cap) { return moe::multistart_trace_get(out, cap); }
 
 // The deal-and-exchange step of the multi-rank optimisers on synthetic items -- item i's result is width copies of

@@ -42,8 +42,10 @@ struct Error : public std::runtime_error {
 class DevicePool {
  public:
   static DevicePool& get() {
-    static DevicePool pool;
-    return pool;
+    // (never destroyed: objects that outlive static destruction -- a handle closed by an exit handler -- must still find it, and the
+    //  blocks it holds at process exit are left to the runtime's own teardown)
+    static DevicePool* pool = new DevicePool;
+    return *pool;
   }
   // a block of at least `bytes` on the current device; *got = its size
   void* take(size_t bytes, size_t* got) {
@@ -190,8 +192,6 @@ class DevicePool {
     const char* gb = std::getenv("MOE_POOL_MAX_GB");
     max_held_ = (size_t)((gb != nullptr ? std::atof(gb) : 48.0) * 1e9);
   }
-  // (the blocks still held at process exit are left to the runtime's own teardown: its objects may be gone by then)
-  ~DevicePool() = default;
   // sizes in classes, so that shapes a few rows apart share blocks: 256 B granules up to 64 KB, 1/16 of the leading power of two above
   static size_t round_size(size_t bytes) {
     if (bytes <= 65536) return (bytes + 255) / 256 * 256 + (bytes == 0 ? 256 : 0);

@@ -53,7 +53,8 @@ GpDev::GpDev(const double* hyper, int cov_type, const double* X_in, const double
     rebuild();
   } catch (...) {  // (a singular K: no destructor runs for a constructor that throws)
     DevicePool::get().give_stream(device, stream);
-    stream = nullptr;
+    DevicePool::get().give_stream(device, side_stream);
+    stream = side_stream = nullptr;
     throw;
   }
 }
@@ -260,6 +261,7 @@ GpDev::~GpDev() {
   if (stream) {
     (void)hipSetDevice(device);
     DevicePool::get().give_stream(device, stream);
+    DevicePool::get().give_stream(device, side_stream);
   }
 }
 
@@ -315,7 +317,8 @@ void GpDev::rebuild() {
   }
   launch_cov_build(cp, dX.p, n, derivs, dX.p, n, derivs, dNoise.p, dL.p, ldL, 0, stream, false, true);
   dWE.reserve(cholesky_work_doubles(N));  // the state workspace doubles as scratch of the recursive inversion
-  launch_cholesky_and_inverse(N, dL.p, ldL, dLinv.p, ldL, dWE.p, dInfo.p, stream, true);
+  if (side_stream == nullptr && early_inverse_split(N) > 0) side_stream = DevicePool::get().take_stream(device);
+  launch_cholesky_and_inverse(N, dL.p, ldL, dLinv.p, ldL, dWE.p, dInfo.p, stream, true, side_stream);
   const double t_queued = trace ? ms_since(t0) : 0.0;
   if (trace) MOE_HIP_CHECK(hipStreamSynchronize(stream));
   const double t_dev = trace ? ms_since(t0) : 0.0;

@@ -109,9 +109,13 @@ void launch_gram_cross_batch(int E, int m, int ng, int A, int K, const double* S
 // work: cholesky_work_doubles(N) doubles of device scratch for the recursive inversion.
 // upper_is_zero: the caller guarantees that A's strict upper triangle already holds zeros (a lower_only covariance build into a
 // cleared buffer); otherwise it is zeroed here after the factorisation.
+// side (r5): a second stream for the early-inverse schedule (kernels_linalg.hip) -- the leading half's inverse and the top level's first
+// product run on it while `s` factors the trailing half; NULL: everything on `s`, one level after the other.  The caller need not
+// synchronise `side`: `s` waits for it before the call's last launches.
 void launch_cholesky_and_inverse(int N, double* A, long lda, double* Linv, long ldl, double* work, int* info,
-                                 hipStream_t s, bool upper_is_zero = false);
+                                 hipStream_t s, bool upper_is_zero = false, hipStream_t side = nullptr);
 size_t cholesky_work_doubles(int N);
+long early_inverse_split(int N);  // the early-inverse schedule's split row (0: the schedule does not apply at this N)
 // scratch of the two-level factorisation's step kernel (two N x 64 column-block buffers), in doubles
 size_t chol_scratch_doubles(int N);
 

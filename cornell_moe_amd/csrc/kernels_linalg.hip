@@ -9,6 +9,7 @@
 //    (gpp_linear_algebra.cpp:109-148) and turns every TriangularMatrixVectorSolve (:160-187) of the reference into a
 //    GEMM against L^-1, which is what lets the posterior solves run wide instead of as 1000 dependent steps.
 #include <algorithm>
+#include <functional>
 #include <cmath>
 #include <cstdlib>
 
@@ -1746,8 +1747,11 @@ namespace {
 // two triangular GEMMs per node -- and ALL nodes of a level go down in one batched launch of each (grid.z = node).  The
 // recursion this replaces issued them node by node: 248 launches at N = 8000, most of them 64 .. 256-wide products that are
 // pure launch latency (~2.5 of the inverse's 7 ms).  r3.
-void trtri_levels(const double* L, long lda, double* Linv, long ldl, int N, double* work, hipStream_t s) {
-  for (long B = NB; B < N; B *= 2) {
+// r5: levels B_lo <= B < B_hi only; phase 1 = only the first product of each (L21 X11 -> work), 2 = only the second (X21 = -X22 work),
+// 0 = both -- the early-inverse schedule of launch_cholesky_and_inverse runs a level's two products at different times.
+void trtri_levels(const double* L, long lda, double* Linv, long ldl, int N, double* work, hipStream_t s, long B_lo = NB,
+                  long B_hi = (long)1 << 40, int phase = 0) {
+  for (long B = B_lo; B < N && B < B_hi; B *= 2) {
     const int nn = (int)((N - B + 2 * B - 1) / (2 * B));  // nodes with a non-empty lower block: (2k + 1) B < N
     const int rows_max = (int)std::min<long>(B, N - B);
     const long ldw = rows_max;
@@ -1785,7 +1789,7 @@ void trtri_levels(const double* L, long lda, double* Linv, long ldl, int N, doub
       g1.sC = ldw * B;
       g1.m_total = (int)(N - B);
       g1.m_step = (int)(2 * B);
-      launch_gemm128<false, 0, true, 2, false>(g1, nn, s);
+      if (phase != 2) launch_gemm128<false, 0, true, 2, false>(g1, nn, s);
       g128::GemmArgs g2{};
       g2.A = g128::Operand{Linv + B + B * ldl, ldl, rows_max, rows_max, 1};  // X22: lower triangular, rows contiguous
       g2.B = g128::Operand{work, ldw, (int)B, rows_max, 1};                  // L21 X11: K contiguous
@@ -1799,17 +1803,19 @@ void trtri_levels(const double* L, long lda, double* Linv, long ldl, int N, doub
       g2.sC = 2 * B * (1 + ldl);
       g2.m_total = (int)(N - B);
       g2.m_step = (int)(2 * B);
-      launch_gemm128<false, 1, true, 0, true>(g2, nn, s);
+      if (phase != 1) launch_gemm128<false, 1, true, 0, true>(g2, nn, s);
       continue;
     }
     // work_k (rows x B) = L21 X11   (X11 lower triangular: MODE 3)
     const int pairc = (ct >= 16) ? 2 : 0;  // (column pairing: see mfma_gemm_kernel)
+    if (phase != 2)
     hipLaunchKernelGGL((mfma_gemm_kernel<3, false, 16>), dim3(pairc ? (ct + 1) / 2 : ct, rt, nn), dim3(256), 0, s, rows_max, (int)B,
                        (int)B, L + B, lda, (const double*)Linv, ldl, work, ldw, xmul, pairc, 2 * B * (1 + lda), 2 * B * (1 + ldl),
                        ldw * B, (int)(N - B), (int)(2 * B));
     // X21 = -X22 work_k   (X22 lower triangular: MODE 1, negated).  A single big node (the top levels) pairs row tile p with its
     // mirror so that every workgroup walks the same number of K steps (see mfma_gemm_kernel).
     const int pair = (nn == 1 && rt >= 16) ? 1 : 0;
+    if (phase != 1)
     hipLaunchKernelGGL((mfma_gemm_kernel<1, true, 16>), dim3(ct, pair ? (rt + 1) / 2 : rt, nn), dim3(256), 0, s, rows_max, (int)B,
                        rows_max, (const double*)(Linv + B + B * ldl), ldl, (const double*)work, ldw, Linv + B, ldl, xmul, pair,
                        2 * B * (1 + ldl), ldw * B, 2 * B * (1 + ldl), (int)(N - B), (int)(2 * B));
@@ -1817,12 +1823,34 @@ void trtri_levels(const double* L, long lda, double* Linv, long ldl, int N, doub
 }
 }  // namespace
 
-size_t cholesky_work_doubles(int N) {
-  size_t need = 1;  // the largest level of trtri_levels: nodes x (rows x B)
-  for (long B = NB; B < N; B *= 2) {
+namespace {
+size_t trtri_level_doubles(long N, long B_hi) {  // the largest level below B_hi of trtri_levels: nodes x (rows x B)
+  size_t need = 1;
+  for (long B = NB; B < N && B < B_hi; B *= 2) {
     const long nn = (N - B + 2 * B - 1) / (2 * B), rows_max = std::min<long>(B, N - B);
     need = std::max(need, (size_t)(nn * rows_max * B));
   }
+  return need;
+}
+}  // namespace
+
+// Early-inverse split (r5): H = the top level's block size (the largest 64 * 2^k below N) when the schedule applies -- H on an outer-block
+// boundary, and a trailing part worth a level of its own -- else 0.
+long early_inverse_split(int N) {
+  if (N < 2048) return 0;
+  long H = NB;
+  while (H * 2 < N) H *= 2;
+  if (H % kOuter != 0 || N - H < 4 * NB) return 0;
+  return H;
+}
+
+size_t cholesky_work_doubles(int N) {
+  size_t need = trtri_level_doubles(N, (long)1 << 40);
+  // the early-inverse schedule keeps four regions alive at once: the step kernel's column-block buffers | the levels below the top of
+  // the leading part | the same of the trailing part | the top level's L21 X11
+  const long H = early_inverse_split(N);
+  if (H > 0)
+    need = std::max(need, chol_scratch_doubles(N) + trtri_level_doubles(H, H) + trtri_level_doubles(N - H, H) + (size_t)(N - H) * H);
   return need;
 }
 
@@ -1839,7 +1867,8 @@ size_t cholesky_work_doubles(int N) {
 // `scratch`: chol_scratch_doubles(N) doubles for the step kernel's two column-block buffers (NULL: taken from the stream's pool).
 size_t chol_scratch_doubles(int N) { return (size_t)2 * (((size_t)N + 15) / 16 * 16) * NB; }
 
-void cholesky_factor_two_level(int N, double* A, long lda, double* Linv, long ldl, int* info, hipStream_t s, double* scratch) {
+void cholesky_factor_two_level(int N, double* A, long lda, double* Linv, long ldl, int* info, hipStream_t s, double* scratch,
+                               long hook_rows = 0, const std::function<void()>* hook = nullptr) {
   const char* fs_env = std::getenv("MOE_CHOL_FUSED_STEP");  // (read per call: the tests compare the two schedules)
   // beyond ~16 k rows the step kernel's recomputed panels cost more than the look-ahead buys (N = 26 000: 330 vs 299 ms -- the
   // rank-512 updates dominate there and the diagonal chain hides behind nothing anyway): the three-launch schedule
@@ -1892,6 +1921,8 @@ void cholesky_factor_two_level(int N, double* A, long lda, double* Linv, long ld
         ahead_done = true;
       }
     }
+    // (columns below hook_rows are final from here on -- this outer block's rank-512 update touches the trailing matrix only)
+    if (hook != nullptr && ko + wo == hook_rows) (*hook)();
     const int trailing = N - (ko + wo);
     if (trailing > 0) {
       const int t128 = (trailing + 127) / 128;
@@ -1911,10 +1942,41 @@ void cholesky_factor_two_level(int N, double* A, long lda, double* Linv, long ld
 }
 
 void launch_cholesky_and_inverse(int N, double* A, long lda, double* Linv, long ldl, double* work, int* info,
-                                 hipStream_t s, bool upper_is_zero) {
+                                 hipStream_t s, bool upper_is_zero, hipStream_t side) {
   MOE_HIP_CHECK(hipMemsetAsync(info, 0, sizeof(int), s));
   MOE_HIP_CHECK(hipMemsetAsync(Linv, 0, sizeof(double) * (size_t)ldl * N, s));
   const int nblk = (N + NB - 1) / NB;
+  // r5, early inverse: once the leading H columns are final -- the top level's block size, on an outer-block boundary -- the inverse of
+  // the leading H x H triangle (every level below the top) and the top level's first product L21 X11 run on `side` while `s` factors
+  // the trailing part, whose 64-column steps leave most of the chip idle; afterwards the trailing part's own levels and the top level's
+  // second product.  The same launches on the same data as the level-wise schedule (a level's batch is split by halves), so the
+  // result agrees with it to rounding (a level's kernel is picked from its batch).  MOE_CHOL_EARLY_INVERSE=0: off.
+  long H = 0;
+  bool early_top = true;
+  {
+    const char* ei = std::getenv("MOE_CHOL_EARLY_INVERSE");
+    if (side != nullptr && side != s && work != nullptr && !(ei && *ei == '0')) H = early_inverse_split(N);
+    early_top = !(ei && *ei == '1');  // (MOE_CHOL_EARLY_INVERSE=1: the leading half's levels only; A/B)
+  }
+  double* work_lead = work;
+  double* work_trail = work;
+  double* work_top = work;
+  hipEvent_t ev_cols = nullptr, ev_side = nullptr;
+  std::function<void()> hook;
+  if (H > 0) {
+    work_lead = work + chol_scratch_doubles(N);
+    work_trail = work_lead + trtri_level_doubles(H, H);
+    work_top = work_trail + trtri_level_doubles(N - H, H);
+    MOE_HIP_CHECK(hipEventCreateWithFlags(&ev_cols, hipEventDisableTiming));
+    MOE_HIP_CHECK(hipEventCreateWithFlags(&ev_side, hipEventDisableTiming));
+    hook = [&] {
+      MOE_HIP_CHECK(hipEventRecord(ev_cols, s));
+      MOE_HIP_CHECK(hipStreamWaitEvent(side, ev_cols, 0));
+      trtri_levels(A, lda, Linv, ldl, (int)H, work_lead, side);
+      if (early_top) trtri_levels(A, lda, Linv, ldl, N, work_top, side, H, 2 * H, 1);
+      MOE_HIP_CHECK(hipEventRecord(ev_side, side));
+    };
+  }
   const char* tl_env = std::getenv("MOE_CHOL_TWO_LEVEL_MIN");  // (read per call: tests force the two-level path at small N)
   // r3: 256 (was 2048) -- with one launch per 64-column step and the 25 us diagonal block the two-level schedule also wins at
   // BO-sized training sets: factor + inverse at N = 1000 0.9 instead of 1.7 ms (one-level: three launches per step and a
@@ -1923,8 +1985,10 @@ void launch_cholesky_and_inverse(int N, double* A, long lda, double* Linv, long 
   if (N >= two_level_min) {
     // (the inversion's workspace is idle during the factorisation: it lends the step kernel its column-block buffers)
     cholesky_factor_two_level(N, A, lda, Linv, ldl, info, s,
-                              (work != nullptr && cholesky_work_doubles(N) >= chol_scratch_doubles(N)) ? work : nullptr);
+                              (work != nullptr && cholesky_work_doubles(N) >= chol_scratch_doubles(N)) ? work : nullptr, H,
+                              H > 0 ? &hook : nullptr);
   } else {
+    H = 0;
     for (int b = 0; b < nblk; ++b) {
       const int k0 = b * NB, nb = std::min(NB, N - k0);
       hipLaunchKernelGGL(chol_diag_kernel, dim3(1), dim3(64), 0, s, A, lda, Linv, ldl, k0, nb, info);
@@ -1945,8 +2009,16 @@ void launch_cholesky_and_inverse(int N, double* A, long lda, double* Linv, long 
   // -- two triangular GEMMs per node, big and wide near the root, instead of one dependent block row after another.
   if (nblk > 1) {
     if (work == nullptr) throw Error(MOE_ERR_RUNTIME, "launch_cholesky_and_inverse: workspace missing");
-    trtri_levels(A, lda, Linv, ldl, N, work, s);
+    if (H > 0) {
+      trtri_levels(A + H + H * lda, lda, Linv + H + H * ldl, ldl, (int)(N - H), work_trail, s);
+      MOE_HIP_CHECK(hipStreamWaitEvent(s, ev_side, 0));
+      trtri_levels(A, lda, Linv, ldl, N, work_top, s, H, 2 * H, early_top ? 2 : 0);
+    } else {
+      trtri_levels(A, lda, Linv, ldl, N, work, s);
+    }
   }
+  if (ev_cols) (void)hipEventDestroy(ev_cols);
+  if (ev_side) (void)hipEventDestroy(ev_side);
   MOE_HIP_CHECK(hipGetLastError());
 }
 

@@ -330,6 +330,15 @@ typedef struct moe_comm {
  * per batched evaluation the optimiser issued, out[3 i ..] = kind (0 values, 1 gradients), items in the batch, wall milliseconds
  * (device work + exchange).  Returns the number of rows (out may be NULL / cap 0 to ask). */
 int moe_multistart_trace(double* out, int cap);
+
+/* Device-memory pool (r5).  The library keeps the device buffers, pinned staging buffers and streams its objects release (a GP of
+ * N = 8000 holds 1 GB; a fresh hipMalloc / hipStreamCreate per hyper-parameter sample costs a 14 ms build 3 ms) and hands them to the
+ * next object they fit.  Environment: MOE_POOL=0 switches it off; MOE_POOL_MAX_GB (default 48) bounds the device bytes held.
+ * moe_pool_held_bytes: device bytes the pool holds right now (not those in use by live objects).  moe_pool_trim: returns all of them
+ * (and the pinned buffers) to the runtime -- call it before handing the device to another library that needs the memory.  No
+ * counterpart in the reference (its GaussianProcess lives in host memory). */
+long long moe_pool_held_bytes(void);
+int moe_pool_trim(void);
 /* (diagnostic) the deal-and-exchange step alone, on synthetic items -- out[n][width], item i = seed + i + j / 1000; fail_item >= 0
  * makes its owner fail with MOE_ERR_SINGULAR, which every rank must then report.  No device work: the CPU tests run it over gloo. */
 int moe_debug_sharded_items(const moe_comm_t* comm, int n, int width, double seed, int fail_item, double* out, moe_error_t* err);

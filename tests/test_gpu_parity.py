@@ -609,6 +609,40 @@ def test_two_level_cholesky(api, monkeypatch):
     assert np.abs(K @ kiy - (y[:, 0] - mean)).max() <= 1e-8 * np.abs(y).max()
 
 
+def test_early_inverse_schedule(api, monkeypatch):
+    """r5: the build's early-inverse schedule (kernels_linalg.hip: launch_cholesky_and_inverse -- the leading half's inverse and the top
+    level's first product on a second stream while the trailing half is still being factored) against the level-wise schedule on one
+    stream (MOE_CHOL_EARLY_INVERSE=0): same factor bit for bit (the factorisation's launches do not change), the same inverse
+    application and posterior to round-off (a level's kernel is picked from its batch, which the schedule splits), bit-identical from
+    run to run (no race between the two streams), K (K^-1 y) = y - mean.  Sizes: the split on the first eligible outer-block boundary
+    with a short trailing part, a trailing part almost as long as the leading one, derivative observations."""
+    rng = np.random.default_rng(29)
+    for n, d, derivs in ((2400, 3, ()), (3900, 4, ()), (1100, 5, (0, 2))):
+        X = rng.uniform(size=(n, d))
+        g = len(derivs)
+        y = rng.uniform(size=(n, 1 + g))
+        hyper = [1.2] + list(0.25 + 0.1 * np.arange(d))
+        noise = [0.02] * (1 + g)
+        monkeypatch.setenv("MOE_CHOL_EARLY_INVERSE", "0")
+        a = api.DeviceGP(hyper, X, y, noise, derivatives=derivs)
+        monkeypatch.setenv("MOE_CHOL_EARLY_INVERSE", "1")
+        b = api.DeviceGP(hyper, X, y, noise, derivatives=derivs)
+        b2 = api.DeviceGP(hyper, X, y, noise, derivatives=derivs)
+        La, kiya, _ = a.get_factor()
+        Lb, kiyb, mean = b.get_factor()
+        Lb2, kiyb2, _ = b2.get_factor()
+        assert np.array_equal(La, Lb)
+        assert np.array_equal(Lb, Lb2) and np.array_equal(kiyb, kiyb2)
+        assert np.abs(kiya - kiyb).max() <= 1e-10 * np.abs(kiya).max()
+        q = rng.uniform(size=(5, d))
+        assert np.abs(a.mean(q) - b.mean(q)).max() <= 1e-11 and np.abs(a.variance(q) - b.variance(q)).max() <= 1e-11
+        assert np.array_equal(b.variance(q), b2.variance(q))
+        if g == 0:
+            K = b.mix_covariance(X) + noise[0] * np.eye(n)
+            assert np.abs(K @ kiyb - (y[:, 0] - mean)).max() <= 1e-8 * np.abs(y).max()
+        monkeypatch.delenv("MOE_CHOL_EARLY_INVERSE")
+
+
 def test_gemm128_products_of_the_build(api, monkeypatch):
     """r4: the 128-tile matrix-pipe kernel (csrc/gemm128.hpp) behind the inverse factor's two products per level and the rank-512
     update, forced at sizes where the 64-tile kernel is the default -- row / column counts that are no multiple of 128, K ranges that
