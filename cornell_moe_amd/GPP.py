@@ -754,6 +754,9 @@ def restarted_hyperparameter_optimization(optimizer_parameters, hyperparameter_d
 
 
 def run_cpp_tests():
-    """The reference runs its C++ unit-test suite here (gpp_python_test.cpp:307-314); this backend's tests are the pytest
-    suite under tests/ (returns 0 = no failures, like the reference on success)."""
-    return 0
+    """The reference runs its C++ unit-test suites here and returns the number of failures (gpp_python_test.cpp:60-314).  This backend
+    runs its device self-test (cornell_moe_amd/selftest.py): the same kinds of check -- finite-difference pings of every gradient entry
+    point, analytic vs Monte-Carlo EI, linear algebra, random sources, optimiser end-to-end -- on the GPU, each against an identity, not
+    against the reference (parity with the reference is the pytest suite under tests/).  Returns the number of failed checks."""
+    from . import selftest
+    return selftest.run()

@@ -242,3 +242,16 @@ def test_log_likelihood_wrapper_flow():
         fd = np.diff(cw.evaluate_log_likelihood_at_hyperparameter_list(ll, np.array([theta - e, theta + e])))[0] / (2 * e[k])
         assert abs(fd - g[k]) <= 1e-5 * max(1.0, abs(g[k]))
 
+
+
+def test_run_cpp_tests_is_a_real_self_test():
+    """GPP.run_cpp_tests() (r5): the reference returns its C++ suites' failure count (gpp_python_test.cpp:60-314); here the device
+    self-test (cornell_moe_amd/selftest.py: gradient pings, EI consistency, linear algebra, random sources, optimisers).  0 failures on
+    a healthy installation -- and a failing or raising check IS counted."""
+    from cornell_moe_amd import GPP, selftest
+    assert selftest.run(verbose=True) == 0
+    assert GPP.run_cpp_tests() == 0
+
+    def boom():
+        raise RuntimeError("x")
+    assert selftest.run(checks=(("always fails", lambda: False), ("raises", boom), ("passes", lambda: True))) == 2
