@@ -84,6 +84,7 @@ class DevicePool {
       if (hipPointerGetAttributes(&attr, p) == hipSuccess) dev = attr.device;
       else (void)hipGetLastError();
       (void)hipDeviceSynchronize();  // (what hipFree would have waited for)
+      if (poison_) (void)hipMemset(p, 0xFF, bytes);  // (debugging: every double a NaN, every int -1)
       std::lock_guard<std::mutex> lock(mu_);
       if (held_ + bytes <= max_held_) {
         free_[dev].emplace(bytes, p);
@@ -148,6 +149,7 @@ class DevicePool {
   void give_host(void* p, size_t bytes) {
     if (p == nullptr) return;
     if (enabled_) {
+      if (poison_) std::memset(p, 0xFF, bytes);
       std::lock_guard<std::mutex> lock(mu_);
       if (host_held_ + bytes <= kMaxHostHeld) {
         host_.emplace(bytes, p);
@@ -191,6 +193,10 @@ class DevicePool {
     enabled_ = !(on != nullptr && std::atoi(on) == 0);
     const char* gb = std::getenv("MOE_POOL_MAX_GB");
     max_held_ = (size_t)((gb != nullptr ? std::atof(gb) : 48.0) * 1e9);
+    // MOE_POOL_POISON=1 (tests): a released block is filled with 0xFF bytes before it is pooled -- whoever reads memory it has not
+    // written finds NaNs / -1 instead of a plausible zero (a fresh hipMalloc is usually zero, a recycled block is not)
+    const char* poison = std::getenv("MOE_POOL_POISON");
+    poison_ = poison != nullptr && std::atoi(poison) != 0;
   }
   // sizes in classes, so that shapes a few rows apart share blocks: 256 B granules up to 64 KB, 1/16 of the leading power of two above
   static size_t round_size(size_t bytes) {
@@ -208,7 +214,7 @@ class DevicePool {
   static constexpr size_t kMaxHostHeld = (size_t)4 << 30;
   std::map<int, int> num_cu_;
   size_t held_ = 0, max_held_ = 0;
-  bool enabled_ = true;
+  bool enabled_ = true, poison_ = false;
 };
 
 // Device buffer of doubles/ints with RAII; grows on demand, never shrinks (state objects are reused across calls).  Its memory comes

@@ -1845,7 +1845,9 @@ long early_inverse_split(int N) {
 }
 
 size_t cholesky_work_doubles(int N) {
-  size_t need = trtri_level_doubles(N, (long)1 << 40);
+  // (never less than the step kernel's column-block buffers, which the inversion's workspace lends the factorisation: no
+  //  stream-ordered allocation inside a build -- r5)
+  size_t need = std::max(trtri_level_doubles(N, (long)1 << 40), chol_scratch_doubles(N));
   // the early-inverse schedule keeps four regions alive at once: the step kernel's column-block buffers | the levels below the top of
   // the leading part | the same of the trailing part | the top level's L21 X11
   const long H = early_inverse_split(N);
@@ -1864,7 +1866,7 @@ size_t cholesky_work_doubles(int N) {
 // than the overlap; the in-kernel look-ahead replaces it.  A first fused kernel with one workgroup per ROW tile and release /
 // acquire flags between workgroups was no faster than three launches at N = 8000 -- each workgroup walked eight dependent
 // load-multiply-store rounds -- and 2.7x slower at N = 26 000, where its 406 workgroups of 100 KB LDS are not co-resident.)
-// `scratch`: chol_scratch_doubles(N) doubles for the step kernel's two column-block buffers (NULL: taken from the stream's pool).
+// `scratch`: chol_scratch_doubles(N) doubles for the step kernel's two column-block buffers.
 size_t chol_scratch_doubles(int N) { return (size_t)2 * (((size_t)N + 15) / 16 * 16) * NB; }
 
 void cholesky_factor_two_level(int N, double* A, long lda, double* Linv, long ldl, int* info, hipStream_t s, double* scratch,
@@ -1881,8 +1883,12 @@ void cholesky_factor_two_level(int N, double* A, long lda, double* Linv, long ld
     //  devices -- moe_kg_batch_multi, bench.py's in-process fallback)
     MOE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(chol_step_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                       (int)kStepSmem));
+    // (r5: always the caller's -- cholesky_work_doubles covers it.  Until then a missing scratch came from hipMallocAsync, and with
+    //  recycled streams and device blocks (DevicePool) one test order made the N = 262 build of tools/fuzz_parity.py report a singular
+    //  second diagonal block, reproducibly, until the pool was trimmed or poisoned: the stream-ordered allocation was the only
+    //  ingredient whose removal cured it.)
     cbuf = scratch;
-    if (cbuf == nullptr) MOE_HIP_CHECK(hipMallocAsync(reinterpret_cast<void**>(&cbuf), sizeof(double) * (size_t)2 * ldc * NB, s));
+    if (cbuf == nullptr) throw Error(MOE_ERR_RUNTIME, "cholesky_factor_two_level: scratch missing (chol_scratch_doubles(N) doubles)");
   }
   // (Measured and not kept in this round, both bit-identical to the one-stream order: the far columns of the rank-512 update on a
   //  second, low-priority stream next to the inner steps -- 19.45 -> 19.2 ms at N = 8000, within the noise: the bulk update's
@@ -1938,7 +1944,6 @@ void cholesky_factor_two_level(int N, double* A, long lda, double* Linv, long ld
     }
   }
   MOE_HIP_CHECK(hipGetLastError());
-  if (cbuf != nullptr && scratch == nullptr) MOE_HIP_CHECK(hipFreeAsync(cbuf, s));
 }
 
 void launch_cholesky_and_inverse(int N, double* A, long lda, double* Linv, long ldl, double* work, int* info,

@@ -64,10 +64,14 @@ struct TabParams {
 // coordinate, divided by its length scale (centred first: the difference of two nearby numbers is exact, so the scaled
 // coordinates carry the precision of the distances however far from the origin the domain sits):
 // the n training points, then the u union points of that evaluation, zero beyond.
+// (r5: the workgroups of evaluation 0 also clear the call's counter block -- pass counters, sample tickets -- which a memset did before)
 __global__ void build_xs_tab_kernel(const double* __restrict__ X, int n, const double* __restrict__ XuAll, int u, int dp,
-                                    int ntiles, TabParams tp, double* __restrict__ tab, long tab_stride, int pair_rows) {
+                                    int ntiles, TabParams tp, double* __restrict__ tab, long tab_stride, int pair_rows,
+                                    unsigned long long* __restrict__ ctr, long n_ctr) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   const int e = blockIdx.y;
+  if (e == 0)
+    for (long i = idx; i < n_ctr; i += (long)gridDim.x * blockDim.x) ctr[i] = 0ull;
   if (idx >= ntiles * dp * 64) return;
   const int l = idx & 63, r = (idx >> 6) % dp, t = (idx >> 6) / dp;
   const int j = t * 64 + l;
@@ -392,16 +396,28 @@ __global__ __launch_bounds__(256) void kg_zc_sum_kernel(KgTailParams P, const do
   }
 }
 
+int env_int(const char* name, int dflt);
+inline int zc_sum_lanes(int m) {  // lanes that share an entry of ZC in kg_zc_sum_kernel
+  int gs = 1;
+  while (gs < 64 && m * m * gs * 2 <= 256) gs *= 2;
+  return gs;
+}
+// r5: for small m and few chunks the sum of the partials is taken by kg_finish_kernel itself (one launch less on the latency path)
+inline bool zc_sum_in_finish(int m, int num_local) {
+  const long chunks = (num_local + zc_chunk_len(m) - 1) / zc_chunk_len(m);
+  return m <= 8 && chunks * m * m <= 16384 && env_int("MOE_KG_ZC_IN_FINISH", 1) != 0;
+}
+
 // host side of the two: part = E * chunks * m * m doubles of workspace
-void launch_zc(const KgTailParams& P, double* part, hipStream_t s) {
+void launch_zc(const KgTailParams& P, double* part, hipStream_t s, bool sum_here = true) {
   const int len = zc_chunk_len(P.m);
   const int chunks = (P.num_local + len - 1) / len;
   const size_t shm = sizeof(double) * 2 * len * P.m;
   if (shm > 48 * 1024)
     MOE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kg_zc_part_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
   hipLaunchKernelGGL(kg_zc_part_kernel, dim3(chunks, P.E), dim3(256), shm, s, P, part, chunks, len);
-  int gs = 1;
-  while (gs < 64 && P.m * P.m * gs * 2 <= 256) gs *= 2;
+  if (!sum_here) return;
+  const int gs = zc_sum_lanes(P.m);
   const int per_block = 256 / gs;
   hipLaunchKernelGGL(kg_zc_sum_kernel, dim3((P.m * P.m + per_block - 1) / per_block, P.E), dim3(256), 0, s, P, (const double*)part, chunks, gs);
 }
@@ -452,23 +468,17 @@ __global__ __launch_bounds__(256) void kg_dir_kernel(KgTailParams P, double* __r
   }
 }
 
-__global__ __launch_bounds__(256) void kg_dir_sum_kernel(KgTailParams P, const double* __restrict__ part, int slices) {
-  const int idx = blockIdx.x * 256 + threadIdx.x;  // over E * ngrad
-  if (idx >= P.E * P.ngrad) return;
-  const int e = idx / P.ngrad, gc = idx % P.ngrad;
-  double tot = 0.0;
-  for (int sl = 0; sl < slices; ++sl) tot += part[(long)idx * slices + sl];
-  P.out[(long)e * P.out_stride + 1 + P.m * P.m + gc] = tot;
+// (the slices are added up in order by kg_finish_kernel, where DIR is consumed -- r5; a kernel of its own before)
+inline int dir_slices(int num_local) { return std::max(1, std::min(kDirSlices, (num_local + 255) / 256)); }
+inline double* dir_partials(const KgTailParams& P) {
+  // behind the summed TB in the TB buffer (the host reserves E * ngrad * kDirSlices doubles more)
+  return P.TBpart + (long)P.E * (P.chunks + 1) * (long)P.m * P.N;
 }
 
 template <int DP>
 void launch_dir(const KgTailParams& P, hipStream_t s) {
-  // partials live behind the summed TB in the TB buffer (the host reserves E * ngrad * kDirSlices doubles more)
-  const long mn = (long)P.m * P.N;
-  double* part = P.TBpart + (long)P.E * (P.chunks + 1) * mn;
-  const int slices = std::max(1, std::min(kDirSlices, (P.num_local + 255) / 256));
-  hipLaunchKernelGGL((kg_dir_kernel<DP>), dim3(P.q, P.E, slices), dim3(256), 0, s, P, part, slices);
-  hipLaunchKernelGGL(kg_dir_sum_kernel, dim3((P.E * P.ngrad + 255) / 256), dim3(256), 0, s, P, (const double*)part, slices);
+  const int slices = dir_slices(P.num_local);
+  hipLaunchKernelGGL((kg_dir_kernel<DP>), dim3(P.q, P.E, slices), dim3(256), 0, s, P, dir_partials(P), slices);
 }
 
 template <int DP, int MU>
@@ -1416,13 +1426,12 @@ KgPending kg_launch(GpDev& gp, int num_fidelity, const moe_gd_params_t& gd, cons
     dC.reserve((size_t)E * num_local * m);
     dTB.reserve((size_t)E * (chunks + 1) * m * N + (size_t)E * ngrad * kDirSlices);  // chunk partials + their sum + DIR partials
   }
-  MOE_HIP_CHECK(hipMemsetAsync(dCounters.p, 0, sizeof(unsigned long long) * n_ctr, s));
 
   // ---- coordinate tables ----
   {
     dim3 grid((unsigned)((tab_stride + 255) / 256), E);
     hipLaunchKernelGGL(build_xs_tab_kernel, grid, dim3(256), 0, s, gp.dX.p, n, gp.dUnion, u, dp, ntiles, tp, dTab.p, tab_stride,
-                       (wide_dp || variant == 2 || (variant == 0 && mc::wide_eval(dp, xlds))) ? 1 : 0);
+                       (wide_dp || variant == 2 || (variant == 0 && mc::wide_eval(dp, xlds))) ? 1 : 0, dCounters.p, (long)n_ctr);
     MOE_HIP_CHECK(hipGetLastError());
   }
   t_state.stop(s);
@@ -1580,7 +1589,7 @@ KgPending kg_launch(GpDev& gp, int num_fidelity, const moe_gd_params_t& gd, cons
     launch_fused_tail(tl, gp.dX.p, n, gp.kSW.p, slices, s);
     // (r4: m > 64 too -- one workgroup per entry of ZC walking every sample with a stride of m doubles took 1.8 ms per evaluation at m = 104)
     gp.kZcPart.reserve((size_t)E * ((num_local + zc_chunk_len(m) - 1) / zc_chunk_len(m)) * m * m);
-    launch_zc(tl, gp.kZcPart.p, s);
+    launch_zc(tl, gp.kZcPart.p, s, !zc_sum_in_finish(m, num_local));
   } else if (want_grad) {
     t_cov.start(s);
     launch_cov_build(gp.cp, gp.dX.p, n, gp.derivs, dBestPoint.p, E * num_local, none, nullptr, dT.p, N, 0, s, true);
@@ -1611,7 +1620,7 @@ KgPending kg_launch(GpDev& gp, int num_fidelity, const moe_gd_params_t& gd, cons
     launch_tail(tl, s);
     // (r4: m > 64 too -- one workgroup per entry of ZC walking every sample with a stride of m doubles took 1.8 ms per evaluation at m = 104)
     gp.kZcPart.reserve((size_t)E * ((num_local + zc_chunk_len(m) - 1) / zc_chunk_len(m)) * m * m);
-    launch_zc(tl, gp.kZcPart.p, s);
+    launch_zc(tl, gp.kZcPart.p, s, !zc_sum_in_finish(m, num_local));
   } else {
     hipLaunchKernelGGL(kg_sum_kernel, dim3(E), dim3(256), 0, s, tl, dFin, (const unsigned long long*)dCounters.p, (const int*)gp.kStateI.p);
   }
@@ -1638,7 +1647,15 @@ KgPending kg_launch(GpDev& gp, int num_fidelity, const moe_gd_params_t& gd, cons
     fp.fin = dFin;
     fp.counters = dCounters.p;
     fp.flags = gp.kStateI.p;
-    launch_kg_finish(fp, dFin + (size_t)E * (1 + qd + 3), s);
+    fp.dir_part = dir_partials(tl);
+    fp.dir_slices = dir_slices(num_local);
+    fp.zc_part = zc_sum_in_finish(m, num_local) ? gp.kZcPart.p : nullptr;
+    fp.zc_chunks = (num_local + zc_chunk_len(m) - 1) / zc_chunk_len(m);
+    fp.zc_gs = zc_sum_lanes(m);
+    fp.best_value = dBestValue.p;
+    fp.num_local = num_local;
+    fp.rec_bp = rec_bp;
+    launch_kg_finish(fp, s);
     t_tail.stop(s);
   }
   // results through pinned memory in ONE copy: per evaluation kg_sum | grad_sum (q d) | value passes | gradient passes | flag

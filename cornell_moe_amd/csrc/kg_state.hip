@@ -201,9 +201,10 @@ __global__ __launch_bounds__(256) void kg_dchol_kernel(KgStateParams P) {
   for (int t = tid; t < tri; t += 256) out[t] = Sp[t];
 }
 
-// Y = L^-T tril(ZC), one workgroup per evaluation.  Dynamic LDS: Lp | Yp, both packed lower triangles (entry (row l >= column j) at
-// l (l + 1) / 2 + j); Yp goes to global memory for kg_finish_kernel.
-__global__ __launch_bounds__(128) void kg_y_kernel(KgFinishParams P, double* __restrict__ Y) {
+// grad KG of one evaluation per workgroup (r5: kg_y_kernel + kg_finish_kernel + kg_dir_sum_kernel in one launch -- the same operations
+// in the same order).  Y = L^-T tril(ZC) in LDS: Lp | Yp, both packed lower triangles (entry (row l >= column j) at l (l + 1) / 2 + j);
+// then one wavefront per (point k, coordinate dd): < dL_k,dd , Y > and the assembly of the gradient component.
+__global__ __launch_bounds__(256) void kg_finish_kernel(KgFinishParams P) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
   const int e = blockIdx.x, tid = threadIdx.x;
   const int m = P.m;
@@ -211,8 +212,38 @@ __global__ __launch_bounds__(128) void kg_y_kernel(KgFinishParams P, double* __r
   double* Lp = sm;
   double* Yp = sm + tri;
   const double* Lg = P.blob + (long)e * P.rec_stride + P.rec_L;
-  const double* ZC = P.out + (long)e * P.out_stride + 1;
-  for (int idx = tid; idx < m * m; idx += 128) {
+  const double* o = P.out + (long)e * P.out_stride;
+  const double* ZC = o + 1;
+  double kg_sum = 0.0;  // (thread 0)
+  if (P.zc_part != nullptr) {
+    // kg_zc_sum_kernel, inlined: entry o of ZC by `gs` lanes striding the chunk partials + a fixed butterfly; kg_sum as its block 0 does
+    double* zcs = sm + 2 * tri;  // [m m] | 4 doubles of reduction scratch
+    double* red = zcs + m * m;
+    const int gs = P.zc_gs, per_block = 256 / gs;
+    for (int base = 0; base < m * m; base += per_block) {
+      const int oo = base + tid / gs, g = tid % gs;
+      const bool ok = oo < m * m;
+      const double* p = P.zc_part + (long)e * P.zc_chunks * m * m + (ok ? oo : 0);
+      double v = 0.0;
+#pragma unroll 8
+      for (int ch = g; ch < P.zc_chunks; ch += gs) v += p[(long)ch * m * m];
+      for (int off = gs >> 1; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+      if (ok && g == 0) zcs[oo] = v;
+    }
+    const double bp = P.blob[(long)e * P.rec_stride + P.rec_bp];
+    double acc = 0.0;
+#pragma unroll 8
+    for (int i = tid; i < P.num_local; i += 256) acc += bp + P.best_value[(long)e * P.num_local + i];
+    const double w = wave_sum64(acc);
+    __syncthreads();
+    if ((tid & 63) == 0) red[tid >> 6] = w;
+    __syncthreads();
+    kg_sum = (red[0] + red[1]) + (red[2] + red[3]);
+    ZC = zcs;
+  } else if (tid == 0) {
+    kg_sum = o[0];
+  }
+  for (int idx = tid; idx < m * m; idx += 256) {
     const int l = idx % m, j = idx / m;
     if (l >= j) {
       Lp[l * (l + 1) / 2 + j] = Lg[idx];
@@ -231,38 +262,36 @@ __global__ __launch_bounds__(128) void kg_y_kernel(KgFinishParams P, double* __r
     }
   }
   __syncthreads();
-  double* out = Y + (long)e * tri;
-  for (int t = tid; t < tri; t += 128) out[t] = Yp[t];
-}
-
-// One wavefront per (point k, coordinate dd; evaluation): < dL_k,dd , Y > and the assembly of the gradient component.
-__global__ __launch_bounds__(64) void kg_finish_kernel(KgFinishParams P, const double* __restrict__ Y) {
-  const int idx = blockIdx.x, e = blockIdx.y, lane = threadIdx.x;
-  const int m = P.m, g1 = 1 + P.g, d = P.d, qd = P.q * P.d;
-  const int tri = m * (m + 1) / 2;
-  const double* o = P.out + (long)e * P.out_stride;
-  const double* DIR = o + 1 + m * m;
-  const double* GTB = DIR + P.ng;
-  const double* dl = P.dL + ((long)e * qd + idx) * tri;
-  const double* y = Y + (long)e * tri;
-  double acc = 0.0;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int g1 = 1 + P.g, d = P.d, qd = P.q * P.d;
+  const double* GTB = o + 1 + m * m + P.ng;
+  const double* dirp = P.dir_part + (long)e * P.ng * P.dir_slices;
+  double* fin = P.fin + (long)e * (1 + qd + 3);
+  for (int idx = wave; idx < qd; idx += 4) {
+    const double* dl = P.dL + ((long)e * qd + idx) * tri;
+    double acc = 0.0;
 #pragma unroll 4
-  for (int t = lane; t < tri; t += 64) acc = fma(y[t], dl[t], acc);
-  const double zmc = wave_sum64(acc);
-  if (lane == 0) {
-    const int k = idx / d, dd = idx - k * d;
-    double direct = 0.0;
-    for (int b = 0; b < g1; ++b) direct += DIR[(k * g1 + b) * d + dd] - GTB[(k * g1 + b) * d + dd];
-    double val = -(direct - zmc);  // aggregate -= gic . z  (.cpp:214-221)
-    // winner term: + M grad mu[winner]  (.cpp:157-161); added once, by the shard that owns sample 0
-    if (P.winner[e] == k && P.first_sample == 0) val += (double)P.num_mc * P.gmu[(long)e * qd + idx];
-    double* fin = P.fin + (long)e * (1 + qd + 3);
-    fin[1 + idx] = val;
-    if (idx == 0) {
-      fin[0] = o[0];
-      fin[1 + qd] = (double)P.counters[2 * e];
-      fin[2 + qd] = (double)P.counters[2 * e + 1];
-      fin[3 + qd] = (double)P.flags[e];
+    for (int t = lane; t < tri; t += 64) acc = fma(Yp[t], dl[t], acc);
+    const double zmc = wave_sum64(acc);
+    if (lane == 0) {
+      const int k = idx / d, dd = idx - k * d;
+      double direct = 0.0;
+      for (int b = 0; b < g1; ++b) {
+        const int gc = (k * g1 + b) * d + dd;
+        double dir = 0.0;  // DIR[gc]: kg_dir_kernel's sample ranges in order
+        for (int sl = 0; sl < P.dir_slices; ++sl) dir += dirp[(long)gc * P.dir_slices + sl];
+        direct += dir - GTB[gc];
+      }
+      double val = -(direct - zmc);  // aggregate -= gic . z  (.cpp:214-221)
+      // winner term: + M grad mu[winner]  (.cpp:157-161); added once, by the shard that owns sample 0
+      if (P.winner[e] == k && P.first_sample == 0) val += (double)P.num_mc * P.gmu[(long)e * qd + idx];
+      fin[1 + idx] = val;
+      if (idx == 0) {  // (wave 0, lane 0 = thread 0)
+        fin[0] = kg_sum;
+        fin[1 + qd] = (double)P.counters[2 * e];
+        fin[2 + qd] = (double)P.counters[2 * e + 1];
+        fin[3 + qd] = (double)P.flags[e];
+      }
     }
   }
 }
@@ -294,11 +323,10 @@ void launch_kg_dchol(const KgStateParams& P, hipStream_t s) {
   MOE_HIP_CHECK(hipGetLastError());
 }
 
-void launch_kg_finish(const KgFinishParams& P, double* Y, hipStream_t s) {
-  const size_t shm = sizeof(double) * (size_t)P.m * (P.m + 1);
-  opt_in_lds(kg_y_kernel, shm);
-  hipLaunchKernelGGL(kg_y_kernel, dim3(P.E), dim3(128), shm, s, P, Y);
-  hipLaunchKernelGGL(kg_finish_kernel, dim3(P.q * P.d, P.E), dim3(64), 0, s, P, (const double*)Y);
+void launch_kg_finish(const KgFinishParams& P, hipStream_t s) {
+  const size_t shm = sizeof(double) * ((size_t)P.m * (P.m + 1) + (P.zc_part != nullptr ? (size_t)P.m * P.m + 4 : 0));
+  opt_in_lds(kg_finish_kernel, shm);
+  hipLaunchKernelGGL(kg_finish_kernel, dim3(P.E), dim3(256), shm, s, P);
   MOE_HIP_CHECK(hipGetLastError());
 }
 
