@@ -46,9 +46,12 @@ def _run(env_extra):
 def test_pooled_buffers_give_the_results_of_fresh_ones():
     pooled, held = _run({"MOE_POOL": "1"})
     fresh, held_off = _run({"MOE_POOL": "0"})
+    # MOE_POOL_POISON=1: a released block is filled with 0xFF bytes (NaN doubles, -1 ints) before it is pooled
+    poisoned, _ = _run({"MOE_POOL": "1", "MOE_POOL_POISON": "1"})
     assert held > 0 and held_off == 0
-    # build 0 on fresh memory, build 1 on the blocks build 0 released, build 2 after a trim: all the same, and the same without the pool
-    assert pooled[0] == pooled[1] == pooled[2] == fresh[0] == fresh[1] == fresh[2]
+    # build 0 on fresh memory, build 1 on the blocks build 0 released, build 2 after a trim: all the same, the same without the pool, and
+    # the same when every recycled block comes back as NaNs
+    assert pooled[0] == pooled[1] == pooled[2] == fresh[0] == fresh[1] == fresh[2] == poisoned[0] == poisoned[1] == poisoned[2]
 
 
 def test_pool_accounting_and_trim():
