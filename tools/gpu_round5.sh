@@ -10,6 +10,9 @@ mkdir -p $O
 export TMPDIR=/tmp
 timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | tail -6 > $O/${TAG}_pytest_gpu.txt
 timeout 120 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2 >> $O/${TAG}_pytest_gpu.txt
+# the same suite with every recycled device / pinned block poisoned (0xFF bytes) before it is pooled
+MOE_POOL_POISON=1 timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | tail -3 > $O/${TAG}_pytest_gpu_poisoned.txt
+timeout 300 python -c "from cornell_moe_amd import selftest; print('failures', selftest.run(verbose=True))" > $O/${TAG}_selftest.txt 2>&1
 timeout 900 python bench.py > $O/${TAG}_bench.json 2> $O/${TAG}_bench.err
 timeout 900 python bench.py --config C5 --steps 6 --warmup 2 --no-cpu-baseline > $O/${TAG}_c5_bench.json 2> $O/${TAG}_c5_bench.err
 timeout 900 python bench.py --config C5 --derivs 12 --steps 3 --warmup 1 --no-cpu-baseline > $O/${TAG}_c5g12_bench.json 2> $O/${TAG}_c5g12_bench.err
@@ -42,6 +45,9 @@ timeout 300 python tools/dkg_sweep.py > $O/${TAG}_dkg_sweep.txt 2>&1
 timeout 200 python tools/chol_time.py > $O/${TAG}_chol_time.txt 2>&1
 timeout 200 python tools/ll_time.py > $O/${TAG}_ll_time.txt 2>&1
 bash tools/kg1_timeline.sh > $O/${TAG}_kg1_timeline.txt 2>&1
+bash tools/build_timeline.sh 3 > $O/${TAG}_build_timeline.txt 2>&1
+timeout 300 python tools/build_sweep.py 4000 8000 16000 > $O/${TAG}_build_sweep.txt 2>&1
 tail -3 $O/${TAG}_pytest_gpu.txt; cut -c1-300 $O/${TAG}_bench.json; tail -3 $O/${TAG}_bench.err; head -5 $O/${TAG}_bench_kernel_stats.csv
-cat $O/${TAG}_kxx_N8000.txt $O/${TAG}_kxx_N26000.txt $O/${TAG}_latency.txt $O/${TAG}_chol_time.txt $O/${TAG}_ll_time.txt
+cat $O/${TAG}_pytest_gpu_poisoned.txt $O/${TAG}_selftest.txt
+cat $O/${TAG}_kxx_N8000.txt $O/${TAG}_kxx_N26000.txt $O/${TAG}_latency.txt $O/${TAG}_chol_time.txt $O/${TAG}_ll_time.txt $O/${TAG}_build_sweep.txt
 for f in c5 c5g12 suggest suggest_c3 suggest_w8; do echo "== $f"; cut -c1-400 $O/${TAG}_${f}_bench.json; done
