@@ -1655,7 +1655,7 @@ KgPending kg_launch(GpDev& gp, int num_fidelity, const moe_gd_params_t& gd, cons
     fp.best_value = dBestValue.p;
     fp.num_local = num_local;
     fp.rec_bp = rec_bp;
-    launch_kg_finish(fp, s);
+    launch_kg_finish(fp, dFin + (size_t)E * (1 + qd + 3), s);
     t_tail.stop(s);
   }
   // results through pinned memory in ONE copy: per evaluation kg_sum | grad_sum (q d) | value passes | gradient passes | flag

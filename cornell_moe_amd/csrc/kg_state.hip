@@ -201,10 +201,9 @@ __global__ __launch_bounds__(256) void kg_dchol_kernel(KgStateParams P) {
   for (int t = tid; t < tri; t += 256) out[t] = Sp[t];
 }
 
-// grad KG of one evaluation per workgroup (r5: kg_y_kernel + kg_finish_kernel + kg_dir_sum_kernel in one launch -- the same operations
-// in the same order).  Y = L^-T tril(ZC) in LDS: Lp | Yp, both packed lower triangles (entry (row l >= column j) at l (l + 1) / 2 + j);
-// then one wavefront per (point k, coordinate dd): < dL_k,dd , Y > and the assembly of the gradient component.
-__global__ __launch_bounds__(256) void kg_finish_kernel(KgFinishParams P) {
+// Y = L^-T tril(ZC), one workgroup per evaluation.  Dynamic LDS: Lp | Yp, both packed lower triangles (entry (row l >= column j) at
+// l (l + 1) / 2 + j); Yp goes to global memory for kg_finish_kernel.  (general m; small m: kg_finish_small_kernel)
+__global__ __launch_bounds__(128) void kg_y_kernel(KgFinishParams P, double* __restrict__ Y) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
   const int e = blockIdx.x, tid = threadIdx.x;
   const int m = P.m;
@@ -212,38 +211,8 @@ __global__ __launch_bounds__(256) void kg_finish_kernel(KgFinishParams P) {
   double* Lp = sm;
   double* Yp = sm + tri;
   const double* Lg = P.blob + (long)e * P.rec_stride + P.rec_L;
-  const double* o = P.out + (long)e * P.out_stride;
-  const double* ZC = o + 1;
-  double kg_sum = 0.0;  // (thread 0)
-  if (P.zc_part != nullptr) {
-    // kg_zc_sum_kernel, inlined: entry o of ZC by `gs` lanes striding the chunk partials + a fixed butterfly; kg_sum as its block 0 does
-    double* zcs = sm + 2 * tri;  // [m m] | 4 doubles of reduction scratch
-    double* red = zcs + m * m;
-    const int gs = P.zc_gs, per_block = 256 / gs;
-    for (int base = 0; base < m * m; base += per_block) {
-      const int oo = base + tid / gs, g = tid % gs;
-      const bool ok = oo < m * m;
-      const double* p = P.zc_part + (long)e * P.zc_chunks * m * m + (ok ? oo : 0);
-      double v = 0.0;
-#pragma unroll 8
-      for (int ch = g; ch < P.zc_chunks; ch += gs) v += p[(long)ch * m * m];
-      for (int off = gs >> 1; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-      if (ok && g == 0) zcs[oo] = v;
-    }
-    const double bp = P.blob[(long)e * P.rec_stride + P.rec_bp];
-    double acc = 0.0;
-#pragma unroll 8
-    for (int i = tid; i < P.num_local; i += 256) acc += bp + P.best_value[(long)e * P.num_local + i];
-    const double w = wave_sum64(acc);
-    __syncthreads();
-    if ((tid & 63) == 0) red[tid >> 6] = w;
-    __syncthreads();
-    kg_sum = (red[0] + red[1]) + (red[2] + red[3]);
-    ZC = zcs;
-  } else if (tid == 0) {
-    kg_sum = o[0];
-  }
-  for (int idx = tid; idx < m * m; idx += 256) {
+  const double* ZC = P.out + (long)e * P.out_stride + 1;
+  for (int idx = tid; idx < m * m; idx += 128) {
     const int l = idx % m, j = idx / m;
     if (l >= j) {
       Lp[l * (l + 1) / 2 + j] = Lg[idx];
@@ -262,38 +231,122 @@ __global__ __launch_bounds__(256) void kg_finish_kernel(KgFinishParams P) {
     }
   }
   __syncthreads();
-  const int lane = tid & 63, wave = tid >> 6;
-  const int g1 = 1 + P.g, d = P.d, qd = P.q * P.d;
-  const double* GTB = o + 1 + m * m + P.ng;
-  const double* dirp = P.dir_part + (long)e * P.ng * P.dir_slices;
+  double* out = Y + (long)e * tri;
+  for (int t = tid; t < tri; t += 128) out[t] = Yp[t];
+}
+
+// DIR[gc] of evaluation e: kg_dir_kernel's partial sums over sample ranges, added up in slice order (r5: where DIR is consumed; a
+// kernel of its own before).  The loads go out together, one slice per lane; lane 0 adds them in order.  Valid in lane 0; at most 64
+// slices (kDirSlices = 32).
+__device__ __forceinline__ double dir_sum(const KgFinishParams& P, int e, int gc, int lane) {
+  const double* p = P.dir_part + ((long)e * P.ng + gc) * P.dir_slices;
+  const double mine = (lane < P.dir_slices) ? p[lane] : 0.0;
+  double tot = 0.0;
+  for (int sl = 0; sl < P.dir_slices; ++sl) tot += __shfl(mine, sl, 64);
+  return tot;
+}
+
+// The gradient component of (point k, coordinate dd) from < dL_k,dd , Y >, DIR - GTB and the winner's grad mu; lane 0 writes it.
+__device__ __forceinline__ void finish_component(const KgFinishParams& P, int e, int idx, int lane, double zmc, double kg_sum) {
+  const int m = P.m, g1 = 1 + P.g, d = P.d, qd = P.q * P.d;
+  const double* GTB = P.out + (long)e * P.out_stride + 1 + m * m + P.ng;
+  const int k = idx / d, dd = idx - k * d;
+  double direct = 0.0;
+  for (int b = 0; b < g1; ++b) {
+    const int gc = (k * g1 + b) * d + dd;
+    const double dir = dir_sum(P, e, gc, lane);
+    direct += dir - GTB[gc];
+  }
+  if (lane != 0) return;
+  double val = -(direct - zmc);  // aggregate -= gic . z  (.cpp:214-221)
+  // winner term: + M grad mu[winner]  (.cpp:157-161); added once, by the shard that owns sample 0
+  if (P.winner[e] == k && P.first_sample == 0) val += (double)P.num_mc * P.gmu[(long)e * qd + idx];
   double* fin = P.fin + (long)e * (1 + qd + 3);
-  for (int idx = wave; idx < qd; idx += 4) {
-    const double* dl = P.dL + ((long)e * qd + idx) * tri;
-    double acc = 0.0;
+  fin[1 + idx] = val;
+  if (idx == 0) {
+    fin[0] = kg_sum;
+    fin[1 + qd] = (double)P.counters[2 * e];
+    fin[2 + qd] = (double)P.counters[2 * e + 1];
+    fin[3 + qd] = (double)P.flags[e];
+  }
+}
+
+// One wavefront per (point k, coordinate dd; evaluation): < dL_k,dd , Y > and the assembly of the gradient component.
+__global__ __launch_bounds__(64) void kg_finish_kernel(KgFinishParams P, const double* __restrict__ Y) {
+  const int idx = blockIdx.x, e = blockIdx.y, lane = threadIdx.x;
+  const int m = P.m, qd = P.q * P.d;
+  const int tri = m * (m + 1) / 2;
+  const double* dl = P.dL + ((long)e * qd + idx) * tri;
+  const double* y = Y + (long)e * tri;
+  double acc = 0.0;
 #pragma unroll 4
-    for (int t = lane; t < tri; t += 64) acc = fma(Yp[t], dl[t], acc);
-    const double zmc = wave_sum64(acc);
-    if (lane == 0) {
-      const int k = idx / d, dd = idx - k * d;
-      double direct = 0.0;
-      for (int b = 0; b < g1; ++b) {
-        const int gc = (k * g1 + b) * d + dd;
-        double dir = 0.0;  // DIR[gc]: kg_dir_kernel's sample ranges in order
-        for (int sl = 0; sl < P.dir_slices; ++sl) dir += dirp[(long)gc * P.dir_slices + sl];
-        direct += dir - GTB[gc];
-      }
-      double val = -(direct - zmc);  // aggregate -= gic . z  (.cpp:214-221)
-      // winner term: + M grad mu[winner]  (.cpp:157-161); added once, by the shard that owns sample 0
-      if (P.winner[e] == k && P.first_sample == 0) val += (double)P.num_mc * P.gmu[(long)e * qd + idx];
-      fin[1 + idx] = val;
-      if (idx == 0) {  // (wave 0, lane 0 = thread 0)
-        fin[0] = kg_sum;
-        fin[1 + qd] = (double)P.counters[2 * e];
-        fin[2 + qd] = (double)P.counters[2 * e + 1];
-        fin[3 + qd] = (double)P.flags[e];
-      }
+  for (int t = lane; t < tri; t += 64) acc = fma(y[t], dl[t], acc);
+  const double zmc = wave_sum64(acc);
+  finish_component(P, e, idx, lane, zmc, P.out[(long)e * P.out_stride]);
+}
+
+// Small m (<= 8) and few chunk partials -- the latency path of a q-KG call (r5): ONE launch, a 256-thread workgroup per (component,
+// evaluation), each forming what it needs itself instead of waiting for three more kernels: ZC from kg_zc_part_kernel's chunk partials
+// (kg_zc_sum_kernel's own scheme: gs lanes per entry striding the chunks + a fixed butterfly), Y = L^-T tril(ZC) in LDS (kg_y_kernel's
+// substitution), its own < dL, Y >, DIR - GTB term; workgroup 0 of an evaluation also adds up kg_sum as kg_zc_sum_kernel's block 0 does.
+// The same operations in the same order as the separate kernels: the same bits.
+__global__ __launch_bounds__(256) void kg_finish_small_kernel(KgFinishParams P) {
+  __shared__ double zcs[64], Lp[36], Yp[36], red[4];
+  const int idx = blockIdx.x, e = blockIdx.y, tid = threadIdx.x;
+  const int m = P.m, qd = P.q * P.d;
+  const int tri = m * (m + 1) / 2;
+  {
+    const int gs = P.zc_gs, per_block = 256 / gs;
+    for (int base = 0; base < m * m; base += per_block) {
+      const int oo = base + tid / gs, g = tid % gs;
+      const bool ok = oo < m * m;
+      const double* p = P.zc_part + (long)e * P.zc_chunks * m * m + (ok ? oo : 0);
+      double v = 0.0;
+#pragma unroll 8
+      for (int ch = g; ch < P.zc_chunks; ch += gs) v += p[(long)ch * m * m];
+      for (int off = gs >> 1; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+      if (ok && g == 0) zcs[oo] = v;
     }
   }
+  double kg_sum = 0.0;
+  if (idx == 0) {  // (uniform over the workgroup)
+    const double bp = P.blob[(long)e * P.rec_stride + P.rec_bp];
+    double acc = 0.0;
+#pragma unroll 8
+    for (int i = tid; i < P.num_local; i += 256) acc += bp + P.best_value[(long)e * P.num_local + i];
+    const double w = wave_sum64(acc);
+    __syncthreads();
+    if ((tid & 63) == 0) red[tid >> 6] = w;
+    __syncthreads();
+    kg_sum = (red[0] + red[1]) + (red[2] + red[3]);
+  }
+  __syncthreads();
+  const double* Lg = P.blob + (long)e * P.rec_stride + P.rec_L;
+  if (tid < m * m) {
+    const int l = tid % m, j = tid / m;
+    if (l >= j) {
+      Lp[l * (l + 1) / 2 + j] = Lg[tid];
+      Yp[l * (l + 1) / 2 + j] = zcs[tid];
+    }
+  }
+  __syncthreads();
+  for (int rr = m - 1; rr >= 0; --rr) {
+    if (tid <= rr) {
+      double t = Yp[rr * (rr + 1) / 2 + tid];
+#pragma unroll 4
+      for (int i = m - 1; i > rr; --i) t = fma(-Lp[i * (i + 1) / 2 + rr], Yp[i * (i + 1) / 2 + tid], t);
+      Yp[rr * (rr + 1) / 2 + tid] = t / Lp[rr * (rr + 1) / 2 + rr];
+    }
+  }
+  __syncthreads();
+  if (tid >= 64) return;
+  const int lane = tid;
+  const double* dl = P.dL + ((long)e * qd + idx) * tri;
+  double acc = 0.0;
+#pragma unroll 4
+  for (int t = lane; t < tri; t += 64) acc = fma(Yp[t], dl[t], acc);
+  const double zmc = wave_sum64(acc);
+  finish_component(P, e, idx, lane, zmc, kg_sum);
 }
 
 template <class K>
@@ -323,10 +376,15 @@ void launch_kg_dchol(const KgStateParams& P, hipStream_t s) {
   MOE_HIP_CHECK(hipGetLastError());
 }
 
-void launch_kg_finish(const KgFinishParams& P, hipStream_t s) {
-  const size_t shm = sizeof(double) * ((size_t)P.m * (P.m + 1) + (P.zc_part != nullptr ? (size_t)P.m * P.m + 4 : 0));
-  opt_in_lds(kg_finish_kernel, shm);
-  hipLaunchKernelGGL(kg_finish_kernel, dim3(P.E), dim3(256), shm, s, P);
+void launch_kg_finish(const KgFinishParams& P, double* Y, hipStream_t s) {
+  if (P.zc_part != nullptr) {  // (m <= 8: the caller did not launch kg_zc_sum_kernel)
+    hipLaunchKernelGGL(kg_finish_small_kernel, dim3(P.q * P.d, P.E), dim3(256), 0, s, P);
+  } else {
+    const size_t shm = sizeof(double) * (size_t)P.m * (P.m + 1);
+    opt_in_lds(kg_y_kernel, shm);
+    hipLaunchKernelGGL(kg_y_kernel, dim3(P.E), dim3(128), shm, s, P, Y);
+    hipLaunchKernelGGL(kg_finish_kernel, dim3(P.q * P.d, P.E), dim3(64), 0, s, P, (const double*)Y);
+  }
   MOE_HIP_CHECK(hipGetLastError());
 }
 

@@ -53,17 +53,17 @@ struct KgFinishParams {
   // consumed (a kernel of its own did that before)
   const double* dir_part;
   int dir_slices;
-  // r5, small m only (zc_part != NULL): ZC and kg_sum are formed here from kg_zc_part_kernel's chunk partials and the samples' best
-  // values, in kg_zc_sum_kernel's own order (gs lanes per entry striding the chunks, a fixed butterfly; 256-thread block sum) -- that
-  // kernel is then not launched.  Otherwise both are read from `out`.
+  // r5, m <= 8 only (zc_part != NULL): ZC and kg_sum are formed by the finish kernel from kg_zc_part_kernel's chunk partials and the
+  // samples' best values, in kg_zc_sum_kernel's own order (gs lanes per entry striding the chunks, a fixed butterfly; 256-thread block
+  // sum) -- that kernel is then not launched.  Otherwise both are read from `out`.
   const double* zc_part;
   int zc_chunks, zc_gs;
   const double* best_value;  // [E][num_local]
   int num_local, rec_bp;
 };
 // grad KG from the sample sums: < L^-1 dL, ZC > taken as < dL, L^-T tril(ZC) > (one m-column back substitution per evaluation
-// instead of q d m forward ones), the DIR - GTB terms and the winner's grad mu.  One kernel, one workgroup per evaluation (r5; two
-// kernels and a round trip of Y through global memory before).
-void launch_kg_finish(const KgFinishParams& P, hipStream_t s);
+// instead of q d m forward ones), the DIR - GTB terms and the winner's grad mu.  Y: E m (m + 1) / 2 doubles of workspace.  Two kernels
+// (Y, then a wavefront per gradient component); for m <= 8 with zc_part set ONE, which also takes kg_zc_sum_kernel's place (r5).
+void launch_kg_finish(const KgFinishParams& P, double* Y, hipStream_t s);
 
 }  // namespace moe
