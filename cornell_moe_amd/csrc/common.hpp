@@ -83,8 +83,12 @@ class DevicePool {
       int dev = 0;
       if (hipPointerGetAttributes(&attr, p) == hipSuccess) dev = attr.device;
       else (void)hipGetLastError();
-      (void)hipDeviceSynchronize();  // (what hipFree would have waited for)
+      int cur = dev;
+      (void)hipGetDevice(&cur);
+      if (cur != dev) (void)hipSetDevice(dev);  // (a block of another device than the calling thread's current one)
+      (void)hipDeviceSynchronize();             // (what hipFree would have waited for)
       if (poison_) (void)hipMemset(p, 0xFF, bytes);  // (debugging: every double a NaN, every int -1)
+      if (cur != dev) (void)hipSetDevice(cur);
       std::lock_guard<std::mutex> lock(mu_);
       if (held_ + bytes <= max_held_) {
         free_[dev].emplace(bytes, p);
