@@ -558,19 +558,24 @@ KgStateEnqueued enqueue_kg_state_batch(GpDev& gp, const double* U_all, int u, in
   gp.dVE.reserve((size_t)N * cm * 2);  // (the second half: workspace of the gradient tail's K^-1 TB, kg.hip)
   gp.dWE.reserve((size_t)N * cm);
   // (one workspace for the split-K partials of the triangular products -- here and in the gradient tail -- and of the Gram kernels)
-  gp.dEK.reserve(std::max({(size_t)E * gram_batch_slices(E, m, N) * m * m, (size_t)E * gram_cross_slices(m, ng, A, N) * R * m,
-                           tri_cols_work_doubles(N, (int)cm)}));
+  // (the two Gram kernels' partials side by side: with m <= 8 they stay there for kg_state.hip to add up)
+  const size_t part_kk = (size_t)E * gram_batch_slices(E, m, N) * m * m, part_x = (size_t)E * gram_cross_slices(m, ng, A, N) * R * m;
+  gp.dEK.reserve(std::max(part_kk + part_x, tri_cols_work_doubles(N, (int)cm)));
   launch_tri_gemm_cols('N', N, (int)cm, m, gp.dLinv.p, gp.ldL, gp.dE.p + bl.col_kstar0(0) * N, N, gp.dVE.p, N, gp.dEK.p, s);
   launch_tri_gemm_cols('T', N, (int)cm, m, gp.dLinv.p, gp.ldL, gp.dVE.p, N, gp.dWE.p, N, gp.dEK.p, s);
   const size_t n_kk = (size_t)E * m * m, n_x = (size_t)E * R * m;
   gp.dGram.reserve(n_kk + n_x + ctot);
-  launch_gram_batch(E, m, 0, 0, N, gp.dVE.p, N, gp.dGram.p, gp.dEK.p, s);
-  launch_gram_cross_batch(E, m, ng, A, N, gp.dE.p, N, gp.dWE.p, N, gp.dGram.p + n_kk, gp.dEK.p, s);
+  static const bool defer_env = !(std::getenv("MOE_KG_GRAM_IN_STATE") != nullptr && std::atoi(std::getenv("MOE_KG_GRAM_IN_STATE")) == 0);
+  const bool defer = defer_env && m <= 8;  // (the latency path: q-KG with a handful of points)
+  const int s_kk = launch_gram_batch(E, m, 0, 0, N, gp.dVE.p, N, gp.dGram.p, gp.dEK.p, s, defer);
+  const int s_x = launch_gram_cross_batch(E, m, ng, A, N, gp.dE.p, N, gp.dWE.p, N, gp.dGram.p + n_kk, gp.dEK.p + part_kk, s, defer);
   launch_gemm_tn((int)ctot, 1, N, gp.dE.p, N, gp.dKinvY.p, N, gp.dGram.p + n_kk + n_x, (int)ctot, s);
   KgStateEnqueued se;
   se.bl = bl;
-  se.gkk = gp.dGram.p;
-  se.gx = gp.dGram.p + n_kk;
+  se.gkk = (defer && s_kk > 1) ? gp.dEK.p : gp.dGram.p;
+  se.gx = (defer && s_x > 1) ? gp.dEK.p + part_kk : gp.dGram.p + n_kk;
+  se.gkk_slices = defer ? s_kk : 1;
+  se.gx_slices = defer ? s_x : 1;
   se.ek = gp.dGram.p + n_kk + n_x;
   se.U = gp.dUnion;
   se.extra = dEp;

@@ -140,8 +140,9 @@ StateEnqueued enqueue_state_batch(GpDev& gp, const double* U_all, int u, const D
 // The KG evaluator's state set-up (r4), everything left on the device for kg_state.hip: see gp.hip.
 struct KgStateEnqueued {
   BatchLayout bl;
-  const double* gkk = nullptr;    // [E][m x m]
-  const double* gx = nullptr;     // [E][(ngrad + A) x m]
+  const double* gkk = nullptr;    // [E][m x m]              -- or, gkk_slices > 1: [E][gkk_slices][m x m] partial sums over K slices that
+  const double* gx = nullptr;     // [E][(ngrad + A) x m]    --     the consumer adds up in slice order (r5, m <= 8: two launches less)
+  int gkk_slices = 1, gx_slices = 1;
   const double* ek = nullptr;     // [E m | E ngrad | E A]
   const double* U = nullptr;      // [E][u][dp]
   const double* extra = nullptr;  // [E][A][dp]

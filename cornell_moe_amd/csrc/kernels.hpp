@@ -94,15 +94,17 @@ void launch_sum_slices(const double* work, int slices, long count, double* C, hi
 // where V_e's column `l` is V's column  l < m ? e*m + l : l < m+ng ? E*m + e*ng + (l-m) : E*(m+ng) + e*A + (l-m-ng).
 // work (may be NULL: single pass): E * gram_batch_slices(E, c, K) * c * c doubles of scratch for the K-sliced version.
 int gram_batch_slices(int E, int c, int K);
-void launch_gram_batch(int E, int m, int ng, int A, int K, const double* V, long ldv, double* G, double* work,
-                       hipStream_t s);
+// defer_sum (r5): with more than one K slice leave the partial Grams in `work` ([E][slices][c c]) for a consumer that adds them up in
+// slice order itself (kg_state.hip); G is then not written.  Returns the slice count (1: G holds the result).
+int launch_gram_batch(int E, int m, int ng, int A, int K, const double* V, long ldv, double* G, double* work,
+                      hipStream_t s, bool defer_sum = false);
 
 // Batched cross products of the KG state (r4): for eval e, G_e[(ng + A) x m] (ld ng + A, eval stride (ng + A) m) = S_e^T W_e, where
 // S_e = the evaluation's gradient and extra columns of S (column map of launch_gram_batch, l >= m) and W_e = columns e m .. of W.
 // work: E * gram_cross_slices(m, ng, A, K) * (ng + A) * m doubles.
 int gram_cross_slices(int m, int ng, int A, int K);
-void launch_gram_cross_batch(int E, int m, int ng, int A, int K, const double* S, long lds, const double* W, long ldw, double* G,
-                             double* work, hipStream_t s);
+int launch_gram_cross_batch(int E, int m, int ng, int A, int K, const double* S, long lds, const double* W, long ldw, double* G,
+                            double* work, hipStream_t s, bool defer_sum = false);  // (defer_sum, return value: as launch_gram_batch)
 
 // In-place blocked Cholesky of the lower triangle of A (N x N, lda) + explicit inverse of the factor into Linv
 // (N x N, ldl, lower; strict upper zeroed).  info (device int): 0 or failing pivot index + 1 (pivot <= 1e-16).

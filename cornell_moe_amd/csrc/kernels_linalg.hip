@@ -1135,10 +1135,10 @@ int gram_cross_slices(int m, int ng, int A, int K) {
   return (int)std::max<long>(1, std::min<long>(s, 16));
 }
 
-void launch_gram_cross_batch(int E, int m, int ng, int A, int K, const double* S, long lds, const double* W, long ldw, double* G,
-                             double* work, hipStream_t s) {
+int launch_gram_cross_batch(int E, int m, int ng, int A, int K, const double* S, long lds, const double* W, long ldw, double* G,
+                            double* work, hipStream_t s, bool defer_sum) {
   const int r = ng + A;
-  if (r <= 0 || m <= 0 || E <= 0) return;
+  if (r <= 0 || m <= 0 || E <= 0) return 1;
   GramMap gm{E, m, ng, A};
   const int slices = gram_cross_slices(m, ng, A, K);
   dim3 grid((r + 31) / 32, (m + 31) / 32, E * slices);
@@ -1147,14 +1147,17 @@ void launch_gram_cross_batch(int E, int m, int ng, int A, int K, const double* S
   } else {
     const long cc = (long)r * m;
     hipLaunchKernelGGL(gram_cross_batch_kernel, grid, dim3(256), 0, s, gm, K, S, lds, W, ldw, work, slices);
-    hipLaunchKernelGGL(gram_sum_kernel, dim3((unsigned)((cc + 255) / 256), E), dim3(256), 0, s, (const double*)work, slices, cc, G);
+    if (!defer_sum)
+      hipLaunchKernelGGL(gram_sum_kernel, dim3((unsigned)((cc + 255) / 256), E), dim3(256), 0, s, (const double*)work, slices, cc, G);
   }
   MOE_HIP_CHECK(hipGetLastError());
+  return slices;
 }
 
-void launch_gram_batch(int E, int m, int ng, int A, int K, const double* V, long ldv, double* G, double* work, hipStream_t s) {
+int launch_gram_batch(int E, int m, int ng, int A, int K, const double* V, long ldv, double* G, double* work, hipStream_t s,
+                      bool defer_sum) {
   const int c = m + ng + A;
-  if (c <= 0 || E <= 0) return;
+  if (c <= 0 || E <= 0) return 1;
   GramMap gm{E, m, ng, A};
   const int slices = (work != nullptr) ? gram_batch_slices(E, c, K) : 1;
   dim3 grid((c + 31) / 32, (c + 31) / 32, E * slices);
@@ -1163,9 +1166,11 @@ void launch_gram_batch(int E, int m, int ng, int A, int K, const double* V, long
   } else {
     const long cc = (long)c * c;
     hipLaunchKernelGGL(gram_batch_kernel, grid, dim3(256), 0, s, gm, K, V, ldv, work, slices);
-    hipLaunchKernelGGL(gram_sum_kernel, dim3((unsigned)((cc + 255) / 256), E), dim3(256), 0, s, (const double*)work, slices, cc, G);
+    if (!defer_sum)
+      hipLaunchKernelGGL(gram_sum_kernel, dim3((unsigned)((cc + 255) / 256), E), dim3(256), 0, s, (const double*)work, slices, cc, G);
   }
   MOE_HIP_CHECK(hipGetLastError());
+  return slices;
 }
 
 

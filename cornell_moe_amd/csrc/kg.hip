@@ -1391,6 +1391,8 @@ KgPending kg_launch(GpDev& gp, int num_fidelity, const moe_gd_params_t& gd, cons
   sp.ng = ngrad;
   sp.gkk = se.gkk;
   sp.gx = se.gx;
+  sp.gkk_slices = se.gkk_slices;
+  sp.gx_slices = se.gx_slices;
   sp.ek = se.ek;
   sp.U = se.U;
   sp.extra = se.extra;

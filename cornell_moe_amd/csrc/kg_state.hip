@@ -27,6 +27,29 @@ __device__ __forceinline__ double pts_cov(const CovParams& cp, const double* p1,
   return cov_entry_g(cp, rd, df, a, b, d1, d2);
 }
 
+// Entry `idx` of evaluation e's Gram block of `cc` entries: the plain value (slices == 1, base = [E][cc]) or the sum of the K-slice
+// partials the Gram kernel left (base = [E][slices][cc]) in slice order -- the sum gram_sum_kernel would have taken (r5).
+struct GramView {
+  const double* base;  // already offset to evaluation e
+  int slices;
+  long cc;
+  __device__ __forceinline__ double operator[](long idx) const {
+    if (slices == 1) return base[idx];
+    // (at most 16 slices: the loads go out together from clamped addresses, the adds keep the slice order)
+    double t[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) t[k] = base[(long)min(k, slices - 1) * cc + idx];
+    double v = 0.0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k)
+      if (k < slices) v += t[k];
+    return v;
+  }
+};
+__device__ __forceinline__ GramView gram_view(const double* g, int slices, long cc, int e) {
+  return GramView{g + (long)e * slices * cc, slices, cc};
+}
+
 // One workgroup per evaluation.  Dynamic LDS: Ls [m][m] (column-major) | Rs [m][rchunk] (right-hand sides of the discretised set).
 __global__ __launch_bounds__(256) void kg_state_kernel(KgStateParams P, int rchunk) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
@@ -36,8 +59,8 @@ __global__ __launch_bounds__(256) void kg_state_kernel(KgStateParams P, int rchu
   double* Rs = sm + m * m;
   const double* U = P.U + (long)e * u * dp;
   const double* X = P.extra + (long)e * A * dp;
-  const double* gkk = P.gkk + (long)e * m * m;
-  const double* gx = P.gx + (long)e * R * m;
+  const GramView gkk = gram_view(P.gkk, P.gkk_slices, (long)m * m, e);
+  const GramView gx = gram_view(P.gx, P.gx_slices, (long)R * m, e);
   const double* ek_k = P.ek + (long)e * m;
   const double* ek_g = P.ek + (long)P.E * m + (long)e * P.ng;
   const double* ek_x = P.ek + (long)P.E * (m + P.ng) + (long)e * A;
@@ -130,7 +153,7 @@ __global__ __launch_bounds__(256) void kg_state_kernel(KgStateParams P, int rchu
 }
 
 // d Var(row, col) / d Xq_p,dd for col in block p, row = (j, a)  (ComputeGradVarianceOfPointsPerPoint, gpp_math.cpp:1267-1357)
-__device__ __forceinline__ double grad_var_entry(const KgStateParams& P, const double* U, const double* gx, int R, int p, int dd,
+__device__ __forceinline__ double grad_var_entry(const KgStateParams& P, const double* U, const GramView& gx, int R, int p, int dd,
                                                  int row, int col) {
   const int g1 = 1 + P.g, d = P.d;
   const int j = row / g1, a = row - j * g1, b = col - p * g1;
@@ -159,7 +182,7 @@ __global__ __launch_bounds__(256) void kg_dchol_kernel(KgStateParams P) {
   double* lcol = sm + tri;
   double* srow = lcol + 2 * m;
   const double* U = P.U + (long)e * P.u * P.dp;
-  const double* gx = P.gx + (long)e * R * m;
+  const GramView gx = gram_view(P.gx, P.gx_slices, (long)R * m, e);
   const double* Lg = P.blob + (long)e * P.rec_stride + P.rec_L;
   for (int idx = tid; idx < m * m; idx += 256) {
     const int row = idx % m, col = idx / m;

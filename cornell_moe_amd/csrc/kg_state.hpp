@@ -18,8 +18,9 @@ struct KgStateParams {
   double mean;
   double best_so_far;
   int E, u, q, m, g, d, dp, A, ng;  // ng = q (1 + g) d gradient columns (0: value only)
-  const double* gkk;    // [E][m x m]        (L^-1 K*)^T (L^-1 K*)
-  const double* gx;     // [E][(ng + A) x m] [dK* | K(X, discretised set)]^T K^-1 K*
+  const double* gkk;    // [E][m x m]        (L^-1 K*)^T (L^-1 K*)                        (slices > 1: [E][slices][...] partial sums over
+  const double* gx;     // [E][(ng + A) x m] [dK* | K(X, discretised set)]^T K^-1 K*      K slices, added up in slice order on use: gram_entry)
+  int gkk_slices, gx_slices;
   const double* ek;     // [E m | E ng | E A] E^T K^-1 (y - mean), grouped by kind (BatchLayout)
   const double* U;      // [E][u][dp]  union points
   const double* extra;  // [E][A][dp]  discretised set (fidelity coordinates at 1)
