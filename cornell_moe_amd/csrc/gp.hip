@@ -463,9 +463,10 @@ const double* build_state_matrix(GpDev& gp, const double* U_all, int u, const De
   const size_t nApx = apx ? apx->doubles : 0;
   gp.hStateIn.reserve(nU + nD + nX + nApx);
   std::memset(gp.hStateIn.p, 0, sizeof(double) * (nU + nD + nX));
+  // (r5: the extras right behind the union points -- without derivative observations the two value builds are one launch)
   double* Up = gp.hStateIn.p;
-  double* Dp = Up + nU;
-  double* Ep = Dp + nD;
+  double* Ep = Up + nU;
+  double* Dp = Ep + nX;
   for (int e = 0; e < E; ++e) {
     for (int i = 0; i < u; ++i)
       for (int k = 0; k < gp.d; ++k) Up[((size_t)e * u + i) * gp.dp + k] = U_all[((size_t)e * u + i) * gp.d + k];
@@ -477,14 +478,18 @@ const double* build_state_matrix(GpDev& gp, const double* U_all, int u, const De
   if (apx) apx->fill(gp.hStateIn.p + nU + nD + nX);
   gp.dStateIn.upload(gp.hStateIn.p, nU + nD + nX + nApx, s);
   double* dUp = gp.dStateIn.p;
-  double* dDp = dUp + nU;
-  double* dEp = dDp + nD;
+  double* dEp = dUp + nU;
+  double* dDp = dEp + nX;
   gp.dUnion = dUp;  // (kg.hip / ei.hip read the padded union points back from here)
-  gp.dAppendix = dEp + nX;
+  gp.dAppendix = dDp + nD;
   gp.dE.reserve((size_t)N * ctot);
-  launch_cov_build(gp.cp, gp.dX.p, gp.n, gp.derivs, dUp, E * u, dt, nullptr, gp.dE.p, N, bl.col_kstar0(0), s);
+  const bool pair = A > 0 && dt.g == 0 && gp.derivs.g == 0;
+  if (pair)
+    launch_cov_build_pair(gp.cp, gp.dX.p, gp.n, dUp, E * u, bl.col_kstar0(0), E * A, bl.col_extra0(0), gp.dE.p, N, s);
+  else
+    launch_cov_build(gp.cp, gp.dX.p, gp.n, gp.derivs, dUp, E * u, dt, nullptr, gp.dE.p, N, bl.col_kstar0(0), s);
   if (nd > 0) launch_grad_kstar(gp.cp, gp.dX.p, gp.n, gp.derivs, dDp, E * nd, dt, gp.dE.p, N, bl.col_grad0(0), s);
-  if (A > 0) {
+  if (A > 0 && !pair) {
     DerivList none;
     none.g = 0;
     for (int i = 0; i < kMaxDerivs; ++i) none.idx[i] = 0;

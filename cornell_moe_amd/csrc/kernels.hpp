@@ -44,6 +44,9 @@ struct DerivList {
 void launch_cov_build(const CovParams& cp, const double* A, int nA, const DerivList& dA, const double* B, int nB,
                       const DerivList& dB, const double* diag_noise, double* out, long ld, long col0, hipStream_t s,
                       bool streaming = false, bool lower_only = false);
+// K(A, [B1 | B2]) without derivative observations, two column ranges, one launch (r5; kernels_cov.hip)
+void launch_cov_build_pair(const CovParams& cp, const double* A, int nA, const double* B, int nB1, long col1, int nB2, long col2,
+                           double* out, long ld, hipStream_t s);
 
 // E[(j*(1+g)+n) + (col0 + (i*(1+gt)+m)*dim + dd) * ld] = d cov(P_i, X_j)[m, n] / d P_{i,dd}
 // (grad_K_star fill, gpp_math.cpp:616-637)

@@ -22,7 +22,9 @@ __global__ __launch_bounds__(kCovRows) void cov_build_kernel(CovParams cp, const
                                                             DerivList dA, const double* __restrict__ B, int nB,
                                                             DerivList dB, const double* __restrict__ diag_noise,
                                                             double* __restrict__ out, long ld, long col0, int lower_only,
-                                                            int cols_per_wg) {
+                                                            int cols_per_wg, int split_at = 0x7fffffff, long split_shift = 0) {
+  // (split_at / split_shift, r5, value-only builds: B points from index split_at on write their columns split_shift further right --
+  //  two point sets with separate column ranges in ONE launch, launch_cov_build_pair)
   __shared__ double Bs[kCovCols][DP];
   const int gA = DERIVS ? dA.g : 0, gB = DERIVS ? dB.g : 0;
   const int rows = nA * (1 + gA);
@@ -53,7 +55,7 @@ __global__ __launch_bounds__(kCovRows) void cov_build_kernel(CovParams cp, const
       double v = rd.base;
       const long col = col0 + j0 + jj;
       if (diag_noise != nullptr && (long)r == col - col0) v += diag_noise[0];
-      if (!lower_only || (long)r >= col - col0) out[(long)r + col * ld] = v;
+      if (!lower_only || (long)r >= col - col0) out[(long)r + (col + (j0 + jj >= split_at ? split_shift : 0)) * ld] = v;
     } else {
       for (int b = 0; b < 1 + gB; ++b) {
         double v = cov_entry<DP>(cp, rd, diff, a, b, dA, dB);
@@ -371,6 +373,39 @@ void launch_cov_build(const CovParams& cp, const double* A, int nA, const DerivL
     case 16: cov_build_dp<16>(cp, A, nA, dA, B, nB, dB, diag_noise, out, ld, col0, s, streaming, lower_only); break;
     case 24: cov_build_dp<24>(cp, A, nA, dA, B, nB, dB, diag_noise, out, ld, col0, s, streaming, lower_only); break;
     case 32: cov_build_dp<32>(cp, A, nA, dA, B, nB, dB, diag_noise, out, ld, col0, s, streaming, lower_only); break;
+    default: throw Error(MOE_ERR_RUNTIME, "unsupported padded dimension");
+  }
+  MOE_HIP_CHECK(hipGetLastError());
+}
+
+namespace {
+template <int DP>
+void cov_build_pair_dp(const CovParams& cp, const double* A, int nA, const double* B, int nB1, long col1, int nB2, long col2,
+                       double* out, long ld, hipStream_t s) {
+  DerivList none;
+  none.g = 0;
+  for (int i = 0; i < kMaxDerivs; ++i) none.idx[i] = 0;
+  const int nB = nB1 + nB2;
+  dim3 grid((nB + kCovCols - 1) / kCovCols, (nA + kCovRows - 1) / kCovRows);
+  if (grid.x == 0 || grid.y == 0) return;
+  // point b >= nB1 belongs at column col2 + (b - nB1) = col1 + b + (col2 - col1 - nB1)
+  hipLaunchKernelGGL((cov_build_kernel<DP, false>), grid, dim3(kCovRows), 0, s, cp, A, nA, none, B, nB, none, (const double*)nullptr, out,
+                     ld, col1, 0, kCovCols, nB1, col2 - col1 - (long)nB1);
+}
+}  // namespace
+
+// K(A, [B1 | B2]) without derivative observations on either side, B1's nB1 columns from col1 on and B2's nB2 (the points right behind
+// B1 in memory) from col2 on: the two builds of a q-KG state -- K* and K(X, discretised set) -- in ONE launch (r5).  Entry for entry
+// what two launch_cov_build calls write.
+void launch_cov_build_pair(const CovParams& cp, const double* A, int nA, const double* B, int nB1, long col1, int nB2, long col2,
+                           double* out, long ld, hipStream_t s) {
+  switch (cp.dp) {
+    case 4: cov_build_pair_dp<4>(cp, A, nA, B, nB1, col1, nB2, col2, out, ld, s); break;
+    case 8: cov_build_pair_dp<8>(cp, A, nA, B, nB1, col1, nB2, col2, out, ld, s); break;
+    case 12: cov_build_pair_dp<12>(cp, A, nA, B, nB1, col1, nB2, col2, out, ld, s); break;
+    case 16: cov_build_pair_dp<16>(cp, A, nA, B, nB1, col1, nB2, col2, out, ld, s); break;
+    case 24: cov_build_pair_dp<24>(cp, A, nA, B, nB1, col1, nB2, col2, out, ld, s); break;
+    case 32: cov_build_pair_dp<32>(cp, A, nA, B, nB1, col1, nB2, col2, out, ld, s); break;
     default: throw Error(MOE_ERR_RUNTIME, "unsupported padded dimension");
   }
   MOE_HIP_CHECK(hipGetLastError());
