@@ -57,6 +57,11 @@ def test_no_silent_cpu_fallback(lib):
     assert "no CPU fallback" in str(ei.value)
     with pytest.raises(api.OptimalLearningException):
         api.debug_cholesky(np.eye(3))
+    # GPP.run_cpp_tests() is a device self-test (r5): without a device it must not report "0 failures"
+    from cornell_moe_amd import GPP
+    with pytest.raises(RuntimeError) as er:
+        GPP.run_cpp_tests()
+    assert "no CPU fallback" in str(er.value)
 
 
 def test_null_arguments_are_errors_not_crashes(lib):
