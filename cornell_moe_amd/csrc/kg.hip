@@ -1092,7 +1092,18 @@ KgPending kg_launch(GpDev& gp, int num_fidelity, const moe_gd_params_t& gd, cons
   // ... and only up to four dimensions: with eight or more coordinate rows the 128-VGPR instantiation spills heavily (0.5 - 1 KB of
   // scratch per lane) -- n = 60, d = 8: 27 300 vs 44 500 evals/s on the 8-wavefront instantiation, d = 12: 9 500 vs 35 800,
   // d = 16: 6 200 vs 25 200 (r2)
-  const int max_waves = (ntiles <= env_int("MOE_KG_SMALL_TILES", 2) && dp <= env_int("MOE_KG_SMALL_DP", 4)) ? 16 : 8;
+  // r5: a call with FEW samples on such a shape -- one evaluation of a KG-MCMC suggestion: n = 30, 20 restarts x 128 samples; the
+  // drop-in boundary's one-at-a-time calls -- takes the lane-parked kernel instead, eight wavefronts, with the same single-trial passes:
+  // the same bits as the 16-wavefront instantiation (tests/test_gpu_sweep.py: test_small_shape_kernels_agree), so which of the two runs
+  // may depend on the size of the call.  MC kernel of one evaluation at n = 30, M = 128: 0.087 -> 0.056 ms (M = 2000: 0.165 -> 0.132);
+  // a suggestion 0.212 -> 0.18-0.19 s.  In throughput the 16-wavefront instantiation keeps its lead (batch of 64, M = 2000: 0.0200 vs
+  // 0.0249 ms per evaluation), hence the sample bound.  (The lane-parked kernel's MULTI-trial passes would be faster still -- 0.17 s --
+  // but their dot-form distances move the end points of the reference's 100-step x 10-restart fixtures by up to 1.01e-6, beyond the
+  // 1e-6 those fixtures are held to: not taken.)  `profiles/r05_z_*`.
+  const bool small_shape = ntiles <= env_int("MOE_KG_SMALL_TILES", 2) && dp <= env_int("MOE_KG_SMALL_DP", 4);
+  const bool small_lane = small_shape && !simplex && env_int("MOE_KG_LANE", 1) != 0 &&
+                          (long)E * num_local <= (long)env_int("MOE_KG_SMALL_LANE_MAX_SAMPLES", 8192);
+  const int max_waves = (small_shape && !small_lane) ? 16 : 8;
   int waves = 0;
   if (tab_bytes + slab_bytes <= lds_max) waves = (int)std::min<size_t>(max_waves, (lds_max - tab_bytes) / slab_bytes);
   // (3 wavefronts per CU on the LDS table still beat the workgroup-per-sample kernel without derivative observations --
@@ -1458,7 +1469,7 @@ KgPending kg_launch(GpDev& gp, int num_fidelity, const moe_gd_params_t& gd, cons
   mp.ntiles = ntiles;
   mp.E = E;
   mp.mean = gp.mean;
-  mp.multi_trial = far_frame ? 0 : env_int("MOE_KG_MULTI_TRIAL", 1);  // (0: A/B runs)
+  mp.multi_trial = (far_frame || small_lane) ? 0 : env_int("MOE_KG_MULTI_TRIAL", 1);  // (0: A/B runs)
   mp.XsTab = dTab.p;
   mp.tab_stride = tab_stride;
   mp.wide_lds_tiles = wide_lds_tiles;

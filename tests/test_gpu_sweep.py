@@ -468,7 +468,8 @@ def test_lane_kernel_bit_identical_to_frame_kernel(case, monkeypatch):
         monkeypatch.setenv("MOE_KG_LANE", lane)
         res[lane] = G.kg(gd, w.bounds_inner, w.discrete, w.Xq, Xp, w.M, best, w.kg_normals, num_fidelity=f, want_best_points=True)
         info = G.last_kernel_info()
-        # (one or two tiles at d <= 4 take the 16-wavefront instantiation of the frame kernel either way: case 101)
+        # (one or two tiles at d <= 4: the lane-parked kernel for a call this small, else the 16-wavefront instantiation of the frame
+        #  kernel -- case 101, test_small_shape_kernels_agree)
         assert info["variant"] == 0 and info["xlds"] == 1 and info["lane"] == (int(lane) if info["waves"] <= 8 else 0), info
     a, b = res["1"], res["0"]
     assert a["kg_sum"] == b["kg_sum"] and np.array_equal(a["grad_sum"], b["grad_sum"])
@@ -499,6 +500,31 @@ def test_fly_kernel_bit_identical_to_frame_kernel(case, monkeypatch):
         elif info["lane"] and (w.q + w.p) <= 4:  # (wherever the lane-parked kernel is eligible and m <= 4)
             assert info["fly"] == 1 and info["waves"] == 16, info
     a, b = res["1"], res["0"]
+    assert a["kg_sum"] == b["kg_sum"] and np.array_equal(a["grad_sum"], b["grad_sum"])
+    assert np.array_equal(a["best_point"], b["best_point"])
+    assert a["grad_evals"] == b["grad_evals"] and a["mean_evals"] == b["mean_evals"]
+
+
+@pytest.mark.parametrize("case", [CASES[i] for i in (0, 1, 2, 11, 12, 15, 16, 17)], ids=lambda c: str(c[0]))
+def test_small_shape_kernels_agree(case, monkeypatch):
+    """r5: one or two tiles at d <= 4.  A call with few samples takes the lane-parked kernel (eight wavefronts, single-trial passes), a
+    big one the 16-wavefront small-shape instantiation of the frame kernel (kg.hip: small_lane): which of the two runs depends on the
+    SIZE of the call, so they must agree bit for bit -- sums, end points, pass counters."""
+    from cornell_moe_amd import api
+    w, cov, f, gd = _mk(case)
+    G = api.DeviceGP(w.hyperparameters, w.X, w.y, w.noise, w.derivs, cov_type=cov)
+    full = np.hstack([w.discrete, np.ones((w.discrete.shape[0], f))])
+    best = float(G.additional_mean(full).min())
+    Xp = w.Xp if w.p else None
+    monkeypatch.setenv("MOE_KG_VARIANT", "0")
+    res = {}
+    for cap in ("8192", "0"):
+        monkeypatch.setenv("MOE_KG_SMALL_LANE_MAX_SAMPLES", cap)
+        res[cap] = G.kg(gd, w.bounds_inner, w.discrete, w.Xq, Xp, w.M, best, w.kg_normals, num_fidelity=f, want_best_points=True)
+        info = G.last_kernel_info()
+        assert info["variant"] == 0 and info["xlds"] == 1, info
+        assert (info["lane"], info["waves"]) == ((1, 8) if cap == "8192" else (0, 16)), info
+    a, b = res["8192"], res["0"]
     assert a["kg_sum"] == b["kg_sum"] and np.array_equal(a["grad_sum"], b["grad_sum"])
     assert np.array_equal(a["best_point"], b["best_point"])
     assert a["grad_evals"] == b["grad_evals"] and a["mean_evals"] == b["mean_evals"]
