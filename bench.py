@@ -168,7 +168,7 @@ def committed_traffic():
         return {}
 
 
-def measure_traffic(config, restarts, log, timeout_s=180):
+def measure_traffic(config, restarts, log, timeout_s=180, passes=None):
     """HBM bytes per launch AND executed FP64 wave-instructions per launch of the reported kernels, measured NOW: three rocprofv3
     passes (FETCH_SIZE; WRITE_SIZE; SQ_INSTS_VALU_{FMA,ADD,MUL,TRANS}_F64 -- each in its own --pmc run with --kernel-trace only,
     as MI355X_MICROARCH.md prescribes; FETCH_SIZE doubled for gfx950) over tools/prof_kg.py -- the same batched evaluation this
@@ -189,6 +189,8 @@ def measure_traffic(config, restarts, log, timeout_s=180):
                           ("clock", ["GRBM_GUI_ACTIVE", "GRBM_COUNT"]),
                           ("busy", ["SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES", "SQ_ACTIVE_INST_VALU", "SQ_INST_CYCLES_SALU"]),
                           ("insts", ["SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY"])):
+            if passes is not None and tag not in passes:
+                continue
             cmd = [exe, "--kernel-trace", "--pmc"] + ctrs + ["--output-format", "csv", "-d", os.path.join(tmp, tag), "-o", "p",
                    "--", sys.executable, os.path.join(ROOT, "tools", "prof_kg.py"), config, str(restarts), "2"]
             try:
@@ -382,6 +384,106 @@ def run_suggest(args, rank, local_rank, world, comm, log):
             log("suggest: reference timing unavailable (%s: %s)" % (type(e).__name__, e))
     print(json.dumps(out), flush=True)
     comm.close()
+
+
+def side_configs(local_rank, log, c5_traffic=True):
+    """r6: every other BASELINE.json configuration measured by the DEFAULT run, after the timed region, as a compact
+    object -- C1 posterior queries (us), C2 q-EI value + gradient (us), C5 d-KG (evals/s, its MC phase against the FP64 peak with the
+    device-counted passes, HBM traffic of the phase from an in-run PMC pass), one whole KG-MCMC suggestion (s) -- so that the driver's
+    record of the headline line carries them.  Each entry is reproducible alone: `bench.py --config C5`, `--config suggest`,
+    tools/latency.py."""
+    import torch
+    from cornell_moe_amd import api as mapi
+    from cornell_moe_amd.api import DeviceGP
+    from cornell_moe_amd.workloads import make_workload
+    out = {}
+
+    def timed(fn, reps, warm=3):
+        for _ in range(warm):
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / reps
+
+    try:   # configs[0]: GP posterior mean / variance, n = 200, d = 2
+        w = make_workload("C1")
+        t0 = time.perf_counter()
+        G = DeviceGP(w.hyperparameters, w.X, w.y, w.noise, w.derivs, device=local_rank)
+        build_ms = 1e3 * (time.perf_counter() - t0)
+        one, hundred = w.query[:1], w.query[:100]
+        out["C1"] = {"workload": "posterior mean / variance, n=200 d=2 (the GP stays resident)", "gp_build_ms": build_ms,
+                     "mean_1pt_us": 1e6 * timed(lambda: G.mean(one), 200), "var_1pt_us": 1e6 * timed(lambda: G.variance(one), 200),
+                     "mean_100pts_us": 1e6 * timed(lambda: G.mean(hundred), 100), "var_100pts_us": 1e6 * timed(lambda: G.variance(hundred), 50)}
+        G.close()
+    except Exception as e:  # pragma: no cover
+        out["C1"] = {"error": "%s: %s" % (type(e).__name__, e)}
+    try:   # configs[1]: q-EI value + gradient, n = 500, d = 4, q = 2, 1k MC, one at a time
+        w = make_workload("C2")
+        G = DeviceGP(w.hyperparameters, w.X, w.y, w.noise, w.derivs, device=local_rank)
+        best = float(w.y[:, 0].min())
+        out["C2"] = {"workload": "q-EI, n=500 d=4 q=2 M=1000, one evaluation per call",
+                     "value_grad_us": 1e6 * timed(lambda: G.ei(w.Xq, None, w.M, best, w.ei_normals), 200),
+                     "value_only_us": 1e6 * timed(lambda: G.ei(w.Xq, None, w.M, best, w.ei_normals, want_grad=False), 200)}
+        G.close()
+    except Exception as e:  # pragma: no cover
+        out["C2"] = {"error": "%s: %s" % (type(e).__name__, e)}
+    try:   # configs[4]: d-KG, n = 2000, d = 12, q = 8, g = 3, 20k MC -- two evaluations per call, as `--config C5`
+        w = make_workload("C5", num_restarts=2)
+        t0 = time.perf_counter()
+        G = DeviceGP(w.hyperparameters, w.X, w.y, w.noise, w.derivs, device=local_rank)
+        build_ms = 1e3 * (time.perf_counter() - t0)
+        best = float(G.additional_mean(w.discrete).min())
+        call = lambda: G.kg_batch(w.inner_gd, w.bounds, w.discrete, w.Xq_restarts, None, w.M, best, w.kg_normals)  # noqa: E731
+        call()
+        torch.cuda.synchronize()
+        steps, ms_mc, vp, gp_ = 4, 0.0, 0, 0
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            r = call()
+            km = G.last_kernel_ms()
+            ms_mc += km["mc"]
+            vp += r["mean_evals"]
+            gp_ += r["grad_evals"]
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        npts, f_val, f_grad = pass_flops(w)
+        S, Gp = vp / float(2 * steps * w.M), gp_ / float(2 * steps * w.M)
+        flops = w.M * npts * (S * f_val + Gp * f_grad)
+        mc_ms = ms_mc / steps       # per evaluation (HIP events on the library's stream: sample pre-pass + weight table + MC kernel)
+        kinfo = G.last_kernel_info()
+        kname = {0: "kg_mc_kernel", 1: "kg_mc_block_kernel", 2: "kg_mc_stream_kernel", 3: "kg_mc_gang_kernel"}[kinfo["variant"]]
+        out["C5"] = {"workload": "d-KG value+gradient, n=2000 d=12 q=8 g=3 M=20000, 2 evaluations per call", "evals_per_s": 2 * steps / dt,
+                     "gp_build_ms": build_ms, "mc_phase_ms_per_eval": mc_ms, "kernel": kname,
+                     "frac": flops / (mc_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS, "bound": "fp64_valu", "peak_tflops": FP64_PEAK_TFLOPS,
+                     "value_passes_per_sample": S, "grad_passes_per_sample": Gp,
+                     "weight_table_bytes_per_eval": 8.0 * w.M * ((w.n + w.q + 63) // 64) * 64 * (1 + w.g), "traffic_bytes_per_eval": None}
+        G.close()
+        if c5_traffic:
+            pmc, src = measure_traffic("C5", 2, log, timeout_s=90, passes=("fetch", "write"))
+            pk = (pmc or {}).get(kname) or {}
+            if pk.get("hbm_bytes_per_launch") is not None:
+                out["C5"]["traffic_bytes_per_eval"] = pk["hbm_bytes_per_launch"] / 2.0
+                out["C5"]["traffic_over_table"] = out["C5"]["traffic_bytes_per_eval"] / out["C5"]["weight_table_bytes_per_eval"]
+            out["C5"]["traffic_source"] = src + " (MC kernel alone; the table's own write is one table size more)"
+    except Exception as e:  # pragma: no cover
+        out["C5"] = {"error": "%s: %s" % (type(e).__name__, e)}
+    try:   # the thing users invoke: one whole KG-MCMC suggestion (examples/main.py's settings), as `--config suggest`
+        pb = suggest_problem("suggest")
+        q, M, nm = pb["q"], pb["M"], pb["num_mcmc"]
+        G = mapi.DeviceGPMCMC(pb["hypers"], pb["noises"], pb["X"], pb["y"], (), device=local_rank)
+        best_all = np.array([float(g.additional_mean(pb["discrete_all"][i]).min()) for g, i in zip(G.gps, G.members)])
+        starts = np.stack([mapi.latin_hypercube(pb["uniform_seed"] + k, pb["bounds"], pb["outer_gd"][0]) for k in range(q)], axis=1)
+        normals = mapi.normal_draws(pb["normal_seed"], ((M + 1) // 2) * q)
+        sug = lambda: G.kg_multistart(pb["outer_gd"], pb["inner_gd"], pb["bounds"], pb["discrete_all"], starts, None, M, best_all, normals)  # noqa: E731
+        sec = timed(sug, 3, warm=1)
+        out["suggest"] = {"workload": "one q-KG-MCMC suggestion: Branin n=30, 16 GPs, 200 starts -> 20, 50 steps x 2 restarts, M=128, q=4",
+                          "s_per_suggestion": sec}
+    except Exception as e:  # pragma: no cover
+        out["suggest"] = {"error": "%s: %s" % (type(e).__name__, e)}
+    return out
 
 
 C4_RESTARTS = 64  # BASELINE.json configs[3]: "q-KG 64-multistart x 10k MC sharded across 8 x MI355X"
@@ -671,7 +773,7 @@ def main():
         cov_tbs = cov_bytes_launch / (cov_launch_ms * 1e-3) / 1e12 if cov_launch_ms > 0 else 0.0
         # (which MC kernel the library launched for this shape: wave-per-sample, workgroup-per-sample, or streamed-weights -- r3)
         kinfo = G.last_kernel_info()
-        mc_kernel = {0: "kg_mc_kernel", 1: "kg_mc_block_kernel", 2: "kg_mc_stream_kernel"}[kinfo["variant"]]
+        mc_kernel = {0: "kg_mc_kernel", 1: "kg_mc_block_kernel", 2: "kg_mc_stream_kernel", 3: "kg_mc_gang_kernel"}[kinfo["variant"]]
         if kinfo["variant"] == 0 and kinfo.get("lane"):
             mc_kernel = "kg_mc_lane_kernel"   # r5: the lane-parked form of the LDS-table kernel (csrc/kg_mc_lane.hpp)
         pmc, traffic_src = (None, "skipped (--no-traffic)")
@@ -777,6 +879,23 @@ def main():
                 out["roofline_cov_build_kxx"] = mapi.kxx_build_probe(log)
             except Exception as e:  # pragma: no cover
                 log("kxx_build_probe failed: %s" % e)
+        # r6: scalars a driver that trims nested objects still records, and every other BASELINE configuration in one object
+        out["cov_build_frac"] = out["roofline_cov_build"]["frac"]
+        if isinstance(out.get("roofline_cov_build_kxx"), dict):
+            kx = out["roofline_cov_build_kxx"]
+            fr = [v.get("frac") for v in kx.values() if isinstance(v, dict) and v.get("frac") is not None] if "frac" not in kx else [kx["frac"]]
+            out["kxx_frac"] = max(fr) if fr else None
+        if not args.no_extras and world == 1 and args.config in ("C3", "C4") and multi_fallback is None:
+            G.close()   # (the headline GP: its workspaces go back to the pool before the other configurations build theirs)
+            t_side = time.perf_counter()
+            out["configs"] = side_configs(local_rank, log, c5_traffic=not args.no_traffic)
+            out["configs"]["C3"] = {"evals_per_s": value, "frac": out["roofline"]["frac"], "kernel": mc_kernel}
+            out["configs"]["C4"] = {"ms_per_64_restart_step": 1e3 * elapsed / args.steps,
+                                    "note": "one step of this line IS the C4 job on %d GPU(s)" % world}
+            out["configs"]["seconds_spent"] = time.perf_counter() - t_side
+            for key, field in (("C5", "evals_per_s"), ("C5", "frac"), ("suggest", "s_per_suggestion"), ("C2", "value_grad_us"), ("C1", "mean_1pt_us")):
+                if field in out["configs"].get(key, {}):
+                    out["%s_%s" % (key.lower(), field)] = out["configs"][key][field]
         if not args.no_cpu_baseline and world == 1 and args.config == "C5" and args.derivs is None:
             out["cpu_baseline"] = cpu_baseline_c5(w, log)
             out["speedup_vs_cpu_one_core"] = value / out["cpu_baseline"]["value"]

@@ -81,8 +81,13 @@ class DevicePool {
     if (enabled_) {
       hipPointerAttribute_t attr;
       int dev = 0;
-      if (hipPointerGetAttributes(&attr, p) == hipSuccess) dev = attr.device;
-      else (void)hipGetLastError();
+      if (hipPointerGetAttributes(&attr, p) == hipSuccess) {
+        dev = attr.device;
+      } else {  // (whose block is this? filed under a guessed device it could be handed to another device's request: not pooled)
+        (void)hipGetLastError();
+        (void)hipFree(p);
+        return;
+      }
       int cur = dev;
       (void)hipGetDevice(&cur);
       if (cur != dev) (void)hipSetDevice(dev);  // (a block of another device than the calling thread's current one)
@@ -196,7 +201,13 @@ class DevicePool {
     const char* on = std::getenv("MOE_POOL");
     enabled_ = !(on != nullptr && std::atoi(on) == 0);
     const char* gb = std::getenv("MOE_POOL_MAX_GB");
-    max_held_ = (size_t)((gb != nullptr ? std::atof(gb) : 48.0) * 1e9);
+    // (what the pool holds is invisible to the other allocators of the process -- PyTorch, RCCL: 16 GB by default, the two factors of an
+    //  N = 26 000 GP and a call's workspaces; only a failed hipMalloc of THIS library trims it, so a co-resident framework that runs
+    //  short calls moe_pool_trim(); a negative or unparsable value means 0)
+    double cap_gb = gb != nullptr ? std::atof(gb) : 16.0;
+    if (!(cap_gb >= 0.0)) cap_gb = 0.0;
+    if (cap_gb > 1.0e6) cap_gb = 1.0e6;
+    max_held_ = (size_t)(cap_gb * 1e9);
     // MOE_POOL_POISON=1 (tests): a released block is filled with 0xFF bytes before it is pooled -- whoever reads memory it has not
     // written finds NaNs / -1 instead of a plausible zero (a fresh hipMalloc is usually zero, a recycled block is not)
     const char* poison = std::getenv("MOE_POOL_POISON");

@@ -8,6 +8,7 @@
 //  * blocked right-looking Cholesky (NB = 64) + explicit inverse of the factor: replaces ComputeCholeskyFactorL
 //    (gpp_linear_algebra.cpp:109-148) and turns every TriangularMatrixVectorSolve (:160-187) of the reference into a
 //    GEMM against L^-1, which is what lets the posterior solves run wide instead of as 1000 dependent steps.
+#include <exception>
 #include <algorithm>
 #include <functional>
 #include <cmath>
@@ -1971,7 +1972,20 @@ void launch_cholesky_and_inverse(int N, double* A, long lda, double* Linv, long 
   double* work_lead = work;
   double* work_trail = work;
   double* work_top = work;
-  hipEvent_t ev_cols = nullptr, ev_side = nullptr;
+  // (the two events of the early-inverse schedule: destroyed on every way out; when an exception unwinds through here the side stream
+  //  may hold queued work nobody waits for any more -- it is drained before the buffers it touches can be released)
+  struct SideGuard {
+    hipEvent_t cols = nullptr, side_ev = nullptr;
+    hipStream_t side_stream = nullptr;
+    int exceptions = std::uncaught_exceptions();
+    ~SideGuard() {
+      if (side_stream != nullptr && std::uncaught_exceptions() > exceptions) (void)hipStreamSynchronize(side_stream);
+      if (cols) (void)hipEventDestroy(cols);
+      if (side_ev) (void)hipEventDestroy(side_ev);
+    }
+  } guard;
+  hipEvent_t& ev_cols = guard.cols;
+  hipEvent_t& ev_side = guard.side_ev;
   std::function<void()> hook;
   if (H > 0) {
     work_lead = work + chol_scratch_doubles(N);
@@ -1979,6 +1993,7 @@ void launch_cholesky_and_inverse(int N, double* A, long lda, double* Linv, long 
     work_top = work_trail + trtri_level_doubles(N - H, H);
     MOE_HIP_CHECK(hipEventCreateWithFlags(&ev_cols, hipEventDisableTiming));
     MOE_HIP_CHECK(hipEventCreateWithFlags(&ev_side, hipEventDisableTiming));
+    guard.side_stream = side;
     hook = [&] {
       MOE_HIP_CHECK(hipEventRecord(ev_cols, s));
       MOE_HIP_CHECK(hipStreamWaitEvent(side, ev_cols, 0));
@@ -2027,8 +2042,6 @@ void launch_cholesky_and_inverse(int N, double* A, long lda, double* Linv, long 
       trtri_levels(A, lda, Linv, ldl, N, work, s);
     }
   }
-  if (ev_cols) (void)hipEventDestroy(ev_cols);
-  if (ev_side) (void)hipEventDestroy(ev_side);
   MOE_HIP_CHECK(hipGetLastError());
 }
 

@@ -352,10 +352,16 @@ void sharded_items(const Comm& comm, int n, int width,
     if (!idx.empty()) eval_local(idx, send.data() + 4);
   } catch (const Error& e) {
     mine = e;
-    send[0] = (double)e.code;
-    send[1] = e.payload[0];
-    send[2] = e.payload[1];
-    send[3] = e.payload[2];
+  } catch (const std::exception& e) {  // (bad_alloc, ...: this rank still joins the exchange -- no rank is left waiting in it)
+    mine = Error(MOE_ERR_RUNTIME, std::string("exception in a rank's share of a multi-rank evaluation: ") + e.what());
+  } catch (...) {
+    mine = Error(MOE_ERR_RUNTIME, "unknown exception in a rank's share of a multi-rank evaluation");
+  }
+  if (mine.code != MOE_OK) {
+    send[0] = (double)mine.code;
+    send[1] = mine.payload[0];
+    send[2] = mine.payload[1];
+    send[3] = mine.payload[2];
     std::fill(send.begin() + 4, send.end(), 0.0);
   }
   if (W > 1) {
