@@ -87,8 +87,26 @@ def cpu_baseline(w, best, sample_mc, log, budget_s=60.0):
                 sweep.append({"threads": T, "evals_per_s": T / full, "sample_mc": list(counts), "wall_s": walls, "T0_s": t0,
                               "per_sample_s": t_s, "linear_in_M_evals_per_s": T / (walls[1] * w.M / float(counts[1]))})
             top = max(sweep, key=lambda e: e["evals_per_s"])
+            # r6: the best point of the sweep measured a SECOND time (its spread says how far to trust the sweep),
+            # and what the host looks like to this process -- the sweep usually peaks far below the core count: every thread's State
+            # owns a copy of the fantasy GP and streams its (N + m)^2 factor (8 MB at C3) through two triangular sweeps per MC sample
+            # (gpp_math.cpp:531-551), so beyond a few dozen threads the run is bound by the sockets' memory bandwidth and the shared
+            # L3, and threads placed across NUMA nodes (no OMP_PROC_BIND in the reference's own drivers) make it worse, not better
+            repeat = None
+            if top["threads"] > 1 and time.time() - t_begin <= 1.5 * budget_s:
+                T = top["threads"]
+                Xq_all = np.ascontiguousarray(w.Xq_restarts[np.arange(T) % len(w.Xq_restarts)])
+                walls = [gp.kg_grad_batch(w.inner_gd, w.bounds, w.discrete, Xq_all, mc, best, w.kg_normals[: (mc + 1) // 2], T)[2]
+                         for mc in top["sample_mc"]]
+                repeat = {"threads": T, "evals_per_s": T / fit(walls, top["sample_mc"])[2], "wall_s": walls}
+            host = {"online_cpus": ncores, "affinity_cpus": len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else None,
+                    "numa_nodes": len([n_ for n_ in os.listdir("/sys/devices/system/node") if n_.startswith("node")])
+                    if os.path.isdir("/sys/devices/system/node") else None,
+                    "omp_env": {k: os.environ[k] for k in ("OMP_NUM_THREADS", "OMP_PROC_BIND", "OMP_PLACES", "GOMP_CPU_AFFINITY") if k in os.environ}}
             return {"value": top["evals_per_s"], "unit": "evals/s", "cores": top["threads"], "kind": "reference",
-                    "host_cores": ncores, "one_core_evals_per_s": one_core, "thread_sweep": sweep,
+                    "host_cores": ncores, "one_core_evals_per_s": one_core, "thread_sweep": sweep, "repeat_of_best": repeat, "host": host,
+                    "why_the_sweep_peaks_below_the_core_count": "one 8 MB factor per thread streamed twice per MC sample: memory-bandwidth / "
+                                                                "L3 bound beyond a few dozen threads; threads unpinned, as in the reference's drivers",
                     "model": "T(M) = T0 + M t_s per evaluation, from two sample counts per thread count, read at M = %d" % w.M,
                     "sample": "1 core: ComputeGradKnowledgeGradient at n=%d d=%d q=%d with %d and %d of the %d MC samples "
                               "(%.1f + %.1f s); sweep: T independent evaluations under OpenMP (one per thread) with two sample counts "
@@ -286,7 +304,7 @@ def run_suggest(args, rank, local_rank, world, comm, log):
         best_all = np.sum(np.array(allb), axis=0)
     starts = np.stack([mapi.latin_hypercube(pb["uniform_seed"] + k, pb["bounds"], pb["outer_gd"][0]) for k in range(q)], axis=1)
     normals = mapi.normal_draws(pb["normal_seed"], ((M + 1) // 2) * q)
-    ex = mdist.Exchange.from_comm(comm) if world > 1 else None
+    ex = mdist.make_exchange(comm, local_rank) if world > 1 else None   # (RCCL data plane: the library's native communicator, r6)
 
     def suggestion():
         return G.kg_multistart(pb["outer_gd"], pb["inner_gd"], pb["bounds"], pb["discrete_all"], starts, None, M, best_all, normals,
@@ -343,7 +361,7 @@ def run_suggest(args, rank, local_rank, world, comm, log):
                                "issued, exchange included"},
     }
     if ex is not None:
-        out["exchange"] = {"calls_per_suggestion": ex.calls / float(steps), "doubles_per_call": ex.doubles / float(max(ex.calls, 1)),
+        out["exchange"] = {"provider": type(ex).__name__, "calls_per_suggestion": ex.calls / float(steps), "doubles_per_call": ex.doubles / float(max(ex.calls, 1)),
                            "ms_per_call": 1e3 * ex.seconds / max(ex.calls, 1), "s_per_suggestion": ex.seconds / steps}
     if not args.no_cpu_baseline and world == 1:
         try:
@@ -454,7 +472,7 @@ def side_configs(local_rank, log, c5_traffic=True):
         flops = w.M * npts * (S * f_val + Gp * f_grad)
         mc_ms = ms_mc / steps       # per evaluation (HIP events on the library's stream: sample pre-pass + weight table + MC kernel)
         kinfo = G.last_kernel_info()
-        kname = {0: "kg_mc_kernel", 1: "kg_mc_block_kernel", 2: "kg_mc_stream_kernel", 3: "kg_mc_gang_kernel"}[kinfo["variant"]]
+        kname = {0: "kg_mc_kernel", 1: "kg_mc_block_kernel", 2: "kg_mc_stream_kernel"}[kinfo["variant"]]
         out["C5"] = {"workload": "d-KG value+gradient, n=2000 d=12 q=8 g=3 M=20000, 2 evaluations per call", "evals_per_s": 2 * steps / dt,
                      "gp_build_ms": build_ms, "mc_phase_ms_per_eval": mc_ms, "kernel": kname,
                      "frac": flops / (mc_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS, "bound": "fp64_valu", "peak_tflops": FP64_PEAK_TFLOPS,
@@ -773,7 +791,7 @@ def main():
         cov_tbs = cov_bytes_launch / (cov_launch_ms * 1e-3) / 1e12 if cov_launch_ms > 0 else 0.0
         # (which MC kernel the library launched for this shape: wave-per-sample, workgroup-per-sample, or streamed-weights -- r3)
         kinfo = G.last_kernel_info()
-        mc_kernel = {0: "kg_mc_kernel", 1: "kg_mc_block_kernel", 2: "kg_mc_stream_kernel", 3: "kg_mc_gang_kernel"}[kinfo["variant"]]
+        mc_kernel = {0: "kg_mc_kernel", 1: "kg_mc_block_kernel", 2: "kg_mc_stream_kernel"}[kinfo["variant"]]
         if kinfo["variant"] == 0 and kinfo.get("lane"):
             mc_kernel = "kg_mc_lane_kernel"   # r5: the lane-parked form of the LDS-table kernel (csrc/kg_mc_lane.hpp)
         pmc, traffic_src = (None, "skipped (--no-traffic)")

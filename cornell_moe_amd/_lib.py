@@ -81,6 +81,12 @@ SIGNATURES = {
     "moe_pool_held_bytes": (C.c_longlong, []),
     "moe_pool_trim": (C.c_int, []),
     "moe_debug_sharded_items": (C.c_int, [C.POINTER(Comm), C.c_int, C.c_int, C.c_double, C.c_int, dp, _EP]),
+    "moe_rccl_unique_id": (C.c_int, [C.c_char_p, _EP]),
+    "moe_rccl_create": (C.c_int, [C.c_char_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p), _EP]),
+    "moe_rccl_comm": (C.c_int, [C.c_void_p, C.POINTER(Comm)]),
+    "moe_rccl_allreduce_sum": (C.c_int, [C.c_void_p, dp, C.c_int, _EP]),
+    "moe_rccl_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong), C.POINTER(C.c_double)]),
+    "moe_rccl_destroy": (None, [C.c_void_p]),
     "moe_kg_multistart_comm": (C.c_int, [_GP, C.POINTER(Comm), C.c_int, C.POINTER(GdParams), C.POINTER(GdParams), dp, dp, C.c_int,
                                          dp, C.c_int, dp, C.c_int, C.c_int, C.c_int, C.c_double, dp, C.c_int, dp, dp, ip, _EP]),
     "moe_kg_mcmc_multistart_comm": (C.c_int, [_GPA, C.c_int, C.c_int, C.POINTER(Comm), C.c_int, C.POINTER(GdParams),

@@ -219,10 +219,7 @@ int moe_gp_grad_variance(const moe_gp_t* gp_c, const double* pts, int num_pts, i
     std::unique_lock<std::mutex> lk;
     moe::GpDev& gp = lock_gp(gp_c, lk);
     require(num_derivs >= 0 && num_derivs <= num_pts, "num_derivs must be in [0, num_pts]");
-    moe::StateHost h;
-    moe::compute_state(gp, pts, num_pts, gp.derivs, num_derivs, nullptr, 0, false, nullptr, &h);
-    const size_t blk = (size_t)gp.d * h.lay.m * h.lay.m;
-    for (int p = 0; p < num_derivs; ++p) moe::host_grad_variance_per_point(h, p, out + blk * p);
+    moe::grad_variance_on_device(gp, pts, num_pts, num_derivs, false, out);  // r6: the m x m x d algebra on the device (query_grad.hip)
   });
 }
 
@@ -232,19 +229,7 @@ int moe_gp_grad_cholesky_variance(const moe_gp_t* gp_c, const double* pts, int n
     std::unique_lock<std::mutex> lk;
     moe::GpDev& gp = lock_gp(gp_c, lk);
     require(num_derivs >= 0 && num_derivs <= num_pts, "num_derivs must be in [0, num_pts]");
-    moe::StateHost h;
-    moe::compute_state(gp, pts, num_pts, gp.derivs, num_derivs, nullptr, 0, false, nullptr, &h);
-    const int m = h.lay.m;
-    std::vector<double> chol((size_t)m * m);
-    moe::host_variance(h, chol.data());
-    const int lm = moe::host_cholesky(m, chol.data());
-    if (lm != 0)
-      throw moe::Error(MOE_ERR_SINGULAR,
-                       "GP-Variance matrix singular. Check for duplicate points_to_sample or points_to_sample "
-                       "duplicating points_sampled with 0 noise.",
-                       m, lm);
-    const size_t blk = (size_t)gp.d * m * m;
-    for (int p = 0; p < num_derivs; ++p) moe::host_grad_cholesky_per_point(h, p, chol.data(), out + blk * p);
+    moe::grad_variance_on_device(gp, pts, num_pts, num_derivs, true, out);
   });
 }
 

@@ -155,5 +155,8 @@ void compute_state_batch(GpDev& gp, const double* U_all, int u, const DerivList&
 // keep the host algebra (kDeviceVarianceMinM).
 constexpr int kDeviceVarianceMinM = 33;
 void variance_on_device(GpDev& gp, const double* pts, int k, bool cholesky, double* out);
+// r6 (query_grad.hip): ComputeGradVarianceOfPoints / ComputeGradCholeskyVarianceOfPoints (gpp_math.cpp:1267-1474) for the first
+// `num_derivs` of the `num_pts` points, the m x m x d algebra on the device: out[num_derivs][d m m] in the reference's layout.
+void grad_variance_on_device(GpDev& gp, const double* pts, int num_pts, int num_derivs, bool cholesky, double* out);
 
 }  // namespace moe

@@ -995,15 +995,6 @@ void launch_mc_stream(const KgMcParams& P, int dp, int G, int blocks, int waves,
   }
 }
 
-void launch_mc_gang(const KgMcParams& P, int dp, int G, int W, int lds_tiles, int blocks, size_t shm, hipStream_t s) {
-  switch (dp) {
-    case 8: launch_kg_mc_gang_dp8(P, G, W, lds_tiles, blocks, shm, s); break;
-    case 12: launch_kg_mc_gang_dp12(P, G, W, lds_tiles, blocks, shm, s); break;
-    case 16: launch_kg_mc_gang_dp16(P, G, W, lds_tiles, blocks, shm, s); break;
-    default: throw Error(MOE_ERR_RUNTIME, "unsupported padded dimension in the gang MC kernel");
-  }
-}
-
 void launch_mc_block(const KgMcParams& P, int dp, int G, int tr, int num_lds_tiles, int blocks, int waves, hipStream_t s) {
   switch (dp) {
     case 4: launch_kg_mc_block_dp4(P, G, tr, num_lds_tiles, blocks, waves, s); break;
@@ -1190,22 +1181,6 @@ KgPending kg_launch(GpDev& gp, int num_fidelity, const moe_gd_params_t& gd, cons
   }
   // (the simplex update lives in line_search_lds: the streamed-weights or the workgroup-per-sample kernel)
   if (simplex && variant == 0) variant = stream_ok ? 2 : 1;
-  // Variant 3 (r6), the gang kernel (kg_mc_gang.hpp): what the streamed-weights kernel would take, with the sample shared by W
-  // wavefronts that keep its weights in registers -- the table is read once per sample instead of once per sweep.  Lane-parked line
-  // search with dot-product distances: tensor-product inner domain, frames within 100 length scales, padded dimension 8 / 12 / 16;
-  // W from the evaluation's shape alone (4: <= 32 tiles and <= 4 derivative slots; 8: <= 64 tiles, or 8 / 12 slots and <= 32 tiles).
-  int gang_w = 0;
-  if (!simplex && !far_frame && !wide_frame && (dp == 8 || dp == 12 || dp == 16) && stream_ok) {
-    if (G <= 4 && ntiles <= 32) gang_w = 4;
-    else if (G <= 4 && ntiles <= 64) gang_w = 8;
-    else if ((G == 8 || G == 12) && G <= dp && ntiles <= 32) gang_w = 8;
-  }
-  if (gang_w != 0) {
-    const int gang_min_tiles = env_int("MOE_KG_GANG_MIN_TILES", 12);
-    if (variant == 2 && std::getenv("MOE_KG_VARIANT") == nullptr && env_int("MOE_KG_GANG", 1) != 0 && ntiles >= gang_min_tiles) variant = 3;
-  } else if (variant == 3) {
-    throw Error(MOE_ERR_RUNTIME, "the gang MC kernel is not built for this shape");
-  }
   if (variant == 1 && (tr < 0 || kg_mc_block_lds_bytes(dp, G, num_lds_tiles) > (size_t)160 * 1024))
     throw Error(MOE_ERR_RUNTIME, "point set too large for the workgroup-per-sample MC kernel");
   if (variant == 0 && waves < 1)
@@ -1248,11 +1223,6 @@ KgPending kg_launch(GpDev& gp, int num_fidelity, const moe_gd_params_t& gd, cons
         wide_lds_tiles = 0;
       }
     }
-  } else if (variant == 3) {
-    waves = 8 / gang_w;  // (samples in flight per workgroup: what the grid arithmetic below calls waves)
-    wide_lds_tiles = (int)std::min<size_t>((size_t)ntiles, ((size_t)160 * 1024 - kg_mc_gang_lds_bytes(dp, 0)) / (sizeof(double) * (dp + 1) * 64));
-    wide_lds_tiles = std::max(0, std::min(wide_lds_tiles, env_int("MOE_KG_WIDE_LDS_TILES", wide_lds_tiles)));
-    shm = kg_mc_gang_lds_bytes(dp, wide_lds_tiles);
   } else if (variant == 2) {
     waves = std::max(1, std::min(8, env_int("MOE_KG_WAVES", 8)));
     shm = sizeof(double) * (kExpTabLen + (size_t)waves * mc::kWideScratch);
@@ -1489,7 +1459,7 @@ KgPending kg_launch(GpDev& gp, int num_fidelity, const moe_gd_params_t& gd, cons
   {
     dim3 grid((unsigned)((tab_stride + 255) / 256), E);
     hipLaunchKernelGGL(build_xs_tab_kernel, grid, dim3(256), 0, s, gp.dX.p, n, gp.dUnion, u, dp, ntiles, tp, dTab.p, tab_stride,
-                       (wide_dp || variant == 2 || (variant == 0 && mc::wide_eval(dp, xlds))) ? 1 : 0, dCounters.p, (long)n_ctr);  // (the gang kernel: plain rows)
+                       (wide_dp || variant == 2 || (variant == 0 && mc::wide_eval(dp, xlds))) ? 1 : 0, dCounters.p, (long)n_ctr);
     MOE_HIP_CHECK(hipGetLastError());
   }
   t_state.stop(s);
@@ -1566,8 +1536,8 @@ KgPending kg_launch(GpDev& gp, int num_fidelity, const moe_gd_params_t& gd, cons
     }
     MOE_HIP_CHECK(hipGetLastError());
   }
-  mp.v_stride = (variant >= 2) ? v_stride_tiles : N;  // (whole tiles: the streamed-weights and the gang kernel)
-  mp.v_slots1 = (variant >= 2) ? 1 + G : g1;
+  mp.v_stride = (variant == 2) ? v_stride_tiles : N;
+  mp.v_slots1 = (variant == 2) ? 1 + G : g1;
   if (variant >= 1 && mp.best_j != nullptr) {
     const long total = (long)E * num_local;
     // the weight table: N doubles per sample (1.28 GB per evaluation at C5); beyond its cap -- the caller's share of the
@@ -1581,14 +1551,12 @@ KgPending kg_launch(GpDev& gp, int num_fidelity, const moe_gd_params_t& gd, cons
       launch_sample_weights(mp, gp.kV.p, s);
     }
   }
-  if (variant >= 2 && (mp.V == nullptr || mp.best_j == nullptr))
-    throw Error(MOE_ERR_RUNTIME, "streamed-weights / gang MC kernel selected without its weight table");
+  if (variant == 2 && (mp.V == nullptr || mp.best_j == nullptr))
+    throw Error(MOE_ERR_RUNTIME, "streamed-weights MC kernel selected without its weight table");
   if (variant == 0 && lane_kernel)
     launch_mc_lane(mp, dp, G, fly_kernel, rec_head, blocks, waves, shm, s);
   else if (variant == 0)
     launch_mc(mp, dp, G, xlds, blocks, waves, shm, s);
-  else if (variant == 3)
-    launch_mc_gang(mp, dp, G, gang_w, wide_lds_tiles, blocks, shm, s);
   else if (variant == 2)
     launch_mc_stream(mp, dp, G, blocks, waves, shm, s);
   else
@@ -1597,7 +1565,7 @@ KgPending kg_launch(GpDev& gp, int num_fidelity, const moe_gd_params_t& gd, cons
   {
     // (bits 1 / 2 of the second word, r4: the frame-extent decisions -- a domain box or point set wider than 100 length scales
     //  silently costs the LDS-table kernel and the multi-trial passes; this is where a caller can see it)
-    const int info[8] = {variant, ((variant == 0 && xlds) ? 1 : 0) | (far_frame ? 2 : 0) | (wide_frame ? 4 : 0) | (lane_kernel ? 8 : 0) | (fly_kernel ? 16 : 0), variant == 3 ? gang_w : waves, variant == 1 ? tr : wide_lds_tiles, mp.V != nullptr ? 1 : 0, 0, blocks,
+    const int info[8] = {variant, ((variant == 0 && xlds) ? 1 : 0) | (far_frame ? 2 : 0) | (wide_frame ? 4 : 0) | (lane_kernel ? 8 : 0) | (fly_kernel ? 16 : 0), waves, variant == 1 ? tr : wide_lds_tiles, mp.V != nullptr ? 1 : 0, 0, blocks,
                          mp.best_j != nullptr ? 1 : 0};
     std::copy(info, info + 8, gp.last_info);
   }

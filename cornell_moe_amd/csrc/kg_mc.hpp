@@ -134,13 +134,6 @@ void launch_kg_mc_lane_dp16(const KgMcParams& P, int G, bool fly, int rec_head, 
 size_t kg_mc_lane_fixed_bytes(int dp, int rec_head);  // LDS in front of the coordinate table
 size_t kg_mc_lane_fly_bytes(int dp, int ntiles, int rec_head, int waves);  // all of the on-the-fly-weights instantiation's LDS
 
-// Gang kernel (r6, kg_mc_gang.hpp): a sample shared by W wavefronts of a workgroup, its weights in registers (read ONCE from the table
-// P.V), the leading `lds_tiles` tiles of the plain coordinate table in LDS; `shm` = kg_mc_gang_lds_bytes(dp, lds_tiles).
-void launch_kg_mc_gang_dp8(const KgMcParams& P, int G, int W, int lds_tiles, int blocks, size_t shm, hipStream_t s);
-void launch_kg_mc_gang_dp12(const KgMcParams& P, int G, int W, int lds_tiles, int blocks, size_t shm, hipStream_t s);
-void launch_kg_mc_gang_dp16(const KgMcParams& P, int G, int W, int lds_tiles, int blocks, size_t shm, hipStream_t s);
-size_t kg_mc_gang_lds_bytes(int dp, int lds_tiles);
-
 // Streamed-weights wave-per-sample kernel (kg_mc_stream_kernel): weights from the table P.V, P.wide_lds_tiles tiles of coordinates in LDS.
 void launch_kg_mc_stream_dp4(const KgMcParams& P, int G, int blocks, int waves, size_t shm, hipStream_t s);
 void launch_kg_mc_stream_dp8(const KgMcParams& P, int G, int blocks, int waves, size_t shm, hipStream_t s);
@@ -2986,7 +2979,6 @@ inline void launch_block_dp(const KgMcParams& P, int G, int tr, int num_lds_tile
 }
 
 #include "kg_mc_lane.hpp"
-#include "kg_mc_gang.hpp"
 
 template <int DP, int G, bool XLDS, bool SMALL>
 inline void launch_inst2(const KgMcParams& P, int blocks, int waves, size_t shm, hipStream_t s) {

@@ -226,247 +226,6 @@ __device__ __forceinline__ double value_pass_fly(const double* __restrict__ xs, 
   return -(mean + wave_sum_uniform(accf));
 }
 
-// The passes of the LDS-slab kernel: the whole point set per wavefront, coordinates `xs` and this wave's weights `aw` in LDS.
-template <int DP, int G, int WM>
-struct SlabPasses {
-  const double* __restrict__ xs;
-  const double* __restrict__ aw;
-  const double* __restrict__ etab;
-  int ntiles, cov_type, lane;
-  double mean;
-  const FlyWeights* fwp;
-  __device__ __forceinline__ double grad(const double (&xq)[DP], double, lds_rw_ptr R1, double& g_l) const {
-    return (cov_type == MOE_COV_SQUARE_EXPONENTIAL)
-               ? grad_pass_parked<DP, G, MOE_COV_SQUARE_EXPONENTIAL, WM>(xs, aw, etab, ntiles, mean, xq, R1, lane, g_l, fwp)
-               : grad_pass_parked<DP, G, MOE_COV_MATERN_NU_2P5, WM>(xs, aw, etab, ntiles, mean, xq, R1, lane, g_l, fwp);
-  }
-  template <int T>
-  __device__ __forceinline__ bool multi(const double (&x2)[DP], const double (&d2)[DP], double, double, double sxx, double sxd, double sdd,
-                                        double alpha0, double (&f)[T]) const {
-    return (cov_type == MOE_COV_SQUARE_EXPONENTIAL)
-               ? eval_multi_loop_s<DP, MOE_COV_SQUARE_EXPONENTIAL, T, false, true, G, WM>(xs, aw, etab, ntiles, mean, x2, d2, sxx, sxd, sdd,
-                                                                                          alpha0, lane, f, fwp)
-               : eval_multi_loop_s<DP, MOE_COV_MATERN_NU_2P5, T, false, true, G, WM>(xs, aw, etab, ntiles, mean, x2, d2, sxx, sxd, sdd, alpha0,
-                                                                                     lane, f, fwp);
-  }
-  __device__ __forceinline__ double value(const double (&q2)[DP], double) const {
-    if constexpr (WM > 0) {
-      return (cov_type == MOE_COV_SQUARE_EXPONENTIAL)
-                 ? value_pass_fly<DP, MOE_COV_SQUARE_EXPONENTIAL, WM>(xs, aw, etab, ntiles, mean, q2, lane, *fwp)
-                 : value_pass_fly<DP, MOE_COV_MATERN_NU_2P5, WM>(xs, aw, etab, ntiles, mean, q2, lane, *fwp);
-    } else {
-      double unused[DP];
-      return eval_pass<DP, G, false, false, true, true, false>(xs, aw, etab, ntiles, cov_type, mean, q2, nullptr, unused, lane);
-    }
-  }
-};
-
-// What a lane-parked line search asks of its evaluator `ps` (SlabPasses below: the LDS-slab kernel's passes; kg_mc_gang.hpp: a gang of
-// wavefronts sharing one sample):
-//   double ps.grad(xq, xq_l, R1, g_l)   f and grad f (frame coordinates, lane k < DP holds component k) at the frame point xq; R1 = scratch
-//   bool   ps.multi<T>(x2, d2, x2_l, d2_l, sxx, sxd, sdd, alpha0, f)   T Armijo trials in one sweep (eval_multi_loop_s); false = not evaluated
-//   double ps.value(q2, q2_l)           f at the frame point -q2 / 2
-// (every wave-uniform vector comes with its lane-parked copy `_l` -- lane r < DP holds row r: an evaluator that hands the vector on to
-//  other wavefronts stores it from there with one instruction)
-// Everything else -- the reference's sequence of decisions (gpp_optimization.hpp:708-828, 1242-1283), TensorProductDomain::LimitUpdate
-// (gpp_domain.cpp:64-105) one coordinate per lane, the carried clamped-step pass -- is here, once.  On entry xo_l = the start point
-// (original units, lane r < DP: table row r); on return the end point.  C = the lane constants (fill_lane_constants), Z = 2 kMaxM
-// doubles of the wave's scratch.
-template <int DP, class PS>
-__device__ __forceinline__ void lane_line_search(const KgMcParams& P, const PS& ps, const volatile __attribute__((address_space(3))) double* C,
-                                                 lds_rw_ptr Z, int lane, double& xo_l, double& fcur, unsigned int& n_val,
-                                                 unsigned int& n_grad) {
-  const int lk = lane < DP ? lane : 0;
-  const bool in_l = lane < DP;
-  const double s_l = C[lk], is_l = C[DP + lk], c_l = C[2 * DP + lk], pin_l = C[3 * DP + lk];
-  const double lo_l = C[4 * DP + lk], hi_l = C[5 * DP + lk];
-  const bool free_l = in_l && C[7 * DP + lk] != 0.0;
-  const int max_num_steps = P.max_num_steps, max_num_restarts = P.max_num_restarts;
-  if (max_num_restarts <= 0) {
-    // reference returns without touching its outputs (.cpp:425-427): value 0, point filled with 1.0 (.cpp:163)
-    xo_l = pin_l;
-  } else {
-    const double tolerance = P.tolerance;
-    const double step_tolerance = tolerance / (double)max_num_steps;
-    // rows of the wave's scratch (z / beta are spent): three broadcast rows of kMaxLaneDP + 1, the gradient sums and their dump area
-    lds_rw_ptr R0 = Z, R2 = Z + (kMaxLaneDP + 1), R3 = Z + 2 * (kMaxLaneDP + 1), R1 = Z + 3 * (kMaxLaneDP + 1);
-    static_assert(3 * (kMaxLaneDP + 1) + 2 * kMaxLaneDP + 4 <= 2 * kMaxM, "line-search rows exceed the wave's scratch");
-    double xf_l = (xo_l - c_l) * s_l;  // the iterate in the frame: it only feeds the evaluator (see line_search_frame)
-    double gf_l = 0.0;
-    bool have_g = false;  // a clamped step's f(x + step) and the next iteration's gradient are ONE pass, carried over
-    double f_carried = 0.0, g_carried_l = 0.0;
-    int pred = 1;  // Armijo trials the previous step consumed
-    for (int restart = 0; restart < max_num_restarts; ++restart) {
-      const double xstart_l = xf_l;
-      for (int istep = 0; istep < max_num_steps;) {
-        // ---- f(x), grad f(x) ----
-        double f0;
-        if (have_g) {
-          f0 = f_carried;
-          gf_l = g_carried_l;
-          have_g = false;
-        } else {
-          double xq[DP];
-          lane_broadcast<DP>(xf_l, R0, lane, xq);
-          make_scalar<DP>(xq);
-          f0 = ps.grad(xq, xf_l, R1, gf_l);
-        }
-        f0 = uniform(f0);  // (tells the compiler: the Armijo decisions below are scalar branches)
-        n_grad++;
-        fcur = f0;
-        // the gradient in the original units (pinned rows 0), d2 = -2 g s, x2 = -2 x' (line_search_frame), |g|^2 in row order
-        const double g_l = free_l ? gf_l * s_l : 0.0;
-        const double d2_l = -2.0 * (g_l * s_l);
-        const double x2_l = -2.0 * xf_l;
-        double norm = 0.0;
-        {
-          double gk[DP];
-          lane_broadcast<DP>(g_l, R0, lane, gk);
-#pragma unroll
-          for (int k = 0; k < DP; ++k) norm = fma(gk[k], gk[k], norm);
-          norm = uniform(norm);
-        }
-        double x2[DP], d2[DP];
-        lane_broadcast<DP>(x2_l, R2, lane, x2);
-        lane_broadcast<DP>(d2_l, R3, lane, d2);
-        double sxx = 0.0, sxd = 0.0, sdd = 0.0;  // (fixed along the trial line: formed once per step, eval_multi_loop's order)
-#pragma unroll
-        for (int k = 0; k < DP; ++k) {
-          sxx = fma(x2[k], x2[k], sxx);
-          sxd = fma(x2[k], d2[k], sxd);
-          sdd = fma(d2[k], d2[k], sdd);
-        }
-        sxx = uniform(sxx);
-        sxd = uniform(sxd);
-        sdd = uniform(sdd);
-        make_scalar<DP>(x2);
-        make_scalar<DP>(d2);
-        // pre_mult * (i+1)^-gamma (gpp_optimization.hpp:741); x^-0 == 1 exactly, so gamma == 0 needs no pow()
-        double alpha_n = uniform((P.gamma == 0.0) ? P.pre_mult : P.pre_mult * pow((double)(istep + 1), -P.gamma));
-        // ---- Armijo back-tracking (.hpp:745-760), several trial step sizes per sweep: line_search_frame's schedule ----
-        int search = 0;
-        double ftrial = 0.0;
-        {
-          int batch = pred;
-          bool done = false;
-          while (!done) {
-            bool evaluated = false;
-            if (P.multi_trial != 0) {
-              const int want = min(batch, 30 - search);
-              if (want >= 2) {
-                // T trials in one sweep, then the reference's sequence of decisions over them (gpp_optimization.hpp:752-769): stops at
-                // the first accepted one, halves alpha and counts `search` for every rejected one; only consumed trials are counted
-#define MOE_LANE_TRIALS(T)                                                                                                              \
-  {                                                                                                                                     \
-    double ft[T];                                                                                                                       \
-    evaluated = ps.template multi<T>(x2, d2, x2_l, d2_l, sxx, sxd, sdd, alpha_n, ft);                                                  \
-    if (evaluated) {                                                                                                                    \
-      _Pragma("unroll") for (int t = 0; t < T; ++t) {                                                                                   \
-        if (!done) {                                                                                                                    \
-          ftrial = uniform(ft[t]);                                                                                                            \
-          n_val++;                                                                                                                      \
-          if (ftrial - f0 > 0.5 * alpha_n * norm) {                                                                                     \
-            done = true;                                                                                                                \
-          } else {                                                                                                                      \
-            alpha_n *= 0.5;                                                                                                             \
-            if (++search >= 30) done = true;                                                                                            \
-          }                                                                                                                             \
-        }                                                                                                                               \
-      }                                                                                                                                 \
-    }                                                                                                                                   \
-  }
-                switch (want) {
-                  case 2: MOE_LANE_TRIALS(2) break;
-                  case 3: MOE_LANE_TRIALS(3) break;
-                  case 4: MOE_LANE_TRIALS(4) break;
-                  default: MOE_LANE_TRIALS(5) break;
-                }
-#undef MOE_LANE_TRIALS
-              }
-            }
-            if (!evaluated) {
-              double q2[DP];
-#pragma unroll
-              for (int k = 0; k < DP; ++k) q2[k] = fma(alpha_n, d2[k], x2[k]);
-              ftrial = ps.value(q2, fma(alpha_n, d2_l, x2_l));
-              n_val++;
-              if (ftrial - f0 > 0.5 * alpha_n * norm) {
-                done = true;
-              } else {
-                alpha_n *= 0.5;
-                if (++search >= 30) done = true;
-              }
-            }
-            // (a first trial that fails is usually followed by several halvings: four more at once, then pairs)
-            batch = (batch == 1 && search == 1) ? 4 : 2;
-          }
-          pred = min(search + 1, 5);
-        }
-        // ---- LimitUpdate on the original units, one coordinate per lane, then accept only if f improves (.hpp:762-795) ----
-        const double want_o = alpha_n * (gf_l * s_l);  // alpha grad_r (the frame gradient x scale)
-        double step_o = 0.0;
-        if (free_l) step_o = limit_update_1d(lo_l, hi_l, P.max_relative_change, xo_l, want_o);
-        const bool changed = __ballot(free_l && step_o != want_o) != 0ull;
-        const bool nonzero = __ballot(free_l && step_o != 0.0) != 0ull;
-        // the step in the frame: the trial point's own offset where the clamp left it alone (its value is reused below)
-        const double step_f = changed ? step_o * s_l : (-0.5 * alpha_n) * d2_l;
-        const double st_l = free_l ? step_f : 0.0;
-        if (search == 30 || !nonzero) break;  // .hpp:781-785: x restored (a zero step re-evaluates f(x) == f0: rejected)
-        double obj2 = ftrial;  // the clamp left the step untouched: f(x + step) is the last trial value
-        bool carried = false;
-        double gn_l = 0.0;
-        if (changed) {
-          if (istep + 1 < max_num_steps || restart + 1 < max_num_restarts) {
-            double xq[DP];
-            lane_broadcast<DP>(xf_l + st_l, R0, lane, xq);
-            make_scalar<DP>(xq);
-            obj2 = ps.grad(xq, xf_l + st_l, R1, gn_l);
-            carried = true;
-          } else {
-            double q2[DP];
-            lane_broadcast<DP>(fma(-2.0, st_l, x2_l), R0, lane, q2);
-            obj2 = ps.value(q2, fma(-2.0, st_l, x2_l));
-            n_val++;
-          }
-        }
-        if (obj2 <= f0) {
-          if (carried) n_val++;
-          break;
-        }
-        xf_l += st_l;
-        xo_l += step_o;
-        double ss = 0.0;  // |step|^2 in the original coordinates, row order
-        {
-          double so[DP];
-          lane_broadcast<DP>(st_l * is_l, R0, lane, so);
-#pragma unroll
-          for (int k = 0; k < DP; ++k) ss = fma(so[k], so[k], ss);
-          ss = uniform(ss);  // (a volatile LDS read counts as divergent: without this the loop exits below are vector branches and
-                             //  every scalar of the line search -- alpha, the counters -- lives in vector registers)
-        }
-        fcur = obj2;
-        istep += 1;
-        have_g = carried;
-        f_carried = obj2;
-        g_carried_l = gn_l;
-        if (sqrt(ss) < step_tolerance) break;
-      }
-      double ds = 0.0;
-      {
-        double dk[DP];
-        lane_broadcast<DP>((xstart_l - xf_l) * is_l, R0, lane, dk);
-#pragma unroll
-        for (int k = 0; k < DP; ++k) ds = fma(dk[k], dk[k], ds);
-        ds = uniform(ds);
-      }
-      if (!(sqrt(ds) > tolerance)) break;
-    }
-    if (have_g) n_val++;  // carried but never used
-    if (!free_l) xo_l = pin_l;
-  }
-
-}
-
 // One MC sample on the lane-parked line search.  xs = the workgroup's LDS coordinate table, aw = this wave's weight slab, zb = its
 // scratch (2 kMaxM doubles: z | beta during the set-up, then the line search's rows), cst = the lane constants, rc = the LDS copy of
 // the evaluation's record head [L | mu_disc | C_disc | disc] (offsets as in KgRec).
@@ -599,14 +358,216 @@ __device__ __forceinline__ void kg_sample_lane(const KgMcParams& P, int e, int s
   // ---- the line search, lane r < DP holding table row r (= original dimension perm_l) ----
   const int lk = lane < DP ? lane : 0;
   const bool in_l = lane < DP;
+  const double s_l = C[lk], is_l = C[DP + lk], c_l = C[2 * DP + lk], pin_l = C[3 * DP + lk];
+  const double lo_l = C[4 * DP + lk], hi_l = C[5 * DP + lk];
   const int perm_l = (int)C[6 * DP + lk];
+  const bool free_l = in_l && C[7 * DP + lk] != 0.0;
   // start: the discretised point's coordinates on the optimised rows, 1 on fidelity rows, 0 on pads (.cpp:353-357)
-  double xo_l = (perm_l < size) ? RC[P.rec.disc + best_j * size + min(perm_l, size - 1)] : C[3 * DP + lk];
+  double xo_l = (perm_l < size) ? RC[P.rec.disc + best_j * size + min(perm_l, size - 1)] : pin_l;
   double fcur = 0.0;
   unsigned int n_val = 0, n_grad = 0;  // passes over the n + u points
-  {
-    const SlabPasses<DP, G, WM> ps{xs, aw, etab, ntiles, P.cov_type, lane, P.mean, fwp};
-    lane_line_search<DP>(P, ps, C, Z, lane, xo_l, fcur, n_val, n_grad);
+  const int max_num_steps = P.max_num_steps, max_num_restarts = P.max_num_restarts;
+  if (max_num_restarts <= 0) {
+    // reference returns without touching its outputs (.cpp:425-427): value 0, point filled with 1.0 (.cpp:163)
+    xo_l = pin_l;
+  } else {
+    const double tolerance = P.tolerance;
+    const double step_tolerance = tolerance / (double)max_num_steps;
+    const double mean = P.mean;
+    const int cov_type = P.cov_type;
+    // rows of the wave's scratch (z / beta are spent): three broadcast rows of kMaxLaneDP + 1, the gradient sums and their dump area
+    lds_rw_ptr R0 = Z, R2 = Z + (kMaxLaneDP + 1), R3 = Z + 2 * (kMaxLaneDP + 1), R1 = Z + 3 * (kMaxLaneDP + 1);
+    static_assert(3 * (kMaxLaneDP + 1) + 2 * kMaxLaneDP + 4 <= 2 * kMaxM, "line-search rows exceed the wave's scratch");
+    double xf_l = (xo_l - c_l) * s_l;  // the iterate in the frame: it only feeds the evaluator (see line_search_frame)
+    double gf_l = 0.0;
+    bool have_g = false;  // a clamped step's f(x + step) and the next iteration's gradient are ONE pass, carried over
+    double f_carried = 0.0, g_carried_l = 0.0;
+    int pred = 1;  // Armijo trials the previous step consumed
+    for (int restart = 0; restart < max_num_restarts; ++restart) {
+      const double xstart_l = xf_l;
+      for (int istep = 0; istep < max_num_steps;) {
+        // ---- f(x), grad f(x) ----
+        double f0;
+        if (have_g) {
+          f0 = f_carried;
+          gf_l = g_carried_l;
+          have_g = false;
+        } else {
+          double xq[DP];
+          lane_broadcast<DP>(xf_l, R0, lane, xq);
+          make_scalar<DP>(xq);
+          f0 = (cov_type == MOE_COV_SQUARE_EXPONENTIAL)
+                   ? grad_pass_parked<DP, G, MOE_COV_SQUARE_EXPONENTIAL, WM>(xs, aw, etab, ntiles, mean, xq, R1, lane, gf_l, fwp)
+                   : grad_pass_parked<DP, G, MOE_COV_MATERN_NU_2P5, WM>(xs, aw, etab, ntiles, mean, xq, R1, lane, gf_l, fwp);
+        }
+        f0 = uniform(f0);  // (tells the compiler: the Armijo decisions below are scalar branches)
+        n_grad++;
+        fcur = f0;
+        // the gradient in the original units (pinned rows 0), d2 = -2 g s, x2 = -2 x' (line_search_frame), |g|^2 in row order
+        const double g_l = free_l ? gf_l * s_l : 0.0;
+        const double d2_l = -2.0 * (g_l * s_l);
+        const double x2_l = -2.0 * xf_l;
+        double norm = 0.0;
+        {
+          double gk[DP];
+          lane_broadcast<DP>(g_l, R0, lane, gk);
+#pragma unroll
+          for (int k = 0; k < DP; ++k) norm = fma(gk[k], gk[k], norm);
+          norm = uniform(norm);
+        }
+        double x2[DP], d2[DP];
+        lane_broadcast<DP>(x2_l, R2, lane, x2);
+        lane_broadcast<DP>(d2_l, R3, lane, d2);
+        double sxx = 0.0, sxd = 0.0, sdd = 0.0;  // (fixed along the trial line: formed once per step, eval_multi_loop's order)
+#pragma unroll
+        for (int k = 0; k < DP; ++k) {
+          sxx = fma(x2[k], x2[k], sxx);
+          sxd = fma(x2[k], d2[k], sxd);
+          sdd = fma(d2[k], d2[k], sdd);
+        }
+        sxx = uniform(sxx);
+        sxd = uniform(sxd);
+        sdd = uniform(sdd);
+        make_scalar<DP>(x2);
+        make_scalar<DP>(d2);
+        // pre_mult * (i+1)^-gamma (gpp_optimization.hpp:741); x^-0 == 1 exactly, so gamma == 0 needs no pow()
+        double alpha_n = uniform((P.gamma == 0.0) ? P.pre_mult : P.pre_mult * pow((double)(istep + 1), -P.gamma));
+        // ---- Armijo back-tracking (.hpp:745-760), several trial step sizes per sweep: line_search_frame's schedule ----
+        int search = 0;
+        double ftrial = 0.0;
+        {
+          int batch = pred;
+          bool done = false;
+          while (!done) {
+            bool evaluated = false;
+            if (P.multi_trial != 0) {
+              const int want = min(batch, 30 - search);
+              if (want >= 2) {
+                const bool se = cov_type == MOE_COV_SQUARE_EXPONENTIAL;
+                // T trials in one sweep, then the reference's sequence of decisions over them (gpp_optimization.hpp:752-769): stops at
+                // the first accepted one, halves alpha and counts `search` for every rejected one; only consumed trials are counted
+#define MOE_LANE_TRIALS(T)                                                                                                              \
+  {                                                                                                                                     \
+    double ft[T];                                                                                                                       \
+    evaluated = se ? eval_multi_loop_s<DP, MOE_COV_SQUARE_EXPONENTIAL, T, false, true, G, WM>(xs, aw, etab, ntiles, mean, x2, d2, sxx,  \
+                                                                                              sxd, sdd, alpha_n, lane, ft, fwp)         \
+                   : eval_multi_loop_s<DP, MOE_COV_MATERN_NU_2P5, T, false, true, G, WM>(xs, aw, etab, ntiles, mean, x2, d2, sxx, sxd,  \
+                                                                                         sdd, alpha_n, lane, ft, fwp);                  \
+    if (evaluated) {                                                                                                                    \
+      _Pragma("unroll") for (int t = 0; t < T; ++t) {                                                                                   \
+        if (!done) {                                                                                                                    \
+          ftrial = uniform(ft[t]);                                                                                                            \
+          n_val++;                                                                                                                      \
+          if (ftrial - f0 > 0.5 * alpha_n * norm) {                                                                                     \
+            done = true;                                                                                                                \
+          } else {                                                                                                                      \
+            alpha_n *= 0.5;                                                                                                             \
+            if (++search >= 30) done = true;                                                                                            \
+          }                                                                                                                             \
+        }                                                                                                                               \
+      }                                                                                                                                 \
+    }                                                                                                                                   \
+  }
+                switch (want) {
+                  case 2: MOE_LANE_TRIALS(2) break;
+                  case 3: MOE_LANE_TRIALS(3) break;
+                  case 4: MOE_LANE_TRIALS(4) break;
+                  default: MOE_LANE_TRIALS(5) break;
+                }
+#undef MOE_LANE_TRIALS
+              }
+            }
+            if (!evaluated) {
+              double q2[DP], unused[DP];
+#pragma unroll
+              for (int k = 0; k < DP; ++k) q2[k] = fma(alpha_n, d2[k], x2[k]);
+              if constexpr (WM > 0)
+                ftrial = (cov_type == MOE_COV_SQUARE_EXPONENTIAL)
+                             ? value_pass_fly<DP, MOE_COV_SQUARE_EXPONENTIAL, WM>(xs, aw, etab, ntiles, mean, q2, lane, fw)
+                             : value_pass_fly<DP, MOE_COV_MATERN_NU_2P5, WM>(xs, aw, etab, ntiles, mean, q2, lane, fw);
+              else
+                ftrial = eval_pass<DP, G, false, false, true, true, false>(xs, aw, etab, ntiles, cov_type, mean, q2, nullptr, unused, lane);
+              n_val++;
+              if (ftrial - f0 > 0.5 * alpha_n * norm) {
+                done = true;
+              } else {
+                alpha_n *= 0.5;
+                if (++search >= 30) done = true;
+              }
+            }
+            // (a first trial that fails is usually followed by several halvings: four more at once, then pairs)
+            batch = (batch == 1 && search == 1) ? 4 : 2;
+          }
+          pred = min(search + 1, 5);
+        }
+        // ---- LimitUpdate on the original units, one coordinate per lane, then accept only if f improves (.hpp:762-795) ----
+        const double want_o = alpha_n * (gf_l * s_l);  // alpha grad_r (the frame gradient x scale)
+        double step_o = 0.0;
+        if (free_l) step_o = limit_update_1d(lo_l, hi_l, P.max_relative_change, xo_l, want_o);
+        const bool changed = __ballot(free_l && step_o != want_o) != 0ull;
+        const bool nonzero = __ballot(free_l && step_o != 0.0) != 0ull;
+        // the step in the frame: the trial point's own offset where the clamp left it alone (its value is reused below)
+        const double step_f = changed ? step_o * s_l : (-0.5 * alpha_n) * d2_l;
+        const double st_l = free_l ? step_f : 0.0;
+        if (search == 30 || !nonzero) break;  // .hpp:781-785: x restored (a zero step re-evaluates f(x) == f0: rejected)
+        double obj2 = ftrial;  // the clamp left the step untouched: f(x + step) is the last trial value
+        bool carried = false;
+        double gn_l = 0.0;
+        if (changed) {
+          if (istep + 1 < max_num_steps || restart + 1 < max_num_restarts) {
+            double xq[DP];
+            lane_broadcast<DP>(xf_l + st_l, R0, lane, xq);
+            make_scalar<DP>(xq);
+            obj2 = (cov_type == MOE_COV_SQUARE_EXPONENTIAL)
+                       ? grad_pass_parked<DP, G, MOE_COV_SQUARE_EXPONENTIAL, WM>(xs, aw, etab, ntiles, mean, xq, R1, lane, gn_l, fwp)
+                       : grad_pass_parked<DP, G, MOE_COV_MATERN_NU_2P5, WM>(xs, aw, etab, ntiles, mean, xq, R1, lane, gn_l, fwp);
+            carried = true;
+          } else {
+            double q2[DP], unused[DP];
+            lane_broadcast<DP>(fma(-2.0, st_l, x2_l), R0, lane, q2);
+            if constexpr (WM > 0)
+              obj2 = (cov_type == MOE_COV_SQUARE_EXPONENTIAL)
+                         ? value_pass_fly<DP, MOE_COV_SQUARE_EXPONENTIAL, WM>(xs, aw, etab, ntiles, mean, q2, lane, fw)
+                         : value_pass_fly<DP, MOE_COV_MATERN_NU_2P5, WM>(xs, aw, etab, ntiles, mean, q2, lane, fw);
+            else
+              obj2 = eval_pass<DP, G, false, false, true, true, false>(xs, aw, etab, ntiles, cov_type, mean, q2, nullptr, unused, lane);
+            n_val++;
+          }
+        }
+        if (obj2 <= f0) {
+          if (carried) n_val++;
+          break;
+        }
+        xf_l += st_l;
+        xo_l += step_o;
+        double ss = 0.0;  // |step|^2 in the original coordinates, row order
+        {
+          double so[DP];
+          lane_broadcast<DP>(st_l * is_l, R0, lane, so);
+#pragma unroll
+          for (int k = 0; k < DP; ++k) ss = fma(so[k], so[k], ss);
+          ss = uniform(ss);  // (a volatile LDS read counts as divergent: without this the loop exits below are vector branches and
+                             //  every scalar of the line search -- alpha, the counters -- lives in vector registers)
+        }
+        fcur = obj2;
+        istep += 1;
+        have_g = carried;
+        f_carried = obj2;
+        g_carried_l = gn_l;
+        if (sqrt(ss) < step_tolerance) break;
+      }
+      double ds = 0.0;
+      {
+        double dk[DP];
+        lane_broadcast<DP>((xstart_l - xf_l) * is_l, R0, lane, dk);
+#pragma unroll
+        for (int k = 0; k < DP; ++k) ds = fma(dk[k], dk[k], ds);
+        ds = uniform(ds);
+      }
+      if (!(sqrt(ds) > tolerance)) break;
+    }
+    if (have_g) n_val++;  // carried but never used
+    if (!free_l) xo_l = pin_l;
   }
 
   if (lane == 0) P.best_value[so] = fcur;

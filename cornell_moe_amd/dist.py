@@ -63,7 +63,6 @@ def gather_restarts(local_idx, local_kg, local_grad, num_restarts, group=None, d
     """all_gather the per-restart (KG, grad KG) of every rank; returns arrays ordered by global restart index.
 
     local_idx: global indices this rank evaluated (from shard_restarts); local_kg[len], local_grad[len, q, d]."""
-    import torch
     import torch.distributed as dist
     world = dist.get_world_size(group)
     local_grad = np.asarray(local_grad, dtype=np.float64)
@@ -75,19 +74,49 @@ def gather_restarts(local_idx, local_kg, local_grad, num_restarts, group=None, d
         buf[row, 0] = gi
         buf[row, 1] = kgv
         buf[row, 2:] = local_grad[row].ravel()
-    t = _tensor(buf, device)
-    outs = [torch.empty_like(t) for _ in range(world)]
-    dist.all_gather(outs, t, group=group)
+    rows = _allgather_flat(buf.ravel(), world, group, device).reshape(world * per, 2 + qd)   # ONE collective, ONE copy back
     kg = np.zeros(num_restarts)
     grad = np.zeros((num_restarts,) + tuple(local_grad.shape[1:]))
-    for o in outs:
-        o = o.cpu().numpy()
-        for row in o:
-            gi = int(row[0])
-            if gi >= 0:
-                kg[gi] = row[1]
-                grad[gi] = row[2:].reshape(grad.shape[1:])
+    for row in rows:
+        gi = int(row[0])
+        if gi >= 0:
+            kg[gi] = row[1]
+            grad[gi] = row[2:].reshape(grad.shape[1:])
     return kg, grad
+
+
+_NO_INTO_TENSOR = set()   # (backend names whose all_gather_into_tensor raised: they take the list form from then on)
+
+
+def _allgather_flat(send, world, group, device, bufs=None):
+    """All-gather of a flat float64 array over `group`: recv[world * n] in rank order.  One collective into ONE tensor
+    (all_gather_into_tensor) and -- with the buffers on a device -- ONE device->host copy (r6; until r5 a list all_gather followed by
+    a .cpu() per rank: `world` synchronising copies per exchange).  `bufs`: a dict the caller keeps, so that repeated exchanges of
+    one size reuse their tensors."""
+    import torch
+    import torch.distributed as dist
+    n = int(send.size)
+    key = (n, str(device))
+    if bufs is not None and key in bufs:
+        tin, tout = bufs[key]
+    else:
+        tin = torch.empty(n, dtype=torch.float64, device=device if device is not None else "cpu")
+        tout = torch.empty(world * n, dtype=torch.float64, device=tin.device)
+        if bufs is not None:
+            if len(bufs) > 16:
+                bufs.clear()
+            bufs[key] = (tin, tout)
+    tin.copy_(torch.from_numpy(np.ascontiguousarray(send, dtype=np.float64)))
+    backend = dist.get_backend(group)
+    if backend not in _NO_INTO_TENSOR:
+        try:
+            dist.all_gather_into_tensor(tout, tin, group=group)
+            return tout.cpu().numpy() if tout.is_cuda else tout.numpy().copy()
+        except (RuntimeError, NotImplementedError):
+            _NO_INTO_TENSOR.add(backend)
+    outs = list(tout.view(world, n).unbind(0))   # (views of the one receive tensor: still a single copy back)
+    dist.all_gather(outs, tin, group=group)
+    return tout.cpu().numpy() if tout.is_cuda else tout.numpy().copy()
 
 
 class Exchange(object):
@@ -103,6 +132,7 @@ class Exchange(object):
         self.rank, self.world, self.group, self.device = int(rank), int(world), group, device
         self.calls, self.doubles, self.seconds = 0, 0, 0.0
         self._exc = None
+        self._bufs = {}
         self._impl = allgather or self._torch_allgather
         self._cb = _lib.ALLGATHER_FN(self._callback)  # (kept alive with the object)
         self.c_struct = _lib.Comm(self.rank, self.world, self._cb, None)
@@ -114,14 +144,8 @@ class Exchange(object):
         return cls(comm.rank, comm.world, comm.group, comm.device)
 
     def _torch_allgather(self, send):
-        import torch
-        import torch.distributed as dist
-        t = torch.from_numpy(send)
-        if self.device is not None:
-            t = t.to(self.device)
-        outs = [torch.empty_like(t) for _ in range(self.world)]
-        dist.all_gather(outs, t, group=self.group)
-        return np.concatenate([o.cpu().numpy() for o in outs])
+        # one collective into one preallocated tensor, one copy back (r6; `world` .cpu() calls per exchange before)
+        return _allgather_flat(send, self.world, self.group, self.device, self._bufs)
 
     def _callback(self, ctx, send, recv, count):
         import time
@@ -142,6 +166,116 @@ class Exchange(object):
         if self._exc is not None:
             e, self._exc = self._exc, None
             raise e
+
+
+class NativeExchange(object):
+    """moe_comm_t carried by the library's OWN RCCL communicator (r6; include/moe_hip.h: moe_rccl_*, csrc/rccl_comm.hip): the
+    all-gather of the multi-rank optimisers is ncclAllGather on a stream of the library -- no Python callback inside the optimiser
+    loop.  The 128-byte unique id is made on rank 0 and broadcast over the DEFAULT process group (gloo: the control plane of
+    bring_up); construction is collective over the ranks.  Same attributes as Exchange (c_struct, calls, doubles, seconds, reraise)."""
+
+    def __init__(self, rank, world, device_index, broadcast=None):
+        import ctypes as C
+        from . import _lib
+        L = _lib.load()
+        self.rank, self.world = int(rank), int(world)
+        err = _lib.MoeError()
+        ident = C.create_string_buffer(128)
+        if self.rank == 0:
+            _check_rc(L.moe_rccl_unique_id(ident, C.byref(err)), err)
+        raw = bytes(ident.raw)
+        if self.world > 1:
+            if broadcast is None:
+                import torch.distributed as dist
+                box = [raw if self.rank == 0 else None]
+                dist.broadcast_object_list(box, src=0)
+                raw = box[0]
+            else:
+                raw = broadcast(raw)
+        self._h = C.c_void_p(None)
+        _check_rc(L.moe_rccl_create(raw, self.rank, self.world, int(device_index), C.byref(self._h), C.byref(err)), err)
+        self.c_struct = _lib.Comm()
+        L.moe_rccl_comm(self._h, C.byref(self.c_struct))
+        self._L, self._C = L, C
+        self._base = (0, 0, 0.0)
+
+    @staticmethod
+    def available():
+        """True where a device is visible, librccl can be loaded and hands out a unique id (no communicator is created)."""
+        import ctypes as C
+        from . import _lib
+        if _lib.device_count() <= 0:
+            return False
+        err = _lib.MoeError()
+        return _lib.load().moe_rccl_unique_id(C.create_string_buffer(128), C.byref(err)) == 0
+
+    def _stats(self):
+        C = self._C
+        calls, nbytes, sec = C.c_longlong(0), C.c_longlong(0), C.c_double(0.0)
+        self._L.moe_rccl_stats(self._h, C.byref(calls), C.byref(nbytes), C.byref(sec))
+        return calls.value, nbytes.value, sec.value
+
+    calls = property(lambda self: self._stats()[0] - self._base[0], lambda self, v: self._reset())
+    doubles = property(lambda self: (self._stats()[1] - self._base[1]) // (8 * max(self.world, 1)), lambda self, v: None)
+    seconds = property(lambda self: self._stats()[2] - self._base[2], lambda self, v: None)
+
+    def _reset(self):
+        self._base = self._stats()
+
+    def allreduce_sum(self, values):
+        """In-place sum over the ranks of a float64 array (the MC-sharded evaluation's collective)."""
+        from . import _lib
+        a = np.ascontiguousarray(values, dtype=np.float64)
+        err = _lib.MoeError()
+        _check_rc(self._L.moe_rccl_allreduce_sum(self._h, a.ctypes.data_as(_lib.dp), int(a.size), self._C.byref(err)), err)
+        return a
+
+    def allgather(self, send):
+        """The exchange itself, callable from Python (tests): recv[world][count]."""
+        from . import _lib
+        a = np.ascontiguousarray(send, dtype=np.float64)
+        out = np.zeros(self.world * a.size)
+        rc = self.c_struct.allgather(self.c_struct.ctx, a.ctypes.data_as(_lib.dp), out.ctypes.data_as(_lib.dp), int(a.size))
+        if rc != 0:
+            raise RuntimeError("native RCCL all-gather failed")
+        return out.reshape(self.world, a.size)
+
+    def reraise(self):
+        pass
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self._L.moe_rccl_destroy(self._h)
+            self._h = self._C.c_void_p(None)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # pragma: no cover
+            pass
+
+
+def _check_rc(rc, err):
+    if rc != 0:
+        from .api import OptimalLearningException
+        raise OptimalLearningException(err.message.decode("utf-8", "replace") or "native RCCL exchange failed (code %d)" % rc)
+
+
+def make_exchange(comm, local_rank=0, native=None):
+    """The exchange of the multi-rank optimisers for dist.bring_up()'s Comm: the library's native RCCL communicator where the data
+    plane is RCCL (MOE_NATIVE_RCCL=0, or native=False: torch.distributed's), torch.distributed otherwise (gloo)."""
+    import os
+    if native is None:
+        native = os.environ.get("MOE_NATIVE_RCCL", "1") != "0"
+    if native and comm.world > 1 and comm.backend == "nccl":
+        # construction is collective: the ranks first agree (control plane) that every one of them can load librccl
+        import torch
+        import torch.distributed as dist
+        flag = torch.tensor([1.0 if NativeExchange.available() else 0.0], dtype=torch.float64)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if float(flag.item()) >= 0.5:
+            return NativeExchange(comm.rank, comm.world, local_rank)
+    return Exchange.from_comm(comm)
 
 
 def shard_members(num_mcmc, rank, world):

@@ -354,6 +354,23 @@ int moe_kg_mcmc_multistart_comm(const moe_gp_t* const* local_gps, int num_local,
                                 int num_to_sample, int num_being_sampled, int num_mc, const double* best_so_far_local,
                                 const double* normals, int do_gradient_ascent, double* best_points, double* best_kg, int* found,
                                 moe_error_t* err);
+/* Native exchange (r6): moe_comm_t carried by RCCL itself -- ncclAllGather on a stream and staging buffers the library owns, one pinned
+ * copy in, one out, one stream wait per exchange; the optimiser loop never re-enters the host language.  This is the merge the reference
+ * does under `omp critical` (cpp/gpp_optimization.hpp:1537-1545) once its restarts are dealt to processes, one per GPU.  librccl is
+ * resolved at run time (dlopen; MOE_RCCL_LIB overrides the search): without it these entry points return MOE_ERR_RUNTIME.
+ *   moe_rccl_unique_id: on rank 0; the 128 bytes travel to the other ranks by whatever the host has (dist.py: the gloo control group).
+ *   moe_rccl_create: collective over the `world` ranks (ncclCommInitRank), one rank per device.
+ *   moe_rccl_comm: fills a moe_comm_t (valid while the handle lives) for moe_kg_multistart_comm / moe_kg_mcmc_multistart_comm.
+ *   moe_rccl_allreduce_sum: the MC-sharded evaluation's one collective (1 + q d doubles), host buffer in and out.
+ *   moe_rccl_stats: exchanges so far, bytes received, seconds spent in them. */
+#define MOE_RCCL_ID_BYTES 128
+typedef struct moe_rccl moe_rccl_t;
+int moe_rccl_unique_id(char* id, moe_error_t* err);
+int moe_rccl_create(const char* id, int rank, int world, int device, moe_rccl_t** out, moe_error_t* err);
+int moe_rccl_comm(moe_rccl_t* r, moe_comm_t* out);
+int moe_rccl_allreduce_sum(moe_rccl_t* r, double* inout, int count, moe_error_t* err);
+int moe_rccl_stats(const moe_rccl_t* r, long long* calls, long long* bytes, double* seconds);
+void moe_rccl_destroy(moe_rccl_t* r);
 /* The same for ONE process that drives several devices (a C / C++ host without torch; the twins of moe_kg_batch_multi): one host
  * thread per worker, the exchange in shared memory.  moe_kg_multistart_multi: gps[num_devices] hold the SAME GP on different
  * devices.  moe_kg_mcmc_multistart_multi: gps[num_mcmc] is the whole ensemble (the caller builds member g on device

@@ -73,6 +73,17 @@ def test_bench_world8_c4_job_on_one_gpu():
     assert out["collective_us_per_step"]["rank0"] > 0 and out["collective_backend"] == "gloo"
 
 
+def test_bench_c5_mc_sharded_on_two_ranks():
+    """BASELINE configs[4] names d-KG at C5 "x 8 MI355X": its launcher -- `bench.py --gpus N --config C5 --shard mc`, every rank an
+    even-aligned slice of the 20 000 samples of each evaluation, ONE all_reduce of 1 + q d doubles per evaluation -- on two ranks
+    sharing the test box's GPU (gloo hook).  (r6)"""
+    out, _ = _run({"MOE_BENCH_BACKEND": "gloo"}, "--config", "C5", "--shard", "mc", "--restarts", "1", "--no-batch1", "--no-determinism")
+    assert out["n_gpus"] == 2 and out["scaling"] == "strong" and out["config"]["shard"] == "mc"
+    assert "n=2000" in out["config"]["workload"] and "g=3" in out["config"]["workload"] and "M=20000" in out["config"]["workload"]
+    assert out["value"] > 0 and out["roofline"]["kernel"] == "kg_mc_stream_kernel" and 0.05 < out["roofline"]["frac"] < 1.0
+    assert out["collective_backend"] == "gloo" and out["rccl_ranks"] == 0
+
+
 def test_rccl_preflight_child_passes_under_a_launcher_environment():
     """The pre-flight child of dist.bring_up as a rank would start it UNDER torch.distributed.run -- TORCHELASTIC_* variables set,
     its own rendezvous port -- with the one GPU of the test box as a world of 1: RCCL bring-up, one checked all_reduce, exit 0.

@@ -81,8 +81,7 @@ def test_kg_against_oracle(case, monkeypatch):
     ptol = 1e-8 if gd[1] * gd[2] <= 8 else 1e-6
     # both MC kernels, and the wave-per-sample kernel with the sample pre-pass off (beta / discretised-set scan in the kernel)
     # (r3: and the streamed-weights wave-per-sample kernel, variant 2, wherever it is built for the shape)
-    # (r6: and the gang kernel, variant 3 -- a sample shared by 4 or 8 wavefronts -- wherever it is built for the shape)
-    for variant, prep in (("0", "1"), ("1", "1"), ("0", "0"), ("2", "1"), ("3", "1")):
+    for variant, prep in (("0", "1"), ("1", "1"), ("0", "0"), ("2", "1")):
         if (len(w.derivs) > 4 or (w.q + w.p) * (1 + len(w.derivs)) > 64) and variant == "0":
             continue  # more than four derivative slots / more than 64 components: not the LDS-slab wave-per-sample kernel
                       # (r4: the streamed-weights kernel takes 8 / 12 observed derivatives and m > 64 where every slot is observed)
@@ -95,8 +94,6 @@ def test_kg_against_oracle(case, monkeypatch):
         except api.OptimalLearningException as e:
             if variant == "2" and "streamed-weights" in str(e):
                 continue  # (d > 16 with 1 .. 3 observed derivatives: they occupy four slots, the table rows are not the weights)
-            if variant == "3" and "gang MC kernel" in str(e):
-                continue  # (padded dimension 8 / 12 / 16, frames within 100 length scales, tensor-product inner domain)
             raise
         assert G.last_kernel_info()["variant"] == int(variant)
         assert abs(rg["kg"] - rc["kg"]) <= TOL["kg"] * max(abs(rc["kg"]), 1e-6), (variant, rg["kg"], rc["kg"])

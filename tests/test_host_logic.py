@@ -193,6 +193,54 @@ def test_gloo_world2_exchange_of_the_multi_rank_optimisers():
         assert calls == 5 and doubles == sum(4 + -(-n // world) * w for n, w in ((7, 3), (1, 1), (2, 5), (20, 33), (5, 2)))
 
 
+def _flat_worker(rank, world, port, ret):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        bufs = {}
+        send = np.arange(5, dtype=np.float64) + 100.0 * rank
+        a = mdist._allgather_flat(send, world, None, None, bufs)          # one collective into one tensor
+        b = mdist._allgather_flat(send + 1.0, world, None, None, bufs)    # the same size again: the tensors are reused
+        n_bufs = len(bufs)
+        mdist._NO_INTO_TENSOR.add(dist.get_backend(None))                  # a backend without all_gather_into_tensor: list form on views
+        c = mdist._allgather_flat(send, world, None, None, bufs)
+        ret[rank] = (a, b, c, n_bufs)
+    finally:
+        mdist._NO_INTO_TENSOR.clear()
+        dist.destroy_process_group()
+
+
+def test_gloo_world2_single_buffer_allgather():
+    """r6: the exchange of dist.Exchange / gather_restarts is ONE collective into ONE preallocated tensor and one
+    copy back, whichever form of all_gather the backend offers."""
+    import torch.multiprocessing as mp
+    world = 2
+    ret = mp.Manager().dict()
+    mp.spawn(_flat_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+    want = np.concatenate([np.arange(5.0), np.arange(5.0) + 100.0])
+    for r in range(world):
+        a, b, c, n_bufs = ret[r]
+        assert np.array_equal(a, want) and np.array_equal(b, want + 1.0) and np.array_equal(c, want) and n_bufs == 1
+
+
+def test_native_rccl_exchange_fails_loudly_without_a_device():
+    """r6: the library's own RCCL communicator (moe_rccl_*, csrc/rccl_comm.hip).  Without a GPU nothing of it may pretend to work --
+    and make_exchange must hand back the torch.distributed exchange instead (world 1: never called)."""
+    from cornell_moe_amd import _lib, api
+    if _lib.device_count() > 0:
+        pytest.skip("a device is visible: tests/test_gpu_multistart.py covers the native exchange")
+    assert mdist.NativeExchange.available() is False
+    with pytest.raises(api.OptimalLearningException):
+        mdist.NativeExchange(0, 1, 0)
+    ex = mdist.make_exchange(mdist.Comm(0, 1, "none", None, None, None))
+    assert isinstance(ex, mdist.Exchange) and ex.world == 1
+    L = _lib.load()
+    assert L.moe_rccl_comm(None, None) == _lib.MOE_ERR_INVALID_VALUE and L.moe_rccl_stats(None, None, None, None) == _lib.MOE_ERR_INVALID_VALUE
+    L.moe_rccl_destroy(None)
+
+
 def test_exchange_three_ranks_in_threads_and_callback_errors():
     """The same with three ranks as threads of this process (ctypes releases the GIL around the library call, the callback takes it
     back): an in-memory all-gather handed to dist.Exchange; and an exception INSIDE the callback comes back as the library's failure

@@ -97,16 +97,29 @@ def run(num_cases=100, seed=2026, n_max=300, d_max=16, g_max=4):
               #  restatement's pass count is then not the reference's -- seed 2024 case 127, one free dimension again: 1.0e-8 between
               #  the CPU codes, the device within 3e-9 of the restatement with one gradient pass more)
               loose = loose or dis_p > 1.0e-9
-          mism = float((np.abs(rg["best_point"] - rc["best_point"]).max(axis=1) > ptol).mean())
+          dev_d = np.abs(rg["best_point"] - rc["best_point"]).max(axis=1)
           e_kg = abs(rg["kg"] - rc["kg"]) / max(abs(rc["kg"]), 1e-6)
           e_gr = float(np.abs(rg["grad"] - rc["grad"]).max()) / scale
-          # (a sample or two may sit on a decision boundary of the line search -- the reference itself does against its
-          #  restatement -- without moving KG or its gradient)
-          # (a sample whose end point flipped on a rounding-level decision -- dot-product distances of the LDS-table kernel against the
-          #  reference's direct differences: seed 555 case 84, one of 12 samples, 1.2e-7 -- moves grad KG by ~ (flipped / M) x 1e-5:
-          #  with the handful of samples of a fuzz case that is above the 1e-8 meant for M in the thousands)
-          gtol = max(gtol, 2.0e-5 * mism)
-          if e_kg > ktol or e_gr > gtol or mism > max(0.05, 2.5 / M) or (not loose and rg["grad_evals"] != ro["grad_evals"]):
+          if R is not None and gd[1] * gd[2] <= 8:
+              # r6: at production depth with the reference as the checker an end point may differ from the
+              # reference's by more than 1e-8 ONLY on a sample where the two CPU codes -- the reference and its restatement --
+              # themselves disagree (a decision of that sample's line search hinges on a difference below rounding); any other
+              # mismatch fails the case.  Such a flipped sample moves grad KG by ~ 1e-5 / M: that much, per flipped sample, is
+              # granted -- nothing for samples that agree.
+              cpu_d = np.abs(ro["best_point"] - rc["best_point"]).max(axis=1)
+              knife = cpu_d > 1.0e-9
+              flipped = knife & (dev_d > 1.0e-8)
+              mism = float(((dev_d > 1.0e-8) & ~knife).mean())
+              gtol = max(TOL["grad_kg"], 10.0 * dis_g, 2.0e-5 * float(flipped.sum()) / M)
+              ktol = max(TOL["kg"], 10.0 * dis_k, 2.0e-5 * float(flipped.sum()) / M)
+              mism_cap = 0.0
+          else:
+              # (beyond production depth -- or without the reference on the box -- samples reach stationary points and a handful may sit
+              #  on decision boundaries: the r4 rule)
+              mism = float((dev_d > ptol).mean())
+              gtol = max(gtol, 2.0e-5 * mism)
+              mism_cap = max(0.05, 2.5 / M)
+          if e_kg > ktol or e_gr > gtol or mism > mism_cap or (not loose and rg["grad_evals"] != ro["grad_evals"]):
               bad += 1
               print("KG MISMATCH" + aff + " case %d variant %s: n=%d d=%d q=%d p=%d g=%s f=%d P=%d M=%d cov=%d gd=%s: rel kg %.2e grad %.2e "
                     "best-point mismatch %.3f grad passes %d vs %d" % (case, variant, n, d, q, p, derivs, f, P, M, cov, gd, e_kg,

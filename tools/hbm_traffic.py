@@ -16,7 +16,7 @@ for f in glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recursiv
     with open(f) as fh:
         for row in csv.DictReader(fh):
             name = row["Kernel_Name"]
-            key = "kg_mc_gang_kernel" if "kg_mc_gang_kernel" in name else "kg_mc_lane_kernel" if "kg_mc_lane_kernel" in name else "kg_mc_block_kernel" if "kg_mc_block_kernel" in name else "kg_mc_stream_kernel" if "kg_mc_stream_kernel" in name else "kg_mc_kernel" if "kg_mc_kernel" in name else (
+            key = "kg_mc_lane_kernel" if "kg_mc_lane_kernel" in name else "kg_mc_block_kernel" if "kg_mc_block_kernel" in name else "kg_mc_stream_kernel" if "kg_mc_stream_kernel" in name else "kg_mc_kernel" if "kg_mc_kernel" in name else (
                 "cov_build_kernel" if ("cov_build_kernel" in name or "cov_build_value_kernel" in name) else None)
             if key == "cov_build_kernel" and int(row["Grid_Size"]) < 1_000_000:
                 continue  # only the N x (E M) gradient-tail build, not the small state builds

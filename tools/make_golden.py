@@ -273,6 +273,56 @@ def shape_fixtures_r4():
     print("wrote", OUT_SHAPES4, os.path.getsize(OUT_SHAPES4), "bytes")
 
 
+OUT_SHAPES6 = os.path.join(ROOT, "tests", "golden", "ref_shapes_r6.npz")
+BUILD16K = dict(name="C5", n=4096, M=2)   # N = 16 384 training entries (d = 12, g = 3): the build beyond the fused-step schedule's limit
+
+
+def shape_fixtures_r6():
+    """Round 6, from the unmodified reference:
+    `c5m512` -- BASELINE.json configs[4] EXACTLY at M = 512 samples (N = 8000, 32 tiles): KG, grad KG, all 512 end points, the
+    value-only evaluation (the r4 fixture has M = 64);
+    `build16k` -- the GP BUILD at N = 16 384 (n = 4096, d = 12, g = 3): the reference's own factor (diagonal, three rows) and
+    K^-1 (y - mean) in full, plus the posterior at three points -- the N^3 / 3 of its scalar Cholesky, no Monte Carlo."""
+    from cornell_moe_amd.workloads import make_workload
+    blob = {}
+    w = make_workload("C5", M=512)
+    gp = ref.RefGP(1, w.alpha, w.lengths, w.X, w.y, w.noise, list(w.derivs))
+    best = float(gp.additional_mean(w.discrete).min())
+    r = gp.kg(w.inner_gd, w.bounds, w.discrete, w.Xq, None, w.M, best, w.kg_normals, want_grad=True, details=True)
+    tag = "c5m512"
+    blob[tag + "_best_so_far"] = np.array(best)
+    blob[tag + "_kg"], blob[tag + "_grad_kg"], blob[tag + "_best_point"] = np.array(r["kg"]), r["grad"], r["best_point"]
+    blob[tag + "_check"] = np.array([float(w.X.sum()), float(w.kg_normals.sum()), float(w.Xq.sum()), float(w.discrete.sum())])
+    blob[tag + "_seconds"] = np.array(r["seconds"])
+    rv = gp.kg(w.inner_gd, w.bounds, w.discrete, w.Xq, None, w.M, best, w.kg_normals, want_grad=False)
+    blob[tag + "_kg_value_only"] = np.array(rv["kg"])
+    print("%s: n=%d d=%d q=%d g=%d m=%d M=%d  KG=%.15g  (reference: %.2f s state + %.2f s evaluation)" % (
+        tag, w.n, w.d, w.q, w.g, w.m, w.M, r["kg"], r["seconds"][0], r["seconds"][1]), flush=True)
+    del gp
+    np.savez_compressed(OUT_SHAPES6, **blob)   # (kept even if the big build below is interrupted)
+    import time
+    w = make_workload(**BUILD16K)
+    t0 = time.time()
+    gp = ref.RefGP(1, w.alpha, w.lengths, w.X, w.y, w.noise, list(w.derivs))
+    secs = time.time() - t0
+    N = gp.N
+    K, kiy, mean = gp.dump()
+    tag = "build16k"
+    rows = np.array([N - 1, N // 2, 4097])
+    blob[tag + "_check"] = np.array([float(w.X.sum()), float(w.y.sum()), float(N)])
+    blob[tag + "_chol_diag"] = np.diag(K).copy()
+    blob[tag + "_chol_rows_idx"] = rows
+    blob[tag + "_chol_rows"] = np.stack([np.tril(K)[r_] for r_ in rows])
+    blob[tag + "_K_inv_y"], blob[tag + "_mean"] = kiy, np.array(mean)
+    blob[tag + "_seconds"] = np.array(secs)
+    del K
+    pts = w.query[:3]
+    blob[tag + "_q_mean"], blob[tag + "_q_grad_mean"], blob[tag + "_q_var"] = gp.mean(pts), gp.grad_mean(pts), gp.var(pts)
+    print("%s: N=%d built by the reference in %.1f s; log det K = %.15g" % (tag, N, secs, 2.0 * np.log(blob[tag + "_chol_diag"]).sum()), flush=True)
+    np.savez_compressed(OUT_SHAPES6, **blob)
+    print("wrote", OUT_SHAPES6, os.path.getsize(OUT_SHAPES6), "bytes")
+
+
 OUT_SIMPLEX = os.path.join(ROOT, "tests", "golden", "ref_simplex.npz")
 
 
@@ -575,6 +625,9 @@ def main():
         return
     if "--shapes-r4" in sys.argv:
         shape_fixtures_r4()
+        return
+    if "--shapes-r6" in sys.argv:
+        shape_fixtures_r6()
         return
     if "--simplex-kg" in sys.argv:
         simplex_kg_fixtures()
