@@ -1187,7 +1187,10 @@ int launch_gram_batch(int E, int m, int ng, int A, int K, const double* V, long 
 //     and 8 x more flops per byte is what lets the MFMA tiles run compute-bound.
 // Same pivot rule (1e-16, gpp_linear_algebra.cpp:118) and the same error report as the one-level path.
 // ---------------------------------------------------------------------------------------------------------------------
-constexpr int kOuter = 512;
+#ifndef MOE_CHOL_OUTER
+#define MOE_CHOL_OUTER 512
+#endif
+constexpr int kOuter = MOE_CHOL_OUTER;
 
 // Diagonal 64 x 64 block: factor AND invert, 256 threads, everything in LDS, in 16-column sub-steps:
 //   (1) the 16 x 16 diagonal sub-block is factored and inverted by 16 lanes holding one row each in registers (16 unrolled

@@ -939,8 +939,12 @@ __global__ __launch_bounds__(256, 2) void kg_table128_kernel(KgMcParams P, doubl
   }
 }
 
-void launch_sample_weights(const KgMcParams& P, double* V, hipStream_t s) {
-  if (P.m > 64 && P.v_slots1 == 1 + P.g) {
+void launch_sample_weights(const KgMcParams& P, double* V, hipStream_t s, bool table_only = false) {
+  // r6: `table_only` -- the consumer (the streamed-weights kernel) has no in-kernel form of the weights whose bits the table would have
+  // to reproduce -- takes the matrix-pipe kernel from m = 16 on: per (row, sample) entry the fma version's loop is one dependent chain
+  // of m fmas behind a scalar-load round trip and the previous store's acknowledgement (1.17 ms per 2.56 GB at C5 = 2.2 TB/s)
+  const bool mfma = P.v_slots1 == 1 + P.g && (P.m > 64 || (table_only && P.m >= 16 && env_int("MOE_KG_TABLE_MFMA", 1) != 0));
+  if (mfma) {
     MOE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kg_table128_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                       (int)g128::kSmemBytes));
     hipLaunchKernelGGL(kg_table128_kernel, dim3((unsigned)((P.v_stride + g128::TM - 1) / g128::TM), (P.num_local + g128::TM - 1) / g128::TM, P.E),
@@ -1548,7 +1552,7 @@ KgPending kg_launch(GpDev& gp, int num_fidelity, const moe_gd_params_t& gd, cons
       gp.kV.reserve((size_t)mp.v_stride * (size_t)total + (size_t)64 * mp.v_slots1);  // (+ one tile: the sweeps prefetch one tile ahead)
       MOE_HIP_CHECK(hipMemsetAsync(dBeta.p + (size_t)total * m, 0, sizeof(double) * 64, s));
       mp.V = gp.kV.p;
-      launch_sample_weights(mp, gp.kV.p, s);
+      launch_sample_weights(mp, gp.kV.p, s, variant == 2);
     }
   }
   if (variant == 2 && (mp.V == nullptr || mp.best_j == nullptr))
