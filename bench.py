@@ -212,7 +212,12 @@ def measure_traffic(config, restarts, log, timeout_s=180, passes=None):
             cmd = [exe, "--kernel-trace", "--pmc"] + ctrs + ["--output-format", "csv", "-d", os.path.join(tmp, tag), "-o", "p",
                    "--", sys.executable, os.path.join(ROOT, "tools", "prof_kg.py"), config, str(restarts), "2"]
             try:
-                subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout_s, check=True)
+                # (rocprofv3 has been seen to die in its own teardown AFTER writing its tables: the exit code is not the criterion,
+                #  the counter table is)
+                subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout_s, check=False)
+                import glob
+                if not glob.glob(os.path.join(tmp, tag, "**", "*counter_collection.csv"), recursive=True):
+                    raise RuntimeError("no counter table written")
             except Exception as e:  # the FP64 pass is an extra: keep the traffic passes' result if only it fails
                 if tag in ("fetch", "write"):
                     raise

@@ -505,7 +505,6 @@ class DeviceGP(object):
         keys = ("variant", "xlds", "waves", "tr", "weight_table", "fused_tail", "blocks", "prep")
         info = dict(zip(keys, [int(v) for v in out]))
         info["far_frame"], info["wide_frame"], info["lane"] = (info["xlds"] >> 1) & 1, (info["xlds"] >> 2) & 1, (info["xlds"] >> 3) & 1
-        info["fly"] = (info["xlds"] >> 4) & 1
         info["xlds"] &= 1
         return info
 

@@ -120,42 +120,6 @@ class DevicePool {
     if (e != hipSuccess) throw Error(MOE_ERR_RUNTIME, std::string("HIP error: ") + hipGetErrorString(e) + " (hipStreamCreate)");
     return s;
   }
-  // r6: a stream restricted to `cus` of the device's CUs (hipExtStreamCreateWithCUMask; mask bit i <-> CU i / 8 of XCD i % 8 on
-  // gfx950 -- tools/cumask_probe.hip -- so the low `cus` bits leave 32 - cus / 8 CUs of EVERY XCD to the other streams).  The GP
-  // build queues its bulk GEMMs there: the 64-column steps of the factorisation, on the unrestricted stream, then always find a CU at
-  // once instead of queueing behind GEMM tiles (kernels_linalg.hip: look-ahead schedule).  nullptr where the runtime refuses.
-  hipStream_t take_masked_stream(int dev, int cus) {
-    {
-      std::lock_guard<std::mutex> lock(mu_);
-      auto& v = masked_[std::make_pair(dev, cus)];
-      if (!v.empty()) {
-        hipStream_t s = v.back();
-        v.pop_back();
-        return s;
-      }
-    }
-    std::vector<uint32_t> mask((size_t)(cus + 31) / 32, 0u);
-    for (int i = 0; i < cus; ++i) mask[(size_t)i / 32] |= 1u << (i % 32);
-    hipStream_t s = nullptr;
-    if (hipExtStreamCreateWithCUMask(&s, (uint32_t)mask.size(), mask.data()) != hipSuccess) {
-      (void)hipGetLastError();
-      return nullptr;
-    }
-    return s;
-  }
-  void give_masked_stream(int dev, int cus, hipStream_t s) {
-    if (s == nullptr) return;
-    (void)hipStreamSynchronize(s);
-    if (enabled_) {
-      std::lock_guard<std::mutex> lock(mu_);
-      auto& v = masked_[std::make_pair(dev, cus)];
-      if (v.size() < 64) {
-        v.push_back(s);
-        return;
-      }
-    }
-    (void)hipStreamDestroy(s);
-  }
   void give_stream(int dev, hipStream_t s) {
     if (s == nullptr) return;
     (void)hipStreamSynchronize(s);
@@ -260,7 +224,6 @@ class DevicePool {
   std::mutex mu_;
   std::map<int, std::multimap<size_t, void*>> free_;
   std::map<int, std::vector<hipStream_t>> streams_;
-  std::map<std::pair<int, int>, std::vector<hipStream_t>> masked_;
   std::multimap<size_t, void*> host_;
   size_t host_held_ = 0;
   static constexpr size_t kMaxHostHeld = (size_t)4 << 30;

@@ -268,12 +268,8 @@ GpDev::~GpDev() {
 void GpDev::use_device() const { MOE_HIP_CHECK(hipSetDevice(device)); }
 
 void GpDev::release_side_streams() {
-  if (side_cus > 0)
-    DevicePool::get().give_masked_stream(device, side_cus, side_stream);
-  else
-    DevicePool::get().give_stream(device, side_stream);
+  DevicePool::get().give_stream(device, side_stream);
   side_stream = nullptr;
-  side_cus = 0;
 }
 
 std::vector<double> GpDev::padded(const double* pts, int k) const {
@@ -326,18 +322,10 @@ void GpDev::rebuild() {
   }
   launch_cov_build(cp, dX.p, n, derivs, dX.p, n, derivs, dNoise.p, dL.p, ldL, 0, stream, false, true);
   dWE.reserve(cholesky_work_doubles(N));  // the state workspace doubles as scratch of the recursive inversion
-  // r6: the early inverse -- bulk GEMMs that run NEXT TO the trailing half's 64-column steps -- on a stream restricted to 3/4 of every
-  // XCD's CUs (MOE_CHOL_SIDE_CUS: the CU count, 0 = unrestricted as in r5): a step's workgroups find a CU at once instead of queueing
-  // behind 0.1 - 0.5 ms GEMM tiles.  N = 8000: 11.1 -> 10.5 - 10.65 ms (`profiles/r06_g_chol_lookahead_ab.txt`).  Beyond the fused-step
-  // schedule (N > 16 384) the side work is the longer of the two and takes the whole chip (N = 26 000: 229 against 233 ms restricted).
-  if (side_stream == nullptr && early_inverse_split(N) > 0 && N <= 16384) {
-    const char* lc = std::getenv("MOE_CHOL_SIDE_CUS");
-    const int cus = (lc && *lc) ? std::atoi(lc) : (num_cu * 3 / 4) / 8 * 8;
-    if (cus > 0 && cus < num_cu) {
-      side_stream = DevicePool::get().take_masked_stream(device, cus);
-      side_cus = side_stream != nullptr ? cus : 0;
-    }
-  }
+  // (r6, measured and NOT kept: the early inverse on a stream restricted to 3/4 of every XCD's CUs -- hipExtStreamCreateWithCUMask -- so
+  //  that the trailing half's 64-column steps find a CU at once: 11.1 -> 10.5 ms at N = 8000 while the stream is pooled, but a masked
+  //  hardware queue left alive doubles the time of every later burst of small kernels (a KG-MCMC suggestion 0.18 -> 0.37 s), and
+  //  created / destroyed per build the second build of a process hung in the runtime.  `profiles/r06_g_chol_lookahead_ab.txt`.)
   if (side_stream == nullptr && early_inverse_split(N) > 0) side_stream = DevicePool::get().take_stream(device);
   launch_cholesky_and_inverse(N, dL.p, ldL, dLinv.p, ldL, dWE.p, dInfo.p, stream, true, side_stream);
   const double t_queued = trace ? ms_since(t0) : 0.0;

@@ -23,7 +23,6 @@ struct GpDev {
   int device = 0;
   hipStream_t stream = nullptr;
   hipStream_t side_stream = nullptr;  // early-inverse schedule of the build (kernels.hpp: launch_cholesky_and_inverse); taken on first need
-  int side_cus = 0;                   // r6: > 0 = side_stream is restricted to that many CUs (DevicePool::take_masked_stream)
   void release_side_streams();
   int d = 0, dp = 0, n = 0, g = 0, N = 0;
   long ldL = 0;  // leading dimension of dL / dLinv: N at the last rebuild + head-room for appended rows

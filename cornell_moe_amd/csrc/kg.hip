@@ -977,12 +977,12 @@ void launch_mc(const KgMcParams& P, int dp, int G, bool xlds, int blocks, int wa
   }
 }
 
-void launch_mc_lane(const KgMcParams& P, int dp, int G, bool fly, int rec_head, int blocks, int waves, size_t shm, hipStream_t s) {
+void launch_mc_lane(const KgMcParams& P, int dp, int G, int rec_head, int blocks, int waves, size_t shm, hipStream_t s) {
   switch (dp) {
-    case 4: launch_kg_mc_lane_dp4(P, G, fly, rec_head, blocks, waves, shm, s); break;
-    case 8: launch_kg_mc_lane_dp8(P, G, fly, rec_head, blocks, waves, shm, s); break;
-    case 12: launch_kg_mc_lane_dp12(P, G, fly, rec_head, blocks, waves, shm, s); break;
-    case 16: launch_kg_mc_lane_dp16(P, G, fly, rec_head, blocks, waves, shm, s); break;
+    case 4: launch_kg_mc_lane_dp4(P, G, rec_head, blocks, waves, shm, s); break;
+    case 8: launch_kg_mc_lane_dp8(P, G, rec_head, blocks, waves, shm, s); break;
+    case 12: launch_kg_mc_lane_dp12(P, G, rec_head, blocks, waves, shm, s); break;
+    case 16: launch_kg_mc_lane_dp16(P, G, rec_head, blocks, waves, shm, s); break;
     default: throw Error(MOE_ERR_RUNTIME, "unsupported padded dimension in the lane-parked MC kernel");
   }
 }
@@ -1197,7 +1197,7 @@ KgPending kg_launch(GpDev& gp, int num_fidelity, const moe_gd_params_t& gd, cons
   // depends on the evaluation's shape alone).  Same results bit for bit (MOE_KG_LANE=0: the frame line search of rounds 2-4).
   auto even = [](int v) { return (v + 1) & ~1; };
   const int rec_head = even(m * m) + even(A) + even(A * m) + even(A * size);
-  bool lane_kernel = false, fly_kernel = false;
+  bool lane_kernel = false;
   if (variant == 0 && xlds && waves <= 8 && !simplex && dp <= 16 && env_int("MOE_KG_LANE", 1) != 0) {
     const size_t lane_fixed = kg_mc_lane_fixed_bytes(dp, rec_head);
     const int wl = std::min(waves, env_int("MOE_KG_WAVES", waves));
@@ -1213,19 +1213,6 @@ KgPending kg_launch(GpDev& gp, int num_fidelity, const moe_gd_params_t& gd, cons
       wide_lds_tiles = (int)std::min<size_t>((size_t)ntiles, (share - shm) / (sizeof(double) * dp * 64));
       wide_lds_tiles = std::max(0, std::min(wide_lds_tiles, env_int("MOE_KG_WIDE_LDS_TILES", wide_lds_tiles)));
       shm += sizeof(double) * (size_t)wide_lds_tiles * dp * 64;
-    }
-    // r5: q-KG with at most four fantasy points: no per-wavefront weight slabs -- one (K^-1 y | W) table per workgroup, the
-    // weights formed on the fly from the sample's beta: up to 16 wavefronts (kg_mc_lane.hpp, WM = 4).  Same results bit for bit.
-    if (lane_kernel && G == 0 && g == 0 && m <= 4) {
-      const int fw = std::max(1, std::min(16, env_int("MOE_KG_FLY_WAVES", 16)));
-      const size_t fb = kg_mc_lane_fly_bytes(dp, ntiles, rec_head, fw);
-      if (env_int("MOE_KG_ONFLY", 0) != 0 && fb <= (size_t)160 * 1024) {
-        fly_kernel = true;
-        waves = fw;
-        shm = fb;
-        wg_per_cu = std::max(1, std::min((int)((size_t)160 * 1024 / shm), 16 / waves));
-        wide_lds_tiles = 0;
-      }
     }
   } else if (variant == 2) {
     waves = std::max(1, std::min(8, env_int("MOE_KG_WAVES", 8)));
@@ -1558,7 +1545,7 @@ KgPending kg_launch(GpDev& gp, int num_fidelity, const moe_gd_params_t& gd, cons
   if (variant == 2 && (mp.V == nullptr || mp.best_j == nullptr))
     throw Error(MOE_ERR_RUNTIME, "streamed-weights MC kernel selected without its weight table");
   if (variant == 0 && lane_kernel)
-    launch_mc_lane(mp, dp, G, fly_kernel, rec_head, blocks, waves, shm, s);
+    launch_mc_lane(mp, dp, G, rec_head, blocks, waves, shm, s);
   else if (variant == 0)
     launch_mc(mp, dp, G, xlds, blocks, waves, shm, s);
   else if (variant == 2)
@@ -1569,7 +1556,7 @@ KgPending kg_launch(GpDev& gp, int num_fidelity, const moe_gd_params_t& gd, cons
   {
     // (bits 1 / 2 of the second word, r4: the frame-extent decisions -- a domain box or point set wider than 100 length scales
     //  silently costs the LDS-table kernel and the multi-trial passes; this is where a caller can see it)
-    const int info[8] = {variant, ((variant == 0 && xlds) ? 1 : 0) | (far_frame ? 2 : 0) | (wide_frame ? 4 : 0) | (lane_kernel ? 8 : 0) | (fly_kernel ? 16 : 0), waves, variant == 1 ? tr : wide_lds_tiles, mp.V != nullptr ? 1 : 0, 0, blocks,
+    const int info[8] = {variant, ((variant == 0 && xlds) ? 1 : 0) | (far_frame ? 2 : 0) | (wide_frame ? 4 : 0) | (lane_kernel ? 8 : 0), waves, variant == 1 ? tr : wide_lds_tiles, mp.V != nullptr ? 1 : 0, 0, blocks,
                          mp.best_j != nullptr ? 1 : 0};
     std::copy(info, info + 8, gp.last_info);
   }

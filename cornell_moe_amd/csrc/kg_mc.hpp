@@ -42,10 +42,6 @@ namespace moe {
 #ifndef MOE_KG_FAST_SQRT
 #define MOE_KG_FAST_SQRT 1
 #endif
-// trial counts up to which the multi-trial sweeps unroll four tiles instead of two (0: never -- the measured default, see DESIGN)
-#ifndef MOE_KG_MULTI_UNROLL4_MAXT
-#define MOE_KG_MULTI_UNROLL4_MAXT 0
-#endif
 #if MOE_BLOCK_PROF
 #define MOE_PROF_T(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
 #define MOE_PROF_ADD(dst, a, b) dst += (b) - (a)
@@ -127,12 +123,11 @@ void launch_kg_mc_dp32(const KgMcParams& P, int G, bool xlds, int blocks, int wa
 
 // Lane-parked wave-per-sample kernel (r5, kg_mc_lane.hpp): the LDS-table kernel above with the line search's vectors one row per lane and
 // the evaluation's record head ([L | mu_disc | C_disc | disc]: `rec_head` doubles) in LDS; 8 wavefronts, padded dimension <= 16.
-void launch_kg_mc_lane_dp4(const KgMcParams& P, int G, bool fly, int rec_head, int blocks, int waves, size_t shm, hipStream_t s);
-void launch_kg_mc_lane_dp8(const KgMcParams& P, int G, bool fly, int rec_head, int blocks, int waves, size_t shm, hipStream_t s);
-void launch_kg_mc_lane_dp12(const KgMcParams& P, int G, bool fly, int rec_head, int blocks, int waves, size_t shm, hipStream_t s);
-void launch_kg_mc_lane_dp16(const KgMcParams& P, int G, bool fly, int rec_head, int blocks, int waves, size_t shm, hipStream_t s);
+void launch_kg_mc_lane_dp4(const KgMcParams& P, int G, int rec_head, int blocks, int waves, size_t shm, hipStream_t s);
+void launch_kg_mc_lane_dp8(const KgMcParams& P, int G, int rec_head, int blocks, int waves, size_t shm, hipStream_t s);
+void launch_kg_mc_lane_dp12(const KgMcParams& P, int G, int rec_head, int blocks, int waves, size_t shm, hipStream_t s);
+void launch_kg_mc_lane_dp16(const KgMcParams& P, int G, int rec_head, int blocks, int waves, size_t shm, hipStream_t s);
 size_t kg_mc_lane_fixed_bytes(int dp, int rec_head);  // LDS in front of the coordinate table
-size_t kg_mc_lane_fly_bytes(int dp, int ntiles, int rec_head, int waves);  // all of the on-the-fly-weights instantiation's LDS
 
 // Streamed-weights wave-per-sample kernel (kg_mc_stream_kernel): weights from the table P.V, P.wide_lds_tiles tiles of coordinates in LDS.
 void launch_kg_mc_stream_dp4(const KgMcParams& P, int G, int blocks, int waves, size_t shm, hipStream_t s);
@@ -543,29 +538,12 @@ __device__ __forceinline__ double eval_pass(const double* __restrict__ xs, const
 // fma per trial), multiplied by the first-derivative coefficient of the trial's distance.
 // (eval_multi_loop_s: the three sums |x2|^2, x2.d2, |d2|^2 -- fixed along a trial line -- handed in by a caller that forms them once
 //  per bracket, kg_mc_lane.hpp; eval_multi_loop forms them itself, in the same order)
-// Weights formed ON THE FLY (r5, kg_mc_lane.hpp: WM > 0, q-KG with at most four fantasy points): `aw` is then not a wave's slab but
-// the workgroup's shared table [tile][1 + WM][64] of (K^-1 y, W columns) rows, and a point's weight is
-//   alpha * fma(-W_3, b_3, fma(-W_2, b_2, fma(-W_1, b_1, fma(-W_0, b_0, K^-1 y))))      (b = this sample's beta; the slab's chain, its bits)
-// -- five instructions per point and sweep instead of an 8 KB slab per wavefront in LDS.
-struct FlyWeights {
-  double alpha, b[4];
-};
-template <int WM>
-__device__ __forceinline__ double fly_weight(const double (&rows)[1 + WM], const FlyWeights& fw) {
-  double v = rows[0];
-#pragma unroll
-  for (int c = 0; c < 4; ++c)
-    if (c < WM) v = fma(-rows[1 + (c < WM ? c : 0)], fw.b[c], v);
-  return v * fw.alpha;
-}
-
-template <int DP, int COV, int T, bool SMALL, bool XL = true, int G = 0, int WM = 0>
+template <int DP, int COV, int T, bool SMALL, bool XL = true, int G = 0>
 __device__ __forceinline__ bool eval_multi_loop_s(const double* __restrict__ xs, const double* __restrict__ aw,
                                                   const double* __restrict__ etab, int ntiles, double mean, const double (&x2)[DP],
                                                   const double (&d2)[DP], double sxx, double sxd, double sdd, double alpha0, int lane,
-                                                  double (&f)[T], const FlyWeights* fw = nullptr) {
-  static_assert(WM == 0 || G == 0, "on-the-fly weights: no derivative observations");
-  constexpr int WR = 1 + G + WM;  // weight rows per tile
+                                                  double (&f)[T]) {
+  constexpr int WR = 1 + G;  // weight rows per tile
   double al[T], qq[T];
 #pragma unroll
   for (int t = 0; t < T; ++t) {
@@ -594,7 +572,7 @@ __device__ __forceinline__ bool eval_multi_loop_s(const double* __restrict__ xs,
 #pragma unroll
     for (int t = 0; t < T; ++t) tt[t] = (al[t] * al[t]) * (0.25 * sdd);  // alpha_t^2 |dv|^2
   }
-#pragma unroll(SMALL ? 1 : (T <= MOE_KG_MULTI_UNROLL4_MAXT ? 4 : 2))
+#pragma unroll(SMALL ? 1 : 2)  // (four tiles for few trials: +-0.3 %, r5)
   for (int tile = 0; tile < ntiles; ++tile) {
     double nx[NX], nwa[WR];
     xt += NX * 64;  // (one tile of padding behind both arrays: see eval_loop)
@@ -603,13 +581,7 @@ __device__ __forceinline__ bool eval_multi_loop_s(const double* __restrict__ xs,
     for (int k = 0; k < NX; ++k) nx[k] = xt[k * 64];
 #pragma unroll
     for (int a = 0; a < WR; ++a) nwa[a] = wt[a * 64];
-    double cw = cwa[0];
-    if constexpr (WM > 0) {
-      double rows[1 + WM];
-#pragma unroll
-      for (int a = 0; a < 1 + WM; ++a) rows[a] = cwa[a];
-      cw = fly_weight<WM>(rows, *fw);
-    }
+    const double cw = cwa[0];
     // derivative-weight sum of trial t: sum_a w_a (x_ja - x0_a - alpha_t dv_a) = sdA - alpha_t sdB
     double sdA = 0.0, sdB = 0.0;
     if (G > 0) {

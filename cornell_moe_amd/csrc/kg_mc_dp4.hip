@@ -19,14 +19,13 @@ size_t kg_mc_lane_fixed_bytes(int dp, int rec_head) {
   return sizeof(double) * ((size_t)kExpTabLen + (size_t)mc::kLaneCstRows * dp + (size_t)((rec_head + 1) & ~1));
 }
 
-size_t kg_mc_lane_fly_bytes(int dp, int ntiles, int rec_head, int waves) { return mc::lane_lds_bytes(dp, 0, 4, ntiles, rec_head, waves); }
 
 void launch_kg_mc_stream_dp4(const KgMcParams& P, int G, int blocks, int waves, size_t shm, hipStream_t s) {
   mc::launch_stream_dp<4>(P, G, blocks, waves, shm, s);
 }
 
-void launch_kg_mc_lane_dp4(const KgMcParams& P, int G, bool fly, int rec_head, int blocks, int waves, size_t shm, hipStream_t s) {
-  mc::launch_lane_dp<4>(P, G, fly, rec_head, blocks, waves, shm, s);
+void launch_kg_mc_lane_dp4(const KgMcParams& P, int G, int rec_head, int blocks, int waves, size_t shm, hipStream_t s) {
+  mc::launch_lane_dp<4>(P, G, rec_head, blocks, waves, shm, s);
 }
 
 }  // namespace moe

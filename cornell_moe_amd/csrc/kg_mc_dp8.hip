@@ -15,8 +15,8 @@ void launch_kg_mc_stream_dp8(const KgMcParams& P, int G, int blocks, int waves, 
   mc::launch_stream_dp<8>(P, G, blocks, waves, shm, s);
 }
 
-void launch_kg_mc_lane_dp8(const KgMcParams& P, int G, bool fly, int rec_head, int blocks, int waves, size_t shm, hipStream_t s) {
-  mc::launch_lane_dp<8>(P, G, fly, rec_head, blocks, waves, shm, s);
+void launch_kg_mc_lane_dp8(const KgMcParams& P, int G, int rec_head, int blocks, int waves, size_t shm, hipStream_t s) {
+  mc::launch_lane_dp<8>(P, G, rec_head, blocks, waves, shm, s);
 }
 
 }  // namespace moe

@@ -22,22 +22,11 @@
 // gpp_domain.cpp:64-105.
 #pragma once
 
-// x2 / d2 / the query of a gradient pass / the trial step sizes as SCALAR operands of the tile loops (v_readfirstlane, two
-// vector-ALU slots per double and pass) instead of wave-uniform vector registers (none, but 2 registers per double inside the loops)
-#ifndef MOE_LANE_SGPR
-#define MOE_LANE_SGPR 1
-#endif
-
 // threads per workgroup the kernel is compiled for (512: two wavefronts per SIMD, up to 256 VGPRs)
-#ifndef MOE_LANE_MAX_THREADS
-#define MOE_LANE_MAX_THREADS 512
-#endif
-#ifndef MOE_LANE_GRAD_UNROLL
-#define MOE_LANE_GRAD_UNROLL 4
-#endif
-#ifndef MOE_LANE_RELOAD_ARGS
-#define MOE_LANE_RELOAD_ARGS 1
-#endif
+constexpr int kLaneMaxThreads = 512;
+constexpr int kLaneGradUnroll = 4;  // tiles unrolled in the gradient pass (r5 A/B: 1 / 2 / 4 -> -4 % / 0 / +0.8 %)
+// (closed r5 A/Bs, `profiles/r05_a_lane_ab.txt`, `r05_b_unroll_variants_ab.txt`: a pass's wave-uniform operands as SCALAR registers --
+//  v_readfirstlane -- against wave-uniform vector registers +-0.5 %; kernel arguments re-read per sample against held -1 %)
 
 constexpr int kLaneCstRows = 8;  // s | 1 / s | centre | pinned value | lower bound | upper bound (original units) | perm | free (1 / 0)
 constexpr int kMaxLaneDP = 16;
@@ -72,10 +61,8 @@ __device__ __forceinline__ void lane_broadcast(double v_l, lds_rw_ptr row, int l
 
 template <int DP>
 __device__ __forceinline__ void make_scalar(double (&v)[DP]) {
-#if MOE_LANE_SGPR
 #pragma unroll
   for (int k = 0; k < DP; ++k) v[k] = uniform(v[k]);
-#endif
 }
 
 // max over the 64 lanes, wave-uniform (fmax is exact: any order gives the bits of the butterfly in discrete_scan)
@@ -92,12 +79,12 @@ __device__ __forceinline__ double wave_max_uniform(double v) {
 
 // Value + gradient pass with the gradient returned LANE-PARKED (lane k < DP: d f / d x'_k in the frame): eval_loop<DP, G, true, COV,
 // false, true, false, true> of kg_mc.hpp with the read-back of the packed sums changed -- lane k reads sum k.  `S` = 2 kMaxLaneDP doubles of scratch.
-template <int DP, int G, int COV, int WM = 0>
+template <int DP, int G, int COV>
 __device__ __forceinline__ double grad_pass_parked(const double* __restrict__ xs, const double* __restrict__ aw,
                                                    const double* __restrict__ etab, int ntiles, double mean, const double (&xq)[DP],
-                                                   lds_rw_ptr S, int lane, double& g_l, const FlyWeights* fw = nullptr) {
+                                                   lds_rw_ptr S, int lane, double& g_l) {
   constexpr int XR = DP + 1;  // rows per coordinate tile (the |x|^2 row is not read here)
-  constexpr int WR = 1 + G + WM;  // weight rows per tile (WM > 0: the shared (K^-1 y | W) table, weights formed on the fly)
+  constexpr int WR = 1 + G;  // weight rows per tile
   double accf = 0.0;
   double accg[DP];
   double accd[G > 0 ? G : 1];
@@ -112,7 +99,7 @@ __device__ __forceinline__ double grad_pass_parked(const double* __restrict__ xs
   for (int k = 0; k < DP; ++k) cx[k] = xt[k * 64];
 #pragma unroll
   for (int a = 0; a < WR; ++a) cw[a] = wt[a * 64];
-#pragma unroll MOE_LANE_GRAD_UNROLL
+#pragma unroll kLaneGradUnroll
   for (int t = 0; t < ntiles; ++t) {
     double nx[DP], nw[WR];
     xt += XR * 64;
@@ -128,13 +115,7 @@ __device__ __forceinline__ double grad_pass_parked(const double* __restrict__ xs
       diff[k] = cx[k] - xq[k];
       r2 = fma(diff[k], diff[k], r2);
     }
-    double w0 = cw[0];
-    if constexpr (WM > 0) {
-      double rows[1 + WM];
-#pragma unroll
-      for (int a = 0; a < 1 + WM; ++a) rows[a] = cw[a];
-      w0 = fly_weight<WM>(rows, *fw);
-    }
+    const double w0 = cw[0];
     double base, first, second;
     radial3<COV, true, (G > 0)>(r2, etab, base, first, second);
     double sd = 0.0;
@@ -182,54 +163,10 @@ __device__ __forceinline__ double grad_pass_parked(const double* __restrict__ xs
   return -mu;
 }
 
-// f at the point whose frame coordinates are -q2 / 2 (one Armijo trial, or a clamped last step): eval_loop<DP, 0, false, COV, false,
-// true, true> of kg_mc.hpp -- squared distances from the |x|^2 row, four tiles unrolled -- with the weights formed on the fly.
-template <int DP, int COV, int WM>
-__device__ __forceinline__ double value_pass_fly(const double* __restrict__ xs, const double* __restrict__ aw,
-                                                 const double* __restrict__ etab, int ntiles, double mean, const double (&q2)[DP],
-                                                 int lane, const FlyWeights& fw) {
-  constexpr int XR = DP + 1, WR = 1 + WM;
-  double ss = 0.0;
-#pragma unroll
-  for (int k = 0; k < DP; ++k) ss = fma(q2[k], q2[k], ss);
-  const double qq = fma(ss, 0.25, 1.0e-300);
-  if (!(uniform(qq) <= kFarRadius * kFarRadius)) return -mean;
-  double accf = 0.0;
-  lds_tile_ptr xt = (lds_tile_ptr)(xs + lane);
-  lds_tile_ptr wt = (lds_tile_ptr)(aw + lane);
-  double cx[XR], cw[WR];
-#pragma unroll
-  for (int k = 0; k < XR; ++k) cx[k] = xt[k * 64];
-#pragma unroll
-  for (int a = 0; a < WR; ++a) cw[a] = wt[a * 64];
-#pragma unroll 4
-  for (int t = 0; t < ntiles; ++t) {
-    double nx[XR], nw[WR];
-    xt += XR * 64;
-    wt += WR * 64;
-#pragma unroll
-    for (int k = 0; k < XR; ++k) nx[k] = xt[k * 64];
-#pragma unroll
-    for (int a = 0; a < WR; ++a) nw[a] = wt[a * 64];
-    double r2 = cx[DP] + qq;
-#pragma unroll
-    for (int k = 0; k < DP; ++k) r2 = fma(cx[k], q2[k], r2);
-    r2 = fmax(r2, 1.0e-300);
-    double base, first, second;
-    radial3<COV, false, false>(r2, etab, base, first, second);
-    accf = fma(fly_weight<WM>(cw, fw), base, accf);
-#pragma unroll
-    for (int k = 0; k < XR; ++k) cx[k] = nx[k];
-#pragma unroll
-    for (int a = 0; a < WR; ++a) cw[a] = nw[a];
-  }
-  return -(mean + wave_sum_uniform(accf));
-}
-
 // One MC sample on the lane-parked line search.  xs = the workgroup's LDS coordinate table, aw = this wave's weight slab, zb = its
 // scratch (2 kMaxM doubles: z | beta during the set-up, then the line search's rows), cst = the lane constants, rc = the LDS copy of
 // the evaluation's record head [L | mu_disc | C_disc | disc] (offsets as in KgRec).
-template <int DP, int G, int WM = 0>
+template <int DP, int G>
 __device__ __forceinline__ void kg_sample_lane(const KgMcParams& P, int e, int sl, const double* __restrict__ xs,
                                                double* __restrict__ aw, double* __restrict__ zb, const double* __restrict__ etab,
                                                const double* __restrict__ cst, const double* __restrict__ rc, int lane,
@@ -264,15 +201,7 @@ __device__ __forceinline__ void kg_sample_lane(const KgMcParams& P, int e, int s
   Z[lane] = zc;  // kMaxM == 64 == wavefront size
   Z[kMaxM + lane] = bc;
 
-  // ---- WM > 0: the weights are formed on the fly inside the passes from the workgroup's (K^-1 y | W) table and this sample's beta ----
-  FlyWeights fw;
-  fw.alpha = P.alpha;
-#pragma unroll
-  for (int c = 0; c < 4; ++c) fw.b[c] = uniform(Z[kMaxM + c]);  // (0 beyond m)
-  const FlyWeights* fwp = (WM > 0) ? &fw : nullptr;
-  // ---- per-sample weights into this wave's LDS slab: v(j, a) = KinvY[(j, a)] - sum_c W[(j, a), c] beta_c  (kg_sample's loops) ----
-  if (WM > 0) {
-  } else if (G == 0 && g1 == 1 && m <= 4) {
+  if (G == 0 && g1 == 1 && m <= 4) {
     const double b0 = Z[kMaxM], b1 = Z[kMaxM + 1], b2 = Z[kMaxM + 2], b3 = Z[kMaxM + 3];  // 0 beyond m
     const long c1 = (long)min(1, m - 1) * P.N, c2 = (long)min(2, m - 1) * P.N, c3 = (long)min(3, m - 1) * P.N;
     for (int t0 = 0; t0 < ntiles; t0 += 8) {
@@ -397,8 +326,8 @@ __device__ __forceinline__ void kg_sample_lane(const KgMcParams& P, int e, int s
           lane_broadcast<DP>(xf_l, R0, lane, xq);
           make_scalar<DP>(xq);
           f0 = (cov_type == MOE_COV_SQUARE_EXPONENTIAL)
-                   ? grad_pass_parked<DP, G, MOE_COV_SQUARE_EXPONENTIAL, WM>(xs, aw, etab, ntiles, mean, xq, R1, lane, gf_l, fwp)
-                   : grad_pass_parked<DP, G, MOE_COV_MATERN_NU_2P5, WM>(xs, aw, etab, ntiles, mean, xq, R1, lane, gf_l, fwp);
+                   ? grad_pass_parked<DP, G, MOE_COV_SQUARE_EXPONENTIAL>(xs, aw, etab, ntiles, mean, xq, R1, lane, gf_l)
+                   : grad_pass_parked<DP, G, MOE_COV_MATERN_NU_2P5>(xs, aw, etab, ntiles, mean, xq, R1, lane, gf_l);
         }
         f0 = uniform(f0);  // (tells the compiler: the Armijo decisions below are scalar branches)
         n_grad++;
@@ -449,10 +378,10 @@ __device__ __forceinline__ void kg_sample_lane(const KgMcParams& P, int e, int s
 #define MOE_LANE_TRIALS(T)                                                                                                              \
   {                                                                                                                                     \
     double ft[T];                                                                                                                       \
-    evaluated = se ? eval_multi_loop_s<DP, MOE_COV_SQUARE_EXPONENTIAL, T, false, true, G, WM>(xs, aw, etab, ntiles, mean, x2, d2, sxx,  \
-                                                                                              sxd, sdd, alpha_n, lane, ft, fwp)         \
-                   : eval_multi_loop_s<DP, MOE_COV_MATERN_NU_2P5, T, false, true, G, WM>(xs, aw, etab, ntiles, mean, x2, d2, sxx, sxd,  \
-                                                                                         sdd, alpha_n, lane, ft, fwp);                  \
+    evaluated = se ? eval_multi_loop_s<DP, MOE_COV_SQUARE_EXPONENTIAL, T, false, true, G>(xs, aw, etab, ntiles, mean, x2, d2, sxx, sxd,  \
+                                                                                          sdd, alpha_n, lane, ft)                      \
+                   : eval_multi_loop_s<DP, MOE_COV_MATERN_NU_2P5, T, false, true, G>(xs, aw, etab, ntiles, mean, x2, d2, sxx, sxd, sdd,  \
+                                                                                     alpha_n, lane, ft);                               \
     if (evaluated) {                                                                                                                    \
       _Pragma("unroll") for (int t = 0; t < T; ++t) {                                                                                   \
         if (!done) {                                                                                                                    \
@@ -481,12 +410,7 @@ __device__ __forceinline__ void kg_sample_lane(const KgMcParams& P, int e, int s
               double q2[DP], unused[DP];
 #pragma unroll
               for (int k = 0; k < DP; ++k) q2[k] = fma(alpha_n, d2[k], x2[k]);
-              if constexpr (WM > 0)
-                ftrial = (cov_type == MOE_COV_SQUARE_EXPONENTIAL)
-                             ? value_pass_fly<DP, MOE_COV_SQUARE_EXPONENTIAL, WM>(xs, aw, etab, ntiles, mean, q2, lane, fw)
-                             : value_pass_fly<DP, MOE_COV_MATERN_NU_2P5, WM>(xs, aw, etab, ntiles, mean, q2, lane, fw);
-              else
-                ftrial = eval_pass<DP, G, false, false, true, true, false>(xs, aw, etab, ntiles, cov_type, mean, q2, nullptr, unused, lane);
+              ftrial = eval_pass<DP, G, false, false, true, true, false>(xs, aw, etab, ntiles, cov_type, mean, q2, nullptr, unused, lane);
               n_val++;
               if (ftrial - f0 > 0.5 * alpha_n * norm) {
                 done = true;
@@ -519,18 +443,13 @@ __device__ __forceinline__ void kg_sample_lane(const KgMcParams& P, int e, int s
             lane_broadcast<DP>(xf_l + st_l, R0, lane, xq);
             make_scalar<DP>(xq);
             obj2 = (cov_type == MOE_COV_SQUARE_EXPONENTIAL)
-                       ? grad_pass_parked<DP, G, MOE_COV_SQUARE_EXPONENTIAL, WM>(xs, aw, etab, ntiles, mean, xq, R1, lane, gn_l, fwp)
-                       : grad_pass_parked<DP, G, MOE_COV_MATERN_NU_2P5, WM>(xs, aw, etab, ntiles, mean, xq, R1, lane, gn_l, fwp);
+                       ? grad_pass_parked<DP, G, MOE_COV_SQUARE_EXPONENTIAL>(xs, aw, etab, ntiles, mean, xq, R1, lane, gn_l)
+                       : grad_pass_parked<DP, G, MOE_COV_MATERN_NU_2P5>(xs, aw, etab, ntiles, mean, xq, R1, lane, gn_l);
             carried = true;
           } else {
             double q2[DP], unused[DP];
             lane_broadcast<DP>(fma(-2.0, st_l, x2_l), R0, lane, q2);
-            if constexpr (WM > 0)
-              obj2 = (cov_type == MOE_COV_SQUARE_EXPONENTIAL)
-                         ? value_pass_fly<DP, MOE_COV_SQUARE_EXPONENTIAL, WM>(xs, aw, etab, ntiles, mean, q2, lane, fw)
-                         : value_pass_fly<DP, MOE_COV_MATERN_NU_2P5, WM>(xs, aw, etab, ntiles, mean, q2, lane, fw);
-            else
-              obj2 = eval_pass<DP, G, false, false, true, true, false>(xs, aw, etab, ntiles, cov_type, mean, q2, nullptr, unused, lane);
+            obj2 = eval_pass<DP, G, false, false, true, true, false>(xs, aw, etab, ntiles, cov_type, mean, q2, nullptr, unused, lane);
             n_val++;
           }
         }
@@ -579,24 +498,20 @@ __device__ __forceinline__ void kg_sample_lane(const KgMcParams& P, int e, int s
 
 // LDS: [64] exp table | [kLaneCstRows x DP] lane constants | [rec_head] the evaluation's record head | [tab] coordinates | per-wave slabs
 // (weights [ntiles (1 + G) 64] + 2 kMaxM doubles of scratch) | one weight tile of padding.  Built for the LDS coordinate table, 8 waves.
-// WM = 4 (r5, q-KG with at most four fantasy points): no slabs -- behind the coordinates ONE table [ntiles + 1][1 + WM][64] of
-// (K^-1 y | W_0 .. W_3) rows per workgroup (the fantasy points' rows hold 0 | -e_c, so that the chain gives beta_c; pad rows 0) and
-// 2 kMaxM doubles of scratch per wave: 16 wavefronts per workgroup, four per SIMD at <= 128 vector registers.
-template <int DP, int G, int WM>
-__global__ __launch_bounds__(WM > 0 ? 1024 : MOE_LANE_MAX_THREADS) void kg_mc_lane_kernel(KgMcParams P, int rec_head) {
+template <int DP, int G>
+__global__ __launch_bounds__(kLaneMaxThreads) void kg_mc_lane_kernel(KgMcParams P, int rec_head) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   const int ntiles = P.ntiles;
   const int tab = ntiles * (DP + 1) * 64;
-  const int wtab = (WM > 0) ? (ntiles + 1) * (1 + WM) * 64 : 0;
-  const int wslab = (WM > 0) ? 2 * kMaxM : ntiles * (1 + G) * 64 + 2 * kMaxM;
+  const int wslab = ntiles * (1 + G) * 64 + 2 * kMaxM;
   double* cst = smem + kExpTabLen;
   double* rc = cst + kLaneCstRows * DP;
   double* coords = rc + rec_head;
   double* wshared = coords + tab;
-  double* aw = (WM > 0) ? wshared : wshared + wave * wslab;
-  double* zb = (WM > 0) ? wshared + wtab + wave * wslab : aw + ntiles * (1 + G) * 64;
+  double* aw = wshared + wave * wslab;
+  double* zb = aw + ntiles * (1 + G) * 64;
   if (threadIdx.x < kExpTabLen) smem[threadIdx.x] = kExp2Tab64[threadIdx.x];
   fill_lane_constants<DP>(P, cst);
   for (int e = blockIdx.x % P.E; e < P.E; e += (gridDim.x < (unsigned)P.E ? gridDim.x : P.E)) {
@@ -614,23 +529,7 @@ __global__ __launch_bounds__(WM > 0 ? 1024 : MOE_LANE_MAX_THREADS) void kg_mc_la
         xx = fma(v, v, xx);
       }
       dst[DP * 64] = xx;
-      if (WM > 0) {  // this point's (K^-1 y | W) rows
-        const double* We = P.W + (long)e * P.w_stride;
-        double* wd = wshared + tl * (1 + WM) * 64 + l;
-        const int j = pt;
-#pragma unroll
-        for (int a = 0; a < 1 + WM; ++a) {
-          double v = 0.0;
-          if (j < P.n)
-            v = (a == 0) ? P.KinvY[j] : ((a - 1 < P.m) ? We[j + (long)(a - 1) * P.N] : 0.0);
-          else if (j < P.n + P.u && a == 1 + (j - P.n))
-            v = -1.0;  // fantasy point c = j - n: fma(-(-1), beta_c, 0) = beta_c
-          wd[a * 64] = v;
-        }
-      }
     }
-    if (WM > 0)  // (the tile of padding the sweeps prefetch past the end)
-      for (int i = threadIdx.x; i < (1 + WM) * 64; i += blockDim.x) wshared[ntiles * (1 + WM) * 64 + i] = 0.0;
     {
       const double* rec = P.blob + (long)e * P.rec.stride;
       for (int i = threadIdx.x; i < rec_head; i += blockDim.x) rc[i] = rec[i];
@@ -644,17 +543,13 @@ __global__ __launch_bounds__(WM > 0 ? 1024 : MOE_LANE_MAX_THREADS) void kg_mc_la
       const unsigned int sl = (unsigned int)__builtin_amdgcn_readfirstlane((int)ticket);
       if (sl >= (unsigned int)P.num_local) break;
       if (lane == 0) ticket = atomicAdd(next, 1u);  // drawn ONE AHEAD: the atomic's round trip overlaps the sample
-#if MOE_LANE_RELOAD_ARGS
       // The kernel arguments are re-read from the kernarg segment by every sample (scalar loads through an opaque copy of its
       // address) instead of being loaded once at kernel entry and held -- or spilt to vector-register lanes -- for the kernel's lifetime.
       // (P is the kernel's first argument: offset 0 of the segment)
       const __attribute__((address_space(4))) KgMcParams* Pk =
           (const __attribute__((address_space(4))) KgMcParams*)__builtin_amdgcn_kernarg_segment_ptr();
       asm volatile("" : "+s"(Pk));
-      kg_sample_lane<DP, G, WM>(*(const KgMcParams*)Pk, e, (int)sl, coords, aw, zb, smem, cst, rc, lane, tot_val, tot_grad);
-#else
-      kg_sample_lane<DP, G, WM>(P, e, (int)sl, coords, aw, zb, smem, cst, rc, lane, tot_val, tot_grad);
-#endif
+      kg_sample_lane<DP, G>(*(const KgMcParams*)Pk, e, (int)sl, coords, aw, zb, smem, cst, rc, lane, tot_val, tot_grad);
     }
     if (lane == 0 && (tot_val | tot_grad) != 0) {
       atomicAdd(&P.counters[2 * e], (unsigned long long)tot_val);
@@ -665,36 +560,29 @@ __global__ __launch_bounds__(WM > 0 ? 1024 : MOE_LANE_MAX_THREADS) void kg_mc_la
 }
 
 // LDS bytes of a workgroup of `waves` wavefronts (host side: kg.hip's geometry)
-inline size_t lane_lds_bytes(int dp, int G, int WM, int ntiles, int rec_head, int waves) {
+inline size_t lane_lds_bytes(int dp, int G, int ntiles, int rec_head, int waves) {
   const size_t fixed = (size_t)kExpTabLen + (size_t)kLaneCstRows * dp + (size_t)((rec_head + 1) & ~1);
   const size_t tab = (size_t)ntiles * (dp + 1) * 64;
-  if (WM > 0) return sizeof(double) * (fixed + tab + (size_t)(ntiles + 1) * (1 + WM) * 64 + (size_t)waves * 2 * kMaxM);
   return sizeof(double) * (fixed + tab + (size_t)waves * ((size_t)ntiles * (1 + G) * 64 + 2 * kMaxM) + (size_t)(1 + G) * 64);
 }
 
-template <int DP, int G, int WM>
+template <int DP, int G>
 inline void launch_lane_inst(const KgMcParams& P, int rec_head, int blocks, int waves, size_t shm, hipStream_t s) {
-  auto kern = kg_mc_lane_kernel<DP, G, WM>;
+  auto kern = kg_mc_lane_kernel<DP, G>;
   MOE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
   hipLaunchKernelGGL(kern, dim3(blocks), dim3(waves * 64), shm, s, P, rec_head);
   MOE_HIP_CHECK(hipGetLastError());
 }
 
-// fly = the on-the-fly-weights instantiation (G = 0, at most four fantasy points)
 template <int DP>
-inline void launch_lane_dp(const KgMcParams& P, int G, bool fly, int rec_head, int blocks, int waves, size_t shm, hipStream_t s) {
+inline void launch_lane_dp(const KgMcParams& P, int G, int rec_head, int blocks, int waves, size_t shm, hipStream_t s) {
   static_assert(DP <= kMaxLaneDP, "lane-parked line search: one scratch row holds kMaxLaneDP doubles");
-  if (fly) {
-    if (G != 0 || P.m > 4) throw Error(MOE_ERR_RUNTIME, "on-the-fly weights need G = 0 and m <= 4");
-    launch_lane_inst<DP, 0, 4>(P, rec_head, blocks, waves, shm, s);
-    return;
-  }
   switch (G) {
-    case 0: launch_lane_inst<DP, 0, 0>(P, rec_head, blocks, waves, shm, s); break;
-    case 1: launch_lane_inst<DP, 1, 0>(P, rec_head, blocks, waves, shm, s); break;
-    case 2: launch_lane_inst<DP, 2, 0>(P, rec_head, blocks, waves, shm, s); break;
-    case 3: launch_lane_inst<DP, 3, 0>(P, rec_head, blocks, waves, shm, s); break;
-    case 4: launch_lane_inst<DP, 4, 0>(P, rec_head, blocks, waves, shm, s); break;
+    case 0: launch_lane_inst<DP, 0>(P, rec_head, blocks, waves, shm, s); break;
+    case 1: launch_lane_inst<DP, 1>(P, rec_head, blocks, waves, shm, s); break;
+    case 2: launch_lane_inst<DP, 2>(P, rec_head, blocks, waves, shm, s); break;
+    case 3: launch_lane_inst<DP, 3>(P, rec_head, blocks, waves, shm, s); break;
+    case 4: launch_lane_inst<DP, 4>(P, rec_head, blocks, waves, shm, s); break;
     default: throw Error(MOE_ERR_RUNTIME, "unsupported derivative-slot count in the lane-parked MC kernel");
   }
 }

@@ -477,34 +477,6 @@ def test_lane_kernel_bit_identical_to_frame_kernel(case, monkeypatch):
     assert a["grad_evals"] == b["grad_evals"] and a["mean_evals"] == b["mean_evals"]
 
 
-@pytest.mark.parametrize("case", [CASES[i] for i in (0, 1, 2, 3, 4, 8, 10, 15, 16, 17)], ids=lambda c: str(c[0]))
-def test_fly_kernel_bit_identical_to_frame_kernel(case, monkeypatch):
-    """r5: the on-the-fly-weights instantiation of the lane-parked kernel (q-KG, at most four fantasy points: no per-wavefront weight
-    slabs, 16 wavefronts per workgroup) against the frame kernel (MOE_KG_LANE=0): a weight is the same fma chain over the same
-    (K^-1 y, W) values, so every sum, end point and counter agrees BIT FOR BIT."""
-    from cornell_moe_amd import api
-    w, cov, f, gd = _mk(case)
-    G = api.DeviceGP(w.hyperparameters, w.X, w.y, w.noise, w.derivs, cov_type=cov)
-    full = np.hstack([w.discrete, np.ones((w.discrete.shape[0], f))])
-    best = float(G.additional_mean(full).min())
-    Xp = w.Xp if w.p else None
-    monkeypatch.setenv("MOE_KG_VARIANT", "0")
-    res = {}
-    for fly in ("1", "0"):
-        monkeypatch.setenv("MOE_KG_ONFLY", fly)
-        monkeypatch.setenv("MOE_KG_LANE", fly)
-        res[fly] = G.kg(gd, w.bounds_inner, w.discrete, w.Xq, Xp, w.M, best, w.kg_normals, num_fidelity=f, want_best_points=True)
-        info = G.last_kernel_info()
-        if fly == "0":
-            assert info["fly"] == 0 and info["lane"] == 0, info
-        elif info["lane"] and (w.q + w.p) <= 4:  # (wherever the lane-parked kernel is eligible and m <= 4)
-            assert info["fly"] == 1 and info["waves"] == 16, info
-    a, b = res["1"], res["0"]
-    assert a["kg_sum"] == b["kg_sum"] and np.array_equal(a["grad_sum"], b["grad_sum"])
-    assert np.array_equal(a["best_point"], b["best_point"])
-    assert a["grad_evals"] == b["grad_evals"] and a["mean_evals"] == b["mean_evals"]
-
-
 @pytest.mark.parametrize("case", [CASES[i] for i in (0, 1, 2, 11, 12, 15, 16, 17)], ids=lambda c: str(c[0]))
 def test_small_shape_kernels_agree(case, monkeypatch):
     """r5: one or two tiles at d <= 4.  A call with few samples takes the lane-parked kernel (eight wavefronts, single-trial passes), a
