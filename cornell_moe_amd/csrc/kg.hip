@@ -1108,8 +1108,9 @@ KgPending kg_launch(GpDev& gp, int num_fidelity, const moe_gd_params_t& gd, cons
   // r6: decided from the evaluation's OWN sample count, not from the call's -- which kernel an evaluation takes never
   // depends on the batch or the rank it is evaluated in (the two kernels agree bit for bit on the tested shapes; the promise of
   // batch-independent bits no longer rests on that)
-  const bool small_lane = small_shape && !simplex && env_int("MOE_KG_LANE", 1) != 0 &&
-                          (long)num_local <= (long)env_int("MOE_KG_SMALL_LANE_MAX_SAMPLES", 1024);
+  // (a simplex inner domain: the lane-parked kernel at every sample count -- the 16-wavefront instantiation has no simplex update)
+  const bool small_lane = small_shape && env_int("MOE_KG_LANE", 1) != 0 &&
+                          (simplex || (long)num_local <= (long)env_int("MOE_KG_SMALL_LANE_MAX_SAMPLES", 1024));
   const int max_waves = (small_shape && !small_lane) ? 16 : 8;
   int waves = 0;
   if (tab_bytes + slab_bytes <= lds_max) waves = (int)std::min<size_t>(max_waves, (lds_max - tab_bytes) / slab_bytes);
@@ -1183,10 +1184,6 @@ KgPending kg_launch(GpDev& gp, int num_fidelity, const moe_gd_params_t& gd, cons
     // (shapes the LDS-slab wave-per-sample kernel is not built for keep to the other two)
     if (!(forced == 0 && (G > 4 || m > kMaxM))) variant = forced;
   }
-  // (the simplex update lives in line_search_lds: the streamed-weights or the workgroup-per-sample kernel)
-  if (simplex && variant == 0) variant = stream_ok ? 2 : 1;
-  if (variant == 1 && (tr < 0 || kg_mc_block_lds_bytes(dp, G, num_lds_tiles) > (size_t)160 * 1024))
-    throw Error(MOE_ERR_RUNTIME, "point set too large for the workgroup-per-sample MC kernel");
   if (variant == 0 && waves < 1)
     throw Error(MOE_ERR_RUNTIME, "training set too large for the MC kernel (one sample's weights exceed LDS)");
   const int num_cu = gp.num_cu;
@@ -1198,11 +1195,16 @@ KgPending kg_launch(GpDev& gp, int num_fidelity, const moe_gd_params_t& gd, cons
   auto even = [](int v) { return (v + 1) & ~1; };
   const int rec_head = even(m * m) + even(A) + even(A * m) + even(A * size);
   bool lane_kernel = false;
-  if (variant == 0 && xlds && waves <= 8 && !simplex && dp <= 16 && env_int("MOE_KG_LANE", 1) != 0) {
+  if (variant == 0 && xlds && waves <= 8 && dp <= 16 && env_int("MOE_KG_LANE", 1) != 0) {
     const size_t lane_fixed = kg_mc_lane_fixed_bytes(dp, rec_head);
     const int wl = std::min(waves, env_int("MOE_KG_WAVES", waves));
     lane_kernel = wl >= 1 && lane_fixed + tab_bytes + (size_t)wl * slab_bytes + pad_bytes <= (size_t)160 * 1024;
   }
+  // the simplex update (simplex_limit) lives in the lane-parked line search (r6) and in line_search_lds -- the streamed-weights and the
+  // workgroup-per-sample kernel; the frame line search of the other wave-per-sample instantiations has none
+  if (simplex && variant == 0 && !lane_kernel) variant = stream_ok ? 2 : 1;
+  if (variant == 1 && (tr < 0 || kg_mc_block_lds_bytes(dp, G, num_lds_tiles) > (size_t)160 * 1024))
+    throw Error(MOE_ERR_RUNTIME, "point set too large for the workgroup-per-sample MC kernel");
   if (variant == 0) {
     waves = std::max(1, std::min(waves, env_int("MOE_KG_WAVES", waves)));
     shm = (lane_kernel ? kg_mc_lane_fixed_bytes(dp, rec_head) : fixed_bytes) +

@@ -428,6 +428,15 @@ __device__ __forceinline__ void kg_sample_lane(const KgMcParams& P, int e, int s
         const double want_o = alpha_n * (gf_l * s_l);  // alpha grad_r (the frame gradient x scale)
         double step_o = 0.0;
         if (free_l) step_o = limit_update_1d(lo_l, hi_l, P.max_relative_change, xo_l, want_o);
+        if (P.simplex != 0) {
+          // r6: SimplexIntersectTensorProductDomain::LimitUpdate's second half (gpp_domain.cpp:255-289; simplex_limit of kg_mc.hpp) on
+          // two rows of the wave's scratch -- the trial line's rows R2 / R3 are spent by now: the point and the clamped step in table-row
+          // order (the bounds are the box clipped to the unit hypercube, max_relative_change carries the reference's tweak: kg.hip)
+          R2[lane < DP ? lane : DP] = xo_l;
+          R3[lane < DP ? lane : DP] = step_o;
+          double relaxed, vnorm;
+          if (simplex_limit(P, (const double*)R2, (const double*)R3, relaxed, vnorm)) step_o = free_l ? relaxed * (step_o / vnorm) : 0.0;
+        }
         const bool changed = __ballot(free_l && step_o != want_o) != 0ull;
         const bool nonzero = __ballot(free_l && step_o != 0.0) != 0ull;
         // the step in the frame: the trial point's own offset where the clamp left it alone (its value is reused below)

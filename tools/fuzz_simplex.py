@@ -87,7 +87,7 @@ def run(num_cases=60, seed=4):
             mism = float((off > ptol).mean())
             gtol = max(1e-6 if loose else TOL["grad_kg"], 2.0e-5 * mism)
             inside = rg["best_point"][:, :size].min() >= -1e-12 and rg["best_point"][:, :size].sum(axis=1).max() <= 1.0 + 1e-12
-            if e_kg > TOL["kg"] or e_gr > gtol or mism > max(0.05, 2.5 / M) or not inside or G.last_kernel_info()["variant"] == 0:
+            if e_kg > TOL["kg"] or e_gr > gtol or mism > max(0.05, 2.5 / M) or not inside or (G.last_kernel_info()["variant"] == 0 and not G.last_kernel_info()["lane"]):   # (r6: the lane-parked kernel carries the simplex update)
                 bad += 1
                 print("SIMPLEX KG MISMATCH case %d variant %s (kernel %d): n=%d d=%d f=%d g=%s q=%d p=%d P=%d M=%d cov=%d box=[%g, %g] gd=%s: "
                       "rel kg %.2e grad %.2e end points off %.3f (max %.2e; on the face: %d of %d) inside=%s" % (
