@@ -101,3 +101,34 @@ def test_rccl_preflight_child_passes_under_a_launcher_environment():
     res = subprocess.run([sys.executable, "-m", "cornell_moe_amd.dist", "--preflight"], env=env, cwd=ROOT, stdout=subprocess.PIPE,
                          stderr=subprocess.PIPE, universal_newlines=True, timeout=300)
     assert res.returncode == 0, res.stderr[-2000:]
+
+
+def test_single_buffer_exchange_over_rccl_world1():
+    """r6: dist._allgather_flat / gather_restarts / Exchange with their buffers ON THE DEVICE over the nccl (= RCCL) backend -- what the
+    driver's multi-GPU run does first -- as a world of one on the test box's GPU: all_gather_into_tensor into the preallocated tensor,
+    one copy back, the values intact."""
+    code = r'''
+import os, numpy as np, torch, torch.distributed as dist
+from cornell_moe_amd import dist as mdist
+os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", str(mdist._free_port()))
+dev = torch.device("cuda", 0); torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+bufs = {}
+send = np.linspace(0.0, 1.0, 33)
+a = mdist._allgather_flat(send, 1, None, dev, bufs)
+b = mdist._allgather_flat(send * 2.0, 1, None, dev, bufs)
+assert np.array_equal(a, send) and np.array_equal(b, 2.0 * send) and len(bufs) == 1 and bufs[(33, str(dev))][1].is_cuda
+kg, grad = mdist.gather_restarts([0, 1, 2], [1.0, 2.0, 3.0], np.arange(3 * 4 * 2, dtype=float).reshape(3, 4, 2), 3, group=None, device=dev)
+assert np.array_equal(kg, [1.0, 2.0, 3.0]) and np.array_equal(grad.ravel(), np.arange(24.0))
+ex = mdist.Exchange(0, 1, None, dev)
+out = ex._torch_allgather(send)
+assert np.array_equal(out, send)
+dist.destroy_process_group()
+print("rccl world-1 exchange ok")
+'''
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    res = subprocess.run([sys.executable, "-c", code], env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                         universal_newlines=True, timeout=300)
+    assert res.returncode == 0 and "rccl world-1 exchange ok" in res.stdout, res.stderr[-2000:]

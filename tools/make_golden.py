@@ -323,6 +323,36 @@ def shape_fixtures_r6():
     print("wrote", OUT_SHAPES6, os.path.getsize(OUT_SHAPES6), "bytes")
 
 
+OUT_BUILD26K = os.path.join(ROOT, "tests", "golden", "ref_build26k.npz")
+
+
+def build26k_fixture():
+    """Round 6: the GP build at the SURVEY 8(d) stretch point itself -- n = 2000, d = 12, all 12 derivatives observed: N = 26 000, K =
+    5.4 GB -- from the unmodified reference's scalar Cholesky (~40 minutes on one core, ~20 GB of host memory): the factor's diagonal
+    and three rows, K^-1 (y - mean) in full, the posterior at three points.  Build only: no Monte Carlo."""
+    import time
+    from cornell_moe_amd.workloads import make_workload
+    w = make_workload("C5", derivs=tuple(range(12)), M=2)
+    t0 = time.time()
+    gp = ref.RefGP(1, w.alpha, w.lengths, w.X, w.y, w.noise, list(w.derivs))
+    secs = time.time() - t0
+    N = gp.N
+    print("reference build at N = %d: %.1f s" % (N, secs), flush=True)
+    K, kiy, mean = gp.dump()
+    blob = {}
+    rows = np.array([N - 1, N // 2, 4097])
+    blob["check"] = np.array([float(w.X.sum()), float(w.y.sum()), float(N)])
+    blob["chol_diag"] = np.diag(K).copy()
+    blob["chol_rows_idx"] = rows
+    blob["chol_rows"] = np.stack([np.where(np.arange(N) <= r_, K[r_], 0.0) for r_ in rows])
+    blob["K_inv_y"], blob["mean"], blob["seconds"] = kiy, np.array(mean), np.array(secs)
+    del K
+    pts = w.query[:3]
+    blob["q_mean"], blob["q_grad_mean"], blob["q_var"] = gp.mean(pts), gp.grad_mean(pts), gp.var(pts)
+    np.savez_compressed(OUT_BUILD26K, **blob)
+    print("wrote", OUT_BUILD26K, os.path.getsize(OUT_BUILD26K), "bytes; log det K = %.15g" % (2.0 * np.log(blob["chol_diag"]).sum()))
+
+
 OUT_SIMPLEX = os.path.join(ROOT, "tests", "golden", "ref_simplex.npz")
 
 
@@ -628,6 +658,9 @@ def main():
         return
     if "--shapes-r6" in sys.argv:
         shape_fixtures_r6()
+        return
+    if "--build26k" in sys.argv:
+        build26k_fixture()
         return
     if "--simplex-kg" in sys.argv:
         simplex_kg_fixtures()
