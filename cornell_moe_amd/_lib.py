@@ -115,6 +115,8 @@ SIGNATURES = {
     "moe_debug_fp64_rate": (C.c_int, [C.c_int, dp, _EP]),
     "moe_set_reference_quirks": (C.c_int, [C.c_int]),
     "moe_get_reference_quirks": (C.c_int, []),
+    "moe_set_ensemble_launches": (C.c_int, [C.c_int]),
+    "moe_ensemble_launch_stats": (C.c_int, [C.POINTER(C.c_longlong)]),
     "moe_last_kernel_ms": (C.c_int, [_GP, dp]),
     "moe_last_kernel_info": (C.c_int, [_GP, C.POINTER(C.c_int)]),
 }

@@ -116,6 +116,20 @@ def get_reference_quirks():
     return bool(_lib.load().moe_get_reference_quirks())
 
 
+def set_ensemble_launches(on):
+    """moe_set_ensemble_launches: 1 = the MCMC-averaged KG evaluators issue every kernel once for all ensemble members (default),
+    0 = member by member, -1 = follow MOE_ENS_LAUNCH.  Same bits either way."""
+    _lib.load().moe_set_ensemble_launches(int(on))
+
+
+def ensemble_launch_stats():
+    """(merged evaluations, member-by-member fall-backs, launches issued by merged evaluations, member launches they stand for)"""
+    import ctypes
+    out = (ctypes.c_longlong * 4)()
+    _lib.load().moe_ensemble_launch_stats(out)
+    return tuple(int(v) for v in out)
+
+
 def normal_draws(seed, count):
     out = np.empty(int(count), dtype=np.float64)
     _lib.load().moe_normal_draws(C.c_uint(int(seed) & 0xFFFFFFFF), int(count), out.ctypes.data_as(dp))

@@ -96,6 +96,15 @@ int moe_set_reference_quirks(int on) {
   return MOE_OK;
 }
 int moe_get_reference_quirks(void) { return moe::reference_quirks() ? 1 : 0; }
+int moe_set_ensemble_launches(int on) {
+  moe::set_ensemble_launches(on);
+  return MOE_OK;
+}
+int moe_ensemble_launch_stats(long long* out4) {
+  if (out4 == nullptr) return MOE_ERR_INVALID_VALUE;
+  moe::ensemble_launch_stats(out4);
+  return MOE_OK;
+}
 
 int moe_device_count(int* count) {
   int c = 0;
@@ -402,9 +411,9 @@ int moe_debug_fp64_rate(int device, double* tflops, moe_error_t* err) {
     hipEvent_t e0, e1;
     MOE_HIP_CHECK(hipEventCreate(&e0));
     MOE_HIP_CHECK(hipEventCreate(&e1));
-    hipLaunchKernelGGL(fp64_rate_kernel, dim3(blocks), dim3(256), 0, s, dOut.p, 0.999999, 1.0e-6, 2000);  // warm-up, clocks up
+    MOE_LAUNCH_NOW(fp64_rate_kernel, dim3(blocks), dim3(256), 0, s, dOut.p, 0.999999, 1.0e-6, 2000);  // warm-up, clocks up
     MOE_HIP_CHECK(hipEventRecord(e0, s));
-    hipLaunchKernelGGL(fp64_rate_kernel, dim3(blocks), dim3(256), 0, s, dOut.p, 0.999999, 1.0e-6, iters);
+    MOE_LAUNCH_NOW(fp64_rate_kernel, dim3(blocks), dim3(256), 0, s, dOut.p, 0.999999, 1.0e-6, iters);
     MOE_HIP_CHECK(hipEventRecord(e1, s));
     MOE_HIP_CHECK(hipEventSynchronize(e1));
     float ms = 0.f;

@@ -33,6 +33,10 @@ struct Error : public std::runtime_error {
     }                                                                                                         \
   } while (0)
 
+}  // namespace moe
+#include "launch.hpp"
+namespace moe {
+
 // Device-memory pool (r5).  A GP build at N = 8000 allocates two 520 MB matrices and half a dozen small buffers, and every
 // hyper-parameter sample of an ensemble builds a fresh GP: hipMalloc / hipFree of that size cost more than a millisecond of a 14 ms
 // build.  Blocks a DevBuf releases are kept per device, keyed by size, and handed to the next request they fit (at most half as large
@@ -245,20 +249,23 @@ struct DevBuf {
   ~DevBuf() { DevicePool::get().give(p, bytes); }
   void reserve(size_t n) {
     if (n <= cap) return;
-    DevicePool::get().give(p, bytes);
+    // (while launches are being recorded, ops already recorded may name the old block: it goes back to the pool after their replay)
+    if (Recorder* r = Recorder::current()) {
+      if (p != nullptr) r->retired_dev.emplace_back(p, bytes);
+    } else {
+      DevicePool::get().give(p, bytes);
+    }
     p = nullptr;
     cap = 0;
     bytes = 0;
     p = static_cast<T*>(DevicePool::get().take(n * sizeof(T), &bytes));
     cap = n;
   }
-  void upload(const T* host, size_t n, hipStream_t s) {
+  void upload(const T* host, size_t n, hipStream_t s, bool host_pinned = false) {
     reserve(n);
-    if (n) MOE_HIP_CHECK(hipMemcpyAsync(p, host, n * sizeof(T), hipMemcpyHostToDevice, s));
+    copy_async(p, host, n * sizeof(T), hipMemcpyHostToDevice, s, host_pinned);
   }
-  void download(T* host, size_t n, hipStream_t s) const {
-    if (n) MOE_HIP_CHECK(hipMemcpyAsync(host, p, n * sizeof(T), hipMemcpyDeviceToHost, s));
-  }
+  void download(T* host, size_t n, hipStream_t s) const { copy_async(host, p, n * sizeof(T), hipMemcpyDeviceToHost, s); }
   void swap(DevBuf& o) {
     std::swap(p, o.p);
     std::swap(cap, o.cap);
@@ -279,7 +286,11 @@ struct PinnedBuf {
   ~PinnedBuf() { DevicePool::get().give_host(p, bytes); }
   void reserve(size_t n) {
     if (n <= cap) return;
-    DevicePool::get().give_host(p, bytes);
+    if (Recorder* r = Recorder::current()) {
+      if (p != nullptr) r->retired_host.emplace_back(p, bytes);
+    } else {
+      DevicePool::get().give_host(p, bytes);
+    }
     p = nullptr;
     cap = 0;
     bytes = 0;

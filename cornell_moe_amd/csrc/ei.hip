@@ -520,7 +520,7 @@ void ei_evaluate_batch(GpDev& gp, const double* Xq_all, int num_evals, const dou
     auto launch_state = [&](auto kern) {
       if (shm > 48 * 1024)
         MOE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
-      hipLaunchKernelGGL(kern, dim3(E), dim3(256), shm, s, sp);
+      MOE_LAUNCH(kern, dim3(E), dim3(256), shm, s, sp);
     };
     if (se.fused) {
       if (u <= 4)
@@ -591,7 +591,7 @@ void ei_evaluate_batch(GpDev& gp, const double* Xq_all, int num_evals, const dou
   P.blob_stride = (long)rec;
   P.out = dOut.p;
   P.ticket = gp.kEiTicket.p;
-  hipLaunchKernelGGL(ei_mc_kernel, dim3(blocks, E), dim3(256), 0, s, P);
+  MOE_LAUNCH(ei_mc_kernel, dim3(blocks, E), dim3(256), 0, s, P);
   MOE_HIP_CHECK(hipGetLastError());
   const size_t n_down = (size_t)E * ncomp + (on_device ? (size_t)E : 0);
   gp.hKgOut.reserve(n_down);

@@ -205,8 +205,8 @@ template <int DP>
 void launch_ll_grad(const CovParams& cp, const double* X, int n, int g1, const double* alpha, const double* Kinv, long ldk,
                     const double* kdiag, double* part, double* out, hipStream_t s) {
   dim3 grid((n + 255) / 256, (n + 63) / 64);
-  hipLaunchKernelGGL((ll_grad_kernel<DP>), grid, dim3(256), 0, s, cp, X, n, g1, alpha, Kinv, ldk, part);
-  hipLaunchKernelGGL(ll_grad_finish_kernel, dim3(1), dim3(256), 0, s, (const double*)part, (int)(grid.x * grid.y), 1 + DP, n,
+  MOE_LAUNCH((ll_grad_kernel<DP>), grid, dim3(256), 0, s, cp, X, n, g1, alpha, Kinv, ldk, part);
+  MOE_LAUNCH(ll_grad_finish_kernel, dim3(1), dim3(256), 0, s, (const double*)part, (int)(grid.x * grid.y), 1 + DP, n,
                      g1, alpha, kdiag, out);
   MOE_HIP_CHECK(hipGetLastError());
 }
@@ -249,7 +249,7 @@ void GpDev::grad_log_marginal_likelihood(double* grad) {
 double GpDev::log_marginal_likelihood() {
   use_device();
   // dTmp[0, N) still holds yc = y - mean on the value rows (rebuild), dTmp[N, 2N) is free scratch
-  hipLaunchKernelGGL(ll_terms_kernel, dim3(1), dim3(256), 0, stream, dL.p, ldL, N, dTmp.p, dKinvY.p, dTmp.p + N);
+  MOE_LAUNCH(ll_terms_kernel, dim3(1), dim3(256), 0, stream, dL.p, ldL, N, dTmp.p, dKinvY.p, dTmp.p + N);
   MOE_HIP_CHECK(hipGetLastError());
   double terms[2] = {0.0, 0.0};
   MOE_HIP_CHECK(hipMemcpyAsync(terms, dTmp.p + N, sizeof(terms), hipMemcpyDeviceToHost, stream));
@@ -485,7 +485,7 @@ const double* build_state_matrix(GpDev& gp, const double* U_all, int u, const De
       for (int k = 0; k < gp.d; ++k) Ep[((size_t)e * A + j) * gp.dp + k] = extra_all[((size_t)e * A + j) * gp.d + k];
   }
   if (apx) apx->fill(gp.hStateIn.p + nU + nD + nX);
-  gp.dStateIn.upload(gp.hStateIn.p, nU + nD + nX + nApx, s);
+  gp.dStateIn.upload(gp.hStateIn.p, nU + nD + nX + nApx, s, true);  // (hStateIn: pinned)
   double* dUp = gp.dStateIn.p;
   double* dEp = dUp + nU;
   double* dDp = dEp + nX;
@@ -630,7 +630,7 @@ void variance_on_device(GpDev& gp, const double* pts, int k, bool cholesky, doub
   gp.dVarWork.reserve(mm * (cholesky ? 4 : 1) + work);
   double* dVar = gp.dVarWork.p;
   launch_cov_build(gp.cp, gp.dUnion, k, gp.derivs, gp.dUnion, k, gp.derivs, nullptr, dVar, m, 0, s);
-  hipLaunchKernelGGL(var_sub_kernel, dim3((unsigned)((mm + 255) / 256)), dim3(256), 0, s, dVar, gp.dGram.p, (long)mm);
+  MOE_LAUNCH_NOW(var_sub_kernel, dim3((unsigned)((mm + 255) / 256)), dim3(256), 0, s, dVar, gp.dGram.p, (long)mm);
   MOE_HIP_CHECK(hipGetLastError());
   gp.hStateOut.reserve(mm + 1);
   if (!cholesky) {
@@ -646,7 +646,7 @@ void variance_on_device(GpDev& gp, const double* pts, int k, bool cholesky, doub
   MOE_HIP_CHECK(hipMemcpyAsync(dChol, dVar, sizeof(double) * mm, hipMemcpyDeviceToDevice, s));
   gp.dInfo.reserve(1);
   launch_cholesky_and_inverse(m, dChol, m, dInv, m, dWork, gp.dInfo.p, s);
-  hipLaunchKernelGGL(chol_merge_kernel, dim3((unsigned)((mm + 255) / 256)), dim3(256), 0, s, dOut, dChol, dVar, m);
+  MOE_LAUNCH(chol_merge_kernel, dim3((unsigned)((mm + 255) / 256)), dim3(256), 0, s, dOut, dChol, dVar, m);
   MOE_HIP_CHECK(hipGetLastError());
   int info = 0;
   gp.dInfo.download(&info, 1, s);

@@ -18,53 +18,59 @@ constexpr int kCovRows = 256;  // output rows per workgroup (4 wavefronts)
 constexpr int kCovCols = 16;   // B points per workgroup
 
 template <int DP, bool DERIVS>
+struct cov_build_kernel_body {
+  static __device__ __forceinline__ void run(const VIdx blockIdx, const VIdx gridDim, const void*, const CovParams& cp, const double* __restrict__ A, int nA, const DerivList& dA, const double* __restrict__ B, int nB, const DerivList& dB, const double* __restrict__ diag_noise, double* __restrict__ out, long ld, long col0, int lower_only, int cols_per_wg, int split_at, long split_shift) {
+    // (split_at / split_shift, r5, value-only builds: B points from index split_at on write their columns split_shift further right --
+    //  two point sets with separate column ranges in ONE launch, launch_cov_build_pair)
+    __shared__ double Bs[kCovCols][DP];
+    const int gA = DERIVS ? dA.g : 0, gB = DERIVS ? dB.g : 0;
+    const int rows = nA * (1 + gA);
+    const int j0 = blockIdx.x * cols_per_wg;  // column tiles on grid.x (up to 2^31-1 tiles: N x M builds have M >> 65535*16)
+    const int nj = min(cols_per_wg, nB - j0);
+    // lower_only (K(X, X) for the factorisation, r4): tiles above the diagonal are not visited and entries above it not stored -- the
+    // strict upper triangle of the destination stays what it is (zero: GpDev::rebuild clears the buffer when its shape changes)
+    if (lower_only && (long)blockIdx.y * kCovRows + kCovRows - 1 < (long)j0 * (1 + gB)) return;
+    for (int t = threadIdx.x; t < nj * DP; t += blockDim.x) Bs[t / DP][t % DP] = B[(long)(j0 + t / DP) * DP + (t % DP)];
+    __syncthreads();
+    const int r = blockIdx.y * kCovRows + threadIdx.x;
+    if (r >= rows) return;
+    const int i = DERIVS ? r / (1 + gA) : r;
+    const int a = DERIVS ? r % (1 + gA) : 0;
+    double xi[DP];
+  #pragma unroll
+    for (int k = 0; k < DP; ++k) xi[k] = A[(long)i * DP + k];
+    for (int jj = 0; jj < nj; ++jj) {
+      double diff[DP];
+      double r2 = 0.0;
+  #pragma unroll
+      for (int k = 0; k < DP; ++k) {
+        diff[k] = xi[k] - Bs[jj][k];
+        r2 = fma(diff[k] * diff[k], cp.inv_l2[k], r2);
+      }
+      const Radial rd = radial_scalars(cp.type, cp.alpha, r2);
+      if (!DERIVS) {
+        double v = rd.base;
+        const long col = col0 + j0 + jj;
+        if (diag_noise != nullptr && (long)r == col - col0) v += diag_noise[0];
+        if (!lower_only || (long)r >= col - col0) out[(long)r + (col + (j0 + jj >= split_at ? split_shift : 0)) * ld] = v;
+      } else {
+        for (int b = 0; b < 1 + gB; ++b) {
+          double v = cov_entry<DP>(cp, rd, diff, a, b, dA, dB);
+          const long colrel = (long)(j0 + jj) * (1 + gB) + b;
+          if (diag_noise != nullptr && (long)r == colrel) v += diag_noise[a];
+          if (!lower_only || (long)r >= colrel) out[(long)r + (col0 + colrel) * ld] = v;
+        }
+      }
+    }
+  }
+};
+template <int DP, bool DERIVS>
 __global__ __launch_bounds__(kCovRows) void cov_build_kernel(CovParams cp, const double* __restrict__ A, int nA,
                                                             DerivList dA, const double* __restrict__ B, int nB,
                                                             DerivList dB, const double* __restrict__ diag_noise,
                                                             double* __restrict__ out, long ld, long col0, int lower_only,
                                                             int cols_per_wg, int split_at = 0x7fffffff, long split_shift = 0) {
-  // (split_at / split_shift, r5, value-only builds: B points from index split_at on write their columns split_shift further right --
-  //  two point sets with separate column ranges in ONE launch, launch_cov_build_pair)
-  __shared__ double Bs[kCovCols][DP];
-  const int gA = DERIVS ? dA.g : 0, gB = DERIVS ? dB.g : 0;
-  const int rows = nA * (1 + gA);
-  const int j0 = blockIdx.x * cols_per_wg;  // column tiles on grid.x (up to 2^31-1 tiles: N x M builds have M >> 65535*16)
-  const int nj = min(cols_per_wg, nB - j0);
-  // lower_only (K(X, X) for the factorisation, r4): tiles above the diagonal are not visited and entries above it not stored -- the
-  // strict upper triangle of the destination stays what it is (zero: GpDev::rebuild clears the buffer when its shape changes)
-  if (lower_only && (long)blockIdx.y * kCovRows + kCovRows - 1 < (long)j0 * (1 + gB)) return;
-  for (int t = threadIdx.x; t < nj * DP; t += blockDim.x) Bs[t / DP][t % DP] = B[(long)(j0 + t / DP) * DP + (t % DP)];
-  __syncthreads();
-  const int r = blockIdx.y * kCovRows + threadIdx.x;
-  if (r >= rows) return;
-  const int i = DERIVS ? r / (1 + gA) : r;
-  const int a = DERIVS ? r % (1 + gA) : 0;
-  double xi[DP];
-#pragma unroll
-  for (int k = 0; k < DP; ++k) xi[k] = A[(long)i * DP + k];
-  for (int jj = 0; jj < nj; ++jj) {
-    double diff[DP];
-    double r2 = 0.0;
-#pragma unroll
-    for (int k = 0; k < DP; ++k) {
-      diff[k] = xi[k] - Bs[jj][k];
-      r2 = fma(diff[k] * diff[k], cp.inv_l2[k], r2);
-    }
-    const Radial rd = radial_scalars(cp.type, cp.alpha, r2);
-    if (!DERIVS) {
-      double v = rd.base;
-      const long col = col0 + j0 + jj;
-      if (diag_noise != nullptr && (long)r == col - col0) v += diag_noise[0];
-      if (!lower_only || (long)r >= col - col0) out[(long)r + (col + (j0 + jj >= split_at ? split_shift : 0)) * ld] = v;
-    } else {
-      for (int b = 0; b < 1 + gB; ++b) {
-        double v = cov_entry<DP>(cp, rd, diff, a, b, dA, dB);
-        const long colrel = (long)(j0 + jj) * (1 + gB) + b;
-        if (diag_noise != nullptr && (long)r == colrel) v += diag_noise[a];
-        if (!lower_only || (long)r >= colrel) out[(long)r + (col0 + colrel) * ld] = v;
-      }
-    }
-  }
+  cov_build_kernel_body<DP, DERIVS>::run(MOE_VBLOCK, MOE_VGRID, nullptr, cp, A, nA, dA, B, nB, dB, diag_noise, out, ld, col0, lower_only, cols_per_wg, split_at, split_shift);
 }
 
 // Derivative observations on the A side (K(X, X) of a d-KG GP, K*, the N x M gradient-tail matrix): one thread per A POINT
@@ -186,45 +192,51 @@ __global__ __launch_bounds__(kCovRows) void cov_build_value_kernel(CovParams cp,
 
 // d cov(P_i, X_j)[m, n] / d P_{i,dd}: one thread per training row (j, n); P staged in LDS.
 template <int DP, bool DERIVS>
+struct grad_kstar_kernel_body {
+  static __device__ __forceinline__ void run(const VIdx blockIdx, const VIdx gridDim, const void*, const CovParams& cp, const double* __restrict__ X, int n, const DerivList& dX, const double* __restrict__ P, int nP, const DerivList& dP, double* __restrict__ out, long ld, long col0, int pts_per_block) {
+    extern __shared__ double Ps[];  // [nP][DP]
+    for (int t = threadIdx.x; t < nP * DP; t += blockDim.x) Ps[t] = P[t];
+    __syncthreads();
+    // grid.y cuts the points into runs of pts_per_block: with a thread per training row alone, 8000 rows are 32 workgroups that
+    // each walk every point and column serially (336 us for two C5 evaluations' 768 columns, 0.15 TB/s)
+    const int i_lo = blockIdx.y * pts_per_block, i_hi = min(nP, i_lo + pts_per_block);
+    const int g = DERIVS ? dX.g : 0, gt = DERIVS ? dP.g : 0;
+    const int rows = n * (1 + g);
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= rows) return;
+    const int j = DERIVS ? r / (1 + g) : r;
+    const int nb = DERIVS ? r % (1 + g) : 0;
+    double xj[DP];
+  #pragma unroll
+    for (int k = 0; k < DP; ++k) xj[k] = X[(long)j * DP + k];
+    for (int i = i_lo; i < i_hi; ++i) {
+      double diff[DP];  // p1 - p2 = P_i - X_j
+      double r2 = 0.0;
+  #pragma unroll
+      for (int k = 0; k < DP; ++k) {
+        diff[k] = Ps[i * DP + k] - xj[k];
+        r2 = fma(diff[k] * diff[k], cp.inv_l2[k], r2);
+      }
+      const Radial rd = radial_scalars(cp.type, cp.alpha, r2);
+      if (!DERIVS) {
+  #pragma unroll
+        for (int dd = 0; dd < DP; ++dd) {
+          if (dd < cp.dim) out[(long)r + (col0 + (long)i * cp.dim + dd) * ld] = (-diff[dd] * cp.inv_l2[dd]) * rd.first;
+        }
+      } else {
+        for (int m = 0; m < 1 + gt; ++m)
+          for (int dd = 0; dd < cp.dim; ++dd)
+            out[(long)r + (col0 + ((long)i * (1 + gt) + m) * cp.dim + dd) * ld] =
+                grad_cov_entry<DP>(cp, rd, diff, m, nb, dd, dP, dX);
+      }
+    }
+  }
+};
+template <int DP, bool DERIVS>
 __global__ __launch_bounds__(256) void grad_kstar_kernel(CovParams cp, const double* __restrict__ X, int n, DerivList dX,
                                                         const double* __restrict__ P, int nP, DerivList dP,
                                                         double* __restrict__ out, long ld, long col0, int pts_per_block) {
-  extern __shared__ double Ps[];  // [nP][DP]
-  for (int t = threadIdx.x; t < nP * DP; t += blockDim.x) Ps[t] = P[t];
-  __syncthreads();
-  // grid.y cuts the points into runs of pts_per_block: with a thread per training row alone, 8000 rows are 32 workgroups that
-  // each walk every point and column serially (336 us for two C5 evaluations' 768 columns, 0.15 TB/s)
-  const int i_lo = blockIdx.y * pts_per_block, i_hi = min(nP, i_lo + pts_per_block);
-  const int g = DERIVS ? dX.g : 0, gt = DERIVS ? dP.g : 0;
-  const int rows = n * (1 + g);
-  const int r = blockIdx.x * blockDim.x + threadIdx.x;
-  if (r >= rows) return;
-  const int j = DERIVS ? r / (1 + g) : r;
-  const int nb = DERIVS ? r % (1 + g) : 0;
-  double xj[DP];
-#pragma unroll
-  for (int k = 0; k < DP; ++k) xj[k] = X[(long)j * DP + k];
-  for (int i = i_lo; i < i_hi; ++i) {
-    double diff[DP];  // p1 - p2 = P_i - X_j
-    double r2 = 0.0;
-#pragma unroll
-    for (int k = 0; k < DP; ++k) {
-      diff[k] = Ps[i * DP + k] - xj[k];
-      r2 = fma(diff[k] * diff[k], cp.inv_l2[k], r2);
-    }
-    const Radial rd = radial_scalars(cp.type, cp.alpha, r2);
-    if (!DERIVS) {
-#pragma unroll
-      for (int dd = 0; dd < DP; ++dd) {
-        if (dd < cp.dim) out[(long)r + (col0 + (long)i * cp.dim + dd) * ld] = (-diff[dd] * cp.inv_l2[dd]) * rd.first;
-      }
-    } else {
-      for (int m = 0; m < 1 + gt; ++m)
-        for (int dd = 0; dd < cp.dim; ++dd)
-          out[(long)r + (col0 + ((long)i * (1 + gt) + m) * cp.dim + dd) * ld] =
-              grad_cov_entry<DP>(cp, rd, diff, m, nb, dd, dP, dX);
-    }
-  }
+  grad_kstar_kernel_body<DP, DERIVS>::run(MOE_VBLOCK, MOE_VGRID, nullptr, cp, X, n, dX, P, nP, dP, out, ld, col0, pts_per_block);
 }
 
 
@@ -314,15 +326,15 @@ void cov_build_dp(const CovParams& cp, const double* A, int nA, const DerivList&
   if (grid.x == 0 || grid.y == 0) return;
   if (dA.g > 0 && value_fast_path()) {  // thread per point, rows transposed through LDS (MOE_COV_FAST=0: the row-per-thread kernel)
     dim3 pgrid(grid.x, (nA + 255) / 256);
-    hipLaunchKernelGGL((cov_build_points_kernel<DP>), pgrid, dim3(256), 0, s, cp, A, nA, dA, B, nB, dB, diag_noise, out, ld, col0, lo, cpw);
+    MOE_LAUNCH((cov_build_points_kernel<DP>), pgrid, dim3(256), 0, s, cp, A, nA, dA, B, nB, dB, diag_noise, out, ld, col0, lo, cpw);
   } else if (derivs)
-    hipLaunchKernelGGL((cov_build_kernel<DP, true>), grid, dim3(kCovRows), 0, s, cp, A, nA, dA, B, nB, dB, diag_noise, out, ld,
-                       col0, lo, cpw);
+    launch_kernel_ens<cov_build_kernel_body<DP, true>, kCovRows>(cov_build_kernel<DP, true>, grid, dim3(kCovRows), 0, s, cp, A, nA, dA, B, nB, dB,
+                                                                 diag_noise, out, ld, col0, lo, cpw, 0x7fffffff, 0L);
   else if (streaming && value_fast_path() && !lower_only)
-    hipLaunchKernelGGL((cov_build_value_kernel<DP>), grid, dim3(kCovRows), 0, s, cp, A, nA, B, nB, diag_noise, out, ld, col0);
+    MOE_LAUNCH((cov_build_value_kernel<DP>), grid, dim3(kCovRows), 0, s, cp, A, nA, B, nB, diag_noise, out, ld, col0);
   else
-    hipLaunchKernelGGL((cov_build_kernel<DP, false>), grid, dim3(kCovRows), 0, s, cp, A, nA, dA, B, nB, dB, diag_noise, out,
-                       ld, col0, lo, cpw);
+    launch_kernel_ens<cov_build_kernel_body<DP, false>, kCovRows>(cov_build_kernel<DP, false>, grid, dim3(kCovRows), 0, s, cp, A, nA, dA, B, nB,
+                                                                  dB, diag_noise, out, ld, col0, lo, cpw, 0x7fffffff, 0L);
 }
 
 template <int DP>
@@ -341,11 +353,11 @@ void grad_kstar_dp(const CovParams& cp, const double* X, int n, const DerivList&
     const size_t shm = sizeof(double) * (size_t)np * DP;
     const long c0 = col0 + (long)p0 * (1 + dP.g) * cp.dim;
     if (derivs)
-      hipLaunchKernelGGL((grad_kstar_kernel<DP, true>), grid, dim3(256), shm, s, cp, X, n, dX, P + (long)p0 * DP, np, dP, out,
-                         ld, c0, ppb);
+      launch_kernel_ens<grad_kstar_kernel_body<DP, true>, 256>(grad_kstar_kernel<DP, true>, grid, dim3(256), shm, s, cp, X, n, dX,
+                                                               P + (long)p0 * DP, np, dP, out, ld, c0, ppb);
     else
-      hipLaunchKernelGGL((grad_kstar_kernel<DP, false>), grid, dim3(256), shm, s, cp, X, n, dX, P + (long)p0 * DP, np, dP, out,
-                         ld, c0, ppb);
+      launch_kernel_ens<grad_kstar_kernel_body<DP, false>, 256>(grad_kstar_kernel<DP, false>, grid, dim3(256), shm, s, cp, X, n, dX,
+                                                                P + (long)p0 * DP, np, dP, out, ld, c0, ppb);
   }
 }
 
@@ -359,7 +371,7 @@ __global__ void debug_math_kernel(const double* __restrict__ x, int n, double* _
 }  // namespace
 
 void launch_debug_math(const double* x, int n, double* e, double* r, hipStream_t s) {
-  hipLaunchKernelGGL(debug_math_kernel, dim3((n + 255) / 256), dim3(256), 0, s, x, n, e, r);
+  MOE_LAUNCH(debug_math_kernel, dim3((n + 255) / 256), dim3(256), 0, s, x, n, e, r);
   MOE_HIP_CHECK(hipGetLastError());
 }
 
@@ -389,8 +401,9 @@ void cov_build_pair_dp(const CovParams& cp, const double* A, int nA, const doubl
   dim3 grid((nB + kCovCols - 1) / kCovCols, (nA + kCovRows - 1) / kCovRows);
   if (grid.x == 0 || grid.y == 0) return;
   // point b >= nB1 belongs at column col2 + (b - nB1) = col1 + b + (col2 - col1 - nB1)
-  hipLaunchKernelGGL((cov_build_kernel<DP, false>), grid, dim3(kCovRows), 0, s, cp, A, nA, none, B, nB, none, (const double*)nullptr, out,
-                     ld, col1, 0, kCovCols, nB1, col2 - col1 - (long)nB1);
+  launch_kernel_ens<cov_build_kernel_body<DP, false>, kCovRows>(cov_build_kernel<DP, false>, grid, dim3(kCovRows), 0, s, cp, A, nA, none, B, nB, none,
+                                                                (const double*)nullptr, out, ld, col1, 0, kCovCols, nB1,
+                                                                col2 - col1 - (long)nB1);
 }
 }  // namespace
 
@@ -417,9 +430,9 @@ void launch_mean(const CovParams& cp, const double* X, int n, const DerivList& d
 #define MOE_MEAN_CASE(DPV)                                                                                                \
   case DPV:                                                                                                               \
     if (want_grad)                                                                                                        \
-      hipLaunchKernelGGL((mean_kernel<DPV, true>), dim3(nP), dim3(256), 0, s, cp, X, n, dX, KinvY, P, mean, out);        \
+      MOE_LAUNCH((mean_kernel<DPV, true>), dim3(nP), dim3(256), 0, s, cp, X, n, dX, KinvY, P, mean, out);        \
     else                                                                                                                  \
-      hipLaunchKernelGGL((mean_kernel<DPV, false>), dim3(nP), dim3(256), 0, s, cp, X, n, dX, KinvY, P, mean, out);       \
+      MOE_LAUNCH((mean_kernel<DPV, false>), dim3(nP), dim3(256), 0, s, cp, X, n, dX, KinvY, P, mean, out);       \
     break;
   switch (cp.dp) {
     MOE_MEAN_CASE(4)

@@ -31,94 +31,100 @@ constexpr int TK = 16;
 // KT = depth of one LDS stage: skinny outputs (few workgroups, latency-bound K loop) use deep stages so the loop has 4x
 // fewer global-load / barrier round trips; big outputs keep 16 for occupancy.
 template <int TM, int TN, int MODE, int KT, bool NEG = false>
+struct tile_gemm_kernel_body {
+  static __device__ __forceinline__ void run(const VIdx blockIdx, const VIdx gridDim, const void*, int M, int Ncols, int K, const double* __restrict__ A, long lda, const double* __restrict__ B, long ldb, double* __restrict__ C, long ldc) {
+    constexpr int RM = TM / 16, RN = TN / 16;
+    constexpr int TK = KT;
+    __shared__ double As[TK][TM + 1];
+    __shared__ double Bs[TK][TN + 1];
+    const int tx = threadIdx.x % 16, ty = threadIdx.x / 16;
+    const int i0 = blockIdx.x * TM, j0 = blockIdx.y * TN;
+    int k_lo = 0, k_hi = K;
+    if (MODE == 1) k_hi = min(K, i0 + TM);
+    if (MODE == 2) k_lo = (i0 / TK) * TK;
+    if (MODE == 3) k_lo = (j0 / TK) * TK;
+    double acc[RM][RN];
+  #pragma unroll
+    for (int a = 0; a < RM; ++a)
+  #pragma unroll
+      for (int b = 0; b < RN; ++b) acc[a][b] = 0.0;
+
+    // The next stage's operand tiles travel global -> registers while the current stage is multiplied out of LDS: skinny
+    // outputs leave a handful of workgroups walking K, and without the prefetch every stage pays a full memory round trip
+    // (65 us for L^-1 (1000 x 1000) times 50 columns -- a quarter of a batch-1 q-KG evaluation's set-up).
+    constexpr int NA = TK * TM / 256, NBV = TK * TN / 256;
+    static_assert(TK * TM % 256 == 0 && TK * TN % 256 == 0, "operand tiles are whole multiples of the workgroup");
+    double pa[NA], pb[NBV];
+    auto fetch = [&](int k0) {
+  #pragma unroll
+      for (int i = 0; i < NA; ++i) {
+        const int t = threadIdx.x + i * 256;
+        if (MODE == 1 || MODE == 3) {
+          const int ii = t % TM, kk = t / TM;
+          const int gi = i0 + ii, gk = k0 + kk;
+          pa[i] = (gi < M && gk < K && (MODE == 3 || gk <= gi)) ? A[(long)gi + (long)gk * lda] : 0.0;
+        } else {
+          const int kk = t % TK, ii = t / TK;
+          const int gi = i0 + ii, gk = k0 + kk;
+          bool ok = gi < M && gk < K;
+          if (MODE == 2) ok = ok && gk >= gi;
+          pa[i] = ok ? A[(long)gk + (long)gi * lda] : 0.0;
+        }
+      }
+  #pragma unroll
+      for (int i = 0; i < NBV; ++i) {
+        const int t = threadIdx.x + i * 256;
+        const int kk = t % TK, jj = t / TK;
+        const int gk = k0 + kk, gj = j0 + jj;
+        pb[i] = (gk < K && gj < Ncols && (MODE != 3 || gk >= gj)) ? B[(long)gk + (long)gj * ldb] : 0.0;
+      }
+    };
+    if (k_lo < k_hi) fetch(k_lo);
+    for (int k0 = k_lo; k0 < k_hi; k0 += TK) {
+      // stage the tiles: As[kk][ii] = Aop(i0+ii, k0+kk), Bs[kk][jj] = B(k0+kk, j0+jj)
+  #pragma unroll
+      for (int i = 0; i < NA; ++i) {
+        const int t = threadIdx.x + i * 256;
+        if (MODE == 1 || MODE == 3)
+          As[t / TM][t % TM] = pa[i];
+        else
+          As[t % TK][t / TK] = pa[i];
+      }
+  #pragma unroll
+      for (int i = 0; i < NBV; ++i) {
+        const int t = threadIdx.x + i * 256;
+        Bs[t % TK][t / TK] = pb[i];
+      }
+      __syncthreads();
+      if (k0 + TK < k_hi) fetch(k0 + TK);
+  #pragma unroll
+      for (int kk = 0; kk < TK; ++kk) {
+        double av[RM], bv[RN];
+  #pragma unroll
+        for (int a = 0; a < RM; ++a) av[a] = As[kk][tx + 16 * a];
+  #pragma unroll
+        for (int b = 0; b < RN; ++b) bv[b] = Bs[kk][ty + 16 * b];
+  #pragma unroll
+        for (int a = 0; a < RM; ++a)
+  #pragma unroll
+          for (int b = 0; b < RN; ++b) acc[a][b] = fma(av[a], bv[b], acc[a][b]);
+      }
+      __syncthreads();
+    }
+  #pragma unroll
+    for (int a = 0; a < RM; ++a)
+  #pragma unroll
+      for (int b = 0; b < RN; ++b) {
+        const int gi = i0 + tx + 16 * a, gj = j0 + ty + 16 * b;
+        if (gi < M && gj < Ncols) C[(long)gi + (long)gj * ldc] = NEG ? -acc[a][b] : acc[a][b];
+      }
+  }
+};
+template <int TM, int TN, int MODE, int KT, bool NEG = false>
 __global__ __launch_bounds__(256) void tile_gemm_kernel(int M, int Ncols, int K, const double* __restrict__ A, long lda,
                                                        const double* __restrict__ B, long ldb, double* __restrict__ C,
                                                        long ldc) {
-  constexpr int RM = TM / 16, RN = TN / 16;
-  constexpr int TK = KT;
-  __shared__ double As[TK][TM + 1];
-  __shared__ double Bs[TK][TN + 1];
-  const int tx = threadIdx.x % 16, ty = threadIdx.x / 16;
-  const int i0 = blockIdx.x * TM, j0 = blockIdx.y * TN;
-  int k_lo = 0, k_hi = K;
-  if (MODE == 1) k_hi = min(K, i0 + TM);
-  if (MODE == 2) k_lo = (i0 / TK) * TK;
-  if (MODE == 3) k_lo = (j0 / TK) * TK;
-  double acc[RM][RN];
-#pragma unroll
-  for (int a = 0; a < RM; ++a)
-#pragma unroll
-    for (int b = 0; b < RN; ++b) acc[a][b] = 0.0;
-
-  // The next stage's operand tiles travel global -> registers while the current stage is multiplied out of LDS: skinny
-  // outputs leave a handful of workgroups walking K, and without the prefetch every stage pays a full memory round trip
-  // (65 us for L^-1 (1000 x 1000) times 50 columns -- a quarter of a batch-1 q-KG evaluation's set-up).
-  constexpr int NA = TK * TM / 256, NBV = TK * TN / 256;
-  static_assert(TK * TM % 256 == 0 && TK * TN % 256 == 0, "operand tiles are whole multiples of the workgroup");
-  double pa[NA], pb[NBV];
-  auto fetch = [&](int k0) {
-#pragma unroll
-    for (int i = 0; i < NA; ++i) {
-      const int t = threadIdx.x + i * 256;
-      if (MODE == 1 || MODE == 3) {
-        const int ii = t % TM, kk = t / TM;
-        const int gi = i0 + ii, gk = k0 + kk;
-        pa[i] = (gi < M && gk < K && (MODE == 3 || gk <= gi)) ? A[(long)gi + (long)gk * lda] : 0.0;
-      } else {
-        const int kk = t % TK, ii = t / TK;
-        const int gi = i0 + ii, gk = k0 + kk;
-        bool ok = gi < M && gk < K;
-        if (MODE == 2) ok = ok && gk >= gi;
-        pa[i] = ok ? A[(long)gk + (long)gi * lda] : 0.0;
-      }
-    }
-#pragma unroll
-    for (int i = 0; i < NBV; ++i) {
-      const int t = threadIdx.x + i * 256;
-      const int kk = t % TK, jj = t / TK;
-      const int gk = k0 + kk, gj = j0 + jj;
-      pb[i] = (gk < K && gj < Ncols && (MODE != 3 || gk >= gj)) ? B[(long)gk + (long)gj * ldb] : 0.0;
-    }
-  };
-  if (k_lo < k_hi) fetch(k_lo);
-  for (int k0 = k_lo; k0 < k_hi; k0 += TK) {
-    // stage the tiles: As[kk][ii] = Aop(i0+ii, k0+kk), Bs[kk][jj] = B(k0+kk, j0+jj)
-#pragma unroll
-    for (int i = 0; i < NA; ++i) {
-      const int t = threadIdx.x + i * 256;
-      if (MODE == 1 || MODE == 3)
-        As[t / TM][t % TM] = pa[i];
-      else
-        As[t % TK][t / TK] = pa[i];
-    }
-#pragma unroll
-    for (int i = 0; i < NBV; ++i) {
-      const int t = threadIdx.x + i * 256;
-      Bs[t % TK][t / TK] = pb[i];
-    }
-    __syncthreads();
-    if (k0 + TK < k_hi) fetch(k0 + TK);
-#pragma unroll
-    for (int kk = 0; kk < TK; ++kk) {
-      double av[RM], bv[RN];
-#pragma unroll
-      for (int a = 0; a < RM; ++a) av[a] = As[kk][tx + 16 * a];
-#pragma unroll
-      for (int b = 0; b < RN; ++b) bv[b] = Bs[kk][ty + 16 * b];
-#pragma unroll
-      for (int a = 0; a < RM; ++a)
-#pragma unroll
-        for (int b = 0; b < RN; ++b) acc[a][b] = fma(av[a], bv[b], acc[a][b]);
-    }
-    __syncthreads();
-  }
-#pragma unroll
-  for (int a = 0; a < RM; ++a)
-#pragma unroll
-    for (int b = 0; b < RN; ++b) {
-      const int gi = i0 + tx + 16 * a, gj = j0 + ty + 16 * b;
-      if (gi < M && gj < Ncols) C[(long)gi + (long)gj * ldc] = NEG ? -acc[a][b] : acc[a][b];
-    }
+  tile_gemm_kernel_body<TM, TN, MODE, KT, NEG>::run(MOE_VBLOCK, MOE_VGRID, nullptr, M, Ncols, K, A, lda, B, ldb, C, ldc);
 }
 
 // The same GEMM on the matrix pipe for big outputs: 64 x 64 tile per workgroup, 4 wavefronts, each owning a 32 x 32
@@ -306,17 +312,19 @@ void tile_gemm(int M, int Ncols, int K, const double* A, long lda, const double*
         return (v && *v) ? std::atoi(v) : 16;
       }();
       if (tk == 32)
-        hipLaunchKernelGGL((mfma_gemm_kernel<MODE, NEG, 32>), mgrid, dim3(256), 0, s, M, Ncols, K, A, lda, B, ldb, C, ldc, xmul, pair_rows,
+        MOE_LAUNCH((mfma_gemm_kernel<MODE, NEG, 32>), mgrid, dim3(256), 0, s, M, Ncols, K, A, lda, B, ldb, C, ldc, xmul, pair_rows,
                            0L, 0L, 0L, 0, 0, tri_scale);
       else
-        hipLaunchKernelGGL((mfma_gemm_kernel<MODE, NEG, 16>), mgrid, dim3(256), 0, s, M, Ncols, K, A, lda, B, ldb, C, ldc, xmul, pair_rows,
+        MOE_LAUNCH((mfma_gemm_kernel<MODE, NEG, 16>), mgrid, dim3(256), 0, s, M, Ncols, K, A, lda, B, ldb, C, ldc, xmul, pair_rows,
                            0L, 0L, 0L, 0, 0, tri_scale);
     }
     else
-      hipLaunchKernelGGL((tile_gemm_kernel<64, 64, MODE, 16, NEG>), grid, dim3(256), 0, s, M, Ncols, K, A, lda, B, ldb, C, ldc);
+      launch_kernel_ens<tile_gemm_kernel_body<64, 64, MODE, 16, NEG>, 256>(tile_gemm_kernel<64, 64, MODE, 16, NEG>, grid, dim3(256), 0, s, M, Ncols, K, A,
+                                                                           lda, B, ldb, C, ldc);
   } else {
     dim3 grid((M + 31) / 32, (Ncols + 15) / 16);
-    hipLaunchKernelGGL((tile_gemm_kernel<32, 16, MODE, 128, NEG>), grid, dim3(256), 0, s, M, Ncols, K, A, lda, B, ldb, C, ldc);
+    launch_kernel_ens<tile_gemm_kernel_body<32, 16, MODE, 128, NEG>, 256>(tile_gemm_kernel<32, 16, MODE, 128, NEG>, grid, dim3(256), 0, s, M, Ncols, K, A,
+                                                                          lda, B, ldb, C, ldc);
   }
   MOE_HIP_CHECK(hipGetLastError());
 }
@@ -331,7 +339,7 @@ void launch_gemm128(const g128::GemmArgs& g, int batch, hipStream_t s) {
   const int R = (g.M + g128::TM - 1) / g128::TM, Ct = (g.N + g128::TM - 1) / g128::TM;
   g128::GemmArgs ga = g;
   ga.batch = batch;
-  hipLaunchKernelGGL(kern, dim3((unsigned)(R * Ct * batch)), dim3(256), g128::kSmemBytes, s, ga);
+  MOE_LAUNCH(kern, dim3((unsigned)(R * Ct * batch)), dim3(256), g128::kSmemBytes, s, ga);
   MOE_HIP_CHECK(hipGetLastError());
 }
 // Which kernel a big product of the build takes: a cost estimate for either, from measured rates (MI355X, r4).  The 128-tile
@@ -383,67 +391,72 @@ struct GramMap {
   }
 };
 
+struct gram_batch_kernel_body {
+  static __device__ __forceinline__ void run(const VIdx blockIdx, const VIdx gridDim, const void*, const GramMap& gm, int K, const double* __restrict__ V, long ldv, double* __restrict__ G, int slices) {
+    constexpr int T = 32;
+    constexpr int TK = 64;  // deep stages: the grid is tiny (c <= a few hundred), the K loop is latency-bound
+    __shared__ double As[TK][T + 1];
+    __shared__ double Bs[TK][T + 1];
+    if (blockIdx.y > blockIdx.x) return;
+    const int c = gm.m + gm.ng + gm.A;
+    // blockIdx.z = evaluation * slices + K slice: with `slices` > 1 the output is a partial Gram per slice (summed in slice
+    // order by gram_sum_kernel), which gives the few output tiles enough workgroups to hide the K loop's latency
+    const int e = blockIdx.z / slices, sl = blockIdx.z % slices;
+    const int kper = ((K + slices - 1) / slices + TK - 1) / TK * TK;
+    const int k_begin = sl * kper, k_end = min(K, k_begin + kper);
+    const int i0 = blockIdx.x * T, j0 = blockIdx.y * T;
+    const int tx = threadIdx.x % 16, ty = threadIdx.x / 16;
+    double acc[2][2] = {{0.0, 0.0}, {0.0, 0.0}};
+    // (the next stage's columns travel global -> registers while the current stage is multiplied out of LDS: see tile_gemm_kernel)
+    constexpr int NE = TK * T / 256;
+    double pa[NE], pb[NE];
+    auto fetch = [&](int k0) {
+  #pragma unroll
+      for (int i = 0; i < NE; ++i) {
+        const int t = threadIdx.x + i * 256;
+        const int kk = t % TK, ii = t / TK;
+        const int gk = k0 + kk;
+        const int gi = i0 + ii, gj = j0 + ii;
+        pa[i] = (gi < c && gk < k_end) ? V[(long)gk + gm.col(e, gi) * ldv] : 0.0;
+        pb[i] = (gj < c && gk < k_end) ? V[(long)gk + gm.col(e, gj) * ldv] : 0.0;
+      }
+    };
+    if (k_begin < k_end) fetch(k_begin);
+    for (int k0 = k_begin; k0 < k_end; k0 += TK) {
+  #pragma unroll
+      for (int i = 0; i < NE; ++i) {
+        const int t = threadIdx.x + i * 256;
+        As[t % TK][t / TK] = pa[i];
+        Bs[t % TK][t / TK] = pb[i];
+      }
+      __syncthreads();
+      if (k0 + TK < k_end) fetch(k0 + TK);
+  #pragma unroll
+      for (int kk = 0; kk < TK; ++kk) {
+        const double a0 = As[kk][tx], a1 = As[kk][tx + 16], b0 = Bs[kk][ty], b1 = Bs[kk][ty + 16];
+        acc[0][0] = fma(a0, b0, acc[0][0]);
+        acc[0][1] = fma(a0, b1, acc[0][1]);
+        acc[1][0] = fma(a1, b0, acc[1][0]);
+        acc[1][1] = fma(a1, b1, acc[1][1]);
+      }
+      __syncthreads();
+    }
+    double* Ge = G + (long)blockIdx.z * c * c;
+  #pragma unroll
+    for (int a = 0; a < 2; ++a)
+  #pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        const int gi = i0 + tx + 16 * a, gj = j0 + ty + 16 * b;
+        if (gi < c && gj < c) {
+          Ge[(long)gi + (long)gj * c] = acc[a][b];
+          Ge[(long)gj + (long)gi * c] = acc[a][b];  // symmetric: identical sum, so both triangles hold the same bits
+        }
+      }
+  }
+};
 __global__ __launch_bounds__(256) void gram_batch_kernel(GramMap gm, int K, const double* __restrict__ V, long ldv,
                                                         double* __restrict__ G, int slices) {
-  constexpr int T = 32;
-  constexpr int TK = 64;  // deep stages: the grid is tiny (c <= a few hundred), the K loop is latency-bound
-  __shared__ double As[TK][T + 1];
-  __shared__ double Bs[TK][T + 1];
-  if (blockIdx.y > blockIdx.x) return;
-  const int c = gm.m + gm.ng + gm.A;
-  // blockIdx.z = evaluation * slices + K slice: with `slices` > 1 the output is a partial Gram per slice (summed in slice
-  // order by gram_sum_kernel), which gives the few output tiles enough workgroups to hide the K loop's latency
-  const int e = blockIdx.z / slices, sl = blockIdx.z % slices;
-  const int kper = ((K + slices - 1) / slices + TK - 1) / TK * TK;
-  const int k_begin = sl * kper, k_end = min(K, k_begin + kper);
-  const int i0 = blockIdx.x * T, j0 = blockIdx.y * T;
-  const int tx = threadIdx.x % 16, ty = threadIdx.x / 16;
-  double acc[2][2] = {{0.0, 0.0}, {0.0, 0.0}};
-  // (the next stage's columns travel global -> registers while the current stage is multiplied out of LDS: see tile_gemm_kernel)
-  constexpr int NE = TK * T / 256;
-  double pa[NE], pb[NE];
-  auto fetch = [&](int k0) {
-#pragma unroll
-    for (int i = 0; i < NE; ++i) {
-      const int t = threadIdx.x + i * 256;
-      const int kk = t % TK, ii = t / TK;
-      const int gk = k0 + kk;
-      const int gi = i0 + ii, gj = j0 + ii;
-      pa[i] = (gi < c && gk < k_end) ? V[(long)gk + gm.col(e, gi) * ldv] : 0.0;
-      pb[i] = (gj < c && gk < k_end) ? V[(long)gk + gm.col(e, gj) * ldv] : 0.0;
-    }
-  };
-  if (k_begin < k_end) fetch(k_begin);
-  for (int k0 = k_begin; k0 < k_end; k0 += TK) {
-#pragma unroll
-    for (int i = 0; i < NE; ++i) {
-      const int t = threadIdx.x + i * 256;
-      As[t % TK][t / TK] = pa[i];
-      Bs[t % TK][t / TK] = pb[i];
-    }
-    __syncthreads();
-    if (k0 + TK < k_end) fetch(k0 + TK);
-#pragma unroll
-    for (int kk = 0; kk < TK; ++kk) {
-      const double a0 = As[kk][tx], a1 = As[kk][tx + 16], b0 = Bs[kk][ty], b1 = Bs[kk][ty + 16];
-      acc[0][0] = fma(a0, b0, acc[0][0]);
-      acc[0][1] = fma(a0, b1, acc[0][1]);
-      acc[1][0] = fma(a1, b0, acc[1][0]);
-      acc[1][1] = fma(a1, b1, acc[1][1]);
-    }
-    __syncthreads();
-  }
-  double* Ge = G + (long)blockIdx.z * c * c;
-#pragma unroll
-  for (int a = 0; a < 2; ++a)
-#pragma unroll
-    for (int b = 0; b < 2; ++b) {
-      const int gi = i0 + tx + 16 * a, gj = j0 + ty + 16 * b;
-      if (gi < c && gj < c) {
-        Ge[(long)gi + (long)gj * c] = acc[a][b];
-        Ge[(long)gj + (long)gi * c] = acc[a][b];  // symmetric: identical sum, so both triangles hold the same bits
-      }
-    }
+  gram_batch_kernel_body::run(MOE_VBLOCK, MOE_VGRID, nullptr, gm, K, V, ldv, G, slices);
 }
 
 // Batched cross products X_e[r x m] = S_e^T W_e (r4, the KG state): S_e = the evaluation's `ng` gradient columns and `A` extra
@@ -451,61 +464,66 @@ __global__ __launch_bounds__(256) void gram_batch_kernel(GramMap gm, int K, cons
 // (columns e m .. e m + m - 1 of W).  This is how the reference itself forms these blocks -- dK*^T (K^-1 K*), gpp_math.cpp:1277-1290 --
 // and it means L^-1 is never applied to the gradient / extra columns (474 columns per evaluation at C5 against 32 of K*).
 // 32 x 32 output tile per workgroup, blockIdx.z = evaluation * slices + K slice (partials summed in slice order).
+struct gram_cross_batch_kernel_body {
+  static __device__ __forceinline__ void run(const VIdx blockIdx, const VIdx gridDim, const void*, const GramMap& gm, int K, const double* __restrict__ S, long lds, const double* __restrict__ W, long ldw, double* __restrict__ G, int slices) {
+    constexpr int T = 32;
+    constexpr int TK = 64;
+    __shared__ double As[TK][T + 1];
+    __shared__ double Bs[TK][T + 1];
+    const int r = gm.ng + gm.A;
+    const int e = blockIdx.z / slices, sl = blockIdx.z % slices;
+    const int kper = ((K + slices - 1) / slices + TK - 1) / TK * TK;
+    const int k_begin = sl * kper, k_end = min(K, k_begin + kper);
+    const int i0 = blockIdx.x * T, j0 = blockIdx.y * T;
+    const int tx = threadIdx.x % 16, ty = threadIdx.x / 16;
+    double acc[2][2] = {{0.0, 0.0}, {0.0, 0.0}};
+    constexpr int NE = TK * T / 256;
+    double pa[NE], pb[NE];
+    auto fetch = [&](int k0) {
+  #pragma unroll
+      for (int i = 0; i < NE; ++i) {
+        const int t = threadIdx.x + i * 256;
+        const int kk = t % TK, ii = t / TK;
+        const int gk = k0 + kk;
+        const int gi = i0 + ii, gj = j0 + ii;
+        pa[i] = (gi < r && gk < k_end) ? S[(long)gk + gm.col(e, gm.m + gi) * lds] : 0.0;
+        pb[i] = (gj < gm.m && gk < k_end) ? W[(long)gk + ((long)e * gm.m + gj) * ldw] : 0.0;
+      }
+    };
+    if (k_begin < k_end) fetch(k_begin);
+    for (int k0 = k_begin; k0 < k_end; k0 += TK) {
+  #pragma unroll
+      for (int i = 0; i < NE; ++i) {
+        const int t = threadIdx.x + i * 256;
+        As[t % TK][t / TK] = pa[i];
+        Bs[t % TK][t / TK] = pb[i];
+      }
+      __syncthreads();
+      if (k0 + TK < k_end) fetch(k0 + TK);
+  #pragma unroll
+      for (int kk = 0; kk < TK; ++kk) {
+        const double a0 = As[kk][tx], a1 = As[kk][tx + 16], b0 = Bs[kk][ty], b1 = Bs[kk][ty + 16];
+        acc[0][0] = fma(a0, b0, acc[0][0]);
+        acc[0][1] = fma(a0, b1, acc[0][1]);
+        acc[1][0] = fma(a1, b0, acc[1][0]);
+        acc[1][1] = fma(a1, b1, acc[1][1]);
+      }
+      __syncthreads();
+    }
+    double* Ge = G + (long)blockIdx.z * r * gm.m;
+  #pragma unroll
+    for (int a = 0; a < 2; ++a)
+  #pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        const int gi = i0 + tx + 16 * a, gj = j0 + ty + 16 * b;
+        if (gi < r && gj < gm.m) Ge[(long)gi + (long)gj * r] = acc[a][b];
+      }
+  }
+};
 __global__ __launch_bounds__(256) void gram_cross_batch_kernel(GramMap gm, int K, const double* __restrict__ S, long lds,
                                                               const double* __restrict__ W, long ldw, double* __restrict__ G,
                                                               int slices) {
-  constexpr int T = 32;
-  constexpr int TK = 64;
-  __shared__ double As[TK][T + 1];
-  __shared__ double Bs[TK][T + 1];
-  const int r = gm.ng + gm.A;
-  const int e = blockIdx.z / slices, sl = blockIdx.z % slices;
-  const int kper = ((K + slices - 1) / slices + TK - 1) / TK * TK;
-  const int k_begin = sl * kper, k_end = min(K, k_begin + kper);
-  const int i0 = blockIdx.x * T, j0 = blockIdx.y * T;
-  const int tx = threadIdx.x % 16, ty = threadIdx.x / 16;
-  double acc[2][2] = {{0.0, 0.0}, {0.0, 0.0}};
-  constexpr int NE = TK * T / 256;
-  double pa[NE], pb[NE];
-  auto fetch = [&](int k0) {
-#pragma unroll
-    for (int i = 0; i < NE; ++i) {
-      const int t = threadIdx.x + i * 256;
-      const int kk = t % TK, ii = t / TK;
-      const int gk = k0 + kk;
-      const int gi = i0 + ii, gj = j0 + ii;
-      pa[i] = (gi < r && gk < k_end) ? S[(long)gk + gm.col(e, gm.m + gi) * lds] : 0.0;
-      pb[i] = (gj < gm.m && gk < k_end) ? W[(long)gk + ((long)e * gm.m + gj) * ldw] : 0.0;
-    }
-  };
-  if (k_begin < k_end) fetch(k_begin);
-  for (int k0 = k_begin; k0 < k_end; k0 += TK) {
-#pragma unroll
-    for (int i = 0; i < NE; ++i) {
-      const int t = threadIdx.x + i * 256;
-      As[t % TK][t / TK] = pa[i];
-      Bs[t % TK][t / TK] = pb[i];
-    }
-    __syncthreads();
-    if (k0 + TK < k_end) fetch(k0 + TK);
-#pragma unroll
-    for (int kk = 0; kk < TK; ++kk) {
-      const double a0 = As[kk][tx], a1 = As[kk][tx + 16], b0 = Bs[kk][ty], b1 = Bs[kk][ty + 16];
-      acc[0][0] = fma(a0, b0, acc[0][0]);
-      acc[0][1] = fma(a0, b1, acc[0][1]);
-      acc[1][0] = fma(a1, b0, acc[1][0]);
-      acc[1][1] = fma(a1, b1, acc[1][1]);
-    }
-    __syncthreads();
-  }
-  double* Ge = G + (long)blockIdx.z * r * gm.m;
-#pragma unroll
-  for (int a = 0; a < 2; ++a)
-#pragma unroll
-    for (int b = 0; b < 2; ++b) {
-      const int gi = i0 + tx + 16 * a, gj = j0 + ty + 16 * b;
-      if (gi < r && gj < gm.m) Ge[(long)gi + (long)gj * r] = acc[a][b];
-    }
+  gram_cross_batch_kernel_body::run(MOE_VBLOCK, MOE_VGRID, nullptr, gm, K, S, lds, W, ldw, G, slices);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -821,9 +839,9 @@ void launch_tri_skinny(char op, int N, int c, const double* T, long ldt, const d
     const size_t shm = sizeof(double) * ((size_t)8 * CB * 64 + (size_t)512 * CB);
     if (shm > 48 * 1024)
       MOE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
-    hipLaunchKernelGGL(kern, dim3((N + 63) / 64, groups), dim3(1024), shm, s, N, T, ldt, B, ldb, c, C, ldc);
+    MOE_LAUNCH(kern, dim3((N + 63) / 64, groups), dim3(1024), shm, s, N, T, ldt, B, ldb, c, C, ldc);
   } else {
-    hipLaunchKernelGGL((tri_skinny_t_kernel<CB>), dim3((N + 3) / 4, groups), dim3(256), 0, s, N, T, ldt, B, ldb, c, C, ldc);
+    MOE_LAUNCH((tri_skinny_t_kernel<CB>), dim3((N + 3) / 4, groups), dim3(256), 0, s, N, T, ldt, B, ldb, c, C, ldc);
   }
   MOE_HIP_CHECK(hipGetLastError());
 }
@@ -966,16 +984,16 @@ void launch_tri_gemm_cols(char op, int N, int c, int cols_per_problem, const dou
   }();
   if (op == 'N') {
     if (tk == 32)
-      hipLaunchKernelGGL((tri_splitk_kernel<1, 32>), grid, dim3(256), 0, s, N, c, KS, T, ldt, B, ldb, work);
+      MOE_LAUNCH((tri_splitk_kernel<1, 32>), grid, dim3(256), 0, s, N, c, KS, T, ldt, B, ldb, work);
     else
-      hipLaunchKernelGGL((tri_splitk_kernel<1, 16>), grid, dim3(256), 0, s, N, c, KS, T, ldt, B, ldb, work);
-    hipLaunchKernelGGL(tri_splitk_sum_kernel<1>, sgrid, dim3(256), 0, s, N, c, KS, slices, (const double*)work, C, ldc);
+      MOE_LAUNCH((tri_splitk_kernel<1, 16>), grid, dim3(256), 0, s, N, c, KS, T, ldt, B, ldb, work);
+    MOE_LAUNCH(tri_splitk_sum_kernel<1>, sgrid, dim3(256), 0, s, N, c, KS, slices, (const double*)work, C, ldc);
   } else {
     if (tk == 32)
-      hipLaunchKernelGGL((tri_splitk_kernel<2, 32>), grid, dim3(256), 0, s, N, c, KS, T, ldt, B, ldb, work);
+      MOE_LAUNCH((tri_splitk_kernel<2, 32>), grid, dim3(256), 0, s, N, c, KS, T, ldt, B, ldb, work);
     else
-      hipLaunchKernelGGL((tri_splitk_kernel<2, 16>), grid, dim3(256), 0, s, N, c, KS, T, ldt, B, ldb, work);
-    hipLaunchKernelGGL(tri_splitk_sum_kernel<2>, sgrid, dim3(256), 0, s, N, c, KS, slices, (const double*)work, C, ldc);
+      MOE_LAUNCH((tri_splitk_kernel<2, 16>), grid, dim3(256), 0, s, N, c, KS, T, ldt, B, ldb, work);
+    MOE_LAUNCH(tri_splitk_sum_kernel<2>, sgrid, dim3(256), 0, s, N, c, KS, slices, (const double*)work, C, ldc);
   }
   MOE_HIP_CHECK(hipGetLastError());
 }
@@ -1008,7 +1026,7 @@ void launch_tri_gram_strided(int N, int c, int stride, const double* T, long ldt
   // dimension stride * ldt whose row i starts at k = i stride
   tile_gemm<2>(c, c, N, T, (long)stride * ldt, T, (long)stride * ldt, G, ldg, s, stride);
   if (diag != nullptr) {
-    hipLaunchKernelGGL(tri_colnorm2_kernel, dim3((N + 3) / 4), dim3(256), 0, s, N, T, ldt, diag);
+    MOE_LAUNCH(tri_colnorm2_kernel, dim3((N + 3) / 4), dim3(256), 0, s, N, T, ldt, diag);
     MOE_HIP_CHECK(hipGetLastError());
   }
 }
@@ -1035,23 +1053,28 @@ void launch_tri_gemm_skinny(char op, int N, int c, const double* T, long ldt, co
 namespace {
 // out[c] = sum_k A[k + c * lda] x[k]: one workgroup per column, coalesced reads, fixed-order reduction.  (A^T x as a tile
 // GEMM with ONE output column leaves a handful of workgroups walking K serially: 0.84 ms at 8000 x 474.)
+struct gemv_t_kernel_body {
+  static __device__ __forceinline__ void run(const VIdx blockIdx, const VIdx gridDim, const void*, int K, const double* __restrict__ A, long lda, const double* __restrict__ x, double* __restrict__ out) {
+    __shared__ double red[4];
+    const double* col = A + (long)blockIdx.x * lda;
+    double acc0 = 0.0, acc1 = 0.0;
+    int k = threadIdx.x;
+    for (; k + 256 < K; k += 512) {
+      acc0 = fma(col[k], x[k], acc0);
+      acc1 = fma(col[k + 256], x[k + 256], acc1);
+    }
+    if (k < K) acc0 = fma(col[k], x[k], acc0);
+    double v = acc0 + acc1;
+  #pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) out[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+  }
+};
 __global__ __launch_bounds__(256) void gemv_t_kernel(int K, const double* __restrict__ A, long lda,
                                                     const double* __restrict__ x, double* __restrict__ out) {
-  __shared__ double red[4];
-  const double* col = A + (long)blockIdx.x * lda;
-  double acc0 = 0.0, acc1 = 0.0;
-  int k = threadIdx.x;
-  for (; k + 256 < K; k += 512) {
-    acc0 = fma(col[k], x[k], acc0);
-    acc1 = fma(col[k + 256], x[k + 256], acc1);
-  }
-  if (k < K) acc0 = fma(col[k], x[k], acc0);
-  double v = acc0 + acc1;
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
-  __syncthreads();
-  if (threadIdx.x == 0) out[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+  gemv_t_kernel_body::run(MOE_VBLOCK, MOE_VGRID, nullptr, K, A, lda, x, out);
 }
 }  // namespace
 
@@ -1078,24 +1101,24 @@ void launch_gemm_tn_splitk(int m, int n, int K, const double* A, long lda, const
       break;
     }
   // problem e's m x n result is dense (ldc == m) at e * m * n, in C and inside every slice of work
-  hipLaunchKernelGGL((mfma_gemm_kernel<0, false, 16>), mgrid, dim3(256), 0, s, m, n, K, A, lda, B, ldb, slices > 1 ? work : C, (long)m,
+  MOE_LAUNCH((mfma_gemm_kernel<0, false, 16>), mgrid, dim3(256), 0, s, m, n, K, A, lda, B, ldb, slices > 1 ? work : C, (long)m,
                      xmul, 0, sA, sB, (long)m * n, batch, 0, 1);
   if (slices > 1) {
     const long count = (long)m * n * batch;
-    hipLaunchKernelGGL(sum_slices_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, s, (const double*)work, slices, count, C);
+    MOE_LAUNCH(sum_slices_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, s, (const double*)work, slices, count, C);
   }
   MOE_HIP_CHECK(hipGetLastError());
 }
 
 void launch_sum_slices(const double* work, int slices, long count, double* C, hipStream_t s) {
-  hipLaunchKernelGGL(sum_slices_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, s, work, slices, count, C);
+  MOE_LAUNCH(sum_slices_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, s, work, slices, count, C);
   MOE_HIP_CHECK(hipGetLastError());
 }
 
 void launch_gemm_tn(int m, int n, int K, const double* A, long lda, const double* B, long ldb, double* C, long ldc,
                     hipStream_t s) {
   if (n == 1 && m > 0) {
-    hipLaunchKernelGGL(gemv_t_kernel, dim3(m), dim3(256), 0, s, K, A, lda, B, C);
+    launch_kernel_ens<gemv_t_kernel_body, 256>(gemv_t_kernel, dim3(m), dim3(256), 0, s, K, A, lda, B, C);
     MOE_HIP_CHECK(hipGetLastError());
     return;
   }
@@ -1104,14 +1127,19 @@ void launch_gemm_tn(int m, int n, int K, const double* A, long lda, const double
 
 namespace {
 // G[e] = sum over the K slices of the partial Grams, in slice order.
+struct gram_sum_kernel_body {
+  static __device__ __forceinline__ void run(const VIdx blockIdx, const VIdx gridDim, const void*, const double* __restrict__ part, int slices, long cc, double* __restrict__ G) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    const int e = blockIdx.y;
+    if (idx >= cc) return;
+    const double* p = part + (long)e * slices * cc + idx;
+    double v = 0.0;
+    for (int sl = 0; sl < slices; ++sl) v += p[(long)sl * cc];
+    G[(long)e * cc + idx] = v;
+  }
+};
 __global__ __launch_bounds__(256) void gram_sum_kernel(const double* __restrict__ part, int slices, long cc, double* __restrict__ G) {
-  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
-  const int e = blockIdx.y;
-  if (idx >= cc) return;
-  const double* p = part + (long)e * slices * cc + idx;
-  double v = 0.0;
-  for (int sl = 0; sl < slices; ++sl) v += p[(long)sl * cc];
-  G[(long)e * cc + idx] = v;
+  gram_sum_kernel_body::run(MOE_VBLOCK, MOE_VGRID, nullptr, part, slices, cc, G);
 }
 }  // namespace
 
@@ -1144,12 +1172,12 @@ int launch_gram_cross_batch(int E, int m, int ng, int A, int K, const double* S,
   const int slices = gram_cross_slices(m, ng, A, K);
   dim3 grid((r + 31) / 32, (m + 31) / 32, E * slices);
   if (slices == 1) {
-    hipLaunchKernelGGL(gram_cross_batch_kernel, grid, dim3(256), 0, s, gm, K, S, lds, W, ldw, G, 1);
+    launch_kernel_ens<gram_cross_batch_kernel_body, 256>(gram_cross_batch_kernel, grid, dim3(256), 0, s, gm, K, S, lds, W, ldw, G, 1);
   } else {
     const long cc = (long)r * m;
-    hipLaunchKernelGGL(gram_cross_batch_kernel, grid, dim3(256), 0, s, gm, K, S, lds, W, ldw, work, slices);
+    launch_kernel_ens<gram_cross_batch_kernel_body, 256>(gram_cross_batch_kernel, grid, dim3(256), 0, s, gm, K, S, lds, W, ldw, work, slices);
     if (!defer_sum)
-      hipLaunchKernelGGL(gram_sum_kernel, dim3((unsigned)((cc + 255) / 256), E), dim3(256), 0, s, (const double*)work, slices, cc, G);
+      launch_kernel_ens<gram_sum_kernel_body, 256>(gram_sum_kernel, dim3((unsigned)((cc + 255) / 256), E), dim3(256), 0, s, (const double*)work, slices, cc, G);
   }
   MOE_HIP_CHECK(hipGetLastError());
   return slices;
@@ -1163,12 +1191,12 @@ int launch_gram_batch(int E, int m, int ng, int A, int K, const double* V, long 
   const int slices = (work != nullptr) ? gram_batch_slices(E, c, K) : 1;
   dim3 grid((c + 31) / 32, (c + 31) / 32, E * slices);
   if (slices == 1) {
-    hipLaunchKernelGGL(gram_batch_kernel, grid, dim3(256), 0, s, gm, K, V, ldv, G, 1);
+    launch_kernel_ens<gram_batch_kernel_body, 256>(gram_batch_kernel, grid, dim3(256), 0, s, gm, K, V, ldv, G, 1);
   } else {
     const long cc = (long)c * c;
-    hipLaunchKernelGGL(gram_batch_kernel, grid, dim3(256), 0, s, gm, K, V, ldv, work, slices);
+    launch_kernel_ens<gram_batch_kernel_body, 256>(gram_batch_kernel, grid, dim3(256), 0, s, gm, K, V, ldv, work, slices);
     if (!defer_sum)
-      hipLaunchKernelGGL(gram_sum_kernel, dim3((unsigned)((cc + 255) / 256), E), dim3(256), 0, s, (const double*)work, slices, cc, G);
+      launch_kernel_ens<gram_sum_kernel_body, 256>(gram_sum_kernel, dim3((unsigned)((cc + 255) / 256), E), dim3(256), 0, s, (const double*)work, slices, cc, G);
   }
   MOE_HIP_CHECK(hipGetLastError());
   return slices;
@@ -1818,14 +1846,14 @@ void trtri_levels(const double* L, long lda, double* Linv, long ldl, int N, doub
     // work_k (rows x B) = L21 X11   (X11 lower triangular: MODE 3)
     const int pairc = (ct >= 16) ? 2 : 0;  // (column pairing: see mfma_gemm_kernel)
     if (phase != 2)
-    hipLaunchKernelGGL((mfma_gemm_kernel<3, false, 16>), dim3(pairc ? (ct + 1) / 2 : ct, rt, nn), dim3(256), 0, s, rows_max, (int)B,
+    MOE_LAUNCH((mfma_gemm_kernel<3, false, 16>), dim3(pairc ? (ct + 1) / 2 : ct, rt, nn), dim3(256), 0, s, rows_max, (int)B,
                        (int)B, L + B, lda, (const double*)Linv, ldl, work, ldw, xmul, pairc, 2 * B * (1 + lda), 2 * B * (1 + ldl),
                        ldw * B, (int)(N - B), (int)(2 * B));
     // X21 = -X22 work_k   (X22 lower triangular: MODE 1, negated).  A single big node (the top levels) pairs row tile p with its
     // mirror so that every workgroup walks the same number of K steps (see mfma_gemm_kernel).
     const int pair = (nn == 1 && rt >= 16) ? 1 : 0;
     if (phase != 1)
-    hipLaunchKernelGGL((mfma_gemm_kernel<1, true, 16>), dim3(ct, pair ? (rt + 1) / 2 : rt, nn), dim3(256), 0, s, rows_max, (int)B,
+    MOE_LAUNCH((mfma_gemm_kernel<1, true, 16>), dim3(ct, pair ? (rt + 1) / 2 : rt, nn), dim3(256), 0, s, rows_max, (int)B,
                        rows_max, (const double*)(Linv + B + B * ldl), ldl, (const double*)work, ldw, Linv + B, ldl, xmul, pair,
                        2 * B * (1 + ldl), ldw * B, 2 * B * (1 + ldl), (int)(N - B), (int)(2 * B));
   }
@@ -1906,9 +1934,9 @@ void cholesky_factor_two_level(int N, double* A, long lda, double* Linv, long ld
   //  until the update drains.  profiles/r03_c2_chol_overlap.txt, r03_k_chol_time.txt.)
   auto diag_and_copy = [&](int k0, hipStream_t st, int buf) {  // the start of an outer block
     const int nb = std::min(NB, N - k0), below = N - k0 - nb;
-    hipLaunchKernelGGL(chol_diag_lds_kernel, dim3(1), dim3(256), 0, st, A, lda, Linv, ldl, k0, nb, info);
+    MOE_LAUNCH(chol_diag_lds_kernel, dim3(1), dim3(256), 0, st, A, lda, Linv, ldl, k0, nb, info);
     if (fused && below > 0)
-      hipLaunchKernelGGL(chol_colcopy_kernel, dim3((below + 255) / 256, nb), dim3(256), 0, st, (const double*)A, lda, N, k0, nb,
+      MOE_LAUNCH(chol_colcopy_kernel, dim3((below + 255) / 256, nb), dim3(256), 0, st, (const double*)A, lda, N, k0, nb,
                          cbuf + (size_t)buf * ldc * NB, ldc);
   };
   int cur = 0;
@@ -1925,11 +1953,11 @@ void cholesky_factor_two_level(int N, double* A, long lda, double* Linv, long ld
       const int left = ko + wo - (k0 + nb);  // columns of this outer block still to be factored
       const int cb = (left + NB - 1) / NB;
       if (!fused) {
-        hipLaunchKernelGGL(chol_panel_kernel, dim3(tb), dim3(256), 0, s, A, lda, Linv, ldl, N, k0, nb, info);
-        if (left > 0) hipLaunchKernelGGL(chol_update_kernel, dim3(tb, cb), dim3(256), 0, s, A, lda, N, k0, nb, info);
+        MOE_LAUNCH(chol_panel_kernel, dim3(tb), dim3(256), 0, s, A, lda, Linv, ldl, N, k0, nb, info);
+        if (left > 0) MOE_LAUNCH(chol_update_kernel, dim3(tb, cb), dim3(256), 0, s, A, lda, N, k0, nb, info);
         continue;
       }
-      hipLaunchKernelGGL(chol_step_kernel, dim3(cb + 1, tb), dim3(256), kStepSmem, s, A, lda, Linv, ldl, N, k0, nb, cb, info,
+      MOE_LAUNCH(chol_step_kernel, dim3(cb + 1, tb), dim3(256), kStepSmem, s, A, lda, Linv, ldl, N, k0, nb, cb, info,
                          (const double*)(cbuf + (size_t)cur * ldc * NB), cbuf + (size_t)(1 - cur) * ldc * NB, ldc, left > 0 ? 1 : 0);
       if (left > 0) {
         cur = 1 - cur;
@@ -1944,11 +1972,11 @@ void cholesky_factor_two_level(int N, double* A, long lda, double* Linv, long ld
       if (use_syrk128(trailing, wo)) {
         MOE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(g128::syrk128_kernel),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)g128::kSmemBytes));
-        hipLaunchKernelGGL(g128::syrk128_kernel, dim3(t128 * (t128 + 1) / 2), dim3(256), g128::kSmemBytes, s, A, lda, N, ko + wo, ko,
+        MOE_LAUNCH(g128::syrk128_kernel, dim3(t128 * (t128 + 1) / 2), dim3(256), g128::kSmemBytes, s, A, lda, N, ko + wo, ko,
                            wo, (const int*)info);
       } else {
         const int tt = (trailing + 63) / 64;
-        hipLaunchKernelGGL(syrk_mfma_kernel, dim3(tt, tt), dim3(256), 0, s, A, lda, N, ko + wo, ko, wo, (const int*)info, 0);
+        MOE_LAUNCH(syrk_mfma_kernel, dim3(tt, tt), dim3(256), 0, s, A, lda, N, ko + wo, ko, wo, (const int*)info, 0);
       }
     }
   }
@@ -2019,18 +2047,18 @@ void launch_cholesky_and_inverse(int N, double* A, long lda, double* Linv, long 
     H = 0;
     for (int b = 0; b < nblk; ++b) {
       const int k0 = b * NB, nb = std::min(NB, N - k0);
-      hipLaunchKernelGGL(chol_diag_kernel, dim3(1), dim3(64), 0, s, A, lda, Linv, ldl, k0, nb, info);
+      MOE_LAUNCH(chol_diag_kernel, dim3(1), dim3(64), 0, s, A, lda, Linv, ldl, k0, nb, info);
       const int below = N - k0 - nb;
       if (below > 0) {
-        hipLaunchKernelGGL(chol_panel_kernel, dim3((below + NB - 1) / NB), dim3(256), 0, s, A, lda, Linv, ldl, N, k0, nb, info);
+        MOE_LAUNCH(chol_panel_kernel, dim3((below + NB - 1) / NB), dim3(256), 0, s, A, lda, Linv, ldl, N, k0, nb, info);
         const int tb = (below + NB - 1) / NB;
-        hipLaunchKernelGGL(chol_update_kernel, dim3(tb, tb), dim3(256), 0, s, A, lda, N, k0, nb, info);
+        MOE_LAUNCH(chol_update_kernel, dim3(tb, tb), dim3(256), 0, s, A, lda, N, k0, nb, info);
       }
     }
   }
   if (!upper_is_zero) {
     const long total = (long)N * N;
-    hipLaunchKernelGGL(zero_strict_upper_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, A, lda, N);
+    MOE_LAUNCH(zero_strict_upper_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, A, lda, N);
   }
   // Off-diagonal blocks of L^-1 by recursive halving over the block range (diagonal blocks are already inverted):
   //   inv [[L11, 0], [L21, L22]] = [[X11, 0], [-X22 (L21 X11), X22]]
@@ -2087,7 +2115,7 @@ void launch_cholesky_append(int N0, int kk, double* L, long ldl, double* Linv, l
   // V = L11^-1 K12;  Schur complement S = K22 - V^T V;  L22 = chol(S), X22 = L22^-1
   launch_tri_gemm_skinny('N', N0, kk, Linv, ldi, B, N0, V, N0, s);
   launch_gemm_tn(kk, kk, N0, V, N0, V, N0, G, kk, s);
-  hipLaunchKernelGGL(sub_inplace_kernel, dim3((kk * kk + 255) / 256), dim3(256), 0, s, C, (const double*)G, kk * kk);
+  MOE_LAUNCH(sub_inplace_kernel, dim3((kk * kk + 255) / 256), dim3(256), 0, s, C, (const double*)G, kk * kk);
   launch_cholesky_and_inverse(kk, C, kk, X22, kk, cw, info, s);
   MOE_HIP_CHECK(hipMemcpy2DAsync(L + N0 + (size_t)N0 * ldl, sizeof(double) * ldl, C, sizeof(double) * kk,
                                  sizeof(double) * kk, kk, hipMemcpyDeviceToDevice, s));
@@ -2095,7 +2123,7 @@ void launch_cholesky_append(int N0, int kk, double* L, long ldl, double* Linv, l
                                  sizeof(double) * kk, kk, hipMemcpyDeviceToDevice, s));
   // L21 = V^T;  X21 = -X22 (L21 X11) = -X22 W^T
   launch_tri_gemm_skinny('T', N0, kk, Linv, ldi, V, N0, W, N0, s);
-  hipLaunchKernelGGL(append_rows_kernel, dim3((N0 + 255) / 256), dim3(256), 0, s, (const double*)V, (const double*)W,
+  MOE_LAUNCH(append_rows_kernel, dim3((N0 + 255) / 256), dim3(256), 0, s, (const double*)V, (const double*)W,
                      (const double*)X22, N0, kk, L + N0, ldl, Linv + N0, ldi);
   MOE_HIP_CHECK(hipGetLastError());
 }
@@ -2157,25 +2185,25 @@ void launch_cholesky_batch(int N, double* A, long lda, long a_stride, double* Li
   const int nblk = (N + NB - 1) / NB;
   for (int b = 0; b < nblk; ++b) {
     const int k0 = b * NB, nb = std::min(NB, N - k0);
-    hipLaunchKernelGGL(chol_diag_kernel, dim3(1, 1, batch), dim3(64), 0, s, A, lda, Linv, ldl, k0, nb, info, a_stride, l_stride);
+    MOE_LAUNCH(chol_diag_kernel, dim3(1, 1, batch), dim3(64), 0, s, A, lda, Linv, ldl, k0, nb, info, a_stride, l_stride);
     const int below = N - k0 - nb;
     if (below > 0) {
       const int tb = (below + NB - 1) / NB;
-      hipLaunchKernelGGL(chol_panel_kernel, dim3(tb, 1, batch), dim3(256), 0, s, A, lda, (const double*)Linv, ldl, N, k0, nb,
+      MOE_LAUNCH(chol_panel_kernel, dim3(tb, 1, batch), dim3(256), 0, s, A, lda, (const double*)Linv, ldl, N, k0, nb,
                          (const int*)info, a_stride, l_stride);
-      hipLaunchKernelGGL(chol_update_kernel, dim3(tb, tb, batch), dim3(256), 0, s, A, lda, N, k0, nb, (const int*)info, a_stride);
+      MOE_LAUNCH(chol_update_kernel, dim3(tb, tb, batch), dim3(256), 0, s, A, lda, N, k0, nb, (const int*)info, a_stride);
     }
   }
   MOE_HIP_CHECK(hipGetLastError());
 }
 
 void launch_ll_border(double* A, long lda, long a_stride, int N, const double* yc, int batch, hipStream_t s) {
-  hipLaunchKernelGGL(ll_border_kernel, dim3((N + 1 + 255) / 256, batch), dim3(256), 0, s, A, lda, a_stride, N, yc);
+  MOE_LAUNCH(ll_border_kernel, dim3((N + 1 + 255) / 256, batch), dim3(256), 0, s, A, lda, a_stride, N, yc);
   MOE_HIP_CHECK(hipGetLastError());
 }
 
 void launch_ll_terms_batch(const double* A, long lda, long a_stride, int N, double* out, int batch, hipStream_t s) {
-  hipLaunchKernelGGL(ll_terms_batch_kernel, dim3(batch), dim3(256), 0, s, A, lda, a_stride, N, out);
+  MOE_LAUNCH(ll_terms_batch_kernel, dim3(batch), dim3(256), 0, s, A, lda, a_stride, N, out);
   MOE_HIP_CHECK(hipGetLastError());
 }
 

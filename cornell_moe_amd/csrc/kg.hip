@@ -65,25 +65,30 @@ struct TabParams {
 // coordinates carry the precision of the distances however far from the origin the domain sits):
 // the n training points, then the u union points of that evaluation, zero beyond.
 // (r5: the workgroups of evaluation 0 also clear the call's counter block -- pass counters, sample tickets -- which a memset did before)
-__global__ void build_xs_tab_kernel(const double* __restrict__ X, int n, const double* __restrict__ XuAll, int u, int dp,
+struct build_xs_tab_kernel_body {
+  static __device__ __forceinline__ void run(const VIdx blockIdx, const VIdx gridDim, const void*, const double* __restrict__ X, int n, const double* __restrict__ XuAll, int u, int dp, int ntiles, const TabParams& tp, double* __restrict__ tab, long tab_stride, int pair_rows, unsigned long long* __restrict__ ctr, long n_ctr) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int e = blockIdx.y;
+    if (e == 0)
+      for (long i = idx; i < n_ctr; i += (long)gridDim.x * blockDim.x) ctr[i] = 0ull;
+    if (idx >= ntiles * dp * 64) return;
+    const int l = idx & 63, r = (idx >> 6) % dp, t = (idx >> 6) / dp;
+    const int j = t * 64 + l;
+    const int k = tp.perm[r];
+    double v = tp.center[r];  // padded points sit at the centre (zero weight; a far-away pad would only stress the exp)
+    if (j < n)
+      v = X[(long)j * dp + k];
+    else if (j < n + u)
+      v = XuAll[((long)e * u + (j - n)) * dp + k];
+    // (pair_rows: the rows of a point in pairs, [tile][dp / 2][64][2] -- one 16-byte load per lane and pair, kg_mc.hpp WideEval)
+    const long out = pair_rows ? (((long)t * (dp / 2) + (r >> 1)) * 64 + l) * 2 + (r & 1) : idx;
+    tab[(long)e * tab_stride + out] = (v - tp.center[r]) * tp.inv_lp[r];
+  }
+};
+__global__ __launch_bounds__(256) void build_xs_tab_kernel(const double* __restrict__ X, int n, const double* __restrict__ XuAll, int u, int dp,
                                     int ntiles, TabParams tp, double* __restrict__ tab, long tab_stride, int pair_rows,
                                     unsigned long long* __restrict__ ctr, long n_ctr) {
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  const int e = blockIdx.y;
-  if (e == 0)
-    for (long i = idx; i < n_ctr; i += (long)gridDim.x * blockDim.x) ctr[i] = 0ull;
-  if (idx >= ntiles * dp * 64) return;
-  const int l = idx & 63, r = (idx >> 6) % dp, t = (idx >> 6) / dp;
-  const int j = t * 64 + l;
-  const int k = tp.perm[r];
-  double v = tp.center[r];  // padded points sit at the centre (zero weight; a far-away pad would only stress the exp)
-  if (j < n)
-    v = X[(long)j * dp + k];
-  else if (j < n + u)
-    v = XuAll[((long)e * u + (j - n)) * dp + k];
-  // (pair_rows: the rows of a point in pairs, [tile][dp / 2][64][2] -- one 16-byte load per lane and pair, kg_mc.hpp WideEval)
-  const long out = pair_rows ? (((long)t * (dp / 2) + (r >> 1)) * 64 + l) * 2 + (r & 1) : idx;
-  tab[(long)e * tab_stride + out] = (v - tp.center[r]) * tp.inv_lp[r];
+  build_xs_tab_kernel_body::run(MOE_VBLOCK, MOE_VGRID, nullptr, X, n, XuAll, u, dp, ntiles, tp, tab, tab_stride, pair_rows, ctr, n_ctr);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -301,36 +306,46 @@ __global__ __launch_bounds__(256, 2) void kg_sw128_kernel(KgTailParams P, double
 }
 
 // TB[e][c][row] = sum of the chunk partials in chunk order (one pass over TBpart instead of one per gradient column).
+struct kg_tbsum_kernel_body {
+  static __device__ __forceinline__ void run(const VIdx blockIdx, const VIdx gridDim, const void*, const KgTailParams& P, double* __restrict__ TBsum) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;  // over m * N
+    const int e = blockIdx.y;
+    const long mn = (long)P.m * P.N;
+    if (idx >= mn) return;
+    const double* part = P.TBpart + (long)e * P.chunks * mn + idx;
+    double tb = 0.0;
+  #pragma unroll 8
+    for (int ch = 0; ch < P.chunks; ++ch) tb += part[(long)ch * mn];  // (independent loads, issued eight at a time)
+    TBsum[(long)e * mn + idx] = tb;
+  }
+};
 __global__ __launch_bounds__(256) void kg_tbsum_kernel(KgTailParams P, double* __restrict__ TBsum) {
-  const long idx = (long)blockIdx.x * 256 + threadIdx.x;  // over m * N
-  const int e = blockIdx.y;
-  const long mn = (long)P.m * P.N;
-  if (idx >= mn) return;
-  const double* part = P.TBpart + (long)e * P.chunks * mn + idx;
-  double tb = 0.0;
-#pragma unroll 8
-  for (int ch = 0; ch < P.chunks; ++ch) tb += part[(long)ch * mn];  // (independent loads, issued eight at a time)
-  TBsum[(long)e * mn + idx] = tb;
+  kg_tbsum_kernel_body::run(MOE_VBLOCK, MOE_VGRID, nullptr, P, TBsum);
 }
 
 // GTB[e][gc] = sum_row dK*_e[row, gc] * (K^-1 TB_e)[row, col(gc)];  gc = (k (1+g) + b) d + dd  ->  col = k (1+g) + b.
+struct kg_gtb_kernel_body {
+  static __device__ __forceinline__ void run(const VIdx blockIdx, const VIdx gridDim, const void*, const KgTailParams& P, const double* __restrict__ TBsum) {
+    __shared__ double red[4];
+    const int gc = blockIdx.x, e = blockIdx.y;
+    const int col = gc / P.cp.dim;
+    const double* Gc = P.Gm + (long)e * P.g_stride + (long)gc * P.N;
+    const double* tb = TBsum + ((long)e * P.m + col) * P.N;
+    double acc = 0.0;
+    for (int row = threadIdx.x; row < P.N; row += 256) acc = fma(Gc[row], tb[row], acc);
+    const double tot = block_sum_256(acc, red);
+    if (threadIdx.x == 0) P.out[(long)e * P.out_stride + 1 + P.m * P.m + P.ngrad + gc] = tot;
+  }
+};
 __global__ __launch_bounds__(256) void kg_gtb_kernel(KgTailParams P, const double* __restrict__ TBsum) {
-  __shared__ double red[4];
-  const int gc = blockIdx.x, e = blockIdx.y;
-  const int col = gc / P.cp.dim;
-  const double* Gc = P.Gm + (long)e * P.g_stride + (long)gc * P.N;
-  const double* tb = TBsum + ((long)e * P.m + col) * P.N;
-  double acc = 0.0;
-  for (int row = threadIdx.x; row < P.N; row += 256) acc = fma(Gc[row], tb[row], acc);
-  const double tot = block_sum_256(acc, red);
-  if (threadIdx.x == 0) P.out[(long)e * P.out_stride + 1 + P.m * P.m + P.ngrad + gc] = tot;
+  kg_gtb_kernel_body::run(MOE_VBLOCK, MOE_VGRID, nullptr, P, TBsum);
 }
 
 // The summed TB lives behind the chunk partials in the same buffer (the host reserves E (chunks + 1) m N doubles).
 void launch_gtb(const KgTailParams& P, hipStream_t s) {
   const long mn = (long)P.m * P.N;
   double* TBsum = P.TBpart + (long)P.E * P.chunks * mn;
-  hipLaunchKernelGGL(kg_tbsum_kernel, dim3((unsigned)((mn + 255) / 256), P.E), dim3(256), 0, s, P, TBsum);
+  launch_kernel_ens<kg_tbsum_kernel_body, 256>(kg_tbsum_kernel, dim3((unsigned)((mn + 255) / 256), P.E), dim3(256), 0, s, P, TBsum);
   // (K^-1 dK*)^T TB = dK*^T (K^-1 TB): the two triangular products run over the m columns of TB, not over the q (1 + g) d columns of
   // dK* (r4: 32 against 384 per evaluation at C5)
   const int cm = P.E * P.m;
@@ -338,7 +353,7 @@ void launch_gtb(const KgTailParams& P, hipStream_t s) {
   double* KinvTB = P.work + (long)P.N * cm;
   launch_tri_gemm_cols('N', P.N, cm, P.m, P.Linv, P.ldL, TBsum, P.N, half, P.N, P.tri_work, s);
   launch_tri_gemm_cols('T', P.N, cm, P.m, P.Linv, P.ldL, half, P.N, KinvTB, P.N, P.tri_work, s);
-  hipLaunchKernelGGL(kg_gtb_kernel, dim3(P.ngrad, P.E), dim3(256), 0, s, P, (const double*)KinvTB);
+  launch_kernel_ens<kg_gtb_kernel_body, 256>(kg_gtb_kernel, dim3(P.ngrad, P.E), dim3(256), 0, s, P, (const double*)KinvTB);
 }
 
 // ZC[e][r + j m] = sum_i z_i[r] c_i[j] and kg_sum = sum_i (best_posterior + best_value_i)   (.cpp:196).
@@ -347,53 +362,63 @@ void launch_gtb(const KgTailParams& P, hipStream_t s) {
 // m x m partial products; kg_zc_sum_kernel adds the chunk partials in chunk order and forms kg_sum exactly as kg_sum_kernel does.
 constexpr int kZcChunk = 64;  // samples per chunk (32 for m > 32: the two staged blocks stay within 32 KB)
 inline int zc_chunk_len(int m) { return m > 32 ? kZcChunk / 2 : kZcChunk; }  // (r4: m > 64 too -- 2 x 32 x 128 doubles: 64 KB, opted in)
+struct kg_zc_part_kernel_body {
+  static __device__ __forceinline__ void run(const VIdx blockIdx, const VIdx gridDim, const void*, const KgTailParams& P, double* __restrict__ part, int chunks, int len) {
+    extern __shared__ __attribute__((aligned(16))) double zc_sm[];  // z [len][m] | c [len][m]
+    const int chunk = blockIdx.x, e = blockIdx.y, m = P.m;
+    const int i0 = chunk * len, cnt = min(len, P.num_local - i0);
+    double* zs = zc_sm;
+    double* cs = zc_sm + len * m;
+    for (int t = threadIdx.x; t < cnt * m; t += 256) {
+      const int ii = t / m, r = t - ii * m;
+      const int s = P.first_sample + i0 + ii;
+      zs[t] = ((s & 1) ? -1.0 : 1.0) * P.normals[(long)(s >> 1) * m + r];
+      cs[t] = P.C[((long)e * P.num_local + i0 + ii) * m + r];
+    }
+    __syncthreads();
+    for (int o = threadIdx.x; o < m * m; o += 256) {
+      const int r = o % m, j = o / m;
+      double acc = 0.0;
+  #pragma unroll 4
+      for (int ii = 0; ii < cnt; ++ii) acc = fma(zs[ii * m + r], cs[ii * m + j], acc);
+      part[((long)e * chunks + chunk) * m * m + o] = acc;
+    }
+  }
+};
 __global__ __launch_bounds__(256) void kg_zc_part_kernel(KgTailParams P, double* __restrict__ part, int chunks, int len) {
-  extern __shared__ __attribute__((aligned(16))) double zc_sm[];  // z [len][m] | c [len][m]
-  const int chunk = blockIdx.x, e = blockIdx.y, m = P.m;
-  const int i0 = chunk * len, cnt = min(len, P.num_local - i0);
-  double* zs = zc_sm;
-  double* cs = zc_sm + len * m;
-  for (int t = threadIdx.x; t < cnt * m; t += 256) {
-    const int ii = t / m, r = t - ii * m;
-    const int s = P.first_sample + i0 + ii;
-    zs[t] = ((s & 1) ? -1.0 : 1.0) * P.normals[(long)(s >> 1) * m + r];
-    cs[t] = P.C[((long)e * P.num_local + i0 + ii) * m + r];
-  }
-  __syncthreads();
-  for (int o = threadIdx.x; o < m * m; o += 256) {
-    const int r = o % m, j = o / m;
-    double acc = 0.0;
-#pragma unroll 4
-    for (int ii = 0; ii < cnt; ++ii) acc = fma(zs[ii * m + r], cs[ii * m + j], acc);
-    part[((long)e * chunks + chunk) * m * m + o] = acc;
-  }
+  kg_zc_part_kernel_body::run(MOE_VBLOCK, MOE_VGRID, nullptr, P, part, chunks, len);
 }
 
 // (r4: `gs` lanes share an output -- a power of two, m m gs <= 256 -- and stride the chunks, then a fixed butterfly: a lane per output
 //  walked all the chunks in batches of eight loads, one memory round trip per batch: 19 us for the 157 chunks of one C3 evaluation)
+struct kg_zc_sum_kernel_body {
+  static __device__ __forceinline__ void run(const VIdx blockIdx, const VIdx gridDim, const void*, const KgTailParams& P, const double* __restrict__ part, int chunks, int gs) {
+    __shared__ double red[4];
+    const int e = blockIdx.y, m = P.m;
+    const int per_block = 256 / gs;
+    const int o = blockIdx.x * per_block + (int)threadIdx.x / gs, g = (int)threadIdx.x % gs;
+    double* out = P.out + (long)e * P.out_stride;
+    {
+      const bool ok = o < m * m;
+      const double* p = part + (long)e * chunks * m * m + (ok ? o : 0);
+      double v = 0.0;
+  #pragma unroll 8
+      for (int ch = g; ch < chunks; ch += gs) v += p[(long)ch * m * m];
+      for (int off = gs >> 1; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+      if (ok && g == 0) out[1 + o] = v;
+    }
+    if (blockIdx.x == 0) {  // kg_sum = sum_i (best_posterior + best_value_i): the summation of kg_sum_kernel, bit for bit
+      const double bp = P.blob[(long)e * P.rec.stride + P.rec_bp];
+      double acc = 0.0;
+  #pragma unroll 8
+      for (int i = threadIdx.x; i < P.num_local; i += 256) acc += bp + P.best_value[(long)e * P.num_local + i];
+      const double tot = block_sum_256(acc, red);
+      if (threadIdx.x == 0) out[0] = tot;
+    }
+  }
+};
 __global__ __launch_bounds__(256) void kg_zc_sum_kernel(KgTailParams P, const double* __restrict__ part, int chunks, int gs) {
-  __shared__ double red[4];
-  const int e = blockIdx.y, m = P.m;
-  const int per_block = 256 / gs;
-  const int o = blockIdx.x * per_block + (int)threadIdx.x / gs, g = (int)threadIdx.x % gs;
-  double* out = P.out + (long)e * P.out_stride;
-  {
-    const bool ok = o < m * m;
-    const double* p = part + (long)e * chunks * m * m + (ok ? o : 0);
-    double v = 0.0;
-#pragma unroll 8
-    for (int ch = g; ch < chunks; ch += gs) v += p[(long)ch * m * m];
-    for (int off = gs >> 1; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-    if (ok && g == 0) out[1 + o] = v;
-  }
-  if (blockIdx.x == 0) {  // kg_sum = sum_i (best_posterior + best_value_i): the summation of kg_sum_kernel, bit for bit
-    const double bp = P.blob[(long)e * P.rec.stride + P.rec_bp];
-    double acc = 0.0;
-#pragma unroll 8
-    for (int i = threadIdx.x; i < P.num_local; i += 256) acc += bp + P.best_value[(long)e * P.num_local + i];
-    const double tot = block_sum_256(acc, red);
-    if (threadIdx.x == 0) out[0] = tot;
-  }
+  kg_zc_sum_kernel_body::run(MOE_VBLOCK, MOE_VGRID, nullptr, P, part, chunks, gs);
 }
 
 int env_int(const char* name, int dflt);
@@ -415,57 +440,63 @@ void launch_zc(const KgTailParams& P, double* part, hipStream_t s, bool sum_here
   const size_t shm = sizeof(double) * 2 * len * P.m;
   if (shm > 48 * 1024)
     MOE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kg_zc_part_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
-  hipLaunchKernelGGL(kg_zc_part_kernel, dim3(chunks, P.E), dim3(256), shm, s, P, part, chunks, len);
+  launch_kernel_ens<kg_zc_part_kernel_body, 256>(kg_zc_part_kernel, dim3(chunks, P.E), dim3(256), shm, s, P, part, chunks, len);
   if (!sum_here) return;
   const int gs = zc_sum_lanes(P.m);
   const int per_block = 256 / gs;
-  hipLaunchKernelGGL(kg_zc_sum_kernel, dim3((P.m * P.m + per_block - 1) / per_block, P.E), dim3(256), 0, s, P, (const double*)part, chunks, gs);
+  launch_kernel_ens<kg_zc_sum_kernel_body, 256>(kg_zc_sum_kernel, dim3((P.m * P.m + per_block - 1) / per_block, P.E), dim3(256), 0, s, P, (const double*)part, chunks, gs);
 }
 
 // DIR[e][(k (1+g) + b) d + dd] = sum_i beta_i[(k,b)] * d cov(Xu_k, x*_i)[b, 0] / d Xu_k,dd ; workgroup (k, e).
 template <int DP>
-__global__ __launch_bounds__(256) void kg_dir_kernel(KgTailParams P, double* __restrict__ part, int slices) {
-  __shared__ double red[4];
-  const int k = blockIdx.x, e = blockIdx.y, sl = blockIdx.z;
-  // the samples are cut into `slices` contiguous ranges (grid.z) so that q x E workgroups become q x E x slices -- at C5
-  // eight workgroups walked 20 000 samples each while 248 CUs idled; kg_dir_sum_kernel adds the partials in slice order
-  const int per = (P.num_local + slices - 1) / slices;
-  const int i_lo = sl * per, i_hi = min(P.num_local, i_lo + per);
-  const int m = P.m, g1 = 1 + P.g, d = P.cp.dim;
-  const double* Xu = P.blob + (long)e * P.rec.stride + P.rec.XuP + (long)k * DP;
-  DerivList none;
-  none.g = 0;
-  double xk[DP];
-#pragma unroll
-  for (int kk = 0; kk < DP; ++kk) xk[kk] = Xu[kk];
-  for (int b = 0; b < g1; ++b) {
-    double acc[DP];
-#pragma unroll
-    for (int dd = 0; dd < DP; ++dd) acc[dd] = 0.0;
-    for (int i = i_lo + threadIdx.x; i < i_hi; i += 256) {
-      const long w = (long)e * P.num_local + i;
-      const double* xs = P.best_point + w * DP;
-      double diff[DP];
-      double r2 = 0.0;
-#pragma unroll
-      for (int kk = 0; kk < DP; ++kk) {
-        diff[kk] = xk[kk] - xs[kk];
-        r2 = fma(diff[kk] * diff[kk], P.cp.inv_l2[kk], r2);
+struct kg_dir_kernel_body {
+  static __device__ __forceinline__ void run(const VIdx blockIdx, const VIdx gridDim, const void*, const KgTailParams& P, double* __restrict__ part, int slices) {
+    __shared__ double red[4];
+    const int k = blockIdx.x, e = blockIdx.y, sl = blockIdx.z;
+    // the samples are cut into `slices` contiguous ranges (grid.z) so that q x E workgroups become q x E x slices -- at C5
+    // eight workgroups walked 20 000 samples each while 248 CUs idled; kg_dir_sum_kernel adds the partials in slice order
+    const int per = (P.num_local + slices - 1) / slices;
+    const int i_lo = sl * per, i_hi = min(P.num_local, i_lo + per);
+    const int m = P.m, g1 = 1 + P.g, d = P.cp.dim;
+    const double* Xu = P.blob + (long)e * P.rec.stride + P.rec.XuP + (long)k * DP;
+    DerivList none;
+    none.g = 0;
+    double xk[DP];
+  #pragma unroll
+    for (int kk = 0; kk < DP; ++kk) xk[kk] = Xu[kk];
+    for (int b = 0; b < g1; ++b) {
+      double acc[DP];
+  #pragma unroll
+      for (int dd = 0; dd < DP; ++dd) acc[dd] = 0.0;
+      for (int i = i_lo + threadIdx.x; i < i_hi; i += 256) {
+        const long w = (long)e * P.num_local + i;
+        const double* xs = P.best_point + w * DP;
+        double diff[DP];
+        double r2 = 0.0;
+  #pragma unroll
+        for (int kk = 0; kk < DP; ++kk) {
+          diff[kk] = xk[kk] - xs[kk];
+          r2 = fma(diff[kk] * diff[kk], P.cp.inv_l2[kk], r2);
+        }
+        const Radial rd = radial_scalars(P.cp.type, P.cp.alpha, r2);
+        const double bt = P.beta[w * m + k * g1 + b];
+  #pragma unroll
+        for (int dd = 0; dd < DP; ++dd)
+          if (dd < d) acc[dd] = fma(bt, grad_cov_entry<DP>(P.cp, rd, diff, b, 0, dd, P.derivs, none), acc[dd]);
       }
-      const Radial rd = radial_scalars(P.cp.type, P.cp.alpha, r2);
-      const double bt = P.beta[w * m + k * g1 + b];
-#pragma unroll
-      for (int dd = 0; dd < DP; ++dd)
-        if (dd < d) acc[dd] = fma(bt, grad_cov_entry<DP>(P.cp, rd, diff, b, 0, dd, P.derivs, none), acc[dd]);
-    }
-#pragma unroll
-    for (int dd = 0; dd < DP; ++dd) {
-      if (dd < d) {  // d is workgroup-uniform
-        const double tot = block_sum_256(acc[dd], red);
-        if (threadIdx.x == 0) part[((long)e * P.ngrad + (k * g1 + b) * d + dd) * slices + sl] = tot;
+  #pragma unroll
+      for (int dd = 0; dd < DP; ++dd) {
+        if (dd < d) {  // d is workgroup-uniform
+          const double tot = block_sum_256(acc[dd], red);
+          if (threadIdx.x == 0) part[((long)e * P.ngrad + (k * g1 + b) * d + dd) * slices + sl] = tot;
+        }
       }
     }
   }
+};
+template <int DP>
+__global__ __launch_bounds__(256) void kg_dir_kernel(KgTailParams P, double* __restrict__ part, int slices) {
+  kg_dir_kernel_body<DP>::run(MOE_VBLOCK, MOE_VGRID, nullptr, P, part, slices);
 }
 
 // (the slices are added up in order by kg_finish_kernel, where DIR is consumed -- r5; a kernel of its own before)
@@ -478,7 +509,7 @@ inline double* dir_partials(const KgTailParams& P) {
 template <int DP>
 void launch_dir(const KgTailParams& P, hipStream_t s) {
   const int slices = dir_slices(P.num_local);
-  hipLaunchKernelGGL((kg_dir_kernel<DP>), dim3(P.q, P.E, slices), dim3(256), 0, s, P, dir_partials(P), slices);
+  launch_kernel_ens<kg_dir_kernel_body<DP>, 256>(kg_dir_kernel<DP>, dim3(P.q, P.E, slices), dim3(256), 0, s, P, dir_partials(P), slices);
 }
 
 template <int DP, int MU>
@@ -488,7 +519,7 @@ void launch_sw_inst(const KgTailParams& P, hipStream_t s) {
   auto kern = kg_sw_kernel<DP, MU>;
   if (shm > 48 * 1024)
     MOE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
-  hipLaunchKernelGGL(kern, grid, dim3(256), shm, s, P);
+  MOE_LAUNCH(kern, grid, dim3(256), shm, s, P);
 }
 
 template <int DP>
@@ -506,7 +537,7 @@ void launch_sw_dp(const KgTailParams& P, hipStream_t s) {
   else {  // two components per lane; S_W comes precomputed (the host always forms it by GEMM for m > 8)
     if (P.SW == nullptr) throw Error(MOE_ERR_RUNTIME, "m > 64 needs the precomputed W^T T");
     dim3 grid((P.num_local + P.sw_chunk - 1) / P.sw_chunk, P.E);
-    hipLaunchKernelGGL((kg_sw_kernel<DP, 1, 2>), grid, dim3(256), 0, s, P);
+    MOE_LAUNCH((kg_sw_kernel<DP, 1, 2>), grid, dim3(256), 0, s, P);
   }
   launch_dir<DP>(P, s);
 }
@@ -523,19 +554,19 @@ void launch_tail(const KgTailParams& P, hipStream_t s) {
   }
   dim3 gtb((P.N + 255) / 256, P.chunks, P.E);
   if (P.m <= 4)
-    hipLaunchKernelGGL((kg_tb_kernel<4>), gtb, dim3(256), 0, s, P, 0);
+    MOE_LAUNCH((kg_tb_kernel<4>), gtb, dim3(256), 0, s, P, 0);
   else if (P.m <= 8)
-    hipLaunchKernelGGL((kg_tb_kernel<8>), gtb, dim3(256), 0, s, P, 0);
+    MOE_LAUNCH((kg_tb_kernel<8>), gtb, dim3(256), 0, s, P, 0);
   else if (P.m <= 16)
-    hipLaunchKernelGGL((kg_tb_kernel<16>), gtb, dim3(256), 0, s, P, 0);
+    MOE_LAUNCH((kg_tb_kernel<16>), gtb, dim3(256), 0, s, P, 0);
   else if (P.m <= 32)
-    hipLaunchKernelGGL((kg_tb_kernel<32>), gtb, dim3(256), 0, s, P, 0);
+    MOE_LAUNCH((kg_tb_kernel<32>), gtb, dim3(256), 0, s, P, 0);
   else if (P.m <= 64) {
-    hipLaunchKernelGGL((kg_tb_kernel<64>), gtb, dim3(256), 0, s, P, 0);
+    MOE_LAUNCH((kg_tb_kernel<64>), gtb, dim3(256), 0, s, P, 0);
   } else {  // (m <= kMaxMB = 128: one column tile)
     MOE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kg_tb128_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                       (int)g128::kSmemBytes));
-    hipLaunchKernelGGL(kg_tb128_kernel, dim3((P.N + g128::TM - 1) / g128::TM, P.chunks, P.E), dim3(256), g128::kSmemBytes, s, P);
+    MOE_LAUNCH(kg_tb128_kernel, dim3((P.N + g128::TM - 1) / g128::TM, P.chunks, P.E), dim3(256), g128::kSmemBytes, s, P);
   }
   launch_gtb(P, s);
   MOE_HIP_CHECK(hipGetLastError());
@@ -561,150 +592,168 @@ __device__ __forceinline__ double radial_base(double r2, const double* __restric
 // thread = sample, blockIdx.z = slice of the training points: SWpart[e][i][slice][c] = sum over the slice of W[j, c] k(X_j, x*_i)
 // (the slices only exist to give the chip enough wavefronts: E * M / 64 alone is ~1 per SIMD at the headline shape)
 template <int DP, int MU, int COV>
+struct kg_fused_sample_kernel_body {
+  static __device__ __forceinline__ void run(const VIdx blockIdx, const VIdx gridDim, const void*, const KgTailParams& P, const double* __restrict__ X, int n, double* __restrict__ SWpart) {
+    __shared__ double etab[kExpTabLen];
+    __shared__ double Xt[kFusedTile][DP];
+    __shared__ double Wt[kFusedTile][MU];
+    const int e = blockIdx.y, m = P.m, N = P.N;
+    const int slices = gridDim.z, slice = blockIdx.z;
+    const int per = ((n + slices - 1) / slices + 63) / 64 * 64;
+    const int j_lo = slice * per, j_hi = min(n, j_lo + per);
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const bool ok = i < P.num_local;
+    const long w = (long)e * P.num_local + (ok ? i : 0);
+    if (threadIdx.x < kExpTabLen) etab[threadIdx.x] = kExp2Tab64[threadIdx.x];
+    double xs[DP], acc[MU];
+  #pragma unroll
+    for (int k = 0; k < DP; ++k) xs[k] = P.best_point[w * DP + k] * P.cp.inv_l[k];
+  #pragma unroll
+    for (int c = 0; c < MU; ++c) acc[c] = 0.0;
+    const double* We = P.W + (long)e * P.w_stride;
+    for (int j0 = j_lo; j0 < j_hi; j0 += kFusedTile) {
+      __syncthreads();
+      for (int t = threadIdx.x; t < kFusedTile * DP; t += 256) {
+        const int jj = t / DP, k = t % DP;
+        Xt[jj][k] = (j0 + jj < j_hi) ? X[(long)(j0 + jj) * DP + k] * P.cp.inv_l[k] : 0.0;
+      }
+      for (int t = threadIdx.x; t < kFusedTile * MU; t += 256) {
+        const int jj = t % kFusedTile, c = t / kFusedTile;  // W_e is [N x m] col-major: consecutive jj are contiguous
+        Wt[jj][c] = (j0 + jj < j_hi && c < m) ? We[(long)c * N + j0 + jj] : 0.0;  // zero weight: padded points drop out
+      }
+      __syncthreads();
+      const int cnt = min(kFusedTile, j_hi - j0);
+  #pragma unroll 2
+      for (int jj = 0; jj < cnt; ++jj) {
+        double r2 = 1.0e-300;
+  #pragma unroll
+        for (int k = 0; k < DP; ++k) {
+          const double dlt = Xt[jj][k] - xs[k];
+          r2 = fma(dlt, dlt, r2);
+        }
+        const double t = radial_base<COV>(r2, etab);
+  #pragma unroll
+        for (int c = 0; c < MU; ++c) acc[c] = fma(Wt[jj][c], t, acc[c]);
+      }
+    }
+    if (!ok) return;
+  #pragma unroll
+    for (int c = 0; c < MU; ++c) SWpart[(w * slices + slice) * MU + c] = acc[c];
+  }
+};
+template <int DP, int MU, int COV>
 __global__ __launch_bounds__(256) void kg_fused_sample_kernel(KgTailParams P, const double* __restrict__ X, int n,
                                                              double* __restrict__ SWpart) {
-  __shared__ double etab[kExpTabLen];
-  __shared__ double Xt[kFusedTile][DP];
-  __shared__ double Wt[kFusedTile][MU];
-  const int e = blockIdx.y, m = P.m, N = P.N;
-  const int slices = gridDim.z, slice = blockIdx.z;
-  const int per = ((n + slices - 1) / slices + 63) / 64 * 64;
-  const int j_lo = slice * per, j_hi = min(n, j_lo + per);
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  const bool ok = i < P.num_local;
-  const long w = (long)e * P.num_local + (ok ? i : 0);
-  if (threadIdx.x < kExpTabLen) etab[threadIdx.x] = kExp2Tab64[threadIdx.x];
-  double xs[DP], acc[MU];
-#pragma unroll
-  for (int k = 0; k < DP; ++k) xs[k] = P.best_point[w * DP + k] * P.cp.inv_l[k];
-#pragma unroll
-  for (int c = 0; c < MU; ++c) acc[c] = 0.0;
-  const double* We = P.W + (long)e * P.w_stride;
-  for (int j0 = j_lo; j0 < j_hi; j0 += kFusedTile) {
-    __syncthreads();
-    for (int t = threadIdx.x; t < kFusedTile * DP; t += 256) {
-      const int jj = t / DP, k = t % DP;
-      Xt[jj][k] = (j0 + jj < j_hi) ? X[(long)(j0 + jj) * DP + k] * P.cp.inv_l[k] : 0.0;
-    }
-    for (int t = threadIdx.x; t < kFusedTile * MU; t += 256) {
-      const int jj = t % kFusedTile, c = t / kFusedTile;  // W_e is [N x m] col-major: consecutive jj are contiguous
-      Wt[jj][c] = (j0 + jj < j_hi && c < m) ? We[(long)c * N + j0 + jj] : 0.0;  // zero weight: padded points drop out
-    }
-    __syncthreads();
-    const int cnt = min(kFusedTile, j_hi - j0);
-#pragma unroll 2
-    for (int jj = 0; jj < cnt; ++jj) {
-      double r2 = 1.0e-300;
-#pragma unroll
-      for (int k = 0; k < DP; ++k) {
-        const double dlt = Xt[jj][k] - xs[k];
-        r2 = fma(dlt, dlt, r2);
-      }
-      const double t = radial_base<COV>(r2, etab);
-#pragma unroll
-      for (int c = 0; c < MU; ++c) acc[c] = fma(Wt[jj][c], t, acc[c]);
-    }
-  }
-  if (!ok) return;
-#pragma unroll
-  for (int c = 0; c < MU; ++c) SWpart[(w * slices + slice) * MU + c] = acc[c];
+  kg_fused_sample_kernel_body<DP, MU, COV>::run(MOE_VBLOCK, MOE_VGRID, nullptr, P, X, n, SWpart);
 }
 
 // thread = sample: S_W = sum of the slices (fixed order); R_r = alpha (k(Xu_r, x*_i) - S_W[r]); c_i = L^-1 R by forward
 // substitution (L is m x m, column-major, workgroup-uniform)
 template <int DP, int MU, int COV>
-__global__ __launch_bounds__(256) void kg_fused_c_kernel(KgTailParams P, const double* __restrict__ SWpart, int slices) {
-  __shared__ double etab[kExpTabLen];
-  const int e = blockIdx.y, m = P.m;
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (threadIdx.x < kExpTabLen) etab[threadIdx.x] = kExp2Tab64[threadIdx.x];
-  __syncthreads();
-  if (i >= P.num_local) return;
-  const long w = (long)e * P.num_local + i;
-  double xs[DP], sw[MU], cv[MU];
-#pragma unroll
-  for (int k = 0; k < DP; ++k) xs[k] = P.best_point[w * DP + k] * P.cp.inv_l[k];
-#pragma unroll
-  for (int c = 0; c < MU; ++c) {
-    sw[c] = 0.0;
-    for (int sl = 0; sl < slices; ++sl) sw[c] += SWpart[(w * slices + sl) * MU + c];
-  }
-  const double* rec = P.blob + (long)e * P.rec.stride;
-  const double* Lsm = rec + P.rec.L;
-#pragma unroll
-  for (int r = 0; r < MU; ++r) {
-    cv[r] = 0.0;
-    if (r < m) {
-      const double* Xu = rec + P.rec.XuP + (long)r * DP;
-      double r2 = 1.0e-300;
-#pragma unroll
-      for (int k = 0; k < DP; ++k) {
-        const double dlt = Xu[k] * P.cp.inv_l[k] - xs[k];
-        r2 = fma(dlt, dlt, r2);
+struct kg_fused_c_kernel_body {
+  static __device__ __forceinline__ void run(const VIdx blockIdx, const VIdx gridDim, const void*, const KgTailParams& P, const double* __restrict__ SWpart, int slices) {
+    __shared__ double etab[kExpTabLen];
+    const int e = blockIdx.y, m = P.m;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (threadIdx.x < kExpTabLen) etab[threadIdx.x] = kExp2Tab64[threadIdx.x];
+    __syncthreads();
+    if (i >= P.num_local) return;
+    const long w = (long)e * P.num_local + i;
+    double xs[DP], sw[MU], cv[MU];
+  #pragma unroll
+    for (int k = 0; k < DP; ++k) xs[k] = P.best_point[w * DP + k] * P.cp.inv_l[k];
+  #pragma unroll
+    for (int c = 0; c < MU; ++c) {
+      sw[c] = 0.0;
+      for (int sl = 0; sl < slices; ++sl) sw[c] += SWpart[(w * slices + sl) * MU + c];
+    }
+    const double* rec = P.blob + (long)e * P.rec.stride;
+    const double* Lsm = rec + P.rec.L;
+  #pragma unroll
+    for (int r = 0; r < MU; ++r) {
+      cv[r] = 0.0;
+      if (r < m) {
+        const double* Xu = rec + P.rec.XuP + (long)r * DP;
+        double r2 = 1.0e-300;
+  #pragma unroll
+        for (int k = 0; k < DP; ++k) {
+          const double dlt = Xu[k] * P.cp.inv_l[k] - xs[k];
+          r2 = fma(dlt, dlt, r2);
+        }
+        double R = P.cp.alpha * (radial_base<COV>(r2, etab) - sw[r]);
+  #pragma unroll
+        for (int c = 0; c < MU; ++c)
+          if (c < r) R -= Lsm[r + c * m] * cv[c];
+        cv[r] = R / Lsm[r + r * m];
+        P.C[w * m + r] = cv[r];
       }
-      double R = P.cp.alpha * (radial_base<COV>(r2, etab) - sw[r]);
-#pragma unroll
-      for (int c = 0; c < MU; ++c)
-        if (c < r) R -= Lsm[r + c * m] * cv[c];
-      cv[r] = R / Lsm[r + r * m];
-      P.C[w * m + r] = cv[r];
     }
   }
+};
+template <int DP, int MU, int COV>
+__global__ __launch_bounds__(256) void kg_fused_c_kernel(KgTailParams P, const double* __restrict__ SWpart, int slices) {
+  kg_fused_c_kernel_body<DP, MU, COV>::run(MOE_VBLOCK, MOE_VGRID, nullptr, P, SWpart, slices);
 }
 
 // thread = training point: TBpart[e][chunk][c][row] = sum over the chunk's samples of K(X_row, x*_i) beta_i[c]
 template <int DP, int MU, int COV>
-__global__ __launch_bounds__(256) void kg_fused_point_kernel(KgTailParams P, const double* __restrict__ X, int n) {
-  __shared__ double etab[kExpTabLen];
-  __shared__ double St[kFusedTile][DP];
-  __shared__ double Bt[kFusedTile][MU];
-  const int row = blockIdx.x * 256 + threadIdx.x;
-  const int chunk = blockIdx.y, e = blockIdx.z;
-  const int m = P.m;
-  const int i0 = chunk * P.chunk_len, cnt = min(P.num_local - i0, P.chunk_len);  // (chunk_len <= kFusedTile)
-  if (threadIdx.x < kExpTabLen) etab[threadIdx.x] = kExp2Tab64[threadIdx.x];
-  for (int t = threadIdx.x; t < kFusedTile * DP; t += 256) {
-    const int ii = t / DP, k = t % DP;
-    St[ii][k] = (ii < cnt) ? P.best_point[((long)e * P.num_local + i0 + ii) * DP + k] * P.cp.inv_l[k] : 0.0;
-  }
-  for (int t = threadIdx.x; t < kFusedTile * MU; t += 256) {
-    const int ii = t / MU, c = t % MU;
-    Bt[ii][c] = (ii < cnt && c < m) ? P.beta[((long)e * P.num_local + i0 + ii) * m + c] : 0.0;
-  }
-  __syncthreads();
-  const bool ok = row < n;
-  double xr[DP], acc[MU];
-#pragma unroll
-  for (int k = 0; k < DP; ++k) xr[k] = ok ? X[(long)row * DP + k] * P.cp.inv_l[k] : 0.0;
-#pragma unroll
-  for (int c = 0; c < MU; ++c) acc[c] = 0.0;
-#pragma unroll 2
-  for (int ii = 0; ii < cnt; ++ii) {
-    double r2 = 1.0e-300;
-#pragma unroll
-    for (int k = 0; k < DP; ++k) {
-      const double dlt = xr[k] - St[ii][k];
-      r2 = fma(dlt, dlt, r2);
+struct kg_fused_point_kernel_body {
+  static __device__ __forceinline__ void run(const VIdx blockIdx, const VIdx gridDim, const void*, const KgTailParams& P, const double* __restrict__ X, int n) {
+    __shared__ double etab[kExpTabLen];
+    __shared__ double St[kFusedTile][DP];
+    __shared__ double Bt[kFusedTile][MU];
+    const int row = blockIdx.x * 256 + threadIdx.x;
+    const int chunk = blockIdx.y, e = blockIdx.z;
+    const int m = P.m;
+    const int i0 = chunk * P.chunk_len, cnt = min(P.num_local - i0, P.chunk_len);  // (chunk_len <= kFusedTile)
+    if (threadIdx.x < kExpTabLen) etab[threadIdx.x] = kExp2Tab64[threadIdx.x];
+    for (int t = threadIdx.x; t < kFusedTile * DP; t += 256) {
+      const int ii = t / DP, k = t % DP;
+      St[ii][k] = (ii < cnt) ? P.best_point[((long)e * P.num_local + i0 + ii) * DP + k] * P.cp.inv_l[k] : 0.0;
     }
-    const double t = radial_base<COV>(r2, etab);
-#pragma unroll
-    for (int c = 0; c < MU; ++c) acc[c] = fma(t, Bt[ii][c], acc[c]);
+    for (int t = threadIdx.x; t < kFusedTile * MU; t += 256) {
+      const int ii = t / MU, c = t % MU;
+      Bt[ii][c] = (ii < cnt && c < m) ? P.beta[((long)e * P.num_local + i0 + ii) * m + c] : 0.0;
+    }
+    __syncthreads();
+    const bool ok = row < n;
+    double xr[DP], acc[MU];
+  #pragma unroll
+    for (int k = 0; k < DP; ++k) xr[k] = ok ? X[(long)row * DP + k] * P.cp.inv_l[k] : 0.0;
+  #pragma unroll
+    for (int c = 0; c < MU; ++c) acc[c] = 0.0;
+  #pragma unroll 2
+    for (int ii = 0; ii < cnt; ++ii) {
+      double r2 = 1.0e-300;
+  #pragma unroll
+      for (int k = 0; k < DP; ++k) {
+        const double dlt = xr[k] - St[ii][k];
+        r2 = fma(dlt, dlt, r2);
+      }
+      const double t = radial_base<COV>(r2, etab);
+  #pragma unroll
+      for (int c = 0; c < MU; ++c) acc[c] = fma(t, Bt[ii][c], acc[c]);
+    }
+    if (ok) {
+      double* dst = P.TBpart + ((long)e * P.chunks + chunk) * m * P.N;
+  #pragma unroll
+      for (int c = 0; c < MU; ++c)
+        if (c < m) dst[(long)c * P.N + row] = P.cp.alpha * acc[c];
+    }
   }
-  if (ok) {
-    double* dst = P.TBpart + ((long)e * P.chunks + chunk) * m * P.N;
-#pragma unroll
-    for (int c = 0; c < MU; ++c)
-      if (c < m) dst[(long)c * P.N + row] = P.cp.alpha * acc[c];
-  }
+};
+template <int DP, int MU, int COV>
+__global__ __launch_bounds__(256) void kg_fused_point_kernel(KgTailParams P, const double* __restrict__ X, int n) {
+  kg_fused_point_kernel_body<DP, MU, COV>::run(MOE_VBLOCK, MOE_VGRID, nullptr, P, X, n);
 }
 
 template <int DP, int MU, int COV>
 void launch_fused_tail_cov(const KgTailParams& P, const double* X, int n, double* SWpart, int slices, hipStream_t s) {
   dim3 ga((P.num_local + 255) / 256, P.E, slices), gc((P.num_local + 255) / 256, P.E), gb((n + 255) / 256, P.chunks, P.E);
-  hipLaunchKernelGGL((kg_fused_sample_kernel<DP, MU, COV>), ga, dim3(256), 0, s, P, X, n, SWpart);
-  hipLaunchKernelGGL((kg_fused_c_kernel<DP, MU, COV>), gc, dim3(256), 0, s, P, SWpart, slices);
+  launch_kernel_ens<kg_fused_sample_kernel_body<DP, MU, COV>, 256>(kg_fused_sample_kernel<DP, MU, COV>, ga, dim3(256), 0, s, P, X, n, SWpart);
+  launch_kernel_ens<kg_fused_c_kernel_body<DP, MU, COV>, 256>(kg_fused_c_kernel<DP, MU, COV>, gc, dim3(256), 0, s, P, SWpart, slices);
   launch_dir<DP>(P, s);
-  hipLaunchKernelGGL((kg_fused_point_kernel<DP, MU, COV>), gb, dim3(256), 0, s, P, X, n);
+  launch_kernel_ens<kg_fused_point_kernel_body<DP, MU, COV>, 256>(kg_fused_point_kernel<DP, MU, COV>, gb, dim3(256), 0, s, P, X, n);
   launch_gtb(P, s);
   MOE_HIP_CHECK(hipGetLastError());
 }
@@ -742,20 +791,25 @@ void launch_fused_tail(const KgTailParams& P, const double* X, int n, double* SW
 }
 
 // value-only finish: kg_sum per evaluation (same summation as block 0 of kg_zc_sum_kernel)
+struct kg_sum_kernel_body {
+  static __device__ __forceinline__ void run(const VIdx blockIdx, const VIdx gridDim, const void*, const KgTailParams& P, double* __restrict__ fin, const unsigned long long* __restrict__ counters, const int* __restrict__ flags) {
+    __shared__ double red[4];
+    const int e = blockIdx.x;
+    const double bp = P.blob[(long)e * P.rec.stride + P.rec_bp];
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < P.num_local; i += 256) acc += bp + P.best_value[(long)e * P.num_local + i];
+    const double tot = block_sum_256(acc, red);
+    if (threadIdx.x == 0) {  // the record the host reads back: kg_sum | value passes | gradient passes | singular flag
+      fin[4 * e] = tot;
+      fin[4 * e + 1] = (double)counters[2 * e];
+      fin[4 * e + 2] = (double)counters[2 * e + 1];
+      fin[4 * e + 3] = (double)flags[e];
+    }
+  }
+};
 __global__ __launch_bounds__(256) void kg_sum_kernel(KgTailParams P, double* __restrict__ fin, const unsigned long long* __restrict__ counters,
                                                      const int* __restrict__ flags) {
-  __shared__ double red[4];
-  const int e = blockIdx.x;
-  const double bp = P.blob[(long)e * P.rec.stride + P.rec_bp];
-  double acc = 0.0;
-  for (int i = threadIdx.x; i < P.num_local; i += 256) acc += bp + P.best_value[(long)e * P.num_local + i];
-  const double tot = block_sum_256(acc, red);
-  if (threadIdx.x == 0) {  // the record the host reads back: kg_sum | value passes | gradient passes | singular flag
-    fin[4 * e] = tot;
-    fin[4 * e + 1] = (double)counters[2 * e];
-    fin[4 * e + 2] = (double)counters[2 * e + 1];
-    fin[4 * e + 3] = (double)flags[e];
-  }
+  kg_sum_kernel_body::run(MOE_VBLOCK, MOE_VGRID, nullptr, P, fin, counters, flags);
 }
 
 struct EventTimer {
@@ -768,9 +822,16 @@ struct EventTimer {
     (void)hipEventDestroy(a);
     (void)hipEventDestroy(b);
   }
-  void start(hipStream_t s) { MOE_HIP_CHECK(hipEventRecord(a, s)); }
-  void stop(hipStream_t s) { MOE_HIP_CHECK(hipEventRecord(b, s)); }
+  bool on = false;  // (nothing is timed while launches are being recorded: launch.hpp)
+  void start(hipStream_t s) {
+    on = Recorder::current() == nullptr;
+    if (on) MOE_HIP_CHECK(hipEventRecord(a, s));
+  }
+  void stop(hipStream_t s) {
+    if (on) MOE_HIP_CHECK(hipEventRecord(b, s));
+  }
   double ms() {
+    if (!on) return 0.0;
     MOE_HIP_CHECK(hipEventSynchronize(b));
     float t = 0.f;
     MOE_HIP_CHECK(hipEventElapsedTime(&t, a, b));
@@ -947,7 +1008,7 @@ void launch_sample_weights(const KgMcParams& P, double* V, hipStream_t s, bool t
   if (mfma) {
     MOE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kg_table128_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                       (int)g128::kSmemBytes));
-    hipLaunchKernelGGL(kg_table128_kernel, dim3((unsigned)((P.v_stride + g128::TM - 1) / g128::TM), (P.num_local + g128::TM - 1) / g128::TM, P.E),
+    MOE_LAUNCH(kg_table128_kernel, dim3((unsigned)((P.v_stride + g128::TM - 1) / g128::TM), (P.num_local + g128::TM - 1) / g128::TM, P.E),
                        dim3(256), g128::kSmemBytes, s, P, V);
     MOE_HIP_CHECK(hipGetLastError());
     return;
@@ -955,13 +1016,13 @@ void launch_sample_weights(const KgMcParams& P, double* V, hipStream_t s, bool t
   const int spb = 64;
   dim3 grid((unsigned)((P.v_stride + 255) / 256), (P.num_local + spb - 1) / spb, P.E);
   if (P.m <= 16)
-    hipLaunchKernelGGL(kg_sample_weights_kernel<16>, grid, dim3(256), 0, s, P, V, spb);
+    MOE_LAUNCH(kg_sample_weights_kernel<16>, grid, dim3(256), 0, s, P, V, spb);
   else if (P.m <= 32)
-    hipLaunchKernelGGL(kg_sample_weights_kernel<32>, grid, dim3(256), 0, s, P, V, spb);
+    MOE_LAUNCH(kg_sample_weights_kernel<32>, grid, dim3(256), 0, s, P, V, spb);
   else  // (m > 64 in passes of 64 columns; ONE pass with a 128-column row of W in registers -- 256 of them, half in the accumulation file --
         //  measured slower: 34 against 21 ms of MC phase per evaluation at the stretch point, m = 104)
     for (int c_lo = 0; c_lo < P.m; c_lo += 64)
-      hipLaunchKernelGGL(kg_sample_weights_kernel<64>, grid, dim3(256), 0, s, P, V, spb, c_lo, c_lo == 0 ? 1 : 0, c_lo + 64 >= P.m ? 1 : 0);
+      MOE_LAUNCH(kg_sample_weights_kernel<64>, grid, dim3(256), 0, s, P, V, spb, c_lo, c_lo == 0 ? 1 : 0, c_lo + 64 >= P.m ? 1 : 0);
   MOE_HIP_CHECK(hipGetLastError());
 }
 
@@ -1451,8 +1512,12 @@ KgPending kg_launch(GpDev& gp, int num_fidelity, const moe_gd_params_t& gd, cons
   // ---- coordinate tables ----
   {
     dim3 grid((unsigned)((tab_stride + 255) / 256), E);
-    hipLaunchKernelGGL(build_xs_tab_kernel, grid, dim3(256), 0, s, gp.dX.p, n, gp.dUnion, u, dp, ntiles, tp, dTab.p, tab_stride,
-                       (wide_dp || variant == 2 || (variant == 0 && mc::wide_eval(dp, xlds))) ? 1 : 0, dCounters.p, (long)n_ctr);
+    const double *dXp = gp.dX.p, *dUnionP = gp.dUnion;
+    double* dTabP = dTab.p;
+    unsigned long long* dCtrP = dCounters.p;
+    const int pair_rows = (wide_dp || variant == 2 || (variant == 0 && mc::wide_eval(dp, xlds))) ? 1 : 0;
+    launch_kernel_ens<build_xs_tab_kernel_body, 256>(build_xs_tab_kernel, grid, dim3(256), 0, s, dXp, n, dUnionP, u, dp, ntiles, tp, dTabP, tab_stride,
+                                                     pair_rows, dCtrP, (long)n_ctr);
     MOE_HIP_CHECK(hipGetLastError());
   }
   t_state.stop(s);
@@ -1521,11 +1586,12 @@ KgPending kg_launch(GpDev& gp, int num_fidelity, const moe_gd_params_t& gd, cons
     gp.kBestJ.reserve((size_t)E * num_local);
     mp.best_j = gp.kBestJ.p;
     const long total = (long)E * num_local;
+    int* best_j_p = gp.kBestJ.p;
     if (m > kMaxM) {  // more components than lanes: thread-per-sample pre-pass (mandatory there)
-      hipLaunchKernelGGL(kg_sample_prep_generic_kernel, dim3((unsigned)((total + 63) / 64)), dim3(64), 0, s, mp, gp.kBestJ.p);
+      MOE_LAUNCH(kg_sample_prep_generic_kernel, dim3((unsigned)((total + 63) / 64)), dim3(64), 0, s, mp, best_j_p);
     } else {
       const int pb = (int)std::min<long>((total + 3) / 4, (long)num_cu * 8);
-      hipLaunchKernelGGL(kg_sample_prep_kernel, dim3(pb), dim3(256), 0, s, mp, gp.kBestJ.p);
+      MOE_LAUNCH(kg_sample_prep_kernel, dim3(pb), dim3(256), 0, s, mp, best_j_p);
     }
     MOE_HIP_CHECK(hipGetLastError());
   }
@@ -1539,7 +1605,7 @@ KgPending kg_launch(GpDev& gp, int num_fidelity, const moe_gd_params_t& gd, cons
     const double v_gb = 8.0 * (double)mp.v_stride * (double)num_local / 1e9;  // (per evaluation, as above)
     if (v_gb <= v_cap) {  // (m > 64: the table kernel takes the columns of W 64 at a time, r4)
       gp.kV.reserve((size_t)mp.v_stride * (size_t)total + (size_t)64 * mp.v_slots1);  // (+ one tile: the sweeps prefetch one tile ahead)
-      MOE_HIP_CHECK(hipMemsetAsync(dBeta.p + (size_t)total * m, 0, sizeof(double) * 64, s));
+      memset_async(dBeta.p + (size_t)total * m, 0, sizeof(double) * 64, s);
       mp.V = gp.kV.p;
       launch_sample_weights(mp, gp.kV.p, s, variant == 2);
     }
@@ -1630,8 +1696,9 @@ KgPending kg_launch(GpDev& gp, int num_fidelity, const moe_gd_params_t& gd, cons
         tq.T = dT.p;
         MOE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kg_sw128_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                           (int)g128::kSmemBytes));
-        hipLaunchKernelGGL(kg_sw128_kernel, dim3((num_local + g128::TM - 1) / g128::TM, sw_slices, E), dim3(256), g128::kSmemBytes, s, tq,
-                           gp.kSWpart.p, sw_slices);
+        double* sw_part_p = gp.kSWpart.p;
+        MOE_LAUNCH(kg_sw128_kernel, dim3((num_local + g128::TM - 1) / g128::TM, sw_slices, E), dim3(256), g128::kSmemBytes, s, tq,
+                   sw_part_p, sw_slices);
         launch_sum_slices(gp.kSWpart.p, sw_slices, (long)m * num_local * E, gp.kSW.p, s);
       } else {
         launch_gemm_tn_splitk(m, num_local, N, tl.W, N, dT.p, N, gp.kSW.p, gp.kSWpart.p, sw_slices, s, E, tl.w_stride, (long)num_local * N);
@@ -1643,7 +1710,9 @@ KgPending kg_launch(GpDev& gp, int num_fidelity, const moe_gd_params_t& gd, cons
     gp.kZcPart.reserve((size_t)E * ((num_local + zc_chunk_len(m) - 1) / zc_chunk_len(m)) * m * m);
     launch_zc(tl, gp.kZcPart.p, s, !zc_sum_in_finish(m, num_local));
   } else {
-    hipLaunchKernelGGL(kg_sum_kernel, dim3(E), dim3(256), 0, s, tl, dFin, (const unsigned long long*)dCounters.p, (const int*)gp.kStateI.p);
+    const unsigned long long* ctr_p = dCounters.p;
+    const int* flags_p = gp.kStateI.p;
+    launch_kernel_ens<kg_sum_kernel_body, 256>(kg_sum_kernel, dim3(E), dim3(256), 0, s, tl, dFin, ctr_p, flags_p);
   }
   MOE_HIP_CHECK(hipGetLastError());
   // ---- grad KG from the sample sums, on the device (kg_state.hip) ----
@@ -1684,10 +1753,10 @@ KgPending kg_launch(GpDev& gp, int num_fidelity, const moe_gd_params_t& gd, cons
   const size_t n_out = (size_t)fin_stride * E;
   gp.hKgOut.reserve(n_out);
   double* out = gp.hKgOut.p;
-  MOE_HIP_CHECK(hipMemcpyAsync(out, dFin, sizeof(double) * n_out, hipMemcpyDeviceToHost, s));
+  copy_async(out, dFin, sizeof(double) * n_out, hipMemcpyDeviceToHost, s, true);  // (hKgOut: pinned)
 #if MOE_BLOCK_PROF
   auto prof_p = std::make_shared<std::vector<unsigned long long>>(16);
-  MOE_HIP_CHECK(hipMemcpyAsync(prof_p->data(), dCounters.p + n_ctr - 16, sizeof(unsigned long long) * 16, hipMemcpyDeviceToHost, s));
+  copy_async(prof_p->data(), dCounters.p + n_ctr - 16, sizeof(unsigned long long) * 16, hipMemcpyDeviceToHost, s);
 #endif
   const bool fetch_bp = want_best_points && E == 1;
   auto bp_p = std::make_shared<std::vector<double>>();

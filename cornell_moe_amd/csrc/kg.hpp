@@ -58,6 +58,10 @@ KgPending kg_launch(GpDev& gp, int num_fidelity, const moe_gd_params_t& gd, cons
 // (env MOE_REFERENCE_QUIRKS=0 or moe_set_reference_quirks(0) turn it off; include/moe_hip.h).
 bool reference_quirks();
 void set_reference_quirks(int on);  // < 0: back to the environment's setting
+// ensemble-wide launches of the MCMC-averaged KG evaluators (mcmc.hip, launch.hpp; include/moe_hip.h)
+bool ensemble_launches();
+void set_ensemble_launches(int on);  // < 0: back to the environment's setting (MOE_ENS_LAUNCH)
+void ensemble_launch_stats(long long* out4);
 // The exchange step of an outer optimisation that runs on several ranks (r5): an all-gather of `count` doubles per rank, every rank
 // receiving recv[world][count] in rank order.  One process per GPU passes torch.distributed's collective through the C ABI
 // (moe_comm_t: RCCL over xGMI, or gloo); one process driving several devices gets an in-memory exchange between its host threads

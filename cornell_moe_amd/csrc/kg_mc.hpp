@@ -2152,7 +2152,7 @@ template <int DP, int G>
 inline void launch_stream_inst(const KgMcParams& P, int blocks, int waves, size_t shm, hipStream_t s) {
   auto kern = kg_mc_stream_kernel<DP, G>;
   MOE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
-  hipLaunchKernelGGL(kern, dim3(blocks), dim3(waves * 64), shm, s, P);
+  MOE_LAUNCH(kern, dim3(blocks), dim3(waves * 64), shm, s, P);
   MOE_HIP_CHECK(hipGetLastError());
 }
 
@@ -2920,7 +2920,7 @@ inline void launch_block_inst(const KgMcParams& P, int num_lds_tiles, int blocks
   const size_t shm = sizeof(double) * (kBlockFixed + (size_t)num_lds_tiles * (DP + 1 + G) * 64);
   auto kern = kg_mc_block_kernel<DP, G, TR>;
   MOE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
-  hipLaunchKernelGGL(kern, dim3(blocks), dim3(waves * 64), shm, s, P, num_lds_tiles);
+  MOE_LAUNCH(kern, dim3(blocks), dim3(waves * 64), shm, s, P, num_lds_tiles);
   MOE_HIP_CHECK(hipGetLastError());
 }
 
@@ -2956,7 +2956,7 @@ template <int DP, int G, bool XLDS, bool SMALL>
 inline void launch_inst2(const KgMcParams& P, int blocks, int waves, size_t shm, hipStream_t s) {
   auto kern = kg_mc_kernel<DP, G, XLDS, SMALL>;
   MOE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
-  hipLaunchKernelGGL(kern, dim3(blocks), dim3(waves * 64), shm, s, P);
+  MOE_LAUNCH(kern, dim3(blocks), dim3(waves * 64), shm, s, P);
   MOE_HIP_CHECK(hipGetLastError());
 }
 

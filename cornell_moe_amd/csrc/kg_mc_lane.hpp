@@ -507,8 +507,11 @@ __device__ __forceinline__ void kg_sample_lane(const KgMcParams& P, int e, int s
 
 // LDS: [64] exp table | [kLaneCstRows x DP] lane constants | [rec_head] the evaluation's record head | [tab] coordinates | per-wave slabs
 // (weights [ntiles (1 + G) 64] + 2 kMaxM doubles of scratch) | one weight tile of padding.  Built for the LDS coordinate table, 8 waves.
+// (r6: the body as a device function -- launch.hpp -- so that the members of a GP ensemble share one launch; `argbase`: where this
+//  member's arguments lie, the kernarg segment or its record in the ensemble twin's table)
 template <int DP, int G>
-__global__ __launch_bounds__(kLaneMaxThreads) void kg_mc_lane_kernel(KgMcParams P, int rec_head) {
+struct kg_mc_lane_kernel_body {
+static __device__ __forceinline__ void run(const VIdx blockIdx, const VIdx gridDim, const void* argbase, const KgMcParams& P, int rec_head) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
@@ -555,8 +558,7 @@ __global__ __launch_bounds__(kLaneMaxThreads) void kg_mc_lane_kernel(KgMcParams 
       // The kernel arguments are re-read from the kernarg segment by every sample (scalar loads through an opaque copy of its
       // address) instead of being loaded once at kernel entry and held -- or spilt to vector-register lanes -- for the kernel's lifetime.
       // (P is the kernel's first argument: offset 0 of the segment)
-      const __attribute__((address_space(4))) KgMcParams* Pk =
-          (const __attribute__((address_space(4))) KgMcParams*)__builtin_amdgcn_kernarg_segment_ptr();
+      const __attribute__((address_space(4))) KgMcParams* Pk = (const __attribute__((address_space(4))) KgMcParams*)argbase;
       asm volatile("" : "+s"(Pk));
       kg_sample_lane<DP, G>(*(const KgMcParams*)Pk, e, (int)sl, coords, aw, zb, smem, cst, rc, lane, tot_val, tot_grad);
     }
@@ -566,6 +568,11 @@ __global__ __launch_bounds__(kLaneMaxThreads) void kg_mc_lane_kernel(KgMcParams 
     }
     if (gridDim.x >= (unsigned)P.E) break;
   }
+}
+};
+template <int DP, int G>
+__global__ __launch_bounds__(kLaneMaxThreads) void kg_mc_lane_kernel(KgMcParams P, int rec_head) {
+  kg_mc_lane_kernel_body<DP, G>::run(MOE_VBLOCK, MOE_VGRID, (const void*)__builtin_amdgcn_kernarg_segment_ptr(), P, rec_head);
 }
 
 // LDS bytes of a workgroup of `waves` wavefronts (host side: kg.hip's geometry)
@@ -579,7 +586,7 @@ template <int DP, int G>
 inline void launch_lane_inst(const KgMcParams& P, int rec_head, int blocks, int waves, size_t shm, hipStream_t s) {
   auto kern = kg_mc_lane_kernel<DP, G>;
   MOE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
-  hipLaunchKernelGGL(kern, dim3(blocks), dim3(waves * 64), shm, s, P, rec_head);
+  launch_kernel_ens<kg_mc_lane_kernel_body<DP, G>, kLaneMaxThreads>(kern, dim3(blocks), dim3(waves * 64), shm, s, P, rec_head);
   MOE_HIP_CHECK(hipGetLastError());
 }
 

@@ -12,6 +12,7 @@
 // axis: kg_mcmc_sums returns plain sums over the GPs it was given so ranks holding disjoint GP subsets can all-reduce them
 // before kg_mcmc_finalize (cornell_moe_amd/dist.py).
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 
@@ -19,6 +20,7 @@
 #include "kg.hpp"
 
 #include <cstdlib>
+#include <map>
 #include <thread>
 
 namespace moe {
@@ -31,6 +33,116 @@ void check_ensemble(const std::vector<GpDev*>& gps) {
     if (g == nullptr) throw Error(MOE_ERR_RUNTIME, "NULL GP handle in the MCMC ensemble");
     if (g->d != gps[0]->d || g->g != gps[0]->g)
       throw Error(MOE_ERR_INVALID_VALUE, "MCMC ensemble members must share dim and the observed-derivative list", g->d, gps[0]->d, 0);
+  }
+}
+
+std::atomic<int> g_ens_launch{-1};  // -1: follow the environment
+std::atomic<long long> g_ens_stats[4];
+}  // namespace
+
+bool ensemble_launches() {
+  const int v = g_ens_launch.load();
+  if (v >= 0) return v != 0;
+  const char* e = std::getenv("MOE_ENS_LAUNCH");
+  return !(e != nullptr && *e != 0 && std::atoi(e) == 0);
+}
+void set_ensemble_launches(int on) { g_ens_launch.store(on < 0 ? -1 : (on != 0 ? 1 : 0)); }
+void ensemble_launch_stats(long long* out4) {
+  for (int i = 0; i < 4; ++i) out4[i] = g_ens_stats[i].load();
+}
+
+namespace {
+// ---- ensemble-wide launches (r6; launch.hpp) ----
+// The recordings of the members' evaluation chains, zipped: position by position ONE launch of a kernel's ensemble twin over all
+// members (their argument records side by side in a device table), one copy kernel for their small pinned copies, everything else
+// member after member -- on ONE stream.  Returns false (nothing launched) when the recordings do not line up or too few positions
+// merge to be worth the members' concurrency on their own streams.
+struct EnsArena {
+  PinnedBuf<unsigned char> host;
+  DevBuf<unsigned char> dev;
+};
+constexpr size_t kEnsCopyMaxBytes = (size_t)4 << 20;
+
+bool ens_copy_mergeable(const std::vector<Recorder>& recs, size_t pos) {
+  static const bool on = !(std::getenv("MOE_ENS_COPY") != nullptr && std::atoi(std::getenv("MOE_ENS_COPY")) == 0);
+  if (!on) return false;
+  for (const Recorder& r : recs) {
+    const LaunchOp& o = r.ops[pos];
+    if (!o.host_pinned || o.copy.bytes % 8 != 0 || o.copy.bytes > kEnsCopyMaxBytes) return false;
+  }
+  return true;
+}
+
+bool replay_ensemble(const std::vector<Recorder>& recs, hipStream_t z, EnsArena& arena, int* merged_out) {
+  const size_t M = recs.size(), L = recs[0].ops.size();
+  std::vector<char> how(L, 0);  // 0: member after member, 1: ensemble twin, 2: copy kernel
+  std::vector<size_t> off(L, 0);
+  size_t total = 0, merged = 0;
+  for (const Recorder& r : recs)
+    if (r.ops.size() != L) return false;
+  for (size_t k = 0; k < L; ++k) {
+    const LaunchOp& a = recs[0].ops[k];
+    bool same = true;
+    for (size_t i = 1; i < M && same; ++i) {
+      const LaunchOp& b = recs[i].ops[k];
+      same = b.kind == a.kind && b.ens_launch == a.ens_launch && b.args.size() == a.args.size() && b.shm == a.shm &&
+             b.grid.x == a.grid.x && b.grid.y == a.grid.y && b.grid.z == a.grid.z && b.block.x == a.block.x &&
+             b.block.y == a.block.y && b.block.z == a.block.z;
+    }
+    if (!same) {
+      if (recs[0].ops[k].kind != LaunchOp::kKernel) return false;  // (copies and the rest must line up; kernels may differ in shape)
+      for (size_t i = 1; i < M; ++i)
+        if (recs[i].ops[k].kind != LaunchOp::kKernel) return false;
+      continue;
+    }
+    if (a.kind == LaunchOp::kKernel && a.ens_launch != nullptr && (size_t)a.grid.z * M <= 65535) {
+      how[k] = 1;
+      off[k] = total;
+      total += (a.args.size() * M + 255) / 256 * 256;
+      ++merged;
+    } else if (a.kind == LaunchOp::kCopy && ens_copy_mergeable(recs, k)) {
+      how[k] = 2;
+      off[k] = total;
+      total += (sizeof(CopyEntry) * M + 255) / 256 * 256;
+      ++merged;
+    }
+  }
+  if (merged_out) *merged_out = (int)merged;
+  if (merged * 10 < L * 6) return false;
+  arena.host.reserve(total);
+  arena.dev.reserve(total);
+  for (size_t k = 0; k < L; ++k) {
+    if (how[k] == 1) {
+      const size_t sz = recs[0].ops[k].args.size();
+      for (size_t i = 0; i < M; ++i) std::memcpy(arena.host.p + off[k] + i * sz, recs[i].ops[k].args.data(), sz);
+    } else if (how[k] == 2) {
+      for (size_t i = 0; i < M; ++i) std::memcpy(arena.host.p + off[k] + i * sizeof(CopyEntry), &recs[i].ops[k].copy, sizeof(CopyEntry));
+    }
+  }
+  MOE_HIP_CHECK(hipMemcpyAsync(arena.dev.p, arena.host.p, total, hipMemcpyHostToDevice, z));
+  for (size_t k = 0; k < L; ++k) {
+    const LaunchOp& a = recs[0].ops[k];
+    if (how[k] == 1) {
+      a.ens_launch(arena.dev.p + off[k], (int)M, a.grid, a.block, a.shm, z);
+    } else if (how[k] == 2) {
+      size_t most = 0;
+      for (size_t i = 0; i < M; ++i) most = std::max(most, recs[i].ops[k].copy.bytes);
+      const unsigned bx = (unsigned)std::max<size_t>(1, std::min<size_t>(64, (most / 8 + 1023) / 1024));
+      ens_copy_kernel<0><<<dim3(bx, (unsigned)M), dim3(256), 0, z>>>((const CopyEntry*)(arena.dev.p + off[k]));
+    } else {
+      for (size_t i = 0; i < M; ++i) recs[i].ops[k].run(z);
+    }
+  }
+  MOE_HIP_CHECK(hipGetLastError());
+  return true;
+}
+
+void release_retired(std::vector<Recorder>& recs) {
+  for (Recorder& r : recs) {
+    for (auto& b : r.retired_dev) DevicePool::get().give(b.first, b.second);
+    for (auto& b : r.retired_host) DevicePool::get().give_host(b.first, b.second);
+    r.retired_dev.clear();
+    r.retired_host.clear();
   }
 }
 
@@ -57,12 +169,25 @@ void kg_mcmc_members(const std::vector<GpDev*>& gps, int num_fidelity, const moe
     // members are issued by host threads side by side (r5: 2.0 -> ms per optimiser step of 16 members x 20 restarts; MOE_MCMC_THREADS=1:
     // one after another, as in round 4).  Each member owns its stream, workspaces and staging buffers; results are collected in order.
     std::vector<KgPending> pending(gps.size());
+    // r6: ensemble-wide launches -- the members' chains are RECORDED (same host threads), then replayed as one chain of launches over all
+    // members on the first member's stream (replay_ensemble); recordings that do not line up are replayed per member on the members'
+    // own streams, and a shape that did not merge twice is launched directly from then on.  MOE_ENS_LAUNCH=0: always direct.
+    static thread_local std::map<long, int> ens_misses;
+    const long ens_key = ((long)gps[0]->N * 4096 + (long)(q + p) * 64 + (want_grad ? 1 : 0)) * 64 + (long)gps.size();
+    bool ens = ensemble_launches() && gps.size() > 1 && ens_misses[ens_key] < 2;
+    for (size_t i = 1; i < gps.size() && ens; ++i) ens = gps[i]->device == gps[0]->device;
+    std::vector<Recorder> recs(ens ? gps.size() : 0);
     auto issue = [&](size_t i) {
+      Recorder::Scope scope(ens ? &recs[i] : Recorder::current());
       pending[i] = kg_launch(*gps[i], num_fidelity, inner, bounds, discrete_all + i * disc_stride, P, Xq_all + (size_t)e0 * qd, ne, Xp, q,
                              p, num_mc, best_so_far[i], normals, 0, num_mc, want_grad, false, budget, disc_head);
     };
     const char* mt = std::getenv("MOE_MCMC_THREADS");
     const size_t nthreads = std::min(gps.size(), (size_t)std::max(1, (mt && *mt) ? std::atoi(mt) : 16));
+    struct Retire {  // (blocks the members' buffers outgrew while their launches were pending: back to the pool on every path)
+      std::vector<Recorder>& r;
+      ~Retire() { release_retired(r); }
+    } retire{recs};
     if (nthreads <= 1) {
       for (size_t i = 0; i < gps.size(); ++i) issue(i);
     } else {
@@ -93,8 +218,8 @@ void kg_mcmc_members(const std::vector<GpDev*>& gps, int num_fidelity, const moe
       for (size_t k = 0; k < nthreads; ++k)
         if (failed[k]) {
           // (members already in flight finish on their own streams; their workspaces are not touched again before the next call's
-          //  stream-ordered work)
-          for (size_t i = 0; i < gps.size(); ++i)
+          //  stream-ordered work.  With recorded launches nothing is in flight.)
+          for (size_t i = 0; i < gps.size() && !ens; ++i)
             if (pending[i].collect) {
               try {
                 pending[i].collect(ks.data(), want_grad ? gs.data() : nullptr, nullptr, nullptr);
@@ -103,6 +228,29 @@ void kg_mcmc_members(const std::vector<GpDev*>& gps, int num_fidelity, const moe
             }
           throw errors[k];
         }
+    }
+    if (ens) {
+      static thread_local EnsArena arena;
+      gps[0]->use_device();
+      hipStream_t z = gps[0]->stream;
+      int merged = 0;
+      if (replay_ensemble(recs, z, arena, &merged)) {
+        MOE_HIP_CHECK(hipStreamSynchronize(z));
+        ens_misses[ens_key] = 0;
+        g_ens_stats[0] += 1;
+        g_ens_stats[2] += 1 + merged + ((long long)recs[0].ops.size() - merged) * (long long)gps.size();  // (1: the table's copy)
+        g_ens_stats[3] += (long long)recs[0].ops.size() * (long long)gps.size();
+      } else {
+        ++ens_misses[ens_key];
+        g_ens_stats[1] += 1;
+        for (size_t i = 0; i < gps.size(); ++i) {
+          gps[i]->use_device();
+          for (const LaunchOp& op : recs[i].ops) op.run(gps[i]->stream);
+        }
+      }
+      if (std::getenv("MOE_ENS_TRACE") != nullptr)
+        std::fprintf(stderr, "[moe ens] members %zu, ops %zu, merged positions %d, misses %d\n", gps.size(), recs[0].ops.size(), merged,
+                     ens_misses[ens_key]);
     }
     for (size_t i = 0; i < gps.size(); ++i) {
       pending[i].collect(ks.data(), want_grad ? gs.data() : nullptr, nullptr, nullptr);

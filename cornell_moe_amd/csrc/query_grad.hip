@@ -179,7 +179,7 @@ void grad_variance_on_device(GpDev& gp, const double* pts, int num_pts, int num_
   P.out = gp.dVarWork.p;
   P.chol = gp.dVarWork.p + (size_t)num_derivs * blk;
   P.info = gp.dInfo.p;
-  hipLaunchKernelGGL(query_grad_kernel, dim3(num_derivs), dim3(256), 0, s, P);
+  MOE_LAUNCH(query_grad_kernel, dim3(num_derivs), dim3(256), 0, s, P);
   MOE_HIP_CHECK(hipGetLastError());
   gp.dVarWork.download(out, (size_t)num_derivs * blk, s);
   int info[4] = {0, 0, 0, 0};

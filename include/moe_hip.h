@@ -252,6 +252,15 @@ int moe_kg_multistart(const moe_gp_t* gp, int num_fidelity, const moe_gd_params_
  * a fresh state per call, as the reference's Python boundary does. */
 int moe_set_reference_quirks(int on);
 int moe_get_reference_quirks(void);
+/* Ensemble-wide launches (r6): the MCMC-averaged KG entry points (moe_kg_mcmc_batch, moe_kg_mcmc_multistart and their _comm
+ * forms: KnowledgeGradientMCMCEvaluator, gpp_knowledge_gradient_mcmc_optimization.cpp:129-180, evaluates the ensemble members one
+ * after another) record every member's chain of kernels and issue each kernel ONCE for all members of the ensemble; same bits as
+ * member-by-member launches.  moe_set_ensemble_launches(0) -> member by member (MOE_ENS_LAUNCH=0 in the environment does the same),
+ * (1) -> on (the default), (-1) -> back to the environment.  moe_ensemble_launch_stats: out[0] = evaluations of an ensemble that
+ * went down merged, out[1] = that fell back to member-by-member launches, out[2] = kernel launches issued by merged evaluations,
+ * out[3] = member launches they stand for.  Process-wide. */
+int moe_set_ensemble_launches(int on);
+int moe_ensemble_launch_stats(long long* out4);
 /* posterior_mean_optimization (gpp_python_knowledge_gradient.cpp:315-342) -> ComputeOptimalPosteriorMean from ONE initial
  * guess: line-search ascent on -mu with fidelity coordinates pinned to 1.  best_point[dim - num_fidelity]. */
 int moe_posterior_mean_optimize(const moe_gp_t* gp, int num_fidelity, const moe_gd_params_t* params, const double* domain_bounds,
