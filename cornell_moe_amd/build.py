@@ -56,7 +56,9 @@ def build(force=False, verbose=False):
         results = list(ex.map(lambda s: _compile(s, force), SOURCES))
     objs = [r[0] for r in results]
     rebuilt = any(r[1] for r in results)
-    if rebuilt or not os.path.exists(LIB):
+    stale = not os.path.exists(LIB) or any(os.path.getmtime(o) > os.path.getmtime(LIB) for o in objs)  # (an object compiled by hand)
+    rebuilt = rebuilt or stale
+    if rebuilt:
         cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
         res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, universal_newlines=True)
         if res.returncode != 0:

@@ -813,19 +813,23 @@ __global__ __launch_bounds__(256) void kg_sum_kernel(KgTailParams P, double* __r
 }
 
 struct EventTimer {
-  hipEvent_t a, b;
-  EventTimer() {
-    MOE_HIP_CHECK(hipEventCreate(&a));
-    MOE_HIP_CHECK(hipEventCreate(&b));
-  }
+  hipEvent_t a = nullptr, b = nullptr;  // (created on first use: a recorded evaluation -- launch.hpp -- times nothing)
+  bool on = false;
+  EventTimer() = default;
+  EventTimer(const EventTimer&) = delete;
+  EventTimer& operator=(const EventTimer&) = delete;
   ~EventTimer() {
-    (void)hipEventDestroy(a);
-    (void)hipEventDestroy(b);
+    if (a != nullptr) (void)hipEventDestroy(a);
+    if (b != nullptr) (void)hipEventDestroy(b);
   }
-  bool on = false;  // (nothing is timed while launches are being recorded: launch.hpp)
   void start(hipStream_t s) {
     on = Recorder::current() == nullptr;
-    if (on) MOE_HIP_CHECK(hipEventRecord(a, s));
+    if (!on) return;
+    if (a == nullptr) {
+      MOE_HIP_CHECK(hipEventCreate(&a));
+      MOE_HIP_CHECK(hipEventCreate(&b));
+    }
+    MOE_HIP_CHECK(hipEventRecord(a, s));
   }
   void stop(hipStream_t s) {
     if (on) MOE_HIP_CHECK(hipEventRecord(b, s));

@@ -183,7 +183,9 @@ void kg_mcmc_members(const std::vector<GpDev*>& gps, int num_fidelity, const moe
                              p, num_mc, best_so_far[i], normals, 0, num_mc, want_grad, false, budget, disc_head);
     };
     const char* mt = std::getenv("MOE_MCMC_THREADS");
-    const size_t nthreads = std::min(gps.size(), (size_t)std::max(1, (mt && *mt) ? std::atoi(mt) : 16));
+    // (recording is cheap -- no launch is issued -- and starting 16 host threads per evaluation costs more than it: 0.156 s per
+    //  suggestion with them, 0.113 s without; MOE_MCMC_THREADS still sets the count for member-by-member launches)
+    const size_t nthreads = ens ? 1 : std::min(gps.size(), (size_t)std::max(1, (mt && *mt) ? std::atoi(mt) : 16));
     struct Retire {  // (blocks the members' buffers outgrew while their launches were pending: back to the pool on every path)
       std::vector<Recorder>& r;
       ~Retire() { release_retired(r); }
