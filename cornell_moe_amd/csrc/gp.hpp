@@ -41,6 +41,9 @@ struct GpDev {
   const double* dUnion = nullptr;
   const double* dAppendix = nullptr;
   PinnedBuf<double> hStateIn, hStateOut, hKgIn, hKgOut;  // pinned staging for the per-call operands / results
+  // the argument tables of ensemble-wide launches (mcmc.hip: replay_ensemble; held by the ensemble's first member)
+  PinnedBuf<unsigned char> hEns;
+  DevBuf<unsigned char> dEns;
   PinnedBuf<double> hYc;  // y - mean on its way to the device, and the factorisation's status word on its way back
   // reusable workspaces of the KG evaluator (kg.hip)
   DevBuf<double> kBlob, kNormals, kTab, kBestPoint, kBestValue, kBeta, kT, kC, kTB, kOut, kSW, kSWpart, kZcPart, kV;

@@ -731,102 +731,114 @@ namespace {
 // C = T B:  one workgroup per strip of 64 rows (a row per lane), the K range dealt out to its wavefronts round-robin (each
 // wavefront load is one 512-byte segment of a column), B[k, :] wave-uniform; partial sums meet in LDS in wavefront order.
 template <int CB, int WAVES>
+struct tri_skinny_n_kernel_body {
+  static __device__ __forceinline__ void run(const VIdx blockIdx, const VIdx gridDim, const void*, int N, const double* __restrict__ T, long ldt, const double* __restrict__ B, long ldb, int c, double* __restrict__ C, long ldc) {
+    // r4: the k range goes down in chunks of KC = 32 WAVES; per chunk a lane issues its 32 loads of T in ONE batch and the chunk's rows
+    // of B are staged in LDS by the whole workgroup (coalesced), so a chunk costs one memory round trip -- the per-k version (one T load
+    // and CB wave-uniform B loads per iteration, four iterations in flight) paid a round trip of 2 - 4 us every few k: 34 us for the
+    // 500 x 500 factor of C2 against 10 columns.  Summation order of an entry: wave w adds its k = w, w + WAVES, ... in ascending order,
+    // the waves' partial sums are added in wave order -- fixed by N alone.
+    constexpr int TPL = 32;            // T loads per lane and chunk
+    constexpr int KC = TPL * WAVES;    // k per chunk
+    constexpr int HW = WAVES / 2;
+    // dynamic LDS: red [WAVES / 2][CB][64] | Bs [KC][CB]   (64 KB at CB = 8 with 16 waves: opted in by the launcher)
+    extern __shared__ __attribute__((aligned(16))) double sk_sm[];
+    double(*red)[CB][64] = reinterpret_cast<double(*)[CB][64]>(sk_sm);
+    double(*Bs)[CB] = reinterpret_cast<double(*)[CB]>(sk_sm + HW * CB * 64);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int i0 = blockIdx.x * 64, i = i0 + lane, c0 = blockIdx.y * CB;
+    const int kend = min(N, i0 + 64);
+    const bool row_ok = i < N;
+    const double* Trow = T + (row_ok ? i : 0);
+    double acc[CB];
+  #pragma unroll
+    for (int cc = 0; cc < CB; ++cc) acc[cc] = 0.0;
+    for (int k0 = 0; k0 < kend; k0 += KC) {
+      double tv[TPL];
+  #pragma unroll
+      for (int t = 0; t < TPL; ++t) tv[t] = Trow[(long)min(k0 + w + WAVES * t, kend - 1) * ldt];  // (clamped; masked below)
+      for (int t = threadIdx.x; t < KC * CB; t += WAVES * 64) {
+        const int kk = t % KC, cc = t / KC;
+        Bs[kk][cc] = (k0 + kk < kend && c0 + cc < c) ? B[(long)(k0 + kk) + (long)(c0 + cc) * ldb] : 0.0;
+      }
+      __syncthreads();
+  #pragma unroll
+      for (int t = 0; t < TPL; ++t) {
+        const int kk = w + WAVES * t, k = k0 + kk;
+        const double tm = (row_ok && k <= i && k < kend) ? tv[t] : 0.0;
+  #pragma unroll
+        for (int cc = 0; cc < CB; ++cc) acc[cc] = fma(tm, Bs[kk][cc], acc[cc]);
+      }
+      __syncthreads();
+    }
+    // waves HW .. WAVES - 1 hand their sums to waves 0 .. HW - 1 (w + HW -> w), then the HW partial sums are added in wave order
+    if (w >= HW) {
+  #pragma unroll
+      for (int cc = 0; cc < CB; ++cc) red[w - HW][cc][lane] = acc[cc];
+    }
+    __syncthreads();
+    if (w < HW) {
+  #pragma unroll
+      for (int cc = 0; cc < CB; ++cc) acc[cc] += red[w][cc][lane];
+    }
+    __syncthreads();
+    if (w < HW) {
+  #pragma unroll
+      for (int cc = 0; cc < CB; ++cc) red[w][cc][lane] = acc[cc];
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < CB * 64; t += WAVES * 64) {
+      const int cc = t >> 6, l = t & 63;
+      double v = 0.0;
+  #pragma unroll
+      for (int ww = 0; ww < HW; ++ww) v += red[ww][cc][l];
+      if (i0 + l < N && c0 + cc < c) C[(long)(i0 + l) + (long)(c0 + cc) * ldc] = v;
+    }
+  }
+};
+template <int CB, int WAVES>
 __global__ __launch_bounds__(WAVES * 64) void tri_skinny_n_kernel(int N, const double* __restrict__ T, long ldt,
                                                                   const double* __restrict__ B, long ldb, int c,
                                                                   double* __restrict__ C, long ldc) {
-  // r4: the k range goes down in chunks of KC = 32 WAVES; per chunk a lane issues its 32 loads of T in ONE batch and the chunk's rows
-  // of B are staged in LDS by the whole workgroup (coalesced), so a chunk costs one memory round trip -- the per-k version (one T load
-  // and CB wave-uniform B loads per iteration, four iterations in flight) paid a round trip of 2 - 4 us every few k: 34 us for the
-  // 500 x 500 factor of C2 against 10 columns.  Summation order of an entry: wave w adds its k = w, w + WAVES, ... in ascending order,
-  // the waves' partial sums are added in wave order -- fixed by N alone.
-  constexpr int TPL = 32;            // T loads per lane and chunk
-  constexpr int KC = TPL * WAVES;    // k per chunk
-  constexpr int HW = WAVES / 2;
-  // dynamic LDS: red [WAVES / 2][CB][64] | Bs [KC][CB]   (64 KB at CB = 8 with 16 waves: opted in by the launcher)
-  extern __shared__ __attribute__((aligned(16))) double sk_sm[];
-  double(*red)[CB][64] = reinterpret_cast<double(*)[CB][64]>(sk_sm);
-  double(*Bs)[CB] = reinterpret_cast<double(*)[CB]>(sk_sm + HW * CB * 64);
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int i0 = blockIdx.x * 64, i = i0 + lane, c0 = blockIdx.y * CB;
-  const int kend = min(N, i0 + 64);
-  const bool row_ok = i < N;
-  const double* Trow = T + (row_ok ? i : 0);
-  double acc[CB];
-#pragma unroll
-  for (int cc = 0; cc < CB; ++cc) acc[cc] = 0.0;
-  for (int k0 = 0; k0 < kend; k0 += KC) {
-    double tv[TPL];
-#pragma unroll
-    for (int t = 0; t < TPL; ++t) tv[t] = Trow[(long)min(k0 + w + WAVES * t, kend - 1) * ldt];  // (clamped; masked below)
-    for (int t = threadIdx.x; t < KC * CB; t += WAVES * 64) {
-      const int kk = t % KC, cc = t / KC;
-      Bs[kk][cc] = (k0 + kk < kend && c0 + cc < c) ? B[(long)(k0 + kk) + (long)(c0 + cc) * ldb] : 0.0;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int t = 0; t < TPL; ++t) {
-      const int kk = w + WAVES * t, k = k0 + kk;
-      const double tm = (row_ok && k <= i && k < kend) ? tv[t] : 0.0;
-#pragma unroll
-      for (int cc = 0; cc < CB; ++cc) acc[cc] = fma(tm, Bs[kk][cc], acc[cc]);
-    }
-    __syncthreads();
-  }
-  // waves HW .. WAVES - 1 hand their sums to waves 0 .. HW - 1 (w + HW -> w), then the HW partial sums are added in wave order
-  if (w >= HW) {
-#pragma unroll
-    for (int cc = 0; cc < CB; ++cc) red[w - HW][cc][lane] = acc[cc];
-  }
-  __syncthreads();
-  if (w < HW) {
-#pragma unroll
-    for (int cc = 0; cc < CB; ++cc) acc[cc] += red[w][cc][lane];
-  }
-  __syncthreads();
-  if (w < HW) {
-#pragma unroll
-    for (int cc = 0; cc < CB; ++cc) red[w][cc][lane] = acc[cc];
-  }
-  __syncthreads();
-  for (int t = threadIdx.x; t < CB * 64; t += WAVES * 64) {
-    const int cc = t >> 6, l = t & 63;
-    double v = 0.0;
-#pragma unroll
-    for (int ww = 0; ww < HW; ++ww) v += red[ww][cc][l];
-    if (i0 + l < N && c0 + cc < c) C[(long)(i0 + l) + (long)(c0 + cc) * ldc] = v;
-  }
+  tri_skinny_n_kernel_body<CB, WAVES>::run(MOE_VBLOCK, MOE_VGRID, nullptr, N, T, ldt, B, ldb, c, C, ldc);
 }
 
 // C = T^T B:  one wavefront per column of T (contiguous), lanes stride down the rows from the 64-aligned row at or above
 // the diagonal, fixed-order butterfly at the end.
 template <int CB>
+struct tri_skinny_t_kernel_body {
+  static __device__ __forceinline__ void run(const VIdx blockIdx, const VIdx gridDim, const void*, int N, const double* __restrict__ T, long ldt, const double* __restrict__ B, long ldb, int c, double* __restrict__ C, long ldc) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int j = blockIdx.x * 4 + w, c0 = blockIdx.y * CB;
+    if (j >= N) return;
+    const double* col = T + (long)j * ldt;
+    double acc[CB];
+  #pragma unroll
+    for (int cc = 0; cc < CB; ++cc) acc[cc] = 0.0;
+    const double* Bc[CB];
+  #pragma unroll
+    for (int cc = 0; cc < CB; ++cc) Bc[cc] = B + (long)min(c0 + cc, c - 1) * ldb;
+  #pragma unroll 8
+    for (int i = (j & ~63) + lane; i < N; i += 64) {  // (unconditional loads, masked afterwards: see tri_skinny_n_kernel)
+      const double tv = col[i];
+      const double t = (i >= j) ? tv : 0.0;
+  #pragma unroll
+      for (int cc = 0; cc < CB; ++cc) acc[cc] = fma(t, Bc[cc][i], acc[cc]);
+    }
+  #pragma unroll
+    for (int cc = 0; cc < CB; ++cc) {
+      double v = acc[cc];
+  #pragma unroll
+      for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+      if (lane == 0 && c0 + cc < c) C[(long)j + (long)(c0 + cc) * ldc] = v;
+    }
+  }
+};
+template <int CB>
 __global__ __launch_bounds__(256) void tri_skinny_t_kernel(int N, const double* __restrict__ T, long ldt,
                                                           const double* __restrict__ B, long ldb, int c,
                                                           double* __restrict__ C, long ldc) {
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int j = blockIdx.x * 4 + w, c0 = blockIdx.y * CB;
-  if (j >= N) return;
-  const double* col = T + (long)j * ldt;
-  double acc[CB];
-#pragma unroll
-  for (int cc = 0; cc < CB; ++cc) acc[cc] = 0.0;
-  const double* Bc[CB];
-#pragma unroll
-  for (int cc = 0; cc < CB; ++cc) Bc[cc] = B + (long)min(c0 + cc, c - 1) * ldb;
-#pragma unroll 8
-  for (int i = (j & ~63) + lane; i < N; i += 64) {  // (unconditional loads, masked afterwards: see tri_skinny_n_kernel)
-    const double tv = col[i];
-    const double t = (i >= j) ? tv : 0.0;
-#pragma unroll
-    for (int cc = 0; cc < CB; ++cc) acc[cc] = fma(t, Bc[cc][i], acc[cc]);
-  }
-#pragma unroll
-  for (int cc = 0; cc < CB; ++cc) {
-    double v = acc[cc];
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-    if (lane == 0 && c0 + cc < c) C[(long)j + (long)(c0 + cc) * ldc] = v;
-  }
+  tri_skinny_t_kernel_body<CB>::run(MOE_VBLOCK, MOE_VGRID, nullptr, N, T, ldt, B, ldb, c, C, ldc);
 }
 
 template <int CB>
@@ -839,9 +851,9 @@ void launch_tri_skinny(char op, int N, int c, const double* T, long ldt, const d
     const size_t shm = sizeof(double) * ((size_t)8 * CB * 64 + (size_t)512 * CB);
     if (shm > 48 * 1024)
       MOE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
-    MOE_LAUNCH(kern, dim3((N + 63) / 64, groups), dim3(1024), shm, s, N, T, ldt, B, ldb, c, C, ldc);
+    launch_kernel_ens<tri_skinny_n_kernel_body<CB, 16>, 1024>(kern, dim3((N + 63) / 64, groups), dim3(1024), shm, s, N, T, ldt, B, ldb, c, C, ldc);
   } else {
-    MOE_LAUNCH((tri_skinny_t_kernel<CB>), dim3((N + 3) / 4, groups), dim3(256), 0, s, N, T, ldt, B, ldb, c, C, ldc);
+    launch_kernel_ens<tri_skinny_t_kernel_body<CB>, 256>(tri_skinny_t_kernel<CB>, dim3((N + 3) / 4, groups), dim3(256), 0, s, N, T, ldt, B, ldb, c, C, ldc);
   }
   MOE_HIP_CHECK(hipGetLastError());
 }
@@ -856,95 +868,107 @@ namespace {
 // alone, so an entry's summation order does not depend on how many columns (evaluations) share the call.
 // MODE 1: C = T B (T lower: row tile r needs k < (r + 1) 64).  MODE 2: C = T^T B (k >= r 64).
 template <int MODE, int TK = 16>
+struct tri_splitk_kernel_body {
+  static __device__ __forceinline__ void run(const VIdx blockIdx, const VIdx gridDim, const void*, int N, int c, int KS, const double* __restrict__ T, long ldt, const double* __restrict__ B, long ldb, double* __restrict__ work) {
+    constexpr int TM = 64, LD = 65;
+    constexpr int NF = TM * TK / 256;
+    __shared__ double As[TK][LD];
+    __shared__ double Bs[TK][LD];
+    const int j0 = blockIdx.x * 64, i0 = blockIdx.y * TM, sl = blockIdx.z;
+    int k_lo = sl * KS, k_hi = min(N, k_lo + KS);
+    if (MODE == 1) k_hi = min(k_hi, min(N, i0 + TM));
+    if (MODE == 2) k_lo = max(k_lo, (i0 / TK) * TK);
+    if (k_lo >= k_hi) return;  // this row tile has no work in this slice (tri_splitk_sum_kernel skips it, too)
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wi = (wave & 1) * 32, wj = (wave >> 1) * 32;
+    const int lk = lane >> 4, lx = lane & 15;
+    f64x4 acc[2][2];
+  #pragma unroll
+    for (int a = 0; a < 2; ++a)
+  #pragma unroll
+      for (int b = 0; b < 2; ++b) acc[a][b] = f64x4{0.0, 0.0, 0.0, 0.0};
+    double ra[NF], rb[NF];
+    auto fetch = [&](int k0) {
+  #pragma unroll
+      for (int it = 0; it < NF; ++it) {
+        const int t = threadIdx.x + 256 * it;
+        if (MODE == 1) {
+          const int ii = t % TM, kk = t / TM;
+          const int gi = i0 + ii, gk = k0 + kk;
+          ra[it] = (gi < N && gk < k_hi && gk <= gi) ? T[(long)gi + (long)gk * ldt] : 0.0;
+        } else {
+          const int kk = t % TK, ii = t / TK;
+          const int gi = i0 + ii, gk = k0 + kk;
+          ra[it] = (gi < N && gk < k_hi && gk >= gi) ? T[(long)gk + (long)gi * ldt] : 0.0;
+        }
+        const int kk = t % TK, jj = t / TK;
+        const int gk = k0 + kk, gj = j0 + jj;
+        rb[it] = (gk < k_hi && gj < c) ? B[(long)gk + (long)gj * ldb] : 0.0;
+      }
+    };
+    fetch(k_lo);
+    for (int k0 = k_lo; k0 < k_hi; k0 += TK) {
+  #pragma unroll
+      for (int it = 0; it < NF; ++it) {
+        const int t = threadIdx.x + 256 * it;
+        if (MODE == 1)
+          As[t / TM][t % TM] = ra[it];
+        else
+          As[t % TK][t / TK] = ra[it];
+        Bs[t % TK][t / TK] = rb[it];
+      }
+      __syncthreads();
+      if (k0 + TK < k_hi) fetch(k0 + TK);
+  #pragma unroll
+      for (int k4 = 0; k4 < TK; k4 += 4) {
+        double fa[2], fb[2];
+  #pragma unroll
+        for (int a = 0; a < 2; ++a) fa[a] = As[k4 + lk][wi + 16 * a + lx];
+  #pragma unroll
+        for (int b = 0; b < 2; ++b) fb[b] = Bs[k4 + lk][wj + 16 * b + lx];
+  #pragma unroll
+        for (int a = 0; a < 2; ++a)
+  #pragma unroll
+          for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb[b], fa[a], acc[a][b], 0, 0, 0);
+      }
+      __syncthreads();
+    }
+    double* W = work + (long)sl * N * c;
+  #pragma unroll
+    for (int a = 0; a < 2; ++a)
+  #pragma unroll
+      for (int b = 0; b < 2; ++b)
+  #pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int gi = i0 + wi + 16 * a + lx, gj = j0 + wj + 16 * b + lk + 4 * r;
+          if (gi < N && gj < c) W[(long)gi + (long)gj * N] = acc[a][b][r];
+        }
+  }
+};
+template <int MODE, int TK = 16>
 __global__ __launch_bounds__(256) void tri_splitk_kernel(int N, int c, int KS, const double* __restrict__ T, long ldt,
                                                         const double* __restrict__ B, long ldb, double* __restrict__ work) {
-  constexpr int TM = 64, LD = 65;
-  constexpr int NF = TM * TK / 256;
-  __shared__ double As[TK][LD];
-  __shared__ double Bs[TK][LD];
-  const int j0 = blockIdx.x * 64, i0 = blockIdx.y * TM, sl = blockIdx.z;
-  int k_lo = sl * KS, k_hi = min(N, k_lo + KS);
-  if (MODE == 1) k_hi = min(k_hi, min(N, i0 + TM));
-  if (MODE == 2) k_lo = max(k_lo, (i0 / TK) * TK);
-  if (k_lo >= k_hi) return;  // this row tile has no work in this slice (tri_splitk_sum_kernel skips it, too)
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int wi = (wave & 1) * 32, wj = (wave >> 1) * 32;
-  const int lk = lane >> 4, lx = lane & 15;
-  f64x4 acc[2][2];
-#pragma unroll
-  for (int a = 0; a < 2; ++a)
-#pragma unroll
-    for (int b = 0; b < 2; ++b) acc[a][b] = f64x4{0.0, 0.0, 0.0, 0.0};
-  double ra[NF], rb[NF];
-  auto fetch = [&](int k0) {
-#pragma unroll
-    for (int it = 0; it < NF; ++it) {
-      const int t = threadIdx.x + 256 * it;
-      if (MODE == 1) {
-        const int ii = t % TM, kk = t / TM;
-        const int gi = i0 + ii, gk = k0 + kk;
-        ra[it] = (gi < N && gk < k_hi && gk <= gi) ? T[(long)gi + (long)gk * ldt] : 0.0;
-      } else {
-        const int kk = t % TK, ii = t / TK;
-        const int gi = i0 + ii, gk = k0 + kk;
-        ra[it] = (gi < N && gk < k_hi && gk >= gi) ? T[(long)gk + (long)gi * ldt] : 0.0;
-      }
-      const int kk = t % TK, jj = t / TK;
-      const int gk = k0 + kk, gj = j0 + jj;
-      rb[it] = (gk < k_hi && gj < c) ? B[(long)gk + (long)gj * ldb] : 0.0;
-    }
-  };
-  fetch(k_lo);
-  for (int k0 = k_lo; k0 < k_hi; k0 += TK) {
-#pragma unroll
-    for (int it = 0; it < NF; ++it) {
-      const int t = threadIdx.x + 256 * it;
-      if (MODE == 1)
-        As[t / TM][t % TM] = ra[it];
-      else
-        As[t % TK][t / TK] = ra[it];
-      Bs[t % TK][t / TK] = rb[it];
-    }
-    __syncthreads();
-    if (k0 + TK < k_hi) fetch(k0 + TK);
-#pragma unroll
-    for (int k4 = 0; k4 < TK; k4 += 4) {
-      double fa[2], fb[2];
-#pragma unroll
-      for (int a = 0; a < 2; ++a) fa[a] = As[k4 + lk][wi + 16 * a + lx];
-#pragma unroll
-      for (int b = 0; b < 2; ++b) fb[b] = Bs[k4 + lk][wj + 16 * b + lx];
-#pragma unroll
-      for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb[b], fa[a], acc[a][b], 0, 0, 0);
-    }
-    __syncthreads();
-  }
-  double* W = work + (long)sl * N * c;
-#pragma unroll
-  for (int a = 0; a < 2; ++a)
-#pragma unroll
-    for (int b = 0; b < 2; ++b)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int gi = i0 + wi + 16 * a + lx, gj = j0 + wj + 16 * b + lk + 4 * r;
-        if (gi < N && gj < c) W[(long)gi + (long)gj * N] = acc[a][b][r];
-      }
+  tri_splitk_kernel_body<MODE, TK>::run(MOE_VBLOCK, MOE_VGRID, nullptr, N, c, KS, T, ldt, B, ldb, work);
 }
 
 template <int MODE>
+struct tri_splitk_sum_kernel_body {
+  static __device__ __forceinline__ void run(const VIdx blockIdx, const VIdx gridDim, const void*, int N, int c, int KS, int slices, const double* __restrict__ work, double* __restrict__ C, long ldc) {
+    const int i = blockIdx.x * 256 + threadIdx.x, j = blockIdx.y;
+    if (i >= N) return;
+    const int rt = i / 64;  // the slices row tile rt took part in (the k ranges of tri_splitk_kernel)
+    int s_lo = 0, s_hi = slices;
+    if (MODE == 1) s_hi = min(slices, (min(N, (rt + 1) * 64) - 1) / KS + 1);
+    if (MODE == 2) s_lo = ((rt * 64) / 16 * 16) / KS;
+    double v = 0.0;
+    for (int sl = s_lo; sl < s_hi; ++sl) v += work[((long)sl * c + j) * N + i];
+    C[(long)i + (long)j * ldc] = v;
+  }
+};
+template <int MODE>
 __global__ __launch_bounds__(256) void tri_splitk_sum_kernel(int N, int c, int KS, int slices, const double* __restrict__ work,
                                                             double* __restrict__ C, long ldc) {
-  const int i = blockIdx.x * 256 + threadIdx.x, j = blockIdx.y;
-  if (i >= N) return;
-  const int rt = i / 64;  // the slices row tile rt took part in (the k ranges of tri_splitk_kernel)
-  int s_lo = 0, s_hi = slices;
-  if (MODE == 1) s_hi = min(slices, (min(N, (rt + 1) * 64) - 1) / KS + 1);
-  if (MODE == 2) s_lo = ((rt * 64) / 16 * 16) / KS;
-  double v = 0.0;
-  for (int sl = s_lo; sl < s_hi; ++sl) v += work[((long)sl * c + j) * N + i];
-  C[(long)i + (long)j * ldc] = v;
+  tri_splitk_sum_kernel_body<MODE>::run(MOE_VBLOCK, MOE_VGRID, nullptr, N, c, KS, slices, work, C, ldc);
 }
 }  // namespace
 
@@ -984,16 +1008,16 @@ void launch_tri_gemm_cols(char op, int N, int c, int cols_per_problem, const dou
   }();
   if (op == 'N') {
     if (tk == 32)
-      MOE_LAUNCH((tri_splitk_kernel<1, 32>), grid, dim3(256), 0, s, N, c, KS, T, ldt, B, ldb, work);
+      launch_kernel_ens<tri_splitk_kernel_body<1, 32>, 256>(tri_splitk_kernel<1, 32>, grid, dim3(256), 0, s, N, c, KS, T, ldt, B, ldb, work);
     else
-      MOE_LAUNCH((tri_splitk_kernel<1, 16>), grid, dim3(256), 0, s, N, c, KS, T, ldt, B, ldb, work);
-    MOE_LAUNCH(tri_splitk_sum_kernel<1>, sgrid, dim3(256), 0, s, N, c, KS, slices, (const double*)work, C, ldc);
+      launch_kernel_ens<tri_splitk_kernel_body<1, 16>, 256>(tri_splitk_kernel<1, 16>, grid, dim3(256), 0, s, N, c, KS, T, ldt, B, ldb, work);
+    launch_kernel_ens<tri_splitk_sum_kernel_body<1>, 256>(tri_splitk_sum_kernel<1>, sgrid, dim3(256), 0, s, N, c, KS, slices, (const double*)work, C, ldc);
   } else {
     if (tk == 32)
-      MOE_LAUNCH((tri_splitk_kernel<2, 32>), grid, dim3(256), 0, s, N, c, KS, T, ldt, B, ldb, work);
+      launch_kernel_ens<tri_splitk_kernel_body<2, 32>, 256>(tri_splitk_kernel<2, 32>, grid, dim3(256), 0, s, N, c, KS, T, ldt, B, ldb, work);
     else
-      MOE_LAUNCH((tri_splitk_kernel<2, 16>), grid, dim3(256), 0, s, N, c, KS, T, ldt, B, ldb, work);
-    MOE_LAUNCH(tri_splitk_sum_kernel<2>, sgrid, dim3(256), 0, s, N, c, KS, slices, (const double*)work, C, ldc);
+      launch_kernel_ens<tri_splitk_kernel_body<2, 16>, 256>(tri_splitk_kernel<2, 16>, grid, dim3(256), 0, s, N, c, KS, T, ldt, B, ldb, work);
+    launch_kernel_ens<tri_splitk_sum_kernel_body<2>, 256>(tri_splitk_sum_kernel<2>, sgrid, dim3(256), 0, s, N, c, KS, slices, (const double*)work, C, ldc);
   }
   MOE_HIP_CHECK(hipGetLastError());
 }

@@ -58,8 +58,8 @@ namespace {
 // member after member -- on ONE stream.  Returns false (nothing launched) when the recordings do not line up or too few positions
 // merge to be worth the members' concurrency on their own streams.
 struct EnsArena {
-  PinnedBuf<unsigned char> host;
-  DevBuf<unsigned char> dev;
+  PinnedBuf<unsigned char>& host;
+  DevBuf<unsigned char>& dev;
 };
 constexpr size_t kEnsCopyMaxBytes = (size_t)4 << 20;
 
@@ -232,7 +232,7 @@ void kg_mcmc_members(const std::vector<GpDev*>& gps, int num_fidelity, const moe
         }
     }
     if (ens) {
-      static thread_local EnsArena arena;
+      EnsArena arena{gps[0]->hEns, gps[0]->dEns};
       gps[0]->use_device();
       hipStream_t z = gps[0]->stream;
       int merged = 0;
