@@ -1547,6 +1547,9 @@ KgPending kg_launch(GpDev& gp, int num_fidelity, const moe_gd_params_t& gd, cons
   mp.E = E;
   mp.mean = gp.mean;
   mp.multi_trial = (far_frame || small_lane) ? 0 : env_int("MOE_KG_MULTI_TRIAL", 1);  // (0: A/B runs)
+  // r6: the small shapes on the lane-parked kernel take their Armijo trials several per sweep, too -- each trial computed exactly as
+  // a single-trial pass computes it (kg_mc.hpp eval_multi_exact: same bits as one trial per pass; MOE_KG_SMALL_MULTI=0: one per pass)
+  if (small_lane && !far_frame && variant == 0 && lane_kernel && dp == 4 && env_int("MOE_KG_SMALL_MULTI", 1) != 0) mp.multi_trial = 2;
   mp.XsTab = dTab.p;
   mp.tab_stride = tab_stride;
   mp.wide_lds_tiles = wide_lds_tiles;

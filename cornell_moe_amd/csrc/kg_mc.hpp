@@ -648,6 +648,82 @@ __device__ __forceinline__ bool eval_multi_loop_s(const double* __restrict__ xs,
   return true;
 }
 
+// T Armijo trials in one sweep with EVERY trial computed exactly as a single-trial value pass computes it (r6): q2_t = x2 + alpha_t d2
+// and |q_t|^2 formed per trial as eval_loop<..., Q2IN> forms them, r2 = (|x_j|^2 + |q_t|^2) then the DP fmas in row order, the tile
+// sums in tile order, one wave_sum_uniform per trial -- the bits of T separate passes (T DP fmas per point instead of the 2 DP + 2 T of
+// the line decomposition above: no dearer up to DP = 4 and T = 5), with one set of coordinate / weight loads and one decision round.
+// For the small shapes whose end points the reference's 100-step x 10-restart fixtures pin: there the line decomposition's rounding moved
+// them by 1.01e-6 (kg.hip), so until r6 those shapes ran one trial per pass.  LDS table only.  Returns false without evaluating when a
+// trial lies beyond kFarRadius (the single-trial pass returns the prior mean there: the caller falls back to it).
+template <int DP, int COV, int T, int G>
+__device__ __forceinline__ bool eval_multi_exact(const double* __restrict__ xs, const double* __restrict__ aw,
+                                                 const double* __restrict__ etab, int ntiles, double mean, const double (&x2)[DP],
+                                                 const double (&d2)[DP], double alpha0, int lane, double (&f)[T]) {
+  constexpr int WR = 1 + G;
+  constexpr int NX = DP + 1;
+  double al[T], qq[T], q2[T][DP], xq[T][G > 0 ? G : 1];
+  bool near_all = true;
+#pragma unroll
+  for (int t = 0; t < T; ++t) {
+    al[t] = (t == 0) ? alpha0 : 0.5 * al[t > 0 ? t - 1 : 0];
+    double ss = 0.0;
+#pragma unroll
+    for (int k = 0; k < DP; ++k) {
+      q2[t][k] = fma(al[t], d2[k], x2[k]);
+      ss = fma(q2[t][k], q2[t][k], ss);
+    }
+#pragma unroll
+    for (int a = 0; a < G; ++a) xq[t][a] = -0.5 * q2[t][a];
+    qq[t] = fma(ss, 0.25, 1.0e-300);
+    near_all = near_all && (uniform(qq[t]) <= kFarRadius * kFarRadius);
+  }
+  if (!near_all) return false;
+  double acc[T];
+#pragma unroll
+  for (int t = 0; t < T; ++t) acc[t] = 0.0;
+  lds_tile_ptr xt = (lds_tile_ptr)(xs + lane);
+  lds_tile_ptr wt = (lds_tile_ptr)(aw + lane);
+  double cx[NX], cw[WR];
+#pragma unroll
+  for (int k = 0; k < NX; ++k) cx[k] = xt[k * 64];
+#pragma unroll
+  for (int a = 0; a < WR; ++a) cw[a] = wt[a * 64];
+#pragma unroll 1
+  for (int tile = 0; tile < ntiles; ++tile) {
+    double nx[NX], nw[WR];
+    xt += NX * 64;  // (one tile of padding behind both arrays: see eval_loop)
+    wt += WR * 64;
+#pragma unroll
+    for (int k = 0; k < NX; ++k) nx[k] = xt[k * 64];
+#pragma unroll
+    for (int a = 0; a < WR; ++a) nw[a] = wt[a * 64];
+    const double w0 = cw[0];
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+      double r2 = cx[DP] + qq[t];
+#pragma unroll
+      for (int k = 0; k < DP; ++k) r2 = fma(cx[k], q2[t][k], r2);
+      r2 = fmax(r2, 1.0e-300);
+      double base, first, second;
+      radial3<COV, (G > 0), false>(r2, etab, base, first, second);
+      acc[t] = fma(w0, base, acc[t]);
+      if (G > 0) {
+        double sd = 0.0;
+#pragma unroll
+        for (int a = 0; a < G; ++a) sd = fma(cw[1 + a], cx[a] - xq[t][a], sd);
+        acc[t] = fma(first, sd, acc[t]);
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < NX; ++k) cx[k] = nx[k];
+#pragma unroll
+    for (int a = 0; a < WR; ++a) cw[a] = nw[a];
+  }
+#pragma unroll
+  for (int t = 0; t < T; ++t) f[t] = -(mean + wave_sum_uniform(acc[t]));
+  return true;
+}
+
 template <int DP, int COV, int T, bool SMALL, bool XL = true, int G = 0>
 __device__ __forceinline__ bool eval_multi_loop(const double* __restrict__ xs, const double* __restrict__ aw,
                                                 const double* __restrict__ etab, int ntiles, double mean, const double (&x2)[DP],

@@ -166,7 +166,9 @@ __device__ __forceinline__ double grad_pass_parked(const double* __restrict__ xs
 // One MC sample on the lane-parked line search.  xs = the workgroup's LDS coordinate table, aw = this wave's weight slab, zb = its
 // scratch (2 kMaxM doubles: z | beta during the set-up, then the line search's rows), cst = the lane constants, rc = the LDS copy of
 // the evaluation's record head [L | mu_disc | C_disc | disc] (offsets as in KgRec).
-template <int DP, int G>
+// EXACT (r6): the Armijo trials of a bracket in one sweep, each computed as a single-trial pass computes it (eval_multi_exact) -- the
+// instantiation of the small shapes (kg.hip: small_lane), whose passes were single-trial until then; same bits.
+template <int DP, int G, bool EXACT>
 __device__ __forceinline__ void kg_sample_lane(const KgMcParams& P, int e, int sl, const double* __restrict__ xs,
                                                double* __restrict__ aw, double* __restrict__ zb, const double* __restrict__ etab,
                                                const double* __restrict__ cst, const double* __restrict__ rc, int lane,
@@ -369,7 +371,7 @@ __device__ __forceinline__ void kg_sample_lane(const KgMcParams& P, int e, int s
           bool done = false;
           while (!done) {
             bool evaluated = false;
-            if (P.multi_trial != 0) {
+            if (EXACT || P.multi_trial != 0) {
               const int want = min(batch, 30 - search);
               if (want >= 2) {
                 const bool se = cov_type == MOE_COV_SQUARE_EXPONENTIAL;
@@ -378,10 +380,14 @@ __device__ __forceinline__ void kg_sample_lane(const KgMcParams& P, int e, int s
 #define MOE_LANE_TRIALS(T)                                                                                                              \
   {                                                                                                                                     \
     double ft[T];                                                                                                                       \
-    evaluated = se ? eval_multi_loop_s<DP, MOE_COV_SQUARE_EXPONENTIAL, T, false, true, G>(xs, aw, etab, ntiles, mean, x2, d2, sxx, sxd,  \
-                                                                                          sdd, alpha_n, lane, ft)                      \
-                   : eval_multi_loop_s<DP, MOE_COV_MATERN_NU_2P5, T, false, true, G>(xs, aw, etab, ntiles, mean, x2, d2, sxx, sxd, sdd,  \
-                                                                                     alpha_n, lane, ft);                               \
+    if constexpr (EXACT)                                                                                                                \
+      evaluated = se ? eval_multi_exact<DP, MOE_COV_SQUARE_EXPONENTIAL, T, G>(xs, aw, etab, ntiles, mean, x2, d2, alpha_n, lane, ft)    \
+                     : eval_multi_exact<DP, MOE_COV_MATERN_NU_2P5, T, G>(xs, aw, etab, ntiles, mean, x2, d2, alpha_n, lane, ft);        \
+    else                                                                                                                                \
+      evaluated = se ? eval_multi_loop_s<DP, MOE_COV_SQUARE_EXPONENTIAL, T, false, true, G>(xs, aw, etab, ntiles, mean, x2, d2, sxx,    \
+                                                                                            sxd, sdd, alpha_n, lane, ft)               \
+                     : eval_multi_loop_s<DP, MOE_COV_MATERN_NU_2P5, T, false, true, G>(xs, aw, etab, ntiles, mean, x2, d2, sxx, sxd,    \
+                                                                                       sdd, alpha_n, lane, ft);                        \
     if (evaluated) {                                                                                                                    \
       _Pragma("unroll") for (int t = 0; t < T; ++t) {                                                                                   \
         if (!done) {                                                                                                                    \
@@ -509,7 +515,7 @@ __device__ __forceinline__ void kg_sample_lane(const KgMcParams& P, int e, int s
 // (weights [ntiles (1 + G) 64] + 2 kMaxM doubles of scratch) | one weight tile of padding.  Built for the LDS coordinate table, 8 waves.
 // (r6: the body as a device function -- launch.hpp -- so that the members of a GP ensemble share one launch; `argbase`: where this
 //  member's arguments lie, the kernarg segment or its record in the ensemble twin's table)
-template <int DP, int G>
+template <int DP, int G, bool EXACT = false>
 struct kg_mc_lane_kernel_body {
 static __device__ __forceinline__ void run(const VIdx blockIdx, const VIdx gridDim, const void* argbase, const KgMcParams& P, int rec_head) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -560,7 +566,7 @@ static __device__ __forceinline__ void run(const VIdx blockIdx, const VIdx gridD
       // (P is the kernel's first argument: offset 0 of the segment)
       const __attribute__((address_space(4))) KgMcParams* Pk = (const __attribute__((address_space(4))) KgMcParams*)argbase;
       asm volatile("" : "+s"(Pk));
-      kg_sample_lane<DP, G>(*(const KgMcParams*)Pk, e, (int)sl, coords, aw, zb, smem, cst, rc, lane, tot_val, tot_grad);
+      kg_sample_lane<DP, G, EXACT>(*(const KgMcParams*)Pk, e, (int)sl, coords, aw, zb, smem, cst, rc, lane, tot_val, tot_grad);
     }
     if (lane == 0 && (tot_val | tot_grad) != 0) {
       atomicAdd(&P.counters[2 * e], (unsigned long long)tot_val);
@@ -570,9 +576,9 @@ static __device__ __forceinline__ void run(const VIdx blockIdx, const VIdx gridD
   }
 }
 };
-template <int DP, int G>
+template <int DP, int G, bool EXACT = false>
 __global__ __launch_bounds__(kLaneMaxThreads) void kg_mc_lane_kernel(KgMcParams P, int rec_head) {
-  kg_mc_lane_kernel_body<DP, G>::run(MOE_VBLOCK, MOE_VGRID, (const void*)__builtin_amdgcn_kernarg_segment_ptr(), P, rec_head);
+  kg_mc_lane_kernel_body<DP, G, EXACT>::run(MOE_VBLOCK, MOE_VGRID, (const void*)__builtin_amdgcn_kernarg_segment_ptr(), P, rec_head);
 }
 
 // LDS bytes of a workgroup of `waves` wavefronts (host side: kg.hip's geometry)
@@ -582,17 +588,31 @@ inline size_t lane_lds_bytes(int dp, int G, int ntiles, int rec_head, int waves)
   return sizeof(double) * (fixed + tab + (size_t)waves * ((size_t)ntiles * (1 + G) * 64 + 2 * kMaxM) + (size_t)(1 + G) * 64);
 }
 
-template <int DP, int G>
+template <int DP, int G, bool EXACT = false>
 inline void launch_lane_inst(const KgMcParams& P, int rec_head, int blocks, int waves, size_t shm, hipStream_t s) {
-  auto kern = kg_mc_lane_kernel<DP, G>;
+  auto kern = kg_mc_lane_kernel<DP, G, EXACT>;
   MOE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
-  launch_kernel_ens<kg_mc_lane_kernel_body<DP, G>, kLaneMaxThreads>(kern, dim3(blocks), dim3(waves * 64), shm, s, P, rec_head);
+  launch_kernel_ens<kg_mc_lane_kernel_body<DP, G, EXACT>, kLaneMaxThreads>(kern, dim3(blocks), dim3(waves * 64), shm, s, P, rec_head);
   MOE_HIP_CHECK(hipGetLastError());
 }
 
 template <int DP>
 inline void launch_lane_dp(const KgMcParams& P, int G, int rec_head, int blocks, int waves, size_t shm, hipStream_t s) {
   static_assert(DP <= kMaxLaneDP, "lane-parked line search: one scratch row holds kMaxLaneDP doubles");
+  if constexpr (DP == 4) {  // (the small shapes live here: padded dimension 4, one or two tiles -- kg.hip)
+    if (P.multi_trial == 2) {
+      switch (G) {
+        case 0: launch_lane_inst<DP, 0, true>(P, rec_head, blocks, waves, shm, s); break;
+        case 1: launch_lane_inst<DP, 1, true>(P, rec_head, blocks, waves, shm, s); break;
+        case 2: launch_lane_inst<DP, 2, true>(P, rec_head, blocks, waves, shm, s); break;
+        case 3: launch_lane_inst<DP, 3, true>(P, rec_head, blocks, waves, shm, s); break;
+        case 4: launch_lane_inst<DP, 4, true>(P, rec_head, blocks, waves, shm, s); break;
+        default: throw Error(MOE_ERR_RUNTIME, "unsupported derivative-slot count in the lane-parked MC kernel");
+      }
+      return;
+    }
+  }
+  if (P.multi_trial == 2) throw Error(MOE_ERR_RUNTIME, "exact multi-trial passes are built for the padded dimension 4 only");
   switch (G) {
     case 0: launch_lane_inst<DP, 0>(P, rec_head, blocks, waves, shm, s); break;
     case 1: launch_lane_inst<DP, 1>(P, rec_head, blocks, waves, shm, s); break;

@@ -169,6 +169,7 @@ void kg_mcmc_members(const std::vector<GpDev*>& gps, int num_fidelity, const moe
     // members are issued by host threads side by side (r5: 2.0 -> ms per optimiser step of 16 members x 20 restarts; MOE_MCMC_THREADS=1:
     // one after another, as in round 4).  Each member owns its stream, workspaces and staging buffers; results are collected in order.
     std::vector<KgPending> pending(gps.size());
+    const auto t_call = std::chrono::steady_clock::now();
     // r6: ensemble-wide launches -- the members' chains are RECORDED (same host threads), then replayed as one chain of launches over all
     // members on the first member's stream (replay_ensemble); recordings that do not line up are replayed per member on the members'
     // own streams, and a shape that did not merge twice is launched directly from then on.  MOE_ENS_LAUNCH=0: always direct.
@@ -231,13 +232,17 @@ void kg_mcmc_members(const std::vector<GpDev*>& gps, int num_fidelity, const moe
           throw errors[k];
         }
     }
+    const auto t_rec = std::chrono::steady_clock::now();
+    auto t_issue = t_rec, t_sync = t_rec;
     if (ens) {
       EnsArena arena{gps[0]->hEns, gps[0]->dEns};
       gps[0]->use_device();
       hipStream_t z = gps[0]->stream;
       int merged = 0;
       if (replay_ensemble(recs, z, arena, &merged)) {
+        t_issue = std::chrono::steady_clock::now();
         MOE_HIP_CHECK(hipStreamSynchronize(z));
+        t_sync = std::chrono::steady_clock::now();
         ens_misses[ens_key] = 0;
         g_ens_stats[0] += 1;
         g_ens_stats[2] += 1 + merged + ((long long)recs[0].ops.size() - merged) * (long long)gps.size();  // (1: the table's copy)
@@ -250,9 +255,13 @@ void kg_mcmc_members(const std::vector<GpDev*>& gps, int num_fidelity, const moe
           for (const LaunchOp& op : recs[i].ops) op.run(gps[i]->stream);
         }
       }
-      if (std::getenv("MOE_ENS_TRACE") != nullptr)
-        std::fprintf(stderr, "[moe ens] members %zu, ops %zu, merged positions %d, misses %d\n", gps.size(), recs[0].ops.size(), merged,
-                     ens_misses[ens_key]);
+      if (std::getenv("MOE_ENS_TRACE") != nullptr) {
+        auto us = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
+          return std::chrono::duration<double, std::micro>(b - a).count();
+        };
+        std::fprintf(stderr, "[moe ens] members %zu, ops %zu, merged positions %d, misses %d; us: record %.0f, zip + issue %.0f, wait %.0f\n",
+                     gps.size(), recs[0].ops.size(), merged, ens_misses[ens_key], us(t_call, t_rec), us(t_rec, t_issue), us(t_issue, t_sync));
+      }
     }
     for (size_t i = 0; i < gps.size(); ++i) {
       pending[i].collect(ks.data(), want_grad ? gs.data() : nullptr, nullptr, nullptr);

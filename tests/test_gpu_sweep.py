@@ -500,3 +500,39 @@ def test_small_shape_kernels_agree(case, monkeypatch):
     assert a["kg_sum"] == b["kg_sum"] and np.array_equal(a["grad_sum"], b["grad_sum"])
     assert np.array_equal(a["best_point"], b["best_point"])
     assert a["grad_evals"] == b["grad_evals"] and a["mean_evals"] == b["mean_evals"]
+
+
+@pytest.mark.parametrize("case", [CASES[i] for i in (0, 1, 2, 11, 12, 15, 16, 17)], ids=lambda c: str(c[0]))
+def test_small_shape_exact_multi_trial_passes_agree(case, monkeypatch):
+    """r6: the small shapes on the lane-parked kernel take several Armijo trials per sweep, each computed exactly as a single-trial pass
+    computes it (kg_mc.hpp eval_multi_exact) -- against one trial per pass (MOE_KG_SMALL_MULTI=0, the r5 form): sums, end points and
+    pass counters bit for bit, with the tensor-product and the simplex inner domain."""
+    from cornell_moe_amd import api
+    w, cov, f, gd = _mk(case)
+    G = api.DeviceGP(w.hyperparameters, w.X, w.y, w.noise, w.derivs, cov_type=cov)
+    full = np.hstack([w.discrete, np.ones((w.discrete.shape[0], f))])
+    best = float(G.additional_mean(full).min())
+    Xp = w.Xp if w.p else None
+    monkeypatch.setenv("MOE_KG_VARIANT", "0")
+    monkeypatch.setenv("MOE_KG_SMALL_LANE_MAX_SAMPLES", "8192")
+    for domain in (0, 1):
+        if domain == 1 and w.d - f < 2:
+            continue
+        gdd = tuple(gd[:8]) + (domain,)
+        res = {}
+        for multi in ("1", "0"):
+            monkeypatch.setenv("MOE_KG_SMALL_MULTI", multi)
+            try:
+                res[multi] = G.kg(gdd, w.bounds_inner, w.discrete, w.Xq, Xp, w.M, best, w.kg_normals, num_fidelity=f, want_best_points=True)
+            except api.OptimalLearningException as e:
+                assert domain == 1 and "EMPTY" in str(e)   # (a box outside the simplex: the reference's exception, either way)
+                res = None
+                break
+            info = G.last_kernel_info()
+            assert info["variant"] == 0 and info["lane"] == 1, info
+        if res is None:
+            continue
+        a, b = res["1"], res["0"]
+        assert a["kg_sum"] == b["kg_sum"] and np.array_equal(a["grad_sum"], b["grad_sum"]), domain
+        assert np.array_equal(a["best_point"], b["best_point"]), domain
+        assert a["grad_evals"] == b["grad_evals"] and a["mean_evals"] == b["mean_evals"], domain
