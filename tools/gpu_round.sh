@@ -20,7 +20,7 @@ timeout 300 python bench.py --config suggest_c3 --no-cpu-baseline 2> /dev/null >
 timeout 200 python tools/chol_time.py 3 12 2>&1 | grep "two-level" > gpurun_out/${TAG}_chol_time.txt
 # the randomised parity sweep against the unmodified reference under the r6 rule (an end point off by > 1e-8 only where the two CPU codes
 # themselves disagree): three seeds, and one on a poisoned pool
-{ timeout 900 python tools/fuzz_parity.py 150 606 300 16 4 | tail -3; timeout 900 python tools/fuzz_parity.py 150 607 700 32 12 | tail -3; MOE_POOL_POISON=1 timeout 900 python tools/fuzz_parity.py 100 608 300 16 4 | tail -3; } > gpurun_out/${TAG}_fuzz.txt 2>&1; tail -3 gpurun_out/${TAG}_fuzz.txt
+{ timeout 900 python tools/fuzz_parity.py 150 606 300 16 4 | tail -3; timeout 1500 python tools/fuzz_parity.py 60 607 700 32 12 | tail -3; timeout 600 python tools/fuzz_ensemble.py 80 2026 400 | tail -3; MOE_POOL_POISON=1 timeout 900 python tools/fuzz_parity.py 100 608 300 16 4 | tail -3; } > gpurun_out/${TAG}_fuzz.txt 2>&1; tail -3 gpurun_out/${TAG}_fuzz.txt
 cd /tmp
 rm -rf /tmp/prof_${TAG}
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_${TAG} -o kg -- python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-traffic --no-extras --no-batch1 --no-determinism > $R/gpurun_out/${TAG}_bench_under_rocprof.json 2> /dev/null
