@@ -80,55 +80,61 @@ __global__ __launch_bounds__(kCovRows) void cov_build_kernel(CovParams cp, const
 // come from the same cov_entry as before (bit-identical values); a wavefront's 64 (1 + gA) rows of one output column are
 // contiguous in memory, so they are transposed through a per-wave LDS stage and stored as full 512-byte runs.
 template <int DP>
+struct cov_build_points_kernel_body {
+  static __device__ __forceinline__ void run(const VIdx blockIdx, const VIdx gridDim, const void*, const CovParams& cp, const double* __restrict__ A, int nA, const DerivList& dA, const double* __restrict__ B, int nB, const DerivList& dB, const double* __restrict__ diag_noise, double* __restrict__ out, long ld, long col0, int lower_only, int cols_per_wg) {
+    __shared__ double Bs[kCovCols][DP];
+    __shared__ double stage_all[4][64 * (1 + kMaxDerivs)];
+    const int gA = dA.g, gB = dB.g, a1 = 1 + gA;
+    const int j0 = blockIdx.x * cols_per_wg;
+    const int nj = min(cols_per_wg, nB - j0);
+    if (lower_only && ((long)blockIdx.y * 256 + 256) * a1 - 1 < (long)j0 * (1 + gB)) return;  // (see cov_build_kernel)
+    for (int t = threadIdx.x; t < nj * DP; t += blockDim.x) Bs[t / DP][t % DP] = B[(long)(j0 + t / DP) * DP + (t % DP)];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    volatile __attribute__((address_space(3))) double* stage =
+        (volatile __attribute__((address_space(3))) double*)&stage_all[wave][0];
+    const int p0 = blockIdx.y * 256 + wave * 64;  // first A point of this wavefront
+    if (p0 >= nA) return;
+    const int i = min(p0 + lane, nA - 1);  // (lanes beyond nA recompute the last point; their rows are not stored)
+    const long row0 = (long)p0 * a1;       // first output row of this wavefront
+    const long rows = (long)nA * a1;
+    double xi[DP];
+  #pragma unroll
+    for (int k = 0; k < DP; ++k) xi[k] = A[(long)i * DP + k];
+    for (int jj = 0; jj < nj; ++jj) {
+      double diff[DP];
+      double r2 = 0.0;
+  #pragma unroll
+      for (int k = 0; k < DP; ++k) {
+        diff[k] = xi[k] - Bs[jj][k];
+        r2 = fma(diff[k] * diff[k], cp.inv_l2[k], r2);
+      }
+      const Radial rd = radial_scalars(cp.type, cp.alpha, r2);
+      for (int b = 0; b <= gB; ++b) {
+        const long colrel = (long)(j0 + jj) * (1 + gB) + b;
+        if (lower_only && row0 + 64 * a1 - 1 < colrel) continue;  // this wavefront's rows all lie above the diagonal in this column
+        for (int a = 0; a <= gA; ++a) {
+          double v = cov_entry<DP>(cp, rd, diff, a, b, dA, dB);
+          if (diag_noise != nullptr && (long)i * a1 + a == colrel) v += diag_noise[a];
+          stage[lane * a1 + a] = v;
+        }
+        // (LDS operations of one wavefront complete in order: the reads below see the writes above)
+        double* dst = out + (col0 + colrel) * ld + row0;
+        for (int t = 0; t <= gA; ++t) {
+          const int rr = lane + 64 * t;
+          const double v = stage[rr];
+          if (row0 + rr < rows && (!lower_only || row0 + rr >= colrel)) dst[rr] = v;
+        }
+      }
+    }
+  }
+};
+template <int DP>
 __global__ __launch_bounds__(256) void cov_build_points_kernel(CovParams cp, const double* __restrict__ A, int nA, DerivList dA,
                                                               const double* __restrict__ B, int nB, DerivList dB,
                                                               const double* __restrict__ diag_noise, double* __restrict__ out,
                                                               long ld, long col0, int lower_only, int cols_per_wg) {
-  __shared__ double Bs[kCovCols][DP];
-  __shared__ double stage_all[4][64 * (1 + kMaxDerivs)];
-  const int gA = dA.g, gB = dB.g, a1 = 1 + gA;
-  const int j0 = blockIdx.x * cols_per_wg;
-  const int nj = min(cols_per_wg, nB - j0);
-  if (lower_only && ((long)blockIdx.y * 256 + 256) * a1 - 1 < (long)j0 * (1 + gB)) return;  // (see cov_build_kernel)
-  for (int t = threadIdx.x; t < nj * DP; t += blockDim.x) Bs[t / DP][t % DP] = B[(long)(j0 + t / DP) * DP + (t % DP)];
-  __syncthreads();
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  volatile __attribute__((address_space(3))) double* stage =
-      (volatile __attribute__((address_space(3))) double*)&stage_all[wave][0];
-  const int p0 = blockIdx.y * 256 + wave * 64;  // first A point of this wavefront
-  if (p0 >= nA) return;
-  const int i = min(p0 + lane, nA - 1);  // (lanes beyond nA recompute the last point; their rows are not stored)
-  const long row0 = (long)p0 * a1;       // first output row of this wavefront
-  const long rows = (long)nA * a1;
-  double xi[DP];
-#pragma unroll
-  for (int k = 0; k < DP; ++k) xi[k] = A[(long)i * DP + k];
-  for (int jj = 0; jj < nj; ++jj) {
-    double diff[DP];
-    double r2 = 0.0;
-#pragma unroll
-    for (int k = 0; k < DP; ++k) {
-      diff[k] = xi[k] - Bs[jj][k];
-      r2 = fma(diff[k] * diff[k], cp.inv_l2[k], r2);
-    }
-    const Radial rd = radial_scalars(cp.type, cp.alpha, r2);
-    for (int b = 0; b <= gB; ++b) {
-      const long colrel = (long)(j0 + jj) * (1 + gB) + b;
-      if (lower_only && row0 + 64 * a1 - 1 < colrel) continue;  // this wavefront's rows all lie above the diagonal in this column
-      for (int a = 0; a <= gA; ++a) {
-        double v = cov_entry<DP>(cp, rd, diff, a, b, dA, dB);
-        if (diag_noise != nullptr && (long)i * a1 + a == colrel) v += diag_noise[a];
-        stage[lane * a1 + a] = v;
-      }
-      // (LDS operations of one wavefront complete in order: the reads below see the writes above)
-      double* dst = out + (col0 + colrel) * ld + row0;
-      for (int t = 0; t <= gA; ++t) {
-        const int rr = lane + 64 * t;
-        const double v = stage[rr];
-        if (row0 + rr < rows && (!lower_only || row0 + rr >= colrel)) dst[rr] = v;
-      }
-    }
-  }
+  cov_build_points_kernel_body<DP>::run(MOE_VBLOCK, MOE_VGRID, nullptr, cp, A, nA, dA, B, nB, dB, diag_noise, out, ld, col0, lower_only, cols_per_wg);
 }
 
 // Value-only blocks (no derivative observations on either side -- K(X, X) of a q-KG GP, K*, the N x M gradient-tail matrix):
@@ -140,54 +146,60 @@ __global__ __launch_bounds__(256) void cov_build_points_kernel(CovParams cp, con
 //   * exp through the 64-entry table of fastmath.hpp (10 FP64 + 3 integer instructions, <= 1.5 ulp) instead of the degree-11
 //     polynomial (17), sqrt without the clamp (the accumulation starts from 1e-300).
 template <int DP>
+struct cov_build_value_kernel_body {
+  static __device__ __forceinline__ void run(const VIdx blockIdx, const VIdx gridDim, const void*, const CovParams& cp, const double* __restrict__ A, int nA, const double* __restrict__ B, int nB, const double* __restrict__ diag_noise, double* __restrict__ out, long ld, long col0) {
+    __shared__ double Bs[kCovCols][DP];
+    __shared__ double etab[64];
+    const bool matern = cp.type == MOE_COV_MATERN_NU_2P5;
+    const double s5 = matern ? 2.236067977499789696409173668731276235 : 1.0;
+    const int j0 = blockIdx.x * kCovCols;
+    const int nj = min(kCovCols, nB - j0);
+    if (threadIdx.x < 64) etab[threadIdx.x] = kExp2Tab64[threadIdx.x];
+    for (int t = threadIdx.x; t < nj * DP; t += blockDim.x) {
+      const int k = t % DP;
+      Bs[t / DP][k] = (B[(long)(j0 + t / DP) * DP + k] - cp.center[k]) * (cp.inv_l[k] * s5);
+    }
+    __syncthreads();
+    const int r = blockIdx.y * kCovRows + threadIdx.x;
+    if (r >= nA) return;
+    double xi[DP];
+  #pragma unroll
+    for (int k = 0; k < DP; ++k) xi[k] = (A[(long)r * DP + k] - cp.center[k]) * (cp.inv_l[k] * s5);
+    const double noise = diag_noise != nullptr ? diag_noise[0] : 0.0;
+    // two columns per iteration: two independent distance / sqrt / exp chains in flight per thread
+    for (int jj = 0; jj < nj; jj += 2) {
+      const int j1 = min(jj + 1, nj - 1);
+      double ra = 1.0e-300, rb = 1.0e-300;
+  #pragma unroll
+      for (int k = 0; k < DP; ++k) {
+        const double da = xi[k] - Bs[jj][k], db = xi[k] - Bs[j1][k];
+        ra = fma(da, da, ra);
+        rb = fma(db, db, rb);
+      }
+      double va, vb;
+      if (matern) {
+        const double aa = sqrt_pos(ra), ab = sqrt_pos(rb);  // = sqrt(5) r
+        va = (cp.alpha * exp_nonpos_tab(-aa, etab)) * fma(aa, fma(aa, 1.0 / 3.0, 1.0), 1.0);
+        vb = (cp.alpha * exp_nonpos_tab(-ab, etab)) * fma(ab, fma(ab, 1.0 / 3.0, 1.0), 1.0);
+      } else {
+        va = cp.alpha * exp_nonpos_tab(fmax(-0.5 * ra, -1000.0), etab);
+        vb = cp.alpha * exp_nonpos_tab(fmax(-0.5 * rb, -1000.0), etab);
+      }
+      const long col = col0 + j0 + jj;
+      if (diag_noise != nullptr && (long)r == col - col0) va += noise;
+      if (diag_noise != nullptr && (long)r == col + 1 - col0) vb += noise;
+      // (streaming stores: the matrix is written once and read by a later kernel, nothing of it is reused from L2 here)
+      __builtin_nontemporal_store(va, &out[(long)r + col * ld]);
+      if (jj + 1 < nj) __builtin_nontemporal_store(vb, &out[(long)r + (col + 1) * ld]);
+    }
+  }
+};
+template <int DP>
 __global__ __launch_bounds__(kCovRows) void cov_build_value_kernel(CovParams cp, const double* __restrict__ A, int nA,
                                                                   const double* __restrict__ B, int nB,
                                                                   const double* __restrict__ diag_noise,
                                                                   double* __restrict__ out, long ld, long col0) {
-  __shared__ double Bs[kCovCols][DP];
-  __shared__ double etab[64];
-  const bool matern = cp.type == MOE_COV_MATERN_NU_2P5;
-  const double s5 = matern ? 2.236067977499789696409173668731276235 : 1.0;
-  const int j0 = blockIdx.x * kCovCols;
-  const int nj = min(kCovCols, nB - j0);
-  if (threadIdx.x < 64) etab[threadIdx.x] = kExp2Tab64[threadIdx.x];
-  for (int t = threadIdx.x; t < nj * DP; t += blockDim.x) {
-    const int k = t % DP;
-    Bs[t / DP][k] = (B[(long)(j0 + t / DP) * DP + k] - cp.center[k]) * (cp.inv_l[k] * s5);
-  }
-  __syncthreads();
-  const int r = blockIdx.y * kCovRows + threadIdx.x;
-  if (r >= nA) return;
-  double xi[DP];
-#pragma unroll
-  for (int k = 0; k < DP; ++k) xi[k] = (A[(long)r * DP + k] - cp.center[k]) * (cp.inv_l[k] * s5);
-  const double noise = diag_noise != nullptr ? diag_noise[0] : 0.0;
-  // two columns per iteration: two independent distance / sqrt / exp chains in flight per thread
-  for (int jj = 0; jj < nj; jj += 2) {
-    const int j1 = min(jj + 1, nj - 1);
-    double ra = 1.0e-300, rb = 1.0e-300;
-#pragma unroll
-    for (int k = 0; k < DP; ++k) {
-      const double da = xi[k] - Bs[jj][k], db = xi[k] - Bs[j1][k];
-      ra = fma(da, da, ra);
-      rb = fma(db, db, rb);
-    }
-    double va, vb;
-    if (matern) {
-      const double aa = sqrt_pos(ra), ab = sqrt_pos(rb);  // = sqrt(5) r
-      va = (cp.alpha * exp_nonpos_tab(-aa, etab)) * fma(aa, fma(aa, 1.0 / 3.0, 1.0), 1.0);
-      vb = (cp.alpha * exp_nonpos_tab(-ab, etab)) * fma(ab, fma(ab, 1.0 / 3.0, 1.0), 1.0);
-    } else {
-      va = cp.alpha * exp_nonpos_tab(fmax(-0.5 * ra, -1000.0), etab);
-      vb = cp.alpha * exp_nonpos_tab(fmax(-0.5 * rb, -1000.0), etab);
-    }
-    const long col = col0 + j0 + jj;
-    if (diag_noise != nullptr && (long)r == col - col0) va += noise;
-    if (diag_noise != nullptr && (long)r == col + 1 - col0) vb += noise;
-    // (streaming stores: the matrix is written once and read by a later kernel, nothing of it is reused from L2 here)
-    __builtin_nontemporal_store(va, &out[(long)r + col * ld]);
-    if (jj + 1 < nj) __builtin_nontemporal_store(vb, &out[(long)r + (col + 1) * ld]);
-  }
+  cov_build_value_kernel_body<DP>::run(MOE_VBLOCK, MOE_VGRID, nullptr, cp, A, nA, B, nB, diag_noise, out, ld, col0);
 }
 
 // d cov(P_i, X_j)[m, n] / d P_{i,dd}: one thread per training row (j, n); P staged in LDS.
@@ -326,12 +338,12 @@ void cov_build_dp(const CovParams& cp, const double* A, int nA, const DerivList&
   if (grid.x == 0 || grid.y == 0) return;
   if (dA.g > 0 && value_fast_path()) {  // thread per point, rows transposed through LDS (MOE_COV_FAST=0: the row-per-thread kernel)
     dim3 pgrid(grid.x, (nA + 255) / 256);
-    MOE_LAUNCH((cov_build_points_kernel<DP>), pgrid, dim3(256), 0, s, cp, A, nA, dA, B, nB, dB, diag_noise, out, ld, col0, lo, cpw);
+    launch_kernel_ens<cov_build_points_kernel_body<DP>, 256>(cov_build_points_kernel<DP>, pgrid, dim3(256), 0, s, cp, A, nA, dA, B, nB, dB, diag_noise, out, ld, col0, lo, cpw);
   } else if (derivs)
     launch_kernel_ens<cov_build_kernel_body<DP, true>, kCovRows>(cov_build_kernel<DP, true>, grid, dim3(kCovRows), 0, s, cp, A, nA, dA, B, nB, dB,
                                                                  diag_noise, out, ld, col0, lo, cpw, 0x7fffffff, 0L);
   else if (streaming && value_fast_path() && !lower_only)
-    MOE_LAUNCH((cov_build_value_kernel<DP>), grid, dim3(kCovRows), 0, s, cp, A, nA, B, nB, diag_noise, out, ld, col0);
+    launch_kernel_ens<cov_build_value_kernel_body<DP>, kCovRows>(cov_build_value_kernel<DP>, grid, dim3(kCovRows), 0, s, cp, A, nA, B, nB, diag_noise, out, ld, col0);
   else
     launch_kernel_ens<cov_build_kernel_body<DP, false>, kCovRows>(cov_build_kernel<DP, false>, grid, dim3(kCovRows), 0, s, cp, A, nA, dA, B, nB,
                                                                   dB, diag_noise, out, ld, col0, lo, cpw, 0x7fffffff, 0L);

@@ -138,171 +138,193 @@ constexpr int kSwChunk = 64;  // samples per workgroup (16 per wavefront); 16 wh
 
 // SLOTS = 2: components lane and lane + 64 (m up to 128; S_W always precomputed there).
 template <int DP, int MU, int SLOTS = 1>
-__global__ __launch_bounds__(256) void kg_sw_kernel(KgTailParams P) {
-  extern __shared__ __attribute__((aligned(16))) double Ws[];  // [m][N] when P.SW == nullptr
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int e = blockIdx.y;
-  const int m = P.m, g1 = 1 + P.g, N = P.N;
-  const double* rec = P.blob + (long)e * P.rec.stride;
-  const double* Lsm = rec + P.rec.L;
-  if (P.SW == nullptr) {
-    const double* We = P.W + (long)e * P.w_stride;
-    for (int t = threadIdx.x; t < N * m; t += 256) Ws[t] = We[t];  // W_e is [N x m] col-major == [c][row]
-    __syncthreads();
-  }
-  const int i1 = min(P.num_local, (int)(blockIdx.x + 1) * P.sw_chunk);
-  for (int i = blockIdx.x * P.sw_chunk + wave; i < i1; i += 4) {
-    const long w = (long)e * P.num_local + i;
-    double mine[SLOTS];
-#pragma unroll
-    for (int sl = 0; sl < SLOTS; ++sl) mine[sl] = 0.0;
-    if (P.SW != nullptr) {
-#pragma unroll
-      for (int sl = 0; sl < SLOTS; ++sl)
-        if (lane + 64 * sl < m) mine[sl] = P.SW[w * m + lane + 64 * sl];
-    } else {
-      const double* Tc = P.T + w * N;
-      double acc[MU];
-#pragma unroll
-      for (int c = 0; c < MU; ++c) acc[c] = 0.0;
-#pragma unroll 4
-      for (int row = lane; row < N; row += 64) {
-        const double t = Tc[row];
-#pragma unroll
-        for (int c = 0; c < MU; ++c)
-          if (c < m) acc[c] = fma(Ws[c * N + row], t, acc[c]);
-      }
-#pragma unroll
-      for (int c = 0; c < MU; ++c) {
-        const double v = wave_sum64(acc[c]);
-        if (lane == c) mine[0] = v;
-      }
+struct kg_sw_kernel_body {
+  static __device__ __forceinline__ void run(const VIdx blockIdx, const VIdx gridDim, const void*, const KgTailParams& P) {
+    extern __shared__ __attribute__((aligned(16))) double Ws[];  // [m][N] when P.SW == nullptr
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int e = blockIdx.y;
+    const int m = P.m, g1 = 1 + P.g, N = P.N;
+    const double* rec = P.blob + (long)e * P.rec.stride;
+    const double* Lsm = rec + P.rec.L;
+    if (P.SW == nullptr) {
+      const double* We = P.W + (long)e * P.w_stride;
+      for (int t = threadIdx.x; t < N * m; t += 256) Ws[t] = We[t];  // W_e is [N x m] col-major == [c][row]
+      __syncthreads();
     }
-    double R[SLOTS], cv[SLOTS];
-#pragma unroll
-    for (int sl = 0; sl < SLOTS; ++sl) {
-      R[sl] = 0.0;
-      cv[sl] = 0.0;
-      const int comp = lane + 64 * sl;
-      if (comp < m) {
-        const int r = comp / g1, b = comp - r * g1;
-        const double* Xu = rec + P.rec.XuP + (long)r * DP;
-        const double* xs = P.best_point + w * DP;
-        double diff[DP];
-        double r2 = 0.0;
-#pragma unroll
-        for (int k = 0; k < DP; ++k) {
-          diff[k] = Xu[k] - xs[k];
-          r2 = fma(diff[k] * diff[k], P.cp.inv_l2[k], r2);
+    const int i1 = min(P.num_local, (int)(blockIdx.x + 1) * P.sw_chunk);
+    for (int i = blockIdx.x * P.sw_chunk + wave; i < i1; i += 4) {
+      const long w = (long)e * P.num_local + i;
+      double mine[SLOTS];
+  #pragma unroll
+      for (int sl = 0; sl < SLOTS; ++sl) mine[sl] = 0.0;
+      if (P.SW != nullptr) {
+  #pragma unroll
+        for (int sl = 0; sl < SLOTS; ++sl)
+          if (lane + 64 * sl < m) mine[sl] = P.SW[w * m + lane + 64 * sl];
+      } else {
+        const double* Tc = P.T + w * N;
+        double acc[MU];
+  #pragma unroll
+        for (int c = 0; c < MU; ++c) acc[c] = 0.0;
+  #pragma unroll 4
+        for (int row = lane; row < N; row += 64) {
+          const double t = Tc[row];
+  #pragma unroll
+          for (int c = 0; c < MU; ++c)
+            if (c < m) acc[c] = fma(Ws[c * N + row], t, acc[c]);
         }
-        const Radial rd = radial_scalars(P.cp.type, P.cp.alpha, r2);
-        DerivList none;
-        none.g = 0;
-        R[sl] = cov_entry<DP>(P.cp, rd, diff, b, 0, P.derivs, none) - mine[sl];
+  #pragma unroll
+        for (int c = 0; c < MU; ++c) {
+          const double v = wave_sum64(acc[c]);
+          if (lane == c) mine[0] = v;
+        }
       }
-    }
-    for (int r = 0; r < m; ++r) {
-      double part = 0.0;
-#pragma unroll
+      double R[SLOTS], cv[SLOTS];
+  #pragma unroll
+      for (int sl = 0; sl < SLOTS; ++sl) {
+        R[sl] = 0.0;
+        cv[sl] = 0.0;
+        const int comp = lane + 64 * sl;
+        if (comp < m) {
+          const int r = comp / g1, b = comp - r * g1;
+          const double* Xu = rec + P.rec.XuP + (long)r * DP;
+          const double* xs = P.best_point + w * DP;
+          double diff[DP];
+          double r2 = 0.0;
+  #pragma unroll
+          for (int k = 0; k < DP; ++k) {
+            diff[k] = Xu[k] - xs[k];
+            r2 = fma(diff[k] * diff[k], P.cp.inv_l2[k], r2);
+          }
+          const Radial rd = radial_scalars(P.cp.type, P.cp.alpha, r2);
+          DerivList none;
+          none.g = 0;
+          R[sl] = cov_entry<DP>(P.cp, rd, diff, b, 0, P.derivs, none) - mine[sl];
+        }
+      }
+      for (int r = 0; r < m; ++r) {
+        double part = 0.0;
+  #pragma unroll
+        for (int sl = 0; sl < SLOTS; ++sl)
+          if (lane + 64 * sl < r) part = fma(Lsm[r + (long)(lane + 64 * sl) * m], cv[sl], part);
+        const double tot = wave_sum64(part);
+  #pragma unroll
+        for (int sl = 0; sl < SLOTS; ++sl)
+          if (lane + 64 * sl == r) cv[sl] = (R[sl] - tot) / Lsm[r + (long)r * m];
+      }
+  #pragma unroll
       for (int sl = 0; sl < SLOTS; ++sl)
-        if (lane + 64 * sl < r) part = fma(Lsm[r + (long)(lane + 64 * sl) * m], cv[sl], part);
-      const double tot = wave_sum64(part);
-#pragma unroll
-      for (int sl = 0; sl < SLOTS; ++sl)
-        if (lane + 64 * sl == r) cv[sl] = (R[sl] - tot) / Lsm[r + (long)r * m];
+        if (lane + 64 * sl < m) P.C[w * m + lane + 64 * sl] = cv[sl];
     }
-#pragma unroll
-    for (int sl = 0; sl < SLOTS; ++sl)
-      if (lane + 64 * sl < m) P.C[w * m + lane + 64 * sl] = cv[sl];
   }
+};
+template <int DP, int MU, int SLOTS = 1>
+__global__ __launch_bounds__(256) void kg_sw_kernel(KgTailParams P) {
+  kg_sw_kernel_body<DP, MU, SLOTS>::run(MOE_VBLOCK, MOE_VGRID, nullptr, P);
 }
 
 // TBpart[e][chunk][c][row] = sum over the chunk's samples of T[row, i] beta_i[c]   (thread = row; T read coalesced, the
 // beta row is wave-uniform).
 template <int MU>
-__global__ __launch_bounds__(256) void kg_tb_kernel(KgTailParams P, int c_lo = 0) {  // columns [c_lo, c_lo + MU) of beta / TB
-  const int row = blockIdx.x * 256 + threadIdx.x;
-  const int chunk = blockIdx.y, e = blockIdx.z;
-  const int m = P.m;
-  const int i0 = chunk * P.chunk_len, i1 = min(P.num_local, i0 + P.chunk_len);
-  double acc[MU];
-#pragma unroll
-  for (int c = 0; c < MU; ++c) acc[c] = 0.0;
-  const bool ok = row < P.N;
-  const double* __restrict__ Tcol = P.T + (ok ? row : 0);
-  const double* __restrict__ beta = P.beta;
-#pragma unroll 4
-  for (int i = i0; i < i1; ++i) {
-    const long w = (long)e * P.num_local + i;
-    const double t = Tcol[w * P.N];
-    const double* __restrict__ b = beta + w * m + c_lo;
-    // all MU entries unconditionally (uniform, contiguous: wide scalar loads, no branch per entry); the entries beyond m
-    // belong to the next sample / the pad behind the buffer and only feed accumulators that are never stored
-#pragma unroll
-    for (int c = 0; c < MU; ++c) acc[c] = fma(t, b[c], acc[c]);
+struct kg_tb_kernel_body {
+  static __device__ __forceinline__ void run(const VIdx blockIdx, const VIdx gridDim, const void*, const KgTailParams& P, int c_lo) {    // columns [c_lo, c_lo + MU) of beta / TB
+    const int row = blockIdx.x * 256 + threadIdx.x;
+    const int chunk = blockIdx.y, e = blockIdx.z;
+    const int m = P.m;
+    const int i0 = chunk * P.chunk_len, i1 = min(P.num_local, i0 + P.chunk_len);
+    double acc[MU];
+  #pragma unroll
+    for (int c = 0; c < MU; ++c) acc[c] = 0.0;
+    const bool ok = row < P.N;
+    const double* __restrict__ Tcol = P.T + (ok ? row : 0);
+    const double* __restrict__ beta = P.beta;
+  #pragma unroll 4
+    for (int i = i0; i < i1; ++i) {
+      const long w = (long)e * P.num_local + i;
+      const double t = Tcol[w * P.N];
+      const double* __restrict__ b = beta + w * m + c_lo;
+      // all MU entries unconditionally (uniform, contiguous: wide scalar loads, no branch per entry); the entries beyond m
+      // belong to the next sample / the pad behind the buffer and only feed accumulators that are never stored
+  #pragma unroll
+      for (int c = 0; c < MU; ++c) acc[c] = fma(t, b[c], acc[c]);
+    }
+    if (ok) {
+      double* dst = P.TBpart + ((long)e * P.chunks + chunk) * m * P.N;
+  #pragma unroll
+      for (int c = 0; c < MU; ++c)
+        if (c_lo + c < m) dst[(long)(c_lo + c) * P.N + row] = acc[c];
+    }
   }
-  if (ok) {
-    double* dst = P.TBpart + ((long)e * P.chunks + chunk) * m * P.N;
-#pragma unroll
-    for (int c = 0; c < MU; ++c)
-      if (c_lo + c < m) dst[(long)(c_lo + c) * P.N + row] = acc[c];
-  }
+};
+template <int MU>
+__global__ __launch_bounds__(256) void kg_tb_kernel(KgTailParams P, int c_lo = 0) {
+  kg_tb_kernel_body<MU>::run(MOE_VBLOCK, MOE_VGRID, nullptr, P, c_lo);
 }
 
 // The same partial sums for m > 64 (r4; the stretch point's m = 104) as a product on the matrix pipe: TBpart[e][chunk] (N x m) =
 // T_e[:, chunk] (N x len) beta_e[chunk, :] (len x m) through gemm128.hpp's tile core -- one pass over T instead of one per 64 columns
 // of beta, chunks of kTbChunkWide samples (ten partials instead of 79 at M = 20 000).  Grid (row tiles of 128, chunks, E).
+struct kg_tb128_kernel_body {
+  static __device__ __forceinline__ void run(const VIdx blockIdx, const VIdx gridDim, const void*, const KgTailParams& P) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int chunk = blockIdx.y, e = blockIdx.z, m = P.m;
+    const int i0 = chunk * P.chunk_len, len = min(P.num_local - i0, P.chunk_len);
+    const long w0 = (long)e * P.num_local + i0;
+    g128::Operand A{P.T + w0 * P.N, (long)P.N, P.N, len, 1};     // T[row + sample N]: rows contiguous
+    g128::Operand B{P.beta + w0 * m, (long)m, m, len, 1};        // beta[sample m + c]: the output column contiguous
+    g128::f64x4 acc[4][4];
+    const int r0 = blockIdx.x * g128::TM;
+    g128::tile_product<false, false>(A, B, r0, 0, 0, len, smem, acc);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wi = (wave & 1) * 64, wj = (wave >> 1) * 64;
+    const int lk = lane >> 4, lx = lane & 15;
+    double* dst = P.TBpart + ((long)e * P.chunks + chunk) * m * P.N;
+  #pragma unroll
+    for (int a = 0; a < 4; ++a)
+  #pragma unroll
+      for (int b = 0; b < 4; ++b)
+  #pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = r0 + wi + 16 * a + lx, c = wj + 16 * b + lk + 4 * r;
+          if (row < P.N && c < m) dst[(long)c * P.N + row] = acc[a][b][r];
+        }
+  }
+};
 __global__ __launch_bounds__(256, 2) void kg_tb128_kernel(KgTailParams P) {
-  extern __shared__ __attribute__((aligned(16))) double smem[];
-  const int chunk = blockIdx.y, e = blockIdx.z, m = P.m;
-  const int i0 = chunk * P.chunk_len, len = min(P.num_local - i0, P.chunk_len);
-  const long w0 = (long)e * P.num_local + i0;
-  g128::Operand A{P.T + w0 * P.N, (long)P.N, P.N, len, 1};     // T[row + sample N]: rows contiguous
-  g128::Operand B{P.beta + w0 * m, (long)m, m, len, 1};        // beta[sample m + c]: the output column contiguous
-  g128::f64x4 acc[4][4];
-  const int r0 = blockIdx.x * g128::TM;
-  g128::tile_product<false, false>(A, B, r0, 0, 0, len, smem, acc);
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int wi = (wave & 1) * 64, wj = (wave >> 1) * 64;
-  const int lk = lane >> 4, lx = lane & 15;
-  double* dst = P.TBpart + ((long)e * P.chunks + chunk) * m * P.N;
-#pragma unroll
-  for (int a = 0; a < 4; ++a)
-#pragma unroll
-    for (int b = 0; b < 4; ++b)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = r0 + wi + 16 * a + lx, c = wj + 16 * b + lk + 4 * r;
-        if (row < P.N && c < m) dst[(long)c * P.N + row] = acc[a][b][r];
-      }
+  kg_tb128_kernel_body::run(MOE_VBLOCK, MOE_VGRID, nullptr, P);
 }
 
 // S_W = W_e^T T_e (m x samples) for 64 < m <= 128 on the same tile core: one 128-row tile holds all m rows, so T is read ONCE (the
 // 64-tile kernel reads it once per row tile: twice at m = 104).  K = N is cut into `slices`; slice sl of evaluation e goes to
 // SWpart[sl][e] (dense m x num_local), summed in slice order by sum_slices_kernel.  Grid (column tiles of 128 samples, slices, E).
+struct kg_sw128_kernel_body {
+  static __device__ __forceinline__ void run(const VIdx blockIdx, const VIdx gridDim, const void*, const KgTailParams& P, double* __restrict__ SWpart, int slices) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int sl = blockIdx.y, e = blockIdx.z, m = P.m;
+    const int ks = ((P.N + slices - 1) / slices + g128::TK - 1) / g128::TK * g128::TK;
+    const int k_lo = sl * ks, k_hi = min(P.N, k_lo + ks);
+    g128::Operand A{P.W + (long)e * P.w_stride, (long)P.N, m, P.N, 1};                        // W[row + c N]: K (= row) contiguous
+    g128::Operand B{P.T + (long)e * P.num_local * P.N, (long)P.N, P.num_local, P.N, 1};      // T[row + sample N]: K contiguous
+    g128::f64x4 acc[4][4];
+    const int j0 = blockIdx.x * g128::TM;
+    g128::tile_product<true, true>(A, B, 0, j0, k_lo, k_hi, smem, acc);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wi = (wave & 1) * 64, wj = (wave >> 1) * 64;
+    const int lk = lane >> 4, lx = lane & 15;
+    double* dst = SWpart + ((long)sl * P.E + e) * m * P.num_local;
+  #pragma unroll
+    for (int a = 0; a < 4; ++a)
+  #pragma unroll
+      for (int b = 0; b < 4; ++b)
+  #pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int c = wi + 16 * a + lx, smp = j0 + wj + 16 * b + lk + 4 * r;
+          if (c < m && smp < P.num_local) dst[(long)smp * m + c] = acc[a][b][r];
+        }
+  }
+};
 __global__ __launch_bounds__(256, 2) void kg_sw128_kernel(KgTailParams P, double* __restrict__ SWpart, int slices) {
-  extern __shared__ __attribute__((aligned(16))) double smem[];
-  const int sl = blockIdx.y, e = blockIdx.z, m = P.m;
-  const int ks = ((P.N + slices - 1) / slices + g128::TK - 1) / g128::TK * g128::TK;
-  const int k_lo = sl * ks, k_hi = min(P.N, k_lo + ks);
-  g128::Operand A{P.W + (long)e * P.w_stride, (long)P.N, m, P.N, 1};                        // W[row + c N]: K (= row) contiguous
-  g128::Operand B{P.T + (long)e * P.num_local * P.N, (long)P.N, P.num_local, P.N, 1};      // T[row + sample N]: K contiguous
-  g128::f64x4 acc[4][4];
-  const int j0 = blockIdx.x * g128::TM;
-  g128::tile_product<true, true>(A, B, 0, j0, k_lo, k_hi, smem, acc);
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int wi = (wave & 1) * 64, wj = (wave >> 1) * 64;
-  const int lk = lane >> 4, lx = lane & 15;
-  double* dst = SWpart + ((long)sl * P.E + e) * m * P.num_local;
-#pragma unroll
-  for (int a = 0; a < 4; ++a)
-#pragma unroll
-    for (int b = 0; b < 4; ++b)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int c = wi + 16 * a + lx, smp = j0 + wj + 16 * b + lk + 4 * r;
-        if (c < m && smp < P.num_local) dst[(long)smp * m + c] = acc[a][b][r];
-      }
+  kg_sw128_kernel_body::run(MOE_VBLOCK, MOE_VGRID, nullptr, P, SWpart, slices);
 }
 
 // TB[e][c][row] = sum of the chunk partials in chunk order (one pass over TBpart instead of one per gradient column).
@@ -519,7 +541,7 @@ void launch_sw_inst(const KgTailParams& P, hipStream_t s) {
   auto kern = kg_sw_kernel<DP, MU>;
   if (shm > 48 * 1024)
     MOE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
-  MOE_LAUNCH(kern, grid, dim3(256), shm, s, P);
+  launch_kernel_ens<kg_sw_kernel_body<DP, MU>, 256>(kern, grid, dim3(256), shm, s, P);
 }
 
 template <int DP>
@@ -537,7 +559,7 @@ void launch_sw_dp(const KgTailParams& P, hipStream_t s) {
   else {  // two components per lane; S_W comes precomputed (the host always forms it by GEMM for m > 8)
     if (P.SW == nullptr) throw Error(MOE_ERR_RUNTIME, "m > 64 needs the precomputed W^T T");
     dim3 grid((P.num_local + P.sw_chunk - 1) / P.sw_chunk, P.E);
-    MOE_LAUNCH((kg_sw_kernel<DP, 1, 2>), grid, dim3(256), 0, s, P);
+    launch_kernel_ens<kg_sw_kernel_body<DP, 1, 2>, 256>(kg_sw_kernel<DP, 1, 2>, grid, dim3(256), 0, s, P);
   }
   launch_dir<DP>(P, s);
 }
@@ -554,19 +576,19 @@ void launch_tail(const KgTailParams& P, hipStream_t s) {
   }
   dim3 gtb((P.N + 255) / 256, P.chunks, P.E);
   if (P.m <= 4)
-    MOE_LAUNCH((kg_tb_kernel<4>), gtb, dim3(256), 0, s, P, 0);
+    launch_kernel_ens<kg_tb_kernel_body<4>, 256>(kg_tb_kernel<4>, gtb, dim3(256), 0, s, P, 0);
   else if (P.m <= 8)
-    MOE_LAUNCH((kg_tb_kernel<8>), gtb, dim3(256), 0, s, P, 0);
+    launch_kernel_ens<kg_tb_kernel_body<8>, 256>(kg_tb_kernel<8>, gtb, dim3(256), 0, s, P, 0);
   else if (P.m <= 16)
-    MOE_LAUNCH((kg_tb_kernel<16>), gtb, dim3(256), 0, s, P, 0);
+    launch_kernel_ens<kg_tb_kernel_body<16>, 256>(kg_tb_kernel<16>, gtb, dim3(256), 0, s, P, 0);
   else if (P.m <= 32)
-    MOE_LAUNCH((kg_tb_kernel<32>), gtb, dim3(256), 0, s, P, 0);
+    launch_kernel_ens<kg_tb_kernel_body<32>, 256>(kg_tb_kernel<32>, gtb, dim3(256), 0, s, P, 0);
   else if (P.m <= 64) {
-    MOE_LAUNCH((kg_tb_kernel<64>), gtb, dim3(256), 0, s, P, 0);
+    launch_kernel_ens<kg_tb_kernel_body<64>, 256>(kg_tb_kernel<64>, gtb, dim3(256), 0, s, P, 0);
   } else {  // (m <= kMaxMB = 128: one column tile)
     MOE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kg_tb128_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                       (int)g128::kSmemBytes));
-    MOE_LAUNCH(kg_tb128_kernel, dim3((P.N + g128::TM - 1) / g128::TM, P.chunks, P.E), dim3(256), g128::kSmemBytes, s, P);
+    launch_kernel_ens<kg_tb128_kernel_body, 256, 2>(kg_tb128_kernel, dim3((P.N + g128::TM - 1) / g128::TM, P.chunks, P.E), dim3(256), g128::kSmemBytes, s, P);
   }
   launch_gtb(P, s);
   MOE_HIP_CHECK(hipGetLastError());
@@ -850,56 +872,66 @@ int env_int(const char* name, int dflt) {
 
 // z, beta = L^-T z and the discretised-set winner of EVERY sample (they depend on the normal draws alone): one wavefront
 // per sample, grid-stride, the same device functions the MC kernels use -- so the values are the ones they would compute.
-__global__ __launch_bounds__(256) void kg_sample_prep_kernel(KgMcParams P, int* __restrict__ best_j) {
-  __shared__ double zbs[4][2 * kMaxM];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  double* zb = zbs[wave];
-  const long total = (long)P.E * P.num_local;
-  for (long idx = (long)blockIdx.x * 4 + wave; idx < total; idx += (long)gridDim.x * 4) {
-    const int e = (int)(idx / P.num_local), sl = (int)(idx % P.num_local);
-    const double* rec = P.blob + (long)e * P.rec.stride;
-    double zc, bc;
-    mc::draw_z_beta(P, rec + P.rec.L, P.first_sample + sl, lane, zb, zc, bc);
-    const int bj = mc::discrete_scan(P, rec, zb, lane);
-    if (lane < P.m) P.beta[idx * P.m + lane] = bc;
-    if (lane == 0) best_j[idx] = bj;
-    __builtin_amdgcn_wave_barrier();
+struct kg_sample_prep_kernel_body {
+  static __device__ __forceinline__ void run(const VIdx blockIdx, const VIdx gridDim, const void*, const KgMcParams& P, int* __restrict__ best_j) {
+    __shared__ double zbs[4][2 * kMaxM];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    double* zb = zbs[wave];
+    const long total = (long)P.E * P.num_local;
+    for (long idx = (long)blockIdx.x * 4 + wave; idx < total; idx += (long)gridDim.x * 4) {
+      const int e = (int)(idx / P.num_local), sl = (int)(idx % P.num_local);
+      const double* rec = P.blob + (long)e * P.rec.stride;
+      double zc, bc;
+      mc::draw_z_beta(P, rec + P.rec.L, P.first_sample + sl, lane, zb, zc, bc);
+      const int bj = mc::discrete_scan(P, rec, zb, lane);
+      if (lane < P.m) P.beta[idx * P.m + lane] = bc;
+      if (lane == 0) best_j[idx] = bj;
+      __builtin_amdgcn_wave_barrier();
+    }
   }
+};
+__global__ __launch_bounds__(256) void kg_sample_prep_kernel(KgMcParams P, int* __restrict__ best_j) {
+  kg_sample_prep_kernel_body::run(MOE_VBLOCK, MOE_VGRID, nullptr, P, best_j);
 }
 
 // The same for m > 64 (more components than lanes): one THREAD per sample, serial O(m^2) back substitution and O(A m) scan
 // against operands in L2 -- a few hundred microseconds for 2 x 10^4 samples at m = 104; only the workgroup-per-sample kernel
 // consumes it.  z_i (antithetic pairs, .cpp:171-180), beta_i = L^-T z_i, first best discretised point (.cpp:436-449).
-__global__ __launch_bounds__(64) void kg_sample_prep_generic_kernel(KgMcParams P, int* __restrict__ best_j) {
-  const long idx = (long)blockIdx.x * 64 + threadIdx.x;
-  const long total = (long)P.E * P.num_local;
-  if (idx >= total) return;
-  const int e = (int)(idx / P.num_local), sl = (int)(idx % P.num_local);
-  const int m = P.m, s = P.first_sample + sl;
-  const double* rec = P.blob + (long)e * P.rec.stride;
-  const double* L = rec + P.rec.L;
-  const double sign = (s & 1) ? -1.0 : 1.0;
-  const double* zrow = P.normals + (long)(s >> 1) * m;
-  double beta[kMaxMB];
-  for (int r = m - 1; r >= 0; --r) {
-    double acc = 0.0;
-    for (int l = m - 1; l > r; --l) acc = fma(L[l + (long)r * m], beta[l], acc);
-    beta[r] = (sign * zrow[r] - acc) / L[r + (long)r * m];
-  }
-  for (int c = 0; c < m; ++c) P.beta[idx * m + c] = beta[c];
-  const double* mu_disc = rec + P.rec.mu_disc;
-  const double* C_disc = rec + P.rec.C_disc;
-  double best_f = -INFINITY;
-  int bj = 0;
-  for (int j = 0; j < P.A; ++j) {
-    double v = mu_disc[j];
-    for (int c = 0; c < m; ++c) v = fma(C_disc[(long)j * m + c], sign * zrow[c], v);
-    if (-v > best_f) {  // strict: the first best point wins
-      best_f = -v;
-      bj = j;
+struct kg_sample_prep_generic_kernel_body {
+  static __device__ __forceinline__ void run(const VIdx blockIdx, const VIdx gridDim, const void*, const KgMcParams& P, int* __restrict__ best_j) {
+    const long idx = (long)blockIdx.x * 64 + threadIdx.x;
+    const long total = (long)P.E * P.num_local;
+    if (idx >= total) return;
+    const int e = (int)(idx / P.num_local), sl = (int)(idx % P.num_local);
+    const int m = P.m, s = P.first_sample + sl;
+    const double* rec = P.blob + (long)e * P.rec.stride;
+    const double* L = rec + P.rec.L;
+    const double sign = (s & 1) ? -1.0 : 1.0;
+    const double* zrow = P.normals + (long)(s >> 1) * m;
+    double beta[kMaxMB];
+    for (int r = m - 1; r >= 0; --r) {
+      double acc = 0.0;
+      for (int l = m - 1; l > r; --l) acc = fma(L[l + (long)r * m], beta[l], acc);
+      beta[r] = (sign * zrow[r] - acc) / L[r + (long)r * m];
     }
+    for (int c = 0; c < m; ++c) P.beta[idx * m + c] = beta[c];
+    const double* mu_disc = rec + P.rec.mu_disc;
+    const double* C_disc = rec + P.rec.C_disc;
+    double best_f = -INFINITY;
+    int bj = 0;
+    for (int j = 0; j < P.A; ++j) {
+      double v = mu_disc[j];
+      for (int c = 0; c < m; ++c) v = fma(C_disc[(long)j * m + c], sign * zrow[c], v);
+      if (-v > best_f) {  // strict: the first best point wins
+        best_f = -v;
+        bj = j;
+      }
+    }
+    best_j[idx] = bj;
   }
-  best_j[idx] = bj;
+};
+__global__ __launch_bounds__(64) void kg_sample_prep_generic_kernel(KgMcParams P, int* __restrict__ best_j) {
+  kg_sample_prep_generic_kernel_body::run(MOE_VBLOCK, MOE_VGRID, nullptr, P, best_j);
 }
 
 // Per-sample weights of the training rows for every sample, V[(e, sl)][r] = scale_a (KinvY[r] - sum_c W_e[r, c] beta[(e, sl), c])
@@ -910,51 +942,57 @@ __global__ __launch_bounds__(64) void kg_sample_prep_generic_kernel(KgMcParams P
 // m > 64 (r4): the columns go down in passes of 64 -- pass [c_lo, c_lo + MB) continues the fma chain from the partial sum the previous
 // pass left in V (plain store), the last pass scales and streams the result out; one pass (first = last) is the code of m <= 64.
 template <int MB>
-__global__ __launch_bounds__(256) void kg_sample_weights_kernel(KgMcParams P, double* __restrict__ V, int samples_per_block,
-                                                               int c_lo = 0, int first = 1, int last = 1) {
-  // table entry t = (point j, slot a) <-> row r = j (1 + g) + a of the N training rows / the m fantasy rows; slots beyond the GP's
-  // 1 + g (r4: a streamed-weights instantiation with more derivative slots than observed derivatives) hold zeros
-  const int t = blockIdx.x * 256 + threadIdx.x;
-  const int e = blockIdx.z;
-  const int m = P.m, g1 = 1 + P.g;
-  const int pj = t / P.v_slots1, pa = t - pj * P.v_slots1;
-  const bool slot_ok = pa < g1;
-  const int r = slot_ok ? pj * g1 + pa : P.N + m;  // (an unused slot: behind everything, stored as 0)
-  const double* __restrict__ We = P.W + (long)e * P.w_stride;
-  const double* __restrict__ beta = P.beta;
-  double l[MB];
-  const int rr = min(r, P.N - 1);
-#pragma unroll
-  for (int c = 0; c < MB; ++c) {  // zero beyond m: the unconditional fma below then leaves v untouched
-    const double t = We[rr + (long)min(c_lo + c, m - 1) * P.N];
-    l[c] = (c_lo + c < m) ? t : 0.0;
-  }
-  const double kiy = P.KinvY[rr];
-  const int a = rr % g1;
-  const double scale = (a == 0) ? P.alpha : -P.alpha * P.inv_lp[a > 0 ? a - 1 : 0];
-  const int s0 = blockIdx.y * samples_per_block, s1 = min(P.num_local, s0 + samples_per_block);
-  // rows behind the training set (v_stride > N: the streamed-weights MC kernel reads whole tiles): the fantasy points' weights are the
-  // sample's beta itself, scaled like a training row (kg_mc.hpp kg_sample), then zeros up to the end of the last tile
-  const int cf = r - P.N;
-  const bool fantasy = cf >= 0 && cf < m;
-  const double fscale = ((cf % g1) == 0) ? P.alpha : -P.alpha * P.inv_lp[max(cf % g1, 1) - 1];
-  for (int sl = s0; sl < s1; ++sl) {
-    const long so = (long)e * P.num_local + sl;
-    const double* __restrict__ bs = beta + so * m + c_lo;
-    double v = first ? kiy : V[so * P.v_stride + min(t, (int)P.v_stride - 1)];
-#pragma unroll
-    for (int c = 0; c < MB; ++c) v = fma(-l[c], bs[c], v);  // uniform, contiguous: wide scalar loads (reads up to MB - m
-                                                            // doubles past the row: next rows / the zeroed pad, times l = 0)
-    if (t >= P.v_stride) continue;
-    if (r < P.N) {
-      if (last)
-        __builtin_nontemporal_store(v * scale, &V[so * P.v_stride + t]);  // (streaming: 1.28 GB at C5, read once by the MC kernel)
-      else
-        V[so * P.v_stride + t] = v;
-    } else if (last) {
-      V[so * P.v_stride + t] = fantasy ? beta[so * m + min(cf, m - 1)] * fscale : 0.0;
+struct kg_sample_weights_kernel_body {
+  static __device__ __forceinline__ void run(const VIdx blockIdx, const VIdx gridDim, const void*, const KgMcParams& P, double* __restrict__ V, int samples_per_block, int c_lo, int first, int last) {
+    // table entry t = (point j, slot a) <-> row r = j (1 + g) + a of the N training rows / the m fantasy rows; slots beyond the GP's
+    // 1 + g (r4: a streamed-weights instantiation with more derivative slots than observed derivatives) hold zeros
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    const int e = blockIdx.z;
+    const int m = P.m, g1 = 1 + P.g;
+    const int pj = t / P.v_slots1, pa = t - pj * P.v_slots1;
+    const bool slot_ok = pa < g1;
+    const int r = slot_ok ? pj * g1 + pa : P.N + m;  // (an unused slot: behind everything, stored as 0)
+    const double* __restrict__ We = P.W + (long)e * P.w_stride;
+    const double* __restrict__ beta = P.beta;
+    double l[MB];
+    const int rr = min(r, P.N - 1);
+  #pragma unroll
+    for (int c = 0; c < MB; ++c) {  // zero beyond m: the unconditional fma below then leaves v untouched
+      const double t = We[rr + (long)min(c_lo + c, m - 1) * P.N];
+      l[c] = (c_lo + c < m) ? t : 0.0;
+    }
+    const double kiy = P.KinvY[rr];
+    const int a = rr % g1;
+    const double scale = (a == 0) ? P.alpha : -P.alpha * P.inv_lp[a > 0 ? a - 1 : 0];
+    const int s0 = blockIdx.y * samples_per_block, s1 = min(P.num_local, s0 + samples_per_block);
+    // rows behind the training set (v_stride > N: the streamed-weights MC kernel reads whole tiles): the fantasy points' weights are the
+    // sample's beta itself, scaled like a training row (kg_mc.hpp kg_sample), then zeros up to the end of the last tile
+    const int cf = r - P.N;
+    const bool fantasy = cf >= 0 && cf < m;
+    const double fscale = ((cf % g1) == 0) ? P.alpha : -P.alpha * P.inv_lp[max(cf % g1, 1) - 1];
+    for (int sl = s0; sl < s1; ++sl) {
+      const long so = (long)e * P.num_local + sl;
+      const double* __restrict__ bs = beta + so * m + c_lo;
+      double v = first ? kiy : V[so * P.v_stride + min(t, (int)P.v_stride - 1)];
+  #pragma unroll
+      for (int c = 0; c < MB; ++c) v = fma(-l[c], bs[c], v);  // uniform, contiguous: wide scalar loads (reads up to MB - m
+                                                              // doubles past the row: next rows / the zeroed pad, times l = 0)
+      if (t >= P.v_stride) continue;
+      if (r < P.N) {
+        if (last)
+          __builtin_nontemporal_store(v * scale, &V[so * P.v_stride + t]);  // (streaming: 1.28 GB at C5, read once by the MC kernel)
+        else
+          V[so * P.v_stride + t] = v;
+      } else if (last) {
+        V[so * P.v_stride + t] = fantasy ? beta[so * m + min(cf, m - 1)] * fscale : 0.0;
+      }
     }
   }
+};
+template <int MB>
+__global__ __launch_bounds__(256) void kg_sample_weights_kernel(KgMcParams P, double* __restrict__ V, int samples_per_block,
+                                                               int c_lo = 0, int first = 1, int last = 1) {
+  kg_sample_weights_kernel_body<MB>::run(MOE_VBLOCK, MOE_VGRID, nullptr, P, V, samples_per_block, c_lo, first, last);
 }
 
 // The same table for m > 64 (r4; the stretch point's m = 104) with its sums on the matrix pipe: V_e (table rows x samples) = K^-1 y -
@@ -963,45 +1001,50 @@ __global__ __launch_bounds__(256) void kg_sample_weights_kernel(KgMcParams P, do
 // (v_slots1 == 1 + g).  The sums are formed in the MFMA's order, not in the c-order of the in-kernel weights: for these shapes a result
 // depends at rounding level on whether the table fitted its cap (the m <= 64 paths keep their bit-for-bit equality).
 // Grid (row tiles of 128 table entries, column tiles of 128 samples, E).
-__global__ __launch_bounds__(256, 2) void kg_table128_kernel(KgMcParams P, double* __restrict__ V) {
-  extern __shared__ __attribute__((aligned(16))) double smem[];
-  const int e = blockIdx.z, m = P.m, g1 = 1 + P.g;
-  const long s0 = (long)e * P.num_local;
-  g128::Operand A{P.W + (long)e * P.w_stride, (long)P.N, P.N, m, 1};   // W[t + c N]: table rows contiguous
-  g128::Operand B{P.beta + s0 * m, (long)m, P.num_local, m, 1};        // beta[sample m + c]: K (= c) contiguous
-  g128::f64x4 acc[4][4];
-  const int t0 = blockIdx.x * g128::TM, j0 = blockIdx.y * g128::TM;
-  if (t0 < P.N) g128::tile_product<false, true>(A, B, t0, j0, 0, m, smem, acc);
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int wi = (wave & 1) * 64, wj = (wave >> 1) * 64;
-  const int lk = lane >> 4, lx = lane & 15;
-#pragma unroll
-  for (int a = 0; a < 4; ++a) {
-    const int t = t0 + wi + 16 * a + lx;
-    const int tt = min(t, P.N - 1);
-    const double kiy = P.KinvY[tt];
-    const int sa = tt % g1;
-    const double scale = (sa == 0) ? P.alpha : -P.alpha * P.inv_lp[sa > 0 ? sa - 1 : 0];
-    // rows behind the training set: the fantasy points' weights are the sample's beta itself, scaled like a training row, then zeros
-    const int cf = t - P.N;
-    const bool fantasy = cf >= 0 && cf < m;
-    const double fscale = ((cf % g1) == 0) ? P.alpha : -P.alpha * P.inv_lp[max(cf % g1, 1) - 1];
-#pragma unroll
-    for (int b = 0; b < 4; ++b)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int smp = j0 + wj + 16 * b + lk + 4 * r;
-        if (t < P.v_stride && smp < P.num_local) {
-          const long so = s0 + smp;
-          double v;
-          if (t < P.N)
-            v = (kiy - acc[a][b][r]) * scale;
-          else
-            v = fantasy ? P.beta[so * m + min(cf, m - 1)] * fscale : 0.0;
-          __builtin_nontemporal_store(v, &V[so * P.v_stride + t]);
+struct kg_table128_kernel_body {
+  static __device__ __forceinline__ void run(const VIdx blockIdx, const VIdx gridDim, const void*, const KgMcParams& P, double* __restrict__ V) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int e = blockIdx.z, m = P.m, g1 = 1 + P.g;
+    const long s0 = (long)e * P.num_local;
+    g128::Operand A{P.W + (long)e * P.w_stride, (long)P.N, P.N, m, 1};   // W[t + c N]: table rows contiguous
+    g128::Operand B{P.beta + s0 * m, (long)m, P.num_local, m, 1};        // beta[sample m + c]: K (= c) contiguous
+    g128::f64x4 acc[4][4];
+    const int t0 = blockIdx.x * g128::TM, j0 = blockIdx.y * g128::TM;
+    if (t0 < P.N) g128::tile_product<false, true>(A, B, t0, j0, 0, m, smem, acc);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wi = (wave & 1) * 64, wj = (wave >> 1) * 64;
+    const int lk = lane >> 4, lx = lane & 15;
+  #pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      const int t = t0 + wi + 16 * a + lx;
+      const int tt = min(t, P.N - 1);
+      const double kiy = P.KinvY[tt];
+      const int sa = tt % g1;
+      const double scale = (sa == 0) ? P.alpha : -P.alpha * P.inv_lp[sa > 0 ? sa - 1 : 0];
+      // rows behind the training set: the fantasy points' weights are the sample's beta itself, scaled like a training row, then zeros
+      const int cf = t - P.N;
+      const bool fantasy = cf >= 0 && cf < m;
+      const double fscale = ((cf % g1) == 0) ? P.alpha : -P.alpha * P.inv_lp[max(cf % g1, 1) - 1];
+  #pragma unroll
+      for (int b = 0; b < 4; ++b)
+  #pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int smp = j0 + wj + 16 * b + lk + 4 * r;
+          if (t < P.v_stride && smp < P.num_local) {
+            const long so = s0 + smp;
+            double v;
+            if (t < P.N)
+              v = (kiy - acc[a][b][r]) * scale;
+            else
+              v = fantasy ? P.beta[so * m + min(cf, m - 1)] * fscale : 0.0;
+            __builtin_nontemporal_store(v, &V[so * P.v_stride + t]);
+          }
         }
-      }
+    }
   }
+};
+__global__ __launch_bounds__(256, 2) void kg_table128_kernel(KgMcParams P, double* __restrict__ V) {
+  kg_table128_kernel_body::run(MOE_VBLOCK, MOE_VGRID, nullptr, P, V);
 }
 
 void launch_sample_weights(const KgMcParams& P, double* V, hipStream_t s, bool table_only = false) {
@@ -1012,7 +1055,7 @@ void launch_sample_weights(const KgMcParams& P, double* V, hipStream_t s, bool t
   if (mfma) {
     MOE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kg_table128_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                       (int)g128::kSmemBytes));
-    MOE_LAUNCH(kg_table128_kernel, dim3((unsigned)((P.v_stride + g128::TM - 1) / g128::TM), (P.num_local + g128::TM - 1) / g128::TM, P.E),
+    launch_kernel_ens<kg_table128_kernel_body, 256, 2>(kg_table128_kernel, dim3((unsigned)((P.v_stride + g128::TM - 1) / g128::TM), (P.num_local + g128::TM - 1) / g128::TM, P.E),
                        dim3(256), g128::kSmemBytes, s, P, V);
     MOE_HIP_CHECK(hipGetLastError());
     return;
@@ -1020,13 +1063,13 @@ void launch_sample_weights(const KgMcParams& P, double* V, hipStream_t s, bool t
   const int spb = 64;
   dim3 grid((unsigned)((P.v_stride + 255) / 256), (P.num_local + spb - 1) / spb, P.E);
   if (P.m <= 16)
-    MOE_LAUNCH(kg_sample_weights_kernel<16>, grid, dim3(256), 0, s, P, V, spb);
+    launch_kernel_ens<kg_sample_weights_kernel_body<16>, 256>(kg_sample_weights_kernel<16>, grid, dim3(256), 0, s, P, V, spb, 0, 1, 1);
   else if (P.m <= 32)
-    MOE_LAUNCH(kg_sample_weights_kernel<32>, grid, dim3(256), 0, s, P, V, spb);
+    launch_kernel_ens<kg_sample_weights_kernel_body<32>, 256>(kg_sample_weights_kernel<32>, grid, dim3(256), 0, s, P, V, spb, 0, 1, 1);
   else  // (m > 64 in passes of 64 columns; ONE pass with a 128-column row of W in registers -- 256 of them, half in the accumulation file --
         //  measured slower: 34 against 21 ms of MC phase per evaluation at the stretch point, m = 104)
     for (int c_lo = 0; c_lo < P.m; c_lo += 64)
-      MOE_LAUNCH(kg_sample_weights_kernel<64>, grid, dim3(256), 0, s, P, V, spb, c_lo, c_lo == 0 ? 1 : 0, c_lo + 64 >= P.m ? 1 : 0);
+      launch_kernel_ens<kg_sample_weights_kernel_body<64>, 256>(kg_sample_weights_kernel<64>, grid, dim3(256), 0, s, P, V, spb, c_lo, c_lo == 0 ? 1 : 0, c_lo + 64 >= P.m ? 1 : 0);
   MOE_HIP_CHECK(hipGetLastError());
 }
 
@@ -1595,10 +1638,10 @@ KgPending kg_launch(GpDev& gp, int num_fidelity, const moe_gd_params_t& gd, cons
     const long total = (long)E * num_local;
     int* best_j_p = gp.kBestJ.p;
     if (m > kMaxM) {  // more components than lanes: thread-per-sample pre-pass (mandatory there)
-      MOE_LAUNCH(kg_sample_prep_generic_kernel, dim3((unsigned)((total + 63) / 64)), dim3(64), 0, s, mp, best_j_p);
+      launch_kernel_ens<kg_sample_prep_generic_kernel_body, 64>(kg_sample_prep_generic_kernel, dim3((unsigned)((total + 63) / 64)), dim3(64), 0, s, mp, best_j_p);
     } else {
       const int pb = (int)std::min<long>((total + 3) / 4, (long)num_cu * 8);
-      MOE_LAUNCH(kg_sample_prep_kernel, dim3(pb), dim3(256), 0, s, mp, best_j_p);
+      launch_kernel_ens<kg_sample_prep_kernel_body, 256>(kg_sample_prep_kernel, dim3(pb), dim3(256), 0, s, mp, best_j_p);
     }
     MOE_HIP_CHECK(hipGetLastError());
   }
@@ -1704,7 +1747,7 @@ KgPending kg_launch(GpDev& gp, int num_fidelity, const moe_gd_params_t& gd, cons
         MOE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kg_sw128_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                           (int)g128::kSmemBytes));
         double* sw_part_p = gp.kSWpart.p;
-        MOE_LAUNCH(kg_sw128_kernel, dim3((num_local + g128::TM - 1) / g128::TM, sw_slices, E), dim3(256), g128::kSmemBytes, s, tq,
+        launch_kernel_ens<kg_sw128_kernel_body, 256, 2>(kg_sw128_kernel, dim3((num_local + g128::TM - 1) / g128::TM, sw_slices, E), dim3(256), g128::kSmemBytes, s, tq,
                    sw_part_p, sw_slices);
         launch_sum_slices(gp.kSWpart.p, sw_slices, (long)m * num_local * E, gp.kSW.p, s);
       } else {

@@ -2090,69 +2090,75 @@ __device__ __forceinline__ void kg_sample(const KgMcParams& P, int e, int sl, co
 // read -> ~43 dependent FP64 operations -> wave reduction -> decision) that two wavefronts per SIMD cannot cover: compiled
 // for 16 wavefronts per workgroup (<= 128 VGPRs, tile loop not unrolled) so that four wavefronts share each SIMD.
 template <int DP, int G, bool XLDS, bool SMALL>
-__global__ __launch_bounds__(SMALL ? 1024 : 512) void kg_mc_kernel(KgMcParams P) {
-  extern __shared__ __attribute__((aligned(16))) double smem[];
-  const int lane = threadIdx.x & 63;
-  const int wave = threadIdx.x >> 6;
-  const int ntiles = P.ntiles;
-  const int tab = ntiles * (DP + 1) * 64;  // LDS copy: the DP coordinate rows + the |x|^2 row per tile (see eval_loop)
-  const int wslab = ntiles * (1 + G) * 64 + 2 * kMaxM + (wide_eval(DP, XLDS) ? kWideScratch : 0);
-  // LDS: [64] exp table | [kCstRows x DP] per-row constants of the frame line search | [tab] coordinates (if XLDS) | per-wave slabs
-  double* cst = smem + kExpTabLen;
-  double* coords = cst + kCstRows * DP;
-  const int wtab = wide_eval(DP, XLDS) ? P.wide_lds_tiles * DP * 64 : 0;  // streamed table: its leading tiles (paired rows: WideEval)
-  double* aw = coords + (XLDS ? tab : wtab) + wave * wslab;
-  double* zb = aw + ntiles * (1 + G) * 64;
-  if (threadIdx.x < kExpTabLen) smem[threadIdx.x] = kExp2Tab64[threadIdx.x];
-  fill_frame_constants<DP>(P, cst);
-  if (!XLDS) __syncthreads();
-  // evaluation of this workgroup: workgroups b, b + E, b + 2E, ... serve evaluation b mod E (b mod 8 is also the XCD, so
-  // with E = 8 each evaluation's W / table stay in one XCD's L2); with fewer workgroups than evaluations they loop.
-  for (int e = blockIdx.x % P.E; e < P.E; e += (gridDim.x < (unsigned)P.E ? gridDim.x : P.E)) {
-    const double* xs = P.XsTab + (long)e * P.tab_stride;
-    if (XLDS) {
-      __syncthreads();  // previous evaluation's readers are done
-      for (int pt = threadIdx.x; pt < ntiles * 64; pt += blockDim.x) {  // one point per thread and step
-        const int tl = pt >> 6, l = pt & 63;
-        const double* src = xs + (long)tl * DP * 64 + l;
-        double* dst = coords + tl * (DP + 1) * 64 + l;
-        double xx = 0.0;
-#pragma unroll
-        for (int k = 0; k < DP; ++k) {
-          const double v = src[k * 64];
-          dst[k * 64] = v;
-          xx = fma(v, v, xx);
+struct kg_mc_kernel_body {
+  static __device__ __forceinline__ void run(const VIdx blockIdx, const VIdx gridDim, const void*, const KgMcParams& P) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int ntiles = P.ntiles;
+    const int tab = ntiles * (DP + 1) * 64;  // LDS copy: the DP coordinate rows + the |x|^2 row per tile (see eval_loop)
+    const int wslab = ntiles * (1 + G) * 64 + 2 * kMaxM + (wide_eval(DP, XLDS) ? kWideScratch : 0);
+    // LDS: [64] exp table | [kCstRows x DP] per-row constants of the frame line search | [tab] coordinates (if XLDS) | per-wave slabs
+    double* cst = smem + kExpTabLen;
+    double* coords = cst + kCstRows * DP;
+    const int wtab = wide_eval(DP, XLDS) ? P.wide_lds_tiles * DP * 64 : 0;  // streamed table: its leading tiles (paired rows: WideEval)
+    double* aw = coords + (XLDS ? tab : wtab) + wave * wslab;
+    double* zb = aw + ntiles * (1 + G) * 64;
+    if (threadIdx.x < kExpTabLen) smem[threadIdx.x] = kExp2Tab64[threadIdx.x];
+    fill_frame_constants<DP>(P, cst);
+    if (!XLDS) __syncthreads();
+    // evaluation of this workgroup: workgroups b, b + E, b + 2E, ... serve evaluation b mod E (b mod 8 is also the XCD, so
+    // with E = 8 each evaluation's W / table stay in one XCD's L2); with fewer workgroups than evaluations they loop.
+    for (int e = blockIdx.x % P.E; e < P.E; e += (gridDim.x < (unsigned)P.E ? gridDim.x : P.E)) {
+      const double* xs = P.XsTab + (long)e * P.tab_stride;
+      if (XLDS) {
+        __syncthreads();  // previous evaluation's readers are done
+        for (int pt = threadIdx.x; pt < ntiles * 64; pt += blockDim.x) {  // one point per thread and step
+          const int tl = pt >> 6, l = pt & 63;
+          const double* src = xs + (long)tl * DP * 64 + l;
+          double* dst = coords + tl * (DP + 1) * 64 + l;
+          double xx = 0.0;
+  #pragma unroll
+          for (int k = 0; k < DP; ++k) {
+            const double v = src[k * 64];
+            dst[k * 64] = v;
+            xx = fma(v, v, xx);
+          }
+          dst[DP * 64] = xx;
         }
-        dst[DP * 64] = xx;
+        xs = coords;
+        __syncthreads();
       }
-      xs = coords;
-      __syncthreads();
-    }
-    if constexpr (wide_eval(DP, XLDS)) {
-      __syncthreads();  // previous evaluation's readers are done
-      const d2t* src = reinterpret_cast<const d2t*>(xs);
-      d2t* dst = reinterpret_cast<d2t*>(coords);
-      for (int i = threadIdx.x; i < wtab / 2; i += blockDim.x) dst[i] = src[i];
-      __syncthreads();
-    }
-    // sample tickets are drawn ONE AHEAD: the atomic's round trip to L2 overlaps the current sample instead of stalling
-    // the wave between samples (each wave ends up drawing one ticket it does not use)
-    unsigned int ticket = 0;
-    unsigned int* next = P.next_sample + (long)e * kTicketStride;  // one cache line per evaluation
-    if (lane == 0) ticket = atomicAdd(next, 1u);
-    unsigned long long tot_val = 0, tot_grad = 0;
-    while (true) {
-      const unsigned int sl = (unsigned int)__builtin_amdgcn_readfirstlane((int)ticket);
-      if (sl >= (unsigned int)P.num_local) break;
+      if constexpr (wide_eval(DP, XLDS)) {
+        __syncthreads();  // previous evaluation's readers are done
+        const d2t* src = reinterpret_cast<const d2t*>(xs);
+        d2t* dst = reinterpret_cast<d2t*>(coords);
+        for (int i = threadIdx.x; i < wtab / 2; i += blockDim.x) dst[i] = src[i];
+        __syncthreads();
+      }
+      // sample tickets are drawn ONE AHEAD: the atomic's round trip to L2 overlaps the current sample instead of stalling
+      // the wave between samples (each wave ends up drawing one ticket it does not use)
+      unsigned int ticket = 0;
+      unsigned int* next = P.next_sample + (long)e * kTicketStride;  // one cache line per evaluation
       if (lane == 0) ticket = atomicAdd(next, 1u);
-      kg_sample<DP, G, SMALL, XLDS>(P, e, (int)sl, xs, aw, zb, smem, cst, lane, tot_val, tot_grad);
+      unsigned long long tot_val = 0, tot_grad = 0;
+      while (true) {
+        const unsigned int sl = (unsigned int)__builtin_amdgcn_readfirstlane((int)ticket);
+        if (sl >= (unsigned int)P.num_local) break;
+        if (lane == 0) ticket = atomicAdd(next, 1u);
+        kg_sample<DP, G, SMALL, XLDS>(P, e, (int)sl, xs, aw, zb, smem, cst, lane, tot_val, tot_grad);
+      }
+      if (lane == 0 && (tot_val | tot_grad) != 0) {
+        atomicAdd(&P.counters[2 * e], tot_val);
+        atomicAdd(&P.counters[2 * e + 1], tot_grad);
+      }
+      if (gridDim.x >= (unsigned)P.E) break;
     }
-    if (lane == 0 && (tot_val | tot_grad) != 0) {
-      atomicAdd(&P.counters[2 * e], tot_val);
-      atomicAdd(&P.counters[2 * e + 1], tot_grad);
-    }
-    if (gridDim.x >= (unsigned)P.E) break;
   }
+};
+template <int DP, int G, bool XLDS, bool SMALL>
+__global__ __launch_bounds__(SMALL ? 1024 : 512) void kg_mc_kernel(KgMcParams P) {
+  kg_mc_kernel_body<DP, G, XLDS, SMALL>::run(MOE_VBLOCK, MOE_VGRID, nullptr, P);
 }
 
 // =====================================================================================================================
@@ -2166,69 +2172,75 @@ __global__ __launch_bounds__(SMALL ? 1024 : 512) void kg_mc_kernel(KgMcParams P)
 // LDS: [64] exp table | leading tiles of the paired-row table | per wave: kWideScratch doubles.
 // =====================================================================================================================
 template <int DP, int G>
-__global__ __launch_bounds__(512) void kg_mc_stream_kernel(KgMcParams P) {
-  extern __shared__ __attribute__((aligned(16))) double smem[];
-  const int lane = threadIdx.x & 63;
-  const int wave = threadIdx.x >> 6;
-  const int wtab = P.wide_lds_tiles * DP * 64;
-  double* coords = smem + kExpTabLen;
-  double* st = coords + wtab + wave * kWideScratch;
-  if (threadIdx.x < kExpTabLen) smem[threadIdx.x] = kExp2Tab64[threadIdx.x];
-  const int size = P.dim - P.f;
-  for (int e = blockIdx.x % P.E; e < P.E; e += (gridDim.x < (unsigned)P.E ? gridDim.x : P.E)) {
-    const double* xs = P.XsTab + (long)e * P.tab_stride;
-    const double* rec = P.blob + (long)e * P.rec.stride;
-    __syncthreads();  // previous evaluation's readers are done (and the exp table is visible)
-    {
-      const d2t* src = reinterpret_cast<const d2t*>(xs);
-      d2t* dst = reinterpret_cast<d2t*>(coords);
-      for (int i = threadIdx.x; i < wtab / 2; i += blockDim.x) dst[i] = src[i];
-    }
-    __syncthreads();
-    unsigned int ticket = 0;  // drawn one ahead (see kg_mc_kernel)
-    unsigned int* next = P.next_sample + (long)e * kTicketStride;
-    if (lane == 0) ticket = atomicAdd(next, 1u);
-    unsigned long long tot_val = 0, tot_grad = 0;
-    while (true) {
-      const unsigned int sl = (unsigned int)__builtin_amdgcn_readfirstlane((int)ticket);
-      if (sl >= (unsigned int)P.num_local) break;
-      if (lane == 0) ticket = atomicAdd(next, 1u);
-      const long so = (long)e * P.num_local + sl;
-      const int best_j = P.best_j[so];
-      const double* disc = rec + P.rec.disc;
-      double x[DP];
-#pragma unroll
-      for (int k = 0; k < DP; ++k) x[k] = (k < size) ? disc[(long)best_j * size + k] : ((k < P.dim) ? 1.0 : 0.0);
-      const d2t* xg = reinterpret_cast<const d2t*>(xs) + lane;
-      lds_pair_ptr xl = (lds_pair_ptr)coords + lane;
-      WideEval<DP, G, true> ev{xg, xl, {P.V + so * P.v_stride + (long)lane * (1 + G)}, smem, st + kLsRows * kMaxDimPadded,
-                               P.ntiles, P.wide_lds_tiles, P.cov_type, lane, P.mean};
-      unsigned long long n_val = 0, n_grad = 0;
-      const double fcur = line_search_lds<DP, G>(P, ev, st, x, n_val, n_grad);
-      if (lane == 0) P.best_value[so] = fcur;
-      tot_val += n_val;
-      tot_grad += n_grad;
-      if (lane < DP) {
-        double v = 0.0;
-#pragma unroll
-        for (int k = 0; k < DP; ++k)
-          if (lane == k) v = x[k];
-        P.best_point[so * DP + lane] = v;
+struct kg_mc_stream_kernel_body {
+  static __device__ __forceinline__ void run(const VIdx blockIdx, const VIdx gridDim, const void*, const KgMcParams& P) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int wtab = P.wide_lds_tiles * DP * 64;
+    double* coords = smem + kExpTabLen;
+    double* st = coords + wtab + wave * kWideScratch;
+    if (threadIdx.x < kExpTabLen) smem[threadIdx.x] = kExp2Tab64[threadIdx.x];
+    const int size = P.dim - P.f;
+    for (int e = blockIdx.x % P.E; e < P.E; e += (gridDim.x < (unsigned)P.E ? gridDim.x : P.E)) {
+      const double* xs = P.XsTab + (long)e * P.tab_stride;
+      const double* rec = P.blob + (long)e * P.rec.stride;
+      __syncthreads();  // previous evaluation's readers are done (and the exp table is visible)
+      {
+        const d2t* src = reinterpret_cast<const d2t*>(xs);
+        d2t* dst = reinterpret_cast<d2t*>(coords);
+        for (int i = threadIdx.x; i < wtab / 2; i += blockDim.x) dst[i] = src[i];
       }
+      __syncthreads();
+      unsigned int ticket = 0;  // drawn one ahead (see kg_mc_kernel)
+      unsigned int* next = P.next_sample + (long)e * kTicketStride;
+      if (lane == 0) ticket = atomicAdd(next, 1u);
+      unsigned long long tot_val = 0, tot_grad = 0;
+      while (true) {
+        const unsigned int sl = (unsigned int)__builtin_amdgcn_readfirstlane((int)ticket);
+        if (sl >= (unsigned int)P.num_local) break;
+        if (lane == 0) ticket = atomicAdd(next, 1u);
+        const long so = (long)e * P.num_local + sl;
+        const int best_j = P.best_j[so];
+        const double* disc = rec + P.rec.disc;
+        double x[DP];
+  #pragma unroll
+        for (int k = 0; k < DP; ++k) x[k] = (k < size) ? disc[(long)best_j * size + k] : ((k < P.dim) ? 1.0 : 0.0);
+        const d2t* xg = reinterpret_cast<const d2t*>(xs) + lane;
+        lds_pair_ptr xl = (lds_pair_ptr)coords + lane;
+        WideEval<DP, G, true> ev{xg, xl, {P.V + so * P.v_stride + (long)lane * (1 + G)}, smem, st + kLsRows * kMaxDimPadded,
+                                 P.ntiles, P.wide_lds_tiles, P.cov_type, lane, P.mean};
+        unsigned long long n_val = 0, n_grad = 0;
+        const double fcur = line_search_lds<DP, G>(P, ev, st, x, n_val, n_grad);
+        if (lane == 0) P.best_value[so] = fcur;
+        tot_val += n_val;
+        tot_grad += n_grad;
+        if (lane < DP) {
+          double v = 0.0;
+  #pragma unroll
+          for (int k = 0; k < DP; ++k)
+            if (lane == k) v = x[k];
+          P.best_point[so * DP + lane] = v;
+        }
+      }
+      if (lane == 0 && (tot_val | tot_grad) != 0) {
+        atomicAdd(&P.counters[2 * e], tot_val);
+        atomicAdd(&P.counters[2 * e + 1], tot_grad);
+      }
+      if (gridDim.x >= (unsigned)P.E) break;
     }
-    if (lane == 0 && (tot_val | tot_grad) != 0) {
-      atomicAdd(&P.counters[2 * e], tot_val);
-      atomicAdd(&P.counters[2 * e + 1], tot_grad);
-    }
-    if (gridDim.x >= (unsigned)P.E) break;
   }
+};
+template <int DP, int G>
+__global__ __launch_bounds__(512) void kg_mc_stream_kernel(KgMcParams P) {
+  kg_mc_stream_kernel_body<DP, G>::run(MOE_VBLOCK, MOE_VGRID, nullptr, P);
 }
 
 template <int DP, int G>
 inline void launch_stream_inst(const KgMcParams& P, int blocks, int waves, size_t shm, hipStream_t s) {
   auto kern = kg_mc_stream_kernel<DP, G>;
   MOE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
-  MOE_LAUNCH(kern, dim3(blocks), dim3(waves * 64), shm, s, P);
+  launch_kernel_ens<kg_mc_stream_kernel_body<DP, G>, 512>(kern, dim3(blocks), dim3(waves * 64), shm, s, P);
   MOE_HIP_CHECK(hipGetLastError());
 }
 
@@ -2819,176 +2831,182 @@ __device__ __forceinline__ void point_weights_pre(const KgMcParams& P, const dou
 constexpr int kBlockFixed = kExpTabLen + 2 * kMaxMB + 2 * kMaxBlockWaves * kPartLen + 2 + kMaxBlockWaves * kLsRows * kMaxDimPadded;
 
 template <int DP, int G, int TR>
-__global__ __launch_bounds__(512) void kg_mc_block_kernel(KgMcParams P, int num_lds_tiles) {
-  extern __shared__ __attribute__((aligned(16))) double smem[];
-  // LDS: [64] exp table | z / beta scratch of draw_z_beta [0, 2 kMaxM) = [0, kMaxMB), beta of the sample [kMaxMB, 2 kMaxMB) |
-  //      partial slots [2][8][kPartLen] | control words (2 doubles) |
-  //      line-search state [8][kLsRows kMaxDimPadded] | coordinates of the LDS tiles [T_L][DP][64] | their weights [T_L][1+G][64]
-  double* etab = smem;
-  double* zb = smem + kExpTabLen;
-  double* part = zb + 2 * kMaxMB;
-  int* ctl = reinterpret_cast<int*>(part + 2 * kMaxBlockWaves * kPartLen);  // [0] sample index, [1] best discretised point
-  double* stw = part + 2 * kMaxBlockWaves * kPartLen + 2 + (threadIdx.x >> 6) * (kLsRows * kMaxDimPadded);
-  double* ldsx = smem + kBlockFixed;
-  double* ldsw = ldsx + (long)num_lds_tiles * DP * 64;
-  const int lane = threadIdx.x & 63;
-  const int wave = threadIdx.x >> 6;
-  const int nw = blockDim.x >> 6;
-  const int m = P.m;
-  const int size = P.dim - P.f;
-  // LDS tiles [0, T_L) are dealt to the waves in contiguous runs; register tiles are T_L + wave * TR + t
-  const int TL = num_lds_tiles;
-  const int per = (TL + nw - 1) / nw;
-  const int tl0 = min(wave * per, TL), tl1 = min(tl0 + per, TL);
-  if (threadIdx.x < kExpTabLen) etab[threadIdx.x] = kExp2Tab64[threadIdx.x];
-  BlockEval<DP, G, TR> ev;
-  ev.xl = ldsx + (long)tl0 * DP * 64 + lane;
-  ev.wl = ldsw + (long)tl0 * (1 + G) * 64 + lane;
-  ev.ntl = tl1 - tl0;
-  ev.etab = etab;
-  ev.part = part;
-  ev.inv_lp = P.inv_lp;
-  ev.mean = P.mean;
-  ev.nw = nw;
-  ev.wave = wave;
-  ev.lane = lane;
-  ev.cov_type = P.cov_type;
-  ev.par = 0;
-  for (int e = blockIdx.x % P.E; e < P.E; e += (gridDim.x < (unsigned)P.E ? gridDim.x : P.E)) {
-    const double* tab = P.XsTab + (long)e * P.tab_stride;
-    const double* rec = P.blob + (long)e * P.rec.stride;
-    const double* Lsm = rec + P.rec.L;
-    const double* We = P.W + (long)e * P.w_stride;
-    __syncthreads();  // previous evaluation's readers of the LDS coordinates are done
-    if constexpr (DP > 16) {  // (the table of the wide dimensions holds its rows in pairs: WideEval)
-      for (int t = threadIdx.x; t < TL * DP * 64; t += blockDim.x) {
-        const int l = t & 63, r = (t >> 6) % DP, tile = (t >> 6) / DP;
-        ldsx[t] = tab[(((long)tile * (DP / 2) + (r >> 1)) * 64 + l) * 2 + (r & 1)];
-      }
-    } else {
-      for (int t = threadIdx.x; t < TL * DP * 64; t += blockDim.x) ldsx[t] = tab[t];
-    }
-#pragma unroll
-    for (int t = 0; t < TR; ++t) {
-      const int tile = TL + wave * TR + t;
-#pragma unroll
-      for (int k = 0; k < DP; ++k) ev.cx[t][k] = (tile < P.ntiles) ? tab[((long)tile * DP + k) * 64 + lane] : 0.0;
-    }
-#if MOE_BLOCK_PROF
-    unsigned long long p_tick = 0, p_setup = 0, p_w = 0, p_ls = 0, p_zb = 0, p_scan = 0;
-#endif
-    while (true) {
-      MOE_PROF_T(k0);
-      if (threadIdx.x == 0) ctl[0] = (int)atomicAdd(&P.next_sample[(long)e * kTicketStride], 1u);
-      __syncthreads();
-      const int sl = ctl[0];
-      if (sl >= P.num_local) break;
-      const int s = P.first_sample + sl;
-      double zc = 0.0, bc = 0.0;
-      MOE_PROF_T(k1);
-      if (wave == 0) {
-        MOE_PROF_T(k1a0);
-        if (P.best_j != nullptr) {
-          // beta and the discretised-set winner depend on z alone: a pre-pass computed them for every sample with the whole
-          // chip (here they cost one wavefront 10 % of the sample while seven wait at the barrier)
-          const long so0 = (long)e * P.num_local + sl;
-          for (int c = lane; c < kMaxMB; c += 64) zb[kMaxMB + c] = (c < m) ? P.beta[so0 * m + c] : 0.0;
-          if (lane == 0) ctl[1] = P.best_j[so0];
-        } else {  // (m <= 64 only: one lane per component)
-          draw_z_beta(P, Lsm, s, lane, zb, zc, bc);
-          zb[kMaxMB + lane] = bc;
-          zb[kMaxMB + 64 + lane] = 0.0;
-          const int bj = discrete_scan(P, rec, zb, lane);
-          if (lane == 0) ctl[1] = bj;
+struct kg_mc_block_kernel_body {
+  static __device__ __forceinline__ void run(const VIdx blockIdx, const VIdx gridDim, const void*, const KgMcParams& P, int num_lds_tiles) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    // LDS: [64] exp table | z / beta scratch of draw_z_beta [0, 2 kMaxM) = [0, kMaxMB), beta of the sample [kMaxMB, 2 kMaxMB) |
+    //      partial slots [2][8][kPartLen] | control words (2 doubles) |
+    //      line-search state [8][kLsRows kMaxDimPadded] | coordinates of the LDS tiles [T_L][DP][64] | their weights [T_L][1+G][64]
+    double* etab = smem;
+    double* zb = smem + kExpTabLen;
+    double* part = zb + 2 * kMaxMB;
+    int* ctl = reinterpret_cast<int*>(part + 2 * kMaxBlockWaves * kPartLen);  // [0] sample index, [1] best discretised point
+    double* stw = part + 2 * kMaxBlockWaves * kPartLen + 2 + (threadIdx.x >> 6) * (kLsRows * kMaxDimPadded);
+    double* ldsx = smem + kBlockFixed;
+    double* ldsw = ldsx + (long)num_lds_tiles * DP * 64;
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int nw = blockDim.x >> 6;
+    const int m = P.m;
+    const int size = P.dim - P.f;
+    // LDS tiles [0, T_L) are dealt to the waves in contiguous runs; register tiles are T_L + wave * TR + t
+    const int TL = num_lds_tiles;
+    const int per = (TL + nw - 1) / nw;
+    const int tl0 = min(wave * per, TL), tl1 = min(tl0 + per, TL);
+    if (threadIdx.x < kExpTabLen) etab[threadIdx.x] = kExp2Tab64[threadIdx.x];
+    BlockEval<DP, G, TR> ev;
+    ev.xl = ldsx + (long)tl0 * DP * 64 + lane;
+    ev.wl = ldsw + (long)tl0 * (1 + G) * 64 + lane;
+    ev.ntl = tl1 - tl0;
+    ev.etab = etab;
+    ev.part = part;
+    ev.inv_lp = P.inv_lp;
+    ev.mean = P.mean;
+    ev.nw = nw;
+    ev.wave = wave;
+    ev.lane = lane;
+    ev.cov_type = P.cov_type;
+    ev.par = 0;
+    for (int e = blockIdx.x % P.E; e < P.E; e += (gridDim.x < (unsigned)P.E ? gridDim.x : P.E)) {
+      const double* tab = P.XsTab + (long)e * P.tab_stride;
+      const double* rec = P.blob + (long)e * P.rec.stride;
+      const double* Lsm = rec + P.rec.L;
+      const double* We = P.W + (long)e * P.w_stride;
+      __syncthreads();  // previous evaluation's readers of the LDS coordinates are done
+      if constexpr (DP > 16) {  // (the table of the wide dimensions holds its rows in pairs: WideEval)
+        for (int t = threadIdx.x; t < TL * DP * 64; t += blockDim.x) {
+          const int l = t & 63, r = (t >> 6) % DP, tile = (t >> 6) / DP;
+          ldsx[t] = tab[(((long)tile * (DP / 2) + (r >> 1)) * 64 + l) * 2 + (r & 1)];
         }
-        MOE_PROF_T(k1a);
-        MOE_PROF_T(k1b);
-        (void)zc;
-        MOE_PROF_ADD(p_zb, k1a0, k1a);
-        MOE_PROF_ADD(p_scan, k1a, k1b);
+      } else {
+        for (int t = threadIdx.x; t < TL * DP * 64; t += blockDim.x) ldsx[t] = tab[t];
       }
-      __syncthreads();
-      MOE_PROF_T(k2);
-      // ---- weights of this wave's points for this sample: LDS tiles into the LDS slab, register tiles into registers ----
-      {
-        double* wdst = ldsw + (long)tl0 * (1 + G) * 64 + lane;
-        if (P.V != nullptr) {
-          const double* Vs = P.V + ((long)e * P.num_local + sl) * P.v_stride;
-#pragma unroll 2
-          for (int t = tl0; t < tl1; ++t) {
-            double w[1 + G];
-            point_weights_pre<G>(P, Vs, zb, t * 64 + lane, w);
-#pragma unroll
-            for (int a = 0; a < 1 + G; ++a) wdst[a * 64] = w[a];  // read back only by this lane
-            wdst += (1 + G) * 64;
+  #pragma unroll
+      for (int t = 0; t < TR; ++t) {
+        const int tile = TL + wave * TR + t;
+  #pragma unroll
+        for (int k = 0; k < DP; ++k) ev.cx[t][k] = (tile < P.ntiles) ? tab[((long)tile * DP + k) * 64 + lane] : 0.0;
+      }
+  #if MOE_BLOCK_PROF
+      unsigned long long p_tick = 0, p_setup = 0, p_w = 0, p_ls = 0, p_zb = 0, p_scan = 0;
+  #endif
+      while (true) {
+        MOE_PROF_T(k0);
+        if (threadIdx.x == 0) ctl[0] = (int)atomicAdd(&P.next_sample[(long)e * kTicketStride], 1u);
+        __syncthreads();
+        const int sl = ctl[0];
+        if (sl >= P.num_local) break;
+        const int s = P.first_sample + sl;
+        double zc = 0.0, bc = 0.0;
+        MOE_PROF_T(k1);
+        if (wave == 0) {
+          MOE_PROF_T(k1a0);
+          if (P.best_j != nullptr) {
+            // beta and the discretised-set winner depend on z alone: a pre-pass computed them for every sample with the whole
+            // chip (here they cost one wavefront 10 % of the sample while seven wait at the barrier)
+            const long so0 = (long)e * P.num_local + sl;
+            for (int c = lane; c < kMaxMB; c += 64) zb[kMaxMB + c] = (c < m) ? P.beta[so0 * m + c] : 0.0;
+            if (lane == 0) ctl[1] = P.best_j[so0];
+          } else {  // (m <= 64 only: one lane per component)
+            draw_z_beta(P, Lsm, s, lane, zb, zc, bc);
+            zb[kMaxMB + lane] = bc;
+            zb[kMaxMB + 64 + lane] = 0.0;
+            const int bj = discrete_scan(P, rec, zb, lane);
+            if (lane == 0) ctl[1] = bj;
           }
-#pragma unroll
-          for (int t = 0; t < TR; ++t) point_weights_pre<G>(P, Vs, zb, (TL + wave * TR + t) * 64 + lane, ev.cw[t]);
-        } else {
-#pragma unroll 1
-          for (int t = tl0; t < tl1; ++t) {
-            double w[1 + G];
-            point_weights<G>(P, We, zb, t * 64 + lane, w);
-#pragma unroll
-            for (int a = 0; a < 1 + G; ++a) wdst[a * 64] = w[a];  // read back only by this lane
-            wdst += (1 + G) * 64;
+          MOE_PROF_T(k1a);
+          MOE_PROF_T(k1b);
+          (void)zc;
+          MOE_PROF_ADD(p_zb, k1a0, k1a);
+          MOE_PROF_ADD(p_scan, k1a, k1b);
+        }
+        __syncthreads();
+        MOE_PROF_T(k2);
+        // ---- weights of this wave's points for this sample: LDS tiles into the LDS slab, register tiles into registers ----
+        {
+          double* wdst = ldsw + (long)tl0 * (1 + G) * 64 + lane;
+          if (P.V != nullptr) {
+            const double* Vs = P.V + ((long)e * P.num_local + sl) * P.v_stride;
+  #pragma unroll 2
+            for (int t = tl0; t < tl1; ++t) {
+              double w[1 + G];
+              point_weights_pre<G>(P, Vs, zb, t * 64 + lane, w);
+  #pragma unroll
+              for (int a = 0; a < 1 + G; ++a) wdst[a * 64] = w[a];  // read back only by this lane
+              wdst += (1 + G) * 64;
+            }
+  #pragma unroll
+            for (int t = 0; t < TR; ++t) point_weights_pre<G>(P, Vs, zb, (TL + wave * TR + t) * 64 + lane, ev.cw[t]);
+          } else {
+  #pragma unroll 1
+            for (int t = tl0; t < tl1; ++t) {
+              double w[1 + G];
+              point_weights<G>(P, We, zb, t * 64 + lane, w);
+  #pragma unroll
+              for (int a = 0; a < 1 + G; ++a) wdst[a * 64] = w[a];  // read back only by this lane
+              wdst += (1 + G) * 64;
+            }
+  #pragma unroll
+            for (int t = 0; t < TR; ++t) point_weights<G>(P, We, zb, (TL + wave * TR + t) * 64 + lane, ev.cw[t]);
           }
-#pragma unroll
-          for (int t = 0; t < TR; ++t) point_weights<G>(P, We, zb, (TL + wave * TR + t) * 64 + lane, ev.cw[t]);
+        }
+        MOE_PROF_T(k3);
+        const int best_j = ctl[1];
+        const double* disc = rec + P.rec.disc;
+        double x[DP];
+  #pragma unroll
+        for (int k = 0; k < DP; ++k) x[k] = (k < size) ? disc[(long)best_j * size + k] : ((k < P.dim) ? 1.0 : 0.0);
+        unsigned long long n_val = 0, n_grad = 0;
+        const double fcur = line_search_lds<DP, G>(P, ev, stw, x, n_val, n_grad);
+        MOE_PROF_T(k4);
+        MOE_PROF_ADD(p_tick, k0, k1);
+        MOE_PROF_ADD(p_setup, k1, k2);
+        MOE_PROF_ADD(p_w, k2, k3);
+        MOE_PROF_ADD(p_ls, k3, k4);
+        if (wave == 0) {
+          const long so = (long)e * P.num_local + sl;
+          if (lane == 0) {
+            P.best_value[so] = fcur;
+            atomicAdd(&P.counters[2 * e], n_val);
+            atomicAdd(&P.counters[2 * e + 1], n_grad);
+          }
+          if (lane < DP) {
+            double v = 0.0;
+  #pragma unroll
+            for (int k = 0; k < DP; ++k)
+              if (lane == k) v = x[k];
+            P.best_point[so * DP + lane] = v;
+          }
+          if (P.best_j == nullptr && lane < m) P.beta[so * m + lane] = bc;  // (the pre-pass already stored it)
         }
       }
-      MOE_PROF_T(k3);
-      const int best_j = ctl[1];
-      const double* disc = rec + P.rec.disc;
-      double x[DP];
-#pragma unroll
-      for (int k = 0; k < DP; ++k) x[k] = (k < size) ? disc[(long)best_j * size + k] : ((k < P.dim) ? 1.0 : 0.0);
-      unsigned long long n_val = 0, n_grad = 0;
-      const double fcur = line_search_lds<DP, G>(P, ev, stw, x, n_val, n_grad);
-      MOE_PROF_T(k4);
-      MOE_PROF_ADD(p_tick, k0, k1);
-      MOE_PROF_ADD(p_setup, k1, k2);
-      MOE_PROF_ADD(p_w, k2, k3);
-      MOE_PROF_ADD(p_ls, k3, k4);
-      if (wave == 0) {
-        const long so = (long)e * P.num_local + sl;
-        if (lane == 0) {
-          P.best_value[so] = fcur;
-          atomicAdd(&P.counters[2 * e], n_val);
-          atomicAdd(&P.counters[2 * e + 1], n_grad);
-        }
-        if (lane < DP) {
-          double v = 0.0;
-#pragma unroll
-          for (int k = 0; k < DP; ++k)
-            if (lane == k) v = x[k];
-          P.best_point[so * DP + lane] = v;
-        }
-        if (P.best_j == nullptr && lane < m) P.beta[so * m + lane] = bc;  // (the pre-pass already stored it)
+  #if MOE_BLOCK_PROF
+      if (threadIdx.x == 0) {  // wave 0's view: [0..3] ticket, z/beta/scan, weights, line search; [4..8] inside the passes
+        atomicAdd(&P.prof[0], p_tick);
+        atomicAdd(&P.prof[1], p_setup);
+        atomicAdd(&P.prof[2], p_w);
+        atomicAdd(&P.prof[3], p_ls);
+        atomicAdd(&P.prof[4], ev.c_acc);
+        atomicAdd(&P.prof[5], ev.c_red);
+        atomicAdd(&P.prof[6], ev.c_bar);
+        atomicAdd(&P.prof[7], ev.c_post);
+        atomicAdd(&P.prof[8], ev.c_n);
+        atomicAdd(&P.prof[9], ev.c_gtot);
+        atomicAdd(&P.prof[10], ev.c_gn);
+        atomicAdd(&P.prof[11], p_zb);
+        atomicAdd(&P.prof[12], p_scan);
+        atomicAdd(&P.prof[13], ev.seg[0]);
+        atomicAdd(&P.prof[14], ev.seg[1]);
+        atomicAdd(&P.prof[15], ev.seg[2] + ev.seg[3]);
       }
+  #endif
+      if (gridDim.x >= (unsigned)P.E) break;
     }
-#if MOE_BLOCK_PROF
-    if (threadIdx.x == 0) {  // wave 0's view: [0..3] ticket, z/beta/scan, weights, line search; [4..8] inside the passes
-      atomicAdd(&P.prof[0], p_tick);
-      atomicAdd(&P.prof[1], p_setup);
-      atomicAdd(&P.prof[2], p_w);
-      atomicAdd(&P.prof[3], p_ls);
-      atomicAdd(&P.prof[4], ev.c_acc);
-      atomicAdd(&P.prof[5], ev.c_red);
-      atomicAdd(&P.prof[6], ev.c_bar);
-      atomicAdd(&P.prof[7], ev.c_post);
-      atomicAdd(&P.prof[8], ev.c_n);
-      atomicAdd(&P.prof[9], ev.c_gtot);
-      atomicAdd(&P.prof[10], ev.c_gn);
-      atomicAdd(&P.prof[11], p_zb);
-      atomicAdd(&P.prof[12], p_scan);
-      atomicAdd(&P.prof[13], ev.seg[0]);
-      atomicAdd(&P.prof[14], ev.seg[1]);
-      atomicAdd(&P.prof[15], ev.seg[2] + ev.seg[3]);
-    }
-#endif
-    if (gridDim.x >= (unsigned)P.E) break;
   }
+};
+template <int DP, int G, int TR>
+__global__ __launch_bounds__(512) void kg_mc_block_kernel(KgMcParams P, int num_lds_tiles) {
+  kg_mc_block_kernel_body<DP, G, TR>::run(MOE_VBLOCK, MOE_VGRID, nullptr, P, num_lds_tiles);
 }
 
 template <int DP, int G, int TR>
@@ -2996,7 +3014,7 @@ inline void launch_block_inst(const KgMcParams& P, int num_lds_tiles, int blocks
   const size_t shm = sizeof(double) * (kBlockFixed + (size_t)num_lds_tiles * (DP + 1 + G) * 64);
   auto kern = kg_mc_block_kernel<DP, G, TR>;
   MOE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
-  MOE_LAUNCH(kern, dim3(blocks), dim3(waves * 64), shm, s, P, num_lds_tiles);
+  launch_kernel_ens<kg_mc_block_kernel_body<DP, G, TR>, 512>(kern, dim3(blocks), dim3(waves * 64), shm, s, P, num_lds_tiles);
   MOE_HIP_CHECK(hipGetLastError());
 }
 
@@ -3032,7 +3050,7 @@ template <int DP, int G, bool XLDS, bool SMALL>
 inline void launch_inst2(const KgMcParams& P, int blocks, int waves, size_t shm, hipStream_t s) {
   auto kern = kg_mc_kernel<DP, G, XLDS, SMALL>;
   MOE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
-  MOE_LAUNCH(kern, dim3(blocks), dim3(waves * 64), shm, s, P);
+  launch_kernel_ens<kg_mc_kernel_body<DP, G, XLDS, SMALL>, (SMALL ? 1024 : 512)>(kern, dim3(blocks), dim3(waves * 64), shm, s, P);
   MOE_HIP_CHECK(hipGetLastError());
 }
 
