@@ -72,77 +72,83 @@ __device__ __forceinline__ void sum_partials_body(const double* __restrict__ par
   }
 }
 
-__global__ __launch_bounds__(256) void ei_mc_kernel(EiParams P) {
-  constexpr int MU = kMaxUnionEi;
-  __shared__ double red[4];
-  __shared__ double red256[256];
-  __shared__ int s_last;
-  const long eoff = (long)blockIdx.y * P.blob_stride;  // this evaluation's record
-  P.mu += eoff;
-  P.L += eoff;
-  P.grad_mu += eoff;
-  P.gchol += eoff;
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  const bool active = i < P.num_mc;
-  const int u = P.u, d = P.d;
-  const int ncomp = 1 + (P.want_grad ? P.q * d : 0);
-  double z[MU];
-  double imp = 0.0;
-  int winner = u + 1;
-  if (active) {
-#pragma unroll
-    for (int j = 0; j < MU; ++j) z[j] = (j < u) ? P.normals[(long)i * u + j] : 0.0;
-#pragma unroll
-    for (int r = 0; r < MU; ++r) {
-      if (r < u) {
-        double y = P.mu[r];
-#pragma unroll
-        for (int c = 0; c < MU; ++c)
-          if (c <= r) y = fma(P.L[r + c * u], z[c], y);
-        const double t = P.best_so_far - y;
-        if (t > imp) {
-          imp = t;
-          winner = r;
+struct ei_mc_kernel_body {
+  static __device__ __forceinline__ void run(const VIdx blockIdx, const VIdx gridDim, const void*, const EiParams& P_in) {
+    EiParams P = P_in;  // (the record pointers below are moved to this evaluation's record)
+    constexpr int MU = kMaxUnionEi;
+    __shared__ double red[4];
+    __shared__ double red256[256];
+    __shared__ int s_last;
+    const long eoff = (long)blockIdx.y * P.blob_stride;  // this evaluation's record
+    P.mu += eoff;
+    P.L += eoff;
+    P.grad_mu += eoff;
+    P.gchol += eoff;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool active = i < P.num_mc;
+    const int u = P.u, d = P.d;
+    const int ncomp = 1 + (P.want_grad ? P.q * d : 0);
+    double z[MU];
+    double imp = 0.0;
+    int winner = u + 1;
+    if (active) {
+  #pragma unroll
+      for (int j = 0; j < MU; ++j) z[j] = (j < u) ? P.normals[(long)i * u + j] : 0.0;
+  #pragma unroll
+      for (int r = 0; r < MU; ++r) {
+        if (r < u) {
+          double y = P.mu[r];
+  #pragma unroll
+          for (int c = 0; c < MU; ++c)
+            if (c <= r) y = fma(P.L[r + c * u], z[c], y);
+          const double t = P.best_so_far - y;
+          if (t > imp) {
+            imp = t;
+            winner = r;
+          }
         }
       }
     }
-  }
-  for (int comp = 0; comp < ncomp; ++comp) {
-    double contrib = 0.0;
-    if (active && imp > 0.0) {
-      if (comp == 0) {
-        contrib = imp;
-      } else {
-        const int k = (comp - 1) / d, dd = (comp - 1) % d;
-        double v = 0.0;
-        if (winner == k) v = -P.grad_mu[k * d + dd];
-        const double* g = P.gchol + (long)k * d * u * u + dd + (long)winner * d * u;
-#pragma unroll
-        for (int j = 0; j < MU; ++j)
-          if (j <= winner && j < u) v = fma(-g[j * d], z[j], v);
-        contrib = v;
+    for (int comp = 0; comp < ncomp; ++comp) {
+      double contrib = 0.0;
+      if (active && imp > 0.0) {
+        if (comp == 0) {
+          contrib = imp;
+        } else {
+          const int k = (comp - 1) / d, dd = (comp - 1) % d;
+          double v = 0.0;
+          if (winner == k) v = -P.grad_mu[k * d + dd];
+          const double* g = P.gchol + (long)k * d * u * u + dd + (long)winner * d * u;
+  #pragma unroll
+          for (int j = 0; j < MU; ++j)
+            if (j <= winner && j < u) v = fma(-g[j * d], z[j], v);
+          contrib = v;
+        }
       }
+      const double w = wave_sum_ei(contrib);
+      if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = w;
+      __syncthreads();
+      if (threadIdx.x == 0)
+        P.partial[((long)blockIdx.y * gridDim.x + blockIdx.x) * ncomp + comp] = (red[0] + red[1]) + (red[2] + red[3]);
+      __syncthreads();
     }
-    const double w = wave_sum_ei(contrib);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = w;
+    if (P.out == nullptr) return;
+    // the workgroup that arrives last adds the block sums up (r4: one launch less on the latency path; the order of the additions
+    // is fixed, whoever performs them)
+    if (threadIdx.x == 0) {
+      __threadfence();
+      const unsigned int t = atomicAdd(&P.ticket[blockIdx.y], 1u);
+      s_last = (t == gridDim.x - 1) ? 1 : 0;
+    }
     __syncthreads();
-    if (threadIdx.x == 0)
-      P.partial[((long)blockIdx.y * gridDim.x + blockIdx.x) * ncomp + comp] = (red[0] + red[1]) + (red[2] + red[3]);
-    __syncthreads();
-  }
-  if (P.out == nullptr) return;
-  // the workgroup that arrives last adds the block sums up (r4: one launch less on the latency path; the order of the additions
-  // is fixed, whoever performs them)
-  if (threadIdx.x == 0) {
+    if (!s_last) return;
     __threadfence();
-    const unsigned int t = atomicAdd(&P.ticket[blockIdx.y], 1u);
-    s_last = (t == gridDim.x - 1) ? 1 : 0;
+    sum_partials_body(P.partial + (long)blockIdx.y * gridDim.x * ncomp, (int)gridDim.x, ncomp, P.out + (long)blockIdx.y * ncomp, red256);
+    if (threadIdx.x == 0) P.ticket[blockIdx.y] = 0u;
   }
-  __syncthreads();
-  if (!s_last) return;
-  __threadfence();
-  sum_partials_body(P.partial + (long)blockIdx.y * gridDim.x * ncomp, (int)gridDim.x, ncomp, P.out + (long)blockIdx.y * ncomp, red256);
-  if (threadIdx.x == 0) P.ticket[blockIdx.y] = 0u;
+};
+__global__ __launch_bounds__(256) void ei_mc_kernel(EiParams P) {
+  ei_mc_kernel_body::run(MOE_VBLOCK, MOE_VGRID, nullptr, P);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -262,195 +268,203 @@ __device__ __forceinline__ void ei_grad_chol_lane(const EiStateParams& P, const 
 // (UM: the union-size class the factor-derivative recursion is unrolled for -- one kernel per class: with all three classes in one
 //  kernel the register allocation and the scratch spills of the 16 x 16 class were paid by every call)
 template <bool FUSED, int UM>
-__global__ __launch_bounds__(256) void ei_state_kernel(EiStateParams P) {
-  __shared__ double Ls[kMaxUnionEi * kMaxUnionEi];
-  __shared__ int s_bad;
-  extern __shared__ __attribute__((aligned(16))) double ei_sm[];  // FUSED: Gs [c][c] | eks [c] | ys [N] | Vs [c][N] | Es [c][N]
-  __shared__ double Us[kMaxUnionEi * kMaxDimPadded];
-  const int e = blockIdx.x, lane = threadIdx.x;
-  const int u = P.u, d = P.d, c = u + P.nd * d;
-  const double* G = P.gram + (long)e * c * c;
-  const double* ek_k = P.ek + (long)e * u;
-  const double* ek_g = P.ek + (long)P.E * u + (long)e * P.nd * d;
-  MOE_EI_T(0);
-  if constexpr (FUSED) {
-    const int N = P.N, ng = P.nd * d;
-    double* Gs = ei_sm;
-    double* eks = Gs + c * c;
-    double* ys = eks + c;
-    double* Vs = ys + N;
-    double* Es = Vs + (long)c * N;
-    // every global load of a batch is issued before the first LDS store (a store straight behind its load makes each step wait for
-    // its own round trip of 2 - 3 us); the first batch carries the union points and K^-1 (y - mean) along, so a state of up to
-    // 256 x 24 entries -- C2 with its gradient columns: 5000 -- costs ONE round trip
-    constexpr int NB = 24;
-    double uv[2], yv[4];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) uv[i] = P.U[(long)e * u * P.dp + min(lane + 256 * i, u * P.dp - 1)];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) yv[i] = P.KinvY[min(lane + 256 * i, N - 1)];
-    for (int t0 = 0; t0 < N * c; t0 += 256 * NB) {
-      double va[NB], ea[NB];
-#pragma unroll
-      for (int i = 0; i < NB; ++i) {
-        const int t = min(t0 + i * 256 + lane, N * c - 1);
-        const int l = t / N, k = t - l * N;
-        const long col = (l < u) ? ((long)e * u + l) : ((long)P.E * u + (long)e * ng + (l - u));  // columns grouped by kind (BatchLayout)
-        va[i] = P.V[k + col * N];
-        ea[i] = P.Emat[k + col * N];
-      }
-#pragma unroll
-      for (int i = 0; i < NB; ++i) {
-        const int t = t0 + i * 256 + lane;
-        if (t < N * c) {
-          Vs[t] = va[i];
-          Es[t] = ea[i];
+struct ei_state_kernel_body {
+  static __device__ __forceinline__ void run(const VIdx blockIdx, const VIdx gridDim, const void*, const EiStateParams& P) {
+    __shared__ double Ls[kMaxUnionEi * kMaxUnionEi];
+    __shared__ int s_bad;
+    extern __shared__ __attribute__((aligned(16))) double ei_sm[];  // FUSED: Gs [c][c] | eks [c] | ys [N] | Vs [c][N] | Es [c][N]
+    __shared__ double Us[kMaxUnionEi * kMaxDimPadded];
+    const int e = blockIdx.x, lane = threadIdx.x;
+    const int u = P.u, d = P.d, c = u + P.nd * d;
+    const double* G = P.gram + (long)e * c * c;
+    const double* ek_k = P.ek + (long)e * u;
+    const double* ek_g = P.ek + (long)P.E * u + (long)e * P.nd * d;
+    MOE_EI_T(0);
+    if constexpr (FUSED) {
+      const int N = P.N, ng = P.nd * d;
+      double* Gs = ei_sm;
+      double* eks = Gs + c * c;
+      double* ys = eks + c;
+      double* Vs = ys + N;
+      double* Es = Vs + (long)c * N;
+      // every global load of a batch is issued before the first LDS store (a store straight behind its load makes each step wait for
+      // its own round trip of 2 - 3 us); the first batch carries the union points and K^-1 (y - mean) along, so a state of up to
+      // 256 x 24 entries -- C2 with its gradient columns: 5000 -- costs ONE round trip
+      constexpr int NB = 24;
+      double uv[2], yv[4];
+  #pragma unroll
+      for (int i = 0; i < 2; ++i) uv[i] = P.U[(long)e * u * P.dp + min(lane + 256 * i, u * P.dp - 1)];
+  #pragma unroll
+      for (int i = 0; i < 4; ++i) yv[i] = P.KinvY[min(lane + 256 * i, N - 1)];
+      for (int t0 = 0; t0 < N * c; t0 += 256 * NB) {
+        double va[NB], ea[NB];
+  #pragma unroll
+        for (int i = 0; i < NB; ++i) {
+          const int t = min(t0 + i * 256 + lane, N * c - 1);
+          const int l = t / N, k = t - l * N;
+          const long col = (l < u) ? ((long)e * u + l) : ((long)P.E * u + (long)e * ng + (l - u));  // columns grouped by kind (BatchLayout)
+          va[i] = P.V[k + col * N];
+          ea[i] = P.Emat[k + col * N];
         }
-      }
-    }
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-      if (lane + 256 * i < u * P.dp) Us[lane + 256 * i] = uv[i];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-      if (lane + 256 * i < N) ys[lane + 256 * i] = yv[i];
-    for (int k = lane + 1024; k < N; k += 256) ys[k] = P.KinvY[k];
-    __syncthreads();
-    MOE_EI_T(1);
-    // one output per 8-lane group at a time (32 groups): lanes stride k with two accumulators, three in-group butterfly steps; the
-    // outputs are enumerated without gaps (the pairs, then the c entries of ek)
-    // Only the entries the algebra below reads: G(K*, K*) and G(dK*, K*) -- pairs (i <= j) with i < u; the dK* x dK* block (36 of the 55
-    // pairs at C2) is never used.
-    const int tri_u = u * (u + 1) / 2;
-    const int npair = tri_u + (c - u) * u;
-    const int gid = lane >> 3, gl = lane & 7;
-    for (int o = gid; o < npair + c; o += 32) {
-      const double *a, *b;
-      int i = 0, j = 0;
-      if (o < npair) {
-        if (o < tri_u) {
-          int rem = o;
-          while (rem > j) {  // column j of the upper triangle holds j + 1 pairs
-            rem -= j + 1;
-            ++j;
+  #pragma unroll
+        for (int i = 0; i < NB; ++i) {
+          const int t = t0 + i * 256 + lane;
+          if (t < N * c) {
+            Vs[t] = va[i];
+            Es[t] = ea[i];
           }
-          i = rem;
-        } else {
-          const int o2 = o - tri_u;
-          j = u + o2 / u;
-          i = o2 - (j - u) * u;
-        }
-        a = Vs + (long)i * N;
-        b = Vs + (long)j * N;
-      } else {
-        i = o - npair;
-        a = Es + (long)i * N;
-        b = ys;
-      }
-      // (eight LDS reads per operand in flight: one read per step would make the loop a chain of LDS latencies)
-      double acc0 = 0.0, acc1 = 0.0;
-      int k = gl;
-      for (; k + 7 * 8 < N; k += 8 * 8) {
-        double av[8], bv[8];
-#pragma unroll
-        for (int t = 0; t < 8; ++t) {
-          av[t] = a[k + 8 * t];
-          bv[t] = b[k + 8 * t];
-        }
-#pragma unroll
-        for (int t = 0; t < 8; t += 2) {
-          acc0 = fma(av[t], bv[t], acc0);
-          acc1 = fma(av[t + 1], bv[t + 1], acc1);
         }
       }
-      for (; k < N; k += 8) acc0 = fma(a[k], b[k], acc0);
-      double acc = acc0 + acc1;
-#pragma unroll
-      for (int off = 4; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 8);
-      if (gl == 0) {
+  #pragma unroll
+      for (int i = 0; i < 2; ++i)
+        if (lane + 256 * i < u * P.dp) Us[lane + 256 * i] = uv[i];
+  #pragma unroll
+      for (int i = 0; i < 4; ++i)
+        if (lane + 256 * i < N) ys[lane + 256 * i] = yv[i];
+      for (int k = lane + 1024; k < N; k += 256) ys[k] = P.KinvY[k];
+      __syncthreads();
+      MOE_EI_T(1);
+      // one output per 8-lane group at a time (32 groups): lanes stride k with two accumulators, three in-group butterfly steps; the
+      // outputs are enumerated without gaps (the pairs, then the c entries of ek)
+      // Only the entries the algebra below reads: G(K*, K*) and G(dK*, K*) -- pairs (i <= j) with i < u; the dK* x dK* block (36 of the 55
+      // pairs at C2) is never used.
+      const int tri_u = u * (u + 1) / 2;
+      const int npair = tri_u + (c - u) * u;
+      const int gid = lane >> 3, gl = lane & 7;
+      for (int o = gid; o < npair + c; o += 32) {
+        const double *a, *b;
+        int i = 0, j = 0;
         if (o < npair) {
-          Gs[i + j * c] = acc;
-          Gs[j + i * c] = acc;
+          if (o < tri_u) {
+            int rem = o;
+            while (rem > j) {  // column j of the upper triangle holds j + 1 pairs
+              rem -= j + 1;
+              ++j;
+            }
+            i = rem;
+          } else {
+            const int o2 = o - tri_u;
+            j = u + o2 / u;
+            i = o2 - (j - u) * u;
+          }
+          a = Vs + (long)i * N;
+          b = Vs + (long)j * N;
         } else {
-          eks[i] = acc;
+          i = o - npair;
+          a = Es + (long)i * N;
+          b = ys;
+        }
+        // (eight LDS reads per operand in flight: one read per step would make the loop a chain of LDS latencies)
+        double acc0 = 0.0, acc1 = 0.0;
+        int k = gl;
+        for (; k + 7 * 8 < N; k += 8 * 8) {
+          double av[8], bv[8];
+  #pragma unroll
+          for (int t = 0; t < 8; ++t) {
+            av[t] = a[k + 8 * t];
+            bv[t] = b[k + 8 * t];
+          }
+  #pragma unroll
+          for (int t = 0; t < 8; t += 2) {
+            acc0 = fma(av[t], bv[t], acc0);
+            acc1 = fma(av[t + 1], bv[t + 1], acc1);
+          }
+        }
+        for (; k < N; k += 8) acc0 = fma(a[k], b[k], acc0);
+        double acc = acc0 + acc1;
+  #pragma unroll
+        for (int off = 4; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 8);
+        if (gl == 0) {
+          if (o < npair) {
+            Gs[i + j * c] = acc;
+            Gs[j + i * c] = acc;
+          } else {
+            eks[i] = acc;
+          }
         }
       }
+      __syncthreads();
+      MOE_EI_T(2);
+      G = Gs;
+      ek_k = eks;
+      ek_g = eks + u;
+    }
+    // the union points in LDS: the distance loops below (runtime trip count d, two loads per step) otherwise pay a memory round trip
+    // per step -- 16 of them in a row in the factor-derivative part at C2
+    if constexpr (!FUSED) {
+      for (int t = lane; t < u * P.dp; t += 256) Us[t] = P.U[(long)e * u * P.dp + t];
+      __syncthreads();
+    }
+    const double* U = Us;
+    double* r = P.blob + (long)e * P.rec;
+    if (lane == 0) s_bad = 0;
+    if (lane < u) r[P.o_mu + lane] = P.mean + ek_k[lane];  // host_mean
+    for (int idx = lane; idx < u * u; idx += 256) {         // host_variance, + 1e-6 on the diagonal (gpp_math.cpp:2000-2002)
+      const int i = idx % u, j = idx / u;
+      double r2 = 0.0;
+      for (int k = 0; k < d; ++k) {
+        const double df = U[i * P.dp + k] - U[j * P.dp + k];
+        r2 = fma(df * df, P.cp.inv_l2[k], r2);
+      }
+      double v = radial_scalars(P.cp.type, P.cp.alpha, r2).base - G[i + (long)j * c];
+      if (i == j) v += 1.0e-6;
+      Ls[i + j * u] = v;
     }
     __syncthreads();
-    MOE_EI_T(2);
-    G = Gs;
-    ek_k = eks;
-    ek_g = eks + u;
-  }
-  // the union points in LDS: the distance loops below (runtime trip count d, two loads per step) otherwise pay a memory round trip
-  // per step -- 16 of them in a row in the factor-derivative part at C2
-  if constexpr (!FUSED) {
-    for (int t = lane; t < u * P.dp; t += 256) Us[t] = P.U[(long)e * u * P.dp + t];
-    __syncthreads();
-  }
-  const double* U = Us;
-  double* r = P.blob + (long)e * P.rec;
-  if (lane == 0) s_bad = 0;
-  if (lane < u) r[P.o_mu + lane] = P.mean + ek_k[lane];  // host_mean
-  for (int idx = lane; idx < u * u; idx += 256) {         // host_variance, + 1e-6 on the diagonal (gpp_math.cpp:2000-2002)
-    const int i = idx % u, j = idx / u;
-    double r2 = 0.0;
-    for (int k = 0; k < d; ++k) {
-      const double df = U[i * P.dp + k] - U[j * P.dp + k];
-      r2 = fma(df * df, P.cp.inv_l2[k], r2);
+    MOE_EI_T(3);
+    // host_cholesky (ComputeCholeskyFactorL, gpp_linear_algebra.cpp:109-148): lane = row
+    for (int k = 0; k < u; ++k) {
+      const double akk = Ls[k + k * u];
+      if (!(akk > 1.0e-16)) {
+        if (lane == 0) s_bad = k + 1;
+        break;
+      }
+      const double lkk = sqrt(akk);
+      __syncthreads();
+      if (lane == k) Ls[k + k * u] = lkk;
+      if (lane > k && lane < u) Ls[lane + k * u] = Ls[lane + k * u] / lkk;
+      __syncthreads();
+      for (int j = k + 1; j < u; ++j)
+        if (lane >= j && lane < u) Ls[lane + j * u] = Ls[lane + j * u] - Ls[lane + k * u] * Ls[j + k * u];
+      __syncthreads();
     }
-    double v = radial_scalars(P.cp.type, P.cp.alpha, r2).base - G[i + (long)j * c];
-    if (i == j) v += 1.0e-6;
-    Ls[i + j * u] = v;
-  }
-  __syncthreads();
-  MOE_EI_T(3);
-  // host_cholesky (ComputeCholeskyFactorL, gpp_linear_algebra.cpp:109-148): lane = row
-  for (int k = 0; k < u; ++k) {
-    const double akk = Ls[k + k * u];
-    if (!(akk > 1.0e-16)) {
-      if (lane == 0) s_bad = k + 1;
-      break;
+    __syncthreads();
+    if (lane == 0) P.flags[e] = (double)s_bad;
+    if (s_bad != 0) return;
+    for (int idx = lane; idx < u * u; idx += 256) {
+      const int i = idx % u, j = idx / u;
+      r[P.o_L + idx] = (j <= i) ? Ls[idx] : 0.0;
     }
-    const double lkk = sqrt(akk);
-    __syncthreads();
-    if (lane == k) Ls[k + k * u] = lkk;
-    if (lane > k && lane < u) Ls[lane + k * u] = Ls[lane + k * u] / lkk;
-    __syncthreads();
-    for (int j = k + 1; j < u; ++j)
-      if (lane >= j && lane < u) Ls[lane + j * u] = Ls[lane + j * u] - Ls[lane + k * u] * Ls[j + k * u];
-    __syncthreads();
+    MOE_EI_T(4);
+    if (!P.want_grad) return;
+    for (int idx = lane; idx < P.nd * d; idx += 256) r[P.o_gmu + idx] = ek_g[idx];  // host_grad_mean
+    // host_grad_cholesky_per_point for every differentiated point k; lane = dimension dd (independent recursions), each in a
+    // lane-private u x u array (registers for u <= 4 / 8) written to the record once
+    // (r4: one lane per (point, dimension) pair -- nd d independent recursions -- instead of one per dimension looping over the points)
+    for (int t = lane; t < P.nd * d; t += 256) {
+      const int k = t / d, dd = t - k * d;
+      double* gc = r + P.o_gc + (long)k * d * u * u;
+      ei_grad_chol_lane<UM>(P, G, U, Ls, c, k, dd, gc);
+    }
+    MOE_EI_T(5);
   }
-  __syncthreads();
-  if (lane == 0) P.flags[e] = (double)s_bad;
-  if (s_bad != 0) return;
-  for (int idx = lane; idx < u * u; idx += 256) {
-    const int i = idx % u, j = idx / u;
-    r[P.o_L + idx] = (j <= i) ? Ls[idx] : 0.0;
-  }
-  MOE_EI_T(4);
-  if (!P.want_grad) return;
-  for (int idx = lane; idx < P.nd * d; idx += 256) r[P.o_gmu + idx] = ek_g[idx];  // host_grad_mean
-  // host_grad_cholesky_per_point for every differentiated point k; lane = dimension dd (independent recursions), each in a
-  // lane-private u x u array (registers for u <= 4 / 8) written to the record once
-  // (r4: one lane per (point, dimension) pair -- nd d independent recursions -- instead of one per dimension looping over the points)
-  for (int t = lane; t < P.nd * d; t += 256) {
-    const int k = t / d, dd = t - k * d;
-    double* gc = r + P.o_gc + (long)k * d * u * u;
-    ei_grad_chol_lane<UM>(P, G, U, Ls, c, k, dd, gc);
-  }
-  MOE_EI_T(5);
+};
+template <bool FUSED, int UM>
+__global__ __launch_bounds__(256) void ei_state_kernel(EiStateParams P) {
+  ei_state_kernel_body<FUSED, UM>::run(MOE_VBLOCK, MOE_VGRID, nullptr, P);
 }
+
+}  // namespace
 
 bool ei_device_algebra() {  // MOE_EI_DEVICE_ALGEBRA=0: the host-algebra path (two syncs per call; A/B runs and tests)
   const char* v = std::getenv("MOE_EI_DEVICE_ALGEBRA");
   return !(v && *v == '0');
 }
 
-}  // namespace
-
-void ei_evaluate_batch(GpDev& gp, const double* Xq_all, int num_evals, const double* Xp, int q, int p, int num_mc,
-                       double best_so_far, const double* normals, double* ei, double* grad_ei) {
+// r6: the evaluation in two halves -- everything that is ENQUEUED (recordable: launch.hpp), and the collection of the results once the
+// stream has run -- so that the members of a GP ensemble can share their launches (mcmc.hip: ei_mcmc_batch).
+EiPending ei_launch(GpDev& gp, const double* Xq_all, int num_evals, const double* Xp, int q, int p, int num_mc, double best_so_far,
+                    const double* normals, bool want_value, bool want_grad) {
   gp.use_device();
   hipStream_t s = gp.stream;
   const int d = gp.d, u = q + p, E = num_evals;
@@ -459,7 +473,6 @@ void ei_evaluate_batch(GpDev& gp, const double* Xq_all, int num_evals, const dou
   if (E <= 0) throw Error(MOE_ERR_BOUNDS, "num_evals must be positive", E, 1, 1e9);
   if (u > kMaxUnionEi) throw Error(MOE_ERR_BOUNDS, "q + p > 16 is not supported by the device kernels", u, 1, kMaxUnionEi);
   if (num_mc <= 0) throw Error(MOE_ERR_BOUNDS, "num_mc must be positive", num_mc, 1, 1e12);
-  const bool want_grad = grad_ei != nullptr;
   std::vector<double> U_all((size_t)E * u * d);
   for (int e = 0; e < E; ++e) {
     std::copy(Xq_all + (size_t)e * q * d, Xq_all + (size_t)(e + 1) * q * d, &U_all[(size_t)e * u * d]);
@@ -517,26 +530,23 @@ void ei_evaluate_batch(GpDev& gp, const double* Xq_all, int num_evals, const dou
     sp.KinvY = gp.dKinvY.p;
     const int cst = u + (want_grad ? q : 0) * d;
     const size_t shm = se.fused ? sizeof(double) * ((size_t)cst * cst + cst + gp.N + 2 * (size_t)cst * gp.N) : 0;
-    auto launch_state = [&](auto kern) {
-      if (shm > 48 * 1024)
-        MOE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
-      MOE_LAUNCH(kern, dim3(E), dim3(256), shm, s, sp);
-    };
+#define MOE_EI_STATE(FUSED, UM)                                                                                                      \
+  {                                                                                                                                \
+    auto kern = ei_state_kernel<FUSED, UM>;                                                                                        \
+    if (shm > 48 * 1024)                                                                                                           \
+      MOE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm)); \
+    launch_kernel_ens<ei_state_kernel_body<FUSED, UM>, 256>(kern, dim3(E), dim3(256), shm, s, sp);                                 \
+  }
     if (se.fused) {
-      if (u <= 4)
-        launch_state(ei_state_kernel<true, 4>);
-      else if (u <= 8)
-        launch_state(ei_state_kernel<true, 8>);
-      else
-        launch_state(ei_state_kernel<true, kMaxUnionEi>);
+      if (u <= 4) MOE_EI_STATE(true, 4)
+      else if (u <= 8) MOE_EI_STATE(true, 8)
+      else MOE_EI_STATE(true, kMaxUnionEi)
     } else {
-      if (u <= 4)
-        launch_state(ei_state_kernel<false, 4>);
-      else if (u <= 8)
-        launch_state(ei_state_kernel<false, 8>);
-      else
-        launch_state(ei_state_kernel<false, kMaxUnionEi>);
+      if (u <= 4) MOE_EI_STATE(false, 4)
+      else if (u <= 8) MOE_EI_STATE(false, 8)
+      else MOE_EI_STATE(false, kMaxUnionEi)
     }
+#undef MOE_EI_STATE
     MOE_HIP_CHECK(hipGetLastError());
   } else {
   gp.hKgIn.reserve(rec * E + n_norm);
@@ -572,7 +582,7 @@ void ei_evaluate_batch(GpDev& gp, const double* Xq_all, int num_evals, const dou
   // non-zero counter would keep every later call from electing its last workgroup -- so such a call is followed by a clear
   if (gp.kEiTicket.cap < (size_t)E || gp.ei_ticket_dirty) {
     gp.kEiTicket.reserve((size_t)E);
-    MOE_HIP_CHECK(hipMemsetAsync(gp.kEiTicket.p, 0, sizeof(unsigned int) * gp.kEiTicket.cap, s));
+    memset_async(gp.kEiTicket.p, 0, sizeof(unsigned int) * gp.kEiTicket.cap, s);
   }
   gp.ei_ticket_dirty = true;
   EiParams P;
@@ -591,12 +601,17 @@ void ei_evaluate_batch(GpDev& gp, const double* Xq_all, int num_evals, const dou
   P.blob_stride = (long)rec;
   P.out = dOut.p;
   P.ticket = gp.kEiTicket.p;
-  MOE_LAUNCH(ei_mc_kernel, dim3(blocks, E), dim3(256), 0, s, P);
+  launch_kernel_ens<ei_mc_kernel_body, 256>(ei_mc_kernel, dim3(blocks, E), dim3(256), 0, s, P);
   MOE_HIP_CHECK(hipGetLastError());
   const size_t n_down = (size_t)E * ncomp + (on_device ? (size_t)E : 0);
   gp.hKgOut.reserve(n_down);
   double* out = gp.hKgOut.p;
-  dOut.download(out, n_down, s);
+  copy_async(out, dOut.p, sizeof(double) * n_down, hipMemcpyDeviceToHost, s, true);  // (hKgOut: pinned)
+  GpDev* gpp = &gp;
+  EiPending pending;
+  pending.collect = [=](double* ei, double* grad_ei) {
+  GpDev& gp = *gpp;
+  gp.use_device();
   MOE_HIP_CHECK(hipStreamSynchronize(s));
   gp.ei_ticket_dirty = false;
 #if MOE_EI_PROF
@@ -616,9 +631,17 @@ void ei_evaluate_batch(GpDev& gp, const double* Xq_all, int num_evals, const dou
                     u, out[(size_t)E * ncomp + e]);
   for (int e = 0; e < E; ++e) {
     if (ei) ei[e] = out[(size_t)e * ncomp] / (double)num_mc;
-    if (want_grad)
+    if (want_grad && grad_ei)
       for (int c = 0; c < q * d; ++c) grad_ei[(size_t)e * q * d + c] = out[(size_t)e * ncomp + 1 + c] / (double)num_mc;
   }
+  };
+  (void)want_value;
+  return pending;
+}
+
+void ei_evaluate_batch(GpDev& gp, const double* Xq_all, int num_evals, const double* Xp, int q, int p, int num_mc,
+                       double best_so_far, const double* normals, double* ei, double* grad_ei) {
+  ei_launch(gp, Xq_all, num_evals, Xp, q, p, num_mc, best_so_far, normals, ei != nullptr, grad_ei != nullptr).collect(ei, grad_ei);
 }
 
 void ei_evaluate(GpDev& gp, const double* Xq, const double* Xp, int q, int p, int num_mc, double best_so_far,

@@ -16,6 +16,13 @@ void ei_evaluate(GpDev& gp, const double* Xq, const double* Xp, int q, int p, in
 // multistart axis): ei[num_evals], grad_ei[num_evals][q*dim] (either may be NULL).
 void ei_evaluate_batch(GpDev& gp, const double* Xq_all, int num_evals, const double* Xp, int q, int p, int num_mc,
                        double best_so_far, const double* normals, double* ei, double* grad_ei);
+// The same in two halves (r6): everything that is enqueued, and the collection of the results once the stream has run.
+struct EiPending {
+  std::function<void(double* ei, double* grad_ei)> collect;
+};
+EiPending ei_launch(GpDev& gp, const double* Xq_all, int num_evals, const double* Xp, int q, int p, int num_mc, double best_so_far,
+                    const double* normals, bool want_value, bool want_grad);
+bool ei_device_algebra();
 
 // Analytic 1,0-EI (OnePotentialSampleExpectedImprovementEvaluator, gpp_math.cpp:2195-2259) at `num_evals` single points
 // pts[num_evals][dim]: ei[num_evals], grad_ei[num_evals][dim] (either may be NULL).

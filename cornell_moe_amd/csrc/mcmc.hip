@@ -146,6 +146,11 @@ void release_retired(std::vector<Recorder>& recs) {
   }
 }
 
+struct RetireOnExit {  // (blocks the members' buffers outgrew while their launches were pending: back to the pool on every path)
+  std::vector<Recorder>& r;
+  ~RetireOnExit() { release_retired(r); }
+};
+
 }  // namespace
 
 // The per-member values of a batch, not yet added up (r5): what the ranks of a member-sharded optimisation exchange, so that every
@@ -187,10 +192,7 @@ void kg_mcmc_members(const std::vector<GpDev*>& gps, int num_fidelity, const moe
     // (recording is cheap -- no launch is issued -- and starting 16 host threads per evaluation costs more than it: 0.156 s per
     //  suggestion with them, 0.113 s without; MOE_MCMC_THREADS still sets the count for member-by-member launches)
     const size_t nthreads = ens ? 1 : std::min(gps.size(), (size_t)std::max(1, (mt && *mt) ? std::atoi(mt) : 16));
-    struct Retire {  // (blocks the members' buffers outgrew while their launches were pending: back to the pool on every path)
-      std::vector<Recorder>& r;
-      ~Retire() { release_retired(r); }
-    } retire{recs};
+    RetireOnExit retire{recs};
     if (nthreads <= 1) {
       for (size_t i = 0; i < gps.size(); ++i) issue(i);
     } else {
@@ -330,7 +332,47 @@ void ei_mcmc_batch(const std::vector<GpDev*>& gps, const double* Xq_all, int num
   if (ei) std::fill(ei, ei + E, 0.0);
   if (grad_ei) std::fill(grad_ei, grad_ei + (size_t)E * qd, 0.0);
   std::vector<double> es(ei ? E : 0), gs(grad_ei ? (size_t)E * qd : 0);
-  for (size_t i = 0; i < gps.size(); ++i) {
+  // r6: ensemble-wide launches for the Monte-Carlo EI as for KG (kg_mcmc_members): the members' chains recorded, then every kernel issued
+  // once for all of them; the same bits as the loop below.
+  static thread_local std::map<long, int> ens_misses;
+  const long ens_key = ((long)gps[0]->N * 4096 + (long)(q + p) * 64 + (grad_ei ? 1 : 0)) * 64 + (long)gps.size();
+  bool ens = !analytic && ei_device_algebra() && ensemble_launches() && gps.size() > 1 && ens_misses[ens_key] < 2;
+  for (size_t i = 1; i < gps.size() && ens; ++i) ens = gps[i]->device == gps[0]->device;
+  if (ens) {
+    std::vector<Recorder> recs(gps.size());
+    std::vector<EiPending> pending(gps.size());
+    RetireOnExit retire{recs};
+    for (size_t i = 0; i < gps.size(); ++i) {
+      Recorder::Scope scope(&recs[i]);
+      pending[i] = ei_launch(*gps[i], Xq_all, E, Xp, q, p, num_mc, best_so_far[i], normals, ei != nullptr, grad_ei != nullptr);
+    }
+    EnsArena arena{gps[0]->hEns, gps[0]->dEns};
+    gps[0]->use_device();
+    hipStream_t z = gps[0]->stream;
+    int merged = 0;
+    if (replay_ensemble(recs, z, arena, &merged)) {
+      MOE_HIP_CHECK(hipStreamSynchronize(z));
+      ens_misses[ens_key] = 0;
+      g_ens_stats[0] += 1;
+      g_ens_stats[2] += 1 + merged + ((long long)recs[0].ops.size() - merged) * (long long)gps.size();
+      g_ens_stats[3] += (long long)recs[0].ops.size() * (long long)gps.size();
+    } else {
+      ++ens_misses[ens_key];
+      g_ens_stats[1] += 1;
+      for (size_t i = 0; i < gps.size(); ++i) {
+        gps[i]->use_device();
+        for (const LaunchOp& op : recs[i].ops) op.run(gps[i]->stream);
+      }
+    }
+    for (size_t i = 0; i < gps.size(); ++i) {
+      pending[i].collect(ei ? es.data() : nullptr, grad_ei ? gs.data() : nullptr);
+      if (ei)
+        for (int e = 0; e < E; ++e) ei[e] += es[e];
+      if (grad_ei)
+        for (size_t j = 0; j < (size_t)E * qd; ++j) grad_ei[j] += gs[j];
+    }
+  }
+  for (size_t i = 0; i < gps.size() && !ens; ++i) {
     if (analytic)
       ei_analytic_batch(*gps[i], Xq_all, E, best_so_far[i], ei ? es.data() : nullptr, grad_ei ? gs.data() : nullptr);
     else

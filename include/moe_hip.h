@@ -254,7 +254,7 @@ int moe_set_reference_quirks(int on);
 int moe_get_reference_quirks(void);
 /* Ensemble-wide launches (r6): the MCMC-averaged KG entry points (moe_kg_mcmc_batch, moe_kg_mcmc_multistart and their _comm
  * forms: KnowledgeGradientMCMCEvaluator, gpp_knowledge_gradient_mcmc_optimization.cpp:129-180, evaluates the ensemble members one
- * after another) record every member's chain of kernels and issue each kernel ONCE for all members of the ensemble; same bits as
+ * after another; and moe_ei_mcmc_batch / moe_ei_mcmc_multistart for Monte-Carlo EI) record every member's chain of kernels and issue each kernel ONCE for all members of the ensemble; same bits as
  * member-by-member launches.  moe_set_ensemble_launches(0) -> member by member (MOE_ENS_LAUNCH=0 in the environment does the same),
  * (1) -> on (the default), (-1) -> back to the environment.  moe_ensemble_launch_stats: out[0] = evaluations of an ensemble that
  * went down merged, out[1] = that fell back to member-by-member launches, out[2] = kernel launches issued by merged evaluations,
