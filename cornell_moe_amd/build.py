@@ -15,7 +15,7 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "build")
 LIB = os.path.join(HERE, "lib", "libmoe_hip.so")
 SOURCES = ["kernels_cov.hip", "kernels_linalg.hip", "host_math.hip", "gp.hip", "kg.hip", "kg_state.hip", "kg_mc_dp4.hip", "kg_mc_dp8.hip",
-           "kg_mc_dp12.hip", "kg_mc_dp16.hip", "kg_mc_dp24.hip", "kg_mc_dp32.hip", "multistart.hip", "mcmc.hip", "ei.hip", "api.hip", "rccl_comm.hip", "query_grad.hip"]
+           "kg_mc_dp12.hip", "kg_mc_dp16.hip", "kg_mc_dp4b.hip", "kg_mc_dp8b.hip", "kg_mc_dp12b.hip", "kg_mc_dp16b.hip", "kg_mc_dp24.hip", "kg_mc_dp32.hip", "multistart.hip", "mcmc.hip", "ei.hip", "api.hip", "rccl_comm.hip", "query_grad.hip"]
 HEADERS = ["common.hpp", "launch.hpp", "kernels.hpp", "gemm128.hpp", "device_cov.hpp", "fastmath.hpp", "host_math.hpp", "gp.hpp", "kg.hpp", "kg_mc.hpp", "kg_mc_lane.hpp", "kg_state.hpp",
            os.path.join("..", "..", "include", "moe_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function",

@@ -1,18 +1,12 @@
-// cornell_moe_amd/csrc/kg_mc_dp16.hip -- instantiations of the KG Monte-Carlo kernel (kg_mc.hpp) for padded dimension 16.
+// cornell_moe_amd/csrc/kg_mc_dp16.hip -- instantiations of the KG Monte-Carlo kernels (kg_mc.hpp) for padded dimension 16: the LDS-table wave-per-sample kernels
+// (frame and lane-parked line search); the workgroup-per-sample and streamed-weights kernels are in kg_mc_dp16b.hip (r6: two
+// translation units per dimension -- with the ensemble twins one unit took six minutes to compile).
 #include "kg_mc.hpp"
 
 namespace moe {
 
 void launch_kg_mc_dp16(const KgMcParams& P, int G, bool xlds, int blocks, int waves, size_t shm, hipStream_t s) {
   mc::launch_dp<16>(P, G, xlds, blocks, waves, shm, s);
-}
-
-void launch_kg_mc_block_dp16(const KgMcParams& P, int G, int tr, int num_lds_tiles, int blocks, int waves, hipStream_t s) {
-  mc::launch_block_dp<16>(P, G, tr, num_lds_tiles, blocks, waves, s);
-}
-
-void launch_kg_mc_stream_dp16(const KgMcParams& P, int G, int blocks, int waves, size_t shm, hipStream_t s) {
-  mc::launch_stream_dp<16>(P, G, blocks, waves, shm, s);
 }
 
 void launch_kg_mc_lane_dp16(const KgMcParams& P, int G, int rec_head, int blocks, int waves, size_t shm, hipStream_t s) {

@@ -1,0 +1,15 @@
+// cornell_moe_amd/csrc/kg_mc_dp8b.hip -- instantiations of the KG Monte-Carlo kernels (kg_mc.hpp) for padded dimension 8: the
+// workgroup-per-sample and the streamed-weights kernels (the LDS-table kernels are in kg_mc_dp8.hip).
+#include "kg_mc.hpp"
+
+namespace moe {
+
+void launch_kg_mc_block_dp8(const KgMcParams& P, int G, int tr, int num_lds_tiles, int blocks, int waves, hipStream_t s) {
+  mc::launch_block_dp<8>(P, G, tr, num_lds_tiles, blocks, waves, s);
+}
+
+void launch_kg_mc_stream_dp8(const KgMcParams& P, int G, int blocks, int waves, size_t shm, hipStream_t s) {
+  mc::launch_stream_dp<8>(P, G, blocks, waves, shm, s);
+}
+
+}  // namespace moe
