@@ -805,40 +805,56 @@ __global__ __launch_bounds__(WAVES * 64) void tri_skinny_n_kernel(int N, const d
 
 // C = T^T B:  one wavefront per column of T (contiguous), lanes stride down the rows from the 64-aligned row at or above
 // the diagonal, fixed-order butterfly at the end.
-template <int CB>
+// TJ (r6): a wavefront takes TJ consecutive columns of T (TJ | 64: they start at the same 64-aligned row) and reads every row of B once
+// for all of them -- with one column per wavefront the kernel issued 1 + CB loads per CB fmas and ran at the rate of the load pipe
+// (470 us for L^-T on 80 columns of 16 headline-sized GPs); an entry's summation order is that of the one-column form.
+template <int CB, int TJ = 1>
 struct tri_skinny_t_kernel_body {
   static __device__ __forceinline__ void run(const VIdx blockIdx, const VIdx gridDim, const void*, int N, const double* __restrict__ T, long ldt, const double* __restrict__ B, long ldb, int c, double* __restrict__ C, long ldc) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int j = blockIdx.x * 4 + w, c0 = blockIdx.y * CB;
-    if (j >= N) return;
-    const double* col = T + (long)j * ldt;
-    double acc[CB];
+    const int j0 = (blockIdx.x * 4 + w) * TJ, c0 = blockIdx.y * CB;
+    if (j0 >= N) return;
+    const double* col[TJ];
   #pragma unroll
-    for (int cc = 0; cc < CB; ++cc) acc[cc] = 0.0;
+    for (int t = 0; t < TJ; ++t) col[t] = T + (long)min(j0 + t, N - 1) * ldt;
+    double acc[TJ][CB];
+  #pragma unroll
+    for (int t = 0; t < TJ; ++t)
+  #pragma unroll
+      for (int cc = 0; cc < CB; ++cc) acc[t][cc] = 0.0;
     const double* Bc[CB];
   #pragma unroll
     for (int cc = 0; cc < CB; ++cc) Bc[cc] = B + (long)min(c0 + cc, c - 1) * ldb;
-  #pragma unroll 8
-    for (int i = (j & ~63) + lane; i < N; i += 64) {  // (unconditional loads, masked afterwards: see tri_skinny_n_kernel)
-      const double tv = col[i];
-      const double t = (i >= j) ? tv : 0.0;
+  #pragma unroll(TJ > 1 ? 2 : (CB > 8 ? 4 : 8))
+    for (int i = (j0 & ~63) + lane; i < N; i += 64) {  // (unconditional loads, masked afterwards: see tri_skinny_n_kernel)
+      double bv[CB];
   #pragma unroll
-      for (int cc = 0; cc < CB; ++cc) acc[cc] = fma(t, Bc[cc][i], acc[cc]);
+      for (int cc = 0; cc < CB; ++cc) bv[cc] = Bc[cc][i];
+  #pragma unroll
+      for (int t = 0; t < TJ; ++t) {
+        const double tv = col[t][i];
+        const double tm = (i >= j0 + t) ? tv : 0.0;
+  #pragma unroll
+        for (int cc = 0; cc < CB; ++cc) acc[t][cc] = fma(tm, bv[cc], acc[t][cc]);
+      }
     }
   #pragma unroll
-    for (int cc = 0; cc < CB; ++cc) {
-      double v = acc[cc];
+    for (int t = 0; t < TJ; ++t) {
   #pragma unroll
-      for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-      if (lane == 0 && c0 + cc < c) C[(long)j + (long)(c0 + cc) * ldc] = v;
+      for (int cc = 0; cc < CB; ++cc) {
+        double v = acc[t][cc];
+  #pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+        if (lane == 0 && c0 + cc < c && j0 + t < N) C[(long)(j0 + t) + (long)(c0 + cc) * ldc] = v;
+      }
     }
   }
 };
-template <int CB>
+template <int CB, int TJ = 1>
 __global__ __launch_bounds__(256) void tri_skinny_t_kernel(int N, const double* __restrict__ T, long ldt,
                                                           const double* __restrict__ B, long ldb, int c,
                                                           double* __restrict__ C, long ldc) {
-  tri_skinny_t_kernel_body<CB>::run(MOE_VBLOCK, MOE_VGRID, nullptr, N, T, ldt, B, ldb, c, C, ldc);
+  tri_skinny_t_kernel_body<CB, TJ>::run(MOE_VBLOCK, MOE_VGRID, nullptr, N, T, ldt, B, ldb, c, C, ldc);
 }
 
 template <int CB>
@@ -853,7 +869,14 @@ void launch_tri_skinny(char op, int N, int c, const double* T, long ldt, const d
       MOE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
     launch_kernel_ens<tri_skinny_n_kernel_body<CB, 16>, 1024>(kern, dim3((N + 63) / 64, groups), dim3(1024), shm, s, N, T, ldt, B, ldb, c, C, ldc);
   } else {
-    launch_kernel_ens<tri_skinny_t_kernel_body<CB>, 256>(tri_skinny_t_kernel<CB>, dim3((N + 3) / 4, groups), dim3(256), 0, s, N, T, ldt, B, ldb, c, C, ldc);
+    // (several columns of T per wavefront where the call has the columns of many evaluations: MOE_TRI_SKINNY_TJ=1: one, A/B runs)
+    const char* tjv = std::getenv("MOE_TRI_SKINNY_TJ");  // (read per call: tests/test_gpu_sweep.py compares the two forms)
+    const bool tj_on = !(tjv != nullptr && std::atoi(tjv) == 1);
+    if (CB >= 8 && tj_on)
+      launch_kernel_ens<tri_skinny_t_kernel_body<CB, 4>, 256>(tri_skinny_t_kernel<CB, 4>, dim3((N + 15) / 16, groups), dim3(256), 0, s, N, T, ldt, B, ldb,
+                                                              c, C, ldc);
+    else
+      launch_kernel_ens<tri_skinny_t_kernel_body<CB>, 256>(tri_skinny_t_kernel<CB>, dim3((N + 3) / 4, groups), dim3(256), 0, s, N, T, ldt, B, ldb, c, C, ldc);
   }
   MOE_HIP_CHECK(hipGetLastError());
 }
@@ -992,10 +1015,20 @@ void launch_tri_gemm_cols(char op, int N, int c, int cols_per_problem, const dou
     return;
   }
   if (cols_per_problem <= 16) {  // a handful of columns per problem: the row-strip / column-per-wavefront kernels
-    if (cols_per_problem <= 4)
+    // Columns per workgroup (r6: from the CALL's column count, up to 16).  A column's arithmetic does not depend on how many columns share
+    // its workgroup -- the same k ranges per wavefront, the same order of the partial sums -- so the grouping is free to follow the batch:
+    // an ensemble of 16 headline-sized GPs x 20 evaluations x 4 columns re-read every member's factor 20 times per product with groups
+    // of 4 (313 + 470 us per pair of products, a third of an optimiser step of the C3-sized suggestion).  MOE_TRI_SKINNY_CB = 4 / 8 / 16
+    // forces a group size (A/B runs; tests/test_gpu_sweep.py compares the results bit for bit).
+    const char* cbv = std::getenv("MOE_TRI_SKINNY_CB");
+    const int forced = (cbv && *cbv) ? std::atoi(cbv) : 0;
+    const int cb = (forced == 4 || forced == 8 || forced == 16) ? forced : (c <= 4 ? 4 : 8);  // (16: slower for either kernel, profiles/r06_af_*, r06_ah_*)
+    if (cb == 4)
       launch_tri_skinny<4>(op, N, c, T, ldt, B, ldb, C, ldc, s);
-    else
+    else if (cb == 8)
       launch_tri_skinny<8>(op, N, c, T, ldt, B, ldb, C, ldc, s);
+    else
+      launch_tri_skinny<16>(op, N, c, T, ldt, B, ldb, C, ldc, s);
     return;
   }
   int KS = 0;

@@ -536,3 +536,29 @@ def test_small_shape_exact_multi_trial_passes_agree(case, monkeypatch):
         assert a["kg_sum"] == b["kg_sum"] and np.array_equal(a["grad_sum"], b["grad_sum"]), domain
         assert np.array_equal(a["best_point"], b["best_point"]), domain
         assert a["grad_evals"] == b["grad_evals"] and a["mean_evals"] == b["mean_evals"], domain
+
+
+def test_skinny_triangular_products_do_not_depend_on_the_column_grouping(monkeypatch):
+    """r6: the skinny triangular products (L^-1 / L^-T on the few columns of K* per evaluation) take their columns 4, 8 or 16 per
+    workgroup by the size of the CALL; a column's arithmetic must not depend on it -- a batch of KG evaluations on a GP of several
+    hundred points, bit for bit under the three groupings, and equal to the evaluations made one at a time."""
+    from cornell_moe_amd import api
+    from cornell_moe_amd.workloads import make_workload
+    w = make_workload(seed=91, n=700, d=6, q=3, M=64, P=8, p=1)
+    G = api.DeviceGP(w.hyperparameters, w.X, w.y, w.noise, w.derivs)
+    rng = np.random.default_rng(5)
+    Xq_all = rng.uniform(0.05, 0.95, (7, w.q, w.d))
+    best = float(G.additional_mean(w.discrete).min())
+    res = {}
+    for cb in ("4", "8", "16", "", "one column of the factor per wavefront"):
+        monkeypatch.setenv("MOE_TRI_SKINNY_CB", cb if len(cb) <= 2 else "")
+        monkeypatch.setenv("MOE_TRI_SKINNY_TJ", "1" if len(cb) > 2 else "")
+        res[cb] = G.kg_batch(w.inner_gd, w.bounds, w.discrete, Xq_all, w.Xp, w.M, best, w.kg_normals)
+    monkeypatch.setenv("MOE_TRI_SKINNY_TJ", "")
+    for cb in ("8", "16", "", "one column of the factor per wavefront"):
+        assert np.array_equal(res["4"]["kg_sum"], res[cb]["kg_sum"]) and np.array_equal(res["4"]["grad_sum"], res[cb]["grad_sum"]), cb
+    assert np.all(np.isfinite(res[""]["kg_sum"])) and np.abs(res[""]["grad_sum"]).max() > 0
+    monkeypatch.setenv("MOE_TRI_SKINNY_CB", "")
+    for e in range(3):
+        one = G.kg_batch(w.inner_gd, w.bounds, w.discrete, Xq_all[e:e + 1], w.Xp, w.M, best, w.kg_normals)
+        assert one["kg_sum"][0] == res[""]["kg_sum"][e] and np.array_equal(one["grad_sum"][0], res[""]["grad_sum"][e])
