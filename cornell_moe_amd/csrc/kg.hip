@@ -37,6 +37,12 @@
 
 namespace moe {
 
+// how many ensemble members share the launches being recorded on this thread (mcmc.hip; kg_launch sizes its MC grid for its share)
+static thread_local int t_ens_members_hint = 1;
+int ensemble_members_hint() { return t_ens_members_hint; }
+void set_ensemble_members_hint(int members) { t_ens_members_hint = members > 1 ? members : 1; }
+
+
 namespace {
 
 __device__ __forceinline__ double wave_sum64(double v) {
@@ -1346,6 +1352,14 @@ KgPending kg_launch(GpDev& gp, int num_fidelity, const moe_gd_params_t& gd, cons
     // (only where it frees a fifth of the workgroups or more: 250 instead of 256 for one evaluation of 10 000 samples trades the
     //  ticket counter's slack for nothing -- 0.617 vs 0.598 ms)
     if (need >= 1 && need * 5 <= wpe * 4) blocks = (int)(need * E);
+  }
+  // r6: an evaluation that shares its launch with the other members of an ensemble (mcmc.hip sets the hint while it records) shares the
+  // chip with them, too: 16 members x 20 evaluations x 8 workgroups were ten rounds of workgroups whose wavefronts drew two samples
+  // each -- every workgroup ends on its slowest wavefront, a quarter of the kernel's time.  Four draws per wavefront there.
+  if (ensemble_members_hint() > 1 && variant != 1 && blocks >= E && waves > 0) {
+    const long tickets = env_int("MOE_KG_ENS_TICKETS", 4);
+    const long k = std::max<long>(1, (num_local + tickets * waves - 1) / (tickets * waves));
+    blocks = (int)std::min<long>(blocks, k * E);
   }
   blocks = env_int("MOE_KG_BLOCKS", blocks);
 

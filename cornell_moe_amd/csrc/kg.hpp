@@ -69,6 +69,9 @@ void set_reference_quirks(int on);  // < 0: back to the environment's setting
 bool ensemble_launches();
 void set_ensemble_launches(int on);  // < 0: back to the environment's setting (MOE_ENS_LAUNCH)
 void ensemble_launch_stats(long long* out4);
+// how many ensemble members share the launches being recorded on this thread (1: none) -- kg_launch sizes its MC grid for its share
+int ensemble_members_hint();
+void set_ensemble_members_hint(int members);
 // The exchange step of an outer optimisation that runs on several ranks (r5): an all-gather of `count` doubles per rank, every rank
 // receiving recv[world][count] in rank order.  One process per GPU passes torch.distributed's collective through the C ABI
 // (moe_comm_t: RCCL over xGMI, or gloo); one process driving several devices gets an in-memory exchange between its host threads

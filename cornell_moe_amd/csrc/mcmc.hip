@@ -183,6 +183,10 @@ void kg_mcmc_members(const std::vector<GpDev*>& gps, int num_fidelity, const moe
     bool ens = ensemble_launches() && gps.size() > 1 && ens_misses[ens_key] < 2;
     for (size_t i = 1; i < gps.size() && ens; ++i) ens = gps[i]->device == gps[0]->device;
     std::vector<Recorder> recs(ens ? gps.size() : 0);
+    struct Hint {
+      explicit Hint(int m) { set_ensemble_members_hint(m); }
+      ~Hint() { set_ensemble_members_hint(1); }
+    } hint(ens ? (int)gps.size() : 1);
     auto issue = [&](size_t i) {
       Recorder::Scope scope(ens ? &recs[i] : Recorder::current());
       pending[i] = kg_launch(*gps[i], num_fidelity, inner, bounds, discrete_all + i * disc_stride, P, Xq_all + (size_t)e0 * qd, ne, Xp, q,
