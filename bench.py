@@ -504,8 +504,19 @@ def side_configs(local_rank, log, c5_traffic=True):
         sec = timed(sug, 3, warm=1)
         out["suggest"] = {"workload": "one q-KG-MCMC suggestion: Branin n=30, 16 GPs, 200 starts -> 20, 50 steps x 2 restarts, M=128, q=4",
                           "s_per_suggestion": sec}
+        st = mapi.ensemble_launch_stats()   # (r6: every kernel issued once for all members of the ensemble, csrc/launch.hpp)
+        out["suggest"]["ensemble_launches"] = {"merged_evaluations": st[0], "member_by_member_evaluations": st[1],
+                                               "launches_issued": st[2], "member_launches_they_stand_for": st[3]}
+        del G
+        pb = suggest_problem("suggest_c3")   # the same optimiser on an ensemble of GPs of the headline size (n = 1000, d = 8)
+        G = mapi.DeviceGPMCMC(pb["hypers"], pb["noises"], pb["X"], pb["y"], (), device=local_rank)
+        best_all = np.array([float(g.additional_mean(pb["discrete_all"][i]).min()) for g, i in zip(G.gps, G.members)])
+        starts = np.stack([mapi.latin_hypercube(pb["uniform_seed"] + k, pb["bounds"], pb["outer_gd"][0]) for k in range(q)], axis=1)
+        sug3 = lambda: G.kg_multistart(pb["outer_gd"], pb["inner_gd"], pb["bounds"], pb["discrete_all"], starts, None, M, best_all, normals)  # noqa: E731
+        out["suggest_c3"] = {"workload": "the same suggestion on 16 GPs of the headline size (n=1000, d=8)", "s_per_suggestion": timed(sug3, 1, warm=1)}
     except Exception as e:  # pragma: no cover
-        out["suggest"] = {"error": "%s: %s" % (type(e).__name__, e)}
+        out.setdefault("suggest", {"error": "%s: %s" % (type(e).__name__, e)})
+        out.setdefault("suggest_c3", {"error": "%s: %s" % (type(e).__name__, e)})
     return out
 
 
@@ -916,7 +927,7 @@ def main():
             out["configs"]["C4"] = {"ms_per_64_restart_step": 1e3 * elapsed / args.steps,
                                     "note": "one step of this line IS the C4 job on %d GPU(s)" % world}
             out["configs"]["seconds_spent"] = time.perf_counter() - t_side
-            for key, field in (("C5", "evals_per_s"), ("C5", "frac"), ("suggest", "s_per_suggestion"), ("C2", "value_grad_us"), ("C1", "mean_1pt_us")):
+            for key, field in (("C5", "evals_per_s"), ("C5", "frac"), ("suggest", "s_per_suggestion"), ("suggest_c3", "s_per_suggestion"), ("C2", "value_grad_us"), ("C1", "mean_1pt_us")):
                 if field in out["configs"].get(key, {}):
                     out["%s_%s" % (key.lower(), field)] = out["configs"][key][field]
         if not args.no_cpu_baseline and world == 1 and args.config == "C5" and args.derivs is None:
