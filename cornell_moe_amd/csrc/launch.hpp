@@ -5,8 +5,9 @@
 // sample) runs that chain once per ensemble member and optimiser step -- 16 members x 25 kernels of 5-8 us each, dependent within a
 // member, and the device retires them at ~230 k kernels / s whichever stream or host thread issues them.  The members
 // run the SAME kernels with different operands.  So a member's chain can be recorded instead of launched -- every launch site of
-// the library goes through launch_kernel / launch_kernel_ens / copy_async / memset_async below, which append to the calling thread's
-// Recorder when one is active -- and the recordings of all members are then zipped position by position (mcmc.hip: replay_ensemble):
+// the library goes through MOE_LAUNCH / launch_kernel_ens / copy_async / memset_async below, which append to the calling thread's
+// Recorder when one is active -- and the recordings of all members are then zipped position by position (mcmc.hip: replay_ensemble;
+// the MCMC-averaged Monte-Carlo EI goes the same way):
 //   * a kernel that has an ENSEMBLE TWIN becomes ONE launch over all members: its body is a device function
 //     (Body::run(blockIdx, gridDim, argbase, args...): the built-in block coordinates are shadowed by parameters, so a body is the
 //     kernel's text unchanged), the twin reads member z's arguments from a table in device memory and runs the body on that member's
