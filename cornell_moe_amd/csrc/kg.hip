@@ -775,9 +775,154 @@ __global__ __launch_bounds__(256) void kg_fused_point_kernel(KgTailParams P, con
   kg_fused_point_kernel_body<DP, MU, COV>::run(MOE_VBLOCK, MOE_VGRID, nullptr, P, X, n);
 }
 
+// Both contractions of T in ONE pass (r6; m <= 4, d <= 8: the headline): every entry K(X_row, x*_i) is computed once and used for
+// the TB partial of its point AND the S_W partial of its sample (the two kernels above compute every entry twice).  A wavefront
+// is an 8 x 8 grid -- lane = 8 a + b: point slot a, sample slot b -- that walks the chunk's 128 samples eight at a time (si; the
+// sample's coordinates and beta in registers) against its 32 points eight at a time (pi; coordinates and the row of W from LDS):
+// the S_W sums of a sample live across the pi loop and are added up over the eight point slots once per si; the TB sums of the
+// 4 x 8 points live in registers (4 MU doubles per lane) across the whole walk and are added up over the eight sample slots once
+// per wavefront.  The eight wavefronts' S_W sums meet in LDS and are added in wavefront order: SWpart[e][i][point block][c], one
+// partial per 256 points, summed in block order by kg_fused_c_kernel.  Every order is fixed and a function of (n, num_local)
+// alone: an evaluation's bits do not depend on its batch.
+// Measured at C3 (64 evaluations per launch): 1.71 ms against 0.93 + 0.89 ms of the two kernels on the same box, not the 0.95 the
+// instruction count promises (46 VALU instructions per 64 entries): with both operands varying over the lanes every entry costs
+// 7.5 ds_read_b128 where the two-kernel forms read one broadcast row, and the LDS pipe (1.05 ms) and the vector ALU (0.81 ms)
+// overlap badly at four wavefronts per SIMD.  Forms tried and dropped (profiles/r06_aj_*): 64 points per wavefront on four
+// wavefronts (two per SIMD: 1.68 ms), two samples per lane against one point read (half the LDS traffic, 256 VGPRs: 1.99 ms),
+// the wavefront's points held in registers (no LDS reads in the loop, two wavefronts per SIMD: 2.05 ms).
+template <int DP, int MU, int COV>
+struct kg_fused_pair_kernel_body {
+  static constexpr int SB = kFusedChunk / 8;  // sample blocks of eight
+  static constexpr int SROW = DP + 2;         // row stride of the staged points: eight rows 16-byte aligned on distinct banks
+  static constexpr int NW = 8, PB = 4;        // wavefronts per workgroup, point blocks of eight per wavefront: 8 x 32 = 256 points
+  static __device__ __forceinline__ void run(const VIdx blockIdx, const VIdx gridDim, const void*, const KgTailParams& P, const double* __restrict__ X, int n, double* __restrict__ SWpart) {
+    static_assert(MU <= 4 && kFusedChunk == 128, "4 point blocks x MU sums per lane");
+    __shared__ double etab[kExpTabLen];
+    __shared__ __attribute__((aligned(16))) double St[kFusedChunk][SROW];
+    __shared__ __attribute__((aligned(16))) double Bt[kFusedChunk][MU];
+    __shared__ __attribute__((aligned(16))) double Xt[256][SROW];
+    __shared__ __attribute__((aligned(16))) double Wt[256][MU];
+    __shared__ double Sx[NW][kFusedChunk][MU];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int a = lane >> 3, b = lane & 7;
+    const int chunk = blockIdx.y, e = blockIdx.z, m = P.m, N = P.N;
+    const int i0 = chunk * P.chunk_len, cnt = min(P.num_local - i0, P.chunk_len);  // (chunk_len == kFusedChunk)
+    const long w0 = (long)e * P.num_local + i0;
+    const int row0 = blockIdx.x * 256;
+    if (threadIdx.x < kExpTabLen) etab[threadIdx.x] = kExp2Tab64[threadIdx.x];
+    for (int t = threadIdx.x; t < kFusedChunk * DP; t += 64 * NW) {
+      const int ii = t / DP, k = t % DP;
+      St[ii][k] = (ii < cnt) ? P.best_point[(w0 + ii) * DP + k] * P.cp.inv_l[k] : 0.0;
+    }
+    for (int t = threadIdx.x; t < kFusedChunk * MU; t += 64 * NW) {
+      const int ii = t / MU, c = t % MU;
+      Bt[ii][c] = (ii < cnt && c < m) ? P.beta[(w0 + ii) * m + c] : 0.0;  // zero beta: padded samples drop out of TB
+    }
+    for (int t = threadIdx.x; t < 256 * DP; t += 64 * NW) {
+      const int jj = t / DP, k = t % DP;
+      Xt[jj][k] = (row0 + jj < n) ? X[(long)(row0 + jj) * DP + k] * P.cp.inv_l[k] : 0.0;
+    }
+    {
+      const double* We = P.W + (long)e * P.w_stride;
+      for (int t = threadIdx.x; t < 256 * MU; t += 64 * NW) {
+        const int jj = t % 256, c = t / 256;  // W_e is [N x m] col-major: consecutive jj are contiguous
+        Wt[jj][c] = (row0 + jj < n && c < m) ? We[(long)c * N + row0 + jj] : 0.0;  // zero weight: padded points drop out of S_W
+      }
+    }
+    __syncthreads();
+    double tb[PB][MU];
+  #pragma unroll
+    for (int pi = 0; pi < PB; ++pi)
+  #pragma unroll
+      for (int c = 0; c < MU; ++c) tb[pi][c] = 0.0;
+    const int jw = wave * (8 * PB) + a;
+  #pragma unroll 1
+    for (int si = 0; si < SB; ++si) {
+      const int ii = si * 8 + b;
+      int hold = 0;
+      asm volatile("" : "+v"(hold));  // (an index the optimiser cannot see through: the point tile is READ per sample block -- kept in registers, 4 x 8 points
+                                      //  cost 80 VGPRs and with them half the wavefronts: 1.71 -> 2.05 ms per 64 evaluations at C3)
+      double xs[DP], bs[MU], sw[MU];
+  #pragma unroll
+      for (int k = 0; k < DP; ++k) xs[k] = St[ii][k];
+  #pragma unroll
+      for (int c = 0; c < MU; ++c) {
+        bs[c] = Bt[ii][c];
+        sw[c] = 0.0;
+      }
+  #pragma unroll
+      for (int pi = 0; pi < PB; ++pi) {
+        const int jj = jw + pi * 8 + hold;
+        double r2 = 1.0e-300;
+  #pragma unroll
+        for (int k = 0; k < DP; ++k) {
+          const double dlt = Xt[jj][k] - xs[k];
+          r2 = fma(dlt, dlt, r2);
+        }
+        const double t = radial_base<COV>(r2, etab);
+  #pragma unroll
+        for (int c = 0; c < MU; ++c) {
+          tb[pi][c] = fma(t, bs[c], tb[pi][c]);
+          sw[c] = fma(Wt[jj][c], t, sw[c]);
+        }
+      }
+      // S_W partial of sample ii over this wavefront's 32 points: the eight point slots added up (lanes b, b + 8, ...)
+  #pragma unroll
+      for (int c = 0; c < MU; ++c) {
+        double v = sw[c];
+        v += __shfl_xor(v, 8, 64);
+        v += __shfl_xor(v, 16, 64);
+        v += __shfl_xor(v, 32, 64);
+        if (a == 0) Sx[wave][ii][c] = v;
+      }
+    }
+    // TB partial of point jw + 8 pi: the eight sample slots added up (lanes 8 a .. 8 a + 7)
+    double* dst = P.TBpart + ((long)e * P.chunks + chunk) * m * N;
+  #pragma unroll
+    for (int pi = 0; pi < PB; ++pi)
+  #pragma unroll
+      for (int c = 0; c < MU; ++c) {
+        double v = tb[pi][c];
+        v += __shfl_xor(v, 1, 64);
+        v += __shfl_xor(v, 2, 64);
+        v += __shfl_xor(v, 4, 64);
+        const int row = row0 + jw + pi * 8;
+        if (b == 0 && c < m && row < n) dst[(long)c * N + row] = P.cp.alpha * v;
+      }
+    __syncthreads();
+    const int slices = gridDim.x;
+    for (int t = threadIdx.x; t < kFusedChunk * MU; t += 64 * NW) {
+      const int ii = t / MU, c = t % MU;
+      if (ii < cnt) {
+        double v = Sx[0][ii][c];
+  #pragma unroll
+        for (int wv = 1; wv < NW; ++wv) v += Sx[wv][ii][c];
+        SWpart[((w0 + ii) * slices + blockIdx.x) * MU + c] = v;
+      }
+    }
+  }
+};
+template <int DP, int MU, int COV>
+__global__ __launch_bounds__(512, 2) void kg_fused_pair_kernel(KgTailParams P, const double* __restrict__ X, int n, double* __restrict__ SWpart) {
+  kg_fused_pair_kernel_body<DP, MU, COV>::run(MOE_VBLOCK, MOE_VGRID, nullptr, P, X, n, SWpart);
+}
+
+// whether an evaluation's T-free tail takes the one-pass kernel (a function of its shape alone), and how many S_W partials a sample then has
+inline bool fused_tail_one_pass(int m, int dp) { return m <= 4 && dp <= 8 && env_int("MOE_KG_FUSED_ONE_PASS", 1) != 0; }
+
 template <int DP, int MU, int COV>
 void launch_fused_tail_cov(const KgTailParams& P, const double* X, int n, double* SWpart, int slices, hipStream_t s) {
   dim3 ga((P.num_local + 255) / 256, P.E, slices), gc((P.num_local + 255) / 256, P.E), gb((n + 255) / 256, P.chunks, P.E);
+  if constexpr (MU <= 4 && DP <= 8) {
+    if (fused_tail_one_pass(P.m, DP)) {  // (slices == gb.x: fused_tail_slices)
+      launch_kernel_ens<kg_fused_pair_kernel_body<DP, MU, COV>, 512, 2>(kg_fused_pair_kernel<DP, MU, COV>, gb, dim3(512), 0, s, P, X, n, SWpart);
+      launch_kernel_ens<kg_fused_c_kernel_body<DP, MU, COV>, 256>(kg_fused_c_kernel<DP, MU, COV>, gc, dim3(256), 0, s, P, SWpart, (int)gb.x);
+      launch_dir<DP>(P, s);
+      launch_gtb(P, s);
+      MOE_HIP_CHECK(hipGetLastError());
+      return;
+    }
+  }
   launch_kernel_ens<kg_fused_sample_kernel_body<DP, MU, COV>, 256>(kg_fused_sample_kernel<DP, MU, COV>, ga, dim3(256), 0, s, P, X, n, SWpart);
   launch_kernel_ens<kg_fused_c_kernel_body<DP, MU, COV>, 256>(kg_fused_c_kernel<DP, MU, COV>, gc, dim3(256), 0, s, P, SWpart, slices);
   launch_dir<DP>(P, s);
@@ -796,7 +941,8 @@ void launch_fused_tail_inst(const KgTailParams& P, const double* X, int n, doubl
 
 // number of point slices of kg_fused_sample_kernel: enough wavefronts for ~4 per SIMD when ONE evaluation runs alone.  It does not
 // depend on the batch size: the slices are summed in order, so an evaluation's bits would otherwise change with its batch.
-int fused_tail_slices(int /*E*/, int num_local, int n, int num_cu) {
+int fused_tail_slices(int /*E*/, int num_local, int n, int num_cu, int m, int dp) {
+  if (fused_tail_one_pass(m, dp)) return (n + 255) / 256;  // the one-pass kernel: one S_W partial per block of 256 points
   const long waves = (long)((num_local + 255) / 256) * 4;
   const long want = (long)num_cu * 4 * 4;
   int s = (int)std::min<long>(8, std::max<long>(1, (want + waves - 1) / waves));
@@ -1735,7 +1881,7 @@ KgPending kg_launch(GpDev& gp, int num_fidelity, const moe_gd_params_t& gd, cons
     t_cov.start(s);
     t_cov.stop(s);  // no covariance matrix is built on this path
     t_tail.start(s);
-    const int slices = fused_tail_slices(E, num_local, n, num_cu);
+    const int slices = fused_tail_slices(E, num_local, n, num_cu, m, dp);
     gp.kSW.reserve((size_t)E * num_local * slices * 8);  // [E][num_local][slices][MU <= 8]
     launch_fused_tail(tl, gp.dX.p, n, gp.kSW.p, slices, s);
     // (r4: m > 64 too -- one workgroup per entry of ZC walking every sample with a stride of m doubles took 1.8 ms per evaluation at m = 104)
