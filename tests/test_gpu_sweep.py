@@ -341,6 +341,32 @@ def test_fused_tail_matches_materialised_tail(monkeypatch):
         assert np.abs(a["grad_sum"] - b["grad_sum"]).max() <= 1e-11 * scale
 
 
+def test_one_pass_tail_matches_two_kernel_tail(monkeypatch):
+    """r6: for m <= 4 and d <= 8 the T-free tail computes every entry of T once, for both of its contractions, in one kernel
+    (kg_fused_pair_kernel) instead of once in each of two: same gradient to rounding (the partial sums of S_W and TB are taken in
+    another order), for point counts on either side of a 256-point block, sample counts on either side of a 128-sample chunk,
+    m in {1..4}, both kernels; and an evaluation's bits do not depend on the batch it is made in."""
+    from cornell_moe_amd import api
+    from cornell_moe_amd.workloads import make_workload
+    for seed, n, d, q, p, M, cov in ((160, 1000, 8, 4, 0, 700, 1), (161, 257, 2, 2, 2, 129, 0), (162, 30, 2, 4, 0, 128, 1),
+                                    (163, 600, 7, 3, 0, 500, 0), (164, 256, 4, 1, 0, 127, 1), (165, 513, 6, 1, 2, 384, 1)):
+        w = make_workload(seed=seed, n=n, d=d, q=q, M=M, P=7, derivs=(), p=p)
+        G = api.DeviceGP(w.hyperparameters, w.X, w.y, w.noise, (), cov_type=cov)
+        best = float(G.additional_mean(w.discrete).min())
+        Xp = w.Xp if p else None
+        rng = np.random.default_rng(seed)
+        Xq_all = np.concatenate([w.Xq[None], rng.uniform(0.05, 0.95, (2, q, d))])
+        monkeypatch.setenv("MOE_KG_FUSED_ONE_PASS", "0")
+        a = G.kg_batch(w.inner_gd, w.bounds, w.discrete, Xq_all, Xp, w.M, best, w.kg_normals)
+        monkeypatch.setenv("MOE_KG_FUSED_ONE_PASS", "1")
+        b = G.kg_batch(w.inner_gd, w.bounds, w.discrete, Xq_all, Xp, w.M, best, w.kg_normals)
+        assert np.array_equal(a["kg_sum"], b["kg_sum"])
+        scale = max(np.abs(a["grad_sum"]).max(), np.abs(a["kg_sum"]).max())
+        assert np.abs(a["grad_sum"]).max() > 0 and np.abs(a["grad_sum"] - b["grad_sum"]).max() <= 1e-12 * scale, (n, d, q, p, M)
+        one = G.kg_batch(w.inner_gd, w.bounds, w.discrete, Xq_all[1:2], Xp, w.M, best, w.kg_normals)
+        assert one["kg_sum"][0] == b["kg_sum"][1] and np.array_equal(one["grad_sum"][0], b["grad_sum"][1])
+
+
 def test_offset_and_rescaled_domain():
     """The MC kernel takes squared distances as |x|^2 + |q|^2 - 2 x.q in a frame centred on the training-set mean: a domain far
     from the origin (x in [1000, 1001] and [-50, -40]) and anisotropic scales must not cost accuracy against the oracle,
