@@ -15,7 +15,9 @@ namespace moe {
 
 namespace {
 
-constexpr int kMaxUnionEi = 16;
+constexpr int kMaxUnionEi = 16;      // union size (q + p) up to which the u x u algebra of an evaluation runs on the device (ei_state_kernel)
+constexpr int kMaxUnionEiWide = 64;  // r6: up to here the MC kernel is built (MU = 32 / 64); the u x u algebra of such a state runs on the host
+                                     // (host_math.hip -- this library's own code; two waits per call instead of one)
 #ifndef MOE_EI_PROF
 #define MOE_EI_PROF 0
 #endif
@@ -72,10 +74,12 @@ __device__ __forceinline__ void sum_partials_body(const double* __restrict__ par
   }
 }
 
+// MU: the union-size class the sample loop is unrolled for (16: every state the device algebra builds; 32 / 64: wider unions, whose
+// u x u algebra runs on the host, r6)
+template <int MU>
 struct ei_mc_kernel_body {
   static __device__ __forceinline__ void run(const VIdx blockIdx, const VIdx gridDim, const void*, const EiParams& P_in) {
     EiParams P = P_in;  // (the record pointers below are moved to this evaluation's record)
-    constexpr int MU = kMaxUnionEi;
     __shared__ double red[4];
     __shared__ double red256[256];
     __shared__ int s_last;
@@ -147,8 +151,9 @@ struct ei_mc_kernel_body {
     if (threadIdx.x == 0) P.ticket[blockIdx.y] = 0u;
   }
 };
+template <int MU>
 __global__ __launch_bounds__(256) void ei_mc_kernel(EiParams P) {
-  ei_mc_kernel_body::run(MOE_VBLOCK, MOE_VGRID, nullptr, P);
+  ei_mc_kernel_body<MU>::run(MOE_VBLOCK, MOE_VGRID, nullptr, P);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -471,7 +476,7 @@ EiPending ei_launch(GpDev& gp, const double* Xq_all, int num_evals, const double
   if (q <= 0) throw Error(MOE_ERR_BOUNDS, "num_to_sample must be positive", q, 1, 1e9);
   if (p < 0) throw Error(MOE_ERR_BOUNDS, "num_being_sampled must be non-negative", p, 0, 1e9);
   if (E <= 0) throw Error(MOE_ERR_BOUNDS, "num_evals must be positive", E, 1, 1e9);
-  if (u > kMaxUnionEi) throw Error(MOE_ERR_BOUNDS, "q + p > 16 is not supported by the device kernels", u, 1, kMaxUnionEi);
+  if (u > kMaxUnionEiWide) throw Error(MOE_ERR_BOUNDS, "q + p > 64 is not supported by the device kernels", u, 1, kMaxUnionEiWide);
   if (num_mc <= 0) throw Error(MOE_ERR_BOUNDS, "num_mc must be positive", num_mc, 1, 1e12);
   std::vector<double> U_all((size_t)E * u * d);
   for (int e = 0; e < E; ++e) {
@@ -486,7 +491,7 @@ EiPending ei_launch(GpDev& gp, const double* Xq_all, int num_evals, const double
   const size_t o_mu = 0, o_L = u, o_gmu = o_L + (size_t)u * u, o_gc = o_gmu + (size_t)q * d;
   const size_t rec = o_gc + (want_grad ? (size_t)q * d * u * u : 0);
   const size_t n_norm = (size_t)num_mc * u;
-  const bool on_device = ei_device_algebra();
+  const bool on_device = ei_device_algebra() && u <= kMaxUnionEi;
   const int ncomp = 1 + (want_grad ? q * d : 0);
   const int blocks = (num_mc + 255) / 256;
   DevBuf<double>& dBlobDev = gp.kBlob;
@@ -601,7 +606,12 @@ EiPending ei_launch(GpDev& gp, const double* Xq_all, int num_evals, const double
   P.blob_stride = (long)rec;
   P.out = dOut.p;
   P.ticket = gp.kEiTicket.p;
-  launch_kernel_ens<ei_mc_kernel_body, 256>(ei_mc_kernel, dim3(blocks, E), dim3(256), 0, s, P);
+  if (u <= 16)
+    launch_kernel_ens<ei_mc_kernel_body<16>, 256>(ei_mc_kernel<16>, dim3(blocks, E), dim3(256), 0, s, P);
+  else if (u <= 32)
+    launch_kernel_ens<ei_mc_kernel_body<32>, 256>(ei_mc_kernel<32>, dim3(blocks, E), dim3(256), 0, s, P);
+  else
+    launch_kernel_ens<ei_mc_kernel_body<64>, 256>(ei_mc_kernel<64>, dim3(blocks, E), dim3(256), 0, s, P);
   MOE_HIP_CHECK(hipGetLastError());
   const size_t n_down = (size_t)E * ncomp + (on_device ? (size_t)E : 0);
   gp.hKgOut.reserve(n_down);

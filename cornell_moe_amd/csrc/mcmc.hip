@@ -340,7 +340,7 @@ void ei_mcmc_batch(const std::vector<GpDev*>& gps, const double* Xq_all, int num
   // once for all of them; the same bits as the loop below.
   static thread_local std::map<long, int> ens_misses;
   const long ens_key = ((long)gps[0]->N * 4096 + (long)(q + p) * 64 + (grad_ei ? 1 : 0)) * 64 + (long)gps.size();
-  bool ens = !analytic && ei_device_algebra() && ensemble_launches() && gps.size() > 1 && ens_misses[ens_key] < 2;
+  bool ens = !analytic && ei_device_algebra() && q + p <= 16 && ensemble_launches() && gps.size() > 1 && ens_misses[ens_key] < 2;  // (wider unions wait on the host mid-way: ei.hip)
   for (size_t i = 1; i < gps.size() && ens; ++i) ens = gps[i]->device == gps[0]->device;
   if (ens) {
     std::vector<Recorder> recs(gps.size());

@@ -22,6 +22,8 @@
  *   - num_derivatives <= 12           (derivative-weight slots of the d-KG Monte-Carlo kernels: 0..4, 8, 12);
  *   - (num_to_sample + num_being_sampled) * (1 + num_derivatives) <= 128   (m, the fantasy-observation count of one evaluation);
  *   - |x - mean(X)| / length <= 1e5 per coordinate for every tabulated point (32-bit exponent arithmetic of the table exp).
+ * q,p-EI (moe_ei*): num_to_sample + num_being_sampled <= 64; up to 16 the whole evaluation stays on the device, beyond that its
+ *   u x u algebra (variance, factor, Smith's derivative) runs on the host between two waits (r6; it was refused).
  * Every configuration BASELINE.json names is inside them (C5 with all 12 derivatives observed: m = 104).  The GP itself
  * (moe_gp_*, moe_ll_*) is limited by device memory only (N = 26 000 builds in 0.3 s; two N x N matrices stay resident).
  */

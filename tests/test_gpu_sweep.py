@@ -292,7 +292,7 @@ def test_ei_batch_matches_single_evaluations_and_oracle():
 
 def test_limits_fail_loudly_and_ei_extremes():
     """Beyond the kernels' limits the C ABI reports BoundsException (never a silent fallback); at the limits q,p-EI still
-    matches the oracle (u = q + p = 16, one MC sample)."""
+    matches the oracle (u = q + p = 16, one MC sample; r6: u up to 64)."""
     from cornell_moe_amd import api
     from cornell_moe_amd.workloads import make_workload
     from oracle import orc
@@ -300,8 +300,9 @@ def test_limits_fail_loudly_and_ei_extremes():
     G = api.DeviceGP(w.hyperparameters, w.X, w.y, w.noise, w.derivs)
     with pytest.raises(api.BoundsException):   # m = 33 * 4 = 132 > 128
         G.kg(w.inner_gd, w.bounds, w.discrete, w.Xq, None, w.M, 0.0, w.kg_normals)
-    with pytest.raises(api.BoundsException):   # u = 33 > 16
-        G.ei(w.Xq, None, w.M, 0.0, w.ei_normals)
+    w65 = make_workload(seed=132, n=40, d=3, q=65, M=8, P=3, derivs=())
+    with pytest.raises(api.BoundsException):   # u = 65 > 64
+        G.ei(w65.Xq, None, w65.M, 0.0, w65.ei_normals)
     with pytest.raises(api.BoundsException):   # num_mc must be positive
         G.kg(w.inner_gd, w.bounds, w.discrete, w.Xq[:2], None, 0, 0.0, w.kg_normals)
     with pytest.raises(api.BoundsException):   # num_fidelity must leave at least one free dimension
@@ -310,8 +311,9 @@ def test_limits_fail_loudly_and_ei_extremes():
         w5 = make_workload(seed=131, n=20, d=13, q=1, M=8, P=3, derivs=tuple(range(13)))
         G5 = api.DeviceGP(w5.hyperparameters, w5.X, w5.y, w5.noise, w5.derivs)
         G5.kg(w5.inner_gd, w5.bounds, w5.discrete, w5.Xq, None, w5.M, 0.0, w5.kg_normals)
-    for q, p, M in ((16, 0, 1), (9, 7, 3), (1, 15, 64)):
-        w = make_workload(seed=140 + q, n=50, d=3, q=q, M=M, P=3, derivs=(), p=p)
+    # (r6: unions of 17 .. 64 points -- the MC kernel's 32- and 64-wide classes, the u x u algebra on the host)
+    for q, p, M in ((16, 0, 1), (9, 7, 3), (1, 15, 64), (4, 16, 200), (17, 0, 50), (8, 24, 300), (33, 0, 64), (5, 59, 128)):
+        w = make_workload(seed=140 + q, n=50 + 3 * p, d=3, q=q, M=M, P=3, derivs=(), p=p)
         O = orc.OrcGP(1, w.alpha, w.lengths, w.X, w.y, w.noise, ())
         G = api.DeviceGP(w.hyperparameters, w.X, w.y, w.noise, ())
         Xp = w.Xp if p else None
