@@ -369,11 +369,20 @@ void GpDev::mean_of_points(const double* pts, int k, double* mu, double* grad) {
   hStateIn.reserve((size_t)k * dp);
   for (int i = 0; i < k; ++i)
     for (int j = 0; j < dp; ++j) hStateIn.p[(size_t)i * dp + j] = (j < d) ? pts[(size_t)i * d + j] : 0.0;
-  dPts.upload(hStateIn.p, (size_t)k * dp, stream);
-  dE.reserve((size_t)k * wdt);
-  launch_mean(cp, dX.p, n, derivs, dKinvY.p, dPts.p, k, mean, want_grad, dE.p, stream);
   hStateOut.reserve((size_t)k * wdt);
-  dE.download(hStateOut.p, (size_t)k * wdt, stream);
+  // r6, the latency path (compute_posterior_mean one candidate at a time): the kernel reads the few query points from the pinned
+  // staging buffer and writes its results into the pinned result buffer -- pinned host memory is device-visible -- so the call is ONE
+  // kernel and one wait instead of copy + kernel + copy (C1: 23.5 -> see profiles/r06_al_*).  Larger queries keep the copies: a
+  // workgroup re-reads nothing of its point, but k x (1 + dp) doubles over PCIe in single stores stop paying.  MOE_GP_ZERO_COPY=0: copies.
+  static const bool zero_copy_on = !(std::getenv("MOE_GP_ZERO_COPY") && std::getenv("MOE_GP_ZERO_COPY")[0] == '0');
+  if (zero_copy_on && k <= 64 && Recorder::current() == nullptr) {
+    launch_mean(cp, dX.p, n, derivs, dKinvY.p, hStateIn.p, k, mean, want_grad, hStateOut.p, stream);
+  } else {
+    dPts.upload(hStateIn.p, (size_t)k * dp, stream);
+    dE.reserve((size_t)k * wdt);
+    launch_mean(cp, dX.p, n, derivs, dKinvY.p, dPts.p, k, mean, want_grad, dE.p, stream);
+    dE.download(hStateOut.p, (size_t)k * wdt, stream);
+  }
   MOE_HIP_CHECK(hipStreamSynchronize(stream));
   for (int i = 0; i < k; ++i) {
     mu[i] = hStateOut.p[(size_t)i * wdt];
