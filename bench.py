@@ -483,6 +483,18 @@ def side_configs(local_rank, log, c5_traffic=True):
                      "frac": flops / (mc_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS, "bound": "fp64_valu", "peak_tflops": FP64_PEAK_TFLOPS,
                      "value_passes_per_sample": S, "grad_passes_per_sample": Gp,
                      "weight_table_bytes_per_eval": 8.0 * w.M * ((w.n + w.q + 63) // 64) * 64 * (1 + w.g), "traffic_bytes_per_eval": None}
+        try:   # the same evaluations eight per call (a multistart's batch): the state's and the tail's triangular products read L^-1 once per CALL
+            w8 = make_workload("C5", num_restarts=8)
+            call8 = lambda: G.kg_batch(w8.inner_gd, w8.bounds, w8.discrete, w8.Xq_restarts, None, w8.M, best, w8.kg_normals)  # noqa: E731
+            call8()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(2):
+                call8()
+            torch.cuda.synchronize()
+            out["C5"]["evals_per_s_at_8_per_call"] = 16.0 / (time.perf_counter() - t0)
+        except Exception as e:  # pragma: no cover
+            out["C5"]["evals_per_s_at_8_per_call"] = "%s: %s" % (type(e).__name__, e)
         G.close()
         if c5_traffic:
             pmc, src = measure_traffic("C5", 2, log, timeout_s=90, passes=("fetch", "write"))

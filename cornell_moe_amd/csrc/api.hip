@@ -191,7 +191,7 @@ int moe_gp_variance(const moe_gp_t* gp_c, const double* pts, int num_pts, double
   return guarded(err, [&] {
     std::unique_lock<std::mutex> lk;
     moe::GpDev& gp = lock_gp(gp_c, lk);
-    if (num_pts * (1 + gp.g) >= moe::kDeviceVarianceMinM) {  // r5: hundreds of query points -- the m x m algebra on the device too
+    if (num_pts * (1 + gp.g) >= moe::device_variance_min_m(false)) {  // r5: hundreds of query points -- the m x m algebra on the device too
       moe::variance_on_device(gp, pts, num_pts, false, out);
       return;
     }
@@ -205,7 +205,7 @@ int moe_gp_cholesky_variance(const moe_gp_t* gp_c, const double* pts, int num_pt
   return guarded(err, [&] {
     std::unique_lock<std::mutex> lk;
     moe::GpDev& gp = lock_gp(gp_c, lk);
-    if (num_pts * (1 + gp.g) >= moe::kDeviceVarianceMinM) {
+    if (num_pts * (1 + gp.g) >= moe::device_variance_min_m(true)) {
       moe::variance_on_device(gp, pts, num_pts, true, out);
       return;
     }

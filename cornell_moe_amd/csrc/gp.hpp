@@ -1,6 +1,7 @@
 // cornell_moe_amd/csrc/gp.hpp -- device-resident Gaussian process (the object behind moe_gp_t) and the per-call
 // "points state" set-up shared by the posterior queries, q-EI and q-KG.
 #pragma once
+#include <cstdlib>
 #include <functional>
 #include <memory>
 #include <vector>
@@ -156,8 +157,14 @@ KgStateEnqueued enqueue_kg_state_batch(GpDev& gp, const double* U_all, int u, in
 void compute_state_batch(GpDev& gp, const double* U_all, int u, const DerivList& dt, int nd, const double* extra_all, int A,
                          bool need_W, int num_evals, BatchLayout* blay, std::vector<StateHost>* hosts);
 // Variance (or its Cholesky factor) of k query points with the m x m algebra on the device: gp.hip.  For large query sets; small ones
-// keep the host algebra (kDeviceVarianceMinM).
-constexpr int kDeviceVarianceMinM = 33;
+// keep the host algebra (kDeviceVarianceMinM / kDeviceVarianceMinMPlain).
+constexpr int kDeviceVarianceMinM = 33;       // the Cholesky factor of the variance: m x m rows from which the device algebra is used
+constexpr int kDeviceVarianceMinMPlain = 16;  // the variance itself (r6: measured break-even, profiles/r06_am_variance_threshold.txt: at 32 rows 64 against 96 us)
+// (MOE_GP_VARIANCE_DEVICE_MIN / MOE_GP_CHOL_VARIANCE_DEVICE_MIN: A/B runs of the thresholds, read per call; 1 = the device at every size)
+inline int device_variance_min_m(bool cholesky) {
+  const char* v = std::getenv(cholesky ? "MOE_GP_CHOL_VARIANCE_DEVICE_MIN" : "MOE_GP_VARIANCE_DEVICE_MIN");
+  return (v && *v) ? std::atoi(v) : (cholesky ? kDeviceVarianceMinM : kDeviceVarianceMinMPlain);
+}
 void variance_on_device(GpDev& gp, const double* pts, int k, bool cholesky, double* out);
 // r6 (query_grad.hip): ComputeGradVarianceOfPoints / ComputeGradCholeskyVarianceOfPoints (gpp_math.cpp:1267-1474) for the first
 // `num_derivs` of the `num_pts` points, the m x m x d algebra on the device: out[num_derivs][d m m] in the reference's layout.
