@@ -205,7 +205,7 @@ int moe_gp_cholesky_variance(const moe_gp_t* gp_c, const double* pts, int num_pt
   return guarded(err, [&] {
     std::unique_lock<std::mutex> lk;
     moe::GpDev& gp = lock_gp(gp_c, lk);
-    if (num_pts * (1 + gp.g) >= moe::device_variance_min_m(true)) {
+    if (num_pts * (1 + gp.g) >= moe::device_variance_min_m(false)) {  // (the factor itself on the device from device_variance_min_m(true) rows)
       moe::variance_on_device(gp, pts, num_pts, true, out);
       return;
     }

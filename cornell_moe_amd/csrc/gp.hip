@@ -642,10 +642,20 @@ void variance_on_device(GpDev& gp, const double* pts, int k, bool cholesky, doub
   MOE_LAUNCH_NOW(var_sub_kernel, dim3((unsigned)((mm + 255) / 256)), dim3(256), 0, s, dVar, gp.dGram.p, (long)mm);
   MOE_HIP_CHECK(hipGetLastError());
   gp.hStateOut.reserve(mm + 1);
-  if (!cholesky) {
+  const bool factor_on_device = cholesky && m >= device_variance_min_m(true);
+  if (!factor_on_device) {
     MOE_HIP_CHECK(hipMemcpyAsync(gp.hStateOut.p, dVar, sizeof(double) * mm, hipMemcpyDeviceToHost, s));
     MOE_HIP_CHECK(hipStreamSynchronize(s));
     std::copy(gp.hStateOut.p, gp.hStateOut.p + mm, out);
+    if (cholesky) {  // r6: the variance from the device, its factor by the host's column sweep (a few us at these sizes; the blocked device
+                     // factorisation costs 70 us before it does anything): the layout the callers know -- factor below, variance above
+      const int lm = host_cholesky(m, out);
+      if (lm != 0)
+        throw Error(MOE_ERR_SINGULAR,
+                    "GP-Variance matrix singular. Check for duplicate points_to_sample or points_to_sample "
+                    "duplicating points_sampled with 0 noise.",
+                    m, lm);
+    }
     return;
   }
   double* dChol = dVar + mm;

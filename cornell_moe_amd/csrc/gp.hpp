@@ -157,9 +157,12 @@ KgStateEnqueued enqueue_kg_state_batch(GpDev& gp, const double* U_all, int u, in
 void compute_state_batch(GpDev& gp, const double* U_all, int u, const DerivList& dt, int nd, const double* extra_all, int A,
                          bool need_W, int num_evals, BatchLayout* blay, std::vector<StateHost>* hosts);
 // Variance (or its Cholesky factor) of k query points with the m x m algebra on the device: gp.hip.  For large query sets; small ones
-// keep the host algebra (kDeviceVarianceMinM / kDeviceVarianceMinMPlain).
-constexpr int kDeviceVarianceMinM = 33;       // the Cholesky factor of the variance: m x m rows from which the device algebra is used
-constexpr int kDeviceVarianceMinMPlain = 16;  // the variance itself (r6: measured break-even, profiles/r06_am_variance_threshold.txt: at 32 rows 64 against 96 us)
+// keep the host algebra.  Two thresholds in rows of the m x m variance: from kDeviceVarianceMinMPlain the variance itself is assembled
+// on the device (both endpoints), from kDeviceVarianceMinM its factor too (below that the host's column sweep factors the downloaded
+// variance).
+constexpr int kDeviceVarianceMinM = 224;      // the factorisation on the device (r6: was 33; the blocked kernels cost 70 us before they do anything --
+                                              // host sweep 287 us at 192 rows against 357, 536 at 256 against 277: profiles/r06_an_cholesky_variance_threshold.txt)
+constexpr int kDeviceVarianceMinMPlain = 16;  // the variance on the device (r6: measured break-even, profiles/r06_am_variance_threshold.txt: at 32 rows 64 against 96 us)
 // (MOE_GP_VARIANCE_DEVICE_MIN / MOE_GP_CHOL_VARIANCE_DEVICE_MIN: A/B runs of the thresholds, read per call; 1 = the device at every size)
 inline int device_variance_min_m(bool cholesky) {
   const char* v = std::getenv(cholesky ? "MOE_GP_CHOL_VARIANCE_DEVICE_MIN" : "MOE_GP_VARIANCE_DEVICE_MIN");

@@ -8,7 +8,7 @@
 // grad[dd + row d + col d m] (d fastest; for the Cholesky variant the meaning is transposed, grad_chol[dd + c d + r d m] =
 // d L[r][c] / d Xs_{dd,p}, entries below the block zeroed: :1403-1411): one device->host copy per call, no host arithmetic.
 // Every entry goes through the same operations in the same order as csrc/host_math.hip's (which stays: the m x m algebra of the
-// variance endpoints below 16 / 33 rows (gp.hpp: device_variance_min_m), held by the golden fixtures, and tools/).
+// variance endpoints below 16 rows and the factor of a variance of fewer than 224 (gp.hpp: device_variance_min_m), held by the golden fixtures, and tools/).
 #include <hip/hip_runtime.h>
 
 #include "device_cov.hpp"
